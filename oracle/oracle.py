@@ -1,0 +1,487 @@
+"""CPU oracle -- TEST INFRASTRUCTURE ONLY (not part of the product).
+
+numpy/ctypes front-end of ``oracle/nvalchemi_oracle.cpp`` (a single-threaded C++ restatement of the
+reference's Warp kernels) plus the few torch-level steps of the reference path restated in numpy
+(FFT composition of PME, k-vector grid, matrix->COO conversion).  Also holds two *independent*
+checkers that do not share code with the restatement: an O(N^2 * images) brute-force neighbour
+enumerator and an explicit structure-factor Ewald sum.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import this
+module.  Nothing under ``nvalchemi-toolkit-ops_amd/`` does.
+
+Reference files followed (all under /root/reference/nvalchemiops, v0.2.0):
+  neighborlist/cell_list.py:35-556, batch_cell_list.py:36-569, neighbor_utils.py:26-441, naive.py:37-182
+  interactions/dispersion/dftd3.py:341-1615, 1911-2122, 2306-2465
+  interactions/electrostatics/ewald_kernels.py:150-1495, pme_kernels.py:93-657, pme.py:1166-1479,
+  k_vectors.py:167-298, spline.py:127-959, math/math.py:41-93
+"""
+from __future__ import annotations
+
+import ctypes
+import math
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+def build() -> str:
+    """Compile the oracle shared library with g++ (make) and return its path."""
+    subprocess.run(["make", "-s", "-C", _HERE], check=True)
+    return os.path.join(_HERE, "libnvalchemi_oracle.so")
+
+
+def lib() -> ctypes.CDLL:
+    global _LIB
+    if _LIB is None:
+        path = os.path.join(_HERE, "libnvalchemi_oracle.so")
+        src = os.path.join(_HERE, "nvalchemi_oracle.cpp")
+        if not os.path.exists(path) or os.path.getmtime(path) < os.path.getmtime(src):
+            build()
+        _LIB = ctypes.CDLL(path)
+        _LIB.orc_erfc.restype = ctypes.c_double
+        _LIB.orc_erfc.argtypes = [ctypes.c_int, ctypes.c_double]
+        _LIB.orc_cell_list.restype = ctypes.c_int
+    return _LIB
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(ctypes.c_void_p)
+
+
+def _dt(a) -> int:
+    if a.dtype == np.float32:
+        return 0
+    if a.dtype == np.float64:
+        return 1
+    raise ValueError(f"unsupported dtype {a.dtype}")
+
+
+def _c(a, dtype=None):
+    return None if a is None else np.ascontiguousarray(a, dtype=dtype)
+
+
+# --------------------------------------------------------------------------------------
+# neighbour lists
+# --------------------------------------------------------------------------------------
+def estimate_max_neighbors(cutoff: float, atomic_density: float = 0.35, safety_factor: float = 5.0) -> int:
+    """neighbor_utils.py:296-340."""
+    if cutoff <= 0:
+        return 0
+    expected = max(1, safety_factor * atomic_density * (4.0 / 3.0) * math.pi * cutoff**3)
+    return int(math.ceil(expected / 16)) * 16
+
+
+def cell_list(positions, cutoff, cell, pbc, batch_idx=None, max_neighbors=None, fill_value=None, half_fill=False,
+              max_nbins=1000, return_grid=False):
+    """Reference cell-list pipeline (single system when batch_idx is None, batch kernels otherwise)."""
+    pos = _c(positions)
+    n = pos.shape[0]
+    cell = _c(cell, pos.dtype).reshape(-1, 3, 3)
+    nsys = cell.shape[0]
+    pbc = _c(np.asarray(pbc).reshape(-1, 3), np.uint8)
+    if pbc.shape[0] != nsys:
+        pbc = np.ascontiguousarray(np.broadcast_to(pbc, (nsys, 3)))
+    m = estimate_max_neighbors(cutoff) if max_neighbors is None else int(max_neighbors)
+    fv = n if fill_value is None else int(fill_value)
+    nm = np.empty((n, m), np.int32)
+    sh = np.empty((n, m, 3), np.int32)
+    num = np.empty((n,), np.int32)
+    bi = _c(batch_idx, np.int32)
+    cpd = np.zeros((nsys, 3), np.int32)
+    rad = np.zeros((nsys, 3), np.int32)
+    if n > 0 and cutoff > 0:
+        lib().orc_cell_list(_dt(pos), _p(pos), n, _p(cell), _p(pbc), _p(bi), nsys, ctypes.c_double(cutoff),
+                            int(max_nbins), m, fv, int(half_fill), _p(nm), _p(sh), _p(num), _p(cpd), _p(rad))
+    else:
+        nm[:] = fv
+        sh[:] = 0
+        num[:] = 0
+    if return_grid:
+        return nm, num, sh, cpd, rad
+    return nm, num, sh
+
+
+def naive(positions, cutoff, cell=None, pbc=None, max_neighbors=None, fill_value=None, half_fill=False):
+    pos = _c(positions)
+    n = pos.shape[0]
+    m = estimate_max_neighbors(cutoff) if max_neighbors is None else int(max_neighbors)
+    fv = n if fill_value is None else int(fill_value)
+    nm = np.empty((n, m), np.int32)
+    num = np.empty((n,), np.int32)
+    sh = np.zeros((n, m, 3), np.int32) if cell is not None else None
+    c = None if cell is None else _c(cell, pos.dtype).reshape(3, 3)
+    pb = None if pbc is None else _c(np.asarray(pbc).reshape(3), np.uint8)
+    lib().orc_naive(_dt(pos), _p(pos), n, _p(c), _p(pb), ctypes.c_double(cutoff), m, fv, int(half_fill), _p(nm), _p(sh), _p(num))
+    return (nm, num, sh) if cell is not None else (nm, num)
+
+
+class NeighborOverflow(Exception):
+    pass
+
+
+def matrix_to_coo(nm, num, shifts=None, fill_value=-1):
+    """neighbor_utils.py:362-441: boolean-mask conversion, row-major."""
+    if num.size and num.max() > nm.shape[1]:
+        raise NeighborOverflow(f"{num.max()} > {nm.shape[1]}")
+    mask = nm != fill_value
+    i_idx = np.nonzero(mask)[0].astype(np.int32)
+    j_idx = nm[mask].astype(np.int32)
+    ptr = np.zeros(num.shape[0] + 1, np.int32)
+    np.cumsum(num, out=ptr[1:])
+    out = (np.stack([i_idx, j_idx], 0), ptr)
+    if shifts is not None:
+        out = out + (shifts[mask],)
+    return out
+
+
+def canonical_pairs(nm, num, shifts, fill_value=None):
+    """Sorted (i, j, Sx, Sy, Sz) rows of a neighbour matrix -- the order-free comparison key."""
+    n, m = nm.shape
+    cols = np.arange(m)[None, :]
+    mask = cols < np.minimum(num, m)[:, None]
+    i = np.nonzero(mask)[0]
+    rows = np.column_stack([i, nm[mask], shifts[mask]]).astype(np.int64)
+    return rows[np.lexsort(rows.T[::-1])]
+
+
+def brute_force_pairs(positions, cutoff, cell, pbc):
+    """Independent checker: every directed (i, j, S) with |r_j + S.cell - r_i| < cutoff, S over all images.
+
+    Same floating-point expression order as the cell-list distance test so boundary pairs agree.
+    """
+    pos = np.asarray(positions)
+    t = pos.dtype.type
+    cell = np.asarray(cell, pos.dtype).reshape(3, 3)
+    pbc = np.asarray(pbc, bool).reshape(3)
+    inv = np.linalg.inv(cell.astype(np.float64))
+    # atoms may sit outside the cell: extend the image range by the fractional spread
+    frac = pos.astype(np.float64) @ inv
+    spread = np.ceil(frac.max(0) - frac.min(0)).astype(int) if len(pos) else np.zeros(3, int)
+    rng = []
+    for d in range(3):
+        face = 1.0 / np.linalg.norm(inv[:, d])
+        rng.append(int(math.ceil(cutoff / face)) + int(spread[d]) + 1 if pbc[d] else 0)
+    rc2 = t(cutoff) * t(cutoff)
+    rows = []
+    n = len(pos)
+    for sx in range(-rng[0], rng[0] + 1):
+        for sy in range(-rng[1], rng[1] + 1):
+            for sz in range(-rng[2], rng[2] + 1):
+                s = np.array([sx, sy, sz], pos.dtype)
+                cart = np.empty(3, pos.dtype)
+                for c in range(3):
+                    r = cell[0, c] * s[0]
+                    r = r + cell[1, c] * s[1]
+                    r = r + cell[2, c] * s[2]
+                    cart[c] = r
+                dr = (pos[None, :, :] - pos[:, None, :]) + cart[None, None, :]
+                d2 = dr[..., 0] * dr[..., 0] + dr[..., 1] * dr[..., 1] + dr[..., 2] * dr[..., 2]
+                hit = d2 < rc2
+                if sx == 0 and sy == 0 and sz == 0:
+                    hit[np.arange(n), np.arange(n)] = False
+                ii, jj = np.nonzero(hit)
+                if len(ii):
+                    rows.append(np.column_stack([ii, jj, np.full(len(ii), sx), np.full(len(ii), sy), np.full(len(ii), sz)]))
+    if not rows:
+        return np.zeros((0, 5), np.int64)
+    rows = np.concatenate(rows).astype(np.int64)
+    return rows[np.lexsort(rows.T[::-1])]
+
+
+# --------------------------------------------------------------------------------------
+# DFT-D3
+# --------------------------------------------------------------------------------------
+def d3_test_tables(z_max: int = 17, seed: int | None = None):
+    """Analytic test tables of the reference's own test-suite (test/interactions/dispersion/conftest.py:38-160):
+    c6ab = 10 Zi Zj (1 + 0.1p + 0.1q), cn_ref = (p/4) cnmax[Zi].  For z_max > 17 (benchmarks) the element
+    vectors are extended with a seeded generator (real Grimme tables are not in the reference repo: SURVEY F8)."""
+    nz = z_max + 1
+    rcov = np.zeros(nz, np.float32)
+    cnmax = np.zeros(nz, np.float32)
+    r4r2 = np.zeros(nz, np.float32)
+    rcov[:10] = [0.0, 0.6, 0.8, 2.8, 2.0, 1.6, 1.4, 1.3, 1.2, 1.5]
+    cnmax[:10] = [0.0, 1.5, 1.0, 6.0, 4.0, 4.0, 4.0, 4.0, 2.5, 1.5]
+    r4r2[:10] = [0.0, 2.0, 1.5, 10.0, 6.0, 5.0, 4.5, 4.0, 3.5, 3.0]
+    if nz > 10:
+        rcov[10], cnmax[10], r4r2[10] = 1.5, 1.0, 4.5
+    if nz > 17:
+        rcov[17], cnmax[17], r4r2[17] = 1.8, 2.0, 8.0
+    if seed is not None:
+        g = np.random.default_rng(seed)
+        for z in range(1, nz):
+            if rcov[z] == 0.0:
+                rcov[z] = g.uniform(1.0, 3.0)
+                cnmax[z] = g.uniform(1.0, 6.0)
+                r4r2[z] = g.uniform(2.0, 10.0)
+    p = np.arange(5, dtype=np.float32)
+    zi = np.arange(nz, dtype=np.float32)
+    c6ab = (10.0 * zi[:, None, None, None] * zi[None, :, None, None]
+            * (1.0 + 0.1 * p[None, None, :, None] + 0.1 * p[None, None, None, :])).astype(np.float32)
+    cn_ref = np.broadcast_to(((p / 4.0)[None, None, :, None] * cnmax[:, None, None, None]), (nz, nz, 5, 5)).astype(np.float32).copy()
+    return {"rcov": rcov, "r4r2": r4r2, "c6ab": c6ab, "cn_ref": cn_ref}
+
+
+def dftd3(positions, numbers, params, a1, a2, s8, k1=16.0, k3=-4.0, s6=1.0, s5_on=1e10, s5_off=1e10, fill_value=None,
+          neighbor_matrix=None, neighbor_matrix_shifts=None, idx_j=None, neighbor_ptr=None, unit_shifts=None, cell=None,
+          batch_idx=None, compute_virial=False, num_systems=None):
+    pos = _c(positions)
+    n = pos.shape[0]
+    numbers = _c(numbers, np.int32)
+    bi = _c(batch_idx, np.int32)
+    if num_systems is None:
+        num_systems = 1 if bi is None else (np.asarray(cell).reshape(-1, 3, 3).shape[0] if cell is not None else int(bi.max()) + 1)
+    rcov = _c(params["rcov"], np.float32)
+    r4r2 = _c(params["r4r2"], np.float32)
+    c6ab = _c(params["c6ab"], np.float32)
+    cnref = _c(params["cn_ref"], np.float32)
+    energy = np.zeros(num_systems, np.float32)
+    forces = np.zeros((n, 3), np.float32)
+    cn = np.zeros(n, np.float32)
+    virial = np.zeros((num_systems, 3, 3), np.float32)
+    if neighbor_matrix is not None:
+        j = _c(neighbor_matrix, np.int32)
+        m = j.shape[1]
+        ptr = None
+        sh = _c(neighbor_matrix_shifts, np.int32)
+        fv = n if fill_value is None else int(fill_value)
+    else:
+        j = _c(idx_j, np.int32)
+        m = 0
+        ptr = _c(neighbor_ptr, np.int32)
+        sh = _c(unit_shifts, np.int32)
+        fv = 0
+    c = None if (cell is None or sh is None) else _c(cell, pos.dtype).reshape(-1, 3, 3)
+    if c is None:
+        sh = None
+    if n:
+        lib().orc_dftd3(_dt(pos), _p(pos), _p(numbers), n, _p(j), _p(sh), _p(ptr), m, fv, _p(c), _p(bi), num_systems,
+                        _p(rcov), _p(r4r2), _p(c6ab), _p(cnref), rcov.shape[0], *(ctypes.c_double(x) for x in
+                        (a1, a2, s6, s8, k1, k3, s5_on, s5_off)), int(compute_virial), _p(energy), _p(forces), _p(cn), _p(virial))
+    return (energy, forces, cn, virial) if compute_virial else (energy, forces, cn)
+
+
+# --------------------------------------------------------------------------------------
+# electrostatics
+# --------------------------------------------------------------------------------------
+def erfc_as(x, dtype=np.float64):
+    return lib().orc_erfc(0 if dtype == np.float32 else 1, float(x))
+
+
+def ewald_real_space(positions, charges, cell, alpha, neighbor_matrix=None, neighbor_matrix_shifts=None, idx_j=None,
+                     neighbor_ptr=None, neighbor_shifts=None, mask_value=-1, batch_idx=None, compute_forces=False,
+                     compute_charge_gradients=False):
+    pos = _c(positions)
+    n = pos.shape[0]
+    q = _c(charges, pos.dtype)
+    c = _c(cell, pos.dtype).reshape(-1, 3, 3)
+    al = _c(np.broadcast_to(np.asarray(alpha, pos.dtype).reshape(-1), (c.shape[0],)), pos.dtype)
+    bi = _c(batch_idx, np.int32)
+    if neighbor_matrix is not None:
+        j, sh, ptr, m = _c(neighbor_matrix, np.int32), _c(neighbor_matrix_shifts, np.int32), None, neighbor_matrix.shape[1]
+    else:
+        j, sh, ptr, m = _c(idx_j, np.int32), _c(neighbor_shifts, np.int32), _c(neighbor_ptr, np.int32), 0
+    e = np.zeros(n, np.float64)
+    f = np.zeros((n, 3), pos.dtype)
+    cg = np.zeros(n, np.float64)
+    if n:
+        lib().orc_ewald_real(_dt(pos), _p(pos), _p(q), _p(c), _p(al), _p(bi), n, _p(j), _p(sh), _p(ptr), m, int(mask_value),
+                             int(compute_forces), int(compute_charge_gradients), _p(e), _p(f), _p(cg))
+    out = (e.astype(pos.dtype),)
+    if compute_forces:
+        out += (f,)
+    if compute_charge_gradients:
+        out += (cg.astype(pos.dtype),)
+    return out if len(out) > 1 else out[0]
+
+
+def _cell_inv_t(cell):
+    return np.ascontiguousarray(np.swapaxes(np.linalg.inv(cell), -1, -2))
+
+
+def _spline(mode, positions, values, cell, dims, order, batch_idx, mesh):
+    pos = _c(positions)
+    n = pos.shape[0]
+    cell = _c(cell, pos.dtype).reshape(-1, 3, 3)
+    nsys = cell.shape[0]
+    cit = _c(_cell_inv_t(cell), pos.dtype)
+    bi = _c(batch_idx, np.int32)
+    d = np.asarray(dims, np.int32)
+    vals = _c(values, pos.dtype) if values is not None else None
+    if mode == 0:
+        mesh = np.zeros((nsys,) + tuple(dims), pos.dtype)
+        out = None
+    else:
+        mesh = _c(mesh, pos.dtype)
+        out = np.zeros((n,) if mode == 1 else (n, 3), pos.dtype)
+    if n:
+        lib().orc_spline(_dt(pos), mode, _p(pos), _p(vals), _p(bi), _p(cit), n, nsys, _p(d), int(order), _p(mesh), _p(out))
+    if mode == 0:
+        return mesh if batch_idx is not None else mesh[0]
+    return out
+
+
+def spline_spread(positions, values, cell, mesh_dims, spline_order=4, batch_idx=None):
+    return _spline(0, positions, values, cell, mesh_dims, spline_order, batch_idx, None)
+
+
+def spline_gather(positions, mesh, cell, spline_order=4, batch_idx=None):
+    dims = mesh.shape[-3:]
+    return _spline(1, positions, None, cell, dims, spline_order, batch_idx, mesh)
+
+
+def spline_gather_vec3(positions, charges, mesh, cell, spline_order=4, batch_idx=None):
+    dims = mesh.shape[-4:-1]
+    return _spline(2, positions, charges, cell, dims, spline_order, batch_idx, mesh)
+
+
+def generate_k_vectors_pme(cell, mesh_dimensions):
+    """k_vectors.py:167-298 in numpy."""
+    cell = np.asarray(cell).reshape(-1, 3, 3)
+    dt = cell.dtype
+    recip = (2.0 * math.pi) * np.linalg.inv(cell)
+    nx, ny, nz = mesh_dimensions
+    kx = (np.fft.fftfreq(nx, d=1.0) * nx).astype(dt)
+    ky = (np.fft.fftfreq(ny, d=1.0) * ny).astype(dt)
+    kz = (np.fft.rfftfreq(nz, d=1.0) * nz).astype(dt)
+    grid = np.stack(np.meshgrid(kx, ky, kz, indexing="ij"), -1)
+    kvec = np.einsum("ijkd,bcd->bijkc", grid, recip.astype(dt))
+    if kvec.shape[0] == 1:
+        kvec = kvec[0]
+    k2 = np.sum(kvec**2, -1)
+    k2 = np.where(k2 > 1e-12, k2, np.float32(1e-12).astype(dt))
+    return kvec, k2
+
+
+def pme_green_structure_factor(k_squared, mesh_dimensions, alpha, cell, spline_order=4, batched=False):
+    k2 = _c(k_squared)
+    dt = k2.dtype
+    cell = np.asarray(cell, dt).reshape(-1, 3, 3)
+    nsys = cell.shape[0]
+    vol = _c(np.abs(np.linalg.det(cell)), dt)
+    al = _c(np.broadcast_to(np.asarray(alpha, dt).reshape(-1), (nsys,)), dt)
+    nx, ny, nz = mesh_dimensions
+    g = np.zeros(k2.shape, dt)
+    sf2 = np.zeros((nx, ny, nz // 2 + 1), dt)
+    lib().orc_green_sf(_dt(k2), _p(k2), _p(al), _p(vol), nsys, nx, ny, nz, int(spline_order), _p(g), _p(sf2))
+    return g, sf2
+
+
+def pme_energy_corrections(raw, charges, cell, alpha, batch_idx=None, with_charge_grad=False):
+    raw = _c(raw)
+    dt = raw.dtype
+    q = _c(charges, dt)
+    cell = np.asarray(cell, dt).reshape(-1, 3, 3)
+    nsys = cell.shape[0]
+    vol = _c(np.abs(np.linalg.det(cell)), dt)
+    al = _c(np.broadcast_to(np.asarray(alpha, dt).reshape(-1), (nsys,)), dt)
+    bi = _c(batch_idx, np.int32)
+    if bi is None:
+        qtot = np.array([q.sum()], dt)
+    else:
+        qtot = np.zeros(nsys, dt)
+        np.add.at(qtot, bi, q)
+    e = np.zeros_like(raw)
+    cg = np.zeros_like(raw) if with_charge_grad else None
+    lib().orc_corrections(_dt(raw), _p(raw), _p(q), _p(bi), _p(vol), _p(al), _p(qtot), raw.shape[0], _p(e), _p(cg))
+    return (e, cg) if with_charge_grad else e
+
+
+def pme_reciprocal_space(positions, charges, cell, alpha, mesh_dimensions, spline_order=4, batch_idx=None,
+                         compute_forces=False, compute_charge_gradients=False):
+    """pme.py:1338-1479 with numpy FFTs (rfftn unscaled forward, irfftn norm='forward' == unscaled inverse)."""
+    pos = _c(positions)
+    dt = pos.dtype
+    cell = _c(cell, dt).reshape(-1, 3, 3)
+    batched = batch_idx is not None
+    axes = (-3, -2, -1)
+    mesh = spline_spread(pos, charges, cell, mesh_dimensions, spline_order, batch_idx)
+    mesh_fft = np.fft.rfftn(mesh, axes=axes)
+    kvec, k2 = generate_k_vectors_pme(cell, mesh_dimensions)
+    if batched and kvec.ndim == 4:
+        kvec, k2 = kvec[None], k2[None]
+    g, sf2 = pme_green_structure_factor(k2, mesh_dimensions, alpha, cell, spline_order)
+    conv = (mesh_fft / sf2) * g
+    ntot = float(np.prod(mesh_dimensions))
+    phi = (np.fft.irfftn(conv, s=mesh_dimensions, axes=axes) * ntot).astype(dt)
+    raw = spline_gather(pos, phi, cell, spline_order, batch_idx)
+    corr = pme_energy_corrections(raw, charges, cell, alpha, batch_idx, with_charge_grad=compute_charge_gradients)
+    energies, cgrads = (corr if compute_charge_gradients else (corr, None))
+    out = (energies,)
+    if compute_forces:
+        comps = [np.fft.irfftn(-1j * kvec[..., d] * conv, s=mesh_dimensions, axes=axes) * ntot for d in range(3)]
+        efield = np.stack(comps, -1).astype(dt)
+        out += ((2.0 * spline_gather_vec3(pos, charges, efield, cell, spline_order, batch_idx)).astype(dt),)
+    if compute_charge_gradients:
+        out += (cgrads,)
+    return out if len(out) > 1 else out[0]
+
+
+def particle_mesh_ewald(positions, charges, cell, alpha, mesh_dimensions, spline_order=4, batch_idx=None,
+                        neighbor_matrix=None, neighbor_matrix_shifts=None, idx_j=None, neighbor_ptr=None,
+                        neighbor_shifts=None, mask_value=None, compute_forces=False, compute_charge_gradients=False):
+    """pme.py:1673-1994 (real + reciprocal)."""
+    n = np.asarray(positions).shape[0]
+    mv = n if mask_value is None else mask_value
+    rs = ewald_real_space(positions, charges, cell, alpha, neighbor_matrix, neighbor_matrix_shifts, idx_j, neighbor_ptr,
+                          neighbor_shifts, mv, batch_idx, compute_forces, compute_charge_gradients)
+    rec = pme_reciprocal_space(positions, charges, cell, alpha, mesh_dimensions, spline_order, batch_idx, compute_forces,
+                               compute_charge_gradients)
+    if isinstance(rs, tuple):
+        return tuple(a + b for a, b in zip(rs, rec))
+    return rs + rec
+
+
+def explicit_ewald(positions, charges, cell, alpha, kmax, rcut_images=None, exact_erfc=True):
+    """Independent float64 Ewald sum (structure-factor reciprocal part + direct real-space image sum).
+
+    Returns (total energy, forces[N,3]).  Coulomb constant 1.  Used only to pin the PME restatement.
+    """
+    pos = np.asarray(positions, np.float64)
+    q = np.asarray(charges, np.float64)
+    cell = np.asarray(cell, np.float64).reshape(3, 3)
+    vol = abs(np.linalg.det(cell))
+    n = len(q)
+    recip = 2.0 * math.pi * np.linalg.inv(cell)  # columns are reciprocal vectors
+    e_rec = 0.0
+    f = np.zeros((n, 3))
+    rng = range(-kmax, kmax + 1)
+    for h in rng:
+        for k in rng:
+            for l in rng:
+                if h == 0 and k == 0 and l == 0:
+                    continue
+                kv = recip @ np.array([h, k, l], float)
+                k2 = kv @ kv
+                ph = pos @ kv
+                sr, si = (q * np.cos(ph)).sum(), (q * np.sin(ph)).sum()
+                a = (2.0 * math.pi / vol) * math.exp(-k2 / (4 * alpha * alpha)) / k2
+                e_rec += a * (sr * sr + si * si)
+                f += (2.0 * a) * (q * (np.sin(ph) * sr - np.cos(ph) * si))[:, None] * kv[None, :]
+    e_self = -alpha / math.sqrt(math.pi) * (q * q).sum()
+    e_bg = -math.pi * q.sum() ** 2 / (2 * alpha * alpha * vol)
+    # real space over images
+    from math import erfc as _erfc
+    e_real = 0.0
+    inv = np.linalg.inv(cell)
+    rc = rcut_images if rcut_images is not None else 6.0 / alpha
+    reps = [int(math.ceil(rc * np.linalg.norm(inv[:, d]))) for d in range(3)]
+    for sx in range(-reps[0], reps[0] + 1):
+        for sy in range(-reps[1], reps[1] + 1):
+            for sz in range(-reps[2], reps[2] + 1):
+                sh = np.array([sx, sy, sz], float) @ cell
+                dr = pos[None, :, :] - pos[:, None, :] + sh[None, None, :]
+                d = np.sqrt((dr * dr).sum(-1))
+                mask = (d > 1e-10) & (d < rc)
+                dd = d[mask]
+                er = np.array([_erfc(alpha * x) for x in dd])
+                qq = (q[:, None] * q[None, :])[mask]
+                e_real += 0.5 * (qq * er / dd).sum()
+                fm = qq * (er / dd**3 + 2 * alpha / math.sqrt(math.pi) * np.exp(-(alpha * dd) ** 2) / dd**2)
+                fv = np.zeros_like(dr)
+                fv[mask] = -fm[:, None] * dr[mask]
+                f += fv.sum(1)
+    return e_rec + e_self + e_bg + e_real, f

@@ -1,0 +1,145 @@
+"""Pins the CPU oracle against the reference test-suite's own known answers.
+
+CPU-only: these run in the build container (`-m "not gpu"`)."""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from tests import systems as S
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("cutoff", [1.0, 4.0, 6.0])
+def test_nlist_counts_hotlpd_sicu(dtype, cutoff):
+    # test/neighborlist/test_cell_list.py:391-419
+    _, num, _ = O.cell_list(S.HOTLPD_POS.astype(dtype), cutoff, S.HOTLPD_CELL.astype(dtype), [True] * 3)
+    assert num.tolist() == S.HOTLPD_COUNTS[cutoff]
+    _, num, _ = O.cell_list(S.SICU_POS.astype(dtype), cutoff, S.SICU_CELL.astype(dtype), [True] * 3)
+    assert num.tolist() == S.SICU_COUNTS[cutoff]
+
+
+@pytest.mark.parametrize("cutoff", [1.0, 4.0, 6.0])
+def test_nlist_counts_batch(cutoff):
+    # test/neighborlist/test_batch_cell_list.py:516-541
+    pos = np.concatenate([S.HOTLPD_POS, S.SICU_POS]).astype(np.float32)
+    cell = np.stack([S.HOTLPD_CELL, S.SICU_CELL]).astype(np.float32)
+    bi = np.array([0] * 9 + [1] * 2, np.int32)
+    _, num, _ = O.cell_list(pos, cutoff, cell, np.ones((2, 3), bool), batch_idx=bi)
+    assert num.tolist() == S.HOTLPD_COUNTS[cutoff] + S.SICU_COUNTS[cutoff]
+
+
+def test_two_atom_pbc_pair():
+    # test/neighborlist/test_cell_list.py:83-101: two atoms across a periodic face -> exactly 2 directed pairs
+    pos = np.array([[0.5, 5.0, 5.0], [9.5, 5.0, 5.0]], np.float32)
+    nm, num, sh = O.cell_list(pos, 2.0, np.eye(3, dtype=np.float32) * 10, [True] * 3)
+    assert num.tolist() == [1, 1]
+    assert sh[0, 0].tolist() == [-1, 0, 0] and sh[1, 0].tolist() == [1, 0, 0]
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("kind", ["cubic", "triclinic", "outside", "mixed_pbc"])
+def test_cell_list_equals_brute_force(dtype, kind):
+    pos, cell = S.random_box(150, 9.0, seed=42, dtype=dtype, triclinic=(kind == "triclinic"), outside=(kind == "outside"))
+    pbc = [True, False, True] if kind == "mixed_pbc" else [True] * 3
+    nm, num, sh = O.cell_list(pos, 3.1, cell, pbc, max_neighbors=96)
+    assert num.max() <= 96
+    assert np.array_equal(O.canonical_pairs(nm, num, sh), O.brute_force_pairs(pos, 3.1, cell, pbc))
+
+
+def test_naive_equals_cell_list_sets():
+    pos, cell = S.random_box(80, 8.0, seed=7, dtype=np.float64)
+    nm, num, sh = O.naive(pos, 2.9, cell, [True] * 3, max_neighbors=64)
+    nm2, num2, sh2 = O.cell_list(pos, 2.9, cell, [True] * 3, max_neighbors=64)
+    assert np.array_equal(O.canonical_pairs(nm, num, sh), O.canonical_pairs(nm2, num2, sh2))
+    nmn, numn = O.naive(pos, 2.9, max_neighbors=64)  # no pbc
+    bf = O.brute_force_pairs(pos, 2.9, cell, [False] * 3)
+    assert int(numn.sum()) == len(bf)
+
+
+# ---- DFT-D3: test/interactions/dispersion/conftest.py:188-208 (params), :641-730 (golden outputs)
+FP = dict(a1=0.4, a2=4.0, s8=0.8, k1=16.0, k3=-4.0, s6=1.0)
+
+
+def test_d3_ne2_golden():
+    t = O.d3_test_tables(17)
+    pos = np.array([[0, 0, 0], [5.8, 0, 0]], np.float32)
+    nm = np.array([[1, 2, 2, 2, 2], [0, 2, 2, 2, 2]], np.int32)
+    e, f, cn = O.dftd3(pos, np.array([10, 10], np.int32), t, neighbor_matrix=nm, fill_value=2, **FP)
+    np.testing.assert_allclose(e, [-1.4161492698e-02], rtol=2e-6)
+    np.testing.assert_allclose(cn, [4.4183229329e-04] * 2, rtol=2e-6)
+    np.testing.assert_allclose(f, [[3.2497653738e-03, 0, 0], [-3.2497653738e-03, 0, 0]], rtol=2e-6, atol=1e-9)
+
+
+def test_d3_hcl_dimer_golden():
+    t = O.d3_test_tables(17)
+    pos = np.array([[0, 0, 0], [2.4, 0, 0], [0, 7, 0], [2.4, 7, 0]], np.float32)
+    nm = np.full((4, 5), 4, np.int32)
+    nm[0, :3], nm[1, :3], nm[2, :3], nm[3, :3] = [1, 2, 3], [0, 2, 3], [0, 1, 3], [0, 1, 2]
+    e, f, cn = O.dftd3(pos, np.array([1, 17, 1, 17], np.int32), t, neighbor_matrix=nm, fill_value=4, **FP)
+    np.testing.assert_allclose(e, [-2.2127663717e-02], rtol=2e-6)
+    np.testing.assert_allclose(cn, [5.0002193451e-01, 5.0044161081e-01] * 2, rtol=2e-6)
+    ref_f = [[6.2320637517e-03, 8.8818743825e-04, 0], [-6.2320632860e-03, 1.9026985392e-03, 0],
+             [6.2320632860e-03, -8.8818743825e-04, 0], [-6.2320632860e-03, -1.9026985392e-03, 0]]
+    np.testing.assert_allclose(f, ref_f, rtol=5e-6, atol=1e-9)
+
+
+def test_d3_matrix_equals_csr_and_virial_symmetric():
+    pos, cell = S.random_box(60, 12.0, seed=3, dtype=np.float32)
+    numbers = np.random.default_rng(1).choice(np.array([1, 6, 8], np.int32), 60)
+    t = O.d3_test_tables(17)
+    nm, num, sh = O.cell_list(pos, 8.0, cell, [True] * 3, max_neighbors=200)
+    (lst, ptr, lsh) = O.matrix_to_coo(nm, num, sh, fill_value=60)
+    a = O.dftd3(pos, numbers, t, neighbor_matrix=nm, neighbor_matrix_shifts=sh, cell=cell, compute_virial=True, **FP)
+    b = O.dftd3(pos, numbers, t, idx_j=lst[1], neighbor_ptr=ptr, unit_shifts=lsh, cell=cell, compute_virial=True, **FP)
+    for x, y in zip(a, b):
+        np.testing.assert_allclose(x, y, rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(a[3][0], a[3][0].T, rtol=1e-4, atol=1e-7)
+    assert abs(a[1].sum(0)).max() < 1e-5
+
+
+# ---- PME: the reference holds no numbers; pin with Madelung constants + an independent explicit Ewald sum
+def test_erfc_polynomial_error_bound():
+    import math
+    for x in np.linspace(0, 5, 101):
+        assert abs(O.erfc_as(x) - math.erfc(x)) < 2e-7
+
+
+def test_pme_madelung_nacl():
+    a = 5.64
+    base = np.array([[0, 0, 0], [.5, .5, 0], [.5, 0, .5], [0, .5, .5], [.5, 0, 0], [0, .5, 0], [0, 0, .5], [.5, .5, .5]]) * a
+    q = np.array([1, 1, 1, 1, -1, -1, -1, -1.0])
+    cell = np.eye(3) * a
+    nm, num, sh = O.cell_list(base, 9.0, cell, [True] * 3, max_neighbors=160)
+    e, f = O.particle_mesh_ewald(base, q, cell, 0.45, (32, 32, 32), 4, neighbor_matrix=nm, neighbor_matrix_shifts=sh,
+                                 compute_forces=True)
+    assert abs(-e.sum() / 4 * (a / 2) - 1.747565) < 1e-5
+    assert abs(f).max() < 1e-10
+
+
+def test_pme_vs_explicit_ewald_triclinic():
+    g = np.random.default_rng(0)
+    cell = np.array([[10, 0, 0], [2, 9, 0], [1, -1, 11.0]])
+    pos = g.uniform(0, 1, (20, 3)) @ cell
+    q = g.normal(size=20)
+    q -= q.mean()
+    nm, num, sh = O.cell_list(pos, 11.0, cell, [True] * 3, max_neighbors=400)
+    e, f = O.particle_mesh_ewald(pos, q, cell, 0.4, (48, 48, 48), 4, neighbor_matrix=nm, neighbor_matrix_shifts=sh,
+                                 compute_forces=True)
+    ee, fe = O.explicit_ewald(pos, q, cell, 0.4, kmax=9)
+    assert abs(e.sum() - ee) < 1e-5
+    assert abs(f - fe).max() < 5e-6
+
+
+def test_spline_properties():
+    # test/test_spline.py:46 (partition of unity), :179 (charge conservation), :637 (adjointness)
+    g = np.random.default_rng(5)
+    cell = np.eye(3) * 7.0
+    pos = g.uniform(0, 7, (40, 3))
+    q = g.normal(size=40)
+    for order in (2, 3, 4):
+        mesh = O.spline_spread(pos, q, cell, (12, 10, 14), order)
+        assert abs(mesh.sum() - q.sum()) < 1e-12
+        ones = O.spline_gather(pos, np.ones((12, 10, 14)), cell, order)
+        np.testing.assert_allclose(ones, 1.0, atol=1e-7)
+        field = g.normal(size=(12, 10, 14))
+        assert abs((mesh * field).sum() - (q * O.spline_gather(pos, field, cell, order)).sum()) < 1e-6
