@@ -1,0 +1,187 @@
+/*
+ * nvalchemiops_hip.h -- C ABI of libnvalchemiops_hip.so (MI355X / gfx950).
+ *
+ * Drop-in boundary for the reference's L2 seam: the `torch.library.custom_op` wrappers that launch
+ * Warp kernels (reference file:line cited per entry point).  All pointers are DEVICE pointers unless
+ * marked [host]; every buffer is owned by the caller (the Python layer allocates through torch's caching
+ * allocator, exactly as the reference wrappers do); `stream` is a hipStream_t passed as void*; the
+ * library keeps no state between calls.  dtype: 0 = float32, 1 = float64.  Every function returns
+ * 0 on success or a negative MI_E* code; mi_last_error() gives a message for the calling thread.
+ *
+ * A reference maintainer binds these with ctypes; no torch types cross this line.
+ */
+#ifndef NVALCHEMIOPS_HIP_H
+#define NVALCHEMIOPS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MI_OK 0
+#define MI_EINVAL (-1)   /* bad argument                                   */
+#define MI_EHIP (-2)     /* a HIP runtime call failed                      */
+#define MI_EWORKSPACE (-3) /* workspace too small                          */
+
+#define MI_F32 0
+#define MI_F64 1
+
+/* ---- library ------------------------------------------------------------------------------- */
+int mi_version(void);                 /* ABI version, currently 1                                  */
+const char* mi_last_error(void);      /* [host] message of the last failure on this thread         */
+
+/* ---- neighbour list -------------------------------------------------------------------------
+ * Replaces: nvalchemiops::build_cell_list + ::query_cell_list (neighborlist/cell_list.py:725,892),
+ * ::batch_build_cell_list + ::batch_query_cell_list (batch_cell_list.py:739,915), the padded-matrix
+ * fill of cell_list()/batch_cell_list() (cell_list.py:1358-1373), the naive ops (naive.py:221,299) and
+ * get_neighbor_list_from_neighbor_matrix (neighbor_utils.py:362-441).
+ *
+ * One fused pipeline: per-system grid setup -> cell keys -> radix sort by cell -> cell ranges ->
+ * cell-ordered position copy -> wave64-per-atom full-shell query with ballot/popcount compaction.
+ * Rows are written only by their owner wave (no atomics, deterministic order), padding included.
+ */
+#define MI_NL_MODE_MATRIX 0   /* write neighbor_matrix / shifts / num_neighbors (+ padding)          */
+#define MI_NL_MODE_COUNT 1    /* write num_neighbors only (first pass of direct CSR emission)        */
+#define MI_NL_MODE_CSR 2      /* write list_ij / list_shifts at neighbor_ptr[i] (second pass)         */
+
+#define MI_NL_HALF_FILL 1     /* keep one of (i,j,S)/(j,i,-S): S lexicographically > 0, or S==0 and j>i */
+#define MI_NL_NAIVE_EXPR 2    /* distance expression / cutoff^2 rounding / image range of naive.py:37-182 */
+#define MI_NL_REUSE_GRID 4    /* skip the binning stages: workspace still holds the grid of the previous call */
+#define MI_NL_NO_SHIFTS 8     /* matrix mode: do not write the shifts tensor (non-periodic naive output)  */
+#define MI_NL_NO_PAD 16       /* matrix mode: leave slots >= num_neighbors untouched (query_cell_list: the
+                                 caller pre-filled the outputs, cell_list.py:892-1034)                    */
+
+size_t mi_nl_workspace_bytes(int n_atoms, int n_systems, int dtype);
+
+int mi_nl_neighbors(const void* positions,          /* [n_atoms,3] dtype                              */
+                    int n_atoms,
+                    const void* cell,               /* [n_systems,3,3] dtype, rows = lattice vectors   */
+                    const uint8_t* pbc,             /* [n_systems,3] bool                              */
+                    const int32_t* batch_idx,       /* [n_atoms] or NULL (single system)               */
+                    int n_systems, double cutoff, int dtype, int mode, int flags,
+                    int32_t* neighbor_matrix,       /* [n_atoms,max_neighbors]      (MATRIX)           */
+                    int32_t* neighbor_matrix_shifts,/* [n_atoms,max_neighbors,3]    (MATRIX)           */
+                    int32_t* num_neighbors,         /* [n_atoms]                    (MATRIX, COUNT)    */
+                    int max_neighbors, int fill_value,
+                    const int32_t* neighbor_ptr,    /* [n_atoms+1]                  (CSR)              */
+                    int32_t* list_ij,               /* [2,n_pairs]                  (CSR)              */
+                    int32_t* list_shifts,           /* [n_pairs,3]                  (CSR)              */
+                    long long n_pairs,
+                    const void* bin_origin,         /* [n_systems,3] dtype or NULL: origin subtracted for BINNING
+                                                       only (non-periodic inputs far from 0); distances use the
+                                                       caller's coordinates unchanged                        */
+                    void* workspace, size_t workspace_bytes, void* stream);
+
+/* padded matrix -> COO/CSR (neighbor_utils.py:362-441): entries != fill_value, row-major.
+ * neighbor_ptr = [0, cumsum(num_neighbors)] supplied by the caller; shifts may be NULL.              */
+int mi_nl_matrix_to_coo(const int32_t* neighbor_matrix, const int32_t* neighbor_matrix_shifts,
+                        const int32_t* neighbor_ptr, int n_atoms, int max_neighbors, int fill_value,
+                        int32_t* list_ij, int32_t* list_shifts, long long n_pairs, void* stream);
+
+/* Reference-format cell-list cache (cell_list.py:725-889 / batch_cell_list.py:739-912): fills
+ * cells_per_dimension, atom_periodic_shifts, atom_to_cell_mapping, atoms_per_cell_count,
+ * cell_atom_start_indices, cell_atom_list with the reference's binning rule for `max_total_cells`
+ * cells (atoms inside a cell are listed in ascending index order).                                   */
+int mi_nl_build_cell_cache(const void* positions, int n_atoms, const void* cell, const uint8_t* pbc,
+                           const int32_t* batch_idx, int n_systems, double cutoff, int dtype,
+                           int max_total_cells, int32_t* cells_per_dimension, int32_t* atom_periodic_shifts,
+                           int32_t* atom_to_cell_mapping, int32_t* atoms_per_cell_count,
+                           int32_t* cell_atom_start_indices, int32_t* cell_atom_list, void* workspace,
+                           size_t workspace_bytes, void* stream);
+
+/* estimate_cell_list_sizes kernels (cell_list.py:35-99 / batch_cell_list.py:36-99)                   */
+int mi_nl_estimate_sizes(const void* cell, const uint8_t* pbc, int n_systems, double cutoff, int max_nbins,
+                         int dtype, int32_t* number_of_cells /*[n_systems]*/,
+                         int32_t* neighbor_search_radius /*[n_systems,3]*/, void* stream);
+
+/* ---- DFT-D3(BJ) -----------------------------------------------------------------------------
+ * Replaces nvalchemiops::dftd3_nm (dftd3.py:1792-2122) and ::dftd3_nl (:2125-2465): CN pass, fused
+ * C6-interpolation + BJ damping + energy + direct force + dE/dCN pass, chain-rule force pass.  The
+ * reference's pass 0 (materialised cartesian_shifts) is folded into the passes.  Outputs are float32
+ * whatever `dtype` (the positions/cell dtype) is.  Layout selector: neighbor_ptr == NULL -> padded matrix
+ * (entries >= fill_value are padding), else CSR (idx_j[neighbor_ptr[i]..neighbor_ptr[i+1])).
+ */
+typedef struct {
+  const float* rcov;   /* [nz]            */
+  const float* r4r2;   /* [nz]            */
+  const float* c6ab;   /* [nz,nz,5,5]     */
+  const float* cn_ref; /* [nz,nz,5,5]     */
+  int nz;              /* max_Z + 1       */
+  float a1, a2, s6, s8, k1, k3, s5_on, s5_off;
+} mi_d3_params;
+
+size_t mi_d3_workspace_bytes(int n_atoms, int n_systems);
+
+int mi_d3(const void* positions, const int32_t* numbers, int n_atoms, int dtype,
+          const int32_t* idx_j,        /* matrix [n_atoms,max_neighbors] or CSR values [n_pairs]      */
+          const int32_t* unit_shifts,  /* same layout x3, or NULL (non-periodic)                      */
+          const int32_t* neighbor_ptr, /* NULL => matrix layout                                       */
+          int max_neighbors, int fill_value,
+          const void* cell,            /* [n_systems,3,3] dtype or NULL                               */
+          const int32_t* batch_idx,    /* [n_atoms] or NULL                                           */
+          int n_systems, const mi_d3_params* params /* [host] */, int compute_virial,
+          float* energy /*[n_systems]*/, float* forces /*[n_atoms,3]*/, float* coord_num /*[n_atoms]*/,
+          float* virial /*[n_systems,3,3] or NULL*/, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- Ewald real space -----------------------------------------------------------------------
+ * Replaces the 12 alchemiops::_[batch_]ewald_real_space_* ops (ewald.py:263-1365; kernels
+ * ewald_kernels.py:266-1495): erfc(A&S 7.1.26)-damped pair sum over a FULL (symmetric) neighbour list.
+ * energies are float64 whatever dtype is (the wrapper casts, ewald.py:577).  Forces are accumulated by
+ * the row owner only (x2), which equals the reference's i/j atomic scatter for a symmetric list.
+ */
+#define MI_EW_FORCES 1
+#define MI_EW_CHARGE_GRAD 2
+int mi_ewald_real(const void* positions, const void* charges, const void* cell, const void* alpha /*[n_systems]*/,
+                  const int32_t* batch_idx, int n_atoms, int dtype, const int32_t* idx_j,
+                  const int32_t* unit_shifts, const int32_t* neighbor_ptr, int max_neighbors, int mask_value,
+                  int flags, double* energies /*[n_atoms]*/, void* forces /*[n_atoms,3] dtype*/,
+                  double* charge_grads /*[n_atoms]*/, void* stream);
+
+/* ---- B-spline spread / gather ---------------------------------------------------------------
+ * Replaces alchemiops::_[batch_]spline_spread / _gather / _gather_vec3 (spline.py:1500-2107; kernels
+ * :497-676, :763-959).  Orders 1-4 use the reference's piecewise polynomials; orders 5-6 use the true
+ * cardinal B-spline recursion (the reference returns 0 there: SURVEY F2).  mesh is [n_systems,nx,ny,nz].
+ * `batched` selects the reference's batch-kernel weight threshold (w > 1e-8 instead of w > 0 in spread).
+ */
+int mi_spline_spread(const void* positions, const void* values, const int32_t* batch_idx,
+                     const void* cell_inv_t /*[n_systems,3,3]*/, int n_atoms, int n_systems, int nx, int ny,
+                     int nz, int order, int batched, int dtype, void* mesh /* zeroed by caller */, void* stream);
+/* channels = 1: out[n_atoms] += sum_g mesh[g] w ; channels = 3 (mesh [..,3] interleaved) or 4 planar:
+ * see mi_pme_gather below for the fused PME form.                                                     */
+int mi_spline_gather(const void* positions, const void* mesh, const int32_t* batch_idx, const void* cell_inv_t,
+                     int n_atoms, int n_systems, int nx, int ny, int nz, int order, int dtype,
+                     void* out /*[n_atoms]*/, void* stream);
+int mi_spline_gather_vec3(const void* positions, const void* charges, const void* mesh_vec3 /*[B,nx,ny,nz,3]*/,
+                          const int32_t* batch_idx, const void* cell_inv_t, int n_atoms, int n_systems, int nx,
+                          int ny, int nz, int order, int dtype, void* out /*[n_atoms,3]*/, void* stream);
+
+/* ---- PME reciprocal-space mesh kernels ------------------------------------------------------
+ * mi_pme_green_sf: alchemiops::_[batch_]pme_green_structure_factor (pme.py:273-553, pme_kernels.py:121-331)
+ * mi_pme_convolve: the torch elementwise block of _pme_reciprocal_space_impl (pme.py:1418-1419,1455-1457):
+ *   conv = spec / sf2 * G ; E_d = -i k_d conv, fused into one pass that writes 1 or 4 spectra.
+ * mi_pme_gather_finish: spline_gather + pme_energy_corrections[_with_charge_grad] + gather_vec3 + "x2"
+ *   (pme.py:1429-1477; pme_kernels.py:340-657) fused over the 4 planar real-space meshes.
+ */
+int mi_pme_green_sf(const void* k_squared /*[B,nx,ny,nzr]*/, const void* alpha /*[B]*/, const void* volume /*[B]*/,
+                    int n_systems, int nx, int ny, int nz, int order, int dtype, void* green /*[B,nx,ny,nzr]*/,
+                    void* sf_sq /*[nx,ny,nzr]*/, void* stream);
+int mi_pme_convolve(const void* spec /*complex [B,nx,ny,nzr]*/, const void* recip_cell /*[B,3,3] = 2pi inv(cell)*/,
+                    const void* alpha /*[B]*/, const void* volume /*[B]*/, int n_systems, int nx, int ny, int nz,
+                    int order, int with_field, int dtype, void* out /*complex [B,(1|4),nx,ny,nzr]*/, void* stream);
+int mi_pme_gather_finish(const void* positions, const void* charges, const int32_t* batch_idx, const void* cell_inv_t,
+                         const void* meshes /*[B,(1|4),nx,ny,nz] real*/, const void* alpha, const void* volume,
+                         const void* total_charge /*[B]*/, int n_atoms, int n_systems, int nx, int ny, int nz,
+                         int order, int with_field, int dtype, void* energies /*[n_atoms]*/,
+                         void* forces /*[n_atoms,3] or NULL*/, void* charge_grads /*[n_atoms] or NULL*/, void* stream);
+int mi_pme_corrections(const void* raw, const void* charges, const int32_t* batch_idx, const void* volume,
+                       const void* alpha, const void* total_charge, int n_atoms, int dtype, void* energies,
+                       void* charge_grads /*NULL ok*/, void* stream);
+/* per-system sum of charges (charges.sum() / scatter_add_, pme.py:1225,1241-1244); out zeroed by caller */
+int mi_segment_sum(const void* values, const int32_t* batch_idx, int n_atoms, int dtype, void* out /*[B]*/, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NVALCHEMIOPS_HIP_H */

@@ -1,0 +1,596 @@
+// nlist.hip -- batched cell-list neighbour search for MI355X (gfx950, wave64).
+//
+// What it computes is what the reference's cell-list path computes (neighborlist/cell_list.py:372-556,
+// batch_cell_list.py:381-569, neighbor_utils.py:106-147): for every atom i the set of (j, S) with
+// |r_j - r_i + S.cell|^2 < rc^2, S the integer lattice shift, evaluated with the reference's floating-point
+// expression order (file compiled with -ffp-contract=off).  How it computes it is MI355X-first:
+//
+//   setup    one thread per system: own binning (cell edge ~ rc/k, k from the local density; NOT the
+//            reference's 1000-cell cap) -- the result set does not depend on the binning
+//   assign   one thread per atom: cell key + integer wrap of atoms outside the box
+//   sort     radix sort of (cell key, atom index) (rocPRIM via hipcub): stable => ascending index in a cell
+//   ranges   cell -> [begin,end) in the sorted order by binary search (no atomics, no scan)
+//   gather   cell-ordered float4/double4 copy {x,y,z,index} so the query streams 16/32 B records
+//   query    ONE WAVE64 PER ATOM walks the full shell of cells; x-adjacent cells are contiguous in the sorted
+//            order, so each (dy,dz) row is one coalesced run; 64 candidates are tested per step, hits are
+//            compacted with __ballot/__popcll and written to the row owner's slots (coalesced, no atomics,
+//            deterministic order); the owner also writes the padding => no separate torch.full pass.
+//
+// The same query kernel serves the padded matrix, the count pass and the direct CSR/COO fill.
+#include <hipcub/hipcub.hpp>
+
+#include "common.h"
+
+namespace {
+
+template <class T> struct NlSys {
+  T cell[9];
+  T inv[9];
+  T origin[3];  // subtracted before binning only
+  int cpd[3];
+  int R[3];
+  int pbc[3];
+  int nrange[3];  // image range of the naive method (neighbor_utils.py:150-211)
+  int cell_off;
+  int ncells;
+};
+struct NlGlobal { int total_cells; int any_wrap; int pad0; int pad1; };
+
+struct NlLayout {
+  size_t sys, glob, natoms, keys_in, keys_out, vals_in, vals_out, wrap, swrap, spos, cell_start, cub, total;
+  size_t cub_bytes;
+  long long cell_cap;
+};
+
+inline long long nl_cell_cap(int N, int B) { return 4ll * N + 8ll * B; }
+
+inline int nl_key_bits(long long cap) {
+  int bits = 1;
+  while ((1ll << bits) <= cap && bits < 31) ++bits;
+  return bits;
+}
+
+NlLayout nl_layout(int N, int B, int dtype) {
+  NlLayout L;
+  size_t o = 0;
+  const size_t sysz = dtype == MI_F32 ? sizeof(NlSys<float>) : sizeof(NlSys<double>);
+  const size_t esz = dtype == MI_F32 ? 4 : 8;
+  L.cell_cap = nl_cell_cap(N, B);
+  auto take = [&](size_t bytes) { size_t at = o; o += mi_align(bytes); return at; };
+  L.sys = take(sysz * (size_t)B);
+  L.glob = take(sizeof(NlGlobal));
+  L.natoms = take(sizeof(int) * (size_t)B);
+  L.keys_in = take(sizeof(int) * (size_t)N);
+  L.keys_out = take(sizeof(int) * (size_t)N);
+  L.vals_in = take(sizeof(int) * (size_t)N);
+  L.vals_out = take(sizeof(int) * (size_t)N);
+  L.wrap = take(8 * (size_t)N);
+  L.swrap = take(8 * (size_t)N);
+  L.spos = take(4 * esz * (size_t)N);
+  L.cell_start = take(sizeof(int) * (size_t)(L.cell_cap + 2));
+  size_t cub = 0;
+  (void)hipcub::DeviceRadixSort::SortPairs(nullptr, cub, (const int*)nullptr, (int*)nullptr, (const int*)nullptr, (int*)nullptr,
+                                     N > 0 ? N : 1, 0, nl_key_bits(L.cell_cap));
+  L.cub_bytes = cub + 256;
+  L.cub = take(L.cub_bytes);
+  L.total = o;
+  return L;
+}
+
+__device__ __forceinline__ float4 pack4(float x, float y, float z, int idx) { return make_float4(x, y, z, __int_as_float(idx)); }
+__device__ __forceinline__ double4 pack4(double x, double y, double z, int idx) { return make_double4(x, y, z, (double)idx); }
+__device__ __forceinline__ int idx_of(const float4& v) { return __float_as_int(v.w); }
+__device__ __forceinline__ int idx_of(const double4& v) { return (int)v.w; }
+
+__global__ void nl_count_atoms_kernel(const int* __restrict__ batch_idx, int N, int* __restrict__ natoms) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < N) atomicAdd(&natoms[batch_idx[i]], 1);
+}
+
+template <class T>
+__global__ void nl_setup_kernel(const T* __restrict__ cell, const uint8_t* __restrict__ pbc, const int* __restrict__ natoms, int N,
+                                int B, T cutoff, const T* __restrict__ origin, NlSys<T>* __restrict__ sys, NlGlobal* __restrict__ glob) {
+  for (int s = threadIdx.x; s < B; s += blockDim.x) {
+    NlSys<T> S;
+    for (int k = 0; k < 9; ++k) S.cell[k] = cell[9 * (size_t)s + k];
+    for (int k = 0; k < 3; ++k) S.origin[k] = origin ? origin[3 * (size_t)s + k] : T(0);
+    inverse3(S.cell, S.inv);
+    const T* a = S.cell;
+    double det = (double)a[0] * ((double)a[4] * a[8] - (double)a[5] * a[7]) - (double)a[1] * ((double)a[3] * a[8] - (double)a[5] * a[6]) +
+                 (double)a[2] * ((double)a[3] * a[7] - (double)a[4] * a[6]);
+    double vol = fabs(det);
+    int ns = natoms ? natoms[s] : N;
+    double rc = (double)cutoff;
+    double apc = vol > 0 ? (double)ns / vol * rc * rc * rc : 0.0;  // atoms per rc^3 cube
+    int k = apc < 64.0 ? 1 : (apc < 512.0 ? 2 : 3);
+    long long cap = 4ll * ns + 8;
+    double face[3];
+    for (int d = 0; d < 3; ++d) {
+      T col[3] = {S.inv[d], S.inv[3 + d], S.inv[6 + d]};
+      T ln = sqrt(col[0] * col[0] + col[1] * col[1] + col[2] * col[2]);
+      face[d] = 1.0 / (double)ln;
+      S.pbc[d] = pbc[3 * (size_t)s + d] ? 1 : 0;
+      double want = face[d] * k / rc;
+      S.cpd[d] = want >= 1048576.0 ? 1048576 : (want >= 1.0 ? (int)want : 1);
+      S.nrange[d] = S.pbc[d] ? (int)ceil(ln * cutoff) : 0;
+    }
+    long long tot = (long long)S.cpd[0] * S.cpd[1] * S.cpd[2];
+    while (tot > cap) {
+      for (int d = 0; d < 3; ++d) S.cpd[d] = S.cpd[d] / 2 > 1 ? S.cpd[d] / 2 : 1;
+      tot = (long long)S.cpd[0] * S.cpd[1] * S.cpd[2];
+    }
+    for (int d = 0; d < 3; ++d) {
+      if (S.cpd[d] == 1 && !S.pbc[d]) S.R[d] = 0;
+      else S.R[d] = (int)ceil(rc * S.cpd[d] / face[d] * (1.0 + 1e-6));
+    }
+    S.ncells = (int)tot;
+    S.cell_off = 0;
+    sys[s] = S;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int off = 0;
+    for (int s = 0; s < B; ++s) { sys[s].cell_off = off; off += sys[s].ncells; }
+    glob->total_cells = off;
+    glob->any_wrap = 0;
+  }
+}
+
+template <class T>
+__global__ void nl_assign_kernel(const T* __restrict__ pos, const int* __restrict__ batch_idx, int N, const NlSys<T>* __restrict__ sys,
+                                 int* __restrict__ keys, int* __restrict__ vals, short4* __restrict__ wrap, NlGlobal* __restrict__ glob) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  const int s = batch_idx ? batch_idx[i] : 0;
+  const NlSys<T>& S = sys[s];
+  T p[3] = {pos[3 * (size_t)i] - S.origin[0], pos[3 * (size_t)i + 1] - S.origin[1], pos[3 * (size_t)i + 2] - S.origin[2]}, frac[3];
+  rowvec_mat3(p, S.inv, frac);
+  int c[3], w[3];
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    int v = (int)floor(frac[d] * (T)S.cpd[d]);
+    if (S.pbc[d]) floor_divmod(v, S.cpd[d], w[d], c[d]);
+    else { w[d] = 0; c[d] = v < 0 ? 0 : (v >= S.cpd[d] ? S.cpd[d] - 1 : v); }
+  }
+  keys[i] = S.cell_off + c[0] + S.cpd[0] * (c[1] + S.cpd[1] * c[2]);
+  vals[i] = i;
+  wrap[i] = make_short4((short)w[0], (short)w[1], (short)w[2], 0);
+  if (w[0] | w[1] | w[2]) glob->any_wrap = 1;
+}
+
+__global__ void nl_cell_ranges_kernel(const int* __restrict__ keys_sorted, int N, const NlGlobal* __restrict__ glob, long long cap,
+                                      int* __restrict__ cell_start) {
+  long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c > cap || c > glob->total_cells) return;
+  int lo = 0, hi = N;  // first position with key >= c
+  while (lo < hi) {
+    int mid = (lo + hi) >> 1;
+    if (keys_sorted[mid] < (int)c) lo = mid + 1; else hi = mid;
+  }
+  cell_start[c] = lo;
+}
+
+template <class T>
+__global__ void nl_gather_kernel(const T* __restrict__ pos, const int* __restrict__ vals_sorted, const short4* __restrict__ wrap, int N,
+                                 typename Vec4<T>::type* __restrict__ spos, short4* __restrict__ swrap) {
+  int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= N) return;
+  int i = vals_sorted[p];
+  spos[p] = pack4(pos[3 * (size_t)i], pos[3 * (size_t)i + 1], pos[3 * (size_t)i + 2], i);
+  swrap[p] = wrap[i];
+}
+
+// coalesced wave-wide fill of dst[begin,end) with `value`; 16-byte stores in the aligned body
+__device__ __forceinline__ void wave_fill(int* __restrict__ dst, long long begin, long long end, int value, int lane) {
+  long long n = end - begin;
+  if (n <= 0) return;
+  int* p = dst + begin;
+  int head = (int)(((16 - ((uintptr_t)p & 15)) & 15) >> 2);
+  if (head > n) head = (int)n;
+  if (lane < head) p[lane] = value;
+  long long body = (n - head) >> 2;
+  int4* p4 = reinterpret_cast<int4*>(p + head);
+  const int4 v4 = make_int4(value, value, value, value);
+  for (long long t = lane; t < body; t += MI_WAVE) p4[t] = v4;
+  long long done = head + (body << 2);
+  if (done + lane < n) p[done + lane] = value;
+}
+
+template <class T, int MODE>
+__global__ __launch_bounds__(256) void nl_query_kernel(
+    const typename Vec4<T>::type* __restrict__ spos, const short4* __restrict__ swrap, const int* __restrict__ keys_sorted,
+    const int* __restrict__ cell_start, const int* __restrict__ batch_idx, const NlSys<T>* __restrict__ sys,
+    const NlGlobal* __restrict__ glob, int N, T rc2, int flags, int* __restrict__ nm, int* __restrict__ nsh, int* __restrict__ num,
+    int M, int fill_value, const int* __restrict__ ptr, int* __restrict__ list_ij, int* __restrict__ list_sh, long long P) {
+  const int lane = threadIdx.x & (MI_WAVE - 1);
+  const int p = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x / MI_WAVE) + (threadIdx.x / MI_WAVE));
+  if (p >= N) return;
+  const auto ci = spos[p];
+  const int i = __builtin_amdgcn_readfirstlane(idx_of(ci));
+  const T pix = ci.x, piy = ci.y, piz = ci.z;
+  const int s = batch_idx ? __builtin_amdgcn_readfirstlane(batch_idx[i]) : 0;
+  const NlSys<T>* S = sys + s;
+  const int nx = S->cpd[0], ny = S->cpd[1], nz = S->cpd[2];
+  const int Rx = S->R[0], Ry = S->R[1], Rz = S->R[2];
+  const bool pbx = S->pbc[0] != 0, pby = S->pbc[1] != 0, pbz = S->pbc[2] != 0;
+  const int coff = S->cell_off;
+  T cm[9];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) cm[k] = S->cell[k];
+  const int local = __builtin_amdgcn_readfirstlane(keys_sorted[p]) - coff;
+  const int cx = local % nx, cyz = local / nx, cy = cyz % ny, cz = cyz / ny;
+  const bool anyw = glob->any_wrap != 0;
+  short4 wi = make_short4(0, 0, 0, 0);
+  if (anyw) wi = swrap[p];
+  const bool half = (flags & MI_NL_HALF_FILL) != 0;
+  const bool naive = (flags & MI_NL_NAIVE_EXPR) != 0;
+  const int nr0 = S->nrange[0], nr1 = S->nrange[1], nr2 = S->nrange[2];
+  const unsigned long long lt = (1ull << lane) - 1ull;
+  long long out_base;
+  int cap_row;
+  if (MODE == MI_NL_MODE_CSR) { out_base = ptr[i]; cap_row = ptr[i + 1] - ptr[i]; }
+  else { out_base = (long long)i * M; cap_row = M; }
+  int cnt = 0;
+
+  int xlo = cx - Rx, xhi = cx + Rx, sx_lo = 0, sx_hi = 0;
+  if (pbx) { int r; floor_divmod(xlo, nx, sx_lo, r); floor_divmod(xhi, nx, sx_hi, r); }
+  else { xlo = xlo < 0 ? 0 : xlo; xhi = xhi > nx - 1 ? nx - 1 : xhi; }
+
+  for (int dz = -Rz; dz <= Rz; ++dz) {
+    const int tz = cz + dz;
+    if (!pbz && (tz < 0 || tz >= nz)) continue;
+    int csz, wz;
+    floor_divmod(tz, nz, csz, wz);
+    for (int dy = -Ry; dy <= Ry; ++dy) {
+      const int ty = cy + dy;
+      if (!pby && (ty < 0 || ty >= ny)) continue;
+      int csy, wy;
+      floor_divmod(ty, ny, csy, wy);
+      const int rowbase = coff + nx * (wy + ny * wz);
+      for (int sx = sx_lo; sx <= sx_hi; ++sx) {
+        const int img0 = sx * nx;
+        const int xa = (xlo > img0 ? xlo : img0) - img0;
+        const int xb = (xhi < img0 + nx - 1 ? xhi : img0 + nx - 1) - img0;
+        const int beg = cell_start[rowbase + xa], end = cell_start[rowbase + xb + 1];
+        for (int q0 = beg; q0 < end; q0 += MI_WAVE) {
+          const int q = q0 + lane;
+          bool hit = false;
+          int j = 0, Sx = sx, Sy = csy, Sz = csz;
+          if (q < end) {
+            const auto cj = spos[q];
+            j = idx_of(cj);
+            if (anyw) {
+              const short4 wj = swrap[q];
+              if (pbx) Sx += (int)wi.x - (int)wj.x;
+              if (pby) Sy += (int)wi.y - (int)wj.y;
+              if (pbz) Sz += (int)wi.z - (int)wj.z;
+            }
+            const T fs[3] = {(T)Sx, (T)Sy, (T)Sz};
+            T cart[3], dr0, dr1, dr2;
+            rowvec_mat3(fs, cm, cart);
+            bool ok = true;
+            if (!naive) {
+              // cell_list.py:531-544:  dr = pos_j - pos_i + S.cell ; d2 = dot(dr,dr) ; d2 < rc*rc
+              dr0 = (cj.x - pix) + cart[0];
+              dr1 = (cj.y - piy) + cart[1];
+              dr2 = (cj.z - piz) + cart[2];
+            } else {
+              // naive.py:163-172: diff = (S.cell + r_shifted_atom) - r_other, evaluated for the upper-half shift
+              const bool upper = Sx > 0 || (Sx == 0 && Sy > 0) || (Sx == 0 && Sy == 0 && Sz >= 0);
+              if (upper) { dr0 = (cart[0] + cj.x) - pix; dr1 = (cart[1] + cj.y) - piy; dr2 = (cart[2] + cj.z) - piz; }
+              else { dr0 = ((-cart[0]) + pix) - cj.x; dr1 = ((-cart[1]) + piy) - cj.y; dr2 = ((-cart[2]) + piz) - cj.z; }
+              ok = (Sx <= nr0 && -Sx <= nr0) && (Sy <= nr1 && -Sy <= nr1) && (Sz <= nr2 && -Sz <= nr2);
+            }
+            const T d2 = dr0 * dr0 + dr1 * dr1 + dr2 * dr2;
+            const bool zeroS = (Sx | Sy | Sz) == 0;
+            hit = ok && (d2 < rc2) && !(j == i && zeroS);
+            if (half && hit) {
+              const bool pos_shift = Sx > 0 || (Sx == 0 && Sy > 0) || (Sx == 0 && Sy == 0 && Sz > 0);
+              hit = pos_shift || (zeroS && j > i);
+            }
+          }
+          const unsigned long long mask = __ballot(hit);
+          if (mask) {
+            const int slot = cnt + __popcll(mask & lt);
+            if (MODE == MI_NL_MODE_MATRIX) {
+              if (hit && slot < cap_row) {
+                nm[out_base + slot] = j;
+                if (nsh) { int* sp = nsh + (out_base + slot) * 3; sp[0] = Sx; sp[1] = Sy; sp[2] = Sz; }
+              }
+            } else if (MODE == MI_NL_MODE_CSR) {
+              if (hit && slot < cap_row) {
+                list_ij[out_base + slot] = i;
+                list_ij[P + out_base + slot] = j;
+                if (list_sh) { int* sp = list_sh + (out_base + slot) * 3; sp[0] = Sx; sp[1] = Sy; sp[2] = Sz; }
+              }
+            }
+            cnt += __popcll(mask);
+          }
+        }
+      }
+    }
+  }
+  if (MODE != MI_NL_MODE_CSR) {
+    if (lane == 0) num[i] = cnt;
+  }
+  if (MODE == MI_NL_MODE_MATRIX && !(flags & MI_NL_NO_PAD)) {
+    // the row owner also writes the padding (replaces torch.full + zeros of cell_list.py:1358-1373)
+    const int used = cnt < M ? cnt : M;
+    wave_fill(nm, out_base + used, out_base + M, fill_value, lane);
+    if (nsh) wave_fill(nsh, (out_base + used) * 3, (out_base + M) * 3, 0, lane);
+  }
+}
+
+// padded matrix -> COO (neighbor_utils.py:428-438: mask = matrix != fill_value, row-major order)
+__global__ __launch_bounds__(256) void nl_matrix_to_coo_kernel(const int* __restrict__ nm, const int* __restrict__ nsh,
+                                                               const int* __restrict__ ptr, int N, int M, int fill_value,
+                                                               int* __restrict__ ij, int* __restrict__ sh, long long P) {
+  const int lane = threadIdx.x & (MI_WAVE - 1);
+  const int i = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x / MI_WAVE) + (threadIdx.x / MI_WAVE));
+  if (i >= N) return;
+  const long long base = ptr[i];
+  const int room = ptr[i + 1] - ptr[i];
+  const unsigned long long lt = (1ull << lane) - 1ull;
+  int cnt = 0;
+  for (int t0 = 0; t0 < M; t0 += MI_WAVE) {
+    const int t = t0 + lane;
+    int j = fill_value;
+    if (t < M) j = nm[(long long)i * M + t];
+    const bool keep = (t < M) && (j != fill_value);
+    const unsigned long long mask = __ballot(keep);
+    const int slot = cnt + __popcll(mask & lt);
+    if (keep && slot < room) {
+      ij[base + slot] = i;
+      ij[P + base + slot] = j;
+      if (sh) {
+        const int* sp = nsh + ((long long)i * M + t) * 3;
+        int* dp = sh + (base + slot) * 3;
+        dp[0] = sp[0]; dp[1] = sp[1]; dp[2] = sp[2];
+      }
+    }
+    cnt += __popcll(mask);
+  }
+}
+
+// ---- reference-format sizing (cell_list.py:35-99, batch_cell_list.py:36-99) -----------------------
+template <class T>
+__device__ void ref_cells_per_dim(const T* cell9, const uint8_t* pbc3, T cutoff, int cpd[3], int* radius) {
+  T inv[9];
+  inverse3(cell9, inv);
+  for (int d = 0; d < 3; ++d) {
+    T col[3] = {inv[d], inv[3 + d], inv[6 + d]};
+    T face = T(1) / sqrt(col[0] * col[0] + col[1] * col[1] + col[2] * col[2]);
+    int c = (int)(face / cutoff);
+    cpd[d] = c > 1 ? c : 1;
+    if (radius) radius[d] = (cpd[d] == 1 && !pbc3[d]) ? 0 : (int)ceil(cutoff * (T)cpd[d] / face);
+  }
+}
+template <class T>
+__global__ void nl_estimate_sizes_kernel(const T* __restrict__ cell, const uint8_t* __restrict__ pbc, int B, T cutoff, int max_nbins,
+                                         int* __restrict__ ncells, int* __restrict__ radius) {
+  int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= B) return;
+  int cpd[3];
+  ref_cells_per_dim(cell + 9 * (size_t)s, pbc + 3 * (size_t)s, cutoff, cpd, radius + 3 * (size_t)s);
+  long long tot = (long long)cpd[0] * cpd[1] * cpd[2];
+  while (tot > max_nbins) {
+    for (int d = 0; d < 3; ++d) cpd[d] = cpd[d] / 2 > 1 ? cpd[d] / 2 : 1;
+    tot = (long long)cpd[0] * cpd[1] * cpd[2];
+  }
+  ncells[s] = (int)tot;
+}
+
+// reference-format cache: bin size (cell_list.py:102-163 / batch_cell_list.py:103-177) + per-atom cell/shift
+template <class T>
+__global__ void nl_cache_binsize_kernel(const T* __restrict__ cell, const uint8_t* __restrict__ pbc, int B, T cutoff, int max_total_cells,
+                                        int batched, int* __restrict__ cpd_out, int* __restrict__ cell_off /*[B+1]*/) {
+  for (int s = threadIdx.x; s < B; s += blockDim.x) {
+    int cpd[3];
+    ref_cells_per_dim<T>(cell + 9 * (size_t)s, pbc + 3 * (size_t)s, cutoff, cpd, nullptr);
+    long long tot = (long long)cpd[0] * cpd[1] * cpd[2];
+    const long long mult = batched ? B : 1;
+    while (tot * mult > max_total_cells) {
+      for (int d = 0; d < 3; ++d) cpd[d] = cpd[d] / 2 > 1 ? cpd[d] / 2 : 1;
+      tot = (long long)cpd[0] * cpd[1] * cpd[2];
+    }
+    for (int d = 0; d < 3; ++d) cpd_out[3 * (size_t)s + d] = cpd[d];
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int off = 0;
+    for (int s = 0; s < B; ++s) { cell_off[s] = off; off += cpd_out[3 * s] * cpd_out[3 * s + 1] * cpd_out[3 * s + 2]; }
+    cell_off[B] = off;
+  }
+}
+template <class T>
+__global__ void nl_cache_assign_kernel(const T* __restrict__ pos, const T* __restrict__ cell, const uint8_t* __restrict__ pbc,
+                                       const int* __restrict__ batch_idx, int N, const int* __restrict__ cpd, const int* __restrict__ cell_off,
+                                       int* __restrict__ keys, int* __restrict__ vals, int* __restrict__ atom_shift, int* __restrict__ atom_cell) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  const int s = batch_idx ? batch_idx[i] : 0;
+  T inv[9];
+  inverse3(cell + 9 * (size_t)s, inv);
+  T p[3] = {pos[3 * (size_t)i], pos[3 * (size_t)i + 1], pos[3 * (size_t)i + 2]}, frac[3];
+  rowvec_mat3(p, inv, frac);
+  int c[3];
+  for (int d = 0; d < 3; ++d) {
+    const int n = cpd[3 * s + d];
+    int v = (int)floor(frac[d] * (T)n), w = 0;
+    if (pbc[3 * s + d]) floor_divmod(v, n, w, c[d]);
+    else c[d] = v < 0 ? 0 : (v >= n ? n - 1 : v);
+    atom_shift[3 * (size_t)i + d] = w;
+    atom_cell[3 * (size_t)i + d] = c[d];
+  }
+  const int key = cell_off[s] + c[0] + cpd[3 * s] * (c[1] + cpd[3 * s + 1] * c[2]);
+  keys[i] = key;
+  vals[i] = i;
+}
+__device__ __forceinline__ int nl_lower_bound(const int* __restrict__ keys_sorted, int N, int c) {
+  int lo = 0, hi = N;
+  while (lo < hi) { int mid = (lo + hi) >> 1; if (keys_sorted[mid] < c) lo = mid + 1; else hi = mid; }
+  return lo;
+}
+// cell_atom_start_indices = exclusive cumsum of the counts (cell_list.py:869-871); counts = adjacent differences
+__global__ void nl_cache_starts_kernel(const int* __restrict__ keys_sorted, int N, int C, int* __restrict__ starts, int* __restrict__ counts) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const int a = nl_lower_bound(keys_sorted, N, c), b = nl_lower_bound(keys_sorted, N, c + 1);
+  starts[c] = a;
+  counts[c] = b - a;
+}
+
+template <class T>
+int nl_neighbors_impl(const T* pos, int N, const T* cell, const uint8_t* pbc, const int* batch_idx, int B, double cutoff, int mode, int flags,
+                      int* nm, int* nsh, int* num, int M, int fill_value, const int* ptr, int* list_ij, int* list_sh, long long P,
+                      const T* origin, char* ws, const NlLayout& L, hipStream_t st) {
+  auto* sys = reinterpret_cast<NlSys<T>*>(ws + L.sys);
+  auto* glob = reinterpret_cast<NlGlobal*>(ws + L.glob);
+  int* natoms = reinterpret_cast<int*>(ws + L.natoms);
+  int* keys_in = reinterpret_cast<int*>(ws + L.keys_in);
+  int* keys_out = reinterpret_cast<int*>(ws + L.keys_out);
+  int* vals_in = reinterpret_cast<int*>(ws + L.vals_in);
+  int* vals_out = reinterpret_cast<int*>(ws + L.vals_out);
+  auto* wrap = reinterpret_cast<short4*>(ws + L.wrap);
+  auto* swrap = reinterpret_cast<short4*>(ws + L.swrap);
+  auto* spos = reinterpret_cast<typename Vec4<T>::type*>(ws + L.spos);
+  int* cell_start = reinterpret_cast<int*>(ws + L.cell_start);
+  const T rc = (T)cutoff;
+  // cell list: cutoff cast to the positions dtype, then squared (cell_list.py:444,1020);
+  // naive: squared in double, then cast (naive.py:290,388)
+  const T rc2 = (flags & MI_NL_NAIVE_EXPR) ? (T)(cutoff * cutoff) : rc * rc;
+
+  if (!(flags & MI_NL_REUSE_GRID)) {
+    const int* nat = nullptr;
+    if (batch_idx && B > 1) {
+      MI_HIP_CHECK(hipMemsetAsync(natoms, 0, sizeof(int) * (size_t)B, st));
+      nl_count_atoms_kernel<<<mi_blocks(N, 256), 256, 0, st>>>(batch_idx, N, natoms);
+      MI_LAUNCH_CHECK();
+      nat = natoms;
+    }
+    nl_setup_kernel<T><<<1, 256, 0, st>>>(cell, pbc, nat, N, B, rc, origin, sys, glob);
+    MI_LAUNCH_CHECK();
+    nl_assign_kernel<T><<<mi_blocks(N, 256), 256, 0, st>>>(pos, batch_idx, N, sys, keys_in, vals_in, wrap, glob);
+    MI_LAUNCH_CHECK();
+    size_t cub_bytes = L.cub_bytes;
+    MI_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(ws + L.cub, cub_bytes, (const int*)keys_in, keys_out, (const int*)vals_in, vals_out, N, 0,
+                                                    nl_key_bits(L.cell_cap), st));
+    nl_cell_ranges_kernel<<<mi_blocks(L.cell_cap + 1, 256), 256, 0, st>>>(keys_out, N, glob, L.cell_cap, cell_start);
+    MI_LAUNCH_CHECK();
+    nl_gather_kernel<T><<<mi_blocks(N, 256), 256, 0, st>>>(pos, vals_out, wrap, N, spos, swrap);
+    MI_LAUNCH_CHECK();
+  }
+  const int blocks = mi_blocks(N, 4);
+#define MI_NLQ(MODE_)                                                                                                              \
+  nl_query_kernel<T, MODE_><<<blocks, 256, 0, st>>>(spos, swrap, keys_out, cell_start, batch_idx, sys, glob, N, rc2, flags, nm, nsh, num, M, \
+                                                    fill_value, ptr, list_ij, list_sh, P)
+  if (mode == MI_NL_MODE_MATRIX) MI_NLQ(MI_NL_MODE_MATRIX);
+  else if (mode == MI_NL_MODE_COUNT) MI_NLQ(MI_NL_MODE_COUNT);
+  else MI_NLQ(MI_NL_MODE_CSR);
+#undef MI_NLQ
+  MI_LAUNCH_CHECK();
+  return MI_OK;
+}
+
+template <class T>
+int nl_cache_impl(const T* pos, int N, const T* cell, const uint8_t* pbc, const int* batch_idx, int B, double cutoff, int C, int* cpd,
+                  int* atom_shift, int* atom_cell, int* counts, int* starts, int* cell_atoms, char* ws, const NlLayout& L, hipStream_t st) {
+  int* keys_in = reinterpret_cast<int*>(ws + L.keys_in);
+  int* keys_out = reinterpret_cast<int*>(ws + L.keys_out);
+  int* vals_in = reinterpret_cast<int*>(ws + L.vals_in);
+  int* cell_off = reinterpret_cast<int*>(ws + L.cell_start);  // [B+1] scratch (capacity 4N+8B+2 ints)
+  nl_cache_binsize_kernel<T><<<1, 256, 0, st>>>(cell, pbc, B, (T)cutoff, C, batch_idx != nullptr, cpd, cell_off);
+  MI_LAUNCH_CHECK();
+  nl_cache_assign_kernel<T><<<mi_blocks(N, 256), 256, 0, st>>>(pos, cell, pbc, batch_idx, N, cpd, cell_off, keys_in, vals_in, atom_shift, atom_cell);
+  MI_LAUNCH_CHECK();
+  size_t cub_bytes = L.cub_bytes;
+  MI_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(ws + L.cub, cub_bytes, (const int*)keys_in, keys_out, (const int*)vals_in, cell_atoms, N, 0, 31, st));
+  nl_cache_starts_kernel<<<mi_blocks(C, 256), 256, 0, st>>>(keys_out, N, C, starts, counts);
+  MI_LAUNCH_CHECK();
+  return MI_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t mi_nl_workspace_bytes(int n_atoms, int n_systems, int dtype) {
+  if (n_atoms < 0 || n_systems < 1) return 0;
+  return nl_layout(n_atoms, n_systems, dtype).total;
+}
+
+int mi_nl_neighbors(const void* positions, int n_atoms, const void* cell, const uint8_t* pbc, const int32_t* batch_idx, int n_systems,
+                    double cutoff, int dtype, int mode, int flags, int32_t* neighbor_matrix, int32_t* neighbor_matrix_shifts,
+                    int32_t* num_neighbors, int max_neighbors, int fill_value, const int32_t* neighbor_ptr, int32_t* list_ij,
+                    int32_t* list_shifts, long long n_pairs, const void* bin_origin, void* workspace, size_t workspace_bytes, void* stream) {
+  MI_REQUIRE(dtype == MI_F32 || dtype == MI_F64, "dtype must be MI_F32 or MI_F64");
+  MI_REQUIRE(n_atoms >= 0 && n_systems >= 1, "n_atoms >= 0 and n_systems >= 1");
+  MI_REQUIRE(cutoff > 0, "cutoff must be positive");
+  MI_REQUIRE(mode >= 0 && mode <= 2, "mode");
+  if (n_atoms == 0) return MI_OK;
+  MI_REQUIRE(positions && cell && pbc && workspace, "null pointer");
+  if (mode == MI_NL_MODE_MATRIX) MI_REQUIRE(neighbor_matrix && num_neighbors && max_neighbors >= 0, "matrix outputs");
+  if (mode == MI_NL_MODE_COUNT) MI_REQUIRE(num_neighbors != nullptr, "num_neighbors");
+  if (mode == MI_NL_MODE_CSR) MI_REQUIRE(neighbor_ptr && list_ij, "csr outputs");
+  if (flags & MI_NL_NO_SHIFTS) neighbor_matrix_shifts = nullptr;
+  NlLayout L = nl_layout(n_atoms, n_systems, dtype);
+  if (workspace_bytes < L.total) { mi_set_error("workspace too small: %zu < %zu", workspace_bytes, L.total); return MI_EWORKSPACE; }
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == MI_F32)
+    return nl_neighbors_impl<float>((const float*)positions, n_atoms, (const float*)cell, pbc, batch_idx, n_systems, cutoff, mode, flags,
+                                    neighbor_matrix, neighbor_matrix_shifts, num_neighbors, max_neighbors, fill_value, neighbor_ptr, list_ij,
+                                    list_shifts, n_pairs, (const float*)bin_origin, (char*)workspace, L, st);
+  return nl_neighbors_impl<double>((const double*)positions, n_atoms, (const double*)cell, pbc, batch_idx, n_systems, cutoff, mode, flags,
+                                   neighbor_matrix, neighbor_matrix_shifts, num_neighbors, max_neighbors, fill_value, neighbor_ptr, list_ij,
+                                   list_shifts, n_pairs, (const double*)bin_origin, (char*)workspace, L, st);
+}
+
+int mi_nl_matrix_to_coo(const int32_t* neighbor_matrix, const int32_t* neighbor_matrix_shifts, const int32_t* neighbor_ptr, int n_atoms,
+                             int max_neighbors, int fill_value, int32_t* list_ij, int32_t* list_shifts, long long n_pairs, void* stream) {
+  if (n_atoms == 0 || n_pairs == 0) return MI_OK;
+  MI_REQUIRE(neighbor_matrix && neighbor_ptr && list_ij, "null pointer");
+  nl_matrix_to_coo_kernel<<<mi_blocks(n_atoms, 4), 256, 0, (hipStream_t)stream>>>(neighbor_matrix, neighbor_matrix_shifts, neighbor_ptr, n_atoms,
+                                                                                  max_neighbors, fill_value, list_ij,
+                                                                                  neighbor_matrix_shifts ? list_shifts : nullptr, n_pairs);
+  MI_LAUNCH_CHECK();
+  return MI_OK;
+}
+
+int mi_nl_estimate_sizes(const void* cell, const uint8_t* pbc, int n_systems, double cutoff, int max_nbins, int dtype, int32_t* number_of_cells,
+                         int32_t* neighbor_search_radius, void* stream) {
+  MI_REQUIRE(dtype == MI_F32 || dtype == MI_F64, "dtype");
+  MI_REQUIRE(cell && pbc && number_of_cells && neighbor_search_radius && n_systems >= 1, "null pointer");
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == MI_F32)
+    nl_estimate_sizes_kernel<float><<<mi_blocks(n_systems, 128), 128, 0, st>>>((const float*)cell, pbc, n_systems, (float)cutoff, max_nbins,
+                                                                               number_of_cells, neighbor_search_radius);
+  else
+    nl_estimate_sizes_kernel<double><<<mi_blocks(n_systems, 128), 128, 0, st>>>((const double*)cell, pbc, n_systems, cutoff, max_nbins,
+                                                                                number_of_cells, neighbor_search_radius);
+  MI_LAUNCH_CHECK();
+  return MI_OK;
+}
+
+int mi_nl_build_cell_cache(const void* positions, int n_atoms, const void* cell, const uint8_t* pbc, const int32_t* batch_idx, int n_systems,
+                           double cutoff, int dtype, int max_total_cells, int32_t* cells_per_dimension, int32_t* atom_periodic_shifts,
+                           int32_t* atom_to_cell_mapping, int32_t* atoms_per_cell_count, int32_t* cell_atom_start_indices,
+                           int32_t* cell_atom_list, void* workspace, size_t workspace_bytes, void* stream) {
+  MI_REQUIRE(dtype == MI_F32 || dtype == MI_F64, "dtype");
+  if (n_atoms == 0) return MI_OK;
+  MI_REQUIRE(positions && cell && pbc && workspace && cells_per_dimension && atom_periodic_shifts && atom_to_cell_mapping &&
+                 atoms_per_cell_count && cell_atom_start_indices && cell_atom_list,
+             "null pointer");
+  MI_REQUIRE(max_total_cells >= n_systems, "max_total_cells");
+  NlLayout L = nl_layout(n_atoms, n_systems, dtype);
+  if (workspace_bytes < L.total) { mi_set_error("workspace too small: %zu < %zu", workspace_bytes, L.total); return MI_EWORKSPACE; }
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == MI_F32)
+    return nl_cache_impl<float>((const float*)positions, n_atoms, (const float*)cell, pbc, batch_idx, n_systems, cutoff, max_total_cells,
+                                cells_per_dimension, atom_periodic_shifts, atom_to_cell_mapping, atoms_per_cell_count, cell_atom_start_indices,
+                                cell_atom_list, (char*)workspace, L, st);
+  return nl_cache_impl<double>((const double*)positions, n_atoms, (const double*)cell, pbc, batch_idx, n_systems, cutoff, max_total_cells,
+                               cells_per_dimension, atom_periodic_shifts, atom_to_cell_mapping, atoms_per_cell_count, cell_atom_start_indices,
+                               cell_atom_list, (char*)workspace, L, st);
+}
+
+}  // extern "C"

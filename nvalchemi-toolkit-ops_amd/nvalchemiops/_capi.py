@@ -1,0 +1,98 @@
+"""ctypes binding of libnvalchemiops_hip.so (C ABI declared in include/nvalchemiops_hip.h).
+
+Replaces the reference's Warp launch layer (``wp.from_torch`` + ``wp.launch``: e.g. neighborlist/cell_list.py:980-1034,
+autograd.py:300-360).  Zero-copy: raw device pointers of torch tensors and torch's current HIP stream are handed
+to the library, which never allocates, frees or retains them.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+import torch
+
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libnvalchemiops_hip.so")
+_LIB = None
+
+MI_F32, MI_F64 = 0, 1
+NL_MATRIX, NL_COUNT, NL_CSR = 0, 1, 2
+NL_HALF_FILL, NL_NAIVE_EXPR, NL_REUSE_GRID, NL_NO_SHIFTS, NL_NO_PAD = 1, 2, 4, 8, 16
+EW_FORCES, EW_CHARGE_GRAD = 1, 2
+
+
+class NativeLibraryError(RuntimeError):
+    """The HIP library is missing or failed: there is deliberately no fallback path."""
+
+
+class MiD3Params(ctypes.Structure):
+    _fields_ = [("rcov", ctypes.c_void_p), ("r4r2", ctypes.c_void_p), ("c6ab", ctypes.c_void_p), ("cn_ref", ctypes.c_void_p),
+                ("nz", ctypes.c_int), ("a1", ctypes.c_float), ("a2", ctypes.c_float), ("s6", ctypes.c_float), ("s8", ctypes.c_float),
+                ("k1", ctypes.c_float), ("k3", ctypes.c_float), ("s5_on", ctypes.c_float), ("s5_off", ctypes.c_float)]
+
+
+def lib() -> ctypes.CDLL:
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(_LIB_PATH):
+            raise NativeLibraryError(
+                f"{_LIB_PATH} not found: build it with `python nvalchemi-toolkit-ops_amd/build_native.py` "
+                "(hipcc --offload-arch=gfx950). This package has no CPU or PyTorch fallback.")
+        L = ctypes.CDLL(_LIB_PATH)
+        L.mi_last_error.restype = ctypes.c_char_p
+        L.mi_nl_workspace_bytes.restype = ctypes.c_size_t
+        L.mi_nl_workspace_bytes.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int]
+        if hasattr(L, "mi_d3_workspace_bytes"):
+            L.mi_d3_workspace_bytes.restype = ctypes.c_size_t
+            L.mi_d3_workspace_bytes.argtypes = [ctypes.c_int, ctypes.c_int]
+        _LIB = L
+    return _LIB
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        raise NativeLibraryError(f"{what} failed (code {rc}): {lib().mi_last_error().decode()}")
+
+
+def ptr(t: torch.Tensor | None):
+    if t is None:
+        return None
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def stream_of(t: torch.Tensor):
+    return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def dtype_code(dtype: torch.dtype) -> int:
+    # reference: types.py:20-29 raises ValueError for anything but f16/f32/f64; this path supports f32/f64
+    if dtype == torch.float32:
+        return MI_F32
+    if dtype == torch.float64:
+        return MI_F64
+    raise ValueError(f"Unsupported dtype: {dtype}")
+
+
+def require_device(*tensors: torch.Tensor | None) -> torch.device:
+    dev = None
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise NativeLibraryError(
+                "nvalchemiops (MI355X build) computes on ROCm devices only; got a tensor on "
+                f"'{t.device}'. There is no CPU path in this package.")
+        if dev is None:
+            dev = t.device
+        elif t.device != dev:
+            raise ValueError(f"tensors on different devices: {dev} vs {t.device}")
+    return dev
+
+
+def cdouble(x: float):
+    return ctypes.c_double(float(x))
+
+
+def i32(t: torch.Tensor | None) -> torch.Tensor | None:
+    if t is None:
+        return None
+    return t.to(torch.int32).contiguous()

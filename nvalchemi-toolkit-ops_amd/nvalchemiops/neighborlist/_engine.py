@@ -1,0 +1,82 @@
+"""Shared launcher of the fused HIP neighbour pipeline (csrc/nlist.hip) for every public neighbour-list entry point.
+
+Reference seam replaced: the `nvalchemiops::*cell_list*` / `_naive_*` custom ops (neighborlist/cell_list.py:725-1034,
+batch_cell_list.py:739-1067, naive.py:221-397).
+"""
+from __future__ import annotations
+
+import ctypes
+
+import torch
+
+from nvalchemiops import _capi as C
+
+_WS_BYTES: dict[tuple[int, int, int], int] = {}
+
+
+def workspace(n_atoms: int, n_systems: int, dtype: torch.dtype, device: torch.device) -> torch.Tensor:
+    key = (n_atoms, n_systems, C.dtype_code(dtype))
+    nbytes = _WS_BYTES.get(key)
+    if nbytes is None:
+        nbytes = int(C.lib().mi_nl_workspace_bytes(*key))
+        _WS_BYTES[key] = nbytes
+    return torch.empty(nbytes, dtype=torch.uint8, device=device)
+
+
+def canon_geometry(positions: torch.Tensor, cell: torch.Tensor, pbc: torch.Tensor, n_systems: int | None = None):
+    """positions contiguous; cell -> (B,3,3) in the positions dtype; pbc -> (B,3) bool (1 byte per flag)."""
+    pos = positions.detach().contiguous()
+    cell = cell.detach()
+    cell = (cell if cell.ndim == 3 else cell.unsqueeze(0)).to(dtype=pos.dtype, device=pos.device).contiguous()
+    pbc = pbc.reshape(-1, 3).to(device=pos.device, dtype=torch.bool)
+    if pbc.shape[0] != cell.shape[0]:
+        pbc = pbc.expand(cell.shape[0], 3)
+    return pos, cell, pbc.contiguous()
+
+
+def run(pos, cell, pbc, batch_idx, cutoff, mode, flags, *, nm=None, nsh=None, num=None, max_neighbors=0, fill_value=0,
+        nptr=None, list_ij=None, list_sh=None, n_pairs=0, ws=None, origin=None):
+    n = pos.shape[0]
+    nsys = cell.shape[0]
+    if ws is None:
+        ws = workspace(n, nsys, pos.dtype, pos.device)
+    rc = C.lib().mi_nl_neighbors(
+        C.ptr(pos), n, C.ptr(cell), C.ptr(pbc), C.ptr(batch_idx), nsys, C.cdouble(cutoff), C.dtype_code(pos.dtype), mode, flags,
+        C.ptr(nm), C.ptr(nsh), C.ptr(num), int(max_neighbors), int(fill_value), C.ptr(nptr), C.ptr(list_ij), C.ptr(list_sh),
+        ctypes.c_longlong(int(n_pairs)), C.ptr(origin), C.ptr(ws), ctypes.c_size_t(ws.numel()), C.stream_of(pos))
+    C.check(rc, "mi_nl_neighbors")
+    return ws
+
+
+def neighbor_matrix(pos, cell, pbc, batch_idx, cutoff, max_neighbors, fill_value, half_fill, nm, nsh, num, *, naive=False,
+                    want_shifts=True, pad=True, origin=None):
+    flags = (C.NL_HALF_FILL if half_fill else 0) | (C.NL_NAIVE_EXPR if naive else 0)
+    if not want_shifts:
+        flags |= C.NL_NO_SHIFTS
+    if not pad:
+        flags |= C.NL_NO_PAD
+    run(pos, cell, pbc, batch_idx, cutoff, C.NL_MATRIX, flags, nm=nm, nsh=nsh if want_shifts else None, num=num,
+        max_neighbors=max_neighbors, fill_value=fill_value, origin=origin)
+
+
+def neighbor_csr(pos, cell, pbc, batch_idx, cutoff, half_fill, *, naive=False, want_shifts=True, max_neighbors=None, origin=None):
+    """Direct COO/CSR emission: count pass -> prefix sum -> fill pass (the padded matrix is never materialised).
+
+    Returns (neighbor_list[2,P], neighbor_ptr[N+1], shifts[P,3] | None, max_count)."""
+    n = pos.shape[0]
+    dev = pos.device
+    flags = (C.NL_HALF_FILL if half_fill else 0) | (C.NL_NAIVE_EXPR if naive else 0)
+    num = torch.empty(n, dtype=torch.int32, device=dev)
+    ws = run(pos, cell, pbc, batch_idx, cutoff, C.NL_COUNT, flags, num=num, origin=origin)
+    nptr = torch.zeros(n + 1, dtype=torch.int32, device=dev)
+    torch.cumsum(num, dim=0, out=nptr[1:])
+    total, max_count = (int(v) for v in torch.stack([nptr[-1], num.max()]).tolist())  # the one host sync
+    if max_neighbors is not None and max_count > max_neighbors:
+        from nvalchemiops.neighborlist.neighbor_utils import NeighborOverflowError
+
+        raise NeighborOverflowError(max_neighbors, max_count)
+    lst = torch.empty((2, total), dtype=torch.int32, device=dev)
+    sh = torch.empty((total, 3), dtype=torch.int32, device=dev) if want_shifts else None
+    if total > 0:
+        run(pos, cell, pbc, batch_idx, cutoff, C.NL_CSR, flags | C.NL_REUSE_GRID, nptr=nptr, list_ij=lst, list_sh=sh, n_pairs=total, ws=ws)
+    return lst, nptr, sh, max_count

@@ -1,0 +1,202 @@
+"""GPU parity tests of the HIP neighbour-list path against the CPU oracle (bit-exact sets / counts).
+
+Everything here goes through the public API -> ctypes -> C ABI -> HIP kernels.  Run with `-m gpu` on an MI355X."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle as O
+from tests import systems as S
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _t(a, dtype=None):
+    return torch.as_tensor(np.ascontiguousarray(a), device=DEV) if dtype is None else torch.as_tensor(np.ascontiguousarray(a), dtype=dtype, device=DEV)
+
+
+def _pairs(nm, num, sh):
+    return O.canonical_pairs(nm.cpu().numpy(), num.cpu().numpy(), sh.cpu().numpy())
+
+
+def _coo_pairs(lst, sh):
+    rows = np.column_stack([lst.cpu().numpy().T, sh.cpu().numpy()]).astype(np.int64)
+    return rows[np.lexsort(rows.T[::-1])] if len(rows) else rows.reshape(0, 5)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("cutoff", [1.0, 4.0, 6.0])
+def test_golden_counts(dtype, cutoff):
+    from nvalchemiops.neighborlist import batch_cell_list, cell_list
+
+    pbc = torch.tensor([True] * 3, device=DEV)
+    _, num, _ = cell_list(_t(S.HOTLPD_POS.astype(dtype)), cutoff, _t(S.HOTLPD_CELL.astype(dtype)), pbc)
+    assert num.cpu().tolist() == S.HOTLPD_COUNTS[cutoff]
+    _, num, _ = cell_list(_t(S.SICU_POS.astype(dtype)), cutoff, _t(S.SICU_CELL.astype(dtype)), pbc)
+    assert num.cpu().tolist() == S.SICU_COUNTS[cutoff]
+    pos = np.concatenate([S.HOTLPD_POS, S.SICU_POS]).astype(dtype)
+    cell = np.stack([S.HOTLPD_CELL, S.SICU_CELL]).astype(dtype)
+    bi = torch.tensor([0] * 9 + [1] * 2, dtype=torch.int32, device=DEV)
+    _, num, _ = batch_cell_list(_t(pos), cutoff, _t(cell), torch.ones((2, 3), dtype=torch.bool, device=DEV), bi)
+    assert num.cpu().tolist() == S.HOTLPD_COUNTS[cutoff] + S.SICU_COUNTS[cutoff]
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("kind", ["cubic", "triclinic", "outside", "mixed_pbc", "no_pbc"])
+def test_cell_list_matches_oracle(dtype, kind):
+    from nvalchemiops.neighborlist import cell_list
+
+    pos, cell = S.random_box(700, 14.0, seed=42, dtype=dtype, triclinic=(kind == "triclinic"), outside=(kind == "outside"))
+    pbc = {"mixed_pbc": [True, False, True], "no_pbc": [False] * 3}.get(kind, [True] * 3)
+    for cutoff, m in ((3.2, 64), (6.5, 320)):
+        onm, onum, osh = O.cell_list(pos, cutoff, cell, pbc, max_neighbors=m)
+        nm, num, sh = cell_list(_t(pos), cutoff, _t(cell), torch.tensor(pbc, device=DEV), max_neighbors=m)
+        assert num.cpu().numpy().tolist() == onum.tolist()
+        assert np.array_equal(_pairs(nm, num, sh), O.canonical_pairs(onm, onum, osh))
+        # padding contract: slots >= num are fill_value (= N) with zero shifts
+        nmc, numc, shc = nm.cpu().numpy(), num.cpu().numpy(), sh.cpu().numpy()
+        mask = np.arange(m)[None, :] >= numc[:, None]
+        assert (nmc[mask] == len(pos)).all() and (shc[mask] == 0).all()
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_batch_matches_oracle_and_single(dtype):
+    from nvalchemiops.neighborlist import batch_cell_list, cell_list
+
+    parts, cells, pbcs, bis = [], [], [], []
+    for s, (n, box, tri, pb) in enumerate([(300, 11.0, False, [True] * 3), (150, 9.0, True, [True, True, False]), (420, 13.0, False, [False] * 3),
+                                           (1, 8.0, False, [True] * 3)]):
+        p, c = S.random_box(n, box, seed=100 + s, dtype=dtype, triclinic=tri)
+        parts.append(p), cells.append(c), pbcs.append(pb), bis.append(np.full(n, s, np.int32))
+    pos, cell, pbc, bi = np.concatenate(parts), np.stack(cells), np.array(pbcs), np.concatenate(bis)
+    onm, onum, osh = O.cell_list(pos, 4.0, cell, pbc, batch_idx=bi, max_neighbors=128)
+    nm, num, sh = batch_cell_list(_t(pos), 4.0, _t(cell), _t(pbc), _t(bi), max_neighbors=128)
+    assert np.array_equal(num.cpu().numpy(), onum)
+    assert np.array_equal(_pairs(nm, num, sh), O.canonical_pairs(onm, onum, osh))
+    off = 0
+    for p, c, pb in zip(parts, cells, pbcs):  # batch == per-system
+        nm1, num1, sh1 = cell_list(_t(p), 4.0, _t(c), torch.tensor(pb, device=DEV), max_neighbors=128)
+        assert np.array_equal(num1.cpu().numpy(), onum[off:off + len(p)])
+        off += len(p)
+
+
+@pytest.mark.parametrize("direct", [True, False])
+def test_coo_output(direct):
+    from nvalchemiops.neighborlist import cell_list
+
+    pos, cell = S.random_box(500, 12.0, seed=9, dtype=np.float32, outside=True)
+    pbc = torch.tensor([True] * 3, device=DEV)
+    onm, onum, osh = O.cell_list(pos, 4.5, cell, [True] * 3, max_neighbors=160)
+    olst, optr, olsh = O.matrix_to_coo(onm, onum, osh, fill_value=500)
+    kw = {} if direct else dict(neighbor_matrix=torch.empty((500, 160), dtype=torch.int32, device=DEV))
+    lst, nptr, lsh = cell_list(_t(pos), 4.5, _t(cell), pbc, max_neighbors=160, return_neighbor_list=True, **kw)
+    assert lst.dtype == torch.int32 and lst.shape == (2, int(onum.sum())) and lsh.shape == (int(onum.sum()), 3)
+    assert np.array_equal(nptr.cpu().numpy(), optr)
+    assert np.array_equal(_coo_pairs(lst, lsh), _coo_pairs(torch.as_tensor(olst), torch.as_tensor(olsh)))
+    src = lst[0].cpu().numpy()
+    assert (np.diff(src) >= 0).all()  # sorted by source atom (docs/userguide/components/neighborlist.md:133-137)
+
+
+def test_half_fill_and_overflow():
+    from nvalchemiops.neighborlist import NeighborOverflowError, cell_list
+
+    pos, cell = S.random_box(400, 10.0, seed=3, dtype=np.float64)
+    pbc = torch.tensor([True] * 3, device=DEV)
+    nm, num, sh = cell_list(_t(pos), 3.5, _t(cell), pbc, max_neighbors=96)
+    hm, hnum, hsh = cell_list(_t(pos), 3.5, _t(cell), pbc, max_neighbors=96, half_fill=True)
+    full, half = _pairs(nm, num, sh), _pairs(hm, hnum, hsh)
+    assert len(half) * 2 == len(full)
+    mirrored = np.column_stack([half[:, 1], half[:, 0], -half[:, 2:]])
+    both = np.concatenate([half, mirrored])
+    assert np.array_equal(both[np.lexsort(both.T[::-1])], full)
+    # overflow: counts keep counting past M, the matrix is truncated, COO conversion raises
+    sm, snum, ssh = cell_list(_t(pos), 3.5, _t(cell), pbc, max_neighbors=8)
+    assert np.array_equal(snum.cpu().numpy(), num.cpu().numpy()) and int(snum.max()) > 8
+    with pytest.raises(NeighborOverflowError):
+        cell_list(_t(pos), 3.5, _t(cell), pbc, max_neighbors=8, return_neighbor_list=True)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_naive_matches_oracle(dtype):
+    from nvalchemiops.neighborlist import naive_neighbor_list, neighbor_list
+
+    # config 1 of BASELINE.json: 1k atoms, non-periodic, naive
+    mol, _, side = S.molecule(1000, seed=2000, dtype=dtype)
+    onm, onum = O.naive(mol, 5.0, max_neighbors=64)
+    nm, num = neighbor_list(_t(mol), 5.0, method="naive", max_neighbors=64)
+    assert np.array_equal(num.cpu().numpy(), onum)
+    assert np.array_equal(np.sort(nm.cpu().numpy(), 1), np.sort(onm, 1))
+    pos, cell = S.random_box(300, 9.0, seed=4, dtype=dtype, triclinic=True)
+    onm, onum, osh = O.naive(pos, 3.3, cell, [True, True, False], max_neighbors=64)
+    nm, num, sh = naive_neighbor_list(_t(pos), 3.3, cell=_t(cell), pbc=torch.tensor([True, True, False], device=DEV), max_neighbors=64)
+    assert np.array_equal(_pairs(nm, num, sh), O.canonical_pairs(onm, onum, osh))
+
+
+def test_query_api_and_preallocated_buffers():
+    from nvalchemiops.neighborlist import (allocate_cell_list, build_cell_list, cell_list, estimate_cell_list_sizes, query_cell_list)
+
+    pos, cell = S.random_box(600, 12.0, seed=11, dtype=np.float32)
+    tp, tc, pbc = _t(pos), _t(cell), torch.tensor([True] * 3, device=DEV)
+    ncell, radius = estimate_cell_list_sizes(tc, pbc, 3.0)
+    _, _, _, ocpd, orad = O.cell_list(pos, 3.0, cell, [True] * 3, max_neighbors=64, return_grid=True)
+    assert ncell == int(np.prod(ocpd[0])) and radius.cpu().tolist() == orad[0].tolist()
+    cache = allocate_cell_list(600, ncell, radius, tp.device)
+    build_cell_list(tp, 3.0, tc, pbc, *cache)
+    assert cache[0].cpu().tolist() == ocpd[0].tolist()
+    assert int(cache[4].sum()) == 600 and sorted(cache[6].cpu().tolist()) == list(range(600))
+    nm = torch.full((600, 64), 600, dtype=torch.int32, device=DEV)
+    sh = torch.zeros((600, 64, 3), dtype=torch.int32, device=DEV)
+    num = torch.zeros(600, dtype=torch.int32, device=DEV)
+    query_cell_list(tp, 3.0, tc, pbc, *cache, nm, sh, num)
+    onm, onum, osh = O.cell_list(pos, 3.0, cell, [True] * 3, max_neighbors=64)
+    assert np.array_equal(_pairs(nm, num, sh), O.canonical_pairs(onm, onum, osh))
+    a, b, c = cell_list(tp, 3.0, tc, pbc, neighbor_matrix=nm, neighbor_matrix_shifts=sh, num_neighbors=num)
+    assert a.data_ptr() == nm.data_ptr() and b.data_ptr() == num.data_ptr()
+
+
+def test_empty_and_tiny_inputs():
+    from nvalchemiops.neighborlist import cell_list
+
+    pbc = torch.tensor([True] * 3, device=DEV)
+    cell = torch.eye(3, device=DEV) * 10
+    nm, num, sh = cell_list(torch.zeros((0, 3), device=DEV), 2.0, cell, pbc)
+    assert nm.shape == (0, 0) and num.shape == (0,) and sh.shape == (0, 0, 3)
+    nm, num, sh = cell_list(torch.tensor([[1.0, 1.0, 1.0]], device=DEV), 2.0, cell, pbc, max_neighbors=8)
+    assert num.cpu().tolist() == [0] and (nm.cpu() == 1).all()
+    two = torch.tensor([[0.5, 5.0, 5.0], [9.5, 5.0, 5.0]], device=DEV)
+    nm, num, sh = cell_list(two, 2.0, cell, pbc, max_neighbors=8)
+    assert num.cpu().tolist() == [1, 1] and sh[0, 0].cpu().tolist() == [-1, 0, 0] and sh[1, 0].cpu().tolist() == [1, 0, 0]
+
+
+def test_fcc_20k_matches_oracle():
+    from nvalchemiops.neighborlist import cell_list
+
+    pos, cell, _, _ = S.fcc_box(20000, dtype=np.float32)
+    onm, onum, osh = O.cell_list(pos, 5.0, cell, [True] * 3, max_neighbors=64)
+    nm, num, sh = cell_list(_t(pos), 5.0, _t(cell), torch.tensor([True] * 3, device=DEV), max_neighbors=64)
+    assert np.array_equal(num.cpu().numpy(), onum)
+    assert np.array_equal(_pairs(nm, num, sh), O.canonical_pairs(onm, onum, osh))
+
+
+def test_full_size_properties_100k():
+    """BASELINE size (100k-atom periodic box): size-independent properties -- symmetry of the directed pair set under
+    (i,j,S)->(j,i,-S), every stored distance < cutoff, the half list is exactly half, large cutoff (k>1 binning) agrees
+    with the small-cutoff list restricted by distance."""
+    from nvalchemiops.neighborlist import cell_list
+
+    pos, cell, _, _ = S.fcc_box(100000, dtype=np.float32)
+    tp, tc, pbc = _t(pos), _t(cell), torch.tensor([True] * 3, device=DEV)
+    lst, nptr, sh = cell_list(tp, 9.0, tc, pbc, return_neighbor_list=True)
+    n = 100000
+    assert int(nptr[-1]) == lst.shape[1]
+    key = (lst[0].long() * n + lst[1].long()) * 27 + ((sh[:, 0] + 1) * 9 + (sh[:, 1] + 1) * 3 + (sh[:, 2] + 1)).long()
+    mkey = (lst[1].long() * n + lst[0].long()) * 27 + ((-sh[:, 0] + 1) * 9 + (-sh[:, 1] + 1) * 3 + (-sh[:, 2] + 1)).long()
+    assert torch.equal(torch.sort(key).values, torch.sort(mkey).values)
+    assert torch.unique(key).numel() == key.numel()
+    d = tp[lst[1].long()] - tp[lst[0].long()] + sh.to(tp.dtype) @ tc
+    assert float((d * d).sum(1).max()) < 81.0
+    hl, hp, hs = cell_list(tp, 9.0, tc, pbc, return_neighbor_list=True, half_fill=True)
+    assert hl.shape[1] * 2 == lst.shape[1]
+    l5, p5, s5 = cell_list(tp, 5.0, tc, pbc, return_neighbor_list=True)
+    assert int(((d * d).sum(1) < 25.0).sum()) == l5.shape[1]
