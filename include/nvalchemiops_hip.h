@@ -112,7 +112,7 @@ typedef struct {
   float a1, a2, s6, s8, k1, k3, s5_on, s5_off;
 } mi_d3_params;
 
-size_t mi_d3_workspace_bytes(int n_atoms, int n_systems);
+size_t mi_d3_workspace_bytes(int n_atoms, int n_systems, int nz);
 
 int mi_d3(const void* positions, const int32_t* numbers, int n_atoms, int dtype,
           const int32_t* idx_j,        /* matrix [n_atoms,max_neighbors] or CSR values [n_pairs]      */

@@ -1,0 +1,401 @@
+// d3.hip -- DFT-D3(BJ) two-body dispersion: energies, forces, coordination numbers, virial.  gfx950 / wave64.
+//
+// Same arithmetic as the reference kernels (interactions/dispersion/dftd3.py): `_cn_kernel_nm/_nl` (:833,1321),
+// `_direct_forces_and_dE_dCN_kernel_nm/_nl` (:944,1403) with `_c6ab_interpolate` (:427), `_bj_damping` (:648),
+// `_dispersion_energy_force` (:690), `_s5_switch` (:341), and `_cn_forces_contrib_kernel_nm/_nl` (:1134,1535):
+// fp32 pair math, fp64 accumulation of E / F / virial, thresholds (c6 == 0 skip, exp_arg - max < -12 skip,
+// w <= 1e-12, c6 < 1e-12, r < 1e-12) kept verbatim.  Different execution shape:
+//   * ONE WAVE64 PER ATOM, lanes stride the atom's row / CSR range (coalesced 256 B index reads) instead of one
+//     thread looping over a row; per-lane fp64 partial sums are combined with cross-lane shuffles at the end.
+//   * pass 0 of the reference (materialised cartesian_shifts, 12 B per slot written then read 3x) is gone:
+//     S.cell is evaluated in registers in the positions dtype (`_unit_shift_to_cartesian`, :734).
+//   * {c6, cn_ref_i, cn_ref_j^T} are re-packed once per call into one float4 per (Zi,Zj,p,q): 25 x 16 B loads per
+//     pair per loop instead of 75 x 4 B gathers.
+//   * per-system energy / virial: per-atom values + wave-aggregated atomics (one atomic per 64 atoms) instead of one
+//     atomic per atom on B hot addresses.
+#include "common.h"
+
+namespace {
+
+struct D3Dev {
+  const float* rcov;
+  const float* r4r2;
+  const float4* tab;  // [nz,nz,25] {c6ab[zi,zj,p,q], cn_ref[zi,zj,p,q], cn_ref[zj,zi,q,p], 0}
+  int nz;
+  float a1, a2, s6, s8, k1, k3, s5_on, s5_off, inv_w;
+};
+
+__global__ void d3_pack_tables_kernel(const float* __restrict__ c6ab, const float* __restrict__ cnref, int nz, float4* __restrict__ tab) {
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long total = (long long)nz * nz * 25;
+  if (t >= total) return;
+  const int pq = (int)(t % 25), p = pq / 5, q = pq % 5;
+  const long long zz = t / 25;
+  const int zj = (int)(zz % nz), zi = (int)(zz / nz);
+  const float c6 = c6ab[t];
+  const float ci = cnref[t];
+  const float cj = cnref[(((long long)zj * nz + zi) * 5 + q) * 5 + p];
+  tab[t] = make_float4(c6, ci, cj, 0.0f);
+}
+
+template <class T> struct PairGeom { float r, rinv, rx, ry, rz; bool ok; };
+
+// `_compute_distance_vector_pbc` (dftd3.py:551-604): native-dtype difference (+ shift), cast to fp32, length, r<1e-12 skip
+template <class T>
+__device__ __forceinline__ PairGeom<T> d3_geom(const T* __restrict__ pos, T pix, T piy, T piz, int j, const int* __restrict__ ush, long long e,
+                                                const T* __restrict__ cm, bool periodic) {
+  PairGeom<T> g;
+  const T pjx = pos[3 * (size_t)j], pjy = pos[3 * (size_t)j + 1], pjz = pos[3 * (size_t)j + 2];
+  T dx = pjx - pix, dy = pjy - piy, dz = pjz - piz;
+  if (periodic) {
+    const T fs[3] = {(T)ush[3 * e], (T)ush[3 * e + 1], (T)ush[3 * e + 2]};
+    T cart[3];
+    rowvec_mat3(fs, cm, cart);
+    dx = dx + cart[0]; dy = dy + cart[1]; dz = dz + cart[2];
+  }
+  g.rx = (float)dx; g.ry = (float)dy; g.rz = (float)dz;
+  g.r = sqrtf(g.rx * g.rx + g.ry * g.ry + g.rz * g.rz);
+  g.ok = !(g.r < 1e-12f);
+  g.rinv = g.ok ? 1.0f / g.r : 0.0f;
+  return g;
+}
+
+// `_cn_counting` (dftd3.py:608-645)
+__device__ __forceinline__ float d3_cn_count(float rinv, float rci, float rcj, float k1, float* dcn) {
+  const float rr = (rci + rcj) * rinv;
+  const float f = 1.0f / (1.0f + expf(-k1 * (rr - 1.0f)));
+  if (dcn) *dcn = -f * (1.0f - f) * k1 * rr * rinv;
+  return f;
+}
+
+template <class T, bool CSR>
+__device__ __forceinline__ void d3_row(int i, int M, const int* __restrict__ nptr, long long& beg, long long& end) {
+  if (CSR) { beg = nptr[i]; end = nptr[i + 1]; }
+  else { beg = (long long)i * M; end = beg + M; }
+}
+
+// ---- pass 1: coordination numbers ------------------------------------------------------------------
+template <class T, bool CSR>
+__global__ __launch_bounds__(256) void d3_cn_kernel(const T* __restrict__ pos, const int* __restrict__ numbers, int N, const int* __restrict__ idx,
+                                                    const int* __restrict__ ush, const int* __restrict__ nptr, int M, int fill_value,
+                                                    const T* __restrict__ cell, const int* __restrict__ batch_idx, D3Dev P,
+                                                    float* __restrict__ cn) {
+  const int lane = threadIdx.x & (MI_WAVE - 1);
+  const int i = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x / MI_WAVE) + threadIdx.x / MI_WAVE);
+  if (i >= N) return;
+  const int zi = numbers[i];
+  if (zi == 0) return;
+  const bool periodic = (cell != nullptr) && (ush != nullptr);
+  T cm[9];
+  if (periodic) { const T* c = cell + 9 * (size_t)(batch_idx ? batch_idx[i] : 0); for (int k = 0; k < 9; ++k) cm[k] = c[k]; }
+  const T pix = pos[3 * (size_t)i], piy = pos[3 * (size_t)i + 1], piz = pos[3 * (size_t)i + 2];
+  const float rci = P.rcov[zi];
+  long long beg, end;
+  d3_row<T, CSR>(i, M, nptr, beg, end);
+  float acc = 0.0f;
+  for (long long e = beg + lane; e < end; e += MI_WAVE) {
+    const int j = idx[e];
+    if (!CSR && j >= fill_value) continue;
+    const int zj = numbers[j];
+    if (zj == 0) continue;
+    const PairGeom<T> g = d3_geom<T>(pos, pix, piy, piz, j, ush, e, cm, periodic);
+    if (!g.ok) continue;
+    acc += d3_cn_count(g.rinv, rci, P.rcov[zj], P.k1, nullptr);
+  }
+  acc = wave_sum(acc);
+  if (lane == 0) cn[i] = acc;
+}
+
+// `_s5_switch` (dftd3.py:341-423)
+__device__ __forceinline__ void d3_s5(float r, float on, float off, float inv_w, float& sw, float& dsw) {
+  if (off <= on || r <= on) { sw = 1.0f; dsw = 0.0f; return; }
+  if (r >= off) { sw = 0.0f; dsw = 0.0f; return; }
+  const float t = (r - on) * inv_w, t2 = t * t, t3 = t2 * t, t4 = t3 * t, t5 = t4 * t;
+  sw = 1.0f - (10.0f * t3 - 15.0f * t4 + 6.0f * t5);
+  dsw = (-30.0f * t2 + 60.0f * t3 - 30.0f * t4) * inv_w;
+}
+
+// `_c6ab_interpolate` (dftd3.py:427-547) on the packed table
+__device__ __forceinline__ void d3_c6(float cn_i, float cn_j, const float4* __restrict__ t25, float k3, float& c6, float& dci) {
+  float mx = -1e20f;
+#pragma unroll 5
+  for (int t = 0; t < 25; ++t) {
+    const float4 v = t25[t];
+    if (v.x == 0.0f) continue;
+    const float di = cn_i - v.y, dj = cn_j - v.z;
+    const float a = k3 * (di * di + dj * dj);
+    mx = a > mx ? a : mx;
+  }
+  float w = 0.0f, z = 0.0f, wdi = 0.0f, zdi = 0.0f;
+#pragma unroll 5
+  for (int t = 0; t < 25; ++t) {
+    const float4 v = t25[t];
+    if (v.x == 0.0f) continue;
+    const float di = cn_i - v.y, dj = cn_j - v.z;
+    const float a = k3 * (di * di + dj * dj) - mx;
+    if (a < -12.0f) continue;
+    const float L = expf(a);
+    w += L;
+    z += v.x * L;
+    wdi += L * di;
+    zdi += v.x * L * di;
+  }
+  if (w > 1e-12f) {
+    const float wi = 1.0f / w;
+    c6 = z * wi;
+    const float si = zdi - c6 * wdi;
+    dci = ((2.0f * k3) * wi) * si;
+  } else {
+    c6 = 0.0f; dci = 0.0f;
+  }
+}
+
+// ---- pass 2: energy, direct force, dE/dCN ------------------------------------------------------------
+template <class T, bool CSR>
+__global__ __launch_bounds__(256) void d3_energy_kernel(const T* __restrict__ pos, const int* __restrict__ numbers, int N, const int* __restrict__ idx,
+                                                        const int* __restrict__ ush, const int* __restrict__ nptr, int M, int fill_value,
+                                                        const T* __restrict__ cell, const int* __restrict__ batch_idx, D3Dev P,
+                                                        const float* __restrict__ cn, int want_virial, float* __restrict__ dEdCN,
+                                                        float* __restrict__ forces, float* __restrict__ e_atom, float* __restrict__ v_atom) {
+  const int lane = threadIdx.x & (MI_WAVE - 1);
+  const int i = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x / MI_WAVE) + threadIdx.x / MI_WAVE);
+  if (i >= N) return;
+  const int zi = numbers[i];
+  if (zi == 0) return;
+  const bool periodic = (cell != nullptr) && (ush != nullptr);
+  T cm[9];
+  if (periodic) { const T* c = cell + 9 * (size_t)(batch_idx ? batch_idx[i] : 0); for (int k = 0; k < 9; ++k) cm[k] = c[k]; }
+  const T pix = pos[3 * (size_t)i], piy = pos[3 * (size_t)i + 1], piz = pos[3 * (size_t)i + 2];
+  const float cn_i = cn[i], r4r2_i = P.r4r2[zi];
+  const float4* __restrict__ tab_i = P.tab + (size_t)zi * P.nz * 25;
+  long long beg, end;
+  d3_row<T, CSR>(i, M, nptr, beg, end);
+  double Fx = 0, Fy = 0, Fz = 0, E = 0;
+  double V[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  float dacc = 0.0f;
+  for (long long e = beg + lane; e < end; e += MI_WAVE) {
+    const int j = idx[e];
+    if (!CSR && j >= fill_value) continue;
+    const int zj = numbers[j];
+    if (zj == 0) continue;
+    const PairGeom<T> g = d3_geom<T>(pos, pix, piy, piz, j, ush, e, cm, periodic);
+    if (!g.ok) continue;
+    float c6, dci;
+    d3_c6(cn_i, cn[j], tab_i + (size_t)zj * 25, P.k3, c6, dci);
+    if (c6 < 1e-12f) continue;
+    // `_bj_damping` (dftd3.py:648-687)
+    const float r = g.r;
+    const float q = 3.0f * r4r2_i * P.r4r2[zj];
+    const float r0 = P.a1 * sqrtf(q) + P.a2;
+    const float r2 = r * r, r4 = r2 * r2, r6 = r4 * r2, r8 = r4 * r4;
+    const float r02 = r0 * r0, r04 = r02 * r02, r06 = r04 * r02, r08 = r04 * r04;
+    const float i6 = 1.0f / (r6 + r06), i8 = 1.0f / (r8 + r08);
+    const float damp = P.s6 * i6 + P.s8 * q * i8;
+    // `_dispersion_energy_force` (dftd3.py:690-731)
+    const float eij = -c6 * damp;
+    const float r5 = r4 * r, r7 = r6 * r;
+    const float d6 = -6.0f * P.s6 * r5 * i6 * i6;
+    const float d8 = -8.0f * P.s8 * q * r7 * i8 * i8;
+    const float dEdr = -c6 * (d6 + d8);
+    float sw, dsw;
+    d3_s5(r, P.s5_on, P.s5_off, P.inv_w, sw, dsw);
+    const float esw = eij * sw;
+    const float dEsw = sw * dEdr + eij * dsw;
+    const float fx = dEsw * (g.rx * g.rinv), fy = dEsw * (g.ry * g.rinv), fz = dEsw * (g.rz * g.rinv);
+    Fx += (double)fx; Fy += (double)fy; Fz += (double)fz;
+    E += (double)esw;
+    dacc += -damp * dci;
+    if (want_virial) {
+      V[0] += (double)(fx * g.rx); V[1] += (double)(fx * g.ry); V[2] += (double)(fx * g.rz);
+      V[3] += (double)(fy * g.rx); V[4] += (double)(fy * g.ry); V[5] += (double)(fy * g.rz);
+      V[6] += (double)(fz * g.rx); V[7] += (double)(fz * g.ry); V[8] += (double)(fz * g.rz);
+    }
+  }
+  Fx = wave_sum(Fx); Fy = wave_sum(Fy); Fz = wave_sum(Fz); E = wave_sum(E);
+  dacc = wave_sum(dacc);
+  if (want_virial) {
+#pragma unroll
+    for (int k = 0; k < 9; ++k) V[k] = wave_sum(V[k]);
+  }
+  if (lane == 0) {
+    forces[3 * (size_t)i] = (float)Fx; forces[3 * (size_t)i + 1] = (float)Fy; forces[3 * (size_t)i + 2] = (float)Fz;
+    dEdCN[i] = dacc;
+    e_atom[i] = 0.5f * (float)E;
+  }
+  if (want_virial && lane < 9) {
+    double v = V[0];
+#pragma unroll
+    for (int k = 1; k < 9; ++k) v = lane == k ? V[k] : v;
+    v_atom[9 * (size_t)i + lane] = -0.5f * (float)v;
+  }
+}
+
+// ---- pass 3: chain-rule force through the coordination numbers ---------------------------------------
+template <class T, bool CSR>
+__global__ __launch_bounds__(256) void d3_chain_kernel(const T* __restrict__ pos, const int* __restrict__ numbers, int N, const int* __restrict__ idx,
+                                                       const int* __restrict__ ush, const int* __restrict__ nptr, int M, int fill_value,
+                                                       const T* __restrict__ cell, const int* __restrict__ batch_idx, D3Dev P,
+                                                       const float* __restrict__ dEdCN, int want_virial, float* __restrict__ forces,
+                                                       float* __restrict__ v_atom) {
+  const int lane = threadIdx.x & (MI_WAVE - 1);
+  const int i = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x / MI_WAVE) + threadIdx.x / MI_WAVE);
+  if (i >= N) return;
+  const int zi = numbers[i];
+  if (zi == 0) return;
+  const bool periodic = (cell != nullptr) && (ush != nullptr);
+  T cm[9];
+  if (periodic) { const T* c = cell + 9 * (size_t)(batch_idx ? batch_idx[i] : 0); for (int k = 0; k < 9; ++k) cm[k] = c[k]; }
+  const T pix = pos[3 * (size_t)i], piy = pos[3 * (size_t)i + 1], piz = pos[3 * (size_t)i + 2];
+  const float rci = P.rcov[zi], di = dEdCN[i];
+  long long beg, end;
+  d3_row<T, CSR>(i, M, nptr, beg, end);
+  double Fx = 0, Fy = 0, Fz = 0;
+  double V[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  for (long long e = beg + lane; e < end; e += MI_WAVE) {
+    const int j = idx[e];
+    if (!CSR && j >= fill_value) continue;
+    const int zj = numbers[j];
+    if (zj == 0) continue;
+    const PairGeom<T> g = d3_geom<T>(pos, pix, piy, piz, j, ush, e, cm, periodic);
+    if (!g.ok) continue;
+    float dcn;
+    d3_cn_count(g.rinv, rci, P.rcov[zj], P.k1, &dcn);
+    const float dEdr = (di + dEdCN[j]) * dcn;
+    const float fx = dEdr * (g.rx * g.rinv), fy = dEdr * (g.ry * g.rinv), fz = dEdr * (g.rz * g.rinv);
+    Fx += (double)fx; Fy += (double)fy; Fz += (double)fz;
+    if (want_virial) {
+      V[0] += (double)(fx * g.rx); V[1] += (double)(fx * g.ry); V[2] += (double)(fx * g.rz);
+      V[3] += (double)(fy * g.rx); V[4] += (double)(fy * g.ry); V[5] += (double)(fy * g.rz);
+      V[6] += (double)(fz * g.rx); V[7] += (double)(fz * g.ry); V[8] += (double)(fz * g.rz);
+    }
+  }
+  Fx = wave_sum(Fx); Fy = wave_sum(Fy); Fz = wave_sum(Fz);
+  if (want_virial) {
+#pragma unroll
+    for (int k = 0; k < 9; ++k) V[k] = wave_sum(V[k]);
+  }
+  if (lane == 0) {
+    forces[3 * (size_t)i] = forces[3 * (size_t)i] + (float)Fx;
+    forces[3 * (size_t)i + 1] = forces[3 * (size_t)i + 1] + (float)Fy;
+    forces[3 * (size_t)i + 2] = forces[3 * (size_t)i + 2] + (float)Fz;
+  }
+  if (want_virial && lane < 9) {
+    double v = V[0];
+#pragma unroll
+    for (int k = 1; k < 9; ++k) v = lane == k ? V[k] : v;
+    v_atom[9 * (size_t)i + lane] += -0.5f * (float)v;
+  }
+}
+
+// per-system reduction of per-atom energies / virials: one atomic per wave when the 64 atoms share a system
+__global__ void d3_reduce_kernel(const float* __restrict__ e_atom, const float* __restrict__ v_atom, const int* __restrict__ batch_idx, int N,
+                                 int want_virial, float* __restrict__ energy, float* __restrict__ virial) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int lane = threadIdx.x & (MI_WAVE - 1);
+  const bool in = i < N;
+  const int s = in ? (batch_idx ? batch_idx[i] : 0) : -1;
+  const int s0 = __shfl(s, 0, MI_WAVE);
+  const bool uniform = __all(!in || s == s0);
+  float e = in ? e_atom[i] : 0.0f;
+  if (uniform) {
+    e = wave_sum(e);
+    if (lane == 0 && s0 >= 0) atomicAdd(&energy[s0], e);
+    if (want_virial) {
+      for (int k = 0; k < 9; ++k) {
+        float v = in ? v_atom[9 * (size_t)i + k] : 0.0f;
+        v = wave_sum(v);
+        if (lane == 0 && s0 >= 0) atomicAdd(&virial[9 * (size_t)s0 + k], v);
+      }
+    }
+  } else if (in) {
+    atomicAdd(&energy[s], e);
+    if (want_virial) for (int k = 0; k < 9; ++k) atomicAdd(&virial[9 * (size_t)s + k], v_atom[9 * (size_t)i + k]);
+  }
+}
+
+struct D3Layout { size_t dEdCN, e_atom, v_atom, tab, total; };
+D3Layout d3_layout(int N, int nz) {
+  D3Layout L;
+  size_t o = 0;
+  auto take = [&](size_t b) { size_t at = o; o += mi_align(b); return at; };
+  L.dEdCN = take(sizeof(float) * (size_t)N);
+  L.e_atom = take(sizeof(float) * (size_t)N);
+  L.v_atom = take(sizeof(float) * 9 * (size_t)N);
+  L.tab = take(sizeof(float4) * (size_t)nz * nz * 25);
+  L.total = o;
+  return L;
+}
+
+template <class T, bool CSR>
+int d3_impl(const T* pos, const int* numbers, int N, const int* idx, const int* ush, const int* nptr, int M, int fill_value, const T* cell,
+            const int* batch_idx, int B, const mi_d3_params* hp, int want_virial, float* energy, float* forces, float* cn, float* virial,
+            char* ws, const D3Layout& L, hipStream_t st) {
+  float* dEdCN = reinterpret_cast<float*>(ws + L.dEdCN);
+  float* e_atom = reinterpret_cast<float*>(ws + L.e_atom);
+  float* v_atom = reinterpret_cast<float*>(ws + L.v_atom);
+  float4* tab = reinterpret_cast<float4*>(ws + L.tab);
+  D3Dev P;
+  P.rcov = hp->rcov; P.r4r2 = hp->r4r2; P.tab = tab; P.nz = hp->nz;
+  P.a1 = hp->a1; P.a2 = hp->a2; P.s6 = hp->s6; P.s8 = hp->s8; P.k1 = hp->k1; P.k3 = hp->k3; P.s5_on = hp->s5_on; P.s5_off = hp->s5_off;
+  // inv_w in double on the host, then cast (dftd3.py:1983-1986)
+  P.inv_w = (hp->s5_off > hp->s5_on) ? (float)(1.0 / ((double)hp->s5_off - (double)hp->s5_on)) : 0.0f;
+  // outputs are zeroed like the reference wrapper does (dftd3.py:1933-1936); atoms with Z == 0 keep zeros
+  MI_HIP_CHECK(hipMemsetAsync(energy, 0, sizeof(float) * (size_t)B, st));
+  MI_HIP_CHECK(hipMemsetAsync(forces, 0, sizeof(float) * 3 * (size_t)N, st));
+  MI_HIP_CHECK(hipMemsetAsync(cn, 0, sizeof(float) * (size_t)N, st));
+  MI_HIP_CHECK(hipMemsetAsync(dEdCN, 0, sizeof(float) * (size_t)N, st));
+  MI_HIP_CHECK(hipMemsetAsync(e_atom, 0, sizeof(float) * (size_t)N, st));
+  if (want_virial) {
+    MI_HIP_CHECK(hipMemsetAsync(virial, 0, sizeof(float) * 9 * (size_t)B, st));
+    MI_HIP_CHECK(hipMemsetAsync(v_atom, 0, sizeof(float) * 9 * (size_t)N, st));
+  }
+  const long long nt = (long long)hp->nz * hp->nz * 25;
+  d3_pack_tables_kernel<<<mi_blocks(nt, 256), 256, 0, st>>>(hp->c6ab, hp->cn_ref, hp->nz, tab);
+  MI_LAUNCH_CHECK();
+  const int blocks = mi_blocks(N, 4);
+  d3_cn_kernel<T, CSR><<<blocks, 256, 0, st>>>(pos, numbers, N, idx, ush, nptr, M, fill_value, cell, batch_idx, P, cn);
+  MI_LAUNCH_CHECK();
+  d3_energy_kernel<T, CSR><<<blocks, 256, 0, st>>>(pos, numbers, N, idx, ush, nptr, M, fill_value, cell, batch_idx, P, cn, want_virial, dEdCN,
+                                                   forces, e_atom, v_atom);
+  MI_LAUNCH_CHECK();
+  d3_chain_kernel<T, CSR><<<blocks, 256, 0, st>>>(pos, numbers, N, idx, ush, nptr, M, fill_value, cell, batch_idx, P, dEdCN, want_virial, forces,
+                                                  v_atom);
+  MI_LAUNCH_CHECK();
+  d3_reduce_kernel<<<mi_blocks(N, 256), 256, 0, st>>>(e_atom, v_atom, batch_idx, N, want_virial, energy, virial);
+  MI_LAUNCH_CHECK();
+  return MI_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t mi_d3_workspace_bytes(int n_atoms, int n_systems, int nz) {
+  (void)n_systems;
+  if (n_atoms < 0 || nz < 1) return 0;
+  return d3_layout(n_atoms, nz).total;
+}
+
+int mi_d3(const void* positions, const int32_t* numbers, int n_atoms, int dtype, const int32_t* idx_j, const int32_t* unit_shifts,
+          const int32_t* neighbor_ptr, int max_neighbors, int fill_value, const void* cell, const int32_t* batch_idx, int n_systems,
+          const mi_d3_params* params, int compute_virial, float* energy, float* forces, float* coord_num, float* virial, void* workspace,
+          size_t workspace_bytes, void* stream) {
+  MI_REQUIRE(dtype == MI_F32 || dtype == MI_F64, "dtype");
+  MI_REQUIRE(n_atoms >= 0 && n_systems >= 1, "sizes");
+  if (n_atoms == 0) return MI_OK;
+  MI_REQUIRE(positions && numbers && idx_j && params && energy && forces && coord_num && workspace, "null pointer");
+  MI_REQUIRE(params->rcov && params->r4r2 && params->c6ab && params->cn_ref && params->nz >= 2, "D3 parameter tables");
+  MI_REQUIRE(!compute_virial || virial, "virial output");
+  D3Layout L = d3_layout(n_atoms, params->nz);
+  if (workspace_bytes < L.total) { mi_set_error("workspace too small: %zu < %zu", workspace_bytes, L.total); return MI_EWORKSPACE; }
+  hipStream_t st = (hipStream_t)stream;
+  const bool csr = neighbor_ptr != nullptr;
+#define MI_D3_CALL(T_, CSR_)                                                                                                              \
+  return d3_impl<T_, CSR_>((const T_*)positions, numbers, n_atoms, idx_j, unit_shifts, neighbor_ptr, max_neighbors, fill_value, (const T_*)cell, \
+                           batch_idx, n_systems, params, compute_virial, energy, forces, coord_num, virial, (char*)workspace, L, st)
+  if (dtype == MI_F32) { if (csr) MI_D3_CALL(float, true); else MI_D3_CALL(float, false); }
+  else { if (csr) MI_D3_CALL(double, true); else MI_D3_CALL(double, false); }
+#undef MI_D3_CALL
+}
+
+}  // extern "C"

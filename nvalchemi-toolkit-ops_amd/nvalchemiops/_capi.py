@@ -43,7 +43,7 @@ def lib() -> ctypes.CDLL:
         L.mi_nl_workspace_bytes.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int]
         if hasattr(L, "mi_d3_workspace_bytes"):
             L.mi_d3_workspace_bytes.restype = ctypes.c_size_t
-            L.mi_d3_workspace_bytes.argtypes = [ctypes.c_int, ctypes.c_int]
+            L.mi_d3_workspace_bytes.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int]
         _LIB = L
     return _LIB
 

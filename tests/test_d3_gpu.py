@@ -1,0 +1,194 @@
+"""GPU parity of the HIP DFT-D3(BJ) path against the CPU oracle and the reference's golden vectors.
+
+Tolerances (fp32 pair math, fp64 accumulation on both sides; only the summation order differs):
+  energy  |dE| <= 1e-6 Ha + 2e-6 |E|     forces  <= 1e-6 + 1e-5 |F|     CN  rtol 2e-6     virial rtol 1e-5
+(reference's own CPU-vs-GPU tolerance: rtol = atol = 1e-6, test/interactions/dispersion/test_dftd3.py:477-489)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle as O
+from tests import systems as S
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+FP = dict(a1=0.4, a2=4.0, s8=0.8, k1=16.0, k3=-4.0, s6=1.0)
+
+
+def _t(a):
+    return torch.as_tensor(np.ascontiguousarray(a), device=DEV)
+
+
+def _params(zmax=17, seed=None):
+    from nvalchemiops.interactions.dispersion import D3Parameters
+
+    t = O.d3_test_tables(zmax, seed)
+    return t, D3Parameters(rcov=_t(t["rcov"]), r4r2=_t(t["r4r2"]), c6ab=_t(t["c6ab"]), cn_ref=_t(t["cn_ref"]))
+
+
+def _close(got, ref, rtol, atol, what):
+    got = got.detach().cpu().numpy() if isinstance(got, torch.Tensor) else got
+    err = np.abs(got - ref)
+    bound = atol + rtol * np.abs(ref)
+    assert (err <= bound).all(), f"{what}: max err {err.max():.3e} (bound {bound.flat[err.argmax()]:.3e})"
+
+
+def _check(out, ref, virial=False):
+    _close(out[0], ref[0], 2e-6, 1e-6, "energy")
+    _close(out[1], ref[1], 1e-5, 1e-6, "forces")
+    _close(out[2], ref[2], 2e-6, 1e-7, "coord_num")
+    if virial:
+        _close(out[3], ref[3], 1e-5, 2e-6, "virial")
+
+
+def test_golden_ne2_hcl():
+    from nvalchemiops.interactions.dispersion import dftd3
+
+    t, p = _params()
+    pos = np.array([[0, 0, 0], [5.8, 0, 0]], np.float32)
+    nm = np.array([[1, 2, 2, 2, 2], [0, 2, 2, 2, 2]], np.int32)
+    e, f, cn = dftd3(_t(pos), _t(np.array([10, 10], np.int32)), d3_params=p, neighbor_matrix=_t(nm), fill_value=2, **FP)
+    np.testing.assert_allclose(e.cpu().numpy(), [-1.4161492698e-02], rtol=3e-6)
+    np.testing.assert_allclose(cn.cpu().numpy(), [4.4183229329e-04] * 2, rtol=3e-6)
+    np.testing.assert_allclose(f.cpu().numpy(), [[3.2497653738e-03, 0, 0], [-3.2497653738e-03, 0, 0]], rtol=3e-6, atol=1e-9)
+    pos = np.array([[0, 0, 0], [2.4, 0, 0], [0, 7, 0], [2.4, 7, 0]], np.float32)
+    nm = np.full((4, 5), 4, np.int32)
+    nm[0, :3], nm[1, :3], nm[2, :3], nm[3, :3] = [1, 2, 3], [0, 2, 3], [0, 1, 3], [0, 1, 2]
+    e, f, cn = dftd3(_t(pos), _t(np.array([1, 17, 1, 17], np.int32)), d3_params=p, neighbor_matrix=_t(nm), fill_value=4, **FP)
+    np.testing.assert_allclose(e.cpu().numpy(), [-2.2127663717e-02], rtol=3e-6)
+    np.testing.assert_allclose(cn.cpu().numpy(), [5.0002193451e-01, 5.0044161081e-01] * 2, rtol=3e-6)
+    ref_f = [[6.2320637517e-03, 8.8818743825e-04, 0], [-6.2320632860e-03, 1.9026985392e-03, 0],
+             [6.2320632860e-03, -8.8818743825e-04, 0], [-6.2320632860e-03, -1.9026985392e-03, 0]]
+    np.testing.assert_allclose(f.cpu().numpy(), ref_f, rtol=5e-6, atol=1e-9)
+
+
+def test_small_molecules_and_edge_cases():
+    from nvalchemiops.interactions.dispersion import dftd3
+
+    t, p = _params()
+    cases = []
+    for sep in (1.4, 0.1):  # H2 and H2 at very small separation
+        cases.append((np.array([[0, 0, 0], [sep, 0, 0]], np.float32), [1, 1], np.array([[1, 2, 2, 2, 2], [0, 2, 2, 2, 2]], np.int32)))
+    nm = np.full((5, 10), 5, np.int32)
+    nm[0, :4] = [1, 2, 3, 4]
+    nm[1:, 0] = 0
+    cases.append((np.array([[0, 0, 0], [2, 0, 0], [-2, 0, 0], [0, 2, 0], [0, -2, 0]], np.float32), [6, 1, 1, 1, 1], nm))
+    cases.append((np.zeros((1, 3), np.float32), [1], np.full((1, 5), 1, np.int32)))  # single atom
+    cases.append((np.array([[0, 0, 0], [10, 0, 0], [20, 0, 0]], np.float32), [1, 1, 1], np.full((3, 5), 3, np.int32)))  # no neighbours
+    cases.append((np.array([[0, 0, 0], [1.5, 0, 0], [3.0, 0.2, 0]], np.float32), [8, 0, 1], np.array([[1, 2, 3], [0, 2, 3], [0, 1, 3]], np.int32)))  # padding atom
+    for pos, z, nm in cases:
+        z = np.array(z, np.int32)
+        ref = O.dftd3(pos, z, t, neighbor_matrix=nm, **FP)
+        out = dftd3(_t(pos), _t(z), d3_params=p, neighbor_matrix=_t(nm), **FP)
+        _check(out, ref)
+    # S5 switching window active
+    pos, z, nm = cases[2]
+    z = np.array(z, np.int32)
+    ref = O.dftd3(pos, z, t, neighbor_matrix=nm, s5_on=1.0, s5_off=3.5, **FP)
+    out = dftd3(_t(pos), _t(z), d3_params=p, neighbor_matrix=_t(nm), s5_smoothing_on=1.0, s5_smoothing_off=3.5, **FP)
+    _check(out, ref)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("fmt", ["matrix", "csr"])
+def test_periodic_with_virial(dtype, fmt):
+    from nvalchemiops.interactions.dispersion import dftd3
+    from nvalchemiops.neighborlist import cell_list
+
+    t, p = _params()
+    pos, cell = S.random_box(180, 14.0, seed=3, dtype=dtype, triclinic=True)
+    z = np.random.default_rng(1).choice(np.array([1, 6, 8, 17], np.int32), 180)
+    pbc = torch.tensor([True] * 3, device=DEV)
+    if fmt == "matrix":
+        nm, num, sh = cell_list(_t(pos), 9.0, _t(cell), pbc, max_neighbors=320)
+        ref = O.dftd3(pos, z, t, neighbor_matrix=nm.cpu().numpy(), neighbor_matrix_shifts=sh.cpu().numpy(), cell=cell, compute_virial=True, **FP)
+        out = dftd3(_t(pos), _t(z), d3_params=p, neighbor_matrix=nm, neighbor_matrix_shifts=sh, cell=_t(cell)[None], compute_virial=True, **FP)
+    else:
+        lst, nptr, lsh = cell_list(_t(pos), 9.0, _t(cell), pbc, return_neighbor_list=True)
+        ref = O.dftd3(pos, z, t, idx_j=lst[1].cpu().numpy(), neighbor_ptr=nptr.cpu().numpy(), unit_shifts=lsh.cpu().numpy(), cell=cell,
+                      compute_virial=True, **FP)
+        out = dftd3(_t(pos), _t(z), d3_params=p, neighbor_list=lst, neighbor_ptr=nptr, unit_shifts=lsh, cell=_t(cell)[None],
+                    compute_virial=True, **FP)
+    _check(out, ref, virial=True)
+    v = out[3][0].cpu().numpy()
+    np.testing.assert_allclose(v, v.T, rtol=1e-4, atol=1e-6)
+    assert abs(out[1].sum(0).cpu().numpy()).max() < 2e-5
+
+
+def test_batch_equals_individual_and_oracle():
+    from nvalchemiops.interactions.dispersion import dftd3
+    from nvalchemiops.neighborlist import batch_cell_list
+
+    t, p = _params()
+    g = np.random.default_rng(5)
+    parts, cells, bis, zs = [], [], [], []
+    for s, n in enumerate((90, 40, 130, 7)):
+        pp, cc = S.random_box(n, 10.0 + s, seed=20 + s, dtype=np.float32)
+        parts.append(pp), cells.append(cc), bis.append(np.full(n, s, np.int32)), zs.append(g.choice(np.array([1, 6, 7, 8], np.int32), n))
+    pos, cell, bi, z = np.concatenate(parts), np.stack(cells), np.concatenate(bis), np.concatenate(zs)
+    nm, num, sh = batch_cell_list(_t(pos), 8.0, _t(cell), torch.ones((4, 3), dtype=torch.bool, device=DEV), _t(bi), max_neighbors=400)
+    assert int(num.max()) <= 400
+    ref = O.dftd3(pos, z, t, neighbor_matrix=nm.cpu().numpy(), neighbor_matrix_shifts=sh.cpu().numpy(), cell=cell, batch_idx=bi,
+                  compute_virial=True, **FP)
+    out = dftd3(_t(pos), _t(z), d3_params=p, neighbor_matrix=nm, neighbor_matrix_shifts=sh, cell=_t(cell), batch_idx=_t(bi),
+                compute_virial=True, **FP)
+    _check(out, ref, virial=True)
+    # explicit tensors instead of D3Parameters, dict form, num_systems given
+    out2 = dftd3(_t(pos), _t(z), covalent_radii=p.rcov, r4r2=p.r4r2, c6_reference=p.c6ab, coord_num_ref=p.cn_ref, neighbor_matrix=nm,
+                 neighbor_matrix_shifts=sh, cell=_t(cell), batch_idx=_t(bi), num_systems=4, **FP)
+    assert torch.allclose(out2[0], out[0], rtol=1e-6, atol=1e-7)
+
+
+def test_validation_errors():
+    from nvalchemiops.interactions.dispersion import D3Parameters, dftd3
+
+    t, p = _params()
+    pos, z = _t(np.zeros((2, 3), np.float32)), _t(np.array([1, 1], np.int32))
+    nm = _t(np.array([[1, 2], [0, 2]], np.int32))
+    with pytest.raises(ValueError):
+        dftd3(pos, z, d3_params=p, **FP)
+    with pytest.raises(ValueError):
+        dftd3(pos, z, d3_params=p, neighbor_matrix=nm, unit_shifts=nm, **FP)
+    with pytest.raises(ValueError):
+        dftd3(pos, z, d3_params=p, neighbor_matrix=nm, compute_virial=True, **FP)
+    with pytest.raises(RuntimeError):
+        dftd3(pos, z, neighbor_matrix=nm, **FP)
+    with pytest.raises(ValueError):
+        D3Parameters(rcov=torch.rand(5), r4r2=torch.rand(4), c6ab=torch.rand(5, 5, 5, 5), cn_ref=torch.rand(5, 5, 5, 5))
+    with pytest.raises(TypeError):
+        D3Parameters(rcov=[1.0], r4r2=torch.rand(4), c6ab=torch.rand(5, 5, 5, 5), cn_ref=torch.rand(5, 5, 5, 5))
+
+
+def test_config3_molecule_batch_properties():
+    """BASELINE config 3 (256 x 512-atom molecules, D3(BJ) fp32, rc = 40 Bohr): a subset checked against the oracle,
+    the full batch through size-independent properties (matrix == CSR, zero net force per molecule)."""
+    from nvalchemiops.interactions.dispersion import dftd3
+    from nvalchemiops.neighborlist import neighbor_list
+
+    t, p = _params(94, seed=7)
+    nmol = 256
+    mols = [S.molecule(512, seed=2000 + s) for s in range(4)]
+    pos = np.concatenate([(mols[s % 4][0] * 1.8897261 + 3.0 * s).astype(np.float32) for s in range(nmol)])
+    z = np.concatenate([mols[s % 4][1] for s in range(nmol)])
+    bi = np.repeat(np.arange(nmol, dtype=np.int32), 512)
+    bj = dict(a1=0.4289, a2=4.4407, s8=0.7875)
+    tp, tz, tb = _t(pos), _t(z), _t(bi)
+    lst, nptr, lsh = neighbor_list(tp, 40.0, batch_idx=tb, return_neighbor_list=True)
+    assert lsh.abs().max().item() == 0
+    e, f, cn = dftd3(tp, tz, d3_params=p, neighbor_list=lst, neighbor_ptr=nptr, batch_idx=tb, num_systems=nmol, **bj)
+    fs = torch.zeros((nmol, 3), device=DEV).index_add_(0, tb.long(), f)
+    assert fs.abs().max().item() < 5e-5
+    # first two molecules against the oracle (full 512 x 511 pair lists)
+    n2 = 1024
+    sub = (lst[0] < n2)
+    ref = O.dftd3(pos[:n2], z[:n2], t, idx_j=lst[1][sub].cpu().numpy(), neighbor_ptr=nptr[: n2 + 1].cpu().numpy(), batch_idx=bi[:n2],
+                  num_systems=2, **bj)
+    _close(e[:2], ref[0], 2e-6, 1e-6, "energy")
+    _close(f[:n2], ref[1], 1e-5, 1e-6, "forces")
+    _close(cn[:n2], ref[2], 2e-6, 1e-7, "cn")
+    # replicas of the same molecule (translated) have the same energy
+    assert torch.allclose(e[0::4], e[0].expand_as(e[0::4]), rtol=2e-5)
+    # matrix format gives the same answer
+    nm, num, _ = neighbor_list(tp, 40.0, batch_idx=tb, max_neighbors=512)
+    e2, f2, cn2 = dftd3(tp, tz, d3_params=p, neighbor_matrix=nm, batch_idx=tb, num_systems=nmol, **bj)
+    assert torch.allclose(e2, e, rtol=1e-5, atol=1e-6) and torch.allclose(f2, f, rtol=1e-4, atol=1e-6)

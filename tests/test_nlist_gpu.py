@@ -49,7 +49,7 @@ def test_cell_list_matches_oracle(dtype, kind):
 
     pos, cell = S.random_box(700, 14.0, seed=42, dtype=dtype, triclinic=(kind == "triclinic"), outside=(kind == "outside"))
     pbc = {"mixed_pbc": [True, False, True], "no_pbc": [False] * 3}.get(kind, [True] * 3)
-    for cutoff, m in ((3.2, 64), (6.5, 320)):
+    for cutoff, m in ((3.2, 64), (6.5, 416)):  # M above the densest row: overflow truncation is order-dependent
         onm, onum, osh = O.cell_list(pos, cutoff, cell, pbc, max_neighbors=m)
         nm, num, sh = cell_list(_t(pos), cutoff, _t(cell), torch.tensor(pbc, device=DEV), max_neighbors=m)
         assert num.cpu().numpy().tolist() == onum.tolist()
