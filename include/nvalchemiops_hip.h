@@ -161,15 +161,17 @@ int mi_spline_gather_vec3(const void* positions, const void* charges, const void
  * mi_pme_green_sf: alchemiops::_[batch_]pme_green_structure_factor (pme.py:273-553, pme_kernels.py:121-331)
  * mi_pme_convolve: the torch elementwise block of _pme_reciprocal_space_impl (pme.py:1418-1419,1455-1457):
  *   conv = spec / sf2 * G ; E_d = -i k_d conv, fused into one pass that writes 1 or 4 spectra.
+ *   `sf_exponent` in both: power of the sinc product before squaring -- the reference uses min(order, 4)
+ *   (pme_kernels.py:213-225); this build passes `order` for its true order-5/6 splines.
  * mi_pme_gather_finish: spline_gather + pme_energy_corrections[_with_charge_grad] + gather_vec3 + "x2"
  *   (pme.py:1429-1477; pme_kernels.py:340-657) fused over the 4 planar real-space meshes.
  */
 int mi_pme_green_sf(const void* k_squared /*[B,nx,ny,nzr]*/, const void* alpha /*[B]*/, const void* volume /*[B]*/,
-                    int n_systems, int nx, int ny, int nz, int order, int dtype, void* green /*[B,nx,ny,nzr]*/,
+                    int n_systems, int nx, int ny, int nz, int sf_exponent, int dtype, void* green /*[B,nx,ny,nzr]*/,
                     void* sf_sq /*[nx,ny,nzr]*/, void* stream);
 int mi_pme_convolve(const void* spec /*complex [B,nx,ny,nzr]*/, const void* recip_cell /*[B,3,3] = 2pi inv(cell)*/,
                     const void* alpha /*[B]*/, const void* volume /*[B]*/, int n_systems, int nx, int ny, int nz,
-                    int order, int with_field, int dtype, void* out /*complex [B,(1|4),nx,ny,nzr]*/, void* stream);
+                    int sf_exponent, int with_field, int dtype, void* out /*complex [B,(1|4),nx,ny,nzr]*/, void* stream);
 int mi_pme_gather_finish(const void* positions, const void* charges, const int32_t* batch_idx, const void* cell_inv_t,
                          const void* meshes /*[B,(1|4),nx,ny,nz] real*/, const void* alpha, const void* volume,
                          const void* total_charge /*[B]*/, int n_atoms, int n_systems, int nx, int ny, int nz,

