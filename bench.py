@@ -1,0 +1,272 @@
+#!/usr/bin/env python
+"""Headline benchmark: atom-steps/s of one full hot-path step (neighbor lists + DFT-D3(BJ) + particle-mesh Ewald)
+on a 100k-atom periodic box, one process per MI355X.
+
+    python bench.py --gpus 1 --steps 10 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+One "step" (BASELINE.json metric; BASELINE.md headline row) on synthetic data already resident in HBM:
+  1. neighbor_list  rc = 9 A, padded matrix (M = 256), fp64 positions                  -> real-space PME list
+  2. particle_mesh_ewald  alpha = 0.35 /A, mesh 128^3, B-spline order 5, E + F, fp64   (real + reciprocal)
+  3. neighbor_list  rc = 40 Bohr (21.2 A), direct CSR/COO output, fp32 positions        -> D3 list (~2.4k pairs/atom)
+  4. dftd3(BJ)  a1=0.4289 a2=4.4407 s8=0.7875, E + F + virial, fp32
+System: jittered FCC box (a = 4 A, sigma = 0.05 A, seed 1234 + rank), first N sites, +-1 charges, Z in {6, 8}; D3 tables
+are the reference test-suite's analytic tables extended to Z <= 94 (real Grimme tables are not in the reference repo).
+A single box does not shard: for --gpus N > 1 every rank runs its own replica box (weak scaling) and the
+per-system energies are exchanged with ONE RCCL all_gather per step.
+
+Prints ONE JSON line (rank 0) with the driver's fields plus `roofline` (dominant kernel, live HIP-event timing) and
+`cpu_baseline` (the CPU oracle, 1 thread, on a bounded sample of the same workload; N = 1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "nvalchemi-toolkit-ops_amd")]
+
+BOHR = 1.8897261246
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+PME = dict(cutoff=9.0, alpha=0.35, mesh=(128, 128, 128), order=5, max_neighbors=256)
+D3 = dict(cutoff=40.0, a1=0.4289, a2=4.4407, s8=0.7875)
+
+
+def build_system(n_atoms: int, seed: int, device):
+    from oracle import oracle as O  # only the analytic table generator (pure numpy) is used here, not the oracle kernels
+    from tests import systems as S
+
+    pos, cell, q, numbers = S.fcc_box(n_atoms, seed=seed, dtype=np.float64)
+    tables = O.d3_test_tables(94, seed=7)
+    t = lambda a, dt=None: torch.as_tensor(np.ascontiguousarray(a), dtype=dt, device=device)  # noqa: E731
+    sysd = dict(
+        n=n_atoms, pos64=t(pos), cell64=t(cell), q64=t(q), numbers=t(numbers),
+        pos32b=t((pos * BOHR).astype(np.float32)), cell32b=t((cell * BOHR).astype(np.float32)),
+        pbc=torch.tensor([True, True, True], device=device),
+        host=dict(pos=pos, cell=cell, q=q, numbers=numbers, tables=tables),
+    )
+    return sysd, tables
+
+
+def make_step(sysd, tables, device, world):
+    from nvalchemiops.interactions.dispersion import D3Parameters, dftd3
+    from nvalchemiops.interactions.electrostatics import particle_mesh_ewald
+    from nvalchemiops.neighborlist import cell_list
+
+    n = sysd["n"]
+    t = lambda a: torch.as_tensor(a, device=device)  # noqa: E731
+    params = D3Parameters(rcov=t(tables["rcov"]), r4r2=t(tables["r4r2"]), c6ab=t(tables["c6ab"]), cn_ref=t(tables["cn_ref"]))
+    m = PME["max_neighbors"]
+    nm = torch.empty((n, m), dtype=torch.int32, device=device)
+    nsh = torch.empty((n, m, 3), dtype=torch.int32, device=device)
+    num = torch.empty(n, dtype=torch.int32, device=device)
+    gathered = [torch.zeros(2, dtype=torch.float64, device=device) for _ in range(world)] if world > 1 else None
+    stage_ms = {}
+
+    def step(record=None):
+        ev = []
+
+        def mark(name):
+            if record is not None:
+                e = torch.cuda.Event(enable_timing=True)
+                e.record()
+                ev.append((name, e))
+
+        mark("start")
+        cell_list(sysd["pos64"], PME["cutoff"], sysd["cell64"], sysd["pbc"], neighbor_matrix=nm, neighbor_matrix_shifts=nsh,
+                  num_neighbors=num)
+        mark("nlist_pme")
+        e_pme, f_pme = particle_mesh_ewald(sysd["pos64"], sysd["q64"], sysd["cell64"], alpha=PME["alpha"], mesh_dimensions=PME["mesh"],
+                                           spline_order=PME["order"], neighbor_matrix=nm, neighbor_matrix_shifts=nsh, compute_forces=True)
+        mark("pme")
+        lst, nptr, lsh = cell_list(sysd["pos32b"], D3["cutoff"], sysd["cell32b"], sysd["pbc"], return_neighbor_list=True)
+        mark("nlist_d3")
+        e_d3, f_d3, cn, vir = dftd3(sysd["pos32b"], sysd["numbers"], a1=D3["a1"], a2=D3["a2"], s8=D3["s8"], d3_params=params,
+                                    neighbor_list=lst, neighbor_ptr=nptr, unit_shifts=lsh, cell=sysd["cell32b"].unsqueeze(0),
+                                    compute_virial=True, num_systems=1)
+        mark("d3")
+        if gathered is not None:
+            mine = torch.stack([e_d3[0].double(), e_pme.sum()])
+            torch.distributed.all_gather(gathered, mine)
+            mark("gather")
+        if record is not None:
+            record.append(ev)
+        return e_pme, f_pme, e_d3, f_d3, num, nptr
+
+    return step, stage_ms
+
+
+def kernel_report():
+    from nvalchemiops import _capi as C
+
+    buf = ctypes.create_string_buffer(1 << 16)
+    C.lib().mi_timing_report(buf, len(buf))
+    out = {}
+    for line in buf.value.decode().splitlines():
+        name, cnt, ms = line.rsplit(" ", 2)
+        out[name] = (int(cnt), float(ms))
+    return out
+
+
+def algorithmic_bytes(kernel: str, n: int, pairs_d3: int) -> float | None:
+    """Algorithmic HBM bytes per launch (SURVEY.md 8d / DESIGN.md 'roofline accounting')."""
+    m, mesh = PME["max_neighbors"], float(np.prod(PME["mesh"]))
+    if kernel in ("d3_energy", "d3_cn", "d3_chain"):
+        return 16.0 * pairs_d3 + 40.0 * n  # idx_j + 3 shift ints per directed pair; per-atom position/Z/CN in, F/dEdCN/E out
+    if kernel == "nl_query_csr":
+        return n * (3 * 4 + 8) + 20.0 * pairs_d3
+    if kernel == "nl_query_count":
+        return n * (3 * 4 + 4.0)
+    if kernel == "nl_query_matrix":
+        return n * (3 * 8 + 4) + 16.0 * n * m
+    if kernel == "ewald_real":
+        return 16.0 * n * m + n * (3 * 8 + 8) + n * (8 + 3 * 8)
+    if kernel == "spline_spread":
+        return n * 4 * 8 + mesh * 8
+    if kernel == "pme_gather_finish":
+        return 4 * mesh * 8 + n * 4 * 8 + n * 4 * 8
+    if kernel == "pme_convolve":
+        return (mesh / 2) * 16 * 5
+    return None
+
+
+def cpu_baseline(sample_atoms: int = 864, budget_s: float = 12.0):
+    """The CPU oracle (single thread == what Warp's CPU backend does per launch: SURVEY F9) on a bounded sample: full
+    steps of the same workload (same density, cutoffs, alpha; spline order 4, the highest the reference implements) on a
+    smaller periodic box, repeated for ~budget_s seconds.  864 atoms (6^3 FCC cells) keeps the per-atom candidate count
+    of the reference's 40-Bohr cell walk (~13.5 N_s = 11.7k) at what the 100k-atom box costs it (14 cells x ~800 atoms)."""
+    from oracle import oracle as O
+    from tests import systems as S
+
+    pos, cell, q, numbers = S.fcc_box(sample_atoms, seed=1234, dtype=np.float64)
+    tables = O.d3_test_tables(94, seed=7)
+    scale = (sample_atoms / 100000.0) ** (1.0 / 3.0)
+    mesh = tuple(int(2 ** round(np.log2(max(16, d * scale)))) for d in PME["mesh"])
+    pb, cb = (pos * BOHR).astype(np.float32), (cell * BOHR).astype(np.float32)
+    stages = np.zeros(4)
+    steps, t_begin = 0, time.perf_counter()
+    while True:
+        t0 = time.perf_counter()
+        nm, num, sh = O.cell_list(pos, PME["cutoff"], cell, [True] * 3, max_neighbors=PME["max_neighbors"])
+        t1 = time.perf_counter()
+        O.particle_mesh_ewald(pos, q, cell, PME["alpha"], mesh, 4, neighbor_matrix=nm, neighbor_matrix_shifts=sh, compute_forces=True)
+        t2 = time.perf_counter()
+        nm2, num2, sh2 = O.cell_list(pb, D3["cutoff"], cb, [True] * 3, max_neighbors=2816)
+        lst, nptr, lsh = O.matrix_to_coo(nm2, num2, sh2, fill_value=sample_atoms)
+        t3 = time.perf_counter()
+        O.dftd3(pb, numbers, tables, D3["a1"], D3["a2"], D3["s8"], idx_j=lst[1], neighbor_ptr=nptr, unit_shifts=lsh, cell=cb, compute_virial=True)
+        t4 = time.perf_counter()
+        stages += [t1 - t0, t2 - t1, t3 - t2, t4 - t3]
+        steps += 1
+        if time.perf_counter() - t_begin >= budget_s or steps >= 40:
+            break
+    total = float(stages.sum())
+    per = stages / steps
+    return {
+        "value": sample_atoms * steps / total, "unit": "atom-steps/s", "cores": 1, "kind": "port",
+        "sample": f"{steps} steps on a {sample_atoms}-atom periodic box at the same density/cutoffs (mesh {mesh[0]}^3, spline order 4); "
+                  f"per step: nlist9A {per[0]:.3f}s, PME {per[1]:.3f}s, nlist40Bohr {per[2]:.3f}s, D3 {per[3]:.3f}s",
+        "seconds": total,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--atoms", type=int, default=100000)
+    ap.add_argument("--cpu-sample", type=int, default=864, help="atoms in the CPU-baseline sample (0 = skip)")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.distributed.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+
+    from nvalchemiops import _capi as C
+
+    sysd, tables = build_system(args.atoms, 1234 + rank, device)
+    step, _ = make_step(sysd, tables, device, world)
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        out = step()
+    barrier()
+    C.lib().mi_timing_enable(1)
+    records = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step(records)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    C.lib().mi_timing_enable(0)
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    kernels = kernel_report()
+
+    e_pme, f_pme, e_d3, f_d3, num, nptr = out
+    pairs_d3 = int(nptr[-1].item())
+    stage_ms = {}
+    for ev in records:
+        for (_, a), (name, b) in zip(ev[:-1], ev[1:]):
+            stage_ms[name] = stage_ms.get(name, 0.0) + a.elapsed_time(b) / len(records)
+
+    if rank == 0:
+        total_atoms = args.atoms * world
+        value = total_atoms * args.steps / elapsed
+        dom = max(kernels.items(), key=lambda kv: kv[1][1]) if kernels else None
+        roofline = None
+        if dom is not None:
+            name, (cnt, ms) = dom
+            avg_s = ms / cnt / 1e3
+            ab = algorithmic_bytes(name, args.atoms, pairs_d3)
+            achieved = ab / avg_s / 1e9 if ab else None
+            roofline = {
+                "bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": None,
+                "avg_launch_ms": ms / cnt, "launches": cnt, "algorithmic_bytes_per_launch": ab,
+                "note": "d3_energy is exp/VALU-bound (25 expf per directed pair), not HBM-bound: see DESIGN.md; "
+                        f"pairs/s = {pairs_d3 / avg_s:.3e}" if name == "d3_energy" else "",
+            }
+        result = {
+            "metric": "atom-steps/sec (nlist+D3+PME) on 100k-atom PBC box",
+            "value": value, "unit": "atom-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64 (PME) + f32 (D3)", "data": "synthetic",
+            "config": {"workload": f"{args.atoms}-atom periodic FCC box per GPU: nlist(9 A, padded M=256) + PME(alpha 0.35, mesh 128^3, "
+                                   "spline order 5, E+F, fp64) + nlist(40 Bohr, CSR) + DFT-D3(BJ, E+F+virial, fp32)",
+                       "atoms_per_gpu": args.atoms, "d3_directed_pairs": pairs_d3, "pme_neighbors_max": int(num.max().item()),
+                       "parallelism": "replica per GPU + 1 RCCL all_gather of per-system energies" if world > 1 else "single GPU"},
+            "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
+            "kernel_ms": {k: round(v[1] / v[0], 4) for k, v in sorted(kernels.items())},
+            "energies": {"e_d3_Ha": float(e_d3[0].item()), "e_pme": float(e_pme.sum().item())},
+            "roofline": roofline,
+        }
+        if world == 1 and args.cpu_sample > 0:
+            result["cpu_baseline"] = cpu_baseline(args.cpu_sample)
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -31,6 +31,10 @@ extern "C" {
 /* ---- library ------------------------------------------------------------------------------- */
 int mi_version(void);                 /* ABI version, currently 1                                  */
 const char* mi_last_error(void);      /* [host] message of the last failure on this thread         */
+/* Optional per-kernel timing with HIP events recorded on the launch stream (used by bench.py for the live
+ * roofline figure).  mi_timing_report waits for the events and writes "<kernel> <launches> <total_ms>\n" lines. */
+int mi_timing_enable(int on);
+int mi_timing_report(char* buf /*[host]*/, int cap);
 
 /* ---- neighbour list -------------------------------------------------------------------------
  * Replaces: nvalchemiops::build_cell_list + ::query_cell_list (neighborlist/cell_list.py:725,892),

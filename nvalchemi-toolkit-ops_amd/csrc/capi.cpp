@@ -1,6 +1,14 @@
-// capi.cpp -- library-level entry points of libnvalchemiops_hip.so (version, per-thread error string).
+// capi.cpp -- library-level entry points of libnvalchemiops_hip.so: version, per-thread error string and the optional
+// per-kernel HIP-event timing used by bench.py (roofline.achieved is measured live with these events on the launch stream).
+#include <hip/hip_runtime_api.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <string.h>
+
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
 
 #include "../../include/nvalchemiops_hip.h"
 
@@ -13,7 +21,66 @@ void mi_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
+namespace {
+struct Rec { const char* name; hipEvent_t a, b; };
+std::mutex g_mu;
+bool g_timing = false;
+std::vector<Rec> g_recs;
+std::vector<hipEvent_t> g_pool;
+hipEvent_t take_event() {
+  if (!g_pool.empty()) { hipEvent_t e = g_pool.back(); g_pool.pop_back(); return e; }
+  hipEvent_t e = nullptr;
+  (void)hipEventCreate(&e);
+  return e;
+}
+}  // namespace
+
+// called around kernel launches by the MI_TIMED macro (common.h); no-ops unless timing is enabled
+void mi_timing_begin(const char* name, void* stream) {
+  if (!g_timing) return;
+  std::lock_guard<std::mutex> lk(g_mu);
+  Rec r{name, take_event(), take_event()};
+  (void)hipEventRecord(r.a, (hipStream_t)stream);
+  g_recs.push_back(r);
+}
+void mi_timing_end(void* stream) {
+  if (!g_timing) return;
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (!g_recs.empty()) (void)hipEventRecord(g_recs.back().b, (hipStream_t)stream);
+}
+
 extern "C" {
 int mi_version(void) { return 1; }
 const char* mi_last_error(void) { return g_err; }
+
+int mi_timing_enable(int on) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  g_timing = on != 0;
+  return MI_OK;
+}
+
+// Writes one line per kernel: "<name> <launches> <total_ms>\n"; waits for the recorded events; clears the records.
+int mi_timing_report(char* buf, int cap) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  std::map<std::string, std::pair<int, double>> acc;
+  for (auto& r : g_recs) {
+    float ms = 0.0f;
+    if (hipEventSynchronize(r.b) == hipSuccess && hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
+      auto& s = acc[r.name];
+      s.first += 1;
+      s.second += ms;
+    }
+    g_pool.push_back(r.a);
+    g_pool.push_back(r.b);
+  }
+  g_recs.clear();
+  int off = 0;
+  if (buf && cap > 0) buf[0] = 0;
+  for (auto& kv : acc) {
+    int n = snprintf(buf + off, cap > off ? cap - off : 0, "%s %d %.6f\n", kv.first.c_str(), kv.second.first, kv.second.second);
+    if (n < 0 || off + n >= cap) break;
+    off += n;
+  }
+  return MI_OK;
+}
 }

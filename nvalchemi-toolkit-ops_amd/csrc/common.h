@@ -9,6 +9,15 @@
 #define MI_WAVE 64
 
 void mi_set_error(const char* fmt, ...);
+void mi_timing_begin(const char* name, void* stream);
+void mi_timing_end(void* stream);
+// brackets a kernel launch with HIP events when timing is enabled (mi_timing_enable); free otherwise
+#define MI_TIMED(name, st, ...)       \
+  do {                                \
+    mi_timing_begin(name, (void*)st); \
+    __VA_ARGS__;                      \
+    mi_timing_end((void*)st);         \
+  } while (0)
 
 #define MI_HIP_CHECK(expr)                                                                     \
   do {                                                                                         \

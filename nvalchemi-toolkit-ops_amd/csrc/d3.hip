@@ -92,7 +92,9 @@ __global__ __launch_bounds__(256) void d3_cn_kernel(const T* __restrict__ pos, c
   const float rci = P.rcov[zi];
   long long beg, end;
   d3_row<T, CSR>(i, M, nptr, beg, end);
-  float acc = 0.0f;
+  // the reference sums in fp32 sequentially (dftd3.py:911); lanes hold fp64 partials here so the result is the
+  // correctly rounded sum whatever the lane/iteration order
+  double acc = 0.0;
   for (long long e = beg + lane; e < end; e += MI_WAVE) {
     const int j = idx[e];
     if (!CSR && j >= fill_value) continue;
@@ -100,10 +102,10 @@ __global__ __launch_bounds__(256) void d3_cn_kernel(const T* __restrict__ pos, c
     if (zj == 0) continue;
     const PairGeom<T> g = d3_geom<T>(pos, pix, piy, piz, j, ush, e, cm, periodic);
     if (!g.ok) continue;
-    acc += d3_cn_count(g.rinv, rci, P.rcov[zj], P.k1, nullptr);
+    acc += (double)d3_cn_count(g.rinv, rci, P.rcov[zj], P.k1, nullptr);
   }
   acc = wave_sum(acc);
-  if (lane == 0) cn[i] = acc;
+  if (lane == 0) cn[i] = (float)acc;
 }
 
 // `_s5_switch` (dftd3.py:341-423)
@@ -172,7 +174,7 @@ __global__ __launch_bounds__(256) void d3_energy_kernel(const T* __restrict__ po
   d3_row<T, CSR>(i, M, nptr, beg, end);
   double Fx = 0, Fy = 0, Fz = 0, E = 0;
   double V[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-  float dacc = 0.0f;
+  double dacc = 0.0;
   for (long long e = beg + lane; e < end; e += MI_WAVE) {
     const int j = idx[e];
     if (!CSR && j >= fill_value) continue;
@@ -204,7 +206,7 @@ __global__ __launch_bounds__(256) void d3_energy_kernel(const T* __restrict__ po
     const float fx = dEsw * (g.rx * g.rinv), fy = dEsw * (g.ry * g.rinv), fz = dEsw * (g.rz * g.rinv);
     Fx += (double)fx; Fy += (double)fy; Fz += (double)fz;
     E += (double)esw;
-    dacc += -damp * dci;
+    dacc += (double)(-damp * dci);
     if (want_virial) {
       V[0] += (double)(fx * g.rx); V[1] += (double)(fx * g.ry); V[2] += (double)(fx * g.rz);
       V[3] += (double)(fy * g.rx); V[4] += (double)(fy * g.ry); V[5] += (double)(fy * g.rz);
@@ -219,7 +221,7 @@ __global__ __launch_bounds__(256) void d3_energy_kernel(const T* __restrict__ po
   }
   if (lane == 0) {
     forces[3 * (size_t)i] = (float)Fx; forces[3 * (size_t)i + 1] = (float)Fy; forces[3 * (size_t)i + 2] = (float)Fz;
-    dEdCN[i] = dacc;
+    dEdCN[i] = (float)dacc;
     e_atom[i] = 0.5f * (float)E;
   }
   if (want_virial && lane < 9) {
@@ -353,13 +355,13 @@ int d3_impl(const T* pos, const int* numbers, int N, const int* idx, const int* 
   d3_pack_tables_kernel<<<mi_blocks(nt, 256), 256, 0, st>>>(hp->c6ab, hp->cn_ref, hp->nz, tab);
   MI_LAUNCH_CHECK();
   const int blocks = mi_blocks(N, 4);
-  d3_cn_kernel<T, CSR><<<blocks, 256, 0, st>>>(pos, numbers, N, idx, ush, nptr, M, fill_value, cell, batch_idx, P, cn);
+  MI_TIMED("d3_cn", st, (d3_cn_kernel<T, CSR><<<blocks, 256, 0, st>>>(pos, numbers, N, idx, ush, nptr, M, fill_value, cell, batch_idx, P, cn)));
   MI_LAUNCH_CHECK();
-  d3_energy_kernel<T, CSR><<<blocks, 256, 0, st>>>(pos, numbers, N, idx, ush, nptr, M, fill_value, cell, batch_idx, P, cn, want_virial, dEdCN,
-                                                   forces, e_atom, v_atom);
+  MI_TIMED("d3_energy", st, (d3_energy_kernel<T, CSR><<<blocks, 256, 0, st>>>(pos, numbers, N, idx, ush, nptr, M, fill_value, cell, batch_idx, P, cn,
+                                                                              want_virial, dEdCN, forces, e_atom, v_atom)));
   MI_LAUNCH_CHECK();
-  d3_chain_kernel<T, CSR><<<blocks, 256, 0, st>>>(pos, numbers, N, idx, ush, nptr, M, fill_value, cell, batch_idx, P, dEdCN, want_virial, forces,
-                                                  v_atom);
+  MI_TIMED("d3_chain", st, (d3_chain_kernel<T, CSR><<<blocks, 256, 0, st>>>(pos, numbers, N, idx, ush, nptr, M, fill_value, cell, batch_idx, P, dEdCN,
+                                                                            want_virial, forces, v_atom)));
   MI_LAUNCH_CHECK();
   d3_reduce_kernel<<<mi_blocks(N, 256), 256, 0, st>>>(e_atom, v_atom, batch_idx, N, want_virial, energy, virial);
   MI_LAUNCH_CHECK();

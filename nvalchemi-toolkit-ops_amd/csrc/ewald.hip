@@ -93,8 +93,10 @@ extern "C" int mi_ewald_real(const void* positions, const void* charges, const v
   ewald_real_kernel<T_, CSR_><<<blocks, 256, 0, st>>>((const T_*)positions, (const T_*)charges, (const T_*)cell, (const T_*)alpha, batch_idx, \
                                                       n_atoms, idx_j, unit_shifts, neighbor_ptr, max_neighbors, mask_value, flags, energies, \
                                                       (T_*)forces, charge_grads)
+  mi_timing_begin("ewald_real", stream);
   if (dtype == MI_F32) { if (csr) MI_EW(float, true); else MI_EW(float, false); }
   else { if (csr) MI_EW(double, true); else MI_EW(double, false); }
+  mi_timing_end(stream);
 #undef MI_EW
   MI_LAUNCH_CHECK();
   return MI_OK;

@@ -461,6 +461,7 @@ int nl_neighbors_impl(const T* pos, int N, const T* cell, const uint8_t* pbc, co
   const T rc2 = (flags & MI_NL_NAIVE_EXPR) ? (T)(cutoff * cutoff) : rc * rc;
 
   if (!(flags & MI_NL_REUSE_GRID)) {
+    mi_timing_begin("nl_build(setup+assign+sort+ranges+gather)", (void*)st);
     const int* nat = nullptr;
     if (batch_idx && B > 1) {
       MI_HIP_CHECK(hipMemsetAsync(natoms, 0, sizeof(int) * (size_t)B, st));
@@ -479,14 +480,15 @@ int nl_neighbors_impl(const T* pos, int N, const T* cell, const uint8_t* pbc, co
     MI_LAUNCH_CHECK();
     nl_gather_kernel<T><<<mi_blocks(N, 256), 256, 0, st>>>(pos, vals_out, wrap, N, spos, swrap);
     MI_LAUNCH_CHECK();
+    mi_timing_end((void*)st);
   }
   const int blocks = mi_blocks(N, 4);
 #define MI_NLQ(MODE_)                                                                                                              \
   nl_query_kernel<T, MODE_><<<blocks, 256, 0, st>>>(spos, swrap, keys_out, cell_start, batch_idx, sys, glob, N, rc2, flags, nm, nsh, num, M, \
                                                     fill_value, ptr, list_ij, list_sh, P)
-  if (mode == MI_NL_MODE_MATRIX) MI_NLQ(MI_NL_MODE_MATRIX);
-  else if (mode == MI_NL_MODE_COUNT) MI_NLQ(MI_NL_MODE_COUNT);
-  else MI_NLQ(MI_NL_MODE_CSR);
+  if (mode == MI_NL_MODE_MATRIX) MI_TIMED("nl_query_matrix", st, MI_NLQ(MI_NL_MODE_MATRIX));
+  else if (mode == MI_NL_MODE_COUNT) MI_TIMED("nl_query_count", st, MI_NLQ(MI_NL_MODE_COUNT));
+  else MI_TIMED("nl_query_csr", st, MI_NLQ(MI_NL_MODE_CSR));
 #undef MI_NLQ
   MI_LAUNCH_CHECK();
   return MI_OK;

@@ -325,9 +325,11 @@ int mi_spline_spread(const void* positions, const void* values, const int32_t* b
   MI_REQUIRE(positions && values && cell_inv_t && mesh, "null pointer");
   const int apb = 256 / (order * order);
   hipStream_t st = (hipStream_t)stream;
+  mi_timing_begin("spline_spread", stream);
   MI_DISPATCH_T(dtype, (spline_spread_kernel<T_><<<mi_blocks(n_atoms, apb), 256, 0, st>>>((const T_*)positions, (const T_*)values, batch_idx,
                                                                                           (const T_*)cell_inv_t, n_atoms, nx, ny, nz, order,
                                                                                           batched, (T_*)mesh)));
+  mi_timing_end(stream);
   MI_LAUNCH_CHECK();
   return MI_OK;
 }
@@ -381,9 +383,11 @@ int mi_pme_convolve(const void* spec, const void* recip_cell, const void* alpha,
   MI_REQUIRE(spec && recip_cell && alpha && volume && out && n_systems >= 1, "null pointer");
   const size_t tot = (size_t)nx * ny * (nz / 2 + 1) * n_systems;
   hipStream_t st = (hipStream_t)stream;
+  mi_timing_begin("pme_convolve", stream);
   MI_DISPATCH_T(dtype, (pme_convolve_kernel<T_><<<mi_blocks((long long)tot, 256), 256, 0, st>>>((const Cplx<T_>*)spec, (const T_*)recip_cell,
                                                                                                 (const T_*)alpha, (const T_*)volume, n_systems, nx,
                                                                                                 ny, nz, order, with_field, (Cplx<T_>*)out)));
+  mi_timing_end(stream);
   MI_LAUNCH_CHECK();
   return MI_OK;
 }
@@ -397,10 +401,12 @@ int mi_pme_gather_finish(const void* positions, const void* charges, const int32
   if (n_atoms <= 0) return MI_OK;
   MI_REQUIRE(positions && charges && cell_inv_t && meshes && alpha && volume && total_charge && energies, "null pointer");
   hipStream_t st = (hipStream_t)stream;
+  mi_timing_begin("pme_gather_finish", stream);
   MI_DISPATCH_T(dtype, (pme_gather_finish_kernel<T_><<<mi_blocks(n_atoms, 128), 128, 0, st>>>(
                            (const T_*)positions, (const T_*)charges, batch_idx, (const T_*)cell_inv_t, (const T_*)meshes, (const T_*)alpha,
                            (const T_*)volume, (const T_*)total_charge, n_atoms, nx, ny, nz, order, with_field, (T_*)energies, (T_*)forces,
                            (T_*)charge_grads)));
+  mi_timing_end(stream);
   MI_LAUNCH_CHECK();
   return MI_OK;
 }

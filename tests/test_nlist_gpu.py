@@ -128,8 +128,9 @@ def test_naive_matches_oracle(dtype):
     assert np.array_equal(num.cpu().numpy(), onum)
     assert np.array_equal(np.sort(nm.cpu().numpy(), 1), np.sort(onm, 1))
     pos, cell = S.random_box(300, 9.0, seed=4, dtype=dtype, triclinic=True)
-    onm, onum, osh = O.naive(pos, 3.3, cell, [True, True, False], max_neighbors=64)
-    nm, num, sh = naive_neighbor_list(_t(pos), 3.3, cell=_t(cell), pbc=torch.tensor([True, True, False], device=DEV), max_neighbors=64)
+    onm, onum, osh = O.naive(pos, 3.3, cell, [True, True, False], max_neighbors=160)
+    nm, num, sh = naive_neighbor_list(_t(pos), 3.3, cell=_t(cell), pbc=torch.tensor([True, True, False], device=DEV), max_neighbors=160)
+    assert int(onum.max()) <= 160  # no overflow: truncated rows are order-dependent
     assert np.array_equal(_pairs(nm, num, sh), O.canonical_pairs(onm, onum, osh))
 
 

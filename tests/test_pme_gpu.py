@@ -56,7 +56,7 @@ def test_spline_ops_match_oracle(dtype, order):
     _close(spline_gather_vec3(_t(pos), _t(q), _t(vfield), _t(cell), order), O.spline_gather_vec3(pos, q, vfield, cell, order), dtype,
            "gather_vec3")
     ones = spline_gather(_t(pos), torch.ones(dims, dtype=_t(pos).dtype, device=DEV), _t(cell), order)
-    assert float((ones - 1).abs().max()) < (1e-12 if dtype == np.float64 else 1e-5)  # partition of unity
+    assert float((ones - 1).abs().max()) < (1e-6 if dtype == np.float64 else 1e-5)  # partition of unity (weights <= 1e-8 are dropped)
     # batch kernels (threshold w > 1e-8) on two copies with different cells
     pos2 = np.concatenate([pos, pos * 0.9]).astype(dtype)
     q2 = np.concatenate([q, -q]).astype(dtype)
@@ -77,7 +77,7 @@ def test_spline_high_order_properties(order):
     mesh = spline_spread(_t(pos), _t(q), _t(cell), dims, order)
     assert abs(float(mesh.sum()) - q.sum()) < 1e-10
     ones = spline_gather(_t(pos), torch.ones(dims, dtype=torch.float64, device=DEV), _t(cell), order)
-    assert float((ones - 1).abs().max()) < 1e-12
+    assert float((ones - 1).abs().max()) < 1e-6  # weights <= 1e-8 are dropped by the gather (spline.py:608)
     field = torch.randn(dims, dtype=torch.float64, device=DEV)
     assert abs(float((mesh * field).sum() - (_t(q) * spline_gather(_t(pos), field, _t(cell), order)).sum())) < 1e-9
 
