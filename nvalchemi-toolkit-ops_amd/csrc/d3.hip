@@ -9,8 +9,10 @@
 //     thread looping over a row; per-lane fp64 partial sums are combined with cross-lane shuffles at the end.
 //   * pass 0 of the reference (materialised cartesian_shifts, 12 B per slot written then read 3x) is gone:
 //     S.cell is evaluated in registers in the positions dtype (`_unit_shift_to_cartesian`, :734).
-//   * {c6, cn_ref_i, cn_ref_j^T} are re-packed once per call into one float4 per (Zi,Zj,p,q): 25 x 16 B loads per
-//     pair per loop instead of 75 x 4 B gathers.
+//   * {c6, cn_ref_i, cn_ref_j^T} are re-packed once per call into one float4 per (Zi,Zj,p,q); the species actually present
+//     are compacted on the device (no host sync) and each wave stages the <= 16 x 25 float4 rows of ITS element in LDS,
+//     so the 25-term Gaussian interpolation reads ds_read_b128 (conflict-free: 400 B row stride) instead of chasing
+//     dependent global gathers; the term loop is branch-free (selects), exponent arguments stay in registers.
 //   * per-system energy / virial: per-atom values + wave-aggregated atomics (one atomic per 64 atoms) instead of one
 //     atomic per atom on B hot addresses.
 #include "common.h"
@@ -117,30 +119,95 @@ __device__ __forceinline__ void d3_s5(float r, float on, float off, float inv_w,
   dsw = (-30.0f * t2 + 60.0f * t3 - 30.0f * t4) * inv_w;
 }
 
-// `_c6ab_interpolate` (dftd3.py:427-547) on the packed table
+#define D3_SMAX 16  // species held in LDS per wave (16 x 25 float4 = 6.4 KB); more species fall back to the global table
+
+struct D3Species { int S; int pad[3]; };
+
+__global__ void d3_mark_species_kernel(const int* __restrict__ numbers, int N, int nz, int* __restrict__ present) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  const int z = numbers[i];
+  if (z > 0 && z < nz) present[z] = 1;  // benign race: every writer stores 1
+}
+// one block: compact ids of the species present, then the dense [S][S][25] table of {c6, cn_ref_i, cn_ref_j^T}
+__global__ void d3_compact_species_kernel(const int* __restrict__ present, const float* __restrict__ c6ab, const float* __restrict__ cnref, int nz,
+                                          int* __restrict__ smap, D3Species* __restrict__ info, float4* __restrict__ ctab) {
+  __shared__ int zlist[D3_SMAX];
+  __shared__ int count;
+  if (threadIdx.x == 0) {
+    int S = 0;
+    for (int z = 0; z < nz; ++z) {
+      if (z > 0 && present[z]) { smap[z] = S < D3_SMAX ? S : -1; if (S < D3_SMAX) zlist[S] = z; ++S; }
+      else smap[z] = -1;
+    }
+    count = S;
+    info->S = S;
+  }
+  __syncthreads();
+  const int S = count;
+  if (S > D3_SMAX) return;
+  for (int k = threadIdx.x; k < S * S * 25; k += blockDim.x) {
+    const int pq = k % 25, p = pq / 5, q = pq % 5, sj = (k / 25) % S, si = k / (25 * S);
+    const int zi = zlist[si], zj = zlist[sj];
+    const size_t a = ((size_t)zi * nz + zj) * 25 + pq, b = (((size_t)zj * nz + zi) * 5 + q) * 5 + p;
+    ctab[k] = make_float4(c6ab[a], cnref[a], cnref[b], 0.0f);
+  }
+}
+
+// `_c6ab_interpolate` (dftd3.py:427-547) on 25 packed terms {c6, cn_ref_i, cn_ref_j}.  Branch-free: the reference's
+// `continue`s (c6 == 0, exp_arg - max < -12) become selects, so every lane runs the same 25 + 25 steps with no
+// load -> branch -> load dependency; exponent arguments are kept in registers between the max pass and the sum pass.
+// exp(x) for x in [-12, 0] (the only range the interpolation needs): 2^(x log2 e) on the hardware v_exp_f32 with the
+// rounding error of the product x*log2(e) compensated (two FMAs), ~1-2 ulp like libm's expf but without the range
+// reduction / overflow-underflow selects that this argument range never needs.
+__device__ __forceinline__ float d3_exp_neg(float x) {
+  const float L2E_HI = 1.44269502e+00f, L2E_LO = 1.92596299e-08f, LN2 = 6.93147182e-01f;
+  const float t = x * L2E_HI;
+  float lo = fmaf(x, L2E_HI, -t);
+  lo = fmaf(x, L2E_LO, lo);
+  const float e = __builtin_amdgcn_exp2f(t);
+  return fmaf(e, lo * LN2, e);
+}
+
 __device__ __forceinline__ void d3_c6(float cn_i, float cn_j, const float4* __restrict__ t25, float k3, float& c6, float& dci) {
+  float a[25];
   float mx = -1e20f;
-#pragma unroll 5
-  for (int t = 0; t < 25; ++t) {
-    const float4 v = t25[t];
-    if (v.x == 0.0f) continue;
-    const float di = cn_i - v.y, dj = cn_j - v.z;
-    const float a = k3 * (di * di + dj * dj);
-    mx = a > mx ? a : mx;
+#pragma unroll
+  for (int c = 0; c < 5; ++c) {  // 5 terms per chunk: bounds the registers the scheduler may spend on hoisted table reads
+    float4 v[5];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) v[k] = t25[5 * c + k];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+      const float di = cn_i - v[k].y, dj = cn_j - v[k].z;
+      const float sq = di * di + dj * dj;
+      a[5 * c + k] = k3 * sq;
+      mx = (v[k].x != 0.0f && a[5 * c + k] > mx) ? a[5 * c + k] : mx;
+    }
+    __builtin_amdgcn_sched_barrier(0);
   }
   float w = 0.0f, z = 0.0f, wdi = 0.0f, zdi = 0.0f;
-#pragma unroll 5
-  for (int t = 0; t < 25; ++t) {
-    const float4 v = t25[t];
-    if (v.x == 0.0f) continue;
-    const float di = cn_i - v.y, dj = cn_j - v.z;
-    const float a = k3 * (di * di + dj * dj) - mx;
-    if (a < -12.0f) continue;
-    const float L = expf(a);
-    w += L;
-    z += v.x * L;
-    wdi += L * di;
-    zdi += v.x * L * di;
+#pragma unroll
+  for (int c = 0; c < 5; ++c) {
+    float2 v[5];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) v[k] = *reinterpret_cast<const float2*>(&t25[5 * c + k]);  // {c6, cn_ref_i}
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+      const float di = cn_i - v[k].y;
+      const float arg = a[5 * c + k] - mx;
+      const bool keep = (v[k].x != 0.0f) && !(arg < -12.0f);
+      // wave-uniform skip: a term no lane keeps costs nothing (typically only a few of the 25 reference points are
+      // within e^-12 of the dominant one); lanes that do not keep it add exact zeros, as the reference's `continue` does
+      if (__builtin_amdgcn_ballot_w64(keep) == 0) continue;
+      const float L = keep ? d3_exp_neg(arg) : 0.0f;
+      const float cL = v[k].x * L;
+      w += L;
+      z += cL;
+      wdi += L * di;
+      zdi += cL * di;
+    }
+    __builtin_amdgcn_sched_barrier(0);
   }
   if (w > 1e-12f) {
     const float wi = 1.0f / w;
@@ -153,12 +220,18 @@ __device__ __forceinline__ void d3_c6(float cn_i, float cn_j, const float4* __re
 }
 
 // ---- pass 2: energy, direct force, dE/dCN ------------------------------------------------------------
-template <class T, bool CSR>
+template <class T, bool CSR, bool LDS>
 __global__ __launch_bounds__(256) void d3_energy_kernel(const T* __restrict__ pos, const int* __restrict__ numbers, int N, const int* __restrict__ idx,
                                                         const int* __restrict__ ush, const int* __restrict__ nptr, int M, int fill_value,
                                                         const T* __restrict__ cell, const int* __restrict__ batch_idx, D3Dev P,
-                                                        const float* __restrict__ cn, int want_virial, float* __restrict__ dEdCN,
-                                                        float* __restrict__ forces, float* __restrict__ e_atom, float* __restrict__ v_atom) {
+                                                        const float* __restrict__ cn, int want_virial, const int* __restrict__ smap,
+                                                        const D3Species* __restrict__ sinfo, const float4* __restrict__ ctab,
+                                                        float* __restrict__ dEdCN, float* __restrict__ forces, float* __restrict__ e_atom,
+                                                        float* __restrict__ v_atom) {
+  __shared__ float4 lds_tab[LDS ? 4 : 1][LDS ? D3_SMAX * 25 : 1];
+  // both variants are launched; the one that does not match the species count on the device exits at once (no host sync)
+  const int S = sinfo->S;
+  if ((S <= D3_SMAX) != LDS) return;
   const int lane = threadIdx.x & (MI_WAVE - 1);
   const int i = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x / MI_WAVE) + threadIdx.x / MI_WAVE);
   if (i >= N) return;
@@ -170,6 +243,12 @@ __global__ __launch_bounds__(256) void d3_energy_kernel(const T* __restrict__ po
   const T pix = pos[3 * (size_t)i], piy = pos[3 * (size_t)i + 1], piz = pos[3 * (size_t)i + 2];
   const float cn_i = cn[i], r4r2_i = P.r4r2[zi];
   const float4* __restrict__ tab_i = P.tab + (size_t)zi * P.nz * 25;
+  // stage this element's rows of the compact species table in the wave's private LDS slice
+  float4* my_tab = lds_tab[LDS ? (threadIdx.x / MI_WAVE) & 3 : 0];
+  if (LDS) {
+    const float4* __restrict__ src = ctab + (size_t)smap[zi] * S * 25;
+    for (int k = lane; k < S * 25; k += MI_WAVE) my_tab[k] = src[k];
+  }
   long long beg, end;
   d3_row<T, CSR>(i, M, nptr, beg, end);
   double Fx = 0, Fy = 0, Fz = 0, E = 0;
@@ -183,7 +262,7 @@ __global__ __launch_bounds__(256) void d3_energy_kernel(const T* __restrict__ po
     const PairGeom<T> g = d3_geom<T>(pos, pix, piy, piz, j, ush, e, cm, periodic);
     if (!g.ok) continue;
     float c6, dci;
-    d3_c6(cn_i, cn[j], tab_i + (size_t)zj * 25, P.k3, c6, dci);
+    d3_c6(cn_i, cn[j], LDS ? my_tab + smap[zj] * 25 : tab_i + (size_t)zj * 25, P.k3, c6, dci);
     if (c6 < 1e-12f) continue;
     // `_bj_damping` (dftd3.py:648-687)
     const float r = g.r;
@@ -315,7 +394,7 @@ __global__ void d3_reduce_kernel(const float* __restrict__ e_atom, const float* 
   }
 }
 
-struct D3Layout { size_t dEdCN, e_atom, v_atom, tab, total; };
+struct D3Layout { size_t dEdCN, e_atom, v_atom, tab, present, smap, sinfo, ctab, total; };
 D3Layout d3_layout(int N, int nz) {
   D3Layout L;
   size_t o = 0;
@@ -324,6 +403,10 @@ D3Layout d3_layout(int N, int nz) {
   L.e_atom = take(sizeof(float) * (size_t)N);
   L.v_atom = take(sizeof(float) * 9 * (size_t)N);
   L.tab = take(sizeof(float4) * (size_t)nz * nz * 25);
+  L.present = take(sizeof(int) * (size_t)nz);
+  L.smap = take(sizeof(int) * (size_t)nz);
+  L.sinfo = take(sizeof(D3Species));
+  L.ctab = take(sizeof(float4) * D3_SMAX * D3_SMAX * 25);
   L.total = o;
   return L;
 }
@@ -336,6 +419,10 @@ int d3_impl(const T* pos, const int* numbers, int N, const int* idx, const int* 
   float* e_atom = reinterpret_cast<float*>(ws + L.e_atom);
   float* v_atom = reinterpret_cast<float*>(ws + L.v_atom);
   float4* tab = reinterpret_cast<float4*>(ws + L.tab);
+  int* present = reinterpret_cast<int*>(ws + L.present);
+  int* smap = reinterpret_cast<int*>(ws + L.smap);
+  D3Species* sinfo = reinterpret_cast<D3Species*>(ws + L.sinfo);
+  float4* ctab = reinterpret_cast<float4*>(ws + L.ctab);
   D3Dev P;
   P.rcov = hp->rcov; P.r4r2 = hp->r4r2; P.tab = tab; P.nz = hp->nz;
   P.a1 = hp->a1; P.a2 = hp->a2; P.s6 = hp->s6; P.s8 = hp->s8; P.k1 = hp->k1; P.k3 = hp->k3; P.s5_on = hp->s5_on; P.s5_off = hp->s5_off;
@@ -354,11 +441,19 @@ int d3_impl(const T* pos, const int* numbers, int N, const int* idx, const int* 
   const long long nt = (long long)hp->nz * hp->nz * 25;
   d3_pack_tables_kernel<<<mi_blocks(nt, 256), 256, 0, st>>>(hp->c6ab, hp->cn_ref, hp->nz, tab);
   MI_LAUNCH_CHECK();
+  MI_HIP_CHECK(hipMemsetAsync(present, 0, sizeof(int) * (size_t)hp->nz, st));
+  d3_mark_species_kernel<<<mi_blocks(N, 256), 256, 0, st>>>(numbers, N, hp->nz, present);
+  MI_LAUNCH_CHECK();
+  d3_compact_species_kernel<<<1, 256, 0, st>>>(present, hp->c6ab, hp->cn_ref, hp->nz, smap, sinfo, ctab);
+  MI_LAUNCH_CHECK();
   const int blocks = mi_blocks(N, 4);
   MI_TIMED("d3_cn", st, (d3_cn_kernel<T, CSR><<<blocks, 256, 0, st>>>(pos, numbers, N, idx, ush, nptr, M, fill_value, cell, batch_idx, P, cn)));
   MI_LAUNCH_CHECK();
-  MI_TIMED("d3_energy", st, (d3_energy_kernel<T, CSR><<<blocks, 256, 0, st>>>(pos, numbers, N, idx, ush, nptr, M, fill_value, cell, batch_idx, P, cn,
-                                                                              want_virial, dEdCN, forces, e_atom, v_atom)));
+  MI_TIMED("d3_energy", st, (d3_energy_kernel<T, CSR, true><<<blocks, 256, 0, st>>>(pos, numbers, N, idx, ush, nptr, M, fill_value, cell, batch_idx, P,
+                                                                                    cn, want_virial, smap, sinfo, ctab, dEdCN, forces, e_atom, v_atom)));
+  MI_LAUNCH_CHECK();
+  d3_energy_kernel<T, CSR, false><<<blocks, 256, 0, st>>>(pos, numbers, N, idx, ush, nptr, M, fill_value, cell, batch_idx, P, cn, want_virial, smap,
+                                                          sinfo, ctab, dEdCN, forces, e_atom, v_atom);
   MI_LAUNCH_CHECK();
   MI_TIMED("d3_chain", st, (d3_chain_kernel<T, CSR><<<blocks, 256, 0, st>>>(pos, numbers, N, idx, ush, nptr, M, fill_value, cell, batch_idx, P, dEdCN,
                                                                             want_virial, forces, v_atom)));

@@ -1,0 +1,60 @@
+"""Batch (system-level) data parallelism over the GPUs of one node -- the one parallel axis of this path.
+
+The reference has no multi-GPU code at all.  Every kernel of the hot path touches per-system
+data only through ``batch_idx[atom]``, so a batch of independent systems shards embarrassingly: contiguous ranges of
+systems per rank (balanced by atom count), rank-local neighbour lists / D3 / PME with no data-path communication, and
+ONE collective per step -- an RCCL all_gather (``backend="nccl"`` is RCCL on ROCm; ``gloo`` works for CPU tests) of the
+per-system energies, <= 4 KiB for 1024 systems, latency-bound over xGMI.  Forces and neighbour lists stay sharded.
+"""
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+
+
+def partition_systems(atoms_per_system, world_size: int) -> list[tuple[int, int]]:
+    """Contiguous system ranges [s0, s1) per rank with near-equal atom counts (greedy prefix split)."""
+    counts = [int(c) for c in atoms_per_system]
+    total = sum(counts)
+    bounds, acc, s = [0], 0, 0
+    for r in range(1, world_size):
+        target = total * r / world_size
+        while s < len(counts) and acc + counts[s] / 2.0 <= target:
+            acc += counts[s]
+            s += 1
+        bounds.append(s)
+    bounds.append(len(counts))
+    return [(bounds[r], bounds[r + 1]) for r in range(world_size)]
+
+
+def shard_batch(batch_ptr: torch.Tensor, rank: int, world_size: int, *per_atom: torch.Tensor, per_system: tuple[torch.Tensor, ...] = ()):
+    """Slice per-atom and per-system tensors for `rank`.  Returns (s0, s1, a0, a1, local_batch_idx, per_atom_slices,
+    per_system_slices); `local_batch_idx` restarts at 0 and neighbour indices computed from the slices are rank-local."""
+    ptr = batch_ptr.tolist()
+    counts = [ptr[i + 1] - ptr[i] for i in range(len(ptr) - 1)]
+    s0, s1 = partition_systems(counts, world_size)[rank]
+    a0, a1 = ptr[s0], ptr[s1]
+    dev = per_atom[0].device if per_atom else batch_ptr.device
+    local_counts = torch.tensor(counts[s0:s1], dtype=torch.long, device=dev)
+    local_idx = torch.repeat_interleave(torch.arange(s1 - s0, dtype=torch.int32, device=dev), local_counts)
+    return s0, s1, a0, a1, local_idx, tuple(t[a0:a1] for t in per_atom), tuple(t[s0:s1] for t in per_system)
+
+
+def all_gather_system_values(local: torch.Tensor, systems_per_rank: list[int], group=None) -> torch.Tensor:
+    """One all_gather of per-system values ([B_local, ...] -> [B, ...]); ragged shards are padded to the largest."""
+    world = dist.get_world_size(group)
+    width = max(systems_per_rank)
+    pad = torch.zeros((width,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    pad[: local.shape[0]] = local
+    out = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(out, pad, group=group)
+    return torch.cat([o[:n] for o, n in zip(out, systems_per_rank)], dim=0)
+
+
+def segment_energy(per_atom_energy: torch.Tensor, local_batch_idx: torch.Tensor, num_local_systems: int) -> torch.Tensor:
+    """Per-system sum of per-atom energies (PME returns energies per atom, D3 per system: SURVEY F10)."""
+    out = torch.zeros(num_local_systems, dtype=per_atom_energy.dtype, device=per_atom_energy.device)
+    return out.index_add_(0, local_batch_idx.long(), per_atom_energy)
+
+
+__all__ = ["partition_systems", "shard_batch", "all_gather_system_values", "segment_energy"]

@@ -41,7 +41,8 @@ def fcc_box(n_atoms, a=4.0, jitter=0.05, seed=1234, dtype=np.float32):
     g = np.random.default_rng(seed)
     pos = sites * a + g.normal(0.0, jitter, sites.shape)
     cell = np.eye(3) * (nc * a)
-    par = (np.floor(sites * 2).astype(np.int64).sum(1)) % 2
+    # FCC is not bipartite: alternate by (i + j + k + basis index) as the reference benchmark generator does
+    par = (ijk.sum(1)[:, None] + np.arange(4)[None, :]).reshape(-1)[:n_atoms] % 2
     q = np.where(par == 0, 1.0, -1.0)
     q[-1] -= q.sum()  # neutral
     numbers = np.where(par == 0, 6, 8).astype(np.int32)

@@ -1,0 +1,189 @@
+"""CPU-side tests (`-m "not gpu"`): the C ABI library loads and exports every symbol the header declares, host-side API
+logic (validation, empty inputs, parameter estimation, dispatcher rules), the no-CPU-fallback guarantee, and the
+world_size-2 gloo test of the batch-sharding path."""
+import math
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+
+from tests import systems as S
+
+
+def test_library_exports_every_declared_symbol():
+    from nvalchemiops import _capi
+    from tools.abi_symbols import declared_symbols
+
+    lib = _capi.lib()
+    names = declared_symbols()
+    assert len(names) >= 18
+    for name in names:
+        assert hasattr(lib, name), f"{name} declared in include/nvalchemiops_hip.h but not exported"
+    assert lib.mi_version() == 1
+    assert lib.mi_nl_workspace_bytes(100000, 1, 0) > 0
+
+
+def test_no_cpu_fallback():
+    from nvalchemiops._capi import NativeLibraryError
+    from nvalchemiops.interactions.dispersion import D3Parameters, dftd3
+    from nvalchemiops.interactions.electrostatics import ewald_real_space, pme_reciprocal_space
+    from nvalchemiops.neighborlist import cell_list, neighbor_list
+
+    pos = torch.rand(10, 3)
+    cell, pbc = torch.eye(3) * 5, torch.tensor([True] * 3)
+    with pytest.raises(NativeLibraryError):
+        cell_list(pos, 1.0, cell, pbc)
+    with pytest.raises(NativeLibraryError):
+        neighbor_list(pos, 1.0)
+    p = D3Parameters(rcov=torch.rand(5), r4r2=torch.rand(5), c6ab=torch.rand(5, 5, 5, 5), cn_ref=torch.rand(5, 5, 5, 5))
+    with pytest.raises(NativeLibraryError):
+        dftd3(pos, torch.ones(10, dtype=torch.int32), 0.4, 4.0, 0.8, d3_params=p, neighbor_matrix=torch.zeros((10, 4), dtype=torch.int32))
+    with pytest.raises(NativeLibraryError):
+        pme_reciprocal_space(pos, torch.rand(10), cell, 0.3, mesh_dimensions=(8, 8, 8))
+    with pytest.raises(NativeLibraryError):
+        ewald_real_space(pos, torch.rand(10), cell, torch.tensor([0.3]), neighbor_matrix=torch.zeros((10, 4), dtype=torch.int32))
+
+
+def test_empty_inputs_and_shapes():
+    from nvalchemiops.neighborlist import batch_cell_list, cell_list, naive_neighbor_list
+
+    cell, pbc = torch.eye(3), torch.tensor([True] * 3)
+    nm, num, sh = cell_list(torch.zeros(0, 3), 2.0, cell, pbc)
+    assert nm.shape == (0, 0) and num.shape == (0,) and sh.shape == (0, 0, 3)
+    lst, ptr, lsh = cell_list(torch.zeros(0, 3), 2.0, cell, pbc, return_neighbor_list=True)
+    assert lst.shape == (2, 0) and ptr.shape == (1,) and lsh.shape == (0, 3)
+    nm, num, sh = cell_list(torch.zeros(4, 3), 0.0, cell, pbc)  # cutoff <= 0
+    assert nm.shape == (4, 0) and num.tolist() == [0] * 4 and (nm == 4).all()
+    nm, num, sh = batch_cell_list(torch.zeros(0, 3), 2.0, cell[None], pbc[None], torch.zeros(0, dtype=torch.int32))
+    assert nm.shape == (0, 0)
+    nm, num = naive_neighbor_list(torch.zeros(3, 3), 0.0, max_neighbors=4)
+    assert nm.shape == (3, 4) and (nm == 3).all() and num.tolist() == [0, 0, 0]
+    with pytest.raises(ValueError):
+        naive_neighbor_list(torch.zeros(3, 3), 1.0, cell=cell)
+    from nvalchemiops.neighborlist import neighbor_list
+
+    with pytest.raises(ValueError):
+        neighbor_list(torch.zeros(3, 3), 1.0, method="nope")
+    with pytest.raises(NotImplementedError):
+        neighbor_list(torch.zeros(3, 3), 1.0, cutoff2=2.0)
+
+
+def test_estimate_max_neighbors_and_overflow_error():
+    from nvalchemiops.neighborlist import NeighborOverflowError, estimate_max_neighbors
+
+    assert estimate_max_neighbors(5.0) == 928 and estimate_max_neighbors(6.0) == 1584 and estimate_max_neighbors(0.0) == 0
+    assert estimate_max_neighbors(21.2) == 69856
+    assert "12 > 8" in str(NeighborOverflowError(8, 12))
+
+
+def test_pme_parameter_estimation_matches_formulas():
+    from nvalchemiops.interactions.electrostatics import (estimate_ewald_parameters, estimate_pme_mesh_dimensions, estimate_pme_parameters,
+                                                          mesh_spacing_to_dimensions)
+
+    pos = torch.randn(100, 3, dtype=torch.float64)
+    cell = torch.eye(3, dtype=torch.float64) * 20.0
+    p = estimate_ewald_parameters(pos, cell, accuracy=1e-6)
+    eta = (8000.0**2 / 100) ** (1 / 6) / math.sqrt(2 * math.pi)
+    assert abs(p.alpha.item() - 1 / (math.sqrt(2) * eta)) < 1e-12
+    assert abs(p.real_space_cutoff.item() - math.sqrt(-2 * math.log(1e-6)) * eta) < 1e-12
+    assert abs(p.reciprocal_space_cutoff.item() - math.sqrt(-2 * math.log(1e-6)) / eta) < 1e-12
+    q = estimate_pme_parameters(pos, cell)
+    want = 2 ** math.ceil(math.log2(2 * q.alpha.item() * 20.0 / (3 * 1e-6**0.2)))
+    assert q.mesh_dimensions == (want,) * 3
+    assert estimate_pme_mesh_dimensions(cell, torch.tensor([0.3], dtype=torch.float64)) == (64, 64, 64)  # docstring example of the reference
+    assert mesh_spacing_to_dimensions(cell, 0.9) == (32, 32, 32)
+    # batch: per-system atom counts through batch_idx
+    cells = torch.stack([cell, cell * 2])
+    bi = torch.tensor([0] * 40 + [1] * 60, dtype=torch.int32)
+    pb = estimate_ewald_parameters(pos, cells, bi)
+    eta1 = ((8000.0 * 8) ** 2 / 60) ** (1 / 6) / math.sqrt(2 * math.pi)
+    assert abs(pb.alpha[1].item() - 1 / (math.sqrt(2) * eta1)) < 1e-12
+
+
+def test_k_vectors_match_numpy():
+    from nvalchemiops.interactions.electrostatics import generate_k_vectors_pme
+    from oracle import oracle as O
+
+    cell = np.array([[10.0, 0, 0], [2, 9, 0], [1, -1, 11]])
+    kv, k2 = generate_k_vectors_pme(torch.as_tensor(cell), (8, 6, 10))
+    okv, ok2 = O.generate_k_vectors_pme(cell, (8, 6, 10))
+    assert kv.shape == (8, 6, 6, 3)
+    np.testing.assert_allclose(kv.numpy(), okv, rtol=1e-13, atol=1e-14)
+    np.testing.assert_allclose(k2.numpy(), ok2, rtol=1e-13, atol=1e-14)
+
+
+def test_d3_parameter_validation_and_dispatch_rules():
+    from nvalchemiops.interactions.dispersion import D3Parameters, dftd3
+
+    with pytest.raises(ValueError):
+        D3Parameters(rcov=torch.rand(1), r4r2=torch.rand(1), c6ab=torch.rand(1, 1, 5, 5), cn_ref=torch.rand(1, 1, 5, 5))
+    with pytest.raises(TypeError):
+        D3Parameters(rcov=torch.rand(5).int(), r4r2=torch.rand(5), c6ab=torch.rand(5, 5, 5, 5), cn_ref=torch.rand(5, 5, 5, 5))
+    p = D3Parameters(rcov=torch.rand(5), r4r2=torch.rand(5), c6ab=torch.rand(5, 5, 5, 5), cn_ref=torch.rand(5, 5, 5, 5))
+    assert p.max_z == 4 and p.to(dtype=torch.float64).c6ab.dtype == torch.float64
+    pos, z = torch.zeros(2, 3), torch.ones(2, dtype=torch.int32)
+    nm = torch.zeros((2, 2), dtype=torch.int32)
+    with pytest.raises(ValueError):
+        dftd3(pos, z, 0.4, 4.0, 0.8, d3_params=p, neighbor_matrix=nm, neighbor_list=nm)
+    with pytest.raises(ValueError):
+        dftd3(pos, z, 0.4, 4.0, 0.8, d3_params=p, neighbor_list=nm)  # neighbor_ptr missing
+    with pytest.raises(RuntimeError):
+        dftd3(pos, z, 0.4, 4.0, 0.8, neighbor_matrix=nm)
+    e, f, cn, v = dftd3(torch.zeros(0, 3), torch.zeros(0, dtype=torch.int32), 0.4, 4.0, 0.8, d3_params=p, neighbor_matrix=torch.zeros((0, 2), dtype=torch.int32),
+                        cell=torch.eye(3)[None], neighbor_matrix_shifts=torch.zeros((0, 2, 3), dtype=torch.int32), compute_virial=True)
+    assert e.shape == (1,) and f.shape == (0, 3) and v.shape == (0, 3, 3)
+
+
+def test_partition_systems_balances_atoms():
+    from nvalchemiops.distributed import partition_systems
+
+    parts = partition_systems([2000] * 1024, 8)
+    assert parts == [(128 * r, 128 * (r + 1)) for r in range(8)]
+    ragged = [10, 500, 20, 30, 400, 40, 5, 5]
+    p2 = partition_systems(ragged, 2)
+    assert p2[0][0] == 0 and p2[-1][1] == len(ragged) and p2[0][1] == p2[1][0]
+    assert abs(sum(ragged[: p2[0][1]]) - sum(ragged) / 2) <= 250
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _gloo_worker(rank, world, port, out):
+    import torch.distributed as dist
+
+    from nvalchemiops.distributed import all_gather_system_values, segment_energy, shard_batch
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    counts = [3, 5, 2, 4, 6]
+    ptr = torch.tensor(np.concatenate([[0], np.cumsum(counts)]), dtype=torch.int32)
+    n = int(ptr[-1])
+    per_atom_e = torch.arange(n, dtype=torch.float64)
+    s0, s1, a0, a1, local_idx, (e_loc,), (cells,) = shard_batch(ptr, rank, world, per_atom_e, per_system=(torch.arange(5.0)[:, None],))
+    assert cells.shape[0] == s1 - s0 and local_idx.shape[0] == a1 - a0 and (local_idx.max().item() == s1 - s0 - 1)
+    local_sys = segment_energy(e_loc, local_idx, s1 - s0)
+    from nvalchemiops.distributed import partition_systems
+
+    sizes = [b - a for a, b in partition_systems(counts, world)]
+    full = all_gather_system_values(local_sys, sizes)
+    expect = torch.tensor([per_atom_e[ptr[i]:ptr[i + 1]].sum() for i in range(5)], dtype=torch.float64)
+    ok = torch.allclose(full, expect)
+    out[rank] = bool(ok)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gloo_world2_energy_gather():
+    """N > 1 path on CPU: shard a ragged batch over 2 ranks, reduce per-system energies locally, one all_gather."""
+    import torch.multiprocessing as mp
+
+    port = _free_port()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_gloo_worker, args=(2, port, out), nprocs=2, join=True)
+    assert out.get(0) is True and out.get(1) is True

@@ -79,7 +79,7 @@ def test_spline_high_order_properties(order):
     ones = spline_gather(_t(pos), torch.ones(dims, dtype=torch.float64, device=DEV), _t(cell), order)
     assert float((ones - 1).abs().max()) < 1e-6  # weights <= 1e-8 are dropped by the gather (spline.py:608)
     field = torch.randn(dims, dtype=torch.float64, device=DEV)
-    assert abs(float((mesh * field).sum() - (_t(q) * spline_gather(_t(pos), field, _t(cell), order)).sum())) < 1e-9
+    assert abs(float((mesh * field).sum() - (_t(q) * spline_gather(_t(pos), field, _t(cell), order)).sum())) < 1e-6  # gather drops w <= 1e-8
 
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
