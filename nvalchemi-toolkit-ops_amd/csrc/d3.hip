@@ -41,16 +41,34 @@ __global__ void d3_pack_tables_kernel(const float* __restrict__ c6ab, const floa
 }
 
 template <class T> struct PairGeom { float r, rinv, rx, ry, rz; bool ok; };
+struct Int3 { int a, b, c; };  // one 12-byte (dwordx3) load per pair for the unit shift
+
+// Per-atom records gathered by neighbour index j: ONE 16/32-byte load instead of x, y, z, Z, rcov as five gathers.
+//   apos[j] = {x, y, z, rcov[Z_j]}   (w < 0 flags a padding atom, Z_j == 0)      in the positions dtype
+//   aaux[j] = {CN_j, r4r2[Z_j], bits(Z_j << 8 | compact species id), 0}
+template <class T>
+__global__ void d3_pack_atoms_kernel(const T* __restrict__ pos, const int* __restrict__ numbers, int N, const float* __restrict__ rcov,
+                                     const float* __restrict__ r4r2, const int* __restrict__ smap, int nz,
+                                     typename Vec4<T>::type* __restrict__ apos, float4* __restrict__ aaux) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  const int z = numbers[i];
+  const bool real = z > 0 && z < nz;
+  typename Vec4<T>::type r;
+  r.x = pos[3 * (size_t)i]; r.y = pos[3 * (size_t)i + 1]; r.z = pos[3 * (size_t)i + 2];
+  r.w = real ? (T)rcov[z] : (T)-1;
+  apos[i] = r;
+  const int sj = real ? smap[z] : -1;
+  aaux[i] = make_float4(0.0f, real ? r4r2[z] : 0.0f, __int_as_float((z << 8) | (sj & 0xff)), 0.0f);
+}
 
 // `_compute_distance_vector_pbc` (dftd3.py:551-604): native-dtype difference (+ shift), cast to fp32, length, r<1e-12 skip
-template <class T>
-__device__ __forceinline__ PairGeom<T> d3_geom(const T* __restrict__ pos, T pix, T piy, T piz, int j, const int* __restrict__ ush, long long e,
-                                                const T* __restrict__ cm, bool periodic) {
+template <class T, class V4>
+__device__ __forceinline__ PairGeom<T> d3_geom(const V4& pj, T pix, T piy, T piz, const Int3& sh, const T* __restrict__ cm, bool periodic) {
   PairGeom<T> g;
-  const T pjx = pos[3 * (size_t)j], pjy = pos[3 * (size_t)j + 1], pjz = pos[3 * (size_t)j + 2];
-  T dx = pjx - pix, dy = pjy - piy, dz = pjz - piz;
+  T dx = pj.x - pix, dy = pj.y - piy, dz = pj.z - piz;
   if (periodic) {
-    const T fs[3] = {(T)ush[3 * e], (T)ush[3 * e + 1], (T)ush[3 * e + 2]};
+    const T fs[3] = {(T)sh.a, (T)sh.b, (T)sh.c};
     T cart[3];
     rowvec_mat3(fs, cm, cart);
     dx = dx + cart[0]; dy = dy + cart[1]; dz = dz + cart[2];
@@ -81,6 +99,7 @@ template <class T, bool CSR>
 __global__ __launch_bounds__(256) void d3_cn_kernel(const T* __restrict__ pos, const int* __restrict__ numbers, int N, const int* __restrict__ idx,
                                                     const int* __restrict__ ush, const int* __restrict__ nptr, int M, int fill_value,
                                                     const T* __restrict__ cell, const int* __restrict__ batch_idx, D3Dev P,
+                                                    const typename Vec4<T>::type* __restrict__ apos, float4* __restrict__ aaux,
                                                     float* __restrict__ cn) {
   const int lane = threadIdx.x & (MI_WAVE - 1);
   const int i = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x / MI_WAVE) + threadIdx.x / MI_WAVE);
@@ -97,17 +116,29 @@ __global__ __launch_bounds__(256) void d3_cn_kernel(const T* __restrict__ pos, c
   // the reference sums in fp32 sequentially (dftd3.py:911); lanes hold fp64 partials here so the result is the
   // correctly rounded sum whatever the lane/iteration order
   double acc = 0.0;
-  for (long long e = beg + lane; e < end; e += MI_WAVE) {
-    const int j = idx[e];
-    if (!CSR && j >= fill_value) continue;
-    const int zj = numbers[j];
-    if (zj == 0) continue;
-    const PairGeom<T> g = d3_geom<T>(pos, pix, piy, piz, j, ush, e, cm, periodic);
-    if (!g.ok) continue;
-    acc += (double)d3_cn_count(g.rinv, rci, P.rcov[zj], P.k1, nullptr);
+  // Software-pipelined row walk: index + unit shift of step k+1 are requested before step k is evaluated, and validity is
+  // a predicate instead of a branch, so the loads of a step issue back-to-back (no load -> branch -> load chains).
+  const Int3* __restrict__ ush3 = reinterpret_cast<const Int3*>(ush);
+  long long e = beg + lane;
+  int jn = 0;
+  Int3 sn = {0, 0, 0};
+  if (e < end) { jn = idx[e]; if (periodic) sn = ush3[e]; }
+  for (long long base = beg; base < end; base += MI_WAVE) {
+    const int j = jn;
+    const Int3 sh = sn;
+    bool valid = (e < end) && (CSR || j < fill_value);
+    e += MI_WAVE;
+    if (e < end) { jn = idx[e]; if (periodic) sn = ush3[e]; }
+    if (!__any(valid)) continue;  // a step of pure padding (padded matrices are mostly padding)
+    const auto pj = apos[valid ? j : i];
+    valid = valid && !(pj.w < (T)0);  // padding atom (Z == 0)
+    const PairGeom<T> g = d3_geom<T>(pj, pix, piy, piz, sh, cm, periodic);
+    valid = valid && g.ok;
+    const float f = d3_cn_count(g.rinv, rci, (float)pj.w, P.k1, nullptr);
+    acc += valid ? (double)f : 0.0;
   }
   acc = wave_sum(acc);
-  if (lane == 0) cn[i] = (float)acc;
+  if (lane == 0) { cn[i] = (float)acc; aaux[i].x = (float)acc; }
 }
 
 // `_s5_switch` (dftd3.py:341-423)
@@ -226,6 +257,7 @@ __global__ __launch_bounds__(256) void d3_energy_kernel(const T* __restrict__ po
                                                         const T* __restrict__ cell, const int* __restrict__ batch_idx, D3Dev P,
                                                         const float* __restrict__ cn, int want_virial, const int* __restrict__ smap,
                                                         const D3Species* __restrict__ sinfo, const float4* __restrict__ ctab,
+                                                        const typename Vec4<T>::type* __restrict__ apos, const float4* __restrict__ aaux,
                                                         float* __restrict__ dEdCN, float* __restrict__ forces, float* __restrict__ e_atom,
                                                         float* __restrict__ v_atom) {
   __shared__ float4 lds_tab[LDS ? 4 : 1][LDS ? D3_SMAX * 25 : 1];
@@ -244,6 +276,7 @@ __global__ __launch_bounds__(256) void d3_energy_kernel(const T* __restrict__ po
   const float cn_i = cn[i], r4r2_i = P.r4r2[zi];
   const float4* __restrict__ tab_i = P.tab + (size_t)zi * P.nz * 25;
   // stage this element's rows of the compact species table in the wave's private LDS slice
+  const int code_i = (zi << 8) | (smap[zi] & 0xff);  // own species: a safe table row for masked-out lanes
   float4* my_tab = lds_tab[LDS ? (threadIdx.x / MI_WAVE) & 3 : 0];
   if (LDS) {
     const float4* __restrict__ src = ctab + (size_t)smap[zi] * S * 25;
@@ -254,19 +287,32 @@ __global__ __launch_bounds__(256) void d3_energy_kernel(const T* __restrict__ po
   double Fx = 0, Fy = 0, Fz = 0, E = 0;
   double V[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
   double dacc = 0.0;
-  for (long long e = beg + lane; e < end; e += MI_WAVE) {
-    const int j = idx[e];
-    if (!CSR && j >= fill_value) continue;
-    const int zj = numbers[j];
-    if (zj == 0) continue;
-    const PairGeom<T> g = d3_geom<T>(pos, pix, piy, piz, j, ush, e, cm, periodic);
-    if (!g.ok) continue;
+  // Software-pipelined row walk: index + unit shift of step k+1 are requested before step k is evaluated, and validity is
+  // a predicate instead of a branch, so the loads of a step issue back-to-back (no load -> branch -> load chains).
+  const Int3* __restrict__ ush3 = reinterpret_cast<const Int3*>(ush);
+  long long e = beg + lane;
+  int jn = 0;
+  Int3 sn = {0, 0, 0};
+  if (e < end) { jn = idx[e]; if (periodic) sn = ush3[e]; }
+  for (long long base = beg; base < end; base += MI_WAVE) {
+    const int j = jn;
+    const Int3 sh = sn;
+    bool valid = (e < end) && (CSR || j < fill_value);
+    e += MI_WAVE;
+    if (e < end) { jn = idx[e]; if (periodic) sn = ush3[e]; }
+    if (!__any(valid)) continue;  // a step of pure padding (padded matrices are mostly padding)
+    const auto pj = apos[valid ? j : i];
+    const float4 aj = aaux[valid ? j : i];  // {CN_j, r4r2_j, Z_j << 8 | species id}
+    valid = valid && !(pj.w < (T)0);  // padding atom (Z == 0)
+    const PairGeom<T> g = d3_geom<T>(pj, pix, piy, piz, sh, cm, periodic);
+    valid = valid && g.ok;
+    const int code = valid ? __float_as_int(aj.z) : code_i;
     float c6, dci;
-    d3_c6(cn_i, cn[j], LDS ? my_tab + smap[zj] * 25 : tab_i + (size_t)zj * 25, P.k3, c6, dci);
-    if (c6 < 1e-12f) continue;
+    d3_c6(cn_i, aj.x, LDS ? my_tab + (code & 0xff) * 25 : tab_i + (size_t)(code >> 8) * 25, P.k3, c6, dci);
+    valid = valid && !(c6 < 1e-12f);
     // `_bj_damping` (dftd3.py:648-687)
-    const float r = g.r;
-    const float q = 3.0f * r4r2_i * P.r4r2[zj];
+    const float r = valid ? g.r : 1.0f;
+    const float q = 3.0f * r4r2_i * aj.y;
     const float r0 = P.a1 * sqrtf(q) + P.a2;
     const float r2 = r * r, r4 = r2 * r2, r6 = r4 * r2, r8 = r4 * r4;
     const float r02 = r0 * r0, r04 = r02 * r02, r06 = r04 * r02, r08 = r04 * r04;
@@ -280,12 +326,12 @@ __global__ __launch_bounds__(256) void d3_energy_kernel(const T* __restrict__ po
     const float dEdr = -c6 * (d6 + d8);
     float sw, dsw;
     d3_s5(r, P.s5_on, P.s5_off, P.inv_w, sw, dsw);
-    const float esw = eij * sw;
-    const float dEsw = sw * dEdr + eij * dsw;
+    const float esw = valid ? eij * sw : 0.0f;
+    const float dEsw = valid ? sw * dEdr + eij * dsw : 0.0f;
     const float fx = dEsw * (g.rx * g.rinv), fy = dEsw * (g.ry * g.rinv), fz = dEsw * (g.rz * g.rinv);
     Fx += (double)fx; Fy += (double)fy; Fz += (double)fz;
     E += (double)esw;
-    dacc += (double)(-damp * dci);
+    dacc += valid ? (double)(-damp * dci) : 0.0;
     if (want_virial) {
       V[0] += (double)(fx * g.rx); V[1] += (double)(fx * g.ry); V[2] += (double)(fx * g.rz);
       V[3] += (double)(fy * g.rx); V[4] += (double)(fy * g.ry); V[5] += (double)(fy * g.rz);
@@ -316,8 +362,8 @@ template <class T, bool CSR>
 __global__ __launch_bounds__(256) void d3_chain_kernel(const T* __restrict__ pos, const int* __restrict__ numbers, int N, const int* __restrict__ idx,
                                                        const int* __restrict__ ush, const int* __restrict__ nptr, int M, int fill_value,
                                                        const T* __restrict__ cell, const int* __restrict__ batch_idx, D3Dev P,
-                                                       const float* __restrict__ dEdCN, int want_virial, float* __restrict__ forces,
-                                                       float* __restrict__ v_atom) {
+                                                       const typename Vec4<T>::type* __restrict__ apos, const float* __restrict__ dEdCN,
+                                                       int want_virial, float* __restrict__ forces, float* __restrict__ v_atom) {
   const int lane = threadIdx.x & (MI_WAVE - 1);
   const int i = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x / MI_WAVE) + threadIdx.x / MI_WAVE);
   if (i >= N) return;
@@ -332,16 +378,28 @@ __global__ __launch_bounds__(256) void d3_chain_kernel(const T* __restrict__ pos
   d3_row<T, CSR>(i, M, nptr, beg, end);
   double Fx = 0, Fy = 0, Fz = 0;
   double V[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-  for (long long e = beg + lane; e < end; e += MI_WAVE) {
-    const int j = idx[e];
-    if (!CSR && j >= fill_value) continue;
-    const int zj = numbers[j];
-    if (zj == 0) continue;
-    const PairGeom<T> g = d3_geom<T>(pos, pix, piy, piz, j, ush, e, cm, periodic);
-    if (!g.ok) continue;
+  // Software-pipelined row walk: index + unit shift of step k+1 are requested before step k is evaluated, and validity is
+  // a predicate instead of a branch, so the loads of a step issue back-to-back (no load -> branch -> load chains).
+  const Int3* __restrict__ ush3 = reinterpret_cast<const Int3*>(ush);
+  long long e = beg + lane;
+  int jn = 0;
+  Int3 sn = {0, 0, 0};
+  if (e < end) { jn = idx[e]; if (periodic) sn = ush3[e]; }
+  for (long long base = beg; base < end; base += MI_WAVE) {
+    const int j = jn;
+    const Int3 sh = sn;
+    bool valid = (e < end) && (CSR || j < fill_value);
+    e += MI_WAVE;
+    if (e < end) { jn = idx[e]; if (periodic) sn = ush3[e]; }
+    if (!__any(valid)) continue;  // a step of pure padding (padded matrices are mostly padding)
+    const auto pj = apos[valid ? j : i];
+    const float dj = dEdCN[valid ? j : i];
+    valid = valid && !(pj.w < (T)0);  // padding atom (Z == 0)
+    const PairGeom<T> g = d3_geom<T>(pj, pix, piy, piz, sh, cm, periodic);
+    valid = valid && g.ok;
     float dcn;
-    d3_cn_count(g.rinv, rci, P.rcov[zj], P.k1, &dcn);
-    const float dEdr = (di + dEdCN[j]) * dcn;
+    d3_cn_count(g.rinv, rci, (float)pj.w, P.k1, &dcn);
+    const float dEdr = valid ? (di + dj) * dcn : 0.0f;
     const float fx = dEdr * (g.rx * g.rinv), fy = dEdr * (g.ry * g.rinv), fz = dEdr * (g.rz * g.rinv);
     Fx += (double)fx; Fy += (double)fy; Fz += (double)fz;
     if (want_virial) {
@@ -394,8 +452,8 @@ __global__ void d3_reduce_kernel(const float* __restrict__ e_atom, const float* 
   }
 }
 
-struct D3Layout { size_t dEdCN, e_atom, v_atom, tab, present, smap, sinfo, ctab, total; };
-D3Layout d3_layout(int N, int nz) {
+struct D3Layout { size_t dEdCN, e_atom, v_atom, tab, present, smap, sinfo, ctab, apos, aaux, total; };
+D3Layout d3_layout(int N, int nz, int dtype) {
   D3Layout L;
   size_t o = 0;
   auto take = [&](size_t b) { size_t at = o; o += mi_align(b); return at; };
@@ -407,6 +465,8 @@ D3Layout d3_layout(int N, int nz) {
   L.smap = take(sizeof(int) * (size_t)nz);
   L.sinfo = take(sizeof(D3Species));
   L.ctab = take(sizeof(float4) * D3_SMAX * D3_SMAX * 25);
+  L.apos = take((dtype == MI_F32 ? 16 : 32) * (size_t)N);
+  L.aaux = take(sizeof(float4) * (size_t)N);
   L.total = o;
   return L;
 }
@@ -423,6 +483,8 @@ int d3_impl(const T* pos, const int* numbers, int N, const int* idx, const int* 
   int* smap = reinterpret_cast<int*>(ws + L.smap);
   D3Species* sinfo = reinterpret_cast<D3Species*>(ws + L.sinfo);
   float4* ctab = reinterpret_cast<float4*>(ws + L.ctab);
+  auto* apos = reinterpret_cast<typename Vec4<T>::type*>(ws + L.apos);
+  float4* aaux = reinterpret_cast<float4*>(ws + L.aaux);
   D3Dev P;
   P.rcov = hp->rcov; P.r4r2 = hp->r4r2; P.tab = tab; P.nz = hp->nz;
   P.a1 = hp->a1; P.a2 = hp->a2; P.s6 = hp->s6; P.s8 = hp->s8; P.k1 = hp->k1; P.k3 = hp->k3; P.s5_on = hp->s5_on; P.s5_off = hp->s5_off;
@@ -446,16 +508,18 @@ int d3_impl(const T* pos, const int* numbers, int N, const int* idx, const int* 
   MI_LAUNCH_CHECK();
   d3_compact_species_kernel<<<1, 256, 0, st>>>(present, hp->c6ab, hp->cn_ref, hp->nz, smap, sinfo, ctab);
   MI_LAUNCH_CHECK();
+  d3_pack_atoms_kernel<T><<<mi_blocks(N, 256), 256, 0, st>>>(pos, numbers, N, hp->rcov, hp->r4r2, smap, hp->nz, apos, aaux);
+  MI_LAUNCH_CHECK();
   const int blocks = mi_blocks(N, 4);
-  MI_TIMED("d3_cn", st, (d3_cn_kernel<T, CSR><<<blocks, 256, 0, st>>>(pos, numbers, N, idx, ush, nptr, M, fill_value, cell, batch_idx, P, cn)));
+  MI_TIMED("d3_cn", st, (d3_cn_kernel<T, CSR><<<blocks, 256, 0, st>>>(pos, numbers, N, idx, ush, nptr, M, fill_value, cell, batch_idx, P, apos, aaux, cn)));
   MI_LAUNCH_CHECK();
   MI_TIMED("d3_energy", st, (d3_energy_kernel<T, CSR, true><<<blocks, 256, 0, st>>>(pos, numbers, N, idx, ush, nptr, M, fill_value, cell, batch_idx, P,
-                                                                                    cn, want_virial, smap, sinfo, ctab, dEdCN, forces, e_atom, v_atom)));
+                                                                                    cn, want_virial, smap, sinfo, ctab, apos, aaux, dEdCN, forces, e_atom, v_atom)));
   MI_LAUNCH_CHECK();
   d3_energy_kernel<T, CSR, false><<<blocks, 256, 0, st>>>(pos, numbers, N, idx, ush, nptr, M, fill_value, cell, batch_idx, P, cn, want_virial, smap,
-                                                          sinfo, ctab, dEdCN, forces, e_atom, v_atom);
+                                                          sinfo, ctab, apos, aaux, dEdCN, forces, e_atom, v_atom);
   MI_LAUNCH_CHECK();
-  MI_TIMED("d3_chain", st, (d3_chain_kernel<T, CSR><<<blocks, 256, 0, st>>>(pos, numbers, N, idx, ush, nptr, M, fill_value, cell, batch_idx, P, dEdCN,
+  MI_TIMED("d3_chain", st, (d3_chain_kernel<T, CSR><<<blocks, 256, 0, st>>>(pos, numbers, N, idx, ush, nptr, M, fill_value, cell, batch_idx, P, apos, dEdCN,
                                                                             want_virial, forces, v_atom)));
   MI_LAUNCH_CHECK();
   d3_reduce_kernel<<<mi_blocks(N, 256), 256, 0, st>>>(e_atom, v_atom, batch_idx, N, want_virial, energy, virial);
@@ -470,7 +534,7 @@ extern "C" {
 size_t mi_d3_workspace_bytes(int n_atoms, int n_systems, int nz) {
   (void)n_systems;
   if (n_atoms < 0 || nz < 1) return 0;
-  return d3_layout(n_atoms, nz).total;
+  return d3_layout(n_atoms, nz, MI_F64).total;  // sized for the wider dtype
 }
 
 int mi_d3(const void* positions, const int32_t* numbers, int n_atoms, int dtype, const int32_t* idx_j, const int32_t* unit_shifts,
@@ -483,7 +547,7 @@ int mi_d3(const void* positions, const int32_t* numbers, int n_atoms, int dtype,
   MI_REQUIRE(positions && numbers && idx_j && params && energy && forces && coord_num && workspace, "null pointer");
   MI_REQUIRE(params->rcov && params->r4r2 && params->c6ab && params->cn_ref && params->nz >= 2, "D3 parameter tables");
   MI_REQUIRE(!compute_virial || virial, "virial output");
-  D3Layout L = d3_layout(n_atoms, params->nz);
+  D3Layout L = d3_layout(n_atoms, params->nz, dtype);
   if (workspace_bytes < L.total) { mi_set_error("workspace too small: %zu < %zu", workspace_bytes, L.total); return MI_EWORKSPACE; }
   hipStream_t st = (hipStream_t)stream;
   const bool csr = neighbor_ptr != nullptr;

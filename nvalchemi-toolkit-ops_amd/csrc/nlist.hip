@@ -23,6 +23,7 @@
 
 namespace {
 
+#define NL_PRUNE_R 8
 template <class T> struct NlSys {
   T cell[9];
   T inv[9];
@@ -33,6 +34,8 @@ template <class T> struct NlSys {
   int nrange[3];  // image range of the naive method (neighbor_utils.py:150-211)
   int cell_off;
   int ncells;
+  int prune;      // orthorhombic cell with R <= NL_PRUNE_R: dxlim[|dz|][|dy|] = largest |dx| worth visiting (-1: skip the row)
+  signed char dxlim[NL_PRUNE_R + 1][NL_PRUNE_R + 1];
 };
 struct NlGlobal { int total_cells; int any_wrap; int pad0; int pad1; };
 
@@ -125,6 +128,25 @@ __global__ void nl_setup_kernel(const T* __restrict__ cell, const uint8_t* __res
     }
     S.ncells = (int)tot;
     S.cell_off = 0;
+    // Orthorhombic cells: atoms in cells offset by d cells along a periodic axis are at least (|d|-1) cell edges apart along it,
+    // so cells/rows provably beyond the cutoff are never visited.  Non-periodic axes contribute 0 (clamped atoms may sit
+    // outside their cell).  Evaluated once here; the query kernel only does integer look-ups.
+    const bool ortho = a[1] == T(0) && a[2] == T(0) && a[3] == T(0) && a[5] == T(0) && a[6] == T(0) && a[7] == T(0);
+    S.prune = (ortho && S.R[0] <= NL_PRUNE_R && S.R[1] <= NL_PRUNE_R && S.R[2] <= NL_PRUNE_R) ? 1 : 0;
+    if (S.prune) {
+      double w[3];
+      for (int d = 0; d < 3; ++d) w[d] = S.pbc[d] ? face[d] / S.cpd[d] : 0.0;
+      for (int az = 0; az <= NL_PRUNE_R; ++az)
+        for (int ay = 0; ay <= NL_PRUNE_R; ++ay) {
+          const double gz = (az > 1 ? az - 1 : 0) * w[2], gy = (ay > 1 ? ay - 1 : 0) * w[1];
+          const double rem = rc * rc - gz * gz - gy * gy;
+          int lim;
+          if (rem < -1e-6 * rc * rc) lim = -1;
+          else if (w[0] > 0.0) { lim = (int)(sqrt(rem > 0.0 ? rem : 0.0) / w[0] * (1.0 + 1e-6)) + 1; if (lim > S.R[0]) lim = S.R[0]; }
+          else lim = S.R[0];
+          S.dxlim[az][ay] = (signed char)lim;
+        }
+    }
     sys[s] = S;
   }
   __syncthreads();
@@ -232,80 +254,140 @@ __global__ __launch_bounds__(256) void nl_query_kernel(
   else { out_base = (long long)i * M; cap_row = M; }
   int cnt = 0;
 
-  int xlo = cx - Rx, xhi = cx + Rx, sx_lo = 0, sx_hi = 0;
-  if (pbx) { int r; floor_divmod(xlo, nx, sx_lo, r); floor_divmod(xhi, nx, sx_hi, r); }
-  else { xlo = xlo < 0 ? 0 : xlo; xhi = xhi > nx - 1 ? nx - 1 : xhi; }
+  const bool prune = S->prune != 0;
 
-  for (int dz = -Rz; dz <= Rz; ++dz) {
-    const int tz = cz + dz;
-    if (!pbz && (tz < 0 || tz >= nz)) continue;
-    int csz, wz;
-    floor_divmod(tz, nz, csz, wz);
-    for (int dy = -Ry; dy <= Ry; ++dy) {
-      const int ty = cy + dy;
-      if (!pby && (ty < 0 || ty >= ny)) continue;
-      int csy, wy;
-      floor_divmod(ty, ny, csy, wy);
-      const int rowbase = coff + nx * (wy + ny * wz);
-      for (int sx = sx_lo; sx <= sx_hi; ++sx) {
-        const int img0 = sx * nx;
-        const int xa = (xlo > img0 ? xlo : img0) - img0;
-        const int xb = (xhi < img0 + nx - 1 ? xhi : img0 + nx - 1) - img0;
-        const int beg = cell_start[rowbase + xa], end = cell_start[rowbase + xb + 1];
-        for (int q0 = beg; q0 < end; q0 += MI_WAVE) {
-          const int q = q0 + lane;
-          bool hit = false;
-          int j = 0, Sx = sx, Sy = csy, Sz = csz;
-          if (q < end) {
-            const auto cj = spos[q];
-            j = idx_of(cj);
-            if (anyw) {
-              const short4 wj = swrap[q];
-              if (pbx) Sx += (int)wi.x - (int)wj.x;
-              if (pby) Sy += (int)wi.y - (int)wj.y;
-              if (pbz) Sz += (int)wi.z - (int)wj.z;
-            }
-            const T fs[3] = {(T)Sx, (T)Sy, (T)Sz};
-            T cart[3], dr0, dr1, dr2;
-            rowvec_mat3(fs, cm, cart);
-            bool ok = true;
-            if (!naive) {
-              // cell_list.py:531-544:  dr = pos_j - pos_i + S.cell ; d2 = dot(dr,dr) ; d2 < rc*rc
-              dr0 = (cj.x - pix) + cart[0];
-              dr1 = (cj.y - piy) + cart[1];
-              dr2 = (cj.z - piz) + cart[2];
-            } else {
-              // naive.py:163-172: diff = (S.cell + r_shifted_atom) - r_other, evaluated for the upper-half shift
-              const bool upper = Sx > 0 || (Sx == 0 && Sy > 0) || (Sx == 0 && Sy == 0 && Sz >= 0);
-              if (upper) { dr0 = (cart[0] + cj.x) - pix; dr1 = (cart[1] + cj.y) - piy; dr2 = (cart[2] + cj.z) - piz; }
-              else { dr0 = ((-cart[0]) + pix) - cj.x; dr1 = ((-cart[1]) + piy) - cj.y; dr2 = ((-cart[2]) + piz) - cj.z; }
-              ok = (Sx <= nr0 && -Sx <= nr0) && (Sy <= nr1 && -Sy <= nr1) && (Sz <= nr2 && -Sz <= nr2);
-            }
-            const T d2 = dr0 * dr0 + dr1 * dr1 + dr2 * dr2;
-            const bool zeroS = (Sx | Sy | Sz) == 0;
-            hit = ok && (d2 < rc2) && !(j == i && zeroS);
-            if (half && hit) {
-              const bool pos_shift = Sx > 0 || (Sx == 0 && Sy > 0) || (Sx == 0 && Sy == 0 && Sz > 0);
-              hit = pos_shift || (zeroS && j > i);
-            }
+  // one contiguous run of candidates [beg,end) of the sorted order, all with the same cell image shift (sx, csy, csz)
+  auto scan_run = [&](int beg, int end, int sx, int csy, int csz) {
+    for (int q0 = beg; q0 < end; q0 += MI_WAVE) {
+      const int q = q0 + lane;
+      bool hit = false;
+      int j = 0, Sx = sx, Sy = csy, Sz = csz;
+      if (q < end) {
+        const auto cj = spos[q];
+        j = idx_of(cj);
+        if (anyw) {
+          const short4 wj = swrap[q];
+          if (pbx) Sx += (int)wi.x - (int)wj.x;
+          if (pby) Sy += (int)wi.y - (int)wj.y;
+          if (pbz) Sz += (int)wi.z - (int)wj.z;
+        }
+        const T fs[3] = {(T)Sx, (T)Sy, (T)Sz};
+        T cart[3], dr0, dr1, dr2;
+        rowvec_mat3(fs, cm, cart);
+        bool ok = true;
+        if (!naive) {
+          // cell_list.py:531-544:  dr = pos_j - pos_i + S.cell ; d2 = dot(dr,dr) ; d2 < rc*rc
+          dr0 = (cj.x - pix) + cart[0];
+          dr1 = (cj.y - piy) + cart[1];
+          dr2 = (cj.z - piz) + cart[2];
+        } else {
+          // naive.py:163-172: diff = (S.cell + r_shifted_atom) - r_other, evaluated for the upper-half shift
+          const bool upper = Sx > 0 || (Sx == 0 && Sy > 0) || (Sx == 0 && Sy == 0 && Sz >= 0);
+          if (upper) { dr0 = (cart[0] + cj.x) - pix; dr1 = (cart[1] + cj.y) - piy; dr2 = (cart[2] + cj.z) - piz; }
+          else { dr0 = ((-cart[0]) + pix) - cj.x; dr1 = ((-cart[1]) + piy) - cj.y; dr2 = ((-cart[2]) + piz) - cj.z; }
+          ok = (Sx <= nr0 && -Sx <= nr0) && (Sy <= nr1 && -Sy <= nr1) && (Sz <= nr2 && -Sz <= nr2);
+        }
+        const T d2 = dr0 * dr0 + dr1 * dr1 + dr2 * dr2;
+        const bool zeroS = (Sx | Sy | Sz) == 0;
+        hit = ok && (d2 < rc2) && !(j == i && zeroS);
+        if (half && hit) {
+          const bool pos_shift = Sx > 0 || (Sx == 0 && Sy > 0) || (Sx == 0 && Sy == 0 && Sz > 0);
+          hit = pos_shift || (zeroS && j > i);
+        }
+      }
+      const unsigned long long mask = __ballot(hit);
+      if (mask) {
+        const int slot = cnt + __popcll(mask & lt);
+        if (MODE == MI_NL_MODE_MATRIX) {
+          if (hit && slot < cap_row) {
+            nm[out_base + slot] = j;
+            if (nsh) { int* sp = nsh + (out_base + slot) * 3; sp[0] = Sx; sp[1] = Sy; sp[2] = Sz; }
           }
-          const unsigned long long mask = __ballot(hit);
-          if (mask) {
-            const int slot = cnt + __popcll(mask & lt);
-            if (MODE == MI_NL_MODE_MATRIX) {
-              if (hit && slot < cap_row) {
-                nm[out_base + slot] = j;
-                if (nsh) { int* sp = nsh + (out_base + slot) * 3; sp[0] = Sx; sp[1] = Sy; sp[2] = Sz; }
-              }
-            } else if (MODE == MI_NL_MODE_CSR) {
-              if (hit && slot < cap_row) {
-                list_ij[out_base + slot] = i;
-                list_ij[P + out_base + slot] = j;
-                if (list_sh) { int* sp = list_sh + (out_base + slot) * 3; sp[0] = Sx; sp[1] = Sy; sp[2] = Sz; }
-              }
-            }
-            cnt += __popcll(mask);
+        } else if (MODE == MI_NL_MODE_CSR) {
+          if (hit && slot < cap_row) {
+            list_ij[out_base + slot] = i;
+            list_ij[P + out_base + slot] = j;
+            if (list_sh) { int* sp = list_sh + (out_base + slot) * 3; sp[0] = Sx; sp[1] = Sy; sp[2] = Sz; }
           }
+        }
+        cnt += __popcll(mask);
+      }
+    }
+  };
+
+  if (!pbx || Rx <= nx) {
+    // Common case (at most the images -1, 0, +1 along x): the (dy,dz) rows of cells are described by the lanes IN PARALLEL --
+    // wrap, pruning look-up and the up-to-six cell_start reads of 64 rows cost one memory latency -- and then consumed one by
+    // one through wave-uniform readlanes.  (A serial walk pays two dependent global loads per row before any candidate is seen.)
+    const int nyr = 2 * Ry + 1, nrows = (2 * Rz + 1) * nyr;
+    for (int rbase = 0; rbase < nrows; rbase += MI_WAVE) {
+      const int row = rbase + lane;
+      int rb[3] = {0, 0, 0}, re[3] = {0, 0, 0}, cs = 0;
+      if (row < nrows) {
+        const int dzr = row / nyr, dz = dzr - Rz, dy = row - dzr * nyr - Ry;
+        const int tz = cz + dz, ty = cy + dy;
+        bool ok = (pbz || (tz >= 0 && tz < nz)) && (pby || (ty >= 0 && ty < ny));
+        int csz = 0, wz = tz, csy = 0, wy = ty;
+        if (ok) {
+          while (wz < 0) { wz += nz; --csz; }
+          while (wz >= nz) { wz -= nz; ++csz; }
+          while (wy < 0) { wy += ny; --csy; }
+          while (wy >= ny) { wy -= ny; ++csy; }
+        }
+        int dxm = Rx;
+        if (prune) { dxm = S->dxlim[dz < 0 ? -dz : dz][dy < 0 ? -dy : dy]; ok = ok && dxm >= 0; }
+        if (ok) {
+          int xlo = cx - dxm, xhi = cx + dxm;
+          if (!pbx) { xlo = xlo < 0 ? 0 : xlo; xhi = xhi > nx - 1 ? nx - 1 : xhi; }
+          const int rowbase = coff + nx * (wy + ny * wz);
+#pragma unroll
+          for (int g = 0; g < 3; ++g) {
+            const int img0 = (g - 1) * nx;
+            const int xa = (xlo > img0 ? xlo : img0), xb = (xhi < img0 + nx - 1 ? xhi : img0 + nx - 1);
+            if (xa <= xb && (pbx || g == 1)) { rb[g] = cell_start[rowbase + xa - img0]; re[g] = cell_start[rowbase + xb - img0 + 1]; }
+          }
+          cs = (csy & 0xffff) | (csz << 16);
+        }
+      }
+      const int rmax = nrows - rbase < MI_WAVE ? nrows - rbase : MI_WAVE;
+      for (int r = 0; r < rmax; ++r) {
+        const int csr = __builtin_amdgcn_readlane(cs, r);
+        const int csy = (int)(short)(csr & 0xffff), csz = csr >> 16;
+#pragma unroll
+        for (int g = 0; g < 3; ++g) {
+          const int beg = __builtin_amdgcn_readlane(rb[g], r), end = __builtin_amdgcn_readlane(re[g], r);
+          if (beg < end) scan_run(beg, end, g - 1, csy, csz);
+        }
+      }
+    }
+  } else {
+    // tiny periodic boxes (search radius larger than the box along x: many images per row): plain serial walk
+    for (int dz = -Rz; dz <= Rz; ++dz) {
+      const int tz = cz + dz;
+      if (!pbz && (tz < 0 || tz >= nz)) continue;
+      int csz = 0, wz = tz;
+      while (wz < 0) { wz += nz; --csz; }
+      while (wz >= nz) { wz -= nz; ++csz; }
+      for (int dy = -Ry; dy <= Ry; ++dy) {
+        const int ty = cy + dy;
+        if (!pby && (ty < 0 || ty >= ny)) continue;
+        int csy = 0, wy = ty;
+        while (wy < 0) { wy += ny; --csy; }
+        while (wy >= ny) { wy -= ny; ++csy; }
+        int dxm = Rx;
+        if (prune) {
+          dxm = S->dxlim[dz < 0 ? -dz : dz][dy < 0 ? -dy : dy];
+          if (dxm < 0) continue;
+        }
+        int xlo = cx - dxm, xhi = cx + dxm, sx_lo = 0, sx_hi = 0;
+        for (int t = xlo; t < 0; t += nx) --sx_lo;
+        for (int t = xhi; t >= nx; t -= nx) ++sx_hi;
+        const int rowbase = coff + nx * (wy + ny * wz);
+        for (int sx = sx_lo; sx <= sx_hi; ++sx) {
+          const int img0 = sx * nx;
+          const int xa = (xlo > img0 ? xlo : img0) - img0;
+          const int xb = (xhi < img0 + nx - 1 ? xhi : img0 + nx - 1) - img0;
+          scan_run(cell_start[rowbase + xa], cell_start[rowbase + xb + 1], sx, csy, csz);
         }
       }
     }
