@@ -80,6 +80,20 @@ __device__ __forceinline__ PairGeom<T> d3_geom(const V4& pj, T pix, T piy, T piz
   return g;
 }
 
+// One step of a row walk: neighbour index + unit shift of 64 consecutive entries (one per lane).
+struct D3Step { int j; Int3 sh; bool in; };
+__device__ __forceinline__ D3Step d3_fetch(const int* __restrict__ idx, const Int3* __restrict__ ush3, long long e, long long end, bool periodic) {
+  D3Step s;
+  s.in = e < end;
+  s.j = 0;
+  s.sh = Int3{0, 0, 0};
+  if (s.in) { s.j = idx[e]; if (periodic) s.sh = ush3[e]; }
+  return s;
+}
+// The row walks below are software-pipelined three deep: while step k is evaluated, the per-atom records of step k+1 are
+// already being gathered and the index/shift words of step k+2 are in flight; validity is a predicate, not a branch, so
+// no load waits behind a branch on an earlier load (rocprof: the unpipelined walk spent >80 % of its wave cycles waiting).
+
 // `_cn_counting` (dftd3.py:608-645)
 __device__ __forceinline__ float d3_cn_count(float rinv, float rci, float rcj, float k1, float* dcn) {
   const float rr = (rci + rcj) * rinv;
@@ -116,26 +130,24 @@ __global__ __launch_bounds__(256) void d3_cn_kernel(const T* __restrict__ pos, c
   // the reference sums in fp32 sequentially (dftd3.py:911); lanes hold fp64 partials here so the result is the
   // correctly rounded sum whatever the lane/iteration order
   double acc = 0.0;
-  // Software-pipelined row walk: index + unit shift of step k+1 are requested before step k is evaluated, and validity is
-  // a predicate instead of a branch, so the loads of a step issue back-to-back (no load -> branch -> load chains).
   const Int3* __restrict__ ush3 = reinterpret_cast<const Int3*>(ush);
   long long e = beg + lane;
-  int jn = 0;
-  Int3 sn = {0, 0, 0};
-  if (e < end) { jn = idx[e]; if (periodic) sn = ush3[e]; }
+  D3Step s0 = d3_fetch(idx, ush3, e, end, periodic), s1 = d3_fetch(idx, ush3, e + MI_WAVE, end, periodic);
+  bool v0 = s0.in && (CSR || s0.j < fill_value);
+  auto p0 = apos[v0 ? s0.j : i];
   for (long long base = beg; base < end; base += MI_WAVE) {
-    const int j = jn;
-    const Int3 sh = sn;
-    bool valid = (e < end) && (CSR || j < fill_value);
     e += MI_WAVE;
-    if (e < end) { jn = idx[e]; if (periodic) sn = ush3[e]; }
-    if (!__any(valid)) continue;  // a step of pure padding (padded matrices are mostly padding)
-    const auto pj = apos[valid ? j : i];
-    valid = valid && !(pj.w < (T)0);  // padding atom (Z == 0)
-    const PairGeom<T> g = d3_geom<T>(pj, pix, piy, piz, sh, cm, periodic);
-    valid = valid && g.ok;
-    const float f = d3_cn_count(g.rinv, rci, (float)pj.w, P.k1, nullptr);
-    acc += valid ? (double)f : 0.0;
+    const D3Step s2 = d3_fetch(idx, ush3, e + MI_WAVE, end, periodic);
+    const bool v1 = s1.in && (CSR || s1.j < fill_value);
+    const auto p1 = apos[v1 ? s1.j : i];
+    if (__any(v0)) {  // a step of pure padding costs nothing (padded matrices are mostly padding)
+      bool valid = v0 && !(p0.w < (T)0);  // padding atom (Z == 0)
+      const PairGeom<T> g = d3_geom<T>(p0, pix, piy, piz, s0.sh, cm, periodic);
+      valid = valid && g.ok;
+      const float f = d3_cn_count(g.rinv, rci, (float)p0.w, P.k1, nullptr);
+      acc += valid ? (double)f : 0.0;
+    }
+    s0 = s1; v0 = v1; p0 = p1; s1 = s2;
   }
   acc = wave_sum(acc);
   if (lane == 0) { cn[i] = (float)acc; aaux[i].x = (float)acc; }
@@ -287,56 +299,55 @@ __global__ __launch_bounds__(256) void d3_energy_kernel(const T* __restrict__ po
   double Fx = 0, Fy = 0, Fz = 0, E = 0;
   double V[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
   double dacc = 0.0;
-  // Software-pipelined row walk: index + unit shift of step k+1 are requested before step k is evaluated, and validity is
-  // a predicate instead of a branch, so the loads of a step issue back-to-back (no load -> branch -> load chains).
   const Int3* __restrict__ ush3 = reinterpret_cast<const Int3*>(ush);
   long long e = beg + lane;
-  int jn = 0;
-  Int3 sn = {0, 0, 0};
-  if (e < end) { jn = idx[e]; if (periodic) sn = ush3[e]; }
+  D3Step s0 = d3_fetch(idx, ush3, e, end, periodic), s1 = d3_fetch(idx, ush3, e + MI_WAVE, end, periodic);
+  bool v0 = s0.in && (CSR || s0.j < fill_value);
+  auto p0 = apos[v0 ? s0.j : i];
+  float4 a0 = aaux[v0 ? s0.j : i];  // {CN_j, r4r2_j, Z_j << 8 | species id}
   for (long long base = beg; base < end; base += MI_WAVE) {
-    const int j = jn;
-    const Int3 sh = sn;
-    bool valid = (e < end) && (CSR || j < fill_value);
     e += MI_WAVE;
-    if (e < end) { jn = idx[e]; if (periodic) sn = ush3[e]; }
-    if (!__any(valid)) continue;  // a step of pure padding (padded matrices are mostly padding)
-    const auto pj = apos[valid ? j : i];
-    const float4 aj = aaux[valid ? j : i];  // {CN_j, r4r2_j, Z_j << 8 | species id}
-    valid = valid && !(pj.w < (T)0);  // padding atom (Z == 0)
-    const PairGeom<T> g = d3_geom<T>(pj, pix, piy, piz, sh, cm, periodic);
-    valid = valid && g.ok;
-    const int code = valid ? __float_as_int(aj.z) : code_i;
-    float c6, dci;
-    d3_c6(cn_i, aj.x, LDS ? my_tab + (code & 0xff) * 25 : tab_i + (size_t)(code >> 8) * 25, P.k3, c6, dci);
-    valid = valid && !(c6 < 1e-12f);
-    // `_bj_damping` (dftd3.py:648-687)
-    const float r = valid ? g.r : 1.0f;
-    const float q = 3.0f * r4r2_i * aj.y;
-    const float r0 = P.a1 * sqrtf(q) + P.a2;
-    const float r2 = r * r, r4 = r2 * r2, r6 = r4 * r2, r8 = r4 * r4;
-    const float r02 = r0 * r0, r04 = r02 * r02, r06 = r04 * r02, r08 = r04 * r04;
-    const float i6 = 1.0f / (r6 + r06), i8 = 1.0f / (r8 + r08);
-    const float damp = P.s6 * i6 + P.s8 * q * i8;
-    // `_dispersion_energy_force` (dftd3.py:690-731)
-    const float eij = -c6 * damp;
-    const float r5 = r4 * r, r7 = r6 * r;
-    const float d6 = -6.0f * P.s6 * r5 * i6 * i6;
-    const float d8 = -8.0f * P.s8 * q * r7 * i8 * i8;
-    const float dEdr = -c6 * (d6 + d8);
-    float sw, dsw;
-    d3_s5(r, P.s5_on, P.s5_off, P.inv_w, sw, dsw);
-    const float esw = valid ? eij * sw : 0.0f;
-    const float dEsw = valid ? sw * dEdr + eij * dsw : 0.0f;
-    const float fx = dEsw * (g.rx * g.rinv), fy = dEsw * (g.ry * g.rinv), fz = dEsw * (g.rz * g.rinv);
-    Fx += (double)fx; Fy += (double)fy; Fz += (double)fz;
-    E += (double)esw;
-    dacc += valid ? (double)(-damp * dci) : 0.0;
-    if (want_virial) {
-      V[0] += (double)(fx * g.rx); V[1] += (double)(fx * g.ry); V[2] += (double)(fx * g.rz);
-      V[3] += (double)(fy * g.rx); V[4] += (double)(fy * g.ry); V[5] += (double)(fy * g.rz);
-      V[6] += (double)(fz * g.rx); V[7] += (double)(fz * g.ry); V[8] += (double)(fz * g.rz);
+    const D3Step s2 = d3_fetch(idx, ush3, e + MI_WAVE, end, periodic);
+    const bool v1 = s1.in && (CSR || s1.j < fill_value);
+    const auto p1 = apos[v1 ? s1.j : i];
+    const float4 a1 = aaux[v1 ? s1.j : i];
+    if (__any(v0)) {
+      bool valid = v0 && !(p0.w < (T)0);  // padding atom (Z == 0)
+      const PairGeom<T> g = d3_geom<T>(p0, pix, piy, piz, s0.sh, cm, periodic);
+      valid = valid && g.ok;
+      const int code = valid ? __float_as_int(a0.z) : code_i;
+      float c6, dci;
+      d3_c6(cn_i, a0.x, LDS ? my_tab + (code & 0xff) * 25 : tab_i + (size_t)(code >> 8) * 25, P.k3, c6, dci);
+      valid = valid && !(c6 < 1e-12f);
+      // `_bj_damping` (dftd3.py:648-687)
+      const float r = valid ? g.r : 1.0f;
+      const float q = 3.0f * r4r2_i * a0.y;
+      const float r0 = P.a1 * sqrtf(q) + P.a2;
+      const float r2 = r * r, r4 = r2 * r2, r6 = r4 * r2, r8 = r4 * r4;
+      const float r02 = r0 * r0, r04 = r02 * r02, r06 = r04 * r02, r08 = r04 * r04;
+      const float i6 = 1.0f / (r6 + r06), i8 = 1.0f / (r8 + r08);
+      const float damp = P.s6 * i6 + P.s8 * q * i8;
+      // `_dispersion_energy_force` (dftd3.py:690-731)
+      const float eij = -c6 * damp;
+      const float r5 = r4 * r, r7 = r6 * r;
+      const float d6 = -6.0f * P.s6 * r5 * i6 * i6;
+      const float d8 = -8.0f * P.s8 * q * r7 * i8 * i8;
+      const float dEdr = -c6 * (d6 + d8);
+      float sw, dsw;
+      d3_s5(r, P.s5_on, P.s5_off, P.inv_w, sw, dsw);
+      const float esw = valid ? eij * sw : 0.0f;
+      const float dEsw = valid ? sw * dEdr + eij * dsw : 0.0f;
+      const float fx = dEsw * (g.rx * g.rinv), fy = dEsw * (g.ry * g.rinv), fz = dEsw * (g.rz * g.rinv);
+      Fx += (double)fx; Fy += (double)fy; Fz += (double)fz;
+      E += (double)esw;
+      dacc += valid ? (double)(-damp * dci) : 0.0;
+      if (want_virial) {
+        V[0] += (double)(fx * g.rx); V[1] += (double)(fx * g.ry); V[2] += (double)(fx * g.rz);
+        V[3] += (double)(fy * g.rx); V[4] += (double)(fy * g.ry); V[5] += (double)(fy * g.rz);
+        V[6] += (double)(fz * g.rx); V[7] += (double)(fz * g.ry); V[8] += (double)(fz * g.rz);
+      }
     }
+    s0 = s1; v0 = v1; p0 = p1; a0 = a1; s1 = s2;
   }
   Fx = wave_sum(Fx); Fy = wave_sum(Fy); Fz = wave_sum(Fz); E = wave_sum(E);
   dacc = wave_sum(dacc);
@@ -378,35 +389,34 @@ __global__ __launch_bounds__(256) void d3_chain_kernel(const T* __restrict__ pos
   d3_row<T, CSR>(i, M, nptr, beg, end);
   double Fx = 0, Fy = 0, Fz = 0;
   double V[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-  // Software-pipelined row walk: index + unit shift of step k+1 are requested before step k is evaluated, and validity is
-  // a predicate instead of a branch, so the loads of a step issue back-to-back (no load -> branch -> load chains).
   const Int3* __restrict__ ush3 = reinterpret_cast<const Int3*>(ush);
   long long e = beg + lane;
-  int jn = 0;
-  Int3 sn = {0, 0, 0};
-  if (e < end) { jn = idx[e]; if (periodic) sn = ush3[e]; }
+  D3Step s0 = d3_fetch(idx, ush3, e, end, periodic), s1 = d3_fetch(idx, ush3, e + MI_WAVE, end, periodic);
+  bool v0 = s0.in && (CSR || s0.j < fill_value);
+  auto p0 = apos[v0 ? s0.j : i];
+  float d0 = dEdCN[v0 ? s0.j : i];
   for (long long base = beg; base < end; base += MI_WAVE) {
-    const int j = jn;
-    const Int3 sh = sn;
-    bool valid = (e < end) && (CSR || j < fill_value);
     e += MI_WAVE;
-    if (e < end) { jn = idx[e]; if (periodic) sn = ush3[e]; }
-    if (!__any(valid)) continue;  // a step of pure padding (padded matrices are mostly padding)
-    const auto pj = apos[valid ? j : i];
-    const float dj = dEdCN[valid ? j : i];
-    valid = valid && !(pj.w < (T)0);  // padding atom (Z == 0)
-    const PairGeom<T> g = d3_geom<T>(pj, pix, piy, piz, sh, cm, periodic);
-    valid = valid && g.ok;
-    float dcn;
-    d3_cn_count(g.rinv, rci, (float)pj.w, P.k1, &dcn);
-    const float dEdr = valid ? (di + dj) * dcn : 0.0f;
-    const float fx = dEdr * (g.rx * g.rinv), fy = dEdr * (g.ry * g.rinv), fz = dEdr * (g.rz * g.rinv);
-    Fx += (double)fx; Fy += (double)fy; Fz += (double)fz;
-    if (want_virial) {
-      V[0] += (double)(fx * g.rx); V[1] += (double)(fx * g.ry); V[2] += (double)(fx * g.rz);
-      V[3] += (double)(fy * g.rx); V[4] += (double)(fy * g.ry); V[5] += (double)(fy * g.rz);
-      V[6] += (double)(fz * g.rx); V[7] += (double)(fz * g.ry); V[8] += (double)(fz * g.rz);
+    const D3Step s2 = d3_fetch(idx, ush3, e + MI_WAVE, end, periodic);
+    const bool v1 = s1.in && (CSR || s1.j < fill_value);
+    const auto p1 = apos[v1 ? s1.j : i];
+    const float d1 = dEdCN[v1 ? s1.j : i];
+    if (__any(v0)) {
+      bool valid = v0 && !(p0.w < (T)0);  // padding atom (Z == 0)
+      const PairGeom<T> g = d3_geom<T>(p0, pix, piy, piz, s0.sh, cm, periodic);
+      valid = valid && g.ok;
+      float dcn;
+      d3_cn_count(g.rinv, rci, (float)p0.w, P.k1, &dcn);
+      const float dEdr = valid ? (di + d0) * dcn : 0.0f;
+      const float fx = dEdr * (g.rx * g.rinv), fy = dEdr * (g.ry * g.rinv), fz = dEdr * (g.rz * g.rinv);
+      Fx += (double)fx; Fy += (double)fy; Fz += (double)fz;
+      if (want_virial) {
+        V[0] += (double)(fx * g.rx); V[1] += (double)(fx * g.ry); V[2] += (double)(fx * g.rz);
+        V[3] += (double)(fy * g.rx); V[4] += (double)(fy * g.ry); V[5] += (double)(fy * g.rz);
+        V[6] += (double)(fz * g.rx); V[7] += (double)(fz * g.ry); V[8] += (double)(fz * g.rz);
+      }
     }
+    s0 = s1; v0 = v1; p0 = p1; d0 = d1; s1 = s2;
   }
   Fx = wave_sum(Fx); Fy = wave_sum(Fy); Fz = wave_sum(Fz);
   if (want_virial) {
