@@ -436,30 +436,49 @@ __global__ __launch_bounds__(256) void d3_chain_kernel(const T* __restrict__ pos
   }
 }
 
-// per-system reduction of per-atom energies / virials: one atomic per wave when the 64 atoms share a system
-__global__ void d3_reduce_kernel(const float* __restrict__ e_atom, const float* __restrict__ v_atom, const int* __restrict__ batch_idx, int N,
-                                 int want_virial, float* __restrict__ energy, float* __restrict__ virial) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+// per-system reduction of per-atom energies / virials.  A few hundred waves each own a contiguous slab of atoms, keep a
+// running (system, sum) pair and touch global memory with ONE atomic per system change (batches are contiguous per
+// system, so that is ~1 per wave): 10 values x 256 waves instead of one atomic per 64 atoms on the same addresses.
+#define D3_REDUCE_WAVES 256
+__global__ __launch_bounds__(256) void d3_reduce_kernel(const float* __restrict__ e_atom, const float* __restrict__ v_atom,
+                                                        const int* __restrict__ batch_idx, int N, int want_virial,
+                                                        float* __restrict__ energy, float* __restrict__ virial) {
   const int lane = threadIdx.x & (MI_WAVE - 1);
-  const bool in = i < N;
-  const int s = in ? (batch_idx ? batch_idx[i] : 0) : -1;
-  const int s0 = __shfl(s, 0, MI_WAVE);
-  const bool uniform = __all(!in || s == s0);
-  float e = in ? e_atom[i] : 0.0f;
-  if (uniform) {
-    e = wave_sum(e);
-    if (lane == 0 && s0 >= 0) atomicAdd(&energy[s0], e);
-    if (want_virial) {
-      for (int k = 0; k < 9; ++k) {
-        float v = in ? v_atom[9 * (size_t)i + k] : 0.0f;
-        v = wave_sum(v);
-        if (lane == 0 && s0 >= 0) atomicAdd(&virial[9 * (size_t)s0 + k], v);
-      }
+  const int wave = blockIdx.x * (blockDim.x / MI_WAVE) + threadIdx.x / MI_WAVE;
+  const int chunks = (N + MI_WAVE - 1) / MI_WAVE;
+  const int per = (chunks + D3_REDUCE_WAVES - 1) / D3_REDUCE_WAVES;
+  const int c0 = wave * per, c1 = (c0 + per < chunks) ? c0 + per : chunks;
+  int cur = -1;
+  float acc[10];
+#pragma unroll
+  for (int k = 0; k < 10; ++k) acc[k] = 0.0f;
+  auto flush = [&]() {
+    if (cur < 0) return;
+#pragma unroll
+    for (int k = 0; k < 10; ++k) {
+      if (k > 0 && !want_virial) break;
+      const float v = wave_sum(acc[k]);
+      if (lane == 0) atomicAdd(k == 0 ? &energy[cur] : &virial[9 * (size_t)cur + (k - 1)], v);
+      acc[k] = 0.0f;
     }
-  } else if (in) {
-    atomicAdd(&energy[s], e);
-    if (want_virial) for (int k = 0; k < 9; ++k) atomicAdd(&virial[9 * (size_t)s + k], v_atom[9 * (size_t)i + k]);
+  };
+  for (int c = c0; c < c1; ++c) {
+    const int i = c * MI_WAVE + lane;
+    const bool in = i < N;
+    const int s = in ? (batch_idx ? batch_idx[i] : 0) : -1;
+    const int s0 = __shfl(s, 0, MI_WAVE);
+    if (__all(!in || s == s0)) {
+      if (s0 != cur) { flush(); cur = s0; }
+      if (in) {
+        acc[0] += e_atom[i];
+        if (want_virial) for (int k = 0; k < 9; ++k) acc[k + 1] += v_atom[9 * (size_t)i + k];
+      }
+    } else if (in) {  // a chunk straddling systems: per-lane atomics
+      atomicAdd(&energy[s], e_atom[i]);
+      if (want_virial) for (int k = 0; k < 9; ++k) atomicAdd(&virial[9 * (size_t)s + k], v_atom[9 * (size_t)i + k]);
+    }
   }
+  flush();
 }
 
 struct D3Layout { size_t dEdCN, e_atom, v_atom, tab, present, smap, sinfo, ctab, apos, aaux, total; };
@@ -532,7 +551,7 @@ int d3_impl(const T* pos, const int* numbers, int N, const int* idx, const int* 
   MI_TIMED("d3_chain", st, (d3_chain_kernel<T, CSR><<<blocks, 256, 0, st>>>(pos, numbers, N, idx, ush, nptr, M, fill_value, cell, batch_idx, P, apos, dEdCN,
                                                                             want_virial, forces, v_atom)));
   MI_LAUNCH_CHECK();
-  d3_reduce_kernel<<<mi_blocks(N, 256), 256, 0, st>>>(e_atom, v_atom, batch_idx, N, want_virial, energy, virial);
+  d3_reduce_kernel<<<D3_REDUCE_WAVES / 4, 256, 0, st>>>(e_atom, v_atom, batch_idx, N, want_virial, energy, virial);
   MI_LAUNCH_CHECK();
   return MI_OK;
 }

@@ -258,6 +258,12 @@ __global__ __launch_bounds__(256) void nl_query_kernel(
 
   // one contiguous run of candidates [beg,end) of the sorted order, all with the same cell image shift (sx, csy, csz)
   auto scan_run = [&](int beg, int end, int sx, int csy, int csz) {
+    // without per-atom wraps the integer shift (hence S.cell) is the same for the whole run: evaluate it once
+    T cart_u[3];
+    {
+      const T fsu[3] = {(T)sx, (T)csy, (T)csz};
+      rowvec_mat3(fsu, cm, cart_u);
+    }
     for (int q0 = beg; q0 < end; q0 += MI_WAVE) {
       const int q = q0 + lane;
       bool hit = false;
@@ -271,9 +277,11 @@ __global__ __launch_bounds__(256) void nl_query_kernel(
           if (pby) Sy += (int)wi.y - (int)wj.y;
           if (pbz) Sz += (int)wi.z - (int)wj.z;
         }
-        const T fs[3] = {(T)Sx, (T)Sy, (T)Sz};
-        T cart[3], dr0, dr1, dr2;
-        rowvec_mat3(fs, cm, cart);
+        T cart[3] = {cart_u[0], cart_u[1], cart_u[2]}, dr0, dr1, dr2;
+        if (anyw) {
+          const T fs[3] = {(T)Sx, (T)Sy, (T)Sz};
+          rowvec_mat3(fs, cm, cart);
+        }
         bool ok = true;
         if (!naive) {
           // cell_list.py:531-544:  dr = pos_j - pos_i + S.cell ; d2 = dot(dr,dr) ; d2 < rc*rc
