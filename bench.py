@@ -189,11 +189,16 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.distributed.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    # BENCH_BACKEND / BENCH_SHARE_DEVICE exist only to smoke-test the N > 1 code path on a 1-GPU box (gloo, all ranks on cuda:0)
+    if os.environ.get("BENCH_SHARE_DEVICE") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        backend = os.environ.get("BENCH_BACKEND", "nccl")  # "nccl" is RCCL on ROCm
+        kw = {"device_id": device} if backend == "nccl" else {}
+        torch.distributed.init_process_group(backend=backend, **kw)
 
     from nvalchemiops import _capi as C
 

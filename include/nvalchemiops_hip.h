@@ -143,6 +143,17 @@ int mi_ewald_real(const void* positions, const void* charges, const void* cell, 
                   int flags, double* energies /*[n_atoms]*/, void* forces /*[n_atoms,3] dtype*/,
                   double* charge_grads /*[n_atoms]*/, void* stream);
 
+/* Adjoint of mi_ewald_real w.r.t. positions / charges / cell / alpha for L = sum_i g_i E_i (replaces the Warp-tape backward of
+ * the real-space ops, autograd.py:525-665 + the generated adjoints of ewald_kernels.py:266-1495).  Owner-only like the forward:
+ *   dL/dr_i = sum_j (g_i+g_j) fm_ij sep_ij ; dL/dq_i = sum_j 1/2 (g_i+g_j) q_j erfc(a r)/r ;
+ *   dL/dcell[s][a][b] = -sum_i g_i sum_j fm_ij sep_ij[b] S_ij[a] ; dL/dalpha[s] = -sum_i g_i sum_j q_i q_j exp(-a^2 r^2)/sqrt(pi).
+ * grad_cell / grad_alpha ([n_systems,3,3] / [n_systems], float64, zeroed by the caller) may be NULL.                       */
+int mi_ewald_real_bwd(const void* positions, const void* charges, const void* cell, const void* alpha, const int32_t* batch_idx,
+                      int n_atoms, int dtype, const int32_t* idx_j, const int32_t* unit_shifts, const int32_t* neighbor_ptr,
+                      int max_neighbors, int mask_value, const void* grad_energies /*[n_atoms] dtype*/,
+                      void* grad_positions /*[n_atoms,3] dtype*/, void* grad_charges /*[n_atoms] dtype*/,
+                      double* grad_cell, double* grad_alpha, void* stream);
+
 /* ---- B-spline spread / gather ---------------------------------------------------------------
  * Replaces alchemiops::_[batch_]spline_spread / _gather / _gather_vec3 (spline.py:1500-2107; kernels
  * :497-676, :763-959).  Orders 1-4 use the reference's piecewise polynomials; orders 5-6 use the true
@@ -160,6 +171,12 @@ int mi_spline_gather(const void* positions, const void* mesh, const int32_t* bat
 int mi_spline_gather_vec3(const void* positions, const void* charges, const void* mesh_vec3 /*[B,nx,ny,nz,3]*/,
                           const int32_t* batch_idx, const void* cell_inv_t, int n_atoms, int n_systems, int nx,
                           int ny, int nz, int order, int dtype, void* out /*[n_atoms,3]*/, void* stream);
+
+/* Gradient of a gather w.r.t. the fractional coordinate: out[i][a] = sum_g mesh[g] * d w_i(g) / d frac_a  (frac = cell_inv_t . r;
+ * the factor mesh_dims[a] of d theta / d frac is included).  Building block of the spread / gather adjoints
+ * (reference: _bspline_gather_gradient_kernel, spline.py:680-760, and the Warp adjoints of the spread/gather kernels).      */
+int mi_spline_gather_grad(const void* positions, const void* mesh, const int32_t* batch_idx, const void* cell_inv_t, int n_atoms,
+                          int n_systems, int nx, int ny, int nz, int order, int dtype, void* out /*[n_atoms,3]*/, void* stream);
 
 /* ---- PME reciprocal-space mesh kernels ------------------------------------------------------
  * mi_pme_green_sf: alchemiops::_[batch_]pme_green_structure_factor (pme.py:273-553, pme_kernels.py:121-331)

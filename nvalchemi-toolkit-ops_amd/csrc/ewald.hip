@@ -76,7 +76,90 @@ __global__ __launch_bounds__(256) void ewald_real_kernel(const T* __restrict__ p
   }
 }
 
+// adjoint for L = sum_i g_i E_i (see header): same walk, same skips, weights (g_i + g_j)
+template <class T, bool CSR>
+__global__ __launch_bounds__(256) void ewald_real_bwd_kernel(const T* __restrict__ pos, const T* __restrict__ q, const T* __restrict__ cell,
+                                                             const T* __restrict__ alpha, const int* __restrict__ batch_idx, int N,
+                                                             const int* __restrict__ idx, const int* __restrict__ ush,
+                                                             const int* __restrict__ nptr, int M, int mask_value, const T* __restrict__ gE,
+                                                             T* __restrict__ gpos, T* __restrict__ gq, double* __restrict__ gcell,
+                                                             double* __restrict__ galpha) {
+  const int lane = threadIdx.x & (MI_WAVE - 1);
+  const int i = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x / MI_WAVE) + threadIdx.x / MI_WAVE);
+  if (i >= N) return;
+  const int s = batch_idx ? batch_idx[i] : 0;
+  const double qi = (double)q[i], al = (double)alpha[s], gi = (double)gE[i];
+  T cm[9];
+  for (int k = 0; k < 9; ++k) cm[k] = cell[9 * (size_t)s + k];
+  const T pix = pos[3 * (size_t)i], piy = pos[3 * (size_t)i + 1], piz = pos[3 * (size_t)i + 2];
+  const double two_over_sqrt_pi = 2.0 / 1.7724538509055159;
+  long long beg, end;
+  if (CSR) { beg = nptr[i]; end = nptr[i + 1]; } else { beg = (long long)i * M; end = beg + M; }
+  double gx = 0, gy = 0, gz = 0, gqi = 0, ga = 0;
+  double gc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  for (long long e = beg + lane; e < end; e += MI_WAVE) {
+    const int j = idx[e];
+    if (!CSR && j == mask_value) continue;
+    const double qj = (double)q[j], gj = (double)gE[j];
+    const int S0 = ush[3 * e], S1 = ush[3 * e + 1], S2 = ush[3 * e + 2];
+    const T fs[3] = {(T)S0, (T)S1, (T)S2};
+    T sh[3];
+    rowvec_mat3(fs, cm, sh);
+    const T sx = (pos[3 * (size_t)j] - pix) + sh[0], sy = (pos[3 * (size_t)j + 1] - piy) + sh[1], sz = (pos[3 * (size_t)j + 2] - piz) + sh[2];
+    const double dist = (double)sqrt(sx * sx + sy * sy + sz * sz);
+    if (!(dist > 1e-8)) continue;
+    const double ar = al * dist;
+    const double ex = exp(-(ar * ar));
+    const double ec = erfc_as_poly(ar, ex);
+    const double fm = (0.5 * qi * qj) * (ec / (dist * dist * dist) + two_over_sqrt_pi * al * ex / (dist * dist));
+    const double wsum = gi + gj;
+    gx += wsum * fm * (double)sx; gy += wsum * fm * (double)sy; gz += wsum * fm * (double)sz;
+    gqi += 0.5 * wsum * qj * ec / dist;
+    if (galpha) ga += gi * (0.5 * qi * qj) * (-two_over_sqrt_pi * ex);
+    if (gcell) {
+      const double f = -gi * fm;
+      const double sv[3] = {(double)sx, (double)sy, (double)sz};
+      const double Sv[3] = {(double)S0, (double)S1, (double)S2};
+#pragma unroll
+      for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) gc[3 * a + b] += f * Sv[a] * sv[b];
+    }
+  }
+  gx = wave_sum(gx); gy = wave_sum(gy); gz = wave_sum(gz); gqi = wave_sum(gqi);
+  if (lane == 0) {
+    gpos[3 * (size_t)i] = (T)gx; gpos[3 * (size_t)i + 1] = (T)gy; gpos[3 * (size_t)i + 2] = (T)gz;
+    gq[i] = (T)gqi;
+  }
+  if (galpha) { ga = wave_sum(ga); if (lane == 0) atomicAdd(&galpha[s], ga); }
+  if (gcell) {
+#pragma unroll
+    for (int k = 0; k < 9; ++k) { const double v = wave_sum(gc[k]); if (lane == 0 && v != 0.0) atomicAdd(&gcell[9 * (size_t)s + k], v); }
+  }
+}
+
 }  // namespace
+
+extern "C" int mi_ewald_real_bwd(const void* positions, const void* charges, const void* cell, const void* alpha, const int32_t* batch_idx,
+                                 int n_atoms, int dtype, const int32_t* idx_j, const int32_t* unit_shifts, const int32_t* neighbor_ptr,
+                                 int max_neighbors, int mask_value, const void* grad_energies, void* grad_positions, void* grad_charges,
+                                 double* grad_cell, double* grad_alpha, void* stream) {
+  MI_REQUIRE(dtype == MI_F32 || dtype == MI_F64, "dtype");
+  if (n_atoms <= 0) return MI_OK;
+  MI_REQUIRE(positions && charges && cell && alpha && idx_j && unit_shifts && grad_energies && grad_positions && grad_charges, "null pointer");
+  hipStream_t st = (hipStream_t)stream;
+  const int blocks = mi_blocks(n_atoms, 4);
+  const bool csr = neighbor_ptr != nullptr;
+#define MI_EWB(T_, CSR_)                                                                                                                       \
+  ewald_real_bwd_kernel<T_, CSR_><<<blocks, 256, 0, st>>>((const T_*)positions, (const T_*)charges, (const T_*)cell, (const T_*)alpha, batch_idx, \
+                                                          n_atoms, idx_j, unit_shifts, neighbor_ptr, max_neighbors, mask_value,                  \
+                                                          (const T_*)grad_energies, (T_*)grad_positions, (T_*)grad_charges, grad_cell, grad_alpha)
+  if (dtype == MI_F32) { if (csr) MI_EWB(float, true); else MI_EWB(float, false); }
+  else { if (csr) MI_EWB(double, true); else MI_EWB(double, false); }
+#undef MI_EWB
+  MI_LAUNCH_CHECK();
+  return MI_OK;
+}
 
 extern "C" int mi_ewald_real(const void* positions, const void* charges, const void* cell, const void* alpha, const int32_t* batch_idx,
                              int n_atoms, int dtype, const int32_t* idx_j, const int32_t* unit_shifts, const int32_t* neighbor_ptr,

@@ -66,6 +66,31 @@ template <class T> __device__ __forceinline__ T bspline_weight(T u, int order) {
   return order <= 4 ? bspline_ref(u, order) : bspline_high(u, order);
 }
 
+// d M_n / du: the reference's piecewise forms for n <= 4 (spline.py:197-254), M_{n-1}(u) - M_{n-1}(u-1) for n = 5, 6
+template <class T> __device__ __forceinline__ T bspline_deriv(T u, int order) {
+  const T zero = 0, one = 1, two = 2, three = 3, four = 4, six = 6;
+  if (order == 4) {
+    if (u >= zero && u < one) return u * u / two;
+    if (u >= one && u < two) return (T(-9) * u * u + T(24) * u - T(12)) / six;
+    if (u >= two && u < three) return (T(9) * u * u - T(48) * u + T(60)) / six;
+    if (u >= three && u < four) { const T v = four - u; return -three * v * v / six; }
+    return zero;
+  }
+  if (order == 3) {
+    if (u >= zero && u < one) return u;
+    if (u >= one && u < two) return -two * (u - T(1.5));
+    if (u >= two && u < three) return -(three - u);
+    return zero;
+  }
+  if (order == 2) {
+    if (u >= zero && u < one) return one;
+    if (u >= one && u < two) return -one;
+    return zero;
+  }
+  if (order >= 5) return bspline_high(u, order - 1) - bspline_high(u - one, order - 1);
+  return zero;
+}
+
 template <class T> struct Stencil { int base[3]; T theta[3]; int off0[3]; };
 
 // compute_fractional_coords + bspline_grid_offset (spline.py:258-347)
@@ -151,6 +176,41 @@ __global__ void spline_gather_kernel(const T* __restrict__ pos, const T* __restr
     }
   }
   for (int c = 0; c < CH; ++c) out[(size_t)i * CH + c] = acc[c];
+}
+
+// gradient of the scalar gather w.r.t. the fractional coordinate (x mesh dims): building block of the spread/gather adjoints
+template <class T>
+__global__ void spline_gather_grad_kernel(const T* __restrict__ pos, const T* __restrict__ mesh, const int* __restrict__ batch_idx,
+                                          const T* __restrict__ cit, int N, int nx, int ny, int nz, int order, T* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  const int s = batch_idx ? batch_idx[i] : 0;
+  const Stencil<T> st = make_stencil(pos + 3 * (size_t)i, cit + 9 * (size_t)s, nx, ny, nz, order);
+  T w1[3][MI_MAX_ORDER], d1[3][MI_MAX_ORDER];
+  int gi[3][MI_MAX_ORDER];
+  const int dims[3] = {nx, ny, nz};
+  for (int d = 0; d < 3; ++d)
+    for (int t = 0; t < order; ++t) {
+      const T u = (T)order * T(0.5) + st.theta[d] - (T)(t + st.off0[d]);
+      const bool in = !(u < T(0) || u >= (T)order);
+      w1[d][t] = in ? bspline_weight(u, order) : T(0);
+      d1[d][t] = in ? bspline_deriv(u, order) * (T)dims[d] : T(0);  // du/dtheta = +1, dtheta/dfrac = dims
+      gi[d][t] = wrap_idx(st.base[d] + t + st.off0[d], dims[d]);
+    }
+  T gx = 0, gy = 0, gz = 0;
+  const T* m0 = mesh + (size_t)s * nx * ny * nz;
+  for (int tx = 0; tx < order; ++tx)
+    for (int ty = 0; ty < order; ++ty) {
+      const T* row = m0 + ((size_t)gi[0][tx] * ny + gi[1][ty]) * nz;
+      const T wxy = w1[0][tx] * w1[1][ty], dxy = d1[0][tx] * w1[1][ty], xdy = w1[0][tx] * d1[1][ty];
+      for (int tz = 0; tz < order; ++tz) {
+        const T v = row[gi[2][tz]];
+        gx += v * dxy * w1[2][tz];
+        gy += v * xdy * w1[2][tz];
+        gz += v * wxy * d1[2][tz];
+      }
+    }
+  out[3 * (size_t)i] = gx; out[3 * (size_t)i + 1] = gy; out[3 * (size_t)i + 2] = gz;
 }
 
 // PME epilogue: potential (+ field) gather from PLANAR meshes [B,C,nx,ny,nz] (C = 1 or 4), corrections, force factor
@@ -345,6 +405,21 @@ int mi_spline_gather(const void* positions, const void* mesh, const int32_t* bat
   MI_DISPATCH_T(dtype, (spline_gather_kernel<T_, 1><<<mi_blocks(n_atoms, 128), 128, 0, st>>>((const T_*)positions, nullptr, (const T_*)mesh, batch_idx,
                                                                                              (const T_*)cell_inv_t, n_atoms, nx, ny, nz, order,
                                                                                              (T_*)out)));
+  MI_LAUNCH_CHECK();
+  return MI_OK;
+}
+
+int mi_spline_gather_grad(const void* positions, const void* mesh, const int32_t* batch_idx, const void* cell_inv_t, int n_atoms, int n_systems,
+                          int nx, int ny, int nz, int order, int dtype, void* out, void* stream) {
+  MI_REQUIRE(dtype == MI_F32 || dtype == MI_F64, "dtype");
+  MI_REQUIRE(order >= 1 && order <= MI_MAX_ORDER, "spline order must be 1..6");
+  (void)n_systems;
+  if (n_atoms <= 0) return MI_OK;
+  MI_REQUIRE(positions && mesh && cell_inv_t && out, "null pointer");
+  hipStream_t st = (hipStream_t)stream;
+  MI_DISPATCH_T(dtype, (spline_gather_grad_kernel<T_><<<mi_blocks(n_atoms, 128), 128, 0, st>>>((const T_*)positions, (const T_*)mesh, batch_idx,
+                                                                                                (const T_*)cell_inv_t, n_atoms, nx, ny, nz, order,
+                                                                                                (T_*)out)));
   MI_LAUNCH_CHECK();
   return MI_OK;
 }

@@ -13,6 +13,43 @@ import torch
 from nvalchemiops import _capi as C
 
 
+class _EwaldRealEnergyFn(torch.autograd.Function):
+    """Per-atom real-space energies with a hand-written adjoint kernel (`mi_ewald_real_bwd`) for positions, charges, cell and
+    alpha -- the reference differentiates these ops through a recorded Warp tape (autograd.py:525-665)."""
+
+    @staticmethod
+    def forward(ctx, positions, charges, cells, alpha, idx, sh, nptr, m, mask_value, bi):
+        pos, q = positions.detach().contiguous(), charges.detach().contiguous()
+        c, al = cells.detach().contiguous(), alpha.detach().contiguous()
+        n = pos.shape[0]
+        energies = torch.empty(n, dtype=torch.float64, device=pos.device)
+        rc = C.lib().mi_ewald_real(C.ptr(pos), C.ptr(q), C.ptr(c), C.ptr(al), C.ptr(bi), n, C.dtype_code(pos.dtype), C.ptr(idx), C.ptr(sh),
+                                   C.ptr(nptr), int(m), int(mask_value), 0, C.ptr(energies), None, None, C.stream_of(pos))
+        C.check(rc, "mi_ewald_real")
+        empty = torch.empty(0, device=pos.device)
+        ctx.save_for_backward(pos, q, c, al, idx, sh, nptr if nptr is not None else empty, bi if bi is not None else empty)
+        ctx.meta = (m, mask_value, nptr is not None, bi is not None)
+        return energies.to(pos.dtype)
+
+    @staticmethod
+    def backward(ctx, g_e):
+        pos, q, c, al, idx, sh, nptr_t, bi_t = ctx.saved_tensors
+        m, mask_value, has_ptr, has_bi = ctx.meta
+        n, dt, dev = pos.shape[0], pos.dtype, pos.device
+        g = g_e.detach().to(dt).contiguous()
+        gpos = torch.empty((n, 3), dtype=dt, device=dev)
+        gq = torch.empty(n, dtype=dt, device=dev)
+        need = ctx.needs_input_grad
+        gcell = torch.zeros(c.shape, dtype=torch.float64, device=dev) if need[2] else None
+        galpha = torch.zeros(al.shape, dtype=torch.float64, device=dev) if need[3] else None
+        rc = C.lib().mi_ewald_real_bwd(C.ptr(pos), C.ptr(q), C.ptr(c), C.ptr(al), C.ptr(bi_t if has_bi else None), n, C.dtype_code(dt),
+                                       C.ptr(idx), C.ptr(sh), C.ptr(nptr_t if has_ptr else None), int(m), int(mask_value), C.ptr(g),
+                                       C.ptr(gpos), C.ptr(gq), C.ptr(gcell), C.ptr(galpha), C.stream_of(pos))
+        C.check(rc, "mi_ewald_real_bwd")
+        return (gpos if need[0] else None, gq if need[1] else None, None if gcell is None else gcell.to(dt),
+                None if galpha is None else galpha.to(dt), None, None, None, None, None, None)
+
+
 def ewald_real_space(positions: torch.Tensor, charges: torch.Tensor, cell: torch.Tensor, alpha: torch.Tensor,
                      neighbor_list: torch.Tensor | None = None, neighbor_ptr: torch.Tensor | None = None,
                      neighbor_shifts: torch.Tensor | None = None, neighbor_matrix: torch.Tensor | None = None,
@@ -35,14 +72,15 @@ def ewald_real_space(positions: torch.Tensor, charges: torch.Tensor, cell: torch
             out += (torch.zeros(0, dtype=dt, device=dev),)
         return out if len(out) > 1 else out[0]
     C.require_device(positions, charges, cell, neighbor_list, neighbor_ptr, neighbor_matrix, batch_idx)
+    alpha_in = alpha if isinstance(alpha, torch.Tensor) else torch.tensor([float(alpha)], device=dev)
+    alpha_in = alpha_in.to(device=dev, dtype=dt).reshape(-1)
+    if alpha_in.numel() == 1 and cell.reshape(-1, 3, 3).shape[0] > 1:
+        alpha_in = alpha_in.expand(cell.reshape(-1, 3, 3).shape[0])
+    wants_grad = torch.is_grad_enabled() and any(t.requires_grad for t in (positions, charges, cell, alpha_in))
     pos = positions.detach().contiguous()
     q = charges.detach().to(dt).contiguous()
     cells = cell.detach().to(dt).reshape(-1, 3, 3).contiguous()
-    alpha_t = alpha if isinstance(alpha, torch.Tensor) else torch.tensor([float(alpha)], device=dev)
-    alpha_t = alpha_t.detach().to(device=dev, dtype=dt).reshape(-1)
-    if alpha_t.numel() == 1 and cells.shape[0] > 1:
-        alpha_t = alpha_t.expand(cells.shape[0])
-    alpha_t = alpha_t.contiguous()
+    alpha_t = alpha_in.detach().contiguous()
     bi = None if batch_idx is None else C.i32(batch_idx)
     if neighbor_list is not None:
         idx, nptr, m = C.i32(neighbor_list[1]), C.i32(neighbor_ptr), 0
@@ -65,7 +103,11 @@ def ewald_real_space(positions: torch.Tensor, charges: torch.Tensor, cell: torch
         rc = C.lib().mi_ewald_real(C.ptr(pos), C.ptr(q), C.ptr(cells), C.ptr(alpha_t), C.ptr(bi), n, code, C.ptr(idx), C.ptr(sh), C.ptr(nptr),
                                    int(m), int(mask_value), flags, C.ptr(energies), C.ptr(forces), C.ptr(cgrads), C.stream_of(pos))
         C.check(rc, "mi_ewald_real")
-    out = (energies.to(dt),)  # ewald.py:577: energies are accumulated in float64 and returned in the input dtype
+    e_out = energies.to(dt)  # ewald.py:577: energies are accumulated in float64 and returned in the input dtype
+    if wants_grad and n_entries > 0:
+        # differentiable energies (explicit forces / charge gradients above stay plain outputs, as MD codes consume them)
+        e_out = _EwaldRealEnergyFn.apply(positions, charges.to(dt), cell.to(dt).reshape(-1, 3, 3), alpha_in, idx, sh, nptr, m, mask_value, bi)
+    out = (e_out,)
     if compute_forces:
         out += (forces,)
     if compute_charge_gradients:

@@ -163,6 +163,49 @@ def _reciprocal_with_kvectors(pos, q, cells, alpha, mesh_dimensions, spline_orde
     return energies, forces, cgrads
 
 
+def _reciprocal_autograd(positions, charges, cells, alpha, mesh_dimensions, spline_order, bi, compute_forces, compute_charge_gradients):
+    """Differentiable composition used when positions / charges / cell / alpha require grad (reference: every `alchemiops::*` op carries
+    a Warp-tape backward, autograd.py:124-297; the FFTs and elementwise steps differentiate through torch).  Spread and gather have
+    hand-written adjoint kernels (nvalchemiops.spline); Green function, k-grid and corrections are plain differentiable torch here.
+    Explicit forces / charge gradients, when requested, come from the fused non-differentiable pipeline on detached inputs."""
+    from nvalchemiops.interactions.electrostatics.k_vectors import generate_k_vectors_pme
+    from nvalchemiops.spline import _GatherFn, _SpreadFn
+
+    dt, dev = positions.dtype, positions.device
+    nx, ny, nz = mesh_dimensions
+    batched = bi is not None
+    nsys = cells.shape[0] if batched else 1
+    cell_inv = torch.linalg.inv(cells)
+    cit = cell_inv.transpose(-1, -2)
+    q = charges.to(dt)
+    al = alpha.to(dt)
+    vol = torch.abs(torch.linalg.det(cells)).to(dt)
+    mesh = _SpreadFn.apply(positions, q, cit, bi, nsys, (nx, ny, nz), int(spline_order), batched)
+    spec = torch.fft.rfftn(mesh, norm="backward", dim=(1, 2, 3))
+    _, k2 = generate_k_vectors_pme(cells, (nx, ny, nz), reciprocal_cell=TWOPI * cell_inv)
+    k2 = k2.reshape(nsys, nx, ny, nz // 2 + 1)
+    a4 = (4.0 * al * al).reshape(nsys, 1, 1, 1)
+    green = TWOPI * torch.exp(-k2 / a4) / (k2 * vol.reshape(nsys, 1, 1, 1))
+    origin = torch.zeros((nx, ny, nz // 2 + 1), dtype=torch.bool, device=dev)
+    origin[0, 0, 0] = True
+    green = torch.where((k2 < 1e-10) | origin, torch.zeros((), dtype=dt, device=dev), green)
+    _, sf2 = pme_green_structure_factor(k2.detach() if batched else k2.detach()[0], (nx, ny, nz), al.detach(), cells.detach(), spline_order,
+                                        batch_idx=bi)
+    conv = spec / sf2 * green
+    phi = torch.fft.irfftn(conv, norm="forward", s=(nx, ny, nz), dim=(1, 2, 3))
+    raw = _GatherFn.apply(positions, phi, cit, bi, int(spline_order))
+    sys_of = bi.long() if batched else torch.zeros(positions.shape[0], dtype=torch.long, device=dev)
+    qtot = torch.zeros(nsys, dtype=dt, device=dev).index_add(0, sys_of, q)
+    a_i, v_i, qt_i = al[sys_of], vol[sys_of], qtot[sys_of]
+    energies = q * raw - q * q * a_i / math.sqrt(math.pi) - q * math.pi * qt_i / (2.0 * a_i * a_i * v_i)
+    forces = cgrads = None
+    if compute_forces or compute_charge_gradients:
+        with torch.no_grad():
+            _, forces, cgrads = _reciprocal_fused(positions.detach().contiguous(), q.detach().contiguous(), cells.detach().contiguous(),
+                                                  alpha.detach(), mesh_dimensions, spline_order, bi, compute_forces, compute_charge_gradients)
+    return energies, forces, cgrads
+
+
 def pme_reciprocal_space(positions: torch.Tensor, charges: torch.Tensor, cell: torch.Tensor, alpha: float | torch.Tensor,
                          mesh_dimensions: tuple[int, int, int] | None = None, mesh_spacing: float | None = None, spline_order: int = 4,
                          batch_idx: torch.Tensor | None = None, k_vectors: torch.Tensor | None = None,
@@ -186,12 +229,17 @@ def pme_reciprocal_space(positions: torch.Tensor, charges: torch.Tensor, cell: t
     else:
         C.require_device(positions, charges, cell, batch_idx)
         C.dtype_code(dt)
+        bi = None if batch_idx is None else C.i32(batch_idx)
+        wants_grad = torch.is_grad_enabled() and any(isinstance(t, torch.Tensor) and t.requires_grad for t in (positions, charges, cell, alpha))
         pos = positions.detach().contiguous()
         q = charges.detach().to(dt).contiguous()
         cells_t = cells.detach().to(dt).contiguous()
-        bi = None if batch_idx is None else C.i32(batch_idx)
         args = (pos, q, cells_t, alpha_t, mesh_dimensions, spline_order, bi, compute_forces, compute_charge_gradients)
-        if k_vectors is None or k_squared is None:
+        if wants_grad:
+            alpha_g = _prepare_alpha(alpha, num_systems, dt, dev)
+            energies, forces, cgrads = _reciprocal_autograd(positions, charges, cells.to(dt), alpha_g, mesh_dimensions, spline_order, bi,
+                                                            compute_forces, compute_charge_gradients)
+        elif k_vectors is None or k_squared is None:
             energies, forces, cgrads = _reciprocal_fused(*args)
         else:
             energies, forces, cgrads = _reciprocal_with_kvectors(*args, k_vectors, k_squared)

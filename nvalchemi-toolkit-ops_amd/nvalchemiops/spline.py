@@ -22,10 +22,118 @@ def _prep(positions: torch.Tensor, cell: torch.Tensor, batch_idx, cell_inv_t):
     return pos, c, cit, bi
 
 
+# ---- raw launchers (detached, contiguous tensors) ------------------------------------------------------------------
+def _launch_spread(pos, vals, cit, bi, nsys, dims, order, batched):
+    nx, ny, nz = dims
+    mesh = torch.zeros((nsys, nx, ny, nz), dtype=pos.dtype, device=pos.device)
+    rc = C.lib().mi_spline_spread(C.ptr(pos), C.ptr(vals), C.ptr(bi), C.ptr(cit), pos.shape[0], nsys, nx, ny, nz, int(order), int(batched),
+                                  C.dtype_code(pos.dtype), C.ptr(mesh), C.stream_of(pos))
+    C.check(rc, "mi_spline_spread")
+    return mesh
+
+
+def _launch_gather(pos, mesh, cit, bi, order, grad=False):
+    nx, ny, nz = mesh.shape[-3:]
+    out = torch.empty((pos.shape[0], 3) if grad else (pos.shape[0],), dtype=pos.dtype, device=pos.device)
+    fn = C.lib().mi_spline_gather_grad if grad else C.lib().mi_spline_gather
+    rc = fn(C.ptr(pos), C.ptr(mesh), C.ptr(bi), C.ptr(cit), pos.shape[0], cit.shape[0], nx, ny, nz, int(order), C.dtype_code(pos.dtype),
+            C.ptr(out), C.stream_of(pos))
+    C.check(rc, "mi_spline_gather_grad" if grad else "mi_spline_gather")
+    return out
+
+
+def _coordinate_grads(weight, gfrac, pos, cit, bi, need_pos, need_cit):
+    """frac = cell_inv_t . r  =>  dL/dr_b = w sum_a gfrac_a cit[a][b] ;  dL/dcit[s][a][b] = sum_{i in s} w_i gfrac_i[a] r_i[b]."""
+    wg = gfrac * weight.unsqueeze(-1)
+    cit_i = cit[bi.long()] if bi is not None else cit[0].expand(pos.shape[0], 3, 3)
+    gpos = torch.einsum("na,nab->nb", wg, cit_i) if need_pos else None
+    gcit = None
+    if need_cit:
+        outer = wg.unsqueeze(-1) * pos.unsqueeze(-2)
+        gcit = torch.zeros_like(cit)
+        if bi is None:
+            gcit[0] = outer.sum(0)
+        else:
+            gcit.index_add_(0, bi.long(), outer)
+    return gpos, gcit
+
+
+class _SpreadFn(torch.autograd.Function):
+    """mesh = spread(values at positions).  Hand-written adjoint (the reference records a Warp tape: autograd.py:124-297):
+    d/dvalues = gather(grad_mesh), d/dpositions and d/dcell_inv_t through the gather-gradient kernel."""
+
+    @staticmethod
+    def forward(ctx, positions, values, cit, bi, nsys, dims, order, batched):
+        pos, vals, citc = positions.detach().contiguous(), values.detach().contiguous(), cit.detach().contiguous()
+        ctx.save_for_backward(pos, vals, citc, bi if bi is not None else torch.empty(0))
+        ctx.meta = (bi is not None, order)
+        return _launch_spread(pos, vals, citc, bi, nsys, dims, order, batched)
+
+    @staticmethod
+    def backward(ctx, gmesh):
+        pos, vals, cit, bi_t = ctx.saved_tensors
+        has_bi, order = ctx.meta
+        bi = bi_t if has_bi else None
+        g = gmesh.detach().contiguous()
+        need = ctx.needs_input_grad
+        gvals = _launch_gather(pos, g, cit, bi, order) if need[1] else None
+        gpos = gcit = None
+        if need[0] or need[2]:
+            gfrac = _launch_gather(pos, g, cit, bi, order, grad=True)
+            gpos, gcit = _coordinate_grads(vals, gfrac, pos, cit, bi, need[0], need[2])
+        return gpos, gvals, gcit, None, None, None, None, None
+
+
+class _GatherFn(torch.autograd.Function):
+    """out_i = gather(mesh at position i).  Adjoint: d/dmesh = spread(grad_out); d/dpositions, d/dcell_inv_t via gather-gradient."""
+
+    @staticmethod
+    def forward(ctx, positions, mesh, cit, bi, order):
+        pos, m, citc = positions.detach().contiguous(), mesh.detach().contiguous(), cit.detach().contiguous()
+        ctx.save_for_backward(pos, m, citc, bi if bi is not None else torch.empty(0))
+        ctx.meta = (bi is not None, order)
+        return _launch_gather(pos, m, citc, bi, order)
+
+    @staticmethod
+    def backward(ctx, gout):
+        pos, mesh, cit, bi_t = ctx.saved_tensors
+        has_bi, order = ctx.meta
+        bi = bi_t if has_bi else None
+        g = gout.detach().contiguous()
+        need = ctx.needs_input_grad
+        gmesh = None
+        if need[1]:
+            nsys = mesh.shape[0] if mesh.dim() == 4 else 1
+            gm = _launch_spread(pos, g, cit, bi, nsys, tuple(mesh.shape[-3:]), order, has_bi)
+            gmesh = gm if mesh.dim() == 4 else gm[0]
+        gpos = gcit = None
+        if need[0] or need[2]:
+            gfrac = _launch_gather(pos, mesh, cit, bi, order, grad=True)
+            gpos, gcit = _coordinate_grads(g, gfrac, pos, cit, bi, need[0], need[2])
+        return gpos, gmesh, gcit, None, None
+
+
+def _wants_grad(*tensors) -> bool:
+    return torch.is_grad_enabled() and any(t is not None and isinstance(t, torch.Tensor) and t.requires_grad for t in tensors)
+
+
+def _differentiable_cit(cell: torch.Tensor, cell_inv_t, dtype):
+    c = (cell if cell.dim() == 3 else cell.unsqueeze(0)).to(dtype)
+    return (torch.linalg.inv(c).transpose(-1, -2) if cell_inv_t is None else cell_inv_t.to(dtype).reshape(-1, 3, 3)), c
+
+
 def spline_spread(positions: torch.Tensor, values: torch.Tensor, cell: torch.Tensor, mesh_dims: tuple[int, int, int], spline_order: int = 4,
                   batch_idx: torch.Tensor | None = None, cell_inv_t: torch.Tensor | None = None) -> torch.Tensor:
-    """mesh[(B,) nx, ny, nz] += values_i * M_n(x) M_n(y) M_n(z) over each atom's order^3 stencil (periodic wrap)."""
+    """mesh[(B,) nx, ny, nz] += values_i * M_n(x) M_n(y) M_n(z) over each atom's order^3 stencil (periodic wrap).
+    Differentiable w.r.t. positions, values and cell (hand-written adjoint kernels)."""
     C.require_device(positions, values, cell)
+    if _wants_grad(positions, values, cell, cell_inv_t):
+        cit, c = _differentiable_cit(cell, cell_inv_t, positions.dtype)
+        bi = None if batch_idx is None else C.i32(batch_idx)
+        nsys = c.shape[0] if bi is not None else 1
+        mesh = _SpreadFn.apply(positions, values.to(positions.dtype), cit, bi, nsys, tuple(int(v) for v in mesh_dims), int(spline_order),
+                               bi is not None)
+        return mesh if bi is not None else mesh[0]
     pos, c, cit, bi = _prep(positions, cell, batch_idx, cell_inv_t)
     nx, ny, nz = (int(v) for v in mesh_dims)
     nsys = c.shape[0] if bi is not None else 1
@@ -39,8 +147,13 @@ def spline_spread(positions: torch.Tensor, values: torch.Tensor, cell: torch.Ten
 
 def spline_gather(positions: torch.Tensor, mesh: torch.Tensor, cell: torch.Tensor, spline_order: int = 4,
                   batch_idx: torch.Tensor | None = None, cell_inv_t: torch.Tensor | None = None) -> torch.Tensor:
-    """out_i = sum over the stencil of mesh[g] * w  (weights <= 1e-8 are skipped, spline.py:608)."""
+    """out_i = sum over the stencil of mesh[g] * w  (weights <= 1e-8 are skipped, spline.py:608).
+    Differentiable w.r.t. positions, mesh and cell."""
     C.require_device(positions, mesh, cell)
+    if _wants_grad(positions, mesh, cell, cell_inv_t):
+        cit, _ = _differentiable_cit(cell, cell_inv_t, positions.dtype)
+        bi = None if batch_idx is None else C.i32(batch_idx)
+        return _GatherFn.apply(positions, mesh.to(positions.dtype), cit, bi, int(spline_order))
     pos, c, cit, bi = _prep(positions, cell, batch_idx, cell_inv_t)
     m = mesh.detach().to(pos.dtype).contiguous()
     nx, ny, nz = m.shape[-3:]

@@ -1,0 +1,133 @@
+"""Autograd through the electrostatics path: hand-written adjoint kernels for spline spread / gather and the
+real-space sum, torch autograd for the FFT/elementwise middle.  Checks the reference's own properties
+(test/interactions/electrostatics/test_pme.py:1458 explicit forces == -autograd, :1510-1578 finite differences) plus adjoint
+identities of the spline ops (test/test_spline.py:637)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _system(n=60, box=11.0, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    cell = torch.tensor([[box, 0, 0], [0.15 * box, 0.95 * box, 0], [0.1 * box, -0.1 * box, 1.05 * box]], dtype=torch.float64)
+    pos = torch.rand((n, 3), generator=g, dtype=torch.float64) @ cell
+    q = torch.randn(n, generator=g, dtype=torch.float64)
+    q -= q.mean()
+    return pos.to(DEV), cell.to(DEV), q.to(DEV)
+
+
+def test_spline_adjoints_match_finite_differences():
+    from nvalchemiops.spline import spline_gather, spline_spread
+
+    pos, cell, q = _system(20)
+    dims = (10, 12, 9)
+    field = torch.randn(dims, dtype=torch.float64, device=DEV)
+    for order in (3, 4, 5):
+        p = pos.clone().requires_grad_(True)
+        v = q.clone().requires_grad_(True)
+        c = cell.clone().requires_grad_(True)
+        loss = (spline_spread(p, v, c, dims, order) * field).sum()
+        gp, gv, gc = torch.autograd.grad(loss, (p, v, c))
+        # d/dvalues is exactly a gather of the field
+        assert torch.allclose(gv, spline_gather(pos, field, cell, order), rtol=1e-10, atol=1e-12)
+        eps = 1e-6
+        for (idx, d) in ((3, 0), (7, 2)):
+            pp, pm = pos.clone(), pos.clone()
+            pp[idx, d] += eps
+            pm[idx, d] -= eps
+            fd = ((spline_spread(pp, q, cell, dims, order) - spline_spread(pm, q, cell, dims, order)) * field).sum() / (2 * eps)
+            assert abs(fd.item() - gp[idx, d].item()) < 1e-5 * max(1.0, abs(fd.item()))
+        cp, cm = cell.clone(), cell.clone()
+        cp[1, 0] += eps
+        cm[1, 0] -= eps
+        fd = ((spline_spread(pos, q, cp, dims, order) - spline_spread(pos, q, cm, dims, order)) * field).sum() / (2 * eps)
+        assert abs(fd.item() - gc[1, 0].item()) < 1e-5 * max(1.0, abs(fd.item()))
+        # gather: gradient w.r.t. the mesh is a spread of the upstream gradient
+        m = field.clone().requires_grad_(True)
+        p2 = pos.clone().requires_grad_(True)
+        w = torch.randn(20, dtype=torch.float64, device=DEV)
+        out = (spline_gather(p2, m, cell, order) * w).sum()
+        gm, gp2 = torch.autograd.grad(out, (m, p2))
+        assert torch.allclose(gm, spline_spread(pos, w, cell, dims, order), rtol=1e-10, atol=1e-12)
+        pp, pm = pos.clone(), pos.clone()
+        pp[5, 1] += eps
+        pm[5, 1] -= eps
+        fd = ((spline_gather(pp, field, cell, order) - spline_gather(pm, field, cell, order)) * w).sum() / (2 * eps)
+        assert abs(fd.item() - gp2[5, 1].item()) < 1e-5 * max(1.0, abs(fd.item()))
+
+
+@pytest.mark.parametrize("fmt", ["matrix", "csr"])
+def test_pme_autograd_equals_explicit_forces_and_fd(fmt):
+    from nvalchemiops.interactions.electrostatics import particle_mesh_ewald
+    from nvalchemiops.neighborlist import cell_list
+
+    pos, cell, q = _system(60)
+    pbc = torch.tensor([True] * 3, device=DEV)
+    kw = {}
+    if fmt == "matrix":
+        nm, num, sh = cell_list(pos, 6.0, cell, pbc, max_neighbors=128)
+        kw = dict(neighbor_matrix=nm, neighbor_matrix_shifts=sh)
+    else:
+        lst, nptr, lsh = cell_list(pos, 6.0, cell, pbc, return_neighbor_list=True)
+        kw = dict(neighbor_list=lst, neighbor_ptr=nptr, neighbor_shifts=lsh)
+    common = dict(alpha=0.4, mesh_dimensions=(24, 24, 24), spline_order=4)
+    e, f, cg = particle_mesh_ewald(pos, q, cell, compute_forces=True, compute_charge_gradients=True, **common, **kw)
+    p = pos.clone().requires_grad_(True)
+    qq = q.clone().requires_grad_(True)
+    e2 = particle_mesh_ewald(p, qq, cell, **common, **kw)
+    assert torch.allclose(e2.detach(), e, rtol=1e-10, atol=1e-12)
+    gp, gq = torch.autograd.grad(e2.sum(), (p, qq))
+    # explicit forces == -dE/dr (reference tolerance rtol 1e-3 / atol 1e-4, test_pme.py:1458); charge gradients == dE/dq
+    assert torch.allclose(-gp, f, rtol=1e-3, atol=1e-4), float((-gp - f).abs().max())
+    assert torch.allclose(gq, cg, rtol=1e-3, atol=1e-4), float((gq - cg).abs().max())
+    # finite differences of the total energy (neighbour list rebuilt at each displaced geometry)
+    eps = 1e-5
+
+    def total(pp):
+        if fmt == "matrix":
+            a, _, b = cell_list(pp, 6.0, cell, pbc, max_neighbors=128)
+            k2 = dict(neighbor_matrix=a, neighbor_matrix_shifts=b)
+        else:
+            a, b, c2 = cell_list(pp, 6.0, cell, pbc, return_neighbor_list=True)
+            k2 = dict(neighbor_list=a, neighbor_ptr=b, neighbor_shifts=c2)
+        return particle_mesh_ewald(pp, q, cell, **common, **k2).sum().item()
+
+    for (i, d) in ((0, 0), (17, 2)):
+        pp, pm = pos.clone(), pos.clone()
+        pp[i, d] += eps
+        pm[i, d] -= eps
+        fd = (total(pp) - total(pm)) / (2 * eps)
+        assert abs(fd - gp[i, d].item()) < 1e-4 + 1e-2 * abs(fd)
+
+
+def test_cell_and_alpha_gradients_vs_finite_differences():
+    from nvalchemiops.interactions.electrostatics import ewald_real_space, pme_reciprocal_space
+    from nvalchemiops.neighborlist import cell_list
+
+    pos, cell, q = _system(40)
+    pbc = torch.tensor([True] * 3, device=DEV)
+    nm, num, sh = cell_list(pos, 5.5, cell, pbc, max_neighbors=96)
+    frac = pos @ torch.linalg.inv(cell)
+    c = cell.clone().requires_grad_(True)
+    a = torch.tensor([0.4], dtype=torch.float64, device=DEV, requires_grad=True)
+
+    def real(cc, aa):
+        return ewald_real_space(frac @ cc, q, cc[None], aa, neighbor_matrix=nm, neighbor_matrix_shifts=sh, mask_value=40).sum()
+
+    def recip(cc, aa):
+        return pme_reciprocal_space(frac @ cc, q, cc, aa, mesh_dimensions=(20, 20, 20), spline_order=4).sum()
+
+    for fn in (real, recip):
+        gc, ga = torch.autograd.grad(fn(c, a), (c, a))
+        eps = 1e-6
+        for (r, k) in ((0, 0), (2, 1)):
+            cp, cm = cell.clone(), cell.clone()
+            cp[r, k] += eps
+            cm[r, k] -= eps
+            fd = (fn(cp, a.detach()) - fn(cm, a.detach())).item() / (2 * eps)
+            assert abs(fd - gc[r, k].item()) < 1e-5 + 1e-4 * abs(fd), (fn.__name__, r, k, fd, gc[r, k].item())
+        fd = (fn(cell, a.detach() + eps) - fn(cell, a.detach() - eps)).item() / (2 * eps)
+        assert abs(fd - ga.item()) < 1e-5 + 1e-4 * abs(fd), (fn.__name__, fd, ga.item())
