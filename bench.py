@@ -55,6 +55,75 @@ def build_system(n_atoms: int, seed: int, device):
     return sysd, tables
 
 
+def build_batch(n_systems: int, atoms_each: int, seed: int, device):
+    """BASELINE config 5 shard: `n_systems` independent periodic boxes of `atoms_each` atoms (a = 4 A FCC, L = 32 A for 2000)."""
+    from oracle import oracle as O
+    from tests import systems as S
+
+    parts = [S.fcc_box(atoms_each, seed=seed + 17 * b, dtype=np.float64) for b in range(n_systems)]
+    pos = np.concatenate([p[0] for p in parts])
+    cell = np.stack([p[1] for p in parts])
+    q = np.concatenate([p[2] for p in parts])
+    numbers = np.concatenate([p[3] for p in parts])
+    bi = np.repeat(np.arange(n_systems, dtype=np.int32), atoms_each)
+    tables = O.d3_test_tables(94, seed=7)
+    t = lambda a, dt=None: torch.as_tensor(np.ascontiguousarray(a), dtype=dt, device=device)  # noqa: E731
+    sysd = dict(n=len(pos), nsys=n_systems, pos64=t(pos), cell64=t(cell), q64=t(q), numbers=t(numbers), bi=t(bi),
+                pos32b=t((pos * BOHR).astype(np.float32)), cell32b=t((cell * BOHR).astype(np.float32)),
+                pbc=torch.ones((n_systems, 3), dtype=torch.bool, device=device))
+    return sysd, tables
+
+
+def make_batch_step(sysd, tables, device, world, sizes):
+    """Config-5 step on this rank's shard: batch nlist + batch PME (mesh 32^3 per system) + batch nlist + batch D3, then ONE
+    all_gather of the per-system energies (D3 energy[B_local] and the per-system sum of the per-atom PME energies)."""
+    from nvalchemiops.distributed import all_gather_system_values, segment_energy
+    from nvalchemiops.interactions.dispersion import D3Parameters, dftd3
+    from nvalchemiops.interactions.electrostatics import particle_mesh_ewald
+    from nvalchemiops.neighborlist import batch_cell_list
+
+    t = lambda a: torch.as_tensor(a, device=device)  # noqa: E731
+    params = D3Parameters(rcov=t(tables["rcov"]), r4r2=t(tables["r4r2"]), c6ab=t(tables["c6ab"]), cn_ref=t(tables["cn_ref"]))
+    n, nsys, m = sysd["n"], sysd["nsys"], PME["max_neighbors"]
+    nm = torch.empty((n, m), dtype=torch.int32, device=device)
+    nsh = torch.empty((n, m, 3), dtype=torch.int32, device=device)
+    num = torch.empty(n, dtype=torch.int32, device=device)
+    alpha = torch.full((nsys,), PME["alpha"], dtype=torch.float64, device=device)
+
+    def step(record=None):
+        ev = []
+
+        def mark(name):
+            if record is not None:
+                e = torch.cuda.Event(enable_timing=True)
+                e.record()
+                ev.append((name, e))
+
+        mark("start")
+        batch_cell_list(sysd["pos64"], PME["cutoff"], sysd["cell64"], sysd["pbc"], sysd["bi"], neighbor_matrix=nm,
+                        neighbor_matrix_shifts=nsh, num_neighbors=num)
+        mark("nlist_pme")
+        e_pme, f_pme = particle_mesh_ewald(sysd["pos64"], sysd["q64"], sysd["cell64"], alpha=alpha, mesh_dimensions=(32, 32, 32),
+                                           spline_order=PME["order"], batch_idx=sysd["bi"], neighbor_matrix=nm, neighbor_matrix_shifts=nsh,
+                                           compute_forces=True)
+        mark("pme")
+        lst, nptr, lsh = batch_cell_list(sysd["pos32b"], D3["cutoff"], sysd["cell32b"], sysd["pbc"], sysd["bi"], return_neighbor_list=True)
+        mark("nlist_d3")
+        e_d3, f_d3, cn, vir = dftd3(sysd["pos32b"], sysd["numbers"], a1=D3["a1"], a2=D3["a2"], s8=D3["s8"], d3_params=params,
+                                    neighbor_list=lst, neighbor_ptr=nptr, unit_shifts=lsh, cell=sysd["cell32b"], batch_idx=sysd["bi"],
+                                    compute_virial=True, num_systems=nsys)
+        mark("d3")
+        local = torch.stack([e_d3.double(), segment_energy(e_pme, sysd["bi"], nsys)], dim=1)
+        if world > 1:
+            local = all_gather_system_values(local, sizes)
+            mark("gather")
+        if record is not None:
+            record.append(ev)
+        return e_pme, f_pme, e_d3, f_d3, num, nptr
+
+    return step, {}
+
+
 def make_step(sysd, tables, device, world):
     from nvalchemiops.interactions.dispersion import D3Parameters, dftd3
     from nvalchemiops.interactions.electrostatics import particle_mesh_ewald
@@ -184,6 +253,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--atoms", type=int, default=100000)
     ap.add_argument("--cpu-sample", type=int, default=864, help="atoms in the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--workload", default="headline", choices=["headline", "c5"],
+                    help="headline: one 100k-atom box per GPU (default, the BASELINE metric); c5: BASELINE config 5, a batch of "
+                         "--systems x 2000-atom boxes per GPU sharded at system granularity")
+    ap.add_argument("--systems", type=int, default=128, help="systems per GPU for --workload c5")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -202,8 +275,14 @@ def main():
 
     from nvalchemiops import _capi as C
 
-    sysd, tables = build_system(args.atoms, 1234 + rank, device)
-    step, _ = make_step(sysd, tables, device, world)
+    if args.workload == "c5":
+        args.atoms = args.systems * 2000
+        sysd, tables = build_batch(args.systems, 2000, 1234 + 100000 * rank, device)
+        step, _ = make_batch_step(sysd, tables, device, world, [args.systems] * world)
+        args.cpu_sample = 0
+    else:
+        sysd, tables = build_system(args.atoms, 1234 + rank, device)
+        step, _ = make_step(sysd, tables, device, world)
 
     def barrier():
         if world > 1:
@@ -256,8 +335,11 @@ def main():
             "value": value, "unit": "atom-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64 (PME) + f32 (D3)", "data": "synthetic",
-            "config": {"workload": f"{args.atoms}-atom periodic FCC box per GPU: nlist(9 A, padded M=256) + PME(alpha 0.35, mesh 128^3, "
-                                   "spline order 5, E+F, fp64) + nlist(40 Bohr, CSR) + DFT-D3(BJ, E+F+virial, fp32)",
+            "config": {"workload": (f"{args.atoms}-atom periodic FCC box per GPU: nlist(9 A, padded M=256) + PME(alpha 0.35, mesh 128^3, "
+                                    "spline order 5, E+F, fp64) + nlist(40 Bohr, CSR) + DFT-D3(BJ, E+F+virial, fp32)")
+                       if args.workload == "headline" else
+                       (f"config 5: {args.systems} x 2000-atom periodic boxes per GPU (batch): nlist(9 A) + PME(mesh 32^3 per system, order 5, "
+                        "fp64) + nlist(40 Bohr, CSR) + DFT-D3(BJ), one all_gather of per-system energies"),
                        "atoms_per_gpu": args.atoms, "d3_directed_pairs": pairs_d3, "pme_neighbors_max": int(num.max().item()),
                        "parallelism": "replica per GPU + 1 RCCL all_gather of per-system energies" if world > 1 else "single GPU"},
             "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},

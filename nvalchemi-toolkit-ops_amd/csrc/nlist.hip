@@ -86,8 +86,14 @@ __device__ __forceinline__ int idx_of(const float4& v) { return __float_as_int(v
 __device__ __forceinline__ int idx_of(const double4& v) { return (int)v.w; }
 
 __global__ void nl_count_atoms_kernel(const int* __restrict__ batch_idx, int N, int* __restrict__ natoms) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < N) atomicAdd(&natoms[batch_idx[i]], 1);
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool in = i < N;
+  const int s = in ? batch_idx[i] : -1;
+  // atoms of a system are normally contiguous: one atomic per wave instead of 64 colliding on the same address
+  const int s0 = __shfl(s, 0, MI_WAVE);
+  const unsigned long long same = __ballot(in && s == s0);
+  if ((threadIdx.x & (MI_WAVE - 1)) == 0 && s0 >= 0) atomicAdd(&natoms[s0], __popcll(same));
+  if (in && s != s0) atomicAdd(&natoms[s], 1);
 }
 
 template <class T>
