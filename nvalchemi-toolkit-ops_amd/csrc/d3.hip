@@ -213,6 +213,9 @@ __device__ __forceinline__ float d3_exp_neg(float x) {
 }
 
 __device__ __forceinline__ void d3_c6(float cn_i, float cn_j, const float4* __restrict__ t25, float k3, float& c6, float& dci) {
+  // pass A: exponent arguments of all 25 reference points (kept in registers) and their maximum.  Empty reference points
+  // (c6 == 0, which the reference skips in both of its loops) get -inf: they can neither set the maximum nor survive the
+  // exp_arg - max >= -12 test below, so pass B needs no table access at all for terms it drops.
   float a[25];
   float mx = -1e20f;
 #pragma unroll
@@ -224,33 +227,29 @@ __device__ __forceinline__ void d3_c6(float cn_i, float cn_j, const float4* __re
     for (int k = 0; k < 5; ++k) {
       const float di = cn_i - v[k].y, dj = cn_j - v[k].z;
       const float sq = di * di + dj * dj;
-      a[5 * c + k] = k3 * sq;
-      mx = (v[k].x != 0.0f && a[5 * c + k] > mx) ? a[5 * c + k] : mx;
+      const float at = (v[k].x != 0.0f) ? k3 * sq : -INFINITY;
+      a[5 * c + k] = at;
+      mx = fmaxf(mx, at);
     }
     __builtin_amdgcn_sched_barrier(0);
   }
+  // pass B: Gaussian weights of the surviving terms.  Wave-uniform skip: a term no lane keeps costs a compare and a
+  // scalar branch (typically only a few reference points are within e^-12 of the dominant one); lanes that do not keep a
+  // term add exact zeros, which is what the reference's `continue` amounts to.
   float w = 0.0f, z = 0.0f, wdi = 0.0f, zdi = 0.0f;
 #pragma unroll
-  for (int c = 0; c < 5; ++c) {
-    float2 v[5];
-#pragma unroll
-    for (int k = 0; k < 5; ++k) v[k] = *reinterpret_cast<const float2*>(&t25[5 * c + k]);  // {c6, cn_ref_i}
-#pragma unroll
-    for (int k = 0; k < 5; ++k) {
-      const float di = cn_i - v[k].y;
-      const float arg = a[5 * c + k] - mx;
-      const bool keep = (v[k].x != 0.0f) && !(arg < -12.0f);
-      // wave-uniform skip: a term no lane keeps costs nothing (typically only a few of the 25 reference points are
-      // within e^-12 of the dominant one); lanes that do not keep it add exact zeros, as the reference's `continue` does
-      if (__builtin_amdgcn_ballot_w64(keep) == 0) continue;
-      const float L = keep ? d3_exp_neg(arg) : 0.0f;
-      const float cL = v[k].x * L;
-      w += L;
-      z += cL;
-      wdi += L * di;
-      zdi += cL * di;
-    }
-    __builtin_amdgcn_sched_barrier(0);
+  for (int t = 0; t < 25; ++t) {
+    const float arg = a[t] - mx;
+    const bool keep = !(arg < -12.0f);
+    if (__builtin_amdgcn_ballot_w64(keep) == 0) continue;
+    const float2 v = *reinterpret_cast<const float2*>(&t25[t]);  // {c6, cn_ref_i}
+    const float di = cn_i - v.y;
+    const float L = keep ? d3_exp_neg(arg) : 0.0f;
+    const float cL = v.x * L;
+    w += L;
+    z += cL;
+    wdi += L * di;
+    zdi += cL * di;
   }
   if (w > 1e-12f) {
     const float wi = 1.0f / w;
