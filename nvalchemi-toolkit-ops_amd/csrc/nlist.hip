@@ -24,6 +24,9 @@
 namespace {
 
 #define NL_PRUNE_R 8
+#define NL_TILE 1024      // candidates staged in LDS per tile (fp64: 34 KB per block)
+#define NL_MAXROWS 96     // (2Ry+1)(2Rz+1) rows of cells a block can describe (R <= 4)
+#define NL_TILED_GRID 2048
 template <class T> struct NlSys {
   T cell[9];
   T inv[9];
@@ -34,10 +37,11 @@ template <class T> struct NlSys {
   int nrange[3];  // image range of the naive method (neighbor_utils.py:150-211)
   int cell_off;
   int ncells;
+  int tiled;      // dense cells (k >= 2) with a small row table: eligible for the block-per-cell LDS-tiled query
   int prune;      // orthorhombic cell with R <= NL_PRUNE_R: dxlim[|dz|][|dy|] = largest |dx| worth visiting (-1: skip the row)
   signed char dxlim[NL_PRUNE_R + 1][NL_PRUNE_R + 1];
 };
-struct NlGlobal { int total_cells; int any_wrap; int pad0; int pad1; };
+struct NlGlobal { int total_cells; int any_wrap; int use_tiled; int pad1; };
 
 struct NlLayout {
   size_t sys, glob, natoms, keys_in, keys_out, vals_in, vals_out, wrap, swrap, spos, cell_start, cub, total;
@@ -134,6 +138,7 @@ __global__ void nl_setup_kernel(const T* __restrict__ cell, const uint8_t* __res
     }
     S.ncells = (int)tot;
     S.cell_off = 0;
+    S.tiled = (k >= 2 && (2 * S.R[1] + 1) * (2 * S.R[2] + 1) <= NL_MAXROWS && (!S.pbc[0] || S.R[0] <= S.cpd[0])) ? 1 : 0;
     // Orthorhombic cells: atoms in cells offset by d cells along a periodic axis are at least (|d|-1) cell edges apart along it,
     // so cells/rows provably beyond the cutoff are never visited.  Non-periodic axes contribute 0 (clamped atoms may sit
     // outside their cell).  Evaluated once here; the query kernel only does integer look-ups.
@@ -161,6 +166,9 @@ __global__ void nl_setup_kernel(const T* __restrict__ cell, const uint8_t* __res
     for (int s = 0; s < B; ++s) { sys[s].cell_off = off; off += sys[s].ncells; }
     glob->total_cells = off;
     glob->any_wrap = 0;
+    int all_tiled = 1;
+    for (int s = 0; s < B; ++s) all_tiled &= sys[s].tiled;
+    glob->use_tiled = all_tiled;
   }
 }
 
@@ -208,6 +216,8 @@ __global__ void nl_gather_kernel(const T* __restrict__ pos, const int* __restric
   swrap[p] = wrap[i];
 }
 
+struct NlInt3 { int a, b, c; };  // one 12-byte store per hit for the unit shift
+
 // coalesced wave-wide fill of dst[begin,end) with `value`; 16-byte stores in the aligned body
 __device__ __forceinline__ void wave_fill(int* __restrict__ dst, long long begin, long long end, int value, int lane) {
   long long n = end - begin;
@@ -224,12 +234,239 @@ __device__ __forceinline__ void wave_fill(int* __restrict__ dst, long long begin
   if (done + lane < n) p[done + lane] = value;
 }
 
+// The pair test shared by both query kernels: reference expression order (cell_list.py:531-544), or the naive method's
+// orientation / image range (naive.py:163-172), self-pair exclusion, canonical half-fill rule.
+template <class T>
+__device__ __forceinline__ bool nl_pair_hit(T pix, T piy, T piz, int i, T cjx, T cjy, T cjz, int j, int Sx, int Sy, int Sz, const T* cart,
+                                            T rc2, bool naive, bool half, int nr0, int nr1, int nr2) {
+  T dr0, dr1, dr2;
+  bool ok = true;
+  if (!naive) {
+    dr0 = (cjx - pix) + cart[0];
+    dr1 = (cjy - piy) + cart[1];
+    dr2 = (cjz - piz) + cart[2];
+  } else {
+    const bool upper = Sx > 0 || (Sx == 0 && Sy > 0) || (Sx == 0 && Sy == 0 && Sz >= 0);
+    if (upper) { dr0 = (cart[0] + cjx) - pix; dr1 = (cart[1] + cjy) - piy; dr2 = (cart[2] + cjz) - piz; }
+    else { dr0 = ((-cart[0]) + pix) - cjx; dr1 = ((-cart[1]) + piy) - cjy; dr2 = ((-cart[2]) + piz) - cjz; }
+    ok = (Sx <= nr0 && -Sx <= nr0) && (Sy <= nr1 && -Sy <= nr1) && (Sz <= nr2 && -Sz <= nr2);
+  }
+  const T d2 = dr0 * dr0 + dr1 * dr1 + dr2 * dr2;
+  const bool zeroS = (Sx | Sy | Sz) == 0;
+  bool hit = ok && (d2 < rc2) && !(j == i && zeroS);
+  if (half && hit) {
+    const bool pos_shift = Sx > 0 || (Sx == 0 && Sy > 0) || (Sx == 0 && Sy == 0 && Sz > 0);
+    hit = pos_shift || (zeroS && j > i);
+  }
+  return hit;
+}
+
+// ---- block-per-cell, LDS-tiled query for dense cells (large cutoffs) -----------------------------------------------------
+// All atoms of a cell share one candidate set.  A block describes the rows of neighbouring cells once, flattens them into
+// one candidate stream, stages it tile by tile in LDS with coalesced loads (positions, neighbour index, image shift), and
+// its four waves then test their centre atoms against the tile from LDS: no per-run bookkeeping and no global-memory
+// latency inside the 64-candidates-per-step loop, and every candidate record is fetched from L2 once per cell, not once
+// per atom.  Output path (ballot/popcount compaction, owner-written padding) is the same as the wave-per-atom kernel's.
+// FAST = neither naive-expression nor half-fill requested: the per-candidate test is straight-line code.
+template <class T, int MODE, bool FAST>
+__global__ __launch_bounds__(256) void nl_query_tiled_kernel(
+    const typename Vec4<T>::type* __restrict__ spos, const short4* __restrict__ swrap, const int* __restrict__ cell_start,
+    const NlSys<T>* __restrict__ sys, const NlGlobal* __restrict__ glob, int B, T rc2, int flags, int* __restrict__ nm,
+    int* __restrict__ nsh, int* __restrict__ num, int M, int fill_value, const int* __restrict__ ptr, int* __restrict__ list_ij,
+    int* __restrict__ list_sh, long long P) {
+  if (!glob->use_tiled) return;
+  if (FAST != ((flags & (MI_NL_HALF_FILL | MI_NL_NAIVE_EXPR)) == 0)) return;  // the other instantiation handles this call
+  __shared__ T tx[NL_TILE], ty[NL_TILE], tz[NL_TILE];
+  __shared__ int tj[NL_TILE];
+  __shared__ short tsx[NL_TILE], tsy[NL_TILE], tsz[NL_TILE];
+  __shared__ int run_beg[3 * NL_MAXROWS], run_pre[3 * NL_MAXROWS + 1], run_cs[3 * NL_MAXROWS];
+  __shared__ int ccnt[256];
+  __shared__ int grp_run[NL_TILE / MI_WAVE];  // run containing the first candidate of each 64-candidate group of the current tile
+  const int tid = threadIdx.x, lane = tid & (MI_WAVE - 1), wave = tid / MI_WAVE;
+  const int total_cells = glob->total_cells;
+  const bool anyw = glob->any_wrap != 0;
+  const bool half = (flags & MI_NL_HALF_FILL) != 0, naive = (flags & MI_NL_NAIVE_EXPR) != 0;
+  const unsigned long long lt = (1ull << lane) - 1ull;
+  for (int c = blockIdx.x; c < total_cells; c += gridDim.x) {
+    const int c_beg = cell_start[c], n_c = cell_start[c + 1] - c_beg;
+    if (n_c == 0) continue;  // block-uniform
+    int s = 0;
+    {  // system owning this cell (cell_off is increasing)
+      int lo = 0, hi = B - 1;
+      while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (sys[mid].cell_off <= c) lo = mid; else hi = mid - 1; }
+      s = lo;
+    }
+    const NlSys<T>* S = sys + s;
+    const int nx = S->cpd[0], ny = S->cpd[1], nz = S->cpd[2];
+    const int Rx = S->R[0], Ry = S->R[1], Rz = S->R[2];
+    const bool pbx = S->pbc[0] != 0, pby = S->pbc[1] != 0, pbz = S->pbc[2] != 0;
+    const int coff = S->cell_off;
+    const int nr0 = S->nrange[0], nr1 = S->nrange[1], nr2 = S->nrange[2];
+    T cm[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) cm[k] = S->cell[k];
+    const int local = c - coff;
+    const int cx = local % nx, cyz = local / nx, cy = cyz % ny, cz = cyz / ny;
+    const int nyr = 2 * Ry + 1, nrows = (2 * Rz + 1) * nyr;
+    __syncthreads();  // previous cell fully consumed before the run table is overwritten
+    // ---- run table: one thread per (dy,dz) row, up to three x-images each
+    if (tid < nrows) {
+      const int dzr = tid / nyr, dz = dzr - Rz, dy = tid - dzr * nyr - Ry;
+      const int tzc = cz + dz, tyc = cy + dy;
+      bool ok = (pbz || (tzc >= 0 && tzc < nz)) && (pby || (tyc >= 0 && tyc < ny));
+      int csz = 0, wz = tzc, csy = 0, wy = tyc;
+      if (ok) {
+        while (wz < 0) { wz += nz; --csz; }
+        while (wz >= nz) { wz -= nz; ++csz; }
+        while (wy < 0) { wy += ny; --csy; }
+        while (wy >= ny) { wy -= ny; ++csy; }
+      }
+      int dxm = Rx;
+      if (S->prune) { dxm = S->dxlim[dz < 0 ? -dz : dz][dy < 0 ? -dy : dy]; ok = ok && dxm >= 0; }
+      int xlo = cx - dxm, xhi = cx + dxm;
+      if (!pbx) { xlo = xlo < 0 ? 0 : xlo; xhi = xhi > nx - 1 ? nx - 1 : xhi; }
+      const int rowbase = coff + nx * (wy + ny * wz);
+      for (int g = 0; g < 3; ++g) {
+        const int img0 = (g - 1) * nx;
+        const int xa = (xlo > img0 ? xlo : img0), xb = (xhi < img0 + nx - 1 ? xhi : img0 + nx - 1);
+        int b = 0, len = 0;
+        if (ok && xa <= xb && (pbx || g == 1)) { b = cell_start[rowbase + xa - img0]; len = cell_start[rowbase + xb - img0 + 1] - b; }
+        run_beg[3 * tid + g] = b;
+        run_pre[3 * tid + g + 1] = len;  // lengths first, turned into an inclusive prefix below
+        run_cs[3 * tid + g] = ((g - 1) & 0x3ff) | ((csy & 0x3ff) << 10) | ((csz & 0x3ff) << 20);
+      }
+    }
+    __syncthreads();
+    if (tid == 0) {
+      int acc = 0;
+      run_pre[0] = 0;
+      for (int r = 0; r < 3 * nrows; ++r) { acc += run_pre[r + 1]; run_pre[r + 1] = acc; }
+    }
+    __syncthreads();
+    const int nruns = 3 * nrows, total = run_pre[nruns];
+    for (int cbase = 0; cbase < n_c; cbase += 256) {
+      const int cend = (cbase + 256 < n_c) ? cbase + 256 : n_c;
+      ccnt[tid] = 0;
+      for (int tile0 = 0; tile0 < total; tile0 += NL_TILE) {
+        const int tile_n = (total - tile0 < NL_TILE) ? total - tile0 : NL_TILE;
+        __syncthreads();  // the previous tile has been consumed (and ccnt initialised)
+        if (tid < NL_TILE / MI_WAVE && tile0 + tid * MI_WAVE < total) {
+          const int v = tile0 + tid * MI_WAVE;
+          int lo = 0, hi = nruns - 1;  // last run with run_pre[run] <= v (zero-length runs share a prefix value: take the last)
+          while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (run_pre[mid] <= v) lo = mid; else hi = mid - 1; }
+          grp_run[tid] = lo;
+        }
+        __syncthreads();
+        for (int t = tid; t < tile_n; t += 256) {
+          const int v = tile0 + t;
+          int lo = grp_run[t / MI_WAVE];  // 64 consecutive candidates span a few runs at most: short linear advance
+          while (lo + 1 < nruns && run_pre[lo + 1] <= v) ++lo;
+          const int q = run_beg[lo] + (v - run_pre[lo]);
+          const auto rec = spos[q];
+          tx[t] = rec.x; ty[t] = rec.y; tz[t] = rec.z;
+          tj[t] = idx_of(rec);
+          const int cs = run_cs[lo];
+          int sx = (cs << 22) >> 22, sy = (cs << 12) >> 22, sz = (cs << 2) >> 22;  // sign-extend the 10-bit fields
+          if (anyw) {
+            const short4 wj = swrap[q];
+            if (pbx) sx -= wj.x;
+            if (pby) sy -= wj.y;
+            if (pbz) sz -= wj.z;
+          }
+          tsx[t] = (short)sx; tsy[t] = (short)sy; tsz[t] = (short)sz;
+        }
+        __syncthreads();
+        for (int ci = cbase + wave; ci < cend; ci += 4) {
+          const auto cr = spos[c_beg + ci];
+          const int i = __builtin_amdgcn_readfirstlane(idx_of(cr));
+          short4 wi = make_short4(0, 0, 0, 0);
+          if (anyw) wi = swrap[c_beg + ci];
+          long long out_base;
+          int cap_row;
+          if (MODE == MI_NL_MODE_CSR) { out_base = ptr[i]; cap_row = ptr[i + 1] - ptr[i]; }
+          else { out_base = (long long)i * M; cap_row = M; }
+          int cnt = ccnt[ci - cbase];
+          const bool ortho = S->prune != 0;  // orthorhombic: S.cell has one non-zero term per component (adding exact zeros changes nothing)
+          // two groups of 64 candidates per iteration: independent dependency chains, hits of the first group are
+          // emitted before those of the second, so the slot order is the candidate order
+          for (int t0 = 0; t0 < tile_n; t0 += 2 * MI_WAVE) {
+            bool hit[2];
+            int jj[2], SX[2], SY[2], SZ[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+              const int t = t0 + u * MI_WAVE + lane;
+              const bool in = t < tile_n;
+              const int tt = in ? t : 0;
+              int j = tj[tt], Sx = tsx[tt], Sy = tsy[tt], Sz = tsz[tt];
+              const T cjx = tx[tt], cjy = ty[tt], cjz = tz[tt];
+              if (anyw) { if (pbx) Sx += wi.x; if (pby) Sy += wi.y; if (pbz) Sz += wi.z; }
+              T cart[3];
+              if (ortho) { cart[0] = cm[0] * (T)Sx; cart[1] = cm[4] * (T)Sy; cart[2] = cm[8] * (T)Sz; }
+              else { const T fs[3] = {(T)Sx, (T)Sy, (T)Sz}; rowvec_mat3(fs, cm, cart); }
+              bool h;
+              if (FAST) {
+                const T dr0 = (cjx - cr.x) + cart[0], dr1 = (cjy - cr.y) + cart[1], dr2 = (cjz - cr.z) + cart[2];
+                const T d2 = dr0 * dr0 + dr1 * dr1 + dr2 * dr2;
+                h = (d2 < rc2) && !(j == i && (Sx | Sy | Sz) == 0);
+              } else {
+                h = nl_pair_hit<T>(cr.x, cr.y, cr.z, i, cjx, cjy, cjz, j, Sx, Sy, Sz, cart, rc2, naive, half, nr0, nr1, nr2);
+              }
+              hit[u] = in && h;
+              jj[u] = j; SX[u] = Sx; SY[u] = Sy; SZ[u] = Sz;
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+              const unsigned long long mask = __ballot(hit[u]);
+              if (mask) {
+                const int slot = cnt + __popcll(mask & lt);
+                if (MODE == MI_NL_MODE_MATRIX) {
+                  if (hit[u] && slot < cap_row) {
+                    nm[out_base + slot] = jj[u];
+                    if (nsh) reinterpret_cast<NlInt3*>(nsh)[out_base + slot] = NlInt3{SX[u], SY[u], SZ[u]};
+                  }
+                } else if (MODE == MI_NL_MODE_CSR) {
+                  if (hit[u] && slot < cap_row) {  // the source row (constant i) is written in bulk when the centre is finished
+                    list_ij[P + out_base + slot] = jj[u];
+                    if (list_sh) reinterpret_cast<NlInt3*>(list_sh)[out_base + slot] = NlInt3{SX[u], SY[u], SZ[u]};
+                  }
+                }
+                cnt += __popcll(mask);
+              }
+            }
+          }
+          if (lane == 0) ccnt[ci - cbase] = cnt;
+        }
+      }
+      __syncthreads();
+      // counts and (matrix mode) padding of this chunk of centres
+      for (int ci = cbase + wave; ci < cend; ci += 4) {
+        const int i = __builtin_amdgcn_readfirstlane(idx_of(spos[c_beg + ci]));
+        const int cnt = ccnt[ci - cbase];
+        if (MODE != MI_NL_MODE_CSR) { if (lane == 0) num[i] = cnt; }
+        if (MODE == MI_NL_MODE_CSR) {
+          const long long rb = ptr[i];
+          const int room = ptr[i + 1] - ptr[i];
+          wave_fill(list_ij, rb, rb + (cnt < room ? cnt : room), i, lane);
+        }
+        if (MODE == MI_NL_MODE_MATRIX && !(flags & MI_NL_NO_PAD)) {
+          const long long out_base = (long long)i * M;
+          const int used = cnt < M ? cnt : M;
+          wave_fill(nm, out_base + used, out_base + M, fill_value, lane);
+          if (nsh) wave_fill(nsh, (out_base + used) * 3, (out_base + M) * 3, 0, lane);
+        }
+      }
+      __syncthreads();
+    }
+  }
+}
+
 template <class T, int MODE>
 __global__ __launch_bounds__(256) void nl_query_kernel(
     const typename Vec4<T>::type* __restrict__ spos, const short4* __restrict__ swrap, const int* __restrict__ keys_sorted,
     const int* __restrict__ cell_start, const int* __restrict__ batch_idx, const NlSys<T>* __restrict__ sys,
     const NlGlobal* __restrict__ glob, int N, T rc2, int flags, int* __restrict__ nm, int* __restrict__ nsh, int* __restrict__ num,
     int M, int fill_value, const int* __restrict__ ptr, int* __restrict__ list_ij, int* __restrict__ list_sh, long long P) {
+  if (glob->use_tiled) return;  // dense cells: the block-per-cell LDS-tiled kernel (launched next to this one) does the work
   const int lane = threadIdx.x & (MI_WAVE - 1);
   const int p = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x / MI_WAVE) + (threadIdx.x / MI_WAVE));
   if (p >= N) return;
@@ -283,31 +520,12 @@ __global__ __launch_bounds__(256) void nl_query_kernel(
           if (pby) Sy += (int)wi.y - (int)wj.y;
           if (pbz) Sz += (int)wi.z - (int)wj.z;
         }
-        T cart[3] = {cart_u[0], cart_u[1], cart_u[2]}, dr0, dr1, dr2;
+        T cart[3] = {cart_u[0], cart_u[1], cart_u[2]};
         if (anyw) {
           const T fs[3] = {(T)Sx, (T)Sy, (T)Sz};
           rowvec_mat3(fs, cm, cart);
         }
-        bool ok = true;
-        if (!naive) {
-          // cell_list.py:531-544:  dr = pos_j - pos_i + S.cell ; d2 = dot(dr,dr) ; d2 < rc*rc
-          dr0 = (cj.x - pix) + cart[0];
-          dr1 = (cj.y - piy) + cart[1];
-          dr2 = (cj.z - piz) + cart[2];
-        } else {
-          // naive.py:163-172: diff = (S.cell + r_shifted_atom) - r_other, evaluated for the upper-half shift
-          const bool upper = Sx > 0 || (Sx == 0 && Sy > 0) || (Sx == 0 && Sy == 0 && Sz >= 0);
-          if (upper) { dr0 = (cart[0] + cj.x) - pix; dr1 = (cart[1] + cj.y) - piy; dr2 = (cart[2] + cj.z) - piz; }
-          else { dr0 = ((-cart[0]) + pix) - cj.x; dr1 = ((-cart[1]) + piy) - cj.y; dr2 = ((-cart[2]) + piz) - cj.z; }
-          ok = (Sx <= nr0 && -Sx <= nr0) && (Sy <= nr1 && -Sy <= nr1) && (Sz <= nr2 && -Sz <= nr2);
-        }
-        const T d2 = dr0 * dr0 + dr1 * dr1 + dr2 * dr2;
-        const bool zeroS = (Sx | Sy | Sz) == 0;
-        hit = ok && (d2 < rc2) && !(j == i && zeroS);
-        if (half && hit) {
-          const bool pos_shift = Sx > 0 || (Sx == 0 && Sy > 0) || (Sx == 0 && Sy == 0 && Sz > 0);
-          hit = pos_shift || (zeroS && j > i);
-        }
+        hit = nl_pair_hit<T>(pix, piy, piz, i, cj.x, cj.y, cj.z, j, Sx, Sy, Sz, cart, rc2, naive, half, nr0, nr1, nr2);
       }
       const unsigned long long mask = __ballot(hit);
       if (mask) {
@@ -315,13 +533,12 @@ __global__ __launch_bounds__(256) void nl_query_kernel(
         if (MODE == MI_NL_MODE_MATRIX) {
           if (hit && slot < cap_row) {
             nm[out_base + slot] = j;
-            if (nsh) { int* sp = nsh + (out_base + slot) * 3; sp[0] = Sx; sp[1] = Sy; sp[2] = Sz; }
+            if (nsh) reinterpret_cast<NlInt3*>(nsh)[out_base + slot] = NlInt3{Sx, Sy, Sz};
           }
         } else if (MODE == MI_NL_MODE_CSR) {
-          if (hit && slot < cap_row) {
-            list_ij[out_base + slot] = i;
+          if (hit && slot < cap_row) {  // the source row (constant i) is written in bulk at the end
             list_ij[P + out_base + slot] = j;
-            if (list_sh) { int* sp = list_sh + (out_base + slot) * 3; sp[0] = Sx; sp[1] = Sy; sp[2] = Sz; }
+            if (list_sh) reinterpret_cast<NlInt3*>(list_sh)[out_base + slot] = NlInt3{Sx, Sy, Sz};
           }
         }
         cnt += __popcll(mask);
@@ -408,6 +625,8 @@ __global__ __launch_bounds__(256) void nl_query_kernel(
   }
   if (MODE != MI_NL_MODE_CSR) {
     if (lane == 0) num[i] = cnt;
+  } else {
+    wave_fill(list_ij, out_base, out_base + (cnt < cap_row ? cnt : cap_row), i, lane);
   }
   if (MODE == MI_NL_MODE_MATRIX && !(flags & MI_NL_NO_PAD)) {
     // the row owner also writes the padding (replaces torch.full + zeros of cell_list.py:1358-1373)
@@ -582,9 +801,21 @@ int nl_neighbors_impl(const T* pos, int N, const T* cell, const uint8_t* pbc, co
 #define MI_NLQ(MODE_)                                                                                                              \
   nl_query_kernel<T, MODE_><<<blocks, 256, 0, st>>>(spos, swrap, keys_out, cell_start, batch_idx, sys, glob, N, rc2, flags, nm, nsh, num, M, \
                                                     fill_value, ptr, list_ij, list_sh, P)
-  if (mode == MI_NL_MODE_MATRIX) MI_TIMED("nl_query_matrix", st, MI_NLQ(MI_NL_MODE_MATRIX));
-  else if (mode == MI_NL_MODE_COUNT) MI_TIMED("nl_query_count", st, MI_NLQ(MI_NL_MODE_COUNT));
-  else MI_TIMED("nl_query_csr", st, MI_NLQ(MI_NL_MODE_CSR));
+  // both query kernels are launched; the device-side grid description (glob->use_tiled) decides which one does the work
+  // and the other returns at once -- no host synchronisation to pick a variant
+#define MI_NLT(MODE_)                                                                                                                    \
+  do {                                                                                                                                   \
+    if ((flags & (MI_NL_HALF_FILL | MI_NL_NAIVE_EXPR)) == 0)                                                                             \
+      nl_query_tiled_kernel<T, MODE_, true><<<NL_TILED_GRID, 256, 0, st>>>(spos, swrap, cell_start, sys, glob, B, rc2, flags, nm, nsh, num, \
+                                                                          M, fill_value, ptr, list_ij, list_sh, P);                      \
+    else                                                                                                                                 \
+      nl_query_tiled_kernel<T, MODE_, false><<<NL_TILED_GRID, 256, 0, st>>>(spos, swrap, cell_start, sys, glob, B, rc2, flags, nm, nsh, num, \
+                                                                           M, fill_value, ptr, list_ij, list_sh, P);                     \
+  } while (0)
+  if (mode == MI_NL_MODE_MATRIX) MI_TIMED("nl_query_matrix", st, MI_NLQ(MI_NL_MODE_MATRIX); MI_NLT(MI_NL_MODE_MATRIX));
+  else if (mode == MI_NL_MODE_COUNT) MI_TIMED("nl_query_count", st, MI_NLQ(MI_NL_MODE_COUNT); MI_NLT(MI_NL_MODE_COUNT));
+  else MI_TIMED("nl_query_csr", st, MI_NLQ(MI_NL_MODE_CSR); MI_NLT(MI_NL_MODE_CSR));
+#undef MI_NLT
 #undef MI_NLQ
   MI_LAUNCH_CHECK();
   return MI_OK;
