@@ -10,6 +10,8 @@ One "step" (BASELINE.json metric; BASELINE.md headline row) on syn
   2. particle_mesh_ewald  alpha = 0.35 /A, mesh 128^3, B-spline order 5, E + F, fp64   (real + reciprocal)
   3. neighbor_list  rc = 40 Bohr (21.2 A), direct CSR/COO output, fp32 positions        -> D3 list (~2.4k pairs/atom)
   4. dftd3(BJ)  a1=0.4289 a2=4.4407 s8=0.7875, E + F + virial, fp32
+Steps 1-2 and 3-4 are independent and are enqueued on two HIP streams (--overlap 1, default); --overlap 0 serialises them and
+reports per-stage times.
 System: jittered FCC box (a = 4 A, sigma = 0.05 A, seed 1234 + rank), first N sites, +-1 charges, Z in {6, 8}; D3 tables
 are the reference test-suite's analytic tables extended to Z <= 94 (real Grimme tables are not in the reference repo).
 A single box does not shard: for --gpus N > 1 every rank runs its own replica box (weak scaling) and the
@@ -124,6 +126,10 @@ def make_batch_step(sysd, tables, device, world, sizes):
     return step, {}
 
 
+VIRIAL = True
+OVERLAP = False
+
+
 def make_step(sysd, tables, device, world):
     from nvalchemiops.interactions.dispersion import D3Parameters, dftd3
     from nvalchemiops.interactions.electrostatics import particle_mesh_ewald
@@ -138,6 +144,7 @@ def make_step(sysd, tables, device, world):
     num = torch.empty(n, dtype=torch.int32, device=device)
     gathered = [torch.zeros(2, dtype=torch.float64, device=device) for _ in range(world)] if world > 1 else None
     stage_ms = {}
+    side = torch.cuda.Stream(device=device)
 
     def step(record=None):
         ev = []
@@ -149,18 +156,38 @@ def make_step(sysd, tables, device, world):
                 ev.append((name, e))
 
         mark("start")
-        cell_list(sysd["pos64"], PME["cutoff"], sysd["cell64"], sysd["pbc"], neighbor_matrix=nm, neighbor_matrix_shifts=nsh,
-                  num_neighbors=num)
-        mark("nlist_pme")
-        e_pme, f_pme = particle_mesh_ewald(sysd["pos64"], sysd["q64"], sysd["cell64"], alpha=PME["alpha"], mesh_dimensions=PME["mesh"],
-                                           spline_order=PME["order"], neighbor_matrix=nm, neighbor_matrix_shifts=nsh, compute_forces=True)
-        mark("pme")
-        lst, nptr, lsh = cell_list(sysd["pos32b"], D3["cutoff"], sysd["cell32b"], sysd["pbc"], return_neighbor_list=True)
-        mark("nlist_d3")
-        e_d3, f_d3, cn, vir = dftd3(sysd["pos32b"], sysd["numbers"], a1=D3["a1"], a2=D3["a2"], s8=D3["s8"], d3_params=params,
-                                    neighbor_list=lst, neighbor_ptr=nptr, unit_shifts=lsh, cell=sysd["cell32b"].unsqueeze(0),
-                                    compute_virial=True, num_systems=1)
-        mark("d3")
+        if OVERLAP:
+            # The electrostatics branch (9 A list + PME) and the dispersion branch (40 Bohr list + D3) are independent: they are
+            # enqueued on two HIP streams so the latency-bound kernels of one fill the gaps of the other; joined before the gather.
+            main = torch.cuda.current_stream()
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                cell_list(sysd["pos64"], PME["cutoff"], sysd["cell64"], sysd["pbc"], neighbor_matrix=nm, neighbor_matrix_shifts=nsh,
+                          num_neighbors=num)
+                e_pme, f_pme = particle_mesh_ewald(sysd["pos64"], sysd["q64"], sysd["cell64"], alpha=PME["alpha"],
+                                                   mesh_dimensions=PME["mesh"], spline_order=PME["order"], neighbor_matrix=nm,
+                                                   neighbor_matrix_shifts=nsh, compute_forces=True)
+            lst, nptr, lsh = cell_list(sysd["pos32b"], D3["cutoff"], sysd["cell32b"], sysd["pbc"], return_neighbor_list=True)
+            e_d3, f_d3, cn, vir = dftd3(sysd["pos32b"], sysd["numbers"], a1=D3["a1"], a2=D3["a2"], s8=D3["s8"], d3_params=params,
+                                        neighbor_list=lst, neighbor_ptr=nptr, unit_shifts=lsh, cell=sysd["cell32b"].unsqueeze(0),
+                                        compute_virial=VIRIAL, num_systems=1)[:4] + ((None,) if not VIRIAL else ())
+            main.wait_stream(side)
+            for t in (e_pme, f_pme):
+                t.record_stream(main)
+            mark("pme||d3")
+        else:
+            cell_list(sysd["pos64"], PME["cutoff"], sysd["cell64"], sysd["pbc"], neighbor_matrix=nm, neighbor_matrix_shifts=nsh,
+                      num_neighbors=num)
+            mark("nlist_pme")
+            e_pme, f_pme = particle_mesh_ewald(sysd["pos64"], sysd["q64"], sysd["cell64"], alpha=PME["alpha"], mesh_dimensions=PME["mesh"],
+                                               spline_order=PME["order"], neighbor_matrix=nm, neighbor_matrix_shifts=nsh, compute_forces=True)
+            mark("pme")
+            lst, nptr, lsh = cell_list(sysd["pos32b"], D3["cutoff"], sysd["cell32b"], sysd["pbc"], return_neighbor_list=True)
+            mark("nlist_d3")
+            e_d3, f_d3, cn, vir = dftd3(sysd["pos32b"], sysd["numbers"], a1=D3["a1"], a2=D3["a2"], s8=D3["s8"], d3_params=params,
+                                        neighbor_list=lst, neighbor_ptr=nptr, unit_shifts=lsh, cell=sysd["cell32b"].unsqueeze(0),
+                                        compute_virial=VIRIAL, num_systems=1)[:4] + ((None,) if not VIRIAL else ())
+            mark("d3")
         if gathered is not None:
             mine = torch.stack([e_d3[0].double(), e_pme.sum()])
             torch.distributed.all_gather(gathered, mine)
@@ -257,7 +284,12 @@ def main():
                     help="headline: one 100k-atom box per GPU (default, the BASELINE metric); c5: BASELINE config 5, a batch of "
                          "--systems x 2000-atom boxes per GPU sharded at system granularity")
     ap.add_argument("--systems", type=int, default=128, help="systems per GPU for --workload c5")
+    ap.add_argument("--no-virial", action="store_true", help="experiment switch: D3 without the virial (the headline includes it)")
+    ap.add_argument("--overlap", type=int, default=1, help="1 (default): PME and D3 branches on two HIP streams; 0: one stream, per-stage times")
     args = ap.parse_args()
+    global VIRIAL, OVERLAP
+    VIRIAL = not args.no_virial
+    OVERLAP = bool(args.overlap)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
