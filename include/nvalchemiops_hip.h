@@ -100,6 +100,15 @@ int mi_nl_estimate_sizes(const void* cell, const uint8_t* pbc, int n_systems, do
                          int dtype, int32_t* number_of_cells /*[n_systems]*/,
                          int32_t* neighbor_search_radius /*[n_systems,3]*/, void* stream);
 
+/* Rebuild detection for MD loops (neighborlist/rebuild_detection.py:37-170): `flag` (one byte, zeroed by the caller)
+ * is set when any atom's cell (reference binning of mi_nl_build_cell_cache) differs from atom_to_cell_mapping, resp. when any atom
+ * moved farther than `threshold` from its reference position.                                                                    */
+int mi_nl_cells_changed(const void* positions, const void* cell /*[3,3]*/, const int32_t* atom_to_cell_mapping,
+                        const int32_t* cells_per_dimension /*[3]*/, const uint8_t* pbc /*[3]*/, int n_atoms, int dtype,
+                        uint8_t* flag, void* stream);
+int mi_nl_moved_beyond_skin(const void* reference_positions, const void* current_positions, double threshold, int n_atoms, int dtype,
+                            uint8_t* flag, void* stream);
+
 /* ---- DFT-D3(BJ) -----------------------------------------------------------------------------
  * Replaces nvalchemiops::dftd3_nm (dftd3.py:1792-2122) and ::dftd3_nl (:2125-2465): CN pass, fused
  * C6-interpolation + BJ damping + energy + direct force + dE/dCN pass, chain-rule force pass.  The
@@ -142,6 +151,23 @@ int mi_ewald_real(const void* positions, const void* charges, const void* cell, 
                   const int32_t* unit_shifts, const int32_t* neighbor_ptr, int max_neighbors, int mask_value,
                   int flags, double* energies /*[n_atoms]*/, void* forces /*[n_atoms,3] dtype*/,
                   double* charge_grads /*[n_atoms]*/, void* stream);
+
+/* Explicit-k reciprocal-space Ewald.  Replaces `alchemiops::_[batch_]ewald_reciprocal_space_energy[_forces
+ * [_charge_grad]]` (ewald.py:1365-2318; kernels ewald_kernels.py:1496-2480).  Two passes, no [K,N] phase tables:
+ *   mi_ewald_structure_factors : S[b][k] = 8pi/V exp(-k^2/4a^2)/k^2 * sum_j w_j exp(i k.r_j) (interleaved re,im; k^2<1e-10 -> 0)
+ *                                total_charge[b] = sum_j w_j / V (0 when n_k < 2, as the reference's k_idx==1 accumulation)
+ *   mi_ewald_recip_gather      : phi_i = sum_k Re(S_k exp(-i k.r_i)), kforce_i = sum_k (S_re sin - S_im cos) k, and from them
+ *                                E_i = q phi/2 - a q^2/sqrt(pi) - pi q Q/(2a^2), F_i = q kforce_i, dE/dq_i = phi - 2a q/sqrt(pi) - pi Q/a^2
+ * k_vectors [n_systems,n_k,3] in `dtype` (half-space set); system_ptr [n_systems+1] atom ranges (NULL: one system);
+ * total_charge NULL in the gather = no self/background corrections (used by the adjoint).  Any output pointer may be NULL.  */
+int mi_ewald_structure_factors(const void* positions, const void* weights /*[n_atoms] dtype*/, const void* k_vectors, const void* cell,
+                               const void* alpha, const int32_t* system_ptr, int n_atoms, int n_systems, int n_k,
+                               int max_atoms_per_system, int dtype, double* structure_factors /*[n_systems,n_k,2]*/,
+                               double* total_charge /*[n_systems]*/, void* stream);
+int mi_ewald_recip_gather(const void* positions, const void* charges, const void* k_vectors, const void* alpha, const int32_t* batch_idx,
+                          const double* structure_factors, const double* total_charge, int n_atoms, int n_k, int dtype,
+                          double* potential /*[n_atoms]*/, double* kforce /*[n_atoms,3]*/, double* energies /*[n_atoms]*/,
+                          void* forces /*[n_atoms,3] dtype*/, double* charge_grads /*[n_atoms]*/, void* stream);
 
 /* Adjoint of mi_ewald_real w.r.t. positions / charges / cell / alpha for L = sum_i g_i E_i (replaces the Warp-tape backward of
  * the real-space ops, autograd.py:525-665 + the generated adjoints of ewald_kernels.py:266-1495).  Owner-only like the forward:

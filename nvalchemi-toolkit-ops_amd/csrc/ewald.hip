@@ -138,6 +138,89 @@ __global__ __launch_bounds__(256) void ewald_real_bwd_kernel(const T* __restrict
   }
 }
 
+// ---- explicit-k reciprocal space (ewald_kernels.py:1496-2480) -----------------------------------------------
+// The reference stores cos/sin(k.r) for every (k, atom) in two float64 [K,N] tables between its two kernels; here both passes
+// recompute the phases (fp64 sincos from registers) so HBM sees only positions, k-vectors and the [B,K] structure factors.
+constexpr int EK_TILE = 16;       // 16 k-vectors (or atoms) x 16 lanes per 256-thread block
+constexpr int EK_ATOM_CHUNK = 4096;
+
+__device__ __forceinline__ double sum16(double v) {
+  v += __shfl_xor(v, 8, 16); v += __shfl_xor(v, 4, 16); v += __shfl_xor(v, 2, 16); v += __shfl_xor(v, 1, 16);
+  return v;
+}
+
+// S[b][k] = G_k * sum_j w_j exp(i k.r_j),  G_k = 8 pi / V * exp(-k^2 / 4 alpha^2) / k^2   (half-space k set, hence 8 pi)
+template <class T>
+__global__ __launch_bounds__(256) void ewald_sf_kernel(const T* __restrict__ pos, const T* __restrict__ w, const T* __restrict__ kvec,
+                                                       const T* __restrict__ cell, const T* __restrict__ alpha,
+                                                       const int* __restrict__ system_ptr, int n_atoms, int K,
+                                                       double* __restrict__ sf, double* __restrict__ total_charge) {
+  const int b = blockIdx.y, k = blockIdx.x * EK_TILE + (threadIdx.x >> 4), lane = threadIdx.x & 15;
+  const int a0 = system_ptr ? system_ptr[b] : 0, a1 = system_ptr ? system_ptr[b + 1] : n_atoms;
+  const int c0 = a0 + blockIdx.z * EK_ATOM_CHUNK, c1 = min(c0 + EK_ATOM_CHUNK, a1);
+  if (c0 >= a1) return;
+  const T* cm = cell + 9 * (size_t)b;
+  const double vol = fabs((double)(cm[0] * (cm[4] * cm[8] - cm[5] * cm[7]) - cm[1] * (cm[3] * cm[8] - cm[5] * cm[6]) +
+                                   cm[2] * (cm[3] * cm[7] - cm[4] * cm[6])));
+  const bool charge_owner = total_charge && blockIdx.x == 0 && (threadIdx.x >> 4) == 1 && K > 1;  // the reference's k_idx == 1 thread
+  const bool live = k < K;
+  double kx = 0, ky = 0, kz = 0;
+  if (live) { const T* kv = kvec + 3 * ((size_t)b * K + k); kx = kv[0]; ky = kv[1]; kz = kv[2]; }
+  const double k2 = kx * kx + ky * ky + kz * kz;
+  double re = 0, im = 0, qs = 0;
+  for (int a = c0 + lane; a < c1; a += 16) {
+    const double q = w[a];
+    const double ph = kx * (double)pos[3 * (size_t)a] + ky * (double)pos[3 * (size_t)a + 1] + kz * (double)pos[3 * (size_t)a + 2];
+    double sn, cs;
+    sincos(ph, &sn, &cs);
+    re += q * cs; im += q * sn; qs += q;
+  }
+  re = sum16(re); im = sum16(im); qs = sum16(qs);
+  if (lane != 0) return;
+  if (charge_owner) atomicAdd(total_charge + b, qs / vol);
+  if (!live || k2 < 1e-10) return;
+  const double al = alpha[b];
+  const double green = exp(-k2 * (0.25 / (al * al))) / k2 * (8.0 * M_PI) / vol;
+  atomicAdd(sf + 2 * ((size_t)b * K + k), re * green);
+  atomicAdd(sf + 2 * ((size_t)b * K + k) + 1, im * green);
+}
+
+// per atom: phi_i = sum_k (S_re cos + S_im sin)(k.r_i),  kf_i = sum_k (S_re sin - S_im cos) k ; then
+// E_i = q phi/2 - alpha q^2/sqrt(pi) - pi q Q / (2 alpha^2),  F_i = q kf_i,  dE/dq_i = phi - 2 alpha q/sqrt(pi) - pi Q/alpha^2
+template <class T>
+__global__ __launch_bounds__(256) void ewald_recip_gather_kernel(const T* __restrict__ pos, const T* __restrict__ q, const T* __restrict__ kvec,
+                                                                 const T* __restrict__ alpha, const int* __restrict__ batch_idx,
+                                                                 const double* __restrict__ sf, const double* __restrict__ total_charge,
+                                                                 int n_atoms, int K, double* __restrict__ potential,
+                                                                 double* __restrict__ kforce, double* __restrict__ energies,
+                                                                 T* __restrict__ forces, double* __restrict__ charge_grads) {
+  const int i = blockIdx.x * EK_TILE + (threadIdx.x >> 4), lane = threadIdx.x & 15;
+  const bool live = i < n_atoms;
+  const int ii = live ? i : n_atoms - 1;
+  const int b = batch_idx ? batch_idx[ii] : 0;
+  const double x = pos[3 * (size_t)ii], y = pos[3 * (size_t)ii + 1], z = pos[3 * (size_t)ii + 2];
+  const T* kv = kvec + 3 * (size_t)b * K;
+  const double* s = sf + 2 * (size_t)b * K;
+  double phi = 0, fx = 0, fy = 0, fz = 0;
+  for (int k = lane; k < K; k += 16) {
+    const double kx = kv[3 * k], ky = kv[3 * k + 1], kz = kv[3 * k + 2];
+    const double sre = s[2 * k], sim = s[2 * k + 1];
+    double sn, cs;
+    sincos(kx * x + ky * y + kz * z, &sn, &cs);
+    phi += sre * cs + sim * sn;
+    const double fs = sre * sn - sim * cs;
+    fx += fs * kx; fy += fs * ky; fz += fs * kz;
+  }
+  phi = sum16(phi); fx = sum16(fx); fy = sum16(fy); fz = sum16(fz);
+  if (lane != 0 || !live) return;
+  if (potential) potential[i] = phi;
+  if (kforce) { kforce[3 * (size_t)i] = fx; kforce[3 * (size_t)i + 1] = fy; kforce[3 * (size_t)i + 2] = fz; }
+  const double qi = q[i], al = alpha[b], Q = total_charge ? total_charge[b] : 0.0;
+  if (energies) energies[i] = 0.5 * qi * phi - al * qi * qi / sqrt(M_PI) - M_PI * qi * Q / (2.0 * al * al);
+  if (forces) { forces[3 * (size_t)i] = (T)(qi * fx); forces[3 * (size_t)i + 1] = (T)(qi * fy); forces[3 * (size_t)i + 2] = (T)(qi * fz); }
+  if (charge_grads) charge_grads[i] = phi - 2.0 * al / sqrt(M_PI) * qi - M_PI / (al * al) * Q;
+}
+
 }  // namespace
 
 extern "C" int mi_ewald_real_bwd(const void* positions, const void* charges, const void* cell, const void* alpha, const int32_t* batch_idx,
@@ -181,6 +264,52 @@ extern "C" int mi_ewald_real(const void* positions, const void* charges, const v
   else { if (csr) MI_EW(double, true); else MI_EW(double, false); }
   mi_timing_end(stream);
 #undef MI_EW
+  MI_LAUNCH_CHECK();
+  return MI_OK;
+}
+
+extern "C" int mi_ewald_structure_factors(const void* positions, const void* weights, const void* k_vectors, const void* cell, const void* alpha,
+                                          const int32_t* system_ptr, int n_atoms, int n_systems, int n_k, int max_atoms_per_system, int dtype,
+                                          double* structure_factors, double* total_charge, void* stream) {
+  MI_REQUIRE(dtype == MI_F32 || dtype == MI_F64, "dtype");
+  MI_REQUIRE(n_systems >= 1 && (n_systems == 1 || system_ptr), "system_ptr is required for batches");
+  hipStream_t st = (hipStream_t)stream;
+  if (structure_factors && n_k > 0) MI_HIP_CHECK(hipMemsetAsync(structure_factors, 0, sizeof(double) * 2 * (size_t)n_systems * n_k, st));
+  if (total_charge) MI_HIP_CHECK(hipMemsetAsync(total_charge, 0, sizeof(double) * n_systems, st));
+  if (n_atoms <= 0 || n_k <= 0) return MI_OK;
+  MI_REQUIRE(positions && weights && k_vectors && cell && alpha && structure_factors, "null pointer");
+  if (max_atoms_per_system <= 0) max_atoms_per_system = n_atoms;
+  dim3 grid(mi_blocks(n_k, EK_TILE), n_systems, mi_blocks(max_atoms_per_system, EK_ATOM_CHUNK));
+  mi_timing_begin("ewald_structure_factors", stream);
+  if (dtype == MI_F32)
+    ewald_sf_kernel<float><<<grid, 256, 0, st>>>((const float*)positions, (const float*)weights, (const float*)k_vectors, (const float*)cell,
+                                                 (const float*)alpha, system_ptr, n_atoms, n_k, structure_factors, total_charge);
+  else
+    ewald_sf_kernel<double><<<grid, 256, 0, st>>>((const double*)positions, (const double*)weights, (const double*)k_vectors, (const double*)cell,
+                                                  (const double*)alpha, system_ptr, n_atoms, n_k, structure_factors, total_charge);
+  mi_timing_end(stream);
+  MI_LAUNCH_CHECK();
+  return MI_OK;
+}
+
+extern "C" int mi_ewald_recip_gather(const void* positions, const void* charges, const void* k_vectors, const void* alpha, const int32_t* batch_idx,
+                                     const double* structure_factors, const double* total_charge, int n_atoms, int n_k, int dtype,
+                                     double* potential, double* kforce, double* energies, void* forces, double* charge_grads, void* stream) {
+  MI_REQUIRE(dtype == MI_F32 || dtype == MI_F64, "dtype");
+  if (n_atoms <= 0) return MI_OK;
+  MI_REQUIRE(positions && charges && alpha && (n_k == 0 || (k_vectors && structure_factors)), "null pointer");
+  hipStream_t st = (hipStream_t)stream;
+  const int blocks = mi_blocks(n_atoms, EK_TILE);
+  mi_timing_begin("ewald_recip_gather", stream);
+  if (dtype == MI_F32)
+    ewald_recip_gather_kernel<float><<<blocks, 256, 0, st>>>((const float*)positions, (const float*)charges, (const float*)k_vectors,
+                                                             (const float*)alpha, batch_idx, structure_factors, total_charge, n_atoms, n_k,
+                                                             potential, kforce, energies, (float*)forces, charge_grads);
+  else
+    ewald_recip_gather_kernel<double><<<blocks, 256, 0, st>>>((const double*)positions, (const double*)charges, (const double*)k_vectors,
+                                                              (const double*)alpha, batch_idx, structure_factors, total_charge, n_atoms, n_k,
+                                                              potential, kforce, energies, (double*)forces, charge_grads);
+  mi_timing_end(stream);
   MI_LAUNCH_CHECK();
   return MI_OK;
 }

@@ -755,6 +755,36 @@ __global__ void nl_cache_starts_kernel(const int* __restrict__ keys_sorted, int 
   counts[c] = b - a;
 }
 
+// ---- rebuild detection (neighborlist/rebuild_detection.py:37-170): one flag, set when any atom left its cell / moved past the skin
+template <class T>
+__global__ void nl_cells_changed_kernel(const T* __restrict__ pos, const T* __restrict__ cell, const int* __restrict__ atom_cell,
+                                        const int* __restrict__ cpd, const uint8_t* __restrict__ pbc, int N, uint8_t* __restrict__ flag) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  T inv[9];
+  inverse3(cell, inv);
+  const T p[3] = {pos[3 * (size_t)i], pos[3 * (size_t)i + 1], pos[3 * (size_t)i + 2]};
+  T frac[3];
+  rowvec_mat3(p, inv, frac);  // == transpose(inverse(cell)) * r, same summation order
+  bool changed = false;
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    const int n = cpd[d];
+    int c = (int)floor(frac[d] * (T)n);
+    if (pbc[d]) { c = c % n; if (c < 0) c += n; }
+    else c = c < 0 ? 0 : (c >= n ? n - 1 : c);
+    changed = changed || (c != atom_cell[3 * (size_t)i + d]);
+  }
+  if (changed) *flag = 1;
+}
+template <class T>
+__global__ void nl_moved_kernel(const T* __restrict__ ref, const T* __restrict__ cur, T threshold, int N, uint8_t* __restrict__ flag) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  const T dx = cur[3 * (size_t)i] - ref[3 * (size_t)i], dy = cur[3 * (size_t)i + 1] - ref[3 * (size_t)i + 1], dz = cur[3 * (size_t)i + 2] - ref[3 * (size_t)i + 2];
+  if (sqrt(dx * dx + dy * dy + dz * dz) > threshold) *flag = 1;
+}
+
 template <class T>
 int nl_neighbors_impl(const T* pos, int N, const T* cell, const uint8_t* pbc, const int* batch_idx, int B, double cutoff, int mode, int flags,
                       int* nm, int* nsh, int* num, int M, int fill_value, const int* ptr, int* list_ij, int* list_sh, long long P,
@@ -881,6 +911,38 @@ int mi_nl_matrix_to_coo(const int32_t* neighbor_matrix, const int32_t* neighbor_
   nl_matrix_to_coo_kernel<<<mi_blocks(n_atoms, 4), 256, 0, (hipStream_t)stream>>>(neighbor_matrix, neighbor_matrix_shifts, neighbor_ptr, n_atoms,
                                                                                   max_neighbors, fill_value, list_ij,
                                                                                   neighbor_matrix_shifts ? list_shifts : nullptr, n_pairs);
+  MI_LAUNCH_CHECK();
+  return MI_OK;
+}
+
+int mi_nl_cells_changed(const void* positions, const void* cell, const int32_t* atom_to_cell_mapping, const int32_t* cells_per_dimension,
+                        const uint8_t* pbc, int n_atoms, int dtype, uint8_t* flag, void* stream) {
+  MI_REQUIRE(dtype == MI_F32 || dtype == MI_F64, "dtype");
+  if (n_atoms <= 0) return MI_OK;
+  MI_REQUIRE(positions && cell && atom_to_cell_mapping && cells_per_dimension && pbc && flag, "null pointer");
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == MI_F32)
+    nl_cells_changed_kernel<float><<<mi_blocks(n_atoms, 256), 256, 0, st>>>((const float*)positions, (const float*)cell, atom_to_cell_mapping,
+                                                                           cells_per_dimension, pbc, n_atoms, flag);
+  else
+    nl_cells_changed_kernel<double><<<mi_blocks(n_atoms, 256), 256, 0, st>>>((const double*)positions, (const double*)cell, atom_to_cell_mapping,
+                                                                            cells_per_dimension, pbc, n_atoms, flag);
+  MI_LAUNCH_CHECK();
+  return MI_OK;
+}
+
+int mi_nl_moved_beyond_skin(const void* reference_positions, const void* current_positions, double threshold, int n_atoms, int dtype,
+                            uint8_t* flag, void* stream) {
+  MI_REQUIRE(dtype == MI_F32 || dtype == MI_F64, "dtype");
+  if (n_atoms <= 0) return MI_OK;
+  MI_REQUIRE(reference_positions && current_positions && flag, "null pointer");
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == MI_F32)
+    nl_moved_kernel<float><<<mi_blocks(n_atoms, 256), 256, 0, st>>>((const float*)reference_positions, (const float*)current_positions,
+                                                                   (float)threshold, n_atoms, flag);
+  else
+    nl_moved_kernel<double><<<mi_blocks(n_atoms, 256), 256, 0, st>>>((const double*)reference_positions, (const double*)current_positions,
+                                                                    threshold, n_atoms, flag);
   MI_LAUNCH_CHECK();
   return MI_OK;
 }

@@ -3,12 +3,16 @@
 
 One HIP kernel family (csrc/ewald.hip, `mi_ewald_real`) covers matrix / CSR x single / batch x energy / +forces /
 +charge gradients.  The neighbour list must be FULL (symmetric), as the reference's 1/2 prefactor assumes.
-The explicit-k reciprocal half of ewald.py (`ewald_reciprocal_space`, `ewald_summation`) is outside this build's hot
-path.
+
+The explicit-k reciprocal half (`ewald_reciprocal_space` :2631, `ewald_summation` :2798) runs on two HIP
+kernels (`mi_ewald_structure_factors`, `mi_ewald_recip_gather`) that recompute the k.r phases in registers instead of the
+reference's two float64 [K, N] phase tables.
 """
 from __future__ import annotations
 
 import torch
+
+import math
 
 from nvalchemiops import _capi as C
 
@@ -115,4 +119,163 @@ def ewald_real_space(positions: torch.Tensor, charges: torch.Tensor, cell: torch
     return out if len(out) > 1 else out[0]
 
 
-__all__ = ["ewald_real_space"]
+def _prepare_alpha(alpha, num_systems: int, dtype: torch.dtype, device: torch.device) -> torch.Tensor:
+    """float / 0-d / [B] alpha -> [B] tensor (ewald.py:190-235)."""
+    if isinstance(alpha, (int, float)):
+        return torch.full((num_systems,), float(alpha), dtype=dtype, device=device)
+    if isinstance(alpha, torch.Tensor):
+        if alpha.dim() == 0:
+            return alpha.expand(num_systems).to(dtype=dtype, device=device)
+        if alpha.shape[0] != num_systems:
+            raise ValueError(f"alpha has {alpha.shape[0]} values but there are {num_systems} systems")
+        return alpha.to(dtype=dtype, device=device)
+    raise TypeError(f"alpha must be float or torch.Tensor, got {type(alpha)}")
+
+
+def _prepare_cell(cell: torch.Tensor):
+    if cell.dim() == 2:
+        cell = cell.unsqueeze(0)
+    return cell, cell.shape[0]
+
+
+def _structure_factors(pos, w, kv, cells, al, sptr, n_sys, n_k, max_atoms, want_charge=True):
+    dev = pos.device
+    sf = torch.empty((n_sys, n_k, 2), dtype=torch.float64, device=dev)
+    tq = torch.empty(n_sys, dtype=torch.float64, device=dev) if want_charge else None
+    rc = C.lib().mi_ewald_structure_factors(C.ptr(pos), C.ptr(w), C.ptr(kv), C.ptr(cells), C.ptr(al), C.ptr(sptr), pos.shape[0], n_sys, n_k,
+                                            int(max_atoms), C.dtype_code(pos.dtype), C.ptr(sf), C.ptr(tq), C.stream_of(pos))
+    C.check(rc, "mi_ewald_structure_factors")
+    return sf, tq
+
+
+def _recip_gather(pos, q, kv, al, bi, sf, tq, n_k, potential=False, kforce=False, energies=False, forces=False, cgrads=False):
+    n, dev = pos.shape[0], pos.device
+    f64 = dict(dtype=torch.float64, device=dev)
+    out = dict(potential=torch.empty(n, **f64) if potential else None, kforce=torch.empty((n, 3), **f64) if kforce else None,
+               energies=torch.empty(n, **f64) if energies else None,
+               forces=torch.empty((n, 3), dtype=pos.dtype, device=dev) if forces else None,
+               cgrads=torch.empty(n, **f64) if cgrads else None)
+    rc = C.lib().mi_ewald_recip_gather(C.ptr(pos), C.ptr(q), C.ptr(kv), C.ptr(al), C.ptr(bi), C.ptr(sf), C.ptr(tq), n, n_k,
+                                       C.dtype_code(pos.dtype), C.ptr(out["potential"]), C.ptr(out["kforce"]), C.ptr(out["energies"]),
+                                       C.ptr(out["forces"]), C.ptr(out["cgrads"]), C.stream_of(pos))
+    C.check(rc, "mi_ewald_recip_gather")
+    return out
+
+
+class _EwaldRecipEnergyFn(torch.autograd.Function):
+    """Differentiable per-atom reciprocal energies (positions, charges).  With L = sum_i g_i E_i and the g-weighted structure
+    factors S^g = G sum_j g_j q_j exp(i k.r_j):
+        dL/dr_m = -1/2 q_m (g_m kf_m[S] + kf_m[S^g]),
+        dL/dq_m = 1/2 (g_m phi_m[S] + phi_m[S^g]) - 2 g_m alpha q_m/sqrt(pi) - pi/(2 alpha^2 V) (g_m Q + sum_i g_i q_i)
+    -- two more passes of the forward kernels instead of a recorded tape (reference: autograd.py:525-665)."""
+
+    @staticmethod
+    def forward(ctx, positions, charges, kv, cells, al, bi, sptr, max_atoms):
+        pos, q = positions.detach().contiguous(), charges.detach().contiguous()
+        n_sys, n_k = kv.shape[0], kv.shape[1]
+        sf, tq = _structure_factors(pos, q, kv, cells, al, sptr, n_sys, n_k, max_atoms)
+        out = _recip_gather(pos, q, kv, al, bi, sf, tq, n_k, energies=True)
+        ctx.save_for_backward(pos, q, kv, cells, al, sf, tq, *(t for t in (bi, sptr) if t is not None))
+        ctx.meta = (bi is not None, max_atoms)
+        return out["energies"].to(pos.dtype)
+
+    @staticmethod
+    def backward(ctx, g_e):
+        pos, q, kv, cells, al, sf, tq, *rest = ctx.saved_tensors
+        batched, max_atoms = ctx.meta
+        bi, sptr = (rest[0], rest[1]) if batched else (None, None)
+        n_sys, n_k = kv.shape[0], kv.shape[1]
+        g = g_e.detach().to(torch.float64)
+        gq = (g * q.to(torch.float64)).to(pos.dtype).contiguous()
+        sfg, tqg = _structure_factors(pos, gq, kv, cells, al, sptr, n_sys, n_k, max_atoms)
+        a = _recip_gather(pos, q, kv, al, bi, sf, None, n_k, potential=True, kforce=True)
+        b = _recip_gather(pos, q, kv, al, bi, sfg, None, n_k, potential=True, kforce=True)
+        q64, al64 = q.to(torch.float64), al.to(torch.float64)
+        sel = bi.long() if batched else torch.zeros(pos.shape[0], dtype=torch.long, device=pos.device)
+        gpos = (-0.5 * q64).unsqueeze(1) * (g.unsqueeze(1) * a["kforce"] + b["kforce"])
+        a_i = al64[sel]
+        gch = (0.5 * (g * a["potential"] + b["potential"]) - 2.0 * g * a_i * q64 / math.sqrt(math.pi)
+               - math.pi / (2.0 * a_i * a_i) * (g * tq[sel] + tqg[sel]))
+        need = ctx.needs_input_grad
+        return (gpos.to(pos.dtype) if need[0] else None, gch.to(pos.dtype) if need[1] else None, None, None, None, None, None, None)
+
+
+def ewald_reciprocal_space(positions: torch.Tensor, charges: torch.Tensor, cell: torch.Tensor, k_vectors: torch.Tensor, alpha: torch.Tensor,
+                           batch_idx: torch.Tensor | None = None, compute_forces: bool = False, compute_charge_gradients: bool = False):
+    """Reciprocal-space Ewald over an explicit half-space k-vector set (ewald.py:2631-2795):
+    E_i = q_i/2 sum_k Re[S(k) exp(-i k.r_i)] - alpha q_i^2/sqrt(pi) - pi q_i Q/(2 alpha^2 V), per-atom, input dtype.
+
+    Returns ``energies`` | ``(energies, forces)`` | ``(energies, charge_grads)`` | ``(energies, forces, charge_grads)``.
+    `k_vectors` is [K,3] (single system) or [B,K,3] (batch); `alpha` a [B] tensor (see `ewald_summation` for float input).
+    Energies are differentiable w.r.t. positions and charges."""
+    n, dev, dt = positions.shape[0], positions.device, positions.dtype
+    batched = batch_idx is not None
+    cells, n_sys = _prepare_cell(cell)
+    kv = k_vectors if k_vectors.dim() == 3 else k_vectors.unsqueeze(0)
+    n_k = kv.shape[1]
+    if n == 0 or (batched and n_k == 0):
+        out = (torch.zeros(n, dtype=dt, device=dev),)
+        if compute_forces:
+            out += (torch.zeros((n, 3), dtype=dt, device=dev),)
+        if compute_charge_gradients:
+            out += (torch.zeros(n, dtype=dt, device=dev),)
+        return out if len(out) > 1 else out[0]
+    C.require_device(positions, charges, cell, k_vectors, batch_idx)
+    if kv.shape[0] != n_sys:
+        kv = kv.expand(n_sys, -1, -1)
+    al = _prepare_alpha(alpha, n_sys, dt, dev).detach().contiguous()
+    pos, q = positions.detach().contiguous(), charges.detach().to(dt).contiguous()
+    cells_c, kv_c = cells.detach().to(dt).contiguous(), kv.detach().to(dt).contiguous()
+    bi = sptr = None
+    max_atoms = n
+    if batched:
+        bi = C.i32(batch_idx)
+        counts = torch.bincount(batch_idx.long(), minlength=n_sys)
+        sptr = torch.zeros(n_sys + 1, dtype=torch.int32, device=dev)
+        sptr[1:] = torch.cumsum(counts, dim=0)
+        max_atoms = int(counts.max().item())
+    sf, tq = _structure_factors(pos, q, kv_c, cells_c, al, sptr, n_sys, n_k, max_atoms)
+    res = _recip_gather(pos, q, kv_c, al, bi, sf, tq, n_k, energies=True, forces=compute_forces,
+                        cgrads=compute_charge_gradients)
+    e_out = res["energies"].to(dt)
+    if torch.is_grad_enabled() and (positions.requires_grad or charges.requires_grad):
+        e_out = _EwaldRecipEnergyFn.apply(positions, charges.to(dt), kv_c, cells_c, al, bi, sptr, max_atoms)
+    out = (e_out,)
+    if compute_forces:
+        out += (res["forces"],)
+    if compute_charge_gradients:
+        out += (res["cgrads"].to(dt),)
+    return out if len(out) > 1 else out[0]
+
+
+def ewald_summation(positions: torch.Tensor, charges: torch.Tensor, cell: torch.Tensor, alpha=None, k_vectors: torch.Tensor | None = None,
+                    k_cutoff: float | None = None, batch_idx: torch.Tensor | None = None, neighbor_list: torch.Tensor | None = None,
+                    neighbor_ptr: torch.Tensor | None = None, neighbor_shifts: torch.Tensor | None = None,
+                    neighbor_matrix: torch.Tensor | None = None, neighbor_matrix_shifts: torch.Tensor | None = None,
+                    mask_value: int | None = None, compute_forces: bool = False, accuracy: float = 1e-6):
+    """Real + reciprocal Ewald sum with automatic parameters (ewald.py:2798-3050): per-atom energies | (energies, forces)."""
+    from nvalchemiops.interactions.electrostatics.k_vectors import generate_k_vectors_ewald_summation
+    from nvalchemiops.interactions.electrostatics.parameters import estimate_ewald_parameters
+
+    cells, n_sys = _prepare_cell(cell)
+    if alpha is None or (k_cutoff is None and k_vectors is None):
+        params = estimate_ewald_parameters(positions, cells, batch_idx, accuracy)
+        if alpha is None:
+            alpha = params.alpha
+        if k_cutoff is None:
+            k_cutoff = params.reciprocal_space_cutoff
+    alpha_t = _prepare_alpha(alpha, n_sys, positions.dtype, positions.device)
+    if k_vectors is None:
+        k_vectors = generate_k_vectors_ewald_summation(cells, k_cutoff)
+    if mask_value is None:
+        mask_value = positions.shape[0]
+    rs = ewald_real_space(positions, charges, cells, alpha_t, neighbor_list=neighbor_list, neighbor_ptr=neighbor_ptr,
+                          neighbor_shifts=neighbor_shifts, neighbor_matrix=neighbor_matrix, neighbor_matrix_shifts=neighbor_matrix_shifts,
+                          mask_value=mask_value, batch_idx=batch_idx, compute_forces=compute_forces)
+    rec = ewald_reciprocal_space(positions, charges, cells, k_vectors, alpha_t, batch_idx=batch_idx, compute_forces=compute_forces)
+    if compute_forces:
+        return rs[0] + rec[0], rs[1] + rec[1]
+    return rs + rec
+
+
+__all__ = ["ewald_real_space", "ewald_reciprocal_space", "ewald_summation"]

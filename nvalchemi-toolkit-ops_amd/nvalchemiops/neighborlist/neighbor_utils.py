@@ -73,7 +73,7 @@ def _prepare_batch_idx_ptr(batch_idx: torch.Tensor | None, batch_ptr: torch.Tens
         per_system = batch_ptr[1:] - batch_ptr[:-1]
         batch_idx = torch.repeat_interleave(torch.arange(per_system.shape[0], dtype=torch.int32, device=device), per_system)
     elif batch_ptr is None:
-        n_sys = int(batch_idx.max().item()) + 1
+        n_sys = int(batch_idx.max().item()) + 1 if batch_idx.numel() else 0
         per_system = torch.bincount(batch_idx, minlength=n_sys)
         batch_ptr = torch.zeros(n_sys + 1, dtype=torch.int32, device=device)
         torch.cumsum(per_system, dim=0, out=batch_ptr[1:])

@@ -2,8 +2,8 @@
 
 Method selection follows the reference (:213-234): two cutoffs -> dual-cutoff naive; >= 5000 atoms -> cell list; else
 naive; a `batch_` prefix when batch_idx / batch_ptr is given.  On this hot path `cell_list`, `batch_cell_list` and
-`naive` are implemented (HIP); `batch_naive` is served by the batched HIP pipeline with the naive result semantics;
-the dual-cutoff variants are outside the north-star path and raise NotImplementedError.
+`naive` are the HIP search; `batch_naive` is served by the batched HIP pipeline with the naive result semantics; the
+dual-cutoff variants run that search once per cutoff.
 
 One conscious deviation: when no cell is given for a >= 5000-atom input the reference fabricates a
 UNIT cell with pbc=False, which degenerates to one bin (and indexes out of range for batches).  Here a per-system
@@ -16,8 +16,11 @@ import torch
 from nvalchemiops import _capi as C
 from nvalchemiops.neighborlist import _engine as E
 from nvalchemiops.neighborlist.batch_cell_list import batch_cell_list
+from nvalchemiops.neighborlist.batch_naive import batch_naive_neighbor_list
+from nvalchemiops.neighborlist.batch_naive_dual_cutoff import batch_naive_neighbor_list_dual_cutoff
 from nvalchemiops.neighborlist.cell_list import _empty_result, _search, cell_list
 from nvalchemiops.neighborlist.naive import _bounding_cell, naive_neighbor_list
+from nvalchemiops.neighborlist.naive_dual_cutoff import naive_neighbor_list_dual_cutoff
 from nvalchemiops.neighborlist.neighbor_utils import (_prepare_batch_idx_ptr, estimate_max_neighbors,
                                                       get_neighbor_list_from_neighbor_matrix)
 
@@ -56,48 +59,6 @@ def _free_space_cell_list(positions, cutoff, batch_idx, half_fill, fill_value, r
     return nm, num, nsh
 
 
-def _batch_naive(positions, cutoff, pbc, cell, batch_idx, batch_ptr, half_fill, fill_value, return_neighbor_list, kwargs):
-    """`batch_naive` result semantics (naive expression / image range, per system) on the batched HIP pipeline.
-    Reference: neighborlist/batch_naive.py:480-763 (return tuples as naive.py: shifts only with pbc)."""
-    n, dev = positions.shape[0], positions.device
-    if (pbc is None) != (cell is None):
-        raise ValueError("cell and pbc must be provided together")
-    periodic = pbc is not None
-    if fill_value is None:
-        fill_value = n
-    C.require_device(positions, cell, pbc, batch_idx)
-    bi = C.i32(batch_idx)
-    origin = None
-    if periodic:
-        pos, c, p = E.canon_geometry(positions, cell, pbc)
-    else:
-        pos = positions.detach().contiguous()
-        n_sys = batch_ptr.shape[0] - 1
-        c, origin = _bounding_cell(pos, bi, n_sys)
-        c, origin = c.to(pos.dtype).contiguous(), origin.contiguous()
-        p = torch.zeros((n_sys, 3), dtype=torch.bool, device=dev)
-    nm, nsh, num = kwargs.get("neighbor_matrix"), kwargs.get("neighbor_matrix_shifts"), kwargs.get("num_neighbors")
-    m = kwargs.get("max_neighbors")
-    if m is None and nm is None:
-        m = estimate_max_neighbors(cutoff)
-    if nm is None:
-        nm = torch.empty((n, m), dtype=torch.int32, device=dev)
-    if num is None:
-        num = torch.empty((n,), dtype=torch.int32, device=dev)
-    if periodic and nsh is None:
-        nsh = torch.empty((n, nm.shape[1], 3), dtype=torch.int32, device=dev)
-    if n > 0 and cutoff > 0:
-        E.neighbor_matrix(pos, c, p, bi, cutoff, nm.shape[1], fill_value, half_fill, nm, nsh if periodic else None, num, naive=True,
-                          want_shifts=periodic, origin=origin)
-    else:
-        nm.fill_(fill_value)
-        num.zero_()
-    if return_neighbor_list:
-        return get_neighbor_list_from_neighbor_matrix(nm, num_neighbors=num, neighbor_shift_matrix=nsh if periodic else None,
-                                                      fill_value=fill_value)
-    return (nm, num, nsh) if periodic else (nm, num)
-
-
 def neighbor_list(positions: torch.Tensor, cutoff: float, cell: torch.Tensor | None = None, pbc: torch.Tensor | None = None,
                   batch_idx: torch.Tensor | None = None, batch_ptr: torch.Tensor | None = None, cutoff2: float | None = None,
                   half_fill: bool = False, fill_value: int | None = None, return_neighbor_list: bool = False,
@@ -133,9 +94,13 @@ def neighbor_list(positions: torch.Tensor, cutoff: float, cell: torch.Tensor | N
     if method == "batch_naive":
         if batch_idx is None or batch_ptr is None:
             batch_idx, batch_ptr = _prepare_batch_idx_ptr(batch_idx, batch_ptr, positions.shape[0], positions.device)
-        return _batch_naive(positions, cutoff, pbc, cell, batch_idx, batch_ptr, half_fill, fill_value, return_neighbor_list, kwargs)
-    if method in ("naive_dual_cutoff", "batch_naive_dual_cutoff"):
-        raise NotImplementedError(
-            f"method '{method}' (dual cutoff) is outside the MI355X hot path of this build (SURVEY.md 8f, N4); "
-            "call neighbor_list twice with the two cutoffs.")
+        return batch_naive_neighbor_list(positions, cutoff, pbc=pbc, cell=cell, batch_idx=batch_idx, batch_ptr=batch_ptr,
+                                         half_fill=half_fill, fill_value=fill_value, return_neighbor_list=return_neighbor_list, **kwargs)
+    if method == "naive_dual_cutoff":
+        return naive_neighbor_list_dual_cutoff(positions, cutoff, cutoff2, pbc=pbc, cell=cell, half_fill=half_fill, fill_value=fill_value,
+                                               return_neighbor_list=return_neighbor_list, **kwargs)
+    if method == "batch_naive_dual_cutoff":
+        return batch_naive_neighbor_list_dual_cutoff(positions, cutoff, cutoff2, pbc=pbc, cell=cell, batch_idx=batch_idx,
+                                                     batch_ptr=batch_ptr, half_fill=half_fill, fill_value=fill_value,
+                                                     return_neighbor_list=return_neighbor_list, **kwargs)
     raise ValueError(f"Invalid method: {method}")

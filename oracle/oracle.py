@@ -435,6 +435,41 @@ def particle_mesh_ewald(positions, charges, cell, alpha, mesh_dimensions, spline
     return rs + rec
 
 
+def generate_k_vectors_ewald_summation(cell, k_cutoff):
+    """Half-space Miller set times 2 pi cell^-T (interactions/electrostatics/k_vectors.py:19-164); no spherical cut, as the reference."""
+    cell = np.asarray(cell, np.float64).reshape(3, 3)
+    bound = np.ceil(k_cutoff * np.linalg.norm(cell, axis=-1) / (2 * math.pi)).astype(int)
+    axes = [np.fft.fftfreq(2 * b + 1) * (2 * b + 1) for b in bound]
+    mil = np.stack([g.ravel() for g in np.meshgrid(*axes, indexing="ij")], axis=1)
+    h, k, l = mil.T
+    mil = mil[(h > 0) | ((h == 0) & (k > 0)) | ((h == 0) & (k == 0) & (l > 0))]
+    return mil @ (2 * math.pi * np.linalg.inv(cell.T))
+
+
+def ewald_reciprocal_space(positions, charges, cell, k_vectors, alpha):
+    """Explicit-k reciprocal Ewald, single system, float64 (ewald_kernels.py:1496-1980 + the charge-gradient corrections of
+    ewald.py:1761-1766).  Returns per-atom (energies, forces, charge_gradients)."""
+    pos, q = np.asarray(positions, np.float64), np.asarray(charges, np.float64)
+    cell, kv = np.asarray(cell, np.float64).reshape(3, 3), np.asarray(k_vectors, np.float64).reshape(-1, 3)
+    vol = abs(np.linalg.det(cell))
+    k2 = (kv * kv).sum(1)
+    ok = k2 >= 1e-10                                    # :1578 skips k ~ 0 (structure factor stays 0)
+    green = np.zeros_like(k2)
+    green[ok] = np.exp(-k2[ok] * 0.25 / alpha**2) / k2[ok] * 8.0 * math.pi / vol   # :1583, 8 pi: half-space set
+    ph = kv @ pos.T                                     # [K, N]
+    c, s = np.cos(ph), np.sin(ph)
+    s_re, s_im = green * (c @ q), green * (s @ q)       # :1610-1615
+    s_re[~ok] = 0.0
+    s_im[~ok] = 0.0
+    phi = s_re @ c + s_im @ s                           # :1650-1655
+    fs = s_re[:, None] * s - s_im[:, None] * c          # :1815
+    total_charge = q.sum() / vol if len(kv) > 1 else 0.0  # accumulated by the k_idx == 1 thread only (:1594)
+    e = 0.5 * q * phi - alpha * q * q / math.sqrt(math.pi) - math.pi * q * total_charge / (2 * alpha**2)   # :1692-1720
+    f = q[:, None] * (fs.T @ kv)
+    cg = phi - 2 * alpha / math.sqrt(math.pi) * q - math.pi / alpha**2 * total_charge
+    return e, f, cg
+
+
 def explicit_ewald(positions, charges, cell, alpha, kmax, rcut_images=None, exact_erfc=True):
     """Independent float64 Ewald sum (structure-factor reciprocal part + direct real-space image sum).
 

@@ -66,8 +66,8 @@ def test_empty_inputs_and_shapes():
 
     with pytest.raises(ValueError):
         neighbor_list(torch.zeros(3, 3), 1.0, method="nope")
-    with pytest.raises(NotImplementedError):
-        neighbor_list(torch.zeros(3, 3), 1.0, cutoff2=2.0)
+    out = neighbor_list(torch.zeros(0, 3), 1.0, cutoff2=2.0)  # dual cutoff: interleaved (matrix1, num1, matrix2, num2)
+    assert len(out) == 4 and out[0].shape[0] == 0 and out[2].shape[0] == 0
 
 
 def test_estimate_max_neighbors_and_overflow_error():

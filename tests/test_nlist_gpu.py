@@ -204,3 +204,69 @@ def test_full_size_properties_100k():
     l5, p5, s5 = cell_list(tp, 5.0, tc, pbc, return_neighbor_list=True)
     # the 5 A list is the 9 A list restricted by distance (up to fp32 rounding of pairs within 1e-5 of the cutoff)
     assert int((d2 < 25.0 - 1e-3).sum()) <= l5.shape[1] <= int((d2 < 25.0 + 1e-3).sum())
+
+
+def test_rebuild_detection():
+    """SURVEY 8f N1 (neighborlist/rebuild_detection.py): skin and cell-crossing checks against numpy restatements."""
+    from nvalchemiops.neighborlist import (allocate_cell_list, build_cell_list, cell_list_needs_rebuild, check_neighbor_list_rebuild_needed,
+                                           estimate_cell_list_sizes, neighbor_list_needs_rebuild)
+
+    pos, cell = S.random_box(500, 12.0, seed=5, dtype=np.float64, triclinic=True)
+    tp, tc, pbc = _t(pos), _t(cell), torch.tensor([True, True, False], device=DEV)
+    g = np.random.default_rng(0)
+    small = pos + g.uniform(-0.02, 0.02, pos.shape)
+    assert not neighbor_list_needs_rebuild(tp, _t(small), 0.5).item()
+    moved = small.copy()
+    moved[123] += [0.4, 0.4, 0.0]
+    assert neighbor_list_needs_rebuild(tp, _t(moved), 0.5).item() and check_neighbor_list_rebuild_needed(tp, _t(moved), 0.5)
+    assert neighbor_list_needs_rebuild(tp, _t(moved[:10]), 0.5).item()  # shape mismatch -> rebuild
+    ncell, radius = estimate_cell_list_sizes(tc, pbc, 3.0)
+    cache = allocate_cell_list(500, ncell, radius, tp.device)
+    build_cell_list(tp, 3.0, tc, pbc, *cache)
+    assert not cell_list_needs_rebuild(tp, cache[3], cache[0], tc, pbc).item()
+    # numpy restatement of _check_atoms_changed_cells for a displaced configuration
+    cpd = cache[0].cpu().numpy()
+    disp = pos + g.normal(0, 0.35, pos.shape)
+    frac = disp @ np.linalg.inv(cell)
+    cc = np.floor(frac * cpd).astype(int)
+    for d, per in enumerate([True, True, False]):
+        cc[:, d] = np.mod(cc[:, d], cpd[d]) if per else np.clip(cc[:, d], 0, cpd[d] - 1)
+    expect = bool((cc != cache[3].cpu().numpy()).any())
+    assert cell_list_needs_rebuild(_t(disp), cache[3], cache[0], tc, pbc).item() == expect and expect
+
+
+@pytest.mark.parametrize("periodic", [False, True])
+def test_dual_cutoff_and_batch_naive(periodic):
+    """batch_naive / dual-cutoff API (batch_naive.py:480, naive_dual_cutoff.py:544, batch_naive_dual_cutoff.py:592)
+    -- tuple layout of the reference and pair sets equal to the oracle's naive search per cutoff."""
+    from nvalchemiops.neighborlist import (batch_naive_neighbor_list, batch_naive_neighbor_list_dual_cutoff,
+                                           naive_neighbor_list_dual_cutoff)
+
+    pos, cell = S.random_box(300, 9.0, seed=11, dtype=np.float64)
+    pbc_np = np.array([True, True, True])
+    kw = dict(cell=_t(cell).unsqueeze(0), pbc=torch.tensor([[True, True, True]], device=DEV)) if periodic else {}
+    out = naive_neighbor_list_dual_cutoff(_t(pos), 2.5, 4.5, max_neighbors1=40, max_neighbors2=160, **kw)
+    assert len(out) == (6 if periodic else 4)
+    half = len(out) // 2
+    for rc, res in ((2.5, out[:half]), (4.5, out[half:])):
+        nm, num = res[0].cpu().numpy(), res[1].cpu().numpy()
+        sh = res[2].cpu().numpy() if periodic else np.zeros(nm.shape + (3,), np.int32)
+        ref = O.naive(pos, rc, cell, pbc_np, 400) if periodic else O.naive(pos, rc, max_neighbors=400)
+        rsh = ref[2] if periodic else np.zeros(ref[0].shape + (3,), np.int32)
+        assert num.max() < nm.shape[1]
+        assert np.array_equal(O.canonical_pairs(nm, num, sh), O.canonical_pairs(ref[0], ref[1], rsh))
+    # via the dispatcher, COO format
+    lst = neighbor_list(_t(pos), 2.5, cutoff2=4.5, return_neighbor_list=True, max_neighbors1=40, max_neighbors2=160, **kw)
+    assert len(lst) == (6 if periodic else 4) and lst[0].shape[0] == 2 and lst[0].shape[1] == int(out[1].sum())
+    assert lst[half].shape[1] == int(out[half + 1].sum())
+    # batched: two copies of the system, second translated
+    posb = np.concatenate([pos, pos + 3.0])
+    bi = torch.tensor([0] * 300 + [1] * 300, dtype=torch.int32, device=DEV)
+    kwb = dict(cell=_t(np.stack([cell, cell])), pbc=torch.tensor([[True] * 3] * 2, device=DEV)) if periodic else {}
+    rb = batch_naive_neighbor_list(_t(posb), 4.5, batch_idx=bi, max_neighbors=160, **kwb)
+    assert len(rb) == (3 if periodic else 2)
+    numb = rb[1].cpu().numpy()
+    assert (numb[:300] == out[half + 1].cpu().numpy()).all() and (numb[300:] == numb[:300]).all()
+    rd = batch_naive_neighbor_list_dual_cutoff(_t(posb), 2.5, 4.5, batch_idx=bi, max_neighbors1=40, max_neighbors2=160, **kwb)
+    assert len(rd) == (6 if periodic else 4)
+    assert (rd[1].cpu().numpy()[:300] == out[1].cpu().numpy()).all() and (rd[half + 1].cpu().numpy() == numb).all()

@@ -143,3 +143,40 @@ def test_spline_properties():
         np.testing.assert_allclose(ones, 1.0, atol=1e-7)
         field = g.normal(size=(12, 10, 14))
         assert abs((mesh * field).sum() - (q * O.spline_gather(pos, field, cell, order)).sum()) < 1e-6
+
+
+def test_explicit_k_ewald_restatement_vs_independent_sum():
+    """The half-space reciprocal restatement (+ real-space restatement over the oracle's own neighbour list) reproduces the
+    independent full-space Ewald sum and the NaCl Madelung constant (reference tests: test/interactions/electrostatics/test_ewald.py)."""
+    g = np.random.default_rng(3)
+    cell = np.array([[9.0, 0, 0], [1.5, 8.0, 0], [0.5, -1.0, 10.0]])
+    pos = g.uniform(0, 1, (24, 3)) @ cell
+    q = g.normal(size=24)
+    q -= q.mean()
+    alpha = 0.45
+    kv = O.generate_k_vectors_ewald_summation(cell, 4.5)
+    e, f, cg = O.ewald_reciprocal_space(pos, q, cell, kv, alpha)
+    nm, num, sh = O.cell_list(pos, 12.0, cell, [True] * 3, max_neighbors=900)
+    assert num.max() < 900
+    er, fr = O.ewald_real_space(pos, q, cell, alpha, nm, sh, mask_value=24, compute_forces=True)[:2]
+    ee, fe = O.explicit_ewald(pos, q, cell, alpha, kmax=8, rcut_images=12.0, exact_erfc=False)
+    assert abs(e.sum() + er.sum() - ee) < 2e-6 * abs(ee) + 1e-6
+    np.testing.assert_allclose(f + fr, fe, atol=2e-5)
+    # dE/dq_i by central differences of the total reciprocal energy
+    h = 1e-5
+    for i in (0, 7):
+        qp, qm = q.copy(), q.copy()
+        qp[i] += h
+        qm[i] -= h
+        num_cg = (O.ewald_reciprocal_space(pos, qp, cell, kv, alpha)[0].sum() - O.ewald_reciprocal_space(pos, qm, cell, kv, alpha)[0].sum()) / (2 * h)
+        assert abs(num_cg - cg[i]) < 1e-6
+    # rock salt: E per ion pair = -M / r0, M = 1.7475646
+    r0, m = 2.82, 4
+    ijk = np.stack(np.meshgrid(*[np.arange(m)] * 3, indexing="ij"), -1).reshape(-1, 3)
+    p, c, qq = ijk * r0, np.eye(3) * (m * r0), np.where(ijk.sum(1) % 2 == 0, 1.0, -1.0)
+    kv = O.generate_k_vectors_ewald_summation(c, 4.0)
+    nm, num, sh = O.cell_list(p, 11.0, c, [True] * 3, max_neighbors=1200)
+    assert num.max() < 1200
+    er = O.ewald_real_space(p, qq, c, 0.5, nm, sh, mask_value=len(p))
+    etot = O.ewald_reciprocal_space(p, qq, c, kv, 0.5)[0].sum() + np.asarray(er).sum()
+    assert abs(etot / (len(p) / 2) * r0 + 1.7475646) < 2e-5
