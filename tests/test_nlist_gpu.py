@@ -240,12 +240,12 @@ def test_dual_cutoff_and_batch_naive(periodic):
     """batch_naive / dual-cutoff API (batch_naive.py:480, naive_dual_cutoff.py:544, batch_naive_dual_cutoff.py:592)
     -- tuple layout of the reference and pair sets equal to the oracle's naive search per cutoff."""
     from nvalchemiops.neighborlist import (batch_naive_neighbor_list, batch_naive_neighbor_list_dual_cutoff,
-                                           naive_neighbor_list_dual_cutoff)
+                                           naive_neighbor_list_dual_cutoff, neighbor_list)
 
     pos, cell = S.random_box(300, 9.0, seed=11, dtype=np.float64)
     pbc_np = np.array([True, True, True])
     kw = dict(cell=_t(cell).unsqueeze(0), pbc=torch.tensor([[True, True, True]], device=DEV)) if periodic else {}
-    out = naive_neighbor_list_dual_cutoff(_t(pos), 2.5, 4.5, max_neighbors1=40, max_neighbors2=160, **kw)
+    out = naive_neighbor_list_dual_cutoff(_t(pos), 2.5, 4.5, max_neighbors1=64, max_neighbors2=256, **kw)
     assert len(out) == (6 if periodic else 4)
     half = len(out) // 2
     for rc, res in ((2.5, out[:half]), (4.5, out[half:])):
@@ -256,17 +256,17 @@ def test_dual_cutoff_and_batch_naive(periodic):
         assert num.max() < nm.shape[1]
         assert np.array_equal(O.canonical_pairs(nm, num, sh), O.canonical_pairs(ref[0], ref[1], rsh))
     # via the dispatcher, COO format
-    lst = neighbor_list(_t(pos), 2.5, cutoff2=4.5, return_neighbor_list=True, max_neighbors1=40, max_neighbors2=160, **kw)
+    lst = neighbor_list(_t(pos), 2.5, cutoff2=4.5, return_neighbor_list=True, max_neighbors1=64, max_neighbors2=256, **kw)
     assert len(lst) == (6 if periodic else 4) and lst[0].shape[0] == 2 and lst[0].shape[1] == int(out[1].sum())
     assert lst[half].shape[1] == int(out[half + 1].sum())
     # batched: two copies of the system, second translated
     posb = np.concatenate([pos, pos + 3.0])
     bi = torch.tensor([0] * 300 + [1] * 300, dtype=torch.int32, device=DEV)
     kwb = dict(cell=_t(np.stack([cell, cell])), pbc=torch.tensor([[True] * 3] * 2, device=DEV)) if periodic else {}
-    rb = batch_naive_neighbor_list(_t(posb), 4.5, batch_idx=bi, max_neighbors=160, **kwb)
+    rb = batch_naive_neighbor_list(_t(posb), 4.5, batch_idx=bi, max_neighbors=256, **kwb)
     assert len(rb) == (3 if periodic else 2)
     numb = rb[1].cpu().numpy()
     assert (numb[:300] == out[half + 1].cpu().numpy()).all() and (numb[300:] == numb[:300]).all()
-    rd = batch_naive_neighbor_list_dual_cutoff(_t(posb), 2.5, 4.5, batch_idx=bi, max_neighbors1=40, max_neighbors2=160, **kwb)
+    rd = batch_naive_neighbor_list_dual_cutoff(_t(posb), 2.5, 4.5, batch_idx=bi, max_neighbors1=64, max_neighbors2=256, **kwb)
     assert len(rd) == (6 if periodic else 4)
     assert (rd[1].cpu().numpy()[:300] == out[1].cpu().numpy()).all() and (rd[half + 1].cpu().numpy() == numb).all()
