@@ -164,7 +164,8 @@ __device__ __forceinline__ void d3_s5(float r, float on, float off, float inv_w,
 
 #define D3_SMAX 16  // species held in LDS per wave (16 x 25 float4 = 6.4 KB); more species fall back to the global table
 
-struct D3Species { int S; int pad[3]; };
+struct D3Species { int S; int factorized; int pad[2]; };
+#define D3_FROW 40  // factorized c6 block per partner species: 5 rows x 8 floats (b = 0..4 used)
 
 __global__ void d3_mark_species_kernel(const int* __restrict__ numbers, int N, int nz, int* __restrict__ present) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -173,11 +174,21 @@ __global__ void d3_mark_species_kernel(const int* __restrict__ numbers, int N, i
   if (z > 0 && z < nz) present[z] = 1;  // benign race: every writer stores 1
 }
 // one block: compact ids of the species present, then the dense [S][S][25] table of {c6, cn_ref_i, cn_ref_j^T}
+//
+// Factorised form.  In Grimme's tables the reference CN of atom i at reference point (a, b) is a property of (Z_i, a) alone, and
+// the set of populated points is a rectangle (a < n_ref(Z_i), b < n_ref(Z_j)).  When the tables of the species present have
+// that structure (checked here, on the device, entry by entry and bit by bit) the Gaussian weight splits,
+//   exp(k3 [(CN_i - c_i(a))^2 + (CN_j - c_j(b))^2] - max) = u_a(i) v_b(j),
+// so a pair needs 5 exponentials instead of 25 and u_a is wave-uniform.  `ftab` [S][S][5][8] holds c6, `fcr` [S][8] holds
+// {c(0..4), validity bits}.  Tables without that structure keep the general 25-term path.
 __global__ void d3_compact_species_kernel(const int* __restrict__ present, const float* __restrict__ c6ab, const float* __restrict__ cnref, int nz,
-                                          int* __restrict__ smap, D3Species* __restrict__ info, float4* __restrict__ ctab) {
+                                          int* __restrict__ smap, D3Species* __restrict__ info, float4* __restrict__ ctab,
+                                          float* __restrict__ ftab, float* __restrict__ fcr) {
   __shared__ int zlist[D3_SMAX];
   __shared__ int count;
+  __shared__ int fact_ok;
   if (threadIdx.x == 0) {
+    fact_ok = 1;
     int S = 0;
     for (int z = 0; z < nz; ++z) {
       if (z > 0 && present[z]) { smap[z] = S < D3_SMAX ? S : -1; if (S < D3_SMAX) zlist[S] = z; ++S; }
@@ -188,13 +199,35 @@ __global__ void d3_compact_species_kernel(const int* __restrict__ present, const
   }
   __syncthreads();
   const int S = count;
-  if (S > D3_SMAX) return;
+  if (S > D3_SMAX) { if (threadIdx.x == 0) info->factorized = 0; return; }
   for (int k = threadIdx.x; k < S * S * 25; k += blockDim.x) {
     const int pq = k % 25, p = pq / 5, q = pq % 5, sj = (k / 25) % S, si = k / (25 * S);
     const int zi = zlist[si], zj = zlist[sj];
     const size_t a = ((size_t)zi * nz + zj) * 25 + pq, b = (((size_t)zj * nz + zi) * 5 + q) * 5 + p;
     ctab[k] = make_float4(c6ab[a], cnref[a], cnref[b], 0.0f);
+    ftab[((size_t)si * S + sj) * D3_FROW + p * 8 + q] = c6ab[a];
+    const size_t dii = ((size_t)zi * nz + zi) * 25 + p * 6, djj = ((size_t)zj * nz + zj) * 25 + q * 6;  // (p,p) / (q,q) entries
+    const bool valid = c6ab[a] != 0.0f, rect = (c6ab[dii] != 0.0f) && (c6ab[djj] != 0.0f);
+    const bool same = __float_as_int(cnref[a]) == __float_as_int(cnref[dii]) && __float_as_int(cnref[b]) == __float_as_int(cnref[djj]);
+    if (valid != rect || (valid && !same)) fact_ok = 0;  // benign race: every writer stores 0
   }
+  for (int k = threadIdx.x; k < S * S * 5; k += blockDim.x) {  // zero the 3 padding floats of each row
+    float* row = ftab + (size_t)(k / 5) * D3_FROW + (k % 5) * 8;
+    row[5] = row[6] = row[7] = 0.0f;
+  }
+  for (int si = threadIdx.x; si < S; si += blockDim.x) {
+    const int zi = zlist[si];
+    int bits = 0;
+    for (int p = 0; p < 5; ++p) {
+      const size_t dii = ((size_t)zi * nz + zi) * 25 + p * 6;
+      fcr[si * 8 + p] = cnref[dii];
+      bits |= (c6ab[dii] != 0.0f) << p;
+    }
+    fcr[si * 8 + 5] = __int_as_float(bits);
+    fcr[si * 8 + 6] = fcr[si * 8 + 7] = 0.0f;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) info->factorized = fact_ok;
 }
 
 // `_c6ab_interpolate` (dftd3.py:427-547) on 25 packed terms {c6, cn_ref_i, cn_ref_j}.  Branch-free: the reference's
@@ -261,20 +294,99 @@ __device__ __forceinline__ void d3_c6(float cn_i, float cn_j, const float4* __re
   }
 }
 
+// Factorised `_c6ab_interpolate`: same sums, same thresholds (points with c6 == 0 never count; terms more than e^-12 below the
+// dominant one are dropped; w <= 1e-12 -> 0), with the exponent argument split as A_a(i) + B_b(j).  `Ap`, `u`, `di` are the
+// wave-uniform per-atom halves (A_a - max A, exp of it, CN_i - c_i(a)); rows whose u is 0 for the whole wave are skipped.
+struct D3Half { float Ap[5], u[5], di[5]; };
+
+__device__ __forceinline__ D3Half d3_half_i(float cn_i, const float* __restrict__ cr, float k3) {
+  D3Half h;
+  const int bits = __float_as_int(cr[5]);
+  float A[5], mx = -INFINITY;
+#pragma unroll
+  for (int a = 0; a < 5; ++a) {
+    h.di[a] = cn_i - cr[a];
+    A[a] = ((bits >> a) & 1) ? k3 * (h.di[a] * h.di[a]) : -INFINITY;
+    mx = fmaxf(mx, A[a]);
+  }
+#pragma unroll
+  for (int a = 0; a < 5; ++a) {
+    h.Ap[a] = A[a] - mx;
+    const bool keep = h.Ap[a] >= -12.0f;  // false for -inf and NaN (no populated point at all)
+    h.u[a] = keep ? d3_exp_neg(keep ? h.Ap[a] : 0.0f) : 0.0f;
+  }
+  return h;
+}
+
+__device__ __forceinline__ void d3_c6_fact(const D3Half& h, float cn_j, const float* __restrict__ crj, const float* __restrict__ c6rows, float k3,
+                                           float& c6, float& dci) {
+  const float4 c03 = *reinterpret_cast<const float4*>(crj);
+  const float2 c45 = *reinterpret_cast<const float2*>(crj + 4);
+  const int bits = __float_as_int(c45.y);
+  const float cj[5] = {c03.x, c03.y, c03.z, c03.w, c45.x};
+  float Bp[5], v[5], mx = -INFINITY;
+#pragma unroll
+  for (int b = 0; b < 5; ++b) {
+    const float dj = cn_j - cj[b];
+    Bp[b] = ((bits >> b) & 1) ? k3 * (dj * dj) : -INFINITY;
+    mx = fmaxf(mx, Bp[b]);
+  }
+#pragma unroll
+  for (int b = 0; b < 5; ++b) {
+    Bp[b] -= mx;
+    const bool keep = Bp[b] >= -12.0f;
+    v[b] = keep ? d3_exp_neg(keep ? Bp[b] : 0.0f) : 0.0f;
+  }
+  float w = 0.0f, z = 0.0f, wdi = 0.0f, zdi = 0.0f;
+#pragma unroll
+  for (int a = 0; a < 5; ++a) {
+    if (__builtin_amdgcn_readfirstlane(__float_as_int(h.u[a])) == 0) continue;  // wave-uniform: u depends on atom i only
+    const float4 r03 = *reinterpret_cast<const float4*>(c6rows + a * 8);
+    const float r4 = c6rows[a * 8 + 4];
+    const float cr[5] = {r03.x, r03.y, r03.z, r03.w, r4};
+    const float thr = -12.0f - h.Ap[a];
+    float R = 0.0f, Tt = 0.0f;
+#pragma unroll
+    for (int b = 0; b < 5; ++b) {
+      const float L = (Bp[b] >= thr) ? v[b] : 0.0f;
+      R += L;
+      Tt = fmaf(cr[b], L, Tt);
+    }
+    const float uR = h.u[a] * R, uT = h.u[a] * Tt;
+    w += uR;
+    z += uT;
+    wdi = fmaf(uR, h.di[a], wdi);
+    zdi = fmaf(uT, h.di[a], zdi);
+  }
+  if (w > 1e-12f) {
+    const float wi = 1.0f / w;
+    c6 = z * wi;
+    const float si = zdi - c6 * wdi;
+    dci = ((2.0f * k3) * wi) * si;
+  } else {
+    c6 = 0.0f; dci = 0.0f;
+  }
+}
+
 // ---- pass 2: energy, direct force, dE/dCN ------------------------------------------------------------
-template <class T, bool CSR, bool LDS>
+// MODE 0: global [nz,nz,25] table (> 16 species); 1: general 25-term interpolation from the LDS-staged compact table;
+// 2: factorised interpolation.  All three are launched; the two that do not match the device-side species info exit at once.
+template <class T, bool CSR, int MODE>
 __global__ __launch_bounds__(256) void d3_energy_kernel(const T* __restrict__ pos, const int* __restrict__ numbers, int N, const int* __restrict__ idx,
                                                         const int* __restrict__ ush, const int* __restrict__ nptr, int M, int fill_value,
                                                         const T* __restrict__ cell, const int* __restrict__ batch_idx, D3Dev P,
                                                         const float* __restrict__ cn, int want_virial, const int* __restrict__ smap,
                                                         const D3Species* __restrict__ sinfo, const float4* __restrict__ ctab,
+                                                        const float* __restrict__ ftab, const float* __restrict__ fcr,
                                                         const typename Vec4<T>::type* __restrict__ apos, const float4* __restrict__ aaux,
                                                         float* __restrict__ dEdCN, float* __restrict__ forces, float* __restrict__ e_atom,
                                                         float* __restrict__ v_atom) {
-  __shared__ float4 lds_tab[LDS ? 4 : 1][LDS ? D3_SMAX * 25 : 1];
-  // both variants are launched; the one that does not match the species count on the device exits at once (no host sync)
+  constexpr bool LDS = MODE == 1;
+  constexpr int WAVE_F4 = MODE == 1 ? D3_SMAX * 25 : MODE == 2 ? D3_SMAX * (D3_FROW + 8) / 4 : 1;  // float4 per wave
+  __shared__ float4 lds_tab[MODE == 0 ? 1 : 4][WAVE_F4];
   const int S = sinfo->S;
-  if ((S <= D3_SMAX) != LDS) return;
+  const int want_mode = S > D3_SMAX ? 0 : (sinfo->factorized ? 2 : 1);
+  if (want_mode != MODE) return;
   const int lane = threadIdx.x & (MI_WAVE - 1);
   const int i = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x / MI_WAVE) + threadIdx.x / MI_WAVE);
   if (i >= N) return;
@@ -288,11 +400,23 @@ __global__ __launch_bounds__(256) void d3_energy_kernel(const T* __restrict__ po
   const float4* __restrict__ tab_i = P.tab + (size_t)zi * P.nz * 25;
   // stage this element's rows of the compact species table in the wave's private LDS slice
   const int code_i = (zi << 8) | (smap[zi] & 0xff);  // own species: a safe table row for masked-out lanes
-  float4* my_tab = lds_tab[LDS ? (threadIdx.x / MI_WAVE) & 3 : 0];
+  float4* my_tab = lds_tab[MODE != 0 ? (threadIdx.x / MI_WAVE) & 3 : 0];
   if (LDS) {
     const float4* __restrict__ src = ctab + (size_t)smap[zi] * S * 25;
     for (int k = lane; k < S * 25; k += MI_WAVE) my_tab[k] = src[k];
   }
+  float* my_f = reinterpret_cast<float*>(my_tab);  // MODE 2: [S][40] c6 rows of this element, then [S][8] reference CNs
+  D3Half hi;
+  if (MODE == 2) {
+    const float4* __restrict__ src = reinterpret_cast<const float4*>(ftab + (size_t)smap[zi] * S * D3_FROW);
+    for (int k = lane; k < S * (D3_FROW / 4); k += MI_WAVE) my_tab[k] = src[k];
+    const float4* __restrict__ src2 = reinterpret_cast<const float4*>(fcr);
+    for (int k = lane; k < S * 2; k += MI_WAVE) my_tab[D3_SMAX * (D3_FROW / 4) + k] = src2[k];
+    hi = d3_half_i(cn_i, fcr + smap[zi] * 8, P.k3);
+  }
+  // the table is staged as float4 and read back as float / float2 / float4: keep the compiler from moving those reads above
+  // the staging stores (the LDS itself executes a wave's accesses in order)
+  if (MODE != 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   long long beg, end;
   d3_row<T, CSR>(i, M, nptr, beg, end);
   double Fx = 0, Fy = 0, Fz = 0, E = 0;
@@ -316,7 +440,10 @@ __global__ __launch_bounds__(256) void d3_energy_kernel(const T* __restrict__ po
       valid = valid && g.ok;
       const int code = valid ? __float_as_int(a0.z) : code_i;
       float c6, dci;
-      d3_c6(cn_i, a0.x, LDS ? my_tab + (code & 0xff) * 25 : tab_i + (size_t)(code >> 8) * 25, P.k3, c6, dci);
+      if (MODE == 2)
+        d3_c6_fact(hi, a0.x, my_f + D3_SMAX * D3_FROW + (code & 0xff) * 8, my_f + (code & 0xff) * D3_FROW, P.k3, c6, dci);
+      else
+        d3_c6(cn_i, a0.x, LDS ? my_tab + (code & 0xff) * 25 : tab_i + (size_t)(code >> 8) * 25, P.k3, c6, dci);
       valid = valid && !(c6 < 1e-12f);
       // `_bj_damping` (dftd3.py:648-687)
       const float r = valid ? g.r : 1.0f;
@@ -480,7 +607,7 @@ __global__ __launch_bounds__(256) void d3_reduce_kernel(const float* __restrict_
   flush();
 }
 
-struct D3Layout { size_t dEdCN, e_atom, v_atom, tab, present, smap, sinfo, ctab, apos, aaux, total; };
+struct D3Layout { size_t dEdCN, e_atom, v_atom, tab, present, smap, sinfo, ctab, ftab, fcr, apos, aaux, total; };
 D3Layout d3_layout(int N, int nz, int dtype) {
   D3Layout L;
   size_t o = 0;
@@ -493,6 +620,8 @@ D3Layout d3_layout(int N, int nz, int dtype) {
   L.smap = take(sizeof(int) * (size_t)nz);
   L.sinfo = take(sizeof(D3Species));
   L.ctab = take(sizeof(float4) * D3_SMAX * D3_SMAX * 25);
+  L.ftab = take(sizeof(float) * D3_SMAX * D3_SMAX * D3_FROW);
+  L.fcr = take(sizeof(float) * D3_SMAX * 8);
   L.apos = take((dtype == MI_F32 ? 16 : 32) * (size_t)N);
   L.aaux = take(sizeof(float4) * (size_t)N);
   L.total = o;
@@ -511,6 +640,8 @@ int d3_impl(const T* pos, const int* numbers, int N, const int* idx, const int* 
   int* smap = reinterpret_cast<int*>(ws + L.smap);
   D3Species* sinfo = reinterpret_cast<D3Species*>(ws + L.sinfo);
   float4* ctab = reinterpret_cast<float4*>(ws + L.ctab);
+  float* ftab = reinterpret_cast<float*>(ws + L.ftab);
+  float* fcr = reinterpret_cast<float*>(ws + L.fcr);
   auto* apos = reinterpret_cast<typename Vec4<T>::type*>(ws + L.apos);
   float4* aaux = reinterpret_cast<float4*>(ws + L.aaux);
   D3Dev P;
@@ -534,19 +665,21 @@ int d3_impl(const T* pos, const int* numbers, int N, const int* idx, const int* 
   MI_HIP_CHECK(hipMemsetAsync(present, 0, sizeof(int) * (size_t)hp->nz, st));
   d3_mark_species_kernel<<<mi_blocks(N, 256), 256, 0, st>>>(numbers, N, hp->nz, present);
   MI_LAUNCH_CHECK();
-  d3_compact_species_kernel<<<1, 256, 0, st>>>(present, hp->c6ab, hp->cn_ref, hp->nz, smap, sinfo, ctab);
+  d3_compact_species_kernel<<<1, 256, 0, st>>>(present, hp->c6ab, hp->cn_ref, hp->nz, smap, sinfo, ctab, ftab, fcr);
   MI_LAUNCH_CHECK();
   d3_pack_atoms_kernel<T><<<mi_blocks(N, 256), 256, 0, st>>>(pos, numbers, N, hp->rcov, hp->r4r2, smap, hp->nz, apos, aaux);
   MI_LAUNCH_CHECK();
   const int blocks = mi_blocks(N, 4);
   MI_TIMED("d3_cn", st, (d3_cn_kernel<T, CSR><<<blocks, 256, 0, st>>>(pos, numbers, N, idx, ush, nptr, M, fill_value, cell, batch_idx, P, apos, aaux, cn)));
   MI_LAUNCH_CHECK();
-  MI_TIMED("d3_energy", st, (d3_energy_kernel<T, CSR, true><<<blocks, 256, 0, st>>>(pos, numbers, N, idx, ush, nptr, M, fill_value, cell, batch_idx, P,
-                                                                                    cn, want_virial, smap, sinfo, ctab, apos, aaux, dEdCN, forces, e_atom, v_atom)));
+#define MI_D3_ENERGY(MODE_)                                                                                                                    \
+  d3_energy_kernel<T, CSR, MODE_><<<blocks, 256, 0, st>>>(pos, numbers, N, idx, ush, nptr, M, fill_value, cell, batch_idx, P, cn, want_virial, \
+                                                          smap, sinfo, ctab, ftab, fcr, apos, aaux, dEdCN, forces, e_atom, v_atom)
+  MI_TIMED("d3_energy", st, (MI_D3_ENERGY(2), MI_D3_ENERGY(1)));
   MI_LAUNCH_CHECK();
-  d3_energy_kernel<T, CSR, false><<<blocks, 256, 0, st>>>(pos, numbers, N, idx, ush, nptr, M, fill_value, cell, batch_idx, P, cn, want_virial, smap,
-                                                          sinfo, ctab, apos, aaux, dEdCN, forces, e_atom, v_atom);
+  MI_D3_ENERGY(0);
   MI_LAUNCH_CHECK();
+#undef MI_D3_ENERGY
   MI_TIMED("d3_chain", st, (d3_chain_kernel<T, CSR><<<blocks, 256, 0, st>>>(pos, numbers, N, idx, ush, nptr, M, fill_value, cell, batch_idx, P, apos, dEdCN,
                                                                             want_virial, forces, v_atom)));
   MI_LAUNCH_CHECK();

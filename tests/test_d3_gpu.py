@@ -195,3 +195,34 @@ def test_config3_molecule_batch_properties():
     nm, num, _ = neighbor_list(tp, 40.0, batch_idx=tb, max_neighbors=512)
     e2, f2, cn2 = dftd3(tp, tz, d3_params=p, neighbor_matrix=nm, batch_idx=tb, num_systems=nmol, **bj)
     assert torch.allclose(e2, e, rtol=1e-5, atol=1e-6) and torch.allclose(f2, f, rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.parametrize("kind", ["factorised_partial_refs", "pair_dependent_cn_ref", "ragged_mask"])
+def test_c6_table_structures(kind):
+    """The energy kernel picks its C6 interpolation on the device from the structure of the tables: factorised (reference CN a
+    property of (Z, ref index), rectangular validity -- Grimme's tables), or the general 25-term form.  All against the oracle's
+    general restatement of `_c6ab_interpolate` (dftd3.py:427-547)."""
+    from nvalchemiops.interactions.dispersion import D3Parameters, dftd3
+    from nvalchemiops.neighborlist import cell_list
+
+    t = O.d3_test_tables(17)
+    g = np.random.default_rng(5)
+    c6, cr = t["c6ab"].copy(), t["cn_ref"].copy()
+    if kind == "factorised_partial_refs":  # elements with fewer than 5 reference systems: rectangular zero pattern
+        nref = {1: 2, 6: 5, 8: 3, 17: 4}
+        for zi, ni in nref.items():
+            c6[zi, :, ni:, :] = 0.0
+            c6[:, zi, :, ni:] = 0.0
+    elif kind == "pair_dependent_cn_ref":
+        cr = (cr * g.uniform(0.9, 1.1, cr.shape)).astype(np.float32)
+    else:
+        c6[g.uniform(size=c6.shape) < 0.25] = 0.0
+    t = dict(t, c6ab=c6, cn_ref=cr)
+    p = D3Parameters(rcov=_t(t["rcov"]), r4r2=_t(t["r4r2"]), c6ab=_t(c6), cn_ref=_t(cr))
+    pos, cell = S.random_box(160, 24.0, seed=8, dtype=np.float32)
+    z = g.choice(np.array([1, 6, 8, 17], np.int32), 160)
+    nm, num, sh = cell_list(_t(pos), 13.0, _t(cell), torch.tensor([True] * 3, device=DEV), max_neighbors=320)
+    assert int(num.max()) <= 320
+    ref = O.dftd3(pos, z, t, neighbor_matrix=nm.cpu().numpy(), neighbor_matrix_shifts=sh.cpu().numpy(), cell=cell, compute_virial=True, **FP)
+    out = dftd3(_t(pos), _t(z), d3_params=p, neighbor_matrix=nm, neighbor_matrix_shifts=sh, cell=_t(cell)[None], compute_virial=True, **FP)
+    _check(out, ref, virial=True)
