@@ -26,7 +26,8 @@ namespace {
 #define NL_PRUNE_R 8
 #define NL_TILE 1024      // candidates staged in LDS per tile (fp64: 34 KB per block)
 #define NL_MAXROWS 96     // (2Ry+1)(2Rz+1) rows of cells a block can describe (R <= 4)
-#define NL_TILED_GRID 2048
+#define NL_MIXED 0x7fffffff
+#define NL_TILED_GRID 1536   // persistent blocks (6 per CU); cells are handed out dynamically
 template <class T> struct NlSys {
   T cell[9];
   T inv[9];
@@ -41,7 +42,11 @@ template <class T> struct NlSys {
   int prune;      // orthorhombic cell with R <= NL_PRUNE_R: dxlim[|dz|][|dy|] = largest |dx| worth visiting (-1: skip the row)
   signed char dxlim[NL_PRUNE_R + 1][NL_PRUNE_R + 1];
 };
-struct NlGlobal { int total_cells; int any_wrap; int use_tiled; int pad1; };
+struct NlGlobal {
+  int total_cells; int any_wrap; int use_tiled; int pad1;
+  int work[4];  // next cell to hand out, per query mode (dynamic scheduling of the tiled kernel)
+  int done[4];  // blocks that ran out of work; the last one re-arms both counters for the next launch
+};
 
 struct NlLayout {
   size_t sys, glob, natoms, keys_in, keys_out, vals_in, vals_out, wrap, swrap, spos, cell_start, cub, total;
@@ -169,6 +174,7 @@ __global__ void nl_setup_kernel(const T* __restrict__ cell, const uint8_t* __res
     int all_tiled = 1;
     for (int s = 0; s < B; ++s) all_tiled &= sys[s].tiled;
     glob->use_tiled = all_tiled;
+    for (int k = 0; k < 4; ++k) { glob->work[k] = 0; glob->done[k] = 0; }
   }
 }
 
@@ -282,12 +288,22 @@ __global__ __launch_bounds__(256) void nl_query_tiled_kernel(
   __shared__ int run_beg[3 * NL_MAXROWS], run_pre[3 * NL_MAXROWS + 1], run_cs[3 * NL_MAXROWS];
   __shared__ int ccnt[256];
   __shared__ int grp_run[NL_TILE / MI_WAVE];  // run containing the first candidate of each 64-candidate group of the current tile
+  __shared__ int grp_shift[NL_TILE / MI_WAVE];  // packed image shift common to all 64 candidates of the group, or NL_MIXED
+  __shared__ int u_beg[3 * NL_MAXROWS], u_len[3 * NL_MAXROWS], u_cs[3 * NL_MAXROWS];  // run table before ordering by image
   const int tid = threadIdx.x, lane = tid & (MI_WAVE - 1), wave = tid / MI_WAVE;
   const int total_cells = glob->total_cells;
   const bool anyw = glob->any_wrap != 0;
   const bool half = (flags & MI_NL_HALF_FILL) != 0, naive = (flags & MI_NL_NAIVE_EXPR) != 0;
   const unsigned long long lt = (1ull << lane) - 1ull;
-  for (int c = blockIdx.x; c < total_cells; c += gridDim.x) {
+  __shared__ int next_cell;
+  NlGlobal* gw = const_cast<NlGlobal*>(glob);
+  for (;;) {
+    // cells differ in cost (occupancy, boundary images): hand them out one at a time instead of a fixed stride
+    __syncthreads();  // the previous cell is fully consumed (run table, tiles, next_cell)
+    if (tid == 0) next_cell = atomicAdd(&gw->work[MODE], 1);
+    __syncthreads();
+    const int c = next_cell;
+    if (c >= total_cells) break;
     const int c_beg = cell_start[c], n_c = cell_start[c + 1] - c_beg;
     if (n_c == 0) continue;  // block-uniform
     int s = 0;
@@ -331,10 +347,25 @@ __global__ __launch_bounds__(256) void nl_query_tiled_kernel(
         const int xa = (xlo > img0 ? xlo : img0), xb = (xhi < img0 + nx - 1 ? xhi : img0 + nx - 1);
         int b = 0, len = 0;
         if (ok && xa <= xb && (pbx || g == 1)) { b = cell_start[rowbase + xa - img0]; len = cell_start[rowbase + xb - img0 + 1] - b; }
-        run_beg[3 * tid + g] = b;
-        run_pre[3 * tid + g + 1] = len;  // lengths first, turned into an inclusive prefix below
-        run_cs[3 * tid + g] = ((g - 1) & 0x3ff) | ((csy & 0x3ff) << 10) | ((csz & 0x3ff) << 20);
+        u_beg[3 * tid + g] = b;
+        u_len[3 * tid + g] = len;
+        u_cs[3 * tid + g] = ((g - 1) & 0x3ff) | ((csy & 0x3ff) << 10) | ((csz & 0x3ff) << 20);
       }
+    }
+    __syncthreads();
+    // Runs are ordered by periodic image (the un-shifted image first, each image's runs in their row order): groups of 64
+    // candidates then carry one common shift almost everywhere, S.cell becomes a per-group constant and the per-candidate
+    // shift is only consulted for the few groups that straddle two images.  Any fixed candidate order is a valid row order.
+    for (int r = tid; r < 3 * nrows; r += 256) {
+      const int key = u_cs[r];
+      int rank = 0;
+      for (int q = 0; q < 3 * nrows; ++q) {
+        const int kq = u_cs[q];
+        rank += ((unsigned)kq < (unsigned)key) || (kq == key && q < r);
+      }
+      run_beg[rank] = u_beg[r];
+      run_pre[rank + 1] = u_len[r];  // lengths first, turned into an inclusive prefix below
+      run_cs[rank] = key;
     }
     __syncthreads();
     if (tid == 0) {
@@ -374,67 +405,121 @@ __global__ __launch_bounds__(256) void nl_query_tiled_kernel(
             if (pbz) sz -= wj.z;
           }
           tsx[t] = (short)sx; tsy[t] = (short)sy; tsz[t] = (short)sz;
+          // t = tid + 256 k: one wave stages exactly one 64-candidate group per trip (lanes past tile_n have left the loop)
+          const int cs0 = __builtin_amdgcn_readfirstlane(cs);
+          const bool same = __all(cs == cs0) && !anyw;  // per-atom wraps make the shift lane-dependent
+          if (lane == 0) grp_shift[t / MI_WAVE] = same ? cs0 : NL_MIXED;
         }
         __syncthreads();
-        for (int ci = cbase + wave; ci < cend; ci += 4) {
-          const auto cr = spos[c_beg + ci];
-          const int i = __builtin_amdgcn_readfirstlane(idx_of(cr));
-          short4 wi = make_short4(0, 0, 0, 0);
-          if (anyw) wi = swrap[c_beg + ci];
-          long long out_base;
-          int cap_row;
-          if (MODE == MI_NL_MODE_CSR) { out_base = ptr[i]; cap_row = ptr[i + 1] - ptr[i]; }
-          else { out_base = (long long)i * M; cap_row = M; }
-          int cnt = ccnt[ci - cbase];
-          const bool ortho = S->prune != 0;  // orthorhombic: S.cell has one non-zero term per component (adding exact zeros changes nothing)
-          // two groups of 64 candidates per iteration: independent dependency chains, hits of the first group are
-          // emitted before those of the second, so the slot order is the candidate order
-          for (int t0 = 0; t0 < tile_n; t0 += 2 * MI_WAVE) {
-            bool hit[2];
-            int jj[2], SX[2], SY[2], SZ[2];
+        // NC centre atoms per wave at a time share every candidate fetched from LDS (one set of ds_reads and address math per
+        // 64 candidates instead of one per centre); groups of 64 candidates whose image shift is zero for the whole group
+        // (the interior of the box) skip the S.cell term -- adding an exact zero cannot change the reference expression.
+        constexpr int NC = 2;
+        for (int ci0 = cbase + wave; ci0 < cend; ci0 += 4 * NC) {
+          T ccx[NC], ccy[NC], ccz[NC];
+          int ii[NC], cap_row[NC], cnt[NC];
+          long long out_base[NC];
+          short4 wi[NC];
+          const int nc = (cend - ci0 + 3) / 4 < NC ? (cend - ci0 + 3) / 4 : NC;  // centres of this wave in this pass (uniform)
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
-              const int t = t0 + u * MI_WAVE + lane;
-              const bool in = t < tile_n;
-              const int tt = in ? t : 0;
-              int j = tj[tt], Sx = tsx[tt], Sy = tsy[tt], Sz = tsz[tt];
-              const T cjx = tx[tt], cjy = ty[tt], cjz = tz[tt];
-              if (anyw) { if (pbx) Sx += wi.x; if (pby) Sy += wi.y; if (pbz) Sz += wi.z; }
+          for (int u = 0; u < NC; ++u) {
+            const bool live = u < nc;
+            const int ci = live ? ci0 + 4 * u : ci0;
+            const auto cr = spos[c_beg + ci];
+            // a missing centre (last pass of a chunk) gets NaN coordinates: every `d2 < rc2` is false, so the candidate loop
+            // needs no per-centre predicate
+            ccx[u] = live ? cr.x : (T)NAN; ccy[u] = cr.y; ccz[u] = cr.z;
+            ii[u] = __builtin_amdgcn_readfirstlane(idx_of(cr));
+            wi[u] = make_short4(0, 0, 0, 0);
+            if (anyw) wi[u] = swrap[c_beg + ci];
+            if (MODE == MI_NL_MODE_CSR) { out_base[u] = ptr[ii[u]]; cap_row[u] = ptr[ii[u] + 1] - ptr[ii[u]]; }
+            else { out_base[u] = (long long)ii[u] * M; cap_row[u] = M; }
+            cnt[u] = ccnt[ci - cbase];
+          }
+          const bool ortho = S->prune != 0;  // orthorhombic: S.cell has one non-zero term per component (adding exact zeros changes nothing)
+          auto emit = [&](int u, bool hit, int j, int Sx, int Sy, int Sz) {
+            const unsigned long long mask = __ballot(hit);
+            if (MODE == MI_NL_MODE_COUNT) { cnt[u] += __popcll(mask); return; }
+            if (mask) {
+              const int slot = cnt[u] + __popcll(mask & lt);
+              if (MODE == MI_NL_MODE_MATRIX) {
+                if (hit && slot < cap_row[u]) {
+                  nm[out_base[u] + slot] = j;
+                  if (nsh) reinterpret_cast<NlInt3*>(nsh)[out_base[u] + slot] = NlInt3{Sx, Sy, Sz};
+                }
+              } else if (MODE == MI_NL_MODE_CSR) {
+                if (hit && slot < cap_row[u]) {  // the source row (constant i) is written in bulk when the centre is finished
+                  list_ij[P + out_base[u] + slot] = j;
+                  if (list_sh) reinterpret_cast<NlInt3*>(list_sh)[out_base[u] + slot] = NlInt3{Sx, Sy, Sz};
+                }
+              }
+              cnt[u] += __popcll(mask);
+            }
+          };
+          // software-pipelined by one group: the LDS reads of group g+1 are issued before group g is tested, so the wave
+          // does not sit out an LDS round trip at the top of every trip
+          struct Cand { int j, tt, zg; T x, y, z; };
+          auto fetch = [&](int t0) {
+            Cand c;
+            const int t = t0 + lane;
+            const bool in = t < tile_n;
+            c.tt = in ? t : 0;
+            c.j = tj[c.tt];
+            c.x = in ? tx[c.tt] : (T)NAN;  // lanes past the tile: NaN -> never a hit
+            c.y = ty[c.tt]; c.z = tz[c.tt];
+            c.zg = grp_shift[(t0 < tile_n ? t0 : 0) / MI_WAVE];
+            return c;
+          };
+          Cand nxt = fetch(0);
+          for (int t0 = 0; t0 < tile_n; t0 += MI_WAVE) {
+            const Cand cur = nxt;
+            nxt = fetch(t0 + MI_WAVE);
+            const int j = cur.j, tt = cur.tt;
+            const T cjx = cur.x, cjy = cur.y, cjz = cur.z;
+            const int gs = __builtin_amdgcn_readfirstlane(cur.zg);
+            if (FAST && gs == 0) {  // un-shifted image: adding S.cell = 0 cannot change the reference expression
+#pragma unroll
+              for (int u = 0; u < NC; ++u) {
+                const T dr0 = cjx - ccx[u], dr1 = cjy - ccy[u], dr2 = cjz - ccz[u];
+                const T d2 = dr0 * dr0 + dr1 * dr1 + dr2 * dr2;
+                emit(u, (d2 < rc2) & (j != ii[u]), j, 0, 0, 0);
+              }
+            } else if (FAST && gs != NL_MIXED) {  // one common non-zero shift: S.cell once per group, no self-pair possible
+              const int Sx = (gs << 22) >> 22, Sy = (gs << 12) >> 22, Sz = (gs << 2) >> 22;
               T cart[3];
               if (ortho) { cart[0] = cm[0] * (T)Sx; cart[1] = cm[4] * (T)Sy; cart[2] = cm[8] * (T)Sz; }
               else { const T fs[3] = {(T)Sx, (T)Sy, (T)Sz}; rowvec_mat3(fs, cm, cart); }
-              bool h;
-              if (FAST) {
-                const T dr0 = (cjx - cr.x) + cart[0], dr1 = (cjy - cr.y) + cart[1], dr2 = (cjz - cr.z) + cart[2];
-                const T d2 = dr0 * dr0 + dr1 * dr1 + dr2 * dr2;
-                h = (d2 < rc2) && !(j == i && (Sx | Sy | Sz) == 0);
-              } else {
-                h = nl_pair_hit<T>(cr.x, cr.y, cr.z, i, cjx, cjy, cjz, j, Sx, Sy, Sz, cart, rc2, naive, half, nr0, nr1, nr2);
-              }
-              hit[u] = in && h;
-              jj[u] = j; SX[u] = Sx; SY[u] = Sy; SZ[u] = Sz;
-            }
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
-              const unsigned long long mask = __ballot(hit[u]);
-              if (mask) {
-                const int slot = cnt + __popcll(mask & lt);
-                if (MODE == MI_NL_MODE_MATRIX) {
-                  if (hit[u] && slot < cap_row) {
-                    nm[out_base + slot] = jj[u];
-                    if (nsh) reinterpret_cast<NlInt3*>(nsh)[out_base + slot] = NlInt3{SX[u], SY[u], SZ[u]};
-                  }
-                } else if (MODE == MI_NL_MODE_CSR) {
-                  if (hit[u] && slot < cap_row) {  // the source row (constant i) is written in bulk when the centre is finished
-                    list_ij[P + out_base + slot] = jj[u];
-                    if (list_sh) reinterpret_cast<NlInt3*>(list_sh)[out_base + slot] = NlInt3{SX[u], SY[u], SZ[u]};
-                  }
+              for (int u = 0; u < NC; ++u) {
+                const T dr0 = (cjx - ccx[u]) + cart[0], dr1 = (cjy - ccy[u]) + cart[1], dr2 = (cjz - ccz[u]) + cart[2];
+                const T d2 = dr0 * dr0 + dr1 * dr1 + dr2 * dr2;
+                emit(u, d2 < rc2, j, Sx, Sy, Sz);
+              }
+            } else {
+              const int Sx0 = tsx[tt], Sy0 = tsy[tt], Sz0 = tsz[tt];
+#pragma unroll
+              for (int u = 0; u < NC; ++u) {
+                int Sx = Sx0, Sy = Sy0, Sz = Sz0;
+                if (anyw) { if (pbx) Sx += wi[u].x; if (pby) Sy += wi[u].y; if (pbz) Sz += wi[u].z; }
+                T cart[3];
+                if (ortho) { cart[0] = cm[0] * (T)Sx; cart[1] = cm[4] * (T)Sy; cart[2] = cm[8] * (T)Sz; }
+                else { const T fs[3] = {(T)Sx, (T)Sy, (T)Sz}; rowvec_mat3(fs, cm, cart); }
+                bool h;
+                if (FAST) {
+                  const T dr0 = (cjx - ccx[u]) + cart[0], dr1 = (cjy - ccy[u]) + cart[1], dr2 = (cjz - ccz[u]) + cart[2];
+                  const T d2 = dr0 * dr0 + dr1 * dr1 + dr2 * dr2;
+                  h = (d2 < rc2) & !((j == ii[u]) & ((Sx | Sy | Sz) == 0));
+                } else {
+                  h = nl_pair_hit<T>(ccx[u], ccy[u], ccz[u], ii[u], cjx, cjy, cjz, j, Sx, Sy, Sz, cart, rc2, naive, half, nr0, nr1, nr2);
                 }
-                cnt += __popcll(mask);
+                emit(u, h, j, Sx, Sy, Sz);
               }
             }
           }
-          if (lane == 0) ccnt[ci - cbase] = cnt;
+          if (lane == 0) {
+#pragma unroll
+            for (int u = 0; u < NC; ++u) if (u < nc) ccnt[ci0 + 4 * u - cbase] = cnt[u];
+          }
         }
       }
       __syncthreads();
@@ -457,6 +542,10 @@ __global__ __launch_bounds__(256) void nl_query_tiled_kernel(
       }
       __syncthreads();
     }
+  }
+  if (tid == 0 && atomicAdd(&gw->done[MODE], 1) == (int)gridDim.x - 1) {  // last block out re-arms the counters
+    gw->work[MODE] = 0;
+    gw->done[MODE] = 0;
   }
 }
 
