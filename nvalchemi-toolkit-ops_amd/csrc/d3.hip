@@ -74,9 +74,13 @@ __device__ __forceinline__ PairGeom<T> d3_geom(const V4& pj, T pix, T piy, T piz
     dx = dx + cart[0]; dy = dy + cart[1]; dz = dz + cart[2];
   }
   g.rx = (float)dx; g.ry = (float)dy; g.rz = (float)dz;
-  g.r = sqrtf(g.rx * g.rx + g.ry * g.ry + g.rz * g.rz);
-  g.ok = !(g.r < 1e-12f);
-  g.rinv = g.ok ? 1.0f / g.r : 0.0f;
+  // r and 1/r from one hardware reciprocal square root (1 ulp) instead of an IEEE sqrt plus an IEEE divide (~25 VALU
+  // instructions per pair in every pass); r < 1e-12 of the reference is r^2 < 1e-24 here
+  const float r2 = g.rx * g.rx + g.ry * g.ry + g.rz * g.rz;
+  g.ok = !(r2 < 1e-24f);
+  const float rinv = __builtin_amdgcn_rsqf(g.ok ? r2 : 1.0f);
+  g.r = r2 * rinv;
+  g.rinv = g.ok ? rinv : 0.0f;
   return g;
 }
 
@@ -94,10 +98,23 @@ __device__ __forceinline__ D3Step d3_fetch(const int* __restrict__ idx, const In
 // already being gathered and the index/shift words of step k+2 are in flight; validity is a predicate, not a branch, so
 // no load waits behind a branch on an earlier load (rocprof: the unpipelined walk spent >80 % of its wave cycles waiting).
 
+// exp(x) as 2^(x log2 e) on the hardware v_exp_f32, with the rounding error of the product x*log2(e) compensated (two FMAs):
+// ~1-2 ulp like libm's expf but without its range reduction and overflow/underflow selects.  Used where the argument is
+// bounded above (counting function: <= k1; C6 interpolation: [-12, 0]); v_exp_f32 flushes to 0 by itself below.
+__device__ __forceinline__ float d3_exp(float x) {
+  const float L2E_HI = 1.44269502e+00f, L2E_LO = 1.92596299e-08f, LN2 = 6.93147182e-01f;
+  const float t = x * L2E_HI;
+  float lo = fmaf(x, L2E_HI, -t);
+  lo = fmaf(x, L2E_LO, lo);
+  const float e = __builtin_amdgcn_exp2f(t);
+  return fmaf(e, lo * LN2, e);
+}
+__device__ __forceinline__ float d3_exp_neg(float x) { return d3_exp(x); }
+
 // `_cn_counting` (dftd3.py:608-645)
 __device__ __forceinline__ float d3_cn_count(float rinv, float rci, float rcj, float k1, float* dcn) {
   const float rr = (rci + rcj) * rinv;
-  const float f = 1.0f / (1.0f + expf(-k1 * (rr - 1.0f)));
+  const float f = __builtin_amdgcn_rcpf(1.0f + d3_exp(-k1 * (rr - 1.0f)));
   if (dcn) *dcn = -f * (1.0f - f) * k1 * rr * rinv;
   return f;
 }
@@ -233,18 +250,6 @@ __global__ void d3_compact_species_kernel(const int* __restrict__ present, const
 // `_c6ab_interpolate` (dftd3.py:427-547) on 25 packed terms {c6, cn_ref_i, cn_ref_j}.  Branch-free: the reference's
 // `continue`s (c6 == 0, exp_arg - max < -12) become selects, so every lane runs the same 25 + 25 steps with no
 // load -> branch -> load dependency; exponent arguments are kept in registers between the max pass and the sum pass.
-// exp(x) for x in [-12, 0] (the only range the interpolation needs): 2^(x log2 e) on the hardware v_exp_f32 with the
-// rounding error of the product x*log2(e) compensated (two FMAs), ~1-2 ulp like libm's expf but without the range
-// reduction / overflow-underflow selects that this argument range never needs.
-__device__ __forceinline__ float d3_exp_neg(float x) {
-  const float L2E_HI = 1.44269502e+00f, L2E_LO = 1.92596299e-08f, LN2 = 6.93147182e-01f;
-  const float t = x * L2E_HI;
-  float lo = fmaf(x, L2E_HI, -t);
-  lo = fmaf(x, L2E_LO, lo);
-  const float e = __builtin_amdgcn_exp2f(t);
-  return fmaf(e, lo * LN2, e);
-}
-
 __device__ __forceinline__ void d3_c6(float cn_i, float cn_j, const float4* __restrict__ t25, float k3, float& c6, float& dci) {
   // pass A: exponent arguments of all 25 reference points (kept in registers) and their maximum.  Empty reference points
   // (c6 == 0, which the reference skips in both of its loops) get -inf: they can neither set the maximum nor survive the
@@ -285,7 +290,7 @@ __device__ __forceinline__ void d3_c6(float cn_i, float cn_j, const float4* __re
     zdi += cL * di;
   }
   if (w > 1e-12f) {
-    const float wi = 1.0f / w;
+    const float wi = __builtin_amdgcn_rcpf(w);
     c6 = z * wi;
     const float si = zdi - c6 * wdi;
     dci = ((2.0f * k3) * wi) * si;
@@ -359,7 +364,7 @@ __device__ __forceinline__ void d3_c6_fact(const D3Half& h, float cn_j, const fl
     zdi = fmaf(uT, h.di[a], zdi);
   }
   if (w > 1e-12f) {
-    const float wi = 1.0f / w;
+    const float wi = __builtin_amdgcn_rcpf(w);
     c6 = z * wi;
     const float si = zdi - c6 * wdi;
     dci = ((2.0f * k3) * wi) * si;
@@ -448,10 +453,10 @@ __global__ __launch_bounds__(256) void d3_energy_kernel(const T* __restrict__ po
       // `_bj_damping` (dftd3.py:648-687)
       const float r = valid ? g.r : 1.0f;
       const float q = 3.0f * r4r2_i * a0.y;
-      const float r0 = P.a1 * sqrtf(q) + P.a2;
+      const float r0 = P.a1 * __builtin_amdgcn_sqrtf(q) + P.a2;
       const float r2 = r * r, r4 = r2 * r2, r6 = r4 * r2, r8 = r4 * r4;
       const float r02 = r0 * r0, r04 = r02 * r02, r06 = r04 * r02, r08 = r04 * r04;
-      const float i6 = 1.0f / (r6 + r06), i8 = 1.0f / (r8 + r08);
+      const float i6 = __builtin_amdgcn_rcpf(r6 + r06), i8 = __builtin_amdgcn_rcpf(r8 + r08);
       const float damp = P.s6 * i6 + P.s8 * q * i8;
       // `_dispersion_energy_force` (dftd3.py:690-731)
       const float eij = -c6 * damp;
