@@ -1,0 +1,52 @@
+"""HBM traffic per launch from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE), summarised by tools/rocpd_pmc.py.
+
+Usage: pmc_traffic.py FETCH_SIZE.csv WRITE_SIZE.csv out.json
+Counters are in KB (x1024).  FETCH_SIZE is doubled: gfx950 reports half of wide coalesced reads (MI355X_MICROARCH.md,
+HBM / rocprofv3 section); WRITE_SIZE is used as reported.  Several template instantiations share a short name (variants that
+exit at once are launched next to the one that works): the largest per-dispatch value is the working variant."""
+import csv
+import json
+import re
+import sys
+
+SHORT = {"d3_energy_kernel": "d3_energy", "d3_cn_kernel": "d3_cn", "d3_chain_kernel": "d3_chain", "ewald_real_kernel": "ewald_real",
+         "spline_spread_kernel": "spline_spread", "pme_convolve_kernel": "pme_convolve", "pme_gather_finish_kernel": "pme_gather_finish",
+         "nl_query_tiled_kernel": None, "nl_query_kernel": None}
+MODE = {"0": "nl_query_matrix", "1": "nl_query_count", "2": "nl_query_csr"}
+
+
+def short_name(sym: str):
+    m = re.search(r"::(\w+)<([^>]*)>", sym)
+    if not m or m.group(1) not in SHORT:
+        return None
+    if SHORT[m.group(1)] is not None:
+        return SHORT[m.group(1)]
+    args = [a.strip() for a in m.group(2).split(",")]
+    return MODE.get(args[1])
+
+
+def load(path, counter):
+    out = {}
+    for r in csv.DictReader(open(path)):
+        if r["counter"] != counter:
+            continue
+        k = short_name(r["kernel"])
+        if k:
+            out[k] = max(out.get(k, 0.0), float(r["per_dispatch"]) * 1024.0)
+    return out
+
+
+def main(fetch_csv, write_csv, out_json):
+    f, w = load(fetch_csv, "FETCH_SIZE"), load(write_csv, "WRITE_SIZE")
+    kernels = {}
+    for k in sorted(set(f) | set(w)):
+        fr, wr = f.get(k, 0.0), w.get(k, 0.0)
+        kernels[k] = {"fetch_bytes_raw": fr, "fetch_bytes_corrected_x2": 2 * fr, "write_bytes": wr, "hbm_bytes_per_launch": 2 * fr + wr}
+    note = ("rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on `python bench.py --steps 2 --warmup 1 "
+            "--cpu-sample 0 --overlap 0`, per dispatch; KB counters x1024; FETCH_SIZE doubled (gfx950 reports 1/2 of wide coalesced "
+            "reads, MI355X_MICROARCH.md HBM section); WRITE_SIZE as reported.")
+    json.dump({"note": note, "kernels": kernels}, open(out_json, "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main(*sys.argv[1:4])
