@@ -15,3 +15,4 @@ Reference counterpart: nvalchemiops/__init__.py:16-26 (wp.init() at import; here
 __version__ = "0.2.0+mi355x.1"
 
 from nvalchemiops import _capi  # noqa: F401  (lazy: does not load the .so until first use)
+from nvalchemiops import _ops  # noqa: F401,E402  registers torch.ops.nvalchemiops.* (reference op names) for the hot-path seam

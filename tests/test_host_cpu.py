@@ -187,3 +187,12 @@ def test_gloo_world2_energy_gather():
     out = mgr.dict()
     mp.spawn(_gloo_worker, args=(2, port, out), nprocs=2, join=True)
     assert out.get(0) is True and out.get(1) is True
+
+
+def test_custom_ops_registered_under_reference_names():
+    import nvalchemiops  # noqa: F401
+
+    for name in ("build_cell_list", "query_cell_list", "batch_build_cell_list", "batch_query_cell_list", "dftd3_nm", "dftd3_nl"):
+        op = getattr(torch.ops.nvalchemiops, name)
+        schema = str(op.default._schema)
+        assert "-> ()" in schema and "Tensor(a" in schema, schema  # mutating ops returning None, as in the reference

@@ -270,3 +270,38 @@ def test_dual_cutoff_and_batch_naive(periodic):
     rd = batch_naive_neighbor_list_dual_cutoff(_t(posb), 2.5, 4.5, batch_idx=bi, max_neighbors1=64, max_neighbors2=256, **kwb)
     assert len(rd) == (6 if periodic else 4)
     assert (rd[1].cpu().numpy()[:300] == out[1].cpu().numpy()).all() and (rd[half + 1].cpu().numpy() == numb).all()
+
+
+def test_custom_ops_and_graph_capture():
+    """The reference's op seam (`torch.ops.nvalchemiops.*`, cell_list.py:725/892, dftd3.py:1792): same results as the functional
+    API, and traceable as opaque mutating ops by torch.compile (fullgraph, aot_eager backend: no code generation involved)."""
+    from nvalchemiops.interactions.dispersion import D3Parameters, dftd3
+    from nvalchemiops.neighborlist import allocate_cell_list, cell_list, estimate_cell_list_sizes
+
+    pos, cell = S.random_box(400, 14.0, seed=21, dtype=np.float32)
+    tp, tc, pbc = _t(pos), _t(cell), torch.tensor([True] * 3, device=DEV)
+    ncell, radius = estimate_cell_list_sizes(tc, pbc, 4.0)
+    cache = allocate_cell_list(400, ncell, radius, tp.device)
+    nm = torch.full((400, 96), 400, dtype=torch.int32, device=DEV)
+    sh = torch.zeros((400, 96, 3), dtype=torch.int32, device=DEV)
+    num = torch.zeros(400, dtype=torch.int32, device=DEV)
+
+    def step(p):
+        torch.ops.nvalchemiops.build_cell_list(p, 4.0, tc, pbc, *cache)
+        torch.ops.nvalchemiops.query_cell_list(p, 4.0, tc, pbc, *cache, nm, sh, num, False)
+        return num.sum()
+
+    total = torch.compile(step, backend="aot_eager", fullgraph=True)(tp)
+    rm, rnum, rsh = cell_list(tp, 4.0, tc, pbc, max_neighbors=96)
+    assert int(total) == int(rnum.sum()) and torch.equal(num, rnum)
+    assert np.array_equal(O.canonical_pairs(nm.cpu().numpy(), num.cpu().numpy(), sh.cpu().numpy()),
+                          O.canonical_pairs(rm.cpu().numpy(), rnum.cpu().numpy(), rsh.cpu().numpy()))
+    t = O.d3_test_tables(17)
+    prm = D3Parameters(rcov=_t(t["rcov"]), r4r2=_t(t["r4r2"]), c6ab=_t(t["c6ab"]), cn_ref=_t(t["cn_ref"]))
+    z = _t(np.random.default_rng(2).choice(np.array([1, 6, 8], np.int32), 400))
+    e, f, cn = (torch.zeros(1, device=DEV), torch.zeros((400, 3), device=DEV), torch.zeros(400, device=DEV))
+    torch.ops.nvalchemiops.dftd3_nm(tp, z, rm, prm.rcov, prm.r4r2, prm.c6ab, prm.cn_ref, 0.4, 4.0, 0.8, e, f, cn,
+                                    torch.zeros((0, 3, 3), device=DEV), fill_value=400, cell=tc[None], neighbor_matrix_shifts=rsh)
+    e2, f2, cn2 = dftd3(tp, z, 0.4, 4.0, 0.8, d3_params=prm, neighbor_matrix=rm, neighbor_matrix_shifts=rsh, cell=tc[None], fill_value=400)
+    # per-system energy: float atomics over slabs (order-dependent last bit); per-atom outputs are deterministic
+    assert torch.allclose(e, e2, rtol=1e-6) and torch.equal(f, f2) and torch.equal(cn, cn2)
