@@ -200,7 +200,7 @@ __global__ void d3_mark_species_kernel(const int* __restrict__ numbers, int N, i
 // {c(0..4), validity bits}.  Tables without that structure keep the general 25-term path.
 __global__ void d3_compact_species_kernel(const int* __restrict__ present, const float* __restrict__ c6ab, const float* __restrict__ cnref, int nz,
                                           int* __restrict__ smap, D3Species* __restrict__ info, float4* __restrict__ ctab,
-                                          float* __restrict__ ftab, float* __restrict__ fcr) {
+                                          float* __restrict__ ftab, float* __restrict__ fcr, float k3) {
   __shared__ int zlist[D3_SMAX];
   __shared__ int count;
   __shared__ int fact_ok;
@@ -237,14 +237,15 @@ __global__ void d3_compact_species_kernel(const int* __restrict__ present, const
     int bits = 0;
     for (int p = 0; p < 5; ++p) {
       const size_t dii = ((size_t)zi * nz + zi) * 25 + p * 6;
-      fcr[si * 8 + p] = cnref[dii];
-      bits |= (c6ab[dii] != 0.0f) << p;
+      const bool has = c6ab[dii] != 0.0f;
+      fcr[si * 8 + p] = has ? cnref[dii] : 1.0e30f;  // D3_NOREF: masks the point in d3_c6_fact without bit tests
+      bits |= has << p;
     }
     fcr[si * 8 + 5] = __int_as_float(bits);
     fcr[si * 8 + 6] = fcr[si * 8 + 7] = 0.0f;
   }
   __syncthreads();
-  if (threadIdx.x == 0) info->factorized = fact_ok;
+  if (threadIdx.x == 0) info->factorized = fact_ok && k3 < 0.0f;  // the -inf masking of missing points needs k3 < 0
 }
 
 // `_c6ab_interpolate` (dftd3.py:427-547) on 25 packed terms {c6, cn_ref_i, cn_ref_j}.  Branch-free: the reference's
@@ -323,26 +324,31 @@ __device__ __forceinline__ D3Half d3_half_i(float cn_i, const float* __restrict_
   return h;
 }
 
+typedef float d3_f2 __attribute__((ext_vector_type(2)));
+
+// Per pair: the j-side exponents B_b, their maximum, v_b = exp(B_b - max) and the (a, b) contraction.  Reference points that
+// do not exist carry c_j(b) = D3_NOREF in the staged table, so (CN_j - c)^2 overflows to +inf and k3 * inf = -inf masks the
+// term with no bit tests (the factorised path is only selected for k3 < 0).  v_b uses the compensated exponential (the bare
+// v_exp_f32 would be 4 % faster on this kernel but shifts small-system energies by 1e-7 relative); terms below e^-12 are
+// removed by the per-term test A'_a + B'_b >= -12 alone, so v_b itself needs no cut.
+#define D3_NOREF 1.0e30f
 __device__ __forceinline__ void d3_c6_fact(const D3Half& h, float cn_j, const float* __restrict__ crj, const float* __restrict__ c6rows, float k3,
                                            float& c6, float& dci) {
   const float4 c03 = *reinterpret_cast<const float4*>(crj);
-  const float2 c45 = *reinterpret_cast<const float2*>(crj + 4);
-  const int bits = __float_as_int(c45.y);
-  const float cj[5] = {c03.x, c03.y, c03.z, c03.w, c45.x};
+  const float cj[5] = {c03.x, c03.y, c03.z, c03.w, crj[4]};
   float Bp[5], v[5], mx = -INFINITY;
 #pragma unroll
   for (int b = 0; b < 5; ++b) {
     const float dj = cn_j - cj[b];
-    Bp[b] = ((bits >> b) & 1) ? k3 * (dj * dj) : -INFINITY;
+    Bp[b] = k3 * (dj * dj);
     mx = fmaxf(mx, Bp[b]);
   }
 #pragma unroll
   for (int b = 0; b < 5; ++b) {
     Bp[b] -= mx;
-    const bool keep = Bp[b] >= -12.0f;
-    v[b] = keep ? d3_exp_neg(keep ? Bp[b] : 0.0f) : 0.0f;
+    v[b] = d3_exp(Bp[b]);
   }
-  float w = 0.0f, z = 0.0f, wdi = 0.0f, zdi = 0.0f;
+  d3_f2 wz = {0.0f, 0.0f}, wzd = {0.0f, 0.0f};  // {w, z} and {sum w di, sum z di}
 #pragma unroll
   for (int a = 0; a < 5; ++a) {
     if (__builtin_amdgcn_readfirstlane(__float_as_int(h.u[a])) == 0) continue;  // wave-uniform: u depends on atom i only
@@ -350,19 +356,17 @@ __device__ __forceinline__ void d3_c6_fact(const D3Half& h, float cn_j, const fl
     const float r4 = c6rows[a * 8 + 4];
     const float cr[5] = {r03.x, r03.y, r03.z, r03.w, r4};
     const float thr = -12.0f - h.Ap[a];
-    float R = 0.0f, Tt = 0.0f;
+    d3_f2 RT = {0.0f, 0.0f};  // {sum_b L, sum_b c6_ab L}: one packed FMA per term
 #pragma unroll
     for (int b = 0; b < 5; ++b) {
       const float L = (Bp[b] >= thr) ? v[b] : 0.0f;
-      R += L;
-      Tt = fmaf(cr[b], L, Tt);
+      RT = __builtin_elementwise_fma((d3_f2){L, L}, (d3_f2){1.0f, cr[b]}, RT);
     }
-    const float uR = h.u[a] * R, uT = h.u[a] * Tt;
-    w += uR;
-    z += uT;
-    wdi = fmaf(uR, h.di[a], wdi);
-    zdi = fmaf(uT, h.di[a], zdi);
+    const d3_f2 uRT = RT * h.u[a];
+    wz += uRT;
+    wzd = __builtin_elementwise_fma(uRT, (d3_f2){h.di[a], h.di[a]}, wzd);
   }
+  const float w = wz.x, z = wz.y, wdi = wzd.x, zdi = wzd.y;
   if (w > 1e-12f) {
     const float wi = __builtin_amdgcn_rcpf(w);
     c6 = z * wi;
@@ -670,7 +674,7 @@ int d3_impl(const T* pos, const int* numbers, int N, const int* idx, const int* 
   MI_HIP_CHECK(hipMemsetAsync(present, 0, sizeof(int) * (size_t)hp->nz, st));
   d3_mark_species_kernel<<<mi_blocks(N, 256), 256, 0, st>>>(numbers, N, hp->nz, present);
   MI_LAUNCH_CHECK();
-  d3_compact_species_kernel<<<1, 256, 0, st>>>(present, hp->c6ab, hp->cn_ref, hp->nz, smap, sinfo, ctab, ftab, fcr);
+  d3_compact_species_kernel<<<1, 256, 0, st>>>(present, hp->c6ab, hp->cn_ref, hp->nz, smap, sinfo, ctab, ftab, fcr, hp->k3);
   MI_LAUNCH_CHECK();
   d3_pack_atoms_kernel<T><<<mi_blocks(N, 256), 256, 0, st>>>(pos, numbers, N, hp->rcov, hp->r4r2, smap, hp->nz, apos, aaux);
   MI_LAUNCH_CHECK();
