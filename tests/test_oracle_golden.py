@@ -180,3 +180,42 @@ def test_explicit_k_ewald_restatement_vs_independent_sum():
     er = O.ewald_real_space(p, qq, c, 0.5, nm, sh, mask_value=len(p))
     etot = O.ewald_reciprocal_space(p, qq, c, kv, 0.5)[0].sum() + np.asarray(er).sum()
     assert abs(etot / (len(p) / 2) * r0 + 1.7475646) < 2e-5
+
+
+# ---- committed fixtures (tests/golden/): the reference's own known answers as data, and oracle vectors for the GPU suite
+def test_oracle_reproduces_committed_reference_answers():
+    import json
+    import os
+
+    g = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "reference_known_answers.json")))
+    for name in ("HoTlPd", "SiCu"):
+        c = g["neighbor_counts"][name]
+        for rc, want in c["num_neighbors"].items():
+            _, num, _ = O.cell_list(np.array(c["positions"], np.float64), float(rc), np.array(c["cell"], np.float64), c["pbc"])
+            assert num.tolist() == want, (name, rc)
+    t = O.d3_test_tables(17)
+    fp = g["dftd3"]["functional"]
+    for name in ("Ne2", "HCl_dimer"):
+        c = g["dftd3"][name]
+        n = len(c["numbers"])
+        nm = np.array([[j for j in range(n) if j != i] for i in range(n)], np.int32)
+        e, f, cn = O.dftd3(np.array(c["positions_bohr"], np.float32), np.array(c["numbers"], np.int32), t, neighbor_matrix=nm, fill_value=n, **fp)
+        np.testing.assert_allclose(e, c["energy"], rtol=2e-6)
+        np.testing.assert_allclose(cn, c["coord_num"], rtol=2e-6)
+        np.testing.assert_allclose(f, c["forces"], rtol=5e-6, atol=1e-9)
+    for rc, m in ((5.0, 928), (6.0, 1584)):
+        assert O.estimate_max_neighbors(rc) == g["max_neighbors_rule"][str(rc)] == m
+
+
+def test_oracle_vectors_are_current():
+    """tests/golden/oracle_vectors.npz is what the oracle produces today (regenerate with tests/golden/make_golden.py)."""
+    import os
+
+    v = np.load(os.path.join(os.path.dirname(__file__), "golden", "oracle_vectors.npz"))
+    nm, num, sh = O.cell_list(v["nl_pos"], 3.3, v["nl_cell"], [True, True, False], max_neighbors=128)
+    assert np.array_equal(O.canonical_pairs(nm, num, sh), v["nl_pairs"]) and np.array_equal(num, v["nl_num"])
+    e, f, cn, vir = O.dftd3(v["d3_pos"], v["d3_numbers"], O.d3_test_tables(17), neighbor_matrix=v["d3_nm"], neighbor_matrix_shifts=v["d3_shifts"],
+                            cell=v["d3_cell"], compute_virial=True, **FP)
+    assert np.array_equal(e, v["d3_energy"]) and np.array_equal(f, v["d3_forces"])
+    er, fr, cg = O.ewald_reciprocal_space(v["pme_pos"], v["pme_q"], v["pme_cell"], v["ewald_kvec"], 0.4)
+    np.testing.assert_allclose(er, v["ewald_energies"], rtol=1e-13, atol=1e-15)

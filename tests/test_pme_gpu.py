@@ -329,3 +329,34 @@ def test_ewald_reciprocal_space_autograd():
         qp[i] += h
         qm[i] -= h
         assert abs((loss(pos, qp) - loss(pos, qm)) / (2 * h) - tq.grad[i].item()) < 1e-7
+
+
+def test_hip_path_against_committed_oracle_vectors():
+    """HIP nlist / D3 / PME / explicit-k Ewald against tests/golden/oracle_vectors.npz (made by tests/golden/make_golden.py)."""
+    import os
+
+    from nvalchemiops.interactions.dispersion import D3Parameters, dftd3
+    from nvalchemiops.interactions.electrostatics import ewald_reciprocal_space, particle_mesh_ewald
+    from nvalchemiops.neighborlist import cell_list
+
+    v = np.load(os.path.join(os.path.dirname(__file__), "golden", "oracle_vectors.npz"))
+    nm, num, sh = cell_list(_t(v["nl_pos"]), 3.3, _t(v["nl_cell"]), torch.tensor([True, True, False], device=DEV), max_neighbors=128)
+    assert np.array_equal(num.cpu().numpy(), v["nl_num"])
+    assert np.array_equal(O.canonical_pairs(nm.cpu().numpy(), num.cpu().numpy(), sh.cpu().numpy()), v["nl_pairs"])  # bit-exact
+    t = O.d3_test_tables(17)
+    prm = D3Parameters(rcov=_t(t["rcov"]), r4r2=_t(t["r4r2"]), c6ab=_t(t["c6ab"]), cn_ref=_t(t["cn_ref"]))
+    e, f, cn, vir = dftd3(_t(v["d3_pos"]), _t(v["d3_numbers"]), 0.4, 4.0, 0.8, d3_params=prm, neighbor_matrix=_t(v["d3_nm"]),
+                          neighbor_matrix_shifts=_t(v["d3_shifts"]), cell=_t(v["d3_cell"])[None], compute_virial=True)
+    np.testing.assert_allclose(e.cpu().numpy(), v["d3_energy"], rtol=2e-6, atol=1e-6)                 # fp32 tolerances of test_d3_gpu.py
+    np.testing.assert_allclose(f.cpu().numpy(), v["d3_forces"], rtol=1e-5, atol=1e-6 + 5e-6 * np.abs(v["d3_forces"]).max())
+    np.testing.assert_allclose(cn.cpu().numpy(), v["d3_cn"], rtol=5e-6, atol=1e-6)
+    np.testing.assert_allclose(vir.cpu().numpy(), v["d3_virial"], rtol=1e-5, atol=2e-6 + 1e-5 * np.abs(v["d3_virial"]).max())
+    ep, fp = particle_mesh_ewald(_t(v["pme_pos"]), _t(v["pme_q"]), _t(v["pme_cell"]), alpha=0.4, mesh_dimensions=(24, 24, 24), spline_order=4,
+                                 neighbor_matrix=_t(v["pme_nm"]), neighbor_matrix_shifts=_t(v["pme_shifts"]), compute_forces=True)
+    _close(ep, v["pme_energies"], np.float64, "pme energies")
+    _close(fp, v["pme_forces"], np.float64, "pme forces")
+    er, fr, cg = ewald_reciprocal_space(_t(v["pme_pos"]), _t(v["pme_q"]), _t(v["pme_cell"]), _t(v["ewald_kvec"]),
+                                        torch.tensor([0.4], dtype=torch.float64, device=DEV), compute_forces=True, compute_charge_gradients=True)
+    _close(er, v["ewald_energies"], np.float64, "ewald energies")
+    _close(fr, v["ewald_forces"], np.float64, "ewald forces")
+    _close(cg, v["ewald_cgrad"], np.float64, "ewald charge gradients")
