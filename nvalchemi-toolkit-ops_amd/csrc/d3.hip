@@ -125,18 +125,34 @@ __device__ __forceinline__ void d3_row(int i, int M, const int* __restrict__ npt
   else { beg = (long long)i * M; end = beg + M; }
 }
 
+// Lock-step row walks (cn, chain): the D3_LS_WAVES waves of a block own consecutive atoms, whose rows list nearly the same
+// neighbours in nearly the same order.  One barrier per trip keeps them within a trip of each other, so the cache lines one
+// wave's gather brings into the CU's L1 serve the others (probe on the 40-Bohr list: 0.95 -> 0.80 ms for the cn walk; the
+// gather, not the list stream, is what bounds these passes -- DESIGN.md 3.2).  All waves run the block's maximum trip count.
+#define D3_LS_WAVES 8
+__device__ __forceinline__ int d3_lockstep_trips(long long beg, long long end) {
+  __shared__ int trips_sh[D3_LS_WAVES];
+  const int w = threadIdx.x / MI_WAVE;
+  if ((threadIdx.x & (MI_WAVE - 1)) == 0) trips_sh[w] = (int)((end - beg + MI_WAVE - 1) / MI_WAVE);
+  __syncthreads();
+  int t = 0;
+#pragma unroll
+  for (int k = 0; k < D3_LS_WAVES; ++k) t = max(t, trips_sh[k]);
+  return t;
+}
+
 // ---- pass 1: coordination numbers ------------------------------------------------------------------
 template <class T, bool CSR>
-__global__ __launch_bounds__(256) void d3_cn_kernel(const T* __restrict__ pos, const int* __restrict__ numbers, int N, const int* __restrict__ idx,
+__global__ __launch_bounds__(D3_LS_WAVES * MI_WAVE) void d3_cn_kernel(const T* __restrict__ pos, const int* __restrict__ numbers, int N, const int* __restrict__ idx,
                                                     const int* __restrict__ ush, const int* __restrict__ nptr, int M, int fill_value,
                                                     const T* __restrict__ cell, const int* __restrict__ batch_idx, D3Dev P,
                                                     const typename Vec4<T>::type* __restrict__ apos, float4* __restrict__ aaux,
                                                     float* __restrict__ cn) {
   const int lane = threadIdx.x & (MI_WAVE - 1);
-  const int i = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x / MI_WAVE) + threadIdx.x / MI_WAVE);
-  if (i >= N) return;
+  const int i0 = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x / MI_WAVE) + threadIdx.x / MI_WAVE);
+  const int i = i0 < N ? i0 : N - 1;
   const int zi = numbers[i];
-  if (zi == 0) return;
+  const bool live = i0 < N && zi != 0;  // idle waves still take part in the block's lock-step barriers
   const bool periodic = (cell != nullptr) && (ush != nullptr);
   T cm[9];
   if (periodic) { const T* c = cell + 9 * (size_t)(batch_idx ? batch_idx[i] : 0); for (int k = 0; k < 9; ++k) cm[k] = c[k]; }
@@ -144,6 +160,8 @@ __global__ __launch_bounds__(256) void d3_cn_kernel(const T* __restrict__ pos, c
   const float rci = P.rcov[zi];
   long long beg, end;
   d3_row<T, CSR>(i, M, nptr, beg, end);
+  if (!live) end = beg;
+  const int trips = d3_lockstep_trips(beg, end);
   // the reference sums in fp32 sequentially (dftd3.py:911); lanes hold fp64 partials here so the result is the
   // correctly rounded sum whatever the lane/iteration order
   double acc = 0.0;
@@ -152,7 +170,8 @@ __global__ __launch_bounds__(256) void d3_cn_kernel(const T* __restrict__ pos, c
   D3Step s0 = d3_fetch(idx, ush3, e, end, periodic), s1 = d3_fetch(idx, ush3, e + MI_WAVE, end, periodic);
   bool v0 = s0.in && (CSR || s0.j < fill_value);
   auto p0 = apos[v0 ? s0.j : i];
-  for (long long base = beg; base < end; base += MI_WAVE) {
+  for (int trip = 0; trip < trips; ++trip) {
+    __syncthreads();  // lock-step: the block's waves walk rows of consecutive atoms, i.e. nearly the same neighbours in nearly the same order
     e += MI_WAVE;
     const D3Step s2 = d3_fetch(idx, ush3, e + MI_WAVE, end, periodic);
     const bool v1 = s1.in && (CSR || s1.j < fill_value);
@@ -167,7 +186,7 @@ __global__ __launch_bounds__(256) void d3_cn_kernel(const T* __restrict__ pos, c
     s0 = s1; v0 = v1; p0 = p1; s1 = s2;
   }
   acc = wave_sum(acc);
-  if (lane == 0) { cn[i] = (float)acc; aaux[i].x = (float)acc; }
+  if (lane == 0 && live) { cn[i] = (float)acc; aaux[i].x = (float)acc; }
 }
 
 // `_s5_switch` (dftd3.py:341-423)
@@ -505,16 +524,16 @@ __global__ __launch_bounds__(256) void d3_energy_kernel(const T* __restrict__ po
 
 // ---- pass 3: chain-rule force through the coordination numbers ---------------------------------------
 template <class T, bool CSR>
-__global__ __launch_bounds__(256) void d3_chain_kernel(const T* __restrict__ pos, const int* __restrict__ numbers, int N, const int* __restrict__ idx,
+__global__ __launch_bounds__(D3_LS_WAVES * MI_WAVE) void d3_chain_kernel(const T* __restrict__ pos, const int* __restrict__ numbers, int N, const int* __restrict__ idx,
                                                        const int* __restrict__ ush, const int* __restrict__ nptr, int M, int fill_value,
                                                        const T* __restrict__ cell, const int* __restrict__ batch_idx, D3Dev P,
                                                        const typename Vec4<T>::type* __restrict__ apos, const float* __restrict__ dEdCN,
                                                        int want_virial, float* __restrict__ forces, float* __restrict__ v_atom) {
   const int lane = threadIdx.x & (MI_WAVE - 1);
-  const int i = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x / MI_WAVE) + threadIdx.x / MI_WAVE);
-  if (i >= N) return;
+  const int i0 = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x / MI_WAVE) + threadIdx.x / MI_WAVE);
+  const int i = i0 < N ? i0 : N - 1;
   const int zi = numbers[i];
-  if (zi == 0) return;
+  const bool live = i0 < N && zi != 0;  // idle waves still take part in the block's lock-step barriers
   const bool periodic = (cell != nullptr) && (ush != nullptr);
   T cm[9];
   if (periodic) { const T* c = cell + 9 * (size_t)(batch_idx ? batch_idx[i] : 0); for (int k = 0; k < 9; ++k) cm[k] = c[k]; }
@@ -522,6 +541,8 @@ __global__ __launch_bounds__(256) void d3_chain_kernel(const T* __restrict__ pos
   const float rci = P.rcov[zi], di = dEdCN[i];
   long long beg, end;
   d3_row<T, CSR>(i, M, nptr, beg, end);
+  if (!live) end = beg;
+  const int trips = d3_lockstep_trips(beg, end);
   double Fx = 0, Fy = 0, Fz = 0;
   double V[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
   const Int3* __restrict__ ush3 = reinterpret_cast<const Int3*>(ush);
@@ -530,7 +551,8 @@ __global__ __launch_bounds__(256) void d3_chain_kernel(const T* __restrict__ pos
   bool v0 = s0.in && (CSR || s0.j < fill_value);
   auto p0 = apos[v0 ? s0.j : i];
   float d0 = dEdCN[v0 ? s0.j : i];
-  for (long long base = beg; base < end; base += MI_WAVE) {
+  for (int trip = 0; trip < trips; ++trip) {
+    __syncthreads();  // lock-step (see d3_cn_kernel)
     e += MI_WAVE;
     const D3Step s2 = d3_fetch(idx, ush3, e + MI_WAVE, end, periodic);
     const bool v1 = s1.in && (CSR || s1.j < fill_value);
@@ -558,12 +580,12 @@ __global__ __launch_bounds__(256) void d3_chain_kernel(const T* __restrict__ pos
 #pragma unroll
     for (int k = 0; k < 9; ++k) V[k] = wave_sum(V[k]);
   }
-  if (lane == 0) {
+  if (lane == 0 && live) {
     forces[3 * (size_t)i] = forces[3 * (size_t)i] + (float)Fx;
     forces[3 * (size_t)i + 1] = forces[3 * (size_t)i + 1] + (float)Fy;
     forces[3 * (size_t)i + 2] = forces[3 * (size_t)i + 2] + (float)Fz;
   }
-  if (want_virial && lane < 9) {
+  if (want_virial && lane < 9 && live) {
     double v = V[0];
 #pragma unroll
     for (int k = 1; k < 9; ++k) v = lane == k ? V[k] : v;
@@ -679,7 +701,7 @@ int d3_impl(const T* pos, const int* numbers, int N, const int* idx, const int* 
   d3_pack_atoms_kernel<T><<<mi_blocks(N, 256), 256, 0, st>>>(pos, numbers, N, hp->rcov, hp->r4r2, smap, hp->nz, apos, aaux);
   MI_LAUNCH_CHECK();
   const int blocks = mi_blocks(N, 4);
-  MI_TIMED("d3_cn", st, (d3_cn_kernel<T, CSR><<<blocks, 256, 0, st>>>(pos, numbers, N, idx, ush, nptr, M, fill_value, cell, batch_idx, P, apos, aaux, cn)));
+  MI_TIMED("d3_cn", st, (d3_cn_kernel<T, CSR><<<mi_blocks(N, D3_LS_WAVES), D3_LS_WAVES * MI_WAVE, 0, st>>>(pos, numbers, N, idx, ush, nptr, M, fill_value, cell, batch_idx, P, apos, aaux, cn)));
   MI_LAUNCH_CHECK();
 #define MI_D3_ENERGY(MODE_)                                                                                                                    \
   d3_energy_kernel<T, CSR, MODE_><<<blocks, 256, 0, st>>>(pos, numbers, N, idx, ush, nptr, M, fill_value, cell, batch_idx, P, cn, want_virial, \
@@ -689,7 +711,7 @@ int d3_impl(const T* pos, const int* numbers, int N, const int* idx, const int* 
   MI_D3_ENERGY(0);
   MI_LAUNCH_CHECK();
 #undef MI_D3_ENERGY
-  MI_TIMED("d3_chain", st, (d3_chain_kernel<T, CSR><<<blocks, 256, 0, st>>>(pos, numbers, N, idx, ush, nptr, M, fill_value, cell, batch_idx, P, apos, dEdCN,
+  MI_TIMED("d3_chain", st, (d3_chain_kernel<T, CSR><<<mi_blocks(N, D3_LS_WAVES), D3_LS_WAVES * MI_WAVE, 0, st>>>(pos, numbers, N, idx, ush, nptr, M, fill_value, cell, batch_idx, P, apos, dEdCN,
                                                                             want_virial, forces, v_atom)));
   MI_LAUNCH_CHECK();
   d3_reduce_kernel<<<D3_REDUCE_WAVES / 4, 256, 0, st>>>(e_atom, v_atom, batch_idx, N, want_virial, energy, virial);

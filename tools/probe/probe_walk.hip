@@ -77,6 +77,64 @@ __global__ __launch_bounds__(256) void gath(const int* __restrict__ idx, const I
   acc = wsum(acc);
   if (lane == 0) out[i] = acc;
 }
+// variant 40: the cn walk with the four waves of a block kept in lock-step (one barrier per trip, common trip count)
+__global__ __launch_bounds__(256) void walk_lockstep(const int* __restrict__ idx, const Int3* __restrict__ sh, const int* __restrict__ nptr,
+                                                     const float4* __restrict__ apos, int N, float* __restrict__ out) {
+  __shared__ int trips[4];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int i0 = blockIdx.x * 4 + w;
+  const int i = i0 < N ? i0 : N - 1;
+  const long long beg = nptr[i], end = i0 < N ? nptr[i + 1] : beg;
+  if (lane == 0) trips[w] = (int)((end - beg + 63) / 64);
+  __syncthreads();
+  const int T = max(max(trips[0], trips[1]), max(trips[2], trips[3]));
+  const float4 pi = apos[i];
+  float acc = 0.f;
+  long long e = beg + lane;
+  for (int t = 0; t < T; ++t, e += 64) {
+    if (e < end) {
+      const int j = idx[e];
+      const Int3 s = sh[e];
+      const float4 pj = apos[j];
+      const float dx = pj.x - pi.x + 40.f * s.x, dy = pj.y - pi.y + 40.f * s.y, dz = pj.z - pi.z + 40.f * s.z;
+      const float r2 = dx * dx + dy * dy + dz * dz; const float rinv = rsqrtf(r2);
+      acc += 1.0f / (1.0f + __expf(-16.0f * ((pi.w + pj.w) * rinv - 1.0f)));
+    }
+    __syncthreads();
+  }
+  acc = wsum(acc);
+  if (lane == 0 && i0 < N) out[i0] = acc;
+}
+// variants 41/42: W waves per block the cn walk with the four waves of a block kept in lock-step (one barrier per trip, common trip count)
+template <int W>
+__global__ __launch_bounds__(W * 64) void walk_lockstep_w(const int* __restrict__ idx, const Int3* __restrict__ sh, const int* __restrict__ nptr,
+                                                     const float4* __restrict__ apos, int N, float* __restrict__ out) {
+  __shared__ int trips[W];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int i0 = blockIdx.x * W + w;
+  const int i = i0 < N ? i0 : N - 1;
+  const long long beg = nptr[i], end = i0 < N ? nptr[i + 1] : beg;
+  if (lane == 0) trips[w] = (int)((end - beg + 63) / 64);
+  __syncthreads();
+  int T = 0;
+  for (int k = 0; k < W; ++k) T = max(T, trips[k]);
+  const float4 pi = apos[i];
+  float acc = 0.f;
+  long long e = beg + lane;
+  for (int t = 0; t < T; ++t, e += 64) {
+    if (e < end) {
+      const int j = idx[e];
+      const Int3 s = sh[e];
+      const float4 pj = apos[j];
+      const float dx = pj.x - pi.x + 40.f * s.x, dy = pj.y - pi.y + 40.f * s.y, dz = pj.z - pi.z + 40.f * s.z;
+      const float r2 = dx * dx + dy * dy + dz * dz; const float rinv = rsqrtf(r2);
+      acc += 1.0f / (1.0f + __expf(-16.0f * ((pi.w + pj.w) * rinv - 1.0f)));
+    }
+    __syncthreads();
+  }
+  acc = wsum(acc);
+  if (lane == 0 && i0 < N) out[i0] = acc;
+}
 // variant 20: flat streaming of the arrays (no rows): upper bound for idx+shift streaming
 __global__ __launch_bounds__(256) void flat(const int* __restrict__ idx, const Int3* __restrict__ sh, long long P, float* __restrict__ out) {
   float acc = 0.f;
@@ -98,6 +156,9 @@ extern "C" int probe_walk(int variant, const int* idx, const int* sh, const int*
     case 32: gath<32><<<blocks, 256, 0, st>>>(idx, s3, nptr, ap, N, out); break;
     case 34: gath<34><<<blocks, 256, 0, st>>>(idx, s3, nptr, ap, N, out); break;
     case 33: gath<33><<<blocks, 256, 0, st>>>(idx, s3, nptr, ap, N, out); break;
+    case 40: walk_lockstep<<<blocks, 256, 0, st>>>(idx, s3, nptr, ap, N, out); break;
+    case 41: walk_lockstep_w<8><<<(N + 7) / 8, 512, 0, st>>>(idx, s3, nptr, ap, N, out); break;
+    case 42: walk_lockstep_w<16><<<(N + 15) / 16, 1024, 0, st>>>(idx, s3, nptr, ap, N, out); break;
     case 10: walk_u2<<<blocks, 256, 0, st>>>(idx, s3, nptr, ap, N, out); break;
     case 20: flat<<<256 * 16, 256, 0, st>>>(idx, s3, P, out); break;
     default: return 1;

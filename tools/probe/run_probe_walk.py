@@ -20,7 +20,7 @@ print("pairs", P, "bytes/pass %.2f GB" % (16 * P / 1e9))
 row = idx[nptr[50000]:nptr[50001]].cpu().numpy()
 d = np.diff(row)
 print("row len", len(row), "frac consecutive (+1):", float((d == 1).mean()), "mean run:", len(row) / max(1, int((d != 1).sum()) + 1))
-for v in [1, 30, 31, 32, 33, 3]:
+for v in [3, 40, 41, 42]:
     def run():
         rc = lib.probe_walk(v, ctypes.c_void_p(idx.data_ptr()), ctypes.c_void_p(sh.data_ptr()), ctypes.c_void_p(nptr.data_ptr()),
                             ctypes.c_void_p(apos.data_ptr()), n, ctypes.c_longlong(P), ctypes.c_void_p(out.data_ptr()), st)
