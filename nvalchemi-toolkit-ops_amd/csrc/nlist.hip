@@ -128,7 +128,7 @@ __global__ void nl_setup_kernel(const T* __restrict__ cell, const uint8_t* __res
       T ln = sqrt(col[0] * col[0] + col[1] * col[1] + col[2] * col[2]);
       face[d] = 1.0 / (double)ln;
       S.pbc[d] = pbc[3 * (size_t)s + d] ? 1 : 0;
-      double want = face[d] * k / rc;
+      double want = face[d] * k / (rc * (1.0 + 2e-6));  // cell edge strictly above rc/k: a box that is an exact multiple of rc/k must not round the search radius up to k+1
       S.cpd[d] = want >= 1048576.0 ? 1048576 : (want >= 1.0 ? (int)want : 1);
       S.nrange[d] = S.pbc[d] ? (int)ceil(ln * cutoff) : 0;
     }

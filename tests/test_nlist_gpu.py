@@ -305,3 +305,15 @@ def test_custom_ops_and_graph_capture():
     e2, f2, cn2 = dftd3(tp, z, 0.4, 4.0, 0.8, d3_params=prm, neighbor_matrix=rm, neighbor_matrix_shifts=rsh, cell=tc[None], fill_value=400)
     # per-system energy: float atomics over slabs (order-dependent last bit); per-atom outputs are deterministic
     assert torch.allclose(e, e2, rtol=1e-6) and torch.equal(f, f2) and torch.equal(cn, cn2)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_box_exact_multiple_of_cutoff(dtype):
+    """Box edge = integer multiple of the cutoff (cell edge == rc is the tightest legal binning): same pair set as the oracle."""
+    from nvalchemiops.neighborlist import cell_list
+
+    pos, cell = S.random_box(600, 20.0, seed=13, dtype=dtype)
+    nm, num, sh = cell_list(_t(pos), 5.0, _t(cell), torch.tensor([True] * 3, device=DEV), max_neighbors=96)
+    onm, onum, osh = O.cell_list(pos, 5.0, cell, [True] * 3, max_neighbors=96)
+    assert int(num.max()) < 96 and np.array_equal(num.cpu().numpy(), onum)
+    assert np.array_equal(O.canonical_pairs(nm.cpu().numpy(), num.cpu().numpy(), sh.cpu().numpy()), O.canonical_pairs(onm, onum, osh))
