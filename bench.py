@@ -320,6 +320,8 @@ def main():
     if os.environ.get("BENCH_SHARE_DEVICE") == "1":
         local_rank = 0
     torch.cuda.set_device(local_rank)
+    if os.environ.get("BENCH_MAIN_PRIORITY"):  # tuning aid: run the main (dispersion) branch on a prioritised HIP stream
+        torch.cuda.set_stream(torch.cuda.Stream(priority=int(os.environ["BENCH_MAIN_PRIORITY"])))
     device = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")

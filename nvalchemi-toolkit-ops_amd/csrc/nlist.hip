@@ -143,7 +143,7 @@ __global__ void nl_setup_kernel(const T* __restrict__ cell, const uint8_t* __res
     }
     S.ncells = (int)tot;
     S.cell_off = 0;
-    S.tiled = (k >= 2 && (2 * S.R[1] + 1) * (2 * S.R[2] + 1) <= NL_MAXROWS && (!S.pbc[0] || S.R[0] <= S.cpd[0])) ? 1 : 0;
+    S.tiled = ((k >= 2 || apc >= 32.0) && (2 * S.R[1] + 1) * (2 * S.R[2] + 1) <= NL_MAXROWS && (!S.pbc[0] || S.R[0] <= S.cpd[0])) ? 1 : 0;
     // Orthorhombic cells: atoms in cells offset by d cells along a periodic axis are at least (|d|-1) cell edges apart along it,
     // so cells/rows provably beyond the cutoff are never visited.  Non-periodic axes contribute 0 (clamped atoms may sit
     // outside their cell).  Evaluated once here; the query kernel only does integer look-ups.

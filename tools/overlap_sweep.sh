@@ -1,6 +1,6 @@
 #!/bin/bash
-# tuning aid: step time for the overlap schedules of bench.py
-for o in 1 2; do for pr in 0 -1; do
-  echo -n "overlap $o side-priority $pr: "
-  BENCH_SIDE_PRIORITY=$pr python bench.py --steps 20 --warmup 3 --cpu-sample 0 --overlap $o 2>/dev/null | tail -1 | python -c "import sys,json; print(json.loads(sys.stdin.read())['ms_per_step'])"
+# tuning aid: step time for the overlap schedules / stream priorities of bench.py
+for o in 1 2; do for mp in "" -1; do
+  echo -n "overlap $o main-priority '${mp}': "
+  BENCH_MAIN_PRIORITY=$mp python bench.py --steps 20 --warmup 3 --cpu-sample 0 --overlap $o 2>/dev/null | tail -1 | python -c "import sys,json; print(json.loads(sys.stdin.read())['ms_per_step'])"
 done; done
