@@ -100,6 +100,12 @@ int mi_nl_estimate_sizes(const void* cell, const uint8_t* pbc, int n_systems, do
                          int dtype, int32_t* number_of_cells /*[n_systems]*/,
                          int32_t* neighbor_search_radius /*[n_systems,3]*/, void* stream);
 
+/* Bounding boxes of non-periodic systems: cell_out[s] = diag(max(hi - lo, 1) * 1.001), origin_out[s] = lo, the binning frame a
+ * free-space search uses when the caller gives no cell (reference: `neighbor_list` fabricates a unit cell, neighborlist.py:220-226;
+ * SURVEY Appendix B.2).  `scratch`: 6 * n_systems 8-byte words.  batch_idx NULL = one system.                               */
+int mi_nl_bounding_cells(const void* positions, const int32_t* batch_idx, int n_atoms, int n_systems, int dtype, void* cell_out,
+                         void* origin_out, void* scratch, void* stream);
+
 /* Rebuild detection for MD loops (neighborlist/rebuild_detection.py:37-170): `flag` (one byte, zeroed by the caller)
  * is set when any atom's cell (reference binning of mi_nl_build_cell_cache) differs from atom_to_cell_mapping, resp. when any atom
  * moved farther than `threshold` from its reference position.                                                                    */

@@ -844,6 +844,52 @@ __global__ void nl_cache_starts_kernel(const int* __restrict__ keys_sorted, int 
   counts[c] = b - a;
 }
 
+// ---- bounding boxes of non-periodic systems: the "cell" a free-space search bins in (no lattice is given) ---------------------
+// order-preserving unsigned keys so min / max run on integer atomics
+__device__ __forceinline__ unsigned long long nl_key(double v) {
+  const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+  return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+__device__ __forceinline__ double nl_unkey(unsigned long long k) {
+  const unsigned long long b = (k >> 63) ? (k & 0x7fffffffffffffffull) : ~k;
+  return __longlong_as_double((long long)b);
+}
+template <class T>
+__global__ void nl_bbox_kernel(const T* __restrict__ pos, const int* __restrict__ batch_idx, int N, unsigned long long* __restrict__ box /*[B][6]*/) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool in = i < N;
+  const int s = in ? (batch_idx ? batch_idx[i] : 0) : -1;
+  double v[3] = {0, 0, 0};
+  if (in) { v[0] = pos[3 * (size_t)i]; v[1] = pos[3 * (size_t)i + 1]; v[2] = pos[3 * (size_t)i + 2]; }
+  const int s0 = __shfl(s, 0, MI_WAVE);
+  if (__all(!in || s == s0) && s0 >= 0) {  // the usual case: a wave lies inside one system -> one atomic pair per axis per wave
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      double lo = in ? v[d] : INFINITY, hi = in ? v[d] : -INFINITY;
+      for (int o = MI_WAVE / 2; o; o >>= 1) { lo = fmin(lo, __shfl_xor(lo, o, MI_WAVE)); hi = fmax(hi, __shfl_xor(hi, o, MI_WAVE)); }
+      if ((threadIdx.x & (MI_WAVE - 1)) == 0) { atomicMin(&box[6 * (size_t)s0 + d], nl_key(lo)); atomicMax(&box[6 * (size_t)s0 + 3 + d], nl_key(hi)); }
+    }
+  } else if (in) {
+#pragma unroll
+    for (int d = 0; d < 3; ++d) { atomicMin(&box[6 * (size_t)s + d], nl_key(v[d])); atomicMax(&box[6 * (size_t)s + 3 + d], nl_key(v[d])); }
+  }
+}
+// cell = diag(max(hi - lo, 1) * 1.001), origin = lo (an empty system keeps a unit box at the origin)
+template <class T>
+__global__ void nl_bbox_finish_kernel(const unsigned long long* __restrict__ box, int B, T* __restrict__ cell, T* __restrict__ origin) {
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= B) return;
+  for (int k = 0; k < 9; ++k) cell[9 * (size_t)s + k] = T(0);
+  for (int d = 0; d < 3; ++d) {
+    const unsigned long long klo = box[6 * (size_t)s + d], khi = box[6 * (size_t)s + 3 + d];
+    const bool empty = klo == ~0ull;
+    const double lo = empty ? 0.0 : nl_unkey(klo), hi = empty ? 0.0 : nl_unkey(khi);
+    const T span = (T)lo == (T)lo ? (T)(hi - lo) : T(0);
+    cell[9 * (size_t)s + 4 * d] = (span > T(1) ? span : T(1)) * (T)1.001;
+    origin[3 * (size_t)s + d] = (T)lo;
+  }
+}
+
 // ---- rebuild detection (neighborlist/rebuild_detection.py:37-170): one flag, set when any atom left its cell / moved past the skin
 template <class T>
 __global__ void nl_cells_changed_kernel(const T* __restrict__ pos, const T* __restrict__ cell, const int* __restrict__ atom_cell,
@@ -1000,6 +1046,28 @@ int mi_nl_matrix_to_coo(const int32_t* neighbor_matrix, const int32_t* neighbor_
   nl_matrix_to_coo_kernel<<<mi_blocks(n_atoms, 4), 256, 0, (hipStream_t)stream>>>(neighbor_matrix, neighbor_matrix_shifts, neighbor_ptr, n_atoms,
                                                                                   max_neighbors, fill_value, list_ij,
                                                                                   neighbor_matrix_shifts ? list_shifts : nullptr, n_pairs);
+  MI_LAUNCH_CHECK();
+  return MI_OK;
+}
+
+int mi_nl_bounding_cells(const void* positions, const int32_t* batch_idx, int n_atoms, int n_systems, int dtype, void* cell_out,
+                         void* origin_out, void* scratch, void* stream) {
+  MI_REQUIRE(dtype == MI_F32 || dtype == MI_F64, "dtype");
+  MI_REQUIRE(n_systems >= 1 && cell_out && origin_out && scratch, "null pointer");
+  MI_REQUIRE(n_atoms == 0 || positions, "positions");
+  hipStream_t st = (hipStream_t)stream;
+  unsigned long long* box = (unsigned long long*)scratch;
+  // min keys start at all-ones, max keys at zero: one memset of 0xff over the rows, one of 0 over the max halves is avoided by
+  // storing {lo x3 | hi x3} and initialising with two strided fills in the kernel-free way below
+  MI_HIP_CHECK(hipMemsetAsync(box, 0xff, sizeof(unsigned long long) * 6 * (size_t)n_systems, st));
+  MI_HIP_CHECK(hipMemset2DAsync(box + 3, sizeof(unsigned long long) * 6, 0, sizeof(unsigned long long) * 3, (size_t)n_systems, st));
+  if (n_atoms > 0) {
+    if (dtype == MI_F32) nl_bbox_kernel<float><<<mi_blocks(n_atoms, 256), 256, 0, st>>>((const float*)positions, batch_idx, n_atoms, box);
+    else nl_bbox_kernel<double><<<mi_blocks(n_atoms, 256), 256, 0, st>>>((const double*)positions, batch_idx, n_atoms, box);
+    MI_LAUNCH_CHECK();
+  }
+  if (dtype == MI_F32) nl_bbox_finish_kernel<float><<<mi_blocks(n_systems, 256), 256, 0, st>>>(box, n_systems, (float*)cell_out, (float*)origin_out);
+  else nl_bbox_finish_kernel<double><<<mi_blocks(n_systems, 256), 256, 0, st>>>(box, n_systems, (double*)cell_out, (double*)origin_out);
   MI_LAUNCH_CHECK();
   return MI_OK;
 }

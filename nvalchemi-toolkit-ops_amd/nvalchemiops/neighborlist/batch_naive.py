@@ -53,7 +53,6 @@ def batch_naive_neighbor_list(positions: torch.Tensor, cutoff: float, batch_idx:
             pos = positions.detach().contiguous()
             n_sys = batch_ptr.shape[0] - 1
             c, origin = _bounding_cell(pos, bi, n_sys)
-            c, origin = c.to(pos.dtype).contiguous(), origin.contiguous()
             p = torch.zeros((n_sys, 3), dtype=torch.bool, device=dev)
         E.neighbor_matrix(pos, c, p, bi, cutoff, m, fill_value, half_fill, neighbor_matrix, neighbor_matrix_shifts if periodic else None,
                           num_neighbors, naive=True, want_shifts=periodic, origin=origin)

@@ -15,17 +15,16 @@ from nvalchemiops.neighborlist.neighbor_utils import estimate_max_neighbors, get
 
 
 def _bounding_cell(pos: torch.Tensor, batch_idx=None, n_sys: int = 1):
-    """Non-periodic input has no cell: bin inside the axis-aligned bounding box (pbc = F,F,F; shifts stay zero)."""
-    if batch_idx is None:
-        lo, hi = pos.min(dim=0).values, pos.max(dim=0).values
-        span = (hi - lo).clamp_min(1.0) * 1.001
-        return torch.diag(span).unsqueeze(0), lo.unsqueeze(0)
-    idx = batch_idx.long().unsqueeze(1).expand(-1, 3)
-    big = torch.finfo(pos.dtype).max
-    lo = torch.full((n_sys, 3), big, dtype=pos.dtype, device=pos.device).scatter_reduce(0, idx, pos, "amin")
-    hi = torch.full((n_sys, 3), -big, dtype=pos.dtype, device=pos.device).scatter_reduce(0, idx, pos, "amax")
-    span = (hi - lo).clamp_min(1.0) * 1.001
-    return torch.diag_embed(span), lo
+    """Non-periodic input has no cell: bin inside the per-system axis-aligned bounding box (pbc = F,F,F; shifts stay zero).
+    One small HIP kernel pair (`mi_nl_bounding_cells`), no host sync.  Returns (cell[B,3,3], origin[B,3]) in the positions dtype."""
+    dev = pos.device
+    cell = torch.empty((n_sys, 3, 3), dtype=pos.dtype, device=dev)
+    origin = torch.empty((n_sys, 3), dtype=pos.dtype, device=dev)
+    scratch = torch.empty(6 * n_sys, dtype=torch.int64, device=dev)
+    rc = C.lib().mi_nl_bounding_cells(C.ptr(pos), C.ptr(batch_idx), pos.shape[0], n_sys, C.dtype_code(pos.dtype), C.ptr(cell), C.ptr(origin),
+                                      C.ptr(scratch), C.stream_of(pos))
+    C.check(rc, "mi_nl_bounding_cells")
+    return cell, origin
 
 
 def naive_neighbor_list(positions: torch.Tensor, cutoff: float, cell: torch.Tensor | None = None, pbc: torch.Tensor | None = None,
@@ -68,7 +67,6 @@ def naive_neighbor_list(positions: torch.Tensor, cutoff: float, cell: torch.Tens
         pos = positions.detach().contiguous()
         c, origin = _bounding_cell(pos)  # origin shifts the BINNING only; distances use the caller's coordinates
         p = torch.zeros((1, 3), dtype=torch.bool, device=dev)
-        c, origin = c.to(pos.dtype).contiguous(), origin.contiguous()
     if neighbor_matrix is None:
         neighbor_matrix = torch.empty((n, max_neighbors), **i32)
     m = neighbor_matrix.shape[1]

@@ -25,7 +25,7 @@ from nvalchemiops.neighborlist.neighbor_utils import (_prepare_batch_idx_ptr, es
                                                       get_neighbor_list_from_neighbor_matrix)
 
 
-def _free_space_cell_list(positions, cutoff, batch_idx, half_fill, fill_value, return_neighbor_list, kwargs):
+def _free_space_cell_list(positions, cutoff, batch_idx, half_fill, fill_value, return_neighbor_list, kwargs, n_systems=None):
     """Cell-list search of non-periodic input without a cell: bounding-box binning, shifts are identically zero."""
     n = positions.shape[0]
     if fill_value is None:
@@ -34,10 +34,10 @@ def _free_space_cell_list(positions, cutoff, batch_idx, half_fill, fill_value, r
         return _empty_result(n, fill_value, return_neighbor_list, positions.device)
     C.require_device(positions, batch_idx)
     pos = positions.detach().contiguous()
-    n_sys = 1 if batch_idx is None else int(batch_idx.max().item()) + 1
+    # the dispatcher already derived batch_ptr: its length gives the system count without another host sync
+    n_sys = 1 if batch_idx is None else (n_systems if n_systems is not None else int(batch_idx.max().item()) + 1)
     bi = None if batch_idx is None else C.i32(batch_idx)
     cellb, origin = _bounding_cell(pos, bi, n_sys)
-    cellb, origin = cellb.to(pos.dtype).contiguous(), origin.contiguous()
     pbc = torch.zeros((n_sys, 3), dtype=torch.bool, device=pos.device)
     max_neighbors = kwargs.get("max_neighbors")
     nm, nsh, num = kwargs.get("neighbor_matrix"), kwargs.get("neighbor_matrix_shifts"), kwargs.get("num_neighbors")
@@ -80,8 +80,9 @@ def neighbor_list(positions: torch.Tensor, cutoff: float, cell: torch.Tensor | N
             method = "batch_" + method
             batch_idx, batch_ptr = _prepare_batch_idx_ptr(batch_idx, batch_ptr, total_atoms, positions.device)
     if method in ("cell_list", "batch_cell_list") and free_space:
-        return _free_space_cell_list(positions, cutoff, batch_idx if method.startswith("batch_") else None, half_fill, fill_value,
-                                     return_neighbor_list, kwargs)
+        batched = method.startswith("batch_")
+        return _free_space_cell_list(positions, cutoff, batch_idx if batched else None, half_fill, fill_value, return_neighbor_list, kwargs,
+                                     n_systems=(batch_ptr.shape[0] - 1) if batched and batch_ptr is not None else None)
     if method == "naive":
         return naive_neighbor_list(positions, cutoff, pbc=pbc, cell=cell, half_fill=half_fill, fill_value=fill_value,
                                    return_neighbor_list=return_neighbor_list, **kwargs)
