@@ -8,7 +8,9 @@ on a 100k-atom periodic box, one process per MI355X.
 One "step" (BASELINE.json metric; BASELINE.md headline row) on synthetic data already resident in HBM:
   1. neighbor_list  rc = 9 A, padded matrix (M = 256), fp64 positions                  -> real-space PME list
   2. particle_mesh_ewald  alpha = 0.35 /A, mesh 128^3, B-spline order 5, E + F, fp64   (real + reciprocal)
-  3. neighbor_list  rc = 40 Bohr (21.2 A), direct CSR/COO output, fp32 positions        -> D3 list (~2.4k pairs/atom)
+  3. neighbor_list  rc = 40 Bohr (21.2 A), fp32 positions -> D3 list (~2.4k pairs/atom): padded matrix with an explicit row
+     width M = 2560 (--d3-format matrix, default: the format and the explicit `max_neighbors` the reference's own D3 benchmark
+     uses) or exact-size COO/CSR built in two passes (--d3-format csr)
   4. dftd3(BJ)  a1=0.4289 a2=4.4407 s8=0.7875, E + F + virial, fp32
 Steps 1-2 and 3-4 are independent and are enqueued on two HIP streams (--overlap 1, default); --overlap 0 serialises them and
 reports per-stage times.
@@ -38,7 +40,8 @@ sys.path[:0] = [ROOT, os.path.join(ROOT, "nvalchemi-toolkit-ops_amd")]
 BOHR = 1.8897261246
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 PME = dict(cutoff=9.0, alpha=0.35, mesh=(128, 128, 128), order=5, max_neighbors=256)
-D3 = dict(cutoff=40.0, a1=0.4289, a2=4.4407, s8=0.7875)
+D3 = dict(cutoff=40.0, a1=0.4289, a2=4.4407, s8=0.7875, max_neighbors=2560)  # row width: explicit, as in the reference's own
+# D3 benchmark (benchmarks/interactions/dispersion/benchmark_dftd3.py:325-347 + its yaml `max_neighbors`); the fullest row of the headline box has 2497 entries
 
 
 def build_system(n_atoms: int, seed: int, device):
@@ -127,7 +130,27 @@ def make_batch_step(sysd, tables, device, world, sizes):
 
 
 VIRIAL = True
+D3_FORMAT = "matrix"  # D3 leg: padded neighbour matrix (default, the format the reference's D3 benchmark uses) or "csr" (exact-size COO/CSR)
 OVERLAP = False
+
+
+def d3_branch(sysd, params, cell_list, dftd3, n, d3_bufs, between=None):
+    """40-Bohr neighbour list + DFT-D3(BJ) with forces and virial, in the selected list format; `between()` is called after the
+    list is enqueued (stage timing).  Returns (energy, forces, per-atom counts [matrix] or neighbor_ptr [csr])."""
+    common = dict(a1=D3["a1"], a2=D3["a2"], s8=D3["s8"], d3_params=params, cell=sysd["cell32b"].unsqueeze(0), compute_virial=VIRIAL,
+                  num_systems=1)
+    if D3_FORMAT == "matrix":
+        dm, dsh, dnum = d3_bufs
+        cell_list(sysd["pos32b"], D3["cutoff"], sysd["cell32b"], sysd["pbc"], neighbor_matrix=dm, neighbor_matrix_shifts=dsh, num_neighbors=dnum)
+        if between:
+            between()
+        out = dftd3(sysd["pos32b"], sysd["numbers"], neighbor_matrix=dm, neighbor_matrix_shifts=dsh, fill_value=n, **common)
+        return out[0], out[1], dnum
+    lst, nptr, lsh = cell_list(sysd["pos32b"], D3["cutoff"], sysd["cell32b"], sysd["pbc"], return_neighbor_list=True)
+    if between:
+        between()
+    out = dftd3(sysd["pos32b"], sysd["numbers"], neighbor_list=lst, neighbor_ptr=nptr, unit_shifts=lsh, **common)
+    return out[0], out[1], nptr
 
 
 def make_step(sysd, tables, device, world):
@@ -142,6 +165,11 @@ def make_step(sysd, tables, device, world):
     nm = torch.empty((n, m), dtype=torch.int32, device=device)
     nsh = torch.empty((n, m, 3), dtype=torch.int32, device=device)
     num = torch.empty(n, dtype=torch.int32, device=device)
+    d3_bufs = None
+    if D3_FORMAT == "matrix":
+        md = D3["max_neighbors"]
+        d3_bufs = (torch.empty((n, md), dtype=torch.int32, device=device), torch.empty((n, md, 3), dtype=torch.int32, device=device),
+                   torch.empty(n, dtype=torch.int32, device=device))
     gathered = [torch.zeros(2, dtype=torch.float64, device=device) for _ in range(world)] if world > 1 else None
     stage_ms = {}
     side = torch.cuda.Stream(device=device, priority=int(os.environ.get("BENCH_SIDE_PRIORITY", "0")))
@@ -159,8 +187,6 @@ def make_step(sysd, tables, device, world):
         if OVERLAP:
             # The electrostatics branch (9 A list + PME) and the dispersion branch (40 Bohr list + D3) are independent: they are
             # enqueued on two HIP streams so the latency-bound kernels of one fill the gaps of the other; joined before the gather.
-            # OVERLAP == 1: both branches start together.  OVERLAP == 2: the dispersion list is built first (its CSR sizing is
-            # the one host sync of the step), then the PME branch is enqueued next to the D3 passes.
             main = torch.cuda.current_stream()
 
             def pme_branch():
@@ -172,14 +198,8 @@ def make_step(sysd, tables, device, world):
                                                mesh_dimensions=PME["mesh"], spline_order=PME["order"], neighbor_matrix=nm,
                                                neighbor_matrix_shifts=nsh, compute_forces=True)
 
-            if OVERLAP == 1:
-                e_pme, f_pme = pme_branch()
-            lst, nptr, lsh = cell_list(sysd["pos32b"], D3["cutoff"], sysd["cell32b"], sysd["pbc"], return_neighbor_list=True)
-            if OVERLAP != 1:
-                e_pme, f_pme = pme_branch()
-            e_d3, f_d3, cn, vir = dftd3(sysd["pos32b"], sysd["numbers"], a1=D3["a1"], a2=D3["a2"], s8=D3["s8"], d3_params=params,
-                                        neighbor_list=lst, neighbor_ptr=nptr, unit_shifts=lsh, cell=sysd["cell32b"].unsqueeze(0),
-                                        compute_virial=VIRIAL, num_systems=1)[:4] + ((None,) if not VIRIAL else ())
+            e_pme, f_pme = pme_branch()
+            e_d3, f_d3, nptr = d3_branch(sysd, params, cell_list, dftd3, n, d3_bufs)
             main.wait_stream(side)
             for t in (e_pme, f_pme):
                 t.record_stream(main)
@@ -191,11 +211,7 @@ def make_step(sysd, tables, device, world):
             e_pme, f_pme = particle_mesh_ewald(sysd["pos64"], sysd["q64"], sysd["cell64"], alpha=PME["alpha"], mesh_dimensions=PME["mesh"],
                                                spline_order=PME["order"], neighbor_matrix=nm, neighbor_matrix_shifts=nsh, compute_forces=True)
             mark("pme")
-            lst, nptr, lsh = cell_list(sysd["pos32b"], D3["cutoff"], sysd["cell32b"], sysd["pbc"], return_neighbor_list=True)
-            mark("nlist_d3")
-            e_d3, f_d3, cn, vir = dftd3(sysd["pos32b"], sysd["numbers"], a1=D3["a1"], a2=D3["a2"], s8=D3["s8"], d3_params=params,
-                                        neighbor_list=lst, neighbor_ptr=nptr, unit_shifts=lsh, cell=sysd["cell32b"].unsqueeze(0),
-                                        compute_virial=VIRIAL, num_systems=1)[:4] + ((None,) if not VIRIAL else ())
+            e_d3, f_d3, nptr = d3_branch(sysd, params, cell_list, dftd3, n, d3_bufs, lambda: mark("nlist_d3"))
             mark("d3")
         if gathered is not None:
             mine = torch.stack([e_d3[0].double(), e_pme.sum()])
@@ -237,13 +253,18 @@ def algorithmic_bytes(kernel: str, n: int, pairs_d3: int) -> float | None:
     """Algorithmic HBM bytes per launch (SURVEY.md 8d / DESIGN.md 'roofline accounting')."""
     m, mesh = PME["max_neighbors"], float(np.prod(PME["mesh"]))
     if kernel in ("d3_energy", "d3_cn", "d3_chain"):
-        return 16.0 * pairs_d3 + 40.0 * n  # idx_j + 3 shift ints per directed pair; per-atom position/Z/CN in, F/dEdCN/E out
+        # idx_j + 3 shift ints per list entry (matrix format: every slot of the padded row, which the kernel has to read to find
+        # the fill value); per-atom position/Z/CN in, F/dEdCN/E out
+        entries = float(n) * D3["max_neighbors"] if D3_FORMAT == "matrix" else float(pairs_d3)
+        return 16.0 * entries + 40.0 * n
     if kernel == "nl_query_csr":
         return n * (3 * 4 + 8) + 20.0 * pairs_d3
     if kernel == "nl_query_count":
         return n * (3 * 4 + 4.0)
-    if kernel == "nl_query_matrix":
+    if kernel == "nl_query_matrix_f64":
         return n * (3 * 8 + 4) + 16.0 * n * m
+    if kernel == "nl_query_matrix_f32":
+        return n * (3 * 4 + 4) + 16.0 * n * D3["max_neighbors"]
     if kernel == "ewald_real":
         return 16.0 * n * m + n * (3 * 8 + 8) + n * (8 + 3 * 8)
     if kernel == "spline_spread":
@@ -307,10 +328,14 @@ def main():
                          "--systems x 2000-atom boxes per GPU sharded at system granularity")
     ap.add_argument("--systems", type=int, default=128, help="systems per GPU for --workload c5")
     ap.add_argument("--no-virial", action="store_true", help="experiment switch: D3 without the virial (the headline includes it)")
-    ap.add_argument("--overlap", type=int, default=1, help="1 (default): PME and D3 branches on two HIP streams; 0: one stream, per-stage times")
+    ap.add_argument("--d3-format", default="matrix", choices=["matrix", "csr"],
+                    help="neighbour-list format of the D3 leg: padded matrix with explicit row width (default; what the reference's own D3 benchmark "
+                         "uses) or exact-size COO/CSR (two-pass build)")
+    ap.add_argument("--overlap", type=int, default=1, choices=[0, 1], help="1 (default): PME and D3 branches on two HIP streams; 0: one stream, per-stage times")
     args = ap.parse_args()
-    global VIRIAL, OVERLAP
+    global VIRIAL, OVERLAP, D3_FORMAT
     VIRIAL = not args.no_virial
+    D3_FORMAT = args.d3_format
     OVERLAP = int(args.overlap)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -363,7 +388,10 @@ def main():
     kernels = kernel_report()
 
     e_pme, f_pme, e_d3, f_d3, num, nptr = out
-    pairs_d3 = int(nptr[-1].item())
+    matrix_d3 = D3_FORMAT == "matrix" and args.workload == "headline"
+    pairs_d3 = int(nptr.sum().item()) if matrix_d3 else int(nptr[-1].item())  # matrix format: `nptr` holds num_neighbors
+    if matrix_d3 and int(nptr.max().item()) > D3["max_neighbors"]:
+        raise RuntimeError(f"D3 neighbour matrix overflow: {int(nptr.max().item())} > {D3['max_neighbors']}")
     stage_ms = {}
     for ev in records:
         for (_, a), (name, b) in zip(ev[:-1], ev[1:]):
@@ -392,11 +420,11 @@ def main():
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64 (PME) + f32 (D3)", "data": "synthetic",
             "config": {"workload": (f"{args.atoms}-atom periodic FCC box per GPU: nlist(9 A, padded M=256) + PME(alpha 0.35, mesh 128^3, "
-                                    "spline order 5, E+F, fp64) + nlist(40 Bohr, CSR) + DFT-D3(BJ, E+F+virial, fp32)")
+                                    "spline order 5, E+F, fp64) + nlist(40 Bohr, " + (f"padded M={D3['max_neighbors']}" if D3_FORMAT == "matrix" else "CSR") + ") + DFT-D3(BJ, E+F+virial, fp32)")
                        if args.workload == "headline" else
                        (f"config 5: {args.systems} x 2000-atom periodic boxes per GPU (batch): nlist(9 A) + PME(mesh 32^3 per system, order 5, "
                         "fp64) + nlist(40 Bohr, CSR) + DFT-D3(BJ), one all_gather of per-system energies"),
-                       "atoms_per_gpu": args.atoms, "d3_directed_pairs": pairs_d3, "pme_neighbors_max": int(num.max().item()),
+                       "atoms_per_gpu": args.atoms, "d3_directed_pairs": pairs_d3, "pme_neighbors_max": int(num.max().item()), "d3_neighbors_max": int((nptr if matrix_d3 else (nptr[1:] - nptr[:-1])).max().item()),
                        "parallelism": "replica per GPU + 1 RCCL all_gather of per-system energies" if world > 1 else "single GPU"},
             "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
             "kernel_ms": {k: round(v[1] / v[0], 4) for k, v in sorted(kernels.items())},

@@ -977,7 +977,7 @@ int nl_neighbors_impl(const T* pos, int N, const T* cell, const uint8_t* pbc, co
       nl_query_tiled_kernel<T, MODE_, false><<<NL_TILED_GRID, 256, 0, st>>>(spos, swrap, cell_start, sys, glob, B, rc2, flags, nm, nsh, num, \
                                                                            M, fill_value, ptr, list_ij, list_sh, P);                     \
   } while (0)
-  if (mode == MI_NL_MODE_MATRIX) MI_TIMED("nl_query_matrix", st, MI_NLQ(MI_NL_MODE_MATRIX); MI_NLT(MI_NL_MODE_MATRIX));
+  if (mode == MI_NL_MODE_MATRIX) MI_TIMED(sizeof(T) == 4 ? "nl_query_matrix_f32" : "nl_query_matrix_f64", st, MI_NLQ(MI_NL_MODE_MATRIX); MI_NLT(MI_NL_MODE_MATRIX));
   else if (mode == MI_NL_MODE_COUNT) MI_TIMED("nl_query_count", st, MI_NLQ(MI_NL_MODE_COUNT); MI_NLT(MI_NL_MODE_COUNT));
   else MI_TIMED("nl_query_csr", st, MI_NLQ(MI_NL_MODE_CSR); MI_NLT(MI_NL_MODE_CSR));
 #undef MI_NLT

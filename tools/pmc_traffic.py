@@ -22,7 +22,10 @@ def short_name(sym: str):
     if SHORT[m.group(1)] is not None:
         return SHORT[m.group(1)]
     args = [a.strip() for a in m.group(2).split(",")]
-    return MODE.get(args[1])
+    name = MODE.get(args[1])
+    if name == "nl_query_matrix":  # the two matrix lists of the step differ in dtype (PME: double, D3: float)
+        name += "_f64" if args[0] == "double" else "_f32"
+    return name
 
 
 def load(path, counter):
