@@ -198,8 +198,13 @@ def make_step(sysd, tables, device, world):
                                                mesh_dimensions=PME["mesh"], spline_order=PME["order"], neighbor_matrix=nm,
                                                neighbor_matrix_shifts=nsh, compute_forces=True)
 
-            e_pme, f_pme = pme_branch()
-            e_d3, f_d3, nptr = d3_branch(sysd, params, cell_list, dftd3, n, d3_bufs)
+            if OVERLAP == 1:
+                e_pme, f_pme = pme_branch()
+                e_d3, f_d3, nptr = d3_branch(sysd, params, cell_list, dftd3, n, d3_bufs)
+            else:  # schedule 2 (tuning aid): the PME branch is enqueued after the D3 list, next to the D3 passes only
+                box = []
+                e_d3, f_d3, nptr = d3_branch(sysd, params, cell_list, dftd3, n, d3_bufs, lambda: box.append(pme_branch()))
+                e_pme, f_pme = box[0]
             main.wait_stream(side)
             for t in (e_pme, f_pme):
                 t.record_stream(main)
@@ -331,7 +336,7 @@ def main():
     ap.add_argument("--d3-format", default="matrix", choices=["matrix", "csr"],
                     help="neighbour-list format of the D3 leg: padded matrix with explicit row width (default; what the reference's own D3 benchmark "
                          "uses) or exact-size COO/CSR (two-pass build)")
-    ap.add_argument("--overlap", type=int, default=1, choices=[0, 1], help="1 (default): PME and D3 branches on two HIP streams; 0: one stream, per-stage times")
+    ap.add_argument("--overlap", type=int, default=1, choices=[0, 1, 2], help="1 (default): PME and D3 branches on two HIP streams; 0: one stream, per-stage times; 2: tuning aid")
     args = ap.parse_args()
     global VIRIAL, OVERLAP, D3_FORMAT
     VIRIAL = not args.no_virial
