@@ -322,7 +322,7 @@ __device__ __forceinline__ void d3_c6(float cn_i, float cn_j, const float4* __re
 // Factorised `_c6ab_interpolate`: same sums, same thresholds (points with c6 == 0 never count; terms more than e^-12 below the
 // dominant one are dropped; w <= 1e-12 -> 0), with the exponent argument split as A_a(i) + B_b(j).  `Ap`, `u`, `di` are the
 // wave-uniform per-atom halves (A_a - max A, exp of it, CN_i - c_i(a)); rows whose u is 0 for the whole wave are skipped.
-struct D3Half { float Ap[5], u[5], di[5]; };
+struct D3Half { float Ap[5], u[5], di[5], vcut[5]; };  // vcut[a] = exp(-12 - A'_a): v_b survives row a iff v_b >= vcut[a]
 
 __device__ __forceinline__ D3Half d3_half_i(float cn_i, const float* __restrict__ cr, float k3) {
   D3Half h;
@@ -339,34 +339,51 @@ __device__ __forceinline__ D3Half d3_half_i(float cn_i, const float* __restrict_
     h.Ap[a] = A[a] - mx;
     const bool keep = h.Ap[a] >= -12.0f;  // false for -inf and NaN (no populated point at all)
     h.u[a] = keep ? d3_exp_neg(keep ? h.Ap[a] : 0.0f) : 0.0f;
+    h.vcut[a] = keep ? d3_exp_neg(-12.0f - h.Ap[a]) : INFINITY;
   }
   return h;
 }
 
 typedef float d3_f2 __attribute__((ext_vector_type(2)));
 
-// Per pair: the j-side exponents B_b, their maximum, v_b = exp(B_b - max) and the (a, b) contraction.  Reference points that
-// do not exist carry c_j(b) = D3_NOREF in the staged table, so (CN_j - c)^2 overflows to +inf and k3 * inf = -inf masks the
-// term with no bit tests (the factorised path is only selected for k3 < 0).  v_b uses the compensated exponential (the bare
-// v_exp_f32 would be 4 % faster on this kernel but shifts small-system energies by 1e-7 relative); terms below e^-12 are
-// removed by the per-term test A'_a + B'_b >= -12 alone, so v_b itself needs no cut.
+// The j-side half of the factorised weights is a property of atom j alone: v_b(j) = exp(B_b - max_b B_b) with
+// B_b = k3 (CN_j - c_j(b))^2.  It is evaluated ONCE per atom after the CN pass (5 exponentials per atom instead of per
+// pair) and travels with the per-atom record the energy pass gathers anyway:
+//   aw[2j] = {v_0..v_3},  aw[2j+1] = {v_4, r4r2[Z_j], bits(Z_j << 8 | species id), 0}      (one 32-byte line segment)
+// Reference points that do not exist carry c_j(b) = D3_NOREF in `fcr`, so (CN_j - c)^2 overflows to +inf and k3 * inf = -inf
+// masks them (the factorised path is only selected for k3 < 0); weights below e^-12 are stored as exact zeros.
 #define D3_NOREF 1.0e30f
-__device__ __forceinline__ void d3_c6_fact(const D3Half& h, float cn_j, const float* __restrict__ crj, const float* __restrict__ c6rows, float k3,
-                                           float& c6, float& dci) {
-  const float4 c03 = *reinterpret_cast<const float4*>(crj);
-  const float cj[5] = {c03.x, c03.y, c03.z, c03.w, crj[4]};
-  float Bp[5], v[5], mx = -INFINITY;
+__global__ void d3_weights_kernel(const float* __restrict__ cn, const float4* __restrict__ aaux, const D3Species* __restrict__ sinfo,
+                                  const float* __restrict__ fcr, float k3, int N, float4* __restrict__ aw) {
+  if (!sinfo->factorized || sinfo->S > D3_SMAX) return;
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= N) return;
+  const float4 a = aaux[j];
+  const int code = __float_as_int(a.z), sj = code & 0xff;
+  float v[5] = {0, 0, 0, 0, 0};
+  if (sj < D3_SMAX) {  // real atom of a present species (padding atoms carry 0xff)
+    const float cnj = cn[j];
+    float B[5], mx = -INFINITY;
 #pragma unroll
-  for (int b = 0; b < 5; ++b) {
-    const float dj = cn_j - cj[b];
-    Bp[b] = k3 * (dj * dj);
-    mx = fmaxf(mx, Bp[b]);
-  }
+    for (int b = 0; b < 5; ++b) {
+      const float dj = cnj - fcr[sj * 8 + b];
+      B[b] = k3 * (dj * dj);
+      mx = fmaxf(mx, B[b]);
+    }
 #pragma unroll
-  for (int b = 0; b < 5; ++b) {
-    Bp[b] -= mx;
-    v[b] = d3_exp(Bp[b]);
+    for (int b = 0; b < 5; ++b) {
+      const float Bp = B[b] - mx;
+      const bool keep = Bp >= -12.0f;  // false for -inf and NaN (no populated point at all)
+      v[b] = keep ? d3_exp_neg(keep ? Bp : 0.0f) : 0.0f;
+    }
   }
+  aw[2 * (size_t)j] = make_float4(v[0], v[1], v[2], v[3]);
+  aw[2 * (size_t)j + 1] = make_float4(v[4], a.y, a.z, 0.0f);
+}
+
+// Per pair: the (a, b) contraction only.  Same sums and thresholds as `_c6ab_interpolate`: a term survives iff
+// A'_a + B'_b >= -12, evaluated in weight space as v_b >= exp(-12 - A'_a) (wave-uniform per row).
+__device__ __forceinline__ void d3_c6_fact(const D3Half& h, const float* v, const float* __restrict__ c6rows, float k3, float& c6, float& dci) {
   d3_f2 wz = {0.0f, 0.0f}, wzd = {0.0f, 0.0f};  // {w, z} and {sum w di, sum z di}
 #pragma unroll
   for (int a = 0; a < 5; ++a) {
@@ -374,11 +391,10 @@ __device__ __forceinline__ void d3_c6_fact(const D3Half& h, float cn_j, const fl
     const float4 r03 = *reinterpret_cast<const float4*>(c6rows + a * 8);
     const float r4 = c6rows[a * 8 + 4];
     const float cr[5] = {r03.x, r03.y, r03.z, r03.w, r4};
-    const float thr = -12.0f - h.Ap[a];
     d3_f2 RT = {0.0f, 0.0f};  // {sum_b L, sum_b c6_ab L}: one packed FMA per term
 #pragma unroll
     for (int b = 0; b < 5; ++b) {
-      const float L = (Bp[b] >= thr) ? v[b] : 0.0f;
+      const float L = (v[b] >= h.vcut[a]) ? v[b] : 0.0f;
       RT = __builtin_elementwise_fma((d3_f2){L, L}, (d3_f2){1.0f, cr[b]}, RT);
     }
     const d3_f2 uRT = RT * h.u[a];
@@ -407,10 +423,10 @@ __global__ __launch_bounds__(256) void d3_energy_kernel(const T* __restrict__ po
                                                         const D3Species* __restrict__ sinfo, const float4* __restrict__ ctab,
                                                         const float* __restrict__ ftab, const float* __restrict__ fcr,
                                                         const typename Vec4<T>::type* __restrict__ apos, const float4* __restrict__ aaux,
-                                                        float* __restrict__ dEdCN, float* __restrict__ forces, float* __restrict__ e_atom,
-                                                        float* __restrict__ v_atom) {
+                                                        const float4* __restrict__ aw, float* __restrict__ dEdCN,
+                                                        float* __restrict__ forces, float* __restrict__ e_atom, float* __restrict__ v_atom) {
   constexpr bool LDS = MODE == 1;
-  constexpr int WAVE_F4 = MODE == 1 ? D3_SMAX * 25 : MODE == 2 ? D3_SMAX * (D3_FROW + 8) / 4 : 1;  // float4 per wave
+  constexpr int WAVE_F4 = MODE == 1 ? D3_SMAX * 25 : MODE == 2 ? D3_SMAX * D3_FROW / 4 : 1;  // float4 per wave
   __shared__ float4 lds_tab[MODE == 0 ? 1 : 4][WAVE_F4];
   const int S = sinfo->S;
   const int want_mode = S > D3_SMAX ? 0 : (sinfo->factorized ? 2 : 1);
@@ -433,13 +449,11 @@ __global__ __launch_bounds__(256) void d3_energy_kernel(const T* __restrict__ po
     const float4* __restrict__ src = ctab + (size_t)smap[zi] * S * 25;
     for (int k = lane; k < S * 25; k += MI_WAVE) my_tab[k] = src[k];
   }
-  float* my_f = reinterpret_cast<float*>(my_tab);  // MODE 2: [S][40] c6 rows of this element, then [S][8] reference CNs
+  float* my_f = reinterpret_cast<float*>(my_tab);  // MODE 2: [S][40] c6 rows of this element
   D3Half hi;
   if (MODE == 2) {
     const float4* __restrict__ src = reinterpret_cast<const float4*>(ftab + (size_t)smap[zi] * S * D3_FROW);
     for (int k = lane; k < S * (D3_FROW / 4); k += MI_WAVE) my_tab[k] = src[k];
-    const float4* __restrict__ src2 = reinterpret_cast<const float4*>(fcr);
-    for (int k = lane; k < S * 2; k += MI_WAVE) my_tab[D3_SMAX * (D3_FROW / 4) + k] = src2[k];
     hi = d3_half_i(cn_i, fcr + smap[zi] * 8, P.k3);
   }
   // the table is staged as float4 and read back as float / float2 / float4: keep the compiler from moving those reads above
@@ -455,27 +469,37 @@ __global__ __launch_bounds__(256) void d3_energy_kernel(const T* __restrict__ po
   D3Step s0 = d3_fetch(idx, ush3, e, end, periodic), s1 = d3_fetch(idx, ush3, e + MI_WAVE, end, periodic);
   bool v0 = s0.in && (CSR || s0.j < fill_value);
   auto p0 = apos[v0 ? s0.j : i];
-  float4 a0 = aaux[v0 ? s0.j : i];  // {CN_j, r4r2_j, Z_j << 8 | species id}
+  // per-neighbour record: MODE 0/1 {CN_j, r4r2_j, Z_j << 8 | species id} (aaux); MODE 2 the 32-byte weight record (aw)
+  auto aux_of = [&](int j, float4& lo, float4& hi4) {
+    if (MODE == 2) { lo = aw[2 * (size_t)j]; hi4 = aw[2 * (size_t)j + 1]; }
+    else { lo = aaux[j]; hi4 = lo; }
+  };
+  float4 a0, b0;
+  aux_of(v0 ? s0.j : i, a0, b0);
   for (long long base = beg; base < end; base += MI_WAVE) {
     e += MI_WAVE;
     const D3Step s2 = d3_fetch(idx, ush3, e + MI_WAVE, end, periodic);
     const bool v1 = s1.in && (CSR || s1.j < fill_value);
     const auto p1 = apos[v1 ? s1.j : i];
-    const float4 a1 = aaux[v1 ? s1.j : i];
+    float4 a1, b1;
+    aux_of(v1 ? s1.j : i, a1, b1);
     if (__any(v0)) {
       bool valid = v0 && !(p0.w < (T)0);  // padding atom (Z == 0)
       const PairGeom<T> g = d3_geom<T>(p0, pix, piy, piz, s0.sh, cm, periodic);
       valid = valid && g.ok;
-      const int code = valid ? __float_as_int(a0.z) : code_i;
+      const int code = valid ? __float_as_int(MODE == 2 ? b0.z : a0.z) : code_i;
+      const float r4r2_j = MODE == 2 ? b0.y : a0.y;
       float c6, dci;
-      if (MODE == 2)
-        d3_c6_fact(hi, a0.x, my_f + D3_SMAX * D3_FROW + (code & 0xff) * 8, my_f + (code & 0xff) * D3_FROW, P.k3, c6, dci);
-      else
+      if (MODE == 2) {
+        const float vj[5] = {a0.x, a0.y, a0.z, a0.w, b0.x};
+        d3_c6_fact(hi, vj, my_f + (code & 0xff) * D3_FROW, P.k3, c6, dci);
+      } else {
         d3_c6(cn_i, a0.x, LDS ? my_tab + (code & 0xff) * 25 : tab_i + (size_t)(code >> 8) * 25, P.k3, c6, dci);
+      }
       valid = valid && !(c6 < 1e-12f);
       // `_bj_damping` (dftd3.py:648-687)
       const float r = valid ? g.r : 1.0f;
-      const float q = 3.0f * r4r2_i * a0.y;
+      const float q = 3.0f * r4r2_i * r4r2_j;
       const float r0 = P.a1 * __builtin_amdgcn_sqrtf(q) + P.a2;
       const float r2 = r * r, r4 = r2 * r2, r6 = r4 * r2, r8 = r4 * r4;
       const float r02 = r0 * r0, r04 = r02 * r02, r06 = r04 * r02, r08 = r04 * r04;
@@ -501,7 +525,7 @@ __global__ __launch_bounds__(256) void d3_energy_kernel(const T* __restrict__ po
         V[6] += (double)(fz * g.rx); V[7] += (double)(fz * g.ry); V[8] += (double)(fz * g.rz);
       }
     }
-    s0 = s1; v0 = v1; p0 = p1; a0 = a1; s1 = s2;
+    s0 = s1; v0 = v1; p0 = p1; a0 = a1; b0 = b1; s1 = s2;
   }
   Fx = wave_sum(Fx); Fy = wave_sum(Fy); Fz = wave_sum(Fz); E = wave_sum(E);
   dacc = wave_sum(dacc);
@@ -638,7 +662,7 @@ __global__ __launch_bounds__(256) void d3_reduce_kernel(const float* __restrict_
   flush();
 }
 
-struct D3Layout { size_t dEdCN, e_atom, v_atom, tab, present, smap, sinfo, ctab, ftab, fcr, apos, aaux, total; };
+struct D3Layout { size_t dEdCN, e_atom, v_atom, tab, present, smap, sinfo, ctab, ftab, fcr, apos, aaux, aw, total; };
 D3Layout d3_layout(int N, int nz, int dtype) {
   D3Layout L;
   size_t o = 0;
@@ -655,6 +679,7 @@ D3Layout d3_layout(int N, int nz, int dtype) {
   L.fcr = take(sizeof(float) * D3_SMAX * 8);
   L.apos = take((dtype == MI_F32 ? 16 : 32) * (size_t)N);
   L.aaux = take(sizeof(float4) * (size_t)N);
+  L.aw = take(sizeof(float4) * 2 * (size_t)N);
   L.total = o;
   return L;
 }
@@ -675,6 +700,7 @@ int d3_impl(const T* pos, const int* numbers, int N, const int* idx, const int* 
   float* fcr = reinterpret_cast<float*>(ws + L.fcr);
   auto* apos = reinterpret_cast<typename Vec4<T>::type*>(ws + L.apos);
   float4* aaux = reinterpret_cast<float4*>(ws + L.aaux);
+  float4* aw = reinterpret_cast<float4*>(ws + L.aw);
   D3Dev P;
   P.rcov = hp->rcov; P.r4r2 = hp->r4r2; P.tab = tab; P.nz = hp->nz;
   P.a1 = hp->a1; P.a2 = hp->a2; P.s6 = hp->s6; P.s8 = hp->s8; P.k1 = hp->k1; P.k3 = hp->k3; P.s5_on = hp->s5_on; P.s5_off = hp->s5_off;
@@ -703,9 +729,11 @@ int d3_impl(const T* pos, const int* numbers, int N, const int* idx, const int* 
   const int blocks = mi_blocks(N, 4);
   MI_TIMED("d3_cn", st, (d3_cn_kernel<T, CSR><<<mi_blocks(N, D3_LS_WAVES), D3_LS_WAVES * MI_WAVE, 0, st>>>(pos, numbers, N, idx, ush, nptr, M, fill_value, cell, batch_idx, P, apos, aaux, cn)));
   MI_LAUNCH_CHECK();
+  d3_weights_kernel<<<mi_blocks(N, 256), 256, 0, st>>>(cn, aaux, sinfo, fcr, hp->k3, N, aw);
+  MI_LAUNCH_CHECK();
 #define MI_D3_ENERGY(MODE_)                                                                                                                    \
   d3_energy_kernel<T, CSR, MODE_><<<blocks, 256, 0, st>>>(pos, numbers, N, idx, ush, nptr, M, fill_value, cell, batch_idx, P, cn, want_virial, \
-                                                          smap, sinfo, ctab, ftab, fcr, apos, aaux, dEdCN, forces, e_atom, v_atom)
+                                                          smap, sinfo, ctab, ftab, fcr, apos, aaux, aw, dEdCN, forces, e_atom, v_atom)
   MI_TIMED("d3_energy", st, (MI_D3_ENERGY(2), MI_D3_ENERGY(1)));
   MI_LAUNCH_CHECK();
   MI_D3_ENERGY(0);
