@@ -201,7 +201,7 @@ __device__ __forceinline__ void d3_s5(float r, float on, float off, float inv_w,
 #define D3_SMAX 16  // species held in LDS per wave (16 x 25 float4 = 6.4 KB); more species fall back to the global table
 
 struct D3Species { int S; int factorized; int pad[2]; };
-#define D3_FROW 40  // factorized c6 block per partner species: 5 rows x 8 floats (b = 0..4 used)
+#define D3_FROW 44  // factorised block per partner species: 5 c6 rows x 8 floats (b = 0..4 used) + {q, r0^6, r0^8, 0} of the BJ damping
 
 __global__ void d3_mark_species_kernel(const int* __restrict__ numbers, int N, int nz, int* __restrict__ present) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -219,7 +219,8 @@ __global__ void d3_mark_species_kernel(const int* __restrict__ numbers, int N, i
 // {c(0..4), validity bits}.  Tables without that structure keep the general 25-term path.
 __global__ void d3_compact_species_kernel(const int* __restrict__ present, const float* __restrict__ c6ab, const float* __restrict__ cnref, int nz,
                                           int* __restrict__ smap, D3Species* __restrict__ info, float4* __restrict__ ctab,
-                                          float* __restrict__ ftab, float* __restrict__ fcr, float k3) {
+                                          float* __restrict__ ftab, float* __restrict__ fcr, float k3, const float* __restrict__ r4r2,
+                                          float a1, float a2) {
   __shared__ int zlist[D3_SMAX];
   __shared__ int count;
   __shared__ int fact_ok;
@@ -250,6 +251,12 @@ __global__ void d3_compact_species_kernel(const int* __restrict__ present, const
   for (int k = threadIdx.x; k < S * S * 5; k += blockDim.x) {  // zero the 3 padding floats of each row
     float* row = ftab + (size_t)(k / 5) * D3_FROW + (k % 5) * 8;
     row[5] = row[6] = row[7] = 0.0f;
+  }
+  for (int k = threadIdx.x; k < S * S; k += blockDim.x) {  // BJ damping constants of the species pair (`_bj_damping`, dftd3.py:648-687)
+    const float q = 3.0f * r4r2[zlist[k / S]] * r4r2[zlist[k % S]];
+    const float r0 = a1 * sqrtf(q) + a2, r02 = r0 * r0, r04 = r02 * r02;
+    float* d = ftab + (size_t)k * D3_FROW + 40;
+    d[0] = q; d[1] = r04 * r02; d[2] = r04 * r04; d[3] = 0.0f;
   }
   for (int si = threadIdx.x; si < S; si += blockDim.x) {
     const int zi = zlist[si];
@@ -499,10 +506,17 @@ __global__ __launch_bounds__(256) void d3_energy_kernel(const T* __restrict__ po
       valid = valid && !(c6 < 1e-12f);
       // `_bj_damping` (dftd3.py:648-687)
       const float r = valid ? g.r : 1.0f;
-      const float q = 3.0f * r4r2_i * r4r2_j;
-      const float r0 = P.a1 * __builtin_amdgcn_sqrtf(q) + P.a2;
+      float q, r06, r08;
+      if (MODE == 2) {  // species-pair constants staged with the c6 rows
+        const float4 bj = *reinterpret_cast<const float4*>(my_f + (code & 0xff) * D3_FROW + 40);
+        q = bj.x; r06 = bj.y; r08 = bj.z;
+      } else {
+        q = 3.0f * r4r2_i * r4r2_j;
+        const float r0 = P.a1 * __builtin_amdgcn_sqrtf(q) + P.a2;
+        const float r02 = r0 * r0, r04 = r02 * r02;
+        r06 = r04 * r02; r08 = r04 * r04;
+      }
       const float r2 = r * r, r4 = r2 * r2, r6 = r4 * r2, r8 = r4 * r4;
-      const float r02 = r0 * r0, r04 = r02 * r02, r06 = r04 * r02, r08 = r04 * r04;
       const float i6 = __builtin_amdgcn_rcpf(r6 + r06), i8 = __builtin_amdgcn_rcpf(r8 + r08);
       const float damp = P.s6 * i6 + P.s8 * q * i8;
       // `_dispersion_energy_force` (dftd3.py:690-731)
@@ -722,7 +736,7 @@ int d3_impl(const T* pos, const int* numbers, int N, const int* idx, const int* 
   MI_HIP_CHECK(hipMemsetAsync(present, 0, sizeof(int) * (size_t)hp->nz, st));
   d3_mark_species_kernel<<<mi_blocks(N, 256), 256, 0, st>>>(numbers, N, hp->nz, present);
   MI_LAUNCH_CHECK();
-  d3_compact_species_kernel<<<1, 256, 0, st>>>(present, hp->c6ab, hp->cn_ref, hp->nz, smap, sinfo, ctab, ftab, fcr, hp->k3);
+  d3_compact_species_kernel<<<1, 256, 0, st>>>(present, hp->c6ab, hp->cn_ref, hp->nz, smap, sinfo, ctab, ftab, fcr, hp->k3, hp->r4r2, hp->a1, hp->a2);
   MI_LAUNCH_CHECK();
   d3_pack_atoms_kernel<T><<<mi_blocks(N, 256), 256, 0, st>>>(pos, numbers, N, hp->rcov, hp->r4r2, smap, hp->nz, apos, aaux);
   MI_LAUNCH_CHECK();
