@@ -167,7 +167,14 @@ def make_step(sysd, tables, device, world):
     num = torch.empty(n, dtype=torch.int32, device=device)
     d3_bufs = None
     if D3_FORMAT == "matrix":
+        # set-up, outside the timed region: make sure the configured row width holds this rank's box (replica boxes differ in their
+        # jitter seed); the counts returned by a search keep counting past the row width, so one trial build tells
         md = D3["max_neighbors"]
+        trial = cell_list(sysd["pos32b"], D3["cutoff"], sysd["cell32b"], sysd["pbc"], max_neighbors=64)[1]
+        need = int(trial.max().item())
+        if need > md:
+            md = D3["max_neighbors"] = (need + 63) // 64 * 64
+        del trial
         d3_bufs = (torch.empty((n, md), dtype=torch.int32, device=device), torch.empty((n, md, 3), dtype=torch.int32, device=device),
                    torch.empty(n, dtype=torch.int32, device=device))
     gathered = [torch.zeros(2, dtype=torch.float64, device=device) for _ in range(world)] if world > 1 else None
