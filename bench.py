@@ -423,7 +423,7 @@ def main():
                 "bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": measured_traffic(name, args.atoms, args.workload),
                 "avg_launch_ms": ms / cnt, "launches": cnt, "algorithmic_bytes_per_launch": ab,
-                "note": "d3_energy is VALU/latency-bound (5 expf + 25-term contraction per directed pair), not HBM-bound: see DESIGN.md; "
+                "note": "d3_energy is VALU/latency-bound (25-term weight contraction + BJ damping per directed pair), not HBM-bound: see DESIGN.md; "
                         f"pairs/s = {pairs_d3 / avg_s:.3e}" if name == "d3_energy" else "",
             }
         result = {

@@ -226,3 +226,18 @@ def test_c6_table_structures(kind):
     ref = O.dftd3(pos, z, t, neighbor_matrix=nm.cpu().numpy(), neighbor_matrix_shifts=sh.cpu().numpy(), cell=cell, compute_virial=True, **FP)
     out = dftd3(_t(pos), _t(z), d3_params=p, neighbor_matrix=nm, neighbor_matrix_shifts=sh, cell=_t(cell)[None], compute_virial=True, **FP)
     _check(out, ref, virial=True)
+
+
+def test_more_than_16_species_uses_global_table():
+    """> 16 species present: the energy pass reads the global [nz,nz,25] table instead of the LDS-staged compact one (MODE 0)."""
+    from nvalchemiops.interactions.dispersion import dftd3
+    from nvalchemiops.neighborlist import cell_list
+
+    t, p = _params(24, seed=3)
+    pos, cell = S.random_box(150, 24.0, seed=19, dtype=np.float32)
+    z = (np.arange(150) % 22 + 1).astype(np.int32)  # 22 different elements
+    nm, num, sh = cell_list(_t(pos), 13.0, _t(cell), torch.tensor([True] * 3, device=DEV), max_neighbors=320)
+    assert int(num.max()) <= 320
+    ref = O.dftd3(pos, z, t, neighbor_matrix=nm.cpu().numpy(), neighbor_matrix_shifts=sh.cpu().numpy(), cell=cell, compute_virial=True, **FP)
+    out = dftd3(_t(pos), _t(z), d3_params=p, neighbor_matrix=nm, neighbor_matrix_shifts=sh, cell=_t(cell)[None], compute_virial=True, **FP)
+    _check(out, ref, virial=True)
