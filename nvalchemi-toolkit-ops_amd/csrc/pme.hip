@@ -7,8 +7,12 @@
 // torch.fft (pme.py:1398,1422,1459-1461).
 //
 // MI355X-first choices:
-//   * spread: order^2 threads per atom (one (ix,iy) stencil column each), every thread computes its 1-D weights once and
-//     walks the contiguous z-run issuing native fp32/fp64 global atomics (the reference launches N*order^3 threads that
+//   * spread: MESH-TILE OWNERSHIP, no global atomics.  Atoms are binned by the 8^3 mesh tile their stencil starts in (radix
+//     sort by tile key); one block owns one tile, accumulates the in-tile part of the stencils of the atoms of the <= 8 bins
+//     that can reach it in a 4 KB LDS tile (native LDS fp64 adds) and writes the finished tile with plain coalesced stores --
+//     every mesh point is written exactly once, the mesh needs no zero-fill.  (Device-scope fp64 atomics to a mesh shared by
+//     8 XCDs ran at ~25 G/s: 0.49 ms for the 12.5 M contributions of the headline box.)  The order^2-threads-per-atom atomic
+//     kernel remains for meshes that are not multiples of the tile edge (the reference launches N*order^3 threads that
 //     each redo the fractional-coordinate transform and all three 1-D weights).
 //   * convolve: ONE pass over the half-spectrum produces conv = spec/sf^2*G and the three field spectra -i k_d conv;
 //     k, k^2, G and sf^2 are evaluated in registers (no k-vector / Green / structure-factor arrays in HBM).
@@ -16,6 +20,8 @@
 //     force factor applied in the epilogue (reference: 2 gathers of N*order^3 atomics + 2 elementwise kernels + torch ops).
 //   * orders 1-4 use the reference's piecewise polynomials verbatim; orders 5-6 (which the reference evaluates as 0,
 //     SURVEY F2) use the cardinal B-spline recursion.
+#include <hipcub/hipcub.hpp>
+
 #include "common.h"
 
 namespace {
@@ -140,6 +146,107 @@ __global__ __launch_bounds__(256) void spline_spread_kernel(const T* __restrict_
     const T wz = weight_1d(st, 2, tz, order);
     const T w = wx * wy * wz;
     if (w > thr) atomicAdd(row + wrap_idx(st.base[2] + tz + st.off0[2], nz), val * w);
+  }
+}
+
+// ---- tiled spread ----------------------------------------------------------------------------------------------------------
+#define SP_T 8  // mesh tile edge (points); stencils span order <= 6 <= SP_T + 1 points, i.e. at most two tiles per axis
+
+struct SpLayout { size_t keys_in, keys_out, vals_in, vals_out, bin_start, lo3, wts, cub, cub_bytes, total; long long nbins; };
+static SpLayout sp_layout(int N, int B, int nx, int ny, int nz) {
+  SpLayout L;
+  size_t o = 0;
+  auto take = [&](size_t b) { size_t at = o; o += mi_align(b); return at; };
+  L.nbins = (long long)B * (nx / SP_T) * (ny / SP_T) * (nz / SP_T);
+  L.keys_in = take(sizeof(int) * (size_t)N);
+  L.keys_out = take(sizeof(int) * (size_t)N);
+  L.vals_in = take(sizeof(int) * (size_t)N);
+  L.vals_out = take(sizeof(int) * (size_t)N);
+  L.bin_start = take(sizeof(int) * (size_t)(L.nbins + 1));
+  L.lo3 = take(sizeof(int) * 4 * (size_t)N);                       // first stencil index per axis (wrapped), per atom
+  L.wts = take(sizeof(double) * 3 * MI_MAX_ORDER * (size_t)N);     // 1-D weights [3][MI_MAX_ORDER] per atom (sized for fp64)
+  size_t cub = 0;
+  (void)hipcub::DeviceRadixSort::SortPairs(nullptr, cub, (const int*)nullptr, (int*)nullptr, (const int*)nullptr, (int*)nullptr, N > 0 ? N : 1, 0, 31);
+  L.cub_bytes = cub + 256;
+  L.cub = take(L.cub_bytes);
+  L.total = o;
+  return L;
+}
+static bool sp_tiled_ok(int nx, int ny, int nz, int B) {
+  return nx >= MI_MAX_ORDER && ny >= MI_MAX_ORDER && nz >= MI_MAX_ORDER && nx % SP_T == 0 && ny % SP_T == 0 && nz % SP_T == 0 && (long long)B * (nx / SP_T) * (ny / SP_T) * (nz / SP_T) < (1ll << 30);
+}
+
+template <class T>
+__global__ void spread_key_kernel(const T* __restrict__ pos, const int* __restrict__ batch_idx, const T* __restrict__ cit, int N, int nx, int ny,
+                                  int nz, int order, int* __restrict__ keys, int* __restrict__ vals, int4* __restrict__ lo3, T* __restrict__ wts) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  const int s = batch_idx ? batch_idx[i] : 0;
+  const Stencil<T> st = make_stencil(pos + 3 * (size_t)i, cit + 9 * (size_t)s, nx, ny, nz, order);
+  const int lx = wrap_idx(st.base[0] + st.off0[0], nx), ly = wrap_idx(st.base[1] + st.off0[1], ny), lz = wrap_idx(st.base[2] + st.off0[2], nz);
+  keys[i] = ((s * (nx / SP_T) + lx / SP_T) * (ny / SP_T) + ly / SP_T) * (nz / SP_T) + lz / SP_T;
+  vals[i] = i;
+  lo3[i] = make_int4(lx, ly, lz, s);
+  // the 1-D weights are evaluated once per atom here; the tile kernel (up to 8 tiles x order^2 threads per atom) only reads them
+  for (int d = 0; d < 3; ++d)
+    for (int t = 0; t < MI_MAX_ORDER; ++t) wts[((size_t)i * 3 + d) * MI_MAX_ORDER + t] = t < order ? weight_1d(st, d, t, order) : T(0);
+}
+__global__ void spread_bin_start_kernel(const int* __restrict__ keys_sorted, int N, long long nbins, int* __restrict__ bin_start) {
+  const long long b = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (b > nbins) return;
+  int lo = 0, hi = N;  // first sorted position with key >= b
+  while (lo < hi) { const int mid = (lo + hi) >> 1; if (keys_sorted[mid] < b) lo = mid + 1; else hi = mid; }
+  bin_start[b] = lo;
+}
+template <class T>
+__global__ __launch_bounds__(256) void spread_tiled_kernel(const T* __restrict__ values, const int* __restrict__ atom_of, const int* __restrict__ bin_start,
+                                                           const int4* __restrict__ lo3, const T* __restrict__ wts, int nx, int ny, int nz, int order,
+                                                           int batched, T* __restrict__ mesh) {
+  __shared__ T tile[SP_T * SP_T * SP_T];
+  const int nbx = nx / SP_T, nby = ny / SP_T, nbz = nz / SP_T;
+  int b = blockIdx.x;
+  const int bz = b % nbz; b /= nbz;
+  const int by = b % nby; b /= nby;
+  const int bx = b % nbx;
+  const int s = b / nbx;
+  for (int k = threadIdx.x; k < SP_T * SP_T * SP_T; k += blockDim.x) tile[k] = T(0);
+  __syncthreads();
+  const int tpa = order * order;
+  const T thr = batched ? T(1e-8) : T(0);  // spline.py:548 (w > 0) vs :820 (w > 1e-8)
+  // a stencil starting in tile t reaches t and t+1 (periodic): this tile collects from source bins {b, b-1} per axis
+  const int sxn = nbx > 1 ? 2 : 1, syn = nby > 1 ? 2 : 1, szn = nbz > 1 ? 2 : 1;
+  for (int sx = 0; sx < sxn; ++sx)
+    for (int sy = 0; sy < syn; ++sy)
+      for (int sz = 0; sz < szn; ++sz) {
+        const int cx = (bx - sx + nbx) % nbx, cy = (by - sy + nby) % nby, cz = (bz - sz + nbz) % nbz;
+        const int key = ((s * nbx + cx) * nby + cy) * nbz + cz;
+        const int beg = bin_start[key], end = bin_start[key + 1];
+        for (int t = threadIdx.x; t < (end - beg) * tpa; t += blockDim.x) {
+          const int a = beg + t / tpa, col = t - (t / tpa) * tpa;
+          const int i = atom_of[a];
+          const int4 lo = lo3[i];
+          const int tx = col / order, ty = col - tx * order;
+          int gx = lo.x + tx, gy = lo.y + ty;  // lo is already wrapped and order <= n: one conditional subtraction wraps
+          gx -= gx >= nx ? nx : 0;
+          gy -= gy >= ny ? ny : 0;
+          if (gx / SP_T != bx || gy / SP_T != by) continue;
+          const T* w3 = wts + (size_t)i * 3 * MI_MAX_ORDER;
+          const T wxy = w3[tx] * w3[MI_MAX_ORDER + ty];
+          const T val = values[i];
+          T* row = tile + ((gx % SP_T) * SP_T + (gy % SP_T)) * SP_T;
+          for (int tz = 0; tz < order; ++tz) {
+            int gz = lo.z + tz;
+            gz -= gz >= nz ? nz : 0;
+            if (gz / SP_T != bz) continue;
+            const T w = wxy * w3[2 * MI_MAX_ORDER + tz];
+            if (w > thr) atomicAdd(row + (gz % SP_T), val * w);
+          }
+        }
+      }
+  __syncthreads();
+  for (int k = threadIdx.x; k < SP_T * SP_T * SP_T; k += blockDim.x) {
+    const int lx = k / (SP_T * SP_T), ly = (k / SP_T) % SP_T, lz = k % SP_T;
+    mesh[(((size_t)s * nx + bx * SP_T + lx) * ny + by * SP_T + ly) * nz + bz * SP_T + lz] = tile[k];
   }
 }
 
@@ -366,6 +473,30 @@ __global__ void segment_sum_kernel(const T* __restrict__ v, const int* __restric
   }
 }
 
+template <class T>
+int spread_tiled(const T* pos, const T* values, const int* batch_idx, const T* cit, int N, int B, int nx, int ny, int nz, int order,
+                        int batched, T* mesh, char* ws, hipStream_t st) {
+  const SpLayout L = sp_layout(N, B, nx, ny, nz);
+  int* keys_in = reinterpret_cast<int*>(ws + L.keys_in);
+  int* keys_out = reinterpret_cast<int*>(ws + L.keys_out);
+  int* vals_in = reinterpret_cast<int*>(ws + L.vals_in);
+  int* vals_out = reinterpret_cast<int*>(ws + L.vals_out);
+  int* bin_start = reinterpret_cast<int*>(ws + L.bin_start);
+  int4* lo3 = reinterpret_cast<int4*>(ws + L.lo3);
+  T* wts = reinterpret_cast<T*>(ws + L.wts);
+  spread_key_kernel<T><<<mi_blocks(N, 256), 256, 0, st>>>(pos, batch_idx, cit, N, nx, ny, nz, order, keys_in, vals_in, lo3, wts);
+  MI_LAUNCH_CHECK();
+  int bits = 1;
+  while ((1ll << bits) < L.nbins) ++bits;
+  size_t cub_bytes = L.cub_bytes;
+  MI_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(ws + L.cub, cub_bytes, (const int*)keys_in, keys_out, (const int*)vals_in, vals_out, N, 0, bits, st));
+  spread_bin_start_kernel<<<mi_blocks(L.nbins + 1, 256), 256, 0, st>>>(keys_out, N, L.nbins, bin_start);
+  MI_LAUNCH_CHECK();
+  spread_tiled_kernel<T><<<(int)L.nbins, 256, 0, st>>>(values, vals_out, bin_start, lo3, wts, nx, ny, nz, order, batched, mesh);
+  MI_LAUNCH_CHECK();
+  return MI_OK;
+}
+
 }  // namespace
 
 #define MI_DISPATCH_T(dtype, CALL)                     \
@@ -376,20 +507,38 @@ __global__ void segment_sum_kernel(const T* __restrict__ v, const int* __restric
 
 extern "C" {
 
+size_t mi_spline_spread_workspace_bytes(int n_atoms, int n_systems, int nx, int ny, int nz) {
+  if (n_atoms < 0 || n_systems < 1 || nx <= 0 || ny <= 0 || nz <= 0) return 0;
+  if (!sp_tiled_ok(nx, ny, nz, n_systems)) return 256;  // the atomic kernel needs no scratch
+  return sp_layout(n_atoms, n_systems, nx, ny, nz).total;
+}
+
 int mi_spline_spread(const void* positions, const void* values, const int32_t* batch_idx, const void* cell_inv_t, int n_atoms, int n_systems,
-                     int nx, int ny, int nz, int order, int batched, int dtype, void* mesh, void* stream) {
+                     int nx, int ny, int nz, int order, int batched, int dtype, void* mesh, void* workspace, size_t workspace_bytes,
+                     void* stream) {
   MI_REQUIRE(dtype == MI_F32 || dtype == MI_F64, "dtype");
   MI_REQUIRE(order >= 1 && order <= MI_MAX_ORDER, "spline order must be 1..6");
   MI_REQUIRE(nx > 0 && ny > 0 && nz > 0 && n_systems >= 1, "mesh dimensions");
   if (n_atoms <= 0) return MI_OK;
   MI_REQUIRE(positions && values && cell_inv_t && mesh, "null pointer");
-  const int apb = 256 / (order * order);
   hipStream_t st = (hipStream_t)stream;
   mi_timing_begin("spline_spread", stream);
-  MI_DISPATCH_T(dtype, (spline_spread_kernel<T_><<<mi_blocks(n_atoms, apb), 256, 0, st>>>((const T_*)positions, (const T_*)values, batch_idx,
-                                                                                          (const T_*)cell_inv_t, n_atoms, nx, ny, nz, order,
-                                                                                          batched, (T_*)mesh)));
+  int rc = MI_OK;
+  if (workspace && sp_tiled_ok(nx, ny, nz, n_systems) && workspace_bytes >= sp_layout(n_atoms, n_systems, nx, ny, nz).total) {
+    if (dtype == MI_F32)
+      rc = spread_tiled<float>((const float*)positions, (const float*)values, batch_idx, (const float*)cell_inv_t, n_atoms, n_systems, nx, ny, nz,
+                               order, batched, (float*)mesh, (char*)workspace, st);
+    else
+      rc = spread_tiled<double>((const double*)positions, (const double*)values, batch_idx, (const double*)cell_inv_t, n_atoms, n_systems, nx, ny,
+                                nz, order, batched, (double*)mesh, (char*)workspace, st);
+  } else {
+    const int apb = 256 / (order * order);
+    MI_DISPATCH_T(dtype, (spline_spread_kernel<T_><<<mi_blocks(n_atoms, apb), 256, 0, st>>>((const T_*)positions, (const T_*)values, batch_idx,
+                                                                                            (const T_*)cell_inv_t, n_atoms, nx, ny, nz, order,
+                                                                                            batched, (T_*)mesh)));
+  }
   mi_timing_end(stream);
+  if (rc != MI_OK) return rc;
   MI_LAUNCH_CHECK();
   return MI_OK;
 }

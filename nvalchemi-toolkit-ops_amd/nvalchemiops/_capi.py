@@ -41,6 +41,8 @@ def lib() -> ctypes.CDLL:
         L.mi_last_error.restype = ctypes.c_char_p
         L.mi_nl_workspace_bytes.restype = ctypes.c_size_t
         L.mi_nl_workspace_bytes.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int]
+        L.mi_spline_spread_workspace_bytes.restype = ctypes.c_size_t
+        L.mi_spline_spread_workspace_bytes.argtypes = [ctypes.c_int] * 5
         if hasattr(L, "mi_d3_workspace_bytes"):
             L.mi_d3_workspace_bytes.restype = ctypes.c_size_t
             L.mi_d3_workspace_bytes.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int]

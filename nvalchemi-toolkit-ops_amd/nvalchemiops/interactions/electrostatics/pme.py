@@ -22,7 +22,7 @@ from nvalchemiops import _capi as C
 from nvalchemiops.interactions.electrostatics.ewald import ewald_real_space
 from nvalchemiops.interactions.electrostatics.parameters import (estimate_pme_mesh_dimensions, estimate_pme_parameters,
                                                                  mesh_spacing_to_dimensions)
-from nvalchemiops.spline import spline_gather, spline_gather_vec3, spline_spread
+from nvalchemiops.spline import _launch_spread, spline_gather, spline_gather_vec3, spline_spread
 
 TWOPI = 2.0 * math.pi
 
@@ -116,11 +116,8 @@ def _reciprocal_fused(pos, q, cells, alpha, mesh_dimensions, spline_order, bi, c
     recip = (TWOPI * cell_inv).contiguous()
     vol = torch.abs(torch.linalg.det(cells)).to(dt).contiguous()
     al = alpha.to(dt).contiguous()
-    mesh = torch.zeros((nsys, nx, ny, nz), dtype=dt, device=dev)
     st = C.stream_of(pos)
-    rc = C.lib().mi_spline_spread(C.ptr(pos), C.ptr(q), C.ptr(bi), C.ptr(cit), n, nsys, nx, ny, nz, int(spline_order), int(batched), code,
-                                  C.ptr(mesh), st)
-    C.check(rc, "mi_spline_spread")
+    mesh = _launch_spread(pos, q, cit, bi, nsys, (nx, ny, nz), int(spline_order), batched)
     spec = torch.fft.rfftn(mesh, norm="backward", dim=(1, 2, 3))  # unscaled forward (pme.py:1398)
     nch = 4 if compute_forces else 1
     conv = torch.empty((nsys, nch, nx, ny, nz // 2 + 1), dtype=spec.dtype, device=dev)

@@ -24,10 +24,17 @@ def _prep(positions: torch.Tensor, cell: torch.Tensor, batch_idx, cell_inv_t):
 
 # ---- raw launchers (detached, contiguous tensors) ------------------------------------------------------------------
 def _launch_spread(pos, vals, cit, bi, nsys, dims, order, batched):
-    nx, ny, nz = dims
+    """mesh[nsys,nx,ny,nz] = spread of `vals` at `pos`.  The library runs tile-owned (no global atomics) when the mesh dimensions
+    are multiples of 8 and falls back to atomic adds into the zeroed mesh otherwise; the scratch buffer covers the former."""
+    import ctypes
+
+    nx, ny, nz = (int(v) for v in dims)
+    n = pos.shape[0]
     mesh = torch.zeros((nsys, nx, ny, nz), dtype=pos.dtype, device=pos.device)
-    rc = C.lib().mi_spline_spread(C.ptr(pos), C.ptr(vals), C.ptr(bi), C.ptr(cit), pos.shape[0], nsys, nx, ny, nz, int(order), int(batched),
-                                  C.dtype_code(pos.dtype), C.ptr(mesh), C.stream_of(pos))
+    ws_bytes = int(C.lib().mi_spline_spread_workspace_bytes(n, nsys, nx, ny, nz))
+    ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=pos.device)
+    rc = C.lib().mi_spline_spread(C.ptr(pos), C.ptr(vals), C.ptr(bi), C.ptr(cit), n, nsys, nx, ny, nz, int(order), int(batched),
+                                  C.dtype_code(pos.dtype), C.ptr(mesh), C.ptr(ws), ctypes.c_size_t(ws_bytes), C.stream_of(pos))
     C.check(rc, "mi_spline_spread")
     return mesh
 
@@ -137,11 +144,8 @@ def spline_spread(positions: torch.Tensor, values: torch.Tensor, cell: torch.Ten
     pos, c, cit, bi = _prep(positions, cell, batch_idx, cell_inv_t)
     nx, ny, nz = (int(v) for v in mesh_dims)
     nsys = c.shape[0] if bi is not None else 1
-    mesh = torch.zeros((nsys, nx, ny, nz), dtype=pos.dtype, device=pos.device)
     vals = values.detach().to(pos.dtype).contiguous()
-    rc = C.lib().mi_spline_spread(C.ptr(pos), C.ptr(vals), C.ptr(bi), C.ptr(cit), pos.shape[0], nsys, nx, ny, nz, int(spline_order),
-                                  int(bi is not None), C.dtype_code(pos.dtype), C.ptr(mesh), C.stream_of(pos))
-    C.check(rc, "mi_spline_spread")
+    mesh = _launch_spread(pos, vals, cit, bi, nsys, (nx, ny, nz), int(spline_order), bi is not None)
     return mesh if bi is not None else mesh[0]
 
 
