@@ -637,24 +637,24 @@ __global__ __launch_bounds__(D3_LS_WAVES * MI_WAVE) void d3_chain_kernel(const T
 #define D3_REDUCE_WAVES 256
 __global__ __launch_bounds__(256) void d3_reduce_kernel(const float* __restrict__ e_atom, const float* __restrict__ v_atom,
                                                         const int* __restrict__ batch_idx, int N, int want_virial,
-                                                        float* __restrict__ energy, float* __restrict__ virial) {
+                                                        double* __restrict__ sums /*[B][10], zeroed*/) {
   const int lane = threadIdx.x & (MI_WAVE - 1);
   const int wave = blockIdx.x * (blockDim.x / MI_WAVE) + threadIdx.x / MI_WAVE;
   const int chunks = (N + MI_WAVE - 1) / MI_WAVE;
   const int per = (chunks + D3_REDUCE_WAVES - 1) / D3_REDUCE_WAVES;
   const int c0 = wave * per, c1 = (c0 + per < chunks) ? c0 + per : chunks;
   int cur = -1;
-  float acc[10];
+  double acc[10];  // fp64 partial sums (the reference accumulates energies in fp64 and rounds once, dftd3.py:1031)
 #pragma unroll
-  for (int k = 0; k < 10; ++k) acc[k] = 0.0f;
+  for (int k = 0; k < 10; ++k) acc[k] = 0.0;
   auto flush = [&]() {
     if (cur < 0) return;
 #pragma unroll
     for (int k = 0; k < 10; ++k) {
       if (k > 0 && !want_virial) break;
-      const float v = wave_sum(acc[k]);
-      if (lane == 0) atomicAdd(k == 0 ? &energy[cur] : &virial[9 * (size_t)cur + (k - 1)], v);
-      acc[k] = 0.0f;
+      const double v = wave_sum(acc[k]);
+      if (lane == 0) atomicAdd(&sums[10 * (size_t)cur + k], v);
+      acc[k] = 0.0;
     }
   };
   for (int c = c0; c < c1; ++c) {
@@ -665,25 +665,33 @@ __global__ __launch_bounds__(256) void d3_reduce_kernel(const float* __restrict_
     if (__all(!in || s == s0)) {
       if (s0 != cur) { flush(); cur = s0; }
       if (in) {
-        acc[0] += e_atom[i];
-        if (want_virial) for (int k = 0; k < 9; ++k) acc[k + 1] += v_atom[9 * (size_t)i + k];
+        acc[0] += (double)e_atom[i];
+        if (want_virial) for (int k = 0; k < 9; ++k) acc[k + 1] += (double)v_atom[9 * (size_t)i + k];
       }
     } else if (in) {  // a chunk straddling systems: per-lane atomics
-      atomicAdd(&energy[s], e_atom[i]);
-      if (want_virial) for (int k = 0; k < 9; ++k) atomicAdd(&virial[9 * (size_t)s + k], v_atom[9 * (size_t)i + k]);
+      atomicAdd(&sums[10 * (size_t)s], (double)e_atom[i]);
+      if (want_virial) for (int k = 0; k < 9; ++k) atomicAdd(&sums[10 * (size_t)s + 1 + k], (double)v_atom[9 * (size_t)i + k]);
     }
   }
   flush();
 }
+__global__ void d3_finish_kernel(const double* __restrict__ sums, int B, int want_virial, float* __restrict__ energy, float* __restrict__ virial) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= 10 * B) return;
+  const int s = t / 10, k = t - 10 * s;
+  if (k == 0) energy[s] = (float)sums[t];
+  else if (want_virial) virial[9 * (size_t)s + (k - 1)] = (float)sums[t];
+}
 
-struct D3Layout { size_t dEdCN, e_atom, v_atom, tab, present, smap, sinfo, ctab, ftab, fcr, apos, aaux, aw, total; };
-D3Layout d3_layout(int N, int nz, int dtype) {
+struct D3Layout { size_t dEdCN, e_atom, v_atom, sums, tab, present, smap, sinfo, ctab, ftab, fcr, apos, aaux, aw, total; };
+D3Layout d3_layout(int N, int nz, int dtype, int B) {
   D3Layout L;
   size_t o = 0;
   auto take = [&](size_t b) { size_t at = o; o += mi_align(b); return at; };
   L.dEdCN = take(sizeof(float) * (size_t)N);
   L.e_atom = take(sizeof(float) * (size_t)N);
   L.v_atom = take(sizeof(float) * 9 * (size_t)N);
+  L.sums = take(sizeof(double) * 10 * (size_t)(B > 0 ? B : 1));
   L.tab = take(sizeof(float4) * (size_t)nz * nz * 25);
   L.present = take(sizeof(int) * (size_t)nz);
   L.smap = take(sizeof(int) * (size_t)nz);
@@ -756,7 +764,11 @@ int d3_impl(const T* pos, const int* numbers, int N, const int* idx, const int* 
   MI_TIMED("d3_chain", st, (d3_chain_kernel<T, CSR><<<mi_blocks(N, D3_LS_WAVES), D3_LS_WAVES * MI_WAVE, 0, st>>>(pos, numbers, N, idx, ush, nptr, M, fill_value, cell, batch_idx, P, apos, dEdCN,
                                                                             want_virial, forces, v_atom)));
   MI_LAUNCH_CHECK();
-  d3_reduce_kernel<<<D3_REDUCE_WAVES / 4, 256, 0, st>>>(e_atom, v_atom, batch_idx, N, want_virial, energy, virial);
+  double* sums = reinterpret_cast<double*>(ws + L.sums);
+  MI_HIP_CHECK(hipMemsetAsync(sums, 0, sizeof(double) * 10 * (size_t)B, st));
+  d3_reduce_kernel<<<D3_REDUCE_WAVES / 4, 256, 0, st>>>(e_atom, v_atom, batch_idx, N, want_virial, sums);
+  MI_LAUNCH_CHECK();
+  d3_finish_kernel<<<mi_blocks(10ll * B, 256), 256, 0, st>>>(sums, B, want_virial, energy, virial);
   MI_LAUNCH_CHECK();
   return MI_OK;
 }
@@ -766,9 +778,8 @@ int d3_impl(const T* pos, const int* numbers, int N, const int* idx, const int* 
 extern "C" {
 
 size_t mi_d3_workspace_bytes(int n_atoms, int n_systems, int nz) {
-  (void)n_systems;
-  if (n_atoms < 0 || nz < 1) return 0;
-  return d3_layout(n_atoms, nz, MI_F64).total;  // sized for the wider dtype
+  if (n_atoms < 0 || nz < 1 || n_systems < 1) return 0;
+  return d3_layout(n_atoms, nz, MI_F64, n_systems).total;  // sized for the wider dtype
 }
 
 int mi_d3(const void* positions, const int32_t* numbers, int n_atoms, int dtype, const int32_t* idx_j, const int32_t* unit_shifts,
@@ -781,7 +792,7 @@ int mi_d3(const void* positions, const int32_t* numbers, int n_atoms, int dtype,
   MI_REQUIRE(positions && numbers && idx_j && params && energy && forces && coord_num && workspace, "null pointer");
   MI_REQUIRE(params->rcov && params->r4r2 && params->c6ab && params->cn_ref && params->nz >= 2, "D3 parameter tables");
   MI_REQUIRE(!compute_virial || virial, "virial output");
-  D3Layout L = d3_layout(n_atoms, params->nz, dtype);
+  D3Layout L = d3_layout(n_atoms, params->nz, dtype, n_systems);
   if (workspace_bytes < L.total) { mi_set_error("workspace too small: %zu < %zu", workspace_bytes, L.total); return MI_EWORKSPACE; }
   hipStream_t st = (hipStream_t)stream;
   const bool csr = neighbor_ptr != nullptr;
