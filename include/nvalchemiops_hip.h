@@ -192,6 +192,9 @@ int mi_ewald_real_bwd(const void* positions, const void* charges, const void* ce
  * cardinal B-spline recursion (the reference returns 0 there: SURVEY F2).  mesh is [n_systems,nx,ny,nz].
  * `batched` selects the reference's batch-kernel weight threshold (w > 1e-8 instead of w > 0 in spread).
  */
+/* Per-system cell geometry for the mesh ops in one launch: cell_inv_t = (cell^-1)^T, reciprocal_cell = 2 pi cell^-1, volume = |det|
+ * (the torch.linalg.inv_ex / det calls of `_pme_reciprocal_space_impl`, pme.py:1382-1395).  All [n_systems,...] in `dtype`.       */
+int mi_cell_geometry(const void* cell, int n_systems, int dtype, void* cell_inv_t, void* reciprocal_cell, void* volume, void* stream);
 int mi_spline_spread(const void* positions, const void* values, const int32_t* batch_idx,
                      const void* cell_inv_t /*[n_systems,3,3]*/, int n_atoms, int n_systems, int nx, int ny,
                      int nz, int order, int batched, int dtype, void* mesh /* zeroed by caller */,

@@ -250,6 +250,24 @@ __global__ __launch_bounds__(256) void spread_tiled_kernel(const T* __restrict__
   }
 }
 
+// ---- per-system cell geometry in one launch: cell^-T (fractional-coordinate transform), 2 pi cell^-1 (reciprocal rows), |det|
+// (replaces torch.linalg.inv_ex + det + the elementwise glue of `_pme_reciprocal_space_impl`, pme.py:1382-1395: ~30 launches)
+template <class T>
+__global__ void cell_geometry_kernel(const T* __restrict__ cell, int B, T* __restrict__ cit, T* __restrict__ recip, T* __restrict__ vol) {
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= B) return;
+  const T* a = cell + 9 * (size_t)s;
+  T inv[9];
+  inverse3(a, inv);
+  const T det = a[0] * (a[4] * a[8] - a[5] * a[7]) - a[1] * (a[3] * a[8] - a[5] * a[6]) + a[2] * (a[3] * a[7] - a[4] * a[6]);
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < 3; ++c) {
+      cit[9 * (size_t)s + 3 * r + c] = inv[3 * c + r];
+      recip[9 * (size_t)s + 3 * r + c] = (T)(2.0 * M_PI) * inv[3 * r + c];
+    }
+  vol[s] = det < T(0) ? -det : det;
+}
+
 // ---- gathers (one thread per atom, z innermost) -----------------------------------------------------------
 // CH = 1: scalar mesh [B,nx,ny,nz] -> out[N];  CH = 3: interleaved mesh [B,nx,ny,nz,3] times charge -> out[N,3]
 template <class T, int CH>
@@ -506,6 +524,16 @@ int spread_tiled(const T* pos, const T* values, const int* batch_idx, const T* c
   } while (0)
 
 extern "C" {
+
+int mi_cell_geometry(const void* cell, int n_systems, int dtype, void* cell_inv_t, void* reciprocal_cell, void* volume, void* stream) {
+  MI_REQUIRE(dtype == MI_F32 || dtype == MI_F64, "dtype");
+  MI_REQUIRE(n_systems >= 1 && cell && cell_inv_t && reciprocal_cell && volume, "null pointer");
+  hipStream_t st = (hipStream_t)stream;
+  MI_DISPATCH_T(dtype, (cell_geometry_kernel<T_><<<mi_blocks(n_systems, 64), 64, 0, st>>>((const T_*)cell, n_systems, (T_*)cell_inv_t,
+                                                                                         (T_*)reciprocal_cell, (T_*)volume)));
+  MI_LAUNCH_CHECK();
+  return MI_OK;
+}
 
 size_t mi_spline_spread_workspace_bytes(int n_atoms, int n_systems, int nx, int ny, int nz) {
   if (n_atoms < 0 || n_systems < 1 || nx <= 0 || ny <= 0 || nz <= 0) return 0;

@@ -111,12 +111,12 @@ def _reciprocal_fused(pos, q, cells, alpha, mesh_dimensions, spline_order, bi, c
     nx, ny, nz = mesh_dimensions
     batched = bi is not None
     nsys = cells.shape[0] if batched else 1
-    cell_inv = torch.linalg.inv_ex(cells)[0]
-    cit = cell_inv.transpose(-1, -2).contiguous()
-    recip = (TWOPI * cell_inv).contiguous()
-    vol = torch.abs(torch.linalg.det(cells)).to(dt).contiguous()
-    al = alpha.to(dt).contiguous()
     st = C.stream_of(pos)
+    cc = cells.to(dt).contiguous()
+    cit, recip = torch.empty_like(cc), torch.empty_like(cc)
+    vol = torch.empty(cc.shape[0], dtype=dt, device=dev)
+    C.check(C.lib().mi_cell_geometry(C.ptr(cc), cc.shape[0], code, C.ptr(cit), C.ptr(recip), C.ptr(vol), st), "mi_cell_geometry")
+    al = alpha.to(dt).contiguous()
     mesh = _launch_spread(pos, q, cit, bi, nsys, (nx, ny, nz), int(spline_order), batched)
     spec = torch.fft.rfftn(mesh, norm="backward", dim=(1, 2, 3))  # unscaled forward (pme.py:1398)
     nch = 4 if compute_forces else 1
