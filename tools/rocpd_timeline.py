@@ -5,7 +5,7 @@ import sqlite3
 import sys
 
 
-def main(db_path, anchor="nl_setup", count=70):
+def main(db_path, anchor="nl_setup", count=70, queue=None):
     db = sqlite3.connect(db_path)
     rows = db.execute("select d.start, d.end, d.queue_id, s.kernel_name from rocpd_kernel_dispatch d join rocpd_info_kernel_symbol s "
                       "on d.kernel_id = s.id order by d.start").fetchall()
@@ -13,7 +13,13 @@ def main(db_path, anchor="nl_setup", count=70):
     idx = [k for k, r in enumerate(rows) if anchor in r[3]]
     k0 = idx[-4] if len(idx) >= 4 else (idx[0] if idx else 0)
     t0 = rows[k0][0]
-    for st, en, q, name in rows[k0:k0 + int(count)]:
+    shown = 0
+    for st, en, q, name in rows[k0:]:
+        if queue is not None and str(q) != str(queue):
+            continue
+        shown += 1
+        if shown > int(count):
+            break
         m = re.search(r"(\w+)(<[^>]*>)?\(", name.replace("(anonymous namespace)::", ""))
         short = (m.group(1) if m else name)[:38]
         print(f"{(st - t0) / 1e3:9.1f} {(en - t0) / 1e3:9.1f} {(en - st) / 1e3:8.1f} us  q{q}  {short}")
