@@ -9,12 +9,15 @@
 //     thread looping over a row; per-lane fp64 partial sums are combined with cross-lane shuffles at the end.
 //   * pass 0 of the reference (materialised cartesian_shifts, 12 B per slot written then read 3x) is gone:
 //     S.cell is evaluated in registers in the positions dtype (`_unit_shift_to_cartesian`, :734).
-//   * {c6, cn_ref_i, cn_ref_j^T} are re-packed once per call into one float4 per (Zi,Zj,p,q); the species actually present
-//     are compacted on the device (no host sync) and each wave stages the <= 16 x 25 float4 rows of ITS element in LDS,
-//     so the 25-term Gaussian interpolation reads ds_read_b128 (conflict-free: 400 B row stride) instead of chasing
-//     dependent global gathers; the term loop is branch-free (selects), exponent arguments stay in registers.
-//   * per-system energy / virial: per-atom values + wave-aggregated atomics (one atomic per 64 atoms) instead of one
-//     atomic per atom on B hot addresses.
+//   * the species actually present are compacted on the device (no host sync).  If their tables have Grimme's structure
+//     (reference CN a property of (Z, ref index), rectangular validity -- checked bit by bit on the device) the Gaussian
+//     weight factorises into per-atom halves u_a(i) v_b(j): u is wave-uniform, v is evaluated once per atom after the CN pass
+//     and gathered with the neighbour record, and the pair loop holds no exponential at all; the c6 rows and BJ constants of
+//     the wave's element sit in a 2.8 KB LDS slice.  Other tables run the general 25-term form from an LDS-staged
+//     {c6, cn_ref_i, cn_ref_j^T} float4 table (branch-free, selects), or from the global table above 16 species.
+//   * cn / chain walks: 8 waves per block in lock-step (one barrier per trip) so that consecutive atoms share the cache lines
+//     their gathers pull into L1; all walks are software-pipelined three deep with predicated (not branched) validity.
+//   * per-system energy / virial: per-atom values, fp64 slab sums, one atomic per system change per wave, rounded once.
 #include "common.h"
 
 namespace {

@@ -16,7 +16,12 @@
 //            compacted with __ballot/__popcll and written to the row owner's slots (coalesced, no atomics,
 //            deterministic order); the owner also writes the padding => no separate torch.full pass.
 //
-// The same query kernel serves the padded matrix, the count pass and the direct CSR/COO fill.
+//   query'   dense cells (large cutoffs): ONE BLOCK PER CELL, cells handed out through an atomic counter; the candidate stream
+//            of the cell is staged tile-wise in LDS, two centre atoms per wave share each candidate fetched, runs are ordered
+//            by periodic image so that S.cell is a per-64-group constant.  Both query kernels are launched, a device flag
+//            written by `setup` decides which one works (no host sync).
+//
+// The same query kernels serve the padded matrix, the count pass and the direct CSR/COO fill.
 #include <hipcub/hipcub.hpp>
 
 #include "common.h"
