@@ -363,8 +363,11 @@ typedef float d3_f2 __attribute__((ext_vector_type(2)));
 // Reference points that do not exist carry c_j(b) = D3_NOREF in `fcr`, so (CN_j - c)^2 overflows to +inf and k3 * inf = -inf
 // masks them (the factorised path is only selected for k3 < 0); weights below e^-12 are stored as exact zeros.
 #define D3_NOREF 1.0e30f
+// fp32 positions: the record is {x, y, z, v_4 | v_0, v_1, v_2, v_3} with the 4-bit species id in the two spare top bits of v_0 and v_1
+// (weights are in [0, 1]: sign and top exponent bit are always clear), so the energy pass gathers 32 bytes per neighbour instead
+// of 16 (position) + 32 (weights): that pass is bound by its per-neighbour gathers once the exponentials are gone.
 __global__ void d3_weights_kernel(const float* __restrict__ cn, const float4* __restrict__ aaux, const D3Species* __restrict__ sinfo,
-                                  const float* __restrict__ fcr, float k3, int N, float4* __restrict__ aw) {
+                                  const float* __restrict__ fcr, float k3, int N, const float4* __restrict__ apos_f32, float4* __restrict__ aw) {
   if (!sinfo->factorized || sinfo->S > D3_SMAX) return;
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= N) return;
@@ -386,6 +389,14 @@ __global__ void d3_weights_kernel(const float* __restrict__ cn, const float4* __
       const bool keep = Bp >= -12.0f;  // false for -inf and NaN (no populated point at all)
       v[b] = keep ? d3_exp_neg(keep ? Bp : 0.0f) : 0.0f;
     }
+  }
+  if (apos_f32) {
+    const float4 p = apos_f32[j];
+    const int s4 = sj < D3_SMAX ? sj : 0;  // padding atoms: all weights are zero, any table row will do
+    aw[2 * (size_t)j] = make_float4(p.x, p.y, p.z, v[4]);
+    aw[2 * (size_t)j + 1] = make_float4(__int_as_float(__float_as_int(v[0]) | ((s4 & 3) << 30)), __int_as_float(__float_as_int(v[1]) | ((s4 >> 2) << 30)),
+                                        v[2], v[3]);
+    return;
   }
   aw[2 * (size_t)j] = make_float4(v[0], v[1], v[2], v[3]);
   aw[2 * (size_t)j + 1] = make_float4(v[4], a.y, a.z, 0.0f);
@@ -436,6 +447,7 @@ __global__ __launch_bounds__(256) void d3_energy_kernel(const T* __restrict__ po
                                                         const float4* __restrict__ aw, float* __restrict__ dEdCN,
                                                         float* __restrict__ forces, float* __restrict__ e_atom, float* __restrict__ v_atom) {
   constexpr bool LDS = MODE == 1;
+  constexpr bool PACKED = MODE == 2 && sizeof(T) == 4;  // one 32-byte record per neighbour (see d3_weights_kernel)
   constexpr int WAVE_F4 = MODE == 1 ? D3_SMAX * 25 : MODE == 2 ? D3_SMAX * D3_FROW / 4 : 1;  // float4 per wave
   __shared__ float4 lds_tab[MODE == 0 ? 1 : 4][WAVE_F4];
   const int S = sinfo->S;
@@ -478,32 +490,50 @@ __global__ __launch_bounds__(256) void d3_energy_kernel(const T* __restrict__ po
   long long e = beg + lane;
   D3Step s0 = d3_fetch(idx, ush3, e, end, periodic), s1 = d3_fetch(idx, ush3, e + MI_WAVE, end, periodic);
   bool v0 = s0.in && (CSR || s0.j < fill_value);
-  auto p0 = apos[v0 ? s0.j : i];
-  // per-neighbour record: MODE 0/1 {CN_j, r4r2_j, Z_j << 8 | species id} (aaux); MODE 2 the 32-byte weight record (aw)
+  using PosRec = typename Vec4<T>::type;
+  auto pos_of = [&](int j) -> PosRec {
+    if constexpr (PACKED) return aw[2 * (size_t)j];
+    else return apos[j];
+  };
+  // per-neighbour data besides the position: MODE 0/1 {CN_j, r4r2_j, Z_j << 8 | species id} (aaux); MODE 2 the weight record
+  // (fp64 positions: two float4 of aw; fp32 positions: the second half of the packed record)
   auto aux_of = [&](int j, float4& lo, float4& hi4) {
-    if (MODE == 2) { lo = aw[2 * (size_t)j]; hi4 = aw[2 * (size_t)j + 1]; }
+    if (PACKED) { lo = aw[2 * (size_t)j + 1]; hi4 = lo; }
+    else if (MODE == 2) { lo = aw[2 * (size_t)j]; hi4 = aw[2 * (size_t)j + 1]; }
     else { lo = aaux[j]; hi4 = lo; }
   };
+  PosRec p0 = pos_of(v0 ? s0.j : i);
   float4 a0, b0;
   aux_of(v0 ? s0.j : i, a0, b0);
   for (long long base = beg; base < end; base += MI_WAVE) {
     e += MI_WAVE;
     const D3Step s2 = d3_fetch(idx, ush3, e + MI_WAVE, end, periodic);
     const bool v1 = s1.in && (CSR || s1.j < fill_value);
-    const auto p1 = apos[v1 ? s1.j : i];
+    const PosRec p1 = pos_of(v1 ? s1.j : i);
     float4 a1, b1;
     aux_of(v1 ? s1.j : i, a1, b1);
     if (__any(v0)) {
-      bool valid = v0 && !(p0.w < (T)0);  // padding atom (Z == 0)
+      bool valid = v0 && (PACKED || !(p0.w < (T)0));  // padding atom (Z == 0); the packed record marks it by all-zero weights
       const PairGeom<T> g = d3_geom<T>(p0, pix, piy, piz, s0.sh, cm, periodic);
       valid = valid && g.ok;
-      const int code = valid ? __float_as_int(MODE == 2 ? b0.z : a0.z) : code_i;
-      const float r4r2_j = MODE == 2 ? b0.y : a0.y;
-      float c6, dci;
+      float c6, dci, r4r2_j = 0.0f;
+      int code;
       if (MODE == 2) {
-        const float vj[5] = {a0.x, a0.y, a0.z, a0.w, b0.x};
-        d3_c6_fact(hi, vj, my_f + (code & 0xff) * D3_FROW, P.k3, c6, dci);
+        float vj[5];
+        int sj;
+        if (PACKED) {
+          const int w0 = __float_as_int(a0.x), w1 = __float_as_int(a0.y);
+          sj = ((w0 >> 30) & 3) | (((w1 >> 30) & 3) << 2);
+          vj[0] = __int_as_float(w0 & 0x3fffffff); vj[1] = __int_as_float(w1 & 0x3fffffff); vj[2] = a0.z; vj[3] = a0.w; vj[4] = (float)p0.w;
+        } else {
+          sj = __float_as_int(b0.z) & 0xff;
+          vj[0] = a0.x; vj[1] = a0.y; vj[2] = a0.z; vj[3] = a0.w; vj[4] = b0.x;
+        }
+        code = valid ? sj : (code_i & 0xff);
+        d3_c6_fact(hi, vj, my_f + code * D3_FROW, P.k3, c6, dci);
       } else {
+        code = valid ? __float_as_int(a0.z) : code_i;
+        r4r2_j = a0.y;
         d3_c6(cn_i, a0.x, LDS ? my_tab + (code & 0xff) * 25 : tab_i + (size_t)(code >> 8) * 25, P.k3, c6, dci);
       }
       valid = valid && !(c6 < 1e-12f);
@@ -511,7 +541,7 @@ __global__ __launch_bounds__(256) void d3_energy_kernel(const T* __restrict__ po
       const float r = valid ? g.r : 1.0f;
       float q, r06, r08;
       if (MODE == 2) {  // species-pair constants staged with the c6 rows
-        const float4 bj = *reinterpret_cast<const float4*>(my_f + (code & 0xff) * D3_FROW + 40);
+        const float4 bj = *reinterpret_cast<const float4*>(my_f + code * D3_FROW + 40);
         q = bj.x; r06 = bj.y; r08 = bj.z;
       } else {
         q = 3.0f * r4r2_i * r4r2_j;
@@ -754,7 +784,8 @@ int d3_impl(const T* pos, const int* numbers, int N, const int* idx, const int* 
   const int blocks = mi_blocks(N, 4);
   MI_TIMED("d3_cn", st, (d3_cn_kernel<T, CSR><<<mi_blocks(N, D3_LS_WAVES), D3_LS_WAVES * MI_WAVE, 0, st>>>(pos, numbers, N, idx, ush, nptr, M, fill_value, cell, batch_idx, P, apos, aaux, cn)));
   MI_LAUNCH_CHECK();
-  d3_weights_kernel<<<mi_blocks(N, 256), 256, 0, st>>>(cn, aaux, sinfo, fcr, hp->k3, N, aw);
+  d3_weights_kernel<<<mi_blocks(N, 256), 256, 0, st>>>(cn, aaux, sinfo, fcr, hp->k3, N,
+                                                       sizeof(T) == 4 ? reinterpret_cast<const float4*>(apos) : nullptr, aw);
   MI_LAUNCH_CHECK();
 #define MI_D3_ENERGY(MODE_)                                                                                                                    \
   d3_energy_kernel<T, CSR, MODE_><<<blocks, 256, 0, st>>>(pos, numbers, N, idx, ush, nptr, M, fill_value, cell, batch_idx, P, cn, want_virial, \
