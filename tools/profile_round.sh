@@ -10,7 +10,7 @@ python $R/bench.py > $OUT/bench.json 2> $OUT/bench.err
 python $R/bench.py --overlap 0 --cpu-sample 0 > $OUT/bench_serial.json 2>> $OUT/bench.err
 # kernel-trace statistics of the SAME command as bench.json (default flags) and of the serial variant
 rm -rf /tmp/prof_stats /tmp/prof_stats_serial
-rocprofv3 --kernel-trace --stats -d /tmp/prof_stats -- python $R/bench.py --cpu-sample 0 > /tmp/prof_stats.log 2>&1
+rocprofv3 --kernel-trace --stats -d /tmp/prof_stats -- python $R/bench.py --cpu-sample 0 > $OUT/bench_under_rocprof.json 2> /tmp/prof_stats.log
 python $R/tools/rocpd_stats.py $(find /tmp/prof_stats -name "*.db" | head -1) $OUT/kernel_stats.csv 2>&1 | tail -2
 rocprofv3 --kernel-trace --stats -d /tmp/prof_stats_serial -- python $R/bench.py --cpu-sample 0 --overlap 0 > /tmp/prof_stats_serial.log 2>&1
 python $R/tools/rocpd_stats.py $(find /tmp/prof_stats_serial -name "*.db" | head -1) $OUT/kernel_stats_serial.csv 2>&1 | tail -2
