@@ -18,6 +18,8 @@
 //   * cn / chain walks: 8 waves per block in lock-step (one barrier per trip) so that consecutive atoms share the cache lines
 //     their gathers pull into L1; all walks are software-pipelined three deep with predicated (not branched) validity.
 //   * per-system energy / virial: per-atom values, fp64 slab sums, one atomic per system change per wave, rounded once.
+#include <type_traits>
+
 #include "common.h"
 
 namespace {
@@ -437,7 +439,7 @@ __device__ __forceinline__ void d3_c6_fact(const D3Half& h, const float* v, cons
 // MODE 0: global [nz,nz,25] table (> 16 species); 1: general 25-term interpolation from the LDS-staged compact table;
 // 2: factorised interpolation.  All three are launched; the two that do not match the device-side species info exit at once.
 template <class T, bool CSR, int MODE>
-__global__ __launch_bounds__(256) void d3_energy_kernel(const T* __restrict__ pos, const int* __restrict__ numbers, int N, const int* __restrict__ idx,
+__device__ __forceinline__ void d3_energy_body(const T* __restrict__ pos, const int* __restrict__ numbers, int N, const int* __restrict__ idx,
                                                         const int* __restrict__ ush, const int* __restrict__ nptr, int M, int fill_value,
                                                         const T* __restrict__ cell, const int* __restrict__ batch_idx, D3Dev P,
                                                         const float* __restrict__ cn, int want_virial, const int* __restrict__ smap,
@@ -484,7 +486,8 @@ __global__ __launch_bounds__(256) void d3_energy_kernel(const T* __restrict__ po
   long long beg, end;
   d3_row<T, CSR>(i, M, nptr, beg, end);
   double Fx = 0, Fy = 0, Fz = 0, E = 0;
-  double V[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  // virial: f (x) r is symmetric (f is parallel to r) -> six components; fp32 lane partials (~40 terms each), fp64 across lanes
+  float V[6] = {0, 0, 0, 0, 0, 0};  // xx xy xz yy yz zz
   double dacc = 0.0;
   const Int3* __restrict__ ush3 = reinterpret_cast<const Int3*>(ush);
   long long e = beg + lane;
@@ -567,18 +570,18 @@ __global__ __launch_bounds__(256) void d3_energy_kernel(const T* __restrict__ po
       E += (double)esw;
       dacc += valid ? (double)(-damp * dci) : 0.0;
       if (want_virial) {
-        V[0] += (double)(fx * g.rx); V[1] += (double)(fx * g.ry); V[2] += (double)(fx * g.rz);
-        V[3] += (double)(fy * g.rx); V[4] += (double)(fy * g.ry); V[5] += (double)(fy * g.rz);
-        V[6] += (double)(fz * g.rx); V[7] += (double)(fz * g.ry); V[8] += (double)(fz * g.rz);
+        V[0] += fx * g.rx; V[1] += fx * g.ry; V[2] += fx * g.rz;
+        V[3] += fy * g.ry; V[4] += fy * g.rz; V[5] += fz * g.rz;
       }
     }
     s0 = s1; v0 = v1; p0 = p1; a0 = a1; b0 = b1; s1 = s2;
   }
   Fx = wave_sum(Fx); Fy = wave_sum(Fy); Fz = wave_sum(Fz); E = wave_sum(E);
   dacc = wave_sum(dacc);
+  double V6[6];
   if (want_virial) {
 #pragma unroll
-    for (int k = 0; k < 9; ++k) V[k] = wave_sum(V[k]);
+    for (int k = 0; k < 6; ++k) V6[k] = wave_sum((double)V[k]);
   }
   if (lane == 0) {
     forces[3 * (size_t)i] = (float)Fx; forces[3 * (size_t)i + 1] = (float)Fy; forces[3 * (size_t)i + 2] = (float)Fz;
@@ -586,12 +589,27 @@ __global__ __launch_bounds__(256) void d3_energy_kernel(const T* __restrict__ po
     e_atom[i] = 0.5f * (float)E;
   }
   if (want_virial && lane < 9) {
-    double v = V[0];
+    const int r = lane / 3, c = lane - 3 * r, lo = r < c ? r : c, hi2 = r < c ? c : r;
+    const int m = lo == 0 ? hi2 : (lo == 1 ? hi2 + 2 : 5);  // row-major (r, c) -> index in {xx, xy, xz, yy, yz, zz}
+    double v = V6[0];
 #pragma unroll
-    for (int k = 1; k < 9; ++k) v = lane == k ? V[k] : v;
+    for (int q = 1; q < 6; ++q) v = m == q ? V6[q] : v;
     v_atom[9 * (size_t)i + lane] = -0.5f * (float)v;
   }
 }
+
+
+#define D3_ENERGY_PARAMS const T* __restrict__ pos, const int* __restrict__ numbers, int N, const int* __restrict__ idx, const int* __restrict__ ush, const int* __restrict__ nptr, int M, int fill_value, const T* __restrict__ cell, const int* __restrict__ batch_idx, D3Dev P, const float* __restrict__ cn, int want_virial, const int* __restrict__ smap, const D3Species* __restrict__ sinfo, const float4* __restrict__ ctab, const float* __restrict__ ftab, const float* __restrict__ fcr, const typename Vec4<T>::type* __restrict__ apos, const float4* __restrict__ aaux, const float4* __restrict__ aw, float* __restrict__ dEdCN, float* __restrict__ forces, float* __restrict__ e_atom, float* __restrict__ v_atom
+template <class T, bool CSR, int MODE>
+__global__ __launch_bounds__(256) void d3_energy_kernel(D3_ENERGY_PARAMS) {
+  d3_energy_body<T, CSR, MODE>(pos, numbers, N, idx, ush, nptr, M, fill_value, cell, batch_idx, P, cn, want_virial, smap, sinfo, ctab, ftab, fcr, apos, aaux, aw, dEdCN, forces, e_atom, v_atom);
+}
+// the fp32 factorised variant fits 96 VGPRs without spilling: ask for 5 waves per SIMD (the others would spill)
+template <class T, bool CSR, int MODE>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) void d3_energy_kernel_w5(D3_ENERGY_PARAMS) {
+  d3_energy_body<T, CSR, MODE>(pos, numbers, N, idx, ush, nptr, M, fill_value, cell, batch_idx, P, cn, want_virial, smap, sinfo, ctab, ftab, fcr, apos, aaux, aw, dEdCN, forces, e_atom, v_atom);
+}
+#undef D3_ENERGY_PARAMS
 
 // ---- pass 3: chain-rule force through the coordination numbers ---------------------------------------
 template <class T, bool CSR>
@@ -787,14 +805,21 @@ int d3_impl(const T* pos, const int* numbers, int N, const int* idx, const int* 
   d3_weights_kernel<<<mi_blocks(N, 256), 256, 0, st>>>(cn, aaux, sinfo, fcr, hp->k3, N,
                                                        sizeof(T) == 4 ? reinterpret_cast<const float4*>(apos) : nullptr, aw);
   MI_LAUNCH_CHECK();
-#define MI_D3_ENERGY(MODE_)                                                                                                                    \
-  d3_energy_kernel<T, CSR, MODE_><<<blocks, 256, 0, st>>>(pos, numbers, N, idx, ush, nptr, M, fill_value, cell, batch_idx, P, cn, want_virial, \
-                                                          smap, sinfo, ctab, ftab, fcr, apos, aaux, aw, dEdCN, forces, e_atom, v_atom)
-  MI_TIMED("d3_energy", st, (MI_D3_ENERGY(2), MI_D3_ENERGY(1)));
+  // all three variants are launched; two of them exit at once on the device-side species info.  Only the fp32 factorised variant
+  // is instantiated with the 5-waves-per-SIMD register cap (the others would spill under it).
+  auto launch_energy = [&](auto mode) {
+    constexpr int MODE_ = decltype(mode)::value;
+    if constexpr (MODE_ == 2 && sizeof(T) == 4)
+      d3_energy_kernel_w5<T, CSR, MODE_><<<blocks, 256, 0, st>>>(pos, numbers, N, idx, ush, nptr, M, fill_value, cell, batch_idx, P, cn, want_virial,
+                                                                smap, sinfo, ctab, ftab, fcr, apos, aaux, aw, dEdCN, forces, e_atom, v_atom);
+    else
+      d3_energy_kernel<T, CSR, MODE_><<<blocks, 256, 0, st>>>(pos, numbers, N, idx, ush, nptr, M, fill_value, cell, batch_idx, P, cn, want_virial,
+                                                             smap, sinfo, ctab, ftab, fcr, apos, aaux, aw, dEdCN, forces, e_atom, v_atom);
+  };
+  MI_TIMED("d3_energy", st, (launch_energy(std::integral_constant<int, 2>{}), launch_energy(std::integral_constant<int, 1>{})));
   MI_LAUNCH_CHECK();
-  MI_D3_ENERGY(0);
+  launch_energy(std::integral_constant<int, 0>{});
   MI_LAUNCH_CHECK();
-#undef MI_D3_ENERGY
   MI_TIMED("d3_chain", st, (d3_chain_kernel<T, CSR><<<mi_blocks(N, D3_LS_WAVES), D3_LS_WAVES * MI_WAVE, 0, st>>>(pos, numbers, N, idx, ush, nptr, M, fill_value, cell, batch_idx, P, apos, dEdCN,
                                                                             want_virial, forces, v_atom)));
   MI_LAUNCH_CHECK();
