@@ -18,7 +18,7 @@ from nvalchemiops.neighborlist import _engine as E
 from nvalchemiops.neighborlist.batch_cell_list import batch_cell_list
 from nvalchemiops.neighborlist.batch_naive import batch_naive_neighbor_list
 from nvalchemiops.neighborlist.batch_naive_dual_cutoff import batch_naive_neighbor_list_dual_cutoff
-from nvalchemiops.neighborlist.cell_list import _empty_result, _search, cell_list
+from nvalchemiops.neighborlist.cell_list import _empty_result, cell_list
 from nvalchemiops.neighborlist.naive import _bounding_cell, naive_neighbor_list
 from nvalchemiops.neighborlist.naive_dual_cutoff import naive_neighbor_list_dual_cutoff
 from nvalchemiops.neighborlist.neighbor_utils import (_prepare_batch_idx_ptr, estimate_max_neighbors,
