@@ -196,3 +196,23 @@ def test_custom_ops_registered_under_reference_names():
         op = getattr(torch.ops.nvalchemiops, name)
         schema = str(op.default._schema)
         assert "-> ()" in schema and "Tensor(a" in schema, schema  # mutating ops returning None, as in the reference
+
+
+def test_public_signatures_match_reference():
+    """Drop-in boundary: every public function on the path has the reference's argument names, order and defaults
+    (tests/golden/reference_signatures.json, written by tests/golden/make_signatures.py from the reference sources)."""
+    import importlib.util
+    import json
+
+    here = os.path.dirname(os.path.abspath(__file__))
+    spec = importlib.util.spec_from_file_location("make_signatures", os.path.join(here, "golden", "make_signatures.py"))
+    ms = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ms)
+    want = json.load(open(os.path.join(here, "golden", "reference_signatures.json")))
+    mine = os.path.join(os.path.dirname(here), "nvalchemi-toolkit-ops_amd", "nvalchemiops") + os.sep
+    checked = 0
+    for rel, funcs in want.items():
+        for name, sig in funcs.items():
+            assert ms.signature(mine + rel, name) == sig, f"{rel}:{name} differs from the reference signature"
+            checked += 1
+    assert checked == 39
