@@ -32,7 +32,11 @@ struct D3Dev {
   float a1, a2, s6, s8, k1, k3, s5_on, s5_off, inv_w;
 };
 
-__global__ void d3_pack_tables_kernel(const float* __restrict__ c6ab, const float* __restrict__ cnref, int nz, float4* __restrict__ tab) {
+struct D3Species;
+__device__ __forceinline__ int d3_species_count(const D3Species* info);
+__global__ void d3_pack_tables_kernel(const float* __restrict__ c6ab, const float* __restrict__ cnref, int nz, const D3Species* __restrict__ info,
+                                      float4* __restrict__ tab) {
+  if (d3_species_count(info) <= 16) return;  // the global table is only read by the > 16 species variant of the energy pass
   const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const long long total = (long long)nz * nz * 25;
   if (t >= total) return;
@@ -54,9 +58,14 @@ struct Int3 { int a, b, c; };  // one 12-byte (dwordx3) load per pair for the un
 template <class T>
 __global__ void d3_pack_atoms_kernel(const T* __restrict__ pos, const int* __restrict__ numbers, int N, const float* __restrict__ rcov,
                                      const float* __restrict__ r4r2, const int* __restrict__ smap, int nz,
-                                     typename Vec4<T>::type* __restrict__ apos, float4* __restrict__ aaux) {
+                                     typename Vec4<T>::type* __restrict__ apos, float4* __restrict__ aaux, float* __restrict__ forces,
+                                     float* __restrict__ cn, float* __restrict__ dEdCN, float* __restrict__ e_atom, float* __restrict__ v_atom) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= N) return;
+  forces[3 * (size_t)i] = forces[3 * (size_t)i + 1] = forces[3 * (size_t)i + 2] = 0.0f;  // outputs of atoms the passes skip (Z == 0)
+  cn[i] = dEdCN[i] = e_atom[i] = 0.0f;
+  if (v_atom)
+    for (int k = 0; k < 9; ++k) v_atom[9 * (size_t)i + k] = 0.0f;
   const int z = numbers[i];
   const bool real = z > 0 && z < nz;
   typename Vec4<T>::type r;
@@ -206,6 +215,7 @@ __device__ __forceinline__ void d3_s5(float r, float on, float off, float inv_w,
 #define D3_SMAX 16  // species held in LDS per wave (16 x 25 float4 = 6.4 KB); more species fall back to the global table
 
 struct D3Species { int S; int factorized; int pad[2]; };
+__device__ __forceinline__ int d3_species_count(const D3Species* info) { return info->S; }
 #define D3_FROW 44  // factorised block per partner species: 5 c6 rows x 8 floats (b = 0..4 used) + {q, r0^6, r0^8, 0} of the BJ damping
 
 __global__ void d3_mark_species_kernel(const int* __restrict__ numbers, int N, int nz, int* __restrict__ present) {
@@ -779,25 +789,18 @@ int d3_impl(const T* pos, const int* numbers, int N, const int* idx, const int* 
   P.a1 = hp->a1; P.a2 = hp->a2; P.s6 = hp->s6; P.s8 = hp->s8; P.k1 = hp->k1; P.k3 = hp->k3; P.s5_on = hp->s5_on; P.s5_off = hp->s5_off;
   // inv_w in double on the host, then cast (dftd3.py:1983-1986)
   P.inv_w = (hp->s5_off > hp->s5_on) ? (float)(1.0 / ((double)hp->s5_off - (double)hp->s5_on)) : 0.0f;
-  // outputs are zeroed like the reference wrapper does (dftd3.py:1933-1936); atoms with Z == 0 keep zeros
-  MI_HIP_CHECK(hipMemsetAsync(energy, 0, sizeof(float) * (size_t)B, st));
-  MI_HIP_CHECK(hipMemsetAsync(forces, 0, sizeof(float) * 3 * (size_t)N, st));
-  MI_HIP_CHECK(hipMemsetAsync(cn, 0, sizeof(float) * (size_t)N, st));
-  MI_HIP_CHECK(hipMemsetAsync(dEdCN, 0, sizeof(float) * (size_t)N, st));
-  MI_HIP_CHECK(hipMemsetAsync(e_atom, 0, sizeof(float) * (size_t)N, st));
-  if (want_virial) {
-    MI_HIP_CHECK(hipMemsetAsync(virial, 0, sizeof(float) * 9 * (size_t)B, st));
-    MI_HIP_CHECK(hipMemsetAsync(v_atom, 0, sizeof(float) * 9 * (size_t)N, st));
-  }
-  const long long nt = (long long)hp->nz * hp->nz * 25;
-  d3_pack_tables_kernel<<<mi_blocks(nt, 256), 256, 0, st>>>(hp->c6ab, hp->cn_ref, hp->nz, tab);
-  MI_LAUNCH_CHECK();
+  // outputs are zeroed like the reference wrapper does (dftd3.py:1933-1936; atoms with Z == 0 keep zeros): the per-atom arrays by
+  // the pack kernel below, energy / virial are written for every system by the finish kernel
   MI_HIP_CHECK(hipMemsetAsync(present, 0, sizeof(int) * (size_t)hp->nz, st));
   d3_mark_species_kernel<<<mi_blocks(N, 256), 256, 0, st>>>(numbers, N, hp->nz, present);
   MI_LAUNCH_CHECK();
   d3_compact_species_kernel<<<1, 256, 0, st>>>(present, hp->c6ab, hp->cn_ref, hp->nz, smap, sinfo, ctab, ftab, fcr, hp->k3, hp->r4r2, hp->a1, hp->a2);
   MI_LAUNCH_CHECK();
-  d3_pack_atoms_kernel<T><<<mi_blocks(N, 256), 256, 0, st>>>(pos, numbers, N, hp->rcov, hp->r4r2, smap, hp->nz, apos, aaux);
+  const long long nt = (long long)hp->nz * hp->nz * 25;
+  d3_pack_tables_kernel<<<mi_blocks(nt, 256), 256, 0, st>>>(hp->c6ab, hp->cn_ref, hp->nz, sinfo, tab);  // only works for > 16 species
+  MI_LAUNCH_CHECK();
+  d3_pack_atoms_kernel<T><<<mi_blocks(N, 256), 256, 0, st>>>(pos, numbers, N, hp->rcov, hp->r4r2, smap, hp->nz, apos, aaux, forces, cn, dEdCN, e_atom,
+                                                             want_virial ? v_atom : nullptr);
   MI_LAUNCH_CHECK();
   const int blocks = mi_blocks(N, 4);
   MI_TIMED("d3_cn", st, (d3_cn_kernel<T, CSR><<<mi_blocks(N, D3_LS_WAVES), D3_LS_WAVES * MI_WAVE, 0, st>>>(pos, numbers, N, idx, ush, nptr, M, fill_value, cell, batch_idx, P, apos, aaux, cn)));
