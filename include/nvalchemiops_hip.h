@@ -186,6 +186,28 @@ int mi_ewald_real_bwd(const void* positions, const void* charges, const void* ce
                       void* grad_positions /*[n_atoms,3] dtype*/, void* grad_charges /*[n_atoms] dtype*/,
                       double* grad_cell, double* grad_alpha, void* stream);
 
+/* ---- cut-off Coulomb ---------------------------------------------------------------------------
+ * Replaces the eight alchemiops::_[batch_]coulomb_energy[_forces]_{list,matrix} ops (interactions/electrostatics/coulomb.py:716-1330;
+ * kernels :133-708).  float64 only, as the reference upcasts before the launch (:1423-1426).  Pair term over each stored entry
+ * (i, j): r_ij = r_i - r_j - cell^T S, skipped when r >= cutoff or r < 1e-10; phi = erfc_AS(alpha r)/r for alpha > 0, else 1/r.
+ *   energies[i] = energy_prefactor * sum_j q_i q_j phi          (plain store; the reference atomically adds into zeros)
+ *   forces      : += f_ij on i and -= f_ij on j with f_ij = 1/2 q_i q_j (-phi'(r)/r) r_ij -- the reference's scatter, valid for
+ *                 full, half and asymmetric lists (fp64 atomics).  NULL = energy only.  Zeroed by the library.
+ * CSR when neighbor_ptr != NULL (idx_j = neighbor_list[1]); otherwise a [n_atoms,max_neighbors] matrix whose entries
+ * j >= fill_value or j >= n_atoms are padding (:325).  energy_prefactor is 0.5 for every reference kernel except the energy-only
+ * matrix kernels, which omit the 1/2 (:340, :623): the caller passes 1.0 for those to stay result-identical.
+ * mi_coulomb_bwd is the adjoint of `energies` for L = sum_i g_i E_i w.r.t. positions / charges / cell (replaces the Warp-tape
+ * backward, coulomb.py:716-1330 via autograd.py:525-665); outputs float64, zeroed by the library.                           */
+int mi_coulomb(const double* positions, const double* charges, const double* cell /*[n_systems,3,3]*/, const int32_t* batch_idx,
+               int n_atoms, const int32_t* idx_j, const int32_t* unit_shifts, const int32_t* neighbor_ptr, int max_neighbors,
+               int fill_value, double cutoff, double alpha, double energy_prefactor, double* energies /*[n_atoms]*/,
+               double* forces /*[n_atoms,3] or NULL*/, void* stream);
+int mi_coulomb_bwd(const double* positions, const double* charges, const double* cell, const int32_t* batch_idx, int n_atoms,
+                   int n_systems, const int32_t* idx_j, const int32_t* unit_shifts, const int32_t* neighbor_ptr, int max_neighbors,
+                   int fill_value, double cutoff, double alpha, double energy_prefactor, const double* grad_energies /*[n_atoms]*/,
+                   double* grad_positions /*[n_atoms,3]*/, double* grad_charges /*[n_atoms]*/, double* grad_cell /*[n_systems,3,3]*/,
+                   void* stream);
+
 /* ---- B-spline spread / gather ---------------------------------------------------------------
  * Replaces alchemiops::_[batch_]spline_spread / _gather / _gather_vec3 (spline.py:1500-2107; kernels
  * :497-676, :763-959).  Orders 1-4 use the reference's piecewise polynomials; orders 5-6 use the true

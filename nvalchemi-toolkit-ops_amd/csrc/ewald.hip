@@ -221,6 +221,118 @@ __global__ __launch_bounds__(256) void ewald_recip_gather_kernel(const T* __rest
   if (charge_grads) charge_grads[i] = phi - 2.0 * al / sqrt(M_PI) * qi - M_PI / (al * al) * Q;
 }
 
+
+// ---- cut-off Coulomb (coulomb.py:133-708): fp64 throughout, arbitrary (full, half or asymmetric) lists ----------------------------
+// Pair walk of the eight reference kernels: r_ij = r_i - r_j - cell^T S, skip r >= cutoff or r < 1e-10, matrix entries
+// j >= fill_value or j >= N are padding (:325, :385), alpha > 0 selects the erfc_AS-damped form.  Unlike the Ewald kernel above the
+// reference op is used with lists that need not be symmetric, so forces follow its scatter exactly: +f_ij to the row owner and
+// -f_ij to atom j (fp64 global atomics; only the owner's wave sum and the j-scatter touch memory).  `energy_prefactor` is 1/2
+// everywhere except the reference's energy-only MATRIX kernels, which use q_i q_j without the 1/2 (:340, :623) -- the host passes
+// 1.0 there so that results stay identical to the reference's on the same inputs.
+__device__ __forceinline__ bool coulomb_pair(const double* __restrict__ pos, const double* cm, double pix, double piy, double piz, int j,
+                                             const int* __restrict__ ush, long long e, double cutoff, double al, double& rx, double& ry,
+                                             double& rz, double& phi, double& fmr) {
+  const double s0 = (double)ush[3 * e], s1 = (double)ush[3 * e + 1], s2 = (double)ush[3 * e + 2];
+  rx = pix - pos[3 * (size_t)j] - (cm[0] * s0 + cm[3] * s1 + cm[6] * s2);
+  ry = piy - pos[3 * (size_t)j + 1] - (cm[1] * s0 + cm[4] * s1 + cm[7] * s2);
+  rz = piz - pos[3 * (size_t)j + 2] - (cm[2] * s0 + cm[5] * s1 + cm[8] * s2);
+  const double r = sqrt(rx * rx + ry * ry + rz * rz);
+  if (r >= cutoff || r < 1e-10) return false;
+  if (al > 0.0) {
+    const double ar = al * r, ex = exp(-(ar * ar)), ec = erfc_as_poly(ar, ex);
+    phi = ec / r;
+    fmr = ec / (r * r * r) + 1.1283791670955126 * al * ex / (r * r);
+  } else {
+    phi = 1.0 / r;
+    fmr = 1.0 / (r * r * r);
+  }
+  return true;
+}
+
+template <bool CSR>
+__global__ __launch_bounds__(256) void coulomb_kernel(const double* __restrict__ pos, const double* __restrict__ q, const double* __restrict__ cell,
+                                                      const int* __restrict__ batch_idx, int N, const int* __restrict__ idx,
+                                                      const int* __restrict__ ush, const int* __restrict__ nptr, int M, int fill_value,
+                                                      double cutoff, double al, double epref, double* __restrict__ energies,
+                                                      double* __restrict__ forces) {
+  const int lane = threadIdx.x & (MI_WAVE - 1);
+  const int i = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x / MI_WAVE) + threadIdx.x / MI_WAVE);
+  if (i >= N) return;
+  const int s = batch_idx ? batch_idx[i] : 0;
+  double cm[9];
+  for (int k = 0; k < 9; ++k) cm[k] = cell[9 * (size_t)s + k];
+  const double qi = q[i], pix = pos[3 * (size_t)i], piy = pos[3 * (size_t)i + 1], piz = pos[3 * (size_t)i + 2];
+  long long beg, end;
+  if (CSR) { beg = nptr[i]; end = nptr[i + 1]; } else { beg = (long long)i * M; end = beg + M; }
+  double eacc = 0.0, fx = 0.0, fy = 0.0, fz = 0.0;
+  for (long long e = beg + lane; e < end; e += MI_WAVE) {
+    const int j = idx[e];
+    if (j < 0 || j >= N || (!CSR && j >= fill_value)) continue;
+    double rx, ry, rz, phi, fmr;
+    if (!coulomb_pair(pos, cm, pix, piy, piz, j, ush, e, cutoff, al, rx, ry, rz, phi, fmr)) continue;
+    const double qq = qi * q[j];
+    eacc += epref * qq * phi;
+    if (forces) {
+      const double fm = 0.5 * qq * fmr;
+      const double gx = fm * rx, gy = fm * ry, gz = fm * rz;
+      fx += gx; fy += gy; fz += gz;
+      atomicAdd(&forces[3 * (size_t)j], -gx);
+      atomicAdd(&forces[3 * (size_t)j + 1], -gy);
+      atomicAdd(&forces[3 * (size_t)j + 2], -gz);
+    }
+  }
+  eacc = wave_sum(eacc);
+  if (lane == 0) energies[i] = eacc;
+  if (forces) {
+    fx = wave_sum(fx); fy = wave_sum(fy); fz = wave_sum(fz);
+    if (lane == 0) { atomicAdd(&forces[3 * (size_t)i], fx); atomicAdd(&forces[3 * (size_t)i + 1], fy); atomicAdd(&forces[3 * (size_t)i + 2], fz); }
+  }
+}
+
+// adjoint of the per-atom energies for L = sum_i g_i E_i: every directed entry (i, j) contributes g_i * epref * q_i q_j phi(r_ij)
+template <bool CSR>
+__global__ __launch_bounds__(256) void coulomb_bwd_kernel(const double* __restrict__ pos, const double* __restrict__ q, const double* __restrict__ cell,
+                                                          const int* __restrict__ batch_idx, int N, const int* __restrict__ idx,
+                                                          const int* __restrict__ ush, const int* __restrict__ nptr, int M, int fill_value,
+                                                          double cutoff, double al, double epref, const double* __restrict__ gE,
+                                                          double* __restrict__ gpos, double* __restrict__ gq, double* __restrict__ gcell) {
+  const int lane = threadIdx.x & (MI_WAVE - 1);
+  const int i = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x / MI_WAVE) + threadIdx.x / MI_WAVE);
+  if (i >= N) return;
+  const int s = batch_idx ? batch_idx[i] : 0;
+  double cm[9];
+  for (int k = 0; k < 9; ++k) cm[k] = cell[9 * (size_t)s + k];
+  const double qi = q[i], gi = gE[i] * epref, pix = pos[3 * (size_t)i], piy = pos[3 * (size_t)i + 1], piz = pos[3 * (size_t)i + 2];
+  long long beg, end;
+  if (CSR) { beg = nptr[i]; end = nptr[i + 1]; } else { beg = (long long)i * M; end = beg + M; }
+  double px = 0.0, py = 0.0, pz = 0.0, cq = 0.0, gc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  for (long long e = beg + lane; e < end; e += MI_WAVE) {
+    const int j = idx[e];
+    if (j < 0 || j >= N || (!CSR && j >= fill_value)) continue;
+    double rx, ry, rz, phi, fmr;
+    if (!coulomb_pair(pos, cm, pix, piy, piz, j, ush, e, cutoff, al, rx, ry, rz, phi, fmr)) continue;
+    const double qj = q[j];
+    cq += gi * qj * phi;
+    atomicAdd(&gq[j], gi * qi * phi);
+    const double w = -gi * qi * qj * fmr;  // dL/dr_ij = w * r_ij
+    const double wx = w * rx, wy = w * ry, wz = w * rz;
+    px += wx; py += wy; pz += wz;
+    atomicAdd(&gpos[3 * (size_t)j], -wx);
+    atomicAdd(&gpos[3 * (size_t)j + 1], -wy);
+    atomicAdd(&gpos[3 * (size_t)j + 2], -wz);
+    const double sv[3] = {(double)ush[3 * e], (double)ush[3 * e + 1], (double)ush[3 * e + 2]};
+    for (int a = 0; a < 3; ++a) { gc[3 * a] -= sv[a] * wx; gc[3 * a + 1] -= sv[a] * wy; gc[3 * a + 2] -= sv[a] * wz; }
+  }
+  px = wave_sum(px); py = wave_sum(py); pz = wave_sum(pz); cq = wave_sum(cq);
+  bool any_c = false;
+  for (int k = 0; k < 9; ++k) { gc[k] = wave_sum(gc[k]); any_c |= gc[k] != 0.0; }
+  if (lane == 0) {
+    atomicAdd(&gpos[3 * (size_t)i], px); atomicAdd(&gpos[3 * (size_t)i + 1], py); atomicAdd(&gpos[3 * (size_t)i + 2], pz);
+    atomicAdd(&gq[i], cq);
+    if (any_c) for (int k = 0; k < 9; ++k) atomicAdd(&gcell[9 * (size_t)s + k], gc[k]);
+  }
+}
+
 }  // namespace
 
 extern "C" int mi_ewald_real_bwd(const void* positions, const void* charges, const void* cell, const void* alpha, const int32_t* batch_idx,
@@ -310,6 +422,56 @@ extern "C" int mi_ewald_recip_gather(const void* positions, const void* charges,
                                                               (const double*)alpha, batch_idx, structure_factors, total_charge, n_atoms, n_k,
                                                               potential, kforce, energies, (double*)forces, charge_grads);
   mi_timing_end(stream);
+  MI_LAUNCH_CHECK();
+  return MI_OK;
+}
+
+extern "C" int mi_coulomb(const double* positions, const double* charges, const double* cell, const int32_t* batch_idx, int n_atoms,
+                          const int32_t* idx_j, const int32_t* unit_shifts, const int32_t* neighbor_ptr, int max_neighbors, int fill_value,
+                          double cutoff, double alpha, double energy_prefactor, double* energies, double* forces, void* stream) {
+  if (n_atoms <= 0) return MI_OK;
+  MI_REQUIRE(positions && charges && cell && energies, "null pointer");
+  MI_REQUIRE(neighbor_ptr || max_neighbors >= 0, "max_neighbors");
+  hipStream_t st = (hipStream_t)stream;
+  if (forces) MI_HIP_CHECK(hipMemsetAsync(forces, 0, sizeof(double) * 3 * (size_t)n_atoms, st));
+  const bool csr = neighbor_ptr != nullptr;
+  if (!csr && max_neighbors == 0) { MI_HIP_CHECK(hipMemsetAsync(energies, 0, sizeof(double) * (size_t)n_atoms, st)); return MI_OK; }
+  MI_REQUIRE(idx_j && unit_shifts, "null neighbour arrays");
+  const int blocks = mi_blocks(n_atoms, 4);
+  mi_timing_begin("coulomb", stream);
+  if (csr)
+    coulomb_kernel<true><<<blocks, 256, 0, st>>>(positions, charges, cell, batch_idx, n_atoms, idx_j, unit_shifts, neighbor_ptr, 0, 0, cutoff, alpha,
+                                                 energy_prefactor, energies, forces);
+  else
+    coulomb_kernel<false><<<blocks, 256, 0, st>>>(positions, charges, cell, batch_idx, n_atoms, idx_j, unit_shifts, nullptr, max_neighbors,
+                                                  fill_value, cutoff, alpha, energy_prefactor, energies, forces);
+  mi_timing_end(stream);
+  MI_LAUNCH_CHECK();
+  return MI_OK;
+}
+
+extern "C" int mi_coulomb_bwd(const double* positions, const double* charges, const double* cell, const int32_t* batch_idx, int n_atoms,
+                              int n_systems, const int32_t* idx_j, const int32_t* unit_shifts, const int32_t* neighbor_ptr, int max_neighbors,
+                              int fill_value, double cutoff, double alpha, double energy_prefactor, const double* grad_energies,
+                              double* grad_positions, double* grad_charges, double* grad_cell, void* stream) {
+  MI_REQUIRE(n_systems >= 1, "n_systems");
+  MI_REQUIRE(grad_positions && grad_charges && grad_cell, "null gradient outputs");
+  hipStream_t st = (hipStream_t)stream;
+  MI_HIP_CHECK(hipMemsetAsync(grad_cell, 0, sizeof(double) * 9 * (size_t)n_systems, st));
+  if (n_atoms <= 0) return MI_OK;
+  MI_HIP_CHECK(hipMemsetAsync(grad_positions, 0, sizeof(double) * 3 * (size_t)n_atoms, st));
+  MI_HIP_CHECK(hipMemsetAsync(grad_charges, 0, sizeof(double) * (size_t)n_atoms, st));
+  const bool csr = neighbor_ptr != nullptr;
+  if (!csr && max_neighbors <= 0) return MI_OK;
+  MI_REQUIRE(positions && charges && cell && idx_j && unit_shifts && grad_energies, "null pointer");
+  const int blocks = mi_blocks(n_atoms, 4);
+  if (csr)
+    coulomb_bwd_kernel<true><<<blocks, 256, 0, st>>>(positions, charges, cell, batch_idx, n_atoms, idx_j, unit_shifts, neighbor_ptr, 0, 0, cutoff,
+                                                     alpha, energy_prefactor, grad_energies, grad_positions, grad_charges, grad_cell);
+  else
+    coulomb_bwd_kernel<false><<<blocks, 256, 0, st>>>(positions, charges, cell, batch_idx, n_atoms, idx_j, unit_shifts, nullptr, max_neighbors,
+                                                      fill_value, cutoff, alpha, energy_prefactor, grad_energies, grad_positions, grad_charges,
+                                                      grad_cell);
   MI_LAUNCH_CHECK();
   return MI_OK;
 }

@@ -470,6 +470,62 @@ def ewald_reciprocal_space(positions, charges, cell, k_vectors, alpha):
     return e, f, cg
 
 
+def _erfc_as_np(x):
+    """Abramowitz-Stegun 7.1.26 in float64, x >= 0 (math/math.py:52-93)."""
+    t = 1.0 / (1.0 + 0.3275911 * x)
+    poly = t * (0.254829592 + t * (-0.284496736 + t * (1.421413741 + t * (-1.453152027 + t * 1.061405429))))
+    return poly * np.exp(-x * x)
+
+
+def coulomb(positions, charges, cell, cutoff, alpha=0.0, neighbor_list=None, neighbor_ptr=None, neighbor_shifts=None,
+            neighbor_matrix=None, neighbor_matrix_shifts=None, fill_value=None, batch_idx=None, compute_forces=True):
+    """Cut-off Coulomb over stored entries, float64 (interactions/electrostatics/coulomb.py:133-708).  Returns (energies, forces)
+    -- forces None when compute_forces is False.  Entry (i, j): r_ij = r_i - r_j - cell^T S (:185, :248), skipped when r >= cutoff
+    or r < 1e-10 (:189); matrix padding is j >= fill_value or j >= N (:325).  Prefactor 1/2 q_i q_j, except q_i q_j in the
+    energy-only matrix kernels (:340, :623).  Forces: +f_ij on i, -f_ij on j for every entry (:282-286)."""
+    pos, q = np.asarray(positions, np.float64), np.asarray(charges, np.float64)
+    cells = np.asarray(cell, np.float64).reshape(-1, 3, 3)
+    n = pos.shape[0]
+    if neighbor_list is not None:
+        ptr = np.asarray(neighbor_ptr, np.int64)
+        j = np.asarray(neighbor_list, np.int64)[1]
+        i = np.repeat(np.arange(n), np.diff(ptr))     # the kernels walk rows by neighbor_ptr; neighbor_list[0] is not read (:176)
+        j, sh = j[: len(i)], np.asarray(neighbor_shifts, np.float64)[: len(i)]
+        pref = 0.5
+    else:
+        nm = np.asarray(neighbor_matrix, np.int64)
+        fv = n if fill_value is None else int(fill_value)
+        i = np.repeat(np.arange(n), nm.shape[1])
+        j, sh = nm.ravel(), np.asarray(neighbor_matrix_shifts, np.float64).reshape(-1, 3)
+        keep = ~((j >= fv) | (j >= n))
+        i, j, sh = i[keep], j[keep], sh[keep]
+        pref = 0.5 if compute_forces else 1.0
+    sys_i = np.zeros(len(i), np.int64) if batch_idx is None else np.asarray(batch_idx, np.int64)[i]
+    shift_vec = np.einsum("eab,ea->eb", cells[sys_i], sh)           # transpose(cell) @ S
+    rij = pos[i] - pos[j] - shift_vec
+    r = np.sqrt((rij * rij).sum(1))
+    keep = ~((r >= cutoff) | (r < 1e-10))
+    i, j, rij, r = i[keep], j[keep], rij[keep], r[keep]
+    qq = q[i] * q[j]
+    if alpha > 0.0:
+        ar = alpha * r
+        ec = _erfc_as_np(ar)
+        phi = ec / r
+        fmr = ec / (r * r * r) + 1.1283791670955126 * alpha * np.exp(-ar * ar) / (r * r)
+    else:
+        phi = 1.0 / r
+        fmr = 1.0 / (r * r * r)
+    e = np.zeros(n)
+    np.add.at(e, i, pref * qq * phi)
+    if not compute_forces:
+        return e, None
+    fij = (0.5 * qq * fmr)[:, None] * rij
+    f = np.zeros((n, 3))
+    np.add.at(f, i, fij)
+    np.add.at(f, j, -fij)
+    return e, f
+
+
 def explicit_ewald(positions, charges, cell, alpha, kmax, rcut_images=None, exact_erfc=True):
     """Independent float64 Ewald sum (structure-factor reciprocal part + direct real-space image sum).
 

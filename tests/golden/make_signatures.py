@@ -22,6 +22,7 @@ FUNCS = {
     "interactions/electrostatics/pme.py": ["particle_mesh_ewald", "pme_reciprocal_space", "pme_green_structure_factor", "pme_energy_corrections",
                                            "pme_energy_corrections_with_charge_grad"],
     "interactions/electrostatics/ewald.py": ["ewald_real_space", "ewald_reciprocal_space", "ewald_summation"],
+    "interactions/electrostatics/coulomb.py": ["coulomb_energy", "coulomb_forces", "coulomb_energy_forces"],
     "interactions/electrostatics/k_vectors.py": ["generate_k_vectors_pme", "generate_k_vectors_ewald_summation"],
     "interactions/electrostatics/parameters.py": ["estimate_pme_parameters", "estimate_ewald_parameters", "estimate_pme_mesh_dimensions",
                                                   "mesh_spacing_to_dimensions"],

@@ -215,4 +215,4 @@ def test_public_signatures_match_reference():
         for name, sig in funcs.items():
             assert ms.signature(mine + rel, name) == sig, f"{rel}:{name} differs from the reference signature"
             checked += 1
-    assert checked == 39
+    assert checked == 42

@@ -219,3 +219,65 @@ def test_oracle_vectors_are_current():
     assert np.array_equal(e, v["d3_energy"]) and np.array_equal(f, v["d3_forces"])
     er, fr, cg = O.ewald_reciprocal_space(v["pme_pos"], v["pme_q"], v["pme_cell"], v["ewald_kvec"], 0.4)
     np.testing.assert_allclose(er, v["ewald_energies"], rtol=1e-13, atol=1e-15)
+
+
+def test_coulomb_oracle_reference_known_answers():
+    """Pins the Coulomb restatement on the analytic expectations the reference's tests hold
+    (test/interactions/electrostatics/test_coulomb.py:58-92, :191-221, :353-383, :557-614, :654-692, :901-931)."""
+    import math
+
+    pos = np.array([[0.0, 0, 0], [3.0, 0, 0]])
+    q = np.array([1.0, -1.0])
+    cell = np.eye(3) * 100
+    full = dict(neighbor_list=np.array([[0, 1], [1, 0]]), neighbor_ptr=np.array([0, 1, 2]), neighbor_shifts=np.zeros((2, 3), np.int32))
+    e, f = O.coulomb(pos, q, cell, 10.0, 0.0, **full)
+    assert abs(e.sum() + 1.0 / 3.0) < 1e-15                       # :84-91 pair energy split between both atoms
+    np.testing.assert_allclose(f, [[1.0 / 9.0, 0, 0], [-1.0 / 9.0, 0, 0]], atol=1e-15)
+    half = dict(neighbor_list=np.array([[0], [1]]), neighbor_ptr=np.array([0, 1, 1]), neighbor_shifts=np.zeros((1, 3), np.int32))
+    _, f = O.coulomb(pos, q, cell, 10.0, 0.0, **half)
+    np.testing.assert_allclose(f, [[1.0 / 18.0, 0, 0], [-1.0 / 18.0, 0, 0]], atol=1e-15)   # :208-221 F = 0.5 |q1 q2| / r^2, Newton's third law
+    e, f = O.coulomb(np.array([[0.0, 0, 0], [15.0, 0, 0]]), q, cell, 10.0, 0.0, **full)
+    assert not e.any() and not f.any()                             # :353-383 cutoff enforcement
+    e, f = O.coulomb(np.array([[0.0, 0, 0], [1e-11, 0, 0]]), q, cell, 10.0, 0.0, **full)
+    assert not e.any() and not f.any()                             # r < 1e-10 is skipped (coulomb.py:189)
+    # damped pair: 1/2 q q erfc_AS(alpha r)/r per atom, and the force magnitude of coulomb.py:266-273
+    e, f = O.coulomb(pos, q, cell, 10.0, 0.3, **full)
+    ec = O.erfc_as(0.9)
+    assert abs(ec - math.erfc(0.9)) < 2e-7
+    np.testing.assert_allclose(e, [-0.5 * ec / 3.0] * 2, rtol=1e-14)
+    fm = ec / 9.0 + 2.0 / math.sqrt(math.pi) * 0.3 * math.exp(-0.81) / 3.0
+    np.testing.assert_allclose(f[:, 0], [fm, -fm], rtol=1e-13)
+    # three charges: matrix == list for energy+forces (:557-614); energy-only matrix kernel omits the 1/2 (coulomb.py:340)
+    p3, q3 = np.array([[0.0, 0, 0], [2.0, 0, 0], [0, 2.0, 0]]), np.array([1.0, -1.0, 0.5])
+    l3 = dict(neighbor_list=np.array([[0, 0, 1, 1, 2, 2], [1, 2, 0, 2, 0, 1]]), neighbor_ptr=np.array([0, 2, 4, 6]), neighbor_shifts=np.zeros((6, 3), np.int32))
+    m3 = dict(neighbor_matrix=np.array([[1, 2], [0, 2], [0, 1]]), neighbor_matrix_shifts=np.zeros((3, 2, 3), np.int32), fill_value=3)
+    el, fl = O.coulomb(p3, q3, cell, 10.0, 0.0, **l3)
+    em, fmx = O.coulomb(p3, q3, cell, 10.0, 0.0, **m3)
+    np.testing.assert_allclose(em, el, rtol=1e-15); np.testing.assert_allclose(fmx, fl, rtol=1e-15)
+    assert abs(el.sum() - (-1 / 2.0 + 0.5 / 2.0 - 0.5 / math.sqrt(8.0))) < 1e-15
+    eo, none = O.coulomb(p3, q3, cell, 10.0, 0.0, compute_forces=False, **m3)
+    assert none is None
+    np.testing.assert_allclose(eo, 2.0 * el, rtol=1e-15)
+    # minimum image through the integer shift (:654-692): atoms 0.5 and 9.5 in a 10 box are 1.0 apart
+    e, _ = O.coulomb(np.array([[0.5, 5, 5], [9.5, 5, 5]]), q, np.eye(3) * 10, 5.0, 0.0, neighbor_list=np.array([[0, 1], [1, 0]]),
+                     neighbor_ptr=np.array([0, 1, 2]), neighbor_shifts=np.array([[-1, 0, 0], [1, 0, 0]]))
+    assert abs(e.sum() + 1.0) < 1e-15
+
+
+def test_coulomb_input_validation_messages():
+    """ValueErrors of coulomb.py:1409-1421 / :1430 are raised before any device work."""
+    import torch
+    from nvalchemiops.interactions.electrostatics.coulomb import coulomb_energy, coulomb_energy_forces, coulomb_forces
+
+    pos, q, cell = torch.zeros((2, 3)), torch.ones(2), torch.eye(3).reshape(1, 3, 3)
+    nl, sh = torch.zeros((2, 1), dtype=torch.int32), torch.zeros((1, 3), dtype=torch.int32)
+    nm, msh = torch.zeros((2, 1), dtype=torch.int32), torch.zeros((2, 1, 3), dtype=torch.int32)
+    for fn in (coulomb_energy, coulomb_forces, coulomb_energy_forces):
+        with pytest.raises(ValueError, match="Must provide either"):
+            fn(pos, q, cell, 5.0)
+        with pytest.raises(ValueError, match="Must provide either"):
+            fn(pos, q, cell, 5.0, neighbor_list=nl)  # shifts missing
+        with pytest.raises(ValueError, match="Cannot provide both"):
+            fn(pos, q, cell, 5.0, neighbor_list=nl, neighbor_shifts=sh, neighbor_matrix=nm, neighbor_matrix_shifts=msh)
+        with pytest.raises(ValueError, match="neighbor_ptr is required"):
+            fn(pos, q, cell, 5.0, neighbor_list=nl, neighbor_shifts=sh)
