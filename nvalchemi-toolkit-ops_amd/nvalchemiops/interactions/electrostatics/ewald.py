@@ -163,15 +163,23 @@ def _recip_gather(pos, q, kv, al, bi, sf, tq, n_k, potential=False, kforce=False
 
 
 class _EwaldRecipEnergyFn(torch.autograd.Function):
-    """Differentiable per-atom reciprocal energies (positions, charges).  With L = sum_i g_i E_i and the g-weighted structure
-    factors S^g = G sum_j g_j q_j exp(i k.r_j):
+    """Differentiable per-atom reciprocal energies (positions, charges, k-vectors, alpha, volume).  With L = sum_i g_i E_i and the
+    g-weighted structure factors S^g = G sum_j g_j q_j exp(i k.r_j):
         dL/dr_m = -1/2 q_m (g_m kf_m[S] + kf_m[S^g]),
         dL/dq_m = 1/2 (g_m phi_m[S] + phi_m[S^g]) - 2 g_m alpha q_m/sqrt(pi) - pi/(2 alpha^2 V) (g_m Q + sum_i g_i q_i)
-    -- two more passes of the forward kernels instead of a recorded tape (reference: autograd.py:525-665)."""
+    -- two more passes of the forward kernels instead of a recorded tape (reference: autograd.py:525-665).
+    Cell gradients (the reference's `test_cell_gradients`, test_ewald.py:2117) flow through `k_vectors` and the volume: with
+    W_k = Re[conj(S^g) S]/G (the k-th term of 2 L) and G = 8 pi/V exp(-k^2/4 alpha^2)/k^2,
+        dL/dk   = 1/2 W dlnG/dk + 1/(2G) d/dk Re[conj(A^g) A] G^2   (first moments sum_j w_j r_j exp(i k.r_j): six more
+                  structure-factor passes with weights q r_c and g q r_c),
+        dL/dalpha = 1/2 sum_k W k^2/(2 alpha^3) + sum_i g_i (-q_i^2/sqrt(pi) + pi q_i Q/(alpha^3 V)),
+        dL/dV     = -1/(2V) sum_k W + sum_i g_i pi q_i Q/(2 alpha^2 V^2);
+    `vol` = |det cell| is a torch-differentiable input whose value the kernels recompute from `cells`."""
 
     @staticmethod
-    def forward(ctx, positions, charges, kv, cells, al, bi, sptr, max_atoms):
+    def forward(ctx, positions, charges, kv, al, vol, cells, bi, sptr, max_atoms):
         pos, q = positions.detach().contiguous(), charges.detach().contiguous()
+        kv, al = kv.detach().contiguous(), al.detach().contiguous()
         n_sys, n_k = kv.shape[0], kv.shape[1]
         sf, tq = _structure_factors(pos, q, kv, cells, al, sptr, n_sys, n_k, max_atoms)
         out = _recip_gather(pos, q, kv, al, bi, sf, tq, n_k, energies=True)
@@ -185,19 +193,53 @@ class _EwaldRecipEnergyFn(torch.autograd.Function):
         batched, max_atoms = ctx.meta
         bi, sptr = (rest[0], rest[1]) if batched else (None, None)
         n_sys, n_k = kv.shape[0], kv.shape[1]
-        g = g_e.detach().to(torch.float64)
-        gq = (g * q.to(torch.float64)).to(pos.dtype).contiguous()
-        sfg, tqg = _structure_factors(pos, gq, kv, cells, al, sptr, n_sys, n_k, max_atoms)
-        a = _recip_gather(pos, q, kv, al, bi, sf, None, n_k, potential=True, kforce=True)
-        b = _recip_gather(pos, q, kv, al, bi, sfg, None, n_k, potential=True, kforce=True)
-        q64, al64 = q.to(torch.float64), al.to(torch.float64)
-        sel = bi.long() if batched else torch.zeros(pos.shape[0], dtype=torch.long, device=pos.device)
-        gpos = (-0.5 * q64).unsqueeze(1) * (g.unsqueeze(1) * a["kforce"] + b["kforce"])
-        a_i = al64[sel]
-        gch = (0.5 * (g * a["potential"] + b["potential"]) - 2.0 * g * a_i * q64 / math.sqrt(math.pi)
-               - math.pi / (2.0 * a_i * a_i) * (g * tq[sel] + tqg[sel]))
         need = ctx.needs_input_grad
-        return (gpos.to(pos.dtype) if need[0] else None, gch.to(pos.dtype) if need[1] else None, None, None, None, None, None, None)
+        g = g_e.detach().to(torch.float64)
+        q64, al64 = q.to(torch.float64), al.to(torch.float64)
+        gq = (g * q64).to(pos.dtype).contiguous()
+        sfg, tqg = _structure_factors(pos, gq, kv, cells, al, sptr, n_sys, n_k, max_atoms)
+        sel = bi.long() if batched else torch.zeros(pos.shape[0], dtype=torch.long, device=pos.device)
+        a_i = al64[sel]
+        gpos = gch = gkv = gal = gvol = None
+        if need[0] or need[1]:
+            a = _recip_gather(pos, q, kv, al, bi, sf, None, n_k, potential=True, kforce=True)
+            b = _recip_gather(pos, q, kv, al, bi, sfg, None, n_k, potential=True, kforce=True)
+            if need[0]:
+                gpos = ((-0.5 * q64).unsqueeze(1) * (g.unsqueeze(1) * a["kforce"] + b["kforce"])).to(pos.dtype)
+            if need[1]:
+                gch = (0.5 * (g * a["potential"] + b["potential"]) - 2.0 * g * a_i * q64 / math.sqrt(math.pi)
+                       - math.pi / (2.0 * a_i * a_i) * (g * tq[sel] + tqg[sel])).to(pos.dtype)
+        if need[2] or need[3] or need[4]:
+            kv64 = kv.to(torch.float64)
+            k2 = (kv64 * kv64).sum(-1)
+            vol = torch.abs(torch.linalg.det(cells.to(torch.float64)))
+            a2 = (al64 * al64).unsqueeze(1)
+            ok = k2 >= 1e-10
+            k2s = torch.where(ok, k2, torch.ones_like(k2))
+            green = 8.0 * math.pi / vol.unsqueeze(1) * torch.exp(-k2s / (4.0 * a2)) / k2s
+            ok = ok & (green > 1e-280)
+            ginv = torch.where(ok, 1.0 / torch.where(ok, green, torch.ones_like(green)), torch.zeros_like(green))
+            srq, siq, srg, sig = sf[..., 0], sf[..., 1], sfg[..., 0], sfg[..., 1]
+            w = (srg * srq + sig * siq) * ginv
+            if need[2]:
+                gk = 0.5 * w.unsqueeze(-1) * (-kv64 * (0.5 / a2 + 2.0 / k2s).unsqueeze(-1))
+                cross = []
+                for c in range(3):
+                    rc_ = pos[:, c]
+                    m, _ = _structure_factors(pos, (q * rc_).contiguous(), kv, cells, al, sptr, n_sys, n_k, max_atoms, want_charge=False)
+                    mg, _ = _structure_factors(pos, (gq * rc_).contiguous(), kv, cells, al, sptr, n_sys, n_k, max_atoms, want_charge=False)
+                    cross.append((-mg[..., 1] * srq - srg * m[..., 1] + mg[..., 0] * siq + sig * m[..., 0]) * ginv)
+                gkv = (gk + 0.5 * torch.stack(cross, dim=-1)).to(kv.dtype)
+            gi_q = g * q64
+            if need[3]:
+                per_atom = gi_q * (-q64 / math.sqrt(math.pi) + math.pi * tq[sel] / a_i**3)
+                gal = (0.5 * (w * k2).sum(1) / (2.0 * al64**3)
+                       + torch.zeros(n_sys, dtype=torch.float64, device=pos.device).index_add_(0, sel, per_atom)).to(al.dtype)
+            if need[4]:
+                v_i = vol[sel]
+                per_atom = gi_q * math.pi * tq[sel] / (2.0 * a_i * a_i * v_i)
+                gvol = (-0.5 * w.sum(1) / vol + torch.zeros(n_sys, dtype=torch.float64, device=pos.device).index_add_(0, sel, per_atom)).to(pos.dtype)
+        return gpos, gch, gkv, gal, gvol, None, None, None, None
 
 
 def ewald_reciprocal_space(positions: torch.Tensor, charges: torch.Tensor, cell: torch.Tensor, k_vectors: torch.Tensor, alpha: torch.Tensor,
@@ -207,7 +249,8 @@ def ewald_reciprocal_space(positions: torch.Tensor, charges: torch.Tensor, cell:
 
     Returns ``energies`` | ``(energies, forces)`` | ``(energies, charge_grads)`` | ``(energies, forces, charge_grads)``.
     `k_vectors` is [K,3] (single system) or [B,K,3] (batch); `alpha` a [B] tensor (see `ewald_summation` for float input).
-    Energies are differentiable w.r.t. positions and charges."""
+    Energies are differentiable w.r.t. positions, charges, k_vectors, alpha and cell (the latter through |det cell| here and
+    through `k_vectors` when those were generated from a cell that requires grad, as the reference's tests do)."""
     n, dev, dt = positions.shape[0], positions.device, positions.dtype
     batched = batch_idx is not None
     cells, n_sys = _prepare_cell(cell)
@@ -238,8 +281,10 @@ def ewald_reciprocal_space(positions: torch.Tensor, charges: torch.Tensor, cell:
     res = _recip_gather(pos, q, kv_c, al, bi, sf, tq, n_k, energies=True, forces=compute_forces,
                         cgrads=compute_charge_gradients)
     e_out = res["energies"].to(dt)
-    if torch.is_grad_enabled() and (positions.requires_grad or charges.requires_grad):
-        e_out = _EwaldRecipEnergyFn.apply(positions, charges.to(dt), kv_c, cells_c, al, bi, sptr, max_atoms)
+    al_in = _prepare_alpha(alpha, n_sys, dt, dev)
+    if torch.is_grad_enabled() and any(t.requires_grad for t in (positions, charges, kv, cells, al_in)):
+        vol = torch.abs(torch.linalg.det(cells.to(dt)))  # differentiable handle on the volume; the kernels recompute it from cells_c
+        e_out = _EwaldRecipEnergyFn.apply(positions, charges.to(dt), kv.to(dt), al_in, vol, cells_c, bi, sptr, max_atoms)
     out = (e_out,)
     if compute_forces:
         out += (res["forces"],)

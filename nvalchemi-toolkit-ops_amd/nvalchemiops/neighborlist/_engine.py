@@ -23,9 +23,19 @@ def workspace(n_atoms: int, n_systems: int, dtype: torch.dtype, device: torch.de
     return torch.empty(nbytes, dtype=torch.uint8, device=device)
 
 
+def canon_positions(positions: torch.Tensor) -> torch.Tensor:
+    """Detached, contiguous positions in a dtype the kernels take.  The reference also instantiates its neighbour kernels for
+    float16 (naive.py:186-188, types.py:26); here half-precision coordinates are read exactly and the search itself runs in
+    float32, so a pair within half-precision rounding of the cutoff may be classified differently than by fp16 arithmetic."""
+    pos = positions.detach()
+    if pos.dtype in (torch.float16, torch.bfloat16):
+        pos = pos.float()
+    return pos.contiguous()
+
+
 def canon_geometry(positions: torch.Tensor, cell: torch.Tensor, pbc: torch.Tensor, n_systems: int | None = None):
     """positions contiguous; cell -> (B,3,3) in the positions dtype; pbc -> (B,3) bool (1 byte per flag)."""
-    pos = positions.detach().contiguous()
+    pos = canon_positions(positions)
     cell = cell.detach()
     cell = (cell if cell.ndim == 3 else cell.unsqueeze(0)).to(dtype=pos.dtype, device=pos.device).contiguous()
     pbc = pbc.reshape(-1, 3).to(device=pos.device, dtype=torch.bool)

@@ -50,7 +50,7 @@ def batch_naive_neighbor_list(positions: torch.Tensor, cutoff: float, batch_idx:
         if periodic:
             pos, c, p = E.canon_geometry(positions, cell, pbc)
         else:
-            pos = positions.detach().contiguous()
+            pos = E.canon_positions(positions)
             n_sys = batch_ptr.shape[0] - 1
             c, origin = _bounding_cell(pos, bi, n_sys)
             p = torch.zeros((n_sys, 3), dtype=torch.bool, device=dev)

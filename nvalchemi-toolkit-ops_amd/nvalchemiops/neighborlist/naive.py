@@ -64,7 +64,7 @@ def naive_neighbor_list(positions: torch.Tensor, cutoff: float, cell: torch.Tens
     if periodic:
         pos, c, p = E.canon_geometry(positions, cell, pbc)
     else:
-        pos = positions.detach().contiguous()
+        pos = E.canon_positions(positions)
         c, origin = _bounding_cell(pos)  # origin shifts the BINNING only; distances use the caller's coordinates
         p = torch.zeros((1, 3), dtype=torch.bool, device=dev)
     if neighbor_matrix is None:

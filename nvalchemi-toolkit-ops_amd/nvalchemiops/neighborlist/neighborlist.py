@@ -33,7 +33,7 @@ def _free_space_cell_list(positions, cutoff, batch_idx, half_fill, fill_value, r
     if n <= 0 or cutoff <= 0:
         return _empty_result(n, fill_value, return_neighbor_list, positions.device)
     C.require_device(positions, batch_idx)
-    pos = positions.detach().contiguous()
+    pos = E.canon_positions(positions)
     # the dispatcher already derived batch_ptr: its length gives the system count without another host sync
     n_sys = 1 if batch_idx is None else (n_systems if n_systems is not None else int(batch_idx.max().item()) + 1)
     bi = None if batch_idx is None else C.i32(batch_idx)

@@ -8,6 +8,7 @@ from __future__ import annotations
 import torch
 
 from nvalchemiops import _capi as C
+from nvalchemiops.neighborlist import _engine as E
 
 
 def cell_list_needs_rebuild(current_positions: torch.Tensor, atom_to_cell_mapping: torch.Tensor, cells_per_dimension: torch.Tensor,
@@ -19,7 +20,7 @@ def cell_list_needs_rebuild(current_positions: torch.Tensor, atom_to_cell_mappin
     if n == 0:
         return flag
     C.require_device(current_positions, atom_to_cell_mapping, cells_per_dimension, cell, pbc)
-    pos = current_positions.detach().contiguous()
+    pos = E.canon_positions(current_positions)
     c = cell.detach().to(pos.dtype).reshape(-1, 3, 3)[0].contiguous()
     rc = C.lib().mi_nl_cells_changed(C.ptr(pos), C.ptr(c), C.ptr(C.i32(atom_to_cell_mapping)), C.ptr(C.i32(cells_per_dimension.reshape(-1))),
                                      C.ptr(pbc.reshape(-1).to(torch.bool).contiguous()), n, C.dtype_code(pos.dtype), C.ptr(flag),
@@ -40,7 +41,8 @@ def neighbor_list_needs_rebuild(reference_positions: torch.Tensor, current_posit
     if n == 0:
         return flag
     C.require_device(reference_positions, current_positions)
-    ref, cur = reference_positions.detach().contiguous(), current_positions.detach().to(reference_positions.dtype).contiguous()
+    ref = E.canon_positions(reference_positions)
+    cur = current_positions.detach().to(ref.dtype).contiguous()
     rc = C.lib().mi_nl_moved_beyond_skin(C.ptr(ref), C.ptr(cur), C.cdouble(skin_distance_threshold), n, C.dtype_code(ref.dtype), C.ptr(flag),
                                          C.stream_of(ref))
     C.check(rc, "mi_nl_moved_beyond_skin")

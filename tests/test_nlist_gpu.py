@@ -134,6 +134,24 @@ def test_naive_matches_oracle(dtype):
     assert np.array_equal(_pairs(nm, num, sh), O.canonical_pairs(onm, onum, osh))
 
 
+def test_half_precision_positions_are_accepted():
+    """The reference instantiates its neighbour kernels for float16 as well (naive.py:186-188, cell_list.py:761); here fp16 coordinates
+    are read exactly and searched in float32 -- the result equals the float32 search of the same (rounded) coordinates."""
+    from nvalchemiops.neighborlist import neighbor_list
+
+    mol, _, _ = S.molecule(1000, seed=2001, dtype=np.float32)
+    h = _t(mol).half()
+    nm, num = neighbor_list(h, 5.0, method="naive", max_neighbors=96)
+    nm32, num32 = neighbor_list(h.float(), 5.0, method="naive", max_neighbors=96)
+    assert torch.equal(num, num32) and torch.equal(nm, nm32)
+    pos, cell = S.random_box(6000, 24.0, seed=5, dtype=np.float32)
+    h = _t(pos).half()
+    pbc = torch.tensor([True, True, True], device=DEV)
+    out = neighbor_list(h, 3.0, cell=_t(cell).half(), pbc=pbc, max_neighbors=96)
+    ref = neighbor_list(h.float(), 3.0, cell=_t(cell).half().float(), pbc=pbc, max_neighbors=96)
+    assert all(torch.equal(a, b) for a, b in zip(out, ref))
+
+
 def test_query_api_and_preallocated_buffers():
     from nvalchemiops.neighborlist import (allocate_cell_list, build_cell_list, cell_list, estimate_cell_list_sizes, query_cell_list)
 

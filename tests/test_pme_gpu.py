@@ -331,6 +331,55 @@ def test_ewald_reciprocal_space_autograd():
         assert abs((loss(pos, qp) - loss(pos, qm)) / (2 * h) - tq.grad[i].item()) < 1e-7
 
 
+@pytest.mark.parametrize("batched", [False, True])
+def test_ewald_reciprocal_space_cell_alpha_kvector_gradients(batched):
+    """Cell (through k_vectors and the volume), alpha and raw k-vector gradients of L = sum_i g_i E_i against central differences of
+    the HIP forward -- the gradient the reference's test_ewald.py:2117 (`test_cell_gradients`) asks for."""
+    from nvalchemiops.interactions.electrostatics import ewald_reciprocal_space, generate_k_vectors_ewald_summation
+
+    p0, c0, q0 = _system(30, np.float64, True, seed=16, box=9.0)
+    q0[2] += 0.7  # net charge: the background term depends on alpha and V
+    if batched:
+        p1, c1, q1 = _system(22, np.float64, False, seed=17, box=8.0)
+        pos, q, cells = np.concatenate([p0, p1]), np.concatenate([q0, q1]), np.stack([c0, c1])
+        bi = _t(np.concatenate([np.zeros(30, np.int32), np.ones(22, np.int32)]))
+        alpha0 = np.array([0.45, 0.5])
+    else:
+        pos, q, cells, bi, alpha0 = p0, q0, c0[None], None, np.array([0.45])
+    n = pos.shape[0]
+    g = torch.linspace(0.5, 1.5, n, dtype=torch.float64, device=DEV)
+    tp, tq = _t(pos), _t(q)
+
+    def loss(cell_t, alpha_t, kv=None):
+        kv = generate_k_vectors_ewald_summation(cell_t, 2.2) if kv is None else kv
+        return (ewald_reciprocal_space(tp, tq, cell_t, kv, alpha_t, batch_idx=bi) * g).sum()
+
+    tc, ta = _t(cells).requires_grad_(True), _t(alpha0).requires_grad_(True)
+    loss(tc, ta).backward()
+    assert tc.grad is not None and torch.isfinite(tc.grad).all()
+    h = 1e-5
+    with torch.no_grad():
+        for s in range(cells.shape[0]):
+            for a, b in ((0, 0), (1, 0), (2, 1), (1, 2), (2, 2)):
+                d = torch.zeros_like(tc); d[s, a, b] = h
+                fd = float(loss(tc + d, ta) - loss(tc - d, ta)) / (2 * h)
+                assert abs(fd - float(tc.grad[s, a, b])) < 2e-7 * max(1.0, abs(fd)), ("cell", s, a, b, fd, float(tc.grad[s, a, b]))
+            d = torch.zeros_like(ta); d[s] = h
+            fd = float(loss(tc, ta + d) - loss(tc, ta - d)) / (2 * h)
+            assert abs(fd - float(ta.grad[s])) < 2e-7 * max(1.0, abs(fd)), ("alpha", s, fd, float(ta.grad[s]))
+    # k-vectors as an independent leaf (cell fixed)
+    kv = generate_k_vectors_ewald_summation(_t(cells), 2.2).detach().requires_grad_(True)
+    loss(_t(cells), _t(alpha0), kv).backward()
+    k2 = (kv.detach() ** 2).sum(-1).reshape(-1)
+    flat = kv.grad.reshape(-1, 3)
+    with torch.no_grad():
+        for idx in torch.argsort(k2)[:4].tolist() + [int(k2.numel() // 2)]:
+            for c in range(3):
+                d = torch.zeros_like(kv); d.reshape(-1, 3)[idx, c] = h
+                fd = float(loss(_t(cells), _t(alpha0), kv + d) - loss(_t(cells), _t(alpha0), kv - d)) / (2 * h)
+                assert abs(fd - float(flat[idx, c])) < 2e-7 * max(1.0, abs(fd)), ("k", idx, c, fd, float(flat[idx, c]))
+
+
 def test_hip_path_against_committed_oracle_vectors():
     """HIP nlist / D3 / PME / explicit-k Ewald against tests/golden/oracle_vectors.npz (made by tests/golden/make_golden.py)."""
     import os
