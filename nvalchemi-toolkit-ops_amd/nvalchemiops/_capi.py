@@ -7,6 +7,7 @@ to the library, which never allocates, frees or retains them.
 from __future__ import annotations
 
 import ctypes
+import functools
 import os
 
 import torch
@@ -98,3 +99,20 @@ def i32(t: torch.Tensor | None) -> torch.Tensor | None:
     if t is None:
         return None
     return t.to(torch.int32).contiguous()
+
+
+def eager(fn):
+    """Decorator of every public entry point that launches through the C ABI.  The launch layer hands raw device pointers and the
+    current HIP stream to ctypes, which TorchDynamo can neither trace nor guard, so under ``torch.compile`` these functions run as
+    eager islands (a graph break around the call) -- the behaviour the reference's ``@torch.compile`` tests rely on
+    (test/neighborlist/test_cell_list.py:599-760, test_naive.py:1200-1300, test/interactions/dispersion/test_dftd3.py:1204-1330).
+    The ``torch.ops.nvalchemiops.*`` custom ops (``_ops.py``) are the fullgraph-capable seam."""
+    inner = torch.compiler.disable(fn)
+
+    @functools.wraps(fn)
+    def entry(*args, **kwargs):
+        # a plain frame around the disabled callable: `torch.compile(dftd3)` (test_dftd3.py:1228) unwraps a directly disabled
+        # function and would trace its body
+        return inner(*args, **kwargs)
+
+    return entry

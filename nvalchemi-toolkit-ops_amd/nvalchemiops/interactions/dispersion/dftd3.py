@@ -92,6 +92,7 @@ def _launch(positions, numbers, idx, shifts, nptr, max_neighbors, fill_value, ce
     C.check(rc, "mi_d3")
 
 
+@C.eager
 def dftd3(positions: torch.Tensor, numbers: torch.Tensor, a1: float, a2: float, s8: float, k1: float = 16.0, k3: float = -4.0,
           s6: float = 1.0, s5_smoothing_on: float = 1e10, s5_smoothing_off: float = 1e10, fill_value: int | None = None,
           d3_params: D3Parameters | dict[str, torch.Tensor] | None = None, covalent_radii: torch.Tensor | None = None,

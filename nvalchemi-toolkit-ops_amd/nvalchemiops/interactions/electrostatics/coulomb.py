@@ -99,6 +99,7 @@ def _run(positions, charges, cell, cutoff, alpha, neighbor_list, neighbor_ptr, n
                    float(alpha), epref, want_forces)
 
 
+@C.eager
 def coulomb_energy(positions: torch.Tensor, charges: torch.Tensor, cell: torch.Tensor, cutoff: float, alpha: float = 0.0,
                    neighbor_list: torch.Tensor | None = None, neighbor_ptr: torch.Tensor | None = None,
                    neighbor_shifts: torch.Tensor | None = None, neighbor_matrix: torch.Tensor | None = None,
@@ -112,6 +113,7 @@ def coulomb_energy(positions: torch.Tensor, charges: torch.Tensor, cell: torch.T
     return e.to(positions.dtype)
 
 
+@C.eager
 def coulomb_energy_forces(positions: torch.Tensor, charges: torch.Tensor, cell: torch.Tensor, cutoff: float, alpha: float = 0.0,
                           neighbor_list: torch.Tensor | None = None, neighbor_ptr: torch.Tensor | None = None,
                           neighbor_shifts: torch.Tensor | None = None, neighbor_matrix: torch.Tensor | None = None,
@@ -124,6 +126,7 @@ def coulomb_energy_forces(positions: torch.Tensor, charges: torch.Tensor, cell: 
     return e.to(positions.dtype), f.to(positions.dtype)
 
 
+@C.eager
 def coulomb_forces(positions: torch.Tensor, charges: torch.Tensor, cell: torch.Tensor, cutoff: float, alpha: float = 0.0,
                    neighbor_list: torch.Tensor | None = None, neighbor_ptr: torch.Tensor | None = None,
                    neighbor_shifts: torch.Tensor | None = None, neighbor_matrix: torch.Tensor | None = None,

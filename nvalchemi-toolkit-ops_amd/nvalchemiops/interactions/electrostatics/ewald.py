@@ -54,6 +54,7 @@ class _EwaldRealEnergyFn(torch.autograd.Function):
                 None if galpha is None else galpha.to(dt), None, None, None, None, None, None)
 
 
+@C.eager
 def ewald_real_space(positions: torch.Tensor, charges: torch.Tensor, cell: torch.Tensor, alpha: torch.Tensor,
                      neighbor_list: torch.Tensor | None = None, neighbor_ptr: torch.Tensor | None = None,
                      neighbor_shifts: torch.Tensor | None = None, neighbor_matrix: torch.Tensor | None = None,
@@ -242,6 +243,7 @@ class _EwaldRecipEnergyFn(torch.autograd.Function):
         return gpos, gch, gkv, gal, gvol, None, None, None, None
 
 
+@C.eager
 def ewald_reciprocal_space(positions: torch.Tensor, charges: torch.Tensor, cell: torch.Tensor, k_vectors: torch.Tensor, alpha: torch.Tensor,
                            batch_idx: torch.Tensor | None = None, compute_forces: bool = False, compute_charge_gradients: bool = False):
     """Reciprocal-space Ewald over an explicit half-space k-vector set (ewald.py:2631-2795):
@@ -293,6 +295,7 @@ def ewald_reciprocal_space(positions: torch.Tensor, charges: torch.Tensor, cell:
     return out if len(out) > 1 else out[0]
 
 
+@C.eager
 def ewald_summation(positions: torch.Tensor, charges: torch.Tensor, cell: torch.Tensor, alpha=None, k_vectors: torch.Tensor | None = None,
                     k_cutoff: float | None = None, batch_idx: torch.Tensor | None = None, neighbor_list: torch.Tensor | None = None,
                     neighbor_ptr: torch.Tensor | None = None, neighbor_shifts: torch.Tensor | None = None,

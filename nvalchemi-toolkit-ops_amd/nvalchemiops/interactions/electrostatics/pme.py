@@ -46,6 +46,7 @@ def _prepare_cell(cell: torch.Tensor) -> tuple[torch.Tensor, int]:
     return cell, cell.shape[0]
 
 
+@C.eager
 def pme_green_structure_factor(k_squared: torch.Tensor, mesh_dimensions: tuple[int, int, int], alpha: torch.Tensor, cell: torch.Tensor,
                                spline_order: int = 4, batch_idx: torch.Tensor | None = None):
     """G(k) = 2 pi exp(-k^2/4 alpha^2)/(V k^2) (0 at k = 0) and sf^2 = sinc-product^(2 min(order,4)) (pme.py:555-676)."""
@@ -93,11 +94,13 @@ def _corrections(raw, charges, cell, alpha, batch_idx, want_cg):
     return (e, cg) if want_cg else e
 
 
+@C.eager
 def pme_energy_corrections(raw_energies, charges, cell, alpha, batch_idx=None) -> torch.Tensor:
     """E_i = q_i phi_i - q_i^2 alpha/sqrt(pi) - q_i pi Q_tot/(2 alpha^2 V) (pme.py:1166-1250, pme_kernels.py:340-409)."""
     return _corrections(raw_energies, charges, cell, alpha, batch_idx, False)
 
 
+@C.eager
 def pme_energy_corrections_with_charge_grad(raw_energies, charges, cell, alpha, batch_idx=None):
     """... plus dE/dq_i = 2 phi_i - 2 alpha q_i/sqrt(pi) - pi Q_tot/(alpha^2 V) (pme.py:1253-1336)."""
     return _corrections(raw_energies, charges, cell, alpha, batch_idx, True)
@@ -203,6 +206,7 @@ def _reciprocal_autograd(positions, charges, cells, alpha, mesh_dimensions, spli
     return energies, forces, cgrads
 
 
+@C.eager
 def pme_reciprocal_space(positions: torch.Tensor, charges: torch.Tensor, cell: torch.Tensor, alpha: float | torch.Tensor,
                          mesh_dimensions: tuple[int, int, int] | None = None, mesh_spacing: float | None = None, spline_order: int = 4,
                          batch_idx: torch.Tensor | None = None, k_vectors: torch.Tensor | None = None,
@@ -249,6 +253,7 @@ def pme_reciprocal_space(positions: torch.Tensor, charges: torch.Tensor, cell: t
     return energies
 
 
+@C.eager
 def particle_mesh_ewald(positions: torch.Tensor, charges: torch.Tensor, cell: torch.Tensor, alpha: float | torch.Tensor | None = None,
                         mesh_spacing: float | None = None, mesh_dimensions: tuple[int, int, int] | None = None, spline_order: int = 4,
                         batch_idx: torch.Tensor | None = None, k_vectors: torch.Tensor | None = None, k_squared: torch.Tensor | None = None,

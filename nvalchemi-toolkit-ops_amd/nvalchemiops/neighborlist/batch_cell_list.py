@@ -13,6 +13,7 @@ from nvalchemiops.neighborlist.cell_list import _build_cache, _empty_result, _se
 from nvalchemiops.neighborlist.neighbor_utils import estimate_max_neighbors
 
 
+@C.eager
 def estimate_batch_cell_list_sizes(cell: torch.Tensor, pbc: torch.Tensor, cutoff: float, max_nbins: int = 1000):
     """(sum over systems of the per-system cell count, neighbor_search_radius[B,3]) (batch_cell_list.py:36-99, 659-736)."""
     n_sys = cell.shape[0]
@@ -30,6 +31,7 @@ def estimate_batch_cell_list_sizes(cell: torch.Tensor, pbc: torch.Tensor, cutoff
     return int(ncells.sum().item()), radius
 
 
+@C.eager
 def batch_build_cell_list(positions, cutoff, cell, pbc, batch_idx, cells_per_dimension, neighbor_search_radius, atom_periodic_shifts,
                           atom_to_cell_mapping, atoms_per_cell_count, cell_atom_start_indices, cell_atom_list) -> None:
     """Fill the caller's batch cache tensors in place (batch_cell_list.py:739-912, 1070-1136)."""
@@ -41,6 +43,7 @@ def batch_build_cell_list(positions, cutoff, cell, pbc, batch_idx, cells_per_dim
                  atoms_per_cell_count, cell_atom_start_indices, cell_atom_list)
 
 
+@C.eager
 def batch_query_cell_list(positions, cell, pbc, cutoff, batch_idx, cells_per_dimension, neighbor_search_radius, atom_periodic_shifts,
                           atom_to_cell_mapping, atoms_per_cell_count, cell_atom_start_indices, cell_atom_list, neighbor_matrix,
                           neighbor_matrix_shifts, num_neighbors, half_fill: bool = False) -> None:
@@ -54,6 +57,7 @@ def batch_query_cell_list(positions, cell, pbc, cutoff, batch_idx, cells_per_dim
                       neighbor_matrix_shifts, num_neighbors, pad=False)
 
 
+@C.eager
 def batch_cell_list(positions: torch.Tensor, cutoff: float, cell: torch.Tensor, pbc: torch.Tensor, batch_idx: torch.Tensor,
                     max_neighbors: int | None = None, half_fill: bool = False, fill_value: int | None = None,
                     return_neighbor_list: bool = False, neighbor_matrix: torch.Tensor | None = None,

@@ -14,6 +14,7 @@ from nvalchemiops.neighborlist.neighbor_utils import (_prepare_batch_idx_ptr, es
                                                       get_neighbor_list_from_neighbor_matrix)
 
 
+@C.eager
 def batch_naive_neighbor_list(positions: torch.Tensor, cutoff: float, batch_idx: torch.Tensor | None = None,
                               batch_ptr: torch.Tensor | None = None, pbc: torch.Tensor | None = None, cell: torch.Tensor | None = None,
                               max_neighbors: int | None = None, half_fill: bool = False, fill_value: int | None = None,

@@ -4,10 +4,12 @@ from __future__ import annotations
 
 import torch
 
+from nvalchemiops import _capi as C
 from nvalchemiops.neighborlist.neighbor_utils import estimate_max_neighbors
 from nvalchemiops.neighborlist.batch_naive import batch_naive_neighbor_list
 
 
+@C.eager
 def batch_naive_neighbor_list_dual_cutoff(positions: torch.Tensor, cutoff1: float, cutoff2: float, batch_idx: torch.Tensor | None = None,
                                           batch_ptr: torch.Tensor | None = None, pbc: torch.Tensor | None = None,
                                           cell: torch.Tensor | None = None, max_neighbors1: int | None = None,

@@ -21,6 +21,7 @@ _CACHE_NAMES = ("cells_per_dimension", "neighbor_search_radius", "atom_periodic_
                 "atoms_per_cell_count", "cell_atom_start_indices", "cell_atom_list")
 
 
+@C.eager
 def estimate_cell_list_sizes(cell: torch.Tensor, pbc: torch.Tensor, cutoff: float, max_nbins: int = 1000):
     """(max_total_cells, neighbor_search_radius[3]) with the reference's rule: cells/dim = max(int(face/cutoff),1),
     radius = ceil(cutoff*cells/face), halve all dims until the product fits max_nbins (cell_list.py:35-99, 639-722)."""
@@ -48,6 +49,7 @@ def _build_cache(pos, cell, pbc, batch_idx, cutoff, cpd, shifts, mapping, counts
     C.check(rc, "mi_nl_build_cell_cache")
 
 
+@C.eager
 def build_cell_list(positions, cutoff, cell, pbc, cells_per_dimension, neighbor_search_radius, atom_periodic_shifts,
                     atom_to_cell_mapping, atoms_per_cell_count, cell_atom_start_indices, cell_atom_list) -> None:
     """Fill the caller's cache tensors in place (cell_list.py:725-889, 1037-1105).  Capacity = atoms_per_cell_count.shape[0]."""
@@ -59,6 +61,7 @@ def build_cell_list(positions, cutoff, cell, pbc, cells_per_dimension, neighbor_
                  cell_atom_start_indices, cell_atom_list)
 
 
+@C.eager
 def query_cell_list(positions, cutoff, cell, pbc, cells_per_dimension, neighbor_search_radius, atom_periodic_shifts,
                     atom_to_cell_mapping, atoms_per_cell_count, cell_atom_start_indices, cell_atom_list, neighbor_matrix,
                     neighbor_matrix_shifts, num_neighbors, half_fill: bool = False) -> None:
@@ -101,6 +104,7 @@ def _search(pos, c, p, batch_idx, cutoff, max_neighbors, half_fill, fill_value, 
     return neighbor_matrix, num_neighbors, neighbor_matrix_shifts
 
 
+@C.eager
 def cell_list(positions: torch.Tensor, cutoff: float, cell: torch.Tensor, pbc: torch.Tensor, max_neighbors: int | None = None,
               half_fill: bool = False, fill_value: int | None = None, return_neighbor_list: bool = False,
               neighbor_matrix: torch.Tensor | None = None, neighbor_matrix_shifts: torch.Tensor | None = None,

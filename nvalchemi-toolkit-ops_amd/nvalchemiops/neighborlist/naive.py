@@ -27,6 +27,7 @@ def _bounding_cell(pos: torch.Tensor, batch_idx=None, n_sys: int = 1):
     return cell, origin
 
 
+@C.eager
 def naive_neighbor_list(positions: torch.Tensor, cutoff: float, cell: torch.Tensor | None = None, pbc: torch.Tensor | None = None,
                         max_neighbors: int | None = None, half_fill: bool = False, fill_value: int | None = None,
                         return_neighbor_list: bool = False, neighbor_matrix: torch.Tensor | None = None,

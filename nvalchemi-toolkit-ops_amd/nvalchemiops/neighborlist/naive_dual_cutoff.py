@@ -8,10 +8,12 @@ from __future__ import annotations
 
 import torch
 
+from nvalchemiops import _capi as C
 from nvalchemiops.neighborlist.neighbor_utils import estimate_max_neighbors
 from nvalchemiops.neighborlist.naive import naive_neighbor_list
 
 
+@C.eager
 def naive_neighbor_list_dual_cutoff(positions: torch.Tensor, cutoff1: float, cutoff2: float, pbc: torch.Tensor | None = None,
                                     cell: torch.Tensor | None = None, max_neighbors1: int | None = None,
                                     max_neighbors2: int | None = None, half_fill: bool = False, fill_value: int | None = None,

@@ -36,6 +36,7 @@ def assert_max_neighbors(neighbor_matrix: torch.Tensor, num_neighbors: torch.Ten
         raise NeighborOverflowError(neighbor_matrix.shape[1], worst)
 
 
+@C.eager
 def get_neighbor_list_from_neighbor_matrix(neighbor_matrix: torch.Tensor, num_neighbors: torch.Tensor,
                                            neighbor_shift_matrix: torch.Tensor | None = None, fill_value: int = -1):
     """Padded matrix -> (neighbor_list[2,P], neighbor_ptr[N+1][, shifts[P,3]]) (neighbor_utils.py:362-441).

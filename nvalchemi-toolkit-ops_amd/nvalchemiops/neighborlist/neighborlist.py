@@ -59,6 +59,7 @@ def _free_space_cell_list(positions, cutoff, batch_idx, half_fill, fill_value, r
     return nm, num, nsh
 
 
+@C.eager
 def neighbor_list(positions: torch.Tensor, cutoff: float, cell: torch.Tensor | None = None, pbc: torch.Tensor | None = None,
                   batch_idx: torch.Tensor | None = None, batch_ptr: torch.Tensor | None = None, cutoff2: float | None = None,
                   half_fill: bool = False, fill_value: int | None = None, return_neighbor_list: bool = False,

@@ -11,6 +11,7 @@ from nvalchemiops import _capi as C
 from nvalchemiops.neighborlist import _engine as E
 
 
+@C.eager
 def cell_list_needs_rebuild(current_positions: torch.Tensor, atom_to_cell_mapping: torch.Tensor, cells_per_dimension: torch.Tensor,
                             cell: torch.Tensor, pbc: torch.Tensor) -> torch.Tensor:
     """True when any atom now bins into a different cell than `atom_to_cell_mapping` (from `build_cell_list`) says."""
@@ -29,6 +30,7 @@ def cell_list_needs_rebuild(current_positions: torch.Tensor, atom_to_cell_mappin
     return flag
 
 
+@C.eager
 def neighbor_list_needs_rebuild(reference_positions: torch.Tensor, current_positions: torch.Tensor,
                                 skin_distance_threshold: float) -> torch.Tensor:
     """True when any atom moved farther than `skin_distance_threshold` from its position at list-build time
@@ -49,6 +51,7 @@ def neighbor_list_needs_rebuild(reference_positions: torch.Tensor, current_posit
     return flag
 
 
+@C.eager
 def check_cell_list_rebuild_needed(cells_per_dimension, neighbor_search_radius, atom_periodic_shifts, atom_to_cell_mapping,
                                    atoms_per_cell_count, cell_atom_start_indices, cell_atom_list, current_positions, current_cell,
                                    current_pbc, cutoff: float) -> bool:
@@ -56,6 +59,7 @@ def check_cell_list_rebuild_needed(cells_per_dimension, neighbor_search_radius, 
     return bool(cell_list_needs_rebuild(current_positions, atom_to_cell_mapping, cells_per_dimension, current_cell, current_pbc).item())
 
 
+@C.eager
 def check_neighbor_list_rebuild_needed(reference_positions, current_positions, skin_distance_threshold: float) -> bool:
     return bool(neighbor_list_needs_rebuild(reference_positions, current_positions, skin_distance_threshold).item())
 

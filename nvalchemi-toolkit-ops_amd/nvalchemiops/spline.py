@@ -129,6 +129,7 @@ def _differentiable_cit(cell: torch.Tensor, cell_inv_t, dtype):
     return (torch.linalg.inv(c).transpose(-1, -2) if cell_inv_t is None else cell_inv_t.to(dtype).reshape(-1, 3, 3)), c
 
 
+@C.eager
 def spline_spread(positions: torch.Tensor, values: torch.Tensor, cell: torch.Tensor, mesh_dims: tuple[int, int, int], spline_order: int = 4,
                   batch_idx: torch.Tensor | None = None, cell_inv_t: torch.Tensor | None = None) -> torch.Tensor:
     """mesh[(B,) nx, ny, nz] += values_i * M_n(x) M_n(y) M_n(z) over each atom's order^3 stencil (periodic wrap).
@@ -149,6 +150,7 @@ def spline_spread(positions: torch.Tensor, values: torch.Tensor, cell: torch.Ten
     return mesh if bi is not None else mesh[0]
 
 
+@C.eager
 def spline_gather(positions: torch.Tensor, mesh: torch.Tensor, cell: torch.Tensor, spline_order: int = 4,
                   batch_idx: torch.Tensor | None = None, cell_inv_t: torch.Tensor | None = None) -> torch.Tensor:
     """out_i = sum over the stencil of mesh[g] * w  (weights <= 1e-8 are skipped, spline.py:608).
@@ -168,6 +170,7 @@ def spline_gather(positions: torch.Tensor, mesh: torch.Tensor, cell: torch.Tenso
     return out
 
 
+@C.eager
 def spline_gather_vec3(positions: torch.Tensor, charges: torch.Tensor, mesh: torch.Tensor, cell: torch.Tensor, spline_order: int = 4,
                        batch_idx: torch.Tensor | None = None, cell_inv_t: torch.Tensor | None = None) -> torch.Tensor:
     """out_i[3] = sum over the stencil of q_i * mesh[g, :] * w for a mesh of shape [(B,) nx, ny, nz, 3]."""

@@ -1,0 +1,147 @@
+"""`torch.compile` over the public functional API, as the reference's own tests do with a bare `@torch.compile`
+(test/neighborlist/test_cell_list.py:599-760, test_naive.py:1200-1300, test_batch_cell_list.py, test/interactions/dispersion/
+test_dftd3.py:1204-1330): the entry points are `torch.compiler.disable`d eager islands (nvalchemiops._capi.eager), the torch code
+around them is compiled by Inductor, and results equal the eager call.  (The fullgraph seam -- `torch.ops.nvalchemiops.*` -- is
+covered by tests/test_nlist_gpu.py::test_custom_ops_and_graph_capture.)"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle as O
+from tests import systems as S
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _t(a):
+    return torch.as_tensor(np.ascontiguousarray(a), device=DEV)
+
+
+def _same(a, b):
+    assert len(a) == len(b)
+    for x, y in zip(a, b):
+        assert x.shape == y.shape and x.dtype == y.dtype and x.device == y.device
+        assert torch.equal(x, y) if x.dtype in (torch.int32, torch.int64, torch.bool) else torch.allclose(x, y, rtol=1e-6, atol=1e-9)
+
+
+@pytest.mark.parametrize("half_fill", [False, True])
+def test_naive_neighbor_list_compiles(half_fill):
+    from nvalchemiops.neighborlist import naive_neighbor_list
+
+    pos, cell = S.random_box(50, 6.0, seed=31, dtype=np.float32)
+    tp, tc, pbc = _t(pos), _t(cell).reshape(1, 3, 3), torch.ones((1, 3), dtype=torch.bool, device=DEV)
+
+    @torch.compile
+    def free(positions, cutoff, neighbor_matrix, num_neighbors, half_fill):
+        return naive_neighbor_list(positions=positions, cutoff=cutoff, neighbor_matrix=neighbor_matrix, num_neighbors=num_neighbors,
+                                   half_fill=half_fill)
+
+    nm = torch.full((50, 100), 50, dtype=torch.int32, device=DEV)
+    num = torch.zeros(50, dtype=torch.int32, device=DEV)
+    free(tp, 3.0, nm, num, half_fill)
+    assert int(num.sum()) > 0
+    _same((nm, num), naive_neighbor_list(tp, 3.0, max_neighbors=100, half_fill=half_fill))
+
+    @torch.compile
+    def periodic(positions, cutoff, cell, pbc, half_fill):
+        nm, num, sh = naive_neighbor_list(positions, cutoff, cell=cell, pbc=pbc, max_neighbors=64, half_fill=half_fill)
+        return nm, num * 1, sh  # some torch work for Inductor on either side of the island
+
+    _same(periodic(tp, 2.0, tc, pbc, half_fill), naive_neighbor_list(tp, 2.0, cell=tc, pbc=pbc, max_neighbors=64, half_fill=half_fill))
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_build_and_query_cell_list_compile(dtype):
+    from nvalchemiops.neighborlist import allocate_cell_list, build_cell_list, estimate_cell_list_sizes, query_cell_list
+
+    pos, cell = S.random_box(400, 14.0, seed=32, dtype=dtype)
+    tp, tc, pbc = _t(pos), _t(cell).reshape(1, 3, 3), torch.tensor([True, True, True], device=DEV)
+    ncell, radius = estimate_cell_list_sizes(tc, pbc, 4.0)
+    eager_cache = allocate_cell_list(400, ncell, radius, tp.device)
+    build_cell_list(tp, 4.0, tc, pbc, *eager_cache)
+    comp_cache = allocate_cell_list(400, ncell, radius, tp.device)
+
+    @torch.compile
+    def compiled_build(positions, cutoff, cell, pbc, cpd, rad, aps, a2c, apc, start, lst):
+        build_cell_list(positions, cutoff, cell, pbc, cpd, rad, aps, a2c, apc, start, lst)
+
+    compiled_build(tp, 4.0, tc, pbc, *comp_cache)
+    _same(eager_cache, comp_cache)
+
+    def outputs():
+        return (torch.full((400, 96), 400, dtype=torch.int32, device=DEV), torch.zeros((400, 96, 3), dtype=torch.int32, device=DEV),
+                torch.zeros(400, dtype=torch.int32, device=DEV))
+
+    eo, co = outputs(), outputs()
+    query_cell_list(tp, 4.0, tc, pbc, *eager_cache, *eo, False)
+
+    @torch.compile
+    def compiled_query(positions, cutoff, cell, pbc, cache, nm, sh, num):
+        query_cell_list(positions, cutoff, cell, pbc, *cache, nm, sh, num, False)
+        return num.sum()
+
+    total = compiled_query(tp, 4.0, tc, pbc, comp_cache, *co)
+    _same(eo, co)
+    assert int(total) == int(eo[2].sum()) > 0
+
+
+def test_batch_cell_list_and_dispatcher_compile():
+    from nvalchemiops.neighborlist import batch_cell_list, neighbor_list
+
+    p0, c0 = S.random_box(300, 12.0, seed=33, dtype=np.float32)
+    p1, c1 = S.random_box(200, 10.0, seed=34, dtype=np.float32, triclinic=True)
+    tp, tc = _t(np.concatenate([p0, p1])), _t(np.stack([c0, c1]))
+    pbc = torch.ones((2, 3), dtype=torch.bool, device=DEV)
+    bi = torch.tensor([0] * 300 + [1] * 200, dtype=torch.int32, device=DEV)
+
+    @torch.compile
+    def f(p, c, b, i):
+        return batch_cell_list(p, 3.5, c, b, i, max_neighbors=96)
+
+    _same(f(tp, tc, pbc, bi), batch_cell_list(tp, 3.5, tc, pbc, bi, max_neighbors=96))
+
+    @torch.compile
+    def g(p, c, b, i):
+        lst, ptr, sh = neighbor_list(p, 3.5, cell=c, pbc=b, batch_idx=i, method="batch_cell_list", max_neighbors=96, return_neighbor_list=True)
+        return lst, ptr, sh
+
+    _same(g(tp, tc, pbc, bi), neighbor_list(tp, 3.5, cell=tc, pbc=pbc, batch_idx=bi, method="batch_cell_list", max_neighbors=96,
+                                            return_neighbor_list=True))
+
+
+def test_dftd3_and_pme_compile():
+    from nvalchemiops.interactions.dispersion import D3Parameters, dftd3
+    from nvalchemiops.interactions.electrostatics import particle_mesh_ewald
+    from nvalchemiops.neighborlist import cell_list
+
+    t = O.d3_test_tables(17)
+    params = D3Parameters(rcov=_t(t["rcov"]), r4r2=_t(t["r4r2"]), c6ab=_t(t["c6ab"]), cn_ref=_t(t["cn_ref"]))
+    pos, cell = S.random_box(300, 22.0, seed=35, dtype=np.float32)
+    g = np.random.default_rng(0)
+    numbers = _t(g.choice([1, 6, 7, 8], 300).astype(np.int32))
+    tp, tc, pbc = _t(pos), _t(cell).reshape(1, 3, 3), torch.tensor([True, True, True], device=DEV)
+    nm, num, sh = cell_list(tp, 10.0, tc, pbc, max_neighbors=160)
+    assert int(num.max()) <= 160
+    kw = dict(a1=0.4, a2=4.0, s8=0.8, d3_params=params, neighbor_matrix=nm, neighbor_matrix_shifts=sh, cell=tc, fill_value=300)
+    compiled = torch.compile(dftd3)  # test_dftd3.py:1228
+    e, f, cn = compiled(positions=tp, numbers=numbers, **kw)
+    e0, f0, cn0 = dftd3(positions=tp, numbers=numbers, **kw)
+    assert e.shape == (1,) and f.shape == (300, 3) and cn.shape == (300,) and f.dtype == torch.float32
+    assert torch.allclose(e, e0, rtol=1e-6) and torch.allclose(f, f0, rtol=1e-5, atol=1e-9) and torch.allclose(cn, cn0, rtol=1e-6)
+
+    q = torch.randn(300, dtype=torch.float64, device=DEV)
+    q -= q.mean()
+    pd, cd = tp.double(), tc.double()
+    nm, num, sh = cell_list(pd, 6.0, cd, pbc, max_neighbors=64)
+
+    @torch.compile
+    def step(p, q, c, nm, sh):
+        e, f = particle_mesh_ewald(p, q, c, alpha=0.4, mesh_dimensions=(16, 16, 16), spline_order=4, neighbor_matrix=nm,
+                                   neighbor_matrix_shifts=sh, compute_forces=True)
+        return e.sum() * 2.0, f
+
+    et, ft = step(pd, q, cd, nm, sh)
+    e0, f0 = particle_mesh_ewald(pd, q, cd, alpha=0.4, mesh_dimensions=(16, 16, 16), spline_order=4, neighbor_matrix=nm,
+                                 neighbor_matrix_shifts=sh, compute_forces=True)
+    assert torch.allclose(et, e0.sum() * 2.0, rtol=1e-12) and torch.allclose(ft, f0, rtol=1e-10, atol=1e-12)
