@@ -133,6 +133,14 @@ __device__ __forceinline__ float d3_cn_count(float rinv, float rci, float rcj, f
   return f;
 }
 
+// A stored index is a neighbour iff 0 <= j < N and, in the padded-matrix layout, j < fill_value (dftd3.py:871: `j >= fill_value` is
+// padding).  The reference reads out of bounds for anything else (e.g. -1 padding with the default fill_value = N); here such
+// entries are padding too.  One unsigned compare against a wave-uniform limit.
+template <bool CSR>
+__device__ __forceinline__ unsigned d3_index_limit(int N, int fill_value) {
+  return CSR ? (unsigned)N : (unsigned)min(N, max(fill_value, 0));
+}
+
 template <class T, bool CSR>
 __device__ __forceinline__ void d3_row(int i, int M, const int* __restrict__ nptr, long long& beg, long long& end) {
   if (CSR) { beg = nptr[i]; end = nptr[i + 1]; }
@@ -181,14 +189,15 @@ __global__ __launch_bounds__(D3_LS_WAVES * MI_WAVE) void d3_cn_kernel(const T* _
   double acc = 0.0;
   const Int3* __restrict__ ush3 = reinterpret_cast<const Int3*>(ush);
   long long e = beg + lane;
+  const unsigned jlim = d3_index_limit<CSR>(N, fill_value);
   D3Step s0 = d3_fetch(idx, ush3, e, end, periodic), s1 = d3_fetch(idx, ush3, e + MI_WAVE, end, periodic);
-  bool v0 = s0.in && (CSR || s0.j < fill_value);
+  bool v0 = s0.in && ((unsigned)s0.j < jlim);
   auto p0 = apos[v0 ? s0.j : i];
   for (int trip = 0; trip < trips; ++trip) {
     __syncthreads();  // lock-step: the block's waves walk rows of consecutive atoms, i.e. nearly the same neighbours in nearly the same order
     e += MI_WAVE;
     const D3Step s2 = d3_fetch(idx, ush3, e + MI_WAVE, end, periodic);
-    const bool v1 = s1.in && (CSR || s1.j < fill_value);
+    const bool v1 = s1.in && ((unsigned)s1.j < jlim);
     const auto p1 = apos[v1 ? s1.j : i];
     if (__any(v0)) {  // a step of pure padding costs nothing (padded matrices are mostly padding)
       bool valid = v0 && !(p0.w < (T)0);  // padding atom (Z == 0)
@@ -501,8 +510,9 @@ __device__ __forceinline__ void d3_energy_body(const T* __restrict__ pos, const 
   double dacc = 0.0;
   const Int3* __restrict__ ush3 = reinterpret_cast<const Int3*>(ush);
   long long e = beg + lane;
+  const unsigned jlim = d3_index_limit<CSR>(N, fill_value);
   D3Step s0 = d3_fetch(idx, ush3, e, end, periodic), s1 = d3_fetch(idx, ush3, e + MI_WAVE, end, periodic);
-  bool v0 = s0.in && (CSR || s0.j < fill_value);
+  bool v0 = s0.in && ((unsigned)s0.j < jlim);
   using PosRec = typename Vec4<T>::type;
   auto pos_of = [&](int j) -> PosRec {
     if constexpr (PACKED) return aw[2 * (size_t)j];
@@ -521,7 +531,7 @@ __device__ __forceinline__ void d3_energy_body(const T* __restrict__ pos, const 
   for (long long base = beg; base < end; base += MI_WAVE) {
     e += MI_WAVE;
     const D3Step s2 = d3_fetch(idx, ush3, e + MI_WAVE, end, periodic);
-    const bool v1 = s1.in && (CSR || s1.j < fill_value);
+    const bool v1 = s1.in && ((unsigned)s1.j < jlim);
     const PosRec p1 = pos_of(v1 ? s1.j : i);
     float4 a1, b1;
     aux_of(v1 ? s1.j : i, a1, b1);
@@ -646,15 +656,16 @@ __global__ __launch_bounds__(D3_LS_WAVES * MI_WAVE) void d3_chain_kernel(const T
   double V[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
   const Int3* __restrict__ ush3 = reinterpret_cast<const Int3*>(ush);
   long long e = beg + lane;
+  const unsigned jlim = d3_index_limit<CSR>(N, fill_value);
   D3Step s0 = d3_fetch(idx, ush3, e, end, periodic), s1 = d3_fetch(idx, ush3, e + MI_WAVE, end, periodic);
-  bool v0 = s0.in && (CSR || s0.j < fill_value);
+  bool v0 = s0.in && ((unsigned)s0.j < jlim);
   auto p0 = apos[v0 ? s0.j : i];
   float d0 = dEdCN[v0 ? s0.j : i];
   for (int trip = 0; trip < trips; ++trip) {
     __syncthreads();  // lock-step (see d3_cn_kernel)
     e += MI_WAVE;
     const D3Step s2 = d3_fetch(idx, ush3, e + MI_WAVE, end, periodic);
-    const bool v1 = s1.in && (CSR || s1.j < fill_value);
+    const bool v1 = s1.in && ((unsigned)s1.j < jlim);
     const auto p1 = apos[v1 ? s1.j : i];
     const float d1 = dEdCN[v1 ? s1.j : i];
     if (__any(v0)) {

@@ -45,7 +45,7 @@ __global__ __launch_bounds__(256) void ewald_real_kernel(const T* __restrict__ p
   T fx = 0, fy = 0, fz = 0;
   for (long long e = beg + lane; e < end; e += MI_WAVE) {
     const int j = idx[e];
-    if (!CSR && j == mask_value) continue;
+    if ((!CSR && j == mask_value) || (unsigned)j >= (unsigned)N) continue;  // out-of-range indices (e.g. -1 padding with another mask_value) are padding
     const double qj = (double)q[j];
     const T fs[3] = {(T)ush[3 * e], (T)ush[3 * e + 1], (T)ush[3 * e + 2]};
     T sh[3];
@@ -99,7 +99,7 @@ __global__ __launch_bounds__(256) void ewald_real_bwd_kernel(const T* __restrict
   double gc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
   for (long long e = beg + lane; e < end; e += MI_WAVE) {
     const int j = idx[e];
-    if (!CSR && j == mask_value) continue;
+    if ((!CSR && j == mask_value) || (unsigned)j >= (unsigned)N) continue;  // out-of-range indices (e.g. -1 padding with another mask_value) are padding
     const double qj = (double)q[j], gj = (double)gE[j];
     const int S0 = ush[3 * e], S1 = ush[3 * e + 1], S2 = ush[3 * e + 2];
     const T fs[3] = {(T)S0, (T)S1, (T)S2};

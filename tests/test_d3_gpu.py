@@ -241,3 +241,27 @@ def test_more_than_16_species_uses_global_table():
     ref = O.dftd3(pos, z, t, neighbor_matrix=nm.cpu().numpy(), neighbor_matrix_shifts=sh.cpu().numpy(), cell=cell, compute_virial=True, **FP)
     out = dftd3(_t(pos), _t(z), d3_params=p, neighbor_matrix=nm, neighbor_matrix_shifts=sh, cell=_t(cell)[None], compute_virial=True, **FP)
     _check(out, ref, virial=True)
+
+
+def test_out_of_range_indices_are_padding():
+    """-1 (or >= N) entries with the default fill_value = N: the reference indexes out of bounds; here they are padding."""
+    from nvalchemiops.interactions.dispersion import dftd3
+
+    t, params = _params()
+    mol, numbers, _ = S.molecule(64, seed=77)
+    n = 64
+    nm = np.array([[j for j in range(n) if j != i] + [n] * 5 for i in range(n)], np.int32)
+    bad = nm.copy()
+    bad[:, -5:] = np.array([-1, -7, n + 3, 1 << 30, -(1 << 31)], np.int64).astype(np.int32)
+    kw = dict(a1=FP["a1"], a2=FP["a2"], s8=FP["s8"], d3_params=params)
+    ref = dftd3(_t(mol), _t(numbers), neighbor_matrix=_t(nm), **kw)
+    out = dftd3(_t(mol), _t(numbers), neighbor_matrix=_t(bad), **kw)
+    for a, b in zip(out, ref):
+        assert torch.equal(a, b)
+    # CSR with stray indices
+    lst = np.stack([np.repeat(np.arange(n), nm.shape[1]), bad.ravel()]).astype(np.int32)
+    ptr = (np.arange(n + 1) * nm.shape[1]).astype(np.int32)
+    out = dftd3(_t(mol), _t(numbers), neighbor_list=_t(lst), neighbor_ptr=_t(ptr), **kw)
+    _close(out[0], ref[0].cpu().numpy(), 2e-6, 1e-7, "energy (CSR with stray indices)")
+    assert torch.isfinite(out[1]).all()
+

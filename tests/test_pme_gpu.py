@@ -380,6 +380,28 @@ def test_ewald_reciprocal_space_cell_alpha_kvector_gradients(batched):
                 assert abs(fd - float(flat[idx, c])) < 2e-7 * max(1.0, abs(fd)), ("k", idx, c, fd, float(flat[idx, c]))
 
 
+def test_out_of_range_indices_are_padding():
+    """The reference's `test_default_mask_value_pme` (test_pme.py:2201) pads a neighbour matrix with -1 while mask_value defaults
+    to N: the reference reads positions[-1]; here any index outside [0, N) is padding, so the result equals the N-padded matrix."""
+    from nvalchemiops.interactions.electrostatics import ewald_real_space, particle_mesh_ewald
+
+    g = np.random.default_rng(3)
+    pos, q = _t(g.uniform(0, 10, (5, 3))), _t(g.normal(size=5))
+    cell = torch.eye(3, dtype=torch.float64, device=DEV) * 10
+    nm_neg = torch.tensor([[1, -1], [0, 2], [1, 3], [2, 4], [3, -1]], dtype=torch.int32, device=DEV)
+    nm_pad = torch.where(nm_neg < 0, torch.full_like(nm_neg, 5), nm_neg)
+    sh = torch.zeros((5, 2, 3), dtype=torch.int32, device=DEV)
+    kw = dict(alpha=0.3, mesh_dimensions=(16, 16, 16), neighbor_matrix_shifts=sh, compute_forces=True)
+    e, f = particle_mesh_ewald(pos, q, cell, neighbor_matrix=nm_neg, **kw)
+    e2, f2 = particle_mesh_ewald(pos, q, cell, neighbor_matrix=nm_pad, **kw)
+    assert e.shape == (5,) and f.shape == (5, 3) and torch.isfinite(e).all() and torch.isfinite(f).all()
+    assert torch.equal(e, e2) and torch.equal(f, f2)
+    al = torch.tensor([0.3], dtype=torch.float64, device=DEV)
+    huge = torch.tensor([[1, 7], [0, 2], [1, 3], [2, 4], [3, 1 << 30]], dtype=torch.int32, device=DEV)
+    assert torch.equal(ewald_real_space(pos, q, cell, al, neighbor_matrix=huge, neighbor_matrix_shifts=sh, mask_value=5),
+                       ewald_real_space(pos, q, cell, al, neighbor_matrix=nm_pad, neighbor_matrix_shifts=sh, mask_value=5))
+
+
 def test_hip_path_against_committed_oracle_vectors():
     """HIP nlist / D3 / PME / explicit-k Ewald against tests/golden/oracle_vectors.npz (made by tests/golden/make_golden.py)."""
     import os
