@@ -57,8 +57,11 @@ def naive_neighbor_list(positions: torch.Tensor, cutoff: float, cell: torch.Tens
         if periodic:
             neighbor_matrix_shifts = (torch.zeros((n, neighbor_matrix.shape[1], 3), **i32) if neighbor_matrix_shifts is None
                                       else neighbor_matrix_shifts.zero_())
-        if return_neighbor_list:  # shapes of naive.py:627-657
+        if return_neighbor_list and cutoff <= 0:  # the reference's own shapes for this case (naive.py:627-657)
             out = (torch.zeros((2, 0), **i32), torch.zeros((n,), **i32), torch.zeros((n + 1,), **i32))
+            return out + (torch.zeros((0, 3), **i32),) if periodic else out
+        if return_neighbor_list:  # no atoms: the regular COO conversion of an empty matrix (test_neighborlist.py:905-921)
+            out = (torch.zeros((2, 0), **i32), torch.zeros((n + 1,), **i32))
             return out + (torch.zeros((0, 3), **i32),) if periodic else out
         return (neighbor_matrix, num_neighbors, neighbor_matrix_shifts) if periodic else (neighbor_matrix, num_neighbors)
     C.require_device(positions, cell, pbc)

@@ -47,7 +47,7 @@ def test_no_cpu_fallback():
 
 
 def test_empty_inputs_and_shapes():
-    from nvalchemiops.neighborlist import batch_cell_list, cell_list, naive_neighbor_list
+    from nvalchemiops.neighborlist import batch_cell_list, batch_naive_neighbor_list, cell_list, naive_neighbor_list
 
     cell, pbc = torch.eye(3), torch.tensor([True] * 3)
     nm, num, sh = cell_list(torch.zeros(0, 3), 2.0, cell, pbc)
@@ -68,6 +68,22 @@ def test_empty_inputs_and_shapes():
         neighbor_list(torch.zeros(3, 3), 1.0, method="nope")
     out = neighbor_list(torch.zeros(0, 3), 1.0, cutoff2=2.0)  # dual cutoff: interleaved (matrix1, num1, matrix2, num2)
     assert len(out) == 4 and out[0].shape[0] == 0 and out[2].shape[0] == 0
+    # no atoms / one atom through the dispatcher, COO output (test_neighborlist.py:905-950): (list, ptr) with ptr = [0] / [0, 0]
+    lst, ptr = neighbor_list(torch.zeros(0, 3), 2.0, method="naive", return_neighbor_list=True)
+    assert lst.shape == (2, 0) and ptr.tolist() == [0]
+    # cutoff <= 0 keeps the reference's own tuple for that case (naive.py:627-657): (list, zeros[n], zeros[n+1])
+    out = neighbor_list(torch.zeros(1, 3), 0.0, method="naive", return_neighbor_list=True)
+    assert len(out) == 3 and out[0].shape == (2, 0) and out[1].shape == (1,) and out[2].shape == (2,)
+    lst, ptr = batch_naive_neighbor_list(torch.zeros(0, 3), 2.0, batch_idx=torch.zeros(0, dtype=torch.int32),
+                                         batch_ptr=torch.zeros(1, dtype=torch.int32), return_neighbor_list=True)
+    assert lst.shape == (2, 0) and ptr.tolist() == [0]
+    lst, ptr, lsh = cell_list(torch.zeros(8, 3), 0.0, cell, pbc, return_neighbor_list=True)  # test_cell_list.py:292-313
+    assert lst.shape == (2, 0) and ptr.shape == (9,) and lsh.shape == (0, 3)
+    from nvalchemiops.neighborlist import estimate_cell_list_sizes
+
+    for c_, p_, rc in ((torch.zeros((0, 3, 3)), torch.zeros((0, 3), dtype=torch.bool), 1.0), (torch.eye(3).reshape(1, 3, 3), pbc[None], -1.0)):
+        ncell, radius = estimate_cell_list_sizes(c_, p_, rc)  # test_cell_list.py:427-446
+        assert ncell == 1 and radius.shape == (3,) and radius.dtype == torch.int32
 
 
 def test_estimate_max_neighbors_and_overflow_error():
