@@ -19,6 +19,10 @@ def _prep(positions: torch.Tensor, cell: torch.Tensor, batch_idx, cell_inv_t):
         cell_inv_t = torch.linalg.inv(c).transpose(-1, -2)
     cit = cell_inv_t.detach().to(pos.dtype).reshape(-1, 3, 3).contiguous()
     bi = None if batch_idx is None else C.i32(batch_idx)
+    if bi is not None and c.shape[0] == 1 and bi.numel():
+        # one cell for the whole batch (spline.py:2256, :2775: `cell.unsqueeze(0).expand(num_systems, ...)`)
+        nsys = int(bi.max().item()) + 1
+        c, cit = c.expand(nsys, 3, 3), cit.expand(nsys, 3, 3).contiguous()
     return pos, c, cit, bi
 
 
@@ -186,4 +190,81 @@ def spline_gather_vec3(positions: torch.Tensor, charges: torch.Tensor, mesh: tor
     return out
 
 
-__all__ = ["spline_spread", "spline_gather", "spline_gather_vec3"]
+@C.eager
+def spline_gather_gradient(positions: torch.Tensor, charges: torch.Tensor, mesh: torch.Tensor, cell: torch.Tensor, spline_order: int = 4,
+                           batch_idx: torch.Tensor | None = None, cell_inv_t: torch.Tensor | None = None) -> torch.Tensor:
+    """F_i = -q_i sum_g mesh[g] grad_r w(r_i, g): the fractional-coordinate gradient (scaled by the mesh dimensions) mapped to Cartesian
+    with cell_inv_t^T (spline.py:2733-2785; kernels :678-755).  Plain output: no second-derivative adjoint is provided."""
+    C.require_device(positions, charges, mesh, cell)
+    pos, c, cit, bi = _prep(positions, cell, batch_idx, cell_inv_t)
+    gfrac = _launch_gather(pos, mesh.detach().to(pos.dtype).contiguous(), cit, bi, int(spline_order), grad=True)
+    cit_i = cit[bi.long()] if bi is not None else cit[0].expand(pos.shape[0], 3, 3)
+    return -charges.detach().to(pos.dtype).unsqueeze(-1) * torch.einsum("na,nab->nb", gfrac, cit_i)
+
+
+@C.eager
+def spline_spread_channels(positions: torch.Tensor, values: torch.Tensor, cell: torch.Tensor, mesh_dims: tuple[int, int, int],
+                           spline_order: int = 4, batch_idx: torch.Tensor | None = None) -> torch.Tensor:
+    """values[N, C] -> mesh[(B,) C, nx, ny, nz] (spline.py:2788-2860).  One tile-owned scalar spread per channel -- the channels
+    share nothing but the per-atom weights, and the multipole path that uses many channels is outside this build's hot path."""
+    chans = [spline_spread(positions, values[:, ch], cell, mesh_dims, spline_order, batch_idx) for ch in range(values.shape[1])]
+    if not chans:
+        lead = () if batch_idx is None else ((cell.shape[0] if cell.dim() == 3 else int(batch_idx.max().item()) + 1),)
+        return torch.zeros(lead + (0,) + tuple(int(v) for v in mesh_dims), dtype=positions.dtype, device=positions.device)
+    return torch.stack(chans, dim=0 if batch_idx is None else 1)
+
+
+@C.eager
+def spline_gather_channels(positions: torch.Tensor, mesh: torch.Tensor, cell: torch.Tensor, spline_order: int = 4,
+                           batch_idx: torch.Tensor | None = None) -> torch.Tensor:
+    """mesh[(B,) C, nx, ny, nz] -> values[N, C] (spline.py:2863-2910); one scalar gather per channel."""
+    nch = mesh.shape[0] if batch_idx is None else mesh.shape[1]
+    cols = [spline_gather(positions, mesh[ch] if batch_idx is None else mesh[:, ch], cell, spline_order, batch_idx) for ch in range(nch)]
+    if not cols:
+        return torch.zeros((positions.shape[0], 0), dtype=positions.dtype, device=positions.device)
+    return torch.stack(cols, dim=1)
+
+
+def _bspline_modulus_sq(n: int, order: int, device) -> torch.Tensor:
+    """|b(k)|^2 of the order-n cardinal B-spline on an n-point grid, b(k) = sum_j M_order(j+1) exp(2 pi i j k/n), k = fftfreq order;
+    float64 (spline.py:2913-2980, Essmann et al. 1995 eq. 4.7)."""
+    # The reference's coefficient table for "order n" holds the cardinal B-spline of order n+1 at the integers 1..n
+    # ([1/6, 4/6, 1/6] for n = 3, ..., spline.py:2999-3022); beyond n = 6 it continues with its own two-term recursion (:3024-3035).
+    base = min(order, 6)
+    m = torch.zeros(base + 2, dtype=torch.float64)
+    m[0] = 1.0  # order 1: indicator of [0, 1) at the integers 0..base+1
+    u = torch.arange(base + 2, dtype=torch.float64)
+    for o in range(2, base + 2):  # Cox-de Boor: M_o(u) = [u M_{o-1}(u) + (o - u) M_{o-1}(u - 1)] / (o - 1)
+        m = (u * m + (o - u) * torch.cat([torch.zeros(1, dtype=torch.float64), m[:-1]])) / (o - 1)
+    coeff = m[1:base + 1]
+    for o in range(7, order + 1):
+        uu = torch.arange(1, o + 1, dtype=torch.float64)
+        cur = torch.cat([coeff, torch.zeros(1, dtype=torch.float64)])
+        prev = torch.cat([torch.zeros(1, dtype=torch.float64), coeff])
+        coeff = (uu * cur + (o - uu) * prev) / (o - 1)
+    coeff = coeff.to(device)
+    k = torch.fft.fftfreq(n, device=device) * n
+    w = 2.0 * torch.pi * k.to(torch.float32).to(torch.float64) / n
+    j = torch.arange(order, dtype=torch.float64, device=device)
+    phase = w.unsqueeze(-1) * j
+    b2 = (coeff * torch.cos(phase)).sum(-1) ** 2 + (coeff * torch.sin(phase)).sum(-1) ** 2
+    return torch.where(k != 0, b2, torch.ones_like(b2))
+
+
+def compute_bspline_deconvolution_1d(n: int, spline_order: int = 4, device=None) -> torch.Tensor:
+    """1 / max(|b(k)|^2, 1e-15) along one mesh axis (spline.py:3117-3148)."""
+    device = torch.device("cpu") if device is None else device
+    return 1.0 / torch.clamp(_bspline_modulus_sq(int(n), int(spline_order), device), min=1e-15)
+
+
+def compute_bspline_deconvolution(mesh_dims: tuple[int, int, int], spline_order: int = 4, device=None) -> torch.Tensor:
+    """deconv[nx, ny, nz] = 1 / max(|b(kx)|^2 |b(ky)|^2 |b(kz)|^2, 1e-15): multiply the FFT of a spread mesh by it to undo the
+    B-spline smoothing (spline.py:3038-3114).  Pure torch on `device` (default CPU, as the reference)."""
+    device = torch.device("cpu") if device is None else device
+    nx, ny, nz = (int(v) for v in mesh_dims)
+    bx, by, bz = (_bspline_modulus_sq(n, int(spline_order), device) for n in (nx, ny, nz))
+    return 1.0 / torch.clamp(bx.view(nx, 1, 1) * by.view(1, ny, 1) * bz.view(1, 1, nz), min=1e-15)
+
+
+__all__ = ["spline_spread", "spline_gather", "spline_gather_vec3", "spline_gather_gradient", "spline_spread_channels", "spline_gather_channels",
+           "compute_bspline_deconvolution", "compute_bspline_deconvolution_1d"]

@@ -26,7 +26,8 @@ FUNCS = {
     "interactions/electrostatics/k_vectors.py": ["generate_k_vectors_pme", "generate_k_vectors_ewald_summation"],
     "interactions/electrostatics/parameters.py": ["estimate_pme_parameters", "estimate_ewald_parameters", "estimate_pme_mesh_dimensions",
                                                   "mesh_spacing_to_dimensions"],
-    "spline.py": ["spline_spread", "spline_gather", "spline_gather_vec3"],
+    "spline.py": ["spline_spread", "spline_gather", "spline_gather_vec3", "spline_gather_gradient", "spline_spread_channels",
+                  "spline_gather_channels", "compute_bspline_deconvolution", "compute_bspline_deconvolution_1d"],
 }
 
 

@@ -231,4 +231,28 @@ def test_public_signatures_match_reference():
         for name, sig in funcs.items():
             assert ms.signature(mine + rel, name) == sig, f"{rel}:{name} differs from the reference signature"
             checked += 1
-    assert checked == 42
+    assert checked == 47
+
+
+def test_bspline_deconvolution_factors():
+    """Properties the reference's tests check (test_spline.py:1537-1600) plus the closed forms of its coefficient table
+    (spline.py:2999-3022: the "order n" table is the order-(n+1) cardinal B-spline at the integers 1..n)."""
+    import math
+
+    from nvalchemiops.spline import compute_bspline_deconvolution, compute_bspline_deconvolution_1d
+
+    for order in (1, 2, 3, 4, 5, 6):
+        d = compute_bspline_deconvolution((8, 12, 16), order)
+        assert d.shape == (8, 12, 16) and d.dtype == torch.float64
+        assert abs(float(d[0, 0, 0]) - 1.0) < 1e-12 and bool((d > 0).all())
+        assert torch.allclose(d[1:], d[1:].flip(0)) and torch.allclose(d[:, 1:], d[:, 1:].flip(1)) and torch.allclose(d[..., 1:], d[..., 1:].flip(2))
+        d1 = [compute_bspline_deconvolution_1d(n, order) for n in (8, 12, 16)]
+        sep = d1[0].view(8, 1, 1) * d1[1].view(1, 12, 1) * d1[2].view(1, 1, 16)
+        ok = sep < 1e14  # even orders vanish at the Nyquist frequency: |b|^2 is clamped to 1e-15 there (spline.py:3108)
+        assert torch.allclose(d[ok], sep[ok], rtol=1e-12)
+    table = {2: [0.5, 0.5], 3: [1 / 6, 4 / 6, 1 / 6], 4: [1 / 24, 11 / 24, 11 / 24, 1 / 24]}
+    for order, c in table.items():
+        n = 10
+        for k in (1, 3, 4):  # not the Nyquist index (clamped for even orders)
+            b = sum(cj * complex(math.cos(2 * math.pi * k * j / n), math.sin(2 * math.pi * k * j / n)) for j, cj in enumerate(c))
+            assert abs(float(compute_bspline_deconvolution_1d(n, order)[k]) - 1.0 / abs(b) ** 2) < 1e-9 / abs(b) ** 2

@@ -402,6 +402,54 @@ def test_out_of_range_indices_are_padding():
                        ewald_real_space(pos, q, cell, al, neighbor_matrix=nm_pad, neighbor_matrix_shifts=sh, mask_value=5))
 
 
+def test_spline_gather_gradient_and_channels():
+    """`spline_gather_gradient` (spline.py:2733) against central differences of `spline_gather` and its uniform-mesh zero
+    (test_spline.py:385); the multi-channel wrappers (:2788, :2863) against the scalar ops; one 2-D cell shared by a batch
+    (test_spline.py:1768-1960)."""
+    from nvalchemiops.spline import (spline_gather, spline_gather_channels, spline_gather_gradient, spline_spread, spline_spread_channels)
+
+    pos, cell, q = _system(40, np.float64, True, seed=21, box=9.0)
+    tp, tq, tc = _t(pos), _t(q), _t(cell)
+    g = np.random.default_rng(5)
+    dims = (12, 10, 14)
+    mesh = _t(g.normal(size=dims))
+    f = spline_gather_gradient(tp, tq, mesh, tc, spline_order=4)
+    assert f.shape == (40, 3)
+    h = 1e-5
+    for d in range(3):
+        dp = torch.zeros_like(tp); dp[:, d] = h
+        fd = (spline_gather(tp + dp, mesh, tc, 4) - spline_gather(tp - dp, mesh, tc, 4)) / (2 * h)
+        # the gather drops weights <= 1e-8 (spline.py:608) and the cubic spline's third derivative jumps at the knots: FD noise ~1e-6
+        assert float((f[:, d] + tq * fd).abs().max()) < 5e-6 * max(1.0, float(f.abs().max()))
+    assert float(spline_gather_gradient(tp, tq, torch.ones(dims, dtype=torch.float64, device=DEV), tc, 4).abs().max()) < 1e-9
+    # channels == per-channel scalar ops
+    vals = _t(g.normal(size=(40, 3)))
+    mc = spline_spread_channels(tp, vals, tc, dims, spline_order=3)
+    assert mc.shape == (3,) + dims
+    for ch in range(3):
+        assert torch.allclose(mc[ch], spline_spread(tp, vals[:, ch].contiguous(), tc, dims, 3), rtol=0, atol=1e-13)  # atomic-add order (mesh not 8-aligned)
+    assert abs(float(mc.sum()) - float(vals.sum())) < 1e-9
+    back = spline_gather_channels(tp, mc, tc, spline_order=3)
+    assert back.shape == (40, 3) and torch.equal(back[:, 1], spline_gather(tp, mc[1], tc, 3))
+    # batch with one shared 2-D cell: two copies of the system give two copies of the mesh
+    bi = torch.tensor([0] * 40 + [1] * 40, dtype=torch.int32, device=DEV)
+    pp, qq = torch.cat([tp, tp]), torch.cat([tq, tq])
+    mb = spline_spread(pp, qq, tc, dims, 4, batch_idx=bi)
+    assert mb.shape == (2,) + dims and torch.allclose(mb[0], mb[1], rtol=0, atol=1e-14)
+    # the reference's batch spread kernels drop weights <= 1e-8, the single-system kernel keeps every w > 0 (spline.py:608 vs :563)
+    np.testing.assert_allclose(mb[0].cpu().numpy(), spline_spread(tp, tq, tc, dims, 4).cpu().numpy(), atol=1e-7)
+    fb = spline_gather_gradient(pp, qq, torch.stack([mesh, mesh]), tc, 4, batch_idx=bi)
+    np.testing.assert_allclose(fb[40:].cpu().numpy(), f.cpu().numpy(), atol=1e-12)
+    mcb = spline_spread_channels(pp, torch.cat([vals, vals]), tc, dims, 3, batch_idx=bi)
+    assert mcb.shape == (2, 3) + dims
+    vb = spline_gather_channels(pp, mcb, tc, 3, batch_idx=bi)
+    assert vb.shape == (80, 3) and torch.allclose(vb[:40], vb[40:], atol=1e-13)
+    # autograd flows through the channel wrappers (test_spline.py:1439-1530)
+    v2 = vals.clone().requires_grad_(True)
+    spline_spread_channels(tp, v2, tc, dims, 3).pow(2).sum().backward()
+    assert v2.grad is not None and torch.isfinite(v2.grad).all()
+
+
 def test_hip_path_against_committed_oracle_vectors():
     """HIP nlist / D3 / PME / explicit-k Ewald against tests/golden/oracle_vectors.npz (made by tests/golden/make_golden.py)."""
     import os
