@@ -285,6 +285,10 @@ def algorithmic_bytes(kernel: str, n: int, pairs_d3: int) -> float | None:
         # idx_j + 3 shift ints per list entry (matrix format: every slot of the padded row, which the kernel has to read to find
         # the fill value); per-atom position/Z/CN in, F/dEdCN/E out
         entries = float(n) * D3["max_neighbors"] if D3_FORMAT == "matrix" else float(pairs_d3)
+        if D3_FORMAT == "matrix" and os.environ.get("NVALCHEMIOPS_D3_PACKED_LIST", "1") != "0":
+            # periodic padded matrix: the CN pass reads the caller's 16 B/slot and leaves a 4 B/slot packed copy, which is all the
+            # energy and chain passes stream
+            return (20.0 if kernel == "d3_cn" else 4.0) * entries + 40.0 * n
         return 16.0 * entries + 40.0 * n
     if kernel == "nl_query_csr":
         return n * (3 * 4 + 8) + 20.0 * pairs_d3
@@ -435,6 +439,20 @@ def main():
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(tt.item())
     kernels = kernel_report()
+    # Untimed extra pass: the same step with the two branches serialised, to time every kernel in isolation.  In the timed region
+    # the bandwidth-bound kernels run beside the other stream's work, so their HIP-event durations include that contention (and
+    # move when a profiler changes the overlap); the isolated figures are the ones comparable across runs and with
+    # profiles/*kernel_stats*_serial.csv.  They do not enter `value`.
+    kernels_isolated = {}
+    if OVERLAP and os.environ.get("BENCH_GRAPH") != "1" and args.workload != "c5":
+        saved, OVERLAP = OVERLAP, 0
+        C.lib().mi_timing_enable(1)
+        for _ in range(max(3, min(args.steps, 10))):
+            step()
+        barrier()
+        C.lib().mi_timing_enable(0)
+        kernels_isolated = kernel_report()
+        OVERLAP = saved
 
     e_pme, f_pme, e_d3, f_d3, num, nptr = out
     matrix_d3 = D3_FORMAT == "matrix"
@@ -460,8 +478,14 @@ def main():
                 "bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": measured_traffic(name, args.atoms, args.workload),
                 "avg_launch_ms": ms / cnt, "launches": cnt, "algorithmic_bytes_per_launch": ab,
-                "note": "d3_energy is VALU/latency-bound (25-term weight contraction + BJ damping per directed pair), not HBM-bound: see DESIGN.md; "
-                        f"pairs/s = {pairs_d3 / avg_s:.3e}" if name == "d3_energy" else "",
+                "isolated_avg_launch_ms": (kernels_isolated[name][1] / kernels_isolated[name][0]) if name in kernels_isolated else None,
+                "isolated_frac": (ab / (kernels_isolated[name][1] / kernels_isolated[name][0] / 1e3) / 1e9 / HBM_PEAK_GBS)
+                if (ab and name in kernels_isolated) else None,
+                "note": ("d3_energy is VALU/latency-bound (25-term weight contraction + BJ damping per directed pair), not HBM-bound: see DESIGN.md; "
+                         f"pairs/s = {pairs_d3 / avg_s:.3e}") if name == "d3_energy" else
+                        ("d3_cn streams the 16 B/slot list, gathers one 16 B record per neighbour and writes the 4 B/slot packed copy; kernel "
+                         "durations are measured with the PME branch running beside it on the second stream (--overlap 0 gives the isolated time); "
+                         f"pairs/s = {pairs_d3 / avg_s:.3e}") if name == "d3_cn" else "",
             }
         result = {
             "metric": "atom-steps/sec (nlist+D3+PME) on 100k-atom PBC box",
@@ -477,6 +501,7 @@ def main():
                        "parallelism": "replica per GPU + 1 RCCL all_gather of per-system energies" if world > 1 else "single GPU"},
             "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
             "kernel_ms": {k: round(v[1] / v[0], 4) for k, v in sorted(kernels.items())},
+            "kernel_ms_isolated": {k: round(v[1] / v[0], 4) for k, v in sorted(kernels_isolated.items())},
             "energies": {"e_d3_Ha": float(e_d3[0].item()), "e_pme": float(e_pme.sum().item())},
             "roofline": roofline,
         }

@@ -132,6 +132,11 @@ typedef struct {
 } mi_d3_params;
 
 size_t mi_d3_workspace_bytes(int n_atoms, int n_systems, int nz);
+/* Optional larger workspace for a periodic padded matrix: base + 4 bytes per slot.  Given at least this much, mi_d3 lets its CN pass
+ * leave a packed copy of the list (index + unit shift in one word) that the energy and chain passes stream instead of the caller's
+ * 16-byte-per-slot arrays; lists with shifts outside {-1,0,1} or >= 2^26 atoms fall back to the arrays on the device. Results are
+ * identical either way.  Equals mi_d3_workspace_bytes when max_neighbors <= 0 (CSR).                                              */
+size_t mi_d3_workspace_bytes_packed(int n_atoms, int n_systems, int nz, int max_neighbors);
 
 int mi_d3(const void* positions, const int32_t* numbers, int n_atoms, int dtype,
           const int32_t* idx_j,        /* matrix [n_atoms,max_neighbors] or CSR values [n_pairs]      */

@@ -108,6 +108,31 @@ __device__ __forceinline__ D3Step d3_fetch(const int* __restrict__ idx, const In
   if (s.in) { s.j = idx[e]; if (periodic) s.sh = ush3[e]; }
   return s;
 }
+// Packed copy of a periodic padded list, written by the CN pass for the two passes after it: 4 B per slot instead of 16
+// (index in bits 0-25, unit shift + 1 in three 2-bit fields; all ones = padding).  Only used when every shift is in {-1, 0, 1}
+// and N < 2^26 -- otherwise `pk_flag` is raised and the passes read the caller's arrays as before.
+#define D3_PK_INVALID 0xffffffffu
+#define D3_PK_MAX_ATOMS (1 << 26)
+__device__ __forceinline__ D3Step d3_fetch_pk(const unsigned* __restrict__ pk, long long e, long long end) {
+  D3Step s;
+  s.in = e < end;
+  const unsigned w = s.in ? __builtin_nontemporal_load(pk + e) : D3_PK_INVALID;  // streamed once per pass: keep it out of the way of the gathered records
+  s.j = (int)(w & 0x3ffffffu);  // padding decodes to 2^26 - 1 >= N: fails the index test below
+  s.sh = Int3{(int)((w >> 26) & 3u) - 1, (int)((w >> 28) & 3u) - 1, (int)(w >> 30) - 1};
+  return s;
+}
+template <bool PK>
+__device__ __forceinline__ D3Step d3_fetch_any(const int* __restrict__ idx, const Int3* __restrict__ ush3, const unsigned* __restrict__ pk,
+                                               long long e, long long end, bool periodic) {
+  if constexpr (PK) return d3_fetch_pk(pk, e, end);
+  else return d3_fetch(idx, ush3, e, end, periodic);
+}
+// which of the two variants of a pass runs: the packed one unless the CN pass raised the flag; without a flag only the plain one exists
+template <bool PK>
+__device__ __forceinline__ bool d3_variant_runs(const int* __restrict__ pk_flag) {
+  if (PK) return *pk_flag == 0;
+  return pk_flag == nullptr || *pk_flag != 0;
+}
 // The row walks below are software-pipelined three deep: while step k is evaluated, the per-atom records of step k+1 are
 // already being gathered and the index/shift words of step k+2 are in flight; validity is a predicate, not a branch, so
 // no load waits behind a branch on an earlier load (rocprof: the unpipelined walk spent >80 % of its wave cycles waiting).
@@ -169,7 +194,7 @@ __global__ __launch_bounds__(D3_LS_WAVES * MI_WAVE) void d3_cn_kernel(const T* _
                                                     const int* __restrict__ ush, const int* __restrict__ nptr, int M, int fill_value,
                                                     const T* __restrict__ cell, const int* __restrict__ batch_idx, D3Dev P,
                                                     const typename Vec4<T>::type* __restrict__ apos, float4* __restrict__ aaux,
-                                                    float* __restrict__ cn) {
+                                                    float* __restrict__ cn, unsigned* __restrict__ pk_out, int* __restrict__ pk_flag) {
   const int lane = threadIdx.x & (MI_WAVE - 1);
   const int i0 = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x / MI_WAVE) + threadIdx.x / MI_WAVE);
   const int i = i0 < N ? i0 : N - 1;
@@ -199,6 +224,11 @@ __global__ __launch_bounds__(D3_LS_WAVES * MI_WAVE) void d3_cn_kernel(const T* _
     const D3Step s2 = d3_fetch(idx, ush3, e + MI_WAVE, end, periodic);
     const bool v1 = s1.in && ((unsigned)s1.j < jlim);
     const auto p1 = apos[v1 ? s1.j : i];
+    if (pk_out && s0.in) {  // wave-uniform pointer test; one coalesced 4-byte store per slot of this trip
+      const unsigned cx = (unsigned)(s0.sh.a + 1), cy = (unsigned)(s0.sh.b + 1), cz = (unsigned)(s0.sh.c + 1);
+      if (v0 && (cx > 2u || cy > 2u || cz > 2u)) *pk_flag = 1;  // benign race: every writer stores 1
+      __builtin_nontemporal_store(v0 ? ((unsigned)s0.j | ((cx & 3u) << 26) | ((cy & 3u) << 28) | (cz << 30)) : D3_PK_INVALID, pk_out + (e - MI_WAVE));
+    }
     if (__any(v0)) {  // a step of pure padding costs nothing (padded matrices are mostly padding)
       bool valid = v0 && !(p0.w < (T)0);  // padding atom (Z == 0)
       const PairGeom<T> g = d3_geom<T>(p0, pix, piy, piz, s0.sh, cm, periodic);
@@ -457,7 +487,7 @@ __device__ __forceinline__ void d3_c6_fact(const D3Half& h, const float* v, cons
 // ---- pass 2: energy, direct force, dE/dCN ------------------------------------------------------------
 // MODE 0: global [nz,nz,25] table (> 16 species); 1: general 25-term interpolation from the LDS-staged compact table;
 // 2: factorised interpolation.  All three are launched; the two that do not match the device-side species info exit at once.
-template <class T, bool CSR, int MODE>
+template <class T, bool CSR, int MODE, bool PK>
 __device__ __forceinline__ void d3_energy_body(const T* __restrict__ pos, const int* __restrict__ numbers, int N, const int* __restrict__ idx,
                                                         const int* __restrict__ ush, const int* __restrict__ nptr, int M, int fill_value,
                                                         const T* __restrict__ cell, const int* __restrict__ batch_idx, D3Dev P,
@@ -466,14 +496,15 @@ __device__ __forceinline__ void d3_energy_body(const T* __restrict__ pos, const 
                                                         const float* __restrict__ ftab, const float* __restrict__ fcr,
                                                         const typename Vec4<T>::type* __restrict__ apos, const float4* __restrict__ aaux,
                                                         const float4* __restrict__ aw, float* __restrict__ dEdCN,
-                                                        float* __restrict__ forces, float* __restrict__ e_atom, float* __restrict__ v_atom) {
+                                                        float* __restrict__ forces, float* __restrict__ e_atom, float* __restrict__ v_atom,
+                                                        const unsigned* __restrict__ pk, const int* __restrict__ pk_flag) {
   constexpr bool LDS = MODE == 1;
   constexpr bool PACKED = MODE == 2 && sizeof(T) == 4;  // one 32-byte record per neighbour (see d3_weights_kernel)
   constexpr int WAVE_F4 = MODE == 1 ? D3_SMAX * 25 : MODE == 2 ? D3_SMAX * D3_FROW / 4 : 1;  // float4 per wave
   __shared__ float4 lds_tab[MODE == 0 ? 1 : 4][WAVE_F4];
   const int S = sinfo->S;
   const int want_mode = S > D3_SMAX ? 0 : (sinfo->factorized ? 2 : 1);
-  if (want_mode != MODE) return;
+  if (want_mode != MODE || !d3_variant_runs<PK>(pk_flag)) return;
   const int lane = threadIdx.x & (MI_WAVE - 1);
   const int i = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x / MI_WAVE) + threadIdx.x / MI_WAVE);
   if (i >= N) return;
@@ -511,7 +542,7 @@ __device__ __forceinline__ void d3_energy_body(const T* __restrict__ pos, const 
   const Int3* __restrict__ ush3 = reinterpret_cast<const Int3*>(ush);
   long long e = beg + lane;
   const unsigned jlim = d3_index_limit<CSR>(N, fill_value);
-  D3Step s0 = d3_fetch(idx, ush3, e, end, periodic), s1 = d3_fetch(idx, ush3, e + MI_WAVE, end, periodic);
+  D3Step s0 = d3_fetch_any<PK>(idx, ush3, pk, e, end, periodic), s1 = d3_fetch_any<PK>(idx, ush3, pk, e + MI_WAVE, end, periodic);
   bool v0 = s0.in && ((unsigned)s0.j < jlim);
   using PosRec = typename Vec4<T>::type;
   auto pos_of = [&](int j) -> PosRec {
@@ -530,7 +561,7 @@ __device__ __forceinline__ void d3_energy_body(const T* __restrict__ pos, const 
   aux_of(v0 ? s0.j : i, a0, b0);
   for (long long base = beg; base < end; base += MI_WAVE) {
     e += MI_WAVE;
-    const D3Step s2 = d3_fetch(idx, ush3, e + MI_WAVE, end, periodic);
+    const D3Step s2 = d3_fetch_any<PK>(idx, ush3, pk, e + MI_WAVE, end, periodic);
     const bool v1 = s1.in && ((unsigned)s1.j < jlim);
     const PosRec p1 = pos_of(v1 ? s1.j : i);
     float4 a1, b1;
@@ -619,25 +650,29 @@ __device__ __forceinline__ void d3_energy_body(const T* __restrict__ pos, const 
 }
 
 
-#define D3_ENERGY_PARAMS const T* __restrict__ pos, const int* __restrict__ numbers, int N, const int* __restrict__ idx, const int* __restrict__ ush, const int* __restrict__ nptr, int M, int fill_value, const T* __restrict__ cell, const int* __restrict__ batch_idx, D3Dev P, const float* __restrict__ cn, int want_virial, const int* __restrict__ smap, const D3Species* __restrict__ sinfo, const float4* __restrict__ ctab, const float* __restrict__ ftab, const float* __restrict__ fcr, const typename Vec4<T>::type* __restrict__ apos, const float4* __restrict__ aaux, const float4* __restrict__ aw, float* __restrict__ dEdCN, float* __restrict__ forces, float* __restrict__ e_atom, float* __restrict__ v_atom
-template <class T, bool CSR, int MODE>
+#define D3_ENERGY_PARAMS const T* __restrict__ pos, const int* __restrict__ numbers, int N, const int* __restrict__ idx, const int* __restrict__ ush, const int* __restrict__ nptr, int M, int fill_value, const T* __restrict__ cell, const int* __restrict__ batch_idx, D3Dev P, const float* __restrict__ cn, int want_virial, const int* __restrict__ smap, const D3Species* __restrict__ sinfo, const float4* __restrict__ ctab, const float* __restrict__ ftab, const float* __restrict__ fcr, const typename Vec4<T>::type* __restrict__ apos, const float4* __restrict__ aaux, const float4* __restrict__ aw, float* __restrict__ dEdCN, float* __restrict__ forces, float* __restrict__ e_atom, float* __restrict__ v_atom, const unsigned* __restrict__ pk, const int* __restrict__ pk_flag
+#define D3_ENERGY_ARGS pos, numbers, N, idx, ush, nptr, M, fill_value, cell, batch_idx, P, cn, want_virial, smap, sinfo, ctab, ftab, fcr, apos, aaux, aw, dEdCN, forces, e_atom, v_atom, pk, pk_flag
+template <class T, bool CSR, int MODE, bool PK>
 __global__ __launch_bounds__(256) void d3_energy_kernel(D3_ENERGY_PARAMS) {
-  d3_energy_body<T, CSR, MODE>(pos, numbers, N, idx, ush, nptr, M, fill_value, cell, batch_idx, P, cn, want_virial, smap, sinfo, ctab, ftab, fcr, apos, aaux, aw, dEdCN, forces, e_atom, v_atom);
+  d3_energy_body<T, CSR, MODE, PK>(D3_ENERGY_ARGS);
 }
 // the fp32 factorised variant fits 96 VGPRs without spilling: ask for 5 waves per SIMD (the others would spill)
-template <class T, bool CSR, int MODE>
+template <class T, bool CSR, int MODE, bool PK>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) void d3_energy_kernel_w5(D3_ENERGY_PARAMS) {
-  d3_energy_body<T, CSR, MODE>(pos, numbers, N, idx, ush, nptr, M, fill_value, cell, batch_idx, P, cn, want_virial, smap, sinfo, ctab, ftab, fcr, apos, aaux, aw, dEdCN, forces, e_atom, v_atom);
+  d3_energy_body<T, CSR, MODE, PK>(D3_ENERGY_ARGS);
 }
+#undef D3_ENERGY_ARGS
 #undef D3_ENERGY_PARAMS
 
 // ---- pass 3: chain-rule force through the coordination numbers ---------------------------------------
-template <class T, bool CSR>
+template <class T, bool CSR, bool PK>
 __global__ __launch_bounds__(D3_LS_WAVES * MI_WAVE) void d3_chain_kernel(const T* __restrict__ pos, const int* __restrict__ numbers, int N, const int* __restrict__ idx,
                                                        const int* __restrict__ ush, const int* __restrict__ nptr, int M, int fill_value,
                                                        const T* __restrict__ cell, const int* __restrict__ batch_idx, D3Dev P,
                                                        const typename Vec4<T>::type* __restrict__ apos, const float* __restrict__ dEdCN,
-                                                       int want_virial, float* __restrict__ forces, float* __restrict__ v_atom) {
+                                                       int want_virial, float* __restrict__ forces, float* __restrict__ v_atom,
+                                                       const unsigned* __restrict__ pk, const int* __restrict__ pk_flag) {
+  if (!d3_variant_runs<PK>(pk_flag)) return;  // block-uniform: no barrier has been reached yet
   const int lane = threadIdx.x & (MI_WAVE - 1);
   const int i0 = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x / MI_WAVE) + threadIdx.x / MI_WAVE);
   const int i = i0 < N ? i0 : N - 1;
@@ -657,14 +692,14 @@ __global__ __launch_bounds__(D3_LS_WAVES * MI_WAVE) void d3_chain_kernel(const T
   const Int3* __restrict__ ush3 = reinterpret_cast<const Int3*>(ush);
   long long e = beg + lane;
   const unsigned jlim = d3_index_limit<CSR>(N, fill_value);
-  D3Step s0 = d3_fetch(idx, ush3, e, end, periodic), s1 = d3_fetch(idx, ush3, e + MI_WAVE, end, periodic);
+  D3Step s0 = d3_fetch_any<PK>(idx, ush3, pk, e, end, periodic), s1 = d3_fetch_any<PK>(idx, ush3, pk, e + MI_WAVE, end, periodic);
   bool v0 = s0.in && ((unsigned)s0.j < jlim);
   auto p0 = apos[v0 ? s0.j : i];
   float d0 = dEdCN[v0 ? s0.j : i];
   for (int trip = 0; trip < trips; ++trip) {
     __syncthreads();  // lock-step (see d3_cn_kernel)
     e += MI_WAVE;
-    const D3Step s2 = d3_fetch(idx, ush3, e + MI_WAVE, end, periodic);
+    const D3Step s2 = d3_fetch_any<PK>(idx, ush3, pk, e + MI_WAVE, end, periodic);
     const bool v1 = s1.in && ((unsigned)s1.j < jlim);
     const auto p1 = apos[v1 ? s1.j : i];
     const float d1 = dEdCN[v1 ? s1.j : i];
@@ -781,7 +816,10 @@ D3Layout d3_layout(int N, int nz, int dtype, int B) {
 template <class T, bool CSR>
 int d3_impl(const T* pos, const int* numbers, int N, const int* idx, const int* ush, const int* nptr, int M, int fill_value, const T* cell,
             const int* batch_idx, int B, const mi_d3_params* hp, int want_virial, float* energy, float* forces, float* cn, float* virial,
-            char* ws, const D3Layout& L, hipStream_t st) {
+            char* ws, const D3Layout& L, unsigned* pk, hipStream_t st) {
+  // `pk` (optional, [N*M] words + one flag word in front): packed copy of a periodic padded list, see d3_fetch_pk
+  int* pk_flag = nullptr;
+  if (pk) { pk_flag = reinterpret_cast<int*>(pk); pk += 64; MI_HIP_CHECK(hipMemsetAsync(pk_flag, 0, sizeof(int), st)); }
   float* dEdCN = reinterpret_cast<float*>(ws + L.dEdCN);
   float* e_atom = reinterpret_cast<float*>(ws + L.e_atom);
   float* v_atom = reinterpret_cast<float*>(ws + L.v_atom);
@@ -814,28 +852,50 @@ int d3_impl(const T* pos, const int* numbers, int N, const int* idx, const int* 
                                                              want_virial ? v_atom : nullptr);
   MI_LAUNCH_CHECK();
   const int blocks = mi_blocks(N, 4);
-  MI_TIMED("d3_cn", st, (d3_cn_kernel<T, CSR><<<mi_blocks(N, D3_LS_WAVES), D3_LS_WAVES * MI_WAVE, 0, st>>>(pos, numbers, N, idx, ush, nptr, M, fill_value, cell, batch_idx, P, apos, aaux, cn)));
+  MI_TIMED("d3_cn", st, (d3_cn_kernel<T, CSR><<<mi_blocks(N, D3_LS_WAVES), D3_LS_WAVES * MI_WAVE, 0, st>>>(pos, numbers, N, idx, ush, nptr, M, fill_value, cell, batch_idx, P, apos, aaux, cn, pk, pk_flag)));
   MI_LAUNCH_CHECK();
   d3_weights_kernel<<<mi_blocks(N, 256), 256, 0, st>>>(cn, aaux, sinfo, fcr, hp->k3, N,
                                                        sizeof(T) == 4 ? reinterpret_cast<const float4*>(apos) : nullptr, aw);
   MI_LAUNCH_CHECK();
   // all three variants are launched; two of them exit at once on the device-side species info.  Only the fp32 factorised variant
   // is instantiated with the 5-waves-per-SIMD register cap (the others would spill under it).
-  auto launch_energy = [&](auto mode) {
+  auto launch_energy = [&](auto mode, auto packed) {
     constexpr int MODE_ = decltype(mode)::value;
+    constexpr bool PK_ = decltype(packed)::value;
+    const unsigned* pk_in = PK_ ? pk : nullptr;
     if constexpr (MODE_ == 2 && sizeof(T) == 4)
-      d3_energy_kernel_w5<T, CSR, MODE_><<<blocks, 256, 0, st>>>(pos, numbers, N, idx, ush, nptr, M, fill_value, cell, batch_idx, P, cn, want_virial,
-                                                                smap, sinfo, ctab, ftab, fcr, apos, aaux, aw, dEdCN, forces, e_atom, v_atom);
+      d3_energy_kernel_w5<T, CSR, MODE_, PK_><<<blocks, 256, 0, st>>>(pos, numbers, N, idx, ush, nptr, M, fill_value, cell, batch_idx, P, cn, want_virial,
+                                                                     smap, sinfo, ctab, ftab, fcr, apos, aaux, aw, dEdCN, forces, e_atom, v_atom, pk_in, pk_flag);
     else
-      d3_energy_kernel<T, CSR, MODE_><<<blocks, 256, 0, st>>>(pos, numbers, N, idx, ush, nptr, M, fill_value, cell, batch_idx, P, cn, want_virial,
-                                                             smap, sinfo, ctab, ftab, fcr, apos, aaux, aw, dEdCN, forces, e_atom, v_atom);
+      d3_energy_kernel<T, CSR, MODE_, PK_><<<blocks, 256, 0, st>>>(pos, numbers, N, idx, ush, nptr, M, fill_value, cell, batch_idx, P, cn, want_virial,
+                                                                  smap, sinfo, ctab, ftab, fcr, apos, aaux, aw, dEdCN, forces, e_atom, v_atom, pk_in, pk_flag);
   };
-  MI_TIMED("d3_energy", st, (launch_energy(std::integral_constant<int, 2>{}), launch_energy(std::integral_constant<int, 1>{})));
+  using Plain = std::integral_constant<bool, false>;
+  using Packed = std::integral_constant<bool, true>;
+  auto launch_modes = [&](auto packed) {
+    launch_energy(std::integral_constant<int, 2>{}, packed);
+    launch_energy(std::integral_constant<int, 1>{}, packed);
+    launch_energy(std::integral_constant<int, 0>{}, packed);
+  };
+  // the plain variants always exist; with a packed list they exit at once unless the CN pass found a shift outside {-1, 0, 1}
+  if constexpr (!CSR) {
+    if (pk) { MI_TIMED("d3_energy", st, (launch_modes(Packed{}))); MI_LAUNCH_CHECK(); launch_modes(Plain{}); }
+    else { MI_TIMED("d3_energy", st, (launch_modes(Plain{}))); }
+  } else {
+    MI_TIMED("d3_energy", st, (launch_modes(Plain{})));
+  }
   MI_LAUNCH_CHECK();
-  launch_energy(std::integral_constant<int, 0>{});
-  MI_LAUNCH_CHECK();
-  MI_TIMED("d3_chain", st, (d3_chain_kernel<T, CSR><<<mi_blocks(N, D3_LS_WAVES), D3_LS_WAVES * MI_WAVE, 0, st>>>(pos, numbers, N, idx, ush, nptr, M, fill_value, cell, batch_idx, P, apos, dEdCN,
-                                                                            want_virial, forces, v_atom)));
+  auto launch_chain = [&](auto packed) {
+    constexpr bool PK_ = decltype(packed)::value;
+    d3_chain_kernel<T, CSR, PK_><<<mi_blocks(N, D3_LS_WAVES), D3_LS_WAVES * MI_WAVE, 0, st>>>(pos, numbers, N, idx, ush, nptr, M, fill_value, cell, batch_idx, P, apos,
+                                                                                             dEdCN, want_virial, forces, v_atom, PK_ ? pk : nullptr, pk_flag);
+  };
+  if constexpr (!CSR) {
+    if (pk) { MI_TIMED("d3_chain", st, (launch_chain(Packed{}))); MI_LAUNCH_CHECK(); launch_chain(Plain{}); }
+    else { MI_TIMED("d3_chain", st, (launch_chain(Plain{}))); }
+  } else {
+    MI_TIMED("d3_chain", st, (launch_chain(Plain{})));
+  }
   MI_LAUNCH_CHECK();
   double* sums = reinterpret_cast<double*>(ws + L.sums);
   MI_HIP_CHECK(hipMemsetAsync(sums, 0, sizeof(double) * 10 * (size_t)B, st));
@@ -855,6 +915,12 @@ size_t mi_d3_workspace_bytes(int n_atoms, int n_systems, int nz) {
   return d3_layout(n_atoms, nz, MI_F64, n_systems).total;  // sized for the wider dtype
 }
 
+size_t mi_d3_workspace_bytes_packed(int n_atoms, int n_systems, int nz, int max_neighbors) {
+  const size_t base = mi_d3_workspace_bytes(n_atoms, n_systems, nz);
+  if (base == 0 || max_neighbors <= 0 || n_atoms >= D3_PK_MAX_ATOMS) return base;
+  return base + 512 + sizeof(unsigned) * (size_t)n_atoms * (size_t)max_neighbors;  // alignment slack + flag line + the words
+}
+
 int mi_d3(const void* positions, const int32_t* numbers, int n_atoms, int dtype, const int32_t* idx_j, const int32_t* unit_shifts,
           const int32_t* neighbor_ptr, int max_neighbors, int fill_value, const void* cell, const int32_t* batch_idx, int n_systems,
           const mi_d3_params* params, int compute_virial, float* energy, float* forces, float* coord_num, float* virial, void* workspace,
@@ -869,9 +935,14 @@ int mi_d3(const void* positions, const int32_t* numbers, int n_atoms, int dtype,
   if (workspace_bytes < L.total) { mi_set_error("workspace too small: %zu < %zu", workspace_bytes, L.total); return MI_EWORKSPACE; }
   hipStream_t st = (hipStream_t)stream;
   const bool csr = neighbor_ptr != nullptr;
+  // a periodic padded list is re-read by all three passes: with the larger workspace the CN pass leaves a 4 B/slot copy for the others
+  unsigned* pk = nullptr;
+  if (!csr && cell && unit_shifts && max_neighbors > 0 && n_atoms < D3_PK_MAX_ATOMS &&
+      workspace_bytes >= mi_d3_workspace_bytes_packed(n_atoms, n_systems, params->nz, max_neighbors))
+    pk = reinterpret_cast<unsigned*>((char*)workspace + ((mi_d3_workspace_bytes(n_atoms, n_systems, params->nz) + 255) & ~(size_t)255));
 #define MI_D3_CALL(T_, CSR_)                                                                                                              \
   return d3_impl<T_, CSR_>((const T_*)positions, numbers, n_atoms, idx_j, unit_shifts, neighbor_ptr, max_neighbors, fill_value, (const T_*)cell, \
-                           batch_idx, n_systems, params, compute_virial, energy, forces, coord_num, virial, (char*)workspace, L, st)
+                           batch_idx, n_systems, params, compute_virial, energy, forces, coord_num, virial, (char*)workspace, L, pk, st)
   if (dtype == MI_F32) { if (csr) MI_D3_CALL(float, true); else MI_D3_CALL(float, false); }
   else { if (csr) MI_D3_CALL(double, true); else MI_D3_CALL(double, false); }
 #undef MI_D3_CALL

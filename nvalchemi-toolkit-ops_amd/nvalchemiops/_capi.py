@@ -47,6 +47,8 @@ def lib() -> ctypes.CDLL:
         if hasattr(L, "mi_d3_workspace_bytes"):
             L.mi_d3_workspace_bytes.restype = ctypes.c_size_t
             L.mi_d3_workspace_bytes.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int]
+            L.mi_d3_workspace_bytes_packed.restype = ctypes.c_size_t
+            L.mi_d3_workspace_bytes_packed.argtypes = [ctypes.c_int] * 4
         _LIB = L
     return _LIB
 

@@ -10,6 +10,7 @@ and cell are detached: explicit forces are returned, there is no autograd throug
 from __future__ import annotations
 
 import ctypes
+import os
 from dataclasses import dataclass
 
 import torch
@@ -83,7 +84,9 @@ def _launch(positions, numbers, idx, shifts, nptr, max_neighbors, fill_value, ce
     cell_t = cell.detach().to(dtype=pos.dtype, device=dev).reshape(-1, 3, 3).contiguous() if periodic else None
     sh = C.i32(shifts.to(dev)) if periodic else None
     bi = None if batch_idx is None else C.i32(batch_idx)
-    ws_bytes = int(C.lib().mi_d3_workspace_bytes(n, num_systems, rcov.shape[0]))
+    # a periodic padded matrix is streamed by all three passes: the larger workspace lets the CN pass leave a 4 B/slot copy for the others
+    pack = periodic and nptr is None and os.environ.get("NVALCHEMIOPS_D3_PACKED_LIST", "1") != "0"  # "0": tuning aid (A/B on one box)
+    ws_bytes = int(C.lib().mi_d3_workspace_bytes_packed(n, num_systems, rcov.shape[0], int(max_neighbors) if pack else 0))
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
     vir = virial if compute_virial else None
     rc = C.lib().mi_d3(C.ptr(pos), C.ptr(C.i32(numbers)), n, code, C.ptr(idx), C.ptr(sh), C.ptr(nptr), int(max_neighbors), int(fill_value),

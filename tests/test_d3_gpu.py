@@ -265,3 +265,30 @@ def test_out_of_range_indices_are_padding():
     _close(out[0], ref[0].cpu().numpy(), 2e-6, 1e-7, "energy (CSR with stray indices)")
     assert torch.isfinite(out[1]).all()
 
+
+
+@pytest.mark.parametrize("box,shift_max", [(26.0, 1), (7.0, 2)])
+def test_packed_list_equals_plain_walk(box, shift_max, monkeypatch):
+    """For a periodic padded matrix `mi_d3` lets its CN pass leave a 4-byte-per-slot copy of the list for the other two passes
+    (DESIGN.md 3.2).  Same data, same arithmetic, same summation order: outputs are bit-identical to the plain walk, both when
+    the copy is used (all unit shifts in {-1, 0, 1}) and when the device falls back because larger shifts occur (small cell)."""
+    from nvalchemiops.interactions.dispersion import dftd3
+    from nvalchemiops.neighborlist import cell_list
+
+    t, p = _params()
+    n = 180 if box > 20 else 12
+    pos, cell = S.random_box(n, box, seed=9, dtype=np.float32, triclinic=True)
+    z = np.random.default_rng(2).choice(np.array([1, 6, 8, 17], np.int32), n)
+    pbc = torch.tensor([True] * 3, device=DEV)
+    nm, num, sh = cell_list(_t(pos), 14.0, _t(cell), pbc, max_neighbors=448)
+    assert int(num.max()) <= 448 and int(sh.abs().max()) >= shift_max and (shift_max > 1 or int(sh.abs().max()) == 1)
+    args = dict(d3_params=p, neighbor_matrix=nm, neighbor_matrix_shifts=sh, cell=_t(cell)[None], compute_virial=True, **FP)
+    monkeypatch.setenv("NVALCHEMIOPS_D3_PACKED_LIST", "1")
+    packed = dftd3(_t(pos), _t(z), **args)
+    monkeypatch.setenv("NVALCHEMIOPS_D3_PACKED_LIST", "0")
+    plain = dftd3(_t(pos), _t(z), **args)
+    for a, b in zip(packed, plain):
+        assert torch.equal(a, b)
+    if shift_max == 1:  # (the 12-atom cell is far denser than matter: its forces are differences of huge terms, outside the tolerance model)
+        ref = O.dftd3(pos, z, t, neighbor_matrix=nm.cpu().numpy(), neighbor_matrix_shifts=sh.cpu().numpy(), cell=cell, compute_virial=True, **FP)
+        _check(packed, ref, virial=True)
