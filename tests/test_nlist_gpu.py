@@ -188,12 +188,17 @@ def test_empty_and_tiny_inputs():
     assert num.cpu().tolist() == [1, 1] and sh[0, 0].cpu().tolist() == [-1, 0, 0] and sh[1, 0].cpu().tolist() == [1, 0, 0]
 
 
-def test_fcc_20k_matches_oracle():
+@pytest.mark.parametrize("n,dtype,cutoff,m", [(50000, np.float32, 5.0, 64), (100000, np.float64, 9.0, 256)])
+def test_baseline_configs_full_size_match_oracle(n, dtype, cutoff, m):
+    """BASELINE.json config 2 (50k-atom periodic box, cell_list, padded matrix, fp32) and the neighbour list of config 4 (100k atoms,
+    fp64, the 9 A real-space cutoff of the headline PME leg) at their FULL sizes: counts and (i, j, S) sets bit-exact vs the oracle
+    (1.4 s / 15 s of oracle time)."""
     from nvalchemiops.neighborlist import cell_list
 
-    pos, cell, _, _ = S.fcc_box(20000, dtype=np.float32)
-    onm, onum, osh = O.cell_list(pos, 5.0, cell, [True] * 3, max_neighbors=64)
-    nm, num, sh = cell_list(_t(pos), 5.0, _t(cell), torch.tensor([True] * 3, device=DEV), max_neighbors=64)
+    pos, cell, _, _ = S.fcc_box(n, dtype=dtype)
+    onm, onum, osh = O.cell_list(pos, cutoff, cell, [True] * 3, max_neighbors=m)
+    nm, num, sh = cell_list(_t(pos), cutoff, _t(cell), torch.tensor([True] * 3, device=DEV), max_neighbors=m)
+    assert int(onum.max()) <= m
     assert np.array_equal(num.cpu().numpy(), onum)
     assert np.array_equal(_pairs(nm, num, sh), O.canonical_pairs(onm, onum, osh))
 

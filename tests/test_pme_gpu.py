@@ -209,7 +209,7 @@ def test_pme_madelung_and_explicit_ewald():
 def test_config4_100k_fp64_properties():
     """BASELINE config 4 (100k-atom periodic box with charges, nlist + PME, fp64): size-independent properties --
     zero net reciprocal force (to mesh accuracy), real-space Newton's third law, translation invariance under a lattice
-    vector, energy against a 1/8-size sub-check is skipped (oracle too slow); the 4k-atom version is compared exactly."""
+    vector; the 4k-atom version AND the full 100k-atom configuration (mesh 128^3, order 4) are compared with the oracle."""
     from nvalchemiops.interactions.electrostatics import particle_mesh_ewald
     from nvalchemiops.neighborlist import cell_list
 
@@ -230,6 +230,11 @@ def test_config4_100k_fp64_properties():
                                neighbor_matrix_shifts=sh, compute_forces=True)
     assert torch.isfinite(e).all() and torch.isfinite(f).all()
     assert float(f.sum(0).abs().max()) < 1e-3 * float(f.abs().max()) * 100
+    # the FULL-size configuration against the oracle as well (5 s of oracle time on the device-built list): same tolerances as the small cases
+    ref = O.particle_mesh_ewald(pos, q, cell, 0.35, (128, 128, 128), 4, neighbor_matrix=nm.cpu().numpy(), neighbor_matrix_shifts=sh.cpu().numpy(),
+                                mask_value=100000, compute_forces=True)
+    _close(e, ref[0], np.float64, "100k energies")
+    _close(f, ref[1], np.float64, "100k forces")
     shift = tc[0] * 1.0  # translate every atom by one lattice vector: same energies (atoms leave the box -> wrap bookkeeping)
     nm2, num2, sh2 = cell_list(tp + shift, 9.0, tc, pbc, max_neighbors=256)
     e2, f2 = particle_mesh_ewald(tp + shift, tq, tc, alpha=0.35, mesh_dimensions=(128, 128, 128), spline_order=4, neighbor_matrix=nm2,
