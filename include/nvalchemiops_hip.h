@@ -226,8 +226,9 @@ int mi_spline_spread(const void* positions, const void* values, const int32_t* b
                      const void* cell_inv_t /*[n_systems,3,3]*/, int n_atoms, int n_systems, int nx, int ny,
                      int nz, int order, int batched, int dtype, void* mesh /* zeroed by caller */,
                      void* workspace /* mi_spline_spread_workspace_bytes, or NULL */, size_t workspace_bytes, void* stream);
-/* With a workspace and mesh dimensions that are multiples of 8 the spread runs tile-owned (atoms binned by 8^3 mesh tile, LDS
- * accumulation, every mesh point written once, no global atomics); otherwise order^2 threads per atom add into the zeroed mesh. */
+/* With a workspace the spread runs tile-owned when every mesh dimension has a divisor e with max(order - 1, 2) <= e <= 8 (atoms
+ * binned by ex*ey*ez mesh tile, LDS accumulation, every mesh point written once, no global atomics); otherwise order^2 threads per
+ * atom add into the zeroed mesh.                                                                                               */
 size_t mi_spline_spread_workspace_bytes(int n_atoms, int n_systems, int nx, int ny, int nz);
 /* channels = 1: out[n_atoms] += sum_g mesh[g] w ; channels = 3 (mesh [..,3] interleaved) or 4 planar:
  * see mi_pme_gather below for the fused PME form.                                                     */

@@ -150,14 +150,19 @@ __global__ __launch_bounds__(256) void spline_spread_kernel(const T* __restrict_
 }
 
 // ---- tiled spread ----------------------------------------------------------------------------------------------------------
-#define SP_T 8  // mesh tile edge (points); stencils span order <= 6 <= SP_T + 1 points, i.e. at most two tiles per axis
+#define SP_T 8  // largest mesh tile edge (points).  Per axis the edge is the largest divisor of the mesh dimension that is <= SP_T; a
+                // stencil of `order` points starting in tile t reaches at most t and t+1 when order <= edge + 1
+struct SpTile { int ex, ey, ez; };
+static int sp_edge(int n) { for (int e = SP_T; e > 1; --e) if (n % e == 0) return e; return 1; }
+static SpTile sp_tile(int nx, int ny, int nz) { return SpTile{sp_edge(nx), sp_edge(ny), sp_edge(nz)}; }
 
 struct SpLayout { size_t keys_in, keys_out, vals_in, vals_out, bin_start, lo3, wts, cub, cub_bytes, total; long long nbins; };
 static SpLayout sp_layout(int N, int B, int nx, int ny, int nz) {
   SpLayout L;
   size_t o = 0;
   auto take = [&](size_t b) { size_t at = o; o += mi_align(b); return at; };
-  L.nbins = (long long)B * (nx / SP_T) * (ny / SP_T) * (nz / SP_T);
+  const SpTile e = sp_tile(nx, ny, nz);
+  L.nbins = (long long)B * (nx / e.ex) * (ny / e.ey) * (nz / e.ez);
   L.keys_in = take(sizeof(int) * (size_t)N);
   L.keys_out = take(sizeof(int) * (size_t)N);
   L.vals_in = take(sizeof(int) * (size_t)N);
@@ -172,19 +177,24 @@ static SpLayout sp_layout(int N, int B, int nx, int ny, int nz) {
   L.total = o;
   return L;
 }
-static bool sp_tiled_ok(int nx, int ny, int nz, int B) {
-  return nx >= MI_MAX_ORDER && ny >= MI_MAX_ORDER && nz >= MI_MAX_ORDER && nx % SP_T == 0 && ny % SP_T == 0 && nz % SP_T == 0 && (long long)B * (nx / SP_T) * (ny / SP_T) * (nz / SP_T) < (1ll << 30);
+// `order` <= 0: can ANY order run tiled on this mesh (sizing the workspace)?  Otherwise: can this order?
+static bool sp_tiled_ok(int nx, int ny, int nz, int B, int order) {
+  const SpTile e = sp_tile(nx, ny, nz);
+  const int need = order > 0 ? order - 1 : 1;  // edge >= order - 1; an edge of 1 would be one block per mesh point
+  const int emin = e.ex < e.ey ? (e.ex < e.ez ? e.ex : e.ez) : (e.ey < e.ez ? e.ey : e.ez);
+  return nx >= MI_MAX_ORDER && ny >= MI_MAX_ORDER && nz >= MI_MAX_ORDER && emin >= (need > 2 ? need : 2) &&
+         (long long)B * (nx / e.ex) * (ny / e.ey) * (nz / e.ez) < (1ll << 30);
 }
 
 template <class T>
 __global__ void spread_key_kernel(const T* __restrict__ pos, const int* __restrict__ batch_idx, const T* __restrict__ cit, int N, int nx, int ny,
-                                  int nz, int order, int* __restrict__ keys, int* __restrict__ vals, int4* __restrict__ lo3, T* __restrict__ wts) {
+                                  int nz, int order, SpTile e, int* __restrict__ keys, int* __restrict__ vals, int4* __restrict__ lo3, T* __restrict__ wts) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= N) return;
   const int s = batch_idx ? batch_idx[i] : 0;
   const Stencil<T> st = make_stencil(pos + 3 * (size_t)i, cit + 9 * (size_t)s, nx, ny, nz, order);
   const int lx = wrap_idx(st.base[0] + st.off0[0], nx), ly = wrap_idx(st.base[1] + st.off0[1], ny), lz = wrap_idx(st.base[2] + st.off0[2], nz);
-  keys[i] = ((s * (nx / SP_T) + lx / SP_T) * (ny / SP_T) + ly / SP_T) * (nz / SP_T) + lz / SP_T;
+  keys[i] = ((s * (nx / e.ex) + lx / e.ex) * (ny / e.ey) + ly / e.ey) * (nz / e.ez) + lz / e.ez;
   vals[i] = i;
   lo3[i] = make_int4(lx, ly, lz, s);
   // the 1-D weights are evaluated once per atom here; the tile kernel (up to 8 tiles x order^2 threads per atom) only reads them
@@ -201,15 +211,15 @@ __global__ void spread_bin_start_kernel(const int* __restrict__ keys_sorted, int
 template <class T>
 __global__ __launch_bounds__(256) void spread_tiled_kernel(const T* __restrict__ values, const int* __restrict__ atom_of, const int* __restrict__ bin_start,
                                                            const int4* __restrict__ lo3, const T* __restrict__ wts, int nx, int ny, int nz, int order,
-                                                           int batched, T* __restrict__ mesh) {
+                                                           int batched, SpTile e, T* __restrict__ mesh) {
   __shared__ T tile[SP_T * SP_T * SP_T];
-  const int nbx = nx / SP_T, nby = ny / SP_T, nbz = nz / SP_T;
+  const int nbx = nx / e.ex, nby = ny / e.ey, nbz = nz / e.ez, tile_n = e.ex * e.ey * e.ez;
   int b = blockIdx.x;
   const int bz = b % nbz; b /= nbz;
   const int by = b % nby; b /= nby;
   const int bx = b % nbx;
   const int s = b / nbx;
-  for (int k = threadIdx.x; k < SP_T * SP_T * SP_T; k += blockDim.x) tile[k] = T(0);
+  for (int k = threadIdx.x; k < tile_n; k += blockDim.x) tile[k] = T(0);
   __syncthreads();
   const int tpa = order * order;
   const T thr = batched ? T(1e-8) : T(0);  // spline.py:548 (w > 0) vs :820 (w > 1e-8)
@@ -229,24 +239,24 @@ __global__ __launch_bounds__(256) void spread_tiled_kernel(const T* __restrict__
           int gx = lo.x + tx, gy = lo.y + ty;  // lo is already wrapped and order <= n: one conditional subtraction wraps
           gx -= gx >= nx ? nx : 0;
           gy -= gy >= ny ? ny : 0;
-          if (gx / SP_T != bx || gy / SP_T != by) continue;
+          if (gx / e.ex != bx || gy / e.ey != by) continue;
           const T* w3 = wts + (size_t)i * 3 * MI_MAX_ORDER;
           const T wxy = w3[tx] * w3[MI_MAX_ORDER + ty];
           const T val = values[i];
-          T* row = tile + ((gx % SP_T) * SP_T + (gy % SP_T)) * SP_T;
+          T* row = tile + ((gx - bx * e.ex) * e.ey + (gy - by * e.ey)) * e.ez;
           for (int tz = 0; tz < order; ++tz) {
             int gz = lo.z + tz;
             gz -= gz >= nz ? nz : 0;
-            if (gz / SP_T != bz) continue;
+            if (gz / e.ez != bz) continue;
             const T w = wxy * w3[2 * MI_MAX_ORDER + tz];
-            if (w > thr) atomicAdd(row + (gz % SP_T), val * w);
+            if (w > thr) atomicAdd(row + (gz - bz * e.ez), val * w);
           }
         }
       }
   __syncthreads();
-  for (int k = threadIdx.x; k < SP_T * SP_T * SP_T; k += blockDim.x) {
-    const int lx = k / (SP_T * SP_T), ly = (k / SP_T) % SP_T, lz = k % SP_T;
-    mesh[(((size_t)s * nx + bx * SP_T + lx) * ny + by * SP_T + ly) * nz + bz * SP_T + lz] = tile[k];
+  for (int k = threadIdx.x; k < tile_n; k += blockDim.x) {
+    const int lx = k / (e.ey * e.ez), ly = (k / e.ez) % e.ey, lz = k % e.ez;
+    mesh[(((size_t)s * nx + bx * e.ex + lx) * ny + by * e.ey + ly) * nz + bz * e.ez + lz] = tile[k];
   }
 }
 
@@ -495,6 +505,7 @@ template <class T>
 int spread_tiled(const T* pos, const T* values, const int* batch_idx, const T* cit, int N, int B, int nx, int ny, int nz, int order,
                         int batched, T* mesh, char* ws, hipStream_t st) {
   const SpLayout L = sp_layout(N, B, nx, ny, nz);
+  const SpTile e = sp_tile(nx, ny, nz);
   int* keys_in = reinterpret_cast<int*>(ws + L.keys_in);
   int* keys_out = reinterpret_cast<int*>(ws + L.keys_out);
   int* vals_in = reinterpret_cast<int*>(ws + L.vals_in);
@@ -502,7 +513,7 @@ int spread_tiled(const T* pos, const T* values, const int* batch_idx, const T* c
   int* bin_start = reinterpret_cast<int*>(ws + L.bin_start);
   int4* lo3 = reinterpret_cast<int4*>(ws + L.lo3);
   T* wts = reinterpret_cast<T*>(ws + L.wts);
-  spread_key_kernel<T><<<mi_blocks(N, 256), 256, 0, st>>>(pos, batch_idx, cit, N, nx, ny, nz, order, keys_in, vals_in, lo3, wts);
+  spread_key_kernel<T><<<mi_blocks(N, 256), 256, 0, st>>>(pos, batch_idx, cit, N, nx, ny, nz, order, e, keys_in, vals_in, lo3, wts);
   MI_LAUNCH_CHECK();
   int bits = 1;
   while ((1ll << bits) < L.nbins) ++bits;
@@ -510,7 +521,7 @@ int spread_tiled(const T* pos, const T* values, const int* batch_idx, const T* c
   MI_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(ws + L.cub, cub_bytes, (const int*)keys_in, keys_out, (const int*)vals_in, vals_out, N, 0, bits, st));
   spread_bin_start_kernel<<<mi_blocks(L.nbins + 1, 256), 256, 0, st>>>(keys_out, N, L.nbins, bin_start);
   MI_LAUNCH_CHECK();
-  spread_tiled_kernel<T><<<(int)L.nbins, 256, 0, st>>>(values, vals_out, bin_start, lo3, wts, nx, ny, nz, order, batched, mesh);
+  spread_tiled_kernel<T><<<(int)L.nbins, 256, 0, st>>>(values, vals_out, bin_start, lo3, wts, nx, ny, nz, order, batched, e, mesh);
   MI_LAUNCH_CHECK();
   return MI_OK;
 }
@@ -537,7 +548,7 @@ int mi_cell_geometry(const void* cell, int n_systems, int dtype, void* cell_inv_
 
 size_t mi_spline_spread_workspace_bytes(int n_atoms, int n_systems, int nx, int ny, int nz) {
   if (n_atoms < 0 || n_systems < 1 || nx <= 0 || ny <= 0 || nz <= 0) return 0;
-  if (!sp_tiled_ok(nx, ny, nz, n_systems)) return 256;  // the atomic kernel needs no scratch
+  if (!sp_tiled_ok(nx, ny, nz, n_systems, 0)) return 256;  // the atomic kernel needs no scratch
   return sp_layout(n_atoms, n_systems, nx, ny, nz).total;
 }
 
@@ -552,7 +563,7 @@ int mi_spline_spread(const void* positions, const void* values, const int32_t* b
   hipStream_t st = (hipStream_t)stream;
   mi_timing_begin("spline_spread", stream);
   int rc = MI_OK;
-  if (workspace && sp_tiled_ok(nx, ny, nz, n_systems) && workspace_bytes >= sp_layout(n_atoms, n_systems, nx, ny, nz).total) {
+  if (workspace && sp_tiled_ok(nx, ny, nz, n_systems, order) && workspace_bytes >= sp_layout(n_atoms, n_systems, nx, ny, nz).total) {
     if (dtype == MI_F32)
       rc = spread_tiled<float>((const float*)positions, (const float*)values, batch_idx, (const float*)cell_inv_t, n_atoms, n_systems, nx, ny, nz,
                                order, batched, (float*)mesh, (char*)workspace, st);

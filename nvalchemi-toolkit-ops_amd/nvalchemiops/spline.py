@@ -28,8 +28,8 @@ def _prep(positions: torch.Tensor, cell: torch.Tensor, batch_idx, cell_inv_t):
 
 # ---- raw launchers (detached, contiguous tensors) ------------------------------------------------------------------
 def _launch_spread(pos, vals, cit, bi, nsys, dims, order, batched):
-    """mesh[nsys,nx,ny,nz] = spread of `vals` at `pos`.  The library runs tile-owned (no global atomics) when the mesh dimensions
-    are multiples of 8 and falls back to atomic adds into the zeroed mesh otherwise; the scratch buffer covers the former."""
+    """mesh[nsys,nx,ny,nz] = spread of `vals` at `pos`.  The library runs tile-owned (no global atomics) when every mesh dimension
+    has a divisor in [max(order - 1, 2), 8] and falls back to atomic adds into the zeroed mesh otherwise; the scratch buffer covers the former."""
     import ctypes
 
     nx, ny, nz = (int(v) for v in dims)

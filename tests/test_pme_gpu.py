@@ -486,11 +486,12 @@ def test_hip_path_against_committed_oracle_vectors():
     _close(cg, v["ewald_cgrad"], np.float64, "ewald charge gradients")
 
 
-@pytest.mark.parametrize("dims", [(8, 8, 8), (16, 8, 24), (32, 32, 32)])
+@pytest.mark.parametrize("dims", [(8, 8, 8), (16, 8, 24), (32, 32, 32), (30, 36, 45), (12, 10, 14), (31, 9, 6)])
 @pytest.mark.parametrize("order", [1, 3, 4, 6])
 def test_tile_owned_spread(dims, order):
-    """Meshes whose dimensions are multiples of 8 take the tile-owned spread (no global atomics; one tile per axis wraps onto
-    itself for n = 8): against the oracle for orders <= 4, charge conservation + adjointness with the gather for order 6; atoms
+    """Meshes take the tile-owned spread (no global atomics) when every dimension has a divisor e with max(order - 1, 2) <= e <= 8 (the
+    per-axis tile edge; one tile per axis wraps onto itself for n = e) and the atomic kernel otherwise (31 is prime; 9 -> e = 3 only
+    carries order <= 4): against the oracle for orders <= 4, charge conservation + adjointness with the gather for order 6; atoms
     outside the cell, fp32 and fp64, single system and batch."""
     from nvalchemiops.spline import spline_gather, spline_spread
 
