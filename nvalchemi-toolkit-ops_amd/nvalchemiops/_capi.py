@@ -115,6 +115,14 @@ def eager(fn):
     def entry(*args, **kwargs):
         # a plain frame around the disabled callable: `torch.compile(dftd3)` (test_dftd3.py:1228) unwraps a directly disabled
         # function and would trace its body
+        for a in (args if args else kwargs.values()):
+            if isinstance(a, torch.Tensor):
+                # HIP launches go to the CURRENT device: tensors on another GPU of the process need the device guard the
+                # reference gets from Warp's per-device launch (`wp.launch(device=...)`)
+                if a.is_cuda and a.device.index != torch.cuda.current_device():
+                    with torch.cuda.device(a.device):
+                        return inner(*args, **kwargs)
+                break
         return inner(*args, **kwargs)
 
     return entry
