@@ -84,7 +84,10 @@ __device__ __forceinline__ PairGeom<T> d3_geom(const V4& pj, T pix, T piy, T piz
   if (periodic) {
     const T fs[3] = {(T)sh.a, (T)sh.b, (T)sh.c};
     T cart[3];
-    rowvec_mat3(fs, cm, cart);
+    // orthorhombic cell (wave-uniform test on the scalar cell entries): the six off-diagonal products are exact zeros, leave them out
+    const bool ortho = cm[1] == T(0) && cm[2] == T(0) && cm[3] == T(0) && cm[5] == T(0) && cm[6] == T(0) && cm[7] == T(0);
+    if (ortho) { cart[0] = fs[0] * cm[0]; cart[1] = fs[1] * cm[4]; cart[2] = fs[2] * cm[8]; }
+    else rowvec_mat3(fs, cm, cart);
     dx = dx + cart[0]; dy = dy + cart[1]; dz = dz + cart[2];
   }
   g.rx = (float)dx; g.ry = (float)dy; g.rz = (float)dz;
@@ -244,7 +247,8 @@ __global__ __launch_bounds__(D3_LS_WAVES * MI_WAVE) void d3_cn_kernel(const T* _
 
 // `_s5_switch` (dftd3.py:341-423)
 __device__ __forceinline__ void d3_s5(float r, float on, float off, float inv_w, float& sw, float& dsw) {
-  if (off <= on || r <= on) { sw = 1.0f; dsw = 0.0f; return; }
+  if (off <= on) { sw = 1.0f; dsw = 0.0f; return; }  // switch disabled (the default): kernel-uniform, a scalar branch around the polynomial
+  if (r <= on) { sw = 1.0f; dsw = 0.0f; return; }
   if (r >= off) { sw = 0.0f; dsw = 0.0f; return; }
   const float t = (r - on) * inv_w, t2 = t * t, t3 = t2 * t, t4 = t3 * t, t5 = t4 * t;
   sw = 1.0f - (10.0f * t3 - 15.0f * t4 + 6.0f * t5);
