@@ -124,17 +124,15 @@ __device__ __forceinline__ D3Step d3_fetch_pk(const unsigned* __restrict__ pk, l
   s.sh = Int3{(int)((w >> 26) & 3u) - 1, (int)((w >> 28) & 3u) - 1, (int)(w >> 30) - 1};
   return s;
 }
+// PK kernels read the packed copy unless the CN pass raised `pk_flag` (a shift outside {-1, 0, 1}): then they walk the caller's
+// arrays like the plain kernels -- a wave-uniform choice, so one launch serves both cases.
 template <bool PK>
 __device__ __forceinline__ D3Step d3_fetch_any(const int* __restrict__ idx, const Int3* __restrict__ ush3, const unsigned* __restrict__ pk,
-                                               long long e, long long end, bool periodic) {
-  if constexpr (PK) return d3_fetch_pk(pk, e, end);
-  else return d3_fetch(idx, ush3, e, end, periodic);
-}
-// which of the two variants of a pass runs: the packed one unless the CN pass raised the flag; without a flag only the plain one exists
-template <bool PK>
-__device__ __forceinline__ bool d3_variant_runs(const int* __restrict__ pk_flag) {
-  if (PK) return *pk_flag == 0;
-  return pk_flag == nullptr || *pk_flag != 0;
+                                               bool use_pk, long long e, long long end, bool periodic) {
+  if constexpr (PK) {
+    if (use_pk) return d3_fetch_pk(pk, e, end);
+  }
+  return d3_fetch(idx, ush3, e, end, periodic);
 }
 // The row walks below are software-pipelined three deep: while step k is evaluated, the per-atom records of step k+1 are
 // already being gathered and the index/shift words of step k+2 are in flight; validity is a predicate, not a branch, so
@@ -508,7 +506,10 @@ __device__ __forceinline__ void d3_energy_body(const T* __restrict__ pos, const 
   __shared__ float4 lds_tab[MODE == 0 ? 1 : 4][WAVE_F4];
   const int S = sinfo->S;
   const int want_mode = S > D3_SMAX ? 0 : (sinfo->factorized ? 2 : 1);
-  if (want_mode != MODE || !d3_variant_runs<PK>(pk_flag)) return;
+  if (want_mode != MODE) return;
+  // (folding the fallback into this kernel as in the chain pass costs it 8 % -- 93 VGPRs and a branch per fetch -- so it stays separate)
+  if (PK ? *pk_flag != 0 : (pk_flag != nullptr && *pk_flag == 0)) return;
+  constexpr bool use_pk = PK;
   const int lane = threadIdx.x & (MI_WAVE - 1);
   const int i = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x / MI_WAVE) + threadIdx.x / MI_WAVE);
   if (i >= N) return;
@@ -546,7 +547,7 @@ __device__ __forceinline__ void d3_energy_body(const T* __restrict__ pos, const 
   const Int3* __restrict__ ush3 = reinterpret_cast<const Int3*>(ush);
   long long e = beg + lane;
   const unsigned jlim = d3_index_limit<CSR>(N, fill_value);
-  D3Step s0 = d3_fetch_any<PK>(idx, ush3, pk, e, end, periodic), s1 = d3_fetch_any<PK>(idx, ush3, pk, e + MI_WAVE, end, periodic);
+  D3Step s0 = d3_fetch_any<PK>(idx, ush3, pk, use_pk, e, end, periodic), s1 = d3_fetch_any<PK>(idx, ush3, pk, use_pk, e + MI_WAVE, end, periodic);
   bool v0 = s0.in && ((unsigned)s0.j < jlim);
   using PosRec = typename Vec4<T>::type;
   auto pos_of = [&](int j) -> PosRec {
@@ -565,7 +566,7 @@ __device__ __forceinline__ void d3_energy_body(const T* __restrict__ pos, const 
   aux_of(v0 ? s0.j : i, a0, b0);
   for (long long base = beg; base < end; base += MI_WAVE) {
     e += MI_WAVE;
-    const D3Step s2 = d3_fetch_any<PK>(idx, ush3, pk, e + MI_WAVE, end, periodic);
+    const D3Step s2 = d3_fetch_any<PK>(idx, ush3, pk, use_pk, e + MI_WAVE, end, periodic);
     const bool v1 = s1.in && ((unsigned)s1.j < jlim);
     const PosRec p1 = pos_of(v1 ? s1.j : i);
     float4 a1, b1;
@@ -665,6 +666,13 @@ template <class T, bool CSR, int MODE, bool PK>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) void d3_energy_kernel_w5(D3_ENERGY_PARAMS) {
   d3_energy_body<T, CSR, MODE, PK>(D3_ENERGY_ARGS);
 }
+// all three plain variants in one launch: what runs behind the packed variants (one dead launch instead of three when the packed copy was usable)
+template <class T, bool CSR>
+__global__ __launch_bounds__(256) void d3_energy_fallback_kernel(D3_ENERGY_PARAMS) {
+  d3_energy_body<T, CSR, 2, false>(D3_ENERGY_ARGS);
+  d3_energy_body<T, CSR, 1, false>(D3_ENERGY_ARGS);
+  d3_energy_body<T, CSR, 0, false>(D3_ENERGY_ARGS);
+}
 #undef D3_ENERGY_ARGS
 #undef D3_ENERGY_PARAMS
 
@@ -676,7 +684,7 @@ __global__ __launch_bounds__(D3_LS_WAVES * MI_WAVE) void d3_chain_kernel(const T
                                                        const typename Vec4<T>::type* __restrict__ apos, const float* __restrict__ dEdCN,
                                                        int want_virial, float* __restrict__ forces, float* __restrict__ v_atom,
                                                        const unsigned* __restrict__ pk, const int* __restrict__ pk_flag) {
-  if (!d3_variant_runs<PK>(pk_flag)) return;  // block-uniform: no barrier has been reached yet
+  const bool use_pk = PK && *pk_flag == 0;
   const int lane = threadIdx.x & (MI_WAVE - 1);
   const int i0 = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x / MI_WAVE) + threadIdx.x / MI_WAVE);
   const int i = i0 < N ? i0 : N - 1;
@@ -696,14 +704,14 @@ __global__ __launch_bounds__(D3_LS_WAVES * MI_WAVE) void d3_chain_kernel(const T
   const Int3* __restrict__ ush3 = reinterpret_cast<const Int3*>(ush);
   long long e = beg + lane;
   const unsigned jlim = d3_index_limit<CSR>(N, fill_value);
-  D3Step s0 = d3_fetch_any<PK>(idx, ush3, pk, e, end, periodic), s1 = d3_fetch_any<PK>(idx, ush3, pk, e + MI_WAVE, end, periodic);
+  D3Step s0 = d3_fetch_any<PK>(idx, ush3, pk, use_pk, e, end, periodic), s1 = d3_fetch_any<PK>(idx, ush3, pk, use_pk, e + MI_WAVE, end, periodic);
   bool v0 = s0.in && ((unsigned)s0.j < jlim);
   auto p0 = apos[v0 ? s0.j : i];
   float d0 = dEdCN[v0 ? s0.j : i];
   for (int trip = 0; trip < trips; ++trip) {
     __syncthreads();  // lock-step (see d3_cn_kernel)
     e += MI_WAVE;
-    const D3Step s2 = d3_fetch_any<PK>(idx, ush3, pk, e + MI_WAVE, end, periodic);
+    const D3Step s2 = d3_fetch_any<PK>(idx, ush3, pk, use_pk, e + MI_WAVE, end, periodic);
     const bool v1 = s1.in && ((unsigned)s1.j < jlim);
     const auto p1 = apos[v1 ? s1.j : i];
     const float d1 = dEdCN[v1 ? s1.j : i];
@@ -881,10 +889,15 @@ int d3_impl(const T* pos, const int* numbers, int N, const int* idx, const int* 
     launch_energy(std::integral_constant<int, 1>{}, packed);
     launch_energy(std::integral_constant<int, 0>{}, packed);
   };
-  // the plain variants always exist; with a packed list they exit at once unless the CN pass found a shift outside {-1, 0, 1}
+  // with a packed list the PK variants run; if the CN pass found a shift outside {-1, 0, 1} they exit and the fallback launch (energy) or
+  // the in-kernel fallback (chain) walks the caller's arrays
   if constexpr (!CSR) {
-    if (pk) { MI_TIMED("d3_energy", st, (launch_modes(Packed{}))); MI_LAUNCH_CHECK(); launch_modes(Plain{}); }
-    else { MI_TIMED("d3_energy", st, (launch_modes(Plain{}))); }
+    if (pk) {
+      MI_TIMED("d3_energy", st, (launch_modes(Packed{})));
+      MI_LAUNCH_CHECK();
+      d3_energy_fallback_kernel<T, CSR><<<blocks, 256, 0, st>>>(pos, numbers, N, idx, ush, nptr, M, fill_value, cell, batch_idx, P, cn, want_virial, smap, sinfo,
+                                                                ctab, ftab, fcr, apos, aaux, aw, dEdCN, forces, e_atom, v_atom, nullptr, pk_flag);
+    } else { MI_TIMED("d3_energy", st, (launch_modes(Plain{}))); }
   } else {
     MI_TIMED("d3_energy", st, (launch_modes(Plain{})));
   }
@@ -895,7 +908,7 @@ int d3_impl(const T* pos, const int* numbers, int N, const int* idx, const int* 
                                                                                              dEdCN, want_virial, forces, v_atom, PK_ ? pk : nullptr, pk_flag);
   };
   if constexpr (!CSR) {
-    if (pk) { MI_TIMED("d3_chain", st, (launch_chain(Packed{}))); MI_LAUNCH_CHECK(); launch_chain(Plain{}); }
+    if (pk) { MI_TIMED("d3_chain", st, (launch_chain(Packed{}))); }
     else { MI_TIMED("d3_chain", st, (launch_chain(Plain{}))); }
   } else {
     MI_TIMED("d3_chain", st, (launch_chain(Plain{})));
