@@ -137,6 +137,9 @@ size_t mi_d3_workspace_bytes(int n_atoms, int n_systems, int nz);
  * 16-byte-per-slot arrays; lists with shifts outside {-1,0,1} or >= 2^26 atoms fall back to the arrays on the device. Results are
  * identical either way.  Equals mi_d3_workspace_bytes when max_neighbors <= 0 (CSR).                                              */
 size_t mi_d3_workspace_bytes_packed(int n_atoms, int n_systems, int nz, int max_neighbors);
+/* The same for any layout, by number of stored entries (CSR: neighbor_ptr[n_atoms]; the caller then passes that count as mi_d3's
+ * `max_neighbors` argument, which the CSR walk does not otherwise read, to enable the packed copy).                          */
+size_t mi_d3_workspace_bytes_entries(int n_atoms, int n_systems, int nz, long long n_entries);
 
 int mi_d3(const void* positions, const int32_t* numbers, int n_atoms, int dtype,
           const int32_t* idx_j,        /* matrix [n_atoms,max_neighbors] or CSR values [n_pairs]      */

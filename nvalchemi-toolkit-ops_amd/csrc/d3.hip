@@ -891,28 +891,20 @@ int d3_impl(const T* pos, const int* numbers, int N, const int* idx, const int* 
   };
   // with a packed list the PK variants run; if the CN pass found a shift outside {-1, 0, 1} they exit and the fallback launch (energy) or
   // the in-kernel fallback (chain) walks the caller's arrays
-  if constexpr (!CSR) {
-    if (pk) {
-      MI_TIMED("d3_energy", st, (launch_modes(Packed{})));
-      MI_LAUNCH_CHECK();
-      d3_energy_fallback_kernel<T, CSR><<<blocks, 256, 0, st>>>(pos, numbers, N, idx, ush, nptr, M, fill_value, cell, batch_idx, P, cn, want_virial, smap, sinfo,
-                                                                ctab, ftab, fcr, apos, aaux, aw, dEdCN, forces, e_atom, v_atom, nullptr, pk_flag);
-    } else { MI_TIMED("d3_energy", st, (launch_modes(Plain{}))); }
-  } else {
-    MI_TIMED("d3_energy", st, (launch_modes(Plain{})));
-  }
+  if (pk) {
+    MI_TIMED("d3_energy", st, (launch_modes(Packed{})));
+    MI_LAUNCH_CHECK();
+    d3_energy_fallback_kernel<T, CSR><<<blocks, 256, 0, st>>>(pos, numbers, N, idx, ush, nptr, M, fill_value, cell, batch_idx, P, cn, want_virial, smap, sinfo,
+                                                              ctab, ftab, fcr, apos, aaux, aw, dEdCN, forces, e_atom, v_atom, nullptr, pk_flag);
+  } else { MI_TIMED("d3_energy", st, (launch_modes(Plain{}))); }
   MI_LAUNCH_CHECK();
   auto launch_chain = [&](auto packed) {
     constexpr bool PK_ = decltype(packed)::value;
     d3_chain_kernel<T, CSR, PK_><<<mi_blocks(N, D3_LS_WAVES), D3_LS_WAVES * MI_WAVE, 0, st>>>(pos, numbers, N, idx, ush, nptr, M, fill_value, cell, batch_idx, P, apos,
                                                                                              dEdCN, want_virial, forces, v_atom, PK_ ? pk : nullptr, pk_flag);
   };
-  if constexpr (!CSR) {
-    if (pk) { MI_TIMED("d3_chain", st, (launch_chain(Packed{}))); }
-    else { MI_TIMED("d3_chain", st, (launch_chain(Plain{}))); }
-  } else {
-    MI_TIMED("d3_chain", st, (launch_chain(Plain{})));
-  }
+  if (pk) { MI_TIMED("d3_chain", st, (launch_chain(Packed{}))); }
+  else { MI_TIMED("d3_chain", st, (launch_chain(Plain{}))); }
   MI_LAUNCH_CHECK();
   double* sums = reinterpret_cast<double*>(ws + L.sums);
   MI_HIP_CHECK(hipMemsetAsync(sums, 0, sizeof(double) * 10 * (size_t)B, st));
@@ -932,10 +924,14 @@ size_t mi_d3_workspace_bytes(int n_atoms, int n_systems, int nz) {
   return d3_layout(n_atoms, nz, MI_F64, n_systems).total;  // sized for the wider dtype
 }
 
-size_t mi_d3_workspace_bytes_packed(int n_atoms, int n_systems, int nz, int max_neighbors) {
+size_t mi_d3_workspace_bytes_entries(int n_atoms, int n_systems, int nz, long long n_entries) {
   const size_t base = mi_d3_workspace_bytes(n_atoms, n_systems, nz);
-  if (base == 0 || max_neighbors <= 0 || n_atoms >= D3_PK_MAX_ATOMS) return base;
-  return base + 512 + sizeof(unsigned) * (size_t)n_atoms * (size_t)max_neighbors;  // alignment slack + flag line + the words
+  if (base == 0 || n_entries <= 0 || n_atoms >= D3_PK_MAX_ATOMS) return base;
+  return base + 512 + sizeof(unsigned) * (size_t)n_entries;  // alignment slack + flag line + the words
+}
+
+size_t mi_d3_workspace_bytes_packed(int n_atoms, int n_systems, int nz, int max_neighbors) {
+  return mi_d3_workspace_bytes_entries(n_atoms, n_systems, nz, max_neighbors > 0 ? (long long)n_atoms * max_neighbors : 0);
 }
 
 int mi_d3(const void* positions, const int32_t* numbers, int n_atoms, int dtype, const int32_t* idx_j, const int32_t* unit_shifts,
@@ -954,8 +950,10 @@ int mi_d3(const void* positions, const int32_t* numbers, int n_atoms, int dtype,
   const bool csr = neighbor_ptr != nullptr;
   // a periodic padded list is re-read by all three passes: with the larger workspace the CN pass leaves a 4 B/slot copy for the others
   unsigned* pk = nullptr;
-  if (!csr && cell && unit_shifts && max_neighbors > 0 && n_atoms < D3_PK_MAX_ATOMS &&
-      workspace_bytes >= mi_d3_workspace_bytes_packed(n_atoms, n_systems, params->nz, max_neighbors))
+  // (CSR callers that know the number of stored entries pass it in `max_neighbors`, which the CSR walk does not otherwise use)
+  const long long n_entries = csr ? (long long)max_neighbors : (long long)n_atoms * max_neighbors;
+  if (cell && unit_shifts && n_entries > 0 && n_atoms < D3_PK_MAX_ATOMS &&
+      workspace_bytes >= mi_d3_workspace_bytes_entries(n_atoms, n_systems, params->nz, n_entries))
     pk = reinterpret_cast<unsigned*>((char*)workspace + ((mi_d3_workspace_bytes(n_atoms, n_systems, params->nz) + 255) & ~(size_t)255));
 #define MI_D3_CALL(T_, CSR_)                                                                                                              \
   return d3_impl<T_, CSR_>((const T_*)positions, numbers, n_atoms, idx_j, unit_shifts, neighbor_ptr, max_neighbors, fill_value, (const T_*)cell, \

@@ -49,6 +49,8 @@ def lib() -> ctypes.CDLL:
             L.mi_d3_workspace_bytes.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int]
             L.mi_d3_workspace_bytes_packed.restype = ctypes.c_size_t
             L.mi_d3_workspace_bytes_packed.argtypes = [ctypes.c_int] * 4
+            L.mi_d3_workspace_bytes_entries.restype = ctypes.c_size_t
+            L.mi_d3_workspace_bytes_entries.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_longlong]
         _LIB = L
     return _LIB
 

@@ -85,8 +85,14 @@ def _launch(positions, numbers, idx, shifts, nptr, max_neighbors, fill_value, ce
     sh = C.i32(shifts.to(dev)) if periodic else None
     bi = None if batch_idx is None else C.i32(batch_idx)
     # a periodic padded matrix is streamed by all three passes: the larger workspace lets the CN pass leave a 4 B/slot copy for the others
-    pack = periodic and nptr is None and os.environ.get("NVALCHEMIOPS_D3_PACKED_LIST", "1") != "0"  # "0": tuning aid (A/B on one box)
-    ws_bytes = int(C.lib().mi_d3_workspace_bytes_packed(n, num_systems, rcov.shape[0], int(max_neighbors) if pack else 0))
+    # NVALCHEMIOPS_D3_PACKED_LIST: "1" (default) padded matrix only; "0" never (A/B on one box); "2" also CSR lists -- measured neutral
+    # there (unaligned rows make the CN pass's extra write cost what the other two passes gain), so it is not the default
+    mode = os.environ.get("NVALCHEMIOPS_D3_PACKED_LIST", "1")
+    pack = periodic and mode != "0" and (nptr is None or mode == "2")
+    if nptr is not None:  # CSR: the number of stored entries is the length of idx_j; it travels in the otherwise unused `max_neighbors`
+        max_neighbors = idx.shape[0] if (pack and idx.shape[0] < 2**31) else 0
+    n_entries = (idx.shape[0] if nptr is not None else n * int(max_neighbors)) if pack else 0
+    ws_bytes = int(C.lib().mi_d3_workspace_bytes_entries(n, num_systems, rcov.shape[0], int(n_entries)))
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
     vir = virial if compute_virial else None
     rc = C.lib().mi_d3(C.ptr(pos), C.ptr(C.i32(numbers)), n, code, C.ptr(idx), C.ptr(sh), C.ptr(nptr), int(max_neighbors), int(fill_value),

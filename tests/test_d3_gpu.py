@@ -286,6 +286,14 @@ def test_packed_list_equals_plain_walk(box, shift_max, monkeypatch):
     plain = dftd3(_t(pos), _t(z), **args)
     for a, b in zip(packed, plain):
         assert torch.equal(a, b)
+    # the same for the CSR layout (the entry count travels in `max_neighbors`)
+    lst, nptr, lsh = cell_list(_t(pos), 14.0, _t(cell), pbc, return_neighbor_list=True)
+    cargs = dict(d3_params=p, neighbor_list=lst, neighbor_ptr=nptr, unit_shifts=lsh, cell=_t(cell)[None], compute_virial=True, **FP)
+    plain_csr = dftd3(_t(pos), _t(z), **cargs)
+    monkeypatch.setenv("NVALCHEMIOPS_D3_PACKED_LIST", "2")  # CSR packing is opt-in (measured neutral)
+    packed_csr = dftd3(_t(pos), _t(z), **cargs)
+    for a, b in zip(packed_csr, plain_csr):
+        assert torch.equal(a, b)
     if shift_max == 1:  # (the 12-atom cell is far denser than matter: its forces are differences of huge terms, outside the tolerance model)
         ref = O.dftd3(pos, z, t, neighbor_matrix=nm.cpu().numpy(), neighbor_matrix_shifts=sh.cpu().numpy(), cell=cell, compute_virial=True, **FP)
         _check(packed, ref, virial=True)
