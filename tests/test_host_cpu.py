@@ -256,3 +256,25 @@ def test_bspline_deconvolution_factors():
         for k in (1, 3, 4):  # not the Nyquist index (clamped for even orders)
             b = sum(cj * complex(math.cos(2 * math.pi * k * j / n), math.sin(2 * math.pi * k * j / n)) for j, cj in enumerate(c))
             assert abs(float(compute_bspline_deconvolution_1d(n, order)[k]) - 1.0 / abs(b) ** 2) < 1e-9 / abs(b) ** 2
+
+
+def test_rebuild_detection_and_batch_size_edge_cases():
+    """Edge cases the reference tests on every device (test_rebuild_detection.py:188-310, test_batch_cell_list.py:550-640): empty
+    systems never need a rebuild, mismatched atom counts always do, empty / negative-cutoff size estimates, empty batch build."""
+    from nvalchemiops.neighborlist import (batch_build_cell_list, cell_list_needs_rebuild, estimate_batch_cell_list_sizes,
+                                           neighbor_list_needs_rebuild)
+
+    i32 = lambda x: torch.tensor(x, dtype=torch.int32)  # noqa: E731
+    r = cell_list_needs_rebuild(current_positions=torch.empty((0, 3)), atom_to_cell_mapping=torch.empty((0, 3), dtype=torch.int32),
+                                cells_per_dimension=i32([1, 1, 1]), cell=torch.eye(3).unsqueeze(0), pbc=torch.tensor([True, True, True]))
+    assert r.shape == (1,) and r.dtype == torch.bool and not r.item()
+    r = neighbor_list_needs_rebuild(reference_positions=torch.randn(5, 3), current_positions=torch.randn(7, 3), skin_distance_threshold=0.5)
+    assert r.shape == (1,) and r.dtype == torch.bool and r.item()
+    r = neighbor_list_needs_rebuild(reference_positions=torch.empty((0, 3)), current_positions=torch.empty((0, 3)), skin_distance_threshold=0.5)
+    assert r.shape == (1,) and not r.item()
+    ncell, radius = estimate_batch_cell_list_sizes(torch.zeros((0, 3, 3)), torch.zeros((0, 3), dtype=torch.bool), 1.0)
+    assert ncell == 1 and radius.shape == (0, 3) and radius.dtype == torch.int32
+    ncell, radius = estimate_batch_cell_list_sizes(torch.eye(3).reshape(1, 3, 3), torch.tensor([[True, True, True]]), -1.0)
+    assert ncell == 1 and radius.shape == (1, 3) and radius.dtype == torch.int32
+    batch_build_cell_list(torch.empty(0, 3), 1.0, torch.eye(3).reshape(1, 3, 3), torch.tensor([[True, True, True]]), torch.empty(0, dtype=torch.int32),
+                          i32([1, 1, 1]), i32([1, 1, 1]), i32([0, 0, 0]), i32([0, 0, 0]), i32([0]), i32([0]), i32([]))  # returns without touching a device
