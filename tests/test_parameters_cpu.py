@@ -75,3 +75,28 @@ def test_mesh_dimension_helpers():
     assert mesh_spacing_to_dimensions(cell[0], mesh_spacing=0.5) == s                                                  # (:603)
     with pytest.raises(ValueError):
         mesh_spacing_to_dimensions(cells, mesh_spacing=torch.tensor([0.5, 0.5, 0.5]))                                  # (:591)
+
+
+def test_k_vector_generators_forms_and_gradients():
+    """Shapes, safe k^2 and autograd through the cell, as test/interactions/electrostatics/test_kvectors.py:64-290 checks them."""
+    from nvalchemiops.interactions.electrostatics import generate_k_vectors_ewald_summation, generate_k_vectors_pme
+
+    cell = torch.eye(3, dtype=torch.float64).unsqueeze(0) * 10.0
+    k = generate_k_vectors_ewald_summation(cell, k_cutoff=8.0)
+    assert k.ndim == 2 and k.shape[1] == 3 and k.shape[0] > 0
+    kb = generate_k_vectors_ewald_summation(cell.expand(3, -1, -1).contiguous(), k_cutoff=8.0)
+    assert kb.shape == (3, k.shape[0], 3)
+    assert generate_k_vectors_ewald_summation(cell, k_cutoff=10.0).shape[0] > generate_k_vectors_ewald_summation(cell, k_cutoff=5.0).shape[0]
+    kv, k2 = generate_k_vectors_pme(cell, (16, 16, 16))
+    assert kv.shape == (16, 16, 9, 3) and k2.shape == (16, 16, 9) and bool((k2 > 0).all())
+    assert float(torch.norm(kv[0, 0, 0])) < 1e-10 and float(k2[0, 0, 0]) > 0
+    for dims in ((8, 8, 8), (16, 32, 64), (12, 10, 14)):
+        kv, k2 = generate_k_vectors_pme(cell, dims)
+        assert kv.shape == (dims[0], dims[1], dims[2] // 2 + 1, 3) and k2.shape == kv.shape[:-1]
+    c = cell.clone().requires_grad_(True)
+    generate_k_vectors_ewald_summation(c, k_cutoff=8.0).sum().backward()
+    assert c.grad is not None and bool(torch.isfinite(c.grad).all())
+    c = cell.clone().requires_grad_(True)
+    kv, k2 = generate_k_vectors_pme(c, (16, 16, 16))
+    (kv.sum() + k2.sum()).backward()
+    assert c.grad is not None and bool(torch.isfinite(c.grad).all())
