@@ -92,3 +92,21 @@ def test_electrostatics_errors():
         ewald_summation(pos, q, cell, alpha="invalid", **lst)
     with pytest.raises(ValueError):
         mesh_spacing_to_dimensions(torch.stack([torch.eye(3) * 20, torch.eye(3) * 30]), mesh_spacing=torch.tensor([0.5, 0.5, 0.5]))
+
+
+def test_d3_parameters_container():
+    """`D3Parameters` behaviours of test_dftd3.py:245-416: valid construction, custom interpolation mesh, `.to()` for device / dtype, float64 tables."""
+    from nvalchemiops.interactions.dispersion import D3Parameters
+
+    r = torch.rand
+    p = D3Parameters(rcov=r(10), r4r2=r(10), c6ab=r(10, 10, 5, 5), cn_ref=r(10, 10, 5, 5))
+    assert p.max_z == 9 and p.device == torch.device("cpu") and p.interp_mesh == 5
+    q = D3Parameters(rcov=r(6), r4r2=r(6), c6ab=r(6, 6, 3, 3), cn_ref=r(6, 6, 3, 3), interp_mesh=3)
+    assert q.interp_mesh == 3 and q.c6ab.shape == (6, 6, 3, 3)
+    assert p.to(device="cpu").rcov.device == torch.device("cpu")
+    d = D3Parameters(rcov=r(10, dtype=torch.float64), r4r2=r(10, dtype=torch.float64), c6ab=r(10, 10, 5, 5, dtype=torch.float64),
+                     cn_ref=r(10, 10, 5, 5, dtype=torch.float64))
+    assert d.rcov.dtype == torch.float64
+    f = d.to(device="cpu", dtype=torch.float32)
+    assert all(t.dtype == torch.float32 for t in (f.rcov, f.r4r2, f.c6ab, f.cn_ref)) and f.device == torch.device("cpu")
+
