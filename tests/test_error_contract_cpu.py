@@ -110,3 +110,17 @@ def test_d3_parameters_container():
     f = d.to(device="cpu", dtype=torch.float32)
     assert all(t.dtype == torch.float32 for t in (f.rcov, f.r4r2, f.c6ab, f.cn_ref)) and f.device == torch.device("cpu")
 
+
+def test_d3_empty_systems():
+    """Empty inputs return before any device work (test_dftd3.py:634-715, :1673-1770): energy per system from batch_idx, empty F / CN."""
+    from nvalchemiops.interactions.dispersion import D3Parameters, dftd3
+
+    r = torch.rand
+    p = D3Parameters(rcov=r(10), r4r2=r(10), c6ab=r(10, 10, 5, 5), cn_ref=r(10, 10, 5, 5))
+    pos, z, nm = torch.empty((0, 3)), torch.empty((0,), dtype=torch.int32), torch.empty((0, 5), dtype=torch.int32)
+    kw = dict(a1=0.4, a2=4.0, s8=0.8, d3_params=p, neighbor_matrix=nm)
+    for bi, nsys in ((None, 1), (torch.empty((0,), dtype=torch.int32), 1), (torch.tensor([0, 1, 2], dtype=torch.int32), 3)):
+        e, f, cn = dftd3(pos, z, batch_idx=bi, **kw)
+        assert e.shape == (nsys,) and float(e.abs().sum()) == 0.0 and f.shape == (0, 3) and cn.shape == (0,)
+        assert e.dtype == torch.float32 and f.dtype == torch.float32
+
