@@ -67,8 +67,9 @@ def _run(positions, charges, cell, cutoff, alpha, neighbor_list, neighbor_ptr, n
         raise ValueError("Cannot provide both neighbor list and neighbor matrix formats")
     if use_list and neighbor_ptr is None:
         raise ValueError("neighbor_ptr is required when using neighbor_list format")
-    C.require_device(positions, charges, cell, neighbor_list, neighbor_ptr, neighbor_shifts, neighbor_matrix, neighbor_matrix_shifts, batch_idx)
     n, dev = positions.shape[0], positions.device
+    if n > 0:
+        C.require_device(positions, charges, cell, neighbor_list, neighbor_ptr, neighbor_shifts, neighbor_matrix, neighbor_matrix_shifts, batch_idx)
     pos = positions.to(torch.float64)
     q = charges.to(torch.float64)
     cells = cell.to(torch.float64).reshape(-1, 3, 3)

@@ -124,3 +124,25 @@ def test_d3_empty_systems():
         assert e.shape == (nsys,) and float(e.abs().sum()) == 0.0 and f.shape == (0, 3) and cn.shape == (0,)
         assert e.dtype == torch.float32 and f.dtype == torch.float32
 
+
+
+def test_electrostatics_empty_systems():
+    """No atoms: every electrostatics entry point returns empty per-atom results without device work (test_pme.py:350, test_ewald.py,
+    test_coulomb.py:1951-2175 shapes)."""
+    from nvalchemiops.interactions.electrostatics import (ewald_real_space, ewald_reciprocal_space, ewald_summation, particle_mesh_ewald,
+                                                          pme_reciprocal_space)
+    from nvalchemiops.interactions.electrostatics.coulomb import coulomb_energy_forces
+
+    pos, q = torch.zeros((0, 3), dtype=torch.float64), torch.zeros(0, dtype=torch.float64)
+    cell = torch.eye(3, dtype=torch.float64).unsqueeze(0) * 10
+    al = torch.tensor([0.3], dtype=torch.float64)
+    nm, sh = torch.zeros((0, 4), dtype=torch.int32), torch.zeros((0, 4, 3), dtype=torch.int32)
+    lst = dict(neighbor_matrix=nm, neighbor_matrix_shifts=sh)
+    outs = [pme_reciprocal_space(pos, q, cell[0], alpha=0.3, mesh_dimensions=(16, 16, 16), compute_forces=True),
+            particle_mesh_ewald(pos, q, cell[0], alpha=0.3, mesh_dimensions=(16, 16, 16), compute_forces=True, **lst),
+            ewald_real_space(pos, q, cell, al, compute_forces=True, **lst),
+            ewald_reciprocal_space(pos, q, cell, torch.zeros((5, 3), dtype=torch.float64), al, compute_forces=True),
+            ewald_summation(pos, q, cell, alpha=0.3, k_cutoff=2.0, compute_forces=True, **lst),
+            coulomb_energy_forces(pos, q, cell, 5.0, 0.0, **lst)]
+    for e, f in outs:
+        assert e.shape == (0,) and f.shape == (0, 3) and e.dtype == torch.float64
