@@ -35,6 +35,8 @@ const char* mi_last_error(void);      /* [host] message of the last failure on t
  * roofline figure).  mi_timing_report waits for the events and writes "<kernel> <launches> <total_ms>\n" lines. */
 int mi_timing_enable(int on);
 int mi_timing_report(char* buf /*[host]*/, int cap);
+/* same records with per-launch statistics: "<kernel> <launches> <total_ms> <median_ms> <min_ms> <max_ms>\n" */
+int mi_timing_report_stats(char* buf /*[host]*/, int cap);
 
 /* ---- neighbour list -------------------------------------------------------------------------
  * Replaces: nvalchemiops::build_cell_list + ::query_cell_list (neighborlist/cell_list.py:725,892),
@@ -137,15 +139,16 @@ size_t mi_d3_workspace_bytes(int n_atoms, int n_systems, int nz);
  * 16-byte-per-slot arrays; lists with shifts outside {-1,0,1} or >= 2^26 atoms fall back to the arrays on the device. Results are
  * identical either way.  Equals mi_d3_workspace_bytes when max_neighbors <= 0 (CSR).                                              */
 size_t mi_d3_workspace_bytes_packed(int n_atoms, int n_systems, int nz, int max_neighbors);
-/* The same for any layout, by number of stored entries (CSR: neighbor_ptr[n_atoms]; the caller then passes that count as mi_d3's
- * `max_neighbors` argument, which the CSR walk does not otherwise read, to enable the packed copy).                          */
+/* The same for any layout, by number of stored entries (CSR: neighbor_ptr[n_atoms] = mi_d3's `n_list_entries`).              */
 size_t mi_d3_workspace_bytes_entries(int n_atoms, int n_systems, int nz, long long n_entries);
 
 int mi_d3(const void* positions, const int32_t* numbers, int n_atoms, int dtype,
           const int32_t* idx_j,        /* matrix [n_atoms,max_neighbors] or CSR values [n_pairs]      */
           const int32_t* unit_shifts,  /* same layout x3, or NULL (non-periodic)                      */
           const int32_t* neighbor_ptr, /* NULL => matrix layout                                       */
-          int max_neighbors, int fill_value,
+          int max_neighbors,           /* matrix row width (ignored for CSR)                          */
+          long long n_list_entries,    /* CSR: length of idx_j, 0 = unknown (no packed copy); ignored for the matrix layout */
+          int fill_value,
           const void* cell,            /* [n_systems,3,3] dtype or NULL                               */
           const int32_t* batch_idx,    /* [n_atoms] or NULL                                           */
           int n_systems, const mi_d3_params* params /* [host] */, int compute_virial,
@@ -154,9 +157,14 @@ int mi_d3(const void* positions, const int32_t* numbers, int n_atoms, int dtype,
 
 /* ---- Ewald real space -----------------------------------------------------------------------
  * Replaces the 12 alchemiops::_[batch_]ewald_real_space_* ops (ewald.py:263-1365; kernels
- * ewald_kernels.py:266-1495): erfc(A&S 7.1.26)-damped pair sum over a FULL (symmetric) neighbour list.
- * energies are float64 whatever dtype is (the wrapper casts, ewald.py:577).  Forces are accumulated by
- * the row owner only (x2), which equals the reference's i/j atomic scatter for a symmetric list.
+ * ewald_kernels.py:266-1495): erfc(A&S 7.1.26)-damped pair sum over the stored neighbour entries.
+ * energies are float64 whatever dtype is (the wrapper casts, ewald.py:577).  The reference adds -f to atom i and
+ * atomically +f to atom j for every stored entry (ewald_kernels.py:518-544; charge gradients :864-873).  Over a
+ * symmetric (full) list that is 2x the row owner's sum, which is what the fast path writes (no atomics).
+ * `symmetry_scratch` (16 bytes of device memory, may be NULL): when given, the same pass checksums the list in both
+ * directions and, if it is NOT symmetric (half lists, rows truncated by overflow, one-sided lists), two fix-up launches
+ * redo forces / charge gradients with the reference's scatter; they exit at once otherwise.  NULL = the caller
+ * guarantees a symmetric list.
  */
 #define MI_EW_FORCES 1
 #define MI_EW_CHARGE_GRAD 2
@@ -164,7 +172,7 @@ int mi_ewald_real(const void* positions, const void* charges, const void* cell, 
                   const int32_t* batch_idx, int n_atoms, int dtype, const int32_t* idx_j,
                   const int32_t* unit_shifts, const int32_t* neighbor_ptr, int max_neighbors, int mask_value,
                   int flags, double* energies /*[n_atoms]*/, void* forces /*[n_atoms,3] dtype*/,
-                  double* charge_grads /*[n_atoms]*/, void* stream);
+                  double* charge_grads /*[n_atoms]*/, void* symmetry_scratch /*16 B or NULL*/, void* stream);
 
 /* Explicit-k reciprocal-space Ewald.  Replaces `alchemiops::_[batch_]ewald_reciprocal_space_energy[_forces
  * [_charge_grad]]` (ewald.py:1365-2318; kernels ewald_kernels.py:1496-2480).  Two passes, no [K,N] phase tables:
@@ -187,12 +195,13 @@ int mi_ewald_recip_gather(const void* positions, const void* charges, const void
  * the real-space ops, autograd.py:525-665 + the generated adjoints of ewald_kernels.py:266-1495).  Owner-only like the forward:
  *   dL/dr_i = sum_j (g_i+g_j) fm_ij sep_ij ; dL/dq_i = sum_j 1/2 (g_i+g_j) q_j erfc(a r)/r ;
  *   dL/dcell[s][a][b] = -sum_i g_i sum_j fm_ij sep_ij[b] S_ij[a] ; dL/dalpha[s] = -sum_i g_i sum_j q_i q_j exp(-a^2 r^2)/sqrt(pi).
- * grad_cell / grad_alpha ([n_systems,3,3] / [n_systems], float64, zeroed by the caller) may be NULL.                       */
+ * grad_cell / grad_alpha ([n_systems,3,3] / [n_systems], float64, zeroed by the caller) may be NULL.  `symmetry_scratch` as in
+ * mi_ewald_real: a list that is not symmetric gets the general adjoint (entry (i -> j) carries g_i to both ends, atomics).      */
 int mi_ewald_real_bwd(const void* positions, const void* charges, const void* cell, const void* alpha, const int32_t* batch_idx,
                       int n_atoms, int dtype, const int32_t* idx_j, const int32_t* unit_shifts, const int32_t* neighbor_ptr,
                       int max_neighbors, int mask_value, const void* grad_energies /*[n_atoms] dtype*/,
                       void* grad_positions /*[n_atoms,3] dtype*/, void* grad_charges /*[n_atoms] dtype*/,
-                      double* grad_cell, double* grad_alpha, void* stream);
+                      double* grad_cell, double* grad_alpha, void* symmetry_scratch /*16 B or NULL*/, void* stream);
 
 /* ---- cut-off Coulomb ---------------------------------------------------------------------------
  * Replaces the eight alchemiops::_[batch_]coulomb_energy[_forces]_{list,matrix} ops (interactions/electrostatics/coulomb.py:716-1330;

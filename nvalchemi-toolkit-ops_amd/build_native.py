@@ -14,6 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT_DIR = os.path.join(HERE, "nvalchemiops", "lib")
 LIB = os.path.join(OUT_DIR, "libnvalchemiops_hip.so")
+LIB_D3_IEEE = os.path.join(OUT_DIR, "libnvalchemiops_d3_ieee.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"
 
@@ -60,10 +61,19 @@ def build(force: bool = False, verbose: bool = True) -> str:
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)
 
+    # tests only: d3.hip with correctly rounded sqrt / divide and libm expf (-DMI_D3_IEEE, no fast-math flag) for the D3 error
+    # budget (tests/test_d3_gpu.py).  The product never loads it.
+    ieee_obj = os.path.join(build_dir, "d3_ieee.o")
+    d3_src = os.path.join(CSRC, "d3.hip")
+    if force or _stale(ieee_obj, [d3_src] + headers):
+        jobs.append([HIPCC] + COMMON + ["-DMI_D3_IEEE", "-x", "hip", "-c", d3_src, "-o", ieee_obj])
+
     with ThreadPoolExecutor(max_workers=4) as ex:
         list(ex.map(run, jobs))
     if force or jobs or _stale(LIB, objs):
         run([HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs)
+    if force or _stale(LIB_D3_IEEE, [ieee_obj, os.path.join(build_dir, "capi.o")]):
+        run([HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB_D3_IEEE, ieee_obj, os.path.join(build_dir, "capi.o")])
     return LIB
 
 

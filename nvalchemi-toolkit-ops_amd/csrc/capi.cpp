@@ -5,6 +5,7 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <algorithm>
 #include <map>
 #include <mutex>
 #include <string>
@@ -80,6 +81,33 @@ int mi_timing_report(char* buf, int cap) {
     int n = snprintf(buf + off, cap > off ? cap - off : 0, "%s %d %.6f\n", kv.first.c_str(), kv.second.first, kv.second.second);
     if (n < 0 || off + n >= cap) break;
     off += n;
+  }
+  return MI_OK;
+}
+
+// Same records, per-launch statistics: "<name> <launches> <total_ms> <median_ms> <min_ms> <max_ms>\n"; clears the records.
+int mi_timing_report_stats(char* buf, int cap) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  std::map<std::string, std::vector<double>> acc;
+  for (auto& r : g_recs) {
+    float ms = 0.0f;
+    if (hipEventSynchronize(r.b) == hipSuccess && hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) acc[r.name].push_back(ms);
+    g_pool.push_back(r.a);
+    g_pool.push_back(r.b);
+  }
+  g_recs.clear();
+  int off = 0;
+  if (buf && cap > 0) buf[0] = 0;
+  for (auto& kv : acc) {
+    std::vector<double>& v = kv.second;
+    std::sort(v.begin(), v.end());
+    double tot = 0.0;
+    for (double x : v) tot += x;
+    const size_t n = v.size();
+    const double med = n % 2 ? v[n / 2] : 0.5 * (v[n / 2 - 1] + v[n / 2]);
+    int w = snprintf(buf + off, cap > off ? cap - off : 0, "%s %zu %.6f %.6f %.6f %.6f\n", kv.first.c_str(), n, tot, med, v.front(), v.back());
+    if (w < 0 || off + w >= cap) break;
+    off += w;
   }
   return MI_OK;
 }

@@ -22,6 +22,18 @@
 
 #include "common.h"
 
+// Pair-math primitives.  Product build: hardware v_rsq / v_rcp / v_sqrt / v_exp (1 ulp each; the exponential with a compensated
+// argument, see d3_exp).  -DMI_D3_IEEE (tests only: libnvalchemiops_d3_ieee.so, built WITHOUT -fno-hip-fp32-correctly-rounded-divide-sqrt)
+// swaps in correctly rounded sqrt / divide and libm expf, so the error budget of DESIGN.md section 5 can separate "fast ops" from
+// "summation order".
+#ifdef MI_D3_IEEE
+#define D3_RCP(x) (1.0f / (x))
+#define D3_SQRT(x) sqrtf(x)
+#else
+#define D3_RCP(x) __builtin_amdgcn_rcpf(x)
+#define D3_SQRT(x) __builtin_amdgcn_sqrtf(x)
+#endif
+
 namespace {
 
 struct D3Dev {
@@ -95,8 +107,13 @@ __device__ __forceinline__ PairGeom<T> d3_geom(const V4& pj, T pix, T piy, T piz
   // instructions per pair in every pass); r < 1e-12 of the reference is r^2 < 1e-24 here
   const float r2 = g.rx * g.rx + g.ry * g.ry + g.rz * g.rz;
   g.ok = !(r2 < 1e-24f);
+#ifdef MI_D3_IEEE
+  g.r = sqrtf(g.ok ? r2 : 1.0f);
+  const float rinv = 1.0f / g.r;
+#else
   const float rinv = __builtin_amdgcn_rsqf(g.ok ? r2 : 1.0f);
   g.r = r2 * rinv;
+#endif
   g.rinv = g.ok ? rinv : 0.0f;
   return g;
 }
@@ -142,6 +159,9 @@ __device__ __forceinline__ D3Step d3_fetch_any(const int* __restrict__ idx, cons
 // ~1-2 ulp like libm's expf but without its range reduction and overflow/underflow selects.  Used where the argument is
 // bounded above (counting function: <= k1; C6 interpolation: [-12, 0]); v_exp_f32 flushes to 0 by itself below.
 __device__ __forceinline__ float d3_exp(float x) {
+#ifdef MI_D3_IEEE
+  return expf(x);
+#endif
   const float L2E_HI = 1.44269502e+00f, L2E_LO = 1.92596299e-08f, LN2 = 6.93147182e-01f;
   const float t = x * L2E_HI;
   float lo = fmaf(x, L2E_HI, -t);
@@ -154,7 +174,7 @@ __device__ __forceinline__ float d3_exp_neg(float x) { return d3_exp(x); }
 // `_cn_counting` (dftd3.py:608-645)
 __device__ __forceinline__ float d3_cn_count(float rinv, float rci, float rcj, float k1, float* dcn) {
   const float rr = (rci + rcj) * rinv;
-  const float f = __builtin_amdgcn_rcpf(1.0f + d3_exp(-k1 * (rr - 1.0f)));
+  const float f = D3_RCP(1.0f + d3_exp(-k1 * (rr - 1.0f)));
   if (dcn) *dcn = -f * (1.0f - f) * k1 * rr * rinv;
   return f;
 }
@@ -373,7 +393,7 @@ __device__ __forceinline__ void d3_c6(float cn_i, float cn_j, const float4* __re
     zdi += cL * di;
   }
   if (w > 1e-12f) {
-    const float wi = __builtin_amdgcn_rcpf(w);
+    const float wi = D3_RCP(w);
     c6 = z * wi;
     const float si = zdi - c6 * wdi;
     dci = ((2.0f * k3) * wi) * si;
@@ -477,7 +497,7 @@ __device__ __forceinline__ void d3_c6_fact(const D3Half& h, const float* v, cons
   }
   const float w = wz.x, z = wz.y, wdi = wzd.x, zdi = wzd.y;
   if (w > 1e-12f) {
-    const float wi = __builtin_amdgcn_rcpf(w);
+    const float wi = D3_RCP(w);
     c6 = z * wi;
     const float si = zdi - c6 * wdi;
     dci = ((2.0f * k3) * wi) * si;
@@ -604,12 +624,12 @@ __device__ __forceinline__ void d3_energy_body(const T* __restrict__ pos, const 
         q = bj.x; r06 = bj.y; r08 = bj.z;
       } else {
         q = 3.0f * r4r2_i * r4r2_j;
-        const float r0 = P.a1 * __builtin_amdgcn_sqrtf(q) + P.a2;
+        const float r0 = P.a1 * D3_SQRT(q) + P.a2;
         const float r02 = r0 * r0, r04 = r02 * r02;
         r06 = r04 * r02; r08 = r04 * r04;
       }
       const float r2 = r * r, r4 = r2 * r2, r6 = r4 * r2, r8 = r4 * r4;
-      const float i6 = __builtin_amdgcn_rcpf(r6 + r06), i8 = __builtin_amdgcn_rcpf(r8 + r08);
+      const float i6 = D3_RCP(r6 + r06), i8 = D3_RCP(r8 + r08);
       const float damp = P.s6 * i6 + P.s8 * q * i8;
       // `_dispersion_energy_force` (dftd3.py:690-731)
       const float eij = -c6 * damp;
@@ -935,7 +955,8 @@ size_t mi_d3_workspace_bytes_packed(int n_atoms, int n_systems, int nz, int max_
 }
 
 int mi_d3(const void* positions, const int32_t* numbers, int n_atoms, int dtype, const int32_t* idx_j, const int32_t* unit_shifts,
-          const int32_t* neighbor_ptr, int max_neighbors, int fill_value, const void* cell, const int32_t* batch_idx, int n_systems,
+          const int32_t* neighbor_ptr, int max_neighbors, long long n_list_entries, int fill_value, const void* cell,
+          const int32_t* batch_idx, int n_systems,
           const mi_d3_params* params, int compute_virial, float* energy, float* forces, float* coord_num, float* virial, void* workspace,
           size_t workspace_bytes, void* stream) {
   MI_REQUIRE(dtype == MI_F32 || dtype == MI_F64, "dtype");
@@ -950,8 +971,8 @@ int mi_d3(const void* positions, const int32_t* numbers, int n_atoms, int dtype,
   const bool csr = neighbor_ptr != nullptr;
   // a periodic padded list is re-read by all three passes: with the larger workspace the CN pass leaves a 4 B/slot copy for the others
   unsigned* pk = nullptr;
-  // (CSR callers that know the number of stored entries pass it in `max_neighbors`, which the CSR walk does not otherwise use)
-  const long long n_entries = csr ? (long long)max_neighbors : (long long)n_atoms * max_neighbors;
+  // CSR: `n_list_entries` = length of idx_j (0 = not given: no packed copy); matrix: n_atoms x max_neighbors
+  const long long n_entries = csr ? n_list_entries : (long long)n_atoms * max_neighbors;
   if (cell && unit_shifts && n_entries > 0 && n_atoms < D3_PK_MAX_ATOMS &&
       workspace_bytes >= mi_d3_workspace_bytes_entries(n_atoms, n_systems, params->nz, n_entries))
     pk = reinterpret_cast<unsigned*>((char*)workspace + ((mi_d3_workspace_bytes(n_atoms, n_systems, params->nz) + 255) & ~(size_t)255));

@@ -7,9 +7,13 @@
 // Matrix entries equal to mask_value are padding (exact equality, ewald_kernels.py:304); pairs with r <= 1e-8 are skipped.
 //
 // Execution shape: one wave64 per atom, lanes stride the row / CSR range; fp64 wave reductions.  The reference adds
-// -f to atom i and atomically +f to atom j for every directed pair; over the symmetric (full) list this kernel requires
-// -- as the reference's own 1/2 prefactor already does -- that equals 2x the row owner's sum, so
-// forces and charge gradients are written by the owner only: no atomics, deterministic.
+// -f to atom i and atomically +f to atom j for every stored entry (ewald_kernels.py:518-544, :864-873).  Over a symmetric (full)
+// list -- what its 1/2 prefactor assumes -- that equals 2x the row owner's sum, so the fast path writes
+// forces and charge gradients by the owner only: no atomics, deterministic.  Whether the list IS symmetric is checked in the same
+// pass: every stored entry adds hash(i, j, S) to one 64-bit sum and hash(j, i, -S) to another; the sums agree iff the entries pair
+// up (up to a 2^-32-ish hash collision).  When they differ (half lists, rows truncated by overflow, one-sided lists) two fix-up
+// launches -- which exit at once otherwise -- redo forces / charge gradients with the reference's i/j scatter (atomics), so any list
+// gives the reference's result.  Same scheme in the adjoint.
 #include "common.h"
 
 namespace {
@@ -23,12 +27,26 @@ __device__ __forceinline__ double erfc_as_poly(double x, double e_neg_x2) {
   return poly * e_neg_x2;
 }
 
+// order-sensitive 32-bit mix of one stored entry; summed per direction in 64 bits (see header)
+__device__ __forceinline__ unsigned ew_entry_hash(unsigned a, unsigned b, int s0, int s1, int s2) {
+  unsigned h = a * 0x9E3779B1u;
+  h ^= __builtin_rotateleft32(b * 0x85EBCA77u, 13);
+  h ^= ((unsigned)(s0 + 1024) | ((unsigned)(s1 + 1024) << 11) | ((unsigned)(s2 + 1024) << 22)) * 0xC2B2AE3Du;
+  h ^= h >> 15; h *= 0x2C1B3C6Du; h ^= h >> 12; h *= 0x297A2D39u; h ^= h >> 15;
+  return h;
+}
+__device__ __forceinline__ void ew_sym_flush(unsigned long long hf, unsigned long long hr, unsigned long long* __restrict__ sym, int lane) {
+  hf = wave_sum(hf); hr = wave_sum(hr);
+  if (lane == 0 && (hf | hr)) { atomicAdd(&sym[0], hf); atomicAdd(&sym[1], hr); }
+}
+
 template <class T, bool CSR>
 __global__ __launch_bounds__(256) void ewald_real_kernel(const T* __restrict__ pos, const T* __restrict__ q, const T* __restrict__ cell,
                                                          const T* __restrict__ alpha, const int* __restrict__ batch_idx, int N,
                                                          const int* __restrict__ idx, const int* __restrict__ ush, const int* __restrict__ nptr,
                                                          int M, int mask_value, int flags, double* __restrict__ energies,
-                                                         T* __restrict__ forces, double* __restrict__ cgrad) {
+                                                         T* __restrict__ forces, double* __restrict__ cgrad,
+                                                         unsigned long long* __restrict__ sym) {
   const int lane = threadIdx.x & (MI_WAVE - 1);
   const int i = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x / MI_WAVE) + threadIdx.x / MI_WAVE);
   if (i >= N) return;
@@ -43,11 +61,14 @@ __global__ __launch_bounds__(256) void ewald_real_kernel(const T* __restrict__ p
   if (CSR) { beg = nptr[i]; end = nptr[i + 1]; } else { beg = (long long)i * M; end = beg + M; }
   double eacc = 0.0, cgi = 0.0;
   T fx = 0, fy = 0, fz = 0;
+  unsigned long long hf = 0, hr = 0;
   for (long long e = beg + lane; e < end; e += MI_WAVE) {
     const int j = idx[e];
     if ((!CSR && j == mask_value) || (unsigned)j >= (unsigned)N) continue;  // out-of-range indices (e.g. -1 padding with another mask_value) are padding
     const double qj = (double)q[j];
-    const T fs[3] = {(T)ush[3 * e], (T)ush[3 * e + 1], (T)ush[3 * e + 2]};
+    const int S0 = ush[3 * e], S1 = ush[3 * e + 1], S2 = ush[3 * e + 2];
+    if (sym) { hf += ew_entry_hash((unsigned)i, (unsigned)j, S0, S1, S2); hr += ew_entry_hash((unsigned)j, (unsigned)i, -S0, -S1, -S2); }
+    const T fs[3] = {(T)S0, (T)S1, (T)S2};
     T sh[3];
     rowvec_mat3(fs, cm, sh);  // == transpose(cell) * S with the same summation order
     const T sx = (pos[3 * (size_t)j] - pix) + sh[0], sy = (pos[3 * (size_t)j + 1] - piy) + sh[1], sz = (pos[3 * (size_t)j + 2] - piz) + sh[2];
@@ -74,6 +95,74 @@ __global__ __launch_bounds__(256) void ewald_real_kernel(const T* __restrict__ p
     cgi = wave_sum(cgi);
     if (lane == 0) cgrad[i] = 2.0 * cgi;
   }
+  if (sym) ew_sym_flush(hf, hr, sym, lane);
+}
+
+// ---- fix-up for lists that are not symmetric: the reference's scatter (ewald_kernels.py:518-544, :864-873) ---------------------
+template <class T>
+__global__ void ewald_fixup_zero_kernel(const unsigned long long* __restrict__ sym, T* __restrict__ a3, T* __restrict__ a1, double* __restrict__ d1, int N) {
+  if (sym[0] == sym[1]) return;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  if (a3) { a3[3 * (size_t)i] = T(0); a3[3 * (size_t)i + 1] = T(0); a3[3 * (size_t)i + 2] = T(0); }
+  if (a1) a1[i] = T(0);
+  if (d1) d1[i] = 0.0;
+}
+template <class T, bool CSR>
+__global__ __launch_bounds__(256) void ewald_real_scatter_kernel(const T* __restrict__ pos, const T* __restrict__ q, const T* __restrict__ cell,
+                                                                 const T* __restrict__ alpha, const int* __restrict__ batch_idx, int N,
+                                                                 const int* __restrict__ idx, const int* __restrict__ ush, const int* __restrict__ nptr,
+                                                                 int M, int mask_value, int flags, T* __restrict__ forces, double* __restrict__ cgrad,
+                                                                 const unsigned long long* __restrict__ sym) {
+  if (sym[0] == sym[1]) return;  // symmetric list: the owner-only results of ewald_real_kernel stand
+  const int lane = threadIdx.x & (MI_WAVE - 1);
+  const int i = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x / MI_WAVE) + threadIdx.x / MI_WAVE);
+  if (i >= N) return;
+  const int s = batch_idx ? batch_idx[i] : 0;
+  const double qi = (double)q[i], al = (double)alpha[s];
+  T cm[9];
+  for (int k = 0; k < 9; ++k) cm[k] = cell[9 * (size_t)s + k];
+  const T pix = pos[3 * (size_t)i], piy = pos[3 * (size_t)i + 1], piz = pos[3 * (size_t)i + 2];
+  const bool wf = (flags & MI_EW_FORCES) != 0, wc = (flags & MI_EW_CHARGE_GRAD) != 0;
+  const double two_over_sqrt_pi = 2.0 / 1.7724538509055159;
+  long long beg, end;
+  if (CSR) { beg = nptr[i]; end = nptr[i + 1]; } else { beg = (long long)i * M; end = beg + M; }
+  double cgi = 0.0;
+  T fx = 0, fy = 0, fz = 0;
+  for (long long e = beg + lane; e < end; e += MI_WAVE) {
+    const int j = idx[e];
+    if ((!CSR && j == mask_value) || (unsigned)j >= (unsigned)N) continue;
+    const double qj = (double)q[j];
+    const T fs[3] = {(T)ush[3 * e], (T)ush[3 * e + 1], (T)ush[3 * e + 2]};
+    T sh[3];
+    rowvec_mat3(fs, cm, sh);
+    const T sx = (pos[3 * (size_t)j] - pix) + sh[0], sy = (pos[3 * (size_t)j + 1] - piy) + sh[1], sz = (pos[3 * (size_t)j + 2] - piz) + sh[2];
+    const double dist = (double)sqrt(sx * sx + sy * sy + sz * sz);
+    if (!(dist > 1e-8)) continue;
+    const double ar = al * dist;
+    const double ex = exp(-(ar * ar));
+    const double ec = erfc_as_poly(ar, ex);
+    if (wf) {
+      const double fm = (0.5 * qi * qj) * (ec / (dist * dist * dist) + two_over_sqrt_pi * al * ex / (dist * dist));
+      const T fmt = (T)fm;
+      const T gx = fmt * sx, gy = fmt * sy, gz = fmt * sz;
+      fx -= gx; fy -= gy; fz -= gz;
+      atomicAdd(&forces[3 * (size_t)j], gx); atomicAdd(&forces[3 * (size_t)j + 1], gy); atomicAdd(&forces[3 * (size_t)j + 2], gz);
+    }
+    if (wc) {
+      const double pot = 0.5 * ec / dist;
+      cgi += qj * pot;
+      atomicAdd(&cgrad[j], qi * pot);
+    }
+  }
+  if (wf) {
+    fx = wave_sum(fx); fy = wave_sum(fy); fz = wave_sum(fz);
+    if (lane == 0) { atomicAdd(&forces[3 * (size_t)i], fx); atomicAdd(&forces[3 * (size_t)i + 1], fy); atomicAdd(&forces[3 * (size_t)i + 2], fz); }
+  }
+  if (wc) {
+    cgi = wave_sum(cgi);
+    if (lane == 0) atomicAdd(&cgrad[i], cgi);
+  }
 }
 
 // adjoint for L = sum_i g_i E_i (see header): same walk, same skips, weights (g_i + g_j)
@@ -83,7 +172,7 @@ __global__ __launch_bounds__(256) void ewald_real_bwd_kernel(const T* __restrict
                                                              const int* __restrict__ idx, const int* __restrict__ ush,
                                                              const int* __restrict__ nptr, int M, int mask_value, const T* __restrict__ gE,
                                                              T* __restrict__ gpos, T* __restrict__ gq, double* __restrict__ gcell,
-                                                             double* __restrict__ galpha) {
+                                                             double* __restrict__ galpha, unsigned long long* __restrict__ sym) {
   const int lane = threadIdx.x & (MI_WAVE - 1);
   const int i = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x / MI_WAVE) + threadIdx.x / MI_WAVE);
   if (i >= N) return;
@@ -97,11 +186,13 @@ __global__ __launch_bounds__(256) void ewald_real_bwd_kernel(const T* __restrict
   if (CSR) { beg = nptr[i]; end = nptr[i + 1]; } else { beg = (long long)i * M; end = beg + M; }
   double gx = 0, gy = 0, gz = 0, gqi = 0, ga = 0;
   double gc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long hf = 0, hr = 0;
   for (long long e = beg + lane; e < end; e += MI_WAVE) {
     const int j = idx[e];
     if ((!CSR && j == mask_value) || (unsigned)j >= (unsigned)N) continue;  // out-of-range indices (e.g. -1 padding with another mask_value) are padding
     const double qj = (double)q[j], gj = (double)gE[j];
     const int S0 = ush[3 * e], S1 = ush[3 * e + 1], S2 = ush[3 * e + 2];
+    if (sym) { hf += ew_entry_hash((unsigned)i, (unsigned)j, S0, S1, S2); hr += ew_entry_hash((unsigned)j, (unsigned)i, -S0, -S1, -S2); }
     const T fs[3] = {(T)S0, (T)S1, (T)S2};
     T sh[3];
     rowvec_mat3(fs, cm, sh);
@@ -135,6 +226,56 @@ __global__ __launch_bounds__(256) void ewald_real_bwd_kernel(const T* __restrict
   if (gcell) {
 #pragma unroll
     for (int k = 0; k < 9; ++k) { const double v = wave_sum(gc[k]); if (lane == 0 && v != 0.0) atomicAdd(&gcell[9 * (size_t)s + k], v); }
+  }
+  if (sym) ew_sym_flush(hf, hr, sym, lane);
+}
+
+// general adjoint for lists that are not symmetric: entry (i -> j) belongs to E_i only, so it carries weight g_i to BOTH ends
+// (d/dr_i = +g_i fm sep, d/dr_j = -g_i fm sep; d/dq_i = g_i q_j pot, d/dq_j = g_i q_i pot); alpha / cell terms are per-owner already.
+template <class T, bool CSR>
+__global__ __launch_bounds__(256) void ewald_real_bwd_scatter_kernel(const T* __restrict__ pos, const T* __restrict__ q, const T* __restrict__ cell,
+                                                                     const T* __restrict__ alpha, const int* __restrict__ batch_idx, int N,
+                                                                     const int* __restrict__ idx, const int* __restrict__ ush,
+                                                                     const int* __restrict__ nptr, int M, int mask_value, const T* __restrict__ gE,
+                                                                     T* __restrict__ gpos, T* __restrict__ gq, const unsigned long long* __restrict__ sym) {
+  if (sym[0] == sym[1]) return;
+  const int lane = threadIdx.x & (MI_WAVE - 1);
+  const int i = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x / MI_WAVE) + threadIdx.x / MI_WAVE);
+  if (i >= N) return;
+  const int s = batch_idx ? batch_idx[i] : 0;
+  const double qi = (double)q[i], al = (double)alpha[s], gi = (double)gE[i];
+  T cm[9];
+  for (int k = 0; k < 9; ++k) cm[k] = cell[9 * (size_t)s + k];
+  const T pix = pos[3 * (size_t)i], piy = pos[3 * (size_t)i + 1], piz = pos[3 * (size_t)i + 2];
+  const double two_over_sqrt_pi = 2.0 / 1.7724538509055159;
+  long long beg, end;
+  if (CSR) { beg = nptr[i]; end = nptr[i + 1]; } else { beg = (long long)i * M; end = beg + M; }
+  double gx = 0, gy = 0, gz = 0, gqi = 0;
+  for (long long e = beg + lane; e < end; e += MI_WAVE) {
+    const int j = idx[e];
+    if ((!CSR && j == mask_value) || (unsigned)j >= (unsigned)N) continue;
+    const double qj = (double)q[j];
+    const T fs[3] = {(T)ush[3 * e], (T)ush[3 * e + 1], (T)ush[3 * e + 2]};
+    T sh[3];
+    rowvec_mat3(fs, cm, sh);
+    const T sx = (pos[3 * (size_t)j] - pix) + sh[0], sy = (pos[3 * (size_t)j + 1] - piy) + sh[1], sz = (pos[3 * (size_t)j + 2] - piz) + sh[2];
+    const double dist = (double)sqrt(sx * sx + sy * sy + sz * sz);
+    if (!(dist > 1e-8)) continue;
+    const double ar = al * dist;
+    const double ex = exp(-(ar * ar));
+    const double ec = erfc_as_poly(ar, ex);
+    const double fm = (0.5 * qi * qj) * (ec / (dist * dist * dist) + two_over_sqrt_pi * al * ex / (dist * dist));
+    const double wx = gi * fm * (double)sx, wy = gi * fm * (double)sy, wz = gi * fm * (double)sz;
+    gx += wx; gy += wy; gz += wz;
+    atomicAdd(&gpos[3 * (size_t)j], (T)(-wx)); atomicAdd(&gpos[3 * (size_t)j + 1], (T)(-wy)); atomicAdd(&gpos[3 * (size_t)j + 2], (T)(-wz));
+    const double pot = 0.5 * ec / dist;
+    gqi += gi * qj * pot;
+    atomicAdd(&gq[j], (T)(gi * qi * pot));
+  }
+  gx = wave_sum(gx); gy = wave_sum(gy); gz = wave_sum(gz); gqi = wave_sum(gqi);
+  if (lane == 0) {
+    atomicAdd(&gpos[3 * (size_t)i], (T)gx); atomicAdd(&gpos[3 * (size_t)i + 1], (T)gy); atomicAdd(&gpos[3 * (size_t)i + 2], (T)gz);
+    atomicAdd(&gq[i], (T)gqi);
   }
 }
 
@@ -338,7 +479,7 @@ __global__ __launch_bounds__(256) void coulomb_bwd_kernel(const double* __restri
 extern "C" int mi_ewald_real_bwd(const void* positions, const void* charges, const void* cell, const void* alpha, const int32_t* batch_idx,
                                  int n_atoms, int dtype, const int32_t* idx_j, const int32_t* unit_shifts, const int32_t* neighbor_ptr,
                                  int max_neighbors, int mask_value, const void* grad_energies, void* grad_positions, void* grad_charges,
-                                 double* grad_cell, double* grad_alpha, void* stream) {
+                                 double* grad_cell, double* grad_alpha, void* symmetry_scratch, void* stream) {
   MI_REQUIRE(dtype == MI_F32 || dtype == MI_F64, "dtype");
   if (n_atoms <= 0) return MI_OK;
   MI_REQUIRE(positions && charges && cell && alpha && idx_j && unit_shifts && grad_energies && grad_positions && grad_charges, "null pointer");
@@ -348,17 +489,33 @@ extern "C" int mi_ewald_real_bwd(const void* positions, const void* charges, con
 #define MI_EWB(T_, CSR_)                                                                                                                       \
   ewald_real_bwd_kernel<T_, CSR_><<<blocks, 256, 0, st>>>((const T_*)positions, (const T_*)charges, (const T_*)cell, (const T_*)alpha, batch_idx, \
                                                           n_atoms, idx_j, unit_shifts, neighbor_ptr, max_neighbors, mask_value,                  \
-                                                          (const T_*)grad_energies, (T_*)grad_positions, (T_*)grad_charges, grad_cell, grad_alpha)
+                                                          (const T_*)grad_energies, (T_*)grad_positions, (T_*)grad_charges, grad_cell, grad_alpha, sym)
+#define MI_EWBS(T_, CSR_)                                                                                                                          \
+  do {                                                                                                                                             \
+    ewald_fixup_zero_kernel<T_><<<mi_blocks(n_atoms, 256), 256, 0, st>>>(sym, (T_*)grad_positions, (T_*)grad_charges, nullptr, n_atoms);          \
+    ewald_real_bwd_scatter_kernel<T_, CSR_><<<blocks, 256, 0, st>>>((const T_*)positions, (const T_*)charges, (const T_*)cell, (const T_*)alpha,    \
+                                                                    batch_idx, n_atoms, idx_j, unit_shifts, neighbor_ptr, max_neighbors, mask_value, \
+                                                                    (const T_*)grad_energies, (T_*)grad_positions, (T_*)grad_charges, sym);        \
+  } while (0)
+  unsigned long long* sym = (unsigned long long*)symmetry_scratch;
+  if (sym) MI_HIP_CHECK(hipMemsetAsync(sym, 0, 16, st));
   if (dtype == MI_F32) { if (csr) MI_EWB(float, true); else MI_EWB(float, false); }
   else { if (csr) MI_EWB(double, true); else MI_EWB(double, false); }
-#undef MI_EWB
   MI_LAUNCH_CHECK();
+  if (sym) {
+    if (dtype == MI_F32) { if (csr) MI_EWBS(float, true); else MI_EWBS(float, false); }
+    else { if (csr) MI_EWBS(double, true); else MI_EWBS(double, false); }
+    MI_LAUNCH_CHECK();
+  }
+#undef MI_EWB
+#undef MI_EWBS
   return MI_OK;
 }
 
 extern "C" int mi_ewald_real(const void* positions, const void* charges, const void* cell, const void* alpha, const int32_t* batch_idx,
                              int n_atoms, int dtype, const int32_t* idx_j, const int32_t* unit_shifts, const int32_t* neighbor_ptr,
-                             int max_neighbors, int mask_value, int flags, double* energies, void* forces, double* charge_grads, void* stream) {
+                             int max_neighbors, int mask_value, int flags, double* energies, void* forces, double* charge_grads,
+                             void* symmetry_scratch, void* stream) {
   MI_REQUIRE(dtype == MI_F32 || dtype == MI_F64, "dtype");
   if (n_atoms <= 0) return MI_OK;
   MI_REQUIRE(positions && charges && cell && alpha && idx_j && unit_shifts && energies, "null pointer");
@@ -370,13 +527,29 @@ extern "C" int mi_ewald_real(const void* positions, const void* charges, const v
 #define MI_EW(T_, CSR_)                                                                                                                     \
   ewald_real_kernel<T_, CSR_><<<blocks, 256, 0, st>>>((const T_*)positions, (const T_*)charges, (const T_*)cell, (const T_*)alpha, batch_idx, \
                                                       n_atoms, idx_j, unit_shifts, neighbor_ptr, max_neighbors, mask_value, flags, energies, \
-                                                      (T_*)forces, charge_grads)
+                                                      (T_*)forces, charge_grads, sym)
+#define MI_EWS(T_, CSR_)                                                                                                                         \
+  do {                                                                                                                                           \
+    ewald_fixup_zero_kernel<T_><<<mi_blocks(n_atoms, 256), 256, 0, st>>>(sym, (T_*)forces, nullptr, charge_grads, n_atoms);                      \
+    ewald_real_scatter_kernel<T_, CSR_><<<blocks, 256, 0, st>>>((const T_*)positions, (const T_*)charges, (const T_*)cell, (const T_*)alpha,      \
+                                                                batch_idx, n_atoms, idx_j, unit_shifts, neighbor_ptr, max_neighbors, mask_value,  \
+                                                                flags, (T_*)forces, charge_grads, sym);                                           \
+  } while (0)
+  // the symmetry check only matters for outputs that are scattered in the reference (forces, charge gradients); energies are per owner
+  unsigned long long* sym = (flags & (MI_EW_FORCES | MI_EW_CHARGE_GRAD)) ? (unsigned long long*)symmetry_scratch : nullptr;
+  if (sym) MI_HIP_CHECK(hipMemsetAsync(sym, 0, 16, st));
   mi_timing_begin("ewald_real", stream);
   if (dtype == MI_F32) { if (csr) MI_EW(float, true); else MI_EW(float, false); }
   else { if (csr) MI_EW(double, true); else MI_EW(double, false); }
   mi_timing_end(stream);
-#undef MI_EW
   MI_LAUNCH_CHECK();
+  if (sym) {
+    if (dtype == MI_F32) { if (csr) MI_EWS(float, true); else MI_EWS(float, false); }
+    else { if (csr) MI_EWS(double, true); else MI_EWS(double, false); }
+    MI_LAUNCH_CHECK();
+  }
+#undef MI_EW
+#undef MI_EWS
   return MI_OK;
 }
 

@@ -68,6 +68,9 @@ class D3Parameters:
                             interp_mesh=self.interp_mesh)
 
 
+_LIB_OVERRIDE = None  # tests only: a ctypes handle of the IEEE-arithmetic build of d3.hip (error budget, tests/test_d3_gpu.py)
+
+
 def _launch(positions, numbers, idx, shifts, nptr, max_neighbors, fill_value, cell, batch_idx, num_systems, tables, scalars,
             compute_virial, energy, forces, coord_num, virial) -> None:
     dev = positions.device
@@ -89,15 +92,18 @@ def _launch(positions, numbers, idx, shifts, nptr, max_neighbors, fill_value, ce
     # there (unaligned rows make the CN pass's extra write cost what the other two passes gain), so it is not the default
     mode = os.environ.get("NVALCHEMIOPS_D3_PACKED_LIST", "1")
     pack = periodic and mode != "0" and (nptr is None or mode == "2")
-    if nptr is not None:  # CSR: the number of stored entries is the length of idx_j; it travels in the otherwise unused `max_neighbors`
-        max_neighbors = idx.shape[0] if (pack and idx.shape[0] < 2**31) else 0
     n_entries = (idx.shape[0] if nptr is not None else n * int(max_neighbors)) if pack else 0
+    L = _LIB_OVERRIDE or C.lib()
     ws_bytes = int(C.lib().mi_d3_workspace_bytes_entries(n, num_systems, rcov.shape[0], int(n_entries)))
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
     vir = virial if compute_virial else None
-    rc = C.lib().mi_d3(C.ptr(pos), C.ptr(C.i32(numbers)), n, code, C.ptr(idx), C.ptr(sh), C.ptr(nptr), int(max_neighbors), int(fill_value),
-                       C.ptr(cell_t), C.ptr(bi), int(num_systems), ctypes.byref(par), int(bool(compute_virial)), C.ptr(energy), C.ptr(forces),
-                       C.ptr(coord_num), C.ptr(vir), C.ptr(ws), ctypes.c_size_t(ws_bytes), C.stream_of(pos))
+    z = C.i32(numbers)  # converted tensors stay referenced until the launch is enqueued (the allocator may otherwise reuse their blocks)
+    rc = L.mi_d3(C.ptr(pos), C.ptr(z), n, code, C.ptr(idx), C.ptr(sh), C.ptr(nptr), int(max_neighbors),
+                 ctypes.c_longlong(idx.shape[0] if (nptr is not None and pack) else 0), int(fill_value),
+                 C.ptr(cell_t), C.ptr(bi), int(num_systems), ctypes.byref(par), int(bool(compute_virial)), C.ptr(energy), C.ptr(forces),
+                 C.ptr(coord_num), C.ptr(vir), C.ptr(ws), ctypes.c_size_t(ws_bytes), C.stream_of(pos))
+    if rc != 0 and _LIB_OVERRIDE is not None:
+        raise C.NativeLibraryError(f"mi_d3 (override library) failed with code {rc}")
     C.check(rc, "mi_d3")
 
 

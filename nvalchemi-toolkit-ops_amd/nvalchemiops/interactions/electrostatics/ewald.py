@@ -2,7 +2,9 @@
 `alchemiops::_[batch_]ewald_real_space_*` ops behind it (:263-1365).
 
 One HIP kernel family (csrc/ewald.hip, `mi_ewald_real`) covers matrix / CSR x single / batch x energy / +forces /
-+charge gradients.  The neighbour list must be FULL (symmetric), as the reference's 1/2 prefactor assumes.
++charge gradients.  Physically meaningful inputs are FULL (symmetric) lists -- the reference's 1/2 prefactor assumes one -- and those
+take an owner-only fast path; any other list (half, truncated, one-sided) is detected on the device in the same pass and gets the
+reference's i/j scatter (`ewald_kernels.py:518-544`), so results match the reference for every input.
 
 The explicit-k reciprocal half (`ewald_reciprocal_space` :2631, `ewald_summation` :2798) runs on two HIP
 kernels (`mi_ewald_structure_factors`, `mi_ewald_recip_gather`) that recompute the k.r phases in registers instead of the
@@ -22,14 +24,16 @@ class _EwaldRealEnergyFn(torch.autograd.Function):
     alpha -- the reference differentiates these ops through a recorded Warp tape (autograd.py:525-665)."""
 
     @staticmethod
-    def forward(ctx, positions, charges, cells, alpha, idx, sh, nptr, m, mask_value, bi):
+    def forward(ctx, positions, charges, cells, alpha, idx, sh, nptr, m, mask_value, bi, precomputed):
         pos, q = positions.detach().contiguous(), charges.detach().contiguous()
         c, al = cells.detach().contiguous(), alpha.detach().contiguous()
         n = pos.shape[0]
-        energies = torch.empty(n, dtype=torch.float64, device=pos.device)
-        rc = C.lib().mi_ewald_real(C.ptr(pos), C.ptr(q), C.ptr(c), C.ptr(al), C.ptr(bi), n, C.dtype_code(pos.dtype), C.ptr(idx), C.ptr(sh),
-                                   C.ptr(nptr), int(m), int(mask_value), 0, C.ptr(energies), None, None, C.stream_of(pos))
-        C.check(rc, "mi_ewald_real")
+        energies = precomputed  # float64 energies of the launch that also produced explicit forces / charge gradients, if there was one
+        if energies is None:
+            energies = torch.empty(n, dtype=torch.float64, device=pos.device)
+            rc = C.lib().mi_ewald_real(C.ptr(pos), C.ptr(q), C.ptr(c), C.ptr(al), C.ptr(bi), n, C.dtype_code(pos.dtype), C.ptr(idx), C.ptr(sh),
+                                       C.ptr(nptr), int(m), int(mask_value), 0, C.ptr(energies), None, None, None, C.stream_of(pos))
+            C.check(rc, "mi_ewald_real")
         empty = torch.empty(0, device=pos.device)
         ctx.save_for_backward(pos, q, c, al, idx, sh, nptr if nptr is not None else empty, bi if bi is not None else empty)
         ctx.meta = (m, mask_value, nptr is not None, bi is not None)
@@ -46,12 +50,13 @@ class _EwaldRealEnergyFn(torch.autograd.Function):
         need = ctx.needs_input_grad
         gcell = torch.zeros(c.shape, dtype=torch.float64, device=dev) if need[2] else None
         galpha = torch.zeros(al.shape, dtype=torch.float64, device=dev) if need[3] else None
+        sym = torch.empty(2, dtype=torch.int64, device=dev)  # list-symmetry checksums (zeroed by the library)
         rc = C.lib().mi_ewald_real_bwd(C.ptr(pos), C.ptr(q), C.ptr(c), C.ptr(al), C.ptr(bi_t if has_bi else None), n, C.dtype_code(dt),
                                        C.ptr(idx), C.ptr(sh), C.ptr(nptr_t if has_ptr else None), int(m), int(mask_value), C.ptr(g),
-                                       C.ptr(gpos), C.ptr(gq), C.ptr(gcell), C.ptr(galpha), C.stream_of(pos))
+                                       C.ptr(gpos), C.ptr(gq), C.ptr(gcell), C.ptr(galpha), C.ptr(sym), C.stream_of(pos))
         C.check(rc, "mi_ewald_real_bwd")
         return (gpos if need[0] else None, gq if need[1] else None, None if gcell is None else gcell.to(dt),
-                None if galpha is None else galpha.to(dt), None, None, None, None, None, None)
+                None if galpha is None else galpha.to(dt), None, None, None, None, None, None, None)
 
 
 @C.eager
@@ -62,7 +67,9 @@ def ewald_real_space(positions: torch.Tensor, charges: torch.Tensor, cell: torch
                      compute_forces: bool = False, compute_charge_gradients: bool = False):
     """E_i = 1/2 sum_j q_i q_j erfc(alpha r_ij)/r_ij over the listed neighbours (per-atom energies, input dtype).
 
-    Returns ``energies`` | ``(energies, forces)`` | ``(energies, charge_grads)`` | ``(energies, forces, charge_grads)``."""
+    Every stored entry (i, j, S) contributes to E_i, -f to F_i and +f to F_j, and to both charge gradients, exactly as in the
+    reference (ewald_kernels.py:518-544, :864-873); pass a FULL (symmetric) list for physically meaningful totals -- that case runs
+    without atomics.  Returns ``energies`` | ``(energies, forces)`` | ``(energies, charge_grads)`` | ``(energies, forces, charge_grads)``."""
     if neighbor_list is None and neighbor_matrix is None:
         raise ValueError("Either neighbor_list or neighbor_matrix must be provided")
     if neighbor_list is not None and neighbor_ptr is None:
@@ -76,7 +83,7 @@ def ewald_real_space(positions: torch.Tensor, charges: torch.Tensor, cell: torch
         if compute_charge_gradients:
             out += (torch.zeros(0, dtype=dt, device=dev),)
         return out if len(out) > 1 else out[0]
-    C.require_device(positions, charges, cell, neighbor_list, neighbor_ptr, neighbor_matrix, batch_idx)
+    C.require_device(positions, charges, cell, neighbor_list, neighbor_ptr, neighbor_shifts, neighbor_matrix, neighbor_matrix_shifts, batch_idx)
     alpha_in = alpha if isinstance(alpha, torch.Tensor) else torch.tensor([float(alpha)], device=dev)
     alpha_in = alpha_in.to(device=dev, dtype=dt).reshape(-1)
     if alpha_in.numel() == 1 and cell.reshape(-1, 3, 3).shape[0] > 1:
@@ -105,13 +112,16 @@ def ewald_real_space(positions: torch.Tensor, charges: torch.Tensor, cell: torch
         cgrads = None if cgrads is None else cgrads.zero_()
     else:
         flags = (C.EW_FORCES if compute_forces else 0) | (C.EW_CHARGE_GRAD if compute_charge_gradients else 0)
-        rc = C.lib().mi_ewald_real(C.ptr(pos), C.ptr(q), C.ptr(cells), C.ptr(alpha_t), C.ptr(bi), n, code, C.ptr(idx), C.ptr(sh), C.ptr(nptr),
-                                   int(m), int(mask_value), flags, C.ptr(energies), C.ptr(forces), C.ptr(cgrads), C.stream_of(pos))
-        C.check(rc, "mi_ewald_real")
-    e_out = energies.to(dt)  # ewald.py:577: energies are accumulated in float64 and returned in the input dtype
+        if flags or not wants_grad:  # with autograd and no explicit outputs the differentiable op below is the only launch needed
+            sym = torch.empty(2, dtype=torch.int64, device=dev) if flags else None  # list-symmetry checksums (zeroed by the library)
+            rc = C.lib().mi_ewald_real(C.ptr(pos), C.ptr(q), C.ptr(cells), C.ptr(alpha_t), C.ptr(bi), n, code, C.ptr(idx), C.ptr(sh), C.ptr(nptr),
+                                       int(m), int(mask_value), flags, C.ptr(energies), C.ptr(forces), C.ptr(cgrads), C.ptr(sym), C.stream_of(pos))
+            C.check(rc, "mi_ewald_real")
+    e_out = energies.to(dt) if not (wants_grad and n_entries > 0) else None  # ewald.py:577: float64 accumulation, input dtype out
     if wants_grad and n_entries > 0:
         # differentiable energies (explicit forces / charge gradients above stay plain outputs, as MD codes consume them)
-        e_out = _EwaldRealEnergyFn.apply(positions, charges.to(dt), cell.to(dt).reshape(-1, 3, 3), alpha_in, idx, sh, nptr, m, mask_value, bi)
+        e_out = _EwaldRealEnergyFn.apply(positions, charges.to(dt), cell.to(dt).reshape(-1, 3, 3), alpha_in, idx, sh, nptr, m, mask_value, bi,
+                                         energies if flags else None)
     out = (e_out,)
     if compute_forces:
         out += (forces,)

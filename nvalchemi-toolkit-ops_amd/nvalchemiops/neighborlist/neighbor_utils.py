@@ -55,11 +55,16 @@ def get_neighbor_list_from_neighbor_matrix(neighbor_matrix: torch.Tensor, num_ne
     nm = C.i32(neighbor_matrix)
     nptr = torch.zeros(n + 1, dtype=torch.int32, device=dev)
     torch.cumsum(num_neighbors, dim=0, out=nptr[1:])
-    total = int(nptr[-1].item())
+    # The list holds the entries != fill_value (the reference's boolean mask, :428-438) while neighbor_ptr is the cumsum of
+    # `num_neighbors`; the two differ when the matrix was padded with another value than `fill_value` (e.g. the default -1 on a
+    # matrix padded with N).  Rows are therefore placed by the mask's own counts, and both outputs are what the reference returns.
+    place = torch.zeros(n + 1, dtype=torch.int32, device=dev)
+    torch.cumsum((nm != int(fill_value)).sum(dim=1, dtype=torch.int32), dim=0, out=place[1:])
+    total = int(place[-1].item())
     lst = torch.empty((2, total), dtype=torch.int32, device=dev)
     sh_in = None if neighbor_shift_matrix is None else C.i32(neighbor_shift_matrix)
     sh = None if sh_in is None else torch.empty((total, 3), dtype=torch.int32, device=dev)
-    rc = C.lib().mi_nl_matrix_to_coo(C.ptr(nm), C.ptr(sh_in), C.ptr(nptr), n, nm.shape[1], int(fill_value), C.ptr(lst), C.ptr(sh),
+    rc = C.lib().mi_nl_matrix_to_coo(C.ptr(nm), C.ptr(sh_in), C.ptr(place), n, nm.shape[1], int(fill_value), C.ptr(lst), C.ptr(sh),
                                      ctypes.c_longlong(total), C.stream_of(nm))
     C.check(rc, "mi_nl_matrix_to_coo")
     lst = lst.to(neighbor_matrix.dtype)

@@ -23,8 +23,9 @@ def cell_list_needs_rebuild(current_positions: torch.Tensor, atom_to_cell_mappin
     C.require_device(current_positions, atom_to_cell_mapping, cells_per_dimension, cell, pbc)
     pos = E.canon_positions(current_positions)
     c = cell.detach().to(pos.dtype).reshape(-1, 3, 3)[0].contiguous()
-    rc = C.lib().mi_nl_cells_changed(C.ptr(pos), C.ptr(c), C.ptr(C.i32(atom_to_cell_mapping)), C.ptr(C.i32(cells_per_dimension.reshape(-1))),
-                                     C.ptr(pbc.reshape(-1).to(torch.bool).contiguous()), n, C.dtype_code(pos.dtype), C.ptr(flag),
+    # converted tensors are bound to names so they outlive the enqueue (a freed temporary's block could be handed out again)
+    amap, cpd, pb = C.i32(atom_to_cell_mapping), C.i32(cells_per_dimension.reshape(-1)), pbc.reshape(-1).to(torch.bool).contiguous()
+    rc = C.lib().mi_nl_cells_changed(C.ptr(pos), C.ptr(c), C.ptr(amap), C.ptr(cpd), C.ptr(pb), n, C.dtype_code(pos.dtype), C.ptr(flag),
                                      C.stream_of(pos))
     C.check(rc, "mi_nl_cells_changed")
     return flag

@@ -128,9 +128,15 @@ def _wants_grad(*tensors) -> bool:
     return torch.is_grad_enabled() and any(t is not None and isinstance(t, torch.Tensor) and t.requires_grad for t in tensors)
 
 
-def _differentiable_cit(cell: torch.Tensor, cell_inv_t, dtype):
+def _differentiable_cit(cell: torch.Tensor, cell_inv_t, dtype, bi=None):
     c = (cell if cell.dim() == 3 else cell.unsqueeze(0)).to(dtype)
-    return (torch.linalg.inv(c).transpose(-1, -2) if cell_inv_t is None else cell_inv_t.to(dtype).reshape(-1, 3, 3)), c
+    cit = torch.linalg.inv(c).transpose(-1, -2) if cell_inv_t is None else cell_inv_t.to(dtype).reshape(-1, 3, 3)
+    if bi is not None and bi.numel() and cit.shape[0] == 1:
+        # one cell for the whole batch (spline.py:2256, :2775): the kernels index cell_inv_t and the mesh by batch_idx, so the
+        # differentiable path needs the same expansion `_prep` does (gradients sum back into the single cell through expand)
+        nsys = int(bi.max().item()) + 1
+        c, cit = c.expand(nsys, 3, 3), cit.expand(nsys, 3, 3)
+    return cit, c
 
 
 @C.eager
@@ -140,8 +146,8 @@ def spline_spread(positions: torch.Tensor, values: torch.Tensor, cell: torch.Ten
     Differentiable w.r.t. positions, values and cell (hand-written adjoint kernels)."""
     C.require_device(positions, values, cell)
     if _wants_grad(positions, values, cell, cell_inv_t):
-        cit, c = _differentiable_cit(cell, cell_inv_t, positions.dtype)
         bi = None if batch_idx is None else C.i32(batch_idx)
+        cit, c = _differentiable_cit(cell, cell_inv_t, positions.dtype, bi)
         nsys = c.shape[0] if bi is not None else 1
         mesh = _SpreadFn.apply(positions, values.to(positions.dtype), cit, bi, nsys, tuple(int(v) for v in mesh_dims), int(spline_order),
                                bi is not None)
@@ -161,8 +167,8 @@ def spline_gather(positions: torch.Tensor, mesh: torch.Tensor, cell: torch.Tenso
     Differentiable w.r.t. positions, mesh and cell."""
     C.require_device(positions, mesh, cell)
     if _wants_grad(positions, mesh, cell, cell_inv_t):
-        cit, _ = _differentiable_cit(cell, cell_inv_t, positions.dtype)
         bi = None if batch_idx is None else C.i32(batch_idx)
+        cit, _ = _differentiable_cit(cell, cell_inv_t, positions.dtype, bi)
         return _GatherFn.apply(positions, mesh.to(positions.dtype), cit, bi, int(spline_order))
     pos, c, cit, bi = _prep(positions, cell, batch_idx, cell_inv_t)
     m = mesh.detach().to(pos.dtype).contiguous()

@@ -26,6 +26,20 @@
 #include <cstring>
 #include <vector>
 
+// OpenMP build (libnvalchemi_oracle_omp.so, -fopenmp): the same loops with the outer atom loop shared between threads and every
+// cross-row update (the reference's atomic_add) as an `omp atomic` -- used ONLY for the all-core leg of bench.py's cpu_baseline.
+// The serial library (no -fopenmp: the pragmas vanish) stays the parity oracle; a CPU test checks both agree.
+#ifdef _OPENMP
+#include <omp.h>
+#define ORC_PARALLEL_FOR _Pragma("omp parallel for schedule(dynamic, 32)")
+#define ORC_ATOMIC _Pragma("omp atomic")
+#define ORC_CAPTURE _Pragma("omp atomic capture")
+#else
+#define ORC_PARALLEL_FOR
+#define ORC_ATOMIC
+#define ORC_CAPTURE
+#endif
+
 namespace {
 
 template <class T> struct Vec3 { T v[3]; };
@@ -194,15 +208,20 @@ int cell_list_reference(const T* pos, int N, const T* cell, const uint8_t* pbc, 
       T d2 = dr[0] * dr[0] + dr[1] * dr[1] + dr[2] * dr[2];
       if (d2 < rc2) {
         // _update_neighbor_matrix_pbc (neighbor_utils.py:106-147)
-        int p = num[i]++;
+        int p;
+        ORC_CAPTURE
+        p = num[i]++;
         if (p < M) { nm[(size_t)i * M + p] = j; for (int d = 0; d < 3; ++d) nsh[((size_t)i * M + p) * 3 + d] = S[d]; }
         if (!half_fill) {
-          int q = num[j]++;
+          int q;
+          ORC_CAPTURE
+          q = num[j]++;
           if (q < M) { nm[(size_t)j * M + q] = i; for (int d = 0; d < 3; ++d) nsh[((size_t)j * M + q) * 3 + d] = -S[d]; }
         }
       }
     }
   };
+  ORC_PARALLEL_FOR
   for (int i = 0; i < N; ++i) {
     int s = batch ? batch_idx[i] : 0;
     const int* R = &rad[3 * s];
@@ -270,6 +289,12 @@ void naive_reference(const T* pos, int N, const T* cell /*null => no pbc*/, cons
 // ---------------------------------------------------------------------------------------
 // DFT-D3(BJ)   (dftd3.py:341-1615; pass sequencing :1911-2122 / :2306-2465)
 // ---------------------------------------------------------------------------------------
+// WIDE-SUM MODE (off by default; orc_set_d3_wide_sums): the same fp32 pair arithmetic, but every accumulation the reference does in
+// fp32 (CN, dE/dCN per atom; energy and virial per system, which it adds with fp32 atomics in arbitrary atom order) is carried in
+// double and rounded once.  Not the reference's result -- the reference's result MINUS its own summation-order noise; the D3 error
+// budget measures the HIP kernels against this and reports the reference-order noise next to it.
+static int g_d3_wide = 0;
+
 struct D3Par {
   const float* rcov; const float* r4r2; const float* c6ab; const float* cnref; int nz;  // nz = maxZ+1
   float k1, k3, a1, a2, s6, s8, s5_on, s5_off, inv_w;
@@ -345,6 +370,7 @@ void dftd3_reference(const T* pos, const int* numbers, int N, const int* jidx, c
   std::memset(cn, 0, sizeof(float) * (size_t)N);
   if (compute_virial) std::memset(virial, 0, sizeof(float) * 9 * B);
   std::vector<float> dEdCN(N, 0.0f);
+  std::vector<double> wide(10 * (size_t)B, 0.0);
   auto range = [&](int i, size_t& b, size_t& e) {
     if (ptr) { b = ptr[i]; e = ptr[i + 1]; } else { b = (size_t)i * M; e = b + M; }
   };
@@ -356,25 +382,29 @@ void dftd3_reference(const T* pos, const int* numbers, int N, const int* jidx, c
     rowvec_mat(fs, C, out);
   };
   // pass 1: coordination numbers
+  ORC_PARALLEL_FOR
   for (int i = 0; i < N; ++i) {
     if (numbers[i] == 0) continue;
-    float acc = 0.0f, rci = P.rcov[numbers[i]];
+    double acc = 0.0;
+    float rci = P.rcov[numbers[i]];
     size_t b, e; range(i, b, e);
     for (size_t k = b; k < e; ++k) {
       int j; if (!valid(k, j)) continue;
       T cs[3]; cartshift(i, k, cs);
       float r, rinv, rij[3];
       if (!d3_geom(pos + 3 * (size_t)i, pos + 3 * (size_t)j, cs, periodic, r, rinv, rij)) continue;
-      acc += cn_count(rinv, rci, P.rcov[numbers[j]], P.k1, nullptr);
+      const float f = cn_count(rinv, rci, P.rcov[numbers[j]], P.k1, nullptr);
+      acc = g_d3_wide ? acc + double(f) : double(float(acc) + f);  // reference: sequential fp32 (dftd3.py:911)
     }
-    cn[i] = acc;
+    cn[i] = float(acc);
   }
   // pass 2: energy, direct force, dE/dCN
+  ORC_PARALLEL_FOR
   for (int i = 0; i < N; ++i) {
     if (numbers[i] == 0) continue;
     int zi = numbers[i];
     double F[3] = {0, 0, 0}, E = 0, V[9] = {0};
-    float dacc = 0.0f;
+    double dacc = 0.0;
     size_t b, e; range(i, b, e);
     for (size_t k = b; k < e; ++k) {
       int j; if (!valid(k, j)) continue;
@@ -406,16 +436,31 @@ void dftd3_reference(const T* pos, const int* numbers, int N, const int* jidx, c
       float Fd[3] = {dEsw * rhat[0], dEsw * rhat[1], dEsw * rhat[2]};
       for (int d = 0; d < 3; ++d) F[d] += double(Fd[d]);
       E += double(esw);
-      dacc += -damp * dci;
+      const float dterm = -damp * dci;
+      dacc = g_d3_wide ? dacc + double(dterm) : double(float(dacc) + dterm);
       if (compute_virial) for (int a = 0; a < 3; ++a) for (int c = 0; c < 3; ++c) V[3 * a + c] += double(Fd[a] * rij[c]);
     }
     for (int d = 0; d < 3; ++d) forces[3 * (size_t)i + d] = float(F[d]);
-    dEdCN[i] = dacc;
+    dEdCN[i] = float(dacc);
     int s = batch_idx ? batch_idx[i] : 0;
-    energy[s] += 0.5f * float(E);
-    if (compute_virial) for (int a = 0; a < 9; ++a) virial[9 * s + a] += -0.5f * float(V[a]);
+    if (g_d3_wide) {
+      ORC_ATOMIC
+      wide[10 * (size_t)s] += 0.5 * E;
+      if (compute_virial) for (int a = 0; a < 9; ++a) {
+        ORC_ATOMIC
+        wide[10 * (size_t)s + 1 + a] += -0.5 * V[a];
+      }
+    } else {
+      ORC_ATOMIC
+      energy[s] += 0.5f * float(E);
+      if (compute_virial) for (int a = 0; a < 9; ++a) {
+        ORC_ATOMIC
+        virial[9 * s + a] += -0.5f * float(V[a]);
+      }
+    }
   }
   // pass 3: chain-rule force through CN
+  ORC_PARALLEL_FOR
   for (int i = 0; i < N; ++i) {
     if (numbers[i] == 0) continue;
     double F[3] = {0, 0, 0}, V[9] = {0};
@@ -434,8 +479,24 @@ void dftd3_reference(const T* pos, const int* numbers, int N, const int* jidx, c
       if (compute_virial) for (int a = 0; a < 3; ++a) for (int c = 0; c < 3; ++c) V[3 * a + c] += double(Fc[a] * rij[c]);
     }
     for (int d = 0; d < 3; ++d) forces[3 * (size_t)i + d] = forces[3 * (size_t)i + d] + float(F[d]);
-    if (compute_virial) { int s = batch_idx ? batch_idx[i] : 0; for (int a = 0; a < 9; ++a) virial[9 * s + a] += -0.5f * float(V[a]); }
+    if (compute_virial) {
+      int s = batch_idx ? batch_idx[i] : 0;
+      for (int a = 0; a < 9; ++a) {
+        if (g_d3_wide) {
+          ORC_ATOMIC
+          wide[10 * (size_t)s + 1 + a] += -0.5 * V[a];
+        } else {
+          ORC_ATOMIC
+          virial[9 * s + a] += -0.5f * float(V[a]);
+        }
+      }
+    }
   }
+  if (g_d3_wide)
+    for (int s = 0; s < B; ++s) {
+      energy[s] = float(wide[10 * (size_t)s]);
+      if (compute_virial) for (int a = 0; a < 9; ++a) virial[9 * s + a] = float(wide[10 * (size_t)s + 1 + a]);
+    }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -461,6 +522,7 @@ void ewald_real_reference(const T* pos, const T* q, const T* cell, const T* alph
   if (want_forces) std::memset(forces, 0, sizeof(T) * 3 * (size_t)N);
   if (want_cg) std::memset(cgrad, 0, sizeof(double) * (size_t)N);
   const double two_over_sqrt_pi = 2.0 / 1.7724538509055159;
+  ORC_PARALLEL_FOR
   for (int i = 0; i < N; ++i) {
     int s = batch_idx ? batch_idx[i] : 0;
     double qi = double(q[i]), al = double(alpha[s]);
@@ -486,25 +548,55 @@ void ewald_real_reference(const T* pos, const T* q, const T* cell, const T* alph
         double ex = std::exp(-(ar * ar));
         double fm = (0.5 * qi * qj) * (ec / (dist * dist * dist) + two_over_sqrt_pi * al * ex / (dist * dist));
         T f[3] = {T(fm) * sep[0], T(fm) * sep[1], T(fm) * sep[2]};
-        for (int d = 0; d < 3; ++d) { fi[d] -= f[d]; forces[3 * (size_t)j + d] += f[d]; }
+        for (int d = 0; d < 3; ++d) {
+          fi[d] -= f[d];
+          ORC_ATOMIC
+          forces[3 * (size_t)j + d] += f[d];
+        }
       }
       if (want_cg) {
         double pot = 0.5 * ec / dist;
         cgi += qj * pot;
+        ORC_ATOMIC
         cgrad[j] += qi * pot;
       }
     }
     energies[i] += eacc;
-    if (want_forces) for (int d = 0; d < 3; ++d) forces[3 * (size_t)i + d] += fi[d];
-    if (want_cg) cgrad[i] += cgi;
+    if (want_forces) for (int d = 0; d < 3; ++d) {
+      ORC_ATOMIC
+      forces[3 * (size_t)i + d] += fi[d];
+    }
+    if (want_cg) {
+      ORC_ATOMIC
+      cgrad[i] += cgi;
+    }
   }
 }
 
 // ---------------------------------------------------------------------------------------
 // Cardinal B-splines, spread / gather  (spline.py:127-488 functions; :497-676, :763-959 kernels)
 // ---------------------------------------------------------------------------------------
+// EXTENDED MODE ("beyond reference", off by default; orc_set_extended): the reference has no order-5/6 branch and caps the
+// structure-factor exponent at 4, so its order-5/6 PME is identically zero.  The product evaluates true cardinal
+// B-splines there; to have something to compare them with, extended mode evaluates M_n(u) for n >= 5 by the closed-form
+// truncated-power sum  M_n(u) = 1/(n-1)! sum_k (-1)^k C(n,k) (u-k)_+^(n-1)  in long double (a formulation that shares nothing
+// with the product's bottom-up Cox-de Boor recursion) and uses exponent = order in the structure factor.  Orders <= 4 are untouched.
+static int g_extended = 0;
+template <class T> inline T bspline_truncated_power(T u, int n) {
+  if (!(u >= T(0) && u < T(n))) return T(0);
+  long double acc = 0.0L, binom = 1.0L, fact = 1.0L;
+  for (int k = 2; k < n; ++k) fact *= (long double)k;
+  for (int k = 0; k <= n; ++k) {
+    long double x = (long double)u - (long double)k;
+    if (x > 0.0L) { long double pw = 1.0L; for (int e = 0; e < n - 1; ++e) pw *= x; acc += ((k & 1) ? -binom : binom) * pw; }
+    binom = binom * (long double)(n - k) / (long double)(k + 1);
+  }
+  return T(acc / fact);
+}
+
 template <class T> inline T bspline_w(T u, int order) {
   const T zero = 0, one = 1, two = 2, three = 3, four = 4, six = 6;
+  if (order >= 5 && g_extended) return bspline_truncated_power(u, order);
   if (order == 4) {
     if (u >= zero && u < one) return u * u * u / six;
     if (u >= one && u < two) { T u2 = u * u, u3 = u2 * u; return (T(-3) * u3 + T(12) * u2 - T(12) * u + four) / six; }
@@ -555,6 +647,7 @@ void spline_reference(int mode, const T* pos, const T* values, const int* batch_
   const bool batch = batch_idx != nullptr;
   const size_t msz = (size_t)dims[0] * dims[1] * dims[2];
   const int P = order * order * order;
+  ORC_PARALLEL_FOR
   for (int i = 0; i < N; ++i) {
     int s = batch ? batch_idx[i] : 0;
     Mat3<T> cit; load_mat(cell_inv_t + 9 * s, cit);
@@ -567,7 +660,10 @@ void spline_reference(int mode, const T* pos, const T* values, const int* batch_
       if (!take) continue;
       size_t g = ((size_t)wrapi(st.base[0] + off[0], dims[0]) * dims[1] + wrapi(st.base[1] + off[1], dims[1])) * dims[2] +
                  wrapi(st.base[2] + off[2], dims[2]);
-      if (mode == 0) mesh[s * msz + g] += values[i] * w;
+      if (mode == 0) {
+        ORC_ATOMIC
+        mesh[s * msz + g] += values[i] * w;
+      }
       else if (mode == 1) out[i] += mesh[s * msz + g] * w;
       else for (int d = 0; d < 3; ++d) out[3 * (size_t)i + d] += (values[i] * mesh[(s * msz + g) * 3 + d]) * w;
     }
@@ -596,7 +692,8 @@ void green_sf_reference(const T* k2, const T* alpha, const T* volume, int B, int
       if (b == 0) {
         T sp = sinc_pi(T(miller(i, nx)) / T(nx)) * sinc_pi(T(miller(j, ny)) / T(ny)) * sinc_pi(T(k) / T(nz));
         T sf = sp;
-        for (int t = 1; t < 4; ++t) if (t < order) sf = sf * sp;  // exponent capped at 4
+        const int cap = g_extended ? order : 4;  // exponent capped at 4 unless extended mode is on
+        for (int t = 1; t < cap; ++t) if (t < order) sf = sf * sp;
         if (sf < T(1e-10)) sf = T(1e-10);
         sf2[((size_t)i * ny + j) * nzr + k] = sf * sf;
       }
@@ -683,6 +780,20 @@ void orc_corrections(int dtype, const void* raw, const void* q, const int* batch
 
 double orc_erfc(int dtype, double x) { return dtype == 0 ? double(erfc_as<float>(float(x))) : erfc_as<double>(x); }
 
-int orc_version() { return 1; }
+int orc_set_d3_wide_sums(int on) { int old = g_d3_wide; g_d3_wide = on != 0; return old; }
+
+int orc_set_threads(int n) {
+#ifdef _OPENMP
+  if (n > 0) omp_set_num_threads(n);
+  return omp_get_max_threads();
+#else
+  (void)n;
+  return 1;
+#endif
+}
+
+int orc_set_extended(int on) { int old = g_extended; g_extended = on != 0; return old; }
+
+int orc_version() { return 2; }
 
 }  // extern "C"

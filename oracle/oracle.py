@@ -34,18 +34,98 @@ def build() -> str:
     return os.path.join(_HERE, "libnvalchemi_oracle.so")
 
 
+def _load(name: str) -> ctypes.CDLL:
+    path = os.path.join(_HERE, name)
+    src = os.path.join(_HERE, "nvalchemi_oracle.cpp")
+    if not os.path.exists(path) or os.path.getmtime(path) < os.path.getmtime(src):
+        build()
+    L = ctypes.CDLL(path)
+    L.orc_erfc.restype = ctypes.c_double
+    L.orc_erfc.argtypes = [ctypes.c_int, ctypes.c_double]
+    L.orc_cell_list.restype = ctypes.c_int
+    return L
+
+
 def lib() -> ctypes.CDLL:
     global _LIB
     if _LIB is None:
-        path = os.path.join(_HERE, "libnvalchemi_oracle.so")
-        src = os.path.join(_HERE, "nvalchemi_oracle.cpp")
-        if not os.path.exists(path) or os.path.getmtime(path) < os.path.getmtime(src):
-            build()
-        _LIB = ctypes.CDLL(path)
-        _LIB.orc_erfc.restype = ctypes.c_double
-        _LIB.orc_erfc.argtypes = [ctypes.c_int, ctypes.c_double]
-        _LIB.orc_cell_list.restype = ctypes.c_int
+        _LIB = _load("libnvalchemi_oracle.so")
     return _LIB
+
+
+_FFT_WORKERS = None  # None: numpy's single-threaded pocketfft; int: scipy.fft with that many workers (all-core baseline leg only)
+
+
+class openmp:
+    """Context manager: run the restatement on `threads` host cores (the -fopenmp build of the same source, scipy.fft workers for
+    the FFTs).  For the all-core leg of bench.py's cpu_baseline ONLY -- parity tests use the serial library, whose accumulation
+    order is the reference's."""
+
+    def __init__(self, threads: int | None = None):
+        self.threads = threads or os.cpu_count() or 1
+
+    def __enter__(self):
+        global _LIB, _FFT_WORKERS
+        self._saved = (_LIB, _FFT_WORKERS)
+        ext = lib().orc_set_extended(0)
+        lib().orc_set_extended(ext)
+        wide = lib().orc_set_d3_wide_sums(0)
+        lib().orc_set_d3_wide_sums(wide)
+        _LIB = _load("libnvalchemi_oracle_omp.so")
+        _LIB.orc_set_extended(ext)
+        _LIB.orc_set_d3_wide_sums(wide)
+        self.threads = int(_LIB.orc_set_threads(int(self.threads)))
+        _FFT_WORKERS = self.threads
+        return self
+
+    def __exit__(self, *exc):
+        global _LIB, _FFT_WORKERS
+        _LIB, _FFT_WORKERS = self._saved
+        return False
+
+
+def _rfftn(x, axes):
+    if _FFT_WORKERS:
+        import scipy.fft
+
+        return scipy.fft.rfftn(x, axes=axes, workers=_FFT_WORKERS)
+    return np.fft.rfftn(x, axes=axes)
+
+
+def _irfftn(x, s, axes):
+    if _FFT_WORKERS:
+        import scipy.fft
+
+        return scipy.fft.irfftn(x, s=s, axes=axes, workers=_FFT_WORKERS)
+    return np.fft.irfftn(x, s=s, axes=axes)
+
+
+class extended_splines:
+    """Context manager: "beyond reference" mode of the spline / structure-factor restatement (true order-5/6 cardinal B-splines by
+    the closed-form truncated-power sum, structure-factor exponent = order).  The reference itself evaluates orders 5/6 as zero
+    (SURVEY F2/F3), so this mode is NOT pinned by the reference; it is pinned by the NaCl Madelung constant and the independent
+    explicit Ewald sum (tests/test_oracle_golden.py) and is what the product's order-5/6 path is compared with."""
+
+    def __enter__(self):
+        self._old = lib().orc_set_extended(1)
+        return self
+
+    def __exit__(self, *exc):
+        lib().orc_set_extended(self._old)
+        return False
+
+
+class d3_wide_sums:
+    """Context manager: D3 restatement with every fp32 accumulation of the reference (CN, dE/dCN, per-system energy / virial) carried
+    in double and rounded once -- the reference's arithmetic without its summation-order noise (error budget)."""
+
+    def __enter__(self):
+        self._old = lib().orc_set_d3_wide_sums(1)
+        return self
+
+    def __exit__(self, *exc):
+        lib().orc_set_d3_wide_sums(self._old)
+        return False
 
 
 def _p(a):
@@ -399,20 +479,20 @@ def pme_reciprocal_space(positions, charges, cell, alpha, mesh_dimensions, splin
     batched = batch_idx is not None
     axes = (-3, -2, -1)
     mesh = spline_spread(pos, charges, cell, mesh_dimensions, spline_order, batch_idx)
-    mesh_fft = np.fft.rfftn(mesh, axes=axes)
+    mesh_fft = _rfftn(mesh, axes)
     kvec, k2 = generate_k_vectors_pme(cell, mesh_dimensions)
     if batched and kvec.ndim == 4:
         kvec, k2 = kvec[None], k2[None]
     g, sf2 = pme_green_structure_factor(k2, mesh_dimensions, alpha, cell, spline_order)
     conv = (mesh_fft / sf2) * g
     ntot = float(np.prod(mesh_dimensions))
-    phi = (np.fft.irfftn(conv, s=mesh_dimensions, axes=axes) * ntot).astype(dt)
+    phi = (_irfftn(conv, mesh_dimensions, axes) * ntot).astype(dt)
     raw = spline_gather(pos, phi, cell, spline_order, batch_idx)
     corr = pme_energy_corrections(raw, charges, cell, alpha, batch_idx, with_charge_grad=compute_charge_gradients)
     energies, cgrads = (corr if compute_charge_gradients else (corr, None))
     out = (energies,)
     if compute_forces:
-        comps = [np.fft.irfftn(-1j * kvec[..., d] * conv, s=mesh_dimensions, axes=axes) * ntot for d in range(3)]
+        comps = [_irfftn(-1j * kvec[..., d] * conv, mesh_dimensions, axes) * ntot for d in range(3)]
         efield = np.stack(comps, -1).astype(dt)
         out += ((2.0 * spline_gather_vec3(pos, charges, efield, cell, spline_order, batch_idx)).astype(dt),)
     if compute_charge_gradients:

@@ -131,3 +131,66 @@ def test_cell_and_alpha_gradients_vs_finite_differences():
             assert abs(fd - gc[r, k].item()) < 1e-5 + 1e-4 * abs(fd), (fn.__name__, r, k, fd, gc[r, k].item())
         fd = (fn(cell, a.detach() + eps) - fn(cell, a.detach() - eps)).item() / (2 * eps)
         assert abs(fd - ga.item()) < 1e-5 + 1e-4 * abs(fd), (fn.__name__, fd, ga.item())
+
+
+def test_real_space_adjoint_on_a_half_list_vs_finite_differences():
+    """Lists that are not symmetric take the general adjoint (entry (i -> j) carries g_i to both ends): d(sum_i w_i E_i)/d(positions,
+    charges) against central differences on a half list, where the owner-only (g_i + g_j) form would be wrong."""
+    from nvalchemiops.interactions.electrostatics import ewald_real_space
+    from nvalchemiops.neighborlist import cell_list
+
+    g = np.random.default_rng(11)
+    cell = np.array([[9.0, 0, 0], [1.0, 8.5, 0], [0.5, -0.7, 9.5]])
+    pos = g.uniform(0, 1, (40, 3)) @ cell
+    q = g.normal(size=40)
+    w = torch.as_tensor(g.normal(size=40), device=DEV)
+    tc = torch.as_tensor(cell, device=DEV)
+    pbc = torch.tensor([True] * 3, device=DEV)
+    alpha = torch.tensor([0.45], dtype=torch.float64, device=DEV)
+    lst, nptr, lsh = cell_list(torch.as_tensor(pos, device=DEV), 6.0, tc, pbc, return_neighbor_list=True, half_fill=True)
+
+    def loss(p, c):
+        e = ewald_real_space(p, c, tc[None], alpha, neighbor_list=lst, neighbor_ptr=nptr, neighbor_shifts=lsh)
+        return (w * e).sum()
+
+    tp = torch.as_tensor(pos, device=DEV, requires_grad=True)
+    tq = torch.as_tensor(q, device=DEV, requires_grad=True)
+    loss(tp, tq).backward()
+    h = 1e-5
+    for (i, d) in ((3, 0), (17, 2), (39, 1)):
+        pp, pm = pos.copy(), pos.copy()
+        pp[i, d] += h
+        pm[i, d] -= h
+        fd = (loss(torch.as_tensor(pp, device=DEV), tq.detach()) - loss(torch.as_tensor(pm, device=DEV), tq.detach())) / (2 * h)
+        assert abs(float(fd) - float(tp.grad[i, d])) < 1e-6 * max(1.0, abs(float(fd)))
+    for i in (0, 21):
+        qp, qm = q.copy(), q.copy()
+        qp[i] += h
+        qm[i] -= h
+        fd = (loss(tp.detach(), torch.as_tensor(qp, device=DEV)) - loss(tp.detach(), torch.as_tensor(qm, device=DEV))) / (2 * h)
+        assert abs(float(fd) - float(tq.grad[i])) < 1e-6 * max(1.0, abs(float(fd)))
+
+
+def test_spline_grad_path_with_one_cell_for_the_whole_batch():
+    """with batch_idx, ONE (3,3) cell and an input that requires grad, the differentiable branch must expand the cell to
+    the batch like the plain branch does (the kernels index mesh and cell_inv_t by batch_idx)."""
+    from nvalchemiops.spline import spline_gather, spline_spread
+
+    g = np.random.default_rng(5)
+    cell = torch.as_tensor(np.eye(3) * 8.0, device=DEV)
+    pos = torch.as_tensor(g.uniform(0, 8, (60, 3)), device=DEV)
+    vals = torch.as_tensor(g.normal(size=60), device=DEV)
+    bi = torch.as_tensor(np.repeat(np.arange(3, dtype=np.int32), 20), device=DEV)
+    plain = spline_spread(pos, vals, cell, (12, 12, 12), 4, batch_idx=bi)
+    vg = vals.clone().requires_grad_(True)
+    mesh = spline_spread(pos, vg, cell, (12, 12, 12), 4, batch_idx=bi)
+    assert mesh.shape == plain.shape == (3, 12, 12, 12)
+    torch.testing.assert_close(mesh.detach(), plain)
+    field = torch.as_tensor(g.normal(size=(3, 12, 12, 12)), device=DEV)
+    (mesh * field).sum().backward()
+    torch.testing.assert_close(vg.grad, spline_gather(pos, field, cell, 4, batch_idx=bi))
+    pg = pos.clone().requires_grad_(True)
+    out = spline_gather(pg, field, cell, 4, batch_idx=bi)
+    torch.testing.assert_close(out.detach(), spline_gather(pos, field, cell, 4, batch_idx=bi))
+    out.sum().backward()
+    assert torch.isfinite(pg.grad).all() and float(pg.grad.abs().max()) > 0

@@ -327,3 +327,82 @@ def test_headline_100k_periodic_full_size_vs_oracle():
     _close(f, rf, 1e-5, 1e-6 + 5e-6 * np.abs(rf).max(), "forces")
     _close(cn, rcn, 2e-5, 1e-6, "cn")  # the reference's sequential fp32 sum of 2350 terms vs fp64 lane partials here (DESIGN.md deviation 6)
     _close(vir[0], v_ref, 1e-5, 2e-6 + 1e-5 * np.abs(v_ref).max(), "virial")
+
+
+# ---- error budget ---------------------------------------------------------------------------------------------
+def _ieee_lib():
+    import ctypes
+    import os
+
+    from nvalchemiops import _capi as C
+
+    path = os.path.join(os.path.dirname(C._LIB_PATH), "libnvalchemiops_d3_ieee.so")
+    return ctypes.CDLL(path)
+
+
+def _budget_case(name):
+    from nvalchemiops.neighborlist import cell_list
+
+    pbc = torch.tensor([True] * 3, device=DEV)
+    if name == "fcc2048":  # the smoke() system: 2048-atom jittered FCC box, 6 A list
+        pos, cell, _, z = S.fcc_box(2048, dtype=np.float32)
+        nm, num, sh = cell_list(_t(pos), 6.0, _t(cell), pbc, max_neighbors=96)
+        return pos, cell, z, nm, sh, O.d3_test_tables(17), dict(a1=0.4289, a2=4.4407, s8=0.7875)
+    if name == "fcc4000_40bohr":  # headline density and cutoff (Bohr coordinates), ~2.4k pairs per atom
+        pos, cell, _, z = S.fcc_box(4000, dtype=np.float64)
+        pos, cell = (pos * 1.8897261246).astype(np.float32), (cell * 1.8897261246).astype(np.float32)
+        nm, num, sh = cell_list(_t(pos), 40.0, _t(cell), pbc, max_neighbors=2560)
+        assert int(num.max()) <= 2560
+        return pos, cell, z, nm, sh, O.d3_test_tables(94, seed=7), dict(a1=0.4289, a2=4.4407, s8=0.7875)
+    pos, cell = S.random_box(180, 26.0, seed=3, dtype=np.float32, triclinic=True)
+    z = np.random.default_rng(1).choice(np.array([1, 6, 8, 17], np.int32), 180)
+    nm, num, sh = cell_list(_t(pos), 14.0, _t(cell), pbc, max_neighbors=320)
+    return pos, cell, z, nm, sh, O.d3_test_tables(17), dict(FP)
+
+
+@pytest.mark.parametrize("case", ["fcc2048", "triclinic180", "fcc4000_40bohr"])
+def test_error_budget_vs_wide_sum_oracle(case):
+    """Separates the three error sources of the D3 path, per output (E, F, CN, virial), against the oracle with every fp32
+    accumulation carried in double (the reference's pair arithmetic without its summation-order noise):
+      fast   the product kernels (v_rsq / v_rcp / v_sqrt / compensated v_exp, fp64 lane partials)
+      ieee   the same kernels compiled with correctly rounded sqrt / divide and libm expf (libnvalchemiops_d3_ieee.so)
+      ref    the oracle in the reference's own accumulation order (sequential fp32 CN / dE/dCN, fp32 per-system sums)
+    The product must meet the reference's CPU-vs-GPU bar, rtol = atol = 1e-6 (test_dftd3.py:477-489), against the wide-sum oracle;
+    the table goes to gpurun_out/d3_error_budget.json."""
+    import json
+    import os
+
+    from nvalchemiops.interactions.dispersion import D3Parameters, dftd3
+    from nvalchemiops.interactions.dispersion import dftd3 as d3mod_fn  # noqa: F401
+    import nvalchemiops.interactions.dispersion.dftd3 as d3mod
+
+    pos, cell, z, nm, sh, tables, bj = _budget_case(case)
+    p = D3Parameters(rcov=_t(tables["rcov"]), r4r2=_t(tables["r4r2"]), c6ab=_t(tables["c6ab"]), cn_ref=_t(tables["cn_ref"]))
+    kw = dict(d3_params=p, neighbor_matrix=nm, neighbor_matrix_shifts=sh, cell=_t(cell)[None], compute_virial=True, **bj)
+    fast = [o.cpu().numpy().astype(np.float64) for o in dftd3(_t(pos), _t(z), **kw)]
+    d3mod._LIB_OVERRIDE = _ieee_lib()
+    try:
+        ieee = [o.cpu().numpy().astype(np.float64) for o in dftd3(_t(pos), _t(z), **kw)]
+    finally:
+        d3mod._LIB_OVERRIDE = None
+    okw = dict(neighbor_matrix=nm.cpu().numpy(), neighbor_matrix_shifts=sh.cpu().numpy(), cell=cell, compute_virial=True, **bj)
+    ref = [np.asarray(o, np.float64) for o in O.dftd3(pos, z, tables, **okw)]
+    with O.d3_wide_sums():
+        wide = [np.asarray(o, np.float64) for o in O.dftd3(pos, z, tables, **okw)]
+    names = ("energy", "forces", "coord_num", "virial")
+    table = {}
+    for k, nme in enumerate(names):
+        scale = np.abs(wide[k]).max()
+        table[nme] = {"scale_max_abs": scale}
+        for tag, arr in (("fast", fast), ("ieee", ieee), ("ref_order", ref)):
+            err = np.abs(arr[k] - wide[k])
+            table[nme][tag] = {"max_abs": float(err.max()), "max_abs_over_scale": float(err.max() / max(scale, 1e-300)),
+                               "max_excess_over_1e-6_bar": float((err - (1e-6 + 1e-6 * np.abs(wide[k]))).max())}
+    os.makedirs("gpurun_out", exist_ok=True)
+    path = os.path.join("gpurun_out", "d3_error_budget.json")
+    allt = json.load(open(path)) if os.path.exists(path) else {}
+    allt[case] = table
+    json.dump(allt, open(path, "w"), indent=1)
+    print(json.dumps({case: table}))
+    for k, nme in enumerate(names):  # the reference's own bar
+        np.testing.assert_allclose(fast[k], wide[k], rtol=1e-6, atol=1e-6, err_msg=f"{case}: {nme} (product vs wide-sum oracle)")

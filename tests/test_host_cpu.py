@@ -278,3 +278,32 @@ def test_rebuild_detection_and_batch_size_edge_cases():
     assert ncell == 1 and radius.shape == (1, 3) and radius.dtype == torch.int32
     batch_build_cell_list(torch.empty(0, 3), 1.0, torch.eye(3).reshape(1, 3, 3), torch.tensor([[True, True, True]]), torch.empty(0, dtype=torch.int32),
                           i32([1, 1, 1]), i32([1, 1, 1]), i32([0, 0, 0]), i32([0, 0, 0]), i32([0]), i32([0]), i32([]))  # returns without touching a device
+
+
+def test_openmp_oracle_equals_serial_oracle():
+    """The -fopenmp build of the oracle (bench.py's all-core cpu_baseline leg) computes what the serial parity oracle computes:
+    identical neighbour sets / counts, D3 and PME equal up to the order of the cross-row additions."""
+    from oracle import oracle as O
+    from tests import systems as S
+
+    pos, cell, q, numbers = S.fcc_box(500, dtype=np.float64)
+    nm, num, sh = O.cell_list(pos, 7.0, cell, [True] * 3, max_neighbors=160)
+    p32, c32 = (pos * 1.8897261246).astype(np.float32), (cell * 1.8897261246).astype(np.float32)
+    dm, dnum, dsh = O.cell_list(p32, 20.0, c32, [True] * 3, max_neighbors=512)
+    tab = O.d3_test_tables(17)
+    kw = dict(neighbor_matrix=dm, neighbor_matrix_shifts=dsh, cell=c32, compute_virial=True)
+    d3 = O.dftd3(p32, numbers, tab, 0.4289, 4.4407, 0.7875, **kw)
+    with O.extended_splines():
+        pme = O.particle_mesh_ewald(pos, q, cell, 0.35, (24, 24, 24), 5, neighbor_matrix=nm, neighbor_matrix_shifts=sh, compute_forces=True)
+        with O.openmp(2) as om:
+            assert om.threads == 2
+            nm2, num2, sh2 = O.cell_list(pos, 7.0, cell, [True] * 3, max_neighbors=160)
+            d3b = O.dftd3(p32, numbers, tab, 0.4289, 4.4407, 0.7875, **kw)
+            pmeb = O.particle_mesh_ewald(pos, q, cell, 0.35, (24, 24, 24), 5, neighbor_matrix=nm, neighbor_matrix_shifts=sh, compute_forces=True)
+    assert np.array_equal(num, num2) and np.array_equal(O.canonical_pairs(nm, num, sh), O.canonical_pairs(nm2, num2, sh2))
+    for a, b in zip(d3, d3b):
+        np.testing.assert_allclose(a, b, rtol=2e-6, atol=1e-7)
+    np.testing.assert_allclose(pme[0], pmeb[0], rtol=1e-12, atol=1e-13)
+    np.testing.assert_allclose(pme[1], pmeb[1], rtol=1e-11, atol=1e-13)
+    # the serial library is untouched by the switch
+    assert np.array_equal(O.dftd3(p32, numbers, tab, 0.4289, 4.4407, 0.7875, **kw)[1], d3[1])

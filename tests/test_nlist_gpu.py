@@ -98,6 +98,25 @@ def test_coo_output(direct):
     assert (np.diff(src) >= 0).all()  # sorted by source atom (docs/userguide/components/neighborlist.md:133-137)
 
 
+def test_coo_conversion_follows_the_mask_not_the_counts():
+    """get_neighbor_list_from_neighbor_matrix: the list is what `neighbor_matrix != fill_value` selects and neighbor_ptr is the cumsum of
+    num_neighbors, as in the reference (neighbor_utils.py:428-438) -- also when the two disagree (matrix padded with N, default
+    fill_value = -1): then EVERY slot is listed, padding included, and nothing is left uninitialised."""
+    from nvalchemiops.neighborlist import cell_list, get_neighbor_list_from_neighbor_matrix
+
+    pos, cell = S.random_box(300, 10.0, seed=9, dtype=np.float32)
+    nm, num, sh = cell_list(_t(pos), 3.0, _t(cell), torch.tensor([True] * 3, device=DEV), max_neighbors=48)
+    lst, nptr, lsh = get_neighbor_list_from_neighbor_matrix(nm, num, sh)  # default fill_value = -1: nothing equals it
+    m = nm.cpu().numpy()
+    assert lst.shape[1] == 300 * 48 and np.array_equal(lst[1].cpu().numpy(), m.ravel())
+    assert np.array_equal(lst[0].cpu().numpy(), np.repeat(np.arange(300), 48))
+    assert np.array_equal(lsh.cpu().numpy(), sh.cpu().numpy().reshape(-1, 3))
+    assert np.array_equal(nptr.cpu().numpy(), np.concatenate([[0], np.cumsum(num.cpu().numpy())]))
+    lst, nptr, lsh = get_neighbor_list_from_neighbor_matrix(nm, num, sh, fill_value=300)
+    mask = m != 300
+    assert lst.shape[1] == int(num.sum()) == int(mask.sum()) and np.array_equal(lst[1].cpu().numpy(), m[mask])
+
+
 def test_half_fill_and_overflow():
     from nvalchemiops.neighborlist import NeighborOverflowError, cell_list
 
@@ -188,17 +207,22 @@ def test_empty_and_tiny_inputs():
     assert num.cpu().tolist() == [1, 1] and sh[0, 0].cpu().tolist() == [-1, 0, 0] and sh[1, 0].cpu().tolist() == [1, 0, 0]
 
 
-@pytest.mark.parametrize("n,dtype,cutoff,m", [(50000, np.float32, 5.0, 64), (100000, np.float64, 9.0, 256)])
+@pytest.mark.parametrize("n,dtype,cutoff,m", [(50000, np.float32, 5.0, 64), (50000, np.float32, 5.0, None), (100000, np.float64, 9.0, 256)])
 def test_baseline_configs_full_size_match_oracle(n, dtype, cutoff, m):
-    """BASELINE.json config 2 (50k-atom periodic box, cell_list, padded matrix, fp32) and the neighbour list of config 4 (100k atoms,
+    """BASELINE.json config 2 (50k-atom periodic box, cell_list, padded matrix, fp32; explicit M = 64 AND the default row width
+    estimate_max_neighbors(5 A) = 928 the API uses when the caller gives none) and the neighbour list of config 4 (100k atoms,
     fp64, the 9 A real-space cutoff of the headline PME leg) at their FULL sizes: counts and (i, j, S) sets bit-exact vs the oracle
-    (1.4 s / 15 s of oracle time)."""
+    (1.4 s / 15 s of oracle time); with the default width also the padding itself (fill value N, zero shifts)."""
     from nvalchemiops.neighborlist import cell_list
 
     pos, cell, _, _ = S.fcc_box(n, dtype=dtype)
     onm, onum, osh = O.cell_list(pos, cutoff, cell, [True] * 3, max_neighbors=m)
     nm, num, sh = cell_list(_t(pos), cutoff, _t(cell), torch.tensor([True] * 3, device=DEV), max_neighbors=m)
-    assert int(onum.max()) <= m
+    if m is None:
+        assert nm.shape[1] == onm.shape[1] == 928
+        pad = torch.arange(928, device=DEV)[None, :] >= num[:, None]
+        assert bool((nm[pad] == n).all()) and bool((sh[pad] == 0).all())
+    assert int(onum.max()) <= nm.shape[1]
     assert np.array_equal(num.cpu().numpy(), onum)
     assert np.array_equal(_pairs(nm, num, sh), O.canonical_pairs(onm, onum, osh))
 

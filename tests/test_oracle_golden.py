@@ -130,6 +130,42 @@ def test_pme_vs_explicit_ewald_triclinic():
     assert abs(f - fe).max() < 5e-6
 
 
+@pytest.mark.parametrize("order", [5, 6])
+def test_extended_splines_pinned_by_madelung_and_explicit_ewald(order):
+    """"Beyond reference" mode of the oracle (true order-5/6 B-splines, structure-factor exponent = order): the reference evaluates
+    these orders as zero, so the mode is pinned like the order-4 restatement is -- NaCl Madelung constant and the independent
+    explicit Ewald sum -- and must be MORE accurate than order 4 on the same mesh; spline identities hold to round-off."""
+    a = 5.64
+    base = np.array([[0, 0, 0], [.5, .5, 0], [.5, 0, .5], [0, .5, .5], [.5, 0, 0], [0, .5, 0], [0, 0, .5], [.5, .5, .5]]) * a
+    q = np.array([1, 1, 1, 1, -1, -1, -1, -1.0])
+    cell = np.eye(3) * a
+    nm, num, sh = O.cell_list(base, 9.0, cell, [True] * 3, max_neighbors=160)
+    with O.extended_splines():
+        e, f = O.particle_mesh_ewald(base, q, cell, 0.45, (32, 32, 32), order, neighbor_matrix=nm, neighbor_matrix_shifts=sh, compute_forces=True)
+    assert abs(-e.sum() / 4 * (a / 2) - 1.747565) < 1e-5 and abs(f).max() < 1e-10
+    g = np.random.default_rng(0)
+    cell = np.array([[10, 0, 0], [2, 9, 0], [1, -1, 11.0]])
+    pos = g.uniform(0, 1, (20, 3)) @ cell
+    q = g.normal(size=20)
+    q -= q.mean()
+    nm, num, sh = O.cell_list(pos, 11.0, cell, [True] * 3, max_neighbors=400)
+    ee, fe = O.explicit_ewald(pos, q, cell, 0.4, kmax=9)
+    e4, f4 = O.particle_mesh_ewald(pos, q, cell, 0.4, (32, 32, 32), 4, neighbor_matrix=nm, neighbor_matrix_shifts=sh, compute_forces=True)
+    with O.extended_splines():
+        e, f = O.particle_mesh_ewald(pos, q, cell, 0.4, (32, 32, 32), order, neighbor_matrix=nm, neighbor_matrix_shifts=sh, compute_forces=True)
+        mesh = O.spline_spread(pos, q + 1.0, cell, (12, 10, 14), order)
+        ones = O.spline_gather(pos, np.ones((12, 10, 14)), cell, order)
+    assert abs(e.sum() - ee) < abs(e4.sum() - ee) and abs(f - fe).max() < abs(f4 - fe).max()
+    assert abs(e.sum() - ee) < 2e-5 and abs(f - fe).max() < 2e-5
+    assert abs(mesh.sum() - (q + 1.0).sum()) < 1e-12
+    np.testing.assert_allclose(ones, 1.0, atol=1e-7)
+    # reference mode is untouched: orders 5/6 stay identically zero (SURVEY F2), order 4 does not change under the switch
+    assert not O.spline_spread(pos, q, cell, (12, 10, 14), order).any()
+    with O.extended_splines():
+        e4x = O.particle_mesh_ewald(pos, q, cell, 0.4, (32, 32, 32), 4, neighbor_matrix=nm, neighbor_matrix_shifts=sh)
+    assert np.array_equal(e4x, e4)
+
+
 def test_spline_properties():
     # test/test_spline.py:46 (partition of unity), :179 (charge conservation), :637 (adjointness)
     g = np.random.default_rng(5)

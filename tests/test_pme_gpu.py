@@ -135,6 +135,40 @@ def test_real_space_matches_oracle(dtype, fmt):
 
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("kind", ["half", "truncated", "one_sided_csr"])
+def test_real_space_on_lists_that_are_not_symmetric(dtype, kind):
+    """The reference scatters -f to atom i and +f to atom j (and the charge gradient to both ends) for EVERY stored entry
+    (ewald_kernels.py:518-544, :864-873), so half lists, rows truncated by max_neighbors overflow and one-sided lists have a defined
+    result; the owner-only fast path is exact for symmetric lists only, the device-side symmetry check must route everything else
+    through the scatter fix-up.  Oracle = the restatement, which scatters like the reference."""
+    from nvalchemiops.interactions.electrostatics import ewald_real_space
+    from nvalchemiops.neighborlist import cell_list
+
+    pos, cell, q = _system(250, dtype, triclinic=True, seed=4)
+    pbc = torch.tensor([True] * 3, device=DEV)
+    alpha = torch.tensor([0.4], dtype=_t(pos).dtype, device=DEV)
+    if kind == "one_sided_csr":
+        lst, nptr, lsh = cell_list(_t(pos), 7.0, _t(cell), pbc, return_neighbor_list=True, half_fill=True)
+        out = ewald_real_space(_t(pos), _t(q), _t(cell)[None], alpha, neighbor_list=lst, neighbor_ptr=nptr, neighbor_shifts=lsh,
+                               compute_forces=True, compute_charge_gradients=True)
+        ref = O.ewald_real_space(pos, q, cell, 0.4, idx_j=lst[1].cpu().numpy(), neighbor_ptr=nptr.cpu().numpy(),
+                                 neighbor_shifts=lsh.cpu().numpy(), compute_forces=True, compute_charge_gradients=True)
+    else:
+        kw = dict(half_fill=True, max_neighbors=160) if kind == "half" else dict(max_neighbors=40)  # 40 < fullest row: truncation
+        nm, num, sh = cell_list(_t(pos), 7.0, _t(cell), pbc, **kw)
+        if kind == "truncated":
+            assert int(num.max()) > 40
+        out = ewald_real_space(_t(pos), _t(q), _t(cell)[None], alpha, neighbor_matrix=nm, neighbor_matrix_shifts=sh, mask_value=250,
+                               compute_forces=True, compute_charge_gradients=True)
+        ref = O.ewald_real_space(pos, q, cell, 0.4, neighbor_matrix=nm.cpu().numpy(), neighbor_matrix_shifts=sh.cpu().numpy(), mask_value=250,
+                                 compute_forces=True, compute_charge_gradients=True)
+    for o, r, w in zip(out, ref, ("energies", "forces", "charge_grads")):
+        _close(o, r, dtype, w, scale=np.abs(r).max() * (10 if dtype == np.float32 else 1))
+    # Newton's third law holds entry by entry whatever the list
+    assert float(out[1].sum(0).abs().max()) <= (1e-10 if dtype == np.float64 else 2e-4) * float(out[1].abs().max()) * 16
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
 @pytest.mark.parametrize("order", [2, 3, 4])
 def test_pme_reciprocal_matches_oracle(dtype, order):
     from nvalchemiops.interactions.electrostatics import generate_k_vectors_pme, pme_reciprocal_space
@@ -242,6 +276,59 @@ def test_config4_100k_fp64_properties():
     assert torch.equal(num, num2)
     assert float((e - e2).abs().max()) < 1e-9 * float(e.abs().max()) * 10
     assert float((f - f2).abs().max()) < 1e-8 * float(f.abs().max()) * 10
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("order", [5, 6])
+def test_orders_5_6_vs_extended_oracle(dtype, order):
+    """Orders 5/6 against the oracle's extended mode (closed-form truncated-power B-splines, structure-factor exponent = order;
+    pinned on Madelung + explicit Ewald in tests/test_oracle_golden.py): spread mesh, gathers, full PME, single + batch, triclinic."""
+    from nvalchemiops.interactions.electrostatics import particle_mesh_ewald
+    from nvalchemiops.neighborlist import cell_list
+    from nvalchemiops.spline import spline_gather, spline_spread
+
+    pbc = torch.tensor([True] * 3, device=DEV)
+    pos, cell, q = _system(300, dtype, triclinic=True, seed=3, box=14.0)
+    dims = (16, 20, 24)
+    with O.extended_splines():
+        ref_mesh = O.spline_spread(pos, q, cell, dims, order)
+        field = np.random.default_rng(1).normal(size=dims).astype(dtype)
+        ref_g = O.spline_gather(pos, field, cell, order)
+    _close(spline_spread(_t(pos), _t(q), _t(cell), dims, order), ref_mesh, dtype, "spread")
+    _close(spline_gather(_t(pos), _t(field), _t(cell), order), ref_g, dtype, "gather")
+    nm, num, sh = cell_list(_t(pos), 6.0, _t(cell), pbc, max_neighbors=160)
+    assert int(num.max()) <= 160
+    e, f = particle_mesh_ewald(_t(pos), _t(q), _t(cell), alpha=0.4, mesh_dimensions=dims, spline_order=order, neighbor_matrix=nm,
+                               neighbor_matrix_shifts=sh, compute_forces=True)
+    with O.extended_splines():
+        ref = O.particle_mesh_ewald(pos, q, cell, 0.4, dims, order, neighbor_matrix=nm.cpu().numpy(), neighbor_matrix_shifts=sh.cpu().numpy(),
+                                    mask_value=len(pos), compute_forces=True)
+    _close(e, ref[0], dtype, "energies")
+    _close(f, ref[1], dtype, "forces")
+
+
+def test_headline_pme_order5_100k_vs_extended_oracle():
+    """The configuration bench.py times (100k atoms, fp64, 9 A list M = 256, alpha 0.35, mesh 128^3, spline ORDER 5, E + F) against
+    the extended oracle at full size -- the 125-point-stencil tile path of the headline number (VERDICT r1 weak #2)."""
+    from nvalchemiops.interactions.electrostatics import particle_mesh_ewald
+    from nvalchemiops.neighborlist import cell_list
+
+    pbc = torch.tensor([True] * 3, device=DEV)
+    pos, cell, q, _ = S.fcc_box(100000, dtype=np.float64)
+    tp, tc, tq = _t(pos), _t(cell), _t(q)
+    nm, num, sh = cell_list(tp, 9.0, tc, pbc, max_neighbors=256)
+    assert int(num.max()) <= 256
+    e, f = particle_mesh_ewald(tp, tq, tc, alpha=0.35, mesh_dimensions=(128, 128, 128), spline_order=5, neighbor_matrix=nm,
+                               neighbor_matrix_shifts=sh, compute_forces=True)
+    with O.extended_splines():
+        ref = O.particle_mesh_ewald(pos, q, cell, 0.35, (128, 128, 128), 5, neighbor_matrix=nm.cpu().numpy(), neighbor_matrix_shifts=sh.cpu().numpy(),
+                                    mask_value=100000, compute_forces=True)
+    _close(e, ref[0], np.float64, "100k order-5 energies")
+    _close(f, ref[1], np.float64, "100k order-5 forces")
+    # and order 5 is closer to order 6 than order 4 is (convergence with the spline order on the same mesh)
+    e4 = particle_mesh_ewald(tp, tq, tc, alpha=0.35, mesh_dimensions=(128, 128, 128), spline_order=4, neighbor_matrix=nm, neighbor_matrix_shifts=sh)
+    e6 = particle_mesh_ewald(tp, tq, tc, alpha=0.35, mesh_dimensions=(128, 128, 128), spline_order=6, neighbor_matrix=nm, neighbor_matrix_shifts=sh)
+    assert float((e.sum() - e6.sum()).abs()) < float((e4.sum() - e6.sum()).abs())
 
 
 # ---- explicit-k Ewald (SURVEY 8f N3) ---------------------------------------------------------------------------------------
