@@ -35,9 +35,28 @@ __device__ __forceinline__ unsigned ew_entry_hash(unsigned a, unsigned b, int s0
   h ^= h >> 15; h *= 0x2C1B3C6Du; h ^= h >> 12; h *= 0x297A2D39u; h ^= h >> 15;
   return h;
 }
-__device__ __forceinline__ void ew_sym_flush(unsigned long long hf, unsigned long long hr, unsigned long long* __restrict__ sym, int lane) {
+// Checksum scratch: sym[0..1] = final {forward, reverse} sums (written by ew_sym_reduce_kernel), then EW_SYM_SLOTS pairs of
+// partial sums.  A wave adds its partials to the slot pair of its atom index: 100k waves on ONE address would serialise at
+// ~12 ns per device-scope atomic (2.4 ms measured); spread over 1024 slot pairs they cost nothing measurable.
+#define EW_SYM_SLOTS 1024
+#define EW_SYM_WORDS (2 + 2 * EW_SYM_SLOTS)
+__device__ __forceinline__ void ew_sym_flush(unsigned long long hf, unsigned long long hr, unsigned long long* __restrict__ sym, int lane, int i) {
   hf = wave_sum(hf); hr = wave_sum(hr);
-  if (lane == 0 && (hf | hr)) { atomicAdd(&sym[0], hf); atomicAdd(&sym[1], hr); }
+  if (lane == 0 && (hf | hr)) {
+    unsigned long long* slot = sym + 2 + 2 * (size_t)(i & (EW_SYM_SLOTS - 1));
+    atomicAdd(&slot[0], hf); atomicAdd(&slot[1], hr);
+  }
+}
+__global__ __launch_bounds__(EW_SYM_SLOTS) void ew_sym_reduce_kernel(unsigned long long* __restrict__ sym) {
+  __shared__ unsigned long long part[2][EW_SYM_SLOTS / MI_WAVE];
+  const unsigned long long f = wave_sum(sym[2 + 2 * threadIdx.x]), r = wave_sum(sym[3 + 2 * threadIdx.x]);
+  if ((threadIdx.x & (MI_WAVE - 1)) == 0) { part[0][threadIdx.x / MI_WAVE] = f; part[1][threadIdx.x / MI_WAVE] = r; }
+  __syncthreads();
+  if (threadIdx.x < 2) {
+    unsigned long long t = 0;
+    for (int k = 0; k < EW_SYM_SLOTS / MI_WAVE; ++k) t += part[threadIdx.x][k];
+    sym[threadIdx.x] = t;
+  }
 }
 
 template <class T, bool CSR>
@@ -95,7 +114,7 @@ __global__ __launch_bounds__(256) void ewald_real_kernel(const T* __restrict__ p
     cgi = wave_sum(cgi);
     if (lane == 0) cgrad[i] = 2.0 * cgi;
   }
-  if (sym) ew_sym_flush(hf, hr, sym, lane);
+  if (sym) ew_sym_flush(hf, hr, sym, lane, i);
 }
 
 // ---- fix-up for lists that are not symmetric: the reference's scatter (ewald_kernels.py:518-544, :864-873) ---------------------
@@ -227,7 +246,7 @@ __global__ __launch_bounds__(256) void ewald_real_bwd_kernel(const T* __restrict
 #pragma unroll
     for (int k = 0; k < 9; ++k) { const double v = wave_sum(gc[k]); if (lane == 0 && v != 0.0) atomicAdd(&gcell[9 * (size_t)s + k], v); }
   }
-  if (sym) ew_sym_flush(hf, hr, sym, lane);
+  if (sym) ew_sym_flush(hf, hr, sym, lane, i);
 }
 
 // general adjoint for lists that are not symmetric: entry (i -> j) belongs to E_i only, so it carries weight g_i to BOTH ends
@@ -476,6 +495,8 @@ __global__ __launch_bounds__(256) void coulomb_bwd_kernel(const double* __restri
 
 }  // namespace
 
+extern "C" size_t mi_ewald_symmetry_scratch_bytes(void) { return sizeof(unsigned long long) * EW_SYM_WORDS; }
+
 extern "C" int mi_ewald_real_bwd(const void* positions, const void* charges, const void* cell, const void* alpha, const int32_t* batch_idx,
                                  int n_atoms, int dtype, const int32_t* idx_j, const int32_t* unit_shifts, const int32_t* neighbor_ptr,
                                  int max_neighbors, int mask_value, const void* grad_energies, void* grad_positions, void* grad_charges,
@@ -498,11 +519,12 @@ extern "C" int mi_ewald_real_bwd(const void* positions, const void* charges, con
                                                                     (const T_*)grad_energies, (T_*)grad_positions, (T_*)grad_charges, sym);        \
   } while (0)
   unsigned long long* sym = (unsigned long long*)symmetry_scratch;
-  if (sym) MI_HIP_CHECK(hipMemsetAsync(sym, 0, 16, st));
+  if (sym) MI_HIP_CHECK(hipMemsetAsync(sym, 0, sizeof(unsigned long long) * EW_SYM_WORDS, st));
   if (dtype == MI_F32) { if (csr) MI_EWB(float, true); else MI_EWB(float, false); }
   else { if (csr) MI_EWB(double, true); else MI_EWB(double, false); }
   MI_LAUNCH_CHECK();
   if (sym) {
+    ew_sym_reduce_kernel<<<1, EW_SYM_SLOTS, 0, st>>>(sym);
     if (dtype == MI_F32) { if (csr) MI_EWBS(float, true); else MI_EWBS(float, false); }
     else { if (csr) MI_EWBS(double, true); else MI_EWBS(double, false); }
     MI_LAUNCH_CHECK();
@@ -537,13 +559,14 @@ extern "C" int mi_ewald_real(const void* positions, const void* charges, const v
   } while (0)
   // the symmetry check only matters for outputs that are scattered in the reference (forces, charge gradients); energies are per owner
   unsigned long long* sym = (flags & (MI_EW_FORCES | MI_EW_CHARGE_GRAD)) ? (unsigned long long*)symmetry_scratch : nullptr;
-  if (sym) MI_HIP_CHECK(hipMemsetAsync(sym, 0, 16, st));
+  if (sym) MI_HIP_CHECK(hipMemsetAsync(sym, 0, sizeof(unsigned long long) * EW_SYM_WORDS, st));
   mi_timing_begin("ewald_real", stream);
   if (dtype == MI_F32) { if (csr) MI_EW(float, true); else MI_EW(float, false); }
   else { if (csr) MI_EW(double, true); else MI_EW(double, false); }
   mi_timing_end(stream);
   MI_LAUNCH_CHECK();
   if (sym) {
+    ew_sym_reduce_kernel<<<1, EW_SYM_SLOTS, 0, st>>>(sym);
     if (dtype == MI_F32) { if (csr) MI_EWS(float, true); else MI_EWS(float, false); }
     else { if (csr) MI_EWS(double, true); else MI_EWS(double, false); }
     MI_LAUNCH_CHECK();

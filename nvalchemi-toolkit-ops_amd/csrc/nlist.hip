@@ -7,10 +7,13 @@
 //
 //   setup    one thread per system: own binning (cell edge ~ rc/k, k from the local density; NOT the
 //            reference's 1000-cell cap) -- the result set does not depend on the binning
-//   assign   one thread per atom: cell key + integer wrap of atoms outside the box
-//   sort     radix sort of (cell key, atom index) (rocPRIM via hipcub): stable => ascending index in a cell
-//   ranges   cell -> [begin,end) in the sorted order by binary search (no atomics, no scan)
-//   gather   cell-ordered float4/double4 copy {x,y,z,index} so the query streams 16/32 B records
+//   assign   one thread per atom: cell key + integer wrap of atoms outside the box + one atomic on the cell's counter
+//   sort     counting sort by cell (binsort.h): block scan of the counters -> cell starts, scatter of the atom ids into their
+//            cell's segment through a second set of atomic counters (3 small kernels; a general radix sort of (key, index)
+//            pairs was ~20 library launches per list)
+//   gather   rank of every atom inside its cell by atom index (the few ids of a cell are compared from L1; => ascending index in
+//            a cell, rows are deterministic) and, in the same kernel, the cell-ordered float4/double4 record {x,y,z,index} the
+//            query streams, the wraps and the per-slot cell key
 //   query    ONE WAVE64 PER ATOM walks the full shell of cells; x-adjacent cells are contiguous in the sorted
 //            order, so each (dy,dz) row is one coalesced run; 64 candidates are tested per step, hits are
 //            compacted with __ballot/__popcll and written to the row owner's slots (coalesced, no atomics,
@@ -22,8 +25,7 @@
 //            written by `setup` decides which one works (no host sync).
 //
 // The same query kernels serve the padded matrix, the count pass and the direct CSR/COO fill.
-#include <hipcub/hipcub.hpp>
-
+#include "binsort.h"
 #include "common.h"
 
 namespace {
@@ -54,8 +56,7 @@ struct NlGlobal {
 };
 
 struct NlLayout {
-  size_t sys, glob, natoms, keys_in, keys_out, vals_in, vals_out, wrap, swrap, spos, cell_start, cub, total;
-  size_t cub_bytes;
+  size_t sys, glob, natoms, keys_in, keys_out, vals_in, vals_out, wrap, swrap, spos, cell_start, bins, total;
   long long cell_cap;
 };
 
@@ -85,11 +86,7 @@ NlLayout nl_layout(int N, int B, int dtype) {
   L.swrap = take(8 * (size_t)N);
   L.spos = take(4 * esz * (size_t)N);
   L.cell_start = take(sizeof(int) * (size_t)(L.cell_cap + 2));
-  size_t cub = 0;
-  (void)hipcub::DeviceRadixSort::SortPairs(nullptr, cub, (const int*)nullptr, (int*)nullptr, (const int*)nullptr, (int*)nullptr,
-                                     N > 0 ? N : 1, 0, nl_key_bits(L.cell_cap));
-  L.cub_bytes = cub + 256;
-  L.cub = take(L.cub_bytes);
+  L.bins = take(sizeof(int) * bs_scratch_ints(L.cell_cap + 2));  // counting-sort counters (binsort.h)
   L.total = o;
   return L;
 }
@@ -185,7 +182,7 @@ __global__ void nl_setup_kernel(const T* __restrict__ cell, const uint8_t* __res
 
 template <class T>
 __global__ void nl_assign_kernel(const T* __restrict__ pos, const int* __restrict__ batch_idx, int N, const NlSys<T>* __restrict__ sys,
-                                 int* __restrict__ keys, int* __restrict__ vals, short4* __restrict__ wrap, NlGlobal* __restrict__ glob) {
+                                 int* __restrict__ keys, int* __restrict__ count, short4* __restrict__ wrap, NlGlobal* __restrict__ glob) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= N) return;
   const int s = batch_idx ? batch_idx[i] : 0;
@@ -199,32 +196,32 @@ __global__ void nl_assign_kernel(const T* __restrict__ pos, const int* __restric
     if (S.pbc[d]) floor_divmod(v, S.cpd[d], w[d], c[d]);
     else { w[d] = 0; c[d] = v < 0 ? 0 : (v >= S.cpd[d] ? S.cpd[d] - 1 : v); }
   }
-  keys[i] = S.cell_off + c[0] + S.cpd[0] * (c[1] + S.cpd[1] * c[2]);
-  vals[i] = i;
+  const int key = S.cell_off + c[0] + S.cpd[0] * (c[1] + S.cpd[1] * c[2]);
+  keys[i] = key;
+  atomicAdd(&count[key], 1);  // result unused: a fire-and-forget atomic per atom
   wrap[i] = make_short4((short)w[0], (short)w[1], (short)w[2], 0);
   if (w[0] | w[1] | w[2]) glob->any_wrap = 1;
 }
 
-__global__ void nl_cell_ranges_kernel(const int* __restrict__ keys_sorted, int N, const NlGlobal* __restrict__ glob, long long cap,
-                                      int* __restrict__ cell_start) {
-  long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (c > cap || c > glob->total_cells) return;
-  int lo = 0, hi = N;  // first position with key >= c
-  while (lo < hi) {
-    int mid = (lo + hi) >> 1;
-    if (keys_sorted[mid] < (int)c) lo = mid + 1; else hi = mid;
-  }
-  cell_start[c] = lo;
-}
-
+// Slot p of the counting sort holds some atom of cell c = keys[id]; its final place is start[c] + (number of atoms of the cell
+// with a smaller index): rows come out in ascending atom index inside a cell whatever order the atomics ran in.  The ids of a
+// cell are adjacent, the lanes of a wave sit in one or two cells and read the same addresses (L1 broadcasts).  Same kernel:
+// the cell-ordered record the query streams.
 template <class T>
-__global__ void nl_gather_kernel(const T* __restrict__ pos, const int* __restrict__ vals_sorted, const short4* __restrict__ wrap, int N,
-                                 typename Vec4<T>::type* __restrict__ spos, short4* __restrict__ swrap) {
+__global__ void nl_rank_gather_kernel(const T* __restrict__ pos, const int* __restrict__ ids, const int* __restrict__ keys,
+                                      const int* __restrict__ cell_start, const short4* __restrict__ wrap, int N,
+                                      typename Vec4<T>::type* __restrict__ spos, short4* __restrict__ swrap, int* __restrict__ keys_sorted) {
   int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= N) return;
-  int i = vals_sorted[p];
-  spos[p] = pack4(pos[3 * (size_t)i], pos[3 * (size_t)i + 1], pos[3 * (size_t)i + 2], i);
-  swrap[p] = wrap[i];
+  const int i = ids[p];
+  const int key = keys[i];
+  const int b = cell_start[key], e = cell_start[key + 1];
+  int rank = 0;
+  for (int q = b; q < e; ++q) rank += ids[q] < i ? 1 : 0;
+  const int dst = b + rank;
+  spos[dst] = pack4(pos[3 * (size_t)i], pos[3 * (size_t)i + 1], pos[3 * (size_t)i + 2], i);
+  swrap[dst] = wrap[i];
+  keys_sorted[dst] = key;
 }
 
 struct NlInt3 { int a, b, c; };  // one 12-byte store per hit for the unit shift
@@ -814,7 +811,7 @@ __global__ void nl_cache_binsize_kernel(const T* __restrict__ cell, const uint8_
 template <class T>
 __global__ void nl_cache_assign_kernel(const T* __restrict__ pos, const T* __restrict__ cell, const uint8_t* __restrict__ pbc,
                                        const int* __restrict__ batch_idx, int N, const int* __restrict__ cpd, const int* __restrict__ cell_off,
-                                       int* __restrict__ keys, int* __restrict__ vals, int* __restrict__ atom_shift, int* __restrict__ atom_cell) {
+                                       int* __restrict__ keys, int* __restrict__ counts, int* __restrict__ atom_shift, int* __restrict__ atom_cell) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= N) return;
   const int s = batch_idx ? batch_idx[i] : 0;
@@ -833,20 +830,33 @@ __global__ void nl_cache_assign_kernel(const T* __restrict__ pos, const T* __res
   }
   const int key = cell_off[s] + c[0] + cpd[3 * s] * (c[1] + cpd[3 * s + 1] * c[2]);
   keys[i] = key;
-  vals[i] = i;
+  atomicAdd(&counts[key], 1);  // atoms_per_cell_count, as the reference's count kernel does (cell_list.py:166-276)
 }
-__device__ __forceinline__ int nl_lower_bound(const int* __restrict__ keys_sorted, int N, int c) {
-  int lo = 0, hi = N;
-  while (lo < hi) { int mid = (lo + hi) >> 1; if (keys_sorted[mid] < c) lo = mid + 1; else hi = mid; }
-  return lo;
+// The reference-format cache is the same counting sort written into the caller's arrays: atoms_per_cell_count by atomics,
+// cell_atom_start_indices = its exclusive cumsum (cell_list.py:869-871), cell_atom_list by a scatter through the start array used as
+// a running cursor, then ranked by atom index inside each cell (the reference's order is whatever its atomics produce; ascending
+// here) and the cursor rewound.
+__global__ void nl_cache_add_offsets_kernel(int* __restrict__ starts, const int* __restrict__ block_off, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < C) starts[c] += block_off[c / BS_CHUNK];
 }
-// cell_atom_start_indices = exclusive cumsum of the counts (cell_list.py:869-871); counts = adjacent differences
-__global__ void nl_cache_starts_kernel(const int* __restrict__ keys_sorted, int N, int C, int* __restrict__ starts, int* __restrict__ counts) {
-  int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  const int a = nl_lower_bound(keys_sorted, N, c), b = nl_lower_bound(keys_sorted, N, c + 1);
-  starts[c] = a;
-  counts[c] = b - a;
+__global__ void nl_cache_scatter_kernel(const int* __restrict__ keys, int N, int* __restrict__ cursor, int* __restrict__ ids) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < N) ids[atomicAdd(&cursor[keys[i]], 1)] = i;
+}
+__global__ void nl_cache_rank_kernel(const int* __restrict__ ids, const int* __restrict__ keys, const int* __restrict__ cursor_end,
+                                     const int* __restrict__ counts, int N, int* __restrict__ cell_atoms) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= N) return;
+  const int i = ids[p], key = keys[i];
+  const int e = cursor_end[key], b = e - counts[key];
+  int rank = 0;
+  for (int q = b; q < e; ++q) rank += ids[q] < i ? 1 : 0;
+  cell_atoms[b + rank] = i;
+}
+__global__ void nl_cache_rewind_kernel(int* __restrict__ starts, const int* __restrict__ counts, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < C) starts[c] -= counts[c];
 }
 
 // ---- bounding boxes of non-periodic systems: the "cell" a free-space search bins in (no lattice is given) ---------------------
@@ -946,7 +956,7 @@ int nl_neighbors_impl(const T* pos, int N, const T* cell, const uint8_t* pbc, co
   const T rc2 = (flags & MI_NL_NAIVE_EXPR) ? (T)(cutoff * cutoff) : rc * rc;
 
   if (!(flags & MI_NL_REUSE_GRID)) {
-    mi_timing_begin("nl_build(setup+assign+sort+ranges+gather)", (void*)st);
+    mi_timing_begin("nl_build(setup+assign+binsort+gather)", (void*)st);
     const int* nat = nullptr;
     if (batch_idx && B > 1) {
       MI_HIP_CHECK(hipMemsetAsync(natoms, 0, sizeof(int) * (size_t)B, st));
@@ -956,14 +966,12 @@ int nl_neighbors_impl(const T* pos, int N, const T* cell, const uint8_t* pbc, co
     }
     nl_setup_kernel<T><<<1, 256, 0, st>>>(cell, pbc, nat, N, B, rc, origin, sys, glob);
     MI_LAUNCH_CHECK();
-    nl_assign_kernel<T><<<mi_blocks(N, 256), 256, 0, st>>>(pos, batch_idx, N, sys, keys_in, vals_in, wrap, glob);
+    const BsScratch bins = bs_carve(reinterpret_cast<int*>(ws + L.bins), L.cell_cap + 2);
+    MI_HIP_CHECK(bs_clear(bins, st));
+    nl_assign_kernel<T><<<mi_blocks(N, 256), 256, 0, st>>>(pos, batch_idx, N, sys, keys_in, bins.count, wrap, glob);
     MI_LAUNCH_CHECK();
-    size_t cub_bytes = L.cub_bytes;
-    MI_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(ws + L.cub, cub_bytes, (const int*)keys_in, keys_out, (const int*)vals_in, vals_out, N, 0,
-                                                    nl_key_bits(L.cell_cap), st));
-    nl_cell_ranges_kernel<<<mi_blocks(L.cell_cap + 1, 256), 256, 0, st>>>(keys_out, N, glob, L.cell_cap, cell_start);
-    MI_LAUNCH_CHECK();
-    nl_gather_kernel<T><<<mi_blocks(N, 256), 256, 0, st>>>(pos, vals_out, wrap, N, spos, swrap);
+    MI_HIP_CHECK(bs_sort(bins, keys_in, N, &glob->total_cells, vals_out, cell_start, st));
+    nl_rank_gather_kernel<T><<<mi_blocks(N, 256), 256, 0, st>>>(pos, vals_out, keys_in, cell_start, wrap, N, spos, swrap, keys_out);
     MI_LAUNCH_CHECK();
     mi_timing_end((void*)st);
   }
@@ -995,16 +1003,24 @@ template <class T>
 int nl_cache_impl(const T* pos, int N, const T* cell, const uint8_t* pbc, const int* batch_idx, int B, double cutoff, int C, int* cpd,
                   int* atom_shift, int* atom_cell, int* counts, int* starts, int* cell_atoms, char* ws, const NlLayout& L, hipStream_t st) {
   int* keys_in = reinterpret_cast<int*>(ws + L.keys_in);
-  int* keys_out = reinterpret_cast<int*>(ws + L.keys_out);
-  int* vals_in = reinterpret_cast<int*>(ws + L.vals_in);
+  int* ids = reinterpret_cast<int*>(ws + L.keys_out);
   int* cell_off = reinterpret_cast<int*>(ws + L.cell_start);  // [B+1] scratch (capacity 4N+8B+2 ints)
+  int* block_sum = reinterpret_cast<int*>(ws + L.bins);        // scan scratch: 2 x (C / 4096 + 1) ints
+  const int nblocks = (C + BS_CHUNK - 1) / BS_CHUNK;
+  MI_REQUIRE((size_t)(2 * nblocks + 8) <= bs_scratch_ints(L.cell_cap + 2), "max_total_cells too large for this workspace");
+  int* block_off = block_sum + nblocks + 4;
   nl_cache_binsize_kernel<T><<<1, 256, 0, st>>>(cell, pbc, B, (T)cutoff, C, batch_idx != nullptr, cpd, cell_off);
   MI_LAUNCH_CHECK();
-  nl_cache_assign_kernel<T><<<mi_blocks(N, 256), 256, 0, st>>>(pos, cell, pbc, batch_idx, N, cpd, cell_off, keys_in, vals_in, atom_shift, atom_cell);
+  MI_HIP_CHECK(hipMemsetAsync(counts, 0, sizeof(int) * (size_t)C, st));
+  nl_cache_assign_kernel<T><<<mi_blocks(N, 256), 256, 0, st>>>(pos, cell, pbc, batch_idx, N, cpd, cell_off, keys_in, counts, atom_shift, atom_cell);
   MI_LAUNCH_CHECK();
-  size_t cub_bytes = L.cub_bytes;
-  MI_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(ws + L.cub, cub_bytes, (const int*)keys_in, keys_out, (const int*)vals_in, cell_atoms, N, 0, 31, st));
-  nl_cache_starts_kernel<<<mi_blocks(C, 256), 256, 0, st>>>(keys_out, N, C, starts, counts);
+  MI_HIP_CHECK(hipMemcpyAsync(starts, counts, sizeof(int) * (size_t)C, hipMemcpyDeviceToDevice, st));
+  bs_scan_partial_kernel<<<nblocks, 256, 0, st>>>(starts, nullptr, C, block_sum);
+  bs_scan_blocks_kernel<<<1, 256, 0, st>>>(block_sum, nblocks, block_off);
+  nl_cache_add_offsets_kernel<<<mi_blocks(C, 256), 256, 0, st>>>(starts, block_off, C);
+  nl_cache_scatter_kernel<<<mi_blocks(N, 256), 256, 0, st>>>(keys_in, N, starts, ids);
+  nl_cache_rank_kernel<<<mi_blocks(N, 256), 256, 0, st>>>(ids, keys_in, starts, counts, N, cell_atoms);
+  nl_cache_rewind_kernel<<<mi_blocks(C, 256), 256, 0, st>>>(starts, counts, C);
   MI_LAUNCH_CHECK();
   return MI_OK;
 }

@@ -55,6 +55,12 @@ def lib() -> ctypes.CDLL:
     return _LIB
 
 
+def ewald_sym_words() -> int:
+    L = lib()
+    L.mi_ewald_symmetry_scratch_bytes.restype = ctypes.c_size_t
+    return int(L.mi_ewald_symmetry_scratch_bytes()) // 8
+
+
 def check(rc: int, what: str) -> None:
     if rc != 0:
         raise NativeLibraryError(f"{what} failed (code {rc}): {lib().mi_last_error().decode()}")

@@ -50,7 +50,7 @@ class _EwaldRealEnergyFn(torch.autograd.Function):
         need = ctx.needs_input_grad
         gcell = torch.zeros(c.shape, dtype=torch.float64, device=dev) if need[2] else None
         galpha = torch.zeros(al.shape, dtype=torch.float64, device=dev) if need[3] else None
-        sym = torch.empty(2, dtype=torch.int64, device=dev)  # list-symmetry checksums (zeroed by the library)
+        sym = torch.empty(C.ewald_sym_words(), dtype=torch.int64, device=dev)  # list-symmetry checksums (zeroed by the library)
         rc = C.lib().mi_ewald_real_bwd(C.ptr(pos), C.ptr(q), C.ptr(c), C.ptr(al), C.ptr(bi_t if has_bi else None), n, C.dtype_code(dt),
                                        C.ptr(idx), C.ptr(sh), C.ptr(nptr_t if has_ptr else None), int(m), int(mask_value), C.ptr(g),
                                        C.ptr(gpos), C.ptr(gq), C.ptr(gcell), C.ptr(galpha), C.ptr(sym), C.stream_of(pos))
@@ -113,7 +113,7 @@ def ewald_real_space(positions: torch.Tensor, charges: torch.Tensor, cell: torch
     else:
         flags = (C.EW_FORCES if compute_forces else 0) | (C.EW_CHARGE_GRAD if compute_charge_gradients else 0)
         if flags or not wants_grad:  # with autograd and no explicit outputs the differentiable op below is the only launch needed
-            sym = torch.empty(2, dtype=torch.int64, device=dev) if flags else None  # list-symmetry checksums (zeroed by the library)
+            sym = torch.empty(C.ewald_sym_words(), dtype=torch.int64, device=dev) if flags else None  # list-symmetry checksums (zeroed by the library)
             rc = C.lib().mi_ewald_real(C.ptr(pos), C.ptr(q), C.ptr(cells), C.ptr(alpha_t), C.ptr(bi), n, code, C.ptr(idx), C.ptr(sh), C.ptr(nptr),
                                        int(m), int(mask_value), flags, C.ptr(energies), C.ptr(forces), C.ptr(cgrads), C.ptr(sym), C.stream_of(pos))
             C.check(rc, "mi_ewald_real")

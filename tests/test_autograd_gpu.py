@@ -153,8 +153,8 @@ def test_real_space_adjoint_on_a_half_list_vs_finite_differences():
         e = ewald_real_space(p, c, tc[None], alpha, neighbor_list=lst, neighbor_ptr=nptr, neighbor_shifts=lsh)
         return (w * e).sum()
 
-    tp = torch.as_tensor(pos, device=DEV, requires_grad=True)
-    tq = torch.as_tensor(q, device=DEV, requires_grad=True)
+    tp = torch.tensor(pos, device=DEV, requires_grad=True)
+    tq = torch.tensor(q, device=DEV, requires_grad=True)
     loss(tp, tq).backward()
     h = 1e-5
     for (i, d) in ((3, 0), (17, 2), (39, 1)):
