@@ -235,9 +235,16 @@ int mi_coulomb_bwd(const double* positions, const double* charges, const double*
 /* Per-system cell geometry for the mesh ops in one launch: cell_inv_t = (cell^-1)^T, reciprocal_cell = 2 pi cell^-1, volume = |det|
  * (the torch.linalg.inv_ex / det calls of `_pme_reciprocal_space_impl`, pme.py:1382-1395).  All [n_systems,...] in `dtype`.       */
 int mi_cell_geometry(const void* cell, int n_systems, int dtype, void* cell_inv_t, void* reciprocal_cell, void* volume, void* stream);
+/* The same plus total_charge[s] = sum of the charges of system s (charges.sum() / scatter_add_, pme.py:1225,1241-1244) in ONE launch
+ * (total_charge is zeroed by the library): everything the fused PME step needs before the spread.                                  */
+int mi_pme_prepare(const void* cell, const void* charges, const int32_t* batch_idx, int n_atoms, int n_systems, int dtype,
+                   void* cell_inv_t, void* reciprocal_cell, void* volume, void* total_charge /*[n_systems]*/, void* stream);
+/* 1 when mi_spline_spread (given its workspace) runs tile-owned for this mesh / order: every mesh point is then written, so the
+ * caller may skip the zero-fill of `mesh`.                                                                                          */
+int mi_spline_spread_is_tiled(int n_systems, int nx, int ny, int nz, int order);
 int mi_spline_spread(const void* positions, const void* values, const int32_t* batch_idx,
                      const void* cell_inv_t /*[n_systems,3,3]*/, int n_atoms, int n_systems, int nx, int ny,
-                     int nz, int order, int batched, int dtype, void* mesh /* zeroed by caller */,
+                     int nz, int order, int batched, int dtype, void* mesh /* zeroed by caller unless mi_spline_spread_is_tiled */,
                      void* workspace /* mi_spline_spread_workspace_bytes, or NULL */, size_t workspace_bytes, void* stream);
 /* With a workspace the spread runs tile-owned when every mesh dimension has a divisor e with max(order - 1, 2) <= e <= 8 (atoms
  * binned by ex*ey*ez mesh tile, LDS accumulation, every mesh point written once, no global atomics); otherwise order^2 threads per
@@ -265,7 +272,9 @@ int mi_spline_gather_grad(const void* positions, const void* mesh, const int32_t
  *   `sf_exponent` in both: power of the sinc product before squaring -- the reference uses min(order, 4)
  *   (pme_kernels.py:213-225); this build passes `order` for its true order-5/6 splines.
  * mi_pme_gather_finish: spline_gather + pme_energy_corrections[_with_charge_grad] + gather_vec3 + "x2"
- *   (pme.py:1429-1477; pme_kernels.py:340-657) fused over the 4 planar real-space meshes.
+ *   (pme.py:1429-1477; pme_kernels.py:340-657) fused over the 4 planar real-space meshes.  add_energies / add_forces /
+ *   add_charge_grads (NULL ok): the real-space part (mi_ewald_real outputs: float64 energies and charge gradients, forces in
+ *   `dtype`) added in the epilogue -- the `real + reciprocal` sums of particle_mesh_ewald (pme.py:1975-1990).
  */
 int mi_pme_green_sf(const void* k_squared /*[B,nx,ny,nzr]*/, const void* alpha /*[B]*/, const void* volume /*[B]*/,
                     int n_systems, int nx, int ny, int nz, int sf_exponent, int dtype, void* green /*[B,nx,ny,nzr]*/,
@@ -277,7 +286,8 @@ int mi_pme_gather_finish(const void* positions, const void* charges, const int32
                          const void* meshes /*[B,(1|4),nx,ny,nz] real*/, const void* alpha, const void* volume,
                          const void* total_charge /*[B]*/, int n_atoms, int n_systems, int nx, int ny, int nz,
                          int order, int with_field, int dtype, void* energies /*[n_atoms]*/,
-                         void* forces /*[n_atoms,3] or NULL*/, void* charge_grads /*[n_atoms] or NULL*/, void* stream);
+                         void* forces /*[n_atoms,3] or NULL*/, void* charge_grads /*[n_atoms] or NULL*/,
+                         const double* add_energies, const void* add_forces, const double* add_charge_grads, void* stream);
 int mi_pme_corrections(const void* raw, const void* charges, const int32_t* batch_idx, const void* volume,
                        const void* alpha, const void* total_charge, int n_atoms, int dtype, void* energies,
                        void* charge_grads /*NULL ok*/, void* stream);

@@ -266,6 +266,38 @@ __global__ void cell_geometry_kernel(const T* __restrict__ cell, int B, T* __res
   vol[s] = det < T(0) ? -det : det;
 }
 
+// geometry of every system AND the per-system total charge in one launch (threads < B: geometry; all threads: wave-reduced charge
+// sums, one atomic per wave and system) -- replaces mi_cell_geometry + a zero-fill + mi_segment_sum in the fused PME step
+template <class T>
+__global__ __launch_bounds__(256) void pme_prepare_kernel(const T* __restrict__ cell, const T* __restrict__ charges, const int* __restrict__ batch_idx,
+                                                          int N, int B, T* __restrict__ cit, T* __restrict__ recip, T* __restrict__ vol,
+                                                          T* __restrict__ qtot /*zeroed*/) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < B) {
+    const T* a = cell + 9 * (size_t)t;
+    T inv[9];
+    inverse3(a, inv);
+    const T det = a[0] * (a[4] * a[8] - a[5] * a[7]) - a[1] * (a[3] * a[8] - a[5] * a[6]) + a[2] * (a[3] * a[7] - a[4] * a[6]);
+    for (int r = 0; r < 3; ++r)
+      for (int c = 0; c < 3; ++c) {
+        cit[9 * (size_t)t + 3 * r + c] = inv[3 * c + r];
+        recip[9 * (size_t)t + 3 * r + c] = (T)(2.0 * M_PI) * inv[3 * r + c];
+      }
+    vol[t] = det < T(0) ? -det : det;
+  }
+  const int lane = threadIdx.x & (MI_WAVE - 1);
+  const bool in = t < N;
+  const int s = in ? (batch_idx ? batch_idx[t] : 0) : -1;
+  const int s0 = __shfl(s, 0, MI_WAVE);
+  T x = in ? charges[t] : T(0);
+  if (__all(!in || s == s0)) {
+    x = wave_sum(x);
+    if (lane == 0 && s0 >= 0) atomicAdd(&qtot[s0], x);
+  } else if (in) {
+    atomicAdd(&qtot[s], x);
+  }
+}
+
 // ---- gathers (one thread per atom, z innermost) -----------------------------------------------------------
 // CH = 1: scalar mesh [B,nx,ny,nz] -> out[N];  CH = 3: interleaved mesh [B,nx,ny,nz,3] times charge -> out[N,3]
 template <class T, int CH>
@@ -341,7 +373,8 @@ template <class T>
 __global__ void pme_gather_finish_kernel(const T* __restrict__ pos, const T* __restrict__ charges, const int* __restrict__ batch_idx,
                                          const T* __restrict__ cit, const T* __restrict__ meshes, const T* __restrict__ alpha,
                                          const T* __restrict__ volume, const T* __restrict__ qtot, int N, int nx, int ny, int nz, int order,
-                                         int with_field, T* __restrict__ energies, T* __restrict__ forces, T* __restrict__ cgrads) {
+                                         int with_field, T* __restrict__ energies, T* __restrict__ forces, T* __restrict__ cgrads,
+                                         const double* __restrict__ add_e, const T* __restrict__ add_f, const double* __restrict__ add_cg) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= N) return;
   const int s = batch_idx ? batch_idx[i] : 0;
@@ -378,10 +411,17 @@ __global__ void pme_gather_finish_kernel(const T* __restrict__ pos, const T* __r
   // `_pme_energy_corrections[_with_charge_grad]_kernel` (pme_kernels.py:340-657)
   const T pi = T(3.14159265358979323846), two = 2;
   const T a = alpha[s], vol = volume[s], qt = qtot[s];
-  energies[i] = q * phi - q * q * a / sqrt(pi) - q * pi * qt / (two * a * a * vol);
-  if (cgrads) cgrads[i] = two * phi - two * a * q / sqrt(pi) - pi * qt / (a * a * vol);
+  // add_*: the real-space part of particle_mesh_ewald (pme.py:1975-1990 adds real + reciprocal with torch; real-space energies and
+  // charge gradients arrive in float64 and are cast to the output dtype first, as `.to(dtype)` does there)
+  const T er = q * phi - q * q * a / sqrt(pi) - q * pi * qt / (two * a * a * vol);
+  energies[i] = add_e ? (T)add_e[i] + er : er;
+  if (cgrads) { const T cr = two * phi - two * a * q / sqrt(pi) - pi * qt / (a * a * vol); cgrads[i] = add_cg ? (T)add_cg[i] + cr : cr; }
   if (with_field && forces) {  // forces = 2 * gather_vec3 (pme.py:1477)
-    forces[3 * (size_t)i] = two * ex; forces[3 * (size_t)i + 1] = two * ey; forces[3 * (size_t)i + 2] = two * ez;
+    const T fx = two * ex, fy = two * ey, fz = two * ez;
+    if (add_f) {
+      forces[3 * (size_t)i] = add_f[3 * (size_t)i] + fx; forces[3 * (size_t)i + 1] = add_f[3 * (size_t)i + 1] + fy;
+      forces[3 * (size_t)i + 2] = add_f[3 * (size_t)i + 2] + fz;
+    } else { forces[3 * (size_t)i] = fx; forces[3 * (size_t)i + 1] = fy; forces[3 * (size_t)i + 2] = fz; }
   }
 }
 
@@ -531,6 +571,26 @@ int mi_cell_geometry(const void* cell, int n_systems, int dtype, void* cell_inv_
   return MI_OK;
 }
 
+int mi_pme_prepare(const void* cell, const void* charges, const int32_t* batch_idx, int n_atoms, int n_systems, int dtype, void* cell_inv_t,
+                   void* reciprocal_cell, void* volume, void* total_charge, void* stream) {
+  MI_REQUIRE(dtype == MI_F32 || dtype == MI_F64, "dtype");
+  MI_REQUIRE(n_systems >= 1 && cell && cell_inv_t && reciprocal_cell && volume && total_charge, "null pointer");
+  MI_REQUIRE(n_atoms == 0 || charges, "charges");
+  hipStream_t st = (hipStream_t)stream;
+  MI_HIP_CHECK(hipMemsetAsync(total_charge, 0, (dtype == MI_F32 ? 4 : 8) * (size_t)n_systems, st));
+  const int threads = n_atoms > n_systems ? n_atoms : n_systems;
+  MI_DISPATCH_T(dtype, (pme_prepare_kernel<T_><<<mi_blocks(threads, 256), 256, 0, st>>>((const T_*)cell, (const T_*)charges, batch_idx, n_atoms, n_systems,
+                                                                                         (T_*)cell_inv_t, (T_*)reciprocal_cell, (T_*)volume,
+                                                                                         (T_*)total_charge)));
+  MI_LAUNCH_CHECK();
+  return MI_OK;
+}
+
+/* 1 when mi_spline_spread runs tile-owned for this mesh / order (every mesh point is then WRITTEN: the mesh needs no zero-fill) */
+int mi_spline_spread_is_tiled(int n_systems, int nx, int ny, int nz, int order) {
+  return (nx > 0 && ny > 0 && nz > 0 && n_systems >= 1 && order >= 1 && order <= MI_MAX_ORDER && sp_tiled_ok(nx, ny, nz, n_systems, order)) ? 1 : 0;
+}
+
 size_t mi_spline_spread_workspace_bytes(int n_atoms, int n_systems, int nx, int ny, int nz) {
   if (n_atoms < 0 || n_systems < 1 || nx <= 0 || ny <= 0 || nz <= 0) return 0;
   if (!sp_tiled_ok(nx, ny, nz, n_systems, 0)) return 256;  // the atomic kernel needs no scratch
@@ -642,7 +702,8 @@ int mi_pme_convolve(const void* spec, const void* recip_cell, const void* alpha,
 
 int mi_pme_gather_finish(const void* positions, const void* charges, const int32_t* batch_idx, const void* cell_inv_t, const void* meshes,
                          const void* alpha, const void* volume, const void* total_charge, int n_atoms, int n_systems, int nx, int ny, int nz,
-                         int order, int with_field, int dtype, void* energies, void* forces, void* charge_grads, void* stream) {
+                         int order, int with_field, int dtype, void* energies, void* forces, void* charge_grads, const double* add_energies,
+                         const void* add_forces, const double* add_charge_grads, void* stream) {
   MI_REQUIRE(dtype == MI_F32 || dtype == MI_F64, "dtype");
   MI_REQUIRE(order >= 1 && order <= MI_MAX_ORDER, "spline order must be 1..6");
   (void)n_systems;
@@ -653,7 +714,7 @@ int mi_pme_gather_finish(const void* positions, const void* charges, const int32
   MI_DISPATCH_T(dtype, (pme_gather_finish_kernel<T_><<<mi_blocks(n_atoms, 128), 128, 0, st>>>(
                            (const T_*)positions, (const T_*)charges, batch_idx, (const T_*)cell_inv_t, (const T_*)meshes, (const T_*)alpha,
                            (const T_*)volume, (const T_*)total_charge, n_atoms, nx, ny, nz, order, with_field, (T_*)energies, (T_*)forces,
-                           (T_*)charge_grads)));
+                           (T_*)charge_grads, add_energies, (const T_*)add_forces, add_charge_grads)));
   mi_timing_end(stream);
   MI_LAUNCH_CHECK();
   return MI_OK;

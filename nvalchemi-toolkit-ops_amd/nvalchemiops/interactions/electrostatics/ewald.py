@@ -59,6 +59,48 @@ class _EwaldRealEnergyFn(torch.autograd.Function):
                 None if galpha is None else galpha.to(dt), None, None, None, None, None, None, None)
 
 
+def _real_space_inputs(positions, charges, cell, alpha, neighbor_list, neighbor_ptr, neighbor_shifts, neighbor_matrix, neighbor_matrix_shifts,
+                       batch_idx):
+    """Argument checks (ewald.py:2460-2470 messages) and the detached, contiguous launch tensors of the real-space sum."""
+    if neighbor_list is None and neighbor_matrix is None:
+        raise ValueError("Either neighbor_list or neighbor_matrix must be provided")
+    if neighbor_list is not None and neighbor_ptr is None:
+        raise ValueError("neighbor_ptr is required when using neighbor_list format")
+    dev, dt = positions.device, positions.dtype
+    C.dtype_code(dt)
+    C.require_device(positions, charges, cell, neighbor_list, neighbor_ptr, neighbor_shifts, neighbor_matrix, neighbor_matrix_shifts, batch_idx)
+    alpha_in = alpha if isinstance(alpha, torch.Tensor) else torch.tensor([float(alpha)], device=dev)
+    alpha_in = alpha_in.to(device=dev, dtype=dt).reshape(-1)
+    if alpha_in.numel() == 1 and cell.reshape(-1, 3, 3).shape[0] > 1:
+        alpha_in = alpha_in.expand(cell.reshape(-1, 3, 3).shape[0])
+    if neighbor_list is not None:
+        idx, nptr, m = C.i32(neighbor_list[1]), C.i32(neighbor_ptr), 0
+        sh, n_entries = neighbor_shifts, idx.shape[0]
+    else:
+        idx, nptr, m = C.i32(neighbor_matrix), None, neighbor_matrix.shape[1]
+        sh, n_entries = neighbor_matrix_shifts, idx.numel()
+    sh = torch.zeros((n_entries, 3), dtype=torch.int32, device=dev) if sh is None else C.i32(sh)
+    return dict(pos=positions.detach().contiguous(), q=charges.detach().to(dt).contiguous(), cells=cell.detach().to(dt).reshape(-1, 3, 3).contiguous(),
+                alpha=alpha_in.detach().contiguous(), alpha_in=alpha_in, bi=None if batch_idx is None else C.i32(batch_idx), idx=idx, sh=sh,
+                nptr=nptr, m=m, n_entries=n_entries)
+
+
+def _real_space_launch(p, mask_value: int, compute_forces: bool, compute_charge_gradients: bool):
+    """One launch of the real-space family: (float64 energies, forces in the input dtype | None, float64 charge gradients | None)."""
+    pos = p["pos"]
+    n, dev, dt = pos.shape[0], pos.device, pos.dtype
+    energies = torch.empty(n, dtype=torch.float64, device=dev)
+    forces = torch.empty((n, 3), dtype=dt, device=dev) if compute_forces else None
+    cgrads = torch.empty(n, dtype=torch.float64, device=dev) if compute_charge_gradients else None
+    flags = (C.EW_FORCES if compute_forces else 0) | (C.EW_CHARGE_GRAD if compute_charge_gradients else 0)
+    sym = torch.empty(C.ewald_sym_words(), dtype=torch.int64, device=dev) if flags else None  # list-symmetry checksums (zeroed by the library)
+    rc = C.lib().mi_ewald_real(C.ptr(pos), C.ptr(p["q"]), C.ptr(p["cells"]), C.ptr(p["alpha"]), C.ptr(p["bi"]), n, C.dtype_code(dt), C.ptr(p["idx"]),
+                               C.ptr(p["sh"]), C.ptr(p["nptr"]), int(p["m"]), int(mask_value), flags, C.ptr(energies), C.ptr(forces), C.ptr(cgrads),
+                               C.ptr(sym), C.stream_of(pos))
+    C.check(rc, "mi_ewald_real")
+    return energies, forces, cgrads
+
+
 @C.eager
 def ewald_real_space(positions: torch.Tensor, charges: torch.Tensor, cell: torch.Tensor, alpha: torch.Tensor,
                      neighbor_list: torch.Tensor | None = None, neighbor_ptr: torch.Tensor | None = None,
@@ -75,53 +117,32 @@ def ewald_real_space(positions: torch.Tensor, charges: torch.Tensor, cell: torch
     if neighbor_list is not None and neighbor_ptr is None:
         raise ValueError("neighbor_ptr is required when using neighbor_list format")
     n, dev, dt = positions.shape[0], positions.device, positions.dtype
-    code = C.dtype_code(dt)
     if n == 0:
+        C.dtype_code(dt)
         out = (torch.zeros(0, dtype=dt, device=dev),)
         if compute_forces:
             out += (torch.zeros((0, 3), dtype=dt, device=dev),)
         if compute_charge_gradients:
             out += (torch.zeros(0, dtype=dt, device=dev),)
         return out if len(out) > 1 else out[0]
-    C.require_device(positions, charges, cell, neighbor_list, neighbor_ptr, neighbor_shifts, neighbor_matrix, neighbor_matrix_shifts, batch_idx)
-    alpha_in = alpha if isinstance(alpha, torch.Tensor) else torch.tensor([float(alpha)], device=dev)
-    alpha_in = alpha_in.to(device=dev, dtype=dt).reshape(-1)
-    if alpha_in.numel() == 1 and cell.reshape(-1, 3, 3).shape[0] > 1:
-        alpha_in = alpha_in.expand(cell.reshape(-1, 3, 3).shape[0])
-    wants_grad = torch.is_grad_enabled() and any(t.requires_grad for t in (positions, charges, cell, alpha_in))
-    pos = positions.detach().contiguous()
-    q = charges.detach().to(dt).contiguous()
-    cells = cell.detach().to(dt).reshape(-1, 3, 3).contiguous()
-    alpha_t = alpha_in.detach().contiguous()
-    bi = None if batch_idx is None else C.i32(batch_idx)
-    if neighbor_list is not None:
-        idx, nptr, m = C.i32(neighbor_list[1]), C.i32(neighbor_ptr), 0
-        sh = neighbor_shifts
-        n_entries = idx.shape[0]
+    p = _real_space_inputs(positions, charges, cell, alpha, neighbor_list, neighbor_ptr, neighbor_shifts, neighbor_matrix, neighbor_matrix_shifts,
+                           batch_idx)
+    wants_grad = torch.is_grad_enabled() and any(t.requires_grad for t in (positions, charges, cell, p["alpha_in"]))
+    explicit = compute_forces or compute_charge_gradients
+    energies = forces = cgrads = None
+    if p["n_entries"] == 0:
+        energies = torch.zeros(n, dtype=torch.float64, device=dev)
+        forces = torch.zeros((n, 3), dtype=dt, device=dev) if compute_forces else None
+        cgrads = torch.zeros(n, dtype=torch.float64, device=dev) if compute_charge_gradients else None
+    elif explicit or not wants_grad:  # with autograd and no explicit outputs the differentiable op below is the only launch needed
+        energies, forces, cgrads = _real_space_launch(p, mask_value, compute_forces, compute_charge_gradients)
+    if wants_grad and p["n_entries"] > 0:
+        # differentiable energies (explicit forces / charge gradients above stay plain outputs, as MD codes consume them); the float64
+        # energies of the launch above, if there was one, are handed over instead of being recomputed
+        e_out = _EwaldRealEnergyFn.apply(positions, charges.to(dt), cell.to(dt).reshape(-1, 3, 3), p["alpha_in"], p["idx"], p["sh"], p["nptr"],
+                                         p["m"], mask_value, p["bi"], energies)
     else:
-        idx, nptr, m = C.i32(neighbor_matrix), None, neighbor_matrix.shape[1]
-        sh = neighbor_matrix_shifts
-        n_entries = idx.numel()
-    sh = torch.zeros((n_entries, 3), dtype=torch.int32, device=dev) if sh is None else C.i32(sh)
-    energies = torch.empty(n, dtype=torch.float64, device=dev)
-    forces = torch.empty((n, 3), dtype=dt, device=dev) if compute_forces else None
-    cgrads = torch.empty(n, dtype=torch.float64, device=dev) if compute_charge_gradients else None
-    if n_entries == 0:
-        energies.zero_()
-        forces = None if forces is None else forces.zero_()
-        cgrads = None if cgrads is None else cgrads.zero_()
-    else:
-        flags = (C.EW_FORCES if compute_forces else 0) | (C.EW_CHARGE_GRAD if compute_charge_gradients else 0)
-        if flags or not wants_grad:  # with autograd and no explicit outputs the differentiable op below is the only launch needed
-            sym = torch.empty(C.ewald_sym_words(), dtype=torch.int64, device=dev) if flags else None  # list-symmetry checksums (zeroed by the library)
-            rc = C.lib().mi_ewald_real(C.ptr(pos), C.ptr(q), C.ptr(cells), C.ptr(alpha_t), C.ptr(bi), n, code, C.ptr(idx), C.ptr(sh), C.ptr(nptr),
-                                       int(m), int(mask_value), flags, C.ptr(energies), C.ptr(forces), C.ptr(cgrads), C.ptr(sym), C.stream_of(pos))
-            C.check(rc, "mi_ewald_real")
-    e_out = energies.to(dt) if not (wants_grad and n_entries > 0) else None  # ewald.py:577: float64 accumulation, input dtype out
-    if wants_grad and n_entries > 0:
-        # differentiable energies (explicit forces / charge gradients above stay plain outputs, as MD codes consume them)
-        e_out = _EwaldRealEnergyFn.apply(positions, charges.to(dt), cell.to(dt).reshape(-1, 3, 3), alpha_in, idx, sh, nptr, m, mask_value, bi,
-                                         energies if flags else None)
+        e_out = energies.to(dt)  # ewald.py:577: energies are accumulated in float64 and returned in the input dtype
     out = (e_out,)
     if compute_forces:
         out += (forces,)

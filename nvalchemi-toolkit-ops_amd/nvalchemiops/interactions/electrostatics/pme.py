@@ -14,12 +14,13 @@ SURVEY F2) with the reference's structure-factor exponent min(order, 4) kept (F3
 """
 from __future__ import annotations
 
+import functools
 import math
 
 import torch
 
 from nvalchemiops import _capi as C
-from nvalchemiops.interactions.electrostatics.ewald import ewald_real_space
+from nvalchemiops.interactions.electrostatics.ewald import _real_space_inputs, _real_space_launch, ewald_real_space
 from nvalchemiops.interactions.electrostatics.parameters import (estimate_pme_mesh_dimensions, estimate_pme_parameters,
                                                                  mesh_spacing_to_dimensions)
 from nvalchemiops.spline import _launch_spread, spline_gather, spline_gather_vec3, spline_spread
@@ -27,10 +28,16 @@ from nvalchemiops.spline import _launch_spread, spline_gather, spline_gather_vec
 TWOPI = 2.0 * math.pi
 
 
+@functools.lru_cache(maxsize=64)
+def _alpha_constant(value: float, num_systems: int, dtype: torch.dtype, device: torch.device) -> torch.Tensor:
+    # a Python-float alpha becomes the same read-only device tensor on every call of an MD loop: no fill kernel per step
+    return torch.full((num_systems,), value, dtype=dtype, device=device)
+
+
 def _prepare_alpha(alpha: float | torch.Tensor, num_systems: int, dtype: torch.dtype, device: torch.device) -> torch.Tensor:
     """float | 0-d tensor | (B,) tensor -> (B,) tensor (pme.py:191-229)."""
     if isinstance(alpha, (int, float)):
-        return torch.full((num_systems,), float(alpha), dtype=dtype, device=device)
+        return _alpha_constant(float(alpha), int(num_systems), dtype, torch.device(device))
     if isinstance(alpha, torch.Tensor):
         if alpha.dim() == 0:
             return alpha.expand(num_systems).to(dtype=dtype, device=device)
@@ -106,8 +113,9 @@ def pme_energy_corrections_with_charge_grad(raw_energies, charges, cell, alpha, 
     return _corrections(raw_energies, charges, cell, alpha, batch_idx, True)
 
 
-def _reciprocal_fused(pos, q, cells, alpha, mesh_dimensions, spline_order, bi, compute_forces, compute_charge_gradients):
-    """The MI355X path: k-space algebra and the gather epilogue fused (k evaluated in registers)."""
+def _reciprocal_fused(pos, q, cells, alpha, mesh_dimensions, spline_order, bi, compute_forces, compute_charge_gradients, add=(None, None, None)):
+    """The MI355X path: k-space algebra and the gather epilogue fused (k evaluated in registers).  `add` = (float64 energies, forces,
+    float64 charge gradients) of the real-space sum, added in the gather epilogue (particle_mesh_ewald's `real + reciprocal`)."""
     dt, dev = pos.dtype, pos.device
     code = C.dtype_code(dt)
     n = pos.shape[0]
@@ -118,7 +126,10 @@ def _reciprocal_fused(pos, q, cells, alpha, mesh_dimensions, spline_order, bi, c
     cc = cells.to(dt).contiguous()
     cit, recip = torch.empty_like(cc), torch.empty_like(cc)
     vol = torch.empty(cc.shape[0], dtype=dt, device=dev)
-    C.check(C.lib().mi_cell_geometry(C.ptr(cc), cc.shape[0], code, C.ptr(cit), C.ptr(recip), C.ptr(vol), st), "mi_cell_geometry")
+    qtot = torch.empty(cc.shape[0], dtype=dt, device=dev)
+    # cell^-T, 2 pi cell^-1, |det| and the per-system total charge: one launch
+    C.check(C.lib().mi_pme_prepare(C.ptr(cc), C.ptr(q), C.ptr(bi), n, cc.shape[0], code, C.ptr(cit), C.ptr(recip), C.ptr(vol), C.ptr(qtot), st),
+            "mi_pme_prepare")
     al = alpha.to(dt).contiguous()
     mesh = _launch_spread(pos, q, cit, bi, nsys, (nx, ny, nz), int(spline_order), batched)
     spec = torch.fft.rfftn(mesh, norm="backward", dim=(1, 2, 3))  # unscaled forward (pme.py:1398)
@@ -128,12 +139,13 @@ def _reciprocal_fused(pos, q, cells, alpha, mesh_dimensions, spline_order, bi, c
                                  C.ptr(conv), st)
     C.check(rc, "mi_pme_convolve")
     real = torch.fft.irfftn(conv, norm="forward", s=(nx, ny, nz), dim=(2, 3, 4)).contiguous()  # unscaled inverse (pme.py:1422)
-    qtot = _total_charge(q, bi, nsys)
     energies = torch.empty(n, dtype=dt, device=dev)
     forces = torch.empty((n, 3), dtype=dt, device=dev) if compute_forces else None
     cgrads = torch.empty(n, dtype=dt, device=dev) if compute_charge_gradients else None
+    add_e, add_f, add_cg = add
     rc = C.lib().mi_pme_gather_finish(C.ptr(pos), C.ptr(q), C.ptr(bi), C.ptr(cit), C.ptr(real), C.ptr(al), C.ptr(vol), C.ptr(qtot), n, nsys, nx,
-                                      ny, nz, int(spline_order), int(compute_forces), code, C.ptr(energies), C.ptr(forces), C.ptr(cgrads), st)
+                                      ny, nz, int(spline_order), int(compute_forces), code, C.ptr(energies), C.ptr(forces), C.ptr(cgrads),
+                                      C.ptr(add_e), C.ptr(add_f if compute_forces else None), C.ptr(add_cg if compute_charge_gradients else None), st)
     C.check(rc, "mi_pme_gather_finish")
     return energies, forces, cgrads
 
@@ -278,6 +290,19 @@ def particle_mesh_ewald(positions: torch.Tensor, charges: torch.Tensor, cell: to
             mesh_dimensions = mesh_spacing_to_dimensions(cells, mesh_spacing)
         else:
             mesh_dimensions = estimate_pme_mesh_dimensions(cells, alpha, accuracy)
+    wants_grad = torch.is_grad_enabled() and any(isinstance(t, torch.Tensor) and t.requires_grad for t in (positions, charges, cell, alpha))
+    if not wants_grad and num_atoms > 0 and (k_vectors is None or k_squared is None):
+        # the whole step on HIP kernels + two FFTs, no torch elementwise pass: the real-space sum hands its float64 energies (and
+        # forces / charge gradients) to the gather epilogue of the reciprocal part, which adds them (pme.py:1975-1990 adds with torch)
+        p = _real_space_inputs(positions, charges, cells, alpha, neighbor_list, neighbor_ptr, neighbor_shifts, neighbor_matrix,
+                               neighbor_matrix_shifts, batch_idx)
+        if p["n_entries"] > 0:
+            add = _real_space_launch(p, mask_value, compute_forces, compute_charge_gradients)
+            mesh_dimensions = tuple(int(v) for v in mesh_dimensions)
+            energies, forces, cgrads = _reciprocal_fused(p["pos"], p["q"], p["cells"], p["alpha"], mesh_dimensions, spline_order, p["bi"],
+                                                         compute_forces, compute_charge_gradients, add=add)
+            out = (energies,) + ((forces,) if compute_forces else ()) + ((cgrads,) if compute_charge_gradients else ())
+            return out if len(out) > 1 else out[0]
     real = ewald_real_space(positions=positions, charges=charges, cell=cells, alpha=alpha, neighbor_list=neighbor_list,
                             neighbor_ptr=neighbor_ptr, neighbor_shifts=neighbor_shifts, neighbor_matrix=neighbor_matrix,
                             neighbor_matrix_shifts=neighbor_matrix_shifts, mask_value=mask_value, batch_idx=batch_idx,

@@ -34,7 +34,9 @@ def _launch_spread(pos, vals, cit, bi, nsys, dims, order, batched):
 
     nx, ny, nz = (int(v) for v in dims)
     n = pos.shape[0]
-    mesh = torch.zeros((nsys, nx, ny, nz), dtype=pos.dtype, device=pos.device)
+    # the tile-owned kernel writes every mesh point exactly once: no zero-fill pass then
+    tiled = n > 0 and bool(C.lib().mi_spline_spread_is_tiled(nsys, nx, ny, nz, int(order)))
+    mesh = (torch.empty if tiled else torch.zeros)((nsys, nx, ny, nz), dtype=pos.dtype, device=pos.device)
     ws_bytes = int(C.lib().mi_spline_spread_workspace_bytes(n, nsys, nx, ny, nz))
     ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=pos.device)
     rc = C.lib().mi_spline_spread(C.ptr(pos), C.ptr(vals), C.ptr(bi), C.ptr(cit), n, nsys, nx, ny, nz, int(order), int(batched),

@@ -1,10 +1,12 @@
 """GPU parity of the HIP DFT-D3(BJ) path against the CPU oracle and the reference's golden vectors.
 
-Tolerances (fp32 pair math, fp64 accumulation on both sides; only the summation order differs):
-  energy  |dE| <= 1e-6 Ha + 2e-6 |E|     forces  <= 1e-6 + 1e-5 |F_i| + 5e-6 max|F|  (the per-atom force is a cancelling
-  sum; the reference accumulates dE/dCN sequentially in fp32, this build in fp64)     CN  <= 1e-6 + 5e-6 CN
-  virial  <= 2e-6 + 1e-5 max|V|
-(reference's own CPU-vs-GPU tolerance: rtol = atol = 1e-6, test/interactions/dispersion/test_dftd3.py:477-489)."""
+Tolerance = the reference's own CPU-vs-GPU bar, rtol = atol = 1e-6 (test/interactions/dispersion/test_dftd3.py:477-489), for energy,
+forces and coordination numbers; for the virial rtol = 1e-6 and atol = 1e-6 + 2e-7 max|V| (a float32 tensor with entries of a few
+hundred has an ulp of 3e-5: an absolute 1e-6 is below the output format's resolution).  The comparison is against the oracle in
+WIDE-SUM mode (`O.d3_wide_sums`): the reference's fp32 pair arithmetic with its fp32 accumulations (sequential CN / dE/dCN sums,
+per-system energy and virial added with fp32 atomics in arbitrary order) carried in double -- i.e. what the reference computes,
+without its summation-order noise, which by itself exceeds this bar (virial: 4.8e-5 relative on a 4000-atom box; the error budget
+test at the end of this file measures it next to the product's error and that of an IEEE-arithmetic build of the kernels)."""
 import numpy as np
 import pytest
 import torch
@@ -35,12 +37,17 @@ def _close(got, ref, rtol, atol, what):
     assert (err <= bound).all(), f"{what}: max err {err.max():.3e} (bound {bound.flat[err.argmax()]:.3e})"
 
 
+def _wide(*args, **kw):
+    with O.d3_wide_sums():
+        return O.dftd3(*args, **kw)
+
+
 def _check(out, ref, virial=False):
-    _close(out[0], ref[0], 2e-6, 1e-6, "energy")
-    _close(out[1], ref[1], 1e-5, 1e-6 + 5e-6 * np.abs(ref[1]).max(), "forces")
-    _close(out[2], ref[2], 5e-6, 1e-6, "coord_num")
+    _close(out[0], ref[0], 1e-6, 1e-6, "energy")
+    _close(out[1], ref[1], 1e-6, 1e-6, "forces")
+    _close(out[2], ref[2], 1e-6, 1e-6, "coord_num")
     if virial:
-        _close(out[3], ref[3], 1e-5, 2e-6 + 1e-5 * np.abs(ref[3]).max(), "virial")
+        _close(out[3], ref[3], 1e-6, 1e-6 + 2e-7 * np.abs(ref[3]).max(), "virial")
 
 
 def test_golden_ne2_hcl():
@@ -80,13 +87,13 @@ def test_small_molecules_and_edge_cases():
     cases.append((np.array([[0, 0, 0], [1.5, 0, 0], [3.0, 0.2, 0]], np.float32), [8, 0, 1], np.array([[1, 2, 3], [0, 2, 3], [0, 1, 3]], np.int32)))  # padding atom
     for pos, z, nm in cases:
         z = np.array(z, np.int32)
-        ref = O.dftd3(pos, z, t, neighbor_matrix=nm, **FP)
+        ref = _wide(pos, z, t, neighbor_matrix=nm, **FP)
         out = dftd3(_t(pos), _t(z), d3_params=p, neighbor_matrix=_t(nm), **FP)
         _check(out, ref)
     # S5 switching window active
     pos, z, nm = cases[2]
     z = np.array(z, np.int32)
-    ref = O.dftd3(pos, z, t, neighbor_matrix=nm, s5_on=1.0, s5_off=3.5, **FP)
+    ref = _wide(pos, z, t, neighbor_matrix=nm, s5_on=1.0, s5_off=3.5, **FP)
     out = dftd3(_t(pos), _t(z), d3_params=p, neighbor_matrix=_t(nm), s5_smoothing_on=1.0, s5_smoothing_off=3.5, **FP)
     _check(out, ref)
 
@@ -104,11 +111,11 @@ def test_periodic_with_virial(dtype, fmt):
     if fmt == "matrix":
         nm, num, sh = cell_list(_t(pos), 14.0, _t(cell), pbc, max_neighbors=320)
         assert int(num.max()) <= 320
-        ref = O.dftd3(pos, z, t, neighbor_matrix=nm.cpu().numpy(), neighbor_matrix_shifts=sh.cpu().numpy(), cell=cell, compute_virial=True, **FP)
+        ref = _wide(pos, z, t, neighbor_matrix=nm.cpu().numpy(), neighbor_matrix_shifts=sh.cpu().numpy(), cell=cell, compute_virial=True, **FP)
         out = dftd3(_t(pos), _t(z), d3_params=p, neighbor_matrix=nm, neighbor_matrix_shifts=sh, cell=_t(cell)[None], compute_virial=True, **FP)
     else:
         lst, nptr, lsh = cell_list(_t(pos), 14.0, _t(cell), pbc, return_neighbor_list=True)
-        ref = O.dftd3(pos, z, t, idx_j=lst[1].cpu().numpy(), neighbor_ptr=nptr.cpu().numpy(), unit_shifts=lsh.cpu().numpy(), cell=cell,
+        ref = _wide(pos, z, t, idx_j=lst[1].cpu().numpy(), neighbor_ptr=nptr.cpu().numpy(), unit_shifts=lsh.cpu().numpy(), cell=cell,
                       compute_virial=True, **FP)
         out = dftd3(_t(pos), _t(z), d3_params=p, neighbor_list=lst, neighbor_ptr=nptr, unit_shifts=lsh, cell=_t(cell)[None],
                     compute_virial=True, **FP)
@@ -131,7 +138,7 @@ def test_batch_equals_individual_and_oracle():
     pos, cell, bi, z = np.concatenate(parts), np.stack(cells), np.concatenate(bis), np.concatenate(zs)
     nm, num, sh = batch_cell_list(_t(pos), 12.0, _t(cell), torch.ones((4, 3), dtype=torch.bool, device=DEV), _t(bi), max_neighbors=400)
     assert int(num.max()) <= 400
-    ref = O.dftd3(pos, z, t, neighbor_matrix=nm.cpu().numpy(), neighbor_matrix_shifts=sh.cpu().numpy(), cell=cell, batch_idx=bi,
+    ref = _wide(pos, z, t, neighbor_matrix=nm.cpu().numpy(), neighbor_matrix_shifts=sh.cpu().numpy(), cell=cell, batch_idx=bi,
                   compute_virial=True, **FP)
     out = dftd3(_t(pos), _t(z), d3_params=p, neighbor_matrix=nm, neighbor_matrix_shifts=sh, cell=_t(cell), batch_idx=_t(bi),
                 compute_virial=True, **FP)
@@ -182,10 +189,10 @@ def test_config3_molecule_batch_full_size():
     fs = torch.zeros((nmol, 3), device=DEV).index_add_(0, tb.long(), f)
     assert fs.abs().max().item() < 5e-5
     # the FULL batch against the oracle (67 M directed pairs, ~8 s of oracle time): energies per molecule, forces, coordination numbers
-    ref = O.dftd3(pos, z, t, idx_j=lst[1].cpu().numpy(), neighbor_ptr=nptr.cpu().numpy(), batch_idx=bi, num_systems=nmol, **bj)
-    _close(e, ref[0], 2e-6, 1e-6, "energy")
-    _close(f, ref[1], 1e-5, 1e-6 + 5e-6 * np.abs(ref[1]).max(), "forces")
-    _close(cn, ref[2], 5e-6, 1e-6, "cn")
+    ref = _wide(pos, z, t, idx_j=lst[1].cpu().numpy(), neighbor_ptr=nptr.cpu().numpy(), batch_idx=bi, num_systems=nmol, **bj)
+    _close(e, ref[0], 1e-6, 1e-6, "energy")
+    _close(f, ref[1], 1e-6, 1e-6, "forces")
+    _close(cn, ref[2], 1e-6, 1e-6, "cn")
     # replicas of the same molecule (translated) have the same energy
     assert torch.allclose(e[0::4], e[0].expand_as(e[0::4]), rtol=2e-5)
     # matrix format gives the same answer
@@ -220,7 +227,7 @@ def test_c6_table_structures(kind):
     z = g.choice(np.array([1, 6, 8, 17], np.int32), 160)
     nm, num, sh = cell_list(_t(pos), 13.0, _t(cell), torch.tensor([True] * 3, device=DEV), max_neighbors=320)
     assert int(num.max()) <= 320
-    ref = O.dftd3(pos, z, t, neighbor_matrix=nm.cpu().numpy(), neighbor_matrix_shifts=sh.cpu().numpy(), cell=cell, compute_virial=True, **FP)
+    ref = _wide(pos, z, t, neighbor_matrix=nm.cpu().numpy(), neighbor_matrix_shifts=sh.cpu().numpy(), cell=cell, compute_virial=True, **FP)
     out = dftd3(_t(pos), _t(z), d3_params=p, neighbor_matrix=nm, neighbor_matrix_shifts=sh, cell=_t(cell)[None], compute_virial=True, **FP)
     _check(out, ref, virial=True)
 
@@ -235,7 +242,7 @@ def test_more_than_16_species_uses_global_table():
     z = (np.arange(150) % 22 + 1).astype(np.int32)  # 22 different elements
     nm, num, sh = cell_list(_t(pos), 13.0, _t(cell), torch.tensor([True] * 3, device=DEV), max_neighbors=320)
     assert int(num.max()) <= 320
-    ref = O.dftd3(pos, z, t, neighbor_matrix=nm.cpu().numpy(), neighbor_matrix_shifts=sh.cpu().numpy(), cell=cell, compute_virial=True, **FP)
+    ref = _wide(pos, z, t, neighbor_matrix=nm.cpu().numpy(), neighbor_matrix_shifts=sh.cpu().numpy(), cell=cell, compute_virial=True, **FP)
     out = dftd3(_t(pos), _t(z), d3_params=p, neighbor_matrix=nm, neighbor_matrix_shifts=sh, cell=_t(cell)[None], compute_virial=True, **FP)
     _check(out, ref, virial=True)
 
@@ -295,7 +302,7 @@ def test_packed_list_equals_plain_walk(box, shift_max, monkeypatch):
     for a, b in zip(packed_csr, plain_csr):
         assert torch.equal(a, b)
     if shift_max == 1:  # (the 12-atom cell is far denser than matter: its forces are differences of huge terms, outside the tolerance model)
-        ref = O.dftd3(pos, z, t, neighbor_matrix=nm.cpu().numpy(), neighbor_matrix_shifts=sh.cpu().numpy(), cell=cell, compute_virial=True, **FP)
+        ref = _wide(pos, z, t, neighbor_matrix=nm.cpu().numpy(), neighbor_matrix_shifts=sh.cpu().numpy(), cell=cell, compute_virial=True, **FP)
         _check(packed, ref, virial=True)
 
 
@@ -319,14 +326,14 @@ def test_headline_100k_periodic_full_size_vs_oracle():
     nm, num, sh = cell_list(tp, 40.0, tc, torch.tensor([True] * 3, device=DEV), max_neighbors=2560)
     assert int(num.max()) <= 2560 and int(num.sum()) > 2.3e8
     e, f, cn, vir = dftd3(tp, tz, d3_params=p, neighbor_matrix=nm, neighbor_matrix_shifts=sh, cell=tc[None], compute_virial=True, **FP)
-    re, rf, rcn, rvir = O.dftd3(pos, z, t, neighbor_matrix=nm.cpu().numpy(), neighbor_matrix_shifts=sh.cpu().numpy(),
+    re, rf, rcn, rvir = _wide(pos, z, t, neighbor_matrix=nm.cpu().numpy(), neighbor_matrix_shifts=sh.cpu().numpy(),
                                 cell=np.broadcast_to(cell, (n, 3, 3)).copy(), batch_idx=np.arange(n, dtype=np.int32), num_systems=n,
                                 compute_virial=True, **FP)
     e_ref, v_ref = re.astype(np.float64).sum(), rvir.astype(np.float64).sum(0)
-    assert abs(float(e[0]) - e_ref) < 1e-6 + 2e-6 * abs(e_ref), (float(e[0]), e_ref)
-    _close(f, rf, 1e-5, 1e-6 + 5e-6 * np.abs(rf).max(), "forces")
-    _close(cn, rcn, 2e-5, 1e-6, "cn")  # the reference's sequential fp32 sum of 2350 terms vs fp64 lane partials here (DESIGN.md deviation 6)
-    _close(vir[0], v_ref, 1e-5, 2e-6 + 1e-5 * np.abs(v_ref).max(), "virial")
+    assert abs(float(e[0]) - e_ref) < 1e-6 + 1e-6 * abs(e_ref), (float(e[0]), e_ref)
+    _close(f, rf, 1e-6, 1e-6, "forces")
+    _close(cn, rcn, 1e-6, 1e-6, "cn")
+    _close(vir[0], v_ref, 1e-6, 1e-6 + 2e-7 * np.abs(v_ref).max(), "virial")
 
 
 # ---- error budget ---------------------------------------------------------------------------------------------
@@ -394,6 +401,7 @@ def test_error_budget_vs_wide_sum_oracle(case):
     for k, nme in enumerate(names):
         scale = np.abs(wide[k]).max()
         table[nme] = {"scale_max_abs": scale}
+        table[nme]["elements_where_fast_and_ieee_builds_differ"] = int((fast[k] != ieee[k]).sum())
         for tag, arr in (("fast", fast), ("ieee", ieee), ("ref_order", ref)):
             err = np.abs(arr[k] - wide[k])
             table[nme][tag] = {"max_abs": float(err.max()), "max_abs_over_scale": float(err.max() / max(scale, 1e-300)),
@@ -404,5 +412,6 @@ def test_error_budget_vs_wide_sum_oracle(case):
     allt[case] = table
     json.dump(allt, open(path, "w"), indent=1)
     print(json.dumps({case: table}))
-    for k, nme in enumerate(names):  # the reference's own bar
-        np.testing.assert_allclose(fast[k], wide[k], rtol=1e-6, atol=1e-6, err_msg=f"{case}: {nme} (product vs wide-sum oracle)")
+    for k, nme in enumerate(names):  # the reference's own bar (virial: plus 2e-7 of the tensor's scale, see the module docstring)
+        atol = 1e-6 + (2e-7 * np.abs(wide[k]).max() if nme == "virial" else 0.0)
+        np.testing.assert_allclose(fast[k], wide[k], rtol=1e-6, atol=atol, err_msg=f"{case}: {nme} (product vs wide-sum oracle)")

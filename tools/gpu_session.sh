@@ -9,7 +9,7 @@ mkdir -p $OUT
 cd $R
 export TMPDIR=/tmp
 if [[ $WHAT == all || $WHAT == tests ]]; then
-  timeout 1500 python -m pytest tests -m gpu -x -q --durations=15 > $OUT/pytest.log 2>&1; echo "pytest rc=$?" >> $OUT/pytest.log
+  timeout 1800 python -m pytest tests -m gpu -q --durations=15 > $OUT/pytest.log 2>&1; echo "pytest rc=$?" >> $OUT/pytest.log
   tail -30 $OUT/pytest.log
   cp gpurun_out/d3_error_budget.json $OUT/ 2>/dev/null
 fi
