@@ -21,10 +21,12 @@ ARCH = "gfx950"
 # per-file extra flags.  nlist.hip must evaluate the cutoff test exactly like the oracle: no FMA contraction.
 SOURCES = {
     "capi.cpp": [],
-    "nlist.hip": ["-ffp-contract=off"],
+    "nlist.hip": ["-ffp-contract=off"] + os.environ.get("MI_NLIST_EXTRA_FLAGS", "").split(),
     # D3 pair math is fp32 with 1/x and sqrt on every pair: hardware v_rcp/v_sqrt (1 ulp) instead of the IEEE-exact expansions
     # (~10 instructions each); energies/forces stay inside the stated 2e-6 / 1e-5 tolerances
-    "d3.hip": ["-fno-hip-fp32-correctly-rounded-divide-sqrt"],
+    # -fno-slp-vectorize: the SLP pass fuses adjacent fp32 FMAs into v_pk_fma_f32, which on gfx950 issues as two passes (no gain) and
+    # costs v_mov's to pair the operands -- the energy pass is VALU-issue-bound
+    "d3.hip": ["-fno-hip-fp32-correctly-rounded-divide-sqrt", "-fno-slp-vectorize"] + os.environ.get("MI_D3_EXTRA_FLAGS", "").split(),
     "ewald.hip": [],
     "pme.hip": [],
 }

@@ -151,6 +151,36 @@ __device__ __forceinline__ D3Step d3_fetch_any(const int* __restrict__ idx, cons
   }
   return d3_fetch(idx, ush3, e, end, periodic);
 }
+// Energy pass: its packed-list steps stay ONE register (the raw word) while they wait in the software pipeline and are decoded where
+// they are used -- the decoded form (index + three shift ints + flag) in three pipeline stages was 10 loop-carried VGPRs, and
+// that pass is latency-bound: registers are occupancy.
+// wave-uniform values (properties of the row atom i, loaded by every lane from one address) pinned into SGPRs: the compiler cannot
+// prove uniformity of a loaded value and would keep ~35 of them in VGPRs across the pair loop
+__device__ __forceinline__ float d3_uni(float x) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(x))); }
+__device__ __forceinline__ double d3_uni(double x) {
+  const long long b = __double_as_longlong(x);
+  const int lo = __builtin_amdgcn_readfirstlane((int)b), hi = __builtin_amdgcn_readfirstlane((int)(b >> 32));
+  return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
+template <bool RAW> struct D3Lazy;
+template <> struct D3Lazy<false> { D3Step s; };
+template <> struct D3Lazy<true> { unsigned w; };
+__device__ __forceinline__ bool d3_lazy_in(const D3Lazy<false>& l) { return l.s.in; }
+__device__ __forceinline__ int d3_lazy_j(const D3Lazy<false>& l) { return l.s.j; }
+__device__ __forceinline__ Int3 d3_lazy_sh(const D3Lazy<false>& l) { return l.s.sh; }
+__device__ __forceinline__ bool d3_lazy_in(const D3Lazy<true>& l) { return l.w != D3_PK_INVALID; }
+__device__ __forceinline__ int d3_lazy_j(const D3Lazy<true>& l) { return (int)(l.w & 0x3ffffffu); }  // padding decodes to 2^26 - 1 >= N
+__device__ __forceinline__ Int3 d3_lazy_sh(const D3Lazy<true>& l) {
+  return Int3{(int)((l.w >> 26) & 3u) - 1, (int)((l.w >> 28) & 3u) - 1, (int)(l.w >> 30) - 1};
+}
+template <bool PK>
+__device__ __forceinline__ D3Lazy<PK> d3_fetch_lazy(const int* __restrict__ idx, const Int3* __restrict__ ush3, const unsigned* __restrict__ pk,
+                                                    long long e, long long end, bool periodic) {
+  D3Lazy<PK> l;
+  if constexpr (PK) l.w = e < end ? __builtin_nontemporal_load(pk + e) : D3_PK_INVALID;
+  else l.s = d3_fetch(idx, ush3, e, end, periodic);
+  return l;
+}
 // The row walks below are software-pipelined three deep: while step k is evaluated, the per-atom records of step k+1 are
 // already being gathered and the index/shift words of step k+2 are in flight; validity is a predicate, not a branch, so
 // no load waits behind a branch on an earlier load (rocprof: the unpipelined walk spent >80 % of its wave cycles waiting).
@@ -421,8 +451,10 @@ __device__ __forceinline__ D3Half d3_half_i(float cn_i, const float* __restrict_
   for (int a = 0; a < 5; ++a) {
     h.Ap[a] = A[a] - mx;
     const bool keep = h.Ap[a] >= -12.0f;  // false for -inf and NaN (no populated point at all)
-    h.u[a] = keep ? d3_exp_neg(keep ? h.Ap[a] : 0.0f) : 0.0f;
-    h.vcut[a] = keep ? d3_exp_neg(-12.0f - h.Ap[a]) : INFINITY;
+    h.u[a] = d3_uni(keep ? d3_exp_neg(keep ? h.Ap[a] : 0.0f) : 0.0f);
+    h.vcut[a] = d3_uni(keep ? d3_exp_neg(-12.0f - h.Ap[a]) : INFINITY);
+    h.Ap[a] = d3_uni(h.Ap[a]);
+    h.di[a] = d3_uni(h.di[a]);
   }
   return h;
 }
@@ -478,24 +510,31 @@ __global__ void d3_weights_kernel(const float* __restrict__ cn, const float4* __
 // Per pair: the (a, b) contraction only.  Same sums and thresholds as `_c6ab_interpolate`: a term survives iff
 // A'_a + B'_b >= -12, evaluated in weight space as v_b >= exp(-12 - A'_a) (wave-uniform per row).
 __device__ __forceinline__ void d3_c6_fact(const D3Half& h, const float* v, const float* __restrict__ c6rows, float k3, float& c6, float& dci) {
-  d3_f2 wz = {0.0f, 0.0f}, wzd = {0.0f, 0.0f};  // {w, z} and {sum w di, sum z di}
+  // plain fp32 FMAs: on gfx950 a v_pk_fma_f32 issues as two passes (the fp32 vector peak IS the unpacked rate), so packing the
+  // {w, z} pairs bought nothing and cost ~50 v_mov per 64 pairs to line the operands up in register pairs
+  float w = 0.0f, z = 0.0f, wdi = 0.0f, zdi = 0.0f;
 #pragma unroll
   for (int a = 0; a < 5; ++a) {
     if (__builtin_amdgcn_readfirstlane(__float_as_int(h.u[a])) == 0) continue;  // wave-uniform: u depends on atom i only
     const float4 r03 = *reinterpret_cast<const float4*>(c6rows + a * 8);
     const float r4 = c6rows[a * 8 + 4];
     const float cr[5] = {r03.x, r03.y, r03.z, r03.w, r4};
-    d3_f2 RT = {0.0f, 0.0f};  // {sum_b L, sum_b c6_ab L}: one packed FMA per term
+    float S = 0.0f, T = 0.0f;  // sum_b L, sum_b c6_ab L over the terms that survive the e^-12 cut
+    if (__builtin_amdgcn_readfirstlane(__float_as_int(h.Ap[a])) == 0) {
+      // the dominant row (A'_a = 0): the cut is B'_b >= -12, which the stored v_b already carry (smaller weights are stored as 0)
 #pragma unroll
-    for (int b = 0; b < 5; ++b) {
-      const float L = (v[b] >= h.vcut[a]) ? v[b] : 0.0f;
-      RT = __builtin_elementwise_fma((d3_f2){L, L}, (d3_f2){1.0f, cr[b]}, RT);
+      for (int b = 0; b < 5; ++b) { S += v[b]; T = fmaf(v[b], cr[b], T); }
+    } else {
+#pragma unroll
+      for (int b = 0; b < 5; ++b) {
+        const float L = (v[b] >= h.vcut[a]) ? v[b] : 0.0f;
+        S += L; T = fmaf(L, cr[b], T);
+      }
     }
-    const d3_f2 uRT = RT * h.u[a];
-    wz += uRT;
-    wzd = __builtin_elementwise_fma(uRT, (d3_f2){h.di[a], h.di[a]}, wzd);
+    const float ud = h.u[a] * h.di[a];  // wave-uniform
+    w = fmaf(h.u[a], S, w); z = fmaf(h.u[a], T, z);
+    wdi = fmaf(ud, S, wdi); zdi = fmaf(ud, T, zdi);
   }
-  const float w = wz.x, z = wz.y, wdi = wzd.x, zdi = wzd.y;
   if (w > 1e-12f) {
     const float wi = D3_RCP(w);
     c6 = z * wi;
@@ -537,9 +576,9 @@ __device__ __forceinline__ void d3_energy_body(const T* __restrict__ pos, const 
   if (zi == 0) return;
   const bool periodic = (cell != nullptr) && (ush != nullptr);
   T cm[9];
-  if (periodic) { const T* c = cell + 9 * (size_t)(batch_idx ? batch_idx[i] : 0); for (int k = 0; k < 9; ++k) cm[k] = c[k]; }
-  const T pix = pos[3 * (size_t)i], piy = pos[3 * (size_t)i + 1], piz = pos[3 * (size_t)i + 2];
-  const float cn_i = cn[i], r4r2_i = P.r4r2[zi];
+  if (periodic) { const T* c = cell + 9 * (size_t)(batch_idx ? batch_idx[i] : 0); for (int k = 0; k < 9; ++k) cm[k] = d3_uni(c[k]); }
+  const T pix = d3_uni(pos[3 * (size_t)i]), piy = d3_uni(pos[3 * (size_t)i + 1]), piz = d3_uni(pos[3 * (size_t)i + 2]);
+  const float cn_i = d3_uni(cn[i]), r4r2_i = d3_uni(P.r4r2[zi]);
   const float4* __restrict__ tab_i = P.tab + (size_t)zi * P.nz * 25;
   // stage this element's rows of the compact species table in the wave's private LDS slice
   const int code_i = (zi << 8) | (smap[zi] & 0xff);  // own species: a safe table row for masked-out lanes
@@ -567,8 +606,9 @@ __device__ __forceinline__ void d3_energy_body(const T* __restrict__ pos, const 
   const Int3* __restrict__ ush3 = reinterpret_cast<const Int3*>(ush);
   long long e = beg + lane;
   const unsigned jlim = d3_index_limit<CSR>(N, fill_value);
-  D3Step s0 = d3_fetch_any<PK>(idx, ush3, pk, use_pk, e, end, periodic), s1 = d3_fetch_any<PK>(idx, ush3, pk, use_pk, e + MI_WAVE, end, periodic);
-  bool v0 = s0.in && ((unsigned)s0.j < jlim);
+  static_assert(use_pk == PK, "the energy pass picks its list format at compile time");
+  D3Lazy<PK> s0 = d3_fetch_lazy<PK>(idx, ush3, pk, e, end, periodic), s1 = d3_fetch_lazy<PK>(idx, ush3, pk, e + MI_WAVE, end, periodic);
+  bool v0 = d3_lazy_in(s0) && ((unsigned)d3_lazy_j(s0) < jlim);
   using PosRec = typename Vec4<T>::type;
   auto pos_of = [&](int j) -> PosRec {
     if constexpr (PACKED) return aw[2 * (size_t)j];
@@ -581,19 +621,19 @@ __device__ __forceinline__ void d3_energy_body(const T* __restrict__ pos, const 
     else if (MODE == 2) { lo = aw[2 * (size_t)j]; hi4 = aw[2 * (size_t)j + 1]; }
     else { lo = aaux[j]; hi4 = lo; }
   };
-  PosRec p0 = pos_of(v0 ? s0.j : i);
+  PosRec p0 = pos_of(v0 ? d3_lazy_j(s0) : i);
   float4 a0, b0;
-  aux_of(v0 ? s0.j : i, a0, b0);
+  aux_of(v0 ? d3_lazy_j(s0) : i, a0, b0);
   for (long long base = beg; base < end; base += MI_WAVE) {
     e += MI_WAVE;
-    const D3Step s2 = d3_fetch_any<PK>(idx, ush3, pk, use_pk, e + MI_WAVE, end, periodic);
-    const bool v1 = s1.in && ((unsigned)s1.j < jlim);
-    const PosRec p1 = pos_of(v1 ? s1.j : i);
+    const D3Lazy<PK> s2 = d3_fetch_lazy<PK>(idx, ush3, pk, e + MI_WAVE, end, periodic);
+    const bool v1 = d3_lazy_in(s1) && ((unsigned)d3_lazy_j(s1) < jlim);
+    const PosRec p1 = pos_of(v1 ? d3_lazy_j(s1) : i);
     float4 a1, b1;
-    aux_of(v1 ? s1.j : i, a1, b1);
+    aux_of(v1 ? d3_lazy_j(s1) : i, a1, b1);
     if (__any(v0)) {
       bool valid = v0 && (PACKED || !(p0.w < (T)0));  // padding atom (Z == 0); the packed record marks it by all-zero weights
-      const PairGeom<T> g = d3_geom<T>(p0, pix, piy, piz, s0.sh, cm, periodic);
+      const PairGeom<T> g = d3_geom<T>(p0, pix, piy, piz, d3_lazy_sh(s0), cm, periodic);
       valid = valid && g.ok;
       float c6, dci, r4r2_j = 0.0f;
       int code;
@@ -681,9 +721,13 @@ template <class T, bool CSR, int MODE, bool PK>
 __global__ __launch_bounds__(256) void d3_energy_kernel(D3_ENERGY_PARAMS) {
   d3_energy_body<T, CSR, MODE, PK>(D3_ENERGY_ARGS);
 }
-// the fp32 factorised variant fits 96 VGPRs without spilling: ask for 5 waves per SIMD (the others would spill)
+// the fp32 factorised variant is latency-bound once its contraction is cheap (gathers from L2): it fits the register budget of
+// D3_ENERGY_WAVES waves per SIMD without spilling, the other variants would spill under that cap
+#ifndef D3_ENERGY_WAVES
+#define D3_ENERGY_WAVES 8  // 63 VGPRs / 78 SGPRs, no scratch (same-box A/B: 5 waves 1.09 ms, 6 waves 0.94, 7 / 8 waves 0.92)
+#endif
 template <class T, bool CSR, int MODE, bool PK>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) void d3_energy_kernel_w5(D3_ENERGY_PARAMS) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(D3_ENERGY_WAVES, D3_ENERGY_WAVES))) void d3_energy_kernel_w5(D3_ENERGY_PARAMS) {
   d3_energy_body<T, CSR, MODE, PK>(D3_ENERGY_ARGS);
 }
 // all three plain variants in one launch: what runs behind the packed variants (one dead launch instead of three when the packed copy was usable)
