@@ -134,3 +134,27 @@ def eager(fn):
         return inner(*args, **kwargs)
 
     return entry
+
+
+def tracing() -> bool:
+    """True while TorchDynamo traces the caller (torch.compile): the public electrostatics functions then take their custom-op path."""
+    return torch.compiler.is_compiling()
+
+
+def traceable(fn):
+    """Decorator of the public electrostatics entry points.  Unlike `eager` the body is visible to TorchDynamo: it branches on
+    `tracing()` into the `alchemiops::*` custom-op composition (nvalchemiops/_eops.py), so `torch.compile(..., fullgraph=True)`
+    captures it; outside a trace it only adds the device guard `eager` has."""
+    @functools.wraps(fn)
+    def entry(*args, **kwargs):
+        if torch.compiler.is_compiling():
+            return fn(*args, **kwargs)
+        for a in (args if args else kwargs.values()):
+            if isinstance(a, torch.Tensor):
+                if a.is_cuda and a.device.index != torch.cuda.current_device():
+                    with torch.cuda.device(a.device):
+                        return fn(*args, **kwargs)
+                break
+        return fn(*args, **kwargs)
+
+    return entry

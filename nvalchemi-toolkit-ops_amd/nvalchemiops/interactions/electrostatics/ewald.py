@@ -19,46 +19,6 @@ import math
 from nvalchemiops import _capi as C
 
 
-class _EwaldRealEnergyFn(torch.autograd.Function):
-    """Per-atom real-space energies with a hand-written adjoint kernel (`mi_ewald_real_bwd`) for positions, charges, cell and
-    alpha -- the reference differentiates these ops through a recorded Warp tape (autograd.py:525-665)."""
-
-    @staticmethod
-    def forward(ctx, positions, charges, cells, alpha, idx, sh, nptr, m, mask_value, bi, precomputed):
-        pos, q = positions.detach().contiguous(), charges.detach().contiguous()
-        c, al = cells.detach().contiguous(), alpha.detach().contiguous()
-        n = pos.shape[0]
-        energies = precomputed  # float64 energies of the launch that also produced explicit forces / charge gradients, if there was one
-        if energies is None:
-            energies = torch.empty(n, dtype=torch.float64, device=pos.device)
-            rc = C.lib().mi_ewald_real(C.ptr(pos), C.ptr(q), C.ptr(c), C.ptr(al), C.ptr(bi), n, C.dtype_code(pos.dtype), C.ptr(idx), C.ptr(sh),
-                                       C.ptr(nptr), int(m), int(mask_value), 0, C.ptr(energies), None, None, None, C.stream_of(pos))
-            C.check(rc, "mi_ewald_real")
-        empty = torch.empty(0, device=pos.device)
-        ctx.save_for_backward(pos, q, c, al, idx, sh, nptr if nptr is not None else empty, bi if bi is not None else empty)
-        ctx.meta = (m, mask_value, nptr is not None, bi is not None)
-        return energies.to(pos.dtype)
-
-    @staticmethod
-    def backward(ctx, g_e):
-        pos, q, c, al, idx, sh, nptr_t, bi_t = ctx.saved_tensors
-        m, mask_value, has_ptr, has_bi = ctx.meta
-        n, dt, dev = pos.shape[0], pos.dtype, pos.device
-        g = g_e.detach().to(dt).contiguous()
-        gpos = torch.empty((n, 3), dtype=dt, device=dev)
-        gq = torch.empty(n, dtype=dt, device=dev)
-        need = ctx.needs_input_grad
-        gcell = torch.zeros(c.shape, dtype=torch.float64, device=dev) if need[2] else None
-        galpha = torch.zeros(al.shape, dtype=torch.float64, device=dev) if need[3] else None
-        sym = torch.empty(C.ewald_sym_words(), dtype=torch.int64, device=dev)  # list-symmetry checksums (zeroed by the library)
-        rc = C.lib().mi_ewald_real_bwd(C.ptr(pos), C.ptr(q), C.ptr(c), C.ptr(al), C.ptr(bi_t if has_bi else None), n, C.dtype_code(dt),
-                                       C.ptr(idx), C.ptr(sh), C.ptr(nptr_t if has_ptr else None), int(m), int(mask_value), C.ptr(g),
-                                       C.ptr(gpos), C.ptr(gq), C.ptr(gcell), C.ptr(galpha), C.ptr(sym), C.stream_of(pos))
-        C.check(rc, "mi_ewald_real_bwd")
-        return (gpos if need[0] else None, gq if need[1] else None, None if gcell is None else gcell.to(dt),
-                None if galpha is None else galpha.to(dt), None, None, None, None, None, None, None)
-
-
 def _real_space_inputs(positions, charges, cell, alpha, neighbor_list, neighbor_ptr, neighbor_shifts, neighbor_matrix, neighbor_matrix_shifts,
                        batch_idx):
     """Argument checks (ewald.py:2460-2470 messages) and the detached, contiguous launch tensors of the real-space sum."""
@@ -101,7 +61,7 @@ def _real_space_launch(p, mask_value: int, compute_forces: bool, compute_charge_
     return energies, forces, cgrads
 
 
-@C.eager
+@C.traceable
 def ewald_real_space(positions: torch.Tensor, charges: torch.Tensor, cell: torch.Tensor, alpha: torch.Tensor,
                      neighbor_list: torch.Tensor | None = None, neighbor_ptr: torch.Tensor | None = None,
                      neighbor_shifts: torch.Tensor | None = None, neighbor_matrix: torch.Tensor | None = None,
@@ -125,25 +85,40 @@ def ewald_real_space(positions: torch.Tensor, charges: torch.Tensor, cell: torch
         if compute_charge_gradients:
             out += (torch.zeros(0, dtype=dt, device=dev),)
         return out if len(out) > 1 else out[0]
-    p = _real_space_inputs(positions, charges, cell, alpha, neighbor_list, neighbor_ptr, neighbor_shifts, neighbor_matrix, neighbor_matrix_shifts,
+    alpha_t = alpha if isinstance(alpha, torch.Tensor) else torch.full((1,), float(alpha), dtype=dt, device=dev)
+    if C.tracing() or (torch.is_grad_enabled() and any(t.requires_grad for t in (positions, charges, cell, alpha_t))):
+        # the registered `alchemiops::_[batch_]ewald_real_space_*` op of this configuration (nvalchemiops/_eops.py): energies are
+        # differentiable w.r.t. positions, charges, cell and alpha through the adjoint kernel; explicit forces / charge gradients are
+        # outputs of the same launch (differentiating THEM raises NotImplementedError)
+        from nvalchemiops import _eops
+
+        batched = batch_idx is not None
+        fmt = "list" if neighbor_list is not None else "matrix"
+        op = _eops.real_space_op(batched, fmt, compute_forces, compute_charge_gradients)
+        cells = cell.reshape(-1, 3, 3)
+        al = alpha_t.to(dt).reshape(-1)
+        if al.shape[0] == 1 and cells.shape[0] > 1:
+            al = al.expand(cells.shape[0])
+        head = (positions, charges.to(dt), cells.to(dt), al) + ((batch_idx,) if batched else ())
+        if fmt == "list":
+            n_entries = neighbor_list.shape[1]
+            sh = neighbor_shifts if neighbor_shifts is not None else torch.zeros((n_entries, 3), dtype=torch.int32, device=dev)
+            res = op(*head, neighbor_list, neighbor_ptr, sh)
+        else:
+            sh = neighbor_matrix_shifts if neighbor_matrix_shifts is not None else torch.zeros(tuple(neighbor_matrix.shape) + (3,), dtype=torch.int32, device=dev)
+            res = op(*head, neighbor_matrix, sh, int(mask_value))
+        res = res if isinstance(res, tuple) else (res,)
+        out = (res[0],) + ((res[1],) if compute_forces else ()) + ((res[-1],) if compute_charge_gradients else ())
+        return out if len(out) > 1 else out[0]
+    p = _real_space_inputs(positions, charges, cell, alpha_t, neighbor_list, neighbor_ptr, neighbor_shifts, neighbor_matrix, neighbor_matrix_shifts,
                            batch_idx)
-    wants_grad = torch.is_grad_enabled() and any(t.requires_grad for t in (positions, charges, cell, p["alpha_in"]))
-    explicit = compute_forces or compute_charge_gradients
-    energies = forces = cgrads = None
     if p["n_entries"] == 0:
         energies = torch.zeros(n, dtype=torch.float64, device=dev)
         forces = torch.zeros((n, 3), dtype=dt, device=dev) if compute_forces else None
         cgrads = torch.zeros(n, dtype=torch.float64, device=dev) if compute_charge_gradients else None
-    elif explicit or not wants_grad:  # with autograd and no explicit outputs the differentiable op below is the only launch needed
-        energies, forces, cgrads = _real_space_launch(p, mask_value, compute_forces, compute_charge_gradients)
-    if wants_grad and p["n_entries"] > 0:
-        # differentiable energies (explicit forces / charge gradients above stay plain outputs, as MD codes consume them); the float64
-        # energies of the launch above, if there was one, are handed over instead of being recomputed
-        e_out = _EwaldRealEnergyFn.apply(positions, charges.to(dt), cell.to(dt).reshape(-1, 3, 3), p["alpha_in"], p["idx"], p["sh"], p["nptr"],
-                                         p["m"], mask_value, p["bi"], energies)
     else:
-        e_out = energies.to(dt)  # ewald.py:577: energies are accumulated in float64 and returned in the input dtype
-    out = (e_out,)
+        energies, forces, cgrads = _real_space_launch(p, mask_value, compute_forces, compute_charge_gradients)
+    out = (energies.to(dt),)  # ewald.py:577: energies are accumulated in float64 and returned in the input dtype
     if compute_forces:
         out += (forces,)
     if compute_charge_gradients:

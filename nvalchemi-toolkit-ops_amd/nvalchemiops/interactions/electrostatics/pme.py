@@ -47,21 +47,50 @@ def _prepare_alpha(alpha: float | torch.Tensor, num_systems: int, dtype: torch.d
     raise TypeError(f"alpha must be float or torch.Tensor, got {type(alpha)}")
 
 
+def _traceable_alpha(alpha, num_systems: int, dtype, device) -> torch.Tensor:
+    """`_prepare_alpha` without the constant cache (an lru_cache'd helper is opaque to TorchDynamo)."""
+    if isinstance(alpha, (int, float)):
+        return torch.full((num_systems,), float(alpha), dtype=dtype, device=device)
+    if isinstance(alpha, torch.Tensor):
+        if alpha.dim() == 0:
+            return alpha.expand(num_systems).to(dtype=dtype, device=device)
+        if alpha.shape[0] != num_systems:
+            raise ValueError(f"alpha has {alpha.shape[0]} values but there are {num_systems} systems")
+        return alpha.to(dtype=dtype, device=device)
+    raise TypeError(f"alpha must be float or torch.Tensor, got {type(alpha)}")
+
+
 def _prepare_cell(cell: torch.Tensor) -> tuple[torch.Tensor, int]:
     if cell.dim() == 2:
         cell = cell.unsqueeze(0)
     return cell, cell.shape[0]
 
 
-@C.eager
+def _miller_placeholders(device):
+    # the reference passes fftfreq index arrays into the op (pme.py:630-640); this build evaluates them in the kernel
+    z = torch.empty(0, dtype=torch.float32, device=device)
+    return z, z, z
+
+
+@C.traceable
 def pme_green_structure_factor(k_squared: torch.Tensor, mesh_dimensions: tuple[int, int, int], alpha: torch.Tensor, cell: torch.Tensor,
                                spline_order: int = 4, batch_idx: torch.Tensor | None = None):
-    """G(k) = 2 pi exp(-k^2/4 alpha^2)/(V k^2) (0 at k = 0) and sf^2 = sinc-product^(2 min(order,4)) (pme.py:555-676)."""
+    """G(k) = 2 pi exp(-k^2/4 alpha^2)/(V k^2) (0 at k = 0) and sf^2 = sinc-product^(2 min(order,4)) (pme.py:555-676).
+    Differentiable w.r.t. k_squared, alpha and the cell (through the volume): op `alchemiops::_[batch_]pme_green_structure_factor`."""
     C.require_device(k_squared, cell)
     nx, ny, nz = (int(v) for v in mesh_dimensions)
     dt, dev = k_squared.dtype, k_squared.device
     cells = cell if cell.dim() == 3 else cell.unsqueeze(0)
     nsys = cells.shape[0] if batch_idx is not None else 1
+    if C.tracing() or (torch.is_grad_enabled() and any(t.requires_grad for t in (k_squared, alpha, cell))):
+        from nvalchemiops import _eops  # noqa: F401
+
+        vol_d = torch.abs(torch.linalg.det(cells)).to(dt).reshape(-1)
+        mx, my, mz = _miller_placeholders(dev)
+        if batch_idx is not None:
+            return torch.ops.alchemiops._batch_pme_green_structure_factor(k_squared, mx, my, mz, alpha.to(dt).reshape(-1), vol_d, nx, ny, nz,
+                                                                          int(spline_order), nsys)
+        return torch.ops.alchemiops._pme_green_structure_factor(k_squared, mx, my, mz, alpha.to(dt).reshape(-1), vol_d[:1], nx, ny, nz, int(spline_order))
     vol = torch.abs(torch.det(cells)).to(dt).reshape(-1).contiguous()
     k2 = k_squared.detach().contiguous()
     al = alpha.detach().to(dt).reshape(-1).contiguous()
@@ -87,6 +116,19 @@ def _corrections(raw, charges, cell, alpha, batch_idx, want_cg):
     dt, dev = raw.dtype, raw.device
     cells = cell if cell.dim() == 3 else cell.unsqueeze(0)
     nsys = cells.shape[0] if batch_idx is not None else 1
+    if C.tracing() or (torch.is_grad_enabled() and any(t.requires_grad for t in (raw, charges, cell, alpha))):
+        from nvalchemiops import _eops  # noqa: F401
+
+        O = torch.ops.alchemiops
+        q = charges.to(dt)
+        vol_d = torch.abs(torch.linalg.det(cells)).to(dt).reshape(-1)
+        al = alpha.to(dt).reshape(-1)
+        if batch_idx is None:
+            args = (raw, q, vol_d[:1], al[:1], q.sum().reshape(1))
+            return O._pme_energy_corrections_with_charge_grad(*args) if want_cg else O._pme_energy_corrections(*args)
+        qtot = torch.zeros(nsys, dtype=dt, device=dev).index_add(0, batch_idx.long(), q)
+        args = (raw, q, batch_idx, vol_d, al, qtot)
+        return O._batch_pme_energy_corrections_with_charge_grad(*args) if want_cg else O._batch_pme_energy_corrections(*args)
     q = charges.detach().to(dt).contiguous()
     bi = None if batch_idx is None else C.i32(batch_idx)
     vol = torch.abs(torch.linalg.det(cells)).to(dt).reshape(-1).contiguous()
@@ -101,13 +143,13 @@ def _corrections(raw, charges, cell, alpha, batch_idx, want_cg):
     return (e, cg) if want_cg else e
 
 
-@C.eager
+@C.traceable
 def pme_energy_corrections(raw_energies, charges, cell, alpha, batch_idx=None) -> torch.Tensor:
     """E_i = q_i phi_i - q_i^2 alpha/sqrt(pi) - q_i pi Q_tot/(2 alpha^2 V) (pme.py:1166-1250, pme_kernels.py:340-409)."""
     return _corrections(raw_energies, charges, cell, alpha, batch_idx, False)
 
 
-@C.eager
+@C.traceable
 def pme_energy_corrections_with_charge_grad(raw_energies, charges, cell, alpha, batch_idx=None):
     """... plus dE/dq_i = 2 phi_i - 2 alpha q_i/sqrt(pi) - pi Q_tot/(alpha^2 V) (pme.py:1253-1336)."""
     return _corrections(raw_energies, charges, cell, alpha, batch_idx, True)
@@ -175,50 +217,67 @@ def _reciprocal_with_kvectors(pos, q, cells, alpha, mesh_dimensions, spline_orde
     return energies, forces, cgrads
 
 
-def _reciprocal_autograd(positions, charges, cells, alpha, mesh_dimensions, spline_order, bi, compute_forces, compute_charge_gradients):
-    """Differentiable composition used when positions / charges / cell / alpha require grad (reference: every `alchemiops::*` op carries
-    a Warp-tape backward, autograd.py:124-297; the FFTs and elementwise steps differentiate through torch).  Spread and gather have
-    hand-written adjoint kernels (nvalchemiops.spline); Green function, k-grid and corrections are plain differentiable torch here.
-    Explicit forces / charge gradients, when requested, come from the fused non-differentiable pipeline on detached inputs."""
+def _reciprocal_composed(positions, charges, cells, alpha, mesh_dimensions, spline_order, batch_idx, compute_forces, compute_charge_gradients,
+                         k_vectors=None, k_squared=None):
+    """The reference's composition (pme.py:1338-1479) on the `alchemiops::*` custom ops (nvalchemiops/_eops.py): what runs when an input
+    requires grad or the call is being traced by torch.compile.  Every step is differentiable -- spread / gather / gather_vec3 by
+    hand-written adjoint kernels, Green function and corrections in closed form, FFTs and the spectrum algebra by torch -- so energies
+    AND reciprocal forces can be differentiated w.r.t. positions, charges, cell and alpha."""
+    from nvalchemiops import _eops  # noqa: F401
     from nvalchemiops.interactions.electrostatics.k_vectors import generate_k_vectors_pme
-    from nvalchemiops.spline import _GatherFn, _SpreadFn
 
+    O = torch.ops.alchemiops
     dt, dev = positions.dtype, positions.device
     nx, ny, nz = mesh_dimensions
-    batched = bi is not None
+    order = int(spline_order)
+    batched = batch_idx is not None
     nsys = cells.shape[0] if batched else 1
-    cell_inv = torch.linalg.inv(cells)
+    cc = cells.to(dt)
+    cell_inv = torch.linalg.inv(cc)
     cit = cell_inv.transpose(-1, -2)
-    q = charges.to(dt)
-    al = alpha.to(dt)
-    vol = torch.abs(torch.linalg.det(cells)).to(dt)
-    mesh = _SpreadFn.apply(positions, q, cit, bi, nsys, (nx, ny, nz), int(spline_order), batched)
-    spec = torch.fft.rfftn(mesh, norm="backward", dim=(1, 2, 3))
-    _, k2 = generate_k_vectors_pme(cells, (nx, ny, nz), reciprocal_cell=TWOPI * cell_inv)
-    k2 = k2.reshape(nsys, nx, ny, nz // 2 + 1)
-    a4 = (4.0 * al * al).reshape(nsys, 1, 1, 1)
-    green = TWOPI * torch.exp(-k2 / a4) / (k2 * vol.reshape(nsys, 1, 1, 1))
-    origin = torch.zeros((nx, ny, nz // 2 + 1), dtype=torch.bool, device=dev)
-    origin[0, 0, 0] = True
-    green = torch.where((k2 < 1e-10) | origin, torch.zeros((), dtype=dt, device=dev), green)
-    _, sf2 = pme_green_structure_factor(k2.detach() if batched else k2.detach()[0], (nx, ny, nz), al.detach(), cells.detach(), spline_order,
-                                        batch_idx=bi)
-    conv = spec / sf2 * green
-    phi = torch.fft.irfftn(conv, norm="forward", s=(nx, ny, nz), dim=(1, 2, 3))
-    raw = _GatherFn.apply(positions, phi, cit, bi, int(spline_order))
-    sys_of = bi.long() if batched else torch.zeros(positions.shape[0], dtype=torch.long, device=dev)
-    qtot = torch.zeros(nsys, dtype=dt, device=dev).index_add(0, sys_of, q)
-    a_i, v_i, qt_i = al[sys_of], vol[sys_of], qtot[sys_of]
-    energies = q * raw - q * q * a_i / math.sqrt(math.pi) - q * math.pi * qt_i / (2.0 * a_i * a_i * v_i)
-    forces = cgrads = None
-    if compute_forces or compute_charge_gradients:
-        with torch.no_grad():
-            _, forces, cgrads = _reciprocal_fused(positions.detach().contiguous(), q.detach().contiguous(), cells.detach().contiguous(),
-                                                  alpha.detach(), mesh_dimensions, spline_order, bi, compute_forces, compute_charge_gradients)
+    vol = torch.abs(torch.linalg.det(cc))
+    q, al = charges.to(dt), alpha.to(dt).reshape(-1)
+    fdims = (1, 2, 3) if batched else (0, 1, 2)
+    if batched:
+        mesh = O._batch_spline_spread(positions, q, batch_idx, cc, nsys, nx, ny, nz, order, cit)
+    else:
+        mesh = O._spline_spread(positions, q, cc[0], nx, ny, nz, order, cit[:1])
+    spec = torch.fft.rfftn(mesh, norm="backward", dim=fdims)  # unscaled forward (pme.py:1398)
+    if k_vectors is None or k_squared is None:
+        k_vectors, k_squared = generate_k_vectors_pme(cc if batched else cc[0], (nx, ny, nz), reciprocal_cell=TWOPI * (cell_inv if batched else cell_inv[:1]))
+    k_squared = k_squared.to(dt)
+    mx, my, mz = _miller_placeholders(dev)
+    if batched:
+        k2 = k_squared if k_squared.dim() == 4 else k_squared.unsqueeze(0).expand(nsys, -1, -1, -1)
+        kv = k_vectors if k_vectors.dim() == 5 else k_vectors.unsqueeze(0).expand(nsys, -1, -1, -1, -1)
+        green, sf2 = O._batch_pme_green_structure_factor(k2.contiguous(), mx, my, mz, al, vol, nx, ny, nz, order, nsys)
+    else:
+        k2, kv = k_squared.reshape(nx, ny, nz // 2 + 1), k_vectors.reshape(nx, ny, nz // 2 + 1, 3)
+        green, sf2 = O._pme_green_structure_factor(k2.contiguous(), mx, my, mz, al[:1], vol[:1], nx, ny, nz, order)
+    conv = spec / sf2 * green                                                                   # pme.py:1418-1419
+    phi = torch.fft.irfftn(conv, norm="forward", s=(nx, ny, nz), dim=fdims).to(dt)             # unscaled inverse (pme.py:1422)
+    if batched:
+        raw = O._batch_spline_gather(positions, phi, batch_idx, cc, order, cit)
+        qtot = torch.zeros(nsys, dtype=dt, device=dev).index_add(0, batch_idx.long(), q)
+        args = (raw, q, batch_idx, vol, al, qtot)
+        corr = O._batch_pme_energy_corrections_with_charge_grad(*args) if compute_charge_gradients else O._batch_pme_energy_corrections(*args)
+    else:
+        raw = O._spline_gather(positions, phi, cc[0], order, cit[:1])
+        args = (raw, q, vol[:1], al[:1], q.sum().reshape(1))
+        corr = O._pme_energy_corrections_with_charge_grad(*args) if compute_charge_gradients else O._pme_energy_corrections(*args)
+    energies, cgrads = corr if compute_charge_gradients else (corr, None)
+    forces = None
+    if compute_forces:
+        comps = [torch.fft.irfftn(-1j * kv[..., d] * conv, norm="forward", s=(nx, ny, nz), dim=fdims) for d in range(3)]
+        field = torch.stack(comps, dim=-1).to(dt)
+        if batched:
+            forces = 2.0 * O._batch_spline_gather_vec3(positions, q, field, batch_idx, cc, order, cit)
+        else:
+            forces = 2.0 * O._spline_gather_vec3(positions, q, field, cc[0], order, cit[:1])
     return energies, forces, cgrads
 
 
-@C.eager
+@C.traceable
 def pme_reciprocal_space(positions: torch.Tensor, charges: torch.Tensor, cell: torch.Tensor, alpha: float | torch.Tensor,
                          mesh_dimensions: tuple[int, int, int] | None = None, mesh_spacing: float | None = None, spline_order: int = 4,
                          batch_idx: torch.Tensor | None = None, k_vectors: torch.Tensor | None = None,
@@ -228,7 +287,8 @@ def pme_reciprocal_space(positions: torch.Tensor, charges: torch.Tensor, cell: t
     Return arity as pme.py:1655-1665."""
     cells, num_systems = _prepare_cell(cell)
     n, dev, dt = positions.shape[0], positions.device, positions.dtype
-    alpha_t = _prepare_alpha(alpha, num_systems, torch.float64, dev)
+    composed = C.tracing() or (torch.is_grad_enabled() and any(isinstance(t, torch.Tensor) and t.requires_grad for t in (positions, charges, cell, alpha)))
+    alpha_t = None if composed else _prepare_alpha(alpha, num_systems, torch.float64, dev)
     if mesh_dimensions is None:
         if mesh_spacing is None:
             raise ValueError("Either mesh_dimensions or mesh_spacing must be provided")
@@ -242,20 +302,20 @@ def pme_reciprocal_space(positions: torch.Tensor, charges: torch.Tensor, cell: t
     else:
         C.require_device(positions, charges, cell, batch_idx)
         C.dtype_code(dt)
-        bi = None if batch_idx is None else C.i32(batch_idx)
-        wants_grad = torch.is_grad_enabled() and any(isinstance(t, torch.Tensor) and t.requires_grad for t in (positions, charges, cell, alpha))
-        pos = positions.detach().contiguous()
-        q = charges.detach().to(dt).contiguous()
-        cells_t = cells.detach().to(dt).contiguous()
-        args = (pos, q, cells_t, alpha_t, mesh_dimensions, spline_order, bi, compute_forces, compute_charge_gradients)
-        if wants_grad:
-            alpha_g = _prepare_alpha(alpha, num_systems, dt, dev)
-            energies, forces, cgrads = _reciprocal_autograd(positions, charges, cells.to(dt), alpha_g, mesh_dimensions, spline_order, bi,
-                                                            compute_forces, compute_charge_gradients)
-        elif k_vectors is None or k_squared is None:
-            energies, forces, cgrads = _reciprocal_fused(*args)
+        if composed:
+            alpha_g = _traceable_alpha(alpha, num_systems, dt, dev)
+            energies, forces, cgrads = _reciprocal_composed(positions, charges, cells, alpha_g, mesh_dimensions, spline_order, batch_idx,
+                                                            compute_forces, compute_charge_gradients, k_vectors, k_squared)
         else:
-            energies, forces, cgrads = _reciprocal_with_kvectors(*args, k_vectors, k_squared)
+            bi = None if batch_idx is None else C.i32(batch_idx)
+            pos = positions.detach().contiguous()
+            q = charges.detach().to(dt).contiguous()
+            cells_t = cells.detach().to(dt).contiguous()
+            args = (pos, q, cells_t, alpha_t, mesh_dimensions, spline_order, bi, compute_forces, compute_charge_gradients)
+            if k_vectors is None or k_squared is None:
+                energies, forces, cgrads = _reciprocal_fused(*args)
+            else:
+                energies, forces, cgrads = _reciprocal_with_kvectors(*args, k_vectors, k_squared)
     if compute_forces and compute_charge_gradients:
         return energies, forces, cgrads
     if compute_forces:
@@ -265,7 +325,7 @@ def pme_reciprocal_space(positions: torch.Tensor, charges: torch.Tensor, cell: t
     return energies
 
 
-@C.eager
+@C.traceable
 def particle_mesh_ewald(positions: torch.Tensor, charges: torch.Tensor, cell: torch.Tensor, alpha: float | torch.Tensor | None = None,
                         mesh_spacing: float | None = None, mesh_dimensions: tuple[int, int, int] | None = None, spline_order: int = 4,
                         batch_idx: torch.Tensor | None = None, k_vectors: torch.Tensor | None = None, k_squared: torch.Tensor | None = None,
@@ -282,7 +342,8 @@ def particle_mesh_ewald(positions: torch.Tensor, charges: torch.Tensor, cell: to
         alpha = est.alpha
         if mesh_dimensions is None and mesh_spacing is None:
             mesh_dimensions = tuple(est.mesh_dimensions)
-    alpha = _prepare_alpha(alpha, num_systems, positions.dtype, positions.device)
+    wants_grad = C.tracing() or (torch.is_grad_enabled() and any(isinstance(t, torch.Tensor) and t.requires_grad for t in (positions, charges, cell, alpha)))
+    alpha = (_traceable_alpha if wants_grad else _prepare_alpha)(alpha, num_systems, positions.dtype, positions.device)
     if mask_value is None:
         mask_value = num_atoms
     if mesh_dimensions is None:
@@ -290,7 +351,6 @@ def particle_mesh_ewald(positions: torch.Tensor, charges: torch.Tensor, cell: to
             mesh_dimensions = mesh_spacing_to_dimensions(cells, mesh_spacing)
         else:
             mesh_dimensions = estimate_pme_mesh_dimensions(cells, alpha, accuracy)
-    wants_grad = torch.is_grad_enabled() and any(isinstance(t, torch.Tensor) and t.requires_grad for t in (positions, charges, cell, alpha))
     if not wants_grad and num_atoms > 0 and (k_vectors is None or k_squared is None):
         # the whole step on HIP kernels + two FFTs, no torch elementwise pass: the real-space sum hands its float64 energies (and
         # forces / charge gradients) to the gather epilogue of the reciprocal part, which adds them (pme.py:1975-1990 adds with torch)

@@ -55,105 +55,37 @@ def _launch_gather(pos, mesh, cit, bi, order, grad=False):
     return out
 
 
-def _coordinate_grads(weight, gfrac, pos, cit, bi, need_pos, need_cit):
-    """frac = cell_inv_t . r  =>  dL/dr_b = w sum_a gfrac_a cit[a][b] ;  dL/dcit[s][a][b] = sum_{i in s} w_i gfrac_i[a] r_i[b]."""
-    wg = gfrac * weight.unsqueeze(-1)
-    cit_i = cit[bi.long()] if bi is not None else cit[0].expand(pos.shape[0], 3, 3)
-    gpos = torch.einsum("na,nab->nb", wg, cit_i) if need_pos else None
-    gcit = None
-    if need_cit:
-        outer = wg.unsqueeze(-1) * pos.unsqueeze(-2)
-        gcit = torch.zeros_like(cit)
-        if bi is None:
-            gcit[0] = outer.sum(0)
-        else:
-            gcit.index_add_(0, bi.long(), outer)
-    return gpos, gcit
-
-
-class _SpreadFn(torch.autograd.Function):
-    """mesh = spread(values at positions).  Hand-written adjoint (the reference records a Warp tape: autograd.py:124-297):
-    d/dvalues = gather(grad_mesh), d/dpositions and d/dcell_inv_t through the gather-gradient kernel."""
-
-    @staticmethod
-    def forward(ctx, positions, values, cit, bi, nsys, dims, order, batched):
-        pos, vals, citc = positions.detach().contiguous(), values.detach().contiguous(), cit.detach().contiguous()
-        ctx.save_for_backward(pos, vals, citc, bi if bi is not None else torch.empty(0))
-        ctx.meta = (bi is not None, order)
-        return _launch_spread(pos, vals, citc, bi, nsys, dims, order, batched)
-
-    @staticmethod
-    def backward(ctx, gmesh):
-        pos, vals, cit, bi_t = ctx.saved_tensors
-        has_bi, order = ctx.meta
-        bi = bi_t if has_bi else None
-        g = gmesh.detach().contiguous()
-        need = ctx.needs_input_grad
-        gvals = _launch_gather(pos, g, cit, bi, order) if need[1] else None
-        gpos = gcit = None
-        if need[0] or need[2]:
-            gfrac = _launch_gather(pos, g, cit, bi, order, grad=True)
-            gpos, gcit = _coordinate_grads(vals, gfrac, pos, cit, bi, need[0], need[2])
-        return gpos, gvals, gcit, None, None, None, None, None
-
-
-class _GatherFn(torch.autograd.Function):
-    """out_i = gather(mesh at position i).  Adjoint: d/dmesh = spread(grad_out); d/dpositions, d/dcell_inv_t via gather-gradient."""
-
-    @staticmethod
-    def forward(ctx, positions, mesh, cit, bi, order):
-        pos, m, citc = positions.detach().contiguous(), mesh.detach().contiguous(), cit.detach().contiguous()
-        ctx.save_for_backward(pos, m, citc, bi if bi is not None else torch.empty(0))
-        ctx.meta = (bi is not None, order)
-        return _launch_gather(pos, m, citc, bi, order)
-
-    @staticmethod
-    def backward(ctx, gout):
-        pos, mesh, cit, bi_t = ctx.saved_tensors
-        has_bi, order = ctx.meta
-        bi = bi_t if has_bi else None
-        g = gout.detach().contiguous()
-        need = ctx.needs_input_grad
-        gmesh = None
-        if need[1]:
-            nsys = mesh.shape[0] if mesh.dim() == 4 else 1
-            gm = _launch_spread(pos, g, cit, bi, nsys, tuple(mesh.shape[-3:]), order, has_bi)
-            gmesh = gm if mesh.dim() == 4 else gm[0]
-        gpos = gcit = None
-        if need[0] or need[2]:
-            gfrac = _launch_gather(pos, mesh, cit, bi, order, grad=True)
-            gpos, gcit = _coordinate_grads(g, gfrac, pos, cit, bi, need[0], need[2])
-        return gpos, gmesh, gcit, None, None
-
-
 def _wants_grad(*tensors) -> bool:
     return torch.is_grad_enabled() and any(t is not None and isinstance(t, torch.Tensor) and t.requires_grad for t in tensors)
 
 
-def _differentiable_cit(cell: torch.Tensor, cell_inv_t, dtype, bi=None):
-    c = (cell if cell.dim() == 3 else cell.unsqueeze(0)).to(dtype)
-    cit = torch.linalg.inv(c).transpose(-1, -2) if cell_inv_t is None else cell_inv_t.to(dtype).reshape(-1, 3, 3)
-    if bi is not None and bi.numel() and cit.shape[0] == 1:
-        # one cell for the whole batch (spline.py:2256, :2775): the kernels index cell_inv_t and the mesh by batch_idx, so the
-        # differentiable path needs the same expansion `_prep` does (gradients sum back into the single cell through expand)
-        nsys = int(bi.max().item()) + 1
-        c, cit = c.expand(nsys, 3, 3), cit.expand(nsys, 3, 3)
-    return cit, c
+def _op_inputs(positions, cell, batch_idx, cell_inv_t):
+    """Arguments of the `alchemiops::_[batch_]spline_*` ops (nvalchemiops/_eops.py): [B,3,3] cell, a DIFFERENTIABLE cell_inv_t (so
+    cell gradients flow through torch.linalg.inv, as in the reference where `cell_inv_t` is the tracked array) and the system count."""
+    from nvalchemiops import _eops  # noqa: F401  (registers the ops)
+
+    dt = positions.dtype
+    c = (cell if cell.dim() == 3 else cell.unsqueeze(0)).to(dt)
+    cit = torch.linalg.inv(c).transpose(-1, -2) if cell_inv_t is None else cell_inv_t.to(dt).reshape(-1, 3, 3)
+    nsys = 1
+    if batch_idx is not None:
+        # one cell for the whole batch (spline.py:2256, :2775): the system count then comes from the indices
+        nsys = c.shape[0] if c.shape[0] > 1 else int(batch_idx.max().item()) + 1
+    return c, cit, nsys
 
 
-@C.eager
+@C.traceable
 def spline_spread(positions: torch.Tensor, values: torch.Tensor, cell: torch.Tensor, mesh_dims: tuple[int, int, int], spline_order: int = 4,
                   batch_idx: torch.Tensor | None = None, cell_inv_t: torch.Tensor | None = None) -> torch.Tensor:
     """mesh[(B,) nx, ny, nz] += values_i * M_n(x) M_n(y) M_n(z) over each atom's order^3 stencil (periodic wrap).
     Differentiable w.r.t. positions, values and cell (hand-written adjoint kernels)."""
     C.require_device(positions, values, cell)
-    if _wants_grad(positions, values, cell, cell_inv_t):
-        bi = None if batch_idx is None else C.i32(batch_idx)
-        cit, c = _differentiable_cit(cell, cell_inv_t, positions.dtype, bi)
-        nsys = c.shape[0] if bi is not None else 1
-        mesh = _SpreadFn.apply(positions, values.to(positions.dtype), cit, bi, nsys, tuple(int(v) for v in mesh_dims), int(spline_order),
-                               bi is not None)
-        return mesh if bi is not None else mesh[0]
+    if C.tracing() or _wants_grad(positions, values, cell, cell_inv_t):
+        c, cit, nsys = _op_inputs(positions, cell, batch_idx, cell_inv_t)
+        nx, ny, nz = (int(v) for v in mesh_dims)
+        if batch_idx is None:
+            return torch.ops.alchemiops._spline_spread(positions, values.to(positions.dtype), c[0], nx, ny, nz, int(spline_order), cit)
+        return torch.ops.alchemiops._batch_spline_spread(positions, values.to(positions.dtype), batch_idx, c, nsys, nx, ny, nz, int(spline_order), cit)
     pos, c, cit, bi = _prep(positions, cell, batch_idx, cell_inv_t)
     nx, ny, nz = (int(v) for v in mesh_dims)
     nsys = c.shape[0] if bi is not None else 1
@@ -162,16 +94,17 @@ def spline_spread(positions: torch.Tensor, values: torch.Tensor, cell: torch.Ten
     return mesh if bi is not None else mesh[0]
 
 
-@C.eager
+@C.traceable
 def spline_gather(positions: torch.Tensor, mesh: torch.Tensor, cell: torch.Tensor, spline_order: int = 4,
                   batch_idx: torch.Tensor | None = None, cell_inv_t: torch.Tensor | None = None) -> torch.Tensor:
     """out_i = sum over the stencil of mesh[g] * w  (weights <= 1e-8 are skipped, spline.py:608).
     Differentiable w.r.t. positions, mesh and cell."""
     C.require_device(positions, mesh, cell)
-    if _wants_grad(positions, mesh, cell, cell_inv_t):
-        bi = None if batch_idx is None else C.i32(batch_idx)
-        cit, _ = _differentiable_cit(cell, cell_inv_t, positions.dtype, bi)
-        return _GatherFn.apply(positions, mesh.to(positions.dtype), cit, bi, int(spline_order))
+    if C.tracing() or _wants_grad(positions, mesh, cell, cell_inv_t):
+        c, cit, _ = _op_inputs(positions, cell, batch_idx, cell_inv_t)
+        if batch_idx is None:
+            return torch.ops.alchemiops._spline_gather(positions, mesh.to(positions.dtype), c[0], int(spline_order), cit)
+        return torch.ops.alchemiops._batch_spline_gather(positions, mesh.to(positions.dtype), batch_idx, c, int(spline_order), cit)
     pos, c, cit, bi = _prep(positions, cell, batch_idx, cell_inv_t)
     m = mesh.detach().to(pos.dtype).contiguous()
     nx, ny, nz = m.shape[-3:]
@@ -182,11 +115,18 @@ def spline_gather(positions: torch.Tensor, mesh: torch.Tensor, cell: torch.Tenso
     return out
 
 
-@C.eager
+@C.traceable
 def spline_gather_vec3(positions: torch.Tensor, charges: torch.Tensor, mesh: torch.Tensor, cell: torch.Tensor, spline_order: int = 4,
                        batch_idx: torch.Tensor | None = None, cell_inv_t: torch.Tensor | None = None) -> torch.Tensor:
-    """out_i[3] = sum over the stencil of q_i * mesh[g, :] * w for a mesh of shape [(B,) nx, ny, nz, 3]."""
+    """out_i[3] = sum over the stencil of q_i * mesh[g, :] * w for a mesh of shape [(B,) nx, ny, nz, 3].
+    Differentiable w.r.t. positions, charges, mesh and cell (adjoint in nvalchemiops/_eops.py)."""
     C.require_device(positions, charges, mesh, cell)
+    if C.tracing() or _wants_grad(positions, charges, mesh, cell, cell_inv_t):
+        c, cit, _ = _op_inputs(positions, cell, batch_idx, cell_inv_t)
+        if batch_idx is None:
+            return torch.ops.alchemiops._spline_gather_vec3(positions, charges.to(positions.dtype), mesh.to(positions.dtype), c[0], int(spline_order), cit)
+        return torch.ops.alchemiops._batch_spline_gather_vec3(positions, charges.to(positions.dtype), mesh.to(positions.dtype), batch_idx, c,
+                                                              int(spline_order), cit)
     pos, c, cit, bi = _prep(positions, cell, batch_idx, cell_inv_t)
     m = mesh.detach().to(pos.dtype).contiguous()
     nx, ny, nz = m.shape[-4:-1]
@@ -198,12 +138,19 @@ def spline_gather_vec3(positions: torch.Tensor, charges: torch.Tensor, mesh: tor
     return out
 
 
-@C.eager
+@C.traceable
 def spline_gather_gradient(positions: torch.Tensor, charges: torch.Tensor, mesh: torch.Tensor, cell: torch.Tensor, spline_order: int = 4,
                            batch_idx: torch.Tensor | None = None, cell_inv_t: torch.Tensor | None = None) -> torch.Tensor:
     """F_i = -q_i sum_g mesh[g] grad_r w(r_i, g): the fractional-coordinate gradient (scaled by the mesh dimensions) mapped to Cartesian
-    with cell_inv_t^T (spline.py:2733-2785; kernels :678-755).  Plain output: no second-derivative adjoint is provided."""
+    with cell_inv_t^T (spline.py:2733-2785; kernels :678-755).  Its derivatives would be second derivatives of the spline weights:
+    requesting them raises NotImplementedError (op `alchemiops::_[batch_]spline_gather_gradient`)."""
     C.require_device(positions, charges, mesh, cell)
+    if C.tracing() or _wants_grad(positions, charges, mesh, cell, cell_inv_t):
+        c, cit, _ = _op_inputs(positions, cell, batch_idx, cell_inv_t)
+        if batch_idx is None:
+            return torch.ops.alchemiops._spline_gather_gradient(positions, charges.to(positions.dtype), mesh.to(positions.dtype), c[0], int(spline_order), cit)
+        return torch.ops.alchemiops._batch_spline_gather_gradient(positions, charges.to(positions.dtype), mesh.to(positions.dtype), batch_idx, c,
+                                                                  int(spline_order), cit)
     pos, c, cit, bi = _prep(positions, cell, batch_idx, cell_inv_t)
     gfrac = _launch_gather(pos, mesh.detach().to(pos.dtype).contiguous(), cit, bi, int(spline_order), grad=True)
     cit_i = cit[bi.long()] if bi is not None else cit[0].expand(pos.shape[0], 3, 3)
