@@ -122,7 +122,10 @@ __global__ void nl_setup_kernel(const T* __restrict__ cell, const uint8_t* __res
     int ns = natoms ? natoms[s] : N;
     double rc = (double)cutoff;
     double apc = vol > 0 ? (double)ns / vol * rc * rc * rc : 0.0;  // atoms per rc^3 cube
-    int k = apc < 64.0 ? 1 : (apc < 512.0 ? 2 : 3);
+#ifndef NL_K2_APC
+#define NL_K2_APC 64.0
+#endif
+    int k = apc < NL_K2_APC ? 1 : (apc < 512.0 ? 2 : 3);
     long long cap = 4ll * ns + 8;
     double face[3];
     for (int d = 0; d < 3; ++d) {
@@ -184,23 +187,26 @@ template <class T>
 __global__ void nl_assign_kernel(const T* __restrict__ pos, const int* __restrict__ batch_idx, int N, const NlSys<T>* __restrict__ sys,
                                  int* __restrict__ keys, int* __restrict__ count, short4* __restrict__ wrap, NlGlobal* __restrict__ glob) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= N) return;
-  const int s = batch_idx ? batch_idx[i] : 0;
-  const NlSys<T>& S = sys[s];
-  T p[3] = {pos[3 * (size_t)i] - S.origin[0], pos[3 * (size_t)i + 1] - S.origin[1], pos[3 * (size_t)i + 2] - S.origin[2]}, frac[3];
-  rowvec_mat3(p, S.inv, frac);
-  int c[3], w[3];
+  const bool in = i < N;
+  int key = 0;
+  if (in) {
+    const int s = batch_idx ? batch_idx[i] : 0;
+    const NlSys<T>& S = sys[s];
+    T p[3] = {pos[3 * (size_t)i] - S.origin[0], pos[3 * (size_t)i + 1] - S.origin[1], pos[3 * (size_t)i + 2] - S.origin[2]}, frac[3];
+    rowvec_mat3(p, S.inv, frac);
+    int c[3], w[3];
 #pragma unroll
-  for (int d = 0; d < 3; ++d) {
-    int v = (int)floor(frac[d] * (T)S.cpd[d]);
-    if (S.pbc[d]) floor_divmod(v, S.cpd[d], w[d], c[d]);
-    else { w[d] = 0; c[d] = v < 0 ? 0 : (v >= S.cpd[d] ? S.cpd[d] - 1 : v); }
+    for (int d = 0; d < 3; ++d) {
+      int v = (int)floor(frac[d] * (T)S.cpd[d]);
+      if (S.pbc[d]) floor_divmod(v, S.cpd[d], w[d], c[d]);
+      else { w[d] = 0; c[d] = v < 0 ? 0 : (v >= S.cpd[d] ? S.cpd[d] - 1 : v); }
+    }
+    key = S.cell_off + c[0] + S.cpd[0] * (c[1] + S.cpd[1] * c[2]);
+    keys[i] = key;
+    wrap[i] = make_short4((short)w[0], (short)w[1], (short)w[2], 0);
+    if (w[0] | w[1] | w[2]) glob->any_wrap = 1;
   }
-  const int key = S.cell_off + c[0] + S.cpd[0] * (c[1] + S.cpd[1] * c[2]);
-  keys[i] = key;
-  atomicAdd(&count[key], 1);  // result unused: a fire-and-forget atomic per atom
-  wrap[i] = make_short4((short)w[0], (short)w[1], (short)w[2], 0);
-  if (w[0] | w[1] | w[2]) glob->any_wrap = 1;
+  bs_wave_add<false>(count, key, in);  // the cell's atom counter, one atomic per distinct cell per wave
 }
 
 // Slot p of the counting sort holds some atom of cell c = keys[id]; its final place is start[c] + (number of atoms of the cell
@@ -813,24 +819,27 @@ __global__ void nl_cache_assign_kernel(const T* __restrict__ pos, const T* __res
                                        const int* __restrict__ batch_idx, int N, const int* __restrict__ cpd, const int* __restrict__ cell_off,
                                        int* __restrict__ keys, int* __restrict__ counts, int* __restrict__ atom_shift, int* __restrict__ atom_cell) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= N) return;
-  const int s = batch_idx ? batch_idx[i] : 0;
-  T inv[9];
-  inverse3(cell + 9 * (size_t)s, inv);
-  T p[3] = {pos[3 * (size_t)i], pos[3 * (size_t)i + 1], pos[3 * (size_t)i + 2]}, frac[3];
-  rowvec_mat3(p, inv, frac);
-  int c[3];
-  for (int d = 0; d < 3; ++d) {
-    const int n = cpd[3 * s + d];
-    int v = (int)floor(frac[d] * (T)n), w = 0;
-    if (pbc[3 * s + d]) floor_divmod(v, n, w, c[d]);
-    else c[d] = v < 0 ? 0 : (v >= n ? n - 1 : v);
-    atom_shift[3 * (size_t)i + d] = w;
-    atom_cell[3 * (size_t)i + d] = c[d];
+  const bool in = i < N;
+  int key = 0;
+  if (in) {
+    const int s = batch_idx ? batch_idx[i] : 0;
+    T inv[9];
+    inverse3(cell + 9 * (size_t)s, inv);
+    T p[3] = {pos[3 * (size_t)i], pos[3 * (size_t)i + 1], pos[3 * (size_t)i + 2]}, frac[3];
+    rowvec_mat3(p, inv, frac);
+    int c[3];
+    for (int d = 0; d < 3; ++d) {
+      const int n = cpd[3 * s + d];
+      int v = (int)floor(frac[d] * (T)n), w = 0;
+      if (pbc[3 * s + d]) floor_divmod(v, n, w, c[d]);
+      else c[d] = v < 0 ? 0 : (v >= n ? n - 1 : v);
+      atom_shift[3 * (size_t)i + d] = w;
+      atom_cell[3 * (size_t)i + d] = c[d];
+    }
+    key = cell_off[s] + c[0] + cpd[3 * s] * (c[1] + cpd[3 * s + 1] * c[2]);
+    keys[i] = key;
   }
-  const int key = cell_off[s] + c[0] + cpd[3 * s] * (c[1] + cpd[3 * s + 1] * c[2]);
-  keys[i] = key;
-  atomicAdd(&counts[key], 1);  // atoms_per_cell_count, as the reference's count kernel does (cell_list.py:166-276)
+  bs_wave_add<false>(counts, key, in);  // atoms_per_cell_count, as the reference's count kernel does (cell_list.py:166-276)
 }
 // The reference-format cache is the same counting sort written into the caller's arrays: atoms_per_cell_count by atomics,
 // cell_atom_start_indices = its exclusive cumsum (cell_list.py:869-871), cell_atom_list by a scatter through the start array used as
@@ -842,7 +851,9 @@ __global__ void nl_cache_add_offsets_kernel(int* __restrict__ starts, const int*
 }
 __global__ void nl_cache_scatter_kernel(const int* __restrict__ keys, int N, int* __restrict__ cursor, int* __restrict__ ids) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < N) ids[atomicAdd(&cursor[keys[i]], 1)] = i;
+  const bool in = i < N;
+  const int slot = bs_wave_add<true>(cursor, in ? keys[i] : 0, in);
+  if (in) ids[slot] = i;
 }
 __global__ void nl_cache_rank_kernel(const int* __restrict__ ids, const int* __restrict__ keys, const int* __restrict__ cursor_end,
                                      const int* __restrict__ counts, int N, int* __restrict__ cell_atoms) {

@@ -184,17 +184,20 @@ template <class T>
 __global__ void spread_key_kernel(const T* __restrict__ pos, const int* __restrict__ batch_idx, const T* __restrict__ cit, int N, int nx, int ny,
                                   int nz, int order, SpTile e, int* __restrict__ keys, int* __restrict__ count, int4* __restrict__ lo3, T* __restrict__ wts) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= N) return;
-  const int s = batch_idx ? batch_idx[i] : 0;
-  const Stencil<T> st = make_stencil(pos + 3 * (size_t)i, cit + 9 * (size_t)s, nx, ny, nz, order);
-  const int lx = wrap_idx(st.base[0] + st.off0[0], nx), ly = wrap_idx(st.base[1] + st.off0[1], ny), lz = wrap_idx(st.base[2] + st.off0[2], nz);
-  const int key = ((s * (nx / e.ex) + lx / e.ex) * (ny / e.ey) + ly / e.ey) * (nz / e.ez) + lz / e.ez;
-  keys[i] = key;
-  atomicAdd(&count[key], 1);  // fire-and-forget: the tile's atom counter (binsort.h)
-  lo3[i] = make_int4(lx, ly, lz, s);
-  // the 1-D weights are evaluated once per atom here; the tile kernel (up to 8 tiles x order^2 threads per atom) only reads them
-  for (int d = 0; d < 3; ++d)
-    for (int t = 0; t < MI_MAX_ORDER; ++t) wts[((size_t)i * 3 + d) * MI_MAX_ORDER + t] = t < order ? weight_1d(st, d, t, order) : T(0);
+  const bool in = i < N;
+  int key = 0;
+  if (in) {
+    const int s = batch_idx ? batch_idx[i] : 0;
+    const Stencil<T> st = make_stencil(pos + 3 * (size_t)i, cit + 9 * (size_t)s, nx, ny, nz, order);
+    const int lx = wrap_idx(st.base[0] + st.off0[0], nx), ly = wrap_idx(st.base[1] + st.off0[1], ny), lz = wrap_idx(st.base[2] + st.off0[2], nz);
+    key = ((s * (nx / e.ex) + lx / e.ex) * (ny / e.ey) + ly / e.ey) * (nz / e.ez) + lz / e.ez;
+    keys[i] = key;
+    lo3[i] = make_int4(lx, ly, lz, s);
+    // the 1-D weights are evaluated once per atom here; the tile kernel (up to 8 tiles x order^2 threads per atom) only reads them
+    for (int d = 0; d < 3; ++d)
+      for (int t = 0; t < MI_MAX_ORDER; ++t) wts[((size_t)i * 3 + d) * MI_MAX_ORDER + t] = t < order ? weight_1d(st, d, t, order) : T(0);
+  }
+  bs_wave_add<false>(count, key, in);  // the tile's atom counter (binsort.h): one atomic per distinct tile per wave
 }
 template <class T>
 __global__ __launch_bounds__(256) void spread_tiled_kernel(const T* __restrict__ values, const int* __restrict__ atom_of, const int* __restrict__ bin_start,

@@ -236,6 +236,67 @@ int cell_list_reference(const T* pos, int N, const T* cell, const uint8_t* pbc, 
   return C;
 }
 
+// Reference-format cell-list cache = what build_cell_list / batch_build_cell_list leave in the caller's tensors
+// (cell_list.py:102-163 bin size against the ALLOCATED capacity, :166-276 count, :869-871 cumsum, :279-369 bin;
+// batch_cell_list.py:103-373).  cell_atom_list is filled in ascending atom order here (thread ≙ loop iteration; the
+// reference's order inside a cell is whatever its atomics produce).
+template <class T>
+void cell_cache_reference(const T* pos, int N, const T* cell, const uint8_t* pbc, const int* batch_idx, int B, T cutoff, int C,
+                          int* cpd_out, int* atom_shift, int* atom_cc, int* counts, int* starts, int* cell_atoms) {
+  const bool batch = batch_idx != nullptr;
+  std::vector<int> cell_off(B + 1, 0);
+  for (int s = 0; s < B; ++s) {
+    int c[3];
+    cells_per_dim_and_radius<T>(cell + 9 * s, pbc + 3 * s, cutoff, c, nullptr);
+    halve_until(c, C, batch ? B : 1);
+    for (int d = 0; d < 3; ++d) cpd_out[3 * s + d] = c[d];
+    cell_off[s + 1] = cell_off[s] + c[0] * c[1] * c[2];
+  }
+  std::vector<Mat3<T>> inv(B);
+  for (int s = 0; s < B; ++s) { Mat3<T> cm; load_mat(cell + 9 * s, cm); inv[s] = inverse3(cm); }
+  std::fill(counts, counts + C, 0);
+  auto lin = [&](int s, const int* cc) { return cell_off[s] + cc[0] + cpd_out[3 * s] * (cc[1] + cpd_out[3 * s + 1] * cc[2]); };
+  for (int i = 0; i < N; ++i) {
+    int s = batch ? batch_idx[i] : 0;
+    atom_cell(pos + 3 * (size_t)i, inv[s], pbc + 3 * s, &cpd_out[3 * s], &atom_cc[3 * (size_t)i], &atom_shift[3 * (size_t)i]);
+    counts[lin(s, &atom_cc[3 * (size_t)i])] += 1;
+  }
+  starts[0] = 0;
+  for (int c = 1; c < C; ++c) starts[c] = starts[c - 1] + counts[c - 1];
+  std::vector<int> fill(C, 0);
+  for (int i = 0; i < N; ++i) {
+    int s = batch ? batch_idx[i] : 0;
+    int l = lin(s, &atom_cc[3 * (size_t)i]);
+    cell_atoms[starts[l] + fill[l]++] = i;
+  }
+}
+
+// rebuild_detection.py:37-170: any atom whose current cell differs from atom_to_cell_mapping / that moved farther than the skin
+template <class T>
+int cells_changed_reference(const T* pos, int N, const T* cell, const int* atom_to_cell, const int* cpd, const uint8_t* pbc) {
+  Mat3<T> C; load_mat(cell, C);
+  Mat3<T> inv = inverse3(C);
+  for (int i = 0; i < N; ++i) {
+    T frac[3];
+    rowvec_mat(pos + 3 * (size_t)i, inv, frac);  // == transpose(inverse(cell)) * r
+    for (int d = 0; d < 3; ++d) {
+      int c = int(std::floor(frac[d] * T(cpd[d])));
+      if (pbc[d]) { c = c % cpd[d]; if (c < 0) c += cpd[d]; }
+      else c = std::min(std::max(c, 0), cpd[d] - 1);
+      if (c != atom_to_cell[3 * (size_t)i + d]) return 1;
+    }
+  }
+  return 0;
+}
+template <class T>
+int moved_beyond_skin_reference(const T* ref, const T* cur, int N, T threshold) {
+  for (int i = 0; i < N; ++i) {
+    T d[3] = {cur[3 * (size_t)i] - ref[3 * (size_t)i], cur[3 * (size_t)i + 1] - ref[3 * (size_t)i + 1], cur[3 * (size_t)i + 2] - ref[3 * (size_t)i + 2]};
+    if (vlen(d) > threshold) return 1;
+  }
+  return 0;
+}
+
 // Naive O(N^2)  (naive.py:37-182, neighbor_utils.py:26-67,150-211)
 template <class T>
 void naive_reference(const T* pos, int N, const T* cell /*null => no pbc*/, const uint8_t* pbc, T cutoff_sq,
@@ -728,6 +789,25 @@ int orc_cell_list(int dtype, const void* pos, int N, const void* cell, const uin
            C = cell_list_reference<float>((const float*)pos, N, (const float*)cell, pbc, batch_idx, B, float(cutoff), max_nbins, M, fill_value, half_fill, nm, nsh, num, out_cpd, out_radius),
            C = cell_list_reference<double>((const double*)pos, N, (const double*)cell, pbc, batch_idx, B, cutoff, max_nbins, M, fill_value, half_fill, nm, nsh, num, out_cpd, out_radius));
   return C;
+}
+
+void orc_cell_cache(int dtype, const void* pos, int N, const void* cell, const uint8_t* pbc, const int* batch_idx, int B, double cutoff, int C,
+                    int* cpd, int* atom_shift, int* atom_cell, int* counts, int* starts, int* cell_atoms) {
+  DISPATCH(dtype,
+           cell_cache_reference<float>((const float*)pos, N, (const float*)cell, pbc, batch_idx, B, float(cutoff), C, cpd, atom_shift, atom_cell, counts, starts, cell_atoms),
+           cell_cache_reference<double>((const double*)pos, N, (const double*)cell, pbc, batch_idx, B, cutoff, C, cpd, atom_shift, atom_cell, counts, starts, cell_atoms));
+}
+int orc_cells_changed(int dtype, const void* pos, int N, const void* cell, const int* atom_to_cell, const int* cpd, const uint8_t* pbc) {
+  int r = 0;
+  DISPATCH(dtype, r = cells_changed_reference<float>((const float*)pos, N, (const float*)cell, atom_to_cell, cpd, pbc),
+           r = cells_changed_reference<double>((const double*)pos, N, (const double*)cell, atom_to_cell, cpd, pbc));
+  return r;
+}
+int orc_moved_beyond_skin(int dtype, const void* ref, const void* cur, int N, double threshold) {
+  int r = 0;
+  DISPATCH(dtype, r = moved_beyond_skin_reference<float>((const float*)ref, (const float*)cur, N, float(threshold)),
+           r = moved_beyond_skin_reference<double>((const double*)ref, (const double*)cur, N, threshold));
+  return r;
 }
 
 void orc_naive(int dtype, const void* pos, int N, const void* cell, const uint8_t* pbc, double cutoff, int M, int fill_value,

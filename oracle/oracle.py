@@ -185,6 +185,38 @@ def cell_list(positions, cutoff, cell, pbc, batch_idx=None, max_neighbors=None, 
     return nm, num, sh
 
 
+def build_cell_cache(positions, cutoff, cell, pbc, max_total_cells, batch_idx=None):
+    """What build_cell_list / batch_build_cell_list leave in the caller's cache tensors (cell_list.py:725-889, batch_cell_list.py:739-912):
+    (cells_per_dimension, atom_periodic_shifts, atom_to_cell_mapping, atoms_per_cell_count, cell_atom_start_indices, cell_atom_list),
+    atoms of a cell listed in ascending index."""
+    pos = _c(positions)
+    n = pos.shape[0]
+    cell = _c(cell, pos.dtype).reshape(-1, 3, 3)
+    nsys = cell.shape[0]
+    pbc = _c(np.broadcast_to(np.asarray(pbc).reshape(-1, 3), (nsys, 3)), np.uint8)
+    bi = _c(batch_idx, np.int32)
+    c = int(max_total_cells)
+    cpd, shift, amap = np.zeros((nsys, 3), np.int32), np.zeros((n, 3), np.int32), np.zeros((n, 3), np.int32)
+    counts, starts, atoms = np.zeros(c, np.int32), np.zeros(c, np.int32), np.zeros(n, np.int32)
+    lib().orc_cell_cache(_dt(pos), _p(pos), n, _p(cell), _p(pbc), _p(bi), nsys, ctypes.c_double(cutoff), c, _p(cpd), _p(shift), _p(amap),
+                         _p(counts), _p(starts), _p(atoms))
+    return (cpd if batch_idx is not None else cpd[0]), shift, amap, counts, starts, atoms
+
+
+def cells_changed(positions, cell, atom_to_cell_mapping, cells_per_dimension, pbc) -> bool:
+    """rebuild_detection.py:37-110."""
+    pos = _c(positions)
+    return bool(lib().orc_cells_changed(_dt(pos), _p(pos), pos.shape[0], _p(_c(cell, pos.dtype).reshape(3, 3)), _p(_c(atom_to_cell_mapping, np.int32)),
+                                        _p(_c(np.asarray(cells_per_dimension).reshape(3), np.int32)), _p(_c(np.asarray(pbc).reshape(3), np.uint8))))
+
+
+def moved_beyond_skin(reference_positions, current_positions, threshold) -> bool:
+    """rebuild_detection.py:113-170."""
+    ref = _c(reference_positions)
+    cur = _c(current_positions, ref.dtype)
+    return bool(lib().orc_moved_beyond_skin(_dt(ref), _p(ref), _p(cur), ref.shape[0], ctypes.c_double(threshold)))
+
+
 def naive(positions, cutoff, cell=None, pbc=None, max_neighbors=None, fill_value=None, half_fill=False):
     pos = _c(positions)
     n = pos.shape[0]

@@ -183,6 +183,11 @@ def test_query_api_and_preallocated_buffers():
     build_cell_list(tp, 3.0, tc, pbc, *cache)
     assert cache[0].cpu().tolist() == ocpd[0].tolist()
     assert int(cache[4].sum()) == 600 and sorted(cache[6].cpu().tolist()) == list(range(600))
+    # every cache tensor against the oracle's restatement of build_cell_list (rebuild detection consumes their VALUES)
+    want = O.build_cell_cache(pos, 3.0, cell, [True] * 3, ncell)
+    names = ("cells_per_dimension", "atom_periodic_shifts", "atom_to_cell_mapping", "atoms_per_cell_count", "cell_atom_start_indices", "cell_atom_list")
+    for got, ref, what in zip((cache[0],) + tuple(cache[2:]), want, names):
+        assert np.array_equal(got.cpu().numpy().reshape(ref.shape), ref), what
     nm = torch.full((600, 64), 600, dtype=torch.int32, device=DEV)
     sh = torch.zeros((600, 64, 3), dtype=torch.int32, device=DEV)
     num = torch.zeros(600, dtype=torch.int32, device=DEV)
@@ -271,15 +276,17 @@ def test_rebuild_detection():
     cache = allocate_cell_list(500, ncell, radius, tp.device)
     build_cell_list(tp, 3.0, tc, pbc, *cache)
     assert not cell_list_needs_rebuild(tp, cache[3], cache[0], tc, pbc).item()
-    # numpy restatement of _check_atoms_changed_cells for a displaced configuration
-    cpd = cache[0].cpu().numpy()
-    disp = pos + g.normal(0, 0.35, pos.shape)
-    frac = disp @ np.linalg.inv(cell)
-    cc = np.floor(frac * cpd).astype(int)
-    for d, per in enumerate([True, True, False]):
-        cc[:, d] = np.mod(cc[:, d], cpd[d]) if per else np.clip(cc[:, d], 0, cpd[d] - 1)
-    expect = bool((cc != cache[3].cpu().numpy()).any())
-    assert cell_list_needs_rebuild(_t(disp), cache[3], cache[0], tc, pbc).item() == expect and expect
+    # the cache the checks consume equals the oracle's (mixed pbc, triclinic), and both checks agree with the oracle's restatements of
+    # _check_atoms_changed_cells / _check_atoms_moved_beyond_skin (rebuild_detection.py:37-170) on displaced configurations
+    want = O.build_cell_cache(pos, 3.0, cell, [True, True, False], ncell)
+    assert np.array_equal(cache[3].cpu().numpy(), want[2]) and np.array_equal(cache[0].cpu().numpy().reshape(-1), want[0].reshape(-1))
+    for sigma in (0.01, 0.05, 0.35):
+        disp = pos + g.normal(0, sigma, pos.shape)
+        expect = O.cells_changed(disp, cell, want[2], want[0], [True, True, False])
+        assert cell_list_needs_rebuild(_t(disp), cache[3], cache[0], tc, pbc).item() == expect, sigma
+        for skin in (0.02, 0.2, 1.5):
+            assert neighbor_list_needs_rebuild(tp, _t(disp), skin).item() == O.moved_beyond_skin(pos, disp, skin), (sigma, skin)
+    assert O.cells_changed(pos + g.normal(0, 0.35, pos.shape), cell, want[2], want[0], [True, True, False])
 
 
 @pytest.mark.parametrize("periodic", [False, True])
