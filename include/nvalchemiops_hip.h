@@ -161,19 +161,23 @@ int mi_d3(const void* positions, const int32_t* numbers, int n_atoms, int dtype,
  * energies are float64 whatever dtype is (the wrapper casts, ewald.py:577).  The reference adds -f to atom i and
  * atomically +f to atom j for every stored entry (ewald_kernels.py:518-544; charge gradients :864-873).  Over a
  * symmetric (full) list that is 2x the row owner's sum, which is what the fast path writes (no atomics).
- * `symmetry_scratch` (mi_ewald_symmetry_scratch_bytes() of device memory, may be NULL): when given, the same pass checksums the list in both
+ * `scratch` (device memory, may be NULL) has two optional parts, used when `scratch_bytes` covers them:
+ *   [0, mi_ewald_symmetry_scratch_bytes())            list-symmetry checksums: when given, the same pass checksums the list in both
  * directions and, if it is NOT symmetric (half lists, rows truncated by overflow, one-sided lists), two fix-up launches
- * redo forces / charge gradients with the reference's scatter; they exit at once otherwise.  NULL = the caller
+ * redo forces / charge gradients with the reference's scatter; they exit at once otherwise.  Without it the caller
  * guarantees a symmetric list.
+ *   [.., mi_ewald_real_scratch_bytes(n_atoms, dtype))  {x,y,z,q} records: the pair loop then gathers one record per neighbour
+ *                                                      instead of three coordinates + the charge (same arithmetic, same results).
  */
 #define MI_EW_FORCES 1
 #define MI_EW_CHARGE_GRAD 2
 size_t mi_ewald_symmetry_scratch_bytes(void);
+size_t mi_ewald_real_scratch_bytes(int n_atoms, int dtype);
 int mi_ewald_real(const void* positions, const void* charges, const void* cell, const void* alpha /*[n_systems]*/,
                   const int32_t* batch_idx, int n_atoms, int dtype, const int32_t* idx_j,
                   const int32_t* unit_shifts, const int32_t* neighbor_ptr, int max_neighbors, int mask_value,
                   int flags, double* energies /*[n_atoms]*/, void* forces /*[n_atoms,3] dtype*/,
-                  double* charge_grads /*[n_atoms]*/, void* symmetry_scratch /*or NULL*/, void* stream);
+                  double* charge_grads /*[n_atoms]*/, void* scratch /*or NULL*/, size_t scratch_bytes, void* stream);
 
 /* Explicit-k reciprocal-space Ewald.  Replaces `alchemiops::_[batch_]ewald_reciprocal_space_energy[_forces
  * [_charge_grad]]` (ewald.py:1365-2318; kernels ewald_kernels.py:1496-2480).  Two passes, no [K,N] phase tables:

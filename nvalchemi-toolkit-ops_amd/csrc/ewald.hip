@@ -59,13 +59,25 @@ __global__ __launch_bounds__(EW_SYM_SLOTS) void ew_sym_reduce_kernel(unsigned lo
   }
 }
 
-template <class T, bool CSR>
+// {x, y, z, q} per atom in one 16 / 32-byte record: the pair loop gathers ONE record per neighbour (fp64: two 16-byte loads of one
+// line) instead of three coordinate loads plus the charge from a second array -- like the D3 passes, this kernel is bound by the cache
+// lines its gathers touch.  Same values, same arithmetic: results are bit-identical with and without the records.
+template <class T>
+__global__ void ewald_pack_kernel(const T* __restrict__ pos, const T* __restrict__ q, int N, typename Vec4<T>::type* __restrict__ rec) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  typename Vec4<T>::type r;
+  r.x = pos[3 * (size_t)i]; r.y = pos[3 * (size_t)i + 1]; r.z = pos[3 * (size_t)i + 2]; r.w = q[i];
+  rec[i] = r;
+}
+
+template <class T, bool CSR, bool REC>
 __global__ __launch_bounds__(256) void ewald_real_kernel(const T* __restrict__ pos, const T* __restrict__ q, const T* __restrict__ cell,
                                                          const T* __restrict__ alpha, const int* __restrict__ batch_idx, int N,
                                                          const int* __restrict__ idx, const int* __restrict__ ush, const int* __restrict__ nptr,
                                                          int M, int mask_value, int flags, double* __restrict__ energies,
                                                          T* __restrict__ forces, double* __restrict__ cgrad,
-                                                         unsigned long long* __restrict__ sym) {
+                                                         unsigned long long* __restrict__ sym, const typename Vec4<T>::type* __restrict__ rec) {
   const int lane = threadIdx.x & (MI_WAVE - 1);
   const int i = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x / MI_WAVE) + threadIdx.x / MI_WAVE);
   if (i >= N) return;
@@ -84,13 +96,16 @@ __global__ __launch_bounds__(256) void ewald_real_kernel(const T* __restrict__ p
   for (long long e = beg + lane; e < end; e += MI_WAVE) {
     const int j = idx[e];
     if ((!CSR && j == mask_value) || (unsigned)j >= (unsigned)N) continue;  // out-of-range indices (e.g. -1 padding with another mask_value) are padding
-    const double qj = (double)q[j];
+    T pjx, pjy, pjz;
+    double qj;
+    if (REC) { const typename Vec4<T>::type r = rec[j]; pjx = r.x; pjy = r.y; pjz = r.z; qj = (double)r.w; }
+    else { pjx = pos[3 * (size_t)j]; pjy = pos[3 * (size_t)j + 1]; pjz = pos[3 * (size_t)j + 2]; qj = (double)q[j]; }
     const int S0 = ush[3 * e], S1 = ush[3 * e + 1], S2 = ush[3 * e + 2];
     if (sym) { hf += ew_entry_hash((unsigned)i, (unsigned)j, S0, S1, S2); hr += ew_entry_hash((unsigned)j, (unsigned)i, -S0, -S1, -S2); }
     const T fs[3] = {(T)S0, (T)S1, (T)S2};
     T sh[3];
     rowvec_mat3(fs, cm, sh);  // == transpose(cell) * S with the same summation order
-    const T sx = (pos[3 * (size_t)j] - pix) + sh[0], sy = (pos[3 * (size_t)j + 1] - piy) + sh[1], sz = (pos[3 * (size_t)j + 2] - piz) + sh[2];
+    const T sx = (pjx - pix) + sh[0], sy = (pjy - piy) + sh[1], sz = (pjz - piz) + sh[2];
     const double dist = (double)sqrt(sx * sx + sy * sy + sz * sz);
     if (!(dist > 1e-8)) continue;
     const double ar = al * dist;
@@ -496,6 +511,9 @@ __global__ __launch_bounds__(256) void coulomb_bwd_kernel(const double* __restri
 }  // namespace
 
 extern "C" size_t mi_ewald_symmetry_scratch_bytes(void) { return sizeof(unsigned long long) * EW_SYM_WORDS; }
+extern "C" size_t mi_ewald_real_scratch_bytes(int n_atoms, int dtype) {
+  return sizeof(unsigned long long) * EW_SYM_WORDS + (dtype == MI_F32 ? 16 : 32) * (size_t)(n_atoms > 0 ? n_atoms : 0);
+}
 
 extern "C" int mi_ewald_real_bwd(const void* positions, const void* charges, const void* cell, const void* alpha, const int32_t* batch_idx,
                                  int n_atoms, int dtype, const int32_t* idx_j, const int32_t* unit_shifts, const int32_t* neighbor_ptr,
@@ -537,7 +555,7 @@ extern "C" int mi_ewald_real_bwd(const void* positions, const void* charges, con
 extern "C" int mi_ewald_real(const void* positions, const void* charges, const void* cell, const void* alpha, const int32_t* batch_idx,
                              int n_atoms, int dtype, const int32_t* idx_j, const int32_t* unit_shifts, const int32_t* neighbor_ptr,
                              int max_neighbors, int mask_value, int flags, double* energies, void* forces, double* charge_grads,
-                             void* symmetry_scratch, void* stream) {
+                             void* scratch, size_t scratch_bytes, void* stream) {
   MI_REQUIRE(dtype == MI_F32 || dtype == MI_F64, "dtype");
   if (n_atoms <= 0) return MI_OK;
   MI_REQUIRE(positions && charges && cell && alpha && idx_j && unit_shifts && energies, "null pointer");
@@ -546,10 +564,19 @@ extern "C" int mi_ewald_real(const void* positions, const void* charges, const v
   hipStream_t st = (hipStream_t)stream;
   const int blocks = mi_blocks(n_atoms, 4);
   const bool csr = neighbor_ptr != nullptr;
-#define MI_EW(T_, CSR_)                                                                                                                     \
-  ewald_real_kernel<T_, CSR_><<<blocks, 256, 0, st>>>((const T_*)positions, (const T_*)charges, (const T_*)cell, (const T_*)alpha, batch_idx, \
-                                                      n_atoms, idx_j, unit_shifts, neighbor_ptr, max_neighbors, mask_value, flags, energies, \
-                                                      (T_*)forces, charge_grads, sym)
+#define MI_EW(T_, CSR_)                                                                                                                        \
+  do {                                                                                                                                         \
+    if (rec) {                                                                                                                                 \
+      ewald_pack_kernel<T_><<<mi_blocks(n_atoms, 256), 256, 0, st>>>((const T_*)positions, (const T_*)charges, n_atoms, (Vec4<T_>::type*)rec);  \
+      ewald_real_kernel<T_, CSR_, true><<<blocks, 256, 0, st>>>((const T_*)positions, (const T_*)charges, (const T_*)cell, (const T_*)alpha,   \
+                                                                batch_idx, n_atoms, idx_j, unit_shifts, neighbor_ptr, max_neighbors, mask_value,  \
+                                                                flags, energies, (T_*)forces, charge_grads, sym, (const Vec4<T_>::type*)rec);  \
+    } else {                                                                                                                                   \
+      ewald_real_kernel<T_, CSR_, false><<<blocks, 256, 0, st>>>((const T_*)positions, (const T_*)charges, (const T_*)cell, (const T_*)alpha,  \
+                                                                 batch_idx, n_atoms, idx_j, unit_shifts, neighbor_ptr, max_neighbors, mask_value, \
+                                                                 flags, energies, (T_*)forces, charge_grads, sym, nullptr);                    \
+    }                                                                                                                                          \
+  } while (0)
 #define MI_EWS(T_, CSR_)                                                                                                                         \
   do {                                                                                                                                           \
     ewald_fixup_zero_kernel<T_><<<mi_blocks(n_atoms, 256), 256, 0, st>>>(sym, (T_*)forces, nullptr, charge_grads, n_atoms);                      \
@@ -557,8 +584,13 @@ extern "C" int mi_ewald_real(const void* positions, const void* charges, const v
                                                                 batch_idx, n_atoms, idx_j, unit_shifts, neighbor_ptr, max_neighbors, mask_value,  \
                                                                 flags, (T_*)forces, charge_grads, sym);                                           \
   } while (0)
+  // scratch = [symmetry checksums | {x,y,z,q} records]: either part is used only when the buffer is large enough for it
+  const size_t sym_bytes = sizeof(unsigned long long) * EW_SYM_WORDS;
+  const size_t rec_bytes = (dtype == MI_F32 ? 16 : 32) * (size_t)n_atoms;
+  if (!scratch) scratch_bytes = 0;
   // the symmetry check only matters for outputs that are scattered in the reference (forces, charge gradients); energies are per owner
-  unsigned long long* sym = (flags & (MI_EW_FORCES | MI_EW_CHARGE_GRAD)) ? (unsigned long long*)symmetry_scratch : nullptr;
+  unsigned long long* sym = ((flags & (MI_EW_FORCES | MI_EW_CHARGE_GRAD)) && scratch_bytes >= sym_bytes) ? (unsigned long long*)scratch : nullptr;
+  void* rec = scratch_bytes >= sym_bytes + rec_bytes ? (void*)((char*)scratch + sym_bytes) : nullptr;
   if (sym) MI_HIP_CHECK(hipMemsetAsync(sym, 0, sizeof(unsigned long long) * EW_SYM_WORDS, st));
   mi_timing_begin("ewald_real", stream);
   if (dtype == MI_F32) { if (csr) MI_EW(float, true); else MI_EW(float, false); }

@@ -61,6 +61,12 @@ def ewald_sym_words() -> int:
     return int(L.mi_ewald_symmetry_scratch_bytes()) // 8
 
 
+def ewald_scratch_bytes(n_atoms: int, dtype: int) -> int:
+    L = lib()
+    L.mi_ewald_real_scratch_bytes.restype = ctypes.c_size_t
+    return int(L.mi_ewald_real_scratch_bytes(int(n_atoms), int(dtype)))
+
+
 def check(rc: int, what: str) -> None:
     if rc != 0:
         raise NativeLibraryError(f"{what} failed (code {rc}): {lib().mi_last_error().decode()}")

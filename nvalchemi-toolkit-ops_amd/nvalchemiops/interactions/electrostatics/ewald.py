@@ -14,6 +14,7 @@ from __future__ import annotations
 
 import torch
 
+import ctypes
 import math
 
 from nvalchemiops import _capi as C
@@ -53,10 +54,12 @@ def _real_space_launch(p, mask_value: int, compute_forces: bool, compute_charge_
     forces = torch.empty((n, 3), dtype=dt, device=dev) if compute_forces else None
     cgrads = torch.empty(n, dtype=torch.float64, device=dev) if compute_charge_gradients else None
     flags = (C.EW_FORCES if compute_forces else 0) | (C.EW_CHARGE_GRAD if compute_charge_gradients else 0)
-    sym = torch.empty(C.ewald_sym_words(), dtype=torch.int64, device=dev) if flags else None  # list-symmetry checksums (zeroed by the library)
+    # scratch: list-symmetry checksums (zeroed by the library) + the {x,y,z,q} records the pair loop gathers
+    nbytes = C.ewald_scratch_bytes(n, C.dtype_code(dt))
+    scratch = torch.empty(nbytes, dtype=torch.uint8, device=dev)
     rc = C.lib().mi_ewald_real(C.ptr(pos), C.ptr(p["q"]), C.ptr(p["cells"]), C.ptr(p["alpha"]), C.ptr(p["bi"]), n, C.dtype_code(dt), C.ptr(p["idx"]),
                                C.ptr(p["sh"]), C.ptr(p["nptr"]), int(p["m"]), int(mask_value), flags, C.ptr(energies), C.ptr(forces), C.ptr(cgrads),
-                               C.ptr(sym), C.stream_of(pos))
+                               C.ptr(scratch), ctypes.c_size_t(nbytes), C.stream_of(pos))
     C.check(rc, "mi_ewald_real")
     return energies, forces, cgrads
 
