@@ -373,8 +373,9 @@ __global__ void spline_gather_grad_kernel(const T* __restrict__ pos, const T* __
 
 // PME epilogue: potential (+ field) gather from PLANAR meshes [B,C,nx,ny,nz] (C = 1 or 4), corrections, force factor.
 // EIGHT LANES PER ATOM: lane l of an atom's group takes the x-plane tx = l of the stencil (order <= 6 planes; idle lanes add zeros) and
-// its order^2 points on the 1 or 4 meshes; the four partial sums meet in three shuffle steps.  One thread per atom was 1 563 waves for
-// the 100k-atom box -- six per CU, each with 500 dependent-latency loads: 0.13 ms for 0.55 GB that sit in L2 / MALL.
+// its order^2 points on the 1 or 4 meshes; the four partial sums meet in three shuffle steps.  Measured neutral on the 100k-atom box
+// (0.131 vs 0.133 ms with one thread per atom: the kernel is bound by the ~1.7 GB of cache lines the stencils pull from L2 / MALL, not by
+// per-thread latency); kept because small systems get 8x the threads.
 #define PG_LANES 8
 template <class T>
 __global__ __launch_bounds__(256) void pme_gather_finish_kernel(const T* __restrict__ pos, const T* __restrict__ charges, const int* __restrict__ batch_idx,
