@@ -610,7 +610,7 @@ def self_launch(n: int) -> int:
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200, help="timed steps (default 200: ~1 s of GPU time)")
+    ap.add_argument("--steps", type=int, default=250, help="timed steps (default 250: > 1 s of GPU time)")
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--atoms", type=int, default=100000)
     ap.add_argument("--cpu-sample", type=int, default=6912, help="atoms in the CPU-baseline sample box (0 = skip the CPU baseline)")
