@@ -240,6 +240,12 @@ __device__ __forceinline__ int d3_lockstep_trips(long long beg, long long end) {
 }
 
 // ---- pass 1: coordination numbers ------------------------------------------------------------------
+#ifndef D3_CN_DS
+#define D3_CN_DS 2  // trips of index / shift words in flight ahead of the one being evaluated
+#endif
+#ifndef D3_CN_DG
+#define D3_CN_DG 1  // trips of gathered atom records in flight (<= D3_CN_DS)
+#endif
 template <class T, bool CSR>
 __global__ __launch_bounds__(D3_LS_WAVES * MI_WAVE) void d3_cn_kernel(const T* __restrict__ pos, const int* __restrict__ numbers, int N, const int* __restrict__ idx,
                                                     const int* __restrict__ ush, const int* __restrict__ nptr, int M, int fill_value,
@@ -266,19 +272,27 @@ __global__ __launch_bounds__(D3_LS_WAVES * MI_WAVE) void d3_cn_kernel(const T* _
   const Int3* __restrict__ ush3 = reinterpret_cast<const Int3*>(ush);
   long long e = beg + lane;
   const unsigned jlim = d3_index_limit<CSR>(N, fill_value);
-  D3Step s0 = d3_fetch(idx, ush3, e, end, periodic), s1 = d3_fetch(idx, ush3, e + MI_WAVE, end, periodic);
-  bool v0 = s0.in && ((unsigned)s0.j < jlim);
-  auto p0 = apos[v0 ? s0.j : i];
+  // software pipeline: the index / shift words of D3_CN_DS trips ahead and the gathered records of D3_CN_DG trips ahead are in flight
+  // while trip 0 is evaluated (the pass is latency-bound on its L2 gathers under load: registers are plentiful here, 8 waves fit anyway)
+  D3Step s[D3_CN_DS + 1];
+  bool v[D3_CN_DG + 1];
+  typename Vec4<T>::type p[D3_CN_DG + 1];
+#pragma unroll
+  for (int k = 0; k < D3_CN_DS; ++k) s[k] = d3_fetch(idx, ush3, e + (long long)k * MI_WAVE, end, periodic);
+#pragma unroll
+  for (int k = 0; k < D3_CN_DG; ++k) { v[k] = s[k].in && ((unsigned)s[k].j < jlim); p[k] = apos[v[k] ? s[k].j : i]; }
   for (int trip = 0; trip < trips; ++trip) {
     __syncthreads();  // lock-step: the block's waves walk rows of consecutive atoms, i.e. nearly the same neighbours in nearly the same order
-    e += MI_WAVE;
-    const D3Step s2 = d3_fetch(idx, ush3, e + MI_WAVE, end, periodic);
-    const bool v1 = s1.in && ((unsigned)s1.j < jlim);
-    const auto p1 = apos[v1 ? s1.j : i];
+    s[D3_CN_DS] = d3_fetch(idx, ush3, e + (long long)D3_CN_DS * MI_WAVE, end, periodic);
+    v[D3_CN_DG] = s[D3_CN_DG].in && ((unsigned)s[D3_CN_DG].j < jlim);
+    p[D3_CN_DG] = apos[v[D3_CN_DG] ? s[D3_CN_DG].j : i];
+    const D3Step s0 = s[0];
+    const bool v0 = v[0];
+    const auto p0 = p[0];
     if (pk_out && s0.in) {  // wave-uniform pointer test; one coalesced 4-byte store per slot of this trip
       const unsigned cx = (unsigned)(s0.sh.a + 1), cy = (unsigned)(s0.sh.b + 1), cz = (unsigned)(s0.sh.c + 1);
       if (v0 && (cx > 2u || cy > 2u || cz > 2u)) *pk_flag = 1;  // benign race: every writer stores 1
-      __builtin_nontemporal_store(v0 ? ((unsigned)s0.j | ((cx & 3u) << 26) | ((cy & 3u) << 28) | (cz << 30)) : D3_PK_INVALID, pk_out + (e - MI_WAVE));
+      __builtin_nontemporal_store(v0 ? ((unsigned)s0.j | ((cx & 3u) << 26) | ((cy & 3u) << 28) | (cz << 30)) : D3_PK_INVALID, pk_out + e);
     }
     if (__any(v0)) {  // a step of pure padding costs nothing (padded matrices are mostly padding)
       bool valid = v0 && !(p0.w < (T)0);  // padding atom (Z == 0)
@@ -287,7 +301,11 @@ __global__ __launch_bounds__(D3_LS_WAVES * MI_WAVE) void d3_cn_kernel(const T* _
       const float f = d3_cn_count(g.rinv, rci, (float)p0.w, P.k1, nullptr);
       acc += valid ? (double)f : 0.0;
     }
-    s0 = s1; v0 = v1; p0 = p1; s1 = s2;
+#pragma unroll
+    for (int k = 0; k < D3_CN_DS; ++k) s[k] = s[k + 1];
+#pragma unroll
+    for (int k = 0; k < D3_CN_DG; ++k) { v[k] = v[k + 1]; p[k] = p[k + 1]; }
+    e += MI_WAVE;
   }
   acc = wave_sum(acc);
   if (lane == 0 && live) { cn[i] = (float)acc; aaux[i].x = (float)acc; }
