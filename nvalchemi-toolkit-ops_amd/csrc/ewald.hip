@@ -313,6 +313,82 @@ __global__ __launch_bounds__(256) void ewald_real_bwd_scatter_kernel(const T* __
   }
 }
 
+// ---- adjoint of the explicit FORCES (second derivatives of the pair sum) -------------------------------------------------------------
+// L = sum_k w_k . F_k with the reference's force definition (every stored entry (i -> j): F_i -= fm sep, F_j += fm sep;
+// ewald_kernels.py:518-544), so force-matching losses on real-space / PME forces can be differentiated (the reference gets this from
+// its Warp tape: "forces" is in the grad_arrays of the `_energy_forces*` ops).  Per entry, with dw = w_j - w_i, u = dw . sep,
+// g(d) = erfc(a d)/d^3 + c e^{-a^2 d^2}/d^2, c = 2a/sqrt(pi), analytic erfc' = -c e^{-a^2 d^2} (as in the energy adjoint):
+//   L_e = 1/2 q_i q_j g u ;   G = dL_e/dsep = 1/2 q_i q_j (g' u sep/d + g dw),   g' = -3 erfc/d^4 - 3 c e/d^3 - 2 a^2 c e/d
+//   dL/dr_j += G, dL/dr_i -= G ;  dL/dq_i += 1/2 q_j g u, dL/dq_j += 1/2 q_i g u ;  dL/dcell[a][b] += S_a G_b ;
+//   dL/dalpha += 1/2 q_i q_j u dg/dalpha,  dg/dalpha = -(4 a^2/sqrt(pi)) e^{-a^2 d^2}   (the erfc and prefactor terms cancel).
+// Entry-wise scatter with atomics: valid for every list, symmetric or not (a training-time kernel, not on the MD hot path).
+template <class T, bool CSR>
+__global__ __launch_bounds__(256) void ewald_real_force_bwd_kernel(const T* __restrict__ pos, const T* __restrict__ q, const T* __restrict__ cell,
+                                                                   const T* __restrict__ alpha, const int* __restrict__ batch_idx, int N,
+                                                                   const int* __restrict__ idx, const int* __restrict__ ush,
+                                                                   const int* __restrict__ nptr, int M, int mask_value, const T* __restrict__ gF,
+                                                                   double* __restrict__ gpos, double* __restrict__ gq, double* __restrict__ gcell,
+                                                                   double* __restrict__ galpha) {
+  const int lane = threadIdx.x & (MI_WAVE - 1);
+  const int i = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x / MI_WAVE) + threadIdx.x / MI_WAVE);
+  if (i >= N) return;
+  const int s = batch_idx ? batch_idx[i] : 0;
+  const double qi = (double)q[i], al = (double)alpha[s];
+  T cm[9];
+  for (int k = 0; k < 9; ++k) cm[k] = cell[9 * (size_t)s + k];
+  const T pix = pos[3 * (size_t)i], piy = pos[3 * (size_t)i + 1], piz = pos[3 * (size_t)i + 2];
+  const double wix = (double)gF[3 * (size_t)i], wiy = (double)gF[3 * (size_t)i + 1], wiz = (double)gF[3 * (size_t)i + 2];
+  const double c = 2.0 / 1.7724538509055159 * al;
+  long long beg, end;
+  if (CSR) { beg = nptr[i]; end = nptr[i + 1]; } else { beg = (long long)i * M; end = beg + M; }
+  double gx = 0, gy = 0, gz = 0, gqi = 0, ga = 0;
+  double gc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  for (long long e = beg + lane; e < end; e += MI_WAVE) {
+    const int j = idx[e];
+    if ((!CSR && j == mask_value) || (unsigned)j >= (unsigned)N) continue;
+    const double qj = (double)q[j];
+    const int S0 = ush[3 * e], S1 = ush[3 * e + 1], S2 = ush[3 * e + 2];
+    const T fs[3] = {(T)S0, (T)S1, (T)S2};
+    T sh[3];
+    rowvec_mat3(fs, cm, sh);
+    const T sxT = (pos[3 * (size_t)j] - pix) + sh[0], syT = (pos[3 * (size_t)j + 1] - piy) + sh[1], szT = (pos[3 * (size_t)j + 2] - piz) + sh[2];
+    const double d = (double)sqrt(sxT * sxT + syT * syT + szT * szT);
+    if (!(d > 1e-8)) continue;
+    const double sx = (double)sxT, sy = (double)syT, sz = (double)szT;
+    const double ar = al * d, ex = exp(-(ar * ar)), ec = erfc_as_poly(ar, ex);
+    const double d2 = d * d, d3 = d2 * d;
+    const double g = ec / d3 + c * ex / d2;
+    const double gp = -3.0 * ec / (d2 * d2) - 3.0 * c * ex / d3 - 2.0 * al * al * c * ex / d;
+    const double dwx = (double)gF[3 * (size_t)j] - wix, dwy = (double)gF[3 * (size_t)j + 1] - wiy, dwz = (double)gF[3 * (size_t)j + 2] - wiz;
+    const double u = dwx * sx + dwy * sy + dwz * sz;
+    const double hq = 0.5 * qi * qj;
+    const double k1 = hq * gp * u / d;
+    const double Gx = k1 * sx + hq * g * dwx, Gy = k1 * sy + hq * g * dwy, Gz = k1 * sz + hq * g * dwz;
+    gx -= Gx; gy -= Gy; gz -= Gz;
+    atomicAdd(&gpos[3 * (size_t)j], Gx); atomicAdd(&gpos[3 * (size_t)j + 1], Gy); atomicAdd(&gpos[3 * (size_t)j + 2], Gz);
+    gqi += 0.5 * qj * g * u;
+    atomicAdd(&gq[j], 0.5 * qi * g * u);
+    if (galpha) ga += hq * u * (-(4.0 * al * al / 1.7724538509055159) * ex);
+    if (gcell) {
+      const double Sv[3] = {(double)S0, (double)S1, (double)S2}, Gv[3] = {Gx, Gy, Gz};
+#pragma unroll
+      for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) gc[3 * a + b] += Sv[a] * Gv[b];
+    }
+  }
+  gx = wave_sum(gx); gy = wave_sum(gy); gz = wave_sum(gz); gqi = wave_sum(gqi);
+  if (lane == 0) {
+    atomicAdd(&gpos[3 * (size_t)i], gx); atomicAdd(&gpos[3 * (size_t)i + 1], gy); atomicAdd(&gpos[3 * (size_t)i + 2], gz);
+    atomicAdd(&gq[i], gqi);
+  }
+  if (galpha) { ga = wave_sum(ga); if (lane == 0 && ga != 0.0) atomicAdd(&galpha[s], ga); }
+  if (gcell) {
+#pragma unroll
+    for (int k = 0; k < 9; ++k) { const double v = wave_sum(gc[k]); if (lane == 0 && v != 0.0) atomicAdd(&gcell[9 * (size_t)s + k], v); }
+  }
+}
+
 // ---- explicit-k reciprocal space (ewald_kernels.py:1496-2480) -----------------------------------------------
 // The reference stores cos/sin(k.r) for every (k, atom) in two float64 [K,N] tables between its two kernels; here both passes
 // recompute the phases (fp64 sincos from registers) so HBM sees only positions, k-vectors and the [B,K] structure factors.
@@ -509,6 +585,34 @@ __global__ __launch_bounds__(256) void coulomb_bwd_kernel(const double* __restri
 }
 
 }  // namespace
+
+extern "C" int mi_ewald_real_forces_bwd(const void* positions, const void* charges, const void* cell, const void* alpha, const int32_t* batch_idx,
+                                        int n_atoms, int n_systems, int dtype, const int32_t* idx_j, const int32_t* unit_shifts,
+                                        const int32_t* neighbor_ptr, int max_neighbors, int mask_value, const void* grad_forces,
+                                        double* grad_positions, double* grad_charges, double* grad_cell, double* grad_alpha, void* stream) {
+  MI_REQUIRE(dtype == MI_F32 || dtype == MI_F64, "dtype");
+  MI_REQUIRE(n_systems >= 1 && grad_positions && grad_charges, "null gradient outputs");
+  hipStream_t st = (hipStream_t)stream;
+  if (n_atoms > 0) {
+    MI_HIP_CHECK(hipMemsetAsync(grad_positions, 0, sizeof(double) * 3 * (size_t)n_atoms, st));
+    MI_HIP_CHECK(hipMemsetAsync(grad_charges, 0, sizeof(double) * (size_t)n_atoms, st));
+  }
+  if (grad_cell) MI_HIP_CHECK(hipMemsetAsync(grad_cell, 0, sizeof(double) * 9 * (size_t)n_systems, st));
+  if (grad_alpha) MI_HIP_CHECK(hipMemsetAsync(grad_alpha, 0, sizeof(double) * (size_t)n_systems, st));
+  if (n_atoms <= 0) return MI_OK;
+  MI_REQUIRE(positions && charges && cell && alpha && idx_j && unit_shifts && grad_forces, "null pointer");
+  const int blocks = mi_blocks(n_atoms, 4);
+  const bool csr = neighbor_ptr != nullptr;
+#define MI_EFB(T_, CSR_)                                                                                                                          \
+  ewald_real_force_bwd_kernel<T_, CSR_><<<blocks, 256, 0, st>>>((const T_*)positions, (const T_*)charges, (const T_*)cell, (const T_*)alpha, batch_idx, \
+                                                                n_atoms, idx_j, unit_shifts, neighbor_ptr, max_neighbors, mask_value,               \
+                                                                (const T_*)grad_forces, grad_positions, grad_charges, grad_cell, grad_alpha)
+  if (dtype == MI_F32) { if (csr) MI_EFB(float, true); else MI_EFB(float, false); }
+  else { if (csr) MI_EFB(double, true); else MI_EFB(double, false); }
+#undef MI_EFB
+  MI_LAUNCH_CHECK();
+  return MI_OK;
+}
 
 extern "C" size_t mi_ewald_symmetry_scratch_bytes(void) { return sizeof(unsigned long long) * EW_SYM_WORDS; }
 extern "C" size_t mi_ewald_real_scratch_bytes(int n_atoms, int dtype) {

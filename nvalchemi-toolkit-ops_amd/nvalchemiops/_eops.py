@@ -10,8 +10,9 @@ the HIP kernels, with
     gather-gradient kernel, `spline_gather_vec3` (the force gather) has its adjoint too -- so forces of the reciprocal part can be
     differentiated once more (force-matching training); Green function and corrections have closed-form derivatives; the
     real-space sum uses `mi_ewald_real_bwd`, the explicit-k sum two more passes of its forward kernels.
-Not provided (explicit NotImplementedError, never a silent zero): derivatives of the real-space / explicit-k FORCE and
-charge-gradient outputs and of `spline_gather_gradient` (second derivatives of the pair kernels).
+The real-space FORCES are differentiable too (`mi_ewald_real_forces_bwd`: second derivatives of the pair sum), so a loss on total PME
+forces back-propagates to positions, charges, cell and alpha.  Not provided (explicit NotImplementedError, never a silent zero):
+derivatives of the charge-gradient outputs and of `spline_gather_gradient`.
 
 The public functions (`spline_spread`, `particle_mesh_ewald`, ...) call these ops when something requires grad or when they are
 being traced; otherwise they take the direct ctypes path (no dispatcher overhead, fused kernels).
@@ -558,6 +559,45 @@ real_bwd_op.register_autograd(lambda ctx, *g: (_ for _ in ()).throw(NotImplement
     op="nvalchemiops::ewald_real_space_backward", what="gradient"))), setup_context=lambda ctx, inputs, output: None)
 
 
+def _real_forces_bwd(positions: Tensor, charges: Tensor, cell: Tensor, alpha: Tensor, batch_idx: Optional[Tensor], neighbor_list: Optional[Tensor],
+                     neighbor_ptr: Optional[Tensor], neighbor_shifts: Optional[Tensor], neighbor_matrix: Optional[Tensor],
+                     neighbor_matrix_shifts: Optional[Tensor], mask_value: int, grad_forces: Tensor) -> tuple[Tensor, Tensor, Tensor, Tensor]:
+    """Float64 (dL/dpositions, dL/dcharges, dL/dcell [B,3,3], dL/dalpha [B]) for L = sum_k grad_forces_k . F_k: `mi_ewald_real_forces_bwd`
+    (second derivatives of the pair sum, entry-wise scatter)."""
+    from nvalchemiops.interactions.electrostatics.ewald import _real_space_inputs
+
+    p = _real_space_inputs(positions, charges, cell, alpha, neighbor_list, neighbor_ptr, neighbor_shifts, neighbor_matrix, neighbor_matrix_shifts,
+                           batch_idx)
+    pos, dt, dev = p["pos"], positions.dtype, positions.device
+    n, nsys = pos.shape[0], p["cells"].shape[0]
+    f64 = dict(dtype=torch.float64, device=dev)
+    gpos, gq = torch.zeros((n, 3), **f64), torch.zeros(n, **f64)
+    gcell, galpha = torch.zeros((nsys, 3, 3), **f64), torch.zeros(p["alpha"].shape[0], **f64)
+    if n == 0 or p["n_entries"] == 0:
+        return gpos, gq, gcell, galpha
+    g = grad_forces.detach().to(dt).contiguous()
+    rc = C.lib().mi_ewald_real_forces_bwd(C.ptr(pos), C.ptr(p["q"]), C.ptr(p["cells"]), C.ptr(p["alpha"]), C.ptr(p["bi"]), n, nsys, C.dtype_code(dt),
+                                          C.ptr(p["idx"]), C.ptr(p["sh"]), C.ptr(p["nptr"]), int(p["m"]), int(mask_value), C.ptr(g), C.ptr(gpos),
+                                          C.ptr(gq), C.ptr(gcell), C.ptr(galpha), C.stream_of(pos))
+    C.check(rc, "mi_ewald_real_forces_bwd")
+    return gpos, gq, gcell, galpha
+
+
+def _real_forces_bwd_fake(positions, charges, cell, alpha, batch_idx, neighbor_list, neighbor_ptr, neighbor_shifts, neighbor_matrix,
+                          neighbor_matrix_shifts, mask_value, grad_forces):
+    nsys = cell.reshape(-1, 3, 3).shape[0]
+    n = positions.shape[0]
+    f64 = dict(dtype=torch.float64)
+    return (positions.new_empty((n, 3), **f64), positions.new_empty((n,), **f64), positions.new_empty((nsys, 3, 3), **f64),
+            positions.new_empty((max(nsys, alpha.reshape(-1).shape[0]),), **f64))
+
+
+real_forces_bwd_op = torch.library.custom_op("nvalchemiops::ewald_real_space_forces_backward", _real_forces_bwd, mutates_args=())
+real_forces_bwd_op.register_fake(_real_forces_bwd_fake)
+real_forces_bwd_op.register_autograd(lambda ctx, *g: (_ for _ in ()).throw(NotImplementedError(
+    "nvalchemiops::ewald_real_space_forces_backward: third derivatives of the pair sum are not provided")), setup_context=lambda ctx, inputs, output: None)
+
+
 def _real_setup(fmt, batched):
     def setup(ctx, inputs, output):
         positions, charges, cell, alpha = inputs[:4]
@@ -580,22 +620,34 @@ def _real_backward(name, fmt, batched, n_out):
     from_names = ("energies", "forces", "charge_gradients")
 
     def backward(ctx, *grads):
-        for k in range(1, n_out):
-            if grads[k] is not None:
-                raise NotImplementedError(_SECOND_ORDER.format(op=f"alchemiops::{name}", what=from_names[k]))
+        # outputs: energies [, forces [, charge_gradients]].  Energies and FORCES are differentiable (first / second derivatives of the pair
+        # sum, two adjoint kernels); the charge-gradient output is not.
+        if n_out == 3 and grads[2] is not None:
+            raise NotImplementedError(_SECOND_ORDER.format(op=f"alchemiops::{name}", what=from_names[2]))
         need = ctx.needs_input_grad
         n_in = len(need)
-        if grads[0] is None:
+        g_e = grads[0]
+        g_f = grads[1] if n_out >= 2 else None
+        if g_e is None and g_f is None:
             return (None,) * n_in
         saved = ctx.saved_tensors
         positions, charges, cell, alpha, batch_idx = saved[:5]
         lists = (saved[5], saved[6], saved[7], None, None) if fmt == "list" else (None, None, None, saved[5], saved[6])
-        gpos, gq, gcell, galpha = real_bwd_op(positions, charges, cell, alpha, batch_idx, *lists, int(ctx.mask), grads[0])
+        gpos = gq = gcell = galpha = None
+        if g_e is not None:
+            gpos, gq, gcell, galpha = real_bwd_op(positions, charges, cell, alpha, batch_idx, *lists, int(ctx.mask), g_e)
+            gpos, gq = gpos.double(), gq.double()
+        if g_f is not None:
+            fp, fq, fc, fa = real_forces_bwd_op(positions, charges, cell, alpha, batch_idx, *lists, int(ctx.mask), g_f)
+            gpos = fp if gpos is None else gpos + fp
+            gq = fq if gq is None else gq + fq
+            gcell = fc if gcell is None else gcell + fc
+            galpha = fa if galpha is None else galpha + fa
         ga = None
         if need[3]:
             ga = (galpha.sum() if alpha.numel() == 1 and galpha.numel() > 1 else galpha[: alpha.numel()]).reshape(alpha.shape).to(alpha.dtype)
-        return (gpos if need[0] else None, gq.to(charges.dtype) if need[1] else None, gcell.reshape(cell.shape).to(cell.dtype) if need[2] else None,
-                ga) + (None,) * (n_in - 4)
+        return (gpos.to(positions.dtype) if need[0] else None, gq.to(charges.dtype) if need[1] else None,
+                gcell.reshape(cell.shape).to(cell.dtype) if need[2] else None, ga) + (None,) * (n_in - 4)
     return backward
 
 
