@@ -104,8 +104,8 @@ def _coordinate_grads(weight, gfrac, pos, cit, bi):
     cit_i = cit[bi.long()] if bi is not None else cit[0].expand(pos.shape[0], 3, 3)
     gpos = torch.einsum("na,nab->nb", wg, cit_i)
     outer = wg.unsqueeze(-1) * pos.unsqueeze(-2)
-    if bi is None:
-        gcit = outer.sum(0, keepdim=True).expand_as(cit) if cit.shape[0] == 1 else torch.zeros_like(cit).index_add(0, torch.zeros(pos.shape[0], dtype=torch.long, device=pos.device), outer)
+    if bi is None:  # single system: cit is [1,3,3]
+        gcit = outer.sum(0, keepdim=True)
     else:
         gcit = torch.zeros_like(cit).index_add(0, bi.long(), outer)
     return gpos, gcit
