@@ -685,7 +685,201 @@ def real_space_op(batched: bool, fmt: str, forces: bool, cgrad: bool):
     return REAL_OPS[(batched, fmt, forces or cgrad, cgrad)]
 
 
+
+# =====================================================================================================================================
+# Ewald reciprocal space over explicit k-vectors: 6 ops = {single, batch} x {energy, +forces, +forces +charge_grad}
+# =====================================================================================================================================
+def _recip_bwd(positions: Tensor, charges: Tensor, cell: Tensor, k_vectors: Tensor, alpha: Tensor, batch_idx: Optional[Tensor],
+               grad_energies: Tensor, need: int) -> tuple[Tensor, Tensor, Tensor, Tensor, Tensor]:
+    """Float64 (dL/dpositions, dL/dcharges, dL/dcell [B,3,3], dL/dk_vectors [B,K,3], dL/dalpha [B]) for L = sum_i g_i E_i; `need` is a bit
+    mask (1 atoms, 2 cell, 4 k_vectors, 8 alpha) of the gradients wanted, the others come back as zeros.  The cell enters through the
+    volume only (k_vectors are an independent input): dL/dcell = dL/dV |det cell| cell^-T."""
+    from nvalchemiops.interactions.electrostatics.ewald import _recip_adjoint, _recip_inputs
+
+    p = _recip_inputs(positions, charges, cell, k_vectors, alpha, batch_idx)
+    n, nsys, nk, dev = positions.shape[0], p["n_sys"], p["n_k"], positions.device
+    f64 = dict(dtype=torch.float64, device=dev)
+    if n == 0 or (batch_idx is not None and nk == 0):
+        return torch.zeros((n, 3), **f64), torch.zeros(n, **f64), torch.zeros((nsys, 3, 3), **f64), torch.zeros((nsys, nk, 3), **f64), torch.zeros(nsys, **f64)
+    gpos, gq, gkv, gal, gvol = _recip_adjoint(p, grad_energies, bool(need & 1), bool(need & 4), bool(need & 8), bool(need & 2))
+    gcell = None
+    if gvol is not None:
+        c64 = p["cells"].to(torch.float64)
+        gcell = (gvol * torch.abs(torch.linalg.det(c64))).reshape(-1, 1, 1) * torch.linalg.inv(c64).transpose(-1, -2)
+    return (gpos if gpos is not None else torch.zeros((n, 3), **f64), gq if gq is not None else torch.zeros(n, **f64),
+            gcell if gcell is not None else torch.zeros((nsys, 3, 3), **f64), gkv if gkv is not None else torch.zeros((nsys, nk, 3), **f64),
+            gal if gal is not None else torch.zeros(nsys, **f64))
+
+
+def _recip_bwd_fake(positions, charges, cell, k_vectors, alpha, batch_idx, grad_energies, need):
+    nsys = cell.reshape(-1, 3, 3).shape[0]
+    n, nk = positions.shape[0], k_vectors.shape[-2]
+    f64 = dict(dtype=torch.float64)
+    return (positions.new_empty((n, 3), **f64), positions.new_empty((n,), **f64), positions.new_empty((nsys, 3, 3), **f64),
+            positions.new_empty((nsys, nk, 3), **f64), positions.new_empty((nsys,), **f64))
+
+
+recip_bwd_op = torch.library.custom_op("nvalchemiops::ewald_reciprocal_space_backward", _recip_bwd, mutates_args=())
+recip_bwd_op.register_fake(_recip_bwd_fake)
+recip_bwd_op.register_autograd(lambda ctx, *g: (_ for _ in ()).throw(NotImplementedError(_SECOND_ORDER.format(
+    op="nvalchemiops::ewald_reciprocal_space_backward", what="gradient"))), setup_context=lambda ctx, inputs, output: None)
+
+
+def _recip_setup(ctx, inputs, output):
+    ctx.save_for_backward(*inputs)
+    ctx.set_materialize_grads(False)
+
+
+def _recip_backward(name, n_out):
+    def backward(ctx, *grads):
+        for k, what in ((1, "forces"), (2, "charge_gradients")):
+            if n_out > k and grads[k] is not None:
+                raise NotImplementedError(_SECOND_ORDER.format(op=f"alchemiops::{name}", what=what))
+        need = ctx.needs_input_grad
+        if grads[0] is None:
+            return (None,) * len(need)
+        positions, charges, cell, k_vectors, alpha, *rest = ctx.saved_tensors
+        mask = (1 if need[0] or need[1] else 0) | (2 if need[2] else 0) | (4 if need[3] else 0) | (8 if need[4] else 0)
+        gpos, gq, gcell, gkv, gal = recip_bwd_op(positions, charges, cell, k_vectors, alpha, rest[0] if rest else None, grads[0], mask)
+        if need[3] and gkv.shape != k_vectors.shape:  # one [K,3] set shared by all systems (or a [1,K,3] one)
+            gkv = gkv.sum(0).reshape(k_vectors.shape)
+        if need[4]:
+            gal = (gal.sum() if alpha.numel() == 1 and gal.numel() > 1 else gal[: alpha.numel()]).reshape(alpha.shape)
+        return (gpos.to(positions.dtype) if need[0] else None, gq.to(charges.dtype) if need[1] else None,
+                gcell.reshape(cell.shape).to(cell.dtype) if need[2] else None, gkv.to(k_vectors.dtype) if need[3] else None,
+                gal.to(alpha.dtype) if need[4] else None) + (None,) * (len(need) - 5)
+    return backward
+
+
+def _make_recip_op(name, batched, forces, cgrad):
+    from nvalchemiops.interactions.electrostatics.ewald import _recip_forward
+
+    n_out = 1 + int(forces) + int(cgrad)
+    ret = "Tensor" if n_out == 1 else "tuple[" + ", ".join(["Tensor"] * n_out) + "]"
+    args = "positions: Tensor, charges: Tensor, cell: Tensor, k_vectors: Tensor, alpha: Tensor" + (", batch_idx: Tensor" if batched else "")
+    src = (f"def {name}({args}) -> {ret}:\n"
+           f"    out = _recip_forward(positions, charges, cell, k_vectors, alpha, {'batch_idx' if batched else 'None'}, {forces}, {cgrad})\n"
+           f"    return out[0] if len(out) == 1 else out\n")
+    scope = {"_recip_forward": _recip_forward, "Tensor": Tensor}
+    exec(src, scope)  # as for the real-space ops: the schema must carry the reference's argument names (ewald.py:1603-2318)
+
+    def fake(positions, *rest):
+        n = positions.shape[0]
+        outs = (positions.new_empty((n,)),) + ((positions.new_empty((n, 3)),) if forces else ()) + ((positions.new_empty((n,)),) if cgrad else ())
+        return outs[0] if n_out == 1 else outs
+    return _op(name, scope[name], fake, _recip_backward(name, n_out), _recip_setup)
+
+
+RECIPROCAL_OPS = {}
+for _b in (False, True):
+    for _f, _c, _suffix in ((False, False, "energy"), (True, False, "energy_forces"), (True, True, "energy_forces_charge_grad")):
+        RECIPROCAL_OPS[(_b, _f, _c)] = _make_recip_op(("_batch" if _b else "") + "_ewald_reciprocal_space_" + _suffix, _b, _f, _c)
+
+
+def reciprocal_space_op(batched: bool, forces: bool, cgrad: bool):
+    return RECIPROCAL_OPS[(batched, forces or cgrad, cgrad)]
+
+
+# =====================================================================================================================================
+# Cut-off Coulomb: 8 ops = {single, batch} x {list, matrix} x {energy, +forces}, registered as `nvalchemiops::` like the reference's
+# (interactions/electrostatics/coulomb.py:716-1330); float64 in and out
+# =====================================================================================================================================
+def _coulomb_bwd(positions: Tensor, charges: Tensor, cell: Tensor, batch_idx: Optional[Tensor], neighbor_list: Optional[Tensor],
+                 neighbor_ptr: Optional[Tensor], neighbor_shifts: Optional[Tensor], neighbor_matrix: Optional[Tensor],
+                 neighbor_matrix_shifts: Optional[Tensor], fill_value: int, cutoff: float, alpha: float, with_forces: bool,
+                 grad_energies: Tensor) -> tuple[Tensor, Tensor, Tensor]:
+    """(dL/dpositions, dL/dcharges, dL/dcell [B,3,3]) for L = sum_i g_i E_i: `mi_coulomb_bwd`.  `with_forces` selects the energy prefactor
+    of the op being differentiated (the energy-only matrix kernels carry no 1/2, coulomb.py:340)."""
+    from nvalchemiops.interactions.electrostatics import coulomb
+
+    return coulomb._backward(positions, charges, cell, batch_idx, neighbor_list, neighbor_ptr, neighbor_shifts, neighbor_matrix,
+                             neighbor_matrix_shifts, fill_value, cutoff, alpha, with_forces, grad_energies)
+
+
+def _coulomb_bwd_fake(positions, charges, cell, batch_idx, neighbor_list, neighbor_ptr, neighbor_shifts, neighbor_matrix, neighbor_matrix_shifts,
+                      fill_value, cutoff, alpha, with_forces, grad_energies):
+    return torch.empty_like(positions), torch.empty_like(charges), cell.new_empty((cell.reshape(-1, 3, 3).shape[0], 3, 3))
+
+
+coulomb_bwd_op = torch.library.custom_op("nvalchemiops::coulomb_backward", _coulomb_bwd, mutates_args=())
+coulomb_bwd_op.register_fake(_coulomb_bwd_fake)
+coulomb_bwd_op.register_autograd(lambda ctx, *g: (_ for _ in ()).throw(NotImplementedError(_SECOND_ORDER.format(
+    op="nvalchemiops::coulomb_backward", what="gradient"))), setup_context=lambda ctx, inputs, output: None)
+
+
+def _coulomb_setup(fmt, batched):
+    def setup(ctx, inputs, output):
+        positions, charges, cell = inputs[:3]
+        rest = list(inputs[3:])
+        if fmt == "list":
+            nl, nptr, nsh = rest[:3]
+            rest = rest[3:]
+            lists = (nl, nptr, nsh, None, None)
+        else:
+            nm, nmsh = rest[:2]
+            rest = rest[2:]
+            lists = (None, None, None, nm, nmsh)
+        batch_idx = rest.pop(0) if batched else None
+        ctx.cutoff, ctx.alpha = rest[0], rest[1]
+        ctx.fill = rest[2] if fmt == "matrix" else 0
+        ctx.save_for_backward(positions, charges, cell, batch_idx, *lists)
+        ctx.set_materialize_grads(False)
+    return setup
+
+
+def _coulomb_backward(name, forces):
+    def backward(ctx, *grads):
+        if forces and grads[1] is not None:
+            raise NotImplementedError(_SECOND_ORDER.format(op=f"nvalchemiops::{name}", what="forces"))
+        need = ctx.needs_input_grad
+        if grads[0] is None:
+            return (None,) * len(need)
+        positions, charges, cell, batch_idx, *lists = ctx.saved_tensors
+        gpos, gq, gcell = coulomb_bwd_op(positions, charges, cell, batch_idx, *lists, int(ctx.fill), float(ctx.cutoff), float(ctx.alpha), forces,
+                                         grads[0])
+        return (gpos if need[0] else None, gq if need[1] else None, gcell.reshape(cell.shape) if need[2] else None) + (None,) * (len(need) - 3)
+    return backward
+
+
+def _make_coulomb_op(name, fmt, batched, forces):
+    from nvalchemiops.interactions.electrostatics import coulomb
+
+    ret = "tuple[Tensor, Tensor]" if forces else "Tensor"
+    lists = ("neighbor_list: Tensor, neighbor_ptr: Tensor, neighbor_shifts: Tensor" if fmt == "list" else
+             "neighbor_matrix: Tensor, neighbor_matrix_shifts: Tensor")
+    args = (f"positions: Tensor, charges: Tensor, cell: Tensor, {lists}, " + ("batch_idx: Tensor, " if batched else "") + "cutoff: float, alpha: float"
+            + (", fill_value: int" if fmt == "matrix" else ""))
+    call = ("neighbor_list, neighbor_ptr, neighbor_shifts, None, None, 0" if fmt == "list" else
+            "None, None, None, neighbor_matrix, neighbor_matrix_shifts, fill_value")
+    src = (f"def {name}({args}) -> {ret}:\n"
+           f"    e, f = _forward(positions, charges, cell, {'batch_idx' if batched else 'None'}, {call}, cutoff, alpha, {forces})\n"
+           f"    return {'(e, f)' if forces else 'e'}\n")
+    scope = {"_forward": coulomb._forward, "Tensor": Tensor}
+    exec(src, scope)  # the schema carries the reference's argument names and order
+
+    def fake(positions, *rest):
+        n = positions.shape[0]
+        e = positions.new_empty((n,), dtype=torch.float64)
+        return (e, positions.new_empty((n, 3), dtype=torch.float64)) if forces else e
+    op = torch.library.custom_op(f"nvalchemiops::{name}", scope[name], mutates_args=())
+    op.register_fake(fake)
+    op.register_autograd(_coulomb_backward(name, forces), setup_context=_coulomb_setup(fmt, batched))
+    return op
+
+
+COULOMB_OPS = {}
+for _b in (False, True):
+    for _fmt in ("list", "matrix"):
+        for _f in (False, True):
+            COULOMB_OPS[(_b, _fmt, _f)] = _make_coulomb_op(("_batch" if _b else "") + "_coulomb_energy" + ("_forces" if _f else "") + "_" + _fmt,
+                                                           _fmt, _b, _f)
+
+
+def coulomb_op(batched: bool, fmt: str, forces: bool):
+    return COULOMB_OPS[(batched, fmt, forces)]
+
+
 __all__ = ["spline_spread_op", "batch_spline_spread_op", "spline_gather_op", "batch_spline_gather_op", "spline_gather_vec3_op",
            "batch_spline_gather_vec3_op", "spline_gather_gradient_op", "batch_spline_gather_gradient_op", "pme_green_structure_factor_op",
            "batch_pme_green_structure_factor_op", "pme_energy_corrections_op", "batch_pme_energy_corrections_op",
-           "pme_energy_corrections_with_charge_grad_op", "batch_pme_energy_corrections_with_charge_grad_op", "REAL_OPS", "real_space_op"]
+           "pme_energy_corrections_with_charge_grad_op", "batch_pme_energy_corrections_with_charge_grad_op", "REAL_OPS", "real_space_op", "RECIPROCAL_OPS", "reciprocal_space_op", "COULOMB_OPS", "coulomb_op"]

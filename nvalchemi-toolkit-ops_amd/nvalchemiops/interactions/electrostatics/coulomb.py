@@ -5,7 +5,8 @@ One HIP kernel family (csrc/ewald.hip, `mi_coulomb` / `mi_coulomb_bwd`) covers l
 As in the reference every input is upcast to float64 before the launch and the results are cast back to the positions dtype
 (:1423-1426, :1489).  Forces follow the reference's scatter (+f on the row owner, -f on atom j), so full, half and asymmetric
 lists all give the reference's numbers.  Energies are differentiable w.r.t. positions, charges and cell through a hand-written
-adjoint kernel (the reference records a Warp tape).
+adjoint kernel (the reference records a Warp tape); when something requires grad, or under torch.compile, the call goes through the
+registered `nvalchemiops::_[batch_]coulomb_*` ops (nvalchemiops/_eops.py), otherwise straight to the C ABI.
 
 Reference behaviour kept on purpose: the energy-only MATRIX kernels use q_i q_j without the 1/2 that every other Coulomb kernel
 applies (coulomb.py:340, :623 vs :192, :400), so `coulomb_energy(neighbor_matrix=...)` returns twice the energies that
@@ -29,32 +30,57 @@ def _launch(pos, q, cells, bi, idx, sh, nptr, m, fill_value, cutoff, alpha, epre
     return energies, forces
 
 
-class _CoulombEnergyFn(torch.autograd.Function):
-    """Per-atom energies (+ non-differentiable explicit forces) with the adjoint kernel `mi_coulomb_bwd` for positions, charges, cell."""
+def _adjoint(pos, q, cells, bi, idx, sh, nptr, m, fill_value, cutoff, alpha, epref, g_e):
+    """(dL/dpositions, dL/dcharges, dL/dcell) of L = sum_i g_i E_i: the adjoint kernel `mi_coulomb_bwd` (the reference records a Warp tape)."""
+    g = g_e.detach().to(torch.float64).contiguous()
+    gpos, gq, gcell = torch.empty_like(pos), torch.empty_like(q), torch.empty_like(cells)
+    rc = C.lib().mi_coulomb_bwd(C.ptr(pos), C.ptr(q), C.ptr(cells), C.ptr(bi), pos.shape[0], cells.shape[0], C.ptr(idx), C.ptr(sh), C.ptr(nptr),
+                                int(m), int(fill_value), C.cdouble(cutoff), C.cdouble(alpha), C.cdouble(epref), C.ptr(g), C.ptr(gpos), C.ptr(gq),
+                                C.ptr(gcell), C.stream_of(pos))
+    C.check(rc, "mi_coulomb_bwd")
+    return gpos, gq, gcell
 
-    @staticmethod
-    def forward(ctx, positions, charges, cells, bi, idx, sh, nptr, m, fill_value, cutoff, alpha, epref, want_forces):
-        pos, q, c = positions.detach().contiguous(), charges.detach().contiguous(), cells.detach().contiguous()
-        energies, forces = _launch(pos, q, c, bi, idx, sh, nptr, m, fill_value, cutoff, alpha, epref, want_forces)
-        ctx.save_for_backward(pos, q, c)
-        ctx.aux = (bi, idx, sh, nptr, m, fill_value, cutoff, alpha, epref)
-        if forces is None:
-            forces = torch.empty(0, dtype=torch.float64, device=pos.device)
-        ctx.mark_non_differentiable(forces)
-        return energies, forces
 
-    @staticmethod
-    def backward(ctx, g_e, _g_f):
-        pos, q, c = ctx.saved_tensors
-        bi, idx, sh, nptr, m, fill_value, cutoff, alpha, epref = ctx.aux
-        n = pos.shape[0]
-        g = g_e.detach().to(torch.float64).contiguous()
-        gpos, gq, gcell = torch.empty_like(pos), torch.empty_like(q), torch.empty_like(c)
-        rc = C.lib().mi_coulomb_bwd(C.ptr(pos), C.ptr(q), C.ptr(c), C.ptr(bi), n, c.shape[0], C.ptr(idx), C.ptr(sh), C.ptr(nptr), int(m),
-                                    int(fill_value), C.cdouble(cutoff), C.cdouble(alpha), C.cdouble(epref), C.ptr(g), C.ptr(gpos), C.ptr(gq),
-                                    C.ptr(gcell), C.stream_of(pos))
-        C.check(rc, "mi_coulomb_bwd")
-        return (gpos, gq, gcell) + (None,) * 10
+def _lists(n, dev, neighbor_list, neighbor_ptr, neighbor_shifts, neighbor_matrix, neighbor_matrix_shifts, fill_value, want_forces):
+    """(idx, shifts, row pointer | None, row width, fill value, energy prefactor) of either neighbour format."""
+    if neighbor_list is not None:
+        idx, sh, nptr, m, fv = C.i32(neighbor_list[1]), C.i32(neighbor_shifts), C.i32(neighbor_ptr), 0, 0
+        if nptr.numel() < n + 1:
+            # the reference's own fixture passes a short neighbor_ptr (test_coulomb.py:50: 2 entries for 2 atoms) and reads past its
+            # end; here the missing rows are defined as empty instead
+            last = nptr[-1:] if nptr.numel() else torch.zeros(1, dtype=torch.int32, device=dev)
+            nptr = torch.cat([nptr, last.expand(n + 1 - nptr.numel())]).contiguous()
+        return idx, sh, nptr, m, fv, 0.5
+    idx, sh, m = C.i32(neighbor_matrix), C.i32(neighbor_matrix_shifts), neighbor_matrix.shape[1]
+    fv = n if fill_value is None else int(fill_value)
+    return idx, sh, None, m, fv, (0.5 if want_forces else 1.0)  # coulomb.py:340 / :623 -- see the module docstring
+
+
+def _forward(positions, charges, cell, batch_idx, neighbor_list, neighbor_ptr, neighbor_shifts, neighbor_matrix, neighbor_matrix_shifts,
+             fill_value, cutoff, alpha, want_forces):
+    """float64 (energies, forces | None) of float64 inputs, no autograd graph: body of the eight `nvalchemiops::_[batch_]coulomb_*` ops
+    (nvalchemiops/_eops.py) and of the plain eager call."""
+    n, dev = positions.shape[0], positions.device
+    idx, sh, nptr, m, fv, epref = _lists(n, dev, neighbor_list, neighbor_ptr, neighbor_shifts, neighbor_matrix, neighbor_matrix_shifts, fill_value,
+                                         want_forces)
+    if n == 0 or idx.numel() == 0:
+        return torch.zeros(n, dtype=torch.float64, device=dev), (torch.zeros((n, 3), dtype=torch.float64, device=dev) if want_forces else None)
+    bi = None if batch_idx is None else C.i32(batch_idx)
+    return _launch(positions.detach().contiguous(), charges.detach().contiguous(), cell.detach().reshape(-1, 3, 3).contiguous(), bi, idx, sh, nptr, m,
+                   fv, float(cutoff), float(alpha), epref, want_forces)
+
+
+def _backward(positions, charges, cell, batch_idx, neighbor_list, neighbor_ptr, neighbor_shifts, neighbor_matrix, neighbor_matrix_shifts,
+              fill_value, cutoff, alpha, want_forces, grad_energies):
+    n, dev = positions.shape[0], positions.device
+    idx, sh, nptr, m, fv, epref = _lists(n, dev, neighbor_list, neighbor_ptr, neighbor_shifts, neighbor_matrix, neighbor_matrix_shifts, fill_value,
+                                         want_forces)
+    cells = cell.detach().reshape(-1, 3, 3).contiguous()
+    if n == 0 or idx.numel() == 0:  # nothing stored: zero gradients, as the reference's tape gives (test_coulomb.py:964-996, :1954-2175)
+        return torch.zeros((n, 3), dtype=torch.float64, device=dev), torch.zeros(n, dtype=torch.float64, device=dev), torch.zeros_like(cells)
+    bi = None if batch_idx is None else C.i32(batch_idx)
+    return _adjoint(positions.detach().contiguous(), charges.detach().contiguous(), cells, bi, idx, sh, nptr, m, fv, float(cutoff), float(alpha),
+                    epref, grad_energies)
 
 
 def _run(positions, charges, cell, cutoff, alpha, neighbor_list, neighbor_ptr, neighbor_shifts, neighbor_matrix, neighbor_matrix_shifts,
@@ -67,40 +93,29 @@ def _run(positions, charges, cell, cutoff, alpha, neighbor_list, neighbor_ptr, n
         raise ValueError("Cannot provide both neighbor list and neighbor matrix formats")
     if use_list and neighbor_ptr is None:
         raise ValueError("neighbor_ptr is required when using neighbor_list format")
-    n, dev = positions.shape[0], positions.device
+    n = positions.shape[0]
     if n > 0:
         C.require_device(positions, charges, cell, neighbor_list, neighbor_ptr, neighbor_shifts, neighbor_matrix, neighbor_matrix_shifts, batch_idx)
     pos = positions.to(torch.float64)
     q = charges.to(torch.float64)
     cells = cell.to(torch.float64).reshape(-1, 3, 3)
-    bi = None if batch_idx is None else C.i32(batch_idx)
-    if use_list:
-        idx, sh, nptr, m, fv = C.i32(neighbor_list[1]), C.i32(neighbor_shifts), C.i32(neighbor_ptr), 0, 0
-        if nptr.numel() < n + 1:
-            # the reference's own fixture passes a short neighbor_ptr (test_coulomb.py:50: 2 entries for 2 atoms) and reads past its
-            # end; here the missing rows are defined as empty instead
-            last = nptr[-1:] if nptr.numel() else torch.zeros(1, dtype=torch.int32, device=dev)
-            nptr = torch.cat([nptr, last.expand(n + 1 - nptr.numel())]).contiguous()
-        epref = 0.5
+    if C.tracing() or (torch.is_grad_enabled() and any(t.requires_grad for t in (pos, q, cells))):
+        from nvalchemiops import _eops
+
+        op = _eops.coulomb_op(batch_idx is not None, "list" if use_list else "matrix", want_forces)
+        lists = (neighbor_list, neighbor_ptr, neighbor_shifts) if use_list else (neighbor_matrix, neighbor_matrix_shifts)
+        tail = (float(cutoff), float(alpha)) + (() if use_list else (n if fill_value is None else int(fill_value),))
+        out = op(pos, q, cells, *lists, *((batch_idx,) if batch_idx is not None else ()), *tail)
+        return out if want_forces else (out, None)
+    if not use_list:
+        neighbor_list = neighbor_ptr = neighbor_shifts = None
     else:
-        idx, sh, nptr, m = C.i32(neighbor_matrix), C.i32(neighbor_matrix_shifts), None, neighbor_matrix.shape[1]
-        fv = n if fill_value is None else int(fill_value)
-        epref = 0.5 if want_forces else 1.0  # coulomb.py:340 / :623 -- see the module docstring
-    if n == 0 or idx.numel() == 0:
-        # nothing stored: zero energies that still hang on the inputs' graph, so .backward() yields zero gradients as the reference's
-        # tape does (test_coulomb.py:964-996, :1954-2175)
-        e = torch.zeros(n, dtype=torch.float64, device=dev)
-        if torch.is_grad_enabled() and any(t.requires_grad for t in (pos, q, cells)):
-            e = e + 0.0 * (pos.sum() + q.sum() + cells.sum())
-        return e, (torch.zeros((n, 3), dtype=torch.float64, device=dev) if want_forces else None)
-    if torch.is_grad_enabled() and any(t.requires_grad for t in (pos, q, cells)):
-        e, f = _CoulombEnergyFn.apply(pos, q, cells, bi, idx, sh, nptr, m, fv, float(cutoff), float(alpha), epref, want_forces)
-        return e, (f if want_forces else None)
-    return _launch(pos.detach().contiguous(), q.detach().contiguous(), cells.detach().contiguous(), bi, idx, sh, nptr, m, fv, float(cutoff),
-                   float(alpha), epref, want_forces)
+        neighbor_matrix = neighbor_matrix_shifts = None
+    return _forward(pos, q, cells, batch_idx, neighbor_list, neighbor_ptr, neighbor_shifts, neighbor_matrix, neighbor_matrix_shifts, fill_value,
+                    cutoff, alpha, want_forces)
 
 
-@C.eager
+@C.traceable
 def coulomb_energy(positions: torch.Tensor, charges: torch.Tensor, cell: torch.Tensor, cutoff: float, alpha: float = 0.0,
                    neighbor_list: torch.Tensor | None = None, neighbor_ptr: torch.Tensor | None = None,
                    neighbor_shifts: torch.Tensor | None = None, neighbor_matrix: torch.Tensor | None = None,
@@ -114,7 +129,7 @@ def coulomb_energy(positions: torch.Tensor, charges: torch.Tensor, cell: torch.T
     return e.to(positions.dtype)
 
 
-@C.eager
+@C.traceable
 def coulomb_energy_forces(positions: torch.Tensor, charges: torch.Tensor, cell: torch.Tensor, cutoff: float, alpha: float = 0.0,
                           neighbor_list: torch.Tensor | None = None, neighbor_ptr: torch.Tensor | None = None,
                           neighbor_shifts: torch.Tensor | None = None, neighbor_matrix: torch.Tensor | None = None,
@@ -127,7 +142,7 @@ def coulomb_energy_forces(positions: torch.Tensor, charges: torch.Tensor, cell: 
     return e.to(positions.dtype), f.to(positions.dtype)
 
 
-@C.eager
+@C.traceable
 def coulomb_forces(positions: torch.Tensor, charges: torch.Tensor, cell: torch.Tensor, cutoff: float, alpha: float = 0.0,
                    neighbor_list: torch.Tensor | None = None, neighbor_ptr: torch.Tensor | None = None,
                    neighbor_shifts: torch.Tensor | None = None, neighbor_matrix: torch.Tensor | None = None,

@@ -172,9 +172,43 @@ def _recip_gather(pos, q, kv, al, bi, sf, tq, n_k, potential=False, kforce=False
     return out
 
 
-class _EwaldRecipEnergyFn(torch.autograd.Function):
-    """Differentiable per-atom reciprocal energies (positions, charges, k-vectors, alpha, volume).  With L = sum_i g_i E_i and the
-    g-weighted structure factors S^g = G sum_j g_j q_j exp(i k.r_j):
+def _recip_inputs(positions, charges, cell, k_vectors, alpha, batch_idx):
+    """Launch arguments of the explicit-k reciprocal sum: detached contiguous arrays in the positions dtype, [B,K,3] k-vectors, [B]
+    alpha, and for a batch the CSR system pointer + the largest system (the structure-factor kernel's block shape)."""
+    n, dev, dt = positions.shape[0], positions.device, positions.dtype
+    cells, n_sys = _prepare_cell(cell)
+    kv = k_vectors if k_vectors.dim() == 3 else k_vectors.unsqueeze(0)
+    if kv.shape[0] != n_sys:
+        kv = kv.expand(n_sys, -1, -1)
+    p = dict(n_sys=n_sys, n_k=kv.shape[1], pos=positions.detach().contiguous(), q=charges.detach().to(dt).contiguous(),
+             cells=cells.detach().to(dt).contiguous(), kv=kv.detach().to(dt).contiguous(),
+             al=_prepare_alpha(alpha, n_sys, dt, dev).detach().contiguous(), bi=None, sptr=None, max_atoms=n)
+    if batch_idx is not None and n > 0:
+        p["bi"] = C.i32(batch_idx)
+        counts = torch.bincount(batch_idx.long(), minlength=n_sys)
+        sptr = torch.zeros(n_sys + 1, dtype=torch.int32, device=dev)
+        sptr[1:] = torch.cumsum(counts, dim=0)
+        p["sptr"], p["max_atoms"] = sptr, int(counts.max().item())
+    return p
+
+
+def _recip_forward(positions, charges, cell, k_vectors, alpha, batch_idx, forces: bool, cgrads: bool):
+    """(energies [, forces] [, charge_grads]) in the positions dtype; no autograd graph (the `alchemiops::_[batch_]ewald_reciprocal_space_*`
+    ops of nvalchemiops/_eops.py and the plain eager call both land here)."""
+    n, dev, dt = positions.shape[0], positions.device, positions.dtype
+    k3 = k_vectors if k_vectors.dim() == 3 else k_vectors.unsqueeze(0)
+    if n == 0 or (batch_idx is not None and k3.shape[1] == 0):
+        return (torch.zeros(n, dtype=dt, device=dev),) + ((torch.zeros((n, 3), dtype=dt, device=dev),) if forces else ()) + (
+            (torch.zeros(n, dtype=dt, device=dev),) if cgrads else ())
+    p = _recip_inputs(positions, charges, cell, k_vectors, alpha, batch_idx)
+    sf, tq = _structure_factors(p["pos"], p["q"], p["kv"], p["cells"], p["al"], p["sptr"], p["n_sys"], p["n_k"], p["max_atoms"])
+    res = _recip_gather(p["pos"], p["q"], p["kv"], p["al"], p["bi"], sf, tq, p["n_k"], energies=True, forces=forces, cgrads=cgrads)
+    return (res["energies"].to(dt),) + ((res["forces"],) if forces else ()) + ((res["cgrads"].to(dt),) if cgrads else ())
+
+
+def _recip_adjoint(p, g_e, need_atoms: bool, need_kv: bool, need_alpha: bool, need_vol: bool):
+    """Adjoint of the per-atom reciprocal energies.  With L = sum_i g_i E_i and the g-weighted structure factors
+    S^g = G sum_j g_j q_j exp(i k.r_j):
         dL/dr_m = -1/2 q_m (g_m kf_m[S] + kf_m[S^g]),
         dL/dq_m = 1/2 (g_m phi_m[S] + phi_m[S^g]) - 2 g_m alpha q_m/sqrt(pi) - pi/(2 alpha^2 V) (g_m Q + sum_i g_i q_i)
     -- two more passes of the forward kernels instead of a recorded tape (reference: autograd.py:525-665).
@@ -183,76 +217,56 @@ class _EwaldRecipEnergyFn(torch.autograd.Function):
         dL/dk   = 1/2 W dlnG/dk + 1/(2G) d/dk Re[conj(A^g) A] G^2   (first moments sum_j w_j r_j exp(i k.r_j): six more
                   structure-factor passes with weights q r_c and g q r_c),
         dL/dalpha = 1/2 sum_k W k^2/(2 alpha^3) + sum_i g_i (-q_i^2/sqrt(pi) + pi q_i Q/(alpha^3 V)),
-        dL/dV     = -1/(2V) sum_k W + sum_i g_i pi q_i Q/(2 alpha^2 V^2);
-    `vol` = |det cell| is a torch-differentiable input whose value the kernels recompute from `cells`."""
-
-    @staticmethod
-    def forward(ctx, positions, charges, kv, al, vol, cells, bi, sptr, max_atoms):
-        pos, q = positions.detach().contiguous(), charges.detach().contiguous()
-        kv, al = kv.detach().contiguous(), al.detach().contiguous()
-        n_sys, n_k = kv.shape[0], kv.shape[1]
-        sf, tq = _structure_factors(pos, q, kv, cells, al, sptr, n_sys, n_k, max_atoms)
-        out = _recip_gather(pos, q, kv, al, bi, sf, tq, n_k, energies=True)
-        ctx.save_for_backward(pos, q, kv, cells, al, sf, tq, *(t for t in (bi, sptr) if t is not None))
-        ctx.meta = (bi is not None, max_atoms)
-        return out["energies"].to(pos.dtype)
-
-    @staticmethod
-    def backward(ctx, g_e):
-        pos, q, kv, cells, al, sf, tq, *rest = ctx.saved_tensors
-        batched, max_atoms = ctx.meta
-        bi, sptr = (rest[0], rest[1]) if batched else (None, None)
-        n_sys, n_k = kv.shape[0], kv.shape[1]
-        need = ctx.needs_input_grad
-        g = g_e.detach().to(torch.float64)
-        q64, al64 = q.to(torch.float64), al.to(torch.float64)
-        gq = (g * q64).to(pos.dtype).contiguous()
-        sfg, tqg = _structure_factors(pos, gq, kv, cells, al, sptr, n_sys, n_k, max_atoms)
-        sel = bi.long() if batched else torch.zeros(pos.shape[0], dtype=torch.long, device=pos.device)
-        a_i = al64[sel]
-        gpos = gch = gkv = gal = gvol = None
-        if need[0] or need[1]:
-            a = _recip_gather(pos, q, kv, al, bi, sf, None, n_k, potential=True, kforce=True)
-            b = _recip_gather(pos, q, kv, al, bi, sfg, None, n_k, potential=True, kforce=True)
-            if need[0]:
-                gpos = ((-0.5 * q64).unsqueeze(1) * (g.unsqueeze(1) * a["kforce"] + b["kforce"])).to(pos.dtype)
-            if need[1]:
-                gch = (0.5 * (g * a["potential"] + b["potential"]) - 2.0 * g * a_i * q64 / math.sqrt(math.pi)
-                       - math.pi / (2.0 * a_i * a_i) * (g * tq[sel] + tqg[sel])).to(pos.dtype)
-        if need[2] or need[3] or need[4]:
-            kv64 = kv.to(torch.float64)
-            k2 = (kv64 * kv64).sum(-1)
-            vol = torch.abs(torch.linalg.det(cells.to(torch.float64)))
-            a2 = (al64 * al64).unsqueeze(1)
-            ok = k2 >= 1e-10
-            k2s = torch.where(ok, k2, torch.ones_like(k2))
-            green = 8.0 * math.pi / vol.unsqueeze(1) * torch.exp(-k2s / (4.0 * a2)) / k2s
-            ok = ok & (green > 1e-280)
-            ginv = torch.where(ok, 1.0 / torch.where(ok, green, torch.ones_like(green)), torch.zeros_like(green))
-            srq, siq, srg, sig = sf[..., 0], sf[..., 1], sfg[..., 0], sfg[..., 1]
-            w = (srg * srq + sig * siq) * ginv
-            if need[2]:
-                gk = 0.5 * w.unsqueeze(-1) * (-kv64 * (0.5 / a2 + 2.0 / k2s).unsqueeze(-1))
-                cross = []
-                for c in range(3):
-                    rc_ = pos[:, c]
-                    m, _ = _structure_factors(pos, (q * rc_).contiguous(), kv, cells, al, sptr, n_sys, n_k, max_atoms, want_charge=False)
-                    mg, _ = _structure_factors(pos, (gq * rc_).contiguous(), kv, cells, al, sptr, n_sys, n_k, max_atoms, want_charge=False)
-                    cross.append((-mg[..., 1] * srq - srg * m[..., 1] + mg[..., 0] * siq + sig * m[..., 0]) * ginv)
-                gkv = (gk + 0.5 * torch.stack(cross, dim=-1)).to(kv.dtype)
-            gi_q = g * q64
-            if need[3]:
-                per_atom = gi_q * (-q64 / math.sqrt(math.pi) + math.pi * tq[sel] / a_i**3)
-                gal = (0.5 * (w * k2).sum(1) / (2.0 * al64**3)
-                       + torch.zeros(n_sys, dtype=torch.float64, device=pos.device).index_add_(0, sel, per_atom)).to(al.dtype)
-            if need[4]:
-                v_i = vol[sel]
-                per_atom = gi_q * math.pi * tq[sel] / (2.0 * a_i * a_i * v_i)
-                gvol = (-0.5 * w.sum(1) / vol + torch.zeros(n_sys, dtype=torch.float64, device=pos.device).index_add_(0, sel, per_atom)).to(pos.dtype)
-        return gpos, gch, gkv, gal, gvol, None, None, None, None
+        dL/dV     = -1/(2V) sum_k W + sum_i g_i pi q_i Q/(2 alpha^2 V^2).
+    Returns float64 (dL/dpositions, dL/dcharges, dL/dk_vectors [B,K,3], dL/dalpha [B], dL/dV [B]); entries not asked for are None."""
+    pos, q, kv, cells, al, bi, sptr, max_atoms = (p[k] for k in ("pos", "q", "kv", "cells", "al", "bi", "sptr", "max_atoms"))
+    n_sys, n_k = p["n_sys"], p["n_k"]
+    batched = bi is not None
+    sf, tq = _structure_factors(pos, q, kv, cells, al, sptr, n_sys, n_k, max_atoms)
+    g = g_e.detach().to(torch.float64)
+    q64, al64 = q.to(torch.float64), al.to(torch.float64)
+    gq = (g * q64).to(pos.dtype).contiguous()
+    sfg, tqg = _structure_factors(pos, gq, kv, cells, al, sptr, n_sys, n_k, max_atoms)
+    sel = bi.long() if batched else torch.zeros(pos.shape[0], dtype=torch.long, device=pos.device)
+    a_i = al64[sel]
+    gpos = gch = gkv = gal = gvol = None
+    if need_atoms:
+        a = _recip_gather(pos, q, kv, al, bi, sf, None, n_k, potential=True, kforce=True)
+        b = _recip_gather(pos, q, kv, al, bi, sfg, None, n_k, potential=True, kforce=True)
+        gpos = (-0.5 * q64).unsqueeze(1) * (g.unsqueeze(1) * a["kforce"] + b["kforce"])
+        gch = (0.5 * (g * a["potential"] + b["potential"]) - 2.0 * g * a_i * q64 / math.sqrt(math.pi)
+               - math.pi / (2.0 * a_i * a_i) * (g * tq[sel] + tqg[sel]))
+    if need_kv or need_alpha or need_vol:
+        kv64 = kv.to(torch.float64)
+        k2 = (kv64 * kv64).sum(-1)
+        vol = torch.abs(torch.linalg.det(cells.to(torch.float64)))
+        a2 = (al64 * al64).unsqueeze(1)
+        ok = k2 >= 1e-10
+        k2s = torch.where(ok, k2, torch.ones_like(k2))
+        green = 8.0 * math.pi / vol.unsqueeze(1) * torch.exp(-k2s / (4.0 * a2)) / k2s
+        ok = ok & (green > 1e-280)
+        ginv = torch.where(ok, 1.0 / torch.where(ok, green, torch.ones_like(green)), torch.zeros_like(green))
+        srq, siq, srg, sig = sf[..., 0], sf[..., 1], sfg[..., 0], sfg[..., 1]
+        w = (srg * srq + sig * siq) * ginv
+        if need_kv:
+            gk = 0.5 * w.unsqueeze(-1) * (-kv64 * (0.5 / a2 + 2.0 / k2s).unsqueeze(-1))
+            cross = []
+            for c in range(3):
+                rc_ = pos[:, c]
+                m, _ = _structure_factors(pos, (q * rc_).contiguous(), kv, cells, al, sptr, n_sys, n_k, max_atoms, want_charge=False)
+                mg, _ = _structure_factors(pos, (gq * rc_).contiguous(), kv, cells, al, sptr, n_sys, n_k, max_atoms, want_charge=False)
+                cross.append((-mg[..., 1] * srq - srg * m[..., 1] + mg[..., 0] * siq + sig * m[..., 0]) * ginv)
+            gkv = gk + 0.5 * torch.stack(cross, dim=-1)
+        gi_q = g * q64
+        seg = lambda x: torch.zeros(n_sys, dtype=torch.float64, device=pos.device).index_add_(0, sel, x)  # noqa: E731
+        if need_alpha:
+            gal = 0.5 * (w * k2).sum(1) / (2.0 * al64**3) + seg(gi_q * (-q64 / math.sqrt(math.pi) + math.pi * tq[sel] / a_i**3))
+        if need_vol:
+            gvol = -0.5 * w.sum(1) / vol + seg(gi_q * math.pi * tq[sel] / (2.0 * a_i * a_i * vol[sel]))
+    return gpos, gch, gkv, gal, gvol
 
 
-@C.eager
+@C.traceable
 def ewald_reciprocal_space(positions: torch.Tensor, charges: torch.Tensor, cell: torch.Tensor, k_vectors: torch.Tensor, alpha: torch.Tensor,
                            batch_idx: torch.Tensor | None = None, compute_forces: bool = False, compute_charge_gradients: bool = False):
     """Reciprocal-space Ewald over an explicit half-space k-vector set (ewald.py:2631-2795):
@@ -261,46 +275,24 @@ def ewald_reciprocal_space(positions: torch.Tensor, charges: torch.Tensor, cell:
     Returns ``energies`` | ``(energies, forces)`` | ``(energies, charge_grads)`` | ``(energies, forces, charge_grads)``.
     `k_vectors` is [K,3] (single system) or [B,K,3] (batch); `alpha` a [B] tensor (see `ewald_summation` for float input).
     Energies are differentiable w.r.t. positions, charges, k_vectors, alpha and cell (the latter through |det cell| here and
-    through `k_vectors` when those were generated from a cell that requires grad, as the reference's tests do)."""
-    n, dev, dt = positions.shape[0], positions.device, positions.dtype
-    batched = batch_idx is not None
+    through `k_vectors` when those were generated from a cell that requires grad, as the reference's tests do).  When something
+    requires grad, or under torch.compile, the call goes through the `alchemiops::_[batch_]ewald_reciprocal_space_*` ops."""
+    dt, dev = positions.dtype, positions.device
+    if positions.shape[0] > 0:
+        C.require_device(positions, charges, cell, k_vectors, batch_idx)
     cells, n_sys = _prepare_cell(cell)
-    kv = k_vectors if k_vectors.dim() == 3 else k_vectors.unsqueeze(0)
-    n_k = kv.shape[1]
-    if n == 0 or (batched and n_k == 0):
-        out = (torch.zeros(n, dtype=dt, device=dev),)
-        if compute_forces:
-            out += (torch.zeros((n, 3), dtype=dt, device=dev),)
-        if compute_charge_gradients:
-            out += (torch.zeros(n, dtype=dt, device=dev),)
-        return out if len(out) > 1 else out[0]
-    C.require_device(positions, charges, cell, k_vectors, batch_idx)
-    if kv.shape[0] != n_sys:
-        kv = kv.expand(n_sys, -1, -1)
-    al = _prepare_alpha(alpha, n_sys, dt, dev).detach().contiguous()
-    pos, q = positions.detach().contiguous(), charges.detach().to(dt).contiguous()
-    cells_c, kv_c = cells.detach().to(dt).contiguous(), kv.detach().to(dt).contiguous()
-    bi = sptr = None
-    max_atoms = n
-    if batched:
-        bi = C.i32(batch_idx)
-        counts = torch.bincount(batch_idx.long(), minlength=n_sys)
-        sptr = torch.zeros(n_sys + 1, dtype=torch.int32, device=dev)
-        sptr[1:] = torch.cumsum(counts, dim=0)
-        max_atoms = int(counts.max().item())
-    sf, tq = _structure_factors(pos, q, kv_c, cells_c, al, sptr, n_sys, n_k, max_atoms)
-    res = _recip_gather(pos, q, kv_c, al, bi, sf, tq, n_k, energies=True, forces=compute_forces,
-                        cgrads=compute_charge_gradients)
-    e_out = res["energies"].to(dt)
     al_in = _prepare_alpha(alpha, n_sys, dt, dev)
-    if torch.is_grad_enabled() and any(t.requires_grad for t in (positions, charges, kv, cells, al_in)):
-        vol = torch.abs(torch.linalg.det(cells.to(dt)))  # differentiable handle on the volume; the kernels recompute it from cells_c
-        e_out = _EwaldRecipEnergyFn.apply(positions, charges.to(dt), kv.to(dt), al_in, vol, cells_c, bi, sptr, max_atoms)
-    out = (e_out,)
-    if compute_forces:
-        out += (res["forces"],)
-    if compute_charge_gradients:
-        out += (res["cgrads"].to(dt),)
+    if C.tracing() or (torch.is_grad_enabled() and any(t.requires_grad for t in (positions, charges, k_vectors, cells, al_in))):
+        from nvalchemiops import _eops
+
+        op = _eops.reciprocal_space_op(batch_idx is not None, compute_forces or compute_charge_gradients, compute_charge_gradients)
+        args = (positions, charges.to(dt), cells.to(dt), k_vectors.to(dt), al_in) + ((batch_idx,) if batch_idx is not None else ())
+        out = op(*args)
+        out = out if isinstance(out, tuple) else (out,)
+        if compute_charge_gradients and not compute_forces:  # no (energies, charge_grads) op: the three-output op minus its forces (ewald.py:2756)
+            out = (out[0], out[2])
+    else:
+        out = _recip_forward(positions, charges, cells, k_vectors, al_in, batch_idx, compute_forces, compute_charge_gradients)
     return out if len(out) > 1 else out[0]
 
 

@@ -157,7 +157,7 @@ def spline_gather_gradient(positions: torch.Tensor, charges: torch.Tensor, mesh:
     return -charges.detach().to(pos.dtype).unsqueeze(-1) * torch.einsum("na,nab->nb", gfrac, cit_i)
 
 
-@C.eager
+@C.traceable
 def spline_spread_channels(positions: torch.Tensor, values: torch.Tensor, cell: torch.Tensor, mesh_dims: tuple[int, int, int],
                            spline_order: int = 4, batch_idx: torch.Tensor | None = None) -> torch.Tensor:
     """values[N, C] -> mesh[(B,) C, nx, ny, nz] (spline.py:2788-2860).  One tile-owned scalar spread per channel -- the channels
@@ -169,7 +169,7 @@ def spline_spread_channels(positions: torch.Tensor, values: torch.Tensor, cell: 
     return torch.stack(chans, dim=0 if batch_idx is None else 1)
 
 
-@C.eager
+@C.traceable
 def spline_gather_channels(positions: torch.Tensor, mesh: torch.Tensor, cell: torch.Tensor, spline_order: int = 4,
                            batch_idx: torch.Tensor | None = None) -> torch.Tensor:
     """mesh[(B,) C, nx, ny, nz] -> values[N, C] (spline.py:2863-2910); one scalar gather per channel."""

@@ -159,7 +159,8 @@ def test_energy_autograd(fmt, alpha):
 
     P, Q, Cc = _t(pos).requires_grad_(True), _t(q).requires_grad_(True), _t(cells).requires_grad_(True)
     E, f = total(P, Q, Cc)
-    assert not f.requires_grad
+    with pytest.raises(NotImplementedError):  # forces are an op output; their derivative is refused, never a silent zero
+        f.sum().backward(retain_graph=True)
     E.backward()
     _close(-P.grad, f.cpu().numpy(), "-dE/dr vs explicit forces", 1e-10)
     g = np.random.default_rng(0)
