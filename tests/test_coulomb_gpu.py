@@ -162,7 +162,7 @@ def test_energy_autograd(fmt, alpha):
     with pytest.raises(NotImplementedError):  # forces are an op output; their derivative is refused, never a silent zero
         f.sum().backward(retain_graph=True)
     E.backward()
-    _close(-P.grad, f.cpu().numpy(), "-dE/dr vs explicit forces", 1e-10)
+    _close(-P.grad, f.detach().cpu().numpy(), "-dE/dr vs explicit forces", 1e-10)
     g = np.random.default_rng(0)
     with torch.no_grad():
         for _ in range(3):
