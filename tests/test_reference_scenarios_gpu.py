@@ -338,3 +338,194 @@ def test_rebuild_detection_scenarios(dtype):
     # reference positions kept in the other precision (:424)
     other = torch.float64 if dtype == torch.float32 else torch.float32
     assert not bool(neighbor_list_needs_rebuild(pos.to(other), pos.to(other) + 0.1, skin / 2))
+
+
+# ------------------------------------------------------------------------------------------------------------------ test_dftd3.py
+D3 = dict(a1=0.3981, a2=4.4211, s8=1.9889)
+
+
+def _d3_tables():
+    from tests.test_d3_gpu import _params
+
+    return _params()
+
+
+def _d3_check(out, ref, virial=False):
+    from tests.test_d3_gpu import _check
+
+    _check(out, ref, virial)
+
+
+def _d3_oracle(pos, z, t, **kw):
+    from tests.test_d3_gpu import _wide
+
+    return _wide(pos, z, t, k1=16.0, k3=-4.0, s6=1.0, **kw)
+
+
+def test_dftd3_custom_op_branches_and_parameter_supply():
+    """TestCustomOpBranches (test_dftd3.py:496-630) and TestParameterSupply (:1772-2148): float64 positions, S5 window, explicit
+    fill_value, `device=` given or not; explicit tensors, D3Parameters, dict, dict / dataclass with single-tensor overrides, nothing."""
+    from nvalchemiops.interactions.dispersion import D3Parameters, dftd3
+
+    t, p = _d3_tables()
+    pos = np.array([[0.0, 0.0, 0.0], [1.4, 0.0, 0.0]], np.float32)
+    z = np.array([1, 1], np.int32)
+    nm = np.array([[1, 2], [0, 2]], np.int32)
+    tp, tz, tnm = torch.as_tensor(pos, device=DEV), torch.as_tensor(z, device=DEV), torch.as_tensor(nm, device=DEV)
+    ref = _d3_oracle(pos, z, t, neighbor_matrix=nm, **D3)
+    explicit = dict(covalent_radii=p.rcov, r4r2=p.r4r2, c6_reference=p.c6ab, coord_num_ref=p.cn_ref)
+    base = dftd3(tp, tz, neighbor_matrix=tnm, **explicit, **D3)
+    _d3_check(base, ref)
+    assert base[0].shape == (1,) and base[1].shape == (2, 3) and base[2].shape == (2,)                     # :1205
+    assert all(o.dtype == torch.float32 for o in base)
+    # float64 positions: results stay float32 (dftd3.py:1912), numbers equal to the float32 run at this geometry
+    out64 = dftd3(tp.double(), tz, neighbor_matrix=tnm, **explicit, **D3)
+    assert all(o.dtype == torch.float32 for o in out64)
+    _d3_check(out64, _d3_oracle(pos.astype(np.float64), z, t, neighbor_matrix=nm, **D3))
+    # explicit fill_value, device argument present / absent
+    for extra in (dict(fill_value=2), dict(device=DEV), dict()):
+        _d3_check(dftd3(tp, tz, neighbor_matrix=tnm, **explicit, **D3, **extra), ref)
+    # S5 window around the bond length (s5_off > s5_on enables it)
+    sm = dftd3(tp, tz, neighbor_matrix=tnm, **explicit, **D3, s5_smoothing_on=5.0, s5_smoothing_off=10.0)
+    _d3_check(sm, _d3_oracle(pos, z, t, neighbor_matrix=nm, s5_on=5.0, s5_off=10.0, **D3))
+    # parameter supply: all of these are the same calculation
+    as_dict = dict(rcov=p.rcov, r4r2=p.r4r2, c6ab=p.c6ab, cn_ref=p.cn_ref)
+    for kw in (dict(d3_params=p), dict(d3_params=as_dict), dict(d3_params=as_dict, r4r2=p.r4r2.clone()),
+               dict(d3_params=p, covalent_radii=p.rcov.clone()), dict(d3_params=p, c6_reference=p.c6ab.clone(), coord_num_ref=p.cn_ref.clone())):
+        got = dftd3(tp, tz, neighbor_matrix=tnm, **kw, **D3)
+        assert all(torch.equal(a, b) for a, b in zip(got, base))
+    # an override really overrides (:1908, :1984): doubled r4r2 changes the energy, as in the oracle
+    t2 = dict(t, r4r2=t["r4r2"] * 2.0)
+    got = dftd3(tp, tz, neighbor_matrix=tnm, d3_params=as_dict, r4r2=p.r4r2 * 2.0, **D3)
+    _d3_check(got, _d3_oracle(pos, z, t2, neighbor_matrix=nm, **D3))
+    assert abs(float(got[0]) - float(base[0])) > 1e-6 * abs(float(base[0]))
+    with pytest.raises(RuntimeError, match="DFT-D3 parameters must be explicitly provided"):              # :1961
+        dftd3(tp, tz, neighbor_matrix=tnm, **D3)
+    # validation messages of the neighbour formats (:2843)
+    nl = torch.tensor([[0, 1], [1, 0]], dtype=torch.int32, device=DEV)
+    ptr = torch.tensor([0, 1, 2], dtype=torch.int32, device=DEV)
+    for kw, msg in ((dict(neighbor_matrix=tnm, neighbor_list=nl), "Cannot provide both neighbor_matrix and neighbor_list"),
+                    (dict(), "Must provide either neighbor_matrix or neighbor_list"),
+                    (dict(neighbor_matrix=tnm, unit_shifts=torch.zeros((2, 3), dtype=torch.int32, device=DEV)), "unit_shifts is for neighbor_list format"),
+                    (dict(neighbor_list=nl, neighbor_matrix_shifts=torch.zeros((2, 2, 3), dtype=torch.int32, device=DEV)),
+                     "neighbor_matrix_shifts is for neighbor_matrix format"),
+                    (dict(neighbor_list=nl), "neighbor_ptr must be provided when using neighbor_list")):
+        with pytest.raises(ValueError, match=msg):
+            dftd3(tp, tz, d3_params=p, **kw, **D3)
+    # list format == matrix format (:2753)
+    lst = dftd3(tp, tz, d3_params=p, neighbor_list=nl, neighbor_ptr=ptr, **D3)
+    _d3_check(lst, ref)
+    # D3Parameters.to (:356-400)
+    p64 = p.to(dtype=torch.float64)
+    assert p64.rcov.dtype == torch.float64 and p64.c6ab.dtype == torch.float64 and p64.device == p.device
+    assert isinstance(p.to(device="cpu"), D3Parameters) and p.to(device="cpu").device == torch.device("cpu")
+    _d3_check(dftd3(tp, tz, d3_params=p64, neighbor_matrix=tnm, **D3), ref)                                 # :400 float64 tables
+
+
+def test_dftd3_batching_scenarios():
+    """TestBatchIndexHandling / TestBatching (test_dftd3.py:2150-2840): batch_idx alone fixes the system count, identical systems give
+    identical results, batch == individual runs for systems of different sizes, per-system energies accumulate per system, a large batch."""
+    from nvalchemiops.interactions.dispersion import dftd3
+
+    t, p = _d3_tables()
+    pos = np.array([[0, 0, 0], [1.4, 0, 0], [5.0, 0, 0], [6.4, 0, 0]], np.float32)
+    z = np.array([1, 1, 1, 1], np.int32)
+    nm = np.full((4, 5), 4, np.int32)
+    nm[0, 0], nm[1, 0], nm[2, 0], nm[3, 0] = 1, 0, 3, 2
+    bi = np.array([0, 0, 1, 1], np.int32)
+    dev = lambda a: torch.as_tensor(a, device=DEV)  # noqa: E731
+    out = dftd3(dev(pos), dev(z), d3_params=p, neighbor_matrix=dev(nm), batch_idx=dev(bi), **D3)
+    assert out[0].shape == (2,) and out[1].shape == (4, 3) and out[2].shape == (4,)                        # :2153
+    _d3_check(out, _d3_oracle(pos, z, t, neighbor_matrix=nm, batch_idx=bi, **D3))
+    assert torch.allclose(out[0][0], out[0][1], rtol=1e-6) and torch.allclose(out[1][:2], out[1][2:], rtol=1e-5, atol=1e-9)   # :2221
+    # systems of different sizes: the batch equals the runs of its members (:2293, :2393)
+    g = np.random.default_rng(12)
+    sizes = (3, 17, 64, 1, 30)
+    parts, zs, mats = [], [], []
+    off = 0
+    total = sum(sizes)
+    width = 70
+    for n in sizes:
+        pp = (g.random((n, 3)) * (2.0 + n ** (1 / 3) * 2.5)).astype(np.float32)
+        parts.append(pp), zs.append(g.choice(np.array([1, 6, 7, 8], np.int32), n))
+        m = np.full((n, width), total, np.int32)
+        for i in range(n):
+            others = [j for j in range(n) if j != i]
+            m[i, :len(others)] = np.array(others, np.int32) + off
+        mats.append(m)
+        off += n
+    P, Z, M = np.concatenate(parts), np.concatenate(zs), np.concatenate(mats)
+    BI = np.concatenate([np.full(n, s, np.int32) for s, n in enumerate(sizes)])
+    batch = dftd3(dev(P), dev(Z), d3_params=p, neighbor_matrix=dev(M), batch_idx=dev(BI), fill_value=total, **D3)
+    assert batch[0].shape == (len(sizes),)
+    _d3_check(batch, _d3_oracle(P, Z, t, neighbor_matrix=M, batch_idx=BI, fill_value=total, **D3))
+    off = 0
+    for s, n in enumerate(sizes):
+        local = np.where(mats[s] == total, n, mats[s] - off).astype(np.int32)
+        one = dftd3(dev(parts[s]), dev(zs[s]), d3_params=p, neighbor_matrix=dev(local), **D3)
+        assert torch.allclose(one[0][0], batch[0][s], rtol=2e-6, atol=1e-9)                                 # :2545 accumulation per system
+        assert torch.allclose(one[1], batch[1][off:off + n], rtol=1e-5, atol=1e-8) and torch.allclose(one[2], batch[2][off:off + n], rtol=1e-6)
+        off += n
+    # many small systems (:2676): 200 dimers
+    nsys = 200
+    P = np.zeros((2 * nsys, 3), np.float32)
+    P[1::2, 0] = 1.2 + 0.01 * np.arange(nsys)
+    P[:, 1] = np.repeat(np.arange(nsys), 2) * 30.0
+    M = np.full((2 * nsys, 4), 2 * nsys, np.int32)
+    M[0::2, 0] = np.arange(1, 2 * nsys, 2)
+    M[1::2, 0] = np.arange(0, 2 * nsys, 2)
+    BI = np.repeat(np.arange(nsys, dtype=np.int32), 2)
+    Z = np.tile(np.array([6, 8], np.int32), nsys)
+    out = dftd3(dev(P), dev(Z), d3_params=p, neighbor_matrix=dev(M), batch_idx=dev(BI), **D3)
+    assert out[0].shape == (nsys,)
+    _d3_check(out, _d3_oracle(P, Z, t, neighbor_matrix=M, batch_idx=BI, **D3))
+
+
+@pytest.mark.parametrize("fmt", ["matrix", "list"])
+def test_dftd3_periodic_and_virial_scenarios(fmt):
+    """TestPBC (test_dftd3.py:768-1200) and the periodic batch cases (:2466, :2976): virial needs cell + shifts (messages), virial for
+    matrix / list / batch / float64 input, periodic batch == members."""
+    from nvalchemiops.interactions.dispersion import dftd3
+    from nvalchemiops.neighborlist import batch_cell_list
+
+    t, p = _d3_tables()
+    g = np.random.default_rng(4)
+    dev = lambda a: torch.as_tensor(np.ascontiguousarray(a), device=DEV)  # noqa: E731
+    sizes, boxes = (24, 40), (9.0, 11.0)
+    parts = []
+    for n, b in zip(sizes, boxes):  # jittered lattice: no unphysical close contacts (their fp32 pair terms would dominate the force error)
+        k = int(np.ceil(n ** (1 / 3)))
+        grid = np.stack(np.meshgrid(*[np.arange(k)] * 3, indexing="ij"), -1).reshape(-1, 3)[:n]
+        parts.append(((grid + 0.5 + (g.random((n, 3)) - 0.5) * 0.4) * (b / k)).astype(np.float32))
+    cells = np.stack([np.eye(3, dtype=np.float32) * b for b in boxes])
+    cells[1, 1, 0] = 1.3
+    P = np.concatenate(parts)
+    Z = g.choice(np.array([1, 6, 8, 14], np.int32), P.shape[0])
+    BI = np.concatenate([np.full(n, s, np.int32) for s, n in enumerate(sizes)])
+    pbc = torch.ones((2, 3), dtype=torch.bool, device=DEV)
+    if fmt == "matrix":
+        nm, num, sh = batch_cell_list(dev(P), 7.0, dev(cells), pbc, dev(BI), max_neighbors=160)
+        assert int(num.max()) <= 160
+        kw = dict(neighbor_matrix=nm, neighbor_matrix_shifts=sh)
+        okw = dict(neighbor_matrix=nm.cpu().numpy(), neighbor_matrix_shifts=sh.cpu().numpy())
+    else:
+        nl, ptr, sh = batch_cell_list(dev(P), 7.0, dev(cells), pbc, dev(BI), return_neighbor_list=True)
+        kw = dict(neighbor_list=nl, neighbor_ptr=ptr, unit_shifts=sh)
+        okw = dict(idx_j=nl[1].cpu().numpy(), neighbor_ptr=ptr.cpu().numpy(), unit_shifts=sh.cpu().numpy())
+    out = dftd3(dev(P), dev(Z), d3_params=p, cell=dev(cells), batch_idx=dev(BI), compute_virial=True, **kw, **D3)
+    assert len(out) == 4 and out[3].shape == (2, 3, 3) and out[3].dtype == torch.float32
+    _d3_check(out, _d3_oracle(P, Z, t, cell=cells, batch_idx=BI, compute_virial=True, **okw, **D3), virial=True)
+    assert torch.allclose(out[3], out[3].transpose(1, 2), rtol=1e-4, atol=1e-7)                             # a symmetric tensor
+    # float64 positions and cell (:1149): float32 results
+    out64 = dftd3(dev(P).double(), dev(Z), d3_params=p, cell=dev(cells).double(), batch_idx=dev(BI), compute_virial=True, **kw, **D3)
+    assert all(o.dtype == torch.float32 for o in out64)
+    _d3_check(out64, _d3_oracle(P.astype(np.float64), Z, t, cell=cells.astype(np.float64), batch_idx=BI, compute_virial=True, **okw, **D3), virial=True)
+    # without virial the first three outputs are unchanged
+    plain = dftd3(dev(P), dev(Z), d3_params=p, cell=dev(cells), batch_idx=dev(BI), **kw, **D3)
+    assert len(plain) == 3 and all(torch.equal(a, b) for a, b in zip(plain, out[:3]))
+    # virial preconditions (:813): no cell, or a cell without shifts
+    no_shift = {k: v for k, v in kw.items() if k not in ("neighbor_matrix_shifts", "unit_shifts")}
+    with pytest.raises(ValueError, match="Virial computation requires periodic boundary conditions"):
+        dftd3(dev(P), dev(Z), d3_params=p, batch_idx=dev(BI), compute_virial=True, **no_shift, **D3)
+    with pytest.raises(ValueError, match="Virial computation requires periodic boundary conditions"):
+        dftd3(dev(P), dev(Z), d3_params=p, cell=dev(cells), batch_idx=dev(BI), compute_virial=True, **no_shift, **D3)
