@@ -529,3 +529,184 @@ def test_dftd3_periodic_and_virial_scenarios(fmt):
         dftd3(dev(P), dev(Z), d3_params=p, batch_idx=dev(BI), compute_virial=True, **no_shift, **D3)
     with pytest.raises(ValueError, match="Virial computation requires periodic boundary conditions"):
         dftd3(dev(P), dev(Z), d3_params=p, cell=dev(cells), batch_idx=dev(BI), compute_virial=True, **no_shift, **D3)
+
+
+# -------------------------------------------------------------------------------------------------------------------- test_pme.py
+def _simple_system(n=5, dtype=torch.float64, box=10.0, seed=0):
+    """The reference's `create_simple_system` shape: random positions in the middle 80 % of a cubic cell, neutral random charges."""
+    g = torch.Generator().manual_seed(seed)
+    pos = torch.rand((n, 3), generator=g, dtype=dtype) * box * 0.8 + box * 0.1
+    q = torch.randn(n, generator=g, dtype=dtype)
+    q[-1] = -q[:-1].sum()
+    return pos.to(DEV), q.to(DEV), (torch.eye(3, dtype=dtype) * box).to(DEV)
+
+
+def _dipole(dtype=torch.float64, sep=2.0, box=10.0):
+    c = box / 2
+    pos = torch.tensor([[c - sep / 2, c, c], [c + sep / 2, c, c]], dtype=dtype, device=DEV)
+    return pos, torch.tensor([1.0, -1.0], dtype=dtype, device=DEV), (torch.eye(3, dtype=dtype) * box).to(DEV)
+
+
+def test_pme_reciprocal_api_scenarios():
+    """TestDtypeSupport, TestPMEReciprocalSpaceAPI, TestPMEConservationLaws, TestPMEConvergence, TestSingleAtomSystem, TestNonCubicCells,
+    TestPrecomputedKVectors, TestAlphaSensitivity, TestZeroCharges, TestPrepareAlphaPME, TestPMEMeshDimensionErrors
+    (test_pme.py:139-535, :1628-2095)."""
+    from nvalchemiops.interactions.electrostatics import generate_k_vectors_pme, pme_reciprocal_space
+
+    kw = dict(alpha=0.3, mesh_dimensions=(16, 16, 16))
+    for dtype in DTYPES:                                                                                   # :144, :275, :296
+        pos, q, cell = _simple_system(4, dtype)
+        e = pme_reciprocal_space(pos, q, cell, **kw)
+        e2, f = pme_reciprocal_space(pos, q, cell, compute_forces=True, **kw)
+        assert e.shape == (4,) and f.shape == (4, 3) and e.dtype == dtype and f.dtype == dtype and torch.equal(e, e2)
+    p64, q64, c64 = _simple_system(6, torch.float64)
+    e64, f64 = pme_reciprocal_space(p64, q64, c64, compute_forces=True, **kw)
+    e32, f32 = pme_reciprocal_space(p64.float(), q64.float(), c64.float(), compute_forces=True, **kw)     # :223
+    assert torch.allclose(e32.double(), e64, rtol=1e-3, atol=1e-5) and torch.allclose(f32.double(), f64, rtol=1e-3, atol=1e-5)
+    want = O.pme_reciprocal_space(p64.cpu().numpy(), q64.cpu().numpy(), c64.cpu().numpy(), 0.3, (16, 16, 16), compute_forces=True)
+    assert np.allclose(e64.cpu().numpy(), want[0], rtol=1e-9, atol=1e-12) and np.allclose(f64.cpu().numpy(), want[1], rtol=1e-9, atol=1e-12)
+    # batch entry: shapes, one system through the batch == the single call (:180, :317, :2275)
+    bi = torch.zeros(6, dtype=torch.int32, device=DEV)
+    eb, fb = pme_reciprocal_space(p64, q64, c64.unsqueeze(0), batch_idx=bi, compute_forces=True, **kw)
+    # (not bit-equal: the reference's single-system spread keeps every weight > 0, its batch spread only weights > 1e-8, spline.py:548 / :820)
+    assert eb.shape == (6,) and fb.shape == (6, 3) and torch.allclose(eb, e64, rtol=1e-6, atol=1e-8) and torch.allclose(fb, f64, rtol=1e-6, atol=1e-8)
+    # empty system (:350)
+    e0, f0 = pme_reciprocal_space(p64[:0], q64[:0], c64, compute_forces=True, **kw)
+    assert e0.shape == (0,) and f0.shape == (0, 3)
+    # spline orders the reference supports (:374)
+    for order in (2, 3, 4):
+        assert torch.isfinite(pme_reciprocal_space(p64, q64, c64, spline_order=order, **kw)).all()
+    # conservation (:409-495): net force, translation invariance, the symmetric dipole
+    _, f = pme_reciprocal_space(p64, q64, c64, alpha=0.3, mesh_dimensions=(20, 20, 20), compute_forces=True)
+    assert float(f.sum(0).abs().max()) < 1e-4
+    dp, dq, dc = _dipole()
+    e1 = pme_reciprocal_space(dp, dq, dc, **kw)
+    e2 = pme_reciprocal_space(dp + torch.tensor([1.5, 0.5, -0.3], dtype=torch.float64, device=DEV), dq, dc, **kw)
+    assert torch.allclose(e1.sum(), e2.sum(), rtol=1e-4)
+    _, fd = pme_reciprocal_space(dp, dq, dc, compute_forces=True, **kw)
+    assert torch.allclose(fd[0], -fd[1], rtol=1e-6, atol=1e-12)
+    # mesh convergence (:499): 4 -> 8 -> 16 -> 64
+    es = [float(pme_reciprocal_space(dp, dq, dc, alpha=0.3, mesh_dimensions=(m, m, m)).sum()) for m in (4, 8, 16, 64)]
+    assert abs(es[2] - es[1]) < abs(es[1] - es[0]) and abs(es[3] - es[2]) < abs(es[2] - es[1])
+    # one atom (:1632): self + background terms only, zero force
+    one = torch.tensor([[5.0, 5.0, 5.0]], dtype=torch.float64, device=DEV)
+    e, f = pme_reciprocal_space(one, torch.tensor([1.0], dtype=torch.float64, device=DEV), dc, compute_forces=True, **kw)
+    assert e.shape == (1,) and torch.isfinite(e).all() and float(f.abs().max()) < 1e-10
+    # orthorhombic and triclinic cells (:1665, :1702) against the oracle
+    for cell in (torch.diag(torch.tensor([8.0, 10.0, 12.0], dtype=torch.float64)),
+                 torch.tensor([[10.0, 0, 0], [2.0, 9.0, 0], [1.0, 1.5, 11.0]], dtype=torch.float64)):
+        cell = cell.to(DEV)
+        frac = torch.rand((8, 3), generator=torch.Generator().manual_seed(3), dtype=torch.float64).to(DEV)
+        pos = frac @ cell
+        q = torch.tensor([1.0, -1.0] * 4, dtype=torch.float64, device=DEV)
+        e, f = pme_reciprocal_space(pos, q, cell, alpha=0.3, mesh_dimensions=(16, 20, 24), compute_forces=True)
+        w = O.pme_reciprocal_space(pos.cpu().numpy(), q.cpu().numpy(), cell.cpu().numpy(), 0.3, (16, 20, 24), compute_forces=True)
+        assert np.allclose(e.cpu().numpy(), w[0], rtol=1e-9, atol=1e-12) and np.allclose(f.cpu().numpy(), w[1], rtol=1e-9, atol=1e-12)
+    # precomputed k-vectors (:1738)
+    kv, k2 = generate_k_vectors_pme(dc, (16, 16, 16))
+    ek, fk = pme_reciprocal_space(dp, dq, dc, compute_forces=True, k_vectors=kv, k_squared=k2, **kw)
+    assert torch.allclose(ek, e1, rtol=1e-6) and torch.allclose(fk, fd, rtol=1e-6, atol=1e-12)
+    # alpha matters, zero charges give zero (:1881, :1915)
+    assert abs(float(pme_reciprocal_space(dp, dq, dc, alpha=0.5, mesh_dimensions=(16, 16, 16)).sum()) - float(e1.sum())) > 1e-6
+    z, fz = pme_reciprocal_space(p64, torch.zeros_like(q64), c64, compute_forces=True, **kw)
+    assert float(z.abs().max()) == 0.0 and float(fz.abs().max()) == 0.0
+    # alpha forms (:1984-2047): 0-d tensor, wrong length, wrong type
+    a0 = pme_reciprocal_space(p64, q64, c64, alpha=torch.tensor(0.3, dtype=torch.float64, device=DEV), mesh_dimensions=(16, 16, 16))
+    assert torch.allclose(a0, e64, rtol=1e-12)
+    with pytest.raises(ValueError):
+        pme_reciprocal_space(p64, q64, c64, alpha=torch.tensor([0.3, 0.5], dtype=torch.float64, device=DEV), mesh_dimensions=(16, 16, 16))
+    with pytest.raises(TypeError):
+        pme_reciprocal_space(p64, q64, c64, alpha="invalid", mesh_dimensions=(16, 16, 16))
+    # mesh given by spacing, or not at all (:2052, :2074)
+    with pytest.raises(ValueError, match="Either mesh_dimensions or mesh_spacing must be provided"):
+        pme_reciprocal_space(p64, q64, c64, alpha=0.3, mesh_dimensions=None, mesh_spacing=None)
+    assert torch.isfinite(pme_reciprocal_space(p64, q64, c64, alpha=0.3, mesh_spacing=0.5)).all()
+
+
+def test_pme_batch_consistency_scenarios():
+    """TestPMEBatchConsistency, TestBatchWithDifferentAlpha, TestBatchPMEShapePaths (test_pme.py:798-1360, :1942-1980, :2271-2343): a batch
+    equals its members run one by one -- energies, explicit forces, and autograd gradients w.r.t. positions, charges and cells."""
+    from nvalchemiops.interactions.electrostatics import pme_reciprocal_space
+
+    sizes, boxes, alphas = (6, 9, 4), (10.0, 12.0, 9.0), (0.3, 0.35, 0.4)
+    systems = [_simple_system(n, torch.float64, b, seed=10 + i) for i, (n, b) in enumerate(zip(sizes, boxes))]
+    P = torch.cat([s[0] for s in systems])
+    Q = torch.cat([s[1] for s in systems])
+    Cc = torch.stack([s[2] for s in systems])
+    bi = torch.cat([torch.full((n,), i, dtype=torch.int32) for i, n in enumerate(sizes)]).to(DEV)
+    al = torch.tensor(alphas, dtype=torch.float64, device=DEV)
+    mesh = (16, 16, 16)
+    eb, fb = pme_reciprocal_space(P, Q, Cc, alpha=al, mesh_dimensions=mesh, batch_idx=bi, compute_forces=True)
+    off = 0
+    for (p, q, c), n, a in zip(systems, sizes, alphas):
+        e, f = pme_reciprocal_space(p, q, c, alpha=a, mesh_dimensions=mesh, compute_forces=True)
+        assert torch.allclose(eb[off:off + n], e, rtol=1e-6, atol=1e-8) and torch.allclose(fb[off:off + n], f, rtol=1e-6, atol=1e-8)   # :840, :915, :1281, :1946
+        assert float(fb[off:off + n].sum(0).abs().max()) < 1e-4                                            # :976 momentum per system
+        off += n
+    # autograd through the batch == autograd through the members (:1030-1280)
+    Pg, Qg, Cg = P.clone().requires_grad_(True), Q.clone().requires_grad_(True), Cc.clone().requires_grad_(True)
+    pme_reciprocal_space(Pg, Qg, Cg, alpha=al, mesh_dimensions=mesh, batch_idx=bi).sum().backward()
+    off = 0
+    for i, ((p, q, c), n, a) in enumerate(zip(systems, sizes, alphas)):
+        pg, qg, cg = p.clone().requires_grad_(True), q.clone().requires_grad_(True), c.clone().requires_grad_(True)
+        pme_reciprocal_space(pg, qg, cg, alpha=a, mesh_dimensions=mesh).sum().backward()
+        assert torch.allclose(Pg.grad[off:off + n], pg.grad, rtol=1e-6, atol=1e-8)
+        assert torch.allclose(Qg.grad[off:off + n], qg.grad, rtol=1e-6, atol=1e-8)
+        assert torch.allclose(Cg.grad[i], cg.grad, rtol=1e-5, atol=1e-8)
+        off += n
+    # forces == -dE/dr (:1417): the explicit forces differentiate in k-space (i k), autograd differentiates the spline weights; on this
+    # coarse 16^3 mesh over 9-12 A boxes the two discretisations differ at the 1e-4 level (finer meshes: tests/test_autograd_gpu.py)
+    assert torch.allclose(-Pg.grad, fb, rtol=1e-2, atol=5e-4)
+
+
+@pytest.mark.parametrize("fmt", ["list", "matrix"])
+def test_particle_mesh_ewald_scenarios(fmt):
+    """TestParticleMeshEwald, TestFullPMENeighborList, TestParticleMeshEwaldAutoEstimation, TestPMEChargeGradients (test_pme.py:1585-1627,
+    :1811-1850, :2095-2270, :2344-2640): output layouts, automatic alpha / mesh, mesh spacing, accuracy-driven mesh, charge gradients ==
+    autograd for single systems and batches."""
+    from nvalchemiops.interactions.electrostatics import particle_mesh_ewald
+    from nvalchemiops.neighborlist import batch_cell_list, cell_list
+
+    pos, q, cell = _simple_system(5)
+    pbc = torch.tensor([True, True, True], device=DEV)
+    if fmt == "list":
+        nl, ptr, sh = cell_list(pos, 5.0, cell, pbc, return_neighbor_list=True)
+        nb = dict(neighbor_list=nl, neighbor_ptr=ptr, neighbor_shifts=sh)
+    else:
+        nm, num, sh = cell_list(pos, 5.0, cell, pbc, max_neighbors=32)
+        nb = dict(neighbor_matrix=nm, neighbor_matrix_shifts=sh)
+    e = particle_mesh_ewald(pos, q, cell, alpha=0.3, mesh_dimensions=(16, 16, 16), **nb)
+    assert e.shape == (5,) and e.dtype == torch.float64                                                    # :1589
+    for kw in (dict(alpha=None), dict(alpha=0.3, mesh_spacing=0.5), dict(alpha=0.3, mesh_dimensions=None, mesh_spacing=None, accuracy=1e-4),
+               dict(alpha=None, mesh_dimensions=None, mesh_spacing=None)):                                 # :2099, :2131, :2164, :2235
+        ee, ff = particle_mesh_ewald(pos, q, cell, compute_forces=True, **kw, **nb)
+        assert ee.shape == (5,) and ff.shape == (5, 3) and torch.isfinite(ee).all() and torch.isfinite(ff).all()
+    # the four output layouts
+    out = particle_mesh_ewald(pos, q, cell, alpha=0.3, mesh_dimensions=(16, 16, 16), compute_forces=True, compute_charge_gradients=True, **nb)
+    assert len(out) == 3 and out[1].shape == (5, 3) and out[2].shape == (5,)
+    ecg = particle_mesh_ewald(pos, q, cell, alpha=0.3, mesh_dimensions=(16, 16, 16), compute_charge_gradients=True, **nb)
+    assert len(ecg) == 2 and torch.equal(ecg[0], out[0]) and torch.equal(ecg[1], out[2])
+    # charge gradients == d(sum E)/dq by autograd (:2416), forces == -d(sum E)/dr
+    qg, pg = q.clone().requires_grad_(True), pos.clone().requires_grad_(True)
+    particle_mesh_ewald(pg, qg, cell, alpha=0.3, mesh_dimensions=(16, 16, 16), **nb).sum().backward()
+    assert torch.allclose(qg.grad, out[2], rtol=1e-6, atol=1e-10)
+    assert torch.allclose(-pg.grad, out[1], rtol=1e-3, atol=1e-4)
+    # batch of two systems (:2570)
+    p2, q2, c2 = _simple_system(7, box=11.0, seed=4)
+    P, Q, Cc = torch.cat([pos, p2]), torch.cat([q, q2]), torch.stack([cell, c2])
+    bi = torch.cat([torch.zeros(5, dtype=torch.int32), torch.ones(7, dtype=torch.int32)]).to(DEV)
+    bp = torch.ones((2, 3), dtype=torch.bool, device=DEV)
+    if fmt == "list":
+        nl, ptr, sh = batch_cell_list(P, 5.0, Cc, bp, bi, return_neighbor_list=True)
+        nbb = dict(neighbor_list=nl, neighbor_ptr=ptr, neighbor_shifts=sh)
+    else:
+        nm, num, sh = batch_cell_list(P, 5.0, Cc, bp, bi, max_neighbors=32)
+        nbb = dict(neighbor_matrix=nm, neighbor_matrix_shifts=sh)
+    al = torch.tensor([0.3, 0.3], dtype=torch.float64, device=DEV)
+    eb, fb, cgb = particle_mesh_ewald(P, Q, Cc, alpha=al, mesh_dimensions=(16, 16, 16), batch_idx=bi, compute_forces=True,
+                                      compute_charge_gradients=True, **nbb)
+    assert torch.allclose(eb[:5], out[0], rtol=1e-6, atol=1e-8) and torch.allclose(fb[:5], out[1], rtol=1e-6, atol=1e-8)
+    assert torch.allclose(cgb[:5], out[2], rtol=1e-6, atol=1e-8)
+    Qg = Q.clone().requires_grad_(True)
+    particle_mesh_ewald(P, Qg, Cc, alpha=al, mesh_dimensions=(16, 16, 16), batch_idx=bi, **nbb).sum().backward()
+    assert torch.allclose(Qg.grad, cgb, rtol=1e-6, atol=1e-10)
