@@ -699,7 +699,7 @@ def _recip_bwd(positions: Tensor, charges: Tensor, cell: Tensor, k_vectors: Tens
     p = _recip_inputs(positions, charges, cell, k_vectors, alpha, batch_idx)
     n, nsys, nk, dev = positions.shape[0], p["n_sys"], p["n_k"], positions.device
     f64 = dict(dtype=torch.float64, device=dev)
-    if n == 0 or (batch_idx is not None and nk == 0):
+    if n == 0:
         return torch.zeros((n, 3), **f64), torch.zeros(n, **f64), torch.zeros((nsys, 3, 3), **f64), torch.zeros((nsys, nk, 3), **f64), torch.zeros(nsys, **f64)
     gpos, gq, gkv, gal, gvol = _recip_adjoint(p, grad_energies, bool(need & 1), bool(need & 4), bool(need & 8), bool(need & 2))
     gcell = None
@@ -739,6 +739,8 @@ def _recip_backward(name, n_out):
         if grads[0] is None:
             return (None,) * len(need)
         positions, charges, cell, k_vectors, alpha, *rest = ctx.saved_tensors
+        if k_vectors.shape[-2] == 0 and (rest or n_out > 1):  # the forward returned constant zeros (see `_recip_forward`)
+            return tuple(torch.zeros_like(t) if w else None for t, w in zip((positions, charges, cell, k_vectors, alpha), need[:5])) + (None,) * (len(need) - 5)
         mask = (1 if need[0] or need[1] else 0) | (2 if need[2] else 0) | (4 if need[3] else 0) | (8 if need[4] else 0)
         gpos, gq, gcell, gkv, gal = recip_bwd_op(positions, charges, cell, k_vectors, alpha, rest[0] if rest else None, grads[0], mask)
         if need[3] and gkv.shape != k_vectors.shape:  # one [K,3] set shared by all systems (or a [1,K,3] one)

@@ -197,7 +197,9 @@ def _recip_forward(positions, charges, cell, k_vectors, alpha, batch_idx, forces
     ops of nvalchemiops/_eops.py and the plain eager call both land here)."""
     n, dev, dt = positions.shape[0], positions.device, positions.dtype
     k3 = k_vectors if k_vectors.dim() == 3 else k_vectors.unsqueeze(0)
-    if n == 0 or (batch_idx is not None and k3.shape[1] == 0):
+    # no k-vectors: every reference op except the single-system energy-only one returns zeros before its kernels (ewald.py:1507, :1655,
+    # :1809, :1976, :2154); that one (:1365) still adds the self and background terms
+    if n == 0 or (k3.shape[1] == 0 and (batch_idx is not None or forces or cgrads)):
         return (torch.zeros(n, dtype=dt, device=dev),) + ((torch.zeros((n, 3), dtype=dt, device=dev),) if forces else ()) + (
             (torch.zeros(n, dtype=dt, device=dev),) if cgrads else ())
     p = _recip_inputs(positions, charges, cell, k_vectors, alpha, batch_idx)

@@ -710,3 +710,288 @@ def test_particle_mesh_ewald_scenarios(fmt):
     Qg = Q.clone().requires_grad_(True)
     particle_mesh_ewald(P, Qg, Cc, alpha=al, mesh_dimensions=(16, 16, 16), batch_idx=bi, **nbb).sum().backward()
     assert torch.allclose(Qg.grad, cgb, rtol=1e-6, atol=1e-10)
+
+
+# ------------------------------------------------------------------------------------------------------------------ test_ewald.py
+def _ewald_lists(pos, cell, cutoff, batch_idx=None, width=64):
+    from nvalchemiops.neighborlist import batch_cell_list, cell_list
+
+    if batch_idx is None:
+        pbc = torch.tensor([True, True, True], device=DEV)
+        nl, ptr, sh = cell_list(pos, cutoff, cell, pbc, return_neighbor_list=True)
+        nm, num, msh = cell_list(pos, cutoff, cell, pbc, max_neighbors=width)
+    else:
+        pbc = torch.ones((cell.shape[0], 3), dtype=torch.bool, device=DEV)
+        nl, ptr, sh = batch_cell_list(pos, cutoff, cell, pbc, batch_idx, return_neighbor_list=True)
+        nm, num, msh = batch_cell_list(pos, cutoff, cell, pbc, batch_idx, max_neighbors=width)
+    assert int(num.max()) <= width
+    return dict(neighbor_list=nl, neighbor_ptr=ptr, neighbor_shifts=sh), dict(neighbor_matrix=nm, neighbor_matrix_shifts=msh)
+
+
+def test_ewald_api_shapes_dtypes_and_physics():
+    """TestDtypeSupport, the three *API classes, TestPhysicalProperties, TestSingleAtomSystem, TestLikeCharges, TestNonCubicCells,
+    TestNeighborMatrixFormat, TestAlphaSensitivity (test_ewald.py:157-860, :3042-3670)."""
+    from nvalchemiops.interactions.electrostatics import (ewald_real_space, ewald_reciprocal_space, ewald_summation,
+                                                          generate_k_vectors_ewald_summation)
+
+    for dtype in DTYPES:
+        pos, q, cell = _simple_system(8, dtype, seed=21)
+        cell3 = cell.unsqueeze(0)
+        al = torch.tensor([0.3], dtype=dtype, device=DEV)
+        lst, mat = _ewald_lists(pos, cell3, 4.5)
+        kv = generate_k_vectors_ewald_summation(cell3, 2.5)
+        for nb in (lst, mat):
+            e = ewald_real_space(pos, q, cell3, al, **nb)
+            e2, f = ewald_real_space(pos, q, cell3, al, compute_forces=True, **nb)
+            assert e.shape == (8,) and f.shape == (8, 3) and e.dtype == dtype and f.dtype == dtype and torch.equal(e, e2)   # :162, :397, :424
+        e = ewald_reciprocal_space(pos, q, cell3, kv, al)
+        e2, f = ewald_reciprocal_space(pos, q, cell3, kv, al, compute_forces=True)
+        assert e.shape == (8,) and f.shape == (8, 3) and e.dtype == dtype and f.dtype == dtype                                # :202, :554
+        e, f = ewald_summation(pos, q, cell3, alpha=0.3, k_cutoff=2.5, compute_forces=True, **lst)
+        assert e.shape == (8,) and f.shape == (8, 3) and e.dtype == dtype                                                       # :237, :689
+    # fp32 vs fp64 (:277)
+    pos, q, cell = _simple_system(8, torch.float64, seed=21)
+    cell3, al = cell.unsqueeze(0), torch.tensor([0.3], dtype=torch.float64, device=DEV)
+    lst, mat = _ewald_lists(pos, cell3, 4.5)
+    e64, f64 = ewald_summation(pos, q, cell3, alpha=0.3, k_cutoff=2.5, compute_forces=True, **lst)
+    l32 = {k: v for k, v in lst.items()}
+    e32, f32 = ewald_summation(pos.float(), q.float(), cell3.float(), alpha=0.3, k_cutoff=2.5, compute_forces=True, **l32)
+    assert torch.allclose(e32.double(), e64, rtol=1e-3, atol=1e-4) and torch.allclose(f32.double(), f64, rtol=1e-3, atol=1e-4)
+    # matrix == list (:3526); against the oracle
+    er_l, fr_l = ewald_real_space(pos, q, cell3, al, compute_forces=True, **lst)
+    er_m, fr_m = ewald_real_space(pos, q, cell3, al, compute_forces=True, **mat)
+    assert torch.allclose(er_l, er_m, rtol=1e-12, atol=1e-14) and torch.allclose(fr_l, fr_m, rtol=1e-11, atol=1e-14)
+    oe, of = O.ewald_real_space(pos.cpu().numpy(), q.cpu().numpy(), cell3.cpu().numpy(), np.array([0.3]),
+                                neighbor_matrix=mat["neighbor_matrix"].cpu().numpy(), neighbor_matrix_shifts=mat["neighbor_matrix_shifts"].cpu().numpy(),
+                                mask_value=8, compute_forces=True)
+    assert np.allclose(er_m.cpu().numpy(), oe, rtol=1e-10, atol=1e-13) and np.allclose(fr_m.cpu().numpy(), of, rtol=1e-10, atol=1e-13)
+    # physics (:3046-3155, :3416-3484): opposite charges attract / like charges repel, q -> 2q scales E by 4, translation invariance
+    dp, dq, dc = _dipole(sep=2.0)
+    dc3 = dc.unsqueeze(0)
+    dl, dm = _ewald_lists(dp, dc3, 4.5)
+    e, f = ewald_summation(dp, dq, dc3, alpha=0.3, k_cutoff=3.0, compute_forces=True, **dl)
+    assert float(e.sum()) < 0 and float(f[0, 0]) > 0 and float(f[1, 0]) < 0
+    same = torch.tensor([1.0, 1.0], dtype=torch.float64, device=DEV)
+    er, fr = ewald_real_space(dp, same, dc3, al, compute_forces=True, **dl)
+    assert float(er.sum()) > 0 and float(fr[0, 0]) < 0 and float(fr[1, 0]) > 0
+    e2 = ewald_summation(dp, 2.0 * dq, dc3, alpha=0.3, k_cutoff=3.0, **dl)
+    assert torch.allclose(e2.sum(), 4.0 * e.sum(), rtol=1e-10)
+    shift = torch.tensor([1.3, -0.7, 0.4], dtype=torch.float64, device=DEV)
+    dl2, _ = _ewald_lists(dp + shift, dc3, 4.5)
+    assert torch.allclose(ewald_summation(dp + shift, dq, dc3, alpha=0.3, k_cutoff=3.0, **dl2).sum(), e.sum(), rtol=1e-9)
+    # alpha changes the split, not the total, once both sums are converged (:3610)
+    tot = [float(ewald_summation(dp, dq, dc3, alpha=a, k_cutoff=6.0, **_ewald_lists(dp, dc3, 4.99)[0]).sum()) for a in (0.8, 1.0)]
+    assert abs(tot[0] - tot[1]) < 1e-5 * abs(tot[0])
+    # one atom (:3230, :3266)
+    one, oq = torch.tensor([[5.0, 5.0, 5.0]], dtype=torch.float64, device=DEV), torch.tensor([1.0], dtype=torch.float64, device=DEV)
+    ol, om = _ewald_lists(one, dc3, 4.0)
+    e, f = ewald_real_space(one, oq, dc3, al, compute_forces=True, **ol)
+    assert e.shape == (1,) and float(e.abs().max()) == 0.0 and float(f.abs().max()) == 0.0
+    e, f = ewald_reciprocal_space(one, oq, dc3, generate_k_vectors_ewald_summation(dc3, 2.0), al, compute_forces=True)
+    assert torch.isfinite(e).all() and float(f.abs().max()) < 1e-12
+    # orthorhombic / triclinic cells (:3299-3411) against the oracle
+    for cell in (torch.diag(torch.tensor([8.0, 10.0, 12.0], dtype=torch.float64)),
+                 torch.tensor([[10.0, 0, 0], [2.0, 9.0, 0], [1.0, 1.5, 11.0]], dtype=torch.float64)):
+        cell3 = cell.to(DEV).unsqueeze(0)
+        frac = torch.rand((10, 3), generator=torch.Generator().manual_seed(8), dtype=torch.float64).to(DEV)
+        pos = frac @ cell3[0]
+        q = torch.tensor([1.0, -1.0] * 5, dtype=torch.float64, device=DEV)
+        kv = generate_k_vectors_ewald_summation(cell3, 2.5)
+        e, f = ewald_reciprocal_space(pos, q, cell3, kv, al, compute_forces=True)
+        oe, of = O.ewald_reciprocal_space(pos.cpu().numpy(), q.cpu().numpy(), cell3.cpu().numpy(), kv.cpu().numpy(), 0.3)[:2]
+        assert np.allclose(e.cpu().numpy(), oe, rtol=1e-10, atol=1e-13) and np.allclose(f.cpu().numpy(), of, rtol=1e-10, atol=1e-13)
+
+
+def test_ewald_batches_alpha_forms_and_validation():
+    """Batch API and consistency (test_ewald.py:454-550, :601-860, :2748-2930, :3918-4020, :4068-4110), per-system alpha (:808), alpha / cell
+    forms (:3669-3810), missing neighbour data (:3581), automatic parameters and default mask value (:4249-4290, :4626-4740)."""
+    from nvalchemiops.interactions.electrostatics import (ewald_real_space, ewald_reciprocal_space, ewald_summation,
+                                                          generate_k_vectors_ewald_summation)
+
+    sizes, boxes = (6, 9), (10.0, 12.0)
+    systems = [_simple_system(n, torch.float64, b, seed=31 + i) for i, (n, b) in enumerate(zip(sizes, boxes))]
+    P, Q = torch.cat([s[0] for s in systems]), torch.cat([s[1] for s in systems])
+    Cc = torch.stack([s[2] for s in systems])
+    bi = torch.cat([torch.full((n,), i, dtype=torch.int32) for i, n in enumerate(sizes)]).to(DEV)
+    al = torch.tensor([0.3, 0.35], dtype=torch.float64, device=DEV)
+    lst, mat = _ewald_lists(P, Cc, 4.5, bi)
+    kvs = [generate_k_vectors_ewald_summation(c.unsqueeze(0), 2.5) for _, _, c in systems]
+    kmax = max(k.shape[0] for k in kvs)
+    # the batch takes [B,K,3]: pad the shorter set with zero vectors (a k = 0 entry contributes nothing: ewald_kernels.py k^2 < 1e-10 guard)
+    KV = torch.stack([torch.cat([k, torch.zeros((kmax - k.shape[0], 3), dtype=k.dtype, device=DEV)]) for k in kvs])
+    for nb in (lst, mat):
+        eb, fb = ewald_real_space(P, Q, Cc, al, batch_idx=bi, compute_forces=True, **nb)
+        assert eb.shape == (15,) and fb.shape == (15, 3)
+        off = 0
+        for i, ((p, q, c), n) in enumerate(zip(systems, sizes)):
+            l1, m1 = _ewald_lists(p, c.unsqueeze(0), 4.5)
+            e, f = ewald_real_space(p, q, c.unsqueeze(0), al[i:i + 1], compute_forces=True, **(l1 if nb is lst else m1))
+            assert torch.allclose(eb[off:off + n], e, rtol=1e-10, atol=1e-13) and torch.allclose(fb[off:off + n], f, rtol=1e-9, atol=1e-13)   # :2752
+            off += n
+    eb, fb = ewald_reciprocal_space(P, Q, Cc, KV, al, batch_idx=bi, compute_forces=True)
+    es, fs = ewald_summation(P, Q, Cc, alpha=al, k_vectors=KV, batch_idx=bi, compute_forces=True, **lst)
+    off = 0
+    for i, ((p, q, c), n) in enumerate(zip(systems, sizes)):
+        e, f = ewald_reciprocal_space(p, q, c.unsqueeze(0), kvs[i], al[i:i + 1], compute_forces=True)
+        assert torch.allclose(eb[off:off + n], e, rtol=1e-10, atol=1e-13) and torch.allclose(fb[off:off + n], f, rtol=1e-9, atol=1e-13)       # :2811
+        l1, _ = _ewald_lists(p, c.unsqueeze(0), 4.5)
+        e, f = ewald_summation(p, q, c.unsqueeze(0), alpha=al[i:i + 1], k_vectors=kvs[i], compute_forces=True, **l1)
+        assert torch.allclose(es[off:off + n], e, rtol=1e-10, atol=1e-13) and torch.allclose(fs[off:off + n], f, rtol=1e-9, atol=1e-13)       # :2866, :808
+        off += n
+    assert ewald_reciprocal_space(P, Q, Cc, KV, al, batch_idx=bi).shape == (15,)                           # :4072
+    # alpha forms: 0-d tensor and float are the same; wrong length and wrong type are errors (:3673-3770); a [3,3] cell is accepted (:3777)
+    p, q, c = systems[0]
+    l1, _ = _ewald_lists(p, c.unsqueeze(0), 4.5)
+    base = ewald_summation(p, q, c.unsqueeze(0), alpha=0.3, k_cutoff=2.5, **l1)
+    assert torch.allclose(ewald_summation(p, q, c.unsqueeze(0), alpha=torch.tensor(0.3, dtype=torch.float64, device=DEV), k_cutoff=2.5, **l1), base, rtol=1e-12)
+    assert torch.allclose(ewald_summation(p, q, c, alpha=0.3, k_cutoff=2.5, **l1), base, rtol=1e-12)
+    with pytest.raises(ValueError):
+        ewald_summation(p, q, c.unsqueeze(0), alpha=torch.tensor([0.3, 0.5], dtype=torch.float64, device=DEV), k_cutoff=2.5, **l1)
+    with pytest.raises(TypeError):
+        ewald_summation(p, q, c.unsqueeze(0), alpha="invalid", k_cutoff=2.5, **l1)
+    with pytest.raises(ValueError):
+        ewald_real_space(p, q, c.unsqueeze(0), al[:1])                                                      # :3581 no neighbour data
+    # automatic alpha / k_cutoff / k-vectors (:4253, :4630, :4663) and the default mask value of the matrix format (:4698)
+    for kw in (dict(), dict(alpha=0.3), dict(alpha=0.3, k_cutoff=2.5)):
+        e, f = ewald_summation(p, q, c.unsqueeze(0), compute_forces=True, **kw, **l1)
+        assert e.shape == (6,) and f.shape == (6, 3) and torch.isfinite(e).all() and torch.isfinite(f).all()
+    nm = torch.tensor([[1, 6], [0, 2], [1, 3], [2, 4], [3, 5], [4, 6]], dtype=torch.int32, device=DEV)
+    e, f = ewald_summation(p, q, c.unsqueeze(0), alpha=0.3, k_cutoff=2.5, neighbor_matrix=nm,
+                           neighbor_matrix_shifts=torch.zeros((6, 2, 3), dtype=torch.int32, device=DEV), compute_forces=True)
+    assert torch.isfinite(e).all() and torch.isfinite(f).all()
+
+
+def test_ewald_empty_inputs_and_charge_gradients():
+    """TestExplicitChargeGradients, TestExplicitReciprocalChargeGradients, TestEmptyNeighborListEarlyReturns, TestReciprocalSpaceEmptyReturns,
+    TestBatchEmptyInputs, TestNumericalStability (test_ewald.py:1373-2062, :3156-3225, :3810-3917, :4112-4210, :4473-4625)."""
+    from nvalchemiops.interactions.electrostatics import ewald_real_space, ewald_reciprocal_space, generate_k_vectors_ewald_summation
+
+    f64 = dict(dtype=torch.float64, device=DEV)
+    pos = torch.tensor([[2.0, 5.0, 5.0], [8.0, 5.0, 5.0]], **f64)
+    q = torch.tensor([1.0, -1.0], **f64)
+    cell = torch.eye(3, **f64).unsqueeze(0) * 10.0
+    al = torch.tensor([0.3], **f64)
+    i32 = dict(dtype=torch.int32, device=DEV)
+    empty_list = dict(neighbor_list=torch.zeros((2, 0), **i32), neighbor_ptr=torch.zeros(3, **i32), neighbor_shifts=torch.zeros((0, 3), **i32))
+    empty_mat = dict(neighbor_matrix=torch.full((2, 4), 2, **i32), neighbor_matrix_shifts=torch.zeros((2, 4, 3), **i32))
+    for nb in (empty_list, empty_mat):                                                                     # :1588, :3160, :3814-3917
+        e, f, cg = ewald_real_space(pos, q, cell, al, compute_forces=True, compute_charge_gradients=True, **nb)
+        assert e.shape == (2,) and f.shape == (2, 3) and cg.shape == (2,)
+        assert float(e.abs().max()) == 0 and float(f.abs().max()) == 0 and float(cg.abs().max()) == 0
+        assert float(ewald_real_space(pos, q, cell, al, **nb).abs().max()) == 0
+    # batch, empty (:4477-4625)
+    P, Q, Cc = torch.cat([pos, pos]), torch.cat([q, q]), cell.expand(2, -1, -1).contiguous()
+    bi = torch.tensor([0, 0, 1, 1], **i32)
+    al2 = torch.tensor([0.3, 0.3], **f64)
+    bl = dict(neighbor_list=torch.zeros((2, 0), **i32), neighbor_ptr=torch.zeros(5, **i32), neighbor_shifts=torch.zeros((0, 3), **i32))
+    bm = dict(neighbor_matrix=torch.full((4, 3), 4, **i32), neighbor_matrix_shifts=torch.zeros((4, 3, 3), **i32))
+    for nb in (bl, bm):
+        e, f = ewald_real_space(P, Q, Cc, al2, batch_idx=bi, compute_forces=True, **nb)
+        assert e.shape == (4,) and f.shape == (4, 3) and float(e.abs().max()) == 0 and float(f.abs().max()) == 0
+        assert float(ewald_real_space(P, Q, Cc, al2, batch_idx=bi, **nb).abs().max()) == 0
+    # no k-vectors (:2023, :4116, :4149): zeros from every op but the single-system energy-only one, which keeps the self term
+    k0 = torch.zeros((0, 3), **f64)
+    e, f, cg = ewald_reciprocal_space(pos, q, cell, k0, al, compute_forces=True, compute_charge_gradients=True)
+    assert e.shape == (2,) and f.shape == (2, 3) and cg.shape == (2,) and float(e.abs().max()) == 0 and float(f.abs().max()) == 0 and float(cg.abs().max()) == 0
+    e, f = ewald_reciprocal_space(pos, q, cell, k0, al, compute_forces=True)
+    assert float(e.abs().max()) == 0 and float(f.abs().max()) == 0
+    e = ewald_reciprocal_space(pos, q, cell, k0, al)
+    assert torch.allclose(e, -0.3 * q * q / np.sqrt(np.pi), rtol=1e-12)                                    # ewald.py:1365-1490 has no early return
+    kb = torch.zeros((2, 0, 3), **f64)
+    assert float(ewald_reciprocal_space(P, Q, Cc, kb, al2, batch_idx=bi).abs().max()) == 0
+    e, f = ewald_reciprocal_space(P, Q, Cc, kb, al2, batch_idx=bi, compute_forces=True)
+    assert e.shape == (4,) and f.shape == (4, 3) and float(e.abs().max()) == 0 and float(f.abs().max()) == 0
+    # and the zeros are differentiable constants
+    qg = q.clone().requires_grad_(True)
+    ewald_reciprocal_space(pos, qg, cell, k0, al, compute_forces=True)[0].sum().backward()
+    assert float(qg.grad.abs().max()) == 0
+    # explicit charge gradients == autograd of the summed energy, various systems, with and without forces, list and matrix, batch
+    for n, seed in ((4, 1), (9, 2), (16, 3)):                                                               # :1377-1830
+        p, qq, c = _simple_system(n, torch.float64, 10.0, seed=40 + seed)
+        c3 = c.unsqueeze(0)
+        lst, mat = _ewald_lists(p, c3, 4.5)
+        for nb in (lst, mat):
+            e, f, cg = ewald_real_space(p, qq, c3, al, compute_forces=True, compute_charge_gradients=True, **nb)
+            e1, cg1 = ewald_real_space(p, qq, c3, al, compute_charge_gradients=True, **nb)
+            assert torch.equal(e, e1) and torch.equal(cg, cg1)                                              # :1489 without forces
+            qg = qq.clone().requires_grad_(True)
+            ewald_real_space(p, qg, c3, al, **nb).sum().backward()
+            assert torch.allclose(qg.grad, cg, rtol=1e-8, atol=1e-12)
+        kv = generate_k_vectors_ewald_summation(c3, 2.5)
+        e, f, cg = ewald_reciprocal_space(p, qq, c3, kv, al, compute_forces=True, compute_charge_gradients=True)
+        e1, cg1 = ewald_reciprocal_space(p, qq, c3, kv, al, compute_charge_gradients=True)
+        assert torch.allclose(e, e1, rtol=1e-13) and torch.allclose(cg, cg1, rtol=1e-13)                   # :1876
+        qg = qq.clone().requires_grad_(True)
+        ewald_reciprocal_space(p, qg, c3, kv, al).sum().backward()
+        assert torch.allclose(qg.grad, cg, rtol=1e-8, atol=1e-12)                                          # :1834, :1905
+    # explicit outputs next to a live autograd graph (:1634): the backward of the energies still works
+    p, qq, c = _simple_system(6, torch.float64, 10.0, seed=50)
+    lst, _ = _ewald_lists(p, c.unsqueeze(0), 4.5)
+    pg = p.clone().requires_grad_(True)
+    e, f, cg = ewald_real_space(pg, qq, c.unsqueeze(0), al, compute_forces=True, compute_charge_gradients=True, **lst)
+    e.sum().backward()
+    assert torch.isfinite(pg.grad).all() and torch.allclose(-pg.grad, f.detach(), rtol=1e-8, atol=1e-12)
+    # reciprocal sum converges with the cutoff (:3193)
+    es = [float(ewald_reciprocal_space(p, qq, c.unsqueeze(0), generate_k_vectors_ewald_summation(c.unsqueeze(0), kc), al).sum()) for kc in (1.0, 2.0, 4.0)]
+    assert abs(es[2] - es[1]) < abs(es[1] - es[0])
+
+
+@pytest.mark.parametrize("fmt", ["list", "matrix"])
+def test_ewald_autograd_scenarios(fmt):
+    """TestAutogradRealSpace / ReciprocalSpace / FullEwald, TestBatchAutograd, TestAutogradWithMatrixFormat, TestBatchMatrixAutograd
+    (test_ewald.py:1108-1372, :2063-2750, :4019, :4207, :4290-4472): gradients exist, are finite, equal the explicit forces, and the batch
+    gives its members' gradients -- positions, charges and cells."""
+    from nvalchemiops.interactions.electrostatics import ewald_real_space, ewald_reciprocal_space, ewald_summation, generate_k_vectors_ewald_summation
+
+    sizes, boxes = (6, 9), (10.0, 11.0)
+    systems = [_simple_system(n, torch.float64, b, seed=61 + i) for i, (n, b) in enumerate(zip(sizes, boxes))]
+    al = torch.tensor([0.3, 0.3], dtype=torch.float64, device=DEV)
+    grads = []
+    for i, (p, q, c) in enumerate(systems):
+        lst, mat = _ewald_lists(p, c.unsqueeze(0), 4.5)
+        nb = lst if fmt == "list" else mat
+        pg, qg, cg = p.clone().requires_grad_(True), q.clone().requires_grad_(True), c.unsqueeze(0).clone().requires_grad_(True)
+        kv = generate_k_vectors_ewald_summation(cg, 2.5)                                                    # k-vectors follow the cell (:2117)
+        e_real = ewald_real_space(pg, qg, cg, al[:1], **nb)
+        e_rec = ewald_reciprocal_space(pg, qg, cg, kv, al[:1])
+        gr = torch.autograd.grad(e_real.sum(), (pg, qg, cg), retain_graph=True)
+        gk = torch.autograd.grad(e_rec.sum(), (pg, qg, cg), retain_graph=True)
+        assert all(torch.isfinite(g).all() for g in gr + gk)
+        _, fr = ewald_real_space(p, q, c.unsqueeze(0), al[:1], compute_forces=True, **nb)
+        _, fk = ewald_reciprocal_space(p, q, c.unsqueeze(0), kv.detach(), al[:1], compute_forces=True)
+        assert torch.allclose(-gr[0], fr, rtol=1e-8, atol=1e-12) and torch.allclose(-gk[0], fk, rtol=1e-8, atol=1e-12)     # :1169, :2142
+        # full Ewald through ewald_summation (:2308-2480): same gradients as the two parts
+        pg2, qg2, cg2 = p.clone().requires_grad_(True), q.clone().requires_grad_(True), c.unsqueeze(0).clone().requires_grad_(True)
+        tot = ewald_summation(pg2, qg2, cg2, alpha=0.3, k_cutoff=2.5, **nb)
+        gt = torch.autograd.grad(tot.sum(), (pg2, qg2, cg2))
+        for a, b, cgrad in zip(gt, gr, gk):
+            assert torch.allclose(a, b + cgrad, rtol=1e-8, atol=1e-11)
+        grads.append(gt)
+        # cell gradient against a central difference of the total energy under a homogeneous strain of one component (:2394)
+        h = 1e-5
+        def total(cc):
+            s = torch.linalg.solve(c, cc[0])  # positions follow the cell
+            kv_ = generate_k_vectors_ewald_summation(cc, 2.5)
+            return float((ewald_real_space(p, q, cc, al[:1], **nb) + ewald_reciprocal_space(p, q, cc, kv_, al[:1])).sum())
+        d = torch.zeros_like(c.unsqueeze(0))
+        d[0, 1, 2] = h
+        fd = (total(c.unsqueeze(0) + d) - total(c.unsqueeze(0) - d)) / (2 * h)
+        assert abs(fd - float(gt[2][0, 1, 2])) < 1e-6 * max(1.0, abs(fd))
+    # batch == members (:2488-2750, :4019, :4207, :4370)
+    P, Q = torch.cat([s[0] for s in systems]), torch.cat([s[1] for s in systems])
+    Cc = torch.stack([s[2] for s in systems])
+    bi = torch.cat([torch.full((n,), i, dtype=torch.int32) for i, n in enumerate(sizes)]).to(DEV)
+    lst, mat = _ewald_lists(P, Cc, 4.5, bi)
+    nb = lst if fmt == "list" else mat
+    Pg, Qg, Cg = P.clone().requires_grad_(True), Q.clone().requires_grad_(True), Cc.clone().requires_grad_(True)
+    kvs = [generate_k_vectors_ewald_summation(Cg[i:i + 1], 2.5) for i in range(2)]
+    kmax = max(k.shape[0] for k in kvs)
+    KV = torch.stack([torch.cat([k, torch.zeros((kmax - k.shape[0], 3), dtype=k.dtype, device=DEV)]) for k in kvs])
+    tot = ewald_summation(Pg, Qg, Cg, alpha=al, k_vectors=KV, batch_idx=bi, **nb)
+    gb = torch.autograd.grad(tot.sum(), (Pg, Qg, Cg))
+    off = 0
+    for i, n in enumerate(sizes):
+        assert torch.allclose(gb[0][off:off + n], grads[i][0], rtol=1e-8, atol=1e-11)
+        assert torch.allclose(gb[1][off:off + n], grads[i][1], rtol=1e-8, atol=1e-11)
+        assert torch.allclose(gb[2][i], grads[i][2][0], rtol=1e-7, atol=1e-10)
+        off += n
