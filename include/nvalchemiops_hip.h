@@ -278,6 +278,18 @@ int mi_spline_gather_vec3(const void* positions, const void* charges, const void
 int mi_spline_gather_grad(const void* positions, const void* mesh, const int32_t* batch_idx, const void* cell_inv_t, int n_atoms,
                           int n_systems, int nx, int ny, int nz, int order, int dtype, void* out /*[n_atoms,3]*/, void* stream);
 
+/* Second-order building blocks: the adjoint of `spline_gather_gradient` (alchemiops::_[batch_]spline_gather_gradient lists positions,
+ * charges, mesh and cell_inv_t in its grad_arrays, spline.py:1750-1840, :2110-2200; the reference replays its Warp tape).  With
+ * W_i(g) the 3-D weight of atom i at mesh point g and frac = cell_inv_t . r (derivatives include the mesh_dims factors):
+ *   mi_spline_gather_hess_dot  out[i][b] = sum_g mesh[g] sum_a vec[i][a] d^2 W_i(g) / dfrac_a dfrac_b
+ *   mi_spline_spread_grad      mesh[g]   = sum_i sum_a vec[i][a] d W_i(g) / dfrac_a          (mesh is zeroed by the call)        */
+int mi_spline_gather_hess_dot(const void* positions, const void* mesh, const int32_t* batch_idx, const void* cell_inv_t,
+                              const void* vec /*[n_atoms,3]*/, int n_atoms, int n_systems, int nx, int ny, int nz, int order, int dtype,
+                              void* out /*[n_atoms,3]*/, void* stream);
+int mi_spline_spread_grad(const void* positions, const void* vec /*[n_atoms,3]*/, const int32_t* batch_idx, const void* cell_inv_t,
+                          int n_atoms, int n_systems, int nx, int ny, int nz, int order, int dtype, void* mesh /*[B,nx,ny,nz]*/,
+                          void* stream);
+
 /* ---- PME reciprocal-space mesh kernels ------------------------------------------------------
  * mi_pme_green_sf: alchemiops::_[batch_]pme_green_structure_factor (pme.py:273-553, pme_kernels.py:121-331)
  * mi_pme_convolve: the torch elementwise block of _pme_reciprocal_space_impl (pme.py:1418-1419,1455-1457):

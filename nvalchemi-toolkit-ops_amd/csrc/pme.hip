@@ -96,6 +96,27 @@ template <class T> __device__ __forceinline__ T bspline_deriv(T u, int order) {
   return zero;
 }
 
+// d^2 M_n / du^2: derivative of the piecewise forms above, interval by interval (what differentiating `bspline_deriv` once more gives;
+// order 3 is piecewise constant, order 2 zero), M_{n-2}(u) - 2 M_{n-2}(u-1) + M_{n-2}(u-2) for n = 5, 6
+template <class T> __device__ __forceinline__ T bspline_deriv2(T u, int order) {
+  const T zero = 0, one = 1, two = 2, three = 3, four = 4;
+  if (order == 4) {
+    if (u >= zero && u < one) return u;
+    if (u >= one && u < two) return T(-3) * u + four;
+    if (u >= two && u < three) return three * u - T(8);
+    if (u >= three && u < four) return four - u;
+    return zero;
+  }
+  if (order == 3) {
+    if (u >= zero && u < one) return one;
+    if (u >= one && u < two) return -two;
+    if (u >= two && u < three) return one;
+    return zero;
+  }
+  if (order >= 5) return bspline_high(u, order - 2) - two * bspline_high(u - one, order - 2) + bspline_high(u - two, order - 2);
+  return zero;
+}
+
 template <class T> struct Stencil { int base[3]; T theta[3]; int off0[3]; };
 
 // compute_fractional_coords + bspline_grid_offset (spline.py:258-347)
@@ -369,6 +390,76 @@ __global__ void spline_gather_grad_kernel(const T* __restrict__ pos, const T* __
       }
     }
   out[3 * (size_t)i] = gx; out[3 * (size_t)i + 1] = gy; out[3 * (size_t)i + 2] = gz;
+}
+
+// Second-order building blocks of the adjoint of `spline_gather_gradient` (F_i = -q_i sum_a G_i[a] cit[a][.], G = the kernel above):
+//   hess_dot   out_i[b] = sum_g mesh[g] sum_a v_i[a] d^2 W_i(g) / dfrac_a dfrac_b      (dL/dfrac_i for L = sum_i v_i . G_i)
+//   spread_grad mesh[g] += sum_i sum_a v_i[a] d W_i(g) / dfrac_a                        (dL/dmesh)
+// One thread per atom; `spread_grad` uses atomics (training path, not the step the bench times).
+template <class T> struct Stencil2 { T w[3][MI_MAX_ORDER], d[3][MI_MAX_ORDER], dd[3][MI_MAX_ORDER]; int gi[3][MI_MAX_ORDER]; };
+template <class T>
+__device__ __forceinline__ void stencil_derivs(const Stencil<T>& st, int nx, int ny, int nz, int order, bool second, Stencil2<T>& o) {
+  const int dims[3] = {nx, ny, nz};
+  for (int d = 0; d < 3; ++d)
+    for (int t = 0; t < order; ++t) {
+      const T u = (T)order * T(0.5) + st.theta[d] - (T)(t + st.off0[d]);
+      const bool in = !(u < T(0) || u >= (T)order);
+      const T n = (T)dims[d];
+      o.w[d][t] = in ? bspline_weight(u, order) : T(0);
+      o.d[d][t] = in ? bspline_deriv(u, order) * n : T(0);
+      o.dd[d][t] = (in && second) ? bspline_deriv2(u, order) * n * n : T(0);
+      o.gi[d][t] = wrap_idx(st.base[d] + t + st.off0[d], dims[d]);
+    }
+}
+template <class T>
+__global__ void spline_gather_hess_dot_kernel(const T* __restrict__ pos, const T* __restrict__ mesh, const int* __restrict__ batch_idx,
+                                              const T* __restrict__ cit, const T* __restrict__ vec, int N, int nx, int ny, int nz, int order,
+                                              T* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  const int s = batch_idx ? batch_idx[i] : 0;
+  const Stencil<T> st = make_stencil(pos + 3 * (size_t)i, cit + 9 * (size_t)s, nx, ny, nz, order);
+  Stencil2<T> k;
+  stencil_derivs(st, nx, ny, nz, order, true, k);
+  const T vx = vec[3 * (size_t)i], vy = vec[3 * (size_t)i + 1], vz = vec[3 * (size_t)i + 2];
+  T ox = 0, oy = 0, oz = 0;
+  const T* m0 = mesh + (size_t)s * nx * ny * nz;
+  for (int tx = 0; tx < order; ++tx)
+    for (int ty = 0; ty < order; ++ty) {
+      const T* row = m0 + ((size_t)k.gi[0][tx] * ny + k.gi[1][ty]) * nz;
+      const T wx = k.w[0][tx], dx = k.d[0][tx], ddx = k.dd[0][tx], wy = k.w[1][ty], dy = k.d[1][ty], ddy = k.dd[1][ty];
+      for (int tz = 0; tz < order; ++tz) {
+        const T m = row[k.gi[2][tz]];
+        const T wz = k.w[2][tz], dz = k.d[2][tz], ddz = k.dd[2][tz];
+        // Hessian of wx wy wz in (x, y, z)
+        const T hxx = ddx * wy * wz, hyy = wx * ddy * wz, hzz = wx * wy * ddz, hxy = dx * dy * wz, hxz = dx * wy * dz, hyz = wx * dy * dz;
+        ox += m * (vx * hxx + vy * hxy + vz * hxz);
+        oy += m * (vx * hxy + vy * hyy + vz * hyz);
+        oz += m * (vx * hxz + vy * hyz + vz * hzz);
+      }
+    }
+  out[3 * (size_t)i] = ox; out[3 * (size_t)i + 1] = oy; out[3 * (size_t)i + 2] = oz;
+}
+template <class T>
+__global__ void spline_spread_grad_kernel(const T* __restrict__ pos, const T* __restrict__ vec, const int* __restrict__ batch_idx,
+                                          const T* __restrict__ cit, int N, int nx, int ny, int nz, int order, T* __restrict__ mesh) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  const int s = batch_idx ? batch_idx[i] : 0;
+  const Stencil<T> st = make_stencil(pos + 3 * (size_t)i, cit + 9 * (size_t)s, nx, ny, nz, order);
+  Stencil2<T> k;
+  stencil_derivs(st, nx, ny, nz, order, false, k);
+  const T vx = vec[3 * (size_t)i], vy = vec[3 * (size_t)i + 1], vz = vec[3 * (size_t)i + 2];
+  T* m0 = mesh + (size_t)s * nx * ny * nz;
+  for (int tx = 0; tx < order; ++tx)
+    for (int ty = 0; ty < order; ++ty) {
+      T* row = m0 + ((size_t)k.gi[0][tx] * ny + k.gi[1][ty]) * nz;
+      const T a = vx * k.d[0][tx] * k.w[1][ty] + vy * k.w[0][tx] * k.d[1][ty], b = vz * k.w[0][tx] * k.w[1][ty];
+      for (int tz = 0; tz < order; ++tz) {
+        const T val = a * k.w[2][tz] + b * k.d[2][tz];
+        if (val != T(0)) atomicAdd(row + k.gi[2][tz], val);
+      }
+    }
 }
 
 // PME epilogue: potential (+ field) gather from PLANAR meshes [B,C,nx,ny,nz] (C = 1 or 4), corrections, force factor.
@@ -668,6 +759,35 @@ int mi_spline_gather_grad(const void* positions, const void* mesh, const int32_t
   MI_DISPATCH_T(dtype, (spline_gather_grad_kernel<T_><<<mi_blocks(n_atoms, 128), 128, 0, st>>>((const T_*)positions, (const T_*)mesh, batch_idx,
                                                                                                 (const T_*)cell_inv_t, n_atoms, nx, ny, nz, order,
                                                                                                 (T_*)out)));
+  MI_LAUNCH_CHECK();
+  return MI_OK;
+}
+
+int mi_spline_gather_hess_dot(const void* positions, const void* mesh, const int32_t* batch_idx, const void* cell_inv_t, const void* vec,
+                              int n_atoms, int n_systems, int nx, int ny, int nz, int order, int dtype, void* out, void* stream) {
+  MI_REQUIRE(dtype == MI_F32 || dtype == MI_F64, "dtype");
+  MI_REQUIRE(order >= 1 && order <= MI_MAX_ORDER, "spline order must be 1..6");
+  (void)n_systems;
+  if (n_atoms <= 0) return MI_OK;
+  MI_REQUIRE(positions && mesh && cell_inv_t && vec && out, "null pointer");
+  hipStream_t st = (hipStream_t)stream;
+  MI_DISPATCH_T(dtype, (spline_gather_hess_dot_kernel<T_><<<mi_blocks(n_atoms, 128), 128, 0, st>>>(
+                           (const T_*)positions, (const T_*)mesh, batch_idx, (const T_*)cell_inv_t, (const T_*)vec, n_atoms, nx, ny, nz, order, (T_*)out)));
+  MI_LAUNCH_CHECK();
+  return MI_OK;
+}
+
+int mi_spline_spread_grad(const void* positions, const void* vec, const int32_t* batch_idx, const void* cell_inv_t, int n_atoms, int n_systems,
+                          int nx, int ny, int nz, int order, int dtype, void* mesh, void* stream) {
+  MI_REQUIRE(dtype == MI_F32 || dtype == MI_F64, "dtype");
+  MI_REQUIRE(order >= 1 && order <= MI_MAX_ORDER, "spline order must be 1..6");
+  MI_REQUIRE(n_systems >= 1 && mesh, "mesh");
+  hipStream_t st = (hipStream_t)stream;
+  MI_HIP_CHECK(hipMemsetAsync(mesh, 0, (size_t)n_systems * nx * ny * nz * (dtype == MI_F32 ? 4 : 8), st));
+  if (n_atoms <= 0) return MI_OK;
+  MI_REQUIRE(positions && vec && cell_inv_t, "null pointer");
+  MI_DISPATCH_T(dtype, (spline_spread_grad_kernel<T_><<<mi_blocks(n_atoms, 128), 128, 0, st>>>(
+                           (const T_*)positions, (const T_*)vec, batch_idx, (const T_*)cell_inv_t, n_atoms, nx, ny, nz, order, (T_*)mesh)));
   MI_LAUNCH_CHECK();
   return MI_OK;
 }

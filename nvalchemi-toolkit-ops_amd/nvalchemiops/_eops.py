@@ -12,7 +12,8 @@ the HIP kernels, with
     real-space sum uses `mi_ewald_real_bwd`, the explicit-k sum two more passes of its forward kernels.
 The real-space FORCES are differentiable too (`mi_ewald_real_forces_bwd`: second derivatives of the pair sum), so a loss on total PME
 forces back-propagates to positions, charges, cell and alpha.  Not provided (explicit NotImplementedError, never a silent zero):
-derivatives of the charge-gradient outputs and of `spline_gather_gradient`.
+derivatives of the charge-gradient outputs and of the explicit-k / Coulomb force outputs.  `spline_gather_gradient` has its adjoint (second
+derivatives of the spline weights: `mi_spline_gather_hess_dot`, `mi_spline_spread_grad`).
 
 The public functions (`spline_spread`, `particle_mesh_ewald`, ...) call these ops when something requires grad or when they are
 being traced; otherwise they take the direct ctypes path (no dispatcher overhead, fused kernels).
@@ -349,10 +350,104 @@ def _noop_setup(ctx, inputs, output):
     return None
 
 
-spline_gather_gradient_op = _op("_spline_gather_gradient", _spline_gather_gradient, _vec3_fake,
-                                _no_second_order("alchemiops::_spline_gather_gradient", "forces"), _noop_setup)
-batch_spline_gather_gradient_op = _op("_batch_spline_gather_gradient", _batch_spline_gather_gradient, _vec3_fake,
-                                      _no_second_order("alchemiops::_batch_spline_gather_gradient", "forces"), _noop_setup)
+# The adjoint of gather_gradient needs second derivatives of the spline weights: two more raw launches, ops for the same reason as
+# `spline_gather_frac_grad`.
+def _hess_dot(positions: Tensor, mesh: Tensor, batch_idx: Optional[Tensor], cell_inv_t: Tensor, vec: Tensor, spline_order: int) -> Tensor:
+    """out_i[b] = sum_g mesh[g] sum_a vec_i[a] d^2 W_i(g) / dfrac_a dfrac_b  (`mi_spline_gather_hess_dot`); mesh is [B,nx,ny,nz]."""
+    pos = positions.detach().contiguous()
+    m, c, v = (t.detach().to(pos.dtype).contiguous() for t in (mesh, cell_inv_t, vec))
+    bi = None if batch_idx is None else C.i32(batch_idx)
+    nx, ny, nz = m.shape[-3:]
+    out = torch.empty((pos.shape[0], 3), dtype=pos.dtype, device=pos.device)
+    rc = C.lib().mi_spline_gather_hess_dot(C.ptr(pos), C.ptr(m), C.ptr(bi), C.ptr(c), C.ptr(v), pos.shape[0], c.shape[0], nx, ny, nz, int(spline_order),
+                                           C.dtype_code(pos.dtype), C.ptr(out), C.stream_of(pos))
+    C.check(rc, "mi_spline_gather_hess_dot")
+    return out
+
+
+def _spread_grad(positions: Tensor, vec: Tensor, batch_idx: Optional[Tensor], cell_inv_t: Tensor, num_systems: int, mesh_nx: int, mesh_ny: int,
+                 mesh_nz: int, spline_order: int) -> Tensor:
+    """mesh[s][g] = sum_{i in s} sum_a vec_i[a] d W_i(g) / dfrac_a  (`mi_spline_spread_grad`) -> [B,nx,ny,nz]."""
+    pos = positions.detach().contiguous()
+    c, v = (t.detach().to(pos.dtype).contiguous() for t in (cell_inv_t, vec))
+    bi = None if batch_idx is None else C.i32(batch_idx)
+    mesh = torch.empty((num_systems, mesh_nx, mesh_ny, mesh_nz), dtype=pos.dtype, device=pos.device)
+    rc = C.lib().mi_spline_spread_grad(C.ptr(pos), C.ptr(v), C.ptr(bi), C.ptr(c), pos.shape[0], int(num_systems), mesh_nx, mesh_ny, mesh_nz,
+                                       int(spline_order), C.dtype_code(pos.dtype), C.ptr(mesh), C.stream_of(pos))
+    C.check(rc, "mi_spline_spread_grad")
+    return mesh
+
+
+hess_dot_op = torch.library.custom_op("nvalchemiops::spline_gather_hess_dot", _hess_dot, mutates_args=())
+hess_dot_op.register_fake(lambda positions, mesh, batch_idx, cell_inv_t, vec, spline_order: positions.new_empty((positions.shape[0], 3)))
+hess_dot_op.register_autograd(_no_second_order("nvalchemiops::spline_gather_hess_dot", "second-derivative gather"), setup_context=_noop_setup)
+spread_grad_op = torch.library.custom_op("nvalchemiops::spline_spread_frac_grad", _spread_grad, mutates_args=())
+spread_grad_op.register_fake(lambda positions, vec, batch_idx, cell_inv_t, num_systems, mesh_nx, mesh_ny, mesh_nz, spline_order:
+                             positions.new_empty((num_systems, mesh_nx, mesh_ny, mesh_nz)))
+spread_grad_op.register_autograd(_no_second_order("nvalchemiops::spline_spread_frac_grad", "gradient-weight spread"), setup_context=_noop_setup)
+
+
+def _gather_gradient_setup(batched):
+    def setup(ctx, inputs, output):
+        if batched:
+            positions, charges, mesh, batch_idx, cell, order, cell_inv_t = inputs
+        else:
+            positions, charges, mesh, cell, order, cell_inv_t = inputs
+            batch_idx = None
+        ctx.save_for_backward(positions, charges, mesh, cell, cell_inv_t, batch_idx)
+        ctx.order = order
+    return setup
+
+
+def _gather_gradient_backward(batched):
+    """Adjoint of F_i[b] = -q_i sum_a G_i[a] cit[a][b], G_i[a] = sum_g mesh[g] dW_i(g)/dfrac_a, for L = sum_i gF_i . F_i.  With
+    v_i[a] = -q_i sum_b cit[a][b] gF_i[b]  (so L = sum_i v_i . G_i at fixed v):
+      dL/dmesh = spread of v with the gradient weights;  dL/dq_i = -G_i . (cit gF_i);
+      dL/dfrac_i = H_i v_i (second-derivative gather)  ->  dL/dr_i = cit^T dL/dfrac_i,  dL/dcit += dL/dfrac_i (x) r_i;
+      dL/dcit[a][b] += sum_i -q_i G_i[a] gF_i[b]  (the explicit cit in F).
+    The reference gets the same from the Warp tape of `_bspline_gather_gradient_kernel` (spline.py:678-755)."""
+    def backward(ctx, gout):
+        positions, charges, mesh, cell, cell_inv_t, batch_idx = ctx.saved_tensors
+        need = ctx.needs_input_grad
+        dt = positions.dtype
+        cit = _cit(cell, cell_inv_t, dt)
+        nsys = mesh.shape[0] if batched else 1
+        if batched and cit.shape[0] == 1 and nsys > 1:
+            cit = cit.expand(nsys, 3, 3)
+        m = (mesh if batched else mesh.unsqueeze(0)).to(dt)
+        nx, ny, nz = m.shape[-3:]
+        g = gout.to(dt).contiguous()
+        q = charges.to(dt)
+        pos, c = positions.detach(), cit.detach()
+        c_i = c[batch_idx.long()] if batch_idx is not None else c[0].expand(pos.shape[0], 3, 3)
+        t = torch.einsum("nab,nb->na", c_i, g)                       # (cit gF)_i
+        v = -q.unsqueeze(-1) * t
+        ci = 6 if batched else 5
+        gq = gmesh = gpos = gcit = None
+        if need[1] or need[ci]:
+            gfr = frac_grad_op(pos, m, batch_idx, c, ctx.order)      # G_i
+        if need[1]:
+            gq = -(gfr * t).sum(-1).to(charges.dtype)
+        if need[2]:
+            gm = spread_grad_op(pos, v, batch_idx, c, nsys, nx, ny, nz, ctx.order)
+            gmesh = (gm if batched else gm[0]).to(mesh.dtype)
+        if need[0] or need[ci]:
+            dfrac = hess_dot_op(pos, m, batch_idx, c, v, ctx.order)
+            gpos, gc = _coordinate_grads(torch.ones_like(q), dfrac, pos, c, batch_idx)
+            if need[ci]:
+                direct = (-q).reshape(-1, 1, 1) * gfr.unsqueeze(-1) * g.unsqueeze(-2)
+                gc = gc + (direct.sum(0, keepdim=True) if batch_idx is None else torch.zeros_like(c).index_add(0, batch_idx.long(), direct))
+                gcit = _like_cell_inv_t(gc if (cell_inv_t is None or cell_inv_t.reshape(-1, 3, 3).shape[0] == gc.shape[0]) else gc.sum(0, keepdim=True), cell_inv_t)
+        if batched:
+            return gpos if need[0] else None, gq, gmesh, None, None, None, gcit if need[6] else None
+        return gpos if need[0] else None, gq, gmesh, None, None, gcit if need[5] else None
+    return backward
+
+
+spline_gather_gradient_op = _op("_spline_gather_gradient", _spline_gather_gradient, _vec3_fake, _gather_gradient_backward(False),
+                                _gather_gradient_setup(False))
+batch_spline_gather_gradient_op = _op("_batch_spline_gather_gradient", _batch_spline_gather_gradient, _vec3_fake, _gather_gradient_backward(True),
+                                      _gather_gradient_setup(True))
 
 
 # =====================================================================================================================================

@@ -142,8 +142,8 @@ def spline_gather_vec3(positions: torch.Tensor, charges: torch.Tensor, mesh: tor
 def spline_gather_gradient(positions: torch.Tensor, charges: torch.Tensor, mesh: torch.Tensor, cell: torch.Tensor, spline_order: int = 4,
                            batch_idx: torch.Tensor | None = None, cell_inv_t: torch.Tensor | None = None) -> torch.Tensor:
     """F_i = -q_i sum_g mesh[g] grad_r w(r_i, g): the fractional-coordinate gradient (scaled by the mesh dimensions) mapped to Cartesian
-    with cell_inv_t^T (spline.py:2733-2785; kernels :678-755).  Its derivatives would be second derivatives of the spline weights:
-    requesting them raises NotImplementedError (op `alchemiops::_[batch_]spline_gather_gradient`)."""
+    with cell_inv_t^T (spline.py:2733-2785; kernels :678-755).  Differentiable w.r.t. positions, charges, mesh and cell: the adjoint uses
+    the second derivatives of the spline weights (nvalchemiops/_eops.py `_gather_gradient_backward`)."""
     C.require_device(positions, charges, mesh, cell)
     if C.tracing() or _wants_grad(positions, charges, mesh, cell, cell_inv_t):
         c, cit, _ = _op_inputs(positions, cell, batch_idx, cell_inv_t)

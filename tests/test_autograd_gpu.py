@@ -345,11 +345,9 @@ def test_total_pme_forces_can_be_differentiated():
 
 
 def test_second_derivatives_of_pair_kernels_raise():
-    """Differentiating the real-space CHARGE GRADIENTS (or `spline_gather_gradient`) is not provided: an explicit NotImplementedError,
-    never a silent zero."""
+    """Differentiating the real-space CHARGE GRADIENTS is not provided: an explicit NotImplementedError, never a silent zero."""
     from nvalchemiops.interactions.electrostatics import ewald_real_space
     from nvalchemiops.neighborlist import cell_list
-    from nvalchemiops.spline import spline_gather_gradient
 
     pos, cell, q = _system(n=30, box=9.0, seed=4)
     nm, num, sh = cell_list(pos, 4.0, cell, torch.tensor([True] * 3, device=DEV), max_neighbors=64)
@@ -360,7 +358,57 @@ def test_second_derivatives_of_pair_kernels_raise():
     assert torch.isfinite(p.grad).all()
     with pytest.raises(NotImplementedError, match="second derivatives"):
         cg.sum().backward()
-    p2 = pos.clone().requires_grad_(True)
-    mesh = torch.randn((12, 12, 12), dtype=torch.float64, device=DEV)
-    with pytest.raises(NotImplementedError, match="second derivatives"):
-        spline_gather_gradient(p2, q, mesh, cell, 4).sum().backward()
+
+
+@pytest.mark.parametrize("order", [3, 4, 5])
+def test_gather_gradient_adjoint_vs_finite_differences(order):
+    """`spline_gather_gradient` is differentiable w.r.t. positions, charges, mesh and cell (grad_arrays of
+    `alchemiops::_[batch_]spline_gather_gradient`, spline.py:1750-1840 / :2110-2200; the reference's tests only ask for a finite
+    positions.grad, test_spline.py:1668, :1729): second derivatives of the spline weights (`mi_spline_gather_hess_dot`) and the
+    gradient-weight spread (`mi_spline_spread_grad`) against central differences, single and batch.  Order 3 has a piecewise-constant
+    second derivative: the points are kept away from the knots by the finite-difference step."""
+    from nvalchemiops.spline import spline_gather_gradient
+
+    g = np.random.default_rng(33)
+    for batched in (False, True):
+        nsys = 2 if batched else 1
+        cell = torch.as_tensor(np.array([[8.0, 0, 0], [0.7, 7.5, 0], [0.3, -0.4, 8.4]]), device=DEV)
+        cells = torch.stack([cell, cell * 1.1]) if batched else cell
+        n = 20
+        pos = torch.tensor(g.uniform(0.5, 7.0, (n, 3)), device=DEV)
+        q = torch.tensor(g.normal(size=n), device=DEV)
+        mesh = torch.tensor(g.normal(size=((nsys, 10, 12, 9) if batched else (10, 12, 9))), device=DEV)
+        w = torch.tensor(g.normal(size=(n, 3)), device=DEV)
+        bi = torch.as_tensor(np.repeat(np.arange(nsys, dtype=np.int32), n // nsys), device=DEV) if batched else None
+
+        def loss(p, c, m, cc):
+            return (w * spline_gather_gradient(p, c, m, cc, order, batch_idx=bi)).sum()
+
+        tp, tq, tm, tc = (t.clone().requires_grad_(True) for t in (pos, q, mesh, cells))
+        loss(tp, tq, tm, tc).backward()
+        assert all(torch.isfinite(t.grad).all() for t in (tp, tq, tm, tc))
+        h = 1e-6
+        for (i, d) in ((0, 0), (7, 2), (n - 1, 1)):
+            pp, pm = pos.clone(), pos.clone()
+            pp[i, d] += h
+            pm[i, d] -= h
+            fd = float(loss(pp, q, mesh, cells) - loss(pm, q, mesh, cells)) / (2 * h)
+            assert abs(fd - float(tp.grad[i, d])) < 2e-6 * max(1.0, abs(fd)), (batched, i, d, fd, float(tp.grad[i, d]))
+        for i in (1, n - 2):
+            qp, qm = q.clone(), q.clone()
+            qp[i] += h
+            qm[i] -= h
+            fd = float(loss(pos, qp, mesh, cells) - loss(pos, qm, mesh, cells)) / (2 * h)
+            assert abs(fd - float(tq.grad[i])) < 1e-6 * max(1.0, abs(fd))
+        idx = (1, 3, 4, 2) if batched else (3, 4, 2)
+        mp, mm = mesh.clone(), mesh.clone()
+        mp[idx] += h
+        mm[idx] -= h
+        fd = float(loss(pos, q, mp, cells) - loss(pos, q, mm, cells)) / (2 * h)
+        assert abs(fd - float(tm.grad[idx])) < 1e-6 * max(1.0, abs(fd))
+        for cidx in (((1, 0, 1), (0, 2, 2)) if batched else ((0, 1), (2, 2), (1, 0))):
+            cp, cm = cells.clone(), cells.clone()
+            cp[cidx] += h
+            cm[cidx] -= h
+            fd = float(loss(pos, q, mesh, cp) - loss(pos, q, mesh, cm)) / (2 * h)
+            assert abs(fd - float(tc.grad[cidx])) < 5e-6 * max(1.0, abs(fd)), (batched, cidx, fd, float(tc.grad[cidx]))
