@@ -239,6 +239,14 @@ int mi_coulomb_bwd(const double* positions, const double* charges, const double*
                    double* grad_positions /*[n_atoms,3]*/, double* grad_charges /*[n_atoms]*/, double* grad_cell /*[n_systems,3,3]*/,
                    void* stream);
 
+/* Adjoint of the `forces` output for L = sum_k grad_forces_k . F_k (the reference lists `forces` in the ops' grad_arrays, coulomb.py:785-790,
+ * :937-945 and replays its tape): second derivatives of the pair term, entry-wise scatter, any list; outputs float64, zeroed by the library. */
+int mi_coulomb_forces_bwd(const double* positions, const double* charges, const double* cell, const int32_t* batch_idx, int n_atoms,
+                          int n_systems, const int32_t* idx_j, const int32_t* unit_shifts, const int32_t* neighbor_ptr, int max_neighbors,
+                          int fill_value, double cutoff, double alpha, const double* grad_forces /*[n_atoms,3]*/,
+                          double* grad_positions /*[n_atoms,3]*/, double* grad_charges /*[n_atoms]*/, double* grad_cell /*[n_systems,3,3]*/,
+                          void* stream);
+
 /* ---- B-spline spread / gather ---------------------------------------------------------------
  * Replaces alchemiops::_[batch_]spline_spread / _gather / _gather_vec3 (spline.py:1500-2107; kernels
  * :497-676, :763-959).  Orders 1-4 use the reference's piecewise polynomials; orders 5-6 use the true

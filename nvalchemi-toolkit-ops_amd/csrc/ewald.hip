@@ -584,6 +584,65 @@ __global__ __launch_bounds__(256) void coulomb_bwd_kernel(const double* __restri
   }
 }
 
+// Adjoint of the explicit FORCES (force-matching on `coulomb_energy_forces` / `coulomb_forces`): L = sum_k w_k . F_k.  Entry (i -> j)
+// adds f = 1/2 q_i q_j g(r) r_ij to F_i and -f to F_j, g = fmr of `coulomb_pair`, so with dw = w_i - w_j and u = r_ij . dw
+//   L_e = 1/2 q_i q_j g u ;  G = dL_e/dr_ij = 1/2 q_i q_j (g' u r_ij / r + g dw),  g' = -3 erfc/r^4 - 3 c e/r^3 - 2 a^2 c e/r  (-3/r^4 undamped)
+//   dL/dr_i += G, dL/dr_j -= G ;  dL/dq_i += 1/2 q_j g u, dL/dq_j += 1/2 q_i g u ;  dL/dcell[a][b] -= S_a G_b   (r_ij = r_i - r_j - cell^T S).
+// The cutoff is a step: it has no derivative.  Entry-wise scatter, any list.
+template <bool CSR>
+__global__ __launch_bounds__(256) void coulomb_force_bwd_kernel(const double* __restrict__ pos, const double* __restrict__ q,
+                                                                const double* __restrict__ cell, const int* __restrict__ batch_idx, int N,
+                                                                const int* __restrict__ idx, const int* __restrict__ ush,
+                                                                const int* __restrict__ nptr, int M, int fill_value, double cutoff, double al,
+                                                                const double* __restrict__ gF, double* __restrict__ gpos,
+                                                                double* __restrict__ gq, double* __restrict__ gcell) {
+  const int lane = threadIdx.x & (MI_WAVE - 1);
+  const int i = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x / MI_WAVE) + threadIdx.x / MI_WAVE);
+  if (i >= N) return;
+  const int s = batch_idx ? batch_idx[i] : 0;
+  double cm[9];
+  for (int k = 0; k < 9; ++k) cm[k] = cell[9 * (size_t)s + k];
+  const double qi = q[i], pix = pos[3 * (size_t)i], piy = pos[3 * (size_t)i + 1], piz = pos[3 * (size_t)i + 2];
+  const double wix = gF[3 * (size_t)i], wiy = gF[3 * (size_t)i + 1], wiz = gF[3 * (size_t)i + 2];
+  const double c = 1.1283791670955126 * al;
+  long long beg, end;
+  if (CSR) { beg = nptr[i]; end = nptr[i + 1]; } else { beg = (long long)i * M; end = beg + M; }
+  double px = 0.0, py = 0.0, pz = 0.0, cq = 0.0, gc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  for (long long e = beg + lane; e < end; e += MI_WAVE) {
+    const int j = idx[e];
+    if (j < 0 || j >= N || (!CSR && j >= fill_value)) continue;
+    double rx, ry, rz, phi, g;
+    if (!coulomb_pair(pos, cm, pix, piy, piz, j, ush, e, cutoff, al, rx, ry, rz, phi, g)) continue;
+    const double r2 = rx * rx + ry * ry + rz * rz, r = sqrt(r2);
+    double gp;
+    if (al > 0.0) {
+      const double ar = al * r, ex = exp(-(ar * ar)), ec = erfc_as_poly(ar, ex);
+      gp = -3.0 * ec / (r2 * r2) - 3.0 * c * ex / (r2 * r) - 2.0 * al * al * c * ex / r;
+    } else {
+      gp = -3.0 / (r2 * r2);
+    }
+    const double qj = q[j];
+    const double dwx = wix - gF[3 * (size_t)j], dwy = wiy - gF[3 * (size_t)j + 1], dwz = wiz - gF[3 * (size_t)j + 2];
+    const double u = rx * dwx + ry * dwy + rz * dwz;
+    const double hq = 0.5 * qi * qj, k1 = hq * gp * u / r;
+    const double Gx = k1 * rx + hq * g * dwx, Gy = k1 * ry + hq * g * dwy, Gz = k1 * rz + hq * g * dwz;
+    px += Gx; py += Gy; pz += Gz;
+    atomicAdd(&gpos[3 * (size_t)j], -Gx); atomicAdd(&gpos[3 * (size_t)j + 1], -Gy); atomicAdd(&gpos[3 * (size_t)j + 2], -Gz);
+    cq += 0.5 * qj * g * u;
+    atomicAdd(&gq[j], 0.5 * qi * g * u);
+    const double sv[3] = {(double)ush[3 * e], (double)ush[3 * e + 1], (double)ush[3 * e + 2]};
+    for (int a = 0; a < 3; ++a) { gc[3 * a] -= sv[a] * Gx; gc[3 * a + 1] -= sv[a] * Gy; gc[3 * a + 2] -= sv[a] * Gz; }
+  }
+  px = wave_sum(px); py = wave_sum(py); pz = wave_sum(pz); cq = wave_sum(cq);
+  bool any_c = false;
+  for (int k = 0; k < 9; ++k) { gc[k] = wave_sum(gc[k]); any_c |= gc[k] != 0.0; }
+  if (lane == 0) {
+    atomicAdd(&gpos[3 * (size_t)i], px); atomicAdd(&gpos[3 * (size_t)i + 1], py); atomicAdd(&gpos[3 * (size_t)i + 2], pz);
+    atomicAdd(&gq[i], cq);
+    if (any_c) for (int k = 0; k < 9; ++k) atomicAdd(&gcell[9 * (size_t)s + k], gc[k]);
+  }
+}
+
 }  // namespace
 
 extern "C" int mi_ewald_real_forces_bwd(const void* positions, const void* charges, const void* cell, const void* alpha, const int32_t* batch_idx,
@@ -804,6 +863,31 @@ extern "C" int mi_coulomb_bwd(const double* positions, const double* charges, co
     coulomb_bwd_kernel<false><<<blocks, 256, 0, st>>>(positions, charges, cell, batch_idx, n_atoms, idx_j, unit_shifts, nullptr, max_neighbors,
                                                       fill_value, cutoff, alpha, energy_prefactor, grad_energies, grad_positions, grad_charges,
                                                       grad_cell);
+  MI_LAUNCH_CHECK();
+  return MI_OK;
+}
+
+extern "C" int mi_coulomb_forces_bwd(const double* positions, const double* charges, const double* cell, const int32_t* batch_idx, int n_atoms,
+                                     int n_systems, const int32_t* idx_j, const int32_t* unit_shifts, const int32_t* neighbor_ptr,
+                                     int max_neighbors, int fill_value, double cutoff, double alpha, const double* grad_forces,
+                                     double* grad_positions, double* grad_charges, double* grad_cell, void* stream) {
+  MI_REQUIRE(n_systems >= 1, "n_systems");
+  MI_REQUIRE(grad_positions && grad_charges && grad_cell, "null gradient outputs");
+  hipStream_t st = (hipStream_t)stream;
+  MI_HIP_CHECK(hipMemsetAsync(grad_cell, 0, sizeof(double) * 9 * (size_t)n_systems, st));
+  if (n_atoms <= 0) return MI_OK;
+  MI_HIP_CHECK(hipMemsetAsync(grad_positions, 0, sizeof(double) * 3 * (size_t)n_atoms, st));
+  MI_HIP_CHECK(hipMemsetAsync(grad_charges, 0, sizeof(double) * (size_t)n_atoms, st));
+  const bool csr = neighbor_ptr != nullptr;
+  if (!csr && max_neighbors <= 0) return MI_OK;
+  MI_REQUIRE(positions && charges && cell && idx_j && unit_shifts && grad_forces, "null pointer");
+  const int blocks = mi_blocks(n_atoms, 4);
+  if (csr)
+    coulomb_force_bwd_kernel<true><<<blocks, 256, 0, st>>>(positions, charges, cell, batch_idx, n_atoms, idx_j, unit_shifts, neighbor_ptr, 0, 0, cutoff,
+                                                           alpha, grad_forces, grad_positions, grad_charges, grad_cell);
+  else
+    coulomb_force_bwd_kernel<false><<<blocks, 256, 0, st>>>(positions, charges, cell, batch_idx, n_atoms, idx_j, unit_shifts, nullptr, max_neighbors,
+                                                            fill_value, cutoff, alpha, grad_forces, grad_positions, grad_charges, grad_cell);
   MI_LAUNCH_CHECK();
   return MI_OK;
 }

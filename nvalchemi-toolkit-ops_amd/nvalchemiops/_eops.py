@@ -12,7 +12,7 @@ the HIP kernels, with
     real-space sum uses `mi_ewald_real_bwd`, the explicit-k sum two more passes of its forward kernels.
 The real-space FORCES are differentiable too (`mi_ewald_real_forces_bwd`: second derivatives of the pair sum), so a loss on total PME
 forces back-propagates to positions, charges, cell and alpha.  Not provided (explicit NotImplementedError, never a silent zero):
-derivatives of the charge-gradient outputs and of the explicit-k / Coulomb force outputs.  `spline_gather_gradient` has its adjoint (second
+derivatives of the charge-gradient outputs and of the explicit-k force outputs.  `spline_gather_gradient` has its adjoint (second
 derivatives of the spline weights: `mi_spline_gather_hess_dot`, `mi_spline_spread_grad`).
 
 The public functions (`spline_spread`, `particle_mesh_ewald`, ...) call these ops when something requires grad or when they are
@@ -904,6 +904,25 @@ coulomb_bwd_op.register_autograd(lambda ctx, *g: (_ for _ in ()).throw(NotImplem
     op="nvalchemiops::coulomb_backward", what="gradient"))), setup_context=lambda ctx, inputs, output: None)
 
 
+def _coulomb_forces_bwd(positions: Tensor, charges: Tensor, cell: Tensor, batch_idx: Optional[Tensor], neighbor_list: Optional[Tensor],
+                        neighbor_ptr: Optional[Tensor], neighbor_shifts: Optional[Tensor], neighbor_matrix: Optional[Tensor],
+                        neighbor_matrix_shifts: Optional[Tensor], fill_value: int, cutoff: float, alpha: float,
+                        grad_forces: Tensor) -> tuple[Tensor, Tensor, Tensor]:
+    """(dL/dpositions, dL/dcharges, dL/dcell [B,3,3]) for L = sum_k g_k . F_k: `mi_coulomb_forces_bwd`."""
+    from nvalchemiops.interactions.electrostatics import coulomb
+
+    return coulomb._forces_backward(positions, charges, cell, batch_idx, neighbor_list, neighbor_ptr, neighbor_shifts, neighbor_matrix,
+                                    neighbor_matrix_shifts, fill_value, cutoff, alpha, grad_forces)
+
+
+coulomb_forces_bwd_op = torch.library.custom_op("nvalchemiops::coulomb_forces_backward", _coulomb_forces_bwd, mutates_args=())
+coulomb_forces_bwd_op.register_fake(lambda positions, charges, cell, batch_idx, neighbor_list, neighbor_ptr, neighbor_shifts, neighbor_matrix,
+                                    neighbor_matrix_shifts, fill_value, cutoff, alpha, grad_forces:
+                                    (torch.empty_like(positions), torch.empty_like(charges), cell.new_empty((cell.reshape(-1, 3, 3).shape[0], 3, 3))))
+coulomb_forces_bwd_op.register_autograd(lambda ctx, *g: (_ for _ in ()).throw(NotImplementedError(
+    "nvalchemiops::coulomb_forces_backward: third derivatives of the pair sum are not provided")), setup_context=lambda ctx, inputs, output: None)
+
+
 def _coulomb_setup(fmt, batched):
     def setup(ctx, inputs, output):
         positions, charges, cell = inputs[:3]
@@ -926,14 +945,17 @@ def _coulomb_setup(fmt, batched):
 
 def _coulomb_backward(name, forces):
     def backward(ctx, *grads):
-        if forces and grads[1] is not None:
-            raise NotImplementedError(_SECOND_ORDER.format(op=f"nvalchemiops::{name}", what="forces"))
         need = ctx.needs_input_grad
-        if grads[0] is None:
+        g_e, g_f = grads[0], (grads[1] if forces else None)
+        if g_e is None and g_f is None:
             return (None,) * len(need)
         positions, charges, cell, batch_idx, *lists = ctx.saved_tensors
-        gpos, gq, gcell = coulomb_bwd_op(positions, charges, cell, batch_idx, *lists, int(ctx.fill), float(ctx.cutoff), float(ctx.alpha), forces,
-                                         grads[0])
+        gpos = gq = gcell = None
+        if g_e is not None:
+            gpos, gq, gcell = coulomb_bwd_op(positions, charges, cell, batch_idx, *lists, int(ctx.fill), float(ctx.cutoff), float(ctx.alpha), forces, g_e)
+        if g_f is not None:  # the explicit forces are differentiable too (second derivatives of the pair term)
+            fp, fq, fc = coulomb_forces_bwd_op(positions, charges, cell, batch_idx, *lists, int(ctx.fill), float(ctx.cutoff), float(ctx.alpha), g_f)
+            gpos, gq, gcell = (fp, fq, fc) if gpos is None else (gpos + fp, gq + fq, gcell + fc)
         return (gpos if need[0] else None, gq if need[1] else None, gcell.reshape(cell.shape) if need[2] else None) + (None,) * (len(need) - 3)
     return backward
 

@@ -4,7 +4,7 @@
 One HIP kernel family (csrc/ewald.hip, `mi_coulomb` / `mi_coulomb_bwd`) covers list / matrix x single / batch x energy / +forces.
 As in the reference every input is upcast to float64 before the launch and the results are cast back to the positions dtype
 (:1423-1426, :1489).  Forces follow the reference's scatter (+f on the row owner, -f on atom j), so full, half and asymmetric
-lists all give the reference's numbers.  Energies are differentiable w.r.t. positions, charges and cell through a hand-written
+lists all give the reference's numbers.  Energies AND explicit forces are differentiable w.r.t. positions, charges and cell through a hand-written
 adjoint kernel (the reference records a Warp tape); when something requires grad, or under torch.compile, the call goes through the
 registered `nvalchemiops::_[batch_]coulomb_*` ops (nvalchemiops/_eops.py), otherwise straight to the C ABI.
 
@@ -38,6 +38,17 @@ def _adjoint(pos, q, cells, bi, idx, sh, nptr, m, fill_value, cutoff, alpha, epr
                                 int(m), int(fill_value), C.cdouble(cutoff), C.cdouble(alpha), C.cdouble(epref), C.ptr(g), C.ptr(gpos), C.ptr(gq),
                                 C.ptr(gcell), C.stream_of(pos))
     C.check(rc, "mi_coulomb_bwd")
+    return gpos, gq, gcell
+
+
+def _force_adjoint(pos, q, cells, bi, idx, sh, nptr, m, fill_value, cutoff, alpha, g_f):
+    """(dL/dpositions, dL/dcharges, dL/dcell) of L = sum_k g_k . F_k: `mi_coulomb_forces_bwd` (second derivatives of the pair term)."""
+    g = g_f.detach().to(torch.float64).contiguous()
+    gpos, gq, gcell = torch.empty_like(pos), torch.empty_like(q), torch.empty_like(cells)
+    rc = C.lib().mi_coulomb_forces_bwd(C.ptr(pos), C.ptr(q), C.ptr(cells), C.ptr(bi), pos.shape[0], cells.shape[0], C.ptr(idx), C.ptr(sh), C.ptr(nptr),
+                                       int(m), int(fill_value), C.cdouble(cutoff), C.cdouble(alpha), C.ptr(g), C.ptr(gpos), C.ptr(gq), C.ptr(gcell),
+                                       C.stream_of(pos))
+    C.check(rc, "mi_coulomb_forces_bwd")
     return gpos, gq, gcell
 
 
@@ -81,6 +92,18 @@ def _backward(positions, charges, cell, batch_idx, neighbor_list, neighbor_ptr, 
     bi = None if batch_idx is None else C.i32(batch_idx)
     return _adjoint(positions.detach().contiguous(), charges.detach().contiguous(), cells, bi, idx, sh, nptr, m, fv, float(cutoff), float(alpha),
                     epref, grad_energies)
+
+
+def _forces_backward(positions, charges, cell, batch_idx, neighbor_list, neighbor_ptr, neighbor_shifts, neighbor_matrix, neighbor_matrix_shifts,
+                     fill_value, cutoff, alpha, grad_forces):
+    n, dev = positions.shape[0], positions.device
+    idx, sh, nptr, m, fv, _ = _lists(n, dev, neighbor_list, neighbor_ptr, neighbor_shifts, neighbor_matrix, neighbor_matrix_shifts, fill_value, True)
+    cells = cell.detach().reshape(-1, 3, 3).contiguous()
+    if n == 0 or idx.numel() == 0:
+        return torch.zeros((n, 3), dtype=torch.float64, device=dev), torch.zeros(n, dtype=torch.float64, device=dev), torch.zeros_like(cells)
+    bi = None if batch_idx is None else C.i32(batch_idx)
+    return _force_adjoint(positions.detach().contiguous(), charges.detach().contiguous(), cells, bi, idx, sh, nptr, m, fv, float(cutoff), float(alpha),
+                          grad_forces)
 
 
 def _run(positions, charges, cell, cutoff, alpha, neighbor_list, neighbor_ptr, neighbor_shifts, neighbor_matrix, neighbor_matrix_shifts,

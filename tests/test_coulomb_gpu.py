@@ -159,9 +159,7 @@ def test_energy_autograd(fmt, alpha):
 
     P, Q, Cc = _t(pos).requires_grad_(True), _t(q).requires_grad_(True), _t(cells).requires_grad_(True)
     E, f = total(P, Q, Cc)
-    with pytest.raises(NotImplementedError):  # forces are an op output; their derivative is refused, never a silent zero
-        f.sum().backward(retain_graph=True)
-    E.backward()
+    E.backward(retain_graph=True)
     _close(-P.grad, f.detach().cpu().numpy(), "-dE/dr vs explicit forces", 1e-10)
     g = np.random.default_rng(0)
     with torch.no_grad():
@@ -200,3 +198,45 @@ def test_float32_inputs_and_empty():
     assert float(e.abs().max()) == 0.0
     e, f = coulomb_energy_forces(P, Q, Cc, 5.0, 0.0, neighbor_matrix=z_nm[:, :0], neighbor_matrix_shifts=torch.zeros((n, 0, 3), dtype=torch.int32, device=DEV))
     assert float(e.abs().max()) == 0.0 and float(f.abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("fmt", ["list", "matrix"])
+@pytest.mark.parametrize("alpha", [0.0, 0.3])
+def test_forces_can_be_differentiated(fmt, alpha):
+    """Force-matching on the explicit Coulomb forces (the reference lists `forces` in the ops' grad_arrays, coulomb.py:785-790, :937-945):
+    d(sum_k w_k . F_k)/d(positions, charges, cell) through `mi_coulomb_forces_bwd` against central differences, full matrix and half list."""
+    from nvalchemiops.interactions.electrostatics.coulomb import coulomb_energy_forces
+
+    p0, c0, q0 = _system(60, seed=18, box=9.0)
+    p1, c1, q1 = _system(40, seed=19, box=10.0, triclinic=False)
+    pos, q, cells = np.concatenate([p0, p1]), np.concatenate([q0, q1]), np.stack([c0, c1])
+    bi = _t(np.concatenate([np.zeros(60, np.int32), np.ones(40, np.int32)]))
+    cutoff = 4.0
+    # the list variant is a HALF list: the scatter (+f on i, -f on j) must carry the adjoint too
+    nm, sh, nl, ptr, lsh = _lists(pos, cells, cutoff + 0.5, half_fill=(fmt == "list"), batch_idx=bi, batch_ptr=_t(np.array([0, 60, 100], np.int32)))
+    if fmt == "list":
+        kw = dict(neighbor_list=nl, neighbor_ptr=ptr, neighbor_shifts=lsh)
+    else:
+        kw = dict(neighbor_matrix=nm, neighbor_matrix_shifts=sh)
+    w = _t(np.random.default_rng(3).normal(size=(100, 3)))
+
+    def loss(P, Q, Cc):
+        return (w * coulomb_energy_forces(P, Q, Cc, cutoff, alpha, batch_idx=bi, **kw)[1]).sum()
+
+    P, Q, Cc = _t(pos).requires_grad_(True), _t(q).requires_grad_(True), _t(cells).requires_grad_(True)
+    loss(P, Q, Cc).backward()
+    g = np.random.default_rng(1)
+    h = 1e-6
+    with torch.no_grad():
+        for _ in range(4):
+            k, d = int(g.integers(0, 100)), int(g.integers(0, 3))
+            dp = torch.zeros_like(P); dp[k, d] = h
+            fd = float(loss(P + dp, Q, Cc) - loss(P - dp, Q, Cc)) / (2 * h)
+            assert abs(fd - float(P.grad[k, d])) < 2e-6 * max(1.0, abs(fd)), ("position", fd, float(P.grad[k, d]))
+            dq = torch.zeros_like(Q); dq[k] = h
+            fd = float(loss(P, Q + dq, Cc) - loss(P, Q - dq, Cc)) / (2 * h)
+            assert abs(fd - float(Q.grad[k])) < 1e-6 * max(1.0, abs(fd)), "charge"
+            s_, a, b = int(g.integers(0, 2)), int(g.integers(0, 3)), int(g.integers(0, 3))
+            dc = torch.zeros_like(Cc); dc[s_, a, b] = h
+            fd = float(loss(P, Q, Cc + dc) - loss(P, Q, Cc - dc)) / (2 * h)
+            assert abs(fd - float(Cc.grad[s_, a, b])) < 5e-6 * max(1.0, abs(fd)), ("cell", fd, float(Cc.grad[s_, a, b]))
