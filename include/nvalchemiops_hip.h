@@ -208,14 +208,16 @@ int mi_ewald_real_bwd(const void* positions, const void* charges, const void* ce
                       void* grad_positions /*[n_atoms,3] dtype*/, void* grad_charges /*[n_atoms] dtype*/,
                       double* grad_cell, double* grad_alpha, void* symmetry_scratch /*or NULL*/, void* stream);
 
-/* Adjoint of the explicit FORCES of mi_ewald_real for L = sum_k w_k . F_k (second derivatives of the pair sum; the reference
- * differentiates its force outputs through the Warp tape: "forces" is in the grad_arrays of the `_energy_forces*` ops, ewald.py:343-348).
- * Entry-wise scatter, valid for any list.  All gradient outputs are float64 and zeroed by the library; grad_cell / grad_alpha may be NULL. */
+/* Adjoint of the explicit FORCES and CHARGE GRADIENTS of mi_ewald_real for L = sum_k w_k . F_k + sum_k v_k cg_k (second derivatives of the
+ * pair sum; the reference differentiates these outputs through the Warp tape: "forces" and "charge_gradients" are in the grad_arrays of the
+ * `_energy_forces*` ops, ewald.py:343-348, :606-612).  grad_forces / grad_charge_grads: either may be NULL.  Entry-wise scatter, valid for
+ * any list.  All gradient outputs are float64 and zeroed by the library; grad_cell / grad_alpha may be NULL.                                */
 int mi_ewald_real_forces_bwd(const void* positions, const void* charges, const void* cell, const void* alpha, const int32_t* batch_idx,
                              int n_atoms, int n_systems, int dtype, const int32_t* idx_j, const int32_t* unit_shifts,
-                             const int32_t* neighbor_ptr, int max_neighbors, int mask_value, const void* grad_forces /*[n_atoms,3] dtype*/,
-                             double* grad_positions /*[n_atoms,3]*/, double* grad_charges /*[n_atoms]*/, double* grad_cell /*[n_systems,3,3]*/,
-                             double* grad_alpha /*[n_systems]*/, void* stream);
+                             const int32_t* neighbor_ptr, int max_neighbors, int mask_value, const void* grad_forces /*[n_atoms,3] dtype or NULL*/,
+                             const void* grad_charge_grads /*[n_atoms] dtype or NULL*/, double* grad_positions /*[n_atoms,3]*/,
+                             double* grad_charges /*[n_atoms]*/, double* grad_cell /*[n_systems,3,3]*/, double* grad_alpha /*[n_systems]*/,
+                             void* stream);
 
 /* ---- cut-off Coulomb ---------------------------------------------------------------------------
  * Replaces the eight alchemiops::_[batch_]coulomb_energy[_forces]_{list,matrix} ops (interactions/electrostatics/coulomb.py:716-1330;

@@ -327,8 +327,8 @@ __global__ __launch_bounds__(256) void ewald_real_force_bwd_kernel(const T* __re
                                                                    const T* __restrict__ alpha, const int* __restrict__ batch_idx, int N,
                                                                    const int* __restrict__ idx, const int* __restrict__ ush,
                                                                    const int* __restrict__ nptr, int M, int mask_value, const T* __restrict__ gF,
-                                                                   double* __restrict__ gpos, double* __restrict__ gq, double* __restrict__ gcell,
-                                                                   double* __restrict__ galpha) {
+                                                                   const T* __restrict__ gC, double* __restrict__ gpos, double* __restrict__ gq,
+                                                                   double* __restrict__ gcell, double* __restrict__ galpha) {
   const int lane = threadIdx.x & (MI_WAVE - 1);
   const int i = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x / MI_WAVE) + threadIdx.x / MI_WAVE);
   if (i >= N) return;
@@ -337,7 +337,8 @@ __global__ __launch_bounds__(256) void ewald_real_force_bwd_kernel(const T* __re
   T cm[9];
   for (int k = 0; k < 9; ++k) cm[k] = cell[9 * (size_t)s + k];
   const T pix = pos[3 * (size_t)i], piy = pos[3 * (size_t)i + 1], piz = pos[3 * (size_t)i + 2];
-  const double wix = (double)gF[3 * (size_t)i], wiy = (double)gF[3 * (size_t)i + 1], wiz = (double)gF[3 * (size_t)i + 2];
+  const double wix = gF ? (double)gF[3 * (size_t)i] : 0.0, wiy = gF ? (double)gF[3 * (size_t)i + 1] : 0.0, wiz = gF ? (double)gF[3 * (size_t)i + 2] : 0.0;
+  const double vi = gC ? (double)gC[i] : 0.0;
   const double c = 2.0 / 1.7724538509055159 * al;
   long long beg, end;
   if (CSR) { beg = nptr[i]; end = nptr[i + 1]; } else { beg = (long long)i * M; end = beg + M; }
@@ -359,16 +360,31 @@ __global__ __launch_bounds__(256) void ewald_real_force_bwd_kernel(const T* __re
     const double d2 = d * d, d3 = d2 * d;
     const double g = ec / d3 + c * ex / d2;
     const double gp = -3.0 * ec / (d2 * d2) - 3.0 * c * ex / d3 - 2.0 * al * al * c * ex / d;
-    const double dwx = (double)gF[3 * (size_t)j] - wix, dwy = (double)gF[3 * (size_t)j + 1] - wiy, dwz = (double)gF[3 * (size_t)j + 2] - wiz;
-    const double u = dwx * sx + dwy * sy + dwz * sz;
-    const double hq = 0.5 * qi * qj;
-    const double k1 = hq * gp * u / d;
-    const double Gx = k1 * sx + hq * g * dwx, Gy = k1 * sy + hq * g * dwy, Gz = k1 * sz + hq * g * dwz;
+    double Gx = 0.0, Gy = 0.0, Gz = 0.0, dqi = 0.0, dqj = 0.0;
+    if (gF) {
+      const double dwx = (double)gF[3 * (size_t)j] - wix, dwy = (double)gF[3 * (size_t)j + 1] - wiy, dwz = (double)gF[3 * (size_t)j + 2] - wiz;
+      const double u = dwx * sx + dwy * sy + dwz * sz;
+      const double hq = 0.5 * qi * qj;
+      const double k1 = hq * gp * u / d;
+      Gx = k1 * sx + hq * g * dwx; Gy = k1 * sy + hq * g * dwy; Gz = k1 * sz + hq * g * dwz;
+      dqi = 0.5 * qj * g * u;
+      dqj = 0.5 * qi * g * u;
+      if (galpha) ga += hq * u * (-(4.0 * al * al / 1.7724538509055159) * ex);
+    }
+    if (gC) {
+      // charge-gradient outputs: the entry adds 1/2 q_j phi to cg_i and 1/2 q_i phi to cg_j, phi = erfc(a d)/d, so for L = sum_k v_k cg_k
+      //   L_e = 1/2 phi A, A = v_i q_j + v_j q_i ;  dL_e/dsep = 1/2 A phi' sep/d = -1/2 A g sep ;  dL_e/dalpha = -1/2 A (2/sqrt(pi)) e^{-a^2 d^2}
+      const double vj = (double)gC[j], phi = ec / d, A = vi * qj + vj * qi;
+      const double k2 = -0.5 * A * g;
+      Gx += k2 * sx; Gy += k2 * sy; Gz += k2 * sz;
+      dqi += 0.5 * phi * vj;
+      dqj += 0.5 * phi * vi;
+      if (galpha) ga += -0.5 * A * (2.0 / 1.7724538509055159) * ex;
+    }
     gx -= Gx; gy -= Gy; gz -= Gz;
     atomicAdd(&gpos[3 * (size_t)j], Gx); atomicAdd(&gpos[3 * (size_t)j + 1], Gy); atomicAdd(&gpos[3 * (size_t)j + 2], Gz);
-    gqi += 0.5 * qj * g * u;
-    atomicAdd(&gq[j], 0.5 * qi * g * u);
-    if (galpha) ga += hq * u * (-(4.0 * al * al / 1.7724538509055159) * ex);
+    gqi += dqi;
+    atomicAdd(&gq[j], dqj);
     if (gcell) {
       const double Sv[3] = {(double)S0, (double)S1, (double)S2}, Gv[3] = {Gx, Gy, Gz};
 #pragma unroll
@@ -648,7 +664,8 @@ __global__ __launch_bounds__(256) void coulomb_force_bwd_kernel(const double* __
 extern "C" int mi_ewald_real_forces_bwd(const void* positions, const void* charges, const void* cell, const void* alpha, const int32_t* batch_idx,
                                         int n_atoms, int n_systems, int dtype, const int32_t* idx_j, const int32_t* unit_shifts,
                                         const int32_t* neighbor_ptr, int max_neighbors, int mask_value, const void* grad_forces,
-                                        double* grad_positions, double* grad_charges, double* grad_cell, double* grad_alpha, void* stream) {
+                                        const void* grad_charge_grads, double* grad_positions, double* grad_charges, double* grad_cell,
+                                        double* grad_alpha, void* stream) {
   MI_REQUIRE(dtype == MI_F32 || dtype == MI_F64, "dtype");
   MI_REQUIRE(n_systems >= 1 && grad_positions && grad_charges, "null gradient outputs");
   hipStream_t st = (hipStream_t)stream;
@@ -659,13 +676,14 @@ extern "C" int mi_ewald_real_forces_bwd(const void* positions, const void* charg
   if (grad_cell) MI_HIP_CHECK(hipMemsetAsync(grad_cell, 0, sizeof(double) * 9 * (size_t)n_systems, st));
   if (grad_alpha) MI_HIP_CHECK(hipMemsetAsync(grad_alpha, 0, sizeof(double) * (size_t)n_systems, st));
   if (n_atoms <= 0) return MI_OK;
-  MI_REQUIRE(positions && charges && cell && alpha && idx_j && unit_shifts && grad_forces, "null pointer");
+  MI_REQUIRE(positions && charges && cell && alpha && idx_j && unit_shifts && (grad_forces || grad_charge_grads), "null pointer");
   const int blocks = mi_blocks(n_atoms, 4);
   const bool csr = neighbor_ptr != nullptr;
 #define MI_EFB(T_, CSR_)                                                                                                                          \
   ewald_real_force_bwd_kernel<T_, CSR_><<<blocks, 256, 0, st>>>((const T_*)positions, (const T_*)charges, (const T_*)cell, (const T_*)alpha, batch_idx, \
                                                                 n_atoms, idx_j, unit_shifts, neighbor_ptr, max_neighbors, mask_value,               \
-                                                                (const T_*)grad_forces, grad_positions, grad_charges, grad_cell, grad_alpha)
+                                                                (const T_*)grad_forces, (const T_*)grad_charge_grads, grad_positions, grad_charges,      \
+                                                                grad_cell, grad_alpha)
   if (dtype == MI_F32) { if (csr) MI_EFB(float, true); else MI_EFB(float, false); }
   else { if (csr) MI_EFB(double, true); else MI_EFB(double, false); }
 #undef MI_EFB

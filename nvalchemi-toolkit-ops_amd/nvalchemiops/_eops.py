@@ -10,10 +10,10 @@ the HIP kernels, with
     gather-gradient kernel, `spline_gather_vec3` (the force gather) has its adjoint too -- so forces of the reciprocal part can be
     differentiated once more (force-matching training); Green function and corrections have closed-form derivatives; the
     real-space sum uses `mi_ewald_real_bwd`, the explicit-k sum two more passes of its forward kernels.
-The real-space FORCES are differentiable too (`mi_ewald_real_forces_bwd`: second derivatives of the pair sum), so a loss on total PME
-forces back-propagates to positions, charges, cell and alpha.  Not provided (explicit NotImplementedError, never a silent zero):
-derivatives of the charge-gradient outputs and of the explicit-k force outputs.  `spline_gather_gradient` has its adjoint (second
-derivatives of the spline weights: `mi_spline_gather_hess_dot`, `mi_spline_spread_grad`).
+The real-space FORCES and CHARGE GRADIENTS are differentiable too (`mi_ewald_real_forces_bwd`: second derivatives of the pair sum), so a
+loss on total PME forces or charge gradients back-propagates to positions, charges, cell and alpha; so are the cut-off Coulomb forces and
+`spline_gather_gradient`.  Not provided (explicit NotImplementedError, never a silent zero): derivatives of the force / charge-gradient
+outputs of the explicit-k reciprocal sum.
 
 The public functions (`spline_spread`, `particle_mesh_ewald`, ...) call these ops when something requires grad or when they are
 being traced; otherwise they take the direct ctypes path (no dispatcher overhead, fused kernels).
@@ -656,9 +656,10 @@ real_bwd_op.register_autograd(lambda ctx, *g: (_ for _ in ()).throw(NotImplement
 
 def _real_forces_bwd(positions: Tensor, charges: Tensor, cell: Tensor, alpha: Tensor, batch_idx: Optional[Tensor], neighbor_list: Optional[Tensor],
                      neighbor_ptr: Optional[Tensor], neighbor_shifts: Optional[Tensor], neighbor_matrix: Optional[Tensor],
-                     neighbor_matrix_shifts: Optional[Tensor], mask_value: int, grad_forces: Tensor) -> tuple[Tensor, Tensor, Tensor, Tensor]:
-    """Float64 (dL/dpositions, dL/dcharges, dL/dcell [B,3,3], dL/dalpha [B]) for L = sum_k grad_forces_k . F_k: `mi_ewald_real_forces_bwd`
-    (second derivatives of the pair sum, entry-wise scatter)."""
+                     neighbor_matrix_shifts: Optional[Tensor], mask_value: int, grad_forces: Optional[Tensor],
+                     grad_charge_grads: Optional[Tensor]) -> tuple[Tensor, Tensor, Tensor, Tensor]:
+    """Float64 (dL/dpositions, dL/dcharges, dL/dcell [B,3,3], dL/dalpha [B]) for L = sum_k grad_forces_k . F_k + sum_k grad_charge_grads_k cg_k:
+    `mi_ewald_real_forces_bwd` (second derivatives of the pair sum, entry-wise scatter); either weight may be None."""
     from nvalchemiops.interactions.electrostatics.ewald import _real_space_inputs
 
     p = _real_space_inputs(positions, charges, cell, alpha, neighbor_list, neighbor_ptr, neighbor_shifts, neighbor_matrix, neighbor_matrix_shifts,
@@ -670,16 +671,19 @@ def _real_forces_bwd(positions: Tensor, charges: Tensor, cell: Tensor, alpha: Te
     gcell, galpha = torch.zeros((nsys, 3, 3), **f64), torch.zeros(p["alpha"].shape[0], **f64)
     if n == 0 or p["n_entries"] == 0:
         return gpos, gq, gcell, galpha
-    g = grad_forces.detach().to(dt).contiguous()
+    g = None if grad_forces is None else grad_forces.detach().to(dt).contiguous()
+    gc = None if grad_charge_grads is None else grad_charge_grads.detach().to(dt).contiguous()
+    if g is None and gc is None:
+        return gpos, gq, gcell, galpha
     rc = C.lib().mi_ewald_real_forces_bwd(C.ptr(pos), C.ptr(p["q"]), C.ptr(p["cells"]), C.ptr(p["alpha"]), C.ptr(p["bi"]), n, nsys, C.dtype_code(dt),
-                                          C.ptr(p["idx"]), C.ptr(p["sh"]), C.ptr(p["nptr"]), int(p["m"]), int(mask_value), C.ptr(g), C.ptr(gpos),
-                                          C.ptr(gq), C.ptr(gcell), C.ptr(galpha), C.stream_of(pos))
+                                          C.ptr(p["idx"]), C.ptr(p["sh"]), C.ptr(p["nptr"]), int(p["m"]), int(mask_value), C.ptr(g), C.ptr(gc),
+                                          C.ptr(gpos), C.ptr(gq), C.ptr(gcell), C.ptr(galpha), C.stream_of(pos))
     C.check(rc, "mi_ewald_real_forces_bwd")
     return gpos, gq, gcell, galpha
 
 
 def _real_forces_bwd_fake(positions, charges, cell, alpha, batch_idx, neighbor_list, neighbor_ptr, neighbor_shifts, neighbor_matrix,
-                          neighbor_matrix_shifts, mask_value, grad_forces):
+                          neighbor_matrix_shifts, mask_value, grad_forces, grad_charge_grads):
     nsys = cell.reshape(-1, 3, 3).shape[0]
     n = positions.shape[0]
     f64 = dict(dtype=torch.float64)
@@ -712,18 +716,14 @@ def _real_setup(fmt, batched):
 
 
 def _real_backward(name, fmt, batched, n_out):
-    from_names = ("energies", "forces", "charge_gradients")
-
     def backward(ctx, *grads):
-        # outputs: energies [, forces [, charge_gradients]].  Energies and FORCES are differentiable (first / second derivatives of the pair
-        # sum, two adjoint kernels); the charge-gradient output is not.
-        if n_out == 3 and grads[2] is not None:
-            raise NotImplementedError(_SECOND_ORDER.format(op=f"alchemiops::{name}", what=from_names[2]))
+        # outputs: energies [, forces [, charge_gradients]]: all differentiable (first / second derivatives of the pair sum, two adjoint kernels)
         need = ctx.needs_input_grad
         n_in = len(need)
         g_e = grads[0]
         g_f = grads[1] if n_out >= 2 else None
-        if g_e is None and g_f is None:
+        g_c = grads[2] if n_out >= 3 else None
+        if g_e is None and g_f is None and g_c is None:
             return (None,) * n_in
         saved = ctx.saved_tensors
         positions, charges, cell, alpha, batch_idx = saved[:5]
@@ -732,8 +732,8 @@ def _real_backward(name, fmt, batched, n_out):
         if g_e is not None:
             gpos, gq, gcell, galpha = real_bwd_op(positions, charges, cell, alpha, batch_idx, *lists, int(ctx.mask), g_e)
             gpos, gq = gpos.double(), gq.double()
-        if g_f is not None:
-            fp, fq, fc, fa = real_forces_bwd_op(positions, charges, cell, alpha, batch_idx, *lists, int(ctx.mask), g_f)
+        if g_f is not None or g_c is not None:
+            fp, fq, fc, fa = real_forces_bwd_op(positions, charges, cell, alpha, batch_idx, *lists, int(ctx.mask), g_f, g_c)
             gpos = fp if gpos is None else gpos + fp
             gq = fq if gq is None else gq + fq
             gcell = fc if gcell is None else gcell + fc

@@ -344,20 +344,79 @@ def test_total_pme_forces_can_be_differentiated():
             assert abs(float(fd) - float(tp.grad[i, d])) < 2e-5 * max(1.0, abs(float(fd))), (i, d, float(fd), float(tp.grad[i, d]))
 
 
-def test_second_derivatives_of_pair_kernels_raise():
-    """Differentiating the real-space CHARGE GRADIENTS is not provided: an explicit NotImplementedError, never a silent zero."""
-    from nvalchemiops.interactions.electrostatics import ewald_real_space
-    from nvalchemiops.neighborlist import cell_list
+def test_outputs_without_an_adjoint_raise():
+    """What has no adjoint raises, never a silent zero: the force / charge-gradient outputs of the explicit-k reciprocal sum."""
+    from nvalchemiops.interactions.electrostatics import ewald_reciprocal_space, generate_k_vectors_ewald_summation
 
     pos, cell, q = _system(n=30, box=9.0, seed=4)
-    nm, num, sh = cell_list(pos, 4.0, cell, torch.tensor([True] * 3, device=DEV), max_neighbors=64)
+    kv = generate_k_vectors_ewald_summation(cell.reshape(1, 3, 3), 2.5)
     p = pos.clone().requires_grad_(True)
-    e, f, cg = ewald_real_space(p, q, cell, torch.tensor([0.4], dtype=torch.float64, device=DEV), neighbor_matrix=nm, neighbor_matrix_shifts=sh,
-                                mask_value=30, compute_forces=True, compute_charge_gradients=True)
-    (e.sum() + f.sum()).backward(retain_graph=True)  # energies and forces: fine
+    e, f, cg = ewald_reciprocal_space(p, q, cell.reshape(1, 3, 3), kv, torch.tensor([0.4], dtype=torch.float64, device=DEV), compute_forces=True,
+                                      compute_charge_gradients=True)
+    e.sum().backward(retain_graph=True)
     assert torch.isfinite(p.grad).all()
     with pytest.raises(NotImplementedError, match="second derivatives"):
+        f.sum().backward(retain_graph=True)
+    with pytest.raises(NotImplementedError, match="second derivatives"):
         cg.sum().backward()
+
+
+@pytest.mark.parametrize("kind", ["matrix", "half_csr"])
+def test_charge_gradient_outputs_can_be_differentiated(kind):
+    """L = sum_k v_k cg_k of the real-space charge gradients (and of the total particle_mesh_ewald charge gradients) differentiated w.r.t.
+    positions, charges, cell and alpha ("charge_gradients" is in the grad_arrays of the reference's `_energy_forces_charge_grad` ops,
+    ewald.py:606-612): `mi_ewald_real_forces_bwd` with charge-gradient weights, against central differences."""
+    from nvalchemiops.interactions.electrostatics import ewald_real_space, particle_mesh_ewald
+    from nvalchemiops.neighborlist import cell_list
+
+    pos, cell, q = _system(n=40, box=9.0, seed=14)
+    pbc = torch.tensor([True] * 3, device=DEV)
+    if kind == "matrix":
+        nm, num, sh = cell_list(pos, 4.0, cell, pbc, max_neighbors=64)
+        nb = dict(neighbor_matrix=nm, neighbor_matrix_shifts=sh, mask_value=40)
+    else:
+        nl, ptr, sh = cell_list(pos, 4.0, cell, pbc, half_fill=True, return_neighbor_list=True)
+        nb = dict(neighbor_list=nl, neighbor_ptr=ptr, neighbor_shifts=sh)
+    v = torch.as_tensor(np.random.default_rng(2).normal(size=40), device=DEV)
+    al0 = torch.tensor([0.4], dtype=torch.float64, device=DEV)
+
+    def loss(p, c, cc, a):
+        return (v * ewald_real_space(p, c, cc, a, compute_charge_gradients=True, **nb)[1]).sum()
+
+    tp, tq, tc, ta = (t.clone().requires_grad_(True) for t in (pos, q, cell.reshape(1, 3, 3), al0))
+    loss(tp, tq, tc, ta).backward()
+    h = 1e-6
+    c3 = cell.reshape(1, 3, 3)
+    with torch.no_grad():
+        for (i, d) in ((0, 0), (17, 2), (39, 1)):
+            dp = torch.zeros_like(pos); dp[i, d] = h
+            fd = float(loss(pos + dp, q, c3, al0) - loss(pos - dp, q, c3, al0)) / (2 * h)
+            assert abs(fd - float(tp.grad[i, d])) < 2e-6 * max(1.0, abs(fd)), ("position", fd, float(tp.grad[i, d]))
+            dq = torch.zeros_like(q); dq[i] = h
+            fd = float(loss(pos, q + dq, c3, al0) - loss(pos, q - dq, c3, al0)) / (2 * h)
+            assert abs(fd - float(tq.grad[i])) < 1e-6 * max(1.0, abs(fd)), "charge"
+        for (a, b) in ((0, 0), (1, 2)):
+            dc = torch.zeros_like(c3); dc[0, a, b] = h
+            fd = float(loss(pos, q, c3 + dc, al0) - loss(pos, q, c3 - dc, al0)) / (2 * h)
+            assert abs(fd - float(tc.grad[0, a, b])) < 5e-6 * max(1.0, abs(fd)), ("cell", fd, float(tc.grad[0, a, b]))
+        fd = float(loss(pos, q, c3, al0 + h) - loss(pos, q, c3, al0 - h)) / (2 * h)
+        assert abs(fd - float(ta.grad[0])) < 2e-5 * max(1.0, abs(fd)), ("alpha", fd, float(ta.grad[0]))  # A&S erfc polynomial vs analytic derivative
+    if kind == "matrix":  # the total PME charge gradients: real-space adjoint + the closed-form corrections adjoint + the gather adjoint
+        kw = dict(alpha=0.4, mesh_dimensions=(16, 16, 16), spline_order=4, compute_charge_gradients=True, **nb)
+
+        def total(p, c):
+            return (v * particle_mesh_ewald(p, c, cell, **kw)[1]).sum()
+
+        tp, tq = pos.clone().requires_grad_(True), q.clone().requires_grad_(True)
+        total(tp, tq).backward()
+        with torch.no_grad():
+            for (i, d) in ((3, 1), (22, 0)):
+                dp = torch.zeros_like(pos); dp[i, d] = h
+                fd = float(total(pos + dp, q) - total(pos - dp, q)) / (2 * h)
+                assert abs(fd - float(tp.grad[i, d])) < 5e-6 * max(1.0, abs(fd)), ("pme position", fd, float(tp.grad[i, d]))
+                dq = torch.zeros_like(q); dq[i] = h
+                fd = float(total(pos, q + dq) - total(pos, q - dq)) / (2 * h)
+                assert abs(fd - float(tq.grad[i])) < 2e-6 * max(1.0, abs(fd)), ("pme charge", fd, float(tq.grad[i]))
 
 
 @pytest.mark.parametrize("order", [3, 4, 5])
