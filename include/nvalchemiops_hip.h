@@ -196,6 +196,12 @@ int mi_ewald_recip_gather(const void* positions, const void* charges, const void
                           double* potential /*[n_atoms]*/, double* kforce /*[n_atoms,3]*/, double* energies /*[n_atoms]*/,
                           void* forces /*[n_atoms,3] dtype*/, double* charge_grads /*[n_atoms]*/, void* stream);
 
+/* out[i] = sum_k k (weights[i] . k) (S_re cos + S_im sin)(k.r_i), float64 [n_atoms,3]: position derivative of sum_i weights_i . kforce_i at
+ * fixed structure factors; one term of the adjoint of the explicit-k FORCES ("forces" is in the grad_arrays of
+ * alchemiops::_[batch_]ewald_reciprocal_space_energy_forces*, ewald.py:1486-1496; the reference replays its tape).                       */
+int mi_ewald_recip_gather_kk(const void* positions, const void* k_vectors, const int32_t* batch_idx, const double* structure_factors,
+                             const double* weights /*[n_atoms,3]*/, int n_atoms, int n_k, int dtype, double* out /*[n_atoms,3]*/, void* stream);
+
 /* Adjoint of mi_ewald_real w.r.t. positions / charges / cell / alpha for L = sum_i g_i E_i (replaces the Warp-tape backward of
  * the real-space ops, autograd.py:525-665 + the generated adjoints of ewald_kernels.py:266-1495).  Owner-only like the forward:
  *   dL/dr_i = sum_j (g_i+g_j) fm_ij sep_ij ; dL/dq_i = sum_j 1/2 (g_i+g_j) q_j erfc(a r)/r ;

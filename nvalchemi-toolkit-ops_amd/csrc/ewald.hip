@@ -489,6 +489,34 @@ __global__ __launch_bounds__(256) void ewald_recip_gather_kernel(const T* __rest
 }
 
 
+// kk_i = sum_k k (w_i . k) (S_re cos + S_im sin)(k.r_i): the position derivative of sum_i w_i . kf_i[S] at fixed S -- one of the terms of
+// the adjoint of the explicit FORCES (nvalchemiops/interactions/electrostatics/ewald.py `_recip_outputs_adjoint`)
+template <class T>
+__global__ __launch_bounds__(256) void ewald_recip_gather_kk_kernel(const T* __restrict__ pos, const T* __restrict__ kvec, const int* __restrict__ batch_idx,
+                                                                    const double* __restrict__ sf, const double* __restrict__ wvec, int n_atoms, int K,
+                                                                    double* __restrict__ out) {
+  const int i = blockIdx.x * EK_TILE + (threadIdx.x >> 4), lane = threadIdx.x & 15;
+  const bool live = i < n_atoms;
+  const int ii = live ? i : n_atoms - 1;
+  const int b = batch_idx ? batch_idx[ii] : 0;
+  const double x = pos[3 * (size_t)ii], y = pos[3 * (size_t)ii + 1], z = pos[3 * (size_t)ii + 2];
+  const double wx = wvec[3 * (size_t)ii], wy = wvec[3 * (size_t)ii + 1], wz = wvec[3 * (size_t)ii + 2];
+  const T* kv = kvec + 3 * (size_t)b * K;
+  const double* s = sf + 2 * (size_t)b * K;
+  double ox = 0, oy = 0, oz = 0;
+  for (int k = lane; k < K; k += 16) {
+    const double kx = kv[3 * k], ky = kv[3 * k + 1], kz = kv[3 * k + 2];
+    double sn, cs;
+    sincos(kx * x + ky * y + kz * z, &sn, &cs);
+    const double t = (wx * kx + wy * ky + wz * kz) * (s[2 * k] * cs + s[2 * k + 1] * sn);
+    ox += t * kx; oy += t * ky; oz += t * kz;
+  }
+  ox = sum16(ox); oy = sum16(oy); oz = sum16(oz);
+  if (lane != 0 || !live) return;
+  out[3 * (size_t)i] = ox; out[3 * (size_t)i + 1] = oy; out[3 * (size_t)i + 2] = oz;
+}
+
+
 // ---- cut-off Coulomb (coulomb.py:133-708): fp64 throughout, arbitrary (full, half or asymmetric) lists ----------------------------
 // Pair walk of the eight reference kernels: r_ij = r_i - r_j - cell^T S, skip r >= cutoff or r < 1e-10, matrix entries
 // j >= fill_value or j >= N are padding (:325, :385), alpha > 0 selects the erfc_AS-damped form.  Unlike the Ewald kernel above the
@@ -906,6 +934,23 @@ extern "C" int mi_coulomb_forces_bwd(const double* positions, const double* char
   else
     coulomb_force_bwd_kernel<false><<<blocks, 256, 0, st>>>(positions, charges, cell, batch_idx, n_atoms, idx_j, unit_shifts, nullptr, max_neighbors,
                                                             fill_value, cutoff, alpha, grad_forces, grad_positions, grad_charges, grad_cell);
+  MI_LAUNCH_CHECK();
+  return MI_OK;
+}
+
+extern "C" int mi_ewald_recip_gather_kk(const void* positions, const void* k_vectors, const int32_t* batch_idx, const double* structure_factors,
+                                        const double* weights, int n_atoms, int n_k, int dtype, double* out, void* stream) {
+  MI_REQUIRE(dtype == MI_F32 || dtype == MI_F64, "dtype");
+  if (n_atoms <= 0) return MI_OK;
+  MI_REQUIRE(positions && weights && out && (n_k == 0 || (k_vectors && structure_factors)), "null pointer");
+  hipStream_t st = (hipStream_t)stream;
+  const int blocks = mi_blocks(n_atoms, EK_TILE);
+  if (dtype == MI_F32)
+    ewald_recip_gather_kk_kernel<float><<<blocks, 256, 0, st>>>((const float*)positions, (const float*)k_vectors, batch_idx, structure_factors, weights,
+                                                                n_atoms, n_k, out);
+  else
+    ewald_recip_gather_kk_kernel<double><<<blocks, 256, 0, st>>>((const double*)positions, (const double*)k_vectors, batch_idx, structure_factors,
+                                                                 weights, n_atoms, n_k, out);
   MI_LAUNCH_CHECK();
   return MI_OK;
 }

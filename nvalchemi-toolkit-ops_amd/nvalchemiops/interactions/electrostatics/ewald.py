@@ -268,6 +268,65 @@ def _recip_adjoint(p, g_e, need_atoms: bool, need_kv: bool, need_alpha: bool, ne
     return gpos, gch, gkv, gal, gvol
 
 
+def _recip_outputs_adjoint(p, g_f, g_c, need_alpha: bool, need_vol: bool):
+    """Adjoint of the explicit FORCES and CHARGE GRADIENTS of the reciprocal sum, L = sum_i W_i . F_i + sum_i v_i cg_i (W = g_f, v = g_c).
+    With c_ik / s_ik = cos / sin(k.r_i), Qc / Qs the charge sums, a_ik = q_i (W_i . k), As / Ac its sine / cosine sums, Vc / Vs those of v:
+        L = sum_k G_k (Qc As - Qs Ac + Qc Vc + Qs Vs) - 2 alpha/sqrt(pi) sum v_i q_i - pi/alpha^2 (Q/V) sum v_i.
+    Structure factors: S^q (weights q), S^v (weights v), S^A = sum_d k_d S[q W_d]  ->  S'' = (G As + G Vc, -G Ac + G Vs).  Then
+        dL/dr_m = q_m KK_m[S^q; W_m] - q_m kf_m[S''] - v_m kf_m[S^q]                (KK: `mi_ewald_recip_gather_kk`)
+        dL/dq_m = phi_m[S''] + W_m . kf_m[S^q] - 2 alpha v_m/sqrt(pi) - pi/alpha^2 sum v / V
+        dL/dalpha = sum_k X_k k^2/(2 alpha^3) - 2/sqrt(pi) sum v_i q_i + 2 pi/alpha^3 (Q/V) sum v ,  X_k = Re[conj(S^q) S'']/G_k
+        dL/dV     = -1/V sum_k X_k + pi/alpha^2 (Q/V^2) sum v.
+    Five structure-factor passes and three gathers of the forward kernels' cost.  Gradients w.r.t. the k-vectors are not provided.
+    Returns float64 (dL/dpositions, dL/dcharges, dL/dalpha [B] | None, dL/dV [B] | None)."""
+    pos, q, kv, cells, al, bi, sptr, max_atoms = (p[k] for k in ("pos", "q", "kv", "cells", "al", "bi", "sptr", "max_atoms"))
+    n_sys, n_k, n, dev = p["n_sys"], p["n_k"], pos.shape[0], pos.device
+    f64 = dict(dtype=torch.float64, device=dev)
+    W = torch.zeros((n, 3), **f64) if g_f is None else g_f.detach().to(torch.float64).contiguous()
+    v = torch.zeros(n, **f64) if g_c is None else g_c.detach().to(torch.float64).contiguous()
+    q64, al64, kv64 = q.to(torch.float64), al.to(torch.float64), kv.to(torch.float64)
+    sel = bi.long() if bi is not None else torch.zeros(n, dtype=torch.long, device=dev)
+    sf_of = lambda w, charge=False: _structure_factors(pos, w.to(pos.dtype).contiguous(), kv, cells, al, sptr, n_sys, n_k, max_atoms, want_charge=charge)  # noqa: E731
+    sq, tq = sf_of(q64, True)                                       # tq = Q/V (0 when there is one k-vector: the reference's k_idx == 1 rule)
+    s2 = sf_of(v)[0].clone()
+    if g_f is not None:
+        for d in range(3):
+            sa = sf_of(q64 * W[:, d])[0]                             # (G Ac_d, G As_d)
+            s2[..., 0] += kv64[..., d] * sa[..., 1]
+            s2[..., 1] -= kv64[..., d] * sa[..., 0]
+    a = _recip_gather(pos, q, kv, al, bi, sq, None, n_k, potential=False, kforce=True)
+    b = _recip_gather(pos, q, kv, al, bi, s2.contiguous(), None, n_k, potential=True, kforce=True)
+    a_i = al64[sel]
+    vsum = torch.zeros(n_sys, **f64).index_add_(0, sel, v)
+    vol = torch.abs(torch.linalg.det(cells.to(torch.float64)))
+    gpos = -q64.unsqueeze(1) * b["kforce"] - v.unsqueeze(1) * a["kforce"]
+    if g_f is not None:
+        kk = torch.empty((n, 3), **f64)
+        rc = C.lib().mi_ewald_recip_gather_kk(C.ptr(pos), C.ptr(kv), C.ptr(bi), C.ptr(sq), C.ptr(W), n, n_k, C.dtype_code(pos.dtype), C.ptr(kk),
+                                              C.stream_of(pos))
+        C.check(rc, "mi_ewald_recip_gather_kk")
+        gpos = gpos + q64.unsqueeze(1) * kk
+    # pi/alpha^2 (Q/V) sum v: d/dq_m of Q/V is 1/V wherever the forward accumulated the charge at all (tq != 0 or Q == 0 with K > 1)
+    charged = 1.0 if n_k > 1 else 0.0
+    gq = b["potential"] + (W * a["kforce"]).sum(-1) - 2.0 * a_i * v / math.sqrt(math.pi) - charged * math.pi / (a_i * a_i) * (vsum / vol)[sel]
+    gal = gvol = None
+    if need_alpha or need_vol:
+        k2 = (kv64 * kv64).sum(-1)
+        a2 = (al64 * al64).unsqueeze(1)
+        ok = k2 >= 1e-10
+        k2s = torch.where(ok, k2, torch.ones_like(k2))
+        green = 8.0 * math.pi / vol.unsqueeze(1) * torch.exp(-k2s / (4.0 * a2)) / k2s
+        ok = ok & (green > 1e-280)
+        ginv = torch.where(ok, 1.0 / torch.where(ok, green, torch.ones_like(green)), torch.zeros_like(green))
+        x = (sq[..., 0] * s2[..., 0] + sq[..., 1] * s2[..., 1]) * ginv
+        vq = torch.zeros(n_sys, **f64).index_add_(0, sel, v * q64)
+        if need_alpha:
+            gal = (x * k2).sum(1) / (2.0 * al64**3) - 2.0 / math.sqrt(math.pi) * vq + 2.0 * math.pi / al64**3 * tq * vsum
+        if need_vol:
+            gvol = -x.sum(1) / vol + math.pi / (al64 * al64) * tq / vol * vsum
+    return gpos, gq, gal, gvol
+
+
 @C.traceable
 def ewald_reciprocal_space(positions: torch.Tensor, charges: torch.Tensor, cell: torch.Tensor, k_vectors: torch.Tensor, alpha: torch.Tensor,
                            batch_idx: torch.Tensor | None = None, compute_forces: bool = False, compute_charge_gradients: bool = False):

@@ -344,21 +344,57 @@ def test_total_pme_forces_can_be_differentiated():
             assert abs(float(fd) - float(tp.grad[i, d])) < 2e-5 * max(1.0, abs(float(fd))), (i, d, float(fd), float(tp.grad[i, d]))
 
 
-def test_outputs_without_an_adjoint_raise():
-    """What has no adjoint raises, never a silent zero: the force / charge-gradient outputs of the explicit-k reciprocal sum."""
+@pytest.mark.parametrize("batched", [False, True])
+def test_explicit_k_forces_and_charge_gradients_can_be_differentiated(batched):
+    """L = sum_i W_i . F_i + sum_i v_i cg_i of the explicit-k reciprocal sum ("forces" / "charge_gradients" are in the grad_arrays of the
+    reference's `_ewald_reciprocal_space_energy_forces[_charge_grad]` ops, ewald.py:1486-1496, :1632-1643) w.r.t. positions, charges, alpha and
+    the cell (through the volume, k-vectors held fixed): `_recip_outputs_adjoint` against central differences.  The k-vector gradient of these
+    outputs is the one thing without an adjoint: it raises, never a silent zero."""
     from nvalchemiops.interactions.electrostatics import ewald_reciprocal_space, generate_k_vectors_ewald_summation
 
     pos, cell, q = _system(n=30, box=9.0, seed=4)
-    kv = generate_k_vectors_ewald_summation(cell.reshape(1, 3, 3), 2.5)
-    p = pos.clone().requires_grad_(True)
-    e, f, cg = ewald_reciprocal_space(p, q, cell.reshape(1, 3, 3), kv, torch.tensor([0.4], dtype=torch.float64, device=DEV), compute_forces=True,
-                                      compute_charge_gradients=True)
-    e.sum().backward(retain_graph=True)
-    assert torch.isfinite(p.grad).all()
-    with pytest.raises(NotImplementedError, match="second derivatives"):
-        f.sum().backward(retain_graph=True)
-    with pytest.raises(NotImplementedError, match="second derivatives"):
-        cg.sum().backward()
+    cells = cell.reshape(1, 3, 3)
+    al = torch.tensor([0.4], dtype=torch.float64, device=DEV)
+    bi = None
+    if batched:
+        pos = torch.cat([pos, pos[:20] * 1.05 + 0.2])
+        q = torch.cat([q, q[:20] - q[:20].mean()])
+        cells = torch.cat([cells, cells * 1.1])
+        al = torch.tensor([0.4, 0.45], dtype=torch.float64, device=DEV)
+        bi = torch.cat([torch.zeros(30, dtype=torch.int32), torch.ones(20, dtype=torch.int32)]).to(DEV)
+    n = pos.shape[0]
+    kvs = [generate_k_vectors_ewald_summation(cells[i:i + 1], 2.5) for i in range(cells.shape[0])]
+    kmax = max(k.shape[0] for k in kvs)
+    kv = torch.stack([torch.cat([k, torch.zeros((kmax - k.shape[0], 3), dtype=k.dtype, device=DEV)]) for k in kvs]) if batched else kvs[0]
+    g = np.random.default_rng(9)
+    W, v = torch.as_tensor(g.normal(size=(n, 3)), device=DEV), torch.as_tensor(g.normal(size=n), device=DEV)
+
+    def loss(p, c, cc, a):
+        e, f, cg = ewald_reciprocal_space(p, c, cc, kv, a, batch_idx=bi, compute_forces=True, compute_charge_gradients=True)
+        return (W * f).sum() + (v * cg).sum() + 0.3 * e.sum()
+
+    tp, tq, tc, ta = (t.clone().requires_grad_(True) for t in (pos, q, cells, al))
+    loss(tp, tq, tc, ta).backward()
+    h = 1e-6
+    with torch.no_grad():
+        for (i, d) in ((0, 0), (17, 2), (n - 1, 1)):
+            dp = torch.zeros_like(pos); dp[i, d] = h
+            fd = float(loss(pos + dp, q, cells, al) - loss(pos - dp, q, cells, al)) / (2 * h)
+            assert abs(fd - float(tp.grad[i, d])) < 2e-6 * max(1.0, abs(fd)), ("position", fd, float(tp.grad[i, d]))
+            dq = torch.zeros_like(q); dq[i] = h
+            fd = float(loss(pos, q + dq, cells, al) - loss(pos, q - dq, cells, al)) / (2 * h)
+            assert abs(fd - float(tq.grad[i])) < 2e-6 * max(1.0, abs(fd)), ("charge", fd, float(tq.grad[i]))
+        for s_ in range(cells.shape[0]):
+            dc = torch.zeros_like(cells); dc[s_, 1, 1] = h
+            fd = float(loss(pos, q, cells + dc, al) - loss(pos, q, cells - dc, al)) / (2 * h)
+            assert abs(fd - float(tc.grad[s_, 1, 1])) < 2e-6 * max(1.0, abs(fd)), ("cell volume", fd, float(tc.grad[s_, 1, 1]))
+            da = torch.zeros_like(al); da[s_] = h
+            fd = float(loss(pos, q, cells, al + da) - loss(pos, q, cells, al - da)) / (2 * h)
+            assert abs(fd - float(ta.grad[s_])) < 2e-6 * max(1.0, abs(fd)), ("alpha", fd, float(ta.grad[s_]))
+    kg = kv.clone().requires_grad_(True)
+    f = ewald_reciprocal_space(pos, q, cells, kg, al, batch_idx=bi, compute_forces=True)[1]
+    with pytest.raises(NotImplementedError, match="k_vectors"):
+        f.sum().backward()
 
 
 @pytest.mark.parametrize("kind", ["matrix", "half_csr"])
