@@ -995,3 +995,82 @@ def test_ewald_autograd_scenarios(fmt):
         assert torch.allclose(gb[1][off:off + n], grads[i][1], rtol=1e-8, atol=1e-11)
         assert torch.allclose(gb[2][i], grads[i][2][0], rtol=1e-7, atol=1e-10)
         off += n
+
+
+# ------------------------------------------------------------------------------------- test_naive.py / test_batch_naive.py / test_naive_dual.py
+def _cubic8(dtype):
+    g = torch.arange(2, dtype=dtype)
+    pos = torch.stack(torch.meshgrid(g, g, g, indexing="ij"), -1).reshape(-1, 3).to(DEV)
+    return pos, (torch.eye(3, dtype=dtype) * 2.0).reshape(1, 3, 3).to(DEV), torch.tensor([[True, True, True]], device=DEV)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("half_fill", [False, True])
+def test_naive_family_edge_and_error_scenarios(dtype, half_fill):
+    """TestNaiveMainAPI / Robustness / MemoryAndPerformance and their batch and dual-cutoff twins (test_naive.py:873-945, :1112-1166, :1400-1450;
+    test_batch_naive.py:647-742; test_naive_dual.py:685-790): empty / single atom / zero cutoff, the cell-without-pbc errors, an extremely
+    elongated cell, cutoffs beyond the box, rows that overflow max_neighbors, the max_neighbors2 default."""
+    from nvalchemiops.neighborlist import (batch_naive_neighbor_list, batch_naive_neighbor_list_dual_cutoff, naive_neighbor_list,
+                                           naive_neighbor_list_dual_cutoff)
+
+    i32 = dict(dtype=torch.int32, device=DEV)
+    empty = torch.empty((0, 3), dtype=dtype, device=DEV)
+    one = torch.zeros((1, 3), dtype=dtype, device=DEV)
+    pos, cell, pbc = _cubic8(dtype)
+    # -- naive
+    nm, num = naive_neighbor_list(positions=empty, cutoff=1.0, pbc=None, cell=None, max_neighbors=10, half_fill=half_fill)
+    assert nm.shape == (0, 10) and num.shape == (0,)
+    nm, num = naive_neighbor_list(positions=one, cutoff=1.0, pbc=None, cell=None, max_neighbors=10, half_fill=half_fill)
+    assert int(num[0]) == 0
+    nm, num = naive_neighbor_list(positions=pos[:4], cutoff=0.0, pbc=None, cell=None, max_neighbors=10, half_fill=half_fill)
+    assert int(num.abs().sum()) == 0
+    with pytest.raises(ValueError, match="If cell is provided, pbc must also be provided"):
+        naive_neighbor_list(pos, 1.0, pbc=None, cell=cell, max_neighbors=10)
+    with pytest.raises(ValueError, match="If pbc is provided, cell must also be provided"):
+        naive_neighbor_list(pos, 1.0, pbc=pbc, cell=None, max_neighbors=10)
+    # elongated cell 10 x 0.1 x 0.1 with cutoff 0.2: two image shells along the short axes (:1112)
+    long_cell = torch.tensor([[[10.0, 0, 0], [0, 0.1, 0], [0, 0, 0.1]]], dtype=dtype, device=DEV)
+    lp = torch.rand((10, 3), generator=torch.Generator().manual_seed(1), dtype=dtype).to(DEV) * torch.tensor([10.0, 0.1, 0.1], dtype=dtype, device=DEV)
+    nm, num, sh = naive_neighbor_list(positions=lp, cutoff=0.2, pbc=pbc, cell=long_cell, max_neighbors=64, half_fill=half_fill)
+    ref = O.naive(lp.cpu().numpy(), 0.2, cell=long_cell.cpu().numpy(), pbc=pbc.cpu().numpy(), max_neighbors=64, half_fill=half_fill)
+    assert np.array_equal(num.cpu().numpy(), ref[1]) and int(num.min()) >= (1 if half_fill else 2)   # at least the atom's own images along y and z
+    # cutoff 5 in a box of 2 (:1140): every atom sees many images
+    nm, num, sh = naive_neighbor_list(positions=pos, cutoff=5.0, pbc=pbc, cell=cell, max_neighbors=512, half_fill=half_fill)
+    ref = O.naive(pos.cpu().numpy(), 5.0, cell=cell.cpu().numpy(), pbc=pbc.cpu().numpy(), max_neighbors=512, half_fill=half_fill)
+    assert int(num.min()) > 0 and np.array_equal(num.cpu().numpy(), ref[1])
+    assert int(num.sum()) == (8 * 484 if not half_fill else 4 * 484)                                  # 485 lattice vectors with |v|^2 < 25, minus the atom itself
+    # rows longer than max_neighbors = 3 (:1400): shapes stay, counts keep counting
+    nm, num, sh = naive_neighbor_list(positions=pos, cutoff=2.0, pbc=pbc, cell=cell, max_neighbors=3, half_fill=half_fill)
+    assert nm.shape == (8, 3) and sh.shape == (8, 3, 3) and num.shape == (8,) and int(num.max()) > 3
+    # -- batch naive
+    nm, num = batch_naive_neighbor_list(positions=empty, cutoff=1.0, batch_idx=torch.empty(0, **i32), batch_ptr=torch.tensor([0], **i32),
+                                        max_neighbors=10, pbc=None, cell=None, half_fill=half_fill)
+    assert nm.shape == (0, 10) and num.shape == (0,)
+    nm, num = batch_naive_neighbor_list(positions=one, cutoff=1.0, batch_idx=torch.tensor([0], **i32), batch_ptr=torch.tensor([0, 1], **i32),
+                                        max_neighbors=10, pbc=None, cell=None, half_fill=half_fill)
+    assert int(num[0]) == 0
+    bi, bp = torch.tensor([0, 0, 0, 1, 1, 1, 1], **i32), torch.tensor([0, 3, 7], **i32)
+    nm, num = batch_naive_neighbor_list(positions=pos[:7], cutoff=0.0, batch_idx=bi, batch_ptr=bp, max_neighbors=10, pbc=None, cell=None,
+                                        half_fill=half_fill)
+    assert int(num.abs().sum()) == 0
+    cells2, pbc2 = cell.expand(2, -1, -1).contiguous(), pbc.expand(2, -1).contiguous()
+    with pytest.raises(ValueError, match="If cell is provided, pbc must also be provided"):
+        batch_naive_neighbor_list(pos[:7], 1.0, batch_idx=bi, batch_ptr=bp, max_neighbors=10, pbc=None, cell=cells2)
+    with pytest.raises(ValueError, match="If pbc is provided, cell must also be provided"):
+        batch_naive_neighbor_list(pos[:7], 1.0, batch_idx=bi, batch_ptr=bp, max_neighbors=10, pbc=pbc2, cell=None)
+    nm, num, sh = batch_naive_neighbor_list(pos[:7], 2.0, batch_idx=bi, batch_ptr=bp, max_neighbors=3, pbc=pbc2, cell=cells2, half_fill=half_fill)
+    assert nm.shape == (7, 3) and sh.shape == (7, 3, 3) and int(num.max()) > 3
+    # -- dual cutoff
+    with pytest.raises(ValueError, match="If cell is provided, pbc must also be provided"):
+        naive_neighbor_list_dual_cutoff(pos, 1.0, 1.5, pbc=None, cell=cell, max_neighbors1=10)
+    with pytest.raises(ValueError, match="If pbc is provided, cell must also be provided"):
+        naive_neighbor_list_dual_cutoff(pos, 1.0, 1.5, pbc=pbc, cell=None, max_neighbors1=10)
+    two = torch.tensor([[0.0, 0, 0], [1.0, 0, 0]], dtype=dtype, device=DEV)
+    out = naive_neighbor_list_dual_cutoff(positions=two, cutoff1=0.5, cutoff2=1.5, max_neighbors1=10, half_fill=half_fill)   # :767
+    assert len(out) == 4 and out[0].shape == (2, 10) and out[2].shape == (2, 10)
+    assert int(out[1].sum()) == 0 and int(out[3].sum()) == (1 if half_fill else 2)
+    out = naive_neighbor_list_dual_cutoff(positions=empty, cutoff1=0.5, cutoff2=1.5, max_neighbors1=10, half_fill=half_fill)
+    assert out[0].shape == (0, 10) and out[1].shape == (0,)
+    out = batch_naive_neighbor_list_dual_cutoff(pos[:7], 1.1, 1.5, batch_idx=bi, batch_ptr=bp, pbc=pbc2, cell=cells2, max_neighbors1=30, max_neighbors2=40,
+                                                half_fill=half_fill)
+    assert len(out) == 6 and out[0].shape == (7, 30) and out[3].shape == (7, 40) and int(out[4].sum()) >= int(out[1].sum()) > 0
