@@ -1074,3 +1074,109 @@ def test_naive_family_edge_and_error_scenarios(dtype, half_fill):
     out = batch_naive_neighbor_list_dual_cutoff(pos[:7], 1.1, 1.5, batch_idx=bi, batch_ptr=bp, pbc=pbc2, cell=cells2, max_neighbors1=30, max_neighbors2=40,
                                                 half_fill=half_fill)
     assert len(out) == 6 and out[0].shape == (7, 30) and out[3].shape == (7, 40) and int(out[4].sum()) >= int(out[1].sum()) > 0
+
+
+# ----------------------------------------------------------------------------------------------------------------- test_spline.py
+@pytest.mark.parametrize("order", [1, 2, 3, 4])
+def test_spline_property_scenarios(order):
+    """TestSplineSpread / Gather / GatherGradient / GatherVec3 / NonCubicCell / SpreadGatherConsistency and their batch twins
+    (test_spline.py:174-1215): charge conservation, shapes, locality, centre of mass of the spread, uniform meshes, adjointness,
+    batch == members, one 2-D cell shared by a batch (:1814-1980)."""
+    from nvalchemiops.spline import spline_gather, spline_gather_gradient, spline_gather_vec3, spline_spread
+
+    f64 = dict(dtype=torch.float64, device=DEV)
+    cell = torch.eye(3, **f64) * 10.0
+    g = torch.Generator().manual_seed(5)
+    pos = (torch.rand((12, 3), generator=g, dtype=torch.float64) * 10.0).to(DEV)
+    q = torch.randn(12, generator=g, dtype=torch.float64).to(DEV)
+    mesh = spline_spread(pos, q, cell, [16, 16, 16], order)                                                 # a list of dims is accepted
+    assert mesh.shape == (16, 16, 16) and mesh.dtype == torch.float64
+    assert torch.allclose(mesh.sum(), q.sum(), rtol=1e-10, atol=1e-12)                                        # :179
+    one = torch.tensor([[5.0, 5.0, 5.0]], **f64)
+    m1 = spline_spread(one, torch.ones(1, **f64), cell, (16, 16, 16), order)
+    assert int((m1 != 0).sum()) <= order ** 3                                                                 # :227 locality
+    if order >= 2:
+        for p in ([5.0, 5.0, 5.0], [2.5, 7.5, 4.0], [3.3, 6.1, 8.2]):                                          # :252 centre of mass == position
+            m = spline_spread(torch.tensor([p], **f64), torch.ones(1, **f64), cell, (16, 16, 16), order)
+            coords = torch.arange(16, **f64) * (10.0 / 16)
+            com = torch.stack([(m * coords.view(-1, 1, 1)).sum(), (m * coords.view(1, -1, 1)).sum(), (m * coords.view(1, 1, -1)).sum()]) / m.sum()
+            assert torch.allclose(com, torch.tensor(p, **f64), rtol=1e-10)
+    # uniform mesh: gather returns the constant, gather_gradient zero, gather_vec3 q * field (:337, :385, :440)
+    # (to 1e-6 like the reference's test: weights <= 1e-8 are dropped by the gather kernels, spline.py:608)
+    assert torch.allclose(spline_gather(pos, torch.full((16, 16, 16), 2.5, **f64), cell, order), torch.full((12,), 2.5, **f64), rtol=1e-6)
+    gg = spline_gather_gradient(pos, q, torch.full((16, 16, 16), 2.5, **f64), cell, order)
+    assert gg.shape == (12, 3) and float(gg.abs().max()) < 1e-9
+    field = torch.tensor([1.0, -2.0, 0.5], **f64).expand(16, 16, 16, 3).contiguous()
+    v3 = spline_gather_vec3(pos, q, field, cell, order)
+    assert v3.shape == (12, 3) and torch.allclose(v3, q.unsqueeze(1) * field[0, 0, 0], rtol=1e-6, atol=1e-9)
+    # <spread(q), phi> == <q, gather(phi)> (:637) up to the gather's 1e-8 weight cut
+    phi = torch.randn((16, 16, 16), generator=g, dtype=torch.float64).to(DEV)
+    assert abs(float((mesh * phi).sum() - (q * spline_gather(pos, phi, cell, order)).sum())) < 1e-6
+    # triclinic cell (:601): conservation still holds
+    tri = torch.tensor([[10.0, 0, 0], [2.0, 9.0, 0], [1.0, 1.5, 11.0]], **f64)
+    assert torch.allclose(spline_spread(pos @ torch.linalg.inv(cell) @ tri, q, tri, (12, 16, 20), order).sum(), q.sum(), rtol=1e-10, atol=1e-12)
+    # batch: shapes, conservation per system, members (:710-1215); a single 2-D cell for the whole batch (:1818-1900)
+    bi = torch.cat([torch.zeros(5, dtype=torch.int32), torch.ones(7, dtype=torch.int32)]).to(DEV)
+    cells = torch.stack([cell, cell * 1.2])
+    mb = spline_spread(pos, q, cells, (16, 16, 16), order, batch_idx=bi)
+    assert mb.shape == (2, 16, 16, 16)
+    assert torch.allclose(mb[0].sum(), q[:5].sum(), rtol=1e-6, atol=1e-6) and torch.allclose(mb[1].sum(), q[5:].sum(), rtol=1e-6, atol=1e-6)   # batch spread drops weights <= 1e-8 (spline.py:820)
+    assert torch.allclose(mb[1], spline_spread(pos[5:], q[5:], cells[1], (16, 16, 16), order), rtol=1e-7, atol=1e-7)   # batch cut: weights > 1e-8 only
+    phis = torch.randn((2, 16, 16, 16), generator=g, dtype=torch.float64).to(DEV)
+    gb = spline_gather(pos, phis, cells, order, batch_idx=bi)
+    assert torch.allclose(gb[:5], spline_gather(pos[:5], phis[0], cells[0], order), rtol=1e-12) and torch.allclose(gb[5:], spline_gather(pos[5:], phis[1], cells[1], order), rtol=1e-12)
+    fb = spline_gather_gradient(pos, q, phis, cells, order, batch_idx=bi)
+    assert torch.allclose(fb[5:], spline_gather_gradient(pos[5:], q[5:], phis[1], cells[1], order), rtol=1e-11, atol=1e-13)
+    vb = spline_gather_vec3(pos, q, torch.stack([field, 2 * field]), cells, order, batch_idx=bi)
+    assert vb.shape == (12, 3) and torch.allclose(vb[5:], 2 * q[5:].unsqueeze(1) * field[0, 0, 0], rtol=1e-6, atol=1e-9)
+    shared = spline_spread(pos, q, cell, (16, 16, 16), order, batch_idx=bi)                                   # one [3,3] cell, two systems
+    assert shared.shape == (2, 16, 16, 16) and torch.allclose(shared.sum((1, 2, 3)), torch.stack([q[:5].sum(), q[5:].sum()]), rtol=1e-6, atol=1e-6)
+    assert spline_gather(pos, phis, cell, order, batch_idx=bi).shape == (12,)
+    assert spline_gather_vec3(pos, q, torch.stack([field, field]), cell, order, batch_idx=bi).shape == (12, 3)
+    assert spline_gather_gradient(pos, q, phis, cell, order, batch_idx=bi).shape == (12, 3)
+
+
+def test_spline_channels_and_deconvolution_scenarios():
+    """TestMultiChannel* (test_spline.py:1216-1530, :1764-1980) and TestBSplineDeconvolution / RoundTrip / DeconvolutionCoverage
+    (:1533-1663, :1982-2030)."""
+    from nvalchemiops.spline import (compute_bspline_deconvolution, compute_bspline_deconvolution_1d, spline_gather, spline_gather_channels,
+                                     spline_spread, spline_spread_channels)
+
+    f64 = dict(dtype=torch.float64, device=DEV)
+    cell = torch.eye(3, **f64) * 10.0
+    g = torch.Generator().manual_seed(6)
+    pos = (torch.rand((10, 3), generator=g, dtype=torch.float64) * 10.0).to(DEV)
+    vals = torch.randn((10, 4), generator=g, dtype=torch.float64).to(DEV)
+    m = spline_spread_channels(pos, vals, cell, (8, 8, 8), 4)
+    assert m.shape == (4, 8, 8, 8) and torch.allclose(m.sum((1, 2, 3)), vals.sum(0), rtol=1e-10, atol=1e-12)     # :1221, :1244
+    assert torch.allclose(m[2], spline_spread(pos, vals[:, 2].contiguous(), cell, (8, 8, 8), 4), rtol=1e-12, atol=1e-15)
+    out = spline_gather_channels(pos, m, cell, 4)
+    assert out.shape == (10, 4) and torch.allclose(out[:, 1], spline_gather(pos, m[1], cell, 4), rtol=1e-12)        # :1279, :1329
+    assert torch.allclose(spline_gather_channels(pos, torch.ones((3, 8, 8, 8), **f64), cell, 4), torch.ones((10, 3), **f64), rtol=1e-6)   # :1299
+    bi = torch.cat([torch.zeros(4, dtype=torch.int32), torch.ones(6, dtype=torch.int32)]).to(DEV)
+    cells = torch.stack([cell, cell])
+    mb = spline_spread_channels(pos, vals, cells, (8, 8, 8), 4, batch_idx=bi)
+    assert mb.shape == (2, 4, 8, 8, 8) and spline_gather_channels(pos, mb, cells, 4, batch_idx=bi).shape == (10, 4)  # :1358, :1399
+    assert spline_spread_channels(pos, vals, cell, (8, 8, 8), 4, batch_idx=bi).shape == (2, 4, 8, 8, 8)               # :1927 one 2-D cell
+    vg, pg = vals.clone().requires_grad_(True), pos.clone().requires_grad_(True)                                     # :1439-1530
+    (spline_spread_channels(pg, vg, cell, (8, 8, 8), 4) * torch.randn((4, 8, 8, 8), generator=g, dtype=torch.float64).to(DEV)).sum().backward()
+    assert torch.isfinite(vg.grad).all() and torch.isfinite(pg.grad).all() and float(pg.grad.abs().max()) > 0
+    mg = m.clone().requires_grad_(True)
+    spline_gather_channels(pos, mg, cell, 4).sum().backward()
+    assert torch.isfinite(mg.grad).all() and torch.allclose(mg.grad.sum((1, 2, 3)), torch.full((4,), 10.0, **f64), rtol=1e-6)
+    # deconvolution
+    for order in (2, 3, 4, 5, 6):
+        d = compute_bspline_deconvolution((8, 12, 16), spline_order=order)
+        assert d.shape == (8, 12, 16) and abs(float(d[0, 0, 0]) - 1.0) < 1e-6 and bool((d > 0).all())
+        c = compute_bspline_deconvolution((8, 8, 8), spline_order=order)
+        for i in range(1, 4):
+            assert torch.allclose(c[i, 0, 0], c[-i, 0, 0], rtol=1e-6) and torch.allclose(c[0, i, 0], c[0, -i, 0], rtol=1e-6) and torch.allclose(c[0, 0, i], c[0, 0, -i], rtol=1e-6)
+    d1 = compute_bspline_deconvolution_1d(16, spline_order=4)
+    assert d1.shape == (16,) and abs(float(d1[0]) - 1.0) < 1e-6 and bool((d1 > 0).all()) and d1.device.type == "cpu"
+    assert compute_bspline_deconvolution((8, 8, 8), spline_order=4, device=torch.device(DEV)).device.type == "cuda"
+    assert compute_bspline_deconvolution_1d(16, spline_order=6, device=torch.device(DEV)).device.type == "cuda"
+    p3 = torch.tensor([[2.0, 2.0, 2.0], [5.0, 5.0, 5.0], [7.0, 3.0, 4.0]], **f64)                                   # :1618 round trip
+    q3 = torch.tensor([1.0, -0.5, 0.3], **f64)
+    mesh = spline_spread(p3, q3, cell, (32, 32, 32), spline_order=4)
+    corr = torch.fft.ifftn(torch.fft.fftn(mesh) * compute_bspline_deconvolution((32, 32, 32), spline_order=4, device=torch.device(DEV))).real
+    assert torch.isfinite(spline_gather(p3, corr, cell, spline_order=4)).all() and torch.isfinite(spline_gather(p3, mesh, cell, spline_order=4)).all()
