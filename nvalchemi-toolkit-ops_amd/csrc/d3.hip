@@ -71,13 +71,13 @@ template <class T>
 __global__ void d3_pack_atoms_kernel(const T* __restrict__ pos, const int* __restrict__ numbers, int N, const float* __restrict__ rcov,
                                      const float* __restrict__ r4r2, const int* __restrict__ smap, int nz,
                                      typename Vec4<T>::type* __restrict__ apos, float4* __restrict__ aaux, float* __restrict__ forces,
-                                     float* __restrict__ cn, float* __restrict__ dEdCN, float* __restrict__ e_atom, float* __restrict__ v_atom) {
+                                     float* __restrict__ cn, float* __restrict__ dEdCN, float* __restrict__ e_atom, double* __restrict__ v_atom) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= N) return;
   forces[3 * (size_t)i] = forces[3 * (size_t)i + 1] = forces[3 * (size_t)i + 2] = 0.0f;  // outputs of atoms the passes skip (Z == 0)
   cn[i] = dEdCN[i] = e_atom[i] = 0.0f;
   if (v_atom)
-    for (int k = 0; k < 9; ++k) v_atom[9 * (size_t)i + k] = 0.0f;
+    for (int k = 0; k < 9; ++k) v_atom[9 * (size_t)i + k] = 0.0;
   const int z = numbers[i];
   const bool real = z > 0 && z < nz;
   typename Vec4<T>::type r;
@@ -406,7 +406,7 @@ __device__ __forceinline__ void d3_c6(float cn_i, float cn_j, const float4* __re
   // (c6 == 0, which the reference skips in both of its loops) get -inf: they can neither set the maximum nor survive the
   // exp_arg - max >= -12 test below, so pass B needs no table access at all for terms it drops.
   float a[25];
-  float mx = -1e20f;
+  float mx = -1e20f, d0 = 0.0f;  // d0: CN_i - cn_ref_i of the dominant term (see D3Half: the d's may be taken relative to any constant)
 #pragma unroll
   for (int c = 0; c < 5; ++c) {  // 5 terms per chunk: bounds the registers the scheduler may spend on hoisted table reads
     float4 v[5];
@@ -418,6 +418,7 @@ __device__ __forceinline__ void d3_c6(float cn_i, float cn_j, const float4* __re
       const float sq = di * di + dj * dj;
       const float at = (v[k].x != 0.0f) ? k3 * sq : -INFINITY;
       a[5 * c + k] = at;
+      d0 = at > mx ? di : d0;
       mx = fmaxf(mx, at);
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -432,7 +433,7 @@ __device__ __forceinline__ void d3_c6(float cn_i, float cn_j, const float4* __re
     const bool keep = !(arg < -12.0f);
     if (__builtin_amdgcn_ballot_w64(keep) == 0) continue;
     const float2 v = *reinterpret_cast<const float2*>(&t25[t]);  // {c6, cn_ref_i}
-    const float di = cn_i - v.y;
+    const float di = (cn_i - v.y) - d0;
     const float L = keep ? d3_exp_neg(arg) : 0.0f;
     const float cL = v.x * L;
     w += L;
@@ -453,6 +454,11 @@ __device__ __forceinline__ void d3_c6(float cn_i, float cn_j, const float4* __re
 // Factorised `_c6ab_interpolate`: same sums, same thresholds (points with c6 == 0 never count; terms more than e^-12 below the
 // dominant one are dropped; w <= 1e-12 -> 0), with the exponent argument split as A_a(i) + B_b(j).  `Ap`, `u`, `di` are the
 // wave-uniform per-atom halves (A_a - max A, exp of it, CN_i - c_i(a)); rows whose u is 0 for the whole wave are skipped.
+// `di` is stored RELATIVE to the dominant row (the one with A'_a = 0): dC6/dCN_i = 2 k3/W sum_a u_a d_a (T_a - C6 S_a), and because
+// sum_a u_a (T_a - C6 S_a) = Z - C6 W = 0 any constant may be subtracted from the d_a.  With the dominant row's own d the largest term
+// drops out exactly; with the raw d_a = CN_i - c_i(a) the difference Z_d - C6 W_d cancels to ~|d| eps C6, which an approximate
+// (biased) reciprocal in C6 = Z/W turns into a coherent error over all pairs of the atom: 3e-4 on forces of 0.6 Ha/Bohr when CN_i
+// lies far outside the reference range (|d| ~ 40-80, dense test systems; tests/test_sweep_gpu.py).
 struct D3Half { float Ap[5], u[5], di[5], vcut[5]; };  // vcut[a] = exp(-12 - A'_a): v_b survives row a iff v_b >= vcut[a]
 
 __device__ __forceinline__ D3Half d3_half_i(float cn_i, const float* __restrict__ cr, float k3) {
@@ -465,6 +471,9 @@ __device__ __forceinline__ D3Half d3_half_i(float cn_i, const float* __restrict_
     A[a] = ((bits >> a) & 1) ? k3 * (h.di[a] * h.di[a]) : -INFINITY;
     mx = fmaxf(mx, A[a]);
   }
+  float d0 = 0.0f;
+#pragma unroll
+  for (int a = 4; a >= 0; --a) d0 = (A[a] == mx) ? h.di[a] : d0;  // the first dominant row's CN_i - c_i(a)
 #pragma unroll
   for (int a = 0; a < 5; ++a) {
     h.Ap[a] = A[a] - mx;
@@ -472,7 +481,7 @@ __device__ __forceinline__ D3Half d3_half_i(float cn_i, const float* __restrict_
     h.u[a] = d3_uni(keep ? d3_exp_neg(keep ? h.Ap[a] : 0.0f) : 0.0f);
     h.vcut[a] = d3_uni(keep ? d3_exp_neg(-12.0f - h.Ap[a]) : INFINITY);
     h.Ap[a] = d3_uni(h.Ap[a]);
-    h.di[a] = d3_uni(h.di[a]);
+    h.di[a] = d3_uni(h.di[a] - d0);
   }
   return h;
 }
@@ -575,7 +584,7 @@ __device__ __forceinline__ void d3_energy_body(const T* __restrict__ pos, const 
                                                         const float* __restrict__ ftab, const float* __restrict__ fcr,
                                                         const typename Vec4<T>::type* __restrict__ apos, const float4* __restrict__ aaux,
                                                         const float4* __restrict__ aw, float* __restrict__ dEdCN,
-                                                        float* __restrict__ forces, float* __restrict__ e_atom, float* __restrict__ v_atom,
+                                                        float* __restrict__ forces, float* __restrict__ e_atom, double* __restrict__ v_atom,
                                                         const unsigned* __restrict__ pk, const int* __restrict__ pk_flag) {
   constexpr bool LDS = MODE == 1;
   constexpr bool PACKED = MODE == 2 && sizeof(T) == 4;  // one 32-byte record per neighbour (see d3_weights_kernel)
@@ -728,12 +737,12 @@ __device__ __forceinline__ void d3_energy_body(const T* __restrict__ pos, const 
     double v = V6[0];
 #pragma unroll
     for (int q = 1; q < 6; ++q) v = m == q ? V6[q] : v;
-    v_atom[9 * (size_t)i + lane] = -0.5f * (float)v;
+    v_atom[9 * (size_t)i + lane] = -0.5 * v;
   }
 }
 
 
-#define D3_ENERGY_PARAMS const T* __restrict__ pos, const int* __restrict__ numbers, int N, const int* __restrict__ idx, const int* __restrict__ ush, const int* __restrict__ nptr, int M, int fill_value, const T* __restrict__ cell, const int* __restrict__ batch_idx, D3Dev P, const float* __restrict__ cn, int want_virial, const int* __restrict__ smap, const D3Species* __restrict__ sinfo, const float4* __restrict__ ctab, const float* __restrict__ ftab, const float* __restrict__ fcr, const typename Vec4<T>::type* __restrict__ apos, const float4* __restrict__ aaux, const float4* __restrict__ aw, float* __restrict__ dEdCN, float* __restrict__ forces, float* __restrict__ e_atom, float* __restrict__ v_atom, const unsigned* __restrict__ pk, const int* __restrict__ pk_flag
+#define D3_ENERGY_PARAMS const T* __restrict__ pos, const int* __restrict__ numbers, int N, const int* __restrict__ idx, const int* __restrict__ ush, const int* __restrict__ nptr, int M, int fill_value, const T* __restrict__ cell, const int* __restrict__ batch_idx, D3Dev P, const float* __restrict__ cn, int want_virial, const int* __restrict__ smap, const D3Species* __restrict__ sinfo, const float4* __restrict__ ctab, const float* __restrict__ ftab, const float* __restrict__ fcr, const typename Vec4<T>::type* __restrict__ apos, const float4* __restrict__ aaux, const float4* __restrict__ aw, float* __restrict__ dEdCN, float* __restrict__ forces, float* __restrict__ e_atom, double* __restrict__ v_atom, const unsigned* __restrict__ pk, const int* __restrict__ pk_flag
 #define D3_ENERGY_ARGS pos, numbers, N, idx, ush, nptr, M, fill_value, cell, batch_idx, P, cn, want_virial, smap, sinfo, ctab, ftab, fcr, apos, aaux, aw, dEdCN, forces, e_atom, v_atom, pk, pk_flag
 template <class T, bool CSR, int MODE, bool PK>
 __global__ __launch_bounds__(256) void d3_energy_kernel(D3_ENERGY_PARAMS) {
@@ -764,7 +773,7 @@ __global__ __launch_bounds__(D3_LS_WAVES * MI_WAVE) void d3_chain_kernel(const T
                                                        const int* __restrict__ ush, const int* __restrict__ nptr, int M, int fill_value,
                                                        const T* __restrict__ cell, const int* __restrict__ batch_idx, D3Dev P,
                                                        const typename Vec4<T>::type* __restrict__ apos, const float* __restrict__ dEdCN,
-                                                       int want_virial, float* __restrict__ forces, float* __restrict__ v_atom,
+                                                       int want_virial, float* __restrict__ forces, double* __restrict__ v_atom,
                                                        const unsigned* __restrict__ pk, const int* __restrict__ pk_flag) {
   const bool use_pk = PK && *pk_flag == 0;
   const int lane = threadIdx.x & (MI_WAVE - 1);
@@ -828,7 +837,7 @@ __global__ __launch_bounds__(D3_LS_WAVES * MI_WAVE) void d3_chain_kernel(const T
     double v = V[0];
 #pragma unroll
     for (int k = 1; k < 9; ++k) v = lane == k ? V[k] : v;
-    v_atom[9 * (size_t)i + lane] += -0.5f * (float)v;
+    v_atom[9 * (size_t)i + lane] += -0.5 * v;
   }
 }
 
@@ -836,7 +845,7 @@ __global__ __launch_bounds__(D3_LS_WAVES * MI_WAVE) void d3_chain_kernel(const T
 // running (system, sum) pair and touch global memory with ONE atomic per system change (batches are contiguous per
 // system, so that is ~1 per wave): 10 values x 256 waves instead of one atomic per 64 atoms on the same addresses.
 #define D3_REDUCE_WAVES 256
-__global__ __launch_bounds__(256) void d3_reduce_kernel(const float* __restrict__ e_atom, const float* __restrict__ v_atom,
+__global__ __launch_bounds__(256) void d3_reduce_kernel(const float* __restrict__ e_atom, const double* __restrict__ v_atom,
                                                         const int* __restrict__ batch_idx, int N, int want_virial,
                                                         double* __restrict__ sums /*[B][10], zeroed*/) {
   const int lane = threadIdx.x & (MI_WAVE - 1);
@@ -867,11 +876,11 @@ __global__ __launch_bounds__(256) void d3_reduce_kernel(const float* __restrict_
       if (s0 != cur) { flush(); cur = s0; }
       if (in) {
         acc[0] += (double)e_atom[i];
-        if (want_virial) for (int k = 0; k < 9; ++k) acc[k + 1] += (double)v_atom[9 * (size_t)i + k];
+        if (want_virial) for (int k = 0; k < 9; ++k) acc[k + 1] += v_atom[9 * (size_t)i + k];
       }
     } else if (in) {  // a chunk straddling systems: per-lane atomics
       atomicAdd(&sums[10 * (size_t)s], (double)e_atom[i]);
-      if (want_virial) for (int k = 0; k < 9; ++k) atomicAdd(&sums[10 * (size_t)s + 1 + k], (double)v_atom[9 * (size_t)i + k]);
+      if (want_virial) for (int k = 0; k < 9; ++k) atomicAdd(&sums[10 * (size_t)s + 1 + k], v_atom[9 * (size_t)i + k]);
     }
   }
   flush();
@@ -891,7 +900,7 @@ D3Layout d3_layout(int N, int nz, int dtype, int B) {
   auto take = [&](size_t b) { size_t at = o; o += mi_align(b); return at; };
   L.dEdCN = take(sizeof(float) * (size_t)N);
   L.e_atom = take(sizeof(float) * (size_t)N);
-  L.v_atom = take(sizeof(float) * 9 * (size_t)N);
+  L.v_atom = take(sizeof(double) * 9 * (size_t)N);  // fp64: the direct and the chain-rule part of an atom's virial can cancel (dense systems)
   L.sums = take(sizeof(double) * 10 * (size_t)(B > 0 ? B : 1));
   L.tab = take(sizeof(float4) * (size_t)nz * nz * 25);
   L.present = take(sizeof(int) * (size_t)nz);
@@ -916,7 +925,7 @@ int d3_impl(const T* pos, const int* numbers, int N, const int* idx, const int* 
   if (pk) { pk_flag = reinterpret_cast<int*>(pk); pk += 64; MI_HIP_CHECK(hipMemsetAsync(pk_flag, 0, sizeof(int), st)); }
   float* dEdCN = reinterpret_cast<float*>(ws + L.dEdCN);
   float* e_atom = reinterpret_cast<float*>(ws + L.e_atom);
-  float* v_atom = reinterpret_cast<float*>(ws + L.v_atom);
+  double* v_atom = reinterpret_cast<double*>(ws + L.v_atom);
   float4* tab = reinterpret_cast<float4*>(ws + L.tab);
   int* present = reinterpret_cast<int*>(ws + L.present);
   int* smap = reinterpret_cast<int*>(ws + L.smap);
