@@ -39,7 +39,7 @@ def _random_batch(g, dtype, periodic, sizes, scale=1.0):
     return pos, cell, pbc, bi
 
 
-@pytest.mark.parametrize("seed", range(10))
+@pytest.mark.parametrize("seed", range(24))
 def test_d3_sweep(seed):
     from nvalchemiops.interactions.dispersion import D3Parameters, dftd3
     from nvalchemiops.neighborlist import batch_cell_list
@@ -98,15 +98,16 @@ def test_d3_sweep(seed):
         assert (err <= bound).all(), f"{names[k]}: max err {err.max():.3e}, reference-order noise {slack[k] / 2:.3e}"
 
 
-@pytest.mark.parametrize("seed", range(10))
+@pytest.mark.parametrize("seed", range(24))
 def test_pme_sweep(seed):
     from nvalchemiops.interactions.electrostatics import particle_mesh_ewald
     from nvalchemiops.neighborlist import batch_cell_list, cell_list
 
     g = np.random.default_rng(4000 + seed)
     dtype = np.float64 if seed % 2 else np.float32
-    order = [4, 5, 3, 6, 2, 4, 1, 5, 4, 6][seed]
-    dims = [(16, 16, 16), (20, 24, 18), (13, 17, 11), (12, 12, 30), (7, 9, 10), (32, 16, 24), (8, 8, 8), (15, 21, 14), (19, 19, 19), (24, 24, 24)][seed]
+    order = [4, 5, 3, 6, 2, 4, 1, 5, 4, 6][seed % 10]
+    dims = [(16, 16, 16), (20, 24, 18), (13, 17, 11), (12, 12, 30), (7, 9, 10), (32, 16, 24), (8, 8, 8), (15, 21, 14), (19, 19, 19), (24, 24, 24),
+            (6, 6, 6), (36, 10, 14), (11, 11, 11), (18, 27, 9)][(seed + seed // 10) % 14]   # order and mesh drift apart over the seeds
     batched = seed % 3 != 0
     sizes = [int(g.choice([1, 9, 60, 200])) for _ in range(int(g.integers(2, 5)))] if batched else [int(g.choice([30, 120, 350]))]
     pos, cell, pbc, bi = _random_batch(g, dtype, True, sizes)
@@ -148,3 +149,147 @@ def test_pme_sweep(seed):
         scale = max(np.abs(b).max(), 1e-30)
         err = np.abs(a - b).max() if b.size else 0.0
         assert err <= rel * scale + (1e-12 if dtype == np.float64 else 1e-5), f"{what}: {err:.3e} vs scale {scale:.3e} (order {order}, mesh {dims})"
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_naive_family_sweep(seed):
+    """naive / batch_naive / dual-cutoff searches (the naive result semantics: rc^2 in the input precision, image range from the cell
+    heights, no wrapping of the atoms) on random sheared cells with atoms outside the cell and random pbc flags, against the oracle's
+    restatement of the O(N^2) kernels -- pair multisets bit-exact."""
+    from nvalchemiops.neighborlist import batch_naive_neighbor_list, naive_neighbor_list, naive_neighbor_list_dual_cutoff
+
+    g = np.random.default_rng(5000 + seed)
+    dtype = np.float64 if seed % 2 else np.float32
+    n = int(g.choice([2, 17, 90, 260]))
+    box = float(g.uniform(4.0, 9.0))
+    cell = np.diag(g.uniform(0.8, 1.2, 3) * box)
+    if seed % 3:
+        cell[1, 0], cell[2, 0], cell[2, 1] = g.uniform(-0.3, 0.3, 3) * box
+    pos = (g.uniform(-0.4, 1.4, (n, 3)) @ cell).astype(dtype)
+    cell = cell.astype(dtype)
+    periodic = seed % 4 != 3
+    pbc = (g.uniform(size=3) < 0.75) if periodic else None
+    rc1, rc2 = float(g.uniform(1.0, 2.5)), float(g.uniform(2.6, 5.0))
+    half = seed % 5 == 0
+    kw = dict(cell=_t(cell).reshape(1, 3, 3), pbc=_t(pbc).reshape(1, 3)) if periodic else {}
+    okw = dict(cell=cell, pbc=pbc) if periodic else {}
+    m = 1024
+
+    def same(res, rc):
+        nm, num = res[0].cpu().numpy(), res[1].cpu().numpy()
+        sh = res[2].cpu().numpy() if periodic else np.zeros(nm.shape + (3,), np.int32)
+        ref = O.naive(pos, rc, max_neighbors=m, half_fill=half, **okw)
+        rsh = ref[2] if periodic else np.zeros(ref[0].shape + (3,), np.int32)
+        assert ref[1].max() <= m
+        if half:  # one direction per pair: compare as unordered pairs
+            def und(a):
+                a = a.copy()
+                flip = (a[:, 0] > a[:, 1])
+                a[flip, 0], a[flip, 1] = a[flip, 1].copy(), a[flip, 0].copy()
+                a[flip, 2:] *= -1
+                selfp = a[:, 0] == a[:, 1]
+                neg = selfp & ((a[:, 2] < 0) | ((a[:, 2] == 0) & (a[:, 3] < 0)) | ((a[:, 2] == 0) & (a[:, 3] == 0) & (a[:, 4] < 0)))
+                a[neg, 2:] *= -1
+                return a[np.lexsort(a.T[::-1])]
+            assert np.array_equal(und(O.canonical_pairs(nm, num, sh)), und(O.canonical_pairs(ref[0], ref[1], rsh)))
+        else:
+            assert np.array_equal(O.canonical_pairs(nm, num, sh), O.canonical_pairs(ref[0], ref[1], rsh))
+
+    same(naive_neighbor_list(_t(pos), rc2, max_neighbors=m, half_fill=half, **kw), rc2)
+    out = naive_neighbor_list_dual_cutoff(_t(pos), rc1, rc2, max_neighbors1=m, max_neighbors2=m, half_fill=half, **kw)
+    k = len(out) // 2
+    same(out[:k], rc1), same(out[k:], rc2)
+    # the same system twice in a batch (second copy translated by a lattice-independent vector)
+    posb = np.concatenate([pos, pos + np.asarray([0.7, -1.1, 0.4], dtype)])
+    bi = _t(np.repeat(np.arange(2, dtype=np.int32), n))
+    kwb = dict(cell=_t(np.stack([cell, cell])), pbc=_t(np.stack([pbc, pbc]))) if periodic else {}
+    rb = batch_naive_neighbor_list(_t(posb), rc2, batch_idx=bi, max_neighbors=m, half_fill=half, **kwb)
+    numb = rb[1].cpu().numpy()
+    ref = O.naive(pos, rc2, max_neighbors=m, half_fill=half, **okw)
+    assert int(numb[:n].sum()) == int(ref[1].sum()) and int(numb[n:].sum()) == int(numb[:n].sum())
+    assert int((rb[0][:n][rb[0][:n] < 2 * n] >= n).sum()) == 0 and int((rb[0][n:][rb[0][n:] < 2 * n] < n).sum()) == 0   # no pair across systems
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_pair_sums_on_arbitrary_lists_sweep(seed):
+    """Real-space Ewald (E, F, charge gradients) and cut-off Coulomb (E, F) on lists that are full, half, or randomly PRUNED (neither
+    symmetric nor half: what a caller-side filter produces), matrix and CSR, single and batch, fp32 and fp64, against the oracle's
+    entry-by-entry restatement of the reference's i / j scatter."""
+    from nvalchemiops.interactions.electrostatics import ewald_real_space
+    from nvalchemiops.interactions.electrostatics.coulomb import coulomb_energy_forces
+    from nvalchemiops.neighborlist import batch_cell_list
+
+    g = np.random.default_rng(6000 + seed)
+    dtype = np.float64 if seed % 2 else np.float32
+    sizes = [int(g.choice([3, 30, 120, 300])) for _ in range(int(g.integers(1, 4)))]
+    pos, cell, pbc, bi = _random_batch(g, dtype, True, sizes, scale=1.2)
+    q = g.normal(size=len(pos)).astype(dtype)
+    alpha = g.uniform(0.25, 0.5, len(sizes)).astype(dtype)
+    cutoff = float(g.uniform(3.5, 6.0))
+    kind = ["full", "half", "pruned"][seed % 3]
+    nl, ptr, sh = batch_cell_list(_t(pos), cutoff, _t(cell), _t(pbc), _t(bi), return_neighbor_list=True, half_fill=(kind == "half"), max_neighbors=1024)
+    nl, ptr, sh = nl.cpu().numpy(), ptr.cpu().numpy(), sh.cpu().numpy()
+    if kind == "pruned":
+        keep = g.uniform(size=nl.shape[1]) < 0.7
+        counts = np.bincount(nl[0][keep], minlength=len(pos))
+        nl, sh = nl[:, keep], sh[keep]
+        ptr = np.concatenate([[0], np.cumsum(counts)]).astype(np.int32)
+    n = len(pos)
+    if seed % 4 < 2:   # CSR
+        nb = dict(neighbor_list=_t(nl), neighbor_ptr=_t(ptr), neighbor_shifts=_t(sh))
+        onb_e = dict(idx_j=nl[1], neighbor_ptr=ptr, neighbor_shifts=sh)
+        onb_c = dict(neighbor_list=nl, neighbor_ptr=ptr, neighbor_shifts=sh)
+    else:              # the same entries as a padded matrix
+        width = int(np.diff(ptr).max()) + 3 if n else 1
+        nm = np.full((n, width), n, np.int32)
+        msh = np.zeros((n, width, 3), np.int32)
+        for i in range(n):
+            k = ptr[i + 1] - ptr[i]
+            nm[i, :k], msh[i, :k] = nl[1, ptr[i]:ptr[i + 1]], sh[ptr[i]:ptr[i + 1]]
+        nb = dict(neighbor_matrix=_t(nm), neighbor_matrix_shifts=_t(msh))
+        onb_e = dict(neighbor_matrix=nm, neighbor_matrix_shifts=msh, mask_value=n)
+        onb_c = dict(neighbor_matrix=nm, neighbor_matrix_shifts=msh)
+    rel = 1e-10 if dtype == np.float64 else 1e-4
+    out = ewald_real_space(_t(pos), _t(q), _t(cell), _t(alpha), batch_idx=_t(bi), compute_forces=True, compute_charge_gradients=True,
+                           **nb, **(dict(mask_value=n) if "neighbor_matrix" in nb else {}))
+    ref = O.ewald_real_space(pos, q, cell, alpha, batch_idx=bi, compute_forces=True, compute_charge_gradients=True, **onb_e)
+    for a, b, what in zip(out, ref, ("energies", "forces", "charge gradients")):
+        err = np.abs(a.cpu().numpy().astype(np.float64) - b).max() if b.size else 0.0
+        assert err <= rel * max(np.abs(b).max(), 1e-30) + (1e-12 if dtype == np.float64 else 1e-5), f"ewald {what} ({kind}): {err:.3e}"
+    a0 = float(alpha[0]) if seed % 2 else 0.0
+    e, f = coulomb_energy_forces(_t(pos), _t(q), _t(cell), cutoff * 0.9, a0, batch_idx=_t(bi), **nb)
+    oe, of = O.coulomb(pos.astype(np.float64), q.astype(np.float64), cell.astype(np.float64), cutoff * 0.9, a0, batch_idx=bi, **onb_c)
+    for a, b, what in ((e, oe, "energies"), (f, of, "forces")):
+        err = np.abs(a.cpu().numpy().astype(np.float64) - b).max() if b.size else 0.0
+        assert err <= (1e-11 if dtype == np.float64 else 1e-6) * max(np.abs(b).max(), 1e-30) + 1e-14, f"coulomb {what} ({kind}): {err:.3e}"
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_explicit_k_ewald_sweep(seed):
+    """ewald_reciprocal_space over explicit k-vector sets (sheared cells, several cutoffs, fp32 / fp64, batches padded with zero
+    k-vectors) against the oracle: energies, forces, charge gradients."""
+    from nvalchemiops.interactions.electrostatics import ewald_reciprocal_space, generate_k_vectors_ewald_summation
+
+    g = np.random.default_rng(7000 + seed)
+    dtype = np.float64 if seed % 2 else np.float32
+    sizes = [int(g.choice([2, 25, 90, 200])) for _ in range(int(g.integers(1, 4)))]
+    pos, cell, pbc, bi = _random_batch(g, dtype, True, sizes, scale=1.2)
+    q = g.normal(size=len(pos)).astype(dtype)
+    alpha = g.uniform(0.25, 0.5, len(sizes)).astype(dtype)
+    kc = float(g.uniform(1.5, 3.0))
+    kvs = [generate_k_vectors_ewald_summation(_t(cell[s:s + 1]), kc) for s in range(len(sizes))]
+    for k, c in zip(kvs, cell):     # the host-side generator equals the oracle's
+        assert np.allclose(k.cpu().numpy(), O.generate_k_vectors_ewald_summation(c, kc), rtol=1e-5 if dtype == np.float32 else 1e-12, atol=1e-6 if dtype == np.float32 else 1e-12)
+    kmax = max(k.shape[0] for k in kvs)
+    KV = torch.stack([torch.cat([k, torch.zeros((kmax - k.shape[0], 3), dtype=k.dtype, device=DEV)]) for k in kvs])
+    out = ewald_reciprocal_space(_t(pos), _t(q), _t(cell), KV, _t(alpha), batch_idx=_t(bi), compute_forces=True, compute_charge_gradients=True)
+    off = 0
+    rel = 1e-10 if dtype == np.float64 else 2e-4
+    for s, n in enumerate(sizes):
+        sl = slice(off, off + n)
+        ref = O.ewald_reciprocal_space(pos[sl].astype(np.float64), q[sl].astype(np.float64), cell[s].astype(np.float64),
+                                       kvs[s].cpu().numpy().astype(np.float64), float(alpha[s]))
+        for a, b, what in zip(out, ref, ("energies", "forces", "charge gradients")):
+            err = np.abs(a[sl].cpu().numpy().astype(np.float64) - b).max()
+            assert err <= rel * max(np.abs(b).max(), 1e-30) + (1e-12 if dtype == np.float64 else 2e-5), f"system {s} {what}: {err:.3e}"
+        off += n
