@@ -75,6 +75,11 @@ def test_d3_sweep(seed):
         okw = dict(neighbor_matrix=nm.cpu().numpy()) | (dict(neighbor_matrix_shifts=sh.cpu().numpy(), cell=cell) if periodic else {})
     else:
         nl, ptr, sh = batch_cell_list(_t(pos), cutoff, _t(cell), pb, _t(bi), return_neighbor_list=True, half_fill=half, max_neighbors=width)
+        if seed % 6 == 5:  # a randomly pruned (asymmetric) list: every kernel walks the stored entries of row i only, like the reference's
+            keep = _t(g.uniform(size=nl.shape[1]) < 0.8)
+            counts = torch.zeros(len(pos), dtype=torch.int64, device=DEV).index_add_(0, nl[0][keep].long(), torch.ones(int(keep.sum()), dtype=torch.int64, device=DEV))
+            ptr = torch.cat([torch.zeros(1, dtype=torch.int64, device=DEV), counts.cumsum(0)]).to(torch.int32)
+            nl, sh = nl[:, keep].contiguous(), sh[keep].contiguous()
         kw = dict(neighbor_list=nl, neighbor_ptr=ptr) | (dict(unit_shifts=sh, cell=_t(cell)) if periodic else {})
         okw = dict(idx_j=nl[1].cpu().numpy(), neighbor_ptr=ptr.cpu().numpy()) | (dict(unit_shifts=sh.cpu().numpy(), cell=cell) if periodic else {})
     out = dftd3(_t(pos), _t(z), d3_params=p, batch_idx=_t(bi), num_systems=nsys, compute_virial=virial, **kw, **fp, **tsm)
