@@ -27,7 +27,7 @@ SOURCES = {
     # -fno-slp-vectorize: the SLP pass fuses adjacent fp32 FMAs into v_pk_fma_f32, which on gfx950 issues as two passes (no gain) and
     # costs v_mov's to pair the operands -- the energy pass is VALU-issue-bound
     "d3.hip": ["-fno-hip-fp32-correctly-rounded-divide-sqrt", "-fno-slp-vectorize"] + os.environ.get("MI_D3_EXTRA_FLAGS", "").split(),
-    "ewald.hip": [],
+    "ewald.hip": os.environ.get("MI_EWALD_EXTRA_FLAGS", "").split(),
     "pme.hip": [],
 }
 COMMON = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]

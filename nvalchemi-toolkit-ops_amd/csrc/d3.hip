@@ -125,7 +125,12 @@ __device__ __forceinline__ D3Step d3_fetch(const int* __restrict__ idx, const In
   s.in = e < end;
   s.j = 0;
   s.sh = Int3{0, 0, 0};
-  if (s.in) { s.j = idx[e]; if (periodic) s.sh = ush3[e]; }
+  if (s.in) {
+    // the caller's list is streamed once per pass while the atom records are gathered over and over: non-temporal loads keep the stream
+    // from evicting the records (d3_cn 1.18 -> 1.115 ms on the headline list, same-box A/B profiles/r02_ab_nt.log)
+    s.j = __builtin_nontemporal_load(idx + e);
+    if (periodic) { const int* u = reinterpret_cast<const int*>(ush3 + e); s.sh = Int3{__builtin_nontemporal_load(u), __builtin_nontemporal_load(u + 1), __builtin_nontemporal_load(u + 2)}; }
+  }
   return s;
 }
 // Packed copy of a periodic padded list, written by the CN pass for the two passes after it: 4 B per slot instead of 16
@@ -227,7 +232,9 @@ __device__ __forceinline__ void d3_row(int i, int M, const int* __restrict__ npt
 // neighbours in nearly the same order.  One barrier per trip keeps them within a trip of each other, so the cache lines one
 // wave's gather brings into the CU's L1 serve the others (probe on the 40-Bohr list: 0.95 -> 0.80 ms for the cn walk; the
 // gather, not the list stream, is what bounds these passes -- DESIGN.md 3.2).  All waves run the block's maximum trip count.
+#ifndef D3_LS_WAVES
 #define D3_LS_WAVES 8
+#endif
 __device__ __forceinline__ int d3_lockstep_trips(long long beg, long long end) {
   __shared__ int trips_sh[D3_LS_WAVES];
   const int w = threadIdx.x / MI_WAVE;

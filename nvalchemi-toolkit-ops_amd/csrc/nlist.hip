@@ -242,8 +242,10 @@ __device__ __forceinline__ void wave_fill(int* __restrict__ dst, long long begin
   if (lane < head) p[lane] = value;
   long long body = (n - head) >> 2;
   int4* p4 = reinterpret_cast<int4*>(p + head);
-  const int4 v4 = make_int4(value, value, value, value);
-  for (long long t = lane; t < body; t += MI_WAVE) p4[t] = v4;
+  // padding is never read back by this library: non-temporal stores (ref-nlist 524 288 atoms, 78 % padding: 1.09 -> 1.01 ms)
+  typedef int nl_i4 __attribute__((ext_vector_type(4)));
+  const nl_i4 w4 = {value, value, value, value};
+  for (long long t = lane; t < body; t += MI_WAVE) __builtin_nontemporal_store(w4, reinterpret_cast<nl_i4*>(p4 + t));
   long long done = head + (body << 2);
   if (done + lane < n) p[done + lane] = value;
 }
@@ -452,6 +454,8 @@ __global__ __launch_bounds__(256) void nl_query_tiled_kernel(
               const int slot = cnt[u] + __popcll(mask & lt);
               if (MODE == MI_NL_MODE_MATRIX) {
                 if (hit && slot < cap_row[u]) {
+                  // (plain stores: the hits of a row arrive in short runs that the L2 merges into full lines; non-temporal stores here
+                  // cost +20-60 % on the headline list, profiles/r02_ab_nt.log)
                   nm[out_base[u] + slot] = j;
                   if (nsh) reinterpret_cast<NlInt3*>(nsh)[out_base[u] + slot] = NlInt3{Sx, Sy, Sz};
                 }
