@@ -120,16 +120,24 @@ __device__ __forceinline__ PairGeom<T> d3_geom(const V4& pj, T pix, T piy, T piz
 
 // One step of a row walk: neighbour index + unit shift of 64 consecutive entries (one per lane).
 struct D3Step { int j; Int3 sh; bool in; };
+// NT: non-temporal loads.  The caller's list is streamed once per pass while the 1.6 MB of atom records are gathered over and over; with the
+// hint the stream does not evict the records (headline list, 4.1 GB: d3_cn 1.18 -> 1.115 ms, same-box A/B profiles/r02_ab_nt.log).  A list
+// of about the size of the 256 MB Infinity Cache is better left in it: the reference's 54 000-atom configuration (1.0 GB list) LOSES 14 %
+// with the hint (0.685 -> 0.785 ms), 85 750 atoms (1.65 GB) is neutral -- mi_d3 picks the CN-pass instantiation by list size (> 2 GB).
+template <bool NT>
 __device__ __forceinline__ D3Step d3_fetch(const int* __restrict__ idx, const Int3* __restrict__ ush3, long long e, long long end, bool periodic) {
   D3Step s;
   s.in = e < end;
   s.j = 0;
   s.sh = Int3{0, 0, 0};
   if (s.in) {
-    // the caller's list is streamed once per pass while the atom records are gathered over and over: non-temporal loads keep the stream
-    // from evicting the records (d3_cn 1.18 -> 1.115 ms on the headline list, same-box A/B profiles/r02_ab_nt.log)
-    s.j = __builtin_nontemporal_load(idx + e);
-    if (periodic) { const int* u = reinterpret_cast<const int*>(ush3 + e); s.sh = Int3{__builtin_nontemporal_load(u), __builtin_nontemporal_load(u + 1), __builtin_nontemporal_load(u + 2)}; }
+    if constexpr (NT) {
+      s.j = __builtin_nontemporal_load(idx + e);
+      if (periodic) { const int* u = reinterpret_cast<const int*>(ush3 + e); s.sh = Int3{__builtin_nontemporal_load(u), __builtin_nontemporal_load(u + 1), __builtin_nontemporal_load(u + 2)}; }
+    } else {
+      s.j = idx[e];
+      if (periodic) s.sh = ush3[e];
+    }
   }
   return s;
 }
@@ -154,7 +162,7 @@ __device__ __forceinline__ D3Step d3_fetch_any(const int* __restrict__ idx, cons
   if constexpr (PK) {
     if (use_pk) return d3_fetch_pk(pk, e, end);
   }
-  return d3_fetch(idx, ush3, e, end, periodic);
+  return d3_fetch<false>(idx, ush3, e, end, periodic);
 }
 // Energy pass: its packed-list steps stay ONE register (the raw word) while they wait in the software pipeline and are decoded where
 // they are used -- the decoded form (index + three shift ints + flag) in three pipeline stages was 10 loop-carried VGPRs, and
@@ -183,7 +191,7 @@ __device__ __forceinline__ D3Lazy<PK> d3_fetch_lazy(const int* __restrict__ idx,
                                                     long long e, long long end, bool periodic) {
   D3Lazy<PK> l;
   if constexpr (PK) l.w = e < end ? __builtin_nontemporal_load(pk + e) : D3_PK_INVALID;
-  else l.s = d3_fetch(idx, ush3, e, end, periodic);
+  else l.s = d3_fetch<false>(idx, ush3, e, end, periodic);
   return l;
 }
 // The row walks below are software-pipelined three deep: while step k is evaluated, the per-atom records of step k+1 are
@@ -233,7 +241,9 @@ __device__ __forceinline__ void d3_row(int i, int M, const int* __restrict__ npt
 // wave's gather brings into the CU's L1 serve the others (probe on the 40-Bohr list: 0.95 -> 0.80 ms for the cn walk; the
 // gather, not the list stream, is what bounds these passes -- DESIGN.md 3.2).  All waves run the block's maximum trip count.
 #ifndef D3_LS_WAVES
+#ifndef D3_LS_WAVES
 #define D3_LS_WAVES 8
+#endif
 #endif
 __device__ __forceinline__ int d3_lockstep_trips(long long beg, long long end) {
   __shared__ int trips_sh[D3_LS_WAVES];
@@ -253,7 +263,7 @@ __device__ __forceinline__ int d3_lockstep_trips(long long beg, long long end) {
 #ifndef D3_CN_DG
 #define D3_CN_DG 1  // trips of gathered atom records in flight (<= D3_CN_DS)
 #endif
-template <class T, bool CSR>
+template <class T, bool CSR, bool BIG>  // BIG: the caller's list is far larger than the Infinity Cache -> streamed with non-temporal loads
 __global__ __launch_bounds__(D3_LS_WAVES * MI_WAVE) void d3_cn_kernel(const T* __restrict__ pos, const int* __restrict__ numbers, int N, const int* __restrict__ idx,
                                                     const int* __restrict__ ush, const int* __restrict__ nptr, int M, int fill_value,
                                                     const T* __restrict__ cell, const int* __restrict__ batch_idx, D3Dev P,
@@ -285,12 +295,12 @@ __global__ __launch_bounds__(D3_LS_WAVES * MI_WAVE) void d3_cn_kernel(const T* _
   bool v[D3_CN_DG + 1];
   typename Vec4<T>::type p[D3_CN_DG + 1];
 #pragma unroll
-  for (int k = 0; k < D3_CN_DS; ++k) s[k] = d3_fetch(idx, ush3, e + (long long)k * MI_WAVE, end, periodic);
+  for (int k = 0; k < D3_CN_DS; ++k) s[k] = d3_fetch<BIG>(idx, ush3, e + (long long)k * MI_WAVE, end, periodic);
 #pragma unroll
   for (int k = 0; k < D3_CN_DG; ++k) { v[k] = s[k].in && ((unsigned)s[k].j < jlim); p[k] = apos[v[k] ? s[k].j : i]; }
   for (int trip = 0; trip < trips; ++trip) {
     __syncthreads();  // lock-step: the block's waves walk rows of consecutive atoms, i.e. nearly the same neighbours in nearly the same order
-    s[D3_CN_DS] = d3_fetch(idx, ush3, e + (long long)D3_CN_DS * MI_WAVE, end, periodic);
+    s[D3_CN_DS] = d3_fetch<BIG>(idx, ush3, e + (long long)D3_CN_DS * MI_WAVE, end, periodic);
     v[D3_CN_DG] = s[D3_CN_DG].in && ((unsigned)s[D3_CN_DG].j < jlim);
     p[D3_CN_DG] = apos[v[D3_CN_DG] ? s[D3_CN_DG].j : i];
     const D3Step s0 = s[0];
@@ -926,7 +936,7 @@ D3Layout d3_layout(int N, int nz, int dtype, int B) {
 template <class T, bool CSR>
 int d3_impl(const T* pos, const int* numbers, int N, const int* idx, const int* ush, const int* nptr, int M, int fill_value, const T* cell,
             const int* batch_idx, int B, const mi_d3_params* hp, int want_virial, float* energy, float* forces, float* cn, float* virial,
-            char* ws, const D3Layout& L, unsigned* pk, hipStream_t st) {
+            char* ws, const D3Layout& L, unsigned* pk, long long n_entries, hipStream_t st) {
   // `pk` (optional, [N*M] words + one flag word in front): packed copy of a periodic padded list, see d3_fetch_pk
   int* pk_flag = nullptr;
   if (pk) { pk_flag = reinterpret_cast<int*>(pk); pk += 64; MI_HIP_CHECK(hipMemsetAsync(pk_flag, 0, sizeof(int), st)); }
@@ -962,7 +972,11 @@ int d3_impl(const T* pos, const int* numbers, int N, const int* idx, const int* 
                                                              want_virial ? v_atom : nullptr);
   MI_LAUNCH_CHECK();
   const int blocks = mi_blocks(N, 4);
-  MI_TIMED("d3_cn", st, (d3_cn_kernel<T, CSR><<<mi_blocks(N, D3_LS_WAVES), D3_LS_WAVES * MI_WAVE, 0, st>>>(pos, numbers, N, idx, ush, nptr, M, fill_value, cell, batch_idx, P, apos, aaux, cn, pk, pk_flag)));
+  if ((double)n_entries * ((cell && ush) ? 16.0 : 4.0) > 2.0e9) {  // list bytes (see d3_fetch)
+    MI_TIMED("d3_cn", st, (d3_cn_kernel<T, CSR, true><<<mi_blocks(N, D3_LS_WAVES), D3_LS_WAVES * MI_WAVE, 0, st>>>(pos, numbers, N, idx, ush, nptr, M, fill_value, cell, batch_idx, P, apos, aaux, cn, pk, pk_flag)));
+  } else {
+    MI_TIMED("d3_cn", st, (d3_cn_kernel<T, CSR, false><<<mi_blocks(N, D3_LS_WAVES), D3_LS_WAVES * MI_WAVE, 0, st>>>(pos, numbers, N, idx, ush, nptr, M, fill_value, cell, batch_idx, P, apos, aaux, cn, pk, pk_flag)));
+  }
   MI_LAUNCH_CHECK();
   d3_weights_kernel<<<mi_blocks(N, 256), 256, 0, st>>>(cn, aaux, sinfo, fcr, hp->k3, N,
                                                        sizeof(T) == 4 ? reinterpret_cast<const float4*>(apos) : nullptr, aw);
@@ -1056,7 +1070,7 @@ int mi_d3(const void* positions, const int32_t* numbers, int n_atoms, int dtype,
     pk = reinterpret_cast<unsigned*>((char*)workspace + ((mi_d3_workspace_bytes(n_atoms, n_systems, params->nz) + 255) & ~(size_t)255));
 #define MI_D3_CALL(T_, CSR_)                                                                                                              \
   return d3_impl<T_, CSR_>((const T_*)positions, numbers, n_atoms, idx_j, unit_shifts, neighbor_ptr, max_neighbors, fill_value, (const T_*)cell, \
-                           batch_idx, n_systems, params, compute_virial, energy, forces, coord_num, virial, (char*)workspace, L, pk, st)
+                           batch_idx, n_systems, params, compute_virial, energy, forces, coord_num, virial, (char*)workspace, L, pk, n_entries, st)
   if (dtype == MI_F32) { if (csr) MI_D3_CALL(float, true); else MI_D3_CALL(float, false); }
   else { if (csr) MI_D3_CALL(double, true); else MI_D3_CALL(double, false); }
 #undef MI_D3_CALL

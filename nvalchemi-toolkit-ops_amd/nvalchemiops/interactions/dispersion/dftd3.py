@@ -99,7 +99,7 @@ def _launch(positions, numbers, idx, shifts, nptr, max_neighbors, fill_value, ce
     vir = virial if compute_virial else None
     z = C.i32(numbers)  # converted tensors stay referenced until the launch is enqueued (the allocator may otherwise reuse their blocks)
     rc = L.mi_d3(C.ptr(pos), C.ptr(z), n, code, C.ptr(idx), C.ptr(sh), C.ptr(nptr), int(max_neighbors),
-                 ctypes.c_longlong(idx.shape[0] if (nptr is not None and pack) else 0), int(fill_value),
+                 ctypes.c_longlong(idx.shape[0] if nptr is not None else 0), int(fill_value),  # CSR: the entry count (packing is decided by the workspace size)
                  C.ptr(cell_t), C.ptr(bi), int(num_systems), ctypes.byref(par), int(bool(compute_virial)), C.ptr(energy), C.ptr(forces),
                  C.ptr(coord_num), C.ptr(vir), C.ptr(ws), ctypes.c_size_t(ws_bytes), C.stream_of(pos))
     if rc != 0 and _LIB_OVERRIDE is not None:
