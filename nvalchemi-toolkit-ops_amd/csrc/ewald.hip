@@ -94,13 +94,13 @@ __global__ __launch_bounds__(256) void ewald_real_kernel(const T* __restrict__ p
   T fx = 0, fy = 0, fz = 0;
   unsigned long long hf = 0, hr = 0;
   for (long long e = beg + lane; e < end; e += MI_WAVE) {
-    const int j = __builtin_nontemporal_load(idx + e);  // the list is streamed once; the records it points at are gathered repeatedly
+    const int j = idx[e];
     if ((!CSR && j == mask_value) || (unsigned)j >= (unsigned)N) continue;  // out-of-range indices (e.g. -1 padding with another mask_value) are padding
     T pjx, pjy, pjz;
     double qj;
     if (REC) { const typename Vec4<T>::type r = rec[j]; pjx = r.x; pjy = r.y; pjz = r.z; qj = (double)r.w; }
     else { pjx = pos[3 * (size_t)j]; pjy = pos[3 * (size_t)j + 1]; pjz = pos[3 * (size_t)j + 2]; qj = (double)q[j]; }
-    const int S0 = __builtin_nontemporal_load(ush + 3 * e), S1 = __builtin_nontemporal_load(ush + 3 * e + 1), S2 = __builtin_nontemporal_load(ush + 3 * e + 2);
+    const int S0 = ush[3 * e], S1 = ush[3 * e + 1], S2 = ush[3 * e + 2];
     if (sym) { hf += ew_entry_hash((unsigned)i, (unsigned)j, S0, S1, S2); hr += ew_entry_hash((unsigned)j, (unsigned)i, -S0, -S1, -S2); }
     const T fs[3] = {(T)S0, (T)S1, (T)S2};
     T sh[3];
