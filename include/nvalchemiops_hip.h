@@ -309,7 +309,8 @@ int mi_spline_spread_grad(const void* positions, const void* vec /*[n_atoms,3]*/
 /* ---- PME reciprocal-space mesh kernels ------------------------------------------------------
  * mi_pme_green_sf: alchemiops::_[batch_]pme_green_structure_factor (pme.py:273-553, pme_kernels.py:121-331)
  * mi_pme_convolve: the torch elementwise block of _pme_reciprocal_space_impl (pme.py:1418-1419,1455-1457):
- *   conv = spec / sf2 * G ; E_d = -i k_d conv, fused into one pass that writes 1 or 4 spectra.
+ *   conv = spec / sf2 * G ; E_d = -i k_d conv, fused into one pass that writes 1 or 4 spectra.  k and k^2 are evaluated in registers
+ *   from recip_cell unless the caller's precomputed arrays are passed (pme_reciprocal_space(k_vectors=, k_squared=), pme.py:1386-1392).
  *   `sf_exponent` in both: power of the sinc product before squaring -- the reference uses min(order, 4)
  *   (pme_kernels.py:213-225); this build passes `order` for its true order-5/6 splines.
  * mi_pme_gather_finish: spline_gather + pme_energy_corrections[_with_charge_grad] + gather_vec3 + "x2"
@@ -322,7 +323,9 @@ int mi_pme_green_sf(const void* k_squared /*[B,nx,ny,nzr]*/, const void* alpha /
                     void* sf_sq /*[nx,ny,nzr]*/, void* stream);
 int mi_pme_convolve(const void* spec /*complex [B,nx,ny,nzr]*/, const void* recip_cell /*[B,3,3] = 2pi inv(cell)*/,
                     const void* alpha /*[B]*/, const void* volume /*[B]*/, int n_systems, int nx, int ny, int nz,
-                    int sf_exponent, int with_field, int dtype, void* out /*complex [B,(1|4),nx,ny,nzr]*/, void* stream);
+                    int sf_exponent, int with_field, int dtype,
+                    const void* k_vectors /*[(B,)nx,ny,nzr,3] or NULL*/, const void* k_squared /*[(B,)nx,ny,nzr] or NULL*/,
+                    int k_batched /*the k arrays carry a leading system dimension*/, void* out /*complex [B,(1|4),nx,ny,nzr]*/, void* stream);
 int mi_pme_gather_finish(const void* positions, const void* charges, const int32_t* batch_idx, const void* cell_inv_t,
                          const void* meshes /*[B,(1|4),nx,ny,nz] real*/, const void* alpha, const void* volume,
                          const void* total_charge /*[B]*/, int n_atoms, int n_systems, int nx, int ny, int nz,

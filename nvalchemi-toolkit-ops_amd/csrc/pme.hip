@@ -575,7 +575,7 @@ template <class T> struct Cplx { T re, im; };
 template <class T>
 __global__ void pme_convolve_kernel(const Cplx<T>* __restrict__ spec, const T* __restrict__ recip, const T* __restrict__ alpha,
                                     const T* __restrict__ volume, int B, int nx, int ny, int nz, int order, int with_field,
-                                    Cplx<T>* __restrict__ out) {
+                                    const T* __restrict__ kvec_in, const T* __restrict__ k2_in, int k_batched, Cplx<T>* __restrict__ out) {
   const int nzr = nz / 2 + 1;
   const size_t per = (size_t)nx * ny * nzr;
   const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -592,6 +592,10 @@ __global__ void pme_convolve_kernel(const Cplx<T>* __restrict__ spec, const T* _
   for (int c = 0; c < 3; ++c) kv[c] = m[0] * R[3 * c] + m[1] * R[3 * c + 1] + m[2] * R[3 * c + 2];
   T k2 = kv[0] * kv[0] + kv[1] * kv[1] + kv[2] * kv[2];
   if (!(k2 > T(1e-12))) k2 = T(1e-12);
+  // caller-supplied k arrays (pme_reciprocal_space(k_vectors=, k_squared=), pme.py:1386-1392): read instead of evaluated, wave-uniform tests
+  const size_t kidx = (k_batched ? (size_t)b * per : 0) + r;
+  if (k2_in) k2 = k2_in[kidx];
+  if (kvec_in && with_field) { kv[0] = kvec_in[3 * kidx]; kv[1] = kvec_in[3 * kidx + 1]; kv[2] = kvec_in[3 * kidx + 2]; }
   const T G = green_of(k2, alpha[b], volume[b], i == 0 && j == 0 && k == 0);
   const T sf2 = sf_sq_of<T>(mx, my, mz, nx, ny, nz, order);
   const Cplx<T> v = spec[g];
@@ -821,7 +825,7 @@ int mi_pme_green_sf(const void* k_squared, const void* alpha, const void* volume
 }
 
 int mi_pme_convolve(const void* spec, const void* recip_cell, const void* alpha, const void* volume, int n_systems, int nx, int ny, int nz, int order,
-                    int with_field, int dtype, void* out, void* stream) {
+                    int with_field, int dtype, const void* k_vectors, const void* k_squared, int k_batched, void* out, void* stream) {
   MI_REQUIRE(dtype == MI_F32 || dtype == MI_F64, "dtype");
   MI_REQUIRE(spec && recip_cell && alpha && volume && out && n_systems >= 1, "null pointer");
   const size_t tot = (size_t)nx * ny * (nz / 2 + 1) * n_systems;
@@ -829,7 +833,8 @@ int mi_pme_convolve(const void* spec, const void* recip_cell, const void* alpha,
   mi_timing_begin("pme_convolve", stream);
   MI_DISPATCH_T(dtype, (pme_convolve_kernel<T_><<<mi_blocks((long long)tot, 256), 256, 0, st>>>((const Cplx<T_>*)spec, (const T_*)recip_cell,
                                                                                                 (const T_*)alpha, (const T_*)volume, n_systems, nx,
-                                                                                                ny, nz, order, with_field, (Cplx<T_>*)out)));
+                                                                                                ny, nz, order, with_field, (const T_*)k_vectors,
+                                                                                                (const T_*)k_squared, k_batched, (Cplx<T_>*)out)));
   mi_timing_end(stream);
   MI_LAUNCH_CHECK();
   return MI_OK;

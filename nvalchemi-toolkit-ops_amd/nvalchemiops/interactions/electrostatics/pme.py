@@ -155,7 +155,8 @@ def pme_energy_corrections_with_charge_grad(raw_energies, charges, cell, alpha, 
     return _corrections(raw_energies, charges, cell, alpha, batch_idx, True)
 
 
-def _reciprocal_fused(pos, q, cells, alpha, mesh_dimensions, spline_order, bi, compute_forces, compute_charge_gradients, add=(None, None, None)):
+def _reciprocal_fused(pos, q, cells, alpha, mesh_dimensions, spline_order, bi, compute_forces, compute_charge_gradients, add=(None, None, None),
+                      k_vectors=None, k_squared=None):
     """The MI355X path: k-space algebra and the gather epilogue fused (k evaluated in registers).  `add` = (float64 energies, forces,
     float64 charge gradients) of the real-space sum, added in the gather epilogue (particle_mesh_ewald's `real + reciprocal`)."""
     dt, dev = pos.dtype, pos.device
@@ -177,8 +178,15 @@ def _reciprocal_fused(pos, q, cells, alpha, mesh_dimensions, spline_order, bi, c
     spec = torch.fft.rfftn(mesh, norm="backward", dim=(1, 2, 3))  # unscaled forward (pme.py:1398)
     nch = 4 if compute_forces else 1
     conv = torch.empty((nsys, nch, nx, ny, nz // 2 + 1), dtype=spec.dtype, device=dev)
+    # caller-supplied k arrays are READ by the same kernel instead of being evaluated in registers (the reference's benchmark protocol
+    # passes them precomputed); [nx,ny,nzr(,3)] shared by all systems or with a leading batch dimension
+    kv = k2 = None
+    if k_squared is not None:
+        k2 = k_squared.detach().to(dt).contiguous()
+        kv = k_vectors.detach().to(dt).contiguous() if (k_vectors is not None and compute_forces) else None
+    k_batched = int(k2 is not None and k2.dim() == 4 and k2.shape[0] == nsys and nsys > 1)
     rc = C.lib().mi_pme_convolve(C.ptr(spec), C.ptr(recip), C.ptr(al), C.ptr(vol), nsys, nx, ny, nz, int(spline_order), int(compute_forces), code,
-                                 C.ptr(conv), st)
+                                 C.ptr(kv), C.ptr(k2), k_batched, C.ptr(conv), st)
     C.check(rc, "mi_pme_convolve")
     real = torch.fft.irfftn(conv, norm="forward", s=(nx, ny, nz), dim=(2, 3, 4)).contiguous()  # unscaled inverse (pme.py:1422)
     energies = torch.empty(n, dtype=dt, device=dev)
@@ -189,31 +197,6 @@ def _reciprocal_fused(pos, q, cells, alpha, mesh_dimensions, spline_order, bi, c
                                       ny, nz, int(spline_order), int(compute_forces), code, C.ptr(energies), C.ptr(forces), C.ptr(cgrads),
                                       C.ptr(add_e), C.ptr(add_f if compute_forces else None), C.ptr(add_cg if compute_charge_gradients else None), st)
     C.check(rc, "mi_pme_gather_finish")
-    return energies, forces, cgrads
-
-
-def _reciprocal_with_kvectors(pos, q, cells, alpha, mesh_dimensions, spline_order, bi, compute_forces, compute_charge_gradients, k_vectors,
-                              k_squared):
-    """Caller-supplied k arrays: the reference's composition step by step (pme.py:1338-1479) on the HIP building blocks."""
-    batched = bi is not None
-    fft_dims = (1, 2, 3) if batched else (0, 1, 2)
-    cell_for_ops = cells if batched else cells[0]
-    cit = torch.linalg.inv_ex(cells)[0].transpose(-1, -2).contiguous()
-    mesh = spline_spread(pos, q, cell_for_ops, mesh_dimensions, spline_order, bi, cit)
-    spec = torch.fft.rfftn(mesh, norm="backward", dim=fft_dims)
-    green, sf2 = pme_green_structure_factor(k_squared, mesh_dimensions, alpha, cells, spline_order, batch_idx=bi)
-    conv = (spec / sf2) * green
-    phi = torch.fft.irfftn(conv, norm="forward", s=mesh_dimensions, dim=fft_dims).to(pos.dtype)
-    raw = spline_gather(pos, phi, cell_for_ops, spline_order, bi, cit)
-    if compute_charge_gradients:
-        energies, cgrads = pme_energy_corrections_with_charge_grad(raw, q, cells, alpha, bi)
-    else:
-        energies, cgrads = pme_energy_corrections(raw, q, cells, alpha, bi), None
-    forces = None
-    if compute_forces:
-        comps = [torch.fft.irfftn(-1j * k_vectors[..., d] * conv, norm="forward", s=mesh_dimensions, dim=fft_dims) for d in range(3)]
-        field = torch.stack(comps, dim=-1).to(pos.dtype)
-        forces = 2.0 * spline_gather_vec3(pos, q, field, cell_for_ops, spline_order, bi, cit)
     return energies, forces, cgrads
 
 
@@ -312,10 +295,8 @@ def pme_reciprocal_space(positions: torch.Tensor, charges: torch.Tensor, cell: t
             q = charges.detach().to(dt).contiguous()
             cells_t = cells.detach().to(dt).contiguous()
             args = (pos, q, cells_t, alpha_t, mesh_dimensions, spline_order, bi, compute_forces, compute_charge_gradients)
-            if k_vectors is None or k_squared is None:
-                energies, forces, cgrads = _reciprocal_fused(*args)
-            else:
-                energies, forces, cgrads = _reciprocal_with_kvectors(*args, k_vectors, k_squared)
+            have_k = k_vectors is not None and k_squared is not None
+            energies, forces, cgrads = _reciprocal_fused(*args, k_vectors=k_vectors if have_k else None, k_squared=k_squared if have_k else None)
     if compute_forces and compute_charge_gradients:
         return energies, forces, cgrads
     if compute_forces:
