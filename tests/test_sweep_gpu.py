@@ -298,3 +298,49 @@ def test_explicit_k_ewald_sweep(seed):
             err = np.abs(a[sl].cpu().numpy().astype(np.float64) - b).max()
             assert err <= rel * max(np.abs(b).max(), 1e-30) + (1e-12 if dtype == np.float64 else 2e-5), f"system {s} {what}: {err:.3e}"
         off += n
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_cell_cache_and_rebuild_sweep(seed):
+    """build_cell_list / batch_build_cell_list cache tensors (every element) and the two rebuild checks against the oracle's restatements, on
+    random sheared cells with atoms outside the cell, random pbc flags, fp32 / fp64, single systems and batches, cutoffs from a fraction of
+    the box to several boxes (the <= 1000-cell halving rule of the reference's estimate)."""
+    from nvalchemiops.neighborlist import (allocate_cell_list, build_cell_list, cell_list_needs_rebuild, estimate_cell_list_sizes,
+                                           neighbor_list_needs_rebuild)
+    from nvalchemiops.neighborlist.batch_cell_list import batch_build_cell_list, estimate_batch_cell_list_sizes
+
+    g = np.random.default_rng(8000 + seed)
+    dtype = np.float64 if seed % 2 else np.float32
+    batched = seed % 3 == 2
+    nsys = int(g.integers(2, 4)) if batched else 1
+    parts, cells, pbcs, bis = [], [], [], []
+    for s in range(nsys):
+        n = int(g.choice([3, 40, 300, 1200]))
+        box = float(g.uniform(6.0, 30.0))
+        cell = np.diag(g.uniform(0.8, 1.2, 3) * box)
+        if g.uniform() < 0.6:
+            cell[1, 0], cell[2, 0], cell[2, 1] = g.uniform(-0.3, 0.3, 3) * box
+        parts.append((g.uniform(-0.3, 1.3, (n, 3)) @ cell).astype(dtype)), cells.append(cell.astype(dtype))
+        pbcs.append(g.uniform(size=3) < 0.7), bis.append(np.full(n, s, np.int32))
+    pos, cell, pbc, bi = np.concatenate(parts), np.stack(cells), np.array(pbcs), np.concatenate(bis)
+    n = len(pos)
+    cutoff = float(g.choice([0.9, 2.5, 6.0]))
+    if batched:
+        ncell, radius = estimate_batch_cell_list_sizes(_t(cell), _t(pbc), cutoff)
+        cache = allocate_cell_list(n, ncell, radius, torch.device(DEV))
+        batch_build_cell_list(_t(pos), cutoff, _t(cell), _t(pbc), _t(bi), *cache)
+        want = O.build_cell_cache(pos, cutoff, cell, pbc, ncell, batch_idx=bi)
+    else:
+        ncell, radius = estimate_cell_list_sizes(_t(cell[0]), _t(pbc[0]), cutoff)
+        cache = allocate_cell_list(n, ncell, radius, torch.device(DEV))
+        build_cell_list(_t(pos), cutoff, _t(cell[0]), _t(pbc[0]), *cache)
+        want = O.build_cell_cache(pos, cutoff, cell[0], pbc[0], ncell)
+    names = ("cells_per_dimension", "atom_periodic_shifts", "atom_to_cell_mapping", "atoms_per_cell_count", "cell_atom_start_indices", "cell_atom_list")
+    for got, ref, what in zip((cache[0],) + tuple(cache[2:]), want, names):
+        assert np.array_equal(got.cpu().numpy().reshape(ref.shape), ref), what
+    if not batched:  # the checks of rebuild_detection.py are single-system
+        for sigma in (0.005, 0.08, 0.6):
+            disp = (pos + g.normal(0, sigma, pos.shape)).astype(dtype)
+            assert bool(cell_list_needs_rebuild(_t(disp), cache[3], cache[0], _t(cell[0]), _t(pbc[0]))) == O.cells_changed(disp, cell[0], want[2], want[0], pbc[0]), sigma
+            for skin in (0.01, 0.15, 1.0):
+                assert bool(neighbor_list_needs_rebuild(_t(pos), _t(disp), skin)) == O.moved_beyond_skin(pos, disp, skin), (sigma, skin)
