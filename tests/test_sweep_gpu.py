@@ -344,3 +344,39 @@ def test_cell_cache_and_rebuild_sweep(seed):
             assert bool(cell_list_needs_rebuild(_t(disp), cache[3], cache[0], _t(cell[0]), _t(pbc[0]))) == O.cells_changed(disp, cell[0], want[2], want[0], pbc[0]), sigma
             for skin in (0.01, 0.15, 1.0):
                 assert bool(neighbor_list_needs_rebuild(_t(pos), _t(disp), skin)) == O.moved_beyond_skin(pos, disp, skin), (sigma, skin)
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_matrix_to_list_conversion_sweep(seed):
+    """get_neighbor_list_from_neighbor_matrix on random padded matrices (random row fill, padding value N or -1 with the matching fill_value,
+    with and without shifts): the list is what `matrix != fill_value` selects in row-major order, neighbor_ptr the cumsum of the given counts
+    (neighbor_utils.py:362-470), and it equals the direct CSR output of the search on real geometry."""
+    from nvalchemiops.neighborlist import cell_list
+    from nvalchemiops.neighborlist.neighbor_utils import get_neighbor_list_from_neighbor_matrix
+
+    g = np.random.default_rng(9000 + seed)
+    n, m = int(g.choice([1, 13, 200, 1500])), int(g.choice([1, 7, 64, 200]))
+    fv = n if seed % 2 == 0 else -1
+    counts = g.integers(0, m + 1, n).astype(np.int32)
+    nm = np.full((n, m), fv, np.int32)
+    sh = np.zeros((n, m, 3), np.int32)
+    for i in range(n):
+        nm[i, :counts[i]] = g.integers(0, n, counts[i])
+        sh[i, :counts[i]] = g.integers(-2, 3, (counts[i], 3))
+    with_shifts = seed % 3 != 0
+    out = get_neighbor_list_from_neighbor_matrix(_t(nm), num_neighbors=_t(counts), neighbor_shift_matrix=_t(sh) if with_shifts else None, fill_value=fv)
+    rows, cols = np.nonzero(nm != fv)
+    assert np.array_equal(out[0].cpu().numpy(), np.stack([rows, nm[rows, cols]]).astype(np.int32))
+    assert np.array_equal(out[1].cpu().numpy(), np.concatenate([[0], np.cumsum(counts)]).astype(np.int32))
+    if with_shifts:
+        assert len(out) == 3 and np.array_equal(out[2].cpu().numpy(), sh[rows, cols])
+    else:
+        assert len(out) == 2
+    # on real geometry: matrix -> list == the direct two-pass CSR search
+    pos, cell, pbc, _ = _random_batch(g, np.float32, True, [int(g.choice([50, 400]))], scale=1.0)
+    geo = (_t(pos), 4.0, _t(cell[0]), _t(pbc[0]))
+    a, b, c = cell_list(*geo, max_neighbors=512)
+    via = get_neighbor_list_from_neighbor_matrix(a, num_neighbors=b, neighbor_shift_matrix=c, fill_value=len(pos))
+    direct = cell_list(*geo, return_neighbor_list=True)
+    for x, y in zip(via, direct):
+        assert torch.equal(x, y)
