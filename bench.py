@@ -65,11 +65,10 @@ D3 = dict(cutoff=40.0, a1=0.4289, a2=4.4407, s8=0.7875, max_neighbors=2560)  # r
 
 
 def build_system(n_atoms: int, seed: int, device):
-    from oracle import oracle as O  # only the analytic table generator (pure numpy) is used here, not the oracle kernels
-    from tests import systems as S
+    from tests import systems as S  # input generators only; the oracle is imported by cpu_baseline() alone
 
     pos, cell, q, numbers = S.fcc_box(n_atoms, seed=seed, dtype=np.float64)
-    tables = O.d3_test_tables(94, seed=7)
+    tables = S.d3_test_tables(94, seed=7)
     t = lambda a, dt=None: torch.as_tensor(np.ascontiguousarray(a), dtype=dt, device=device)  # noqa: E731
     sysd = dict(
         n=n_atoms, pos64=t(pos), cell64=t(cell), q64=t(q), numbers=t(numbers),
@@ -84,7 +83,6 @@ def build_batch(n_systems: int, atoms_each: int, seed: int, device, first_system
     """BASELINE config 5 shard: `n_systems` independent periodic boxes of `atoms_each` atoms (a = 4 A FCC, L = 32 A for 2000), systems
     [first_system, first_system + n_systems) of the global batch (the jitter seed is a function of the GLOBAL system id, so the shards of
     an N-rank run are the slices of the single-rank batch)."""
-    from oracle import oracle as O
     from tests import systems as S
 
     parts = [S.fcc_box(atoms_each, seed=seed + 17 * (first_system + b), dtype=np.float64) for b in range(n_systems)]
@@ -93,7 +91,7 @@ def build_batch(n_systems: int, atoms_each: int, seed: int, device, first_system
     q = np.concatenate([p[2] for p in parts])
     numbers = np.concatenate([p[3] for p in parts])
     bi = np.repeat(np.arange(n_systems, dtype=np.int32), atoms_each)
-    tables = O.d3_test_tables(94, seed=7)
+    tables = S.d3_test_tables(94, seed=7)
     t = lambda a, dt=None: torch.as_tensor(np.ascontiguousarray(a), dtype=dt, device=device)  # noqa: E731
     sysd = dict(n=len(pos), nsys=n_systems, pos64=t(pos), cell64=t(cell), q64=t(q), numbers=t(numbers), bi=t(bi),
                 pos32b=t((pos * BOHR).astype(np.float32)), cell32b=t((cell * BOHR).astype(np.float32)),
@@ -402,6 +400,42 @@ def roofline_of(rows):
     return out
 
 
+# ---- in-run HBM calibration (make a slow box distinguishable from a slow build) -------------------------------------------
+def hbm_calibration(device, gib: float = 4.0, reps: int = 5):
+    """Copy and fill rates of THIS box, measured right before the timed region with the library's plain 16-byte-per-lane kernels
+    (csrc/calib.hip) over `gib` GiB: `copy_GBps` counts read + written bytes, `fill_GBps` written bytes (median of `reps`)."""
+    from nvalchemiops import _capi as C
+
+    nbytes = int(gib * (1 << 30)) // 16 * 16
+    src = torch.empty(nbytes, dtype=torch.uint8, device=device)
+    dst = torch.empty(nbytes, dtype=torch.uint8, device=device)
+    src.zero_()
+    st = C.stream_of(src)
+    L = C.lib()
+
+    def med(fn):
+        fn()
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(reps):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            fn()
+            b.record()
+            b.synchronize()
+            ts.append(a.elapsed_time(b))
+        return statistics.median(ts)
+
+    sink = torch.zeros(1, dtype=torch.float32, device=device)
+    t_copy = med(lambda: C.check(L.mi_calibrate_copy(C.ptr(src), C.ptr(dst), ctypes.c_size_t(nbytes), st), "mi_calibrate_copy"))
+    t_fill = med(lambda: C.check(L.mi_calibrate_fill(C.ptr(dst), ctypes.c_size_t(nbytes), ctypes.c_float(1.0), st), "mi_calibrate_fill"))
+    t_read = med(lambda: C.check(L.mi_calibrate_read(C.ptr(src), ctypes.c_size_t(nbytes), C.ptr(sink), st), "mi_calibrate_read"))
+    del src, dst
+    return {"copy_GBps": 2.0 * nbytes / t_copy / 1e6, "fill_GBps": nbytes / t_fill / 1e6, "read_GBps": nbytes / t_read / 1e6, "bytes": nbytes,
+            "copy_ms": t_copy, "fill_ms": t_fill, "read_ms": t_read,
+            "note": "float4 read / fill / copy streams over this many bytes on this box, before the timed region (csrc/calib.hip); copy counts read + written bytes"}
+
+
 # ---- CPU baseline (the oracle; reported, not the target) ----------------------------------------------------------------------------
 def _oracle_step(O, pos, cell, q, numbers, tables, mesh, order):
     """One full step of the oracle on host arrays, the workload of the GPU step: list 9 A (M = 256) -> PME (E + F) -> list 40 Bohr
@@ -428,7 +462,7 @@ def cpu_baseline(sample_atoms: int, full_size_1thread: bool, budget_s: float = 1
     from oracle import oracle as O
     from tests import systems as S
 
-    tables = O.d3_test_tables(94, seed=7)
+    tables = S.d3_test_tables(94, seed=7)
     pos, cell, q, numbers = S.fcc_box(sample_atoms, seed=1234, dtype=np.float64)
     edge = float(cell[0, 0])
     mesh = (int(2 * round(edge / 0.9375 / 2)),) * 3
@@ -681,6 +715,8 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
+    # this box's own HBM rates, measured before the timed region (not part of it)
+    calibration = hbm_calibration(device, gib=float(os.environ.get("BENCH_CALIB_GIB", "4"))) if os.environ.get("BENCH_CALIB", "1") != "0" else None
     for _ in range(args.warmup):
         out = step()
     barrier()
@@ -730,15 +766,23 @@ def main():
     # the bandwidth-bound kernels run beside the other stream's work, so their HIP-event durations include that contention (and
     # move when a profiler changes the overlap); the isolated figures are the ones comparable across runs and with
     # profiles/*kernel_stats*_serial.csv.  They do not enter `value`.
-    isolated = {}
-    if not graph_mode and args.workload != "c5":
+    isolated, serial_ms = {}, []
+    if not graph_mode:
         saved, OVERLAP = OVERLAP, 0
         C.lib().mi_timing_enable(1)
+        sev = []
         for _ in range(max(5, min(args.steps, 20))):
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            sev.append(e)
             step()
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        sev.append(e)
         barrier()
         C.lib().mi_timing_enable(0)
         isolated = kernel_report()
+        serial_ms = [a.elapsed_time(b) for a, b in zip(sev[:-1], sev[1:])]
         OVERLAP = saved
 
     e_pme, f_pme, e_d3, f_d3, num, nptr = out
@@ -765,7 +809,7 @@ def main():
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64 (PME) + f32 (D3)", "data": "synthetic",
             "config": {"workload": (f"{args.atoms}-atom periodic FCC box per GPU: nlist(9 A, padded M=256) + PME(alpha 0.35, mesh 128^3, "
-                                    "spline order 5, E+F, fp64) + nlist(40 Bohr, " + (f"padded M={D3['max_neighbors']}" if D3_FORMAT == "matrix" else "CSR") + ") + DFT-D3(BJ, E+F+virial, fp32)")
+                                    "spline order 5 = true B-spline (the reference evaluates order 5 as 0), E+F, fp64) + nlist(40 Bohr, " + (f"padded M={D3['max_neighbors']}" if D3_FORMAT == "matrix" else "CSR") + ") + DFT-D3(BJ, E+F+virial, fp32)")
                        if args.workload == "headline" else
                        (f"config 5: {args.systems} x 2000-atom periodic boxes per GPU (batch): nlist(9 A) + PME(mesh 32^3 per system, order 5, "
                         "fp64) + nlist(40 Bohr, " + (f"padded M={D3['max_neighbors']}" if D3_FORMAT == "matrix" else "CSR") + ") + DFT-D3(BJ), one all_gather of per-system energies"),
@@ -773,13 +817,21 @@ def main():
                        "parallelism": par, "ranks": world, "backend": backend},
             "stats": ({"step_ms_median": statistics.median(step_ms), "step_ms_min": min(step_ms), "step_ms_max": max(step_ms),
                        "value_at_median": total_atoms / statistics.median(step_ms) * 1e3, "timed_region_s": elapsed,
+                       "overlap": OVERLAP,
+                       "step_ms_median_serial_untimed": statistics.median(serial_ms) if serial_ms else None,
                        "note": "per-step GPU time between HIP events on rank 0's main stream; `value` is the wall-clock figure over exactly `steps` steps"}
                       if step_ms else None),
             "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
             "energies": {"e_d3_Ha": float(e_d3[0].item()), "e_pme": float(e_pme.sum().item())},
             "roofline": roofline_of(rows),
+            "calibration": calibration,
             "kernels": rows,
         }
+        if calibration and result["roofline"] and result["roofline"].get("bound") == "hbm" and result["roofline"].get("achieved"):
+            # the same achieved figure against what a plain copy reaches on THIS box (read + written bytes per second)
+            result["roofline"]["frac_of_box_copy"] = result["roofline"]["achieved"] / calibration["copy_GBps"]
+            result["roofline"]["frac_of_box_fill"] = result["roofline"]["achieved"] / calibration["fill_GBps"]
+            result["roofline"]["frac_of_box_read"] = result["roofline"]["achieved"] / calibration["read_GBps"]
         if world == 1 and args.cpu_sample > 0:
             result["cpu_baseline"] = cpu_baseline(args.cpu_sample, args.cpu_full_size)
         print(json.dumps(result), flush=True)

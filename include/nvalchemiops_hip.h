@@ -37,6 +37,11 @@ int mi_timing_enable(int on);
 int mi_timing_report(char* buf /*[host]*/, int cap);
 /* same records with per-launch statistics: "<kernel> <launches> <total_ms> <median_ms> <min_ms> <max_ms>\n" */
 int mi_timing_report_stats(char* buf /*[host]*/, int cap);
+/* HBM calibration streams for the benchmark (no reference counterpart: the reference's protocol, benchmarks/utils.py:133-240, has no
+ * in-run calibration): 16-byte-per-lane read / fill / copy streams over caller-owned device buffers, `bytes` a multiple of 16. */
+int mi_calibrate_copy(const void* src, void* dst, size_t bytes, void* stream);
+int mi_calibrate_fill(void* dst, size_t bytes, float value, void* stream);
+int mi_calibrate_read(const void* src, size_t bytes, float* sink /* 1 float, never written in practice */, void* stream);
 
 /* ---- neighbour list -------------------------------------------------------------------------
  * Replaces: nvalchemiops::build_cell_list + ::query_cell_list (neighborlist/cell_list.py:725,892),

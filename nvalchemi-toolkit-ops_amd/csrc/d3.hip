@@ -808,7 +808,10 @@ __global__ __launch_bounds__(D3_LS_WAVES * MI_WAVE) void d3_chain_kernel(const T
   if (!live) end = beg;
   const int trips = d3_lockstep_trips(beg, end);
   double Fx = 0, Fy = 0, Fz = 0;
-  double V[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  // virial: f (x) r is symmetric (f is parallel to r) -> six components, fp32 lane partials (~40 terms each) summed in fp64 across lanes,
+  // exactly as in the energy pass.  Nine fp64 lane partials cost 27 instructions per pair (18 of them at the fp64 rate) against 6 FMAs
+  // here, and this pass is VALU-bound (round 3: staging the gathered records in LDS instead changed its time by 4 %, tools/probe/probe_lds.hip)
+  float V[6] = {0, 0, 0, 0, 0, 0};  // xx xy xz yy yz zz
   const Int3* __restrict__ ush3 = reinterpret_cast<const Int3*>(ush);
   long long e = beg + lane;
   const unsigned jlim = d3_index_limit<CSR>(N, fill_value);
@@ -833,17 +836,17 @@ __global__ __launch_bounds__(D3_LS_WAVES * MI_WAVE) void d3_chain_kernel(const T
       const float fx = dEdr * (g.rx * g.rinv), fy = dEdr * (g.ry * g.rinv), fz = dEdr * (g.rz * g.rinv);
       Fx += (double)fx; Fy += (double)fy; Fz += (double)fz;
       if (want_virial) {
-        V[0] += (double)(fx * g.rx); V[1] += (double)(fx * g.ry); V[2] += (double)(fx * g.rz);
-        V[3] += (double)(fy * g.rx); V[4] += (double)(fy * g.ry); V[5] += (double)(fy * g.rz);
-        V[6] += (double)(fz * g.rx); V[7] += (double)(fz * g.ry); V[8] += (double)(fz * g.rz);
+        V[0] = fmaf(fx, g.rx, V[0]); V[1] = fmaf(fx, g.ry, V[1]); V[2] = fmaf(fx, g.rz, V[2]);
+        V[3] = fmaf(fy, g.ry, V[3]); V[4] = fmaf(fy, g.rz, V[4]); V[5] = fmaf(fz, g.rz, V[5]);
       }
     }
     s0 = s1; v0 = v1; p0 = p1; d0 = d1; s1 = s2;
   }
   Fx = wave_sum(Fx); Fy = wave_sum(Fy); Fz = wave_sum(Fz);
+  double V6[6];
   if (want_virial) {
 #pragma unroll
-    for (int k = 0; k < 9; ++k) V[k] = wave_sum(V[k]);
+    for (int k = 0; k < 6; ++k) V6[k] = wave_sum((double)V[k]);
   }
   if (lane == 0 && live) {
     forces[3 * (size_t)i] = forces[3 * (size_t)i] + (float)Fx;
@@ -851,9 +854,11 @@ __global__ __launch_bounds__(D3_LS_WAVES * MI_WAVE) void d3_chain_kernel(const T
     forces[3 * (size_t)i + 2] = forces[3 * (size_t)i + 2] + (float)Fz;
   }
   if (want_virial && lane < 9 && live) {
-    double v = V[0];
+    const int r = lane / 3, c = lane - 3 * r, lo = r < c ? r : c, hi2 = r < c ? c : r;
+    const int m = lo == 0 ? hi2 : (lo == 1 ? hi2 + 2 : 5);  // row-major (r, c) -> index in {xx, xy, xz, yy, yz, zz}
+    double v = V6[0];
 #pragma unroll
-    for (int k = 1; k < 9; ++k) v = lane == k ? V[k] : v;
+    for (int q = 1; q < 6; ++q) v = m == q ? V6[q] : v;
     v_atom[9 * (size_t)i + lane] += -0.5 * v;
   }
 }

@@ -64,3 +64,33 @@ def molecule(n_atoms=512, density=0.05, min_dist=1.0, seed=2000, dtype=np.float3
                     break
     numbers = g.choice(np.array([1, 6, 7, 8], np.int32), n_atoms)
     return pts.astype(dtype), numbers.astype(np.int32), side
+
+
+def d3_test_tables(z_max: int = 17, seed: int | None = None):
+    """Analytic test tables of the reference's own test-suite (test/interactions/dispersion/conftest.py:38-160):
+    c6ab = 10 Zi Zj (1 + 0.1p + 0.1q), cn_ref = (p/4) cnmax[Zi].  For z_max > 17 (benchmarks) the element
+    vectors are extended with a seeded generator (real Grimme tables are not in the reference repo: SURVEY F8)."""
+    nz = z_max + 1
+    rcov = np.zeros(nz, np.float32)
+    cnmax = np.zeros(nz, np.float32)
+    r4r2 = np.zeros(nz, np.float32)
+    rcov[:10] = [0.0, 0.6, 0.8, 2.8, 2.0, 1.6, 1.4, 1.3, 1.2, 1.5]
+    cnmax[:10] = [0.0, 1.5, 1.0, 6.0, 4.0, 4.0, 4.0, 4.0, 2.5, 1.5]
+    r4r2[:10] = [0.0, 2.0, 1.5, 10.0, 6.0, 5.0, 4.5, 4.0, 3.5, 3.0]
+    if nz > 10:
+        rcov[10], cnmax[10], r4r2[10] = 1.5, 1.0, 4.5
+    if nz > 17:
+        rcov[17], cnmax[17], r4r2[17] = 1.8, 2.0, 8.0
+    if seed is not None:
+        g = np.random.default_rng(seed)
+        for z in range(1, nz):
+            if rcov[z] == 0.0:
+                rcov[z] = g.uniform(1.0, 3.0)
+                cnmax[z] = g.uniform(1.0, 6.0)
+                r4r2[z] = g.uniform(2.0, 10.0)
+    p = np.arange(5, dtype=np.float32)
+    zi = np.arange(nz, dtype=np.float32)
+    c6ab = (10.0 * zi[:, None, None, None] * zi[None, :, None, None]
+            * (1.0 + 0.1 * p[None, None, :, None] + 0.1 * p[None, None, None, :])).astype(np.float32)
+    cn_ref = np.broadcast_to(((p / 4.0)[None, None, :, None] * cnmax[:, None, None, None]), (nz, nz, 5, 5)).astype(np.float32).copy()
+    return {"rcov": rcov, "r4r2": r4r2, "c6ab": c6ab, "cn_ref": cn_ref}
