@@ -756,8 +756,13 @@ def main():
         barrier()
         elapsed = time.perf_counter() - t0
         C.lib().mi_timing_enable(0)
+    rank_ms = [elapsed / args.steps * 1e3]
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        mine = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        torch.distributed.all_gather(every, mine)
+        rank_ms = [float(t.item()) / args.steps * 1e3 for t in every]
+        tt = mine.clone()
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(tt.item())
     kernels = kernel_report()
@@ -790,10 +795,12 @@ def main():
     pairs_d3 = int(nptr.sum().item()) if matrix_d3 else int(nptr[-1].item())  # matrix format: `nptr` holds num_neighbors
     if matrix_d3 and int(nptr.max().item()) > D3["max_neighbors"]:
         raise RuntimeError(f"D3 neighbour matrix overflow: {int(nptr.max().item())} > {D3['max_neighbors']}")
-    stage_ms = {}
+    stage_ms, gather_us = {}, []
     for ev in records:
         for (_, a), (name, b) in zip(ev[:-1], ev[1:]):
             stage_ms[name] = stage_ms.get(name, 0.0) + a.elapsed_time(b) / len(records)
+            if name == "gather":
+                gather_us.append(a.elapsed_time(b) * 1e3)
 
     if rank == 0:
         total_atoms = args.atoms * world
@@ -822,6 +829,10 @@ def main():
                        "note": "per-step GPU time between HIP events on rank 0's main stream; `value` is the wall-clock figure over exactly `steps` steps"}
                       if step_ms else None),
             "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
+            "ranks": {"ms_per_step": [round(x, 4) for x in rank_ms], "imbalance_max_over_min": max(rank_ms) / max(min(rank_ms), 1e-9),
+                      "all_gather_us_median": statistics.median(gather_us) if gather_us else None,
+                      "note": "wall-clock per step of every rank over the timed region (`value` uses the slowest); the all_gather figure is rank 0's "
+                              "GPU time between the events around the one collective of a step"},
             "energies": {"e_d3_Ha": float(e_d3[0].item()), "e_pme": float(e_pme.sum().item())},
             "roofline": roofline_of(rows),
             "calibration": calibration,

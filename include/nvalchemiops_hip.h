@@ -85,6 +85,17 @@ int mi_nl_neighbors(const void* positions,          /* [n_atoms,3] dtype        
                                                        caller's coordinates unchanged                        */
                     void* workspace, size_t workspace_bytes, void* stream);
 
+/* Single-sweep dual-cutoff search: ONE walk over the candidate pairs fills two padded matrices, the short list nested in the long one and
+ * both with the image range of the long cutoff.  Replaces: _fill_naive_neighbor_matrix[_pbc]_dual_cutoff and the batch variants
+ * (neighborlist/naive_dual_cutoff.py:36,115 / batch_naive_dual_cutoff.py:37,126).  flags as for mi_nl_neighbors (matrix mode). */
+int mi_nl_neighbors_dual(const void* positions, int n_atoms, const void* cell, const uint8_t* pbc, const int32_t* batch_idx, int n_systems,
+                         double cutoff_short, double cutoff_long, int dtype, int flags,
+                         int32_t* neighbor_matrix_short, int32_t* neighbor_matrix_shifts_short, int32_t* num_neighbors_short,
+                         int max_neighbors_short,
+                         int32_t* neighbor_matrix_long, int32_t* neighbor_matrix_shifts_long, int32_t* num_neighbors_long,
+                         int max_neighbors_long, int fill_value, const void* bin_origin, void* workspace, size_t workspace_bytes,
+                         void* stream);
+
 /* padded matrix -> COO/CSR (neighbor_utils.py:362-441): entries != fill_value, row-major.
  * neighbor_ptr = [0, cumsum(num_neighbors)] supplied by the caller; shifts may be NULL.              */
 int mi_nl_matrix_to_coo(const int32_t* neighbor_matrix, const int32_t* neighbor_matrix_shifts,

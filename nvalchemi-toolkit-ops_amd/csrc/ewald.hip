@@ -27,13 +27,21 @@ __device__ __forceinline__ double erfc_as_poly(double x, double e_neg_x2) {
   return poly * e_neg_x2;
 }
 
-// order-sensitive 32-bit mix of one stored entry; summed per direction in 64 bits (see header)
-__device__ __forceinline__ unsigned ew_entry_hash(unsigned a, unsigned b, int s0, int s1, int s2) {
+// Order-sensitive 64-bit mix of one stored entry: two independent 32-bit mixes of (a, b, S) side by side, summed per direction in 64 bits.
+// The list counts as symmetric iff the forward sum (entries as stored) equals the reverse sum (entries mirrored): a false "symmetric"
+// needs a collision of 64-bit sums, ~2^-64 per call (one 32-bit mix summed in 64 bits gave ~2^-32, round-2 ADVICE).  Shift components
+// beyond +-1024 alias in the packed shift word; that only weakens the mix, it cannot make a symmetric list look asymmetric.
+__device__ __forceinline__ unsigned long long ew_entry_hash(unsigned a, unsigned b, int s0, int s1, int s2) {
+  const unsigned sw = ((unsigned)(s0 + 1024) | ((unsigned)(s1 + 1024) << 11) | ((unsigned)(s2 + 1024) << 22));
   unsigned h = a * 0x9E3779B1u;
   h ^= __builtin_rotateleft32(b * 0x85EBCA77u, 13);
-  h ^= ((unsigned)(s0 + 1024) | ((unsigned)(s1 + 1024) << 11) | ((unsigned)(s2 + 1024) << 22)) * 0xC2B2AE3Du;
+  h ^= sw * 0xC2B2AE3Du;
   h ^= h >> 15; h *= 0x2C1B3C6Du; h ^= h >> 12; h *= 0x297A2D39u; h ^= h >> 15;
-  return h;
+  unsigned g = b * 0x27D4EB2Fu;
+  g ^= __builtin_rotateleft32(a * 0x165667B1u, 17);
+  g ^= __builtin_rotateleft32(sw, 5) * 0x9E3779B9u;
+  g ^= g >> 16; g *= 0x7FEB352Du; g ^= g >> 15; g *= 0x846CA68Bu; g ^= g >> 16;
+  return ((unsigned long long)g << 32) | h;
 }
 // Checksum scratch: sym[0..1] = final {forward, reverse} sums (written by ew_sym_reduce_kernel), then EW_SYM_SLOTS pairs of
 // partial sums.  A wave adds its partials to the slot pair of its atom index: 100k waves on ONE address would serialise at

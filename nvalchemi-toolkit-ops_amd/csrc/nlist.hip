@@ -25,6 +25,8 @@
 //            written by `setup` decides which one works (no host sync).
 //
 // The same query kernels serve the padded matrix, the count pass and the direct CSR/COO fill.
+#include <stdlib.h>
+
 #include "binsort.h"
 #include "common.h"
 
@@ -35,6 +37,11 @@ namespace {
 #define NL_MAXROWS 96     // (2Ry+1)(2Rz+1) rows of cells a block can describe (R <= 4)
 #define NL_MIXED 0x7fffffff
 #define NL_TILED_GRID 1536   // persistent blocks (6 per CU); cells are handed out dynamically
+// tuning aid: NVALCHEMIOPS_NL_TILED_GRID in the environment overrides the number of persistent blocks (read once)
+static int nl_tiled_grid() {
+  static const int g = [] { const char* e = getenv("NVALCHEMIOPS_NL_TILED_GRID"); const int v = e ? atoi(e) : 0; return v > 0 ? v : NL_TILED_GRID; }();
+  return g;
+}
 template <class T> struct NlSys {
   T cell[9];
   T inv[9];
@@ -252,9 +259,14 @@ __device__ __forceinline__ void wave_fill(int* __restrict__ dst, long long begin
 
 // The pair test shared by both query kernels: reference expression order (cell_list.py:531-544), or the naive method's
 // orientation / image range (naive.py:163-172), self-pair exclusion, canonical half-fill rule.
+// Second output set of the single-sweep dual-cutoff search (naive_dual_cutoff.py:115-290: one walk over the pair set, `dist_sq < cutoff2_sq`
+// fills list 2 and, nested in it, `dist_sq < cutoff1_sq` fills list 1 -- same image range for both).  The primary outputs of the query
+// kernels take the LONG cutoff, this struct the short one.
+template <class T> struct NlSecond { T rc2; int* nm; int* nsh; int* num; int M; };
+
 template <class T>
 __device__ __forceinline__ bool nl_pair_hit(T pix, T piy, T piz, int i, T cjx, T cjy, T cjz, int j, int Sx, int Sy, int Sz, const T* cart,
-                                            T rc2, bool naive, bool half, int nr0, int nr1, int nr2) {
+                                            T rc2, bool naive, bool half, int nr0, int nr1, int nr2, T* d2_out = nullptr) {
   T dr0, dr1, dr2;
   bool ok = true;
   if (!naive) {
@@ -268,6 +280,7 @@ __device__ __forceinline__ bool nl_pair_hit(T pix, T piy, T piz, int i, T cjx, T
     ok = (Sx <= nr0 && -Sx <= nr0) && (Sy <= nr1 && -Sy <= nr1) && (Sz <= nr2 && -Sz <= nr2);
   }
   const T d2 = dr0 * dr0 + dr1 * dr1 + dr2 * dr2;
+  if (d2_out) *d2_out = d2;
   const bool zeroS = (Sx | Sy | Sz) == 0;
   bool hit = ok && (d2 < rc2) && !(j == i && zeroS);
   if (half && hit) {
@@ -284,14 +297,16 @@ __device__ __forceinline__ bool nl_pair_hit(T pix, T piy, T piz, int i, T cjx, T
 // latency inside the 64-candidates-per-step loop, and every candidate record is fetched from L2 once per cell, not once
 // per atom.  Output path (ballot/popcount compaction, owner-written padding) is the same as the wave-per-atom kernel's.
 // FAST = neither naive-expression nor half-fill requested: the per-candidate test is straight-line code.
-template <class T, int MODE, bool FAST>
+template <class T, int MODE, bool FAST, bool DUAL = false>
 __global__ __launch_bounds__(256) void nl_query_tiled_kernel(
     const typename Vec4<T>::type* __restrict__ spos, const short4* __restrict__ swrap, const int* __restrict__ cell_start,
     const NlSys<T>* __restrict__ sys, const NlGlobal* __restrict__ glob, int B, T rc2, int flags, int* __restrict__ nm,
     int* __restrict__ nsh, int* __restrict__ num, int M, int fill_value, const int* __restrict__ ptr, int* __restrict__ list_ij,
-    int* __restrict__ list_sh, long long P) {
+    int* __restrict__ list_sh, long long P, NlSecond<T> D) {
+  static_assert(!DUAL || (MODE == MI_NL_MODE_MATRIX && !FAST), "the dual-cutoff sweep is instantiated for the general matrix kernel only");
   if (!glob->use_tiled) return;
-  if (FAST != ((flags & (MI_NL_HALF_FILL | MI_NL_NAIVE_EXPR)) == 0)) return;  // the other instantiation handles this call
+  if (!DUAL && FAST != ((flags & (MI_NL_HALF_FILL | MI_NL_NAIVE_EXPR)) == 0)) return;  // the other instantiation handles this call
+  __shared__ int ccnt2[DUAL ? 256 : 1];
   __shared__ T tx[NL_TILE], ty[NL_TILE], tz[NL_TILE];
   __shared__ int tj[NL_TILE];
   __shared__ short tsx[NL_TILE], tsy[NL_TILE], tsz[NL_TILE];
@@ -388,6 +403,7 @@ __global__ __launch_bounds__(256) void nl_query_tiled_kernel(
     for (int cbase = 0; cbase < n_c; cbase += 256) {
       const int cend = (cbase + 256 < n_c) ? cbase + 256 : n_c;
       ccnt[tid] = 0;
+      if (DUAL) ccnt2[tid] = 0;
       for (int tile0 = 0; tile0 < total; tile0 += NL_TILE) {
         const int tile_n = (total - tile0 < NL_TILE) ? total - tile0 : NL_TILE;
         __syncthreads();  // the previous tile has been consumed (and ccnt initialised)
@@ -427,7 +443,7 @@ __global__ __launch_bounds__(256) void nl_query_tiled_kernel(
         constexpr int NC = 2;
         for (int ci0 = cbase + wave; ci0 < cend; ci0 += 4 * NC) {
           T ccx[NC], ccy[NC], ccz[NC];
-          int ii[NC], cap_row[NC], cnt[NC];
+          int ii[NC], cap_row[NC], cnt[NC], cnt2[NC];
           long long out_base[NC];
           short4 wi[NC];
           const int nc = (cend - ci0 + 3) / 4 < NC ? (cend - ci0 + 3) / 4 : NC;  // centres of this wave in this pass (uniform)
@@ -445,6 +461,7 @@ __global__ __launch_bounds__(256) void nl_query_tiled_kernel(
             if (MODE == MI_NL_MODE_CSR) { out_base[u] = ptr[ii[u]]; cap_row[u] = ptr[ii[u] + 1] - ptr[ii[u]]; }
             else { out_base[u] = (long long)ii[u] * M; cap_row[u] = M; }
             cnt[u] = ccnt[ci - cbase];
+            cnt2[u] = DUAL ? ccnt2[ci - cbase] : 0;
           }
           const bool ortho = S->prune != 0;  // orthorhombic: S.cell has one non-zero term per component (adding exact zeros changes nothing)
           auto emit = [&](int u, bool hit, int j, int Sx, int Sy, int Sz) {
@@ -522,7 +539,21 @@ __global__ __launch_bounds__(256) void nl_query_tiled_kernel(
                   const T d2 = dr0 * dr0 + dr1 * dr1 + dr2 * dr2;
                   h = (d2 < rc2) & !((j == ii[u]) & ((Sx | Sy | Sz) == 0));
                 } else {
-                  h = nl_pair_hit<T>(ccx[u], ccy[u], ccz[u], ii[u], cjx, cjy, cjz, j, Sx, Sy, Sz, cart, rc2, naive, half, nr0, nr1, nr2);
+                  T d2;
+                  h = nl_pair_hit<T>(ccx[u], ccy[u], ccz[u], ii[u], cjx, cjy, cjz, j, Sx, Sy, Sz, cart, rc2, naive, half, nr0, nr1, nr2, &d2);
+                  if (DUAL) {  // the short list, nested in the long one (same walk, same image range)
+                    const bool h2 = h && (d2 < D.rc2);
+                    const unsigned long long m2 = __ballot(h2);
+                    if (m2) {
+                      const int slot = cnt2[u] + __popcll(m2 & lt);
+                      if (h2 && slot < D.M) {
+                        const long long o = (long long)ii[u] * D.M + slot;
+                        D.nm[o] = j;
+                        if (D.nsh) reinterpret_cast<NlInt3*>(D.nsh)[o] = NlInt3{Sx, Sy, Sz};
+                      }
+                      cnt2[u] += __popcll(m2);
+                    }
+                  }
                 }
                 emit(u, h, j, Sx, Sy, Sz);
               }
@@ -530,7 +561,7 @@ __global__ __launch_bounds__(256) void nl_query_tiled_kernel(
           }
           if (lane == 0) {
 #pragma unroll
-            for (int u = 0; u < NC; ++u) if (u < nc) ccnt[ci0 + 4 * u - cbase] = cnt[u];
+            for (int u = 0; u < NC; ++u) if (u < nc) { ccnt[ci0 + 4 * u - cbase] = cnt[u]; if (DUAL) ccnt2[ci0 + 4 * u - cbase] = cnt2[u]; }
           }
         }
       }
@@ -551,6 +582,16 @@ __global__ __launch_bounds__(256) void nl_query_tiled_kernel(
           wave_fill(nm, out_base + used, out_base + M, fill_value, lane);
           if (nsh) wave_fill(nsh, (out_base + used) * 3, (out_base + M) * 3, 0, lane);
         }
+        if (DUAL) {
+          const int c2 = ccnt2[ci - cbase];
+          if (lane == 0) D.num[i] = c2;
+          if (!(flags & MI_NL_NO_PAD)) {
+            const long long ob = (long long)i * D.M;
+            const int used = c2 < D.M ? c2 : D.M;
+            wave_fill(D.nm, ob + used, ob + D.M, fill_value, lane);
+            if (D.nsh) wave_fill(D.nsh, (ob + used) * 3, (ob + D.M) * 3, 0, lane);
+          }
+        }
       }
       __syncthreads();
     }
@@ -561,12 +602,13 @@ __global__ __launch_bounds__(256) void nl_query_tiled_kernel(
   }
 }
 
-template <class T, int MODE>
+template <class T, int MODE, bool DUAL = false>
 __global__ __launch_bounds__(256) void nl_query_kernel(
     const typename Vec4<T>::type* __restrict__ spos, const short4* __restrict__ swrap, const int* __restrict__ keys_sorted,
     const int* __restrict__ cell_start, const int* __restrict__ batch_idx, const NlSys<T>* __restrict__ sys,
     const NlGlobal* __restrict__ glob, int N, T rc2, int flags, int* __restrict__ nm, int* __restrict__ nsh, int* __restrict__ num,
-    int M, int fill_value, const int* __restrict__ ptr, int* __restrict__ list_ij, int* __restrict__ list_sh, long long P) {
+    int M, int fill_value, const int* __restrict__ ptr, int* __restrict__ list_ij, int* __restrict__ list_sh, long long P, NlSecond<T> D) {
+  static_assert(!DUAL || MODE == MI_NL_MODE_MATRIX, "the dual-cutoff sweep fills two padded matrices");
   if (glob->use_tiled) return;  // dense cells: the block-per-cell LDS-tiled kernel (launched next to this one) does the work
   const int lane = threadIdx.x & (MI_WAVE - 1);
   const int p = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x / MI_WAVE) + (threadIdx.x / MI_WAVE));
@@ -596,7 +638,7 @@ __global__ __launch_bounds__(256) void nl_query_kernel(
   int cap_row;
   if (MODE == MI_NL_MODE_CSR) { out_base = ptr[i]; cap_row = ptr[i + 1] - ptr[i]; }
   else { out_base = (long long)i * M; cap_row = M; }
-  int cnt = 0;
+  int cnt = 0, cnt2 = 0;
 
   const bool prune = S->prune != 0;
 
@@ -610,7 +652,7 @@ __global__ __launch_bounds__(256) void nl_query_kernel(
     }
     for (int q0 = beg; q0 < end; q0 += MI_WAVE) {
       const int q = q0 + lane;
-      bool hit = false;
+      bool hit = false, hit2 = false;
       int j = 0, Sx = sx, Sy = csy, Sz = csz;
       if (q < end) {
         const auto cj = spos[q];
@@ -626,7 +668,21 @@ __global__ __launch_bounds__(256) void nl_query_kernel(
           const T fs[3] = {(T)Sx, (T)Sy, (T)Sz};
           rowvec_mat3(fs, cm, cart);
         }
-        hit = nl_pair_hit<T>(pix, piy, piz, i, cj.x, cj.y, cj.z, j, Sx, Sy, Sz, cart, rc2, naive, half, nr0, nr1, nr2);
+        T d2;
+        hit = nl_pair_hit<T>(pix, piy, piz, i, cj.x, cj.y, cj.z, j, Sx, Sy, Sz, cart, rc2, naive, half, nr0, nr1, nr2, &d2);
+        hit2 = DUAL && hit && (d2 < D.rc2);
+      }
+      if (DUAL) {  // the short list, nested in the long one
+        const unsigned long long m2 = __ballot(hit2);
+        if (m2) {
+          const int slot = cnt2 + __popcll(m2 & lt);
+          if (hit2 && slot < D.M) {
+            const long long o = (long long)i * D.M + slot;
+            D.nm[o] = j;
+            if (D.nsh) reinterpret_cast<NlInt3*>(D.nsh)[o] = NlInt3{Sx, Sy, Sz};
+          }
+          cnt2 += __popcll(m2);
+        }
       }
       const unsigned long long mask = __ballot(hit);
       if (mask) {
@@ -734,6 +790,15 @@ __global__ __launch_bounds__(256) void nl_query_kernel(
     const int used = cnt < M ? cnt : M;
     wave_fill(nm, out_base + used, out_base + M, fill_value, lane);
     if (nsh) wave_fill(nsh, (out_base + used) * 3, (out_base + M) * 3, 0, lane);
+  }
+  if (DUAL) {
+    if (lane == 0) D.num[i] = cnt2;
+    if (!(flags & MI_NL_NO_PAD)) {
+      const long long ob = (long long)i * D.M;
+      const int used = cnt2 < D.M ? cnt2 : D.M;
+      wave_fill(D.nm, ob + used, ob + D.M, fill_value, lane);
+      if (D.nsh) wave_fill(D.nsh, (ob + used) * 3, (ob + D.M) * 3, 0, lane);
+    }
   }
 }
 
@@ -953,7 +1018,7 @@ __global__ void nl_moved_kernel(const T* __restrict__ ref, const T* __restrict__
 template <class T>
 int nl_neighbors_impl(const T* pos, int N, const T* cell, const uint8_t* pbc, const int* batch_idx, int B, double cutoff, int mode, int flags,
                       int* nm, int* nsh, int* num, int M, int fill_value, const int* ptr, int* list_ij, int* list_sh, long long P,
-                      const T* origin, char* ws, const NlLayout& L, hipStream_t st) {
+                      const T* origin, char* ws, const NlLayout& L, hipStream_t st, const NlSecond<T>* second = nullptr) {
   auto* sys = reinterpret_cast<NlSys<T>*>(ws + L.sys);
   auto* glob = reinterpret_cast<NlGlobal*>(ws + L.glob);
   int* natoms = reinterpret_cast<int*>(ws + L.natoms);
@@ -991,19 +1056,29 @@ int nl_neighbors_impl(const T* pos, int N, const T* cell, const uint8_t* pbc, co
     mi_timing_end((void*)st);
   }
   const int blocks = mi_blocks(N, 4);
+  const NlSecond<T> none{T(0), nullptr, nullptr, nullptr, 0};
+  if (second) {  // single-sweep dual cutoff: the primary outputs take the long cutoff, `second` the short one
+    MI_TIMED("nl_query_dual", st,
+             (nl_query_kernel<T, MI_NL_MODE_MATRIX, true><<<blocks, 256, 0, st>>>(spos, swrap, keys_out, cell_start, batch_idx, sys, glob, N, rc2, flags, nm, nsh,
+                                                                                 num, M, fill_value, ptr, list_ij, list_sh, P, *second),
+              nl_query_tiled_kernel<T, MI_NL_MODE_MATRIX, false, true><<<nl_tiled_grid(), 256, 0, st>>>(spos, swrap, cell_start, sys, glob, B, rc2, flags, nm, nsh,
+                                                                                                       num, M, fill_value, ptr, list_ij, list_sh, P, *second)));
+    MI_LAUNCH_CHECK();
+    return MI_OK;
+  }
 #define MI_NLQ(MODE_)                                                                                                              \
   nl_query_kernel<T, MODE_><<<blocks, 256, 0, st>>>(spos, swrap, keys_out, cell_start, batch_idx, sys, glob, N, rc2, flags, nm, nsh, num, M, \
-                                                    fill_value, ptr, list_ij, list_sh, P)
+                                                    fill_value, ptr, list_ij, list_sh, P, none)
   // both query kernels are launched; the device-side grid description (glob->use_tiled) decides which one does the work
   // and the other returns at once -- no host synchronisation to pick a variant
 #define MI_NLT(MODE_)                                                                                                                    \
   do {                                                                                                                                   \
     if ((flags & (MI_NL_HALF_FILL | MI_NL_NAIVE_EXPR)) == 0)                                                                             \
-      nl_query_tiled_kernel<T, MODE_, true><<<NL_TILED_GRID, 256, 0, st>>>(spos, swrap, cell_start, sys, glob, B, rc2, flags, nm, nsh, num, \
-                                                                          M, fill_value, ptr, list_ij, list_sh, P);                      \
+      nl_query_tiled_kernel<T, MODE_, true><<<nl_tiled_grid(), 256, 0, st>>>(spos, swrap, cell_start, sys, glob, B, rc2, flags, nm, nsh, num, \
+                                                                          M, fill_value, ptr, list_ij, list_sh, P, none);                \
     else                                                                                                                                 \
-      nl_query_tiled_kernel<T, MODE_, false><<<NL_TILED_GRID, 256, 0, st>>>(spos, swrap, cell_start, sys, glob, B, rc2, flags, nm, nsh, num, \
-                                                                           M, fill_value, ptr, list_ij, list_sh, P);                     \
+      nl_query_tiled_kernel<T, MODE_, false><<<nl_tiled_grid(), 256, 0, st>>>(spos, swrap, cell_start, sys, glob, B, rc2, flags, nm, nsh, num, \
+                                                                           M, fill_value, ptr, list_ij, list_sh, P, none);               \
   } while (0)
   if (mode == MI_NL_MODE_MATRIX) MI_TIMED(sizeof(T) == 4 ? "nl_query_matrix_f32" : "nl_query_matrix_f64", st, MI_NLQ(MI_NL_MODE_MATRIX); MI_NLT(MI_NL_MODE_MATRIX));
   else if (mode == MI_NL_MODE_COUNT) MI_TIMED("nl_query_count", st, MI_NLQ(MI_NL_MODE_COUNT); MI_NLT(MI_NL_MODE_COUNT));
@@ -1073,6 +1148,39 @@ int mi_nl_neighbors(const void* positions, int n_atoms, const void* cell, const 
   return nl_neighbors_impl<double>((const double*)positions, n_atoms, (const double*)cell, pbc, batch_idx, n_systems, cutoff, mode, flags,
                                    neighbor_matrix, neighbor_matrix_shifts, num_neighbors, max_neighbors, fill_value, neighbor_ptr, list_ij,
                                    list_shifts, n_pairs, (const double*)bin_origin, (char*)workspace, L, st);
+}
+
+int mi_nl_neighbors_dual(const void* positions, int n_atoms, const void* cell, const uint8_t* pbc, const int32_t* batch_idx, int n_systems,
+                         double cutoff_short, double cutoff_long, int dtype, int flags, int32_t* neighbor_matrix_short,
+                         int32_t* neighbor_matrix_shifts_short, int32_t* num_neighbors_short, int max_neighbors_short,
+                         int32_t* neighbor_matrix_long, int32_t* neighbor_matrix_shifts_long, int32_t* num_neighbors_long, int max_neighbors_long,
+                         int fill_value, const void* bin_origin, void* workspace, size_t workspace_bytes, void* stream) {
+  MI_REQUIRE(dtype == MI_F32 || dtype == MI_F64, "dtype must be MI_F32 or MI_F64");
+  MI_REQUIRE(n_atoms >= 0 && n_systems >= 1, "n_atoms >= 0 and n_systems >= 1");
+  MI_REQUIRE(cutoff_short > 0 && cutoff_long >= cutoff_short, "0 < cutoff_short <= cutoff_long");
+  if (n_atoms == 0) return MI_OK;
+  MI_REQUIRE(positions && cell && pbc && workspace, "null pointer");
+  MI_REQUIRE(neighbor_matrix_short && num_neighbors_short && max_neighbors_short >= 0 && neighbor_matrix_long && num_neighbors_long &&
+                 max_neighbors_long >= 0, "matrix outputs");
+  if (flags & MI_NL_NO_SHIFTS) neighbor_matrix_shifts_short = neighbor_matrix_shifts_long = nullptr;
+  NlLayout L = nl_layout(n_atoms, n_systems, dtype);
+  if (workspace_bytes < L.total) { mi_set_error("workspace too small: %zu < %zu", workspace_bytes, L.total); return MI_EWORKSPACE; }
+  hipStream_t st = (hipStream_t)stream;
+  // squared cutoffs exactly as the single-cutoff entry point forms them (naive: squared in double, then cast; cell list: cast, then squared)
+  if (dtype == MI_F32) {
+    const float r1 = (float)cutoff_short;
+    const NlSecond<float> sec{(flags & MI_NL_NAIVE_EXPR) ? (float)(cutoff_short * cutoff_short) : r1 * r1, neighbor_matrix_short,
+                              neighbor_matrix_shifts_short, num_neighbors_short, max_neighbors_short};
+    return nl_neighbors_impl<float>((const float*)positions, n_atoms, (const float*)cell, pbc, batch_idx, n_systems, cutoff_long, MI_NL_MODE_MATRIX,
+                                    flags, neighbor_matrix_long, neighbor_matrix_shifts_long, num_neighbors_long, max_neighbors_long, fill_value,
+                                    nullptr, nullptr, nullptr, 0, (const float*)bin_origin, (char*)workspace, L, st, &sec);
+  }
+  const double r1 = cutoff_short;
+  const NlSecond<double> sec{(flags & MI_NL_NAIVE_EXPR) ? cutoff_short * cutoff_short : r1 * r1, neighbor_matrix_short, neighbor_matrix_shifts_short,
+                             num_neighbors_short, max_neighbors_short};
+  return nl_neighbors_impl<double>((const double*)positions, n_atoms, (const double*)cell, pbc, batch_idx, n_systems, cutoff_long, MI_NL_MODE_MATRIX,
+                                   flags, neighbor_matrix_long, neighbor_matrix_shifts_long, num_neighbors_long, max_neighbors_long, fill_value,
+                                   nullptr, nullptr, nullptr, 0, (const double*)bin_origin, (char*)workspace, L, st, &sec);
 }
 
 int mi_nl_matrix_to_coo(const int32_t* neighbor_matrix, const int32_t* neighbor_matrix_shifts, const int32_t* neighbor_ptr, int n_atoms,

@@ -116,6 +116,29 @@ def _like_cell_inv_t(gcit, cell_inv_t):
     return None if cell_inv_t is None else gcit.reshape(cell_inv_t.shape).to(cell_inv_t.dtype)
 
 
+def _n(need, k):
+    """needs_input_grad[k]; False for a trailing optional argument the caller left out (the tuple then ends before it)."""
+    return k < len(need) and need[k]
+
+
+def _fit(need, grads):
+    """One gradient per argument the op was CALLED with (a direct call may omit the trailing optional `cell_inv_t`)."""
+    return tuple(grads[: len(need)])
+
+
+def _cell_grad_without_cit(gc, cit, cell, cell_inv_t, needed):
+    """The op was called WITHOUT `cell_inv_t` (reference signature: it is optional), so cell^-T was formed from `cell` inside the op
+    and the gradient has to reach `cell` itself: cit = cell^-T  =>  dL/dcell = -cit (dL/dcit)^T cit.  None when `cell_inv_t` was given
+    (the gradient then flows through that argument) or `cell` needs no gradient -- never a silently missing cell gradient."""
+    if cell_inv_t is not None or not needed or gc is None:
+        return None
+    c = cit.detach().to(gc.dtype)
+    g = -(c @ gc.transpose(-1, -2) @ c)
+    if cell.reshape(-1, 3, 3).shape[0] != g.shape[0]:
+        g = g.sum(0, keepdim=True)
+    return g.reshape(cell.shape).to(cell.dtype)
+
+
 # ---- spread -------------------------------------------------------------------------------------------------------------------------
 def _spline_spread(positions: Tensor, values: Tensor, cell: Tensor, mesh_nx: int, mesh_ny: int, mesh_nz: int, spline_order: int,
                    cell_inv_t: Optional[Tensor] = None) -> Tensor:
@@ -164,13 +187,16 @@ def _spread_backward(batched):
         vi, ci = (1, 9) if batched else (1, 7)
         if need[vi]:  # d/dvalues = gather(grad_mesh): the gather op, so this branch can be differentiated again
             gvals = gather(positions, g, batch_idx, cell, ctx.order, cell_inv_t) if batched else gather(positions, g, cell, ctx.order, cell_inv_t)
-        if need[0] or need[ci]:
+        cell_i = 3 if batched else 2
+        gcell = None
+        if need[0] or _n(need, ci) or (cell_inv_t is None and need[cell_i]):
             gfrac = frac_grad_op(positions, g if batched else g.unsqueeze(0), batch_idx, cit, ctx.order)
             gpos, gc = _coordinate_grads(values.detach().to(positions.dtype), gfrac, positions.detach(), cit.detach(), None if batch_idx is None else batch_idx)
             gcit = _like_cell_inv_t(gc if (cell_inv_t is None or cell_inv_t.reshape(-1, 3, 3).shape[0] == gc.shape[0]) else gc.sum(0, keepdim=True), cell_inv_t)
+            gcell = _cell_grad_without_cit(gc, cit, cell, cell_inv_t, need[cell_i])
         if batched:
-            return gpos if need[0] else None, gvals, None, None, None, None, None, None, None, gcit if need[9] else None
-        return gpos if need[0] else None, gvals, None, None, None, None, None, gcit if need[7] else None
+            return _fit(need, (gpos if need[0] else None, gvals, None, gcell, None, None, None, None, None, gcit if _n(need, 9) else None))
+        return _fit(need, (gpos if need[0] else None, gvals, gcell, None, None, None, None, gcit if _n(need, 7) else None))
     return backward
 
 
@@ -228,13 +254,16 @@ def _gather_backward(batched):
                 gmesh = torch.ops.alchemiops._batch_spline_spread(positions, g, batch_idx, cell, nsys, nx, ny, nz, ctx.order, cell_inv_t)
             else:
                 gmesh = torch.ops.alchemiops._spline_spread(positions, g, cell, nx, ny, nz, ctx.order, cell_inv_t)
-        if need[0] or need[ci]:
+        cell_i = 3 if batched else 2
+        gcell = None
+        if need[0] or _n(need, ci) or (cell_inv_t is None and need[cell_i]):
             gfrac = frac_grad_op(positions, mesh if batched else mesh.unsqueeze(0), batch_idx, cit, ctx.order)
             gpos, gc = _coordinate_grads(g.detach().to(positions.dtype), gfrac, positions.detach(), cit.detach(), batch_idx)
             gcit = _like_cell_inv_t(gc if (cell_inv_t is None or cell_inv_t.reshape(-1, 3, 3).shape[0] == gc.shape[0]) else gc.sum(0, keepdim=True), cell_inv_t)
+            gcell = _cell_grad_without_cit(gc, cit, cell, cell_inv_t, need[cell_i])
         if batched:
-            return gpos if need[0] else None, gmesh, None, None, None, gcit if need[5] else None
-        return gpos if need[0] else None, gmesh, None, None, gcit if need[4] else None
+            return _fit(need, (gpos if need[0] else None, gmesh, None, gcell, None, gcit if _n(need, 5) else None))
+        return _fit(need, (gpos if need[0] else None, gmesh, gcell, None, gcit if _n(need, 4) else None))
     return backward
 
 
@@ -300,7 +329,9 @@ def _vec3_backward(batched):
                 sp.append(torch.ops.alchemiops._batch_spline_spread(positions, w, batch_idx, cell, nsys, nx, ny, nz, ctx.order, cell_inv_t) if batched else
                           torch.ops.alchemiops._spline_spread(positions, w, cell, nx, ny, nz, ctx.order, cell_inv_t))
             gmesh = torch.stack(sp, dim=-1).to(mesh.dtype)
-        if need[0] or need[ci]:
+        cell_i = 4 if batched else 3
+        gcell = None
+        if need[0] or _n(need, ci) or (cell_inv_t is None and need[cell_i]):
             gpos = torch.zeros_like(positions)
             gc_tot = torch.zeros_like(cit)
             for c in range(3):
@@ -309,9 +340,10 @@ def _vec3_backward(batched):
                 gpos = gpos + gp
                 gc_tot = gc_tot + gc
             gcit = _like_cell_inv_t(gc_tot if (cell_inv_t is None or cell_inv_t.reshape(-1, 3, 3).shape[0] == gc_tot.shape[0]) else gc_tot.sum(0, keepdim=True), cell_inv_t)
+            gcell = _cell_grad_without_cit(gc_tot, cit, cell, cell_inv_t, need[cell_i])
         if batched:
-            return gpos if need[0] else None, gq, gmesh, None, None, None, gcit if need[6] else None
-        return gpos if need[0] else None, gq, gmesh, None, None, gcit if need[5] else None
+            return _fit(need, (gpos if need[0] else None, gq, gmesh, None, gcell, None, gcit if _n(need, 6) else None))
+        return _fit(need, (gpos if need[0] else None, gq, gmesh, gcell, None, gcit if _n(need, 5) else None))
     return backward
 
 
@@ -423,24 +455,27 @@ def _gather_gradient_backward(batched):
         t = torch.einsum("nab,nb->na", c_i, g)                       # (cit gF)_i
         v = -q.unsqueeze(-1) * t
         ci = 6 if batched else 5
-        gq = gmesh = gpos = gcit = None
-        if need[1] or need[ci]:
+        cell_i = 4 if batched else 3
+        want_c = _n(need, ci) or (cell_inv_t is None and need[cell_i])
+        gq = gmesh = gpos = gcit = gcell = None
+        if need[1] or want_c:
             gfr = frac_grad_op(pos, m, batch_idx, c, ctx.order)      # G_i
         if need[1]:
             gq = -(gfr * t).sum(-1).to(charges.dtype)
         if need[2]:
             gm = spread_grad_op(pos, v, batch_idx, c, nsys, nx, ny, nz, ctx.order)
             gmesh = (gm if batched else gm[0]).to(mesh.dtype)
-        if need[0] or need[ci]:
+        if need[0] or want_c:
             dfrac = hess_dot_op(pos, m, batch_idx, c, v, ctx.order)
             gpos, gc = _coordinate_grads(torch.ones_like(q), dfrac, pos, c, batch_idx)
-            if need[ci]:
+            if want_c:
                 direct = (-q).reshape(-1, 1, 1) * gfr.unsqueeze(-1) * g.unsqueeze(-2)
                 gc = gc + (direct.sum(0, keepdim=True) if batch_idx is None else torch.zeros_like(c).index_add(0, batch_idx.long(), direct))
                 gcit = _like_cell_inv_t(gc if (cell_inv_t is None or cell_inv_t.reshape(-1, 3, 3).shape[0] == gc.shape[0]) else gc.sum(0, keepdim=True), cell_inv_t)
+                gcell = _cell_grad_without_cit(gc, cit, cell, cell_inv_t, need[cell_i])
         if batched:
-            return gpos if need[0] else None, gq, gmesh, None, None, None, gcit if need[6] else None
-        return gpos if need[0] else None, gq, gmesh, None, None, gcit if need[5] else None
+            return _fit(need, (gpos if need[0] else None, gq, gmesh, None, gcell, None, gcit if _n(need, 6) else None))
+        return _fit(need, (gpos if need[0] else None, gq, gmesh, gcell, None, gcit if _n(need, 5) else None))
     return backward
 
 
@@ -495,7 +530,8 @@ def _green_backward(ctx, g_green, g_sf2):
     a = alpha.to(k2.dtype).reshape(shape) if batched else alpha.to(k2.dtype).reshape(-1)[0]
     v = volume.to(k2.dtype).reshape(shape) if batched else volume.to(k2.dtype).reshape(-1)[0]
     gg = g_green * green
-    gk2 = -gg * (0.25 / (a * a) + 1.0 / k2) if need[0] else None
+    # G is masked to 0 where k^2 is (near) zero: keep 0 there instead of 0 * inf = NaN when a caller-supplied k_squared holds an exact zero
+    gk2 = torch.where(green != 0, -gg * (0.25 / (a * a) + 1.0 / torch.where(green != 0, k2, torch.ones_like(k2))), torch.zeros_like(gg)) if need[0] else None
     ga = gg * k2 / (2.0 * a * a * a)
     gv = -gg / v
     red = (1, 2, 3) if batched else None

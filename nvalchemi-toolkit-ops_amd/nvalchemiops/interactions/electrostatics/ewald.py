@@ -74,7 +74,9 @@ def ewald_real_space(positions: torch.Tensor, charges: torch.Tensor, cell: torch
 
     Every stored entry (i, j, S) contributes to E_i, -f to F_i and +f to F_j, and to both charge gradients, exactly as in the
     reference (ewald_kernels.py:518-544, :864-873); pass a FULL (symmetric) list for physically meaningful totals -- that case runs
-    without atomics.  Returns ``energies`` | ``(energies, forces)`` | ``(energies, charge_grads)`` | ``(energies, forces, charge_grads)``."""
+    without atomics.  Whether the list is symmetric is decided on the device by comparing two 64-bit checksums (entries as stored vs
+    mirrored); a non-symmetric list passing as symmetric needs a 64-bit collision (~2^-64 per call) -- the one probabilistic step on
+    this path.  Returns ``energies`` | ``(energies, forces)`` | ``(energies, charge_grads)`` | ``(energies, forces, charge_grads)``."""
     if neighbor_list is None and neighbor_matrix is None:
         raise ValueError("Either neighbor_list or neighbor_matrix must be provided")
     if neighbor_list is not None and neighbor_ptr is None:

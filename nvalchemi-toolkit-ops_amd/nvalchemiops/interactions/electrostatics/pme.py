@@ -37,7 +37,11 @@ def _alpha_constant(value: float, num_systems: int, dtype: torch.dtype, device: 
 def _prepare_alpha(alpha: float | torch.Tensor, num_systems: int, dtype: torch.dtype, device: torch.device) -> torch.Tensor:
     """float | 0-d tensor | (B,) tensor -> (B,) tensor (pme.py:191-229)."""
     if isinstance(alpha, (int, float)):
-        return _alpha_constant(float(alpha), int(num_systems), dtype, torch.device(device))
+        dev = torch.device(device)
+        if dev.type == "cuda" and torch.cuda.is_current_stream_capturing():
+            # a tensor first created inside a HIP-graph capture lives in that graph's private pool: never cache it for later calls
+            return torch.full((num_systems,), float(alpha), dtype=dtype, device=dev)
+        return _alpha_constant(float(alpha), int(num_systems), dtype, dev)
     if isinstance(alpha, torch.Tensor):
         if alpha.dim() == 0:
             return alpha.expand(num_systems).to(dtype=dtype, device=device)
@@ -184,6 +188,16 @@ def _reciprocal_fused(pos, q, cells, alpha, mesh_dimensions, spline_order, bi, c
     if k_squared is not None:
         k2 = k_squared.detach().to(dt).contiguous()
         kv = k_vectors.detach().to(dt).contiguous() if (k_vectors is not None and compute_forces) else None
+        # the kernel indexes these through raw pointers: check the layout here (the composed path would fail in torch broadcasting)
+        half = (nx, ny, nz // 2 + 1)
+        if tuple(k2.shape[-3:]) != half or k2.dim() not in (3, 4) or (k2.dim() == 4 and k2.shape[0] not in (1, nsys)):
+            raise ValueError(f"k_squared must have shape {half} or (B, {nx}, {ny}, {nz // 2 + 1}) with B in (1, {nsys}) -- the rfft half grid of "
+                             f"generate_k_vectors_pme -- got {tuple(k_squared.shape)}")
+        if kv is not None:
+            if tuple(kv.shape[-4:]) != half + (3,) or kv.dim() not in (4, 5) or (kv.dim() == 5 and kv.shape[0] not in (1, nsys)):
+                raise ValueError(f"k_vectors must have shape {half + (3,)} or (B,) + that with B in (1, {nsys}), got {tuple(k_vectors.shape)}")
+            if (kv.dim() == 5 and kv.shape[0] == nsys and nsys > 1) != (k2.dim() == 4 and k2.shape[0] == nsys and nsys > 1):
+                raise ValueError("k_vectors and k_squared must both be shared by all systems or both carry the batch dimension")
     k_batched = int(k2 is not None and k2.dim() == 4 and k2.shape[0] == nsys and nsys > 1)
     rc = C.lib().mi_pme_convolve(C.ptr(spec), C.ptr(recip), C.ptr(al), C.ptr(vol), nsys, nx, ny, nz, int(spline_order), int(compute_forces), code,
                                  C.ptr(kv), C.ptr(k2), k_batched, C.ptr(conv), st)

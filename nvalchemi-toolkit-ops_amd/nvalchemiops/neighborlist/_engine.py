@@ -69,6 +69,23 @@ def neighbor_matrix(pos, cell, pbc, batch_idx, cutoff, max_neighbors, fill_value
         max_neighbors=max_neighbors, fill_value=fill_value, origin=origin)
 
 
+def neighbor_matrix_dual(pos, cell, pbc, batch_idx, cutoff_short, cutoff_long, fill_value, half_fill, short, long_, *, naive=True, want_shifts=True,
+                         origin=None):
+    """ONE sweep over the candidate pairs fills both padded matrices (`mi_nl_neighbors_dual`): `short` / `long_` = (nm, nsh | None, num)."""
+    flags = (C.NL_HALF_FILL if half_fill else 0) | (C.NL_NAIVE_EXPR if naive else 0)
+    if not want_shifts:
+        flags |= C.NL_NO_SHIFTS
+    n, nsys = pos.shape[0], cell.shape[0]
+    ws = workspace(n, nsys, pos.dtype, pos.device)
+    (nm1, nsh1, num1), (nm2, nsh2, num2) = short, long_
+    rc = C.lib().mi_nl_neighbors_dual(
+        C.ptr(pos), n, C.ptr(cell), C.ptr(pbc), C.ptr(batch_idx), nsys, C.cdouble(cutoff_short), C.cdouble(cutoff_long), C.dtype_code(pos.dtype), flags,
+        C.ptr(nm1), C.ptr(nsh1 if want_shifts else None), C.ptr(num1), int(nm1.shape[1]),
+        C.ptr(nm2), C.ptr(nsh2 if want_shifts else None), C.ptr(num2), int(nm2.shape[1]),
+        int(fill_value), C.ptr(origin), C.ptr(ws), ctypes.c_size_t(ws.numel()), C.stream_of(pos))
+    C.check(rc, "mi_nl_neighbors_dual")
+
+
 def neighbor_csr(pos, cell, pbc, batch_idx, cutoff, half_fill, *, naive=False, want_shifts=True, max_neighbors=None, origin=None):
     """Direct COO/CSR emission: count pass -> prefix sum -> fill pass (the padded matrix is never materialised).
 

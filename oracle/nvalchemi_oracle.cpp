@@ -818,6 +818,15 @@ void orc_naive(int dtype, const void* pos, int N, const void* cell, const uint8_
            naive_reference<double>((const double*)pos, N, (const double*)cell, pbc, cutoff * cutoff, cutoff, M, fill_value, half_fill, nm, nsh, num));
 }
 
+// The dual-cutoff kernels (naive_dual_cutoff.py:115-290) walk ONE shift table, built for cutoff2 (:835), and nest the cutoff1 test inside
+// the cutoff2 test: list 1 of a dual call = the naive search for cutoff1 with the IMAGE RANGE of cutoff2.
+void orc_naive_range(int dtype, const void* pos, int N, const void* cell, const uint8_t* pbc, double cutoff, double range_cutoff, int M,
+                     int fill_value, int half_fill, int* nm, int* nsh, int* num) {
+  DISPATCH(dtype,
+           naive_reference<float>((const float*)pos, N, (const float*)cell, pbc, float(cutoff * cutoff), range_cutoff, M, fill_value, half_fill, nm, nsh, num),
+           naive_reference<double>((const double*)pos, N, (const double*)cell, pbc, cutoff * cutoff, range_cutoff, M, fill_value, half_fill, nm, nsh, num));
+}
+
 void orc_dftd3(int dtype, const void* pos, const int* numbers, int N, const int* jidx, const int* ushift, const int* ptr, int M,
                int fill_value, const void* cell, const int* batch_idx, int B, const float* rcov, const float* r4r2,
                const float* c6ab, const float* cnref, int nz, double a1, double a2, double s6, double s8, double k1, double k3,

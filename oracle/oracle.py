@@ -217,7 +217,9 @@ def moved_beyond_skin(reference_positions, current_positions, threshold) -> bool
     return bool(lib().orc_moved_beyond_skin(_dt(ref), _p(ref), _p(cur), ref.shape[0], ctypes.c_double(threshold)))
 
 
-def naive(positions, cutoff, cell=None, pbc=None, max_neighbors=None, fill_value=None, half_fill=False):
+def naive(positions, cutoff, cell=None, pbc=None, max_neighbors=None, fill_value=None, half_fill=False, image_range_cutoff=None):
+    """`image_range_cutoff`: the cutoff the periodic-image table is built for when it is not `cutoff` itself -- list 1 of the reference's
+    dual-cutoff kernels uses the table of cutoff2 (naive_dual_cutoff.py:835, :215-226)."""
     pos = _c(positions)
     n = pos.shape[0]
     m = estimate_max_neighbors(cutoff) if max_neighbors is None else int(max_neighbors)
@@ -227,7 +229,11 @@ def naive(positions, cutoff, cell=None, pbc=None, max_neighbors=None, fill_value
     sh = np.zeros((n, m, 3), np.int32) if cell is not None else None
     c = None if cell is None else _c(cell, pos.dtype).reshape(3, 3)
     pb = None if pbc is None else _c(np.asarray(pbc).reshape(3), np.uint8)
-    lib().orc_naive(_dt(pos), _p(pos), n, _p(c), _p(pb), ctypes.c_double(cutoff), m, fv, int(half_fill), _p(nm), _p(sh), _p(num))
+    if image_range_cutoff is None:
+        lib().orc_naive(_dt(pos), _p(pos), n, _p(c), _p(pb), ctypes.c_double(cutoff), m, fv, int(half_fill), _p(nm), _p(sh), _p(num))
+    else:
+        lib().orc_naive_range(_dt(pos), _p(pos), n, _p(c), _p(pb), ctypes.c_double(cutoff), ctypes.c_double(image_range_cutoff), m, fv,
+                              int(half_fill), _p(nm), _p(sh), _p(num))
     return (nm, num, sh) if cell is not None else (nm, num)
 
 

@@ -507,3 +507,46 @@ def test_gather_gradient_adjoint_vs_finite_differences(order):
             cm[cidx] -= h
             fd = float(loss(pos, q, mesh, cp) - loss(pos, q, mesh, cm)) / (2 * h)
             assert abs(fd - float(tc.grad[cidx])) < 5e-6 * max(1.0, abs(fd)), (batched, cidx, fd, float(tc.grad[cidx]))
+
+
+def test_direct_op_calls_without_cell_inv_t_give_the_cell_gradient():
+    """The spline ops keep the reference signature, where `cell_inv_t` is optional (spline.py:757-1040).  Called directly without it, the
+    op forms cell^-T from `cell` itself, so the gradient has to arrive at `cell` (round-2 ADVICE: it used to be silently None): the same
+    number as through the public wrappers, which always pass cell^-T as a differentiable function of the cell."""
+    from nvalchemiops import _eops  # noqa: F401
+    from nvalchemiops.spline import spline_gather, spline_gather_vec3, spline_spread
+
+    O = torch.ops.alchemiops
+    pos, cell, q = _system(24)
+    dims = (9, 10, 8)
+    field = torch.randn(dims, dtype=torch.float64, device=DEV)
+    vfield = torch.randn(dims + (3,), dtype=torch.float64, device=DEV)
+    w = torch.randn(24, dtype=torch.float64, device=DEV)
+    w3 = torch.randn((24, 3), dtype=torch.float64, device=DEV)
+    bi = torch.zeros(24, dtype=torch.int32, device=DEV)
+    bi[12:] = 1
+    cells2 = torch.stack([cell, cell * 1.07])
+    for order in (3, 4):
+        cases = [
+            (lambda c: (O._spline_spread(pos, q, c, *dims, order) * field).sum(), lambda c: (spline_spread(pos, q, c, dims, order) * field).sum(), cell),
+            (lambda c: (O._spline_gather(pos, field, c, order) * w).sum(), lambda c: (spline_gather(pos, field, c, order) * w).sum(), cell),
+            (lambda c: (O._spline_gather_vec3(pos, q, vfield, c, order) * w3).sum(), lambda c: (spline_gather_vec3(pos, q, vfield, c, order) * w3).sum(), cell),
+            (lambda c: (O._spline_gather_gradient(pos, q, field, c, order) * w3).sum(), None, cell),
+            (lambda c: (O._batch_spline_gather(pos, torch.stack([field, field * 0.5]), bi, c, order) * w).sum(), None, cells2),
+        ]
+        for direct, public, c0 in cases:
+            c = c0.clone().requires_grad_(True)
+            (g_direct,) = torch.autograd.grad(direct(c), (c,), allow_unused=True)
+            assert g_direct is not None, "the cell gradient of a direct op call must not be silently missing"
+            if public is not None:
+                c2 = c0.clone().requires_grad_(True)
+                (g_public,) = torch.autograd.grad(public(c2), (c2,))
+                assert torch.allclose(g_direct, g_public, rtol=1e-9, atol=1e-11)
+            eps = 1e-6
+            for (a, b) in ((0, 0), (2, 1)):
+                cp, cm = c0.clone(), c0.clone()
+                idx = (a, b) if c0.dim() == 2 else (1, a, b)
+                cp[idx] += eps
+                cm[idx] -= eps
+                fd = (direct(cp) - direct(cm)).item() / (2 * eps)
+                assert abs(fd - g_direct[idx].item()) < 2e-5 * max(1.0, abs(fd)), (order, idx, fd, g_direct[idx].item())

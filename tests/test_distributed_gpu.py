@@ -24,7 +24,6 @@ def _free_port():
 
 
 def _batch(dev):
-    from oracle import oracle as O
     from tests import systems as S
 
     counts = [500, 864, 256, 700, 500, 864]  # ragged: the partition is by atom count
@@ -35,7 +34,7 @@ def _batch(dev):
              numbers=t(np.concatenate([p[3] for p in parts])), pos_b=t((pos * BOHR).astype(np.float32)),
              cell_b=t((np.stack([p[1] for p in parts]) * BOHR).astype(np.float32)),
              ptr=torch.tensor(np.concatenate([[0], np.cumsum(counts)]), dtype=torch.int32))
-    return d, counts, O.d3_test_tables(17)
+    return d, counts, S.d3_test_tables(17)
 
 
 def _step(pos, cell, q, numbers, pos_b, cell_b, bi, nsys, tables, dev):
@@ -58,16 +57,17 @@ def _step(pos, cell, q, numbers, pos_b, cell_b, bi, nsys, tables, dev):
     return torch.stack([e_d3.double(), segment_energy(e_pme, bi, nsys)], dim=1)
 
 
-def _worker(rank, world, port, out):
+def _worker(rank, world, port, out, backend="gloo", own_device=False):
     import torch.distributed as dist
 
     sys.path[:0] = [ROOT, os.path.join(ROOT, "nvalchemi-toolkit-ops_amd")]
     from nvalchemiops.distributed import all_gather_system_values, partition_systems, shard_batch
 
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    dev = torch.device("cuda", 0)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dev = torch.device("cuda", rank if own_device else 0)
     torch.cuda.set_device(dev)
+    dist.init_process_group(backend, rank=rank, world_size=world, **({"device_id": dev} if backend == "nccl" else {}))
     d, counts, tables = _batch(dev)
     s0, s1, a0, a1, bi, (pos, q, numbers, pos_b), (cell, cell_b) = shard_batch(
         d["ptr"], rank, world, d["pos"], d["q"], d["numbers"], d["pos_b"], per_system=(d["cell"], d["cell_b"]))
@@ -98,6 +98,22 @@ def test_two_ranks_sharded_batch_step_equals_single_rank():
     assert np.all(np.abs(s) > 1e-3)
 
 
+def test_two_ranks_over_rccl_one_gpu_each():
+    """The same sharded step with `backend="nccl"` (RCCL on ROCm), one rank per GPU: runs wherever the box has >= 2 GPUs, so that the
+    first multi-GPU driver run is not the first execution of the RCCL branch (`all_gather_system_values` on device tensors)."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip(f"needs >= 2 GPUs for an RCCL process group (this box has {torch.cuda.device_count()}); the gloo variant above covers the "
+                    "same code path on one device")
+    import torch.multiprocessing as mp
+
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(2, _free_port(), out, "nccl", True), nprocs=2, join=True)
+    g, s = out["gathered"], out["single"]
+    np.testing.assert_allclose(g[:, 0], s[:, 0], rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(g[:, 1], s[:, 1], rtol=1e-10, atol=1e-10)
+
+
 @pytest.mark.parametrize("workload", ["headline", "c5"])
 def test_bench_launches_its_own_ranks(workload):
     """`python bench.py --gpus 2` with no launcher and no WORLD_SIZE: two ranks (sharing the device over gloo on a 1-GPU box), n_gpus 2."""
@@ -110,3 +126,7 @@ def test_bench_launches_its_own_ranks(workload):
     res = json.loads(line)
     assert res["n_gpus"] == 2 and res["config"]["ranks"] == 2 and res["value"] > 0
     assert res["config"]["atoms_per_gpu"] == (20000 if workload == "headline" else 8000)
+    per_rank = res["ranks"]
+    assert len(per_rank["ms_per_step"]) == 2 and per_rank["imbalance_max_over_min"] >= 1.0
+    if workload == "c5":
+        assert per_rank["all_gather_us_median"] is not None and per_rank["all_gather_us_median"] > 0

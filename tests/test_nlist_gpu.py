@@ -326,6 +326,46 @@ def test_dual_cutoff_and_batch_naive(periodic):
     assert (rd[1].cpu().numpy()[:300] == out[1].cpu().numpy()).all() and (rd[half + 1].cpu().numpy() == numb).all()
 
 
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_dual_cutoff_is_one_sweep_with_the_image_table_of_the_long_cutoff(dtype):
+    """The reference's dual-cutoff kernels walk ONE shift table, built for cutoff2, and nest the cutoff1 test in the cutoff2 test
+    (naive_dual_cutoff.py:215-226, :835).  With atoms far outside the cell (the naive family never wraps) list 1 therefore holds pairs that a
+    separate cutoff1 search -- image range of cutoff1 -- cannot see; `mi_nl_neighbors_dual` reproduces the reference, single and batched,
+    including the counts of rows that overflow their matrix."""
+    from nvalchemiops.neighborlist import batch_naive_neighbor_list_dual_cutoff, naive_neighbor_list_dual_cutoff
+
+    g = np.random.default_rng(77)
+    cell = (np.diag([4.0, 4.4, 3.8]) + np.array([[0, 0, 0], [0.6, 0, 0], [-0.4, 0.5, 0]])).astype(dtype)
+    pos = (g.uniform(-1.6, 2.6, (150, 3)) @ cell).astype(dtype)
+    pbc = np.array([True, True, True])
+    rc1, rc2, m = 1.5, 4.6, 2048
+    kw = dict(cell=_t(cell).reshape(1, 3, 3), pbc=_t(pbc).reshape(1, 3))
+    out = naive_neighbor_list_dual_cutoff(_t(pos), rc1, rc2, max_neighbors1=m, max_neighbors2=m, **kw)
+    ref1 = O.naive(pos, rc1, cell, pbc, m, image_range_cutoff=rc2)
+    ref2 = O.naive(pos, rc2, cell, pbc, m)
+    sep1 = O.naive(pos, rc1, cell, pbc, m)
+    assert int(ref1[1].sum()) > int(sep1[1].sum()), "the case must discriminate between the two image tables"
+    for res, ref in ((out[:3], ref1), (out[3:], ref2)):
+        nm, num, sh = (t.cpu().numpy() for t in res)
+        assert np.array_equal(num, ref[1]) and num.max() <= m
+        assert np.array_equal(O.canonical_pairs(nm, num, sh), O.canonical_pairs(*ref))
+    # rows that overflow: counts keep counting (both lists), stored entries are a subset of the reference's pair set
+    small = naive_neighbor_list_dual_cutoff(_t(pos), rc1, rc2, max_neighbors1=8, max_neighbors2=32, **kw)
+    assert np.array_equal(small[1].cpu().numpy(), ref1[1]) and np.array_equal(small[4].cpu().numpy(), ref2[1])
+    assert int(small[4].max()) > 32 and small[3].shape == (150, 32)
+    # batched: the same system twice (second copy translated); list 1 of each copy = the single-system list 1
+    posb = np.concatenate([pos, pos + np.asarray([0.3, -0.2, 0.9], dtype)])
+    bi = _t(np.repeat(np.arange(2, dtype=np.int32), 150))
+    rb = batch_naive_neighbor_list_dual_cutoff(_t(posb), rc1, rc2, batch_idx=bi, cell=_t(np.stack([cell, cell])), pbc=_t(np.stack([pbc, pbc])),
+                                               max_neighbors1=m, max_neighbors2=m)
+    n1, n2 = rb[1].cpu().numpy(), rb[4].cpu().numpy()
+    assert np.array_equal(n1[:150], ref1[1]) and np.array_equal(n2[:150], ref2[1])
+    if dtype == np.float64:  # (in fp32 the translated copy rounds differently: pairs on the cutoff edge may flip)
+        assert int(n1[150:].sum()) == int(n1[:150].sum()) and int(n2[150:].sum()) == int(n2[:150].sum())
+    first = O.canonical_pairs(rb[0].cpu().numpy()[:150], n1[:150], rb[2].cpu().numpy()[:150])
+    assert np.array_equal(first, O.canonical_pairs(*ref1))
+
+
 def test_custom_ops_and_graph_capture():
     """The reference's op seam (`torch.ops.nvalchemiops.*`, cell_list.py:725/892, dftd3.py:1792): same results as the functional
     API, and traceable as opaque mutating ops by torch.compile (fullgraph, aot_eager backend: no code generation involved)."""

@@ -190,6 +190,26 @@ def test_pme_reciprocal_matches_oracle(dtype, order):
     _close(e_only, ref[0], dtype, "energies only")
 
 
+def test_caller_supplied_k_arrays_are_shape_checked():
+    """The fused k-space pass reads caller-supplied k arrays through raw pointers ([nx, ny, nz/2+1(, 3)], optionally with a leading batch
+    dimension): anything else must raise before the launch instead of mis-indexing on the device (round-2 ADVICE)."""
+    from nvalchemiops.interactions.electrostatics import generate_k_vectors_pme, pme_reciprocal_space
+
+    pos, cell, q = _system(64, np.float64, seed=3)
+    dims = (12, 10, 14)
+    kv, k2 = generate_k_vectors_pme(_t(cell), dims)
+    kw = dict(mesh_dimensions=dims, spline_order=4, compute_forces=True)
+    ok = pme_reciprocal_space(_t(pos), _t(q), _t(cell), 0.4, k_vectors=kv, k_squared=k2, **kw)
+    assert torch.isfinite(ok[0]).all()
+    full = torch.zeros(dims, dtype=torch.float64, device=DEV)  # the full-FFT grid instead of the rfft half grid
+    with pytest.raises(ValueError, match="k_squared must have shape"):
+        pme_reciprocal_space(_t(pos), _t(q), _t(cell), 0.4, k_vectors=kv, k_squared=full, **kw)
+    with pytest.raises(ValueError, match="k_vectors must have shape"):
+        pme_reciprocal_space(_t(pos), _t(q), _t(cell), 0.4, k_vectors=kv[..., :2], k_squared=k2, **kw)
+    with pytest.raises(ValueError, match="k_squared must have shape"):
+        pme_reciprocal_space(_t(pos), _t(q), _t(cell), 0.4, k_vectors=kv, k_squared=k2.unsqueeze(0).expand(3, -1, -1, -1).contiguous(), **kw)
+
+
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
 def test_pme_batch_matches_oracle_and_single(dtype):
     from nvalchemiops.interactions.electrostatics import particle_mesh_ewald

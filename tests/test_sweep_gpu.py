@@ -180,10 +180,10 @@ def test_naive_family_sweep(seed):
     okw = dict(cell=cell, pbc=pbc) if periodic else {}
     m = 1024
 
-    def same(res, rc):
+    def same(res, rc, image_range=None):
         nm, num = res[0].cpu().numpy(), res[1].cpu().numpy()
         sh = res[2].cpu().numpy() if periodic else np.zeros(nm.shape + (3,), np.int32)
-        ref = O.naive(pos, rc, max_neighbors=m, half_fill=half, **okw)
+        ref = O.naive(pos, rc, max_neighbors=m, half_fill=half, image_range_cutoff=image_range, **okw)
         rsh = ref[2] if periodic else np.zeros(ref[0].shape + (3,), np.int32)
         assert ref[1].max() <= m
         if half:  # one direction per pair: compare as unordered pairs
@@ -203,7 +203,8 @@ def test_naive_family_sweep(seed):
     same(naive_neighbor_list(_t(pos), rc2, max_neighbors=m, half_fill=half, **kw), rc2)
     out = naive_neighbor_list_dual_cutoff(_t(pos), rc1, rc2, max_neighbors1=m, max_neighbors2=m, half_fill=half, **kw)
     k = len(out) // 2
-    same(out[:k], rc1), same(out[k:], rc2)
+    # one sweep, one image table (that of cutoff2) for both lists, list 1 nested in list 2 (naive_dual_cutoff.py:215-226, :835)
+    same(out[:k], rc1, image_range=rc2), same(out[k:], rc2)
     # the same system twice in a batch (second copy translated by a lattice-independent vector)
     posb = np.concatenate([pos, pos + np.asarray([0.7, -1.1, 0.4], dtype)])
     bi = _t(np.repeat(np.arange(2, dtype=np.int32), n))
