@@ -12,8 +12,9 @@ the HIP kernels, with
     real-space sum uses `mi_ewald_real_bwd`, the explicit-k sum two more passes of its forward kernels.
 The real-space FORCES and CHARGE GRADIENTS are differentiable too (`mi_ewald_real_forces_bwd`: second derivatives of the pair sum), so a
 loss on total PME forces or charge gradients back-propagates to positions, charges, cell and alpha; so are the cut-off Coulomb forces and
-`spline_gather_gradient`, and the forces / charge gradients of the explicit-k reciprocal sum (positions, charges, alpha, cell volume).  Not
-provided (explicit NotImplementedError, never a silent zero): the k-vector gradient of those explicit-k outputs.
+`spline_gather_gradient`, and the forces / charge gradients of the explicit-k reciprocal sum (positions, charges, alpha, cell volume and --
+round 3 -- the k-vectors: every array the reference lists in `grad_arrays` has its adjoint here).  Third derivatives raise
+NotImplementedError (never a silent zero).
 
 The public functions (`spline_spread`, `particle_mesh_ewald`, ...) call these ops when something requires grad or when they are
 being traced; otherwise they take the direct ctypes path (no dispatcher overhead, fused kernels).
@@ -857,23 +858,25 @@ recip_bwd_op.register_autograd(lambda ctx, *g: (_ for _ in ()).throw(NotImplemen
 
 
 def _recip_out_bwd(positions: Tensor, charges: Tensor, cell: Tensor, k_vectors: Tensor, alpha: Tensor, batch_idx: Optional[Tensor],
-                   grad_forces: Optional[Tensor], grad_charge_grads: Optional[Tensor], need: int) -> tuple[Tensor, Tensor, Tensor, Tensor]:
-    """Float64 (dL/dpositions, dL/dcharges, dL/dcell [B,3,3], dL/dalpha [B]) for L = sum_i grad_forces_i . F_i + sum_i grad_charge_grads_i cg_i
-    of the explicit-k reciprocal sum (`_recip_outputs_adjoint`); `need` bits: 2 cell (through the volume), 8 alpha."""
+                   grad_forces: Optional[Tensor], grad_charge_grads: Optional[Tensor], need: int) -> tuple[Tensor, Tensor, Tensor, Tensor, Tensor]:
+    """Float64 (dL/dpositions, dL/dcharges, dL/dcell [B,3,3], dL/dalpha [B], dL/dk_vectors [B,K,3]) for L = sum_i grad_forces_i . F_i +
+    sum_i grad_charge_grads_i cg_i of the explicit-k reciprocal sum (`_recip_outputs_adjoint`); `need` bits: 2 cell (through the volume),
+    4 k_vectors, 8 alpha."""
     from nvalchemiops.interactions.electrostatics.ewald import _recip_inputs, _recip_outputs_adjoint
 
     p = _recip_inputs(positions, charges, cell, k_vectors, alpha, batch_idx)
-    n, nsys, dev = positions.shape[0], p["n_sys"], positions.device
+    n, nsys, nk, dev = positions.shape[0], p["n_sys"], p["n_k"], positions.device
     f64 = dict(dtype=torch.float64, device=dev)
-    zeros = (torch.zeros((n, 3), **f64), torch.zeros(n, **f64), torch.zeros((nsys, 3, 3), **f64), torch.zeros(nsys, **f64))
-    if n == 0 or p["n_k"] == 0 or (grad_forces is None and grad_charge_grads is None):
+    zeros = (torch.zeros((n, 3), **f64), torch.zeros(n, **f64), torch.zeros((nsys, 3, 3), **f64), torch.zeros(nsys, **f64),
+             torch.zeros((nsys, nk, 3), **f64))
+    if n == 0 or nk == 0 or (grad_forces is None and grad_charge_grads is None):
         return zeros
-    gpos, gq, gal, gvol = _recip_outputs_adjoint(p, grad_forces, grad_charge_grads, bool(need & 8), bool(need & 2))
+    gpos, gq, gal, gvol, gkv = _recip_outputs_adjoint(p, grad_forces, grad_charge_grads, bool(need & 8), bool(need & 2), bool(need & 4))
     gcell = zeros[2]
     if gvol is not None:
         c64 = p["cells"].to(torch.float64)
         gcell = (gvol * torch.abs(torch.linalg.det(c64))).reshape(-1, 1, 1) * torch.linalg.inv(c64).transpose(-1, -2)
-    return gpos, gq, gcell, gal if gal is not None else zeros[3]
+    return gpos, gq, gcell, gal if gal is not None else zeros[3], gkv if gkv is not None else zeros[4]
 
 
 def _recip_out_bwd_fake(positions, charges, cell, k_vectors, alpha, batch_idx, grad_forces, grad_charge_grads, need):
@@ -881,7 +884,7 @@ def _recip_out_bwd_fake(positions, charges, cell, k_vectors, alpha, batch_idx, g
     n = positions.shape[0]
     f64 = dict(dtype=torch.float64)
     return (positions.new_empty((n, 3), **f64), positions.new_empty((n,), **f64), positions.new_empty((nsys, 3, 3), **f64),
-            positions.new_empty((nsys,), **f64))
+            positions.new_empty((nsys,), **f64), positions.new_empty((nsys, k_vectors.shape[-2], 3), **f64))
 
 
 recip_out_bwd_op = torch.library.custom_op("nvalchemiops::ewald_reciprocal_space_outputs_backward", _recip_out_bwd, mutates_args=())
@@ -913,11 +916,9 @@ def _recip_backward(name, n_out):
             mask = (1 if need[0] or need[1] else 0) | (2 if need[2] else 0) | (4 if need[3] else 0) | (8 if need[4] else 0)
             gpos, gq, gcell, gkv, gal = recip_bwd_op(positions, charges, cell, k_vectors, alpha, bi, g_e, mask)
         if g_f is not None or g_c is not None:
-            if need[3]:
-                raise NotImplementedError(f"alchemiops::{name}: the gradient of the forces / charge_gradients outputs w.r.t. k_vectors is not provided "
-                                          "(positions, charges, alpha and the cell volume are); detach the k-vectors or differentiate the energies.")
-            fp, fq, fc, fa = recip_out_bwd_op(positions, charges, cell, k_vectors, alpha, bi, g_f, g_c, (2 if need[2] else 0) | (8 if need[4] else 0))
-            gpos, gq, gcell, gal = (fp, fq, fc, fa) if gpos is None else (gpos + fp, gq + fq, gcell + fc, gal + fa)
+            fp, fq, fc, fa, fk = recip_out_bwd_op(positions, charges, cell, k_vectors, alpha, bi, g_f, g_c,
+                                                  (2 if need[2] else 0) | (4 if need[3] else 0) | (8 if need[4] else 0))
+            gpos, gq, gcell, gal, gkv = (fp, fq, fc, fa, fk) if gpos is None else (gpos + fp, gq + fq, gcell + fc, gal + fa, gkv + fk)
         if need[3] and gkv.shape != k_vectors.shape:  # one [K,3] set shared by all systems (or a [1,K,3] one)
             gkv = gkv.sum(0).reshape(k_vectors.shape)
         if need[4]:

@@ -270,7 +270,7 @@ def _recip_adjoint(p, g_e, need_atoms: bool, need_kv: bool, need_alpha: bool, ne
     return gpos, gch, gkv, gal, gvol
 
 
-def _recip_outputs_adjoint(p, g_f, g_c, need_alpha: bool, need_vol: bool):
+def _recip_outputs_adjoint(p, g_f, g_c, need_alpha: bool, need_vol: bool, need_kv: bool = False):
     """Adjoint of the explicit FORCES and CHARGE GRADIENTS of the reciprocal sum, L = sum_i W_i . F_i + sum_i v_i cg_i (W = g_f, v = g_c).
     With c_ik / s_ik = cos / sin(k.r_i), Qc / Qs the charge sums, a_ik = q_i (W_i . k), As / Ac its sine / cosine sums, Vc / Vs those of v:
         L = sum_k G_k (Qc As - Qs Ac + Qc Vc + Qs Vs) - 2 alpha/sqrt(pi) sum v_i q_i - pi/alpha^2 (Q/V) sum v_i.
@@ -279,8 +279,14 @@ def _recip_outputs_adjoint(p, g_f, g_c, need_alpha: bool, need_vol: bool):
         dL/dq_m = phi_m[S''] + W_m . kf_m[S^q] - 2 alpha v_m/sqrt(pi) - pi/alpha^2 sum v / V
         dL/dalpha = sum_k X_k k^2/(2 alpha^3) - 2/sqrt(pi) sum v_i q_i + 2 pi/alpha^3 (Q/V) sum v ,  X_k = Re[conj(S^q) S'']/G_k
         dL/dV     = -1/V sum_k X_k + pi/alpha^2 (Q/V^2) sum v.
-    Five structure-factor passes and three gathers of the forward kernels' cost.  Gradients w.r.t. the k-vectors are not provided.
-    Returns float64 (dL/dpositions, dL/dcharges, dL/dalpha [B] | None, dL/dV [B] | None)."""
+    Five structure-factor passes and three gathers of the forward kernels' cost.
+    k-vectors (`need_kv`; the reference lists them in `grad_arrays` of the force / charge-gradient ops, ewald.py:1481-1489, :1948, :2125 --
+    the route by which a cell that generated the k-vectors receives the gradient of the forces): with L_k the k-th term of the sum above,
+        dL/dk = L_k (-2 k)(1/(4 alpha^2) + 1/k^2)                                                              (through G_k)
+              + G [ -S[q r] (As + Vc) + C[q r] (-Ac + Vs) + Qc (S[q W] + sum_e k_e C[q W_e r] - S[v r]) + Qs (-C[q W] + sum_e k_e S[q W_e r] + C[v r]) ]
+    where C[w] / S[w] = sum_i w_i cos / sin(k.r_i) are structure factors with VECTOR weights (q r_d, v r_d, q W_e r_d: 15 more passes of
+    `mi_ewald_structure_factors`; this is a second-order path, cf. the reference's test_cell_gradients).
+    Returns float64 (dL/dpositions, dL/dcharges, dL/dalpha [B] | None, dL/dV [B] | None, dL/dk_vectors [B,K,3] | None)."""
     pos, q, kv, cells, al, bi, sptr, max_atoms = (p[k] for k in ("pos", "q", "kv", "cells", "al", "bi", "sptr", "max_atoms"))
     n_sys, n_k, n, dev = p["n_sys"], p["n_k"], pos.shape[0], pos.device
     f64 = dict(dtype=torch.float64, device=dev)
@@ -311,8 +317,8 @@ def _recip_outputs_adjoint(p, g_f, g_c, need_alpha: bool, need_vol: bool):
     # pi/alpha^2 (Q/V) sum v: d/dq_m of Q/V is 1/V wherever the forward accumulated the charge at all (tq != 0 or Q == 0 with K > 1)
     charged = 1.0 if n_k > 1 else 0.0
     gq = b["potential"] + (W * a["kforce"]).sum(-1) - 2.0 * a_i * v / math.sqrt(math.pi) - charged * math.pi / (a_i * a_i) * (vsum / vol)[sel]
-    gal = gvol = None
-    if need_alpha or need_vol:
+    gal = gvol = gkv = None
+    if need_alpha or need_vol or need_kv:
         k2 = (kv64 * kv64).sum(-1)
         a2 = (al64 * al64).unsqueeze(1)
         ok = k2 >= 1e-10
@@ -326,7 +332,31 @@ def _recip_outputs_adjoint(p, g_f, g_c, need_alpha: bool, need_vol: bool):
             gal = (x * k2).sum(1) / (2.0 * al64**3) - 2.0 / math.sqrt(math.pi) * vq + 2.0 * math.pi / al64**3 * tq * vsum
         if need_vol:
             gvol = -x.sum(1) / vol + math.pi / (al64 * al64) * tq / vol * vsum
-    return gpos, gq, gal, gvol
+        if need_kv:
+            pos64 = pos.to(torch.float64)
+            gi = ginv.unsqueeze(-1)                                    # 1/G (0 where the Green function is masked)
+            # through G_k: x_k = L_k
+            gkv = (x * (-2.0) * (1.0 / (4.0 * a2) + torch.where(ok, 1.0 / k2s, torch.zeros_like(k2s)))).unsqueeze(-1) * kv64
+            cq, sq_ = sq[..., 0:1] * gi, sq[..., 1:2] * gi             # Qc, Qs
+            for d in range(3):
+                sqr = sf_of(q64 * pos64[:, d])[0]                      # G (C[q r_d], S[q r_d])
+                term = (-sqr[..., 1] * s2[..., 0] + sqr[..., 0] * s2[..., 1]) * ginv
+                inner_c = torch.zeros_like(k2)                         # G (dAs_d + dVc_d), G (-dAc_d + dVs_d)
+                inner_s = torch.zeros_like(k2)
+                if g_f is not None:
+                    sw = sf_of(q64 * W[:, d])[0]
+                    inner_c = inner_c + sw[..., 1]
+                    inner_s = inner_s - sw[..., 0]
+                    for e in range(3):
+                        swr = sf_of(q64 * W[:, e] * pos64[:, d])[0]
+                        inner_c = inner_c + kv64[..., e] * swr[..., 0]
+                        inner_s = inner_s + kv64[..., e] * swr[..., 1]
+                if g_c is not None:
+                    svr = sf_of(v * pos64[:, d])[0]
+                    inner_c = inner_c - svr[..., 1]
+                    inner_s = inner_s + svr[..., 0]
+                gkv[..., d] += term + cq[..., 0] * inner_c + sq_[..., 0] * inner_s
+    return gpos, gq, gal, gvol, gkv
 
 
 @C.traceable

@@ -348,8 +348,8 @@ def test_total_pme_forces_can_be_differentiated():
 def test_explicit_k_forces_and_charge_gradients_can_be_differentiated(batched):
     """L = sum_i W_i . F_i + sum_i v_i cg_i of the explicit-k reciprocal sum ("forces" / "charge_gradients" are in the grad_arrays of the
     reference's `_ewald_reciprocal_space_energy_forces[_charge_grad]` ops, ewald.py:1486-1496, :1632-1643) w.r.t. positions, charges, alpha and
-    the cell (through the volume, k-vectors held fixed): `_recip_outputs_adjoint` against central differences.  The k-vector gradient of these
-    outputs is the one thing without an adjoint: it raises, never a silent zero."""
+    the cell (through the volume, k-vectors held fixed) AND w.r.t. the k-vectors themselves: `_recip_outputs_adjoint` against central
+    differences."""
     from nvalchemiops.interactions.electrostatics import ewald_reciprocal_space, generate_k_vectors_ewald_summation
 
     pos, cell, q = _system(n=30, box=9.0, seed=4)
@@ -391,10 +391,44 @@ def test_explicit_k_forces_and_charge_gradients_can_be_differentiated(batched):
             da = torch.zeros_like(al); da[s_] = h
             fd = float(loss(pos, q, cells, al + da) - loss(pos, q, cells, al - da)) / (2 * h)
             assert abs(fd - float(ta.grad[s_])) < 2e-6 * max(1.0, abs(fd)), ("alpha", fd, float(ta.grad[s_]))
+    # k-vectors (reference: in grad_arrays of the force / charge-gradient ops, ewald.py:1481-1489): central differences on single entries ...
+    def loss_k(k):
+        e, f, cg = ewald_reciprocal_space(pos, q, cells, k, al, batch_idx=bi, compute_forces=True, compute_charge_gradients=True)
+        return (W * f).sum() + (v * cg).sum() + 0.3 * e.sum()
+
     kg = kv.clone().requires_grad_(True)
-    f = ewald_reciprocal_space(pos, q, cells, kg, al, batch_idx=bi, compute_forces=True)[1]
-    with pytest.raises(NotImplementedError, match="k_vectors"):
-        f.sum().backward()
+    loss_k(kg).backward()
+    assert kg.grad is not None and kg.grad.shape == kv.shape
+    with torch.no_grad():
+        picks = [(0, 0), (5, 2), (kvs[0].shape[0] - 1, 1)]
+        for (ik, d) in picks:
+            idx = (0, ik, d) if batched else (ik, d)
+            dk = torch.zeros_like(kv); dk[idx] = h
+            fd = float(loss_k(kv + dk) - loss_k(kv - dk)) / (2 * h)
+            assert abs(fd - float(kg.grad[idx])) < 5e-6 * max(1.0, abs(fd)), ("k-vector", idx, fd, float(kg.grad[idx]))
+        if batched:
+            idx = (1, 3, 0)
+            dk = torch.zeros_like(kv); dk[idx] = h
+            fd = float(loss_k(kv + dk) - loss_k(kv - dk)) / (2 * h)
+            assert abs(fd - float(kg.grad[idx])) < 5e-6 * max(1.0, abs(fd)), ("k-vector", idx, fd, float(kg.grad[idx]))
+    # ... and the route the reference's cell-gradient tests take: the k-vectors generated from a cell that requires grad, so that the
+    # FORCES' dependence on the cell shape reaches `cell` through them (single system)
+    if not batched:
+        def loss_cell(cc):
+            k = generate_k_vectors_ewald_summation(cc, 2.5)
+            e, f = ewald_reciprocal_space(pos, q, cc, k, al, compute_forces=True)
+            return (W * f).sum() + 0.3 * e.sum()
+
+        c = cells.clone().requires_grad_(True)
+        loss_cell(c).backward()
+        with torch.no_grad():
+            for (a_, b_) in ((0, 0), (1, 0), (2, 1)):
+                dc = torch.zeros_like(cells); dc[0, a_, b_] = h
+                kp, km = generate_k_vectors_ewald_summation(cells + dc, 2.5), generate_k_vectors_ewald_summation(cells - dc, 2.5)
+                if kp.shape != km.shape:  # (the k-set changed size under the perturbation: no central difference there)
+                    continue
+                fd = float(loss_cell(cells + dc) - loss_cell(cells - dc)) / (2 * h)
+                assert abs(fd - float(c.grad[0, a_, b_])) < 5e-6 * max(1.0, abs(fd)), ("cell through k", (a_, b_), fd, float(c.grad[0, a_, b_]))
 
 
 @pytest.mark.parametrize("kind", ["matrix", "half_csr"])
