@@ -622,6 +622,69 @@ def ref_pme(device):
 
 
 # ---- launcher -------------------------------------------------------------------------------------------------------------------------
+def pme_train(device, atoms: int = 100000, iters: int = 20):
+    """Training path of the electrostatics leg (reference protocol test_pme.py:1458,1571 / autograd.py:525-665):
+    `particle_mesh_ewald` on the headline box (9 A padded list built once, alpha 0.35, mesh 128^3, fp64), forward + backward through the
+    registered `alchemiops::*` ops and their hand-written adjoint kernels.  Two losses per spline order (4 = formula-identical to the
+    reference, 5 = the headline order):
+      energy        L = sum_i E_i                   backward = the forces by autograd (first-order adjoints)
+      energy+force  L = sum_i E_i + sum_i W_i.F_i   force matching: backward runs the second-order adjoints
+    Reports event-bracketed medians (ms): inference forward (no grad: the fused path), forward under grad, backward, and the adjoint kernels."""
+    from nvalchemiops import _capi as C
+    from nvalchemiops.interactions.electrostatics import particle_mesh_ewald
+    from nvalchemiops.neighborlist import cell_list
+    from tests import systems as S
+
+    pos, cell, q, _ = S.fcc_box(atoms, seed=1234, dtype=np.float64)
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a), device=device)  # noqa: E731
+    tp, tc, tq = t(pos), t(cell), t(q)
+    pbc = torch.tensor([True] * 3, device=device)
+    nm, num, nsh = cell_list(tp, PME["cutoff"], tc, pbc, max_neighbors=PME["max_neighbors"])
+    g = torch.Generator(device=device).manual_seed(3)
+    W = torch.randn((atoms, 3), dtype=torch.float64, device=device, generator=g)
+    rows = []
+    for order in (4, 5):
+        kw = dict(alpha=PME["alpha"], mesh_dimensions=PME["mesh"], spline_order=order, neighbor_matrix=nm, neighbor_matrix_shifts=nsh)
+        infer_e = _median_ms(lambda: particle_mesh_ewald(tp, tq, tc, **kw), 3, iters)[0]
+        infer_ef = _median_ms(lambda: particle_mesh_ewald(tp, tq, tc, compute_forces=True, **kw), 3, iters)[0]
+        for loss_kind in ("energy", "energy+force"):
+            def forward():
+                p = tp.detach().clone().requires_grad_(True)
+                if loss_kind == "energy":
+                    e = particle_mesh_ewald(p, tq, tc, **kw)
+                    return p, e.sum()
+                e, f = particle_mesh_ewald(p, tq, tc, compute_forces=True, **kw)
+                return p, e.sum() + (W * f).sum()
+
+            for _ in range(3):
+                p, loss = forward()
+                loss.backward()
+            torch.cuda.synchronize()
+            C.lib().mi_timing_enable(1)
+            fwd, bwd = [], []
+            for _ in range(iters):
+                a, b, c = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+                a.record()
+                p, loss = forward()
+                b.record()
+                loss.backward()
+                c.record()
+                c.synchronize()
+                fwd.append(a.elapsed_time(b))
+                bwd.append(b.elapsed_time(c))
+            C.lib().mi_timing_enable(0)
+            ker = {k: round(v[2], 4) for k, v in kernel_report().items()}
+            f_ms, b_ms = statistics.median(fwd), statistics.median(bwd)
+            rows.append({"spline_order": order, "loss": loss_kind, "forward_inference_ms": infer_e if loss_kind == "energy" else infer_ef,
+                         "forward_ms": f_ms, "backward_ms": b_ms, "backward_over_forward": b_ms / f_ms,
+                         "backward_over_inference_forward": b_ms / (infer_e if loss_kind == "energy" else infer_ef),
+                         "kernel_median_ms": ker, "grad_norm": float(p.grad.norm().item())})
+    return {"metric": "ms per training step of particle_mesh_ewald (forward + backward) on the 100k-atom box", "unit": "ms", "rows": rows,
+            "config": {"workload": f"{atoms}-atom periodic FCC box, nlist 9 A (M=256) built once, PME alpha 0.35, mesh 128^3, fp64; orders 4 and 5 "
+                                   "(5 = true B-spline: the reference evaluates order 5 as 0)"},
+            "dtype": "f64"}
+
+
 def _free_port() -> int:
     with socket.socket() as so:
         so.bind(("127.0.0.1", 0))
@@ -649,7 +712,7 @@ def main():
     ap.add_argument("--atoms", type=int, default=100000)
     ap.add_argument("--cpu-sample", type=int, default=6912, help="atoms in the CPU-baseline sample box (0 = skip the CPU baseline)")
     ap.add_argument("--cpu-full-size", action="store_true", help="also time ONE full 100k-atom step of the serial oracle (~1 min)")
-    ap.add_argument("--workload", default="headline", choices=["headline", "c5", "ref-nlist", "ref-d3", "ref-pme"],
+    ap.add_argument("--workload", default="headline", choices=["headline", "c5", "ref-nlist", "ref-d3", "ref-pme", "pme-train"],
                     help="headline: one 100k-atom box per GPU (default, the BASELINE metric); c5: BASELINE config 5, --systems x 2000-atom "
                          "boxes per GPU sharded at system granularity; ref-*: the reference's published benchmark rows (BASELINE.md)")
     ap.add_argument("--systems", type=int, default=128, help="systems per GPU for --workload c5")
@@ -686,10 +749,10 @@ def main():
 
     from nvalchemiops import _capi as C
 
-    if args.workload.startswith("ref-"):
+    if args.workload.startswith("ref-") or args.workload == "pme-train":
         if world > 1:
-            raise SystemExit("ref-* workloads are single-GPU (the reference's benchmarks are)")
-        res = {"ref-nlist": ref_nlist, "ref-d3": ref_d3, "ref-pme": ref_pme}[args.workload](device)
+            raise SystemExit("ref-* / pme-train workloads are single-GPU (the reference's benchmarks are)")
+        res = {"ref-nlist": ref_nlist, "ref-d3": ref_d3, "ref-pme": ref_pme, "pme-train": pme_train}[args.workload](device)
         res.update({"n_gpus": 1, "data": "synthetic", "higher_is_better": False, "workload": args.workload,
                     "protocol": "median of event-bracketed calls after warm-up (reference: benchmarks/utils.py:133-240)"})
         print(json.dumps(res), flush=True)

@@ -224,22 +224,27 @@ int mi_ewald_recip_gather_kk(const void* positions, const void* k_vectors, const
  *   dL/dcell[s][a][b] = -sum_i g_i sum_j fm_ij sep_ij[b] S_ij[a] ; dL/dalpha[s] = -sum_i g_i sum_j q_i q_j exp(-a^2 r^2)/sqrt(pi).
  * grad_cell / grad_alpha ([n_systems,3,3] / [n_systems], float64, zeroed by the caller) may be NULL.  `symmetry_scratch` as in
  * mi_ewald_real: a list that is not symmetric gets the general adjoint (entry (i -> j) carries g_i to both ends, atomics).      */
+size_t mi_ewald_real_bwd_scratch_bytes(int n_systems); /* symmetry checksums + slotted partials of the per-system sums (grad_cell / grad_alpha) */
 int mi_ewald_real_bwd(const void* positions, const void* charges, const void* cell, const void* alpha, const int32_t* batch_idx,
-                      int n_atoms, int dtype, const int32_t* idx_j, const int32_t* unit_shifts, const int32_t* neighbor_ptr,
+                      int n_atoms, int n_systems, int dtype, const int32_t* idx_j, const int32_t* unit_shifts, const int32_t* neighbor_ptr,
                       int max_neighbors, int mask_value, const void* grad_energies /*[n_atoms] dtype*/,
                       void* grad_positions /*[n_atoms,3] dtype*/, void* grad_charges /*[n_atoms] dtype*/,
-                      double* grad_cell, double* grad_alpha, void* symmetry_scratch /*or NULL*/, void* stream);
+                      double* grad_cell, double* grad_alpha, void* symmetry_scratch /*or NULL*/,
+                      size_t scratch_bytes /* >= mi_ewald_symmetry_scratch_bytes(); with mi_ewald_real_bwd_scratch_bytes(n_systems) the per-system
+                                              sums go through 64 slots per system instead of one atomic address */,
+                      void* stream);
 
 /* Adjoint of the explicit FORCES and CHARGE GRADIENTS of mi_ewald_real for L = sum_k w_k . F_k + sum_k v_k cg_k (second derivatives of the
  * pair sum; the reference differentiates these outputs through the Warp tape: "forces" and "charge_gradients" are in the grad_arrays of the
  * `_energy_forces*` ops, ewald.py:343-348, :606-612).  grad_forces / grad_charge_grads: either may be NULL.  Entry-wise scatter, valid for
- * any list.  All gradient outputs are float64 and zeroed by the library; grad_cell / grad_alpha may be NULL.                                */
+ * any list; with `scratch` (mi_ewald_real_bwd_scratch_bytes(n_systems)) the list is checksummed in an owner-only pass first (no atomics: the
+ * mirrored entry of a symmetric list contributes the same amount) and the scatter pass only runs when the list is NOT symmetric.  All gradient outputs are float64 and zeroed by the library; grad_cell / grad_alpha may be NULL.                                */
 int mi_ewald_real_forces_bwd(const void* positions, const void* charges, const void* cell, const void* alpha, const int32_t* batch_idx,
                              int n_atoms, int n_systems, int dtype, const int32_t* idx_j, const int32_t* unit_shifts,
                              const int32_t* neighbor_ptr, int max_neighbors, int mask_value, const void* grad_forces /*[n_atoms,3] dtype or NULL*/,
                              const void* grad_charge_grads /*[n_atoms] dtype or NULL*/, double* grad_positions /*[n_atoms,3]*/,
                              double* grad_charges /*[n_atoms]*/, double* grad_cell /*[n_systems,3,3]*/, double* grad_alpha /*[n_systems]*/,
-                             void* stream);
+                             void* scratch /*or NULL; mi_ewald_real_bwd_scratch_bytes(n_systems): slotted per-system sums*/, size_t scratch_bytes, void* stream);
 
 /* ---- cut-off Coulomb ---------------------------------------------------------------------------
  * Replaces the eight alchemiops::_[batch_]coulomb_energy[_forces]_{list,matrix} ops (interactions/electrostatics/coulomb.py:716-1330;

@@ -770,8 +770,9 @@ __global__ __launch_bounds__(256) void d3_energy_kernel(D3_ENERGY_PARAMS) {
 #ifndef D3_ENERGY_WAVES
 #define D3_ENERGY_WAVES 8  // 63 VGPRs / 78 SGPRs, no scratch (same-box A/B: 5 waves 1.09 ms, 6 waves 0.94, 7 / 8 waves 0.92)
 #endif
+// (the plain-list variants need a few registers more for their decoded pipeline steps: 7 waves / SIMD without scratch instead of 8 with 5-7 spills)
 template <class T, bool CSR, int MODE, bool PK>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(D3_ENERGY_WAVES, D3_ENERGY_WAVES))) void d3_energy_kernel_w5(D3_ENERGY_PARAMS) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PK ? D3_ENERGY_WAVES : D3_ENERGY_WAVES - 1, PK ? D3_ENERGY_WAVES : D3_ENERGY_WAVES - 1))) void d3_energy_kernel_w5(D3_ENERGY_PARAMS) {
   d3_energy_body<T, CSR, MODE, PK>(D3_ENERGY_ARGS);
 }
 // all three plain variants in one launch: what runs behind the packed variants (one dead launch instead of three when the packed copy was usable)

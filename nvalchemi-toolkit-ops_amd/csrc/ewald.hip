@@ -48,6 +48,7 @@ __device__ __forceinline__ unsigned long long ew_entry_hash(unsigned a, unsigned
 // ~12 ns per device-scope atomic (2.4 ms measured); spread over 1024 slot pairs they cost nothing measurable.
 #define EW_SYM_SLOTS 1024
 #define EW_SYM_WORDS (2 + 2 * EW_SYM_SLOTS)
+#define EW_BWD_SLOTS 64  // partial rows per system of the backward pass's per-system sums (one wave64 folds them)
 __device__ __forceinline__ void ew_sym_flush(unsigned long long hf, unsigned long long hr, unsigned long long* __restrict__ sym, int lane, int i) {
   hf = wave_sum(hf); hr = wave_sum(hr);
   if (lane == 0 && (hf | hr)) {
@@ -214,7 +215,8 @@ __global__ __launch_bounds__(256) void ewald_real_bwd_kernel(const T* __restrict
                                                              const int* __restrict__ idx, const int* __restrict__ ush,
                                                              const int* __restrict__ nptr, int M, int mask_value, const T* __restrict__ gE,
                                                              T* __restrict__ gpos, T* __restrict__ gq, double* __restrict__ gcell,
-                                                             double* __restrict__ galpha, unsigned long long* __restrict__ sym) {
+                                                             double* __restrict__ galpha, unsigned long long* __restrict__ sym,
+                                                             double* __restrict__ part) {
   const int lane = threadIdx.x & (MI_WAVE - 1);
   const int i = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x / MI_WAVE) + threadIdx.x / MI_WAVE);
   if (i >= N) return;
@@ -264,12 +266,28 @@ __global__ __launch_bounds__(256) void ewald_real_bwd_kernel(const T* __restrict
     gpos[3 * (size_t)i] = (T)gx; gpos[3 * (size_t)i + 1] = (T)gy; gpos[3 * (size_t)i + 2] = (T)gz;
     gq[i] = (T)gqi;
   }
-  if (galpha) { ga = wave_sum(ga); if (lane == 0) atomicAdd(&galpha[s], ga); }
+  // per-system sums: with the partial buffer a wave adds to slot (i mod EW_BWD_SLOTS) of its system and ew_bwd_reduce_kernel folds the slots;
+  // one device-scope fp64 atomic per wave on ONE address serialised 100k waves into 1.3 ms on the headline box (0.16 ms forward pass)
+  double* pa = part ? part + ((size_t)s * EW_BWD_SLOTS + (i & (EW_BWD_SLOTS - 1))) * 10 : nullptr;
+  if (galpha) { ga = wave_sum(ga); if (lane == 0 && ga != 0.0) atomicAdd(pa ? pa + 9 : &galpha[s], ga); }
   if (gcell) {
 #pragma unroll
-    for (int k = 0; k < 9; ++k) { const double v = wave_sum(gc[k]); if (lane == 0 && v != 0.0) atomicAdd(&gcell[9 * (size_t)s + k], v); }
+    for (int k = 0; k < 9; ++k) { const double v = wave_sum(gc[k]); if (lane == 0 && v != 0.0) atomicAdd(pa ? pa + k : &gcell[9 * (size_t)s + k], v); }
   }
   if (sym) ew_sym_flush(hf, hr, sym, lane, i);
+}
+// one block per system: fold the EW_BWD_SLOTS partial rows {cell[9], alpha} into grad_cell / grad_alpha (added: the caller zeroed them)
+__global__ __launch_bounds__(EW_BWD_SLOTS) void ew_bwd_reduce_kernel(const double* __restrict__ part, double* __restrict__ gcell, double* __restrict__ galpha) {
+  const int s = blockIdx.x;
+  const double* row = part + ((size_t)s * EW_BWD_SLOTS + threadIdx.x) * 10;
+#pragma unroll
+  for (int k = 0; k < 10; ++k) {
+    const double v = wave_sum(row[k]);
+    if (threadIdx.x == 0) {
+      if (k < 9) { if (gcell) gcell[9 * (size_t)s + k] += v; }
+      else if (galpha) galpha[s] += v;
+    }
+  }
 }
 
 // general adjoint for lists that are not symmetric: entry (i -> j) belongs to E_i only, so it carries weight g_i to BOTH ends
@@ -329,14 +347,21 @@ __global__ __launch_bounds__(256) void ewald_real_bwd_scatter_kernel(const T* __
 //   L_e = 1/2 q_i q_j g u ;   G = dL_e/dsep = 1/2 q_i q_j (g' u sep/d + g dw),   g' = -3 erfc/d^4 - 3 c e/d^3 - 2 a^2 c e/d
 //   dL/dr_j += G, dL/dr_i -= G ;  dL/dq_i += 1/2 q_j g u, dL/dq_j += 1/2 q_i g u ;  dL/dcell[a][b] += S_a G_b ;
 //   dL/dalpha += 1/2 q_i q_j u dg/dalpha,  dg/dalpha = -(4 a^2/sqrt(pi)) e^{-a^2 d^2}   (the erfc and prefactor terms cancel).
-// Entry-wise scatter with atomics: valid for every list, symmetric or not (a training-time kernel, not on the MD hot path).
-template <class T, bool CSR>
+// OWNER = false: entry-wise scatter with atomics, valid for every list.  OWNER = true (round 3): over a SYMMETRIC list the mirrored entry
+// (j -> i, -S) has sep' = -sep, dw' = -dw, u' = u, hence G' = -G and the same charge terms with the roles swapped: atom i receives -G from
+// its own entry and -G again from the mirrored one, so the row owner writes -2 sum G and 2 sum dq_i and nothing is scattered (76 M fp64
+// atomics on the headline 9 A list: 1.86 -> see profiles/r03_bench_pme_train.json).  The same pass checksums the list (as mi_ewald_real
+// does); if it is not symmetric the scatter variant runs behind it and overwrites positions / charges gradients; the per-system sums
+// (cell, alpha) are sums over the stored entries and identical in both variants.
+template <class T, bool CSR, bool OWNER>
 __global__ __launch_bounds__(256) void ewald_real_force_bwd_kernel(const T* __restrict__ pos, const T* __restrict__ q, const T* __restrict__ cell,
                                                                    const T* __restrict__ alpha, const int* __restrict__ batch_idx, int N,
                                                                    const int* __restrict__ idx, const int* __restrict__ ush,
                                                                    const int* __restrict__ nptr, int M, int mask_value, const T* __restrict__ gF,
                                                                    const T* __restrict__ gC, double* __restrict__ gpos, double* __restrict__ gq,
-                                                                   double* __restrict__ gcell, double* __restrict__ galpha) {
+                                                                   double* __restrict__ gcell, double* __restrict__ galpha, double* __restrict__ part,
+                                                                   unsigned long long* __restrict__ sym) {
+  if (!OWNER && sym && sym[0] == sym[1]) return;  // scatter variant behind the owner pass: only for lists that are not symmetric
   const int lane = threadIdx.x & (MI_WAVE - 1);
   const int i = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x / MI_WAVE) + threadIdx.x / MI_WAVE);
   if (i >= N) return;
@@ -345,6 +370,7 @@ __global__ __launch_bounds__(256) void ewald_real_force_bwd_kernel(const T* __re
   T cm[9];
   for (int k = 0; k < 9; ++k) cm[k] = cell[9 * (size_t)s + k];
   const T pix = pos[3 * (size_t)i], piy = pos[3 * (size_t)i + 1], piz = pos[3 * (size_t)i + 2];
+  unsigned long long hf = 0, hr = 0;
   const double wix = gF ? (double)gF[3 * (size_t)i] : 0.0, wiy = gF ? (double)gF[3 * (size_t)i + 1] : 0.0, wiz = gF ? (double)gF[3 * (size_t)i + 2] : 0.0;
   const double vi = gC ? (double)gC[i] : 0.0;
   const double c = 2.0 / 1.7724538509055159 * al;
@@ -357,6 +383,7 @@ __global__ __launch_bounds__(256) void ewald_real_force_bwd_kernel(const T* __re
     if ((!CSR && j == mask_value) || (unsigned)j >= (unsigned)N) continue;
     const double qj = (double)q[j];
     const int S0 = ush[3 * e], S1 = ush[3 * e + 1], S2 = ush[3 * e + 2];
+    if (OWNER && sym) { hf += ew_entry_hash((unsigned)i, (unsigned)j, S0, S1, S2); hr += ew_entry_hash((unsigned)j, (unsigned)i, -S0, -S1, -S2); }
     const T fs[3] = {(T)S0, (T)S1, (T)S2};
     T sh[3];
     rowvec_mat3(fs, cm, sh);
@@ -390,9 +417,11 @@ __global__ __launch_bounds__(256) void ewald_real_force_bwd_kernel(const T* __re
       if (galpha) ga += -0.5 * A * (2.0 / 1.7724538509055159) * ex;
     }
     gx -= Gx; gy -= Gy; gz -= Gz;
-    atomicAdd(&gpos[3 * (size_t)j], Gx); atomicAdd(&gpos[3 * (size_t)j + 1], Gy); atomicAdd(&gpos[3 * (size_t)j + 2], Gz);
     gqi += dqi;
-    atomicAdd(&gq[j], dqj);
+    if (!OWNER) {
+      atomicAdd(&gpos[3 * (size_t)j], Gx); atomicAdd(&gpos[3 * (size_t)j + 1], Gy); atomicAdd(&gpos[3 * (size_t)j + 2], Gz);
+      atomicAdd(&gq[j], dqj);
+    }
     if (gcell) {
       const double Sv[3] = {(double)S0, (double)S1, (double)S2}, Gv[3] = {Gx, Gy, Gz};
 #pragma unroll
@@ -403,13 +432,20 @@ __global__ __launch_bounds__(256) void ewald_real_force_bwd_kernel(const T* __re
   }
   gx = wave_sum(gx); gy = wave_sum(gy); gz = wave_sum(gz); gqi = wave_sum(gqi);
   if (lane == 0) {
-    atomicAdd(&gpos[3 * (size_t)i], gx); atomicAdd(&gpos[3 * (size_t)i + 1], gy); atomicAdd(&gpos[3 * (size_t)i + 2], gz);
-    atomicAdd(&gq[i], gqi);
+    if (OWNER) {
+      gpos[3 * (size_t)i] = 2.0 * gx; gpos[3 * (size_t)i + 1] = 2.0 * gy; gpos[3 * (size_t)i + 2] = 2.0 * gz;
+      gq[i] = 2.0 * gqi;
+    } else {
+      atomicAdd(&gpos[3 * (size_t)i], gx); atomicAdd(&gpos[3 * (size_t)i + 1], gy); atomicAdd(&gpos[3 * (size_t)i + 2], gz);
+      atomicAdd(&gq[i], gqi);
+    }
   }
-  if (galpha) { ga = wave_sum(ga); if (lane == 0 && ga != 0.0) atomicAdd(&galpha[s], ga); }
+  if (OWNER && sym) ew_sym_flush(hf, hr, sym, lane, i);
+  double* pa = part ? part + ((size_t)s * EW_BWD_SLOTS + (i & (EW_BWD_SLOTS - 1))) * 10 : nullptr;  // slotted per-system sums (see ewald_real_bwd_kernel)
+  if (galpha) { ga = wave_sum(ga); if (lane == 0 && ga != 0.0) atomicAdd(pa ? pa + 9 : &galpha[s], ga); }
   if (gcell) {
 #pragma unroll
-    for (int k = 0; k < 9; ++k) { const double v = wave_sum(gc[k]); if (lane == 0 && v != 0.0) atomicAdd(&gcell[9 * (size_t)s + k], v); }
+    for (int k = 0; k < 9; ++k) { const double v = wave_sum(gc[k]); if (lane == 0 && v != 0.0) atomicAdd(pa ? pa + k : &gcell[9 * (size_t)s + k], v); }
   }
 }
 
@@ -697,11 +733,12 @@ __global__ __launch_bounds__(256) void coulomb_force_bwd_kernel(const double* __
 
 }  // namespace
 
+extern "C" size_t mi_ewald_real_bwd_scratch_bytes(int n_systems);
 extern "C" int mi_ewald_real_forces_bwd(const void* positions, const void* charges, const void* cell, const void* alpha, const int32_t* batch_idx,
                                         int n_atoms, int n_systems, int dtype, const int32_t* idx_j, const int32_t* unit_shifts,
                                         const int32_t* neighbor_ptr, int max_neighbors, int mask_value, const void* grad_forces,
                                         const void* grad_charge_grads, double* grad_positions, double* grad_charges, double* grad_cell,
-                                        double* grad_alpha, void* stream) {
+                                        double* grad_alpha, void* scratch, size_t scratch_bytes, void* stream) {
   MI_REQUIRE(dtype == MI_F32 || dtype == MI_F64, "dtype");
   MI_REQUIRE(n_systems >= 1 && grad_positions && grad_charges, "null gradient outputs");
   hipStream_t st = (hipStream_t)stream;
@@ -715,14 +752,37 @@ extern "C" int mi_ewald_real_forces_bwd(const void* positions, const void* charg
   MI_REQUIRE(positions && charges && cell && alpha && idx_j && unit_shifts && (grad_forces || grad_charge_grads), "null pointer");
   const int blocks = mi_blocks(n_atoms, 4);
   const bool csr = neighbor_ptr != nullptr;
-#define MI_EFB(T_, CSR_)                                                                                                                          \
-  ewald_real_force_bwd_kernel<T_, CSR_><<<blocks, 256, 0, st>>>((const T_*)positions, (const T_*)charges, (const T_*)cell, (const T_*)alpha, batch_idx, \
-                                                                n_atoms, idx_j, unit_shifts, neighbor_ptr, max_neighbors, mask_value,               \
-                                                                (const T_*)grad_forces, (const T_*)grad_charge_grads, grad_positions, grad_charges,      \
-                                                                grad_cell, grad_alpha)
+#define MI_EFB_ARGS(T_) (const T_*)positions, (const T_*)charges, (const T_*)cell, (const T_*)alpha, batch_idx, n_atoms, idx_j, unit_shifts, neighbor_ptr, \
+                        max_neighbors, mask_value, (const T_*)grad_forces, (const T_*)grad_charge_grads, grad_positions, grad_charges
+#define MI_EFB(T_, CSR_)                                                                                                                       \
+  do {                                                                                                                                         \
+    if (sym) {  /* owner pass + checksums; the scatter variant behind it only works when the list turned out not to be symmetric */          \
+      ewald_real_force_bwd_kernel<T_, CSR_, true><<<blocks, 256, 0, st>>>(MI_EFB_ARGS(T_), grad_cell, grad_alpha, part, sym);                  \
+      ew_sym_reduce_kernel<<<1, EW_SYM_SLOTS, 0, st>>>(sym);                                                                                   \
+      ewald_fixup_zero_kernel<double><<<mi_blocks(n_atoms, 256), 256, 0, st>>>(sym, grad_positions, grad_charges, nullptr, n_atoms);            \
+      ewald_real_force_bwd_kernel<T_, CSR_, false><<<blocks, 256, 0, st>>>(MI_EFB_ARGS(T_), nullptr, nullptr, nullptr, sym);                    \
+    } else {                                                                                                                                   \
+      ewald_real_force_bwd_kernel<T_, CSR_, false><<<blocks, 256, 0, st>>>(MI_EFB_ARGS(T_), grad_cell, grad_alpha, part, nullptr);              \
+    }                                                                                                                                          \
+  } while (0)
+  // optional scratch (mi_ewald_real_bwd_scratch_bytes(n_systems); only its partial-sum part is used here): slotted per-system sums
+  double* part = nullptr;
+  unsigned long long* sym = nullptr;
+  if (scratch && scratch_bytes >= sizeof(unsigned long long) * EW_SYM_WORDS) {
+    sym = reinterpret_cast<unsigned long long*>(scratch);
+    MI_HIP_CHECK(hipMemsetAsync(sym, 0, sizeof(unsigned long long) * EW_SYM_WORDS, st));
+  }
+  if (sym && (grad_cell || grad_alpha) && scratch_bytes >= mi_ewald_real_bwd_scratch_bytes(n_systems)) {
+    part = reinterpret_cast<double*>(sym + EW_SYM_WORDS);
+    MI_HIP_CHECK(hipMemsetAsync(part, 0, sizeof(double) * 10 * EW_BWD_SLOTS * (size_t)n_systems, st));
+  }
+  mi_timing_begin("ewald_real_forces_bwd", stream);
   if (dtype == MI_F32) { if (csr) MI_EFB(float, true); else MI_EFB(float, false); }
   else { if (csr) MI_EFB(double, true); else MI_EFB(double, false); }
+  if (part) ew_bwd_reduce_kernel<<<n_systems, EW_BWD_SLOTS, 0, st>>>(part, grad_cell, grad_alpha);
+  mi_timing_end(stream);
 #undef MI_EFB
+#undef MI_EFB_ARGS
   MI_LAUNCH_CHECK();
   return MI_OK;
 }
@@ -732,10 +792,14 @@ extern "C" size_t mi_ewald_real_scratch_bytes(int n_atoms, int dtype) {
   return sizeof(unsigned long long) * EW_SYM_WORDS + (dtype == MI_F32 ? 16 : 32) * (size_t)(n_atoms > 0 ? n_atoms : 0);
 }
 
+extern "C" size_t mi_ewald_real_bwd_scratch_bytes(int n_systems) {
+  return sizeof(unsigned long long) * EW_SYM_WORDS + sizeof(double) * 10 * EW_BWD_SLOTS * (size_t)(n_systems > 0 ? n_systems : 1);
+}
+
 extern "C" int mi_ewald_real_bwd(const void* positions, const void* charges, const void* cell, const void* alpha, const int32_t* batch_idx,
-                                 int n_atoms, int dtype, const int32_t* idx_j, const int32_t* unit_shifts, const int32_t* neighbor_ptr,
+                                 int n_atoms, int n_systems, int dtype, const int32_t* idx_j, const int32_t* unit_shifts, const int32_t* neighbor_ptr,
                                  int max_neighbors, int mask_value, const void* grad_energies, void* grad_positions, void* grad_charges,
-                                 double* grad_cell, double* grad_alpha, void* symmetry_scratch, void* stream) {
+                                 double* grad_cell, double* grad_alpha, void* symmetry_scratch, size_t scratch_bytes, void* stream) {
   MI_REQUIRE(dtype == MI_F32 || dtype == MI_F64, "dtype");
   if (n_atoms <= 0) return MI_OK;
   MI_REQUIRE(positions && charges && cell && alpha && idx_j && unit_shifts && grad_energies && grad_positions && grad_charges, "null pointer");
@@ -745,7 +809,7 @@ extern "C" int mi_ewald_real_bwd(const void* positions, const void* charges, con
 #define MI_EWB(T_, CSR_)                                                                                                                       \
   ewald_real_bwd_kernel<T_, CSR_><<<blocks, 256, 0, st>>>((const T_*)positions, (const T_*)charges, (const T_*)cell, (const T_*)alpha, batch_idx, \
                                                           n_atoms, idx_j, unit_shifts, neighbor_ptr, max_neighbors, mask_value,                  \
-                                                          (const T_*)grad_energies, (T_*)grad_positions, (T_*)grad_charges, grad_cell, grad_alpha, sym)
+                                                          (const T_*)grad_energies, (T_*)grad_positions, (T_*)grad_charges, grad_cell, grad_alpha, sym, part)
 #define MI_EWBS(T_, CSR_)                                                                                                                          \
   do {                                                                                                                                             \
     ewald_fixup_zero_kernel<T_><<<mi_blocks(n_atoms, 256), 256, 0, st>>>(sym, (T_*)grad_positions, (T_*)grad_charges, nullptr, n_atoms);          \
@@ -755,8 +819,17 @@ extern "C" int mi_ewald_real_bwd(const void* positions, const void* charges, con
   } while (0)
   unsigned long long* sym = (unsigned long long*)symmetry_scratch;
   if (sym) MI_HIP_CHECK(hipMemsetAsync(sym, 0, sizeof(unsigned long long) * EW_SYM_WORDS, st));
+  // second part of the scratch (when the caller sized it with mi_ewald_real_bwd_scratch_bytes): slotted partials of the per-system sums
+  double* part = nullptr;
+  if (sym && n_systems >= 1 && (grad_cell || grad_alpha) && scratch_bytes >= mi_ewald_real_bwd_scratch_bytes(n_systems)) {
+    part = reinterpret_cast<double*>(sym + EW_SYM_WORDS);
+    MI_HIP_CHECK(hipMemsetAsync(part, 0, sizeof(double) * 10 * EW_BWD_SLOTS * (size_t)n_systems, st));
+  }
+  mi_timing_begin("ewald_real_bwd", stream);
   if (dtype == MI_F32) { if (csr) MI_EWB(float, true); else MI_EWB(float, false); }
   else { if (csr) MI_EWB(double, true); else MI_EWB(double, false); }
+  if (part) ew_bwd_reduce_kernel<<<n_systems, EW_BWD_SLOTS, 0, st>>>(part, grad_cell, grad_alpha);
+  mi_timing_end(stream);
   MI_LAUNCH_CHECK();
   if (sym) {
     ew_sym_reduce_kernel<<<1, EW_SYM_SLOTS, 0, st>>>(sym);

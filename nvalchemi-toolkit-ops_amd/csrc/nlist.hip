@@ -115,7 +115,7 @@ __global__ void nl_count_atoms_kernel(const int* __restrict__ batch_idx, int N, 
 }
 
 template <class T>
-__global__ void nl_setup_kernel(const T* __restrict__ cell, const uint8_t* __restrict__ pbc, const int* __restrict__ natoms, int N,
+__global__ __launch_bounds__(256) void nl_setup_kernel(const T* __restrict__ cell, const uint8_t* __restrict__ pbc, const int* __restrict__ natoms, int N,
                                 int B, T cutoff, const T* __restrict__ origin, NlSys<T>* __restrict__ sys, NlGlobal* __restrict__ glob) {
   for (int s = threadIdx.x; s < B; s += blockDim.x) {
     NlSys<T> S;

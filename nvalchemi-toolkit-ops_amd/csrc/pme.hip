@@ -53,14 +53,18 @@ template <class T> __device__ __forceinline__ T bspline_ref(T u, int order) {
   return zero;
 }
 // stable bottom-up recursion for orders 5 and 6: value of M_n at u
-template <class T> __device__ T bspline_high(T u, int n) {
+template <class T> __device__ __forceinline__ T bspline_high(T u, int n) {
   if (!(u >= T(0) && u < T(n))) return T(0);
   T m[MI_MAX_ORDER + 1];
 #pragma unroll
   for (int k = 0; k <= MI_MAX_ORDER; ++k) { const T x = u - T(k); m[k] = (x >= T(0) && x < T(1)) ? T(1) : T(0); }  // M_1(u-k)
-  for (int p = 2; p <= n; ++p) {
+#pragma unroll
+  for (int p = 2; p <= MI_MAX_ORDER; ++p) {
+    if (p > n) break;
     const T inv = T(1) / T(p - 1);
-    for (int k = 0; k <= n - p; ++k) {
+#pragma unroll
+    for (int k = 0; k <= MI_MAX_ORDER - 2; ++k) {
+      if (k > n - p) break;
       const T x = u - T(k);
       m[k] = (x * m[k] + (T(p) - x) * m[k + 1]) * inv;  // M_p(u-k) from M_{p-1}(u-k), M_{p-1}(u-k-1)
     }
@@ -358,17 +362,22 @@ __global__ void spline_gather_kernel(const T* __restrict__ pos, const T* __restr
 }
 
 // gradient of the scalar gather w.r.t. the fractional coordinate (x mesh dims): building block of the spread/gather adjoints
-template <class T>
-__global__ void spline_gather_grad_kernel(const T* __restrict__ pos, const T* __restrict__ mesh, const int* __restrict__ batch_idx,
-                                          const T* __restrict__ cit, int N, int nx, int ny, int nz, int order, T* __restrict__ out) {
+template <class T, int ORDER>
+__global__ __launch_bounds__(128) void spline_gather_grad_kernel(const T* __restrict__ pos, const T* __restrict__ mesh, const int* __restrict__ batch_idx,
+                                          const T* __restrict__ cit, int N, int nx, int ny, int nz, T* __restrict__ out) {
+  // ORDER is a template parameter: every stencil loop unrolls and the 1-D weight tables stay in registers (with a run-time order they
+  // were indexed dynamically and lived in scratch: 160 / 368 B per thread)
+  constexpr int order = ORDER;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= N) return;
   const int s = batch_idx ? batch_idx[i] : 0;
   const Stencil<T> st = make_stencil(pos + 3 * (size_t)i, cit + 9 * (size_t)s, nx, ny, nz, order);
-  T w1[3][MI_MAX_ORDER], d1[3][MI_MAX_ORDER];
-  int gi[3][MI_MAX_ORDER];
+  T w1[3][ORDER], d1[3][ORDER];
+  int gi[3][ORDER];
   const int dims[3] = {nx, ny, nz};
+#pragma unroll
   for (int d = 0; d < 3; ++d)
+#pragma unroll
     for (int t = 0; t < order; ++t) {
       const T u = (T)order * T(0.5) + st.theta[d] - (T)(t + st.off0[d]);
       const bool in = !(u < T(0) || u >= (T)order);
@@ -378,10 +387,13 @@ __global__ void spline_gather_grad_kernel(const T* __restrict__ pos, const T* __
     }
   T gx = 0, gy = 0, gz = 0;
   const T* m0 = mesh + (size_t)s * nx * ny * nz;
+#pragma unroll
   for (int tx = 0; tx < order; ++tx)
+#pragma unroll
     for (int ty = 0; ty < order; ++ty) {
       const T* row = m0 + ((size_t)gi[0][tx] * ny + gi[1][ty]) * nz;
       const T wxy = w1[0][tx] * w1[1][ty], dxy = d1[0][tx] * w1[1][ty], xdy = w1[0][tx] * d1[1][ty];
+#pragma unroll
       for (int tz = 0; tz < order; ++tz) {
         const T v = row[gi[2][tz]];
         gx += v * dxy * w1[2][tz];
@@ -396,11 +408,14 @@ __global__ void spline_gather_grad_kernel(const T* __restrict__ pos, const T* __
 //   hess_dot   out_i[b] = sum_g mesh[g] sum_a v_i[a] d^2 W_i(g) / dfrac_a dfrac_b      (dL/dfrac_i for L = sum_i v_i . G_i)
 //   spread_grad mesh[g] += sum_i sum_a v_i[a] d W_i(g) / dfrac_a                        (dL/dmesh)
 // One thread per atom; `spread_grad` uses atomics (training path, not the step the bench times).
-template <class T> struct Stencil2 { T w[3][MI_MAX_ORDER], d[3][MI_MAX_ORDER], dd[3][MI_MAX_ORDER]; int gi[3][MI_MAX_ORDER]; };
-template <class T>
-__device__ __forceinline__ void stencil_derivs(const Stencil<T>& st, int nx, int ny, int nz, int order, bool second, Stencil2<T>& o) {
+template <class T, int ORDER> struct Stencil2 { T w[3][ORDER], d[3][ORDER], dd[3][ORDER]; int gi[3][ORDER]; };
+template <class T, int ORDER>
+__device__ __forceinline__ void stencil_derivs(const Stencil<T>& st, int nx, int ny, int nz, bool second, Stencil2<T, ORDER>& o) {
+  constexpr int order = ORDER;
   const int dims[3] = {nx, ny, nz};
+#pragma unroll
   for (int d = 0; d < 3; ++d)
+#pragma unroll
     for (int t = 0; t < order; ++t) {
       const T u = (T)order * T(0.5) + st.theta[d] - (T)(t + st.off0[d]);
       const bool in = !(u < T(0) || u >= (T)order);
@@ -411,23 +426,27 @@ __device__ __forceinline__ void stencil_derivs(const Stencil<T>& st, int nx, int
       o.gi[d][t] = wrap_idx(st.base[d] + t + st.off0[d], dims[d]);
     }
 }
-template <class T>
-__global__ void spline_gather_hess_dot_kernel(const T* __restrict__ pos, const T* __restrict__ mesh, const int* __restrict__ batch_idx,
-                                              const T* __restrict__ cit, const T* __restrict__ vec, int N, int nx, int ny, int nz, int order,
+template <class T, int ORDER>
+__global__ __launch_bounds__(128) void spline_gather_hess_dot_kernel(const T* __restrict__ pos, const T* __restrict__ mesh, const int* __restrict__ batch_idx,
+                                              const T* __restrict__ cit, const T* __restrict__ vec, int N, int nx, int ny, int nz,
                                               T* __restrict__ out) {
+  constexpr int order = ORDER;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= N) return;
   const int s = batch_idx ? batch_idx[i] : 0;
   const Stencil<T> st = make_stencil(pos + 3 * (size_t)i, cit + 9 * (size_t)s, nx, ny, nz, order);
-  Stencil2<T> k;
-  stencil_derivs(st, nx, ny, nz, order, true, k);
+  Stencil2<T, ORDER> k;
+  stencil_derivs<T, ORDER>(st, nx, ny, nz, true, k);
   const T vx = vec[3 * (size_t)i], vy = vec[3 * (size_t)i + 1], vz = vec[3 * (size_t)i + 2];
   T ox = 0, oy = 0, oz = 0;
   const T* m0 = mesh + (size_t)s * nx * ny * nz;
+#pragma unroll
   for (int tx = 0; tx < order; ++tx)
+#pragma unroll
     for (int ty = 0; ty < order; ++ty) {
       const T* row = m0 + ((size_t)k.gi[0][tx] * ny + k.gi[1][ty]) * nz;
       const T wx = k.w[0][tx], dx = k.d[0][tx], ddx = k.dd[0][tx], wy = k.w[1][ty], dy = k.d[1][ty], ddy = k.dd[1][ty];
+#pragma unroll
       for (int tz = 0; tz < order; ++tz) {
         const T m = row[k.gi[2][tz]];
         const T wz = k.w[2][tz], dz = k.d[2][tz], ddz = k.dd[2][tz];
@@ -440,21 +459,25 @@ __global__ void spline_gather_hess_dot_kernel(const T* __restrict__ pos, const T
     }
   out[3 * (size_t)i] = ox; out[3 * (size_t)i + 1] = oy; out[3 * (size_t)i + 2] = oz;
 }
-template <class T>
-__global__ void spline_spread_grad_kernel(const T* __restrict__ pos, const T* __restrict__ vec, const int* __restrict__ batch_idx,
-                                          const T* __restrict__ cit, int N, int nx, int ny, int nz, int order, T* __restrict__ mesh) {
+template <class T, int ORDER>
+__global__ __launch_bounds__(128) void spline_spread_grad_kernel(const T* __restrict__ pos, const T* __restrict__ vec, const int* __restrict__ batch_idx,
+                                          const T* __restrict__ cit, int N, int nx, int ny, int nz, T* __restrict__ mesh) {
+  constexpr int order = ORDER;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= N) return;
   const int s = batch_idx ? batch_idx[i] : 0;
   const Stencil<T> st = make_stencil(pos + 3 * (size_t)i, cit + 9 * (size_t)s, nx, ny, nz, order);
-  Stencil2<T> k;
-  stencil_derivs(st, nx, ny, nz, order, false, k);
+  Stencil2<T, ORDER> k;
+  stencil_derivs<T, ORDER>(st, nx, ny, nz, false, k);
   const T vx = vec[3 * (size_t)i], vy = vec[3 * (size_t)i + 1], vz = vec[3 * (size_t)i + 2];
   T* m0 = mesh + (size_t)s * nx * ny * nz;
+#pragma unroll
   for (int tx = 0; tx < order; ++tx)
+#pragma unroll
     for (int ty = 0; ty < order; ++ty) {
       T* row = m0 + ((size_t)k.gi[0][tx] * ny + k.gi[1][ty]) * nz;
       const T a = vx * k.d[0][tx] * k.w[1][ty] + vy * k.w[0][tx] * k.d[1][ty], b = vz * k.w[0][tx] * k.w[1][ty];
+#pragma unroll
       for (int tz = 0; tz < order; ++tz) {
         const T val = a * k.w[2][tz] + b * k.d[2][tz];
         if (val != T(0)) atomicAdd(row + k.gi[2][tz], val);
@@ -669,6 +692,19 @@ int spread_tiled(const T* pos, const T* values, const int* batch_idx, const T* c
     else { using T_ = double; CALL; }                  \
   } while (0)
 
+// spline order as a compile-time constant O_ (1..6; the callers have validated the range)
+#define MI_DISPATCH_ORDER(order, CALL)                   \
+  do {                                                   \
+    switch (order) {                                     \
+      case 1: { constexpr int O_ = 1; CALL; } break;     \
+      case 2: { constexpr int O_ = 2; CALL; } break;     \
+      case 3: { constexpr int O_ = 3; CALL; } break;     \
+      case 4: { constexpr int O_ = 4; CALL; } break;     \
+      case 5: { constexpr int O_ = 5; CALL; } break;     \
+      default: { constexpr int O_ = 6; CALL; } break;    \
+    }                                                    \
+  } while (0)
+
 extern "C" {
 
 int mi_cell_geometry(const void* cell, int n_systems, int dtype, void* cell_inv_t, void* reciprocal_cell, void* volume, void* stream) {
@@ -745,9 +781,11 @@ int mi_spline_gather(const void* positions, const void* mesh, const int32_t* bat
   if (n_atoms <= 0) return MI_OK;
   MI_REQUIRE(positions && mesh && cell_inv_t && out, "null pointer");
   hipStream_t st = (hipStream_t)stream;
+  mi_timing_begin("spline_gather", stream);
   MI_DISPATCH_T(dtype, (spline_gather_kernel<T_, 1><<<mi_blocks(n_atoms, 128), 128, 0, st>>>((const T_*)positions, nullptr, (const T_*)mesh, batch_idx,
                                                                                              (const T_*)cell_inv_t, n_atoms, nx, ny, nz, order,
                                                                                              (T_*)out)));
+  mi_timing_end(stream);
   MI_LAUNCH_CHECK();
   return MI_OK;
 }
@@ -760,9 +798,10 @@ int mi_spline_gather_grad(const void* positions, const void* mesh, const int32_t
   if (n_atoms <= 0) return MI_OK;
   MI_REQUIRE(positions && mesh && cell_inv_t && out, "null pointer");
   hipStream_t st = (hipStream_t)stream;
-  MI_DISPATCH_T(dtype, (spline_gather_grad_kernel<T_><<<mi_blocks(n_atoms, 128), 128, 0, st>>>((const T_*)positions, (const T_*)mesh, batch_idx,
-                                                                                                (const T_*)cell_inv_t, n_atoms, nx, ny, nz, order,
-                                                                                                (T_*)out)));
+  mi_timing_begin("spline_gather_grad", stream);
+  MI_DISPATCH_ORDER(order, MI_DISPATCH_T(dtype, (spline_gather_grad_kernel<T_, O_><<<mi_blocks(n_atoms, 128), 128, 0, st>>>(
+                                                    (const T_*)positions, (const T_*)mesh, batch_idx, (const T_*)cell_inv_t, n_atoms, nx, ny, nz, (T_*)out))));
+  mi_timing_end(stream);
   MI_LAUNCH_CHECK();
   return MI_OK;
 }
@@ -775,8 +814,10 @@ int mi_spline_gather_hess_dot(const void* positions, const void* mesh, const int
   if (n_atoms <= 0) return MI_OK;
   MI_REQUIRE(positions && mesh && cell_inv_t && vec && out, "null pointer");
   hipStream_t st = (hipStream_t)stream;
-  MI_DISPATCH_T(dtype, (spline_gather_hess_dot_kernel<T_><<<mi_blocks(n_atoms, 128), 128, 0, st>>>(
-                           (const T_*)positions, (const T_*)mesh, batch_idx, (const T_*)cell_inv_t, (const T_*)vec, n_atoms, nx, ny, nz, order, (T_*)out)));
+  mi_timing_begin("spline_gather_hess_dot", stream);
+  MI_DISPATCH_ORDER(order, MI_DISPATCH_T(dtype, (spline_gather_hess_dot_kernel<T_, O_><<<mi_blocks(n_atoms, 128), 128, 0, st>>>(
+                                                    (const T_*)positions, (const T_*)mesh, batch_idx, (const T_*)cell_inv_t, (const T_*)vec, n_atoms, nx, ny, nz, (T_*)out))));
+  mi_timing_end(stream);
   MI_LAUNCH_CHECK();
   return MI_OK;
 }
@@ -790,8 +831,10 @@ int mi_spline_spread_grad(const void* positions, const void* vec, const int32_t*
   MI_HIP_CHECK(hipMemsetAsync(mesh, 0, (size_t)n_systems * nx * ny * nz * (dtype == MI_F32 ? 4 : 8), st));
   if (n_atoms <= 0) return MI_OK;
   MI_REQUIRE(positions && vec && cell_inv_t, "null pointer");
-  MI_DISPATCH_T(dtype, (spline_spread_grad_kernel<T_><<<mi_blocks(n_atoms, 128), 128, 0, st>>>(
-                           (const T_*)positions, (const T_*)vec, batch_idx, (const T_*)cell_inv_t, n_atoms, nx, ny, nz, order, (T_*)mesh)));
+  mi_timing_begin("spline_spread_grad", stream);
+  MI_DISPATCH_ORDER(order, MI_DISPATCH_T(dtype, (spline_spread_grad_kernel<T_, O_><<<mi_blocks(n_atoms, 128), 128, 0, st>>>(
+                                                    (const T_*)positions, (const T_*)vec, batch_idx, (const T_*)cell_inv_t, n_atoms, nx, ny, nz, (T_*)mesh))));
+  mi_timing_end(stream);
   MI_LAUNCH_CHECK();
   return MI_OK;
 }

@@ -21,6 +21,7 @@ being traced; otherwise they take the direct ctypes path (no dispatcher overhead
 """
 from __future__ import annotations
 
+import ctypes
 import math
 from typing import Optional
 
@@ -48,6 +49,36 @@ def _cit(cell: Tensor, cell_inv_t: Optional[Tensor], dtype) -> Tensor:
         return cell_inv_t.to(dtype).reshape(-1, 3, 3)
     c = cell if cell.dim() == 3 else cell.unsqueeze(0)
     return torch.linalg.inv(c.to(dtype)).transpose(-1, -2)
+
+
+# =====================================================================================================================================
+# per-system sums of per-atom values (adjoints reduce per-atom terms to [B] gradients of alpha / volume / total charge)
+# =====================================================================================================================================
+def _segment_sum(values: Tensor, batch_idx: Optional[Tensor], num_systems: int) -> Tensor:
+    v = values.detach().contiguous()
+    out = torch.zeros(num_systems, dtype=v.dtype, device=v.device)
+    if v.shape[0]:
+        bi = None if batch_idx is None else C.i32(batch_idx)
+        C.check(C.lib().mi_segment_sum(C.ptr(v), C.ptr(bi), v.shape[0], C.dtype_code(v.dtype), C.ptr(out), C.stream_of(v)), "mi_segment_sum")
+    return out
+
+
+segment_sum_op = torch.library.custom_op("nvalchemiops::segment_sum", _segment_sum, mutates_args=())
+segment_sum_op.register_fake(lambda values, batch_idx, num_systems: values.new_empty((num_systems,)))
+segment_sum_op.register_autograd(lambda ctx, g: (g[ctx.sel] if ctx.sel is not None else g.expand(ctx.n), None, None),
+                                 setup_context=lambda ctx, inputs, output: (setattr(ctx, "sel", None if inputs[1] is None else inputs[1].long()),
+                                                                           setattr(ctx, "n", inputs[0].shape[0])) and None)
+
+
+def seg_sum(x: Tensor, batch_idx: Optional[Tensor], num_systems: int) -> Tensor:
+    """sum of x over the atoms of each system, [B].  One wave-aggregated atomic per wave and system (`mi_segment_sum`) for fp32 / fp64
+    instead of `index_add` with one same-address atomic per ATOM: on a single 100k-atom system the latter took 6.5 ms per call and was
+    48 % of the GPU time of a PME training step (profiles/r03_kernel_stats_train_before.csv)."""
+    if x.dtype in (torch.float32, torch.float64) and x.dim() == 1 and x.is_cuda:
+        return segment_sum_op(x, batch_idx, num_systems)
+    if batch_idx is None:
+        return x.sum(0, keepdim=True)
+    return torch.zeros((num_systems,) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device).index_add(0, batch_idx.long(), x)
 
 
 # =====================================================================================================================================
@@ -101,15 +132,16 @@ frac_grad_op.register_autograd(lambda ctx, g: (_ for _ in ()).throw(NotImplement
 
 
 def _coordinate_grads(weight, gfrac, pos, cit, bi):
-    """frac = cell_inv_t . r  =>  dL/dr_b = w sum_a gfrac_a cit[a][b] ;  dL/dcit[s][a][b] = sum_{i in s} w_i gfrac_i[a] r_i[b]."""
+    """frac = cell_inv_t . r  =>  dL/dr_b = w sum_a gfrac_a cit[a][b] ;  dL/dcit[s][a][b] = sum_{i in s} w_i gfrac_i[a] r_i[b].
+    Elementwise contractions + reductions: a per-atom batched 3x3 GEMM (einsum) was 11 % of the GPU time of a PME training step, and the
+    [3,N] x [N,3] GEMM formulation of the cell term is worse still (rocBLAS runs a K = N fp64 product with a 3x3 result in one workgroup:
+    5 ms at 100k atoms).  Batch: nine per-system segment sums (`seg_sum`), not one same-address atomic per atom."""
     wg = gfrac * weight.unsqueeze(-1)
-    cit_i = cit[bi.long()] if bi is not None else cit[0].expand(pos.shape[0], 3, 3)
-    gpos = torch.einsum("na,nab->nb", wg, cit_i)
-    outer = wg.unsqueeze(-1) * pos.unsqueeze(-2)
     if bi is None:  # single system: cit is [1,3,3]
-        gcit = outer.sum(0, keepdim=True)
-    else:
-        gcit = torch.zeros_like(cit).index_add(0, bi.long(), outer)
+        return (wg.unsqueeze(-1) * cit[0]).sum(1), (wg.unsqueeze(-1) * pos.unsqueeze(-2)).sum(0, keepdim=True)
+    gpos = (wg.unsqueeze(-1) * cit[bi.long()]).sum(1)
+    outer = (wg.unsqueeze(-1) * pos.unsqueeze(-2)).reshape(-1, 9)
+    gcit = torch.stack([seg_sum(outer[:, k].contiguous(), bi, cit.shape[0]) for k in range(9)], dim=-1).reshape(-1, 3, 3)
     return gpos, gcit
 
 
@@ -618,7 +650,7 @@ def _corr_backward(batched, with_cg):
         per_v = ge * c * math.pi * qq / (2.0 * a * a * v * v) + gc * math.pi * qq / (a * a * v * v)
         per_a = ge * (-c * c / rp + c * math.pi * qq / (a * a * a * v)) + gc * (-2.0 * c / rp + 2.0 * math.pi * qq / (a * a * a * v))
         per_q = ge * (-c * math.pi / (2.0 * a * a * v)) + gc * (-math.pi / (a * a * v))
-        seg = lambda x, like: torch.zeros(nsys, dtype=dt, device=raw.device).index_add(0, sel, x).reshape(like.shape).to(like.dtype)  # noqa: E731
+        seg = lambda x, like: seg_sum(x, bi, nsys).reshape(like.shape).to(like.dtype)  # noqa: E731
         out = (g_raw, g_q.to(q.dtype)) + ((None,) if batched else ()) + (seg(per_v, vol), seg(per_a, al), seg(per_q, qt))
         return out
     return backward
@@ -669,10 +701,14 @@ def _real_bwd(positions: Tensor, charges: Tensor, cell: Tensor, alpha: Tensor, b
     if n == 0 or p["n_entries"] == 0:
         return gpos, gq, gcell, galpha
     g = grad_energies.detach().to(dt).contiguous()
-    sym = torch.empty(C.ewald_sym_words(), dtype=torch.int64, device=dev)
-    rc = C.lib().mi_ewald_real_bwd(C.ptr(pos), C.ptr(p["q"]), C.ptr(p["cells"]), C.ptr(p["alpha"]), C.ptr(p["bi"]), n, C.dtype_code(dt), C.ptr(p["idx"]),
-                                   C.ptr(p["sh"]), C.ptr(p["nptr"]), int(p["m"]), int(mask_value), C.ptr(g), C.ptr(gpos), C.ptr(gq), C.ptr(gcell),
-                                   C.ptr(galpha), C.ptr(sym), C.stream_of(pos))
+    nsys = int(p["cells"].shape[0])
+    L = C.lib()
+    L.mi_ewald_real_bwd_scratch_bytes.restype = ctypes.c_size_t
+    sbytes = int(L.mi_ewald_real_bwd_scratch_bytes(nsys))
+    sym = torch.empty(sbytes // 8, dtype=torch.int64, device=dev)
+    rc = L.mi_ewald_real_bwd(C.ptr(pos), C.ptr(p["q"]), C.ptr(p["cells"]), C.ptr(p["alpha"]), C.ptr(p["bi"]), n, nsys, C.dtype_code(dt), C.ptr(p["idx"]),
+                             C.ptr(p["sh"]), C.ptr(p["nptr"]), int(p["m"]), int(mask_value), C.ptr(g), C.ptr(gpos), C.ptr(gq), C.ptr(gcell),
+                             C.ptr(galpha), C.ptr(sym), ctypes.c_size_t(sbytes), C.stream_of(pos))
     C.check(rc, "mi_ewald_real_bwd")
     return gpos, gq, gcell, galpha
 
@@ -712,9 +748,13 @@ def _real_forces_bwd(positions: Tensor, charges: Tensor, cell: Tensor, alpha: Te
     gc = None if grad_charge_grads is None else grad_charge_grads.detach().to(dt).contiguous()
     if g is None and gc is None:
         return gpos, gq, gcell, galpha
-    rc = C.lib().mi_ewald_real_forces_bwd(C.ptr(pos), C.ptr(p["q"]), C.ptr(p["cells"]), C.ptr(p["alpha"]), C.ptr(p["bi"]), n, nsys, C.dtype_code(dt),
-                                          C.ptr(p["idx"]), C.ptr(p["sh"]), C.ptr(p["nptr"]), int(p["m"]), int(mask_value), C.ptr(g), C.ptr(gc),
-                                          C.ptr(gpos), C.ptr(gq), C.ptr(gcell), C.ptr(galpha), C.stream_of(pos))
+    L = C.lib()
+    L.mi_ewald_real_bwd_scratch_bytes.restype = ctypes.c_size_t
+    sbytes = int(L.mi_ewald_real_bwd_scratch_bytes(int(nsys)))
+    scratch = torch.empty(sbytes // 8, dtype=torch.int64, device=dev)
+    rc = L.mi_ewald_real_forces_bwd(C.ptr(pos), C.ptr(p["q"]), C.ptr(p["cells"]), C.ptr(p["alpha"]), C.ptr(p["bi"]), n, nsys, C.dtype_code(dt),
+                                    C.ptr(p["idx"]), C.ptr(p["sh"]), C.ptr(p["nptr"]), int(p["m"]), int(mask_value), C.ptr(g), C.ptr(gc),
+                                    C.ptr(gpos), C.ptr(gq), C.ptr(gcell), C.ptr(galpha), C.ptr(scratch), ctypes.c_size_t(sbytes), C.stream_of(pos))
     C.check(rc, "mi_ewald_real_forces_bwd")
     return gpos, gq, gcell, galpha
 

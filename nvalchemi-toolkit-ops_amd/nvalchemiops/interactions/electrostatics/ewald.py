@@ -150,6 +150,15 @@ def _prepare_cell(cell: torch.Tensor):
     return cell, cell.shape[0]
 
 
+def _seg(x, batch_idx, n_sys):
+    """Per-system sum of a per-atom float64 vector (wave-aggregated `mi_segment_sum`, not one same-address atomic per atom)."""
+    out = torch.zeros(n_sys, dtype=x.dtype, device=x.device)
+    xc = x.contiguous()
+    if xc.shape[0]:
+        C.check(C.lib().mi_segment_sum(C.ptr(xc), C.ptr(batch_idx), xc.shape[0], C.dtype_code(xc.dtype), C.ptr(out), C.stream_of(xc)), "mi_segment_sum")
+    return out
+
+
 def _structure_factors(pos, w, kv, cells, al, sptr, n_sys, n_k, max_atoms, want_charge=True):
     dev = pos.device
     sf = torch.empty((n_sys, n_k, 2), dtype=torch.float64, device=dev)
@@ -262,7 +271,7 @@ def _recip_adjoint(p, g_e, need_atoms: bool, need_kv: bool, need_alpha: bool, ne
                 cross.append((-mg[..., 1] * srq - srg * m[..., 1] + mg[..., 0] * siq + sig * m[..., 0]) * ginv)
             gkv = gk + 0.5 * torch.stack(cross, dim=-1)
         gi_q = g * q64
-        seg = lambda x: torch.zeros(n_sys, dtype=torch.float64, device=pos.device).index_add_(0, sel, x)  # noqa: E731
+        seg = lambda x: _seg(x, bi, n_sys)  # noqa: E731
         if need_alpha:
             gal = 0.5 * (w * k2).sum(1) / (2.0 * al64**3) + seg(gi_q * (-q64 / math.sqrt(math.pi) + math.pi * tq[sel] / a_i**3))
         if need_vol:
@@ -305,7 +314,7 @@ def _recip_outputs_adjoint(p, g_f, g_c, need_alpha: bool, need_vol: bool, need_k
     a = _recip_gather(pos, q, kv, al, bi, sq, None, n_k, potential=False, kforce=True)
     b = _recip_gather(pos, q, kv, al, bi, s2.contiguous(), None, n_k, potential=True, kforce=True)
     a_i = al64[sel]
-    vsum = torch.zeros(n_sys, **f64).index_add_(0, sel, v)
+    vsum = _seg(v, bi, n_sys)
     vol = torch.abs(torch.linalg.det(cells.to(torch.float64)))
     gpos = -q64.unsqueeze(1) * b["kforce"] - v.unsqueeze(1) * a["kforce"]
     if g_f is not None:
@@ -327,7 +336,7 @@ def _recip_outputs_adjoint(p, g_f, g_c, need_alpha: bool, need_vol: bool, need_k
         ok = ok & (green > 1e-280)
         ginv = torch.where(ok, 1.0 / torch.where(ok, green, torch.ones_like(green)), torch.zeros_like(green))
         x = (sq[..., 0] * s2[..., 0] + sq[..., 1] * s2[..., 1]) * ginv
-        vq = torch.zeros(n_sys, **f64).index_add_(0, sel, v * q64)
+        vq = _seg(v * q64, bi, n_sys)
         if need_alpha:
             gal = (x * k2).sum(1) / (2.0 * al64**3) - 2.0 / math.sqrt(math.pi) * vq + 2.0 * math.pi / al64**3 * tq * vsum
         if need_vol:

@@ -8,7 +8,10 @@ import tempfile
 
 src = sys.argv[1]
 flt = sys.argv[2] if len(sys.argv) > 2 else ""
-flags = ["-fno-hip-fp32-correctly-rounded-divide-sqrt"] if os.path.basename(src) == "d3.hip" else []
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "nvalchemi-toolkit-ops_amd"))
+import build_native  # noqa: E402  (the product's per-file flags: the numbers must be those of the shipped objects)
+
+flags = [f for f in build_native.SOURCES.get(os.path.basename(src), []) if f]
 with tempfile.TemporaryDirectory() as d:
     r = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", *flags, "-x", "hip", "--cuda-device-only", "-c", src,
                         "-o", os.path.join(d, "k.co"), "-Rpass-analysis=kernel-resource-usage"], capture_output=True, text=True)
