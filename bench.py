@@ -58,7 +58,8 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 VALU_PEAK_GINSTR = 256 * 4 * 2.4 / 2.0
 # VALU wave-instructions per launch of the VALU-bound kernels on the headline box, from the committed SQ_INSTS_VALU pass
 # (profiles/: counters cannot be read from inside the timed run)
-VALU_PROFILE = os.path.join(ROOT, "profiles", "r02_pmc_valu.json")
+VALU_PROFILE = next((p for p in (os.path.join(ROOT, "profiles", n) for n in ("r03_pmc_valu.json", "r02_pmc_valu.json")) if os.path.exists(p)),
+                    os.path.join(ROOT, "profiles", "r03_pmc_valu.json"))
 PME = dict(cutoff=9.0, alpha=0.35, mesh=(128, 128, 128), order=5, max_neighbors=256)
 D3 = dict(cutoff=40.0, a1=0.4289, a2=4.4407, s8=0.7875, max_neighbors=2560)  # row width: explicit, as in the reference's own
 # D3 benchmark (benchmarks/interactions/dispersion/benchmark_dftd3.py:325-347 + its yaml `max_neighbors`); the fullest row of the headline box has 2497 entries
@@ -299,7 +300,7 @@ def profile_lookup(path: str, kernel: str, field: str, atoms: int, workload: str
 
 
 def traffic_profile():
-    for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+    for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
         path = os.path.join(ROOT, "profiles", name)
         if os.path.exists(path):
             return path
@@ -906,6 +907,12 @@ def main():
             result["roofline"]["frac_of_box_copy"] = result["roofline"]["achieved"] / calibration["copy_GBps"]
             result["roofline"]["frac_of_box_fill"] = result["roofline"]["achieved"] / calibration["fill_GBps"]
             result["roofline"]["frac_of_box_read"] = result["roofline"]["achieved"] / calibration["read_GBps"]
+            if result["roofline"].get("design_bytes_per_launch") and result["roofline"].get("launch_ms"):
+                # where the kernel deliberately moves other bytes than the 8(d) formula's (the CN pass also writes the packed copy): the
+                # bytes it moves per second against the same box figures
+                moved = result["roofline"]["design_bytes_per_launch"] / (result["roofline"]["launch_ms"] * 1e-3) / 1e9
+                result["roofline"]["moved_GBps"] = moved
+                result["roofline"]["moved_frac_of_box_copy"] = moved / calibration["copy_GBps"]
         if world == 1 and args.cpu_sample > 0:
             result["cpu_baseline"] = cpu_baseline(args.cpu_sample, args.cpu_full_size)
         print(json.dumps(result), flush=True)

@@ -6,7 +6,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/profile_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-python $R/bench.py --cpu-full-size > $OUT/bench.json 2> $OUT/bench.err
+BENCH_CALIB=1 python $R/bench.py --cpu-full-size > $OUT/bench.json 2> $OUT/bench.err
 python $R/bench.py --overlap 0 --cpu-sample 0 --steps 50 > $OUT/bench_serial.json 2>> $OUT/bench.err
 # kernel-trace statistics of the SAME command as bench.json (default flags) and of the serial variant
 rm -rf /tmp/prof_stats /tmp/prof_stats_serial
