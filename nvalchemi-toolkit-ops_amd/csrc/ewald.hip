@@ -37,10 +37,10 @@ __device__ __forceinline__ unsigned long long ew_entry_hash(unsigned a, unsigned
   h ^= __builtin_rotateleft32(b * 0x85EBCA77u, 13);
   h ^= sw * 0xC2B2AE3Du;
   h ^= h >> 15; h *= 0x2C1B3C6Du; h ^= h >> 12; h *= 0x297A2D39u; h ^= h >> 15;
-  unsigned g = b * 0x27D4EB2Fu;
-  g ^= __builtin_rotateleft32(a * 0x165667B1u, 17);
-  g ^= __builtin_rotateleft32(sw, 5) * 0x9E3779B9u;
-  g ^= g >> 16; g *= 0x7FEB352Du; g ^= g >> 15; g *= 0x846CA68Bu; g ^= g >> 16;
+  // second half: other multipliers on the raw inputs, folded with the finished first half (7 instructions instead of a second full mix:
+  // the check costs the real-space pass 0.195 -> 0.205 ms instead of 0.222)
+  unsigned g = (b * 0x27D4EB2Fu) ^ (a * 0x165667B1u) ^ __builtin_rotateleft32(h, 16) ^ sw;
+  g ^= g >> 15; g *= 0x846CA68Bu; g ^= g >> 16;
   return ((unsigned long long)g << 32) | h;
 }
 // Checksum scratch: sym[0..1] = final {forward, reverse} sums (written by ew_sym_reduce_kernel), then EW_SYM_SLOTS pairs of

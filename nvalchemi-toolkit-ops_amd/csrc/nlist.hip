@@ -33,7 +33,12 @@
 namespace {
 
 #define NL_PRUNE_R 8
+#ifndef NL_TILE
 #define NL_TILE 1024      // candidates staged in LDS per tile (fp64: 34 KB per block)
+#endif
+#ifndef NL_TILED_WAVES
+#define NL_TILED_WAVES 0   // > 0: register cap of the tiled query for this many waves per SIMD (tuning aid)
+#endif
 #define NL_MAXROWS 96     // (2Ry+1)(2Rz+1) rows of cells a block can describe (R <= 4)
 #define NL_MIXED 0x7fffffff
 #define NL_TILED_GRID 1536   // persistent blocks (6 per CU); cells are handed out dynamically
@@ -298,7 +303,11 @@ __device__ __forceinline__ bool nl_pair_hit(T pix, T piy, T piz, int i, T cjx, T
 // per atom.  Output path (ballot/popcount compaction, owner-written padding) is the same as the wave-per-atom kernel's.
 // FAST = neither naive-expression nor half-fill requested: the per-candidate test is straight-line code.
 template <class T, int MODE, bool FAST, bool DUAL = false>
+#if NL_TILED_WAVES > 0
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NL_TILED_WAVES, NL_TILED_WAVES))) void nl_query_tiled_kernel(
+#else
 __global__ __launch_bounds__(256) void nl_query_tiled_kernel(
+#endif
     const typename Vec4<T>::type* __restrict__ spos, const short4* __restrict__ swrap, const int* __restrict__ cell_start,
     const NlSys<T>* __restrict__ sys, const NlGlobal* __restrict__ glob, int B, T rc2, int flags, int* __restrict__ nm,
     int* __restrict__ nsh, int* __restrict__ num, int M, int fill_value, const int* __restrict__ ptr, int* __restrict__ list_ij,
