@@ -246,6 +246,32 @@ def make_step(sysd, tables, device, world):
             if OVERLAP == 1:
                 e_pme, f_pme = pme_branch()
                 e_d3, f_d3, nptr = d3_branch(sysd, params, cell_list, dftd3, n, d3_bufs)
+            elif OVERLAP == 3:
+                # schedule 3 (tuning aid): particle_mesh_ewald as its two public halves -- list + real-space sum (fp64 VALU-heavy) beside the
+                # HBM-bound 40-Bohr list write, the reciprocal half (spread / FFTs / gather: light on VALU) behind an event recorded after that
+                # list, i.e. beside the D3 passes
+                from nvalchemiops.interactions.electrostatics import ewald_real_space, pme_reciprocal_space
+
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    cell_list(sysd["pos64"], PME["cutoff"], sysd["cell64"], sysd["pbc"], neighbor_matrix=nm, neighbor_matrix_shifts=nsh,
+                              num_neighbors=num)
+                    al = torch.full((1,), PME["alpha"], dtype=torch.float64, device=device)
+                    e_r, f_r = ewald_real_space(sysd["pos64"], sysd["q64"], sysd["cell64"], al, neighbor_matrix=nm, neighbor_matrix_shifts=nsh,
+                                                mask_value=n, compute_forces=True)
+                ev_list = torch.cuda.Event()
+
+                def after_list():
+                    ev_list.record(main)
+                    with torch.cuda.stream(side):
+                        side.wait_event(ev_list)
+                        e_k, f_k = pme_reciprocal_space(sysd["pos64"], sysd["q64"], sysd["cell64"], PME["alpha"], mesh_dimensions=PME["mesh"],
+                                                        spline_order=PME["order"], compute_forces=True)
+                        box.append((e_r + e_k, f_r + f_k))
+
+                box = []
+                e_d3, f_d3, nptr = d3_branch(sysd, params, cell_list, dftd3, n, d3_bufs, after_list)
+                e_pme, f_pme = box[0]
             else:  # schedule 2 (tuning aid): the PME branch is enqueued after the D3 list, next to the D3 passes only
                 box = []
                 e_d3, f_d3, nptr = d3_branch(sysd, params, cell_list, dftd3, n, d3_bufs, lambda: box.append(pme_branch()))
@@ -721,7 +747,7 @@ def main():
     ap.add_argument("--d3-format", default="matrix", choices=["matrix", "csr"],
                     help="neighbour-list format of the D3 leg: padded matrix with explicit row width (default; what the reference's own D3 benchmark "
                          "uses) or exact-size COO/CSR (two-pass build)")
-    ap.add_argument("--overlap", type=int, default=1, choices=[0, 1, 2], help="1 (default): PME and D3 branches on two HIP streams; 0: one stream, per-stage times; 2: tuning aid")
+    ap.add_argument("--overlap", type=int, default=1, choices=[0, 1, 2, 3], help="1 (default): PME and D3 branches on two HIP streams; 0: one stream, per-stage times; 2: tuning aid")
     args = ap.parse_args()
     global VIRIAL, OVERLAP, D3_FORMAT
     VIRIAL = not args.no_virial

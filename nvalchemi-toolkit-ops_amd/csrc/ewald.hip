@@ -18,10 +18,43 @@
 
 namespace {
 
+// 1/x and 1/sqrt(x) in fp64 from the hardware seeds (v_rcp_f64 / v_rsq_f64, ~26 bits) + two Newton steps: <= 1 ulp, ~7 / ~10 instructions
+// against ~25 for an IEEE divide and ~30 + 25 for sqrt followed by a divide.  The real-space pass is fp64-VALU-bound; results move in the
+// last bit only (the parity bar of this path is 1e-10 relative).  EW_IEEE_DIV=1 restores the IEEE forms (A/B).
+#ifndef EW_IEEE_DIV
+#define EW_IEEE_DIV 0
+#endif
+__device__ __forceinline__ double ew_rcp(double x) {
+#if EW_IEEE_DIV
+  return 1.0 / x;
+#else
+  double y = __builtin_amdgcn_rcp(x);
+  y = fma(fma(-x, y, 1.0), y, y);
+  y = fma(fma(-x, y, 1.0), y, y);
+  return y;
+#endif
+}
+__device__ __forceinline__ double ew_rsqrt(double x) {
+  double y = __builtin_amdgcn_rsq(x);
+  y = y * fma(-0.5 * x * y, y, 1.5);
+  y = y * fma(-0.5 * x * y, y, 1.5);
+  return y;
+}
+// distance and reciprocal distance of a pair vector held in the positions dtype (see ewald_real_kernel)
+template <class T> __device__ __forceinline__ void ew_dist(T sx, T sy, T sz, double& dist, double& rinv) {
+  if (sizeof(T) == 8 && !EW_IEEE_DIV) {
+    const double r2 = (double)(sx * sx + sy * sy + sz * sz);
+    rinv = ew_rsqrt(r2);
+    dist = r2 * rinv;
+  } else {
+    dist = (double)sqrt(sx * sx + sy * sy + sz * sz);
+    rinv = ew_rcp(dist);
+  }
+}
 __device__ __forceinline__ double erfc_as_poly(double x, double e_neg_x2) {
   // x >= 0 here (alpha * distance); constants verbatim from math/math.py:73-78
   const double p = 0.3275911, a1 = 0.254829592, a2 = -0.284496736, a3 = 1.421413741, a4 = -1.453152027, a5 = 1.061405429;
-  const double t = 1.0 / (1.0 + p * x);
+  const double t = ew_rcp(1.0 + p * x);
   const double t2 = t * t, t3 = t2 * t, t4 = t3 * t, t5 = t4 * t;
   const double poly = a1 * t + a2 * t2 + a3 * t3 + a4 * t4 + a5 * t5;
   return poly * e_neg_x2;
@@ -115,18 +148,24 @@ __global__ __launch_bounds__(256) void ewald_real_kernel(const T* __restrict__ p
     T sh[3];
     rowvec_mat3(fs, cm, sh);  // == transpose(cell) * S with the same summation order
     const T sx = (pjx - pix) + sh[0], sy = (pjy - piy) + sh[1], sz = (pjz - piz) + sh[2];
-    const double dist = (double)sqrt(sx * sx + sy * sy + sz * sz);
-    if (!(dist > 1e-8)) continue;
+    // distance and its reciprocal: fp64 positions -> one reciprocal square root (dist = r2 * rinv, <= 1 ulp from sqrt); fp32 positions keep
+    // the reference's fp32 sqrt (the distance is an fp32 quantity there) and take the reciprocal of its fp64 cast
+    double dist, rinv;
+    ew_dist<T>(sx, sy, sz, dist, rinv);
+    if (!(dist > 1e-8)) continue;  // (r2 == 0: rsq = inf, dist = NaN -> skipped as well)
     const double ar = al * dist;
     const double ex = exp(-(ar * ar));
     const double ec = erfc_as_poly(ar, ex);
-    eacc += 0.5 * qi * qj * ec / dist;
+    // products instead of the reference's quotients ec / d, ec / d^3, ex / d^2: the same numbers to the last bit or two
+    const double pot = ec * rinv;
+    eacc += 0.5 * qi * qj * pot;
     if (wf) {
-      const double fm = (0.5 * qi * qj) * (ec / (dist * dist * dist) + two_over_sqrt_pi * al * ex / (dist * dist));
+      const double rinv2 = rinv * rinv;
+      const double fm = (0.5 * qi * qj) * (pot * rinv2 + two_over_sqrt_pi * al * ex * rinv2);
       const T fmt = (T)fm;
       fx -= fmt * sx; fy -= fmt * sy; fz -= fmt * sz;
     }
-    if (wc) cgi += qj * (0.5 * ec / dist);
+    if (wc) cgi += qj * (0.5 * pot);
   }
   eacc = wave_sum(eacc);
   if (lane == 0) energies[i] = eacc;
@@ -241,15 +280,17 @@ __global__ __launch_bounds__(256) void ewald_real_bwd_kernel(const T* __restrict
     T sh[3];
     rowvec_mat3(fs, cm, sh);
     const T sx = (pos[3 * (size_t)j] - pix) + sh[0], sy = (pos[3 * (size_t)j + 1] - piy) + sh[1], sz = (pos[3 * (size_t)j + 2] - piz) + sh[2];
-    const double dist = (double)sqrt(sx * sx + sy * sy + sz * sz);
+    double dist, rinv;
+    ew_dist<T>(sx, sy, sz, dist, rinv);
     if (!(dist > 1e-8)) continue;
     const double ar = al * dist;
     const double ex = exp(-(ar * ar));
     const double ec = erfc_as_poly(ar, ex);
-    const double fm = (0.5 * qi * qj) * (ec / (dist * dist * dist) + two_over_sqrt_pi * al * ex / (dist * dist));
+    const double rinv2 = rinv * rinv, pot = ec * rinv;
+    const double fm = (0.5 * qi * qj) * (pot * rinv2 + two_over_sqrt_pi * al * ex * rinv2);
     const double wsum = gi + gj;
     gx += wsum * fm * (double)sx; gy += wsum * fm * (double)sy; gz += wsum * fm * (double)sz;
-    gqi += 0.5 * wsum * qj * ec / dist;
+    gqi += 0.5 * wsum * qj * pot;
     if (galpha) ga += gi * (0.5 * qi * qj) * (-two_over_sqrt_pi * ex);
     if (gcell) {
       const double f = -gi * fm;
@@ -388,19 +429,20 @@ __global__ __launch_bounds__(256) void ewald_real_force_bwd_kernel(const T* __re
     T sh[3];
     rowvec_mat3(fs, cm, sh);
     const T sxT = (pos[3 * (size_t)j] - pix) + sh[0], syT = (pos[3 * (size_t)j + 1] - piy) + sh[1], szT = (pos[3 * (size_t)j + 2] - piz) + sh[2];
-    const double d = (double)sqrt(sxT * sxT + syT * syT + szT * szT);
+    double d, ri;
+    ew_dist<T>(sxT, syT, szT, d, ri);
     if (!(d > 1e-8)) continue;
     const double sx = (double)sxT, sy = (double)syT, sz = (double)szT;
     const double ar = al * d, ex = exp(-(ar * ar)), ec = erfc_as_poly(ar, ex);
-    const double d2 = d * d, d3 = d2 * d;
-    const double g = ec / d3 + c * ex / d2;
-    const double gp = -3.0 * ec / (d2 * d2) - 3.0 * c * ex / d3 - 2.0 * al * al * c * ex / d;
+    const double ri2 = ri * ri, ri3 = ri2 * ri;
+    const double g = ec * ri3 + c * ex * ri2;
+    const double gp = -3.0 * ec * (ri2 * ri2) - 3.0 * c * ex * ri3 - 2.0 * al * al * c * ex * ri;
     double Gx = 0.0, Gy = 0.0, Gz = 0.0, dqi = 0.0, dqj = 0.0;
     if (gF) {
       const double dwx = (double)gF[3 * (size_t)j] - wix, dwy = (double)gF[3 * (size_t)j + 1] - wiy, dwz = (double)gF[3 * (size_t)j + 2] - wiz;
       const double u = dwx * sx + dwy * sy + dwz * sz;
       const double hq = 0.5 * qi * qj;
-      const double k1 = hq * gp * u / d;
+      const double k1 = hq * gp * u * ri;
       Gx = k1 * sx + hq * g * dwx; Gy = k1 * sy + hq * g * dwy; Gz = k1 * sz + hq * g * dwz;
       dqi = 0.5 * qj * g * u;
       dqj = 0.5 * qi * g * u;
@@ -409,7 +451,7 @@ __global__ __launch_bounds__(256) void ewald_real_force_bwd_kernel(const T* __re
     if (gC) {
       // charge-gradient outputs: the entry adds 1/2 q_j phi to cg_i and 1/2 q_i phi to cg_j, phi = erfc(a d)/d, so for L = sum_k v_k cg_k
       //   L_e = 1/2 phi A, A = v_i q_j + v_j q_i ;  dL_e/dsep = 1/2 A phi' sep/d = -1/2 A g sep ;  dL_e/dalpha = -1/2 A (2/sqrt(pi)) e^{-a^2 d^2}
-      const double vj = (double)gC[j], phi = ec / d, A = vi * qj + vj * qi;
+      const double vj = (double)gC[j], phi = ec * ri, A = vi * qj + vj * qi;
       const double k2 = -0.5 * A * g;
       Gx += k2 * sx; Gy += k2 * sy; Gz += k2 * sz;
       dqi += 0.5 * phi * vj;
