@@ -28,7 +28,7 @@ SOURCES = {
     # costs v_mov's to pair the operands -- the energy pass is VALU-issue-bound
     "d3.hip": ["-fno-hip-fp32-correctly-rounded-divide-sqrt", "-fno-slp-vectorize"] + os.environ.get("MI_D3_EXTRA_FLAGS", "").split(),
     "ewald.hip": os.environ.get("MI_EWALD_EXTRA_FLAGS", "").split(),
-    "pme.hip": [],
+    "pme.hip": os.environ.get("MI_PME_EXTRA_FLAGS", "").split(),
     "calib.hip": [],
 }
 COMMON = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]

@@ -589,6 +589,9 @@ __device__ __forceinline__ void d3_c6_fact(const D3Half& h, const float* v, cons
   }
 }
 
+// float4 of LDS per wave of the energy pass: general form 16 x 25 {c6, cn_ref_i, cn_ref_j} (6.4 KB), factorised form 16 x 44 floats (2.8 KB)
+__host__ __device__ constexpr int d3_wave_f4(int mode) { return mode == 1 ? D3_SMAX * 25 : mode == 2 ? D3_SMAX * D3_FROW / 4 : 1; }
+
 // ---- pass 2: energy, direct force, dE/dCN ------------------------------------------------------------
 // MODE 0: global [nz,nz,25] table (> 16 species); 1: general 25-term interpolation from the LDS-staged compact table;
 // 2: factorised interpolation.  All three are launched; the two that do not match the device-side species info exit at once.
@@ -602,11 +605,11 @@ __device__ __forceinline__ void d3_energy_body(const T* __restrict__ pos, const 
                                                         const typename Vec4<T>::type* __restrict__ apos, const float4* __restrict__ aaux,
                                                         const float4* __restrict__ aw, float* __restrict__ dEdCN,
                                                         float* __restrict__ forces, float* __restrict__ e_atom, double* __restrict__ v_atom,
-                                                        const unsigned* __restrict__ pk, const int* __restrict__ pk_flag) {
+                                                        const unsigned* __restrict__ pk, const int* __restrict__ pk_flag,
+                                                        float4* __restrict__ lds_buf /* 4 * d3_wave_f4(MODE) float4 of the kernel's LDS */) {
   constexpr bool LDS = MODE == 1;
   constexpr bool PACKED = MODE == 2 && sizeof(T) == 4;  // one 32-byte record per neighbour (see d3_weights_kernel)
-  constexpr int WAVE_F4 = MODE == 1 ? D3_SMAX * 25 : MODE == 2 ? D3_SMAX * D3_FROW / 4 : 1;  // float4 per wave
-  __shared__ float4 lds_tab[MODE == 0 ? 1 : 4][WAVE_F4];
+  constexpr int WAVE_F4 = d3_wave_f4(MODE);  // float4 per wave
   const int S = sinfo->S;
   const int want_mode = S > D3_SMAX ? 0 : (sinfo->factorized ? 2 : 1);
   if (want_mode != MODE) return;
@@ -626,7 +629,7 @@ __device__ __forceinline__ void d3_energy_body(const T* __restrict__ pos, const 
   const float4* __restrict__ tab_i = P.tab + (size_t)zi * P.nz * 25;
   // stage this element's rows of the compact species table in the wave's private LDS slice
   const int code_i = (zi << 8) | (smap[zi] & 0xff);  // own species: a safe table row for masked-out lanes
-  float4* my_tab = lds_tab[MODE != 0 ? (threadIdx.x / MI_WAVE) & 3 : 0];
+  float4* my_tab = lds_buf + (MODE != 0 ? ((threadIdx.x / MI_WAVE) & 3) * WAVE_F4 : 0);
   if (LDS) {
     const float4* __restrict__ src = ctab + (size_t)smap[zi] * S * 25;
     for (int k = lane; k < S * 25; k += MI_WAVE) my_tab[k] = src[k];
@@ -760,9 +763,10 @@ __device__ __forceinline__ void d3_energy_body(const T* __restrict__ pos, const 
 
 
 #define D3_ENERGY_PARAMS const T* __restrict__ pos, const int* __restrict__ numbers, int N, const int* __restrict__ idx, const int* __restrict__ ush, const int* __restrict__ nptr, int M, int fill_value, const T* __restrict__ cell, const int* __restrict__ batch_idx, D3Dev P, const float* __restrict__ cn, int want_virial, const int* __restrict__ smap, const D3Species* __restrict__ sinfo, const float4* __restrict__ ctab, const float* __restrict__ ftab, const float* __restrict__ fcr, const typename Vec4<T>::type* __restrict__ apos, const float4* __restrict__ aaux, const float4* __restrict__ aw, float* __restrict__ dEdCN, float* __restrict__ forces, float* __restrict__ e_atom, double* __restrict__ v_atom, const unsigned* __restrict__ pk, const int* __restrict__ pk_flag
-#define D3_ENERGY_ARGS pos, numbers, N, idx, ush, nptr, M, fill_value, cell, batch_idx, P, cn, want_virial, smap, sinfo, ctab, ftab, fcr, apos, aaux, aw, dEdCN, forces, e_atom, v_atom, pk, pk_flag
+#define D3_ENERGY_ARGS pos, numbers, N, idx, ush, nptr, M, fill_value, cell, batch_idx, P, cn, want_virial, smap, sinfo, ctab, ftab, fcr, apos, aaux, aw, dEdCN, forces, e_atom, v_atom, pk, pk_flag, lds_buf
 template <class T, bool CSR, int MODE, bool PK>
 __global__ __launch_bounds__(256) void d3_energy_kernel(D3_ENERGY_PARAMS) {
+  __shared__ float4 lds_buf[4 * d3_wave_f4(MODE)];
   d3_energy_body<T, CSR, MODE, PK>(D3_ENERGY_ARGS);
 }
 // the fp32 factorised variant is latency-bound once its contraction is cheap (gathers from L2): it fits the register budget of
@@ -773,11 +777,19 @@ __global__ __launch_bounds__(256) void d3_energy_kernel(D3_ENERGY_PARAMS) {
 // (the plain-list variants need a few registers more for their decoded pipeline steps: 7 waves / SIMD without scratch instead of 8 with 5-7 spills)
 template <class T, bool CSR, int MODE, bool PK>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PK ? D3_ENERGY_WAVES : D3_ENERGY_WAVES - 1, PK ? D3_ENERGY_WAVES : D3_ENERGY_WAVES - 1))) void d3_energy_kernel_w5(D3_ENERGY_PARAMS) {
+  __shared__ float4 lds_buf[4 * d3_wave_f4(MODE)];
   d3_energy_body<T, CSR, MODE, PK>(D3_ENERGY_ARGS);
 }
-// all three plain variants in one launch: what runs behind the packed variants (one dead launch instead of three when the packed copy was usable)
+// Everything but the common case in ONE launch behind the packed factorised variant: the packed general / global-table variants and the
+// three plain-list variants (the bodies select themselves on the device-side species info and the packed-list flag; all but at most one
+// return at once).  Round 3: this replaces three dead launches per call (~7 us each on the dependent D3 chain) by one.
 template <class T, bool CSR>
-__global__ __launch_bounds__(256) void d3_energy_fallback_kernel(D3_ENERGY_PARAMS) {
+__global__ __launch_bounds__(256) void d3_energy_fallback_kernel(D3_ENERGY_PARAMS, const unsigned* __restrict__ pk_packed) {
+  __shared__ float4 lds_buf[4 * d3_wave_f4(1)];  // one buffer for all bodies (the general form's is the largest): at most one of them works
+  d3_energy_body<T, CSR, 1, true>(pos, numbers, N, idx, ush, nptr, M, fill_value, cell, batch_idx, P, cn, want_virial, smap, sinfo, ctab, ftab, fcr, apos, aaux,
+                                  aw, dEdCN, forces, e_atom, v_atom, pk_packed, pk_flag, lds_buf);
+  d3_energy_body<T, CSR, 0, true>(pos, numbers, N, idx, ush, nptr, M, fill_value, cell, batch_idx, P, cn, want_virial, smap, sinfo, ctab, ftab, fcr, apos, aaux,
+                                  aw, dEdCN, forces, e_atom, v_atom, pk_packed, pk_flag, lds_buf);
   d3_energy_body<T, CSR, 2, false>(D3_ENERGY_ARGS);
   d3_energy_body<T, CSR, 1, false>(D3_ENERGY_ARGS);
   d3_energy_body<T, CSR, 0, false>(D3_ENERGY_ARGS);
@@ -867,12 +879,16 @@ __global__ __launch_bounds__(D3_LS_WAVES * MI_WAVE) void d3_chain_kernel(const T
 // per-system reduction of per-atom energies / virials.  A few hundred waves each own a contiguous slab of atoms, keep a
 // running (system, sum) pair and touch global memory with ONE atomic per system change (batches are contiguous per
 // system, so that is ~1 per wave): 10 values x 256 waves instead of one atomic per 64 atoms on the same addresses.
+// (round 3: the partial sums of a system are spread over D3_REDUCE_SLOTS slot rows -- 2560 fp64 atomics on ten addresses were 27 us of
+// serialisation on the single-system headline box; d3_finish_kernel folds the slots)
 #define D3_REDUCE_WAVES 256
+#define D3_REDUCE_SLOTS 16
 __global__ __launch_bounds__(256) void d3_reduce_kernel(const float* __restrict__ e_atom, const double* __restrict__ v_atom,
                                                         const int* __restrict__ batch_idx, int N, int want_virial,
-                                                        double* __restrict__ sums /*[B][10], zeroed*/) {
+                                                        double* __restrict__ sums /*[B][D3_REDUCE_SLOTS][10], zeroed*/) {
   const int lane = threadIdx.x & (MI_WAVE - 1);
   const int wave = blockIdx.x * (blockDim.x / MI_WAVE) + threadIdx.x / MI_WAVE;
+  const int slot = wave & (D3_REDUCE_SLOTS - 1);
   const int chunks = (N + MI_WAVE - 1) / MI_WAVE;
   const int per = (chunks + D3_REDUCE_WAVES - 1) / D3_REDUCE_WAVES;
   const int c0 = wave * per, c1 = (c0 + per < chunks) ? c0 + per : chunks;
@@ -886,7 +902,7 @@ __global__ __launch_bounds__(256) void d3_reduce_kernel(const float* __restrict_
     for (int k = 0; k < 10; ++k) {
       if (k > 0 && !want_virial) break;
       const double v = wave_sum(acc[k]);
-      if (lane == 0) atomicAdd(&sums[10 * (size_t)cur + k], v);
+      if (lane == 0) atomicAdd(&sums[10 * ((size_t)cur * D3_REDUCE_SLOTS + slot) + k], v);
       acc[k] = 0.0;
     }
   };
@@ -902,8 +918,8 @@ __global__ __launch_bounds__(256) void d3_reduce_kernel(const float* __restrict_
         if (want_virial) for (int k = 0; k < 9; ++k) acc[k + 1] += v_atom[9 * (size_t)i + k];
       }
     } else if (in) {  // a chunk straddling systems: per-lane atomics
-      atomicAdd(&sums[10 * (size_t)s], (double)e_atom[i]);
-      if (want_virial) for (int k = 0; k < 9; ++k) atomicAdd(&sums[10 * (size_t)s + 1 + k], v_atom[9 * (size_t)i + k]);
+      atomicAdd(&sums[10 * ((size_t)s * D3_REDUCE_SLOTS + slot)], (double)e_atom[i]);
+      if (want_virial) for (int k = 0; k < 9; ++k) atomicAdd(&sums[10 * ((size_t)s * D3_REDUCE_SLOTS + slot) + 1 + k], v_atom[9 * (size_t)i + k]);
     }
   }
   flush();
@@ -912,8 +928,11 @@ __global__ void d3_finish_kernel(const double* __restrict__ sums, int B, int wan
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= 10 * B) return;
   const int s = t / 10, k = t - 10 * s;
-  if (k == 0) energy[s] = (float)sums[t];
-  else if (want_virial) virial[9 * (size_t)s + (k - 1)] = (float)sums[t];
+  double v = 0.0;
+#pragma unroll
+  for (int q = 0; q < D3_REDUCE_SLOTS; ++q) v += sums[10 * ((size_t)s * D3_REDUCE_SLOTS + q) + k];  // fixed order: deterministic given the slot sums
+  if (k == 0) energy[s] = (float)v;
+  else if (want_virial) virial[9 * (size_t)s + (k - 1)] = (float)v;
 }
 
 struct D3Layout { size_t dEdCN, e_atom, v_atom, sums, tab, present, smap, sinfo, ctab, ftab, fcr, apos, aaux, aw, total; };
@@ -924,7 +943,7 @@ D3Layout d3_layout(int N, int nz, int dtype, int B) {
   L.dEdCN = take(sizeof(float) * (size_t)N);
   L.e_atom = take(sizeof(float) * (size_t)N);
   L.v_atom = take(sizeof(double) * 9 * (size_t)N);  // fp64: the direct and the chain-rule part of an atom's virial can cancel (dense systems)
-  L.sums = take(sizeof(double) * 10 * (size_t)(B > 0 ? B : 1));
+  L.sums = take(sizeof(double) * 10 * D3_REDUCE_SLOTS * (size_t)(B > 0 ? B : 1));
   L.tab = take(sizeof(float4) * (size_t)nz * nz * 25);
   L.present = take(sizeof(int) * (size_t)nz);
   L.smap = take(sizeof(int) * (size_t)nz);
@@ -1010,10 +1029,10 @@ int d3_impl(const T* pos, const int* numbers, int N, const int* idx, const int* 
   // with a packed list the PK variants run; if the CN pass found a shift outside {-1, 0, 1} they exit and the fallback launch (energy) or
   // the in-kernel fallback (chain) walks the caller's arrays
   if (pk) {
-    MI_TIMED("d3_energy", st, (launch_modes(Packed{})));
+    MI_TIMED("d3_energy", st, (launch_energy(std::integral_constant<int, 2>{}, Packed{})));
     MI_LAUNCH_CHECK();
     d3_energy_fallback_kernel<T, CSR><<<blocks, 256, 0, st>>>(pos, numbers, N, idx, ush, nptr, M, fill_value, cell, batch_idx, P, cn, want_virial, smap, sinfo,
-                                                              ctab, ftab, fcr, apos, aaux, aw, dEdCN, forces, e_atom, v_atom, nullptr, pk_flag);
+                                                              ctab, ftab, fcr, apos, aaux, aw, dEdCN, forces, e_atom, v_atom, nullptr, pk_flag, pk);
   } else { MI_TIMED("d3_energy", st, (launch_modes(Plain{}))); }
   MI_LAUNCH_CHECK();
   auto launch_chain = [&](auto packed) {
@@ -1025,7 +1044,7 @@ int d3_impl(const T* pos, const int* numbers, int N, const int* idx, const int* 
   else { MI_TIMED("d3_chain", st, (launch_chain(Plain{}))); }
   MI_LAUNCH_CHECK();
   double* sums = reinterpret_cast<double*>(ws + L.sums);
-  MI_HIP_CHECK(hipMemsetAsync(sums, 0, sizeof(double) * 10 * (size_t)B, st));
+  MI_HIP_CHECK(hipMemsetAsync(sums, 0, sizeof(double) * 10 * D3_REDUCE_SLOTS * (size_t)B, st));
   d3_reduce_kernel<<<D3_REDUCE_WAVES / 4, 256, 0, st>>>(e_atom, v_atom, batch_idx, N, want_virial, sums);
   MI_LAUNCH_CHECK();
   d3_finish_kernel<<<mi_blocks(10ll * B, 256), 256, 0, st>>>(sums, B, want_virial, energy, virial);

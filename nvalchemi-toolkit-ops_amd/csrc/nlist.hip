@@ -36,6 +36,9 @@ namespace {
 #ifndef NL_TILE
 #define NL_TILE 1024      // candidates staged in LDS per tile (fp64: 34 KB per block)
 #endif
+#ifndef NL_TILE_F64
+#define NL_TILE_F64 768
+#endif
 #ifndef NL_TILED_WAVES
 #define NL_TILED_WAVES 0   // > 0: register cap of the tiled query for this many waves per SIMD (tuning aid)
 #endif
@@ -313,16 +316,19 @@ __global__ __launch_bounds__(256) void nl_query_tiled_kernel(
     int* __restrict__ nsh, int* __restrict__ num, int M, int fill_value, const int* __restrict__ ptr, int* __restrict__ list_ij,
     int* __restrict__ list_sh, long long P, NlSecond<T> D) {
   static_assert(!DUAL || (MODE == MI_NL_MODE_MATRIX && !FAST), "the dual-cutoff sweep is instantiated for the general matrix kernel only");
+  // candidates staged in LDS per tile: fp64 records are twice as large and the fp64 kernel needs 112 VGPRs (4 waves / SIMD), so the smaller
+  // tile is what lets a fourth block fit the LDS of a CU (9 A headline list: 0.254 -> 0.226 ms, profiles/r03_ab_nl_segfill.log)
+  constexpr int TILE = sizeof(T) == 8 ? NL_TILE_F64 : NL_TILE;
   if (!glob->use_tiled) return;
   if (!DUAL && FAST != ((flags & (MI_NL_HALF_FILL | MI_NL_NAIVE_EXPR)) == 0)) return;  // the other instantiation handles this call
   __shared__ int ccnt2[DUAL ? 256 : 1];
-  __shared__ T tx[NL_TILE], ty[NL_TILE], tz[NL_TILE];
-  __shared__ int tj[NL_TILE];
-  __shared__ short tsx[NL_TILE], tsy[NL_TILE], tsz[NL_TILE];
+  __shared__ T tx[TILE], ty[TILE], tz[TILE];
+  __shared__ int tj[TILE];
+  __shared__ short tsx[TILE], tsy[TILE], tsz[TILE];
   __shared__ int run_beg[3 * NL_MAXROWS], run_pre[3 * NL_MAXROWS + 1], run_cs[3 * NL_MAXROWS];
   __shared__ int ccnt[256];
-  __shared__ int grp_run[NL_TILE / MI_WAVE];  // run containing the first candidate of each 64-candidate group of the current tile
-  __shared__ int grp_shift[NL_TILE / MI_WAVE];  // packed image shift common to all 64 candidates of the group, or NL_MIXED
+  __shared__ int grp_run[TILE / MI_WAVE];  // run containing the first candidate of each 64-candidate group of the current tile
+  __shared__ int grp_shift[TILE / MI_WAVE];  // packed image shift common to all 64 candidates of the group, or NL_MIXED
   __shared__ int u_beg[3 * NL_MAXROWS], u_len[3 * NL_MAXROWS], u_cs[3 * NL_MAXROWS];  // run table before ordering by image
   const int tid = threadIdx.x, lane = tid & (MI_WAVE - 1), wave = tid / MI_WAVE;
   const int total_cells = glob->total_cells;
@@ -413,10 +419,10 @@ __global__ __launch_bounds__(256) void nl_query_tiled_kernel(
       const int cend = (cbase + 256 < n_c) ? cbase + 256 : n_c;
       ccnt[tid] = 0;
       if (DUAL) ccnt2[tid] = 0;
-      for (int tile0 = 0; tile0 < total; tile0 += NL_TILE) {
-        const int tile_n = (total - tile0 < NL_TILE) ? total - tile0 : NL_TILE;
+      for (int tile0 = 0; tile0 < total; tile0 += TILE) {
+        const int tile_n = (total - tile0 < TILE) ? total - tile0 : TILE;
         __syncthreads();  // the previous tile has been consumed (and ccnt initialised)
-        if (tid < NL_TILE / MI_WAVE && tile0 + tid * MI_WAVE < total) {
+        if (tid < TILE / MI_WAVE && tile0 + tid * MI_WAVE < total) {
           const int v = tile0 + tid * MI_WAVE;
           int lo = 0, hi = nruns - 1;  // last run with run_pre[run] <= v (zero-length runs share a prefix value: take the last)
           while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (run_pre[mid] <= v) lo = mid; else hi = mid - 1; }

@@ -491,13 +491,25 @@ __global__ __launch_bounds__(128) void spline_spread_grad_kernel(const T* __rest
 // (0.131 vs 0.133 ms with one thread per atom: the kernel is bound by the ~1.7 GB of cache lines the stencils pull from L2 / MALL, not by
 // per-thread latency); kept because small systems get 8x the threads.
 #define PG_LANES 8
+#ifndef PME_XCD_SLABS
+#define PME_XCD_SLABS 1
+#endif
 template <class T>
 __global__ __launch_bounds__(256) void pme_gather_finish_kernel(const T* __restrict__ pos, const T* __restrict__ charges, const int* __restrict__ batch_idx,
                                          const T* __restrict__ cit, const T* __restrict__ meshes, const T* __restrict__ alpha,
                                          const T* __restrict__ volume, const T* __restrict__ qtot, int N, int nx, int ny, int nz, int order,
                                          int with_field, T* __restrict__ energies, T* __restrict__ forces, T* __restrict__ cgrads,
                                          const double* __restrict__ add_e, const T* __restrict__ add_f, const double* __restrict__ add_cg) {
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  // XCD-aware block -> atom-range mapping: workgroups are dispatched round-robin over the 8 XCDs (each with its own L2), so with the identity
+  // mapping every XCD walks the whole system and each L2 pulls all four meshes (PMC: 0.40 GB of fetches for 0.07 GB of mesh on the headline
+  // box).  Block b runs on XCD b mod 8: give XCD x the x-th eighth of the atom range, so that -- for spatially ordered atoms, the usual
+  // case -- each L2 only sees its slab of the meshes.  Any atom order stays correct; PME_XCD_SLABS=0 restores the identity mapping (A/B).
+  int vb = blockIdx.x;
+  if (PME_XCD_SLABS && gridDim.x >= 64) {
+    const int per = gridDim.x / 8, full = per * 8;  // the last gridDim.x % 8 blocks keep their place
+    if (vb < full) vb = (vb & 7) * per + (vb >> 3);
+  }
+  const int t = vb * blockDim.x + threadIdx.x;
   const int i0 = t / PG_LANES, tx = t - i0 * PG_LANES;
   const int i = i0 < N ? i0 : N - 1;  // surplus groups of the last block recompute the last atom and do not store
   const int s = batch_idx ? batch_idx[i] : 0;
