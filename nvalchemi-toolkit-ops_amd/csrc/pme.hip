@@ -224,10 +224,13 @@ __global__ void spread_key_kernel(const T* __restrict__ pos, const int* __restri
   }
   bs_wave_add<false>(count, key, in);  // the tile's atom counter (binsort.h): one atomic per distinct tile per wave
 }
-template <class T>
+// ORDER is a template parameter (round 3): the item -> (atom, tx, ty) split and the z loop become constant divisions / a full unroll, and
+// the "does this point fall into my tile" tests are range compares instead of divisions by the tile edge
+template <class T, int ORDER>
 __global__ __launch_bounds__(256) void spread_tiled_kernel(const T* __restrict__ values, const int* __restrict__ atom_of, const int* __restrict__ bin_start,
-                                                           const int4* __restrict__ lo3, const T* __restrict__ wts, int nx, int ny, int nz, int order,
+                                                           const int4* __restrict__ lo3, const T* __restrict__ wts, int nx, int ny, int nz,
                                                            int batched, SpTile e, T* __restrict__ mesh) {
+  constexpr int order = ORDER;
   __shared__ T tile[SP_T * SP_T * SP_T];
   const int nbx = nx / e.ex, nby = ny / e.ey, nbz = nz / e.ez, tile_n = e.ex * e.ey * e.ez;
   int b = blockIdx.x;
@@ -255,17 +258,20 @@ __global__ __launch_bounds__(256) void spread_tiled_kernel(const T* __restrict__
           int gx = lo.x + tx, gy = lo.y + ty;  // lo is already wrapped and order <= n: one conditional subtraction wraps
           gx -= gx >= nx ? nx : 0;
           gy -= gy >= ny ? ny : 0;
-          if (gx / e.ex != bx || gy / e.ey != by) continue;
+          const int rx = gx - bx * e.ex, ry = gy - by * e.ey;  // offsets inside this tile, if the point belongs to it
+          if ((unsigned)rx >= (unsigned)e.ex || (unsigned)ry >= (unsigned)e.ey) continue;
           const T* w3 = wts + (size_t)i * 3 * MI_MAX_ORDER;
           const T wxy = w3[tx] * w3[MI_MAX_ORDER + ty];
           const T val = values[i];
-          T* row = tile + ((gx - bx * e.ex) * e.ey + (gy - by * e.ey)) * e.ez;
+          T* row = tile + (rx * e.ey + ry) * e.ez;
+#pragma unroll
           for (int tz = 0; tz < order; ++tz) {
             int gz = lo.z + tz;
             gz -= gz >= nz ? nz : 0;
-            if (gz / e.ez != bz) continue;
+            const int rz = gz - bz * e.ez;
+            if ((unsigned)rz >= (unsigned)e.ez) continue;
             const T w = wxy * w3[2 * MI_MAX_ORDER + tz];
-            if (w > thr) atomicAdd(row + (gz - bz * e.ez), val * w);
+            if (w > thr) atomicAdd(row + rz, val * w);
           }
         }
       }
@@ -691,7 +697,12 @@ int spread_tiled(const T* pos, const T* values, const int* batch_idx, const T* c
   // order inside a tile's atom list is arrival order: the tile kernel adds the contributions with LDS atomics, whose order is
   // not fixed either (fp64/fp32 sums of <= a few hundred terms per mesh point; parity tests hold at 1e-10)
   MI_HIP_CHECK(bs_sort(bins, keys_in, N, nullptr, vals_out, bin_start, st));
-  spread_tiled_kernel<T><<<(int)L.nbins, 256, 0, st>>>(values, vals_out, bin_start, lo3, wts, nx, ny, nz, order, batched, e, mesh);
+  switch (order) {
+#define MI_SPT(O_) case O_: spread_tiled_kernel<T, O_><<<(int)L.nbins, 256, 0, st>>>(values, vals_out, bin_start, lo3, wts, nx, ny, nz, batched, e, mesh); break
+    MI_SPT(1); MI_SPT(2); MI_SPT(3); MI_SPT(4); MI_SPT(5);
+    default: spread_tiled_kernel<T, 6><<<(int)L.nbins, 256, 0, st>>>(values, vals_out, bin_start, lo3, wts, nx, ny, nz, batched, e, mesh); break;
+#undef MI_SPT
+  }
   MI_LAUNCH_CHECK();
   return MI_OK;
 }
