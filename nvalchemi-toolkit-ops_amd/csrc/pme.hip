@@ -500,12 +500,13 @@ __global__ __launch_bounds__(128) void spline_spread_grad_kernel(const T* __rest
 #ifndef PME_XCD_SLABS
 #define PME_XCD_SLABS 1
 #endif
-template <class T>
+template <class T, int ORDER>
 __global__ __launch_bounds__(256) void pme_gather_finish_kernel(const T* __restrict__ pos, const T* __restrict__ charges, const int* __restrict__ batch_idx,
                                          const T* __restrict__ cit, const T* __restrict__ meshes, const T* __restrict__ alpha,
-                                         const T* __restrict__ volume, const T* __restrict__ qtot, int N, int nx, int ny, int nz, int order,
+                                         const T* __restrict__ volume, const T* __restrict__ qtot, int N, int nx, int ny, int nz,
                                          int with_field, T* __restrict__ energies, T* __restrict__ forces, T* __restrict__ cgrads,
                                          const double* __restrict__ add_e, const T* __restrict__ add_f, const double* __restrict__ add_cg) {
+  constexpr int order = ORDER;  // compile-time spline order: the weight evaluations and the stencil loops unroll
   // XCD-aware block -> atom-range mapping: workgroups are dispatched round-robin over the 8 XCDs (each with its own L2), so with the identity
   // mapping every XCD walks the whole system and each L2 pulls all four meshes (PMC: 0.40 GB of fetches for 0.07 GB of mesh on the headline
   // box).  Block b runs on XCD b mod 8: give XCD x the x-th eighth of the atom range, so that -- for spatially ordered atoms, the usual
@@ -520,8 +521,9 @@ __global__ __launch_bounds__(256) void pme_gather_finish_kernel(const T* __restr
   const int i = i0 < N ? i0 : N - 1;  // surplus groups of the last block recompute the last atom and do not store
   const int s = batch_idx ? batch_idx[i] : 0;
   const Stencil<T> st = make_stencil(pos + 3 * (size_t)i, cit + 9 * (size_t)s, nx, ny, nz, order);
-  T wz[MI_MAX_ORDER];
-  int gz[MI_MAX_ORDER];
+  T wz[ORDER];
+  int gz[ORDER];
+#pragma unroll
   for (int k = 0; k < order; ++k) { wz[k] = weight_1d(st, 2, k, order); gz[k] = wrap_idx(st.base[2] + k + st.off0[2], nz); }
   const T q = charges[i];
   const size_t plane = (size_t)nx * ny * nz;
@@ -531,10 +533,12 @@ __global__ __launch_bounds__(256) void pme_gather_finish_kernel(const T* __restr
   if (tx < order) {
     const T wx = weight_1d(st, 0, tx, order);
     const int gx = wrap_idx(st.base[0] + tx + st.off0[0], nx);
+#pragma unroll
     for (int ty = 0; ty < order; ++ty) {
       const T wxy = wx * weight_1d(st, 1, ty, order);
       const int gy = wrap_idx(st.base[1] + ty + st.off0[1], ny);
       const size_t row = ((size_t)gx * ny + gy) * nz;
+#pragma unroll
       for (int tz = 0; tz < order; ++tz) {
         const T w = wxy * wz[tz];
         if (w > T(1e-8)) {
@@ -917,10 +921,10 @@ int mi_pme_gather_finish(const void* positions, const void* charges, const int32
   MI_REQUIRE(positions && charges && cell_inv_t && meshes && alpha && volume && total_charge && energies, "null pointer");
   hipStream_t st = (hipStream_t)stream;
   mi_timing_begin("pme_gather_finish", stream);
-  MI_DISPATCH_T(dtype, (pme_gather_finish_kernel<T_><<<mi_blocks((long long)n_atoms * PG_LANES, 256), 256, 0, st>>>(
+  MI_DISPATCH_ORDER(order, MI_DISPATCH_T(dtype, (pme_gather_finish_kernel<T_, O_><<<mi_blocks((long long)n_atoms * PG_LANES, 256), 256, 0, st>>>(
                            (const T_*)positions, (const T_*)charges, batch_idx, (const T_*)cell_inv_t, (const T_*)meshes, (const T_*)alpha,
-                           (const T_*)volume, (const T_*)total_charge, n_atoms, nx, ny, nz, order, with_field, (T_*)energies, (T_*)forces,
-                           (T_*)charge_grads, add_energies, (const T_*)add_forces, add_charge_grads)));
+                           (const T_*)volume, (const T_*)total_charge, n_atoms, nx, ny, nz, with_field, (T_*)energies, (T_*)forces,
+                           (T_*)charge_grads, add_energies, (const T_*)add_forces, add_charge_grads))));
   mi_timing_end(stream);
   MI_LAUNCH_CHECK();
   return MI_OK;
