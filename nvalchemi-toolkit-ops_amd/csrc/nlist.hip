@@ -169,21 +169,30 @@ __global__ __launch_bounds__(256) void nl_setup_kernel(const T* __restrict__ cel
     // outside their cell).  Evaluated once here; the query kernel only does integer look-ups.
     const bool ortho = a[1] == T(0) && a[2] == T(0) && a[3] == T(0) && a[5] == T(0) && a[6] == T(0) && a[7] == T(0);
     S.prune = (ortho && S.R[0] <= NL_PRUNE_R && S.R[1] <= NL_PRUNE_R && S.R[2] <= NL_PRUNE_R) ? 1 : 0;
-    if (S.prune) {
-      double w[3];
-      for (int d = 0; d < 3; ++d) w[d] = S.pbc[d] ? face[d] / S.cpd[d] : 0.0;
-      for (int az = 0; az <= NL_PRUNE_R; ++az)
-        for (int ay = 0; ay <= NL_PRUNE_R; ++ay) {
-          const double gz = (az > 1 ? az - 1 : 0) * w[2], gy = (ay > 1 ? ay - 1 : 0) * w[1];
-          const double rem = rc * rc - gz * gz - gy * gy;
-          int lim;
-          if (rem < -1e-6 * rc * rc) lim = -1;
-          else if (w[0] > 0.0) { lim = (int)(sqrt(rem > 0.0 ? rem : 0.0) / w[0] * (1.0 + 1e-6)) + 1; if (lim > S.R[0]) lim = S.R[0]; }
-          else lim = S.R[0];
-          S.dxlim[az][ay] = (signed char)lim;
-        }
-    }
     sys[s] = S;
+  }
+  __syncthreads();
+  // pruning tables: one thread per (system, |dz|, |dy|) entry instead of 81 dependent sqrt / divide chains in the system's thread (the
+  // single-system launch was 15 us of serial fp64 latency on the critical path of both lists)
+  constexpr int NE = (NL_PRUNE_R + 1) * (NL_PRUNE_R + 1);
+  for (int t = threadIdx.x; t < B * NE; t += blockDim.x) {
+    const int s = t / NE, az = (t - s * NE) / (NL_PRUNE_R + 1), ay = t - s * NE - az * (NL_PRUNE_R + 1);
+    NlSys<T>& S = sys[s];
+    if (!S.prune) continue;
+    const double rc = (double)cutoff;
+    double w[3];
+    for (int d = 0; d < 3; ++d) {
+      const T col[3] = {S.inv[d], S.inv[3 + d], S.inv[6 + d]};
+      const T ln = sqrt(col[0] * col[0] + col[1] * col[1] + col[2] * col[2]);
+      w[d] = S.pbc[d] ? (1.0 / (double)ln) / S.cpd[d] : 0.0;
+    }
+    const double gz = (az > 1 ? az - 1 : 0) * w[2], gy = (ay > 1 ? ay - 1 : 0) * w[1];
+    const double rem = rc * rc - gz * gz - gy * gy;
+    int lim;
+    if (rem < -1e-6 * rc * rc) lim = -1;
+    else if (w[0] > 0.0) { lim = (int)(sqrt(rem > 0.0 ? rem : 0.0) / w[0] * (1.0 + 1e-6)) + 1; if (lim > S.R[0]) lim = S.R[0]; }
+    else lim = S.R[0];
+    S.dxlim[az][ay] = (signed char)lim;
   }
   __syncthreads();
   if (threadIdx.x == 0) {
