@@ -1,0 +1,82 @@
+// Tuning probe: the write side of the 40-Bohr matrix fill with the compute of the real kernel emulated by a dependent-FMA delay.
+// A persistent block of 4 waves takes "cells" of 20 rows from an atomic counter; every wave owns 2 rows at a time (as NC = 2 centres) and
+// alternates between them; per group of 64 candidates it spends DELAY FMAs and then emits the hits:
+//   mode 0  per-hit stores, 24 of 64 lanes active: 4 B index + 12 B shift (what the shipped kernel does)
+//   mode 1  hits collected in LDS (index + packed shift), flushed as full 256-slot chunks: 1 KiB of indices + 3 KiB of shifts in four
+//           full-width 16-byte-per-lane store instructions
+//   mode 2  as mode 1 but the stores are non-temporal
+#include <hip/hip_runtime.h>
+typedef int i4 __attribute__((ext_vector_type(4)));
+template <int MODE>
+__global__ __launch_bounds__(256) void fill(int* __restrict__ nm, int* __restrict__ sh, int N, int M, int delay, int* __restrict__ work, float* __restrict__ sink) {
+  __shared__ int next;
+  __shared__ int buf[4][2][320 * 2];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int ncell = (N + 19) / 20;
+  float acc = (float)lane;
+  for (;;) {
+    __syncthreads();
+    if (threadIdx.x == 0) next = atomicAdd(work, 1);
+    __syncthreads();
+    const int c = next;
+    if (c >= ncell) break;
+    for (int pass = 0; pass < 3; ++pass) {
+      const int r0 = c * 20 + pass * 8 + wave, r1 = r0 + 4;
+      int cnt[2] = {0, 0}, fl[2] = {0, 0};
+      const int rows[2] = {r0, r1};
+      const int groups = (M + 23) / 24;  // 24 hits per group of 64 candidates
+      for (int g = 0; g < groups; ++g) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          for (int k = 0; k < delay; ++k) acc = fmaf(acc, 1.0000001f, 0.5f);
+          const int r = rows[u];
+          if (r >= N || r >= c * 20 + 20) continue;
+          const int nh = (cnt[u] + 24 <= M) ? 24 : M - cnt[u];
+          if (nh <= 0) continue;
+          const long long base = (long long)r * M;
+          if (MODE == 0) {
+            if (lane < nh) { nm[base + cnt[u] + lane] = lane + g; int* p = sh + (base + cnt[u] + lane) * 3; p[0] = lane; p[1] = g; p[2] = r; }
+            cnt[u] += nh;
+          } else {
+            int* b = buf[wave][u];
+            if (lane < nh) { const int s = (fl[u] + lane) % 320; b[s] = lane + g; b[320 + s] = (lane & 3) | (g << 2); }
+            fl[u] += nh; cnt[u] += nh;
+            const int done = cnt[u] - fl[u];  // slots already flushed
+            if (fl[u] >= 256 || cnt[u] >= M) {
+              const int nflush = fl[u] >= 256 ? 256 : fl[u];
+              const int head = done % 320;
+              // indices: lane l writes slots done + 4l .. + 3
+              if (4 * lane < nflush) {
+                i4 v = {b[(head + 4 * lane) % 320], b[(head + 4 * lane + 1) % 320], b[(head + 4 * lane + 2) % 320], b[(head + 4 * lane + 3) % 320]};
+                i4* dst = reinterpret_cast<i4*>(nm + base + done) + lane;
+                if (MODE == 2) __builtin_nontemporal_store(v, dst); else *dst = v;
+              }
+#pragma unroll
+              for (int k = 0; k < 3; ++k) {  // shifts: 3 x (64 lanes x 16 B) contiguous
+                const int t0 = 256 * k + 4 * lane;  // int index inside the 768-int chunk
+                if (t0 < 3 * nflush) {
+                  int w[4];
+#pragma unroll
+                  for (int q = 0; q < 4; ++q) { const int e = (t0 + q) / 3, cpt = (t0 + q) - 3 * e; const int code = b[320 + (head + e) % 320]; w[q] = cpt == 0 ? (code & 3) : (cpt == 1 ? (code >> 2) : r); }
+                  i4 v = {w[0], w[1], w[2], w[3]};
+                  i4* dst = reinterpret_cast<i4*>(sh + (base + done) * 3) + 64 * k + lane;
+                  if (MODE == 2) __builtin_nontemporal_store(v, dst); else *dst = v;
+                }
+              }
+              fl[u] -= nflush;
+            }
+          }
+        }
+      }
+    }
+  }
+  if (acc == 12345.678f) *sink = acc;
+}
+extern "C" int probe_write2(int mode, int* nm, int* sh, int N, int M, int delay, int blocks, int* work, float* sink, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  (void)hipMemsetAsync(work, 0, 4, st);
+  if (mode == 0) fill<0><<<blocks, 256, 0, st>>>(nm, sh, N, M, delay, work, sink);
+  else if (mode == 1) fill<1><<<blocks, 256, 0, st>>>(nm, sh, N, M, delay, work, sink);
+  else fill<2><<<blocks, 256, 0, st>>>(nm, sh, N, M, delay, work, sink);
+  return hipGetLastError() == hipSuccess ? 0 : 2;
+}
