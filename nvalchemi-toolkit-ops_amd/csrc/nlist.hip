@@ -274,6 +274,12 @@ __device__ __forceinline__ void wave_fill(int* __restrict__ dst, long long begin
   if (done + lane < n) p[done + lane] = value;
 }
 
+// a 64-bit value every lane of the wave agrees on, moved to scalar registers (so that pointers built from it are wave-uniform)
+__device__ __forceinline__ long long nl_uniform64(long long v) {
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)((unsigned long long)v >> 32));
+  return (long long)(((unsigned long long)hi << 32) | lo);
+}
+
 // The pair test shared by both query kernels: reference expression order (cell_list.py:531-544), or the naive method's
 // orientation / image range (naive.py:163-172), self-pair exclusion, canonical half-fill rule.
 // Second output set of the single-sweep dual-cutoff search (naive_dual_cutoff.py:115-290: one walk over the pair set, `dist_sq < cutoff2_sq`
@@ -488,27 +494,35 @@ __global__ __launch_bounds__(256) void nl_query_tiled_kernel(
             cnt2[u] = DUAL ? ccnt2[ci - cbase] : 0;
           }
           const bool ortho = S->prune != 0;  // orthorhombic: S.cell has one non-zero term per component (adding exact zeros changes nothing)
-          auto emit = [&](int u, bool hit, int j, int Sx, int Sy, int Sz) {
-            const unsigned long long mask = __ballot(hit);
+          // Row bases as wave-uniform pointers and slots as 32-bit byte offsets: the hit stores become `global_store v_off, v_data, s[base]`
+          // (one shift / one multiply per store instead of a 64-bit address per lane); the wave-level prefix count goes through
+          // v_mbcnt (two instructions) and the hit mask straight from the compare (no 0/1 round trip).  The per-hit part of the
+          // loop went from ~14 to ~7 vector instructions (profiles/r03_ab_nl_valu.log).
+          int* row_j[NC];
+          NlInt3* row_s[NC];
+#pragma unroll
+          for (int u = 0; u < NC; ++u) {
+            const long long ob = nl_uniform64(out_base[u]);
+            if (MODE == MI_NL_MODE_MATRIX) { row_j[u] = nm + ob; row_s[u] = nsh ? reinterpret_cast<NlInt3*>(nsh) + ob : nullptr; }
+            else if (MODE == MI_NL_MODE_CSR) { row_j[u] = list_ij + P + ob; row_s[u] = list_sh ? reinterpret_cast<NlInt3*>(list_sh) + ob : nullptr; }
+            else { row_j[u] = nullptr; row_s[u] = nullptr; }
+          }
+          auto emit_m = [&](int u, unsigned long long mask, bool hit, int j, int Sx, int Sy, int Sz) {
             if (MODE == MI_NL_MODE_COUNT) { cnt[u] += __popcll(mask); return; }
             if (mask) {
-              const int slot = cnt[u] + __popcll(mask & lt);
-              if (MODE == MI_NL_MODE_MATRIX) {
-                if (hit && slot < cap_row[u]) {
-                  // (plain stores: the hits of a row arrive in short runs that the L2 merges into full lines; non-temporal stores here
-                  // cost +20-60 % on the headline list, profiles/r02_ab_nt.log)
-                  nm[out_base[u] + slot] = j;
-                  if (nsh) reinterpret_cast<NlInt3*>(nsh)[out_base[u] + slot] = NlInt3{Sx, Sy, Sz};
-                }
-              } else if (MODE == MI_NL_MODE_CSR) {
-                if (hit && slot < cap_row[u]) {  // the source row (constant i) is written in bulk when the centre is finished
-                  list_ij[P + out_base[u] + slot] = j;
-                  if (list_sh) reinterpret_cast<NlInt3*>(list_sh)[out_base[u] + slot] = NlInt3{Sx, Sy, Sz};
-                }
+              // slot = entries already in the row + hits in lower lanes
+              const unsigned slot = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, (unsigned)cnt[u]));
+              if (hit && slot < (unsigned)cap_row[u]) {
+                // (plain stores: the hits of a row arrive in short runs that the L2 merges into full lines; non-temporal stores here
+                // cost +20-60 % on the headline list, profiles/r02_ab_nt.log.  CSR: the source row (constant i) is written in bulk
+                // when the centre is finished)
+                *reinterpret_cast<int*>(reinterpret_cast<char*>(row_j[u]) + slot * 4u) = j;
+                if (row_s[u]) *reinterpret_cast<NlInt3*>(reinterpret_cast<char*>(row_s[u]) + __umul24(slot, 12u)) = NlInt3{Sx, Sy, Sz};
               }
               cnt[u] += __popcll(mask);
             }
           };
+          auto emit = [&](int u, bool hit, int j, int Sx, int Sy, int Sz) { emit_m(u, __builtin_amdgcn_ballot_w64(hit), hit, j, Sx, Sy, Sz); };
           // software-pipelined by one group: the LDS reads of group g+1 are issued before group g is tested, so the wave
           // does not sit out an LDS round trip at the top of every trip
           struct Cand { int j, tt, zg; T x, y, z; };
@@ -535,7 +549,8 @@ __global__ __launch_bounds__(256) void nl_query_tiled_kernel(
               for (int u = 0; u < NC; ++u) {
                 const T dr0 = cjx - ccx[u], dr1 = cjy - ccy[u], dr2 = cjz - ccz[u];
                 const T d2 = dr0 * dr0 + dr1 * dr1 + dr2 * dr2;
-                emit(u, (d2 < rc2) & (j != ii[u]), j, 0, 0, 0);
+                const bool in = d2 < rc2, other = j != ii[u];
+                emit_m(u, __builtin_amdgcn_ballot_w64(in) & __builtin_amdgcn_ballot_w64(other), in & other, j, 0, 0, 0);
               }
             } else if (FAST && gs != NL_MIXED) {  // one common non-zero shift: S.cell once per group, no self-pair possible
               const int Sx = (gs << 22) >> 22, Sy = (gs << 12) >> 22, Sz = (gs << 2) >> 22;

@@ -5,6 +5,7 @@
 //   mode 1  hits collected in LDS (index + packed shift), flushed as full 256-slot chunks: 1 KiB of indices + 3 KiB of shifts in four
 //           full-width 16-byte-per-lane store instructions
 //   mode 2  as mode 1 but the stores are non-temporal
+//   mode 3  no stores at all (the compute side alone, for the overlap comparison)
 #include <hip/hip_runtime.h>
 typedef int i4 __attribute__((ext_vector_type(4)));
 template <int MODE>
@@ -34,6 +35,7 @@ __global__ __launch_bounds__(256) void fill(int* __restrict__ nm, int* __restric
           const int nh = (cnt[u] + 24 <= M) ? 24 : M - cnt[u];
           if (nh <= 0) continue;
           const long long base = (long long)r * M;
+          if (MODE == 3) { cnt[u] += nh; continue; }
           if (MODE == 0) {
             if (lane < nh) { nm[base + cnt[u] + lane] = lane + g; int* p = sh + (base + cnt[u] + lane) * 3; p[0] = lane; p[1] = g; p[2] = r; }
             cnt[u] += nh;
@@ -77,6 +79,7 @@ extern "C" int probe_write2(int mode, int* nm, int* sh, int N, int M, int delay,
   (void)hipMemsetAsync(work, 0, 4, st);
   if (mode == 0) fill<0><<<blocks, 256, 0, st>>>(nm, sh, N, M, delay, work, sink);
   else if (mode == 1) fill<1><<<blocks, 256, 0, st>>>(nm, sh, N, M, delay, work, sink);
+  else if (mode == 3) fill<3><<<blocks, 256, 0, st>>>(nm, sh, N, M, delay, work, sink);
   else fill<2><<<blocks, 256, 0, st>>>(nm, sh, N, M, delay, work, sink);
   return hipGetLastError() == hipSuccess ? 0 : 2;
 }
