@@ -42,6 +42,7 @@ namespace {
 #ifndef NL_TILED_WAVES
 #define NL_TILED_WAVES 0   // > 0: register cap of the tiled query for this many waves per SIMD (tuning aid)
 #endif
+#define NL_CCHUNK 64     // centre atoms of a cell handled per sweep over its candidate tiles (cells above this are swept again)
 #define NL_MAXROWS 96     // (2Ry+1)(2Rz+1) rows of cells a block can describe (R <= 4)
 #define NL_MIXED 0x7fffffff
 #define NL_TILED_GRID 1536   // persistent blocks (6 per CU); cells are handed out dynamically
@@ -336,12 +337,18 @@ __global__ __launch_bounds__(256) void nl_query_tiled_kernel(
   constexpr int TILE = sizeof(T) == 8 ? NL_TILE_F64 : NL_TILE;
   if (!glob->use_tiled) return;
   if (!DUAL && FAST != ((flags & (MI_NL_HALF_FILL | MI_NL_NAIVE_EXPR)) == 0)) return;  // the other instantiation handles this call
-  __shared__ int ccnt2[DUAL ? 256 : 1];
+  __shared__ int ccnt2[DUAL ? NL_CCHUNK : 1];
   __shared__ T tx[TILE], ty[TILE], tz[TILE];
   __shared__ int tj[TILE];
   __shared__ short tsx[TILE], tsy[TILE], tsz[TILE];
   __shared__ int run_beg[3 * NL_MAXROWS], run_pre[3 * NL_MAXROWS + 1], run_cs[3 * NL_MAXROWS];
-  __shared__ int ccnt[256];
+  __shared__ int ccnt[NL_CCHUNK];
+  // the centre atoms of the current chunk, staged once per chunk: a wave must not LOAD from global memory inside the tile loop, because
+  // loads and stores share one in-order counter (vmcnt) on this ISA -- waiting for a 16-byte centre record would first wait for every row
+  // store the wave has in flight, once per (tile, pass), and the drain of the row stores to HBM would stop overlapping the distance tests
+  __shared__ T cen_x[NL_CCHUNK], cen_y[NL_CCHUNK], cen_z[NL_CCHUNK];
+  __shared__ int cen_i[NL_CCHUNK];
+  __shared__ short4 cen_w[NL_CCHUNK];
   __shared__ int grp_run[TILE / MI_WAVE];  // run containing the first candidate of each 64-candidate group of the current tile
   __shared__ int grp_shift[TILE / MI_WAVE];  // packed image shift common to all 64 candidates of the group, or NL_MIXED
   __shared__ int u_beg[3 * NL_MAXROWS], u_len[3 * NL_MAXROWS], u_cs[3 * NL_MAXROWS];  // run table before ordering by image
@@ -430,10 +437,18 @@ __global__ __launch_bounds__(256) void nl_query_tiled_kernel(
     }
     __syncthreads();
     const int nruns = 3 * nrows, total = run_pre[nruns];
-    for (int cbase = 0; cbase < n_c; cbase += 256) {
-      const int cend = (cbase + 256 < n_c) ? cbase + 256 : n_c;
-      ccnt[tid] = 0;
-      if (DUAL) ccnt2[tid] = 0;
+    for (int cbase = 0; cbase < n_c; cbase += NL_CCHUNK) {
+      const int cend = (cbase + NL_CCHUNK < n_c) ? cbase + NL_CCHUNK : n_c;
+      if (tid < NL_CCHUNK) {
+        ccnt[tid] = 0;
+        if (DUAL) ccnt2[tid] = 0;
+        if (cbase + tid < cend) {
+          const auto cr = spos[c_beg + cbase + tid];
+          cen_x[tid] = cr.x; cen_y[tid] = cr.y; cen_z[tid] = cr.z;
+          cen_i[tid] = idx_of(cr);
+          cen_w[tid] = anyw ? swrap[c_beg + cbase + tid] : make_short4(0, 0, 0, 0);
+        }
+      }
       for (int tile0 = 0; tile0 < total; tile0 += TILE) {
         const int tile_n = (total - tile0 < TILE) ? total - tile0 : TILE;
         __syncthreads();  // the previous tile has been consumed (and ccnt initialised)
@@ -481,13 +496,11 @@ __global__ __launch_bounds__(256) void nl_query_tiled_kernel(
           for (int u = 0; u < NC; ++u) {
             const bool live = u < nc;
             const int ci = live ? ci0 + 4 * u : ci0;
-            const auto cr = spos[c_beg + ci];
             // a missing centre (last pass of a chunk) gets NaN coordinates: every `d2 < rc2` is false, so the candidate loop
             // needs no per-centre predicate
-            ccx[u] = live ? cr.x : (T)NAN; ccy[u] = cr.y; ccz[u] = cr.z;
-            ii[u] = __builtin_amdgcn_readfirstlane(idx_of(cr));
-            wi[u] = make_short4(0, 0, 0, 0);
-            if (anyw) wi[u] = swrap[c_beg + ci];
+            ccx[u] = live ? cen_x[ci - cbase] : (T)NAN; ccy[u] = cen_y[ci - cbase]; ccz[u] = cen_z[ci - cbase];
+            ii[u] = __builtin_amdgcn_readfirstlane(cen_i[ci - cbase]);
+            wi[u] = cen_w[ci - cbase];
             if (MODE == MI_NL_MODE_CSR) { out_base[u] = ptr[ii[u]]; cap_row[u] = ptr[ii[u] + 1] - ptr[ii[u]]; }
             else { out_base[u] = (long long)ii[u] * M; cap_row[u] = M; }
             cnt[u] = ccnt[ci - cbase];
@@ -607,7 +620,7 @@ __global__ __launch_bounds__(256) void nl_query_tiled_kernel(
       __syncthreads();
       // counts and (matrix mode) padding of this chunk of centres
       for (int ci = cbase + wave; ci < cend; ci += 4) {
-        const int i = __builtin_amdgcn_readfirstlane(idx_of(spos[c_beg + ci]));
+        const int i = __builtin_amdgcn_readfirstlane(cen_i[ci - cbase]);
         const int cnt = ccnt[ci - cbase];
         if (MODE != MI_NL_MODE_CSR) { if (lane == 0) num[i] = cnt; }
         if (MODE == MI_NL_MODE_CSR) {
