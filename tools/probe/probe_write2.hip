@@ -9,7 +9,7 @@
 #include <hip/hip_runtime.h>
 typedef int i4 __attribute__((ext_vector_type(4)));
 template <int MODE>
-__global__ __launch_bounds__(256) void fill(int* __restrict__ nm, int* __restrict__ sh, int N, int M, int delay, int* __restrict__ work, float* __restrict__ sink) {
+__global__ __launch_bounds__(256) void fill(int* __restrict__ nm, int* __restrict__ sh, int N, int M, int delay, int* __restrict__ work, float* __restrict__ sink, int amask) {
   __shared__ int next;
   __shared__ int buf[4][2][320 * 2];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -34,7 +34,7 @@ __global__ __launch_bounds__(256) void fill(int* __restrict__ nm, int* __restric
           if (r >= N || r >= c * 20 + 20) continue;
           const int nh = (cnt[u] + 24 <= M) ? 24 : M - cnt[u];
           if (nh <= 0) continue;
-          const long long base = (long long)r * M;
+          const long long base = (long long)(r & amask) * M;  // amask = 63: the same instructions onto L2-resident rows
           if (MODE == 3) { cnt[u] += nh; continue; }
           if (MODE == 0) {
             if (lane < nh) { nm[base + cnt[u] + lane] = lane + g; int* p = sh + (base + cnt[u] + lane) * 3; p[0] = lane; p[1] = g; p[2] = r; }
@@ -74,12 +74,12 @@ __global__ __launch_bounds__(256) void fill(int* __restrict__ nm, int* __restric
   }
   if (acc == 12345.678f) *sink = acc;
 }
-extern "C" int probe_write2(int mode, int* nm, int* sh, int N, int M, int delay, int blocks, int* work, float* sink, void* stream) {
+extern "C" int probe_write2(int mode, int* nm, int* sh, int N, int M, int delay, int blocks, int* work, float* sink, void* stream, int amask) {
   hipStream_t st = (hipStream_t)stream;
   (void)hipMemsetAsync(work, 0, 4, st);
-  if (mode == 0) fill<0><<<blocks, 256, 0, st>>>(nm, sh, N, M, delay, work, sink);
-  else if (mode == 1) fill<1><<<blocks, 256, 0, st>>>(nm, sh, N, M, delay, work, sink);
-  else if (mode == 3) fill<3><<<blocks, 256, 0, st>>>(nm, sh, N, M, delay, work, sink);
-  else fill<2><<<blocks, 256, 0, st>>>(nm, sh, N, M, delay, work, sink);
+  if (mode == 0) fill<0><<<blocks, 256, 0, st>>>(nm, sh, N, M, delay, work, sink, amask);
+  else if (mode == 1) fill<1><<<blocks, 256, 0, st>>>(nm, sh, N, M, delay, work, sink, amask);
+  else if (mode == 3) fill<3><<<blocks, 256, 0, st>>>(nm, sh, N, M, delay, work, sink, amask);
+  else fill<2><<<blocks, 256, 0, st>>>(nm, sh, N, M, delay, work, sink, amask);
   return hipGetLastError() == hipSuccess ? 0 : 2;
 }

@@ -14,10 +14,14 @@ def t(fn, reps=7):
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record(); fn(); b.record(); b.synchronize(); ts.append(a.elapsed_time(b))
     return float(np.median(ts))
-for blocks in (1280, 1536):
-    for delay in (0, 4, 8, 12, 16):
+for blocks in (1280,):
+    for delay in (0, 4, 8, 12, 16, 24):
         row = []
-        for mode, name in ((3, "no stores"), (0, "per-hit"), (1, "staged"), (2, "staged nt")):
-            ms = t(lambda: lib.probe_write2(mode, P(nm), P(sh), n, m, delay, blocks, P(work), P(sink), st))
-            row.append(f"{name} {ms:.3f} ms ({16.0 * n * m / ms / 1e6:.0f} GB/s)")
+        for mode, name in ((3, "no stores"), (0, "per-hit"), (1, "staged")):
+            ms = t(lambda: lib.probe_write2(mode, P(nm), P(sh), n, m, delay, blocks, P(work), P(sink), st, -1))
+            if mode == 3:
+                row.append(f"{name} {ms:.3f}")
+                continue
+            ms_l2 = t(lambda: lib.probe_write2(mode, P(nm), P(sh), n, m, delay, blocks, P(work), P(sink), st, 63))
+            row.append(f"{name} {ms:.3f} (rows in L2: {ms_l2:.3f}, drain cost {ms - ms_l2:+.3f})")
         print(f"blocks {blocks} delay {delay:3d} FMAs/group: " + "   ".join(row), flush=True)
