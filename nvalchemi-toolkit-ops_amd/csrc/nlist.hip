@@ -430,10 +430,17 @@ __global__ __launch_bounds__(256) void nl_query_tiled_kernel(
       run_cs[rank] = key;
     }
     __syncthreads();
-    if (tid == 0) {
-      int acc = 0;
-      run_pre[0] = 0;
-      for (int r = 0; r < 3 * nrows; ++r) { acc += run_pre[r + 1]; run_pre[r + 1] = acc; }
+    if (wave == 0) {  // inclusive prefix of the run lengths: one wave, a shuffle scan per 64 runs (the serial loop was up to 243 dependent LDS round trips per cell)
+      int carry = 0;
+      if (lane == 0) run_pre[0] = 0;
+      for (int r0 = 0; r0 < 3 * nrows; r0 += MI_WAVE) {
+        const int r = r0 + lane;
+        int inc = r < 3 * nrows ? run_pre[r + 1] : 0;
+#pragma unroll
+        for (int o = 1; o < MI_WAVE; o <<= 1) { const int up = __shfl_up(inc, o, MI_WAVE); if (lane >= o) inc += up; }
+        if (r < 3 * nrows) run_pre[r + 1] = carry + inc;
+        carry += __shfl(inc, MI_WAVE - 1, MI_WAVE);
+      }
     }
     __syncthreads();
     const int nruns = 3 * nrows, total = run_pre[nruns];
