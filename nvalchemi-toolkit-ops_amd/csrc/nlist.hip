@@ -275,6 +275,21 @@ __device__ __forceinline__ void wave_fill(int* __restrict__ dst, long long begin
   if (done + lane < n) p[done + lane] = value;
 }
 
+// inclusive prefix of the run lengths run_pre[1..n] (run_pre[0] = 0), by one wave: a shuffle scan per 64 runs (the serial loop was up to 243
+// dependent LDS round trips per cell).  Not inlined: the scan's registers must not count towards the query kernel's budget (5 waves / SIMD).
+__device__ __noinline__ void nl_prefix_runs(int* run_pre, int n, int lane) {
+  int carry = 0;
+  if (lane == 0) run_pre[0] = 0;
+  for (int r0 = 0; r0 < n; r0 += MI_WAVE) {
+    const int r = r0 + lane;
+    int inc = r < n ? run_pre[r + 1] : 0;
+#pragma unroll
+    for (int o = 1; o < MI_WAVE; o <<= 1) { const int up = __shfl_up(inc, o, MI_WAVE); if (lane >= o) inc += up; }
+    if (r < n) run_pre[r + 1] = carry + inc;
+    carry += __shfl(inc, MI_WAVE - 1, MI_WAVE);
+  }
+}
+
 // a 64-bit value every lane of the wave agrees on, moved to scalar registers (so that pointers built from it are wave-uniform)
 __device__ __forceinline__ long long nl_uniform64(long long v) {
   const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)((unsigned long long)v >> 32));
@@ -430,18 +445,7 @@ __global__ __launch_bounds__(256) void nl_query_tiled_kernel(
       run_cs[rank] = key;
     }
     __syncthreads();
-    if (wave == 0) {  // inclusive prefix of the run lengths: one wave, a shuffle scan per 64 runs (the serial loop was up to 243 dependent LDS round trips per cell)
-      int carry = 0;
-      if (lane == 0) run_pre[0] = 0;
-      for (int r0 = 0; r0 < 3 * nrows; r0 += MI_WAVE) {
-        const int r = r0 + lane;
-        int inc = r < 3 * nrows ? run_pre[r + 1] : 0;
-#pragma unroll
-        for (int o = 1; o < MI_WAVE; o <<= 1) { const int up = __shfl_up(inc, o, MI_WAVE); if (lane >= o) inc += up; }
-        if (r < 3 * nrows) run_pre[r + 1] = carry + inc;
-        carry += __shfl(inc, MI_WAVE - 1, MI_WAVE);
-      }
-    }
+    if (wave == 0) nl_prefix_runs(run_pre, 3 * nrows, lane);
     __syncthreads();
     const int nruns = 3 * nrows, total = run_pre[nruns];
     for (int cbase = 0; cbase < n_c; cbase += NL_CCHUNK) {
