@@ -69,6 +69,9 @@ def build_system(n_atoms: int, seed: int, device):
     from tests import systems as S  # input generators only; the oracle is imported by cpu_baseline() alone
 
     pos, cell, q, numbers = S.fcc_box(n_atoms, seed=seed, dtype=np.float64)
+    if os.environ.get("BENCH_SHUFFLE_ATOMS") == "1":  # tuning aid, not the reported mode: the same box with its atoms in random index order
+        perm = np.random.default_rng(99).permutation(n_atoms)
+        pos, q, numbers = pos[perm], q[perm], numbers[perm]
     tables = S.d3_test_tables(94, seed=7)
     t = lambda a, dt=None: torch.as_tensor(np.ascontiguousarray(a), dtype=dt, device=device)  # noqa: E731
     sysd = dict(

@@ -300,6 +300,11 @@ int mi_spline_spread(const void* positions, const void* values, const int32_t* b
  * binned by ex*ey*ez mesh tile, LDS accumulation, every mesh point written once, no global atomics); otherwise order^2 threads per
  * atom add into the zeroed mesh.                                                                                               */
 size_t mi_spline_spread_workspace_bytes(int n_atoms, int n_systems, int nx, int ny, int nz);
+/* byte offset, inside the workspace mi_spline_spread was given, of int32[4 + n_atoms] that the tile-owned spread leaves behind (valid until
+ * the workspace is reused): [0] = number of consecutive atom pairs (i, i+1) that sit in neither the same nor neighbouring mesh tiles (a
+ * measure of how spatially incoherent the caller's atom order is), [1..3] unused, [4..] = the atom ids grouped by mesh tile.
+ * -1 when this mesh / order runs the atomic kernel, which does not sort. */
+long long mi_spline_spread_order_offset(int n_atoms, int n_systems, int nx, int ny, int nz, int order);
 /* channels = 1: out[n_atoms] += sum_g mesh[g] w ; channels = 3 (mesh [..,3] interleaved) or 4 planar:
  * see mi_pme_gather below for the fused PME form.                                                     */
 int mi_spline_gather(const void* positions, const void* mesh, const int32_t* batch_idx, const void* cell_inv_t,
@@ -338,6 +343,7 @@ int mi_spline_spread_grad(const void* positions, const void* vec /*[n_atoms,3]*/
  *   (pme.py:1429-1477; pme_kernels.py:340-657) fused over the 4 planar real-space meshes.  add_energies / add_forces /
  *   add_charge_grads (NULL ok): the real-space part (mi_ewald_real outputs: float64 energies and charge gradients, forces in
  *   `dtype`) added in the epilogue -- the `real + reciprocal` sums of particle_mesh_ewald (pme.py:1975-1990).
+ *   atom_order only changes which lanes work on which atom (mesh locality for callers whose atoms are not spatially ordered), never a result.
  */
 int mi_pme_green_sf(const void* k_squared /*[B,nx,ny,nzr]*/, const void* alpha /*[B]*/, const void* volume /*[B]*/,
                     int n_systems, int nx, int ny, int nz, int sf_exponent, int dtype, void* green /*[B,nx,ny,nzr]*/,
@@ -352,7 +358,10 @@ int mi_pme_gather_finish(const void* positions, const void* charges, const int32
                          const void* total_charge /*[B]*/, int n_atoms, int n_systems, int nx, int ny, int nz,
                          int order, int with_field, int dtype, void* energies /*[n_atoms]*/,
                          void* forces /*[n_atoms,3] or NULL*/, void* charge_grads /*[n_atoms] or NULL*/,
-                         const double* add_energies, const void* add_forces, const double* add_charge_grads, void* stream);
+                         const double* add_energies, const void* add_forces, const double* add_charge_grads,
+                         const int32_t* atom_order /*NULL, or the int32[4 + n_atoms] array the spread of the same call left in its workspace
+                           (mi_spline_spread_order_offset): the atoms are walked tile by tile when [0] > n_atoms / 4*/,
+                         void* stream);
 int mi_pme_corrections(const void* raw, const void* charges, const int32_t* batch_idx, const void* volume,
                        const void* alpha, const void* total_charge, int n_atoms, int dtype, void* energies,
                        void* charge_grads /*NULL ok*/, void* stream);

@@ -19,8 +19,10 @@
 //     their gathers pull into L1; all walks are software-pipelined three deep with predicated (not branched) validity.
 //   * per-system energy / virial: per-atom values, fp64 slab sums, one atomic per system change per wave, rounded once.
 #include <type_traits>
+#include <mutex>
 
 #include "common.h"
+#include "binsort.h"
 
 // Pair-math primitives.  Product build: hardware v_rsq / v_rcp / v_sqrt / v_exp (1 ulp each; the exponential with a compensated
 // argument, see d3_exp).  -DMI_D3_IEEE (tests only: libnvalchemiops_d3_ieee.so, built WITHOUT -fno-hip-fp32-correctly-rounded-divide-sqrt)
@@ -64,6 +66,105 @@ __global__ void d3_pack_tables_kernel(const float* __restrict__ c6ab, const floa
 template <class T> struct PairGeom { float r, rinv, rx, ry, rz; bool ok; };
 struct Int3 { int a, b, c; };  // one 12-byte (dwordx3) load per pair for the unit shift
 
+// ---- spatial order (round 3) ----------------------------------------------------------------------------------------------------
+// The three passes gather one or two 16..32-byte records per neighbour, and a 64-lane gather costs by the cache LINES it touches
+// (profiles/README.md 3.2).  With the atom records stored in the caller's atom order that cost depends on the caller: a lattice-ordered
+// box touches ~22 lines per gather, the same box with its atoms in random order 64 (step 4.98 -> 8.82 ms).  So, when the packed-list
+// path is taken, the atoms are binned on a coarse grid of the periodic cell (~16 per bin, x fastest, the order the cell-list search
+// emits its rows in), the records are ALSO stored in that order, the CN pass translates each neighbour index into its place in the
+// order while it packs the list (the place rides in the 4th word of the record the CN pass gathers anyway, so the translation is free),
+// and the energy / chain passes gather from the ordered copies.  Rows are processed in the spatial order as well (waves of a block then
+// walk nearly the same neighbours whatever the caller's order is).  Results do not depend on any of this: every sum keeps its order.
+#define D3_SORT_MIN_ATOMS 2048
+#define D3_SORT_PER_BIN 16.0
+template <class T> __device__ __forceinline__ T d3_code_pack(int place, int z);
+template <> __device__ __forceinline__ float d3_code_pack<float>(int place, int z) { return __int_as_float((place << 7) | z); }
+template <> __device__ __forceinline__ double d3_code_pack<double>(int place, int z) { return (double)(((long long)place << 7) | z); }
+__device__ __forceinline__ int d3_code_of(float w) { return __float_as_int(w); }
+__device__ __forceinline__ int d3_code_of(double w) { return (int)(long long)w; }
+
+// The grid of the spatial order.  With an estimate of the list's cutoff (the largest pair distance an earlier call saw, D3OrderState) it
+// is the cell-list search's own grid (csrc/nlist.hip, nl_setup_kernel: k = 1 / 2 / 3 cells per cutoff by density, cells per dimension
+// = floor(face * k / rc)): the rows of a list built by that search then visit the ordered records in long contiguous runs.  Without an
+// estimate (first calls) a cubic grid with ~16 atoms per bin.  One thread per system; systems are assumed equally large (N / B atoms).
+struct D3Grid { int cpd[3]; int off; };
+template <class T>
+__global__ void d3_sort_setup_kernel(const T* __restrict__ cell, int B, int N, float rc_est, D3Grid* __restrict__ grid, long long cap) {
+  for (int s0 = 0; s0 < B; s0 += blockDim.x) {
+    const int sidx = s0 + threadIdx.x;
+    if (sidx < B) {
+      T c[9], ci[9];
+      for (int k = 0; k < 9; ++k) c[k] = cell[9 * (size_t)sidx + k];
+      inverse3(c, ci);
+      const double det = (double)c[0] * ((double)c[4] * c[8] - (double)c[5] * c[7]) - (double)c[1] * ((double)c[3] * c[8] - (double)c[5] * c[6]) +
+                         (double)c[2] * ((double)c[3] * c[7] - (double)c[4] * c[6]);
+      const double vol = fabs(det), ns = (double)N / (double)B;
+      D3Grid g;
+      if (rc_est > 0.0f && vol > 0.0) {
+        const double rc = (double)rc_est;
+        const double apc = ns / vol * rc * rc * rc;
+        const int k = apc < 64.0 ? 1 : (apc < 512.0 ? 2 : 3);
+        for (int d = 0; d < 3; ++d) {
+          const T col[3] = {ci[d], ci[3 + d], ci[6 + d]};
+          const T ln = sqrt(col[0] * col[0] + col[1] * col[1] + col[2] * col[2]);
+          const double want = (1.0 / (double)ln) * k / (rc * (1.0 + 2e-6));
+          g.cpd[d] = want >= 1024.0 ? 1024 : (want >= 1.0 ? (int)want : 1);
+        }
+      } else {
+        int G = (int)cbrt(ns / D3_SORT_PER_BIN);
+        G = G < 1 ? 1 : (G > 256 ? 256 : G);
+        g.cpd[0] = g.cpd[1] = g.cpd[2] = G;
+      }
+      const long long per = cap / (B > 0 ? B : 1);  // bins this system may use
+      while ((long long)g.cpd[0] * g.cpd[1] * g.cpd[2] > per && (g.cpd[0] > 1 || g.cpd[1] > 1 || g.cpd[2] > 1))
+        for (int d = 0; d < 3; ++d) g.cpd[d] = g.cpd[d] / 2 > 1 ? g.cpd[d] / 2 : 1;
+      g.off = g.cpd[0] * g.cpd[1] * g.cpd[2];  // turned into an offset below
+      grid[sidx] = g;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {  // exclusive prefix over the systems (B is small next to N; one serial pass)
+    int off = 0;
+    for (int q = 0; q < B; ++q) { const int n = grid[q].off; grid[q].off = off; off += n; }
+  }
+}
+
+template <class T>
+__global__ void d3_sort_key_kernel(const T* __restrict__ pos, const T* __restrict__ cell, const int* __restrict__ batch_idx, int N,
+                                   const D3Grid* __restrict__ grid, int* __restrict__ keys, int* __restrict__ count, int* __restrict__ incoherent) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool in = i < N;
+  int key = 0, g[3] = {0, 0, 0}, gs = 0, n[3] = {1, 1, 1};
+  if (in) {
+    const int sidx = batch_idx ? batch_idx[i] : 0;
+    const D3Grid G = grid[sidx];
+    T c[9], ci[9];
+    for (int k = 0; k < 9; ++k) c[k] = cell[9 * (size_t)sidx + k];
+    inverse3(c, ci);
+    const T x = pos[3 * (size_t)i], y = pos[3 * (size_t)i + 1], z = pos[3 * (size_t)i + 2];
+    for (int d = 0; d < 3; ++d) {
+      T f = x * ci[d] + y * ci[3 + d] + z * ci[6 + d];  // fractional coordinate (row vectors: pos = frac . cell)
+      f = f - floor(f);
+      const int q = (int)(f * (T)G.cpd[d]);
+      n[d] = G.cpd[d];
+      g[d] = q < 0 ? 0 : (q >= n[d] ? n[d] - 1 : q);  // (NaN / inf positions land in bin 0)
+    }
+    gs = sidx;
+    key = G.off + (g[2] * n[1] + g[1]) * n[0] + g[0];  // x fastest, as the search's cell order
+  }
+  if (count) {  // (NULL: the launch only measures the order, see D3OrderState)
+    if (in) keys[i] = key;
+    bs_wave_add<false>(count, key, in);
+  }
+  // how spatially coherent is the caller's atom order?  consecutive atoms (i, i + 1) in neither the same nor a neighbouring bin
+  const int nx_ = __shfl_down(g[0], 1, MI_WAVE), ny_ = __shfl_down(g[1], 1, MI_WAVE), nz_ = __shfl_down(g[2], 1, MI_WAVE), ns_ = __shfl_down(gs, 1, MI_WAVE);
+  auto far = [](int a, int b, int m) { int d = a > b ? a - b : b - a; d = d < m - d ? d : m - d; return d > 1; };
+  const bool pair = in && i + 1 < N && (threadIdx.x & (MI_WAVE - 1)) != MI_WAVE - 1;
+  const bool bad = pair && (ns_ != gs || far(g[0], nx_, n[0]) || far(g[1], ny_, n[1]) || far(g[2], nz_, n[2]));
+  const unsigned long long m = __ballot(bad);
+  if (m && (threadIdx.x & (MI_WAVE - 1)) == 0) atomicAdd(incoherent, (int)__popcll(m));
+}
+
 // Per-atom records gathered by neighbour index j: ONE 16/32-byte load instead of x, y, z, Z, rcov as five gathers.
 //   apos[j] = {x, y, z, rcov[Z_j]}   (w < 0 flags a padding atom, Z_j == 0)      in the positions dtype
 //   aaux[j] = {CN_j, r4r2[Z_j], bits(Z_j << 8 | compact species id), 0}
@@ -71,9 +172,12 @@ template <class T>
 __global__ void d3_pack_atoms_kernel(const T* __restrict__ pos, const int* __restrict__ numbers, int N, const float* __restrict__ rcov,
                                      const float* __restrict__ r4r2, const int* __restrict__ smap, int nz,
                                      typename Vec4<T>::type* __restrict__ apos, float4* __restrict__ aaux, float* __restrict__ forces,
-                                     float* __restrict__ cn, float* __restrict__ dEdCN, float* __restrict__ e_atom, double* __restrict__ v_atom) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= N) return;
+                                     float* __restrict__ cn, float* __restrict__ dEdCN, float* __restrict__ e_atom, double* __restrict__ v_atom,
+                                     const int* __restrict__ inv, typename Vec4<T>::type* __restrict__ apos_s, float4* __restrict__ aaux_s,
+                                     typename Vec4<T>::type* __restrict__ acn) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= N) return;
+  const int i = inv ? inv[k] : k;  // inv: atom at position k of the spatial order (d3_sort_key_kernel), or NULL
   forces[3 * (size_t)i] = forces[3 * (size_t)i + 1] = forces[3 * (size_t)i + 2] = 0.0f;  // outputs of atoms the passes skip (Z == 0)
   cn[i] = dEdCN[i] = e_atom[i] = 0.0f;
   if (v_atom)
@@ -85,7 +189,14 @@ __global__ void d3_pack_atoms_kernel(const T* __restrict__ pos, const int* __res
   r.w = real ? (T)rcov[z] : (T)-1;
   apos[i] = r;
   const int sj = real ? smap[z] : -1;
-  aaux[i] = make_float4(0.0f, real ? r4r2[z] : 0.0f, __int_as_float((z << 8) | (sj & 0xff)), 0.0f);
+  const float4 ax = make_float4(0.0f, real ? r4r2[z] : 0.0f, __int_as_float((z << 8) | (sj & 0xff)), 0.0f);
+  aaux[i] = ax;
+  if (inv) {  // the same records at the atom's place in the spatial order, and the CN pass's record: position + {place, Z}
+    apos_s[k] = r;
+    aaux_s[k] = ax;
+    r.w = d3_code_pack<T>(k, real ? z : 0);
+    acn[i] = r;
+  }
 }
 
 // `_compute_distance_vector_pbc` (dftd3.py:551-604): native-dtype difference (+ shift), cast to fp32, length, r<1e-12 skip
@@ -263,15 +374,25 @@ __device__ __forceinline__ int d3_lockstep_trips(long long beg, long long end) {
 #ifndef D3_CN_DG
 #define D3_CN_DG 1  // trips of gathered atom records in flight (<= D3_CN_DS)
 #endif
-template <class T, bool CSR, bool BIG>  // BIG: the caller's list is far larger than the Infinity Cache -> streamed with non-temporal loads
+template <class T, bool CSR, bool BIG, bool SORT>  // BIG: the caller's list is far larger than the Infinity Cache -> streamed with non-temporal loads
 __global__ __launch_bounds__(D3_LS_WAVES * MI_WAVE) void d3_cn_kernel(const T* __restrict__ pos, const int* __restrict__ numbers, int N, const int* __restrict__ idx,
                                                     const int* __restrict__ ush, const int* __restrict__ nptr, int M, int fill_value,
                                                     const T* __restrict__ cell, const int* __restrict__ batch_idx, D3Dev P,
                                                     const typename Vec4<T>::type* __restrict__ apos, float4* __restrict__ aaux,
-                                                    float* __restrict__ cn, unsigned* __restrict__ pk_out, int* __restrict__ pk_flag) {
+                                                    float* __restrict__ cn, unsigned* __restrict__ pk_out, int* __restrict__ pk_flag,
+                                                    const int* __restrict__ inv, const typename Vec4<T>::type* __restrict__ acn,
+                                                    float4* __restrict__ aaux_s, int* __restrict__ rmax_bits) {
   const int lane = threadIdx.x & (MI_WAVE - 1);
   const int i0 = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x / MI_WAVE) + threadIdx.x / MI_WAVE);
-  const int i = i0 < N ? i0 : N - 1;
+  const int k0 = i0 < N ? i0 : N - 1;
+  // SORT: rows are walked in the spatial order, the gathered record is acn[j] = {position, place of j in the order << 7 | Z_j}
+  const int i = SORT ? __builtin_amdgcn_readfirstlane(inv[k0]) : k0;
+  __shared__ float rc_lds[SORT ? 128 : 1];
+  if (SORT) {
+    for (int t = threadIdx.x; t < 128; t += blockDim.x) rc_lds[t] = t < P.nz ? P.rcov[t] : 0.0f;
+    __syncthreads();
+  }
+  const typename Vec4<T>::type* __restrict__ arec = SORT ? acn : apos;
   const int zi = numbers[i];
   const bool live = i0 < N && zi != 0;  // idle waves still take part in the block's lock-step barriers
   const bool periodic = (cell != nullptr) && (ush != nullptr);
@@ -286,6 +407,7 @@ __global__ __launch_bounds__(D3_LS_WAVES * MI_WAVE) void d3_cn_kernel(const T* _
   // the reference sums in fp32 sequentially (dftd3.py:911); lanes hold fp64 partials here so the result is the
   // correctly rounded sum whatever the lane/iteration order
   double acc = 0.0;
+  float rmx = 0.0f;  // largest pair distance of this row: every 64th row reports it (the list's cutoff, for the grid of the spatial order)
   const Int3* __restrict__ ush3 = reinterpret_cast<const Int3*>(ush);
   long long e = beg + lane;
   const unsigned jlim = d3_index_limit<CSR>(N, fill_value);
@@ -297,26 +419,29 @@ __global__ __launch_bounds__(D3_LS_WAVES * MI_WAVE) void d3_cn_kernel(const T* _
 #pragma unroll
   for (int k = 0; k < D3_CN_DS; ++k) s[k] = d3_fetch<BIG>(idx, ush3, e + (long long)k * MI_WAVE, end, periodic);
 #pragma unroll
-  for (int k = 0; k < D3_CN_DG; ++k) { v[k] = s[k].in && ((unsigned)s[k].j < jlim); p[k] = apos[v[k] ? s[k].j : i]; }
+  for (int k = 0; k < D3_CN_DG; ++k) { v[k] = s[k].in && ((unsigned)s[k].j < jlim); p[k] = arec[v[k] ? s[k].j : i]; }
   for (int trip = 0; trip < trips; ++trip) {
     __syncthreads();  // lock-step: the block's waves walk rows of consecutive atoms, i.e. nearly the same neighbours in nearly the same order
     s[D3_CN_DS] = d3_fetch<BIG>(idx, ush3, e + (long long)D3_CN_DS * MI_WAVE, end, periodic);
     v[D3_CN_DG] = s[D3_CN_DG].in && ((unsigned)s[D3_CN_DG].j < jlim);
-    p[D3_CN_DG] = apos[v[D3_CN_DG] ? s[D3_CN_DG].j : i];
+    p[D3_CN_DG] = arec[v[D3_CN_DG] ? s[D3_CN_DG].j : i];
     const D3Step s0 = s[0];
     const bool v0 = v[0];
     const auto p0 = p[0];
+    const int code0 = SORT ? d3_code_of(p0.w) : 0;  // place << 7 | Z
     if (pk_out && s0.in) {  // wave-uniform pointer test; one coalesced 4-byte store per slot of this trip
       const unsigned cx = (unsigned)(s0.sh.a + 1), cy = (unsigned)(s0.sh.b + 1), cz = (unsigned)(s0.sh.c + 1);
       if (v0 && (cx > 2u || cy > 2u || cz > 2u)) *pk_flag = 1;  // benign race: every writer stores 1
-      __builtin_nontemporal_store(v0 ? ((unsigned)s0.j | ((cx & 3u) << 26) | ((cy & 3u) << 28) | (cz << 30)) : D3_PK_INVALID, pk_out + e);
+      const unsigned jw = SORT ? (unsigned)(code0 >> 7) : (unsigned)s0.j;  // what the later passes gather by
+      __builtin_nontemporal_store(v0 ? (jw | ((cx & 3u) << 26) | ((cy & 3u) << 28) | (cz << 30)) : D3_PK_INVALID, pk_out + e);
     }
     if (__any(v0)) {  // a step of pure padding costs nothing (padded matrices are mostly padding)
-      bool valid = v0 && !(p0.w < (T)0);  // padding atom (Z == 0)
+      bool valid = v0 && (SORT ? (code0 & 127) != 0 : !(p0.w < (T)0));  // padding atom (Z == 0)
       const PairGeom<T> g = d3_geom<T>(p0, pix, piy, piz, s0.sh, cm, periodic);
       valid = valid && g.ok;
-      const float f = d3_cn_count(g.rinv, rci, (float)p0.w, P.k1, nullptr);
+      const float f = d3_cn_count(g.rinv, rci, SORT ? rc_lds[code0 & 127] : (float)p0.w, P.k1, nullptr);
       acc += valid ? (double)f : 0.0;
+      rmx = fmaxf(rmx, valid ? g.r : 0.0f);
     }
 #pragma unroll
     for (int k = 0; k < D3_CN_DS; ++k) s[k] = s[k + 1];
@@ -325,7 +450,12 @@ __global__ __launch_bounds__(D3_LS_WAVES * MI_WAVE) void d3_cn_kernel(const T* _
     e += MI_WAVE;
   }
   acc = wave_sum(acc);
-  if (lane == 0 && live) { cn[i] = (float)acc; aaux[i].x = (float)acc; }
+  if (lane == 0 && live) { cn[i] = (float)acc; aaux[i].x = (float)acc; if (SORT) aaux_s[k0].x = (float)acc; }
+  if (rmax_bits && (i0 & 63) == 0) {  // (wave-uniform) positive floats order like their bit patterns
+#pragma unroll
+    for (int o = MI_WAVE / 2; o > 0; o >>= 1) rmx = fmaxf(rmx, __shfl_xor(rmx, o, MI_WAVE));
+    if (lane == 0 && rmx > 0.0f) atomicMax(rmax_bits, __float_as_int(rmx));
+  }
 }
 
 // `_s5_switch` (dftd3.py:341-423)
@@ -516,10 +646,12 @@ typedef float d3_f2 __attribute__((ext_vector_type(2)));
 // (weights are in [0, 1]: sign and top exponent bit are always clear), so the energy pass gathers 32 bytes per neighbour instead
 // of 16 (position) + 32 (weights): that pass is bound by its per-neighbour gathers once the exponentials are gone.
 __global__ void d3_weights_kernel(const float* __restrict__ cn, const float4* __restrict__ aaux, const D3Species* __restrict__ sinfo,
-                                  const float* __restrict__ fcr, float k3, int N, const float4* __restrict__ apos_f32, float4* __restrict__ aw) {
+                                  const float* __restrict__ fcr, float k3, int N, const float4* __restrict__ apos_f32, float4* __restrict__ aw,
+                                  const int* __restrict__ inv, float4* __restrict__ aw_s) {
   if (!sinfo->factorized || sinfo->S > D3_SMAX) return;
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= N) return;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= N) return;
+  const int j = inv ? inv[t] : t;  // (the weight record is also written at the atom's place t in the spatial order)
   const float4 a = aaux[j];
   const int code = __float_as_int(a.z), sj = code & 0xff;
   float v[5] = {0, 0, 0, 0, 0};
@@ -542,13 +674,15 @@ __global__ void d3_weights_kernel(const float* __restrict__ cn, const float4* __
   if (apos_f32) {
     const float4 p = apos_f32[j];
     const int s4 = sj < D3_SMAX ? sj : 0;  // padding atoms: all weights are zero, any table row will do
-    aw[2 * (size_t)j] = make_float4(p.x, p.y, p.z, v[4]);
-    aw[2 * (size_t)j + 1] = make_float4(__int_as_float(__float_as_int(v[0]) | ((s4 & 3) << 30)), __int_as_float(__float_as_int(v[1]) | ((s4 >> 2) << 30)),
-                                        v[2], v[3]);
+    const float4 r0 = make_float4(p.x, p.y, p.z, v[4]);
+    const float4 r1 = make_float4(__int_as_float(__float_as_int(v[0]) | ((s4 & 3) << 30)), __int_as_float(__float_as_int(v[1]) | ((s4 >> 2) << 30)), v[2], v[3]);
+    aw[2 * (size_t)j] = r0; aw[2 * (size_t)j + 1] = r1;
+    if (inv) { aw_s[2 * (size_t)t] = r0; aw_s[2 * (size_t)t + 1] = r1; }
     return;
   }
-  aw[2 * (size_t)j] = make_float4(v[0], v[1], v[2], v[3]);
-  aw[2 * (size_t)j + 1] = make_float4(v[4], a.y, a.z, 0.0f);
+  const float4 r0 = make_float4(v[0], v[1], v[2], v[3]), r1 = make_float4(v[4], a.y, a.z, 0.0f);
+  aw[2 * (size_t)j] = r0; aw[2 * (size_t)j + 1] = r1;
+  if (inv) { aw_s[2 * (size_t)t] = r0; aw_s[2 * (size_t)t + 1] = r1; }
 }
 
 // Per pair: the (a, b) contraction only.  Same sums and thresholds as `_c6ab_interpolate`: a term survives iff
@@ -606,6 +740,8 @@ __device__ __forceinline__ void d3_energy_body(const T* __restrict__ pos, const 
                                                         const float4* __restrict__ aw, float* __restrict__ dEdCN,
                                                         float* __restrict__ forces, float* __restrict__ e_atom, double* __restrict__ v_atom,
                                                         const unsigned* __restrict__ pk, const int* __restrict__ pk_flag,
+                                                        const int* __restrict__ inv, const typename Vec4<T>::type* __restrict__ apos_s,
+                                                        const float4* __restrict__ aaux_s, const float4* __restrict__ aw_s, float* __restrict__ dEdCN_s,
                                                         float4* __restrict__ lds_buf /* 4 * d3_wave_f4(MODE) float4 of the kernel's LDS */) {
   constexpr bool LDS = MODE == 1;
   constexpr bool PACKED = MODE == 2 && sizeof(T) == 4;  // one 32-byte record per neighbour (see d3_weights_kernel)
@@ -617,8 +753,13 @@ __device__ __forceinline__ void d3_energy_body(const T* __restrict__ pos, const 
   if (PK ? *pk_flag != 0 : (pk_flag != nullptr && *pk_flag == 0)) return;
   constexpr bool use_pk = PK;
   const int lane = threadIdx.x & (MI_WAVE - 1);
-  const int i = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x / MI_WAVE) + threadIdx.x / MI_WAVE);
-  if (i >= N) return;
+  const int k0 = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x / MI_WAVE) + threadIdx.x / MI_WAVE);
+  if (k0 >= N) return;
+  // spatial order (inv != NULL): rows are taken in that order; the packed list then holds PLACES in the order and the packed variants
+  // gather from the ordered copies of the records, the plain variants keep the caller's indices and the records in atom order
+  const int i = inv ? __builtin_amdgcn_readfirstlane(inv[k0]) : k0;
+  if (PK && inv) { apos = apos_s; aaux = aaux_s; aw = aw_s; }
+  const int self = (PK && inv) ? k0 : i;  // where this atom's own records are (masked-out lanes gather them)
   const int zi = numbers[i];
   if (zi == 0) return;
   const bool periodic = (cell != nullptr) && (ush != nullptr);
@@ -668,16 +809,16 @@ __device__ __forceinline__ void d3_energy_body(const T* __restrict__ pos, const 
     else if (MODE == 2) { lo = aw[2 * (size_t)j]; hi4 = aw[2 * (size_t)j + 1]; }
     else { lo = aaux[j]; hi4 = lo; }
   };
-  PosRec p0 = pos_of(v0 ? d3_lazy_j(s0) : i);
+  PosRec p0 = pos_of(v0 ? d3_lazy_j(s0) : self);
   float4 a0, b0;
-  aux_of(v0 ? d3_lazy_j(s0) : i, a0, b0);
+  aux_of(v0 ? d3_lazy_j(s0) : self, a0, b0);
   for (long long base = beg; base < end; base += MI_WAVE) {
     e += MI_WAVE;
     const D3Lazy<PK> s2 = d3_fetch_lazy<PK>(idx, ush3, pk, e + MI_WAVE, end, periodic);
     const bool v1 = d3_lazy_in(s1) && ((unsigned)d3_lazy_j(s1) < jlim);
-    const PosRec p1 = pos_of(v1 ? d3_lazy_j(s1) : i);
+    const PosRec p1 = pos_of(v1 ? d3_lazy_j(s1) : self);
     float4 a1, b1;
-    aux_of(v1 ? d3_lazy_j(s1) : i, a1, b1);
+    aux_of(v1 ? d3_lazy_j(s1) : self, a1, b1);
     if (__any(v0)) {
       bool valid = v0 && (PACKED || !(p0.w < (T)0));  // padding atom (Z == 0); the packed record marks it by all-zero weights
       const PairGeom<T> g = d3_geom<T>(p0, pix, piy, piz, d3_lazy_sh(s0), cm, periodic);
@@ -749,6 +890,7 @@ __device__ __forceinline__ void d3_energy_body(const T* __restrict__ pos, const 
   if (lane == 0) {
     forces[3 * (size_t)i] = (float)Fx; forces[3 * (size_t)i + 1] = (float)Fy; forces[3 * (size_t)i + 2] = (float)Fz;
     dEdCN[i] = (float)dacc;
+    if (inv) dEdCN_s[k0] = (float)dacc;
     e_atom[i] = 0.5f * (float)E;
   }
   if (want_virial && lane < 9) {
@@ -762,8 +904,8 @@ __device__ __forceinline__ void d3_energy_body(const T* __restrict__ pos, const 
 }
 
 
-#define D3_ENERGY_PARAMS const T* __restrict__ pos, const int* __restrict__ numbers, int N, const int* __restrict__ idx, const int* __restrict__ ush, const int* __restrict__ nptr, int M, int fill_value, const T* __restrict__ cell, const int* __restrict__ batch_idx, D3Dev P, const float* __restrict__ cn, int want_virial, const int* __restrict__ smap, const D3Species* __restrict__ sinfo, const float4* __restrict__ ctab, const float* __restrict__ ftab, const float* __restrict__ fcr, const typename Vec4<T>::type* __restrict__ apos, const float4* __restrict__ aaux, const float4* __restrict__ aw, float* __restrict__ dEdCN, float* __restrict__ forces, float* __restrict__ e_atom, double* __restrict__ v_atom, const unsigned* __restrict__ pk, const int* __restrict__ pk_flag
-#define D3_ENERGY_ARGS pos, numbers, N, idx, ush, nptr, M, fill_value, cell, batch_idx, P, cn, want_virial, smap, sinfo, ctab, ftab, fcr, apos, aaux, aw, dEdCN, forces, e_atom, v_atom, pk, pk_flag, lds_buf
+#define D3_ENERGY_PARAMS const T* __restrict__ pos, const int* __restrict__ numbers, int N, const int* __restrict__ idx, const int* __restrict__ ush, const int* __restrict__ nptr, int M, int fill_value, const T* __restrict__ cell, const int* __restrict__ batch_idx, D3Dev P, const float* __restrict__ cn, int want_virial, const int* __restrict__ smap, const D3Species* __restrict__ sinfo, const float4* __restrict__ ctab, const float* __restrict__ ftab, const float* __restrict__ fcr, const typename Vec4<T>::type* __restrict__ apos, const float4* __restrict__ aaux, const float4* __restrict__ aw, float* __restrict__ dEdCN, float* __restrict__ forces, float* __restrict__ e_atom, double* __restrict__ v_atom, const unsigned* __restrict__ pk, const int* __restrict__ pk_flag, const int* __restrict__ inv, const typename Vec4<T>::type* __restrict__ apos_s, const float4* __restrict__ aaux_s, const float4* __restrict__ aw_s, float* __restrict__ dEdCN_s
+#define D3_ENERGY_ARGS pos, numbers, N, idx, ush, nptr, M, fill_value, cell, batch_idx, P, cn, want_virial, smap, sinfo, ctab, ftab, fcr, apos, aaux, aw, dEdCN, forces, e_atom, v_atom, pk, pk_flag, inv, apos_s, aaux_s, aw_s, dEdCN_s, lds_buf
 template <class T, bool CSR, int MODE, bool PK>
 __global__ __launch_bounds__(256) void d3_energy_kernel(D3_ENERGY_PARAMS) {
   __shared__ float4 lds_buf[4 * d3_wave_f4(MODE)];
@@ -787,9 +929,9 @@ template <class T, bool CSR>
 __global__ __launch_bounds__(256) void d3_energy_fallback_kernel(D3_ENERGY_PARAMS, const unsigned* __restrict__ pk_packed) {
   __shared__ float4 lds_buf[4 * d3_wave_f4(1)];  // one buffer for all bodies (the general form's is the largest): at most one of them works
   d3_energy_body<T, CSR, 1, true>(pos, numbers, N, idx, ush, nptr, M, fill_value, cell, batch_idx, P, cn, want_virial, smap, sinfo, ctab, ftab, fcr, apos, aaux,
-                                  aw, dEdCN, forces, e_atom, v_atom, pk_packed, pk_flag, lds_buf);
+                                  aw, dEdCN, forces, e_atom, v_atom, pk_packed, pk_flag, inv, apos_s, aaux_s, aw_s, dEdCN_s, lds_buf);
   d3_energy_body<T, CSR, 0, true>(pos, numbers, N, idx, ush, nptr, M, fill_value, cell, batch_idx, P, cn, want_virial, smap, sinfo, ctab, ftab, fcr, apos, aaux,
-                                  aw, dEdCN, forces, e_atom, v_atom, pk_packed, pk_flag, lds_buf);
+                                  aw, dEdCN, forces, e_atom, v_atom, pk_packed, pk_flag, inv, apos_s, aaux_s, aw_s, dEdCN_s, lds_buf);
   d3_energy_body<T, CSR, 2, false>(D3_ENERGY_ARGS);
   d3_energy_body<T, CSR, 1, false>(D3_ENERGY_ARGS);
   d3_energy_body<T, CSR, 0, false>(D3_ENERGY_ARGS);
@@ -804,11 +946,18 @@ __global__ __launch_bounds__(D3_LS_WAVES * MI_WAVE) void d3_chain_kernel(const T
                                                        const T* __restrict__ cell, const int* __restrict__ batch_idx, D3Dev P,
                                                        const typename Vec4<T>::type* __restrict__ apos, const float* __restrict__ dEdCN,
                                                        int want_virial, float* __restrict__ forces, double* __restrict__ v_atom,
-                                                       const unsigned* __restrict__ pk, const int* __restrict__ pk_flag) {
+                                                       const unsigned* __restrict__ pk, const int* __restrict__ pk_flag,
+                                                       const int* __restrict__ inv, const typename Vec4<T>::type* __restrict__ apos_s,
+                                                       const float* __restrict__ dEdCN_s) {
   const bool use_pk = PK && *pk_flag == 0;
   const int lane = threadIdx.x & (MI_WAVE - 1);
   const int i0 = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x / MI_WAVE) + threadIdx.x / MI_WAVE);
-  const int i = i0 < N ? i0 : N - 1;
+  const int k0 = i0 < N ? i0 : N - 1;
+  const int i = inv ? __builtin_amdgcn_readfirstlane(inv[k0]) : k0;  // rows in the spatial order (see d3_sort_key_kernel)
+  const bool ordered = use_pk && inv != nullptr;                      // the packed list holds places in that order: gather the ordered copies
+  const typename Vec4<T>::type* __restrict__ arec = ordered ? apos_s : apos;
+  const float* __restrict__ drec = ordered ? dEdCN_s : dEdCN;
+  const int self = ordered ? k0 : i;
   const int zi = numbers[i];
   const bool live = i0 < N && zi != 0;  // idle waves still take part in the block's lock-step barriers
   const bool periodic = (cell != nullptr) && (ush != nullptr);
@@ -830,15 +979,15 @@ __global__ __launch_bounds__(D3_LS_WAVES * MI_WAVE) void d3_chain_kernel(const T
   const unsigned jlim = d3_index_limit<CSR>(N, fill_value);
   D3Step s0 = d3_fetch_any<PK>(idx, ush3, pk, use_pk, e, end, periodic), s1 = d3_fetch_any<PK>(idx, ush3, pk, use_pk, e + MI_WAVE, end, periodic);
   bool v0 = s0.in && ((unsigned)s0.j < jlim);
-  auto p0 = apos[v0 ? s0.j : i];
-  float d0 = dEdCN[v0 ? s0.j : i];
+  auto p0 = arec[v0 ? s0.j : self];
+  float d0 = drec[v0 ? s0.j : self];
   for (int trip = 0; trip < trips; ++trip) {
     __syncthreads();  // lock-step (see d3_cn_kernel)
     e += MI_WAVE;
     const D3Step s2 = d3_fetch_any<PK>(idx, ush3, pk, use_pk, e + MI_WAVE, end, periodic);
     const bool v1 = s1.in && ((unsigned)s1.j < jlim);
-    const auto p1 = apos[v1 ? s1.j : i];
-    const float d1 = dEdCN[v1 ? s1.j : i];
+    const auto p1 = arec[v1 ? s1.j : self];
+    const float d1 = drec[v1 ? s1.j : self];
     if (__any(v0)) {
       bool valid = v0 && !(p0.w < (T)0);  // padding atom (Z == 0)
       const PairGeom<T> g = d3_geom<T>(p0, pix, piy, piz, s0.sh, cm, periodic);
@@ -935,7 +1084,8 @@ __global__ void d3_finish_kernel(const double* __restrict__ sums, int B, int wan
   else if (want_virial) virial[9 * (size_t)s + (k - 1)] = (float)v;
 }
 
-struct D3Layout { size_t dEdCN, e_atom, v_atom, sums, tab, present, smap, sinfo, ctab, ftab, fcr, apos, aaux, aw, total; };
+inline long long d3_sort_cap(int N, int B) { return 4ll * N + 8ll * (B > 0 ? B : 1); }
+struct D3Layout { size_t dEdCN, e_atom, v_atom, sums, tab, present, smap, sinfo, ctab, ftab, fcr, apos, aaux, aw, inv, skeys, sgrid, sbins, apos_s, acn, aaux_s, aw_s, dEdCN_s, total; };
 D3Layout d3_layout(int N, int nz, int dtype, int B) {
   D3Layout L;
   size_t o = 0;
@@ -945,7 +1095,7 @@ D3Layout d3_layout(int N, int nz, int dtype, int B) {
   L.v_atom = take(sizeof(double) * 9 * (size_t)N);  // fp64: the direct and the chain-rule part of an atom's virial can cancel (dense systems)
   L.sums = take(sizeof(double) * 10 * D3_REDUCE_SLOTS * (size_t)(B > 0 ? B : 1));
   L.tab = take(sizeof(float4) * (size_t)nz * nz * 25);
-  L.present = take(sizeof(int) * (size_t)nz);
+  L.present = take(sizeof(int) * ((size_t)nz + 2));  // + 2: the atom-order probe {far-apart consecutive pairs, largest pair distance (bits)}, cleared with the table
   L.smap = take(sizeof(int) * (size_t)nz);
   L.sinfo = take(sizeof(D3Species));
   L.ctab = take(sizeof(float4) * D3_SMAX * D3_SMAX * 25);
@@ -954,8 +1104,60 @@ D3Layout d3_layout(int N, int nz, int dtype, int B) {
   L.apos = take((dtype == MI_F32 ? 16 : 32) * (size_t)N);
   L.aaux = take(sizeof(float4) * (size_t)N);
   L.aw = take(sizeof(float4) * 2 * (size_t)N);
+  // spatial order: permutation, bin keys, counting-sort counters (<= N/16 bins), ordered copies of the gathered records
+  L.inv = take(sizeof(int) * (size_t)N);
+  L.skeys = take(sizeof(int) * (size_t)N);
+  L.sgrid = take(sizeof(D3Grid) * (size_t)(B > 0 ? B : 1));
+  L.sbins = take(sizeof(int) * bs_scratch_ints(d3_sort_cap(N, B) + 1));  // the search's own bound on its cells: 4 N + 8 B
+  L.apos_s = take((dtype == MI_F32 ? 16 : 32) * (size_t)N);
+  L.acn = take((dtype == MI_F32 ? 16 : 32) * (size_t)N);
+  L.aaux_s = take(sizeof(float4) * (size_t)N);
+  L.aw_s = take(sizeof(float4) * 2 * (size_t)N);
+  L.dEdCN_s = take(sizeof(float) * (size_t)N);
   L.total = o;
   return L;
+}
+
+// ---- is the caller's atom order spatially coherent?  (host side of the spatial order) ------------------------------------------------
+// Ordered input (lattice order, molecules, a previous sort) is best left alone: the records in atom order ARE coherent, and sorting them
+// on a grid that is not the neighbour search's own makes the 32-byte gathers of the energy pass worse (0.92 -> 1.18 ms on the headline
+// box), whereas a randomly ordered box gains 8.2 -> 6.2 ms per step.  The order of an MD system does not change from step to step, so
+// the decision is taken from a measurement of an EARLIER call, without any synchronisation: every D3_ORDER_PROBE_EVERY-th call the key
+// kernel counts the consecutive atoms that sit in far-apart bins and the count is copied to pinned host memory asynchronously; a later
+// call reads whatever has arrived (first calls: "coherent").  Both paths give bit-identical results, so a switch is invisible.
+#define D3_ORDER_PROBE_EVERY 64
+struct D3OrderState { int* h_count = nullptr; /* pinned {far-apart pairs, largest pair distance bits} */ int n_atoms = -1, n_systems = -1; long long calls = 0; };
+static D3OrderState g_d3_order[16];
+static std::mutex g_d3_order_mu;
+static bool d3_order_decide(int N, int B, hipStream_t st, bool* probe, float* rc_est) {
+  *probe = false;
+  *rc_est = 0.0f;
+  const char* force = getenv("NVALCHEMIOPS_D3_SORT");  // tuning aid: 0 = never, 1 = always
+  if (force && atoi(force) == 0) return false;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return false;
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  const bool capturing = hipStreamIsCapturing(st, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone;
+  std::lock_guard<std::mutex> lock(g_d3_order_mu);
+  D3OrderState& S = g_d3_order[dev];
+  if (!S.h_count) {
+    if (capturing || hipHostMalloc(reinterpret_cast<void**>(&S.h_count), 2 * sizeof(int), hipHostMallocDefault) != hipSuccess) { S.h_count = nullptr; return force != nullptr; }
+    S.h_count[0] = S.h_count[1] = 0;
+  }
+  volatile int* h = S.h_count;
+  if (S.n_atoms != N || S.n_systems != B) { S.n_atoms = N; S.n_systems = B; S.calls = 0; h[0] = 0; h[1] = 0; }
+  *probe = !capturing && (S.calls < 4 || (S.calls % D3_ORDER_PROBE_EVERY) == 0);  // the first calls, then now and then
+  ++S.calls;
+  const int bits = h[1];
+  *rc_est = __builtin_bit_cast(float, bits);
+  if (force) return true;
+  return 4ll * h[0] > (long long)N;  // more than a quarter of the consecutive pairs are far apart
+}
+static void d3_order_publish(const int* d_count, hipStream_t st) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return;
+  int* h = g_d3_order[dev].h_count;
+  if (h) (void)hipMemcpyAsync(h, d_count, 2 * sizeof(int), hipMemcpyDeviceToHost, st);
 }
 
 template <class T, bool CSR>
@@ -978,6 +1180,19 @@ int d3_impl(const T* pos, const int* numbers, int N, const int* idx, const int* 
   auto* apos = reinterpret_cast<typename Vec4<T>::type*>(ws + L.apos);
   float4* aaux = reinterpret_cast<float4*>(ws + L.aaux);
   float4* aw = reinterpret_cast<float4*>(ws + L.aw);
+  // spatial order (see d3_sort_key_kernel): only with the packed list (periodic, shifts given), enough atoms for it to matter, codes that
+  // fit (place < 2^24, Z < 128) -- and only when the caller's atom order is NOT spatially coherent already (D3OrderState)
+  const bool sortable = pk != nullptr && cell != nullptr && N >= D3_SORT_MIN_ATOMS && N < (1 << 24) && hp->nz <= 128;
+  int* order_probe = present + hp->nz;  // cleared with `present` below
+  bool probe = false;
+  float rc_est = 0.0f;
+  const bool sorted = sortable && d3_order_decide(N, B, st, &probe, &rc_est);
+  int* inv = sorted ? reinterpret_cast<int*>(ws + L.inv) : nullptr;
+  auto* apos_s = reinterpret_cast<typename Vec4<T>::type*>(ws + L.apos_s);
+  auto* acn = reinterpret_cast<typename Vec4<T>::type*>(ws + L.acn);
+  float4* aaux_s = reinterpret_cast<float4*>(ws + L.aaux_s);
+  float4* aw_s = reinterpret_cast<float4*>(ws + L.aw_s);
+  float* dEdCN_s = reinterpret_cast<float*>(ws + L.dEdCN_s);
   D3Dev P;
   P.rcov = hp->rcov; P.r4r2 = hp->r4r2; P.tab = tab; P.nz = hp->nz;
   P.a1 = hp->a1; P.a2 = hp->a2; P.s6 = hp->s6; P.s8 = hp->s8; P.k1 = hp->k1; P.k3 = hp->k3; P.s5_on = hp->s5_on; P.s5_off = hp->s5_off;
@@ -985,7 +1200,24 @@ int d3_impl(const T* pos, const int* numbers, int N, const int* idx, const int* 
   P.inv_w = (hp->s5_off > hp->s5_on) ? (float)(1.0 / ((double)hp->s5_off - (double)hp->s5_on)) : 0.0f;
   // outputs are zeroed like the reference wrapper does (dftd3.py:1933-1936; atoms with Z == 0 keep zeros): the per-atom arrays by
   // the pack kernel below, energy / virial are written for every system by the finish kernel
-  MI_HIP_CHECK(hipMemsetAsync(present, 0, sizeof(int) * (size_t)hp->nz, st));
+  MI_HIP_CHECK(hipMemsetAsync(present, 0, sizeof(int) * ((size_t)hp->nz + 2), st));
+  D3Grid* sgrid = reinterpret_cast<D3Grid*>(ws + L.sgrid);
+  if (sorted || (sortable && probe)) {
+    d3_sort_setup_kernel<T><<<1, 256, 0, st>>>(cell, B, N, rc_est, sgrid, d3_sort_cap(N, B));
+    MI_LAUNCH_CHECK();
+  }
+  if (sorted) {
+    int* skeys = reinterpret_cast<int*>(ws + L.skeys);
+    const BsScratch bins = bs_carve(reinterpret_cast<int*>(ws + L.sbins), d3_sort_cap(N, B) + 1);
+    MI_HIP_CHECK(bs_clear(bins, st));
+    d3_sort_key_kernel<T><<<mi_blocks(N, 256), 256, 0, st>>>(pos, cell, batch_idx, N, sgrid, skeys, bins.count, order_probe);
+    MI_LAUNCH_CHECK();
+    MI_HIP_CHECK(bs_sort(bins, skeys, N, nullptr, inv, nullptr, st));
+  } else if (sortable && probe) {
+    d3_sort_key_kernel<T><<<mi_blocks(N, 256), 256, 0, st>>>(pos, cell, batch_idx, N, sgrid, nullptr, nullptr, order_probe);
+    MI_LAUNCH_CHECK();
+  }
+  const bool publish = sortable && probe;  // (after the CN pass, which adds the largest pair distance)
   d3_mark_species_kernel<<<mi_blocks(N, 256), 256, 0, st>>>(numbers, N, hp->nz, present);
   MI_LAUNCH_CHECK();
   d3_compact_species_kernel<<<1, 256, 0, st>>>(present, hp->c6ab, hp->cn_ref, hp->nz, smap, sinfo, ctab, ftab, fcr, hp->k3, hp->r4r2, hp->a1, hp->a2);
@@ -994,17 +1226,18 @@ int d3_impl(const T* pos, const int* numbers, int N, const int* idx, const int* 
   d3_pack_tables_kernel<<<mi_blocks(nt, 256), 256, 0, st>>>(hp->c6ab, hp->cn_ref, hp->nz, sinfo, tab);  // only works for > 16 species
   MI_LAUNCH_CHECK();
   d3_pack_atoms_kernel<T><<<mi_blocks(N, 256), 256, 0, st>>>(pos, numbers, N, hp->rcov, hp->r4r2, smap, hp->nz, apos, aaux, forces, cn, dEdCN, e_atom,
-                                                             want_virial ? v_atom : nullptr);
+                                                             want_virial ? v_atom : nullptr, inv, apos_s, aaux_s, acn);
   MI_LAUNCH_CHECK();
   const int blocks = mi_blocks(N, 4);
-  if ((double)n_entries * ((cell && ush) ? 16.0 : 4.0) > 2.0e9) {  // list bytes (see d3_fetch)
-    MI_TIMED("d3_cn", st, (d3_cn_kernel<T, CSR, true><<<mi_blocks(N, D3_LS_WAVES), D3_LS_WAVES * MI_WAVE, 0, st>>>(pos, numbers, N, idx, ush, nptr, M, fill_value, cell, batch_idx, P, apos, aaux, cn, pk, pk_flag)));
-  } else {
-    MI_TIMED("d3_cn", st, (d3_cn_kernel<T, CSR, false><<<mi_blocks(N, D3_LS_WAVES), D3_LS_WAVES * MI_WAVE, 0, st>>>(pos, numbers, N, idx, ush, nptr, M, fill_value, cell, batch_idx, P, apos, aaux, cn, pk, pk_flag)));
-  }
+#define MI_D3_CN(BIG_, SORT_) d3_cn_kernel<T, CSR, BIG_, SORT_><<<mi_blocks(N, D3_LS_WAVES), D3_LS_WAVES * MI_WAVE, 0, st>>>(pos, numbers, N, idx, ush, nptr, M, fill_value, cell, batch_idx, P, apos, aaux, cn, pk, pk_flag, inv, acn, aaux_s, sortable ? order_probe + 1 : nullptr)
+  const bool big_list = (double)n_entries * ((cell && ush) ? 16.0 : 4.0) > 2.0e9;  // list bytes (see d3_fetch)
+  if (big_list) { if (sorted) { MI_TIMED("d3_cn", st, (MI_D3_CN(true, true))); } else { MI_TIMED("d3_cn", st, (MI_D3_CN(true, false))); } }
+  else { if (sorted) { MI_TIMED("d3_cn", st, (MI_D3_CN(false, true))); } else { MI_TIMED("d3_cn", st, (MI_D3_CN(false, false))); } }
+#undef MI_D3_CN
+  if (publish) d3_order_publish(order_probe, st);
   MI_LAUNCH_CHECK();
   d3_weights_kernel<<<mi_blocks(N, 256), 256, 0, st>>>(cn, aaux, sinfo, fcr, hp->k3, N,
-                                                       sizeof(T) == 4 ? reinterpret_cast<const float4*>(apos) : nullptr, aw);
+                                                       sizeof(T) == 4 ? reinterpret_cast<const float4*>(apos) : nullptr, aw, inv, aw_s);
   MI_LAUNCH_CHECK();
   // all three variants are launched; two of them exit at once on the device-side species info.  Only the fp32 factorised variant
   // is instantiated with the 5-waves-per-SIMD register cap (the others would spill under it).
@@ -1014,10 +1247,10 @@ int d3_impl(const T* pos, const int* numbers, int N, const int* idx, const int* 
     const unsigned* pk_in = PK_ ? pk : nullptr;
     if constexpr (MODE_ == 2 && sizeof(T) == 4)
       d3_energy_kernel_w5<T, CSR, MODE_, PK_><<<blocks, 256, 0, st>>>(pos, numbers, N, idx, ush, nptr, M, fill_value, cell, batch_idx, P, cn, want_virial,
-                                                                     smap, sinfo, ctab, ftab, fcr, apos, aaux, aw, dEdCN, forces, e_atom, v_atom, pk_in, pk_flag);
+                                                                     smap, sinfo, ctab, ftab, fcr, apos, aaux, aw, dEdCN, forces, e_atom, v_atom, pk_in, pk_flag, inv, apos_s, aaux_s, aw_s, dEdCN_s);
     else
       d3_energy_kernel<T, CSR, MODE_, PK_><<<blocks, 256, 0, st>>>(pos, numbers, N, idx, ush, nptr, M, fill_value, cell, batch_idx, P, cn, want_virial,
-                                                                  smap, sinfo, ctab, ftab, fcr, apos, aaux, aw, dEdCN, forces, e_atom, v_atom, pk_in, pk_flag);
+                                                                  smap, sinfo, ctab, ftab, fcr, apos, aaux, aw, dEdCN, forces, e_atom, v_atom, pk_in, pk_flag, inv, apos_s, aaux_s, aw_s, dEdCN_s);
   };
   using Plain = std::integral_constant<bool, false>;
   using Packed = std::integral_constant<bool, true>;
@@ -1032,13 +1265,13 @@ int d3_impl(const T* pos, const int* numbers, int N, const int* idx, const int* 
     MI_TIMED("d3_energy", st, (launch_energy(std::integral_constant<int, 2>{}, Packed{})));
     MI_LAUNCH_CHECK();
     d3_energy_fallback_kernel<T, CSR><<<blocks, 256, 0, st>>>(pos, numbers, N, idx, ush, nptr, M, fill_value, cell, batch_idx, P, cn, want_virial, smap, sinfo,
-                                                              ctab, ftab, fcr, apos, aaux, aw, dEdCN, forces, e_atom, v_atom, nullptr, pk_flag, pk);
+                                                              ctab, ftab, fcr, apos, aaux, aw, dEdCN, forces, e_atom, v_atom, nullptr, pk_flag, inv, apos_s, aaux_s, aw_s, dEdCN_s, pk);
   } else { MI_TIMED("d3_energy", st, (launch_modes(Plain{}))); }
   MI_LAUNCH_CHECK();
   auto launch_chain = [&](auto packed) {
     constexpr bool PK_ = decltype(packed)::value;
     d3_chain_kernel<T, CSR, PK_><<<mi_blocks(N, D3_LS_WAVES), D3_LS_WAVES * MI_WAVE, 0, st>>>(pos, numbers, N, idx, ush, nptr, M, fill_value, cell, batch_idx, P, apos,
-                                                                                             dEdCN, want_virial, forces, v_atom, PK_ ? pk : nullptr, pk_flag);
+                                                                                             dEdCN, want_virial, forces, v_atom, PK_ ? pk : nullptr, pk_flag, inv, apos_s, dEdCN_s);
   };
   if (pk) { MI_TIMED("d3_chain", st, (launch_chain(Packed{}))); }
   else { MI_TIMED("d3_chain", st, (launch_chain(Plain{}))); }

@@ -178,7 +178,8 @@ def _reciprocal_fused(pos, q, cells, alpha, mesh_dimensions, spline_order, bi, c
     C.check(C.lib().mi_pme_prepare(C.ptr(cc), C.ptr(q), C.ptr(bi), n, cc.shape[0], code, C.ptr(cit), C.ptr(recip), C.ptr(vol), C.ptr(qtot), st),
             "mi_pme_prepare")
     al = alpha.to(dt).contiguous()
-    mesh = _launch_spread(pos, q, cit, bi, nsys, (nx, ny, nz), int(spline_order), batched)
+    # tile_order: the atoms grouped by mesh tile, a by-product of the tile-owned spread; the gather epilogue walks the atoms in that order
+    mesh, tile_order = _launch_spread(pos, q, cit, bi, nsys, (nx, ny, nz), int(spline_order), batched, want_order=True)
     spec = torch.fft.rfftn(mesh, norm="backward", dim=(1, 2, 3))  # unscaled forward (pme.py:1398)
     nch = 4 if compute_forces else 1
     conv = torch.empty((nsys, nch, nx, ny, nz // 2 + 1), dtype=spec.dtype, device=dev)
@@ -209,7 +210,8 @@ def _reciprocal_fused(pos, q, cells, alpha, mesh_dimensions, spline_order, bi, c
     add_e, add_f, add_cg = add
     rc = C.lib().mi_pme_gather_finish(C.ptr(pos), C.ptr(q), C.ptr(bi), C.ptr(cit), C.ptr(real), C.ptr(al), C.ptr(vol), C.ptr(qtot), n, nsys, nx,
                                       ny, nz, int(spline_order), int(compute_forces), code, C.ptr(energies), C.ptr(forces), C.ptr(cgrads),
-                                      C.ptr(add_e), C.ptr(add_f if compute_forces else None), C.ptr(add_cg if compute_charge_gradients else None), st)
+                                      C.ptr(add_e), C.ptr(add_f if compute_forces else None), C.ptr(add_cg if compute_charge_gradients else None),
+                                      C.ptr(tile_order), st)
     C.check(rc, "mi_pme_gather_finish")
     return energies, forces, cgrads
 

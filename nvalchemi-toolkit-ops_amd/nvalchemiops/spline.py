@@ -27,9 +27,11 @@ def _prep(positions: torch.Tensor, cell: torch.Tensor, batch_idx, cell_inv_t):
 
 
 # ---- raw launchers (detached, contiguous tensors) ------------------------------------------------------------------
-def _launch_spread(pos, vals, cit, bi, nsys, dims, order, batched):
+def _launch_spread(pos, vals, cit, bi, nsys, dims, order, batched, want_order=False):
     """mesh[nsys,nx,ny,nz] = spread of `vals` at `pos`.  The library runs tile-owned (no global atomics) when every mesh dimension
-    has a divisor in [max(order - 1, 2), 8] and falls back to atomic adds into the zeroed mesh otherwise; the scratch buffer covers the former."""
+    has a divisor in [max(order - 1, 2), 8] and falls back to atomic adds into the zeroed mesh otherwise; the scratch buffer covers the former.
+    want_order: also return the header + atom ids grouped by mesh tile (int32[4 + n] view into the scratch buffer, see
+    mi_spline_spread_order_offset; None after the atomic kernel)."""
     import ctypes
 
     nx, ny, nz = (int(v) for v in dims)
@@ -42,7 +44,10 @@ def _launch_spread(pos, vals, cit, bi, nsys, dims, order, batched):
     rc = C.lib().mi_spline_spread(C.ptr(pos), C.ptr(vals), C.ptr(bi), C.ptr(cit), n, nsys, nx, ny, nz, int(order), int(batched),
                                   C.dtype_code(pos.dtype), C.ptr(mesh), C.ptr(ws), ctypes.c_size_t(ws_bytes), C.stream_of(pos))
     C.check(rc, "mi_spline_spread")
-    return mesh
+    if not want_order:
+        return mesh
+    off = int(C.lib().mi_spline_spread_order_offset(n, nsys, nx, ny, nz, int(order))) if tiled else -1
+    return mesh, (ws[off:off + 4 * (n + 4)].view(torch.int32) if off >= 0 else None)
 
 
 def _launch_gather(pos, mesh, cit, bi, order, grad=False):

@@ -310,6 +310,52 @@ def test_packed_list_equals_plain_walk(box, shift_max, monkeypatch):
         _check(packed, ref, virial=True)
 
 
+@pytest.mark.parametrize("batched", [False, True])
+def test_spatial_order_is_invisible_in_the_results(batched, monkeypatch):
+    """A periodic box whose atoms are in RANDOM index order: with the spatial order inside `mi_d3` forced on (records and list entries
+    re-indexed by a grid sort, rows walked in that order) and forced off the outputs are bit-identical -- every sum keeps
+    its order, only the gather addresses change -- and permuting the atoms permutes the per-atom outputs.  Twice with the order on: the
+    second call builds its grid from the cutoff the first one measured."""
+    from nvalchemiops.interactions.dispersion import dftd3
+    from nvalchemiops.neighborlist import batch_cell_list, cell_list
+
+    t, p = _params()
+    n = 4000
+    pos, cell, _, numbers = S.fcc_box(n, dtype=np.float32)
+    z = np.where(numbers == 6, 6, 8).astype(np.int32)
+    pbc = torch.tensor([True] * 3, device=DEV)
+
+    def run(pos_, z_):
+        if batched:  # two copies of the box as a batch of two systems
+            P = np.concatenate([pos_, pos_]); Z = np.concatenate([z_, z_])
+            bi = _t(np.repeat(np.arange(2, dtype=np.int32), n)); C = _t(np.stack([cell, cell]))
+            nm, num, sh = batch_cell_list(_t(P), 12.0, C, pbc[None].expand(2, 3).contiguous(), bi, max_neighbors=512)
+            assert int(num.max()) <= 512
+            return dftd3(_t(P), _t(Z), d3_params=p, neighbor_matrix=nm, neighbor_matrix_shifts=sh, cell=C, batch_idx=bi, compute_virial=True, **FP)
+        nm, num, sh = cell_list(_t(pos_), 12.0, _t(cell), pbc, max_neighbors=512)
+        assert int(num.max()) <= 512
+        return dftd3(_t(pos_), _t(z_), d3_params=p, neighbor_matrix=nm, neighbor_matrix_shifts=sh, cell=_t(cell)[None], compute_virial=True, **FP)
+
+    perm = np.random.default_rng(5).permutation(n)
+    monkeypatch.setenv("NVALCHEMIOPS_D3_SORT", "0")
+    off = run(pos[perm], z[perm])
+    monkeypatch.setenv("NVALCHEMIOPS_D3_SORT", "1")
+    on1 = run(pos[perm], z[perm])
+    on2 = run(pos[perm], z[perm])
+    for a, b, c in zip(off, on1, on2):
+        assert torch.equal(a, b) and torch.equal(a, c)
+    monkeypatch.delenv("NVALCHEMIOPS_D3_SORT")
+    auto = run(pos[perm], z[perm])  # decided from the measured order of an earlier call: either path, same bits
+    for a, b in zip(off, auto):
+        assert torch.equal(a, b)
+    ordered = run(pos, z)  # the same box in lattice order: per-atom outputs are the permuted ones (different lists -> different sum order)
+    pp = np.concatenate([perm, perm + n]) if batched else perm
+    for k, what in ((1, "forces"), (2, "cn")):
+        a, b = off[k].cpu().numpy(), ordered[k].cpu().numpy()[pp]
+        assert np.abs(a - b).max() <= 2e-5 * np.abs(b).max(), (what, np.abs(a - b).max(), np.abs(b).max())
+    assert np.abs(off[0].cpu().numpy() - ordered[0].cpu().numpy()).max() <= 2e-6 * np.abs(ordered[0].cpu().numpy()).max()
+
+
 def test_headline_100k_periodic_full_size_vs_oracle():
     """The D3 leg of the headline workload at its FULL size (100k-atom periodic box, rc = 40 Bohr, padded matrix M = 2560,
     E + F + virial, fp32; 235 M directed pairs) against the oracle on the device-built list (~25 s of oracle time).

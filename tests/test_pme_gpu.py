@@ -298,6 +298,31 @@ def test_config4_100k_fp64_properties():
     assert float((f - f2).abs().max()) < 1e-8 * float(f.abs().max()) * 10
 
 
+def test_pme_is_equivariant_under_a_permutation_of_the_atoms():
+    """The gather epilogue walks the atoms tile by tile when the caller's atom order is not spatially coherent (the tile-owned spread of
+    the same call measures that and leaves the tile-grouped ids behind, csrc/pme.hip): a randomly permuted 20k-atom box gives the permuted
+    energies / forces / charge gradients of the lattice-ordered one (fp64: the mesh sums differ only in the order of the tile kernel's
+    LDS atomics)."""
+    from nvalchemiops.interactions.electrostatics import particle_mesh_ewald
+    from nvalchemiops.neighborlist import cell_list
+
+    pbc = torch.tensor([True] * 3, device=DEV)
+    n = 20000
+    pos, cell, q, _ = S.fcc_box(n, dtype=np.float64)
+    perm = np.random.default_rng(11).permutation(n)
+
+    def run(pos_, q_):
+        nm, num, sh = cell_list(_t(pos_), 9.0, _t(cell), pbc, max_neighbors=256)
+        return particle_mesh_ewald(_t(pos_), _t(q_), _t(cell), alpha=0.35, mesh_dimensions=(64, 64, 64), spline_order=5, neighbor_matrix=nm,
+                                   neighbor_matrix_shifts=sh, compute_forces=True, compute_charge_gradients=True)
+
+    a, b = run(pos, q), run(pos[perm], q[perm])
+    for x, y, what in zip(a, b, ("energies", "forces", "charge gradients")):
+        x = x.cpu().numpy()[perm]
+        y = y.cpu().numpy()
+        assert np.abs(x - y).max() < 1e-10 * max(1.0, np.abs(x).max()), what
+
+
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
 @pytest.mark.parametrize("order", [5, 6])
 def test_orders_5_6_vs_extended_oracle(dtype, order):
