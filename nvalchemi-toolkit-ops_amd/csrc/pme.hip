@@ -336,16 +336,38 @@ __global__ __launch_bounds__(256) void pme_prepare_kernel(const T* __restrict__ 
       }
     vol[t] = det < T(0) ? -det : det;
   }
-  const int lane = threadIdx.x & (MI_WAVE - 1);
-  const bool in = t < N;
-  const int s = in ? (batch_idx ? batch_idx[t] : 0) : -1;
-  const int s0 = __shfl(s, 0, MI_WAVE);
-  T x = in ? charges[t] : T(0);
-  if (__all(!in || s == s0)) {
-    x = wave_sum(x);
-    if (lane == 0 && s0 >= 0) atomicAdd(&qtot[s0], x);
-  } else if (in) {
-    atomicAdd(&qtot[s], x);
+  // total charge per system.  Each thread takes atoms t, t + stride, ... (a contiguous run of atoms per wave trip); a wave whose 64 atoms
+  // share a system adds its sum to a running (system, sum) pair and touches global memory once per system change, and the waves of a
+  // block whose pairs agree at the end are combined in LDS first -- the single-system headline box issued 1563 same-address fp64 atomics
+  // (one per wave) before, 20 us of serialisation on the PME branch; now <= 128.
+  const int lane = threadIdx.x & (MI_WAVE - 1), wave = threadIdx.x / MI_WAVE;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  int cur = -1;
+  T acc = T(0);
+  for (long long a = t; a - lane < N; a += stride) {  // (wave-uniform trip count)
+    const bool in = a < N;
+    const int s = in ? (batch_idx ? batch_idx[a] : 0) : -1;
+    T x = in ? charges[a] : T(0);
+    const int s0 = __shfl(s, 0, MI_WAVE);
+    if (__all(!in || s == s0)) {
+      x = wave_sum(x);
+      if (s0 != cur) { if (lane == 0 && cur >= 0) atomicAdd(&qtot[cur], acc); cur = s0; acc = T(0); }
+      acc += x;
+    } else if (in) {
+      atomicAdd(&qtot[s], x);
+    }
+  }
+  __shared__ int cur_sh[4];
+  __shared__ T acc_sh[4];
+  if (lane == 0) { cur_sh[wave] = cur; acc_sh[wave] = acc; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 0; w < (int)(blockDim.x / MI_WAVE); ++w) {
+      if (cur_sh[w] < 0) continue;
+      T v = acc_sh[w];
+      for (int u = w + 1; u < (int)(blockDim.x / MI_WAVE); ++u) if (cur_sh[u] == cur_sh[w]) { v += acc_sh[u]; cur_sh[u] = -1; }
+      atomicAdd(&qtot[cur_sh[w]], v);
+    }
   }
 }
 
@@ -778,7 +800,9 @@ int mi_pme_prepare(const void* cell, const void* charges, const int32_t* batch_i
   hipStream_t st = (hipStream_t)stream;
   MI_HIP_CHECK(hipMemsetAsync(total_charge, 0, (dtype == MI_F32 ? 4 : 8) * (size_t)n_systems, st));
   const int threads = n_atoms > n_systems ? n_atoms : n_systems;
-  MI_DISPATCH_T(dtype, (pme_prepare_kernel<T_><<<mi_blocks(threads, 256), 256, 0, st>>>((const T_*)cell, (const T_*)charges, batch_idx, n_atoms, n_systems,
+  int prep_blocks = mi_blocks(threads, 256);
+  if (prep_blocks > 128 && n_systems <= 128 * 256) prep_blocks = 128;  // (every system still gets its geometry thread: t < B covered by 128 x 256 threads)
+  MI_DISPATCH_T(dtype, (pme_prepare_kernel<T_><<<prep_blocks, 256, 0, st>>>((const T_*)cell, (const T_*)charges, batch_idx, n_atoms, n_systems,
                                                                                          (T_*)cell_inv_t, (T_*)reciprocal_cell, (T_*)volume,
                                                                                          (T_*)total_charge)));
   MI_LAUNCH_CHECK();

@@ -356,6 +356,30 @@ def test_spatial_order_is_invisible_in_the_results(batched, monkeypatch):
     assert np.abs(off[0].cpu().numpy() - ordered[0].cpu().numpy()).max() <= 2e-6 * np.abs(ordered[0].cpu().numpy()).max()
 
 
+def test_spatial_order_with_the_packed_list_fallback(monkeypatch):
+    """The spatial order together with the device-side fallback of the packed list: a box smaller than the cutoff (unit shifts of +-2,
+    so the CN pass raises its flag and the energy / chain passes walk the caller's arrays, which hold ATOM indices while the packed words
+    hold places in the order).  Both record sets have to be right; outputs bit-identical with the order off."""
+    from nvalchemiops.interactions.dispersion import dftd3
+    from nvalchemiops.neighborlist import cell_list
+
+    t, p = _params()
+    n = 2304
+    pos, cell = S.random_box(n, 30.0, seed=3, dtype=np.float32)
+    z = np.random.default_rng(4).choice(np.array([1, 6, 8], np.int32), n)
+    pbc = torch.tensor([True] * 3, device=DEV)
+    nm, num, sh = cell_list(_t(pos), 32.0, _t(cell), pbc, max_neighbors=12800)
+    assert int(num.max()) <= 12800 and int(sh.abs().max()) == 2
+    args = dict(d3_params=p, neighbor_matrix=nm, neighbor_matrix_shifts=sh, cell=_t(cell)[None], compute_virial=True, **FP)
+    monkeypatch.setenv("NVALCHEMIOPS_D3_SORT", "0")
+    off = dftd3(_t(pos), _t(z), **args)
+    monkeypatch.setenv("NVALCHEMIOPS_D3_SORT", "1")
+    on = dftd3(_t(pos), _t(z), **args)
+    on2 = dftd3(_t(pos), _t(z), **args)
+    for a, b, c in zip(off, on, on2):
+        assert torch.isfinite(a).all() and torch.equal(a, b) and torch.equal(a, c)
+
+
 def test_headline_100k_periodic_full_size_vs_oracle():
     """The D3 leg of the headline workload at its FULL size (100k-atom periodic box, rc = 40 Bohr, padded matrix M = 2560,
     E + F + virial, fp32; 235 M directed pairs) against the oracle on the device-built list (~25 s of oracle time).
