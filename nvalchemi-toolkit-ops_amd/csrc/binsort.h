@@ -21,24 +21,26 @@ namespace {
 template <bool RETURN>
 __device__ __forceinline__ int bs_wave_add(int* __restrict__ counter, int key, bool active) {
   const int lane = threadIdx.x & (MI_WAVE - 1);
-  int result = 0;
+  // group the lanes by key first (registers and shuffles only: one trip per distinct key among the remaining lanes) ...
+  int leader_of = lane, rank = 0, size = 0;
   unsigned long long todo = __ballot(active);
-  while (todo) {  // wave-uniform loop: one trip per distinct key among the remaining lanes
+  while (todo) {  // wave-uniform loop
     const int leader = __ffsll((long long)todo) - 1;
     const int k0 = __shfl(key, leader, MI_WAVE);
     const unsigned long long same = __ballot(active && key == k0);
-    int base = 0;
-    if (lane == leader) {
-      if (RETURN) base = atomicAdd(&counter[k0], __popcll(same));
-      else atomicAdd(&counter[k0], __popcll(same));
-    }
-    if (RETURN) {
-      base = __shfl(base, leader, MI_WAVE);
-      if (active && key == k0) result = base + __popcll(same & ((1ull << lane) - 1ull));
-    }
+    if (active && key == k0) { leader_of = leader; rank = __popcll(same & ((1ull << lane) - 1ull)); size = __popcll(same); }
     todo &= ~same;
   }
-  return result;
+  // ... then ONE atomic instruction for all groups at once (their leaders, different addresses): the memory round trip is paid once
+  // per wave, not once per distinct key (the scatter pass of a 100k-atom binning: 16-18 -> ~7 us)
+  int base = 0;
+  if (active && leader_of == lane) {
+    if (RETURN) base = atomicAdd(&counter[key], size);
+    else atomicAdd(&counter[key], size);
+  }
+  if (!RETURN) return 0;
+  base = __shfl(base, leader_of, MI_WAVE);
+  return base + rank;
 }
 
 // count[] -> in-place exclusive prefix inside each BS_CHUNK block; block_sum[b] = total of block b.
