@@ -119,26 +119,53 @@ def i32(t: torch.Tensor | None) -> torch.Tensor | None:
     return t.to(torch.int32).contiguous()
 
 
+def _on_device_of(args, kwargs):
+    """Device of the first tensor argument when it is not the current one (HIP launches go to the CURRENT device: tensors on another
+    GPU of the process need the guard the reference gets from Warp's per-device launch, `wp.launch(device=...)`)."""
+    for a in (args if args else kwargs.values()):
+        if isinstance(a, torch.Tensor):
+            if a.is_cuda and a.device.index != torch.cuda.current_device():
+                return a.device
+            break
+    return None
+
+
 def eager(fn):
-    """Decorator of every public entry point that launches through the C ABI.  The launch layer hands raw device pointers and the
-    current HIP stream to ctypes, which TorchDynamo can neither trace nor guard, so under ``torch.compile`` these functions run as
-    eager islands (a graph break around the call) -- the behaviour the reference's ``@torch.compile`` tests rely on
-    (test/neighborlist/test_cell_list.py:599-760, test_naive.py:1200-1300, test/interactions/dispersion/test_dftd3.py:1204-1330).
-    The ``torch.ops.nvalchemiops.*`` custom ops (``_ops.py``) are the fullgraph-capable seam."""
+    """Decorator of the public entry points whose result SHAPE depends on device data (COO / CSR conversion, size estimates: one host
+    read each).  The launch layer hands raw device pointers and the current HIP stream to ctypes, which TorchDynamo can neither trace nor
+    guard, so under ``torch.compile`` these run as eager islands (a graph break around the call) -- the reference's versions of the same
+    functions break the graph at their ``.item()`` as well (neighbor_utils.py:426, cell_list.py:700-722)."""
     inner = torch.compiler.disable(fn)
 
     @functools.wraps(fn)
     def entry(*args, **kwargs):
-        # a plain frame around the disabled callable: `torch.compile(dftd3)` (test_dftd3.py:1228) unwraps a directly disabled
-        # function and would trace its body
-        for a in (args if args else kwargs.values()):
-            if isinstance(a, torch.Tensor):
-                # HIP launches go to the CURRENT device: tensors on another GPU of the process need the device guard the
-                # reference gets from Warp's per-device launch (`wp.launch(device=...)`)
-                if a.is_cuda and a.device.index != torch.cuda.current_device():
-                    with torch.cuda.device(a.device):
-                        return inner(*args, **kwargs)
-                break
+        # a plain frame around the disabled callable: `torch.compile(f)` unwraps a directly disabled function and would trace its body
+        dev = _on_device_of(args, kwargs)
+        if dev is not None:
+            with torch.cuda.device(dev):
+                return inner(*args, **kwargs)
+        return inner(*args, **kwargs)
+
+    return entry
+
+
+def hybrid(fn):
+    """Decorator of the public neighbour-list / DFT-D3 entry points.  Outside a trace the body runs as plain eager code and launches
+    through ctypes (no custom-op dispatch on a path whose kernels take tens of microseconds).  While TorchDynamo traces the caller
+    (`torch.compile`, also ``fullgraph=True`` under Inductor) the SAME body is traced: every launch in it branches on `tracing()` into the
+    registered, mutation-annotated ``torch.ops.nvalchemiops.*`` custom op (nvalchemiops/_ops.py), which is what the reference's thin
+    wrappers over ``torch.library.custom_op`` do (neighborlist/cell_list.py:725-736, 892-895, 1037-1192; dftd3.py:1792-1796) and what its
+    compiled MD-step example relies on (examples/neighborlist/04_neighbors_list_torch_compile_performance.py:323-346)."""
+    inner = torch.compiler.disable(fn)
+
+    @functools.wraps(fn)
+    def entry(*args, **kwargs):
+        if torch.compiler.is_compiling():
+            return fn(*args, **kwargs)
+        dev = _on_device_of(args, kwargs)
+        if dev is not None:
+            with torch.cuda.device(dev):
+                return inner(*args, **kwargs)
         return inner(*args, **kwargs)
 
     return entry
@@ -157,12 +184,10 @@ def traceable(fn):
     def entry(*args, **kwargs):
         if torch.compiler.is_compiling():
             return fn(*args, **kwargs)
-        for a in (args if args else kwargs.values()):
-            if isinstance(a, torch.Tensor):
-                if a.is_cuda and a.device.index != torch.cuda.current_device():
-                    with torch.cuda.device(a.device):
-                        return fn(*args, **kwargs)
-                break
+        dev = _on_device_of(args, kwargs)
+        if dev is not None:
+            with torch.cuda.device(dev):
+                return fn(*args, **kwargs)
         return fn(*args, **kwargs)
 
     return entry

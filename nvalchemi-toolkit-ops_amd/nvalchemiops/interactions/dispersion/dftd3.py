@@ -107,7 +107,7 @@ def _launch(positions, numbers, idx, shifts, nptr, max_neighbors, fill_value, ce
     C.check(rc, "mi_d3")
 
 
-@C.eager
+@C.hybrid
 def dftd3(positions: torch.Tensor, numbers: torch.Tensor, a1: float, a2: float, s8: float, k1: float = 16.0, k3: float = -4.0,
           s6: float = 1.0, s5_smoothing_on: float = 1e10, s5_smoothing_off: float = 1e10, fill_value: int | None = None,
           d3_params: D3Parameters | dict[str, torch.Tensor] | None = None, covalent_radii: torch.Tensor | None = None,
@@ -152,7 +152,10 @@ def dftd3(positions: torch.Tensor, numbers: torch.Tensor, a1: float, a2: float, 
             raise RuntimeError("DFT-D3 parameters must be explicitly provided. Either supply all individual parameters "
                                "(covalent_radii, r4r2, c6_reference, coord_num_ref), provide a D3Parameters instance, "
                                "or provide a d3_params dictionary. See the function docstring for details.")
-        src = d3_params.__dict__ if isinstance(d3_params, D3Parameters) else d3_params
+        if isinstance(d3_params, D3Parameters):
+            src = {"rcov": d3_params.rcov, "r4r2": d3_params.r4r2, "c6ab": d3_params.c6ab, "cn_ref": d3_params.cn_ref}
+        else:
+            src = d3_params
         covalent_radii = src["rcov"] if covalent_radii is None else covalent_radii
         r4r2 = src["r4r2"] if r4r2 is None else r4r2
         c6_reference = src["c6ab"] if c6_reference is None else c6_reference
@@ -171,11 +174,23 @@ def dftd3(positions: torch.Tensor, numbers: torch.Tensor, a1: float, a2: float, 
             num_systems = cell.size(0)
         else:
             num_systems = int(batch_idx.max().item()) + 1
-    C.require_device(positions, numbers, neighbor_matrix, neighbor_list, neighbor_ptr, batch_idx)
     energy = torch.empty(num_systems, **f32)  # zeroed inside mi_d3
     forces = torch.empty((n, 3), **f32)
     coord_num = torch.empty(n, **f32)
     virial = torch.empty((num_systems, 3, 3), **f32) if compute_virial else torch.zeros((0, 3, 3), **f32)
+    if C.tracing():
+        # torch.compile: the reference's own seam -- one mutating custom op per call (dftd3.py:1792-1796 / :2125-2128, called from
+        # :2806-2870); the conversions the eager path does below happen inside the op
+        if use_matrix:
+            torch.ops.nvalchemiops.dftd3_nm(positions, numbers, neighbor_matrix, covalent_radii, r4r2, c6_reference, coord_num_ref, a1, a2, s8,
+                                            energy, forces, coord_num, virial, k1, k3, s6, s5_smoothing_on, s5_smoothing_off, fill_value,
+                                            batch_idx, cell, neighbor_matrix_shifts, compute_virial, None)
+        else:
+            torch.ops.nvalchemiops.dftd3_nl(positions, numbers, neighbor_list[1], neighbor_ptr, covalent_radii, r4r2, c6_reference,
+                                            coord_num_ref, a1, a2, s8, energy, forces, coord_num, virial, k1, k3, s6, s5_smoothing_on,
+                                            s5_smoothing_off, batch_idx, cell, unit_shifts, compute_virial, None)
+        return (energy, forces, coord_num, virial) if compute_virial else (energy, forces, coord_num)
+    C.require_device(positions, numbers, neighbor_matrix, neighbor_list, neighbor_ptr, batch_idx)
     scalars = dict(a1=a1, a2=a2, s6=s6, s8=s8, k1=k1, k3=k3, s5_on=s5_smoothing_on, s5_off=s5_smoothing_off)
     tables = (covalent_radii, r4r2, c6_reference, coord_num_ref)
     if use_matrix:

@@ -65,6 +65,10 @@ def neighbor_matrix(pos, cell, pbc, batch_idx, cutoff, max_neighbors, fill_value
         flags |= C.NL_NO_SHIFTS
     if not pad:
         flags |= C.NL_NO_PAD
+    if C.tracing():  # torch.compile: the mutation-annotated custom op instead of the ctypes launch (nvalchemiops/_ops.py)
+        torch.ops.nvalchemiops.neighbor_search(pos, cell, pbc, batch_idx, cutoff, flags, fill_value, nm, nsh if want_shifts else None, num,
+                                               origin)
+        return
     run(pos, cell, pbc, batch_idx, cutoff, C.NL_MATRIX, flags, nm=nm, nsh=nsh if want_shifts else None, num=num,
         max_neighbors=max_neighbors, fill_value=fill_value, origin=origin)
 
@@ -76,8 +80,12 @@ def neighbor_matrix_dual(pos, cell, pbc, batch_idx, cutoff_short, cutoff_long, f
     if not want_shifts:
         flags |= C.NL_NO_SHIFTS
     n, nsys = pos.shape[0], cell.shape[0]
-    ws = workspace(n, nsys, pos.dtype, pos.device)
     (nm1, nsh1, num1), (nm2, nsh2, num2) = short, long_
+    if C.tracing():
+        torch.ops.nvalchemiops.neighbor_search_dual(pos, cell, pbc, batch_idx, cutoff_short, cutoff_long, flags, fill_value, nm1,
+                                                    nsh1 if want_shifts else None, num1, nm2, nsh2 if want_shifts else None, num2, origin)
+        return
+    ws = workspace(n, nsys, pos.dtype, pos.device)
     rc = C.lib().mi_nl_neighbors_dual(
         C.ptr(pos), n, C.ptr(cell), C.ptr(pbc), C.ptr(batch_idx), nsys, C.cdouble(cutoff_short), C.cdouble(cutoff_long), C.dtype_code(pos.dtype), flags,
         C.ptr(nm1), C.ptr(nsh1 if want_shifts else None), C.ptr(num1), int(nm1.shape[1]),
@@ -86,10 +94,13 @@ def neighbor_matrix_dual(pos, cell, pbc, batch_idx, cutoff_short, cutoff_long, f
     C.check(rc, "mi_nl_neighbors_dual")
 
 
+@torch.compiler.disable
 def neighbor_csr(pos, cell, pbc, batch_idx, cutoff, half_fill, *, naive=False, want_shifts=True, max_neighbors=None, origin=None):
     """Direct COO/CSR emission: count pass -> prefix sum -> fill pass (the padded matrix is never materialised).
 
-    Returns (neighbor_list[2,P], neighbor_ptr[N+1], shifts[P,3] | None, max_count)."""
+    Returns (neighbor_list[2,P], neighbor_ptr[N+1], shifts[P,3] | None, max_count).  The list length is read back from the device
+    (one host sync), so under `torch.compile` this is an eager island: the reference's COO conversion breaks the graph at its
+    `.item()` too (neighbor_utils.py:426)."""
     n = pos.shape[0]
     dev = pos.device
     flags = (C.NL_HALF_FILL if half_fill else 0) | (C.NL_NAIVE_EXPR if naive else 0)

@@ -31,11 +31,16 @@ def estimate_batch_cell_list_sizes(cell: torch.Tensor, pbc: torch.Tensor, cutoff
     return int(ncells.sum().item()), radius
 
 
-@C.eager
+@C.hybrid
 def batch_build_cell_list(positions, cutoff, cell, pbc, batch_idx, cells_per_dimension, neighbor_search_radius, atom_periodic_shifts,
                           atom_to_cell_mapping, atoms_per_cell_count, cell_atom_start_indices, cell_atom_list) -> None:
-    """Fill the caller's batch cache tensors in place (batch_cell_list.py:739-912, 1070-1136)."""
+    """Fill the caller's batch cache tensors in place (batch_cell_list.py:739-912, 1070-1136); traced as `nvalchemiops::batch_build_cell_list`."""
     if positions.shape[0] == 0 or cutoff <= 0:
+        return
+    if C.tracing():
+        torch.ops.nvalchemiops.batch_build_cell_list(positions, cutoff, cell, pbc, batch_idx, cells_per_dimension, neighbor_search_radius,
+                                                     atom_periodic_shifts, atom_to_cell_mapping, atoms_per_cell_count,
+                                                     cell_atom_start_indices, cell_atom_list)
         return
     C.require_device(positions, cell, pbc, batch_idx)
     pos, c, p = E.canon_geometry(positions, cell, pbc)
@@ -43,13 +48,19 @@ def batch_build_cell_list(positions, cutoff, cell, pbc, batch_idx, cells_per_dim
                  atoms_per_cell_count, cell_atom_start_indices, cell_atom_list)
 
 
-@C.eager
+@C.hybrid
 def batch_query_cell_list(positions, cell, pbc, cutoff, batch_idx, cells_per_dimension, neighbor_search_radius, atom_periodic_shifts,
                           atom_to_cell_mapping, atoms_per_cell_count, cell_atom_start_indices, cell_atom_list, neighbor_matrix,
                           neighbor_matrix_shifts, num_neighbors, half_fill: bool = False) -> None:
     """Batch query into pre-filled outputs; note the reference's argument order (cell, pbc BEFORE cutoff):
-    batch_cell_list.py:1139-1156."""
+    batch_cell_list.py:1139-1156.  Traced as `nvalchemiops::batch_query_cell_list`."""
     if positions.shape[0] == 0:
+        return
+    if C.tracing():
+        torch.ops.nvalchemiops.batch_query_cell_list(positions, cell, pbc, cutoff, batch_idx, cells_per_dimension, neighbor_search_radius,
+                                                     atom_periodic_shifts, atom_to_cell_mapping, atoms_per_cell_count,
+                                                     cell_atom_start_indices, cell_atom_list, neighbor_matrix, neighbor_matrix_shifts,
+                                                     num_neighbors, half_fill)
         return
     C.require_device(positions, cell, pbc, batch_idx, neighbor_matrix, neighbor_matrix_shifts, num_neighbors)
     pos, c, p = E.canon_geometry(positions, cell, pbc)
@@ -57,7 +68,7 @@ def batch_query_cell_list(positions, cell, pbc, cutoff, batch_idx, cells_per_dim
                       neighbor_matrix_shifts, num_neighbors, pad=False)
 
 
-@C.eager
+@C.hybrid
 def batch_cell_list(positions: torch.Tensor, cutoff: float, cell: torch.Tensor, pbc: torch.Tensor, batch_idx: torch.Tensor,
                     max_neighbors: int | None = None, half_fill: bool = False, fill_value: int | None = None,
                     return_neighbor_list: bool = False, neighbor_matrix: torch.Tensor | None = None,
@@ -70,7 +81,8 @@ def batch_cell_list(positions: torch.Tensor, cutoff: float, cell: torch.Tensor, 
     total_atoms = positions.shape[0]
     if total_atoms <= 0 or cutoff <= 0:
         return _empty_result(total_atoms, -1, return_neighbor_list, positions.device)  # -1: batch_cell_list.py:1369
-    C.require_device(positions, cell, pbc, batch_idx)
+    if not C.tracing():
+        C.require_device(positions, cell, pbc, batch_idx)
     if max_neighbors is None and neighbor_matrix is None:
         max_neighbors = estimate_max_neighbors(cutoff)
     if fill_value is None:
@@ -80,8 +92,7 @@ def batch_cell_list(positions: torch.Tensor, cutoff: float, cell: torch.Tensor, 
     cache = (cells_per_dimension, neighbor_search_radius, atom_periodic_shifts, atom_to_cell_mapping, atoms_per_cell_count,
              cell_atom_start_indices, cell_atom_list)
     if all(t is not None for t in cache):
-        _build_cache(pos, c, p, bi, cutoff, cells_per_dimension, atom_periodic_shifts, atom_to_cell_mapping, atoms_per_cell_count,
-                     cell_atom_start_indices, cell_atom_list)
+        batch_build_cell_list(pos, cutoff, c, p, bi, *cache)
     return _search(pos, c, p, bi, cutoff, max_neighbors, half_fill, fill_value, return_neighbor_list, neighbor_matrix,
                    neighbor_matrix_shifts, num_neighbors)
 

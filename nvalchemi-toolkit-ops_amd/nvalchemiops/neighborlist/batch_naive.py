@@ -14,7 +14,7 @@ from nvalchemiops.neighborlist.neighbor_utils import (_prepare_batch_idx_ptr, es
                                                       get_neighbor_list_from_neighbor_matrix)
 
 
-@C.eager
+@C.hybrid
 def batch_naive_neighbor_list(positions: torch.Tensor, cutoff: float, batch_idx: torch.Tensor | None = None,
                               batch_ptr: torch.Tensor | None = None, pbc: torch.Tensor | None = None, cell: torch.Tensor | None = None,
                               max_neighbors: int | None = None, half_fill: bool = False, fill_value: int | None = None,
@@ -45,7 +45,8 @@ def batch_naive_neighbor_list(positions: torch.Tensor, cutoff: float, batch_idx:
     if periodic and neighbor_matrix_shifts is None:
         neighbor_matrix_shifts = torch.empty((n, m, 3), **i32)
     if n > 0 and cutoff > 0:
-        C.require_device(positions, cell, pbc, batch_idx)
+        if not C.tracing():
+            C.require_device(positions, cell, pbc, batch_idx)
         bi = C.i32(batch_idx)
         origin = None
         if periodic:

@@ -9,7 +9,7 @@ from nvalchemiops.neighborlist.naive_dual_cutoff import _dual_cutoff
 from nvalchemiops.neighborlist.neighbor_utils import _prepare_batch_idx_ptr
 
 
-@C.eager
+@C.hybrid
 def batch_naive_neighbor_list_dual_cutoff(positions: torch.Tensor, cutoff1: float, cutoff2: float, batch_idx: torch.Tensor | None = None,
                                           batch_ptr: torch.Tensor | None = None, pbc: torch.Tensor | None = None,
                                           cell: torch.Tensor | None = None, max_neighbors1: int | None = None,

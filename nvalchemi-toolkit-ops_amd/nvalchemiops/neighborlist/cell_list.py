@@ -49,11 +49,16 @@ def _build_cache(pos, cell, pbc, batch_idx, cutoff, cpd, shifts, mapping, counts
     C.check(rc, "mi_nl_build_cell_cache")
 
 
-@C.eager
+@C.hybrid
 def build_cell_list(positions, cutoff, cell, pbc, cells_per_dimension, neighbor_search_radius, atom_periodic_shifts,
                     atom_to_cell_mapping, atoms_per_cell_count, cell_atom_start_indices, cell_atom_list) -> None:
-    """Fill the caller's cache tensors in place (cell_list.py:725-889, 1037-1105).  Capacity = atoms_per_cell_count.shape[0]."""
+    """Fill the caller's cache tensors in place (cell_list.py:725-889, 1037-1105).  Capacity = atoms_per_cell_count.shape[0].
+    Traced by `torch.compile` as ONE call of the mutating op `nvalchemiops::build_cell_list`."""
     if positions.shape[0] == 0 or cutoff <= 0:
+        return
+    if C.tracing():
+        torch.ops.nvalchemiops.build_cell_list(positions, cutoff, cell, pbc, cells_per_dimension, neighbor_search_radius, atom_periodic_shifts,
+                                               atom_to_cell_mapping, atoms_per_cell_count, cell_atom_start_indices, cell_atom_list)
         return
     C.require_device(positions, cell, pbc)
     pos, c, p = E.canon_geometry(positions, cell, pbc)
@@ -61,12 +66,18 @@ def build_cell_list(positions, cutoff, cell, pbc, cells_per_dimension, neighbor_
                  cell_atom_start_indices, cell_atom_list)
 
 
-@C.eager
+@C.hybrid
 def query_cell_list(positions, cutoff, cell, pbc, cells_per_dimension, neighbor_search_radius, atom_periodic_shifts,
                     atom_to_cell_mapping, atoms_per_cell_count, cell_atom_start_indices, cell_atom_list, neighbor_matrix,
                     neighbor_matrix_shifts, num_neighbors, half_fill: bool = False) -> None:
-    """Write neighbours of the current positions into the caller's pre-filled outputs (cell_list.py:892-1034, 1108-1192)."""
+    """Write neighbours of the current positions into the caller's pre-filled outputs (cell_list.py:892-1034, 1108-1192).
+    Traced by `torch.compile` as ONE call of the mutating op `nvalchemiops::query_cell_list`."""
     if positions.shape[0] == 0:
+        return
+    if C.tracing():
+        torch.ops.nvalchemiops.query_cell_list(positions, cutoff, cell, pbc, cells_per_dimension, neighbor_search_radius, atom_periodic_shifts,
+                                               atom_to_cell_mapping, atoms_per_cell_count, cell_atom_start_indices, cell_atom_list,
+                                               neighbor_matrix, neighbor_matrix_shifts, num_neighbors, half_fill)
         return
     C.require_device(positions, cell, pbc, neighbor_matrix, neighbor_matrix_shifts, num_neighbors)
     pos, c, p = E.canon_geometry(positions, cell, pbc)
@@ -104,7 +115,7 @@ def _search(pos, c, p, batch_idx, cutoff, max_neighbors, half_fill, fill_value, 
     return neighbor_matrix, num_neighbors, neighbor_matrix_shifts
 
 
-@C.eager
+@C.hybrid
 def cell_list(positions: torch.Tensor, cutoff: float, cell: torch.Tensor, pbc: torch.Tensor, max_neighbors: int | None = None,
               half_fill: bool = False, fill_value: int | None = None, return_neighbor_list: bool = False,
               neighbor_matrix: torch.Tensor | None = None, neighbor_matrix_shifts: torch.Tensor | None = None,
@@ -121,7 +132,8 @@ def cell_list(positions: torch.Tensor, cutoff: float, cell: torch.Tensor, pbc: t
         fill_value = total_atoms
     if total_atoms <= 0 or cutoff <= 0:
         return _empty_result(total_atoms, fill_value, return_neighbor_list, positions.device)
-    C.require_device(positions, cell, pbc)
+    if not C.tracing():
+        C.require_device(positions, cell, pbc)
     pos, c, p = E.canon_geometry(positions, cell, pbc)
     if max_neighbors is None and (neighbor_matrix is None or neighbor_matrix_shifts is None or num_neighbors is None):
         max_neighbors = estimate_max_neighbors(cutoff)

@@ -17,6 +17,8 @@ from nvalchemiops.neighborlist.neighbor_utils import estimate_max_neighbors, get
 def _bounding_cell(pos: torch.Tensor, batch_idx=None, n_sys: int = 1):
     """Non-periodic input has no cell: bin inside the per-system axis-aligned bounding box (pbc = F,F,F; shifts stay zero).
     One small HIP kernel pair (`mi_nl_bounding_cells`), no host sync.  Returns (cell[B,3,3], origin[B,3]) in the positions dtype."""
+    if C.tracing():
+        return torch.ops.nvalchemiops.bounding_cells(pos, batch_idx, n_sys)
     dev = pos.device
     cell = torch.empty((n_sys, 3, 3), dtype=pos.dtype, device=dev)
     origin = torch.empty((n_sys, 3), dtype=pos.dtype, device=dev)
@@ -27,7 +29,7 @@ def _bounding_cell(pos: torch.Tensor, batch_idx=None, n_sys: int = 1):
     return cell, origin
 
 
-@C.eager
+@C.hybrid
 def naive_neighbor_list(positions: torch.Tensor, cutoff: float, cell: torch.Tensor | None = None, pbc: torch.Tensor | None = None,
                         max_neighbors: int | None = None, half_fill: bool = False, fill_value: int | None = None,
                         return_neighbor_list: bool = False, neighbor_matrix: torch.Tensor | None = None,
@@ -64,7 +66,8 @@ def naive_neighbor_list(positions: torch.Tensor, cutoff: float, cell: torch.Tens
             out = (torch.zeros((2, 0), **i32), torch.zeros((n + 1,), **i32))
             return out + (torch.zeros((0, 3), **i32),) if periodic else out
         return (neighbor_matrix, num_neighbors, neighbor_matrix_shifts) if periodic else (neighbor_matrix, num_neighbors)
-    C.require_device(positions, cell, pbc)
+    if not C.tracing():
+        C.require_device(positions, cell, pbc)
     if periodic:
         pos, c, p = E.canon_geometry(positions, cell, pbc)
     else:

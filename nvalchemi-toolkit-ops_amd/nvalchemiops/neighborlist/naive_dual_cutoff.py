@@ -42,7 +42,8 @@ def _dual_cutoff(positions, cutoff1, cutoff2, batch_idx, n_sys, pbc, cell, max_n
         nsh1 = torch.empty((n, nm1.shape[1], 3), **i32) if nsh1 is None else nsh1
         nsh2 = torch.empty((n, nm2.shape[1], 3), **i32) if nsh2 is None else nsh2
     if n > 0 and cutoff2 > 0 and cutoff1 > 0:
-        C.require_device(positions, cell, pbc, batch_idx)
+        if not C.tracing():
+            C.require_device(positions, cell, pbc, batch_idx)
         bi = None if batch_idx is None else C.i32(batch_idx)
         origin = None
         if periodic:
@@ -79,7 +80,7 @@ def _dual_cutoff(positions, cutoff1, cutoff2, batch_idx, n_sys, pbc, cell, max_n
     return tuple(out)
 
 
-@C.eager
+@C.hybrid
 def naive_neighbor_list_dual_cutoff(positions: torch.Tensor, cutoff1: float, cutoff2: float, pbc: torch.Tensor | None = None,
                                     cell: torch.Tensor | None = None, max_neighbors1: int | None = None,
                                     max_neighbors2: int | None = None, half_fill: bool = False, fill_value: int | None = None,

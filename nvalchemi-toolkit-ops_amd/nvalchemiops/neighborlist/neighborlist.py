@@ -32,7 +32,8 @@ def _free_space_cell_list(positions, cutoff, batch_idx, half_fill, fill_value, r
         fill_value = n
     if n <= 0 or cutoff <= 0:
         return _empty_result(n, fill_value, return_neighbor_list, positions.device)
-    C.require_device(positions, batch_idx)
+    if not C.tracing():
+        C.require_device(positions, batch_idx)
     pos = E.canon_positions(positions)
     # the dispatcher already derived batch_ptr: its length gives the system count without another host sync
     n_sys = 1 if batch_idx is None else (n_systems if n_systems is not None else int(batch_idx.max().item()) + 1)
@@ -59,7 +60,7 @@ def _free_space_cell_list(positions, cutoff, batch_idx, half_fill, fill_value, r
     return nm, num, nsh
 
 
-@C.eager
+@C.hybrid
 def neighbor_list(positions: torch.Tensor, cutoff: float, cell: torch.Tensor | None = None, pbc: torch.Tensor | None = None,
                   batch_idx: torch.Tensor | None = None, batch_ptr: torch.Tensor | None = None, cutoff2: float | None = None,
                   half_fill: bool = False, fill_value: int | None = None, return_neighbor_list: bool = False,

@@ -11,10 +11,13 @@ from nvalchemiops import _capi as C
 from nvalchemiops.neighborlist import _engine as E
 
 
-@C.eager
+@C.hybrid
 def cell_list_needs_rebuild(current_positions: torch.Tensor, atom_to_cell_mapping: torch.Tensor, cells_per_dimension: torch.Tensor,
                             cell: torch.Tensor, pbc: torch.Tensor) -> torch.Tensor:
-    """True when any atom now bins into a different cell than `atom_to_cell_mapping` (from `build_cell_list`) says."""
+    """True when any atom now bins into a different cell than `atom_to_cell_mapping` (from `build_cell_list`) says.
+    Traced by `torch.compile` as the op `nvalchemiops::_cell_list_needs_rebuild` (rebuild_detection.py:258)."""
+    if C.tracing():
+        return torch.ops.nvalchemiops._cell_list_needs_rebuild(current_positions, atom_to_cell_mapping, cells_per_dimension, cell, pbc)
     dev = current_positions.device
     flag = torch.zeros(1, dtype=torch.bool, device=dev)
     n = current_positions.shape[0]
@@ -31,11 +34,13 @@ def cell_list_needs_rebuild(current_positions: torch.Tensor, atom_to_cell_mappin
     return flag
 
 
-@C.eager
+@C.hybrid
 def neighbor_list_needs_rebuild(reference_positions: torch.Tensor, current_positions: torch.Tensor,
                                 skin_distance_threshold: float) -> torch.Tensor:
     """True when any atom moved farther than `skin_distance_threshold` from its position at list-build time
-    (or when the two position arrays have different shapes)."""
+    (or when the two position arrays have different shapes).  Traced as `nvalchemiops::_neighbor_list_needs_rebuild` (:386)."""
+    if C.tracing():
+        return torch.ops.nvalchemiops._neighbor_list_needs_rebuild(reference_positions, current_positions, skin_distance_threshold)
     dev = current_positions.device
     if reference_positions.shape != current_positions.shape:
         return torch.tensor([True], device=dev, dtype=torch.bool)
