@@ -281,7 +281,13 @@ int mi_coulomb_forces_bwd(const double* positions, const double* charges, const 
  * :497-676, :763-959).  Orders 1-4 use the reference's piecewise polynomials; orders 5-6 use the true
  * cardinal B-spline recursion (the reference returns 0 there: SURVEY F2).  mesh is [n_systems,nx,ny,nz].
  * `batched` selects the reference's batch-kernel weight threshold (w > 1e-8 instead of w > 0 in spread).
+ *
+ * Every `order` argument below may carry MI_SPLINE_REFERENCE_ORDERS: orders 5 and 6 are then evaluated as the reference evaluates them --
+ * all weights ZERO (spline.py:150-193 implements orders 1-4 only: spread leaves a zero mesh, every gather returns zeros) and the
+ * structure-factor exponent capped at 4 (pme_kernels.py:213-225) -- instead of as true B-splines with exponent = order.  Orders 1-4 are
+ * the same either way.  The host API sets the bit per call (nvalchemiops.spline.reference_spline_orders); no library state is involved.
  */
+#define MI_SPLINE_REFERENCE_ORDERS 0x100
 /* Per-system cell geometry for the mesh ops in one launch: cell_inv_t = (cell^-1)^T, reciprocal_cell = 2 pi cell^-1, volume = |det|
  * (the torch.linalg.inv_ex / det calls of `_pme_reciprocal_space_impl`, pme.py:1382-1395).  All [n_systems,...] in `dtype`.       */
 int mi_cell_geometry(const void* cell, int n_systems, int dtype, void* cell_inv_t, void* reciprocal_cell, void* volume, void* stream);
@@ -337,8 +343,8 @@ int mi_spline_spread_grad(const void* positions, const void* vec /*[n_atoms,3]*/
  * mi_pme_convolve: the torch elementwise block of _pme_reciprocal_space_impl (pme.py:1418-1419,1455-1457):
  *   conv = spec / sf2 * G ; E_d = -i k_d conv, fused into one pass that writes 1 or 4 spectra.  k and k^2 are evaluated in registers
  *   from recip_cell unless the caller's precomputed arrays are passed (pme_reciprocal_space(k_vectors=, k_squared=), pme.py:1386-1392).
- *   `sf_exponent` in both: power of the sinc product before squaring -- the reference uses min(order, 4)
- *   (pme_kernels.py:213-225); this build passes `order` for its true order-5/6 splines.
+ *   exponent of the sinc product before squaring, in both: `order` (true order-5/6 splines), or min(order, 4) as in the reference
+ *   (pme_kernels.py:213-225) when `order` carries MI_SPLINE_REFERENCE_ORDERS.
  * mi_pme_gather_finish: spline_gather + pme_energy_corrections[_with_charge_grad] + gather_vec3 + "x2"
  *   (pme.py:1429-1477; pme_kernels.py:340-657) fused over the 4 planar real-space meshes.  add_energies / add_forces /
  *   add_charge_grads (NULL ok): the real-space part (mi_ewald_real outputs: float64 energies and charge gradients, forces in

@@ -860,6 +860,7 @@ extern "C" int mi_ewald_real_bwd(const void* positions, const void* charges, con
                                                                     (const T_*)grad_energies, (T_*)grad_positions, (T_*)grad_charges, sym);        \
   } while (0)
   unsigned long long* sym = (unsigned long long*)symmetry_scratch;
+  MI_REQUIRE(!sym || scratch_bytes >= sizeof(unsigned long long) * EW_SYM_WORDS, "symmetry scratch smaller than mi_ewald_symmetry_scratch_bytes()");
   if (sym) MI_HIP_CHECK(hipMemsetAsync(sym, 0, sizeof(unsigned long long) * EW_SYM_WORDS, st));
   // second part of the scratch (when the caller sized it with mi_ewald_real_bwd_scratch_bytes): slotted partials of the per-system sums
   double* part = nullptr;

@@ -554,7 +554,8 @@ __global__ __launch_bounds__(256) void pme_gather_finish_kernel(const T* __restr
                                          const T* __restrict__ volume, const T* __restrict__ qtot, int N, int nx, int ny, int nz,
                                          int with_field, T* __restrict__ energies, T* __restrict__ forces, T* __restrict__ cgrads,
                                          const double* __restrict__ add_e, const T* __restrict__ add_f, const double* __restrict__ add_cg,
-                                         const int* __restrict__ atom_order) {
+                                         const int* __restrict__ atom_order, T wscale) {
+  // wscale: 1, or 0 for the reference's all-zero weights of orders 5 / 6 (MI_SPLINE_REFERENCE_ORDERS): phi = field = 0, corrections only
   constexpr int order = ORDER;  // compile-time spline order: the weight evaluations and the stencil loops unroll
   // XCD-aware block -> atom-range mapping: workgroups are dispatched round-robin over the 8 XCDs (each with its own L2), so with the identity
   // mapping every XCD walks the whole system and each L2 pulls all four meshes (PMC: 0.40 GB of fetches for 0.07 GB of mesh on the headline
@@ -586,7 +587,7 @@ __global__ __launch_bounds__(256) void pme_gather_finish_kernel(const T* __restr
   const T* m0 = meshes + (size_t)s * C * plane;
   T phi = 0, ex = 0, ey = 0, ez = 0;
   if (tx < order) {
-    const T wx = weight_1d(st, 0, tx, order);
+    const T wx = weight_1d(st, 0, tx, order) * wscale;
     const int gx = wrap_idx(st.base[0] + tx + st.off0[0], nx);
 #pragma unroll
     for (int ty = 0; ty < order; ++ty) {
@@ -789,6 +790,20 @@ int spread_tiled(const T* pos, const T* values, const int* batch_idx, const T* c
     }                                                    \
   } while (0)
 
+// `order` arguments of the C ABI: low byte = spline order; MI_SPLINE_REFERENCE_ORDERS + order >= 5 selects the reference's evaluation of
+// those orders -- identically ZERO weights (spline.py:150-193 implements orders 1-4 only) and the structure-factor exponent capped at 4
+// (pme_kernels.py:213-225).  Without the flag orders 5 and 6 are the true cardinal B-splines.
+struct OrderArg { int order; bool ref_zero; int sf_exponent; };
+static inline OrderArg decode_order(int arg) {
+  OrderArg o;
+  o.order = arg & 0xff;
+  const bool ref = (arg & MI_SPLINE_REFERENCE_ORDERS) != 0;
+  o.ref_zero = ref && o.order >= 5;
+  o.sf_exponent = ref && o.order > 4 ? 4 : o.order;
+  return o;
+}
+static inline size_t dtype_bytes(int dtype) { return dtype == MI_F32 ? 4 : 8; }
+
 extern "C" {
 
 int mi_cell_geometry(const void* cell, int n_systems, int dtype, void* cell_inv_t, void* reciprocal_cell, void* volume, void* stream) {
@@ -820,10 +835,14 @@ int mi_pme_prepare(const void* cell, const void* charges, const int32_t* batch_i
 
 /* 1 when mi_spline_spread runs tile-owned for this mesh / order (every mesh point is then WRITTEN: the mesh needs no zero-fill) */
 int mi_spline_spread_is_tiled(int n_systems, int nx, int ny, int nz, int order) {
+  if (decode_order(order).ref_zero) return 0;  // reference-mode orders 5 / 6: the mesh is just zero-filled, no tile list
+  order &= 0xff;
   return (nx > 0 && ny > 0 && nz > 0 && n_systems >= 1 && order >= 1 && order <= MI_MAX_ORDER && sp_tiled_ok(nx, ny, nz, n_systems, order)) ? 1 : 0;
 }
 
 long long mi_spline_spread_order_offset(int n_atoms, int n_systems, int nx, int ny, int nz, int order) {
+  if (decode_order(order).ref_zero) return -1;
+  order &= 0xff;
   if (n_atoms <= 0 || n_systems < 1 || nx <= 0 || ny <= 0 || nz <= 0 || order < 1 || order > MI_MAX_ORDER) return -1;
   if (!sp_tiled_ok(nx, ny, nz, n_systems, order)) return -1;  // the atomic kernel does not sort
   return (long long)sp_layout(n_atoms, n_systems, nx, ny, nz).vals_out;
@@ -839,11 +858,17 @@ int mi_spline_spread(const void* positions, const void* values, const int32_t* b
                      int nx, int ny, int nz, int order, int batched, int dtype, void* mesh, void* workspace, size_t workspace_bytes,
                      void* stream) {
   MI_REQUIRE(dtype == MI_F32 || dtype == MI_F64, "dtype");
+  const OrderArg oa = decode_order(order);
+  order = oa.order;
   MI_REQUIRE(order >= 1 && order <= MI_MAX_ORDER, "spline order must be 1..6");
   MI_REQUIRE(nx > 0 && ny > 0 && nz > 0 && n_systems >= 1, "mesh dimensions");
   if (n_atoms <= 0) return MI_OK;
   MI_REQUIRE(positions && values && cell_inv_t && mesh, "null pointer");
   hipStream_t st = (hipStream_t)stream;
+  if (oa.ref_zero) {  // all weights are zero: nothing is spread
+    MI_HIP_CHECK(hipMemsetAsync(mesh, 0, (size_t)n_systems * nx * ny * nz * dtype_bytes(dtype), st));
+    return MI_OK;
+  }
   mi_timing_begin("spline_spread", stream);
   int rc = MI_OK;
   if (workspace && sp_tiled_ok(nx, ny, nz, n_systems, order) && workspace_bytes >= sp_layout(n_atoms, n_systems, nx, ny, nz).total) {
@@ -868,11 +893,14 @@ int mi_spline_spread(const void* positions, const void* values, const int32_t* b
 int mi_spline_gather(const void* positions, const void* mesh, const int32_t* batch_idx, const void* cell_inv_t, int n_atoms, int n_systems, int nx,
                      int ny, int nz, int order, int dtype, void* out, void* stream) {
   MI_REQUIRE(dtype == MI_F32 || dtype == MI_F64, "dtype");
+  const OrderArg oa = decode_order(order);
+  order = oa.order;
   MI_REQUIRE(order >= 1 && order <= MI_MAX_ORDER, "spline order must be 1..6");
   (void)n_systems;
   if (n_atoms <= 0) return MI_OK;
   MI_REQUIRE(positions && mesh && cell_inv_t && out, "null pointer");
   hipStream_t st = (hipStream_t)stream;
+  if (oa.ref_zero) { MI_HIP_CHECK(hipMemsetAsync(out, 0, (size_t)n_atoms * dtype_bytes(dtype), st)); return MI_OK; }
   mi_timing_begin("spline_gather", stream);
   MI_DISPATCH_T(dtype, (spline_gather_kernel<T_, 1><<<mi_blocks(n_atoms, 128), 128, 0, st>>>((const T_*)positions, nullptr, (const T_*)mesh, batch_idx,
                                                                                              (const T_*)cell_inv_t, n_atoms, nx, ny, nz, order,
@@ -885,11 +913,14 @@ int mi_spline_gather(const void* positions, const void* mesh, const int32_t* bat
 int mi_spline_gather_grad(const void* positions, const void* mesh, const int32_t* batch_idx, const void* cell_inv_t, int n_atoms, int n_systems,
                           int nx, int ny, int nz, int order, int dtype, void* out, void* stream) {
   MI_REQUIRE(dtype == MI_F32 || dtype == MI_F64, "dtype");
+  const OrderArg oa = decode_order(order);
+  order = oa.order;
   MI_REQUIRE(order >= 1 && order <= MI_MAX_ORDER, "spline order must be 1..6");
   (void)n_systems;
   if (n_atoms <= 0) return MI_OK;
   MI_REQUIRE(positions && mesh && cell_inv_t && out, "null pointer");
   hipStream_t st = (hipStream_t)stream;
+  if (oa.ref_zero) { MI_HIP_CHECK(hipMemsetAsync(out, 0, (size_t)n_atoms * 3 * dtype_bytes(dtype), st)); return MI_OK; }
   mi_timing_begin("spline_gather_grad", stream);
   MI_DISPATCH_ORDER(order, MI_DISPATCH_T(dtype, (spline_gather_grad_kernel<T_, O_><<<mi_blocks(n_atoms, 128), 128, 0, st>>>(
                                                     (const T_*)positions, (const T_*)mesh, batch_idx, (const T_*)cell_inv_t, n_atoms, nx, ny, nz, (T_*)out))));
@@ -901,11 +932,14 @@ int mi_spline_gather_grad(const void* positions, const void* mesh, const int32_t
 int mi_spline_gather_hess_dot(const void* positions, const void* mesh, const int32_t* batch_idx, const void* cell_inv_t, const void* vec,
                               int n_atoms, int n_systems, int nx, int ny, int nz, int order, int dtype, void* out, void* stream) {
   MI_REQUIRE(dtype == MI_F32 || dtype == MI_F64, "dtype");
+  const OrderArg oa = decode_order(order);
+  order = oa.order;
   MI_REQUIRE(order >= 1 && order <= MI_MAX_ORDER, "spline order must be 1..6");
   (void)n_systems;
   if (n_atoms <= 0) return MI_OK;
   MI_REQUIRE(positions && mesh && cell_inv_t && vec && out, "null pointer");
   hipStream_t st = (hipStream_t)stream;
+  if (oa.ref_zero) { MI_HIP_CHECK(hipMemsetAsync(out, 0, (size_t)n_atoms * 3 * dtype_bytes(dtype), st)); return MI_OK; }
   mi_timing_begin("spline_gather_hess_dot", stream);
   MI_DISPATCH_ORDER(order, MI_DISPATCH_T(dtype, (spline_gather_hess_dot_kernel<T_, O_><<<mi_blocks(n_atoms, 128), 128, 0, st>>>(
                                                     (const T_*)positions, (const T_*)mesh, batch_idx, (const T_*)cell_inv_t, (const T_*)vec, n_atoms, nx, ny, nz, (T_*)out))));
@@ -917,11 +951,13 @@ int mi_spline_gather_hess_dot(const void* positions, const void* mesh, const int
 int mi_spline_spread_grad(const void* positions, const void* vec, const int32_t* batch_idx, const void* cell_inv_t, int n_atoms, int n_systems,
                           int nx, int ny, int nz, int order, int dtype, void* mesh, void* stream) {
   MI_REQUIRE(dtype == MI_F32 || dtype == MI_F64, "dtype");
+  const OrderArg oa = decode_order(order);
+  order = oa.order;
   MI_REQUIRE(order >= 1 && order <= MI_MAX_ORDER, "spline order must be 1..6");
   MI_REQUIRE(n_systems >= 1 && mesh, "mesh");
   hipStream_t st = (hipStream_t)stream;
   MI_HIP_CHECK(hipMemsetAsync(mesh, 0, (size_t)n_systems * nx * ny * nz * (dtype == MI_F32 ? 4 : 8), st));
-  if (n_atoms <= 0) return MI_OK;
+  if (n_atoms <= 0 || oa.ref_zero) return MI_OK;
   MI_REQUIRE(positions && vec && cell_inv_t, "null pointer");
   mi_timing_begin("spline_spread_grad", stream);
   MI_DISPATCH_ORDER(order, MI_DISPATCH_T(dtype, (spline_spread_grad_kernel<T_, O_><<<mi_blocks(n_atoms, 128), 128, 0, st>>>(
@@ -934,11 +970,14 @@ int mi_spline_spread_grad(const void* positions, const void* vec, const int32_t*
 int mi_spline_gather_vec3(const void* positions, const void* charges, const void* mesh_vec3, const int32_t* batch_idx, const void* cell_inv_t,
                           int n_atoms, int n_systems, int nx, int ny, int nz, int order, int dtype, void* out, void* stream) {
   MI_REQUIRE(dtype == MI_F32 || dtype == MI_F64, "dtype");
+  const OrderArg oa = decode_order(order);
+  order = oa.order;
   MI_REQUIRE(order >= 1 && order <= MI_MAX_ORDER, "spline order must be 1..6");
   (void)n_systems;
   if (n_atoms <= 0) return MI_OK;
   MI_REQUIRE(positions && charges && mesh_vec3 && cell_inv_t && out, "null pointer");
   hipStream_t st = (hipStream_t)stream;
+  if (oa.ref_zero) { MI_HIP_CHECK(hipMemsetAsync(out, 0, (size_t)n_atoms * 3 * dtype_bytes(dtype), st)); return MI_OK; }
   MI_DISPATCH_T(dtype, (spline_gather_kernel<T_, 3><<<mi_blocks(n_atoms, 128), 128, 0, st>>>((const T_*)positions, (const T_*)charges,
                                                                                              (const T_*)mesh_vec3, batch_idx, (const T_*)cell_inv_t,
                                                                                              n_atoms, nx, ny, nz, order, (T_*)out)));
@@ -950,6 +989,7 @@ int mi_pme_green_sf(const void* k_squared, const void* alpha, const void* volume
                     void* green, void* sf_sq, void* stream) {
   MI_REQUIRE(dtype == MI_F32 || dtype == MI_F64, "dtype");
   MI_REQUIRE(k_squared && alpha && volume && green && sf_sq && n_systems >= 1, "null pointer");
+  order = decode_order(order).sf_exponent;
   const size_t tot = (size_t)nx * ny * (nz / 2 + 1) * n_systems;
   hipStream_t st = (hipStream_t)stream;
   MI_DISPATCH_T(dtype, (pme_green_sf_kernel<T_><<<mi_blocks((long long)tot, 256), 256, 0, st>>>((const T_*)k_squared, (const T_*)alpha,
@@ -963,6 +1003,7 @@ int mi_pme_convolve(const void* spec, const void* recip_cell, const void* alpha,
                     int with_field, int dtype, const void* k_vectors, const void* k_squared, int k_batched, void* out, void* stream) {
   MI_REQUIRE(dtype == MI_F32 || dtype == MI_F64, "dtype");
   MI_REQUIRE(spec && recip_cell && alpha && volume && out && n_systems >= 1, "null pointer");
+  order = decode_order(order).sf_exponent;
   const size_t tot = (size_t)nx * ny * (nz / 2 + 1) * n_systems;
   hipStream_t st = (hipStream_t)stream;
   mi_timing_begin("pme_convolve", stream);
@@ -980,6 +1021,8 @@ int mi_pme_gather_finish(const void* positions, const void* charges, const int32
                          int order, int with_field, int dtype, void* energies, void* forces, void* charge_grads, const double* add_energies,
                          const void* add_forces, const double* add_charge_grads, const int32_t* atom_order, void* stream) {
   MI_REQUIRE(dtype == MI_F32 || dtype == MI_F64, "dtype");
+  const OrderArg oa = decode_order(order);
+  order = oa.order;
   MI_REQUIRE(order >= 1 && order <= MI_MAX_ORDER, "spline order must be 1..6");
   (void)n_systems;
   if (n_atoms <= 0) return MI_OK;
@@ -989,7 +1032,7 @@ int mi_pme_gather_finish(const void* positions, const void* charges, const int32
   MI_DISPATCH_ORDER(order, MI_DISPATCH_T(dtype, (pme_gather_finish_kernel<T_, O_><<<mi_blocks((long long)n_atoms * PG_LANES, 256), 256, 0, st>>>(
                            (const T_*)positions, (const T_*)charges, batch_idx, (const T_*)cell_inv_t, (const T_*)meshes, (const T_*)alpha,
                            (const T_*)volume, (const T_*)total_charge, n_atoms, nx, ny, nz, with_field, (T_*)energies, (T_*)forces,
-                           (T_*)charge_grads, add_energies, (const T_*)add_forces, add_charge_grads, atom_order))));
+                           (T_*)charge_grads, add_energies, (const T_*)add_forces, add_charge_grads, atom_order, oa.ref_zero ? T_(0) : T_(1)))));
   mi_timing_end(stream);
   MI_LAUNCH_CHECK();
   return MI_OK;

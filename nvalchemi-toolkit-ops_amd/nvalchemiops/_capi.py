@@ -109,6 +109,16 @@ def require_device(*tensors: torch.Tensor | None) -> torch.device:
     return dev
 
 
+SPLINE_REFERENCE_ORDERS = 0x100  # MI_SPLINE_REFERENCE_ORDERS of include/nvalchemiops_hip.h
+_REFERENCE_SPLINE_ORDERS = os.environ.get("NVALCHEMIOPS_REFERENCE_SPLINE_ORDERS", "0") not in ("", "0")
+
+
+def spline_order_arg(order: int) -> int:
+    """The `order` argument of the C ABI: the spline order, plus the reference-compatibility bit while
+    `nvalchemiops.spline.reference_spline_orders` is active (orders 5 / 6 evaluated as the reference does: zero weights, exponent 4)."""
+    return int(order) | (SPLINE_REFERENCE_ORDERS if _REFERENCE_SPLINE_ORDERS else 0)
+
+
 def cdouble(x: float):
     return ctypes.c_double(float(x))
 

@@ -109,7 +109,7 @@ def _gather_vec3_impl(positions, charges, mesh, batch_idx, cit, order):
     bi = None if batch_idx is None else C.i32(batch_idx)
     nx, ny, nz = m.shape[-4:-1]
     out = torch.empty((pos.shape[0], 3), dtype=pos.dtype, device=pos.device)
-    rc = C.lib().mi_spline_gather_vec3(C.ptr(pos), C.ptr(q), C.ptr(m), C.ptr(bi), C.ptr(c), pos.shape[0], c.shape[0], nx, ny, nz, int(order),
+    rc = C.lib().mi_spline_gather_vec3(C.ptr(pos), C.ptr(q), C.ptr(m), C.ptr(bi), C.ptr(c), pos.shape[0], c.shape[0], nx, ny, nz, C.spline_order_arg(order),
                                        C.dtype_code(pos.dtype), C.ptr(out), C.stream_of(pos))
     C.check(rc, "mi_spline_gather_vec3")
     return out
@@ -424,7 +424,7 @@ def _hess_dot(positions: Tensor, mesh: Tensor, batch_idx: Optional[Tensor], cell
     bi = None if batch_idx is None else C.i32(batch_idx)
     nx, ny, nz = m.shape[-3:]
     out = torch.empty((pos.shape[0], 3), dtype=pos.dtype, device=pos.device)
-    rc = C.lib().mi_spline_gather_hess_dot(C.ptr(pos), C.ptr(m), C.ptr(bi), C.ptr(c), C.ptr(v), pos.shape[0], c.shape[0], nx, ny, nz, int(spline_order),
+    rc = C.lib().mi_spline_gather_hess_dot(C.ptr(pos), C.ptr(m), C.ptr(bi), C.ptr(c), C.ptr(v), pos.shape[0], c.shape[0], nx, ny, nz, C.spline_order_arg(spline_order),
                                            C.dtype_code(pos.dtype), C.ptr(out), C.stream_of(pos))
     C.check(rc, "mi_spline_gather_hess_dot")
     return out
@@ -438,7 +438,7 @@ def _spread_grad(positions: Tensor, vec: Tensor, batch_idx: Optional[Tensor], ce
     bi = None if batch_idx is None else C.i32(batch_idx)
     mesh = torch.empty((num_systems, mesh_nx, mesh_ny, mesh_nz), dtype=pos.dtype, device=pos.device)
     rc = C.lib().mi_spline_spread_grad(C.ptr(pos), C.ptr(v), C.ptr(bi), C.ptr(c), pos.shape[0], int(num_systems), mesh_nx, mesh_ny, mesh_nz,
-                                       int(spline_order), C.dtype_code(pos.dtype), C.ptr(mesh), C.stream_of(pos))
+                                       C.spline_order_arg(spline_order), C.dtype_code(pos.dtype), C.ptr(mesh), C.stream_of(pos))
     C.check(rc, "mi_spline_spread_grad")
     return mesh
 
@@ -528,7 +528,7 @@ def _green_sf_impl(k_squared, alpha, volume, nsys, nx, ny, nz, order):
     sf2 = torch.empty((nx, ny, nz // 2 + 1), dtype=dt, device=dev)
     al = alpha.detach().to(dt).reshape(-1).contiguous()
     vol = volume.detach().to(dt).reshape(-1).contiguous()
-    rc = C.lib().mi_pme_green_sf(C.ptr(k2), C.ptr(al), C.ptr(vol), int(nsys), nx, ny, nz, int(order), C.dtype_code(dt), C.ptr(green), C.ptr(sf2),
+    rc = C.lib().mi_pme_green_sf(C.ptr(k2), C.ptr(al), C.ptr(vol), int(nsys), nx, ny, nz, C.spline_order_arg(order), C.dtype_code(dt), C.ptr(green), C.ptr(sf2),
                                  C.stream_of(k2))
     C.check(rc, "mi_pme_green_sf")
     return green, sf2

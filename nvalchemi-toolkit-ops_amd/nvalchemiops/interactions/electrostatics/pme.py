@@ -9,8 +9,9 @@ Reciprocal-space pipeline on MI355X:
 The reference runs 1 forward + 4 separate inverse FFTs, ~10 elementwise torch passes over the spectrum and four
 N*order^3-thread atomic gathers for the same result (pme.py:1398-1477).
 
-Spline order: 1-4 match the reference bit-for-formula; 5-6 are true B-splines here (reference: all-zero weights,
-SURVEY F2) with the reference's structure-factor exponent min(order, 4) kept (F3).
+Spline order: 1-4 match the reference formula for formula.  Orders 5-6 are true cardinal B-splines here with structure-factor
+exponent = order; the reference evaluates their weights as zero and caps the exponent at 4 (spline.py:150-193,
+pme_kernels.py:213-225).  `nvalchemiops.spline.reference_spline_orders()` switches to the reference's evaluation.
 """
 from __future__ import annotations
 
@@ -79,7 +80,8 @@ def _miller_placeholders(device):
 @C.traceable
 def pme_green_structure_factor(k_squared: torch.Tensor, mesh_dimensions: tuple[int, int, int], alpha: torch.Tensor, cell: torch.Tensor,
                                spline_order: int = 4, batch_idx: torch.Tensor | None = None):
-    """G(k) = 2 pi exp(-k^2/4 alpha^2)/(V k^2) (0 at k = 0) and sf^2 = sinc-product^(2 min(order,4)) (pme.py:555-676).
+    """G(k) = 2 pi exp(-k^2/4 alpha^2)/(V k^2) (0 at k = 0) and sf^2 = sinc-product^(2 order) (pme.py:555-676; the reference's exponent
+    is 2 min(order, 4): identical for orders 1-4, selected for 5-6 by `nvalchemiops.spline.reference_spline_orders()`).
     Differentiable w.r.t. k_squared, alpha and the cell (through the volume): op `alchemiops::_[batch_]pme_green_structure_factor`."""
     C.require_device(k_squared, cell)
     nx, ny, nz = (int(v) for v in mesh_dimensions)
@@ -100,9 +102,9 @@ def pme_green_structure_factor(k_squared: torch.Tensor, mesh_dimensions: tuple[i
     al = alpha.detach().to(dt).reshape(-1).contiguous()
     green = torch.empty_like(k2)
     sf2 = torch.empty((nx, ny, nz // 2 + 1), dtype=dt, device=dev)
-    # exponent of the sinc product: min(order, 4) as in pme_kernels.py:213-225; the true order-5/6 splines of this
-    # build need `order` -- identical for every order the reference actually implements (1-4)
-    rc = C.lib().mi_pme_green_sf(C.ptr(k2), C.ptr(al), C.ptr(vol), nsys, nx, ny, nz, int(spline_order), C.dtype_code(dt), C.ptr(green),
+    # exponent of the sinc product: `order` (the true order-5/6 splines of this build need it), or min(order, 4) as in
+    # pme_kernels.py:213-225 under reference_spline_orders() -- identical for every order the reference implements (1-4)
+    rc = C.lib().mi_pme_green_sf(C.ptr(k2), C.ptr(al), C.ptr(vol), nsys, nx, ny, nz, C.spline_order_arg(spline_order), C.dtype_code(dt), C.ptr(green),
                                  C.ptr(sf2), C.stream_of(k2))
     C.check(rc, "mi_pme_green_sf")
     return green, sf2
@@ -200,7 +202,7 @@ def _reciprocal_fused(pos, q, cells, alpha, mesh_dimensions, spline_order, bi, c
             if (kv.dim() == 5 and kv.shape[0] == nsys and nsys > 1) != (k2.dim() == 4 and k2.shape[0] == nsys and nsys > 1):
                 raise ValueError("k_vectors and k_squared must both be shared by all systems or both carry the batch dimension")
     k_batched = int(k2 is not None and k2.dim() == 4 and k2.shape[0] == nsys and nsys > 1)
-    rc = C.lib().mi_pme_convolve(C.ptr(spec), C.ptr(recip), C.ptr(al), C.ptr(vol), nsys, nx, ny, nz, int(spline_order), int(compute_forces), code,
+    rc = C.lib().mi_pme_convolve(C.ptr(spec), C.ptr(recip), C.ptr(al), C.ptr(vol), nsys, nx, ny, nz, C.spline_order_arg(spline_order), int(compute_forces), code,
                                  C.ptr(kv), C.ptr(k2), k_batched, C.ptr(conv), st)
     C.check(rc, "mi_pme_convolve")
     real = torch.fft.irfftn(conv, norm="forward", s=(nx, ny, nz), dim=(2, 3, 4)).contiguous()  # unscaled inverse (pme.py:1422)
@@ -209,7 +211,7 @@ def _reciprocal_fused(pos, q, cells, alpha, mesh_dimensions, spline_order, bi, c
     cgrads = torch.empty(n, dtype=dt, device=dev) if compute_charge_gradients else None
     add_e, add_f, add_cg = add
     rc = C.lib().mi_pme_gather_finish(C.ptr(pos), C.ptr(q), C.ptr(bi), C.ptr(cit), C.ptr(real), C.ptr(al), C.ptr(vol), C.ptr(qtot), n, nsys, nx,
-                                      ny, nz, int(spline_order), int(compute_forces), code, C.ptr(energies), C.ptr(forces), C.ptr(cgrads),
+                                      ny, nz, C.spline_order_arg(spline_order), int(compute_forces), code, C.ptr(energies), C.ptr(forces), C.ptr(cgrads),
                                       C.ptr(add_e), C.ptr(add_f if compute_forces else None), C.ptr(add_cg if compute_charge_gradients else None),
                                       C.ptr(tile_order), st)
     C.check(rc, "mi_pme_gather_finish")

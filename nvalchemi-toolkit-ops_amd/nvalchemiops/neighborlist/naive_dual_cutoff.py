@@ -18,6 +18,18 @@ from nvalchemiops.neighborlist.naive import _bounding_cell
 from nvalchemiops.neighborlist.neighbor_utils import estimate_max_neighbors, get_neighbor_list_from_neighbor_matrix
 
 
+def _check_outputs(n, dev, nm, nsh, num, which):
+    """Caller-supplied output buffers go to the kernel as raw pointers (rows written at i * M + slot, whole rows padded): anything but
+    int32 / contiguous / the positions' device / N rows / matching widths would be an out-of-bounds device write, so it is an error here."""
+    for name, t, shape in ((f"neighbor_matrix{which}", nm, (n, nm.shape[1] if nm.dim() == 2 else -1)), (f"num_neighbors{which}", num, (n,)),
+                           (f"neighbor_matrix_shifts{which}", nsh, (n, nm.shape[1] if nm.dim() == 2 else -1, 3))):
+        if t is None:
+            continue
+        if t.dtype != torch.int32 or not t.is_contiguous() or t.device != dev or tuple(t.shape) != shape:
+            raise ValueError(f"{name} must be a contiguous int32 tensor of shape {shape} on {dev}, got {t.dtype} {tuple(t.shape)} on {t.device}"
+                             f"{'' if t.is_contiguous() else ' (non-contiguous)'}")
+
+
 def _dual_cutoff(positions, cutoff1, cutoff2, batch_idx, n_sys, pbc, cell, max_neighbors1, max_neighbors2, half_fill, fill_value,
                  return_neighbor_list, nm1, nm2, nsh1, nsh2, num1, num2):
     """Shared body of the single-system and the batched entry point (`batch_idx` None = one system)."""
@@ -41,6 +53,8 @@ def _dual_cutoff(positions, cutoff1, cutoff2, batch_idx, n_sys, pbc, cell, max_n
     if periodic:
         nsh1 = torch.empty((n, nm1.shape[1], 3), **i32) if nsh1 is None else nsh1
         nsh2 = torch.empty((n, nm2.shape[1], 3), **i32) if nsh2 is None else nsh2
+    _check_outputs(n, dev, nm1, nsh1 if periodic else None, num1, 1)
+    _check_outputs(n, dev, nm2, nsh2 if periodic else None, num2, 2)
     if n > 0 and cutoff2 > 0 and cutoff1 > 0:
         if not C.tracing():
             C.require_device(positions, cell, pbc, batch_idx)

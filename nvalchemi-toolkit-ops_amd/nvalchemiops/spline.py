@@ -2,13 +2,43 @@
 (`spline_spread` :2581, `spline_gather` :2640, `spline_gather_vec3` :2684; ops `alchemiops::_[batch_]spline_*` :1500-2107).
 
 HIP kernels in csrc/pme.hip behind `mi_spline_spread / _gather / _gather_vec3`.  Orders 1-4 reproduce the reference's
-piecewise polynomials; orders 5 and 6 are true cardinal B-splines (the reference evaluates them as zero: SURVEY F2).
+piecewise polynomials; orders 5 and 6 are true cardinal B-splines (the reference evaluates them as zero: SURVEY F2) unless
+`reference_spline_orders()` / `set_reference_spline_orders(True)` asks for the reference's evaluation.
 """
 from __future__ import annotations
 
 import torch
 
 from nvalchemiops import _capi as C
+
+
+def set_reference_spline_orders(enabled: bool) -> bool:
+    """Switch for the one deliberate numerical deviation of this build.
+
+    False (default): spline orders 5 and 6 are true cardinal B-splines and the PME structure factor uses exponent = order.
+    True: they are evaluated exactly as the reference evaluates them -- its weight function has cases for orders 1-4 only and returns 0
+    otherwise (spline.py:150-193), and its structure-factor exponent is min(order, 4) (pme_kernels.py:213-225) -- so an order-5 PME
+    call returns the reference's numbers (reciprocal potential identically zero, self / background corrections only).  Orders 1-4 are
+    unaffected.  Also settable at import time with NVALCHEMIOPS_REFERENCE_SPLINE_ORDERS=1.  Returns the previous setting.  The setting is
+    read at launch time (inside the custom ops as well), so it also applies to graphs compiled earlier."""
+    prev = C._REFERENCE_SPLINE_ORDERS
+    C._REFERENCE_SPLINE_ORDERS = bool(enabled)
+    return prev
+
+
+class reference_spline_orders:
+    """Context manager around `set_reference_spline_orders(True)`: ``with reference_spline_orders(): particle_mesh_ewald(..., spline_order=5)``."""
+
+    def __init__(self, enabled: bool = True):
+        self.enabled = enabled
+
+    def __enter__(self):
+        self.prev = set_reference_spline_orders(self.enabled)
+        return self
+
+    def __exit__(self, *exc):
+        set_reference_spline_orders(self.prev)
+        return False
 
 
 def _prep(positions: torch.Tensor, cell: torch.Tensor, batch_idx, cell_inv_t):
@@ -37,16 +67,16 @@ def _launch_spread(pos, vals, cit, bi, nsys, dims, order, batched, want_order=Fa
     nx, ny, nz = (int(v) for v in dims)
     n = pos.shape[0]
     # the tile-owned kernel writes every mesh point exactly once: no zero-fill pass then
-    tiled = n > 0 and bool(C.lib().mi_spline_spread_is_tiled(nsys, nx, ny, nz, int(order)))
+    tiled = n > 0 and bool(C.lib().mi_spline_spread_is_tiled(nsys, nx, ny, nz, C.spline_order_arg(order)))
     mesh = (torch.empty if tiled else torch.zeros)((nsys, nx, ny, nz), dtype=pos.dtype, device=pos.device)
     ws_bytes = int(C.lib().mi_spline_spread_workspace_bytes(n, nsys, nx, ny, nz))
     ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=pos.device)
-    rc = C.lib().mi_spline_spread(C.ptr(pos), C.ptr(vals), C.ptr(bi), C.ptr(cit), n, nsys, nx, ny, nz, int(order), int(batched),
+    rc = C.lib().mi_spline_spread(C.ptr(pos), C.ptr(vals), C.ptr(bi), C.ptr(cit), n, nsys, nx, ny, nz, C.spline_order_arg(order), int(batched),
                                   C.dtype_code(pos.dtype), C.ptr(mesh), C.ptr(ws), ctypes.c_size_t(ws_bytes), C.stream_of(pos))
     C.check(rc, "mi_spline_spread")
     if not want_order:
         return mesh
-    off = int(C.lib().mi_spline_spread_order_offset(n, nsys, nx, ny, nz, int(order))) if tiled else -1
+    off = int(C.lib().mi_spline_spread_order_offset(n, nsys, nx, ny, nz, C.spline_order_arg(order))) if tiled else -1
     return mesh, (ws[off:off + 4 * (n + 4)].view(torch.int32) if off >= 0 else None)
 
 
@@ -54,7 +84,7 @@ def _launch_gather(pos, mesh, cit, bi, order, grad=False):
     nx, ny, nz = mesh.shape[-3:]
     out = torch.empty((pos.shape[0], 3) if grad else (pos.shape[0],), dtype=pos.dtype, device=pos.device)
     fn = C.lib().mi_spline_gather_grad if grad else C.lib().mi_spline_gather
-    rc = fn(C.ptr(pos), C.ptr(mesh), C.ptr(bi), C.ptr(cit), pos.shape[0], cit.shape[0], nx, ny, nz, int(order), C.dtype_code(pos.dtype),
+    rc = fn(C.ptr(pos), C.ptr(mesh), C.ptr(bi), C.ptr(cit), pos.shape[0], cit.shape[0], nx, ny, nz, C.spline_order_arg(order), C.dtype_code(pos.dtype),
             C.ptr(out), C.stream_of(pos))
     C.check(rc, "mi_spline_gather_grad" if grad else "mi_spline_gather")
     return out
@@ -114,7 +144,7 @@ def spline_gather(positions: torch.Tensor, mesh: torch.Tensor, cell: torch.Tenso
     m = mesh.detach().to(pos.dtype).contiguous()
     nx, ny, nz = m.shape[-3:]
     out = torch.empty(pos.shape[0], dtype=pos.dtype, device=pos.device)
-    rc = C.lib().mi_spline_gather(C.ptr(pos), C.ptr(m), C.ptr(bi), C.ptr(cit), pos.shape[0], cit.shape[0], nx, ny, nz, int(spline_order),
+    rc = C.lib().mi_spline_gather(C.ptr(pos), C.ptr(m), C.ptr(bi), C.ptr(cit), pos.shape[0], cit.shape[0], nx, ny, nz, C.spline_order_arg(spline_order),
                                   C.dtype_code(pos.dtype), C.ptr(out), C.stream_of(pos))
     C.check(rc, "mi_spline_gather")
     return out
@@ -138,7 +168,7 @@ def spline_gather_vec3(positions: torch.Tensor, charges: torch.Tensor, mesh: tor
     q = charges.detach().to(pos.dtype).contiguous()
     out = torch.empty((pos.shape[0], 3), dtype=pos.dtype, device=pos.device)
     rc = C.lib().mi_spline_gather_vec3(C.ptr(pos), C.ptr(q), C.ptr(m), C.ptr(bi), C.ptr(cit), pos.shape[0], cit.shape[0], nx, ny, nz,
-                                       int(spline_order), C.dtype_code(pos.dtype), C.ptr(out), C.stream_of(pos))
+                                       C.spline_order_arg(spline_order), C.dtype_code(pos.dtype), C.ptr(out), C.stream_of(pos))
     C.check(rc, "mi_spline_gather_vec3")
     return out
 
@@ -227,4 +257,4 @@ def compute_bspline_deconvolution(mesh_dims: tuple[int, int, int], spline_order:
 
 
 __all__ = ["spline_spread", "spline_gather", "spline_gather_vec3", "spline_gather_gradient", "spline_spread_channels", "spline_gather_channels",
-           "compute_bspline_deconvolution", "compute_bspline_deconvolution_1d"]
+           "compute_bspline_deconvolution", "compute_bspline_deconvolution_1d", "set_reference_spline_orders", "reference_spline_orders"]

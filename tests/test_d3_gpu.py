@@ -102,6 +102,41 @@ def test_small_molecules_and_edge_cases():
     _check(out, ref)
 
 
+def test_small_cases_against_the_reference_order_oracle_at_the_reference_tolerance():
+    """The small D3 cases against the oracle in the REFERENCE's own accumulation order (default mode, pinned to the golden Ne2 / HCl
+    vectors by tests/test_oracle_golden.py) at the reference's own CPU-vs-GPU bar, rtol = atol = 1e-6 (test_dftd3.py:477-489), with no
+    widening for forces or the virial: molecules, a padding atom, the S5 window, and a 180-atom triclinic periodic box."""
+    from nvalchemiops.interactions.dispersion import dftd3
+    from nvalchemiops.neighborlist import cell_list
+
+    t, p = _params()
+
+    def check(out, ref, names=("energy", "forces", "coord_num", "virial")):
+        for got, want, what in zip(out, ref, names):
+            _close(got, want, 1e-6, 1e-6, what + " vs reference order")
+
+    nm5 = np.full((5, 10), 5, np.int32)
+    nm5[0, :4] = [1, 2, 3, 4]
+    nm5[1:, 0] = 0
+    cases = [(np.array([[0, 0, 0], [1.4, 0, 0]], np.float32), [1, 1], np.array([[1, 2, 2, 2, 2], [0, 2, 2, 2, 2]], np.int32), {}),
+             (np.array([[0, 0, 0], [5.8, 0, 0]], np.float32), [10, 10], np.array([[1, 2, 2, 2, 2], [0, 2, 2, 2, 2]], np.int32), {}),
+             (np.array([[0, 0, 0], [2, 0, 0], [-2, 0, 0], [0, 2, 0], [0, -2, 0]], np.float32), [6, 1, 1, 1, 1], nm5, {}),
+             (np.array([[0, 0, 0], [2, 0, 0], [-2, 0, 0], [0, 2, 0], [0, -2, 0]], np.float32), [6, 1, 1, 1, 1], nm5, dict(on=1.0, off=3.5)),
+             (np.array([[0, 0, 0], [1.5, 0, 0], [3.0, 0.2, 0]], np.float32), [8, 0, 1], np.array([[1, 2, 3], [0, 2, 3], [0, 1, 3]], np.int32), {})]
+    for pos, z, nm, s5 in cases:
+        z = np.array(z, np.int32)
+        okw = dict(s5_on=s5["on"], s5_off=s5["off"]) if s5 else {}
+        pkw = dict(s5_smoothing_on=s5["on"], s5_smoothing_off=s5["off"]) if s5 else {}
+        ref = O.dftd3(pos, z, t, neighbor_matrix=nm, **okw, **FP)
+        check(dftd3(_t(pos), _t(z), d3_params=p, neighbor_matrix=_t(nm), **pkw, **FP), ref)
+    pos, cell = S.random_box(180, 26.0, seed=3, dtype=np.float32, triclinic=True)
+    z = np.random.default_rng(1).choice(np.array([1, 6, 8, 17], np.int32), 180)
+    nm, num, sh = cell_list(_t(pos), 14.0, _t(cell), torch.tensor([True] * 3, device=DEV), max_neighbors=320)
+    ref = O.dftd3(pos, z, t, neighbor_matrix=nm.cpu().numpy(), neighbor_matrix_shifts=sh.cpu().numpy(), cell=cell, compute_virial=True, **FP)
+    out = dftd3(_t(pos), _t(z), d3_params=p, neighbor_matrix=nm, neighbor_matrix_shifts=sh, cell=_t(cell)[None], compute_virial=True, **FP)
+    check(out, ref)
+
+
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
 @pytest.mark.parametrize("fmt", ["matrix", "csr"])
 def test_periodic_with_virial(dtype, fmt):
@@ -382,25 +417,26 @@ def test_spatial_order_with_the_packed_list_fallback(monkeypatch):
 
 def test_headline_100k_periodic_full_size_vs_oracle():
     """The D3 leg of the headline workload at its FULL size (100k-atom periodic box, rc = 40 Bohr, padded matrix M = 2560,
-    E + F + virial, fp32; 235 M directed pairs) against the oracle on the device-built list (~25 s of oracle time).
+    E + F + virial, fp32; 235 M directed pairs): the product on the list the PRODUCT built, the oracle on the list the ORACLE built
+    (tests/_headline.py) -- a pair missing from or duplicated in the device list cannot cancel.
 
     The reference adds the per-atom energies / virials into the fp32 per-system outputs one atomic at a time (dftd3.py:1031-1040):
     over 100k atoms that alone is a random walk of ~1e-5 relative (and order-dependent), so the oracle is asked for PER-ATOM values
     (every atom its own "system") and summed in float64 here; this build reduces in float64 and rounds once."""
     from nvalchemiops.interactions.dispersion import dftd3
     from nvalchemiops.neighborlist import cell_list
+    from tests import _headline as H
 
     t, p = _params(17)
-    n = 100000
-    pos, cell, _, numbers = S.fcc_box(n, dtype=np.float32)
-    bohr = 1.8897261
-    pos, cell = (pos * bohr).astype(np.float32), (cell * bohr).astype(np.float32)
-    z = np.where(numbers == 6, 6, 8).astype(np.int32)
+    n = H.N
+    pos, cell, z = H.system()
+    onm, onum, osh = H.oracle_list()
     tp, tc, tz = _t(pos), _t(cell), _t(z)
-    nm, num, sh = cell_list(tp, 40.0, tc, torch.tensor([True] * 3, device=DEV), max_neighbors=2560)
-    assert int(num.max()) <= 2560 and int(num.sum()) > 2.3e8
+    nm, num, sh = cell_list(tp, H.CUTOFF, tc, torch.tensor([True] * 3, device=DEV), max_neighbors=H.M)
+    assert int(num.max()) <= H.M and int(num.sum()) > 2.3e8
     e, f, cn, vir = dftd3(tp, tz, d3_params=p, neighbor_matrix=nm, neighbor_matrix_shifts=sh, cell=tc[None], compute_virial=True, **FP)
-    re, rf, rcn, rvir = _wide(pos, z, t, neighbor_matrix=nm.cpu().numpy(), neighbor_matrix_shifts=sh.cpu().numpy(),
+    del nm, sh
+    re, rf, rcn, rvir = _wide(pos, z, t, neighbor_matrix=onm, neighbor_matrix_shifts=osh,
                                 cell=np.broadcast_to(cell, (n, 3, 3)).copy(), batch_idx=np.arange(n, dtype=np.int32), num_systems=n,
                                 compute_virial=True, **FP)
     e_ref, v_ref = re.astype(np.float64).sum(), rvir.astype(np.float64).sum(0)

@@ -22,6 +22,17 @@ def test_neighbor_list_errors():
             fn(*args, cell=cell, **kw)
         with pytest.raises(ValueError, match="If pbc is provided, cell must also be provided"):
             fn(*args, pbc=pbc, **kw)
+    # caller-supplied dual-cutoff outputs reach the kernel as raw pointers: wrong dtype / row count / width / layout is an error, not an
+    # out-of-bounds device write
+    i32 = dict(dtype=torch.int32)
+    good = dict(neighbor_matrix1=torch.zeros((50, 8), **i32), neighbor_matrix2=torch.zeros((50, 16), **i32), num_neighbors1=torch.zeros(50, **i32),
+                num_neighbors2=torch.zeros(50, **i32), neighbor_matrix_shifts1=torch.zeros((50, 8, 3), **i32),
+                neighbor_matrix_shifts2=torch.zeros((50, 16, 3), **i32))
+    for name, bad in (("neighbor_matrix1", torch.zeros((50, 8), dtype=torch.int64)), ("neighbor_matrix2", torch.zeros((49, 16), **i32)),
+                      ("num_neighbors1", torch.zeros(51, **i32)), ("neighbor_matrix_shifts2", torch.zeros((50, 8, 3), **i32)),
+                      ("neighbor_matrix_shifts1", torch.zeros((50, 3, 8), **i32).transpose(1, 2))):
+        with pytest.raises(ValueError, match=name + " must be a contiguous int32 tensor"):
+            naive_neighbor_list_dual_cutoff(pos, 2.0, 3.0, pbc=pbc, cell=cell, **{**good, name: bad})
     with pytest.raises(ValueError, match="Invalid method"):
         neighbor_list(pos, 2.0, method="invalid_method")
     with pytest.raises(TypeError):

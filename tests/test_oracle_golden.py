@@ -83,6 +83,49 @@ def test_d3_hcl_dimer_golden():
     np.testing.assert_allclose(f, ref_f, rtol=5e-6, atol=1e-9)
 
 
+def test_d3_wide_sum_mode_reproduces_the_reference_golden_vectors():
+    """The checker the GPU suite uses most -- `O.d3_wide_sums()`, the reference's pair arithmetic with its fp32 accumulations carried in
+    double -- pinned to the SAME reference-held vectors as the default mode (conftest.py:641-730), at the same bars."""
+    t = O.d3_test_tables(17)
+    with O.d3_wide_sums():
+        pos = np.array([[0, 0, 0], [5.8, 0, 0]], np.float32)
+        nm = np.array([[1, 2, 2, 2, 2], [0, 2, 2, 2, 2]], np.int32)
+        e, f, cn = O.dftd3(pos, np.array([10, 10], np.int32), t, neighbor_matrix=nm, fill_value=2, **FP)
+        np.testing.assert_allclose(e, [-1.4161492698e-02], rtol=2e-6)
+        np.testing.assert_allclose(cn, [4.4183229329e-04] * 2, rtol=2e-6)
+        np.testing.assert_allclose(f, [[3.2497653738e-03, 0, 0], [-3.2497653738e-03, 0, 0]], rtol=2e-6, atol=1e-9)
+        pos = np.array([[0, 0, 0], [2.4, 0, 0], [0, 7, 0], [2.4, 7, 0]], np.float32)
+        nm = np.full((4, 5), 4, np.int32)
+        nm[0, :3], nm[1, :3], nm[2, :3], nm[3, :3] = [1, 2, 3], [0, 2, 3], [0, 1, 3], [0, 1, 2]
+        e, f, cn = O.dftd3(pos, np.array([1, 17, 1, 17], np.int32), t, neighbor_matrix=nm, fill_value=4, **FP)
+        np.testing.assert_allclose(e, [-2.2127663717e-02], rtol=2e-6)
+        np.testing.assert_allclose(cn, [5.0002193451e-01, 5.0044161081e-01] * 2, rtol=2e-6)
+        ref_f = [[6.2320637517e-03, 8.8818743825e-04, 0], [-6.2320632860e-03, 1.9026985392e-03, 0],
+                 [6.2320632860e-03, -8.8818743825e-04, 0], [-6.2320632860e-03, -1.9026985392e-03, 0]]
+        np.testing.assert_allclose(f, ref_f, rtol=5e-6, atol=1e-9)
+
+
+@pytest.mark.parametrize("n,box,rc,seed,triclinic", [(60, 12.0, 8.0, 3, False), (180, 26.0, 14.0, 3, True), (300, 22.0, 10.0, 35, False)])
+def test_d3_wide_sums_stay_within_a_stated_bound_of_the_reference_order(n, box, rc, seed, triclinic):
+    """|wide-sum oracle - reference-order oracle| on the periodic sweep systems of the GPU suite: the two modes differ only by the
+    reference's own fp32 summation-order noise.  Stated bound: 4 x (1e-6 + 1e-6 |x|) element-wise on E, F, CN and the virial, i.e.
+    four times the reference's CPU-vs-GPU tolerance (test_dftd3.py:477-489); measured maxima are 0.16 / 1.6 / 0.6 / 2.8 of that
+    tolerance.  So a kernel held to 1e-6 of the wide-sum mode is within 5e-6 of what the reference's own arithmetic order gives."""
+    pos, cell = S.random_box(n, box, seed=seed, dtype=np.float32, triclinic=triclinic)
+    z = np.random.default_rng(1).choice(np.array([1, 6, 8, 17], np.int32), n)
+    t = O.d3_test_tables(17)
+    nm, num, sh = O.cell_list(pos, rc, cell, [True] * 3, max_neighbors=400)
+    assert int(num.max()) <= 400
+    kw = dict(neighbor_matrix=nm, neighbor_matrix_shifts=sh, cell=cell, compute_virial=True, **FP)
+    ref_order = O.dftd3(pos, z, t, **kw)
+    with O.d3_wide_sums():
+        wide = O.dftd3(pos, z, t, **kw)
+    for a, b, what in zip(ref_order, wide, ("energy", "forces", "coord_num", "virial")):
+        err, bound = np.abs(a - b), 4.0 * (1e-6 + 1e-6 * np.abs(a))
+        assert (err <= bound).all(), f"{what}: {err.max():.3e} vs {bound.flat[err.argmax()]:.3e}"
+        assert what != "forces" or err.max() > 0.0, "the two modes must actually differ somewhere"
+
+
 def test_d3_matrix_equals_csr_and_virial_symmetric():
     pos, cell = S.random_box(60, 12.0, seed=3, dtype=np.float32)
     numbers = np.random.default_rng(1).choice(np.array([1, 6, 8], np.int32), 60)

@@ -376,6 +376,73 @@ def test_headline_pme_order5_100k_vs_extended_oracle():
     assert float((e.sum() - e6.sum()).abs()) < float((e4.sum() - e6.sum()).abs())
 
 
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("order", [5, 6])
+def test_reference_spline_orders_switch_vs_default_oracle(dtype, order):
+    """`reference_spline_orders()`: orders 5 / 6 evaluated as the REFERENCE evaluates them -- weights identically zero
+    (spline.py:150-193 has cases for orders 1-4 only), structure-factor exponent min(order, 4) (pme_kernels.py:213-225) -- against the
+    oracle's DEFAULT mode, which restates exactly that.  Spread, gathers, Green function / structure factor, reciprocal part and the
+    full PME (energies, forces, charge gradients; single + batch; the fused path and the custom-op composition)."""
+    from nvalchemiops.interactions.electrostatics import particle_mesh_ewald, pme_reciprocal_space
+    from nvalchemiops.interactions.electrostatics.k_vectors import generate_k_vectors_pme
+    from nvalchemiops.interactions.electrostatics.pme import pme_green_structure_factor
+    from nvalchemiops.neighborlist import cell_list
+    from nvalchemiops.spline import reference_spline_orders, spline_gather, spline_gather_vec3, spline_spread
+
+    pbc = torch.tensor([True] * 3, device=DEV)
+    pos, cell, q = _system(300, dtype, triclinic=True, seed=3, box=14.0)
+    dims = (16, 20, 24)
+    tp, tq, tc = _t(pos), _t(q), _t(cell)
+    field = np.random.default_rng(1).normal(size=dims).astype(dtype)
+    vec = np.random.default_rng(2).normal(size=dims + (3,)).astype(dtype)
+    nm, num, sh = cell_list(tp, 6.0, tc, pbc, max_neighbors=160)
+    kw = dict(alpha=0.4, mesh_dimensions=dims, spline_order=order, neighbor_matrix=nm, neighbor_matrix_shifts=sh, compute_forces=True,
+              compute_charge_gradients=True)
+    true_e = particle_mesh_ewald(tp, tq, tc, **kw)[0]
+    with reference_spline_orders():
+        mesh = spline_spread(tp, tq, tc, dims, order)
+        g = spline_gather(tp, _t(field), tc, order)
+        g3 = spline_gather_vec3(tp, tq, _t(vec), tc, order)
+        kv, k2 = generate_k_vectors_pme(tc, dims)
+        green, sf2 = pme_green_structure_factor(k2, dims, torch.tensor([0.4], dtype=tp.dtype, device=DEV), tc, spline_order=order)
+        e, f, cg = particle_mesh_ewald(tp, tq, tc, **kw)
+        er, fr = pme_reciprocal_space(tp, tq, tc, alpha=0.4, mesh_dimensions=dims, spline_order=order, compute_forces=True)
+        tp_g = tp.clone().requires_grad_(True)  # an input that requires grad takes the custom-op composition: same numbers
+        eg, fg, cgg = particle_mesh_ewald(tp_g, tq, tc, **kw)
+        e4 = particle_mesh_ewald(tp, tq, tc, **dict(kw, spline_order=4))[0]
+    assert float(mesh.abs().max()) == 0.0 and float(g.abs().max()) == 0.0 and float(g3.abs().max()) == 0.0 and float(fr.abs().max()) == 0.0
+    ref_mesh = O.spline_spread(pos, q, cell, dims, order)  # the oracle's default mode IS the reference's evaluation
+    assert np.abs(ref_mesh).max() == 0.0
+    ref_green, ref_sf2 = O.pme_green_structure_factor(k2.cpu().numpy(), dims, np.array([0.4]), cell, order)
+    _close(green, ref_green.reshape(green.shape), dtype, "green")
+    _close(sf2, ref_sf2.reshape(sf2.shape), dtype, "sf^2 with the exponent capped at 4")
+    ref = O.particle_mesh_ewald(pos, q, cell, 0.4, dims, order, neighbor_matrix=nm.cpu().numpy(), neighbor_matrix_shifts=sh.cpu().numpy(),
+                                mask_value=len(pos), compute_forces=True, compute_charge_gradients=True)
+    for got, want, what in ((e, ref[0], "energies"), (f, ref[1], "forces"), (cg, ref[2], "charge gradients"), (eg, ref[0], "energies (ops)"),
+                            (fg, ref[1], "forces (ops)"), (cgg, ref[2], "charge gradients (ops)")):
+        _close(got.detach(), want, dtype, what)
+    ref_r = O.pme_reciprocal_space(pos, q, cell, 0.4, dims, order)
+    _close(er, ref_r, dtype, "reciprocal part = the corrections alone")
+    # the switch changes orders 5 / 6 only, and only while it is on
+    assert torch.equal(e4, particle_mesh_ewald(tp, tq, tc, **dict(kw, spline_order=4))[0])
+    assert torch.equal(true_e, particle_mesh_ewald(tp, tq, tc, **kw)[0]) and float((true_e - e).abs().max()) > 1e-3
+    # batch of two systems through the batch kernels
+    p2, c2, q2 = _system(200, dtype, seed=4, box=12.0)
+    bp, bq, bc = _t(np.concatenate([pos, p2])), _t(np.concatenate([q, q2])), _t(np.stack([cell, c2]))
+    bi = torch.tensor([0] * 300 + [1] * 200, dtype=torch.int32, device=DEV)
+    from nvalchemiops.neighborlist import batch_cell_list
+
+    bnm, bnum, bsh = batch_cell_list(bp, 6.0, bc, torch.ones((2, 3), dtype=torch.bool, device=DEV), bi, max_neighbors=160)
+    with reference_spline_orders():
+        be, bf = particle_mesh_ewald(bp, bq, bc, alpha=0.4, mesh_dimensions=dims, spline_order=order, batch_idx=bi, neighbor_matrix=bnm,
+                                     neighbor_matrix_shifts=bsh, compute_forces=True)
+    bref = O.particle_mesh_ewald(np.concatenate([pos, p2]), np.concatenate([q, q2]), np.stack([cell, c2]), 0.4, dims, order,
+                                 batch_idx=bi.cpu().numpy(), neighbor_matrix=bnm.cpu().numpy(), neighbor_matrix_shifts=bsh.cpu().numpy(),
+                                 mask_value=500, compute_forces=True)
+    _close(be, bref[0], dtype, "batch energies")
+    _close(bf, bref[1], dtype, "batch forces")
+
+
 # ---- explicit-k Ewald (SURVEY 8f N3) ---------------------------------------------------------------------------------------
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
 @pytest.mark.parametrize("triclinic", [False, True])
