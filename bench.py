@@ -31,7 +31,8 @@ Prints ONE JSON line (rank 0) with the driver's fields plus
   `roofline`     the entry of the dominant kernel (largest isolated time)
   `cpu_baseline` the CPU oracle on the host: 1 thread on a bounded sample box (same density / cutoffs / spline order), and the
                  all-core OpenMP build on the FULL 100k-atom step (`--cpu-full-size` adds the 1-thread full-size leg, ~1 min)
-Other workloads: `--workload c5` (BASELINE config 5 shard) and `--workload ref-nlist|ref-d3|ref-pme` (the reference's own published
+Other workloads: `--workload c2|c3|c4` (BASELINE.json's single-GPU configurations, same JSON shape: `config.workload`, `roofline` of that
+configuration's dominant kernel, `cpu_baseline`), `--workload c5` (BASELINE config 5 shard) and `--workload ref-nlist|ref-d3|ref-pme` (the reference's own published
 benchmark configurations, BASELINE.md, with its warm-up / median protocol).
 """
 from __future__ import annotations
@@ -403,28 +404,39 @@ def kernel_table(kernels, isolated, n, pairs_d3, workload):
     return rows
 
 
+def _in_step_ms(r):
+    return r["avg_ms_timed_region"]
+
+
 def roofline_of(rows):
-    """The contract's `roofline` object for the dominant kernel = the largest isolated (else timed) median."""
+    """The contract's `roofline` object for the dominant kernel = the largest average launch duration INSIDE the timed region.
+    `achieved` / `frac` use that in-step average (algorithmic bytes per launch / average launch duration over the timed region, HIP events
+    on the kernel's own stream); `achieved_isolated` / `frac_isolated` are the same bytes over the isolated median of the untimed serial
+    pass, the figure that is comparable across runs and with profiles/*_serial.csv."""
     if not rows:
         return None
-    name, r = max(rows.items(), key=lambda kv: kv[1]["isolated_median_ms"] or kv[1]["median_ms_timed_region"])
-    t_ms = r["isolated_median_ms"] or r["median_ms_timed_region"]
-    if r["bound"] == "valu" and r.get("valu_Ginstr_per_s"):
-        out = {"bound": "valu", "kernel": name, "achieved": r["valu_Ginstr_per_s"], "peak": VALU_PEAK_GINSTR, "unit": "G wave-instr/s",
-               "frac": r["frac_of_valu_issue_peak"], "hbm_frac": r.get("frac_of_hbm_peak")}
+    name, r = max(rows.items(), key=lambda kv: _in_step_ms(kv[1]))
+    t_ms, iso_ms = _in_step_ms(r), r["isolated_median_ms"]
+    if r["bound"] == "valu" and r.get("valu_wave_insts"):
+        rate = r["valu_wave_insts"] / (t_ms * 1e-3) / 1e9
+        out = {"bound": "valu", "kernel": name, "achieved": rate, "peak": VALU_PEAK_GINSTR, "unit": "G wave-instr/s", "frac": rate / VALU_PEAK_GINSTR,
+               "achieved_isolated": r.get("valu_Ginstr_per_s"), "frac_isolated": r.get("frac_of_valu_issue_peak"),
+               "hbm_frac": (r["algorithmic_bytes"] / (t_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if r.get("algorithmic_bytes") else None}
     else:
-        out = {"bound": "hbm", "kernel": name, "achieved": r.get("algorithmic_GBps"), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-               "frac": r.get("frac_of_hbm_peak")}
+        ach = (r["algorithmic_bytes"] / (t_ms * 1e-3) / 1e9) if r.get("algorithmic_bytes") else None
+        out = {"bound": "hbm", "kernel": name, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS if ach else None,
+               "achieved_isolated": r.get("algorithmic_GBps") if iso_ms else None, "frac_isolated": r.get("frac_of_hbm_peak") if iso_ms else None}
     out.update({"traffic": r["traffic_bytes"], "traffic_from_profile": r["traffic_from_profile"], "launch_ms": t_ms,
-                "launch_ms_kind": "isolated median" if r["isolated_median_ms"] else "timed-region median",
-                "avg_launch_ms_timed_region": r["avg_ms_timed_region"], "launches": r["launches"],
+                "launch_ms_kind": "average launch duration inside the timed region (HIP events on the kernel's stream)",
+                "launch_ms_isolated_median": iso_ms, "launches": r["launches"],
                 "algorithmic_bytes_per_launch": r["algorithmic_bytes"], "design_bytes_per_launch": r["design_bytes"]})
     # the dominant HBM-bound kernel beside it when the dominant kernel is VALU-bound
-    hb = {k: v for k, v in rows.items() if v["bound"] == "hbm" and v.get("frac_of_hbm_peak")}
+    hb = {k: v for k, v in rows.items() if v["bound"] == "hbm" and v.get("algorithmic_bytes")}
     if out["bound"] != "hbm" and hb:
-        k, v = max(hb.items(), key=lambda kv: kv[1]["isolated_median_ms"] or kv[1]["median_ms_timed_region"])
-        out["dominant_hbm_kernel"] = {"kernel": k, "achieved": v["algorithmic_GBps"], "frac": v["frac_of_hbm_peak"],
-                                      "launch_ms": v["isolated_median_ms"] or v["median_ms_timed_region"],
+        k, v = max(hb.items(), key=lambda kv: _in_step_ms(kv[1]))
+        ach = v["algorithmic_bytes"] / (_in_step_ms(v) * 1e-3) / 1e9
+        out["dominant_hbm_kernel"] = {"kernel": k, "achieved": ach, "frac": ach / HBM_PEAK_GBS, "launch_ms": _in_step_ms(v),
+                                      "frac_isolated": v.get("frac_of_hbm_peak"), "launch_ms_isolated_median": v["isolated_median_ms"],
                                       "algorithmic_bytes_per_launch": v["algorithmic_bytes"], "design_bytes_per_launch": v["design_bytes"],
                                       "traffic": v["traffic_bytes"]}
     return out
@@ -461,6 +473,7 @@ def hbm_calibration(device, gib: float = 4.0, reps: int = 5):
     t_fill = med(lambda: C.check(L.mi_calibrate_fill(C.ptr(dst), ctypes.c_size_t(nbytes), ctypes.c_float(1.0), st), "mi_calibrate_fill"))
     t_read = med(lambda: C.check(L.mi_calibrate_read(C.ptr(src), ctypes.c_size_t(nbytes), C.ptr(sink), st), "mi_calibrate_read"))
     del src, dst
+    torch.cuda.empty_cache()  # hand the two calibration blocks back: they must not shape the allocator state of the timed region
     return {"copy_GBps": 2.0 * nbytes / t_copy / 1e6, "fill_GBps": nbytes / t_fill / 1e6, "read_GBps": nbytes / t_read / 1e6, "bytes": nbytes,
             "copy_ms": t_copy, "fill_ms": t_fill, "read_ms": t_read,
             "note": "float4 read / fill / copy streams over this many bytes on this box, before the timed region (csrc/calib.hip); copy counts read + written bytes"}
@@ -521,11 +534,19 @@ def cpu_baseline(sample_atoms: int, full_size_1thread: bool, budget_s: float = 1
                                  "what": "one full 100k-atom step, OpenMP build of the oracle (atom loops shared between threads, scipy.fft workers)"}
     else:
         full["all_cores"] = {"skipped": f"predicted {predicted_1t / max(0.5 * cores, 1):.0f} s on {cores} cores"}
-    if full_size_1thread:
+    if full_size_1thread or predicted_1t < 75.0:
+        # the 1-thread leg at FULL size whenever the sample predicts about a minute or less (the driver line's own
+        # number should not be an extrapolation): `value` becomes this measurement, the sample-box figure stays beside it
         st = _oracle_step(O, fpos, fcell, fq, fnum, tables, PME["mesh"], PME["order"])
         full["one_thread"] = {"value": 100000.0 / float(st.sum()), "unit": "atom-steps/s", "cores": 1, "seconds": float(st.sum()),
                               "stage_s": {"nlist9A": st[0], "pme": st[1], "nlist40Bohr": st[2], "d3": st[3]},
                               "what": "one full 100k-atom step, serial oracle"}
+        out["sample_box"] = {"value": out["value"], "sample": out["sample"], "seconds": out["seconds"]}
+        out["value"], out["seconds"] = full["one_thread"]["value"], full["one_thread"]["seconds"]
+        out["sample"] = ("ONE full step of the headline workload itself (100 000-atom box, mesh 128^3, spline order 5 in the oracle's extended mode), "
+                         f"serial oracle, 1 thread: nlist9A {st[0]:.2f}s, PME {st[1]:.2f}s, nlist40Bohr {st[2]:.2f}s, D3 {st[3]:.2f}s")
+    else:
+        out["sample"] = "SAMPLE BOX, not the 100k box (1-thread full-size step predicted > 75 s; --cpu-full-size runs it): " + out["sample"]
     out["full_size"] = full
     return out
 
@@ -651,6 +672,219 @@ def ref_pme(device):
             "source": "BASELINE.md / docs/benchmarks/benchmark_results/electrostatics_benchmark_pme_nvalchemiops_h100-80gb-hbm3.csv"}
 
 
+# ---- the other BASELINE.json configurations as driver-parseable lines ---------------------------------------------
+def _timed_steps(step, steps, warmup):
+    """The contract's timing of a single-GPU workload: `warmup` untimed steps, then exactly `steps` steps bracketed by
+    torch.cuda.synchronize(); library kernels timed with HIP events on their own stream inside the region."""
+    from nvalchemiops import _capi as C
+
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    C.lib().mi_timing_enable(1)
+    ev = []
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        ev.append(e)
+        out = step()
+    e = torch.cuda.Event(enable_timing=True)
+    e.record()
+    ev.append(e)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    C.lib().mi_timing_enable(0)
+    return out, elapsed, [a.elapsed_time(b) for a, b in zip(ev[:-1], ev[1:])], kernel_report()
+
+
+def _config_rows(kernels, acct):
+    """Kernel table of a config workload: every timed kernel with its in-step average and, where `acct` prices it, SURVEY 8(d) bytes."""
+    rows = {}
+    for name, (cnt, tot, med, lo, hi) in sorted(kernels.items()):
+        bound, algo, note = acct.get(name, ("latency", None, ""))
+        row = {"launches": cnt, "avg_ms_timed_region": tot / cnt, "median_ms_timed_region": med, "isolated_median_ms": None, "bound": bound,
+               "algorithmic_bytes": algo, "design_bytes": None, "traffic_bytes": None, "traffic_from_profile": None}
+        if algo:
+            row["algorithmic_GBps"] = algo / (tot / cnt * 1e-3) / 1e9
+            row["frac_of_hbm_peak"] = row["algorithmic_GBps"] / HBM_PEAK_GBS
+        if note:
+            row["note"] = note
+        rows[name] = row
+    return rows
+
+
+def _bounded(fn, budget_s, max_reps=20):
+    """Repeat fn() for about budget_s seconds (at least once): (reps, seconds)."""
+    reps, t0 = 0, time.perf_counter()
+    while True:
+        fn()
+        reps += 1
+        if time.perf_counter() - t0 >= budget_s or reps >= max_reps:
+            return reps, time.perf_counter() - t0
+
+
+def config_c2(device, args):
+    """BASELINE config 2: 50 000-atom periodic box (jittered FCC, a = 4 A), `cell_list` rc = 5 A, fp32, padded-matrix output into
+    pre-allocated buffers at the API's default row width M = estimate_max_neighbors(5 A) = 928 (what `cell_list` allocates when the caller
+    names no width; the reference benchmark's protocol, benchmarks/neighborlist/benchmark_config.yaml + utils.py:133-240, pre-allocates too)."""
+    from nvalchemiops.neighborlist import cell_list, estimate_max_neighbors
+    from tests import systems as S
+
+    n, rc = 50000, 5.0
+    pos, cell, _, _ = S.fcc_box(n, seed=1234, dtype=np.float32)
+    tp, tc = torch.as_tensor(pos, device=device), torch.as_tensor(cell, device=device)
+    pbc = torch.tensor([True] * 3, device=device)
+    m = estimate_max_neighbors(rc)
+    nm = torch.empty((n, m), dtype=torch.int32, device=device)
+    sh = torch.empty((n, m, 3), dtype=torch.int32, device=device)
+    num = torch.empty(n, dtype=torch.int32, device=device)
+
+    def step():
+        cell_list(tp, rc, tc, pbc, neighbor_matrix=nm, neighbor_matrix_shifts=sh, num_neighbors=num)
+        return num
+
+    acct = {"nl_query_matrix_f32": ("hbm", n * (3 * 4 + 4) + 16.0 * n * m, "owner-written rows: hits, then padding (fill value N, zero shifts)")}
+
+    def cpu():
+        from oracle import oracle as O
+
+        reps, sec = _bounded(lambda: O.cell_list(pos, rc, cell, [True] * 3, max_neighbors=m), 10.0)
+        return {"value": n * reps / sec, "unit": "atom-steps/s", "cores": 1, "kind": "port", "seconds": sec,
+                "sample": f"{reps} full-size passes of the oracle's cell_list restatement on the same 50 000-atom box (serial, 1 thread)"}
+
+    what = f"config 2: {n}-atom periodic FCC box, cell_list rc = 5 A, fp32, padded matrix M = {m} (default width) into pre-allocated outputs"
+    return dict(step=step, atoms=n, acct=acct, cpu=cpu, workload=what, dtype="f32", extra=lambda out: {"directed_pairs": int(out.sum().item()),
+                                                                                                      "neighbors_max": int(out.max().item())})
+
+
+def config_c3(device, args):
+    """BASELINE config 3: batch of 256 x 512-atom molecules (free space: every molecule in its own non-periodic bounding cell),
+    batch `neighbor_list` rc = 40 Bohr (padded matrix M = 512 + zero shifts) + `dftd3`(BJ) energies / forces / virials, fp32."""
+    from nvalchemiops.interactions.dispersion import D3Parameters, dftd3
+    from nvalchemiops.neighborlist import batch_cell_list
+    from tests import systems as S
+
+    nmol, per, rc, m = 256, 512, 40.0, 512
+    mols = [S.molecule(per, seed=2000 + s) for s in range(4)]
+    pos = np.concatenate([(mols[s % 4][0] * BOHR).astype(np.float32) for s in range(nmol)])
+    z = np.concatenate([mols[s % 4][1] for s in range(nmol)])
+    side = float(max(mm[2] for mm in mols)) * BOHR + 1.0
+    cell = np.broadcast_to(np.eye(3, dtype=np.float32) * side, (nmol, 3, 3)).copy()
+    bi = np.repeat(np.arange(nmol, dtype=np.int32), per)
+    n = nmol * per
+    tables = S.d3_test_tables(94, seed=7)
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a), device=device)  # noqa: E731
+    params = D3Parameters(rcov=t(tables["rcov"]), r4r2=t(tables["r4r2"]), c6ab=t(tables["c6ab"]), cn_ref=t(tables["cn_ref"]))
+    tp, tz, tb, tc = t(pos), t(z), t(bi), t(cell)
+    pbc = torch.zeros((nmol, 3), dtype=torch.bool, device=device)
+    nm = torch.empty((n, m), dtype=torch.int32, device=device)
+    sh = torch.empty((n, m, 3), dtype=torch.int32, device=device)
+    num = torch.empty(n, dtype=torch.int32, device=device)
+    bj = dict(a1=D3["a1"], a2=D3["a2"], s8=D3["s8"])
+
+    def step():
+        batch_cell_list(tp, rc, tc, pbc, tb, neighbor_matrix=nm, neighbor_matrix_shifts=sh, num_neighbors=num)
+        e, f, cn, vir = dftd3(tp, tz, d3_params=params, neighbor_matrix=nm, neighbor_matrix_shifts=sh, cell=tc, batch_idx=tb, num_systems=nmol,
+                              fill_value=n, compute_virial=True, **bj)
+        return num, e, f, vir
+
+    per_pass = 16.0 * n * m + 40.0 * n
+    acct = {"nl_query_matrix_f32": ("hbm", n * (3 * 4 + 4) + 16.0 * n * m, ""), "d3_cn": ("hbm", per_pass, "streams 16 B/slot + one 16 B gather per neighbour"),
+            "d3_energy": ("valu", per_pass, "C6 contraction + BJ damping per directed pair (VALU-issue-bound, DESIGN 3.1)"),
+            "d3_chain": ("hbm", per_pass, "")}
+
+    def cpu():
+        from oracle import oracle as O
+
+        k = 8  # bounded sample: the first 8 molecules (the batch is 64 copies of 4 molecules: identical per-atom work)
+        sp, sz, sb, sc = pos[:k * per], z[:k * per], bi[:k * per], cell[:k]
+
+        def one():
+            onm, onum, osh = O.cell_list(sp, rc, sc, np.zeros((k, 3), bool), batch_idx=sb, max_neighbors=m)
+            O.dftd3(sp, sz, tables, D3["a1"], D3["a2"], D3["s8"], neighbor_matrix=onm, neighbor_matrix_shifts=osh, cell=sc, batch_idx=sb,
+                    num_systems=k, compute_virial=True)
+
+        reps, sec = _bounded(one, 10.0)
+        return {"value": k * per * reps / sec, "unit": "atom-steps/s", "cores": 1, "kind": "port", "seconds": sec,
+                "sample": f"{reps} passes of the oracle (batch cell list + D3 with virial, serial) over the first {k} of the 256 molecules "
+                          "(the batch repeats 4 distinct molecules: per-atom work identical)"}
+
+    what = (f"config 3: {nmol} x {per}-atom molecules (free space, non-periodic cells), batch neighbor_list rc = 40 Bohr (padded M = {m}) + "
+            "DFT-D3(BJ) E + F + virial, fp32")
+    return dict(step=step, atoms=n, acct=acct, cpu=cpu, workload=what, dtype="f32",
+                extra=lambda out: {"directed_pairs": int(out[0].sum().item()), "neighbors_max": int(out[0].max().item()),
+                                   "e_d3_Ha_first_molecule": float(out[1][0].item())})
+
+
+def config_c4(device, args):
+    """BASELINE config 4: 100 000-atom periodic box with charges, `neighbor_list` rc = 9 A (padded M = 256) + `particle_mesh_ewald`
+    (real + reciprocal, alpha 0.35, mesh 128^3, B-spline order 5, energies + forces), fp64 -- the electrostatics branch of the headline step."""
+    from nvalchemiops.interactions.electrostatics import particle_mesh_ewald
+    from nvalchemiops.neighborlist import cell_list
+
+    n = 100000
+    sysd, _ = build_system(n, 1234, device)
+    m, mesh = PME["max_neighbors"], float(np.prod(PME["mesh"]))
+    nm = torch.empty((n, m), dtype=torch.int32, device=device)
+    sh = torch.empty((n, m, 3), dtype=torch.int32, device=device)
+    num = torch.empty(n, dtype=torch.int32, device=device)
+
+    def step():
+        cell_list(sysd["pos64"], PME["cutoff"], sysd["cell64"], sysd["pbc"], neighbor_matrix=nm, neighbor_matrix_shifts=sh, num_neighbors=num)
+        e, f = particle_mesh_ewald(sysd["pos64"], sysd["q64"], sysd["cell64"], alpha=PME["alpha"], mesh_dimensions=PME["mesh"],
+                                   spline_order=PME["order"], neighbor_matrix=nm, neighbor_matrix_shifts=sh, compute_forces=True)
+        return num, e, f
+
+    acct = {"nl_query_matrix_f64": ("hbm", n * (3 * 8 + 4) + 16.0 * n * m, ""),
+            "ewald_real": ("hbm", 16.0 * n * m + n * (3 * 8 + 8) + n * (8 + 3 * 8), "fp64 erfc pair sum over the padded rows"),
+            "spline_spread": ("latency", n * 4 * 8 + mesh * 8, "binning + LDS-tile accumulation"),
+            "pme_gather_finish": ("hbm", 4 * mesh * 8 + n * 4 * 8 + n * 4 * 8, "L2/MALL-resident mesh gather"),
+            "pme_convolve": ("hbm", (mesh / 2) * 16 * 5, "")}
+    host = sysd["host"]
+
+    def cpu():
+        from oracle import oracle as O
+
+        def one():
+            onm, onum, osh = O.cell_list(host["pos"], PME["cutoff"], host["cell"], [True] * 3, max_neighbors=m)
+            with O.extended_splines():  # order 5 as true B-splines, like the GPU step (the oracle's reference mode is zero there)
+                O.particle_mesh_ewald(host["pos"], host["q"], host["cell"], PME["alpha"], PME["mesh"], PME["order"], neighbor_matrix=onm,
+                                      neighbor_matrix_shifts=osh, compute_forces=True)
+
+        reps, sec = _bounded(one, 10.0, max_reps=3)
+        return {"value": n * reps / sec, "unit": "atom-steps/s", "cores": 1, "kind": "port", "seconds": sec,
+                "sample": f"{reps} FULL-size step(s) of the oracle (cell list 9 A + PME mesh 128^3 order 5 in its extended mode, E + F), serial, numpy FFTs"}
+
+    what = (f"config 4: {n}-atom periodic FCC box with +-1 charges, nlist(9 A, padded M = {m}) + particle_mesh_ewald(real + reciprocal, alpha 0.35, "
+            "mesh 128^3, spline order 5 = true B-spline (the reference evaluates order 5 as 0), E + F), fp64")
+    return dict(step=step, atoms=n, acct=acct, cpu=cpu, workload=what, dtype="f64",
+                extra=lambda out: {"pme_neighbors_max": int(out[0].max().item()), "e_pme": float(out[1].sum().item())})
+
+
+def run_config(name, device, args):
+    """`--workload c2|c3|c4`: one BASELINE.json configuration as a line of the same shape as the headline's (metric per config: atom-steps/s of
+    ONE pass of that configuration's hot path; `roofline` = the dominant kernel of that configuration, in-step; `cpu_baseline` = the oracle)."""
+    cfg = {"c2": config_c2, "c3": config_c3, "c4": config_c4}[name](device, args)
+    calibration = hbm_calibration(device, gib=1.0) if os.environ.get("BENCH_CALIB", "1") != "0" else None
+    out, elapsed, step_ms, kernels = _timed_steps(cfg["step"], args.steps, args.warmup)
+    rows = _config_rows(kernels, cfg["acct"])
+    roof = roofline_of({k: v for k, v in rows.items() if v.get("algorithmic_bytes")} or rows)
+    if roof and calibration and roof.get("achieved") and roof["bound"] == "hbm":
+        roof["frac_of_box_fill"] = roof["achieved"] / calibration["fill_GBps"]
+        roof["frac_of_box_copy"] = roof["achieved"] / calibration["copy_GBps"]
+    n = cfg["atoms"]
+    res = {"metric": f"atom-steps/sec of BASELINE config {name[1]} (one pass of its hot path per step)", "value": n * args.steps / elapsed,
+           "unit": "atom-steps/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": cfg["dtype"], "data": "synthetic",
+           "config": {"workload": cfg["workload"], "atoms_per_gpu": n, **cfg["extra"](out)},
+           "stats": {"step_ms_median": statistics.median(step_ms), "step_ms_min": min(step_ms), "step_ms_max": max(step_ms), "timed_region_s": elapsed},
+           "roofline": roof, "calibration": calibration, "kernels": rows}
+    if args.cpu_sample > 0:
+        res["cpu_baseline"] = cfg["cpu"]()
+    print(json.dumps(res), flush=True)
+
+
 # ---- launcher -------------------------------------------------------------------------------------------------------------------------
 def pme_train(device, atoms: int = 100000, iters: int = 20):
     """Training path of the electrostatics leg (reference protocol test_pme.py:1458,1571 / autograd.py:525-665):
@@ -742,7 +976,7 @@ def main():
     ap.add_argument("--atoms", type=int, default=100000)
     ap.add_argument("--cpu-sample", type=int, default=6912, help="atoms in the CPU-baseline sample box (0 = skip the CPU baseline)")
     ap.add_argument("--cpu-full-size", action="store_true", help="also time ONE full 100k-atom step of the serial oracle (~1 min)")
-    ap.add_argument("--workload", default="headline", choices=["headline", "c5", "ref-nlist", "ref-d3", "ref-pme", "pme-train"],
+    ap.add_argument("--workload", default="headline", choices=["headline", "c2", "c3", "c4", "c5", "ref-nlist", "ref-d3", "ref-pme", "pme-train"],
                     help="headline: one 100k-atom box per GPU (default, the BASELINE metric); c5: BASELINE config 5, --systems x 2000-atom "
                          "boxes per GPU sharded at system granularity; ref-*: the reference's published benchmark rows (BASELINE.md)")
     ap.add_argument("--systems", type=int, default=128, help="systems per GPU for --workload c5")
@@ -776,6 +1010,13 @@ def main():
         backend = os.environ.get("BENCH_BACKEND", "nccl")  # "nccl" is RCCL on ROCm
         kw = {"device_id": device} if backend == "nccl" else {}
         torch.distributed.init_process_group(backend=backend, **kw)
+        # self-validating scaling record: a real N-GPU run is RCCL ("nccl") over N DISTINCT devices (asserted, and written into the line)
+        ident = [None] * world
+        props = torch.cuda.get_device_properties(device)
+        torch.distributed.all_gather_object(ident, (local_rank, str(getattr(props, "uuid", "")), props.name))
+        if not shared:
+            assert torch.distributed.get_backend() == "nccl", f"multi-GPU bench must run over RCCL, got {torch.distributed.get_backend()}"
+            assert len({(i[0], i[1]) for i in ident}) == world, f"{world} ranks must sit on {world} distinct devices, saw {ident}"
 
     from nvalchemiops import _capi as C
 
@@ -786,6 +1027,14 @@ def main():
         res.update({"n_gpus": 1, "data": "synthetic", "higher_is_better": False, "workload": args.workload,
                     "protocol": "median of event-bracketed calls after warm-up (reference: benchmarks/utils.py:133-240)"})
         print(json.dumps(res), flush=True)
+        return
+
+    if args.workload in ("c2", "c3", "c4"):
+        if world > 1:
+            raise SystemExit("c2 / c3 / c4 are BASELINE.json's single-GPU configurations")
+        if args.steps == 250:
+            args.steps = 100
+        run_config(args.workload, device, args)
         return
 
     if args.workload == "c5":
@@ -914,7 +1163,9 @@ def main():
                        (f"config 5: {args.systems} x 2000-atom periodic boxes per GPU (batch): nlist(9 A) + PME(mesh 32^3 per system, order 5, "
                         "fp64) + nlist(40 Bohr, " + (f"padded M={D3['max_neighbors']}" if D3_FORMAT == "matrix" else "CSR") + ") + DFT-D3(BJ), one all_gather of per-system energies"),
                        "atoms_per_gpu": args.atoms, "d3_directed_pairs": pairs_d3, "pme_neighbors_max": int(num.max().item()), "d3_neighbors_max": int((nptr if matrix_d3 else (nptr[1:] - nptr[:-1])).max().item()),
-                       "parallelism": par, "ranks": world, "backend": backend},
+                       "parallelism": par, "ranks": world, "backend": backend,
+                       "devices": ([f"{i[2]} #{i[0]} {i[1]}" for i in ident] if world > 1 else [torch.cuda.get_device_name(device)]),
+                       "real_space_divide": "hardware rcp/rsq + Newton (EW_IEEE_DIV=0 build of csrc/ewald.hip)"},
             "stats": ({"step_ms_median": statistics.median(step_ms), "step_ms_min": min(step_ms), "step_ms_max": max(step_ms),
                        "value_at_median": total_atoms / statistics.median(step_ms) * 1e3, "timed_region_s": elapsed,
                        "overlap": OVERLAP,
