@@ -4,9 +4,15 @@
  * Drop-in boundary for the reference's L2 seam: the `torch.library.custom_op` wrappers that launch
  * Warp kernels (reference file:line cited per entry point).  All pointers are DEVICE pointers unless
  * marked [host]; every buffer is owned by the caller (the Python layer allocates through torch's caching
- * allocator, exactly as the reference wrappers do); `stream` is a hipStream_t passed as void*; the
- * library keeps no state between calls.  dtype: 0 = float32, 1 = float64.  Every function returns
- * 0 on success or a negative MI_E* code; mi_last_error() gives a message for the calling thread.
+ * allocator, exactly as the reference wrappers do); `stream` is a hipStream_t passed as void*.
+ * dtype: 0 = float32, 1 = float64.  Every function returns 0 on success or a negative MI_E* code;
+ * mi_last_error() gives a message for the calling thread.
+ *
+ * State between calls: none that a result depends on.  Three things outlive a call, all documented where they are declared:
+ *   - FFT plans (mi_fft_plan_*): explicit handles owned by the caller, each holding its rocFFT work area;
+ *   - mi_d3's atom-order heuristic: per device, 64 bytes of pinned host memory with an earlier call's measurement of how spatially
+ *     coherent the caller's atom numbering is (it picks between two code paths with bit-identical outputs; see mi_d3);
+ *   - the optional per-kernel timing records of mi_timing_enable (bench.py only).
  *
  * A reference maintainer binds these with ctypes; no torch types cross this line.
  */
@@ -158,6 +164,12 @@ size_t mi_d3_workspace_bytes_packed(int n_atoms, int n_systems, int nz, int max_
 /* The same for any layout, by number of stored entries (CSR: neighbor_ptr[n_atoms] = mi_d3's `n_list_entries`).              */
 size_t mi_d3_workspace_bytes_entries(int n_atoms, int n_systems, int nz, long long n_entries);
 
+/* Atom-order heuristic (the one thing mi_d3 remembers between calls): with the packed list and >= 2048 atoms the passes can walk spatially
+ * ordered copies of the per-atom records, which pays when the caller numbers its atoms incoherently and costs a little when it does not.
+ * The choice is made on the host from a measurement an EARLIER call left in pinned host memory (asynchronous copy, no synchronisation,
+ * records kept per device and per (n_atoms, n_systems) generation); both paths produce bit-identical outputs, so the state can change
+ * run-to-run timing only.  Nothing is measured or published while `stream` is being captured into a HIP graph: the choice made at capture
+ * time is part of the graph.  NVALCHEMIOPS_D3_SORT=0|1 in the environment forces the choice.                                         */
 int mi_d3(const void* positions, const int32_t* numbers, int n_atoms, int dtype,
           const int32_t* idx_j,        /* matrix [n_atoms,max_neighbors] or CSR values [n_pairs]      */
           const int32_t* unit_shifts,  /* same layout x3, or NULL (non-periodic)                      */
@@ -337,6 +349,18 @@ int mi_spline_gather_hess_dot(const void* positions, const void* mesh, const int
 int mi_spline_spread_grad(const void* positions, const void* vec /*[n_atoms,3]*/, const int32_t* batch_idx, const void* cell_inv_t,
                           int n_atoms, int n_systems, int nx, int ny, int nz, int order, int dtype, void* mesh /*[B,nx,ny,nz]*/,
                           void* stream);
+
+/* ---- FFT plans (csrc/fft.cpp: hipFFT on rocFFT) ------------------------------------------------------------------------
+ * 3-D real <-> complex transforms over a batch of contiguous meshes: real [batch][nx][ny][nz], complex [batch][nx][ny][nz/2+1]
+ * interleaved.  Replace torch.fft.rfftn(norm="backward") / irfftn(norm="forward") of `_pme_reciprocal_space_impl` (pme.py:1398,
+ * :1422, :1455-1457): both directions UNSCALED.  `inverse` = 0: R2C forward, 1: C2R inverse -- which may OVERWRITE its input
+ * spectrum (rocFFT's multi-dimensional C2R; this is why torch clones before irfftn -- here the spectrum is scratch of the same step).
+ * A plan owns its work area (mi_fft_plan_work_bytes, allocated at creation on the then-current device): the one object of this ABI
+ * that holds device memory.  mi_fft_plan_exec allocates nothing, never synchronises, is HIP-graph capturable.                     */
+int mi_fft_plan_create(int nx, int ny, int nz, int batch, int dtype, int inverse, void** plan_out);
+size_t mi_fft_plan_work_bytes(const void* plan);
+int mi_fft_plan_exec(void* plan, void* in, void* out, void* stream);
+int mi_fft_plan_destroy(void* plan);
 
 /* ---- PME reciprocal-space mesh kernels ------------------------------------------------------
  * mi_pme_green_sf: alchemiops::_[batch_]pme_green_structure_factor (pme.py:273-553, pme_kernels.py:121-331)

@@ -21,6 +21,7 @@ ARCH = "gfx950"
 # per-file extra flags.  nlist.hip must evaluate the cutoff test exactly like the oracle: no FMA contraction.
 SOURCES = {
     "capi.cpp": [],
+    "fft.cpp": [],  # hipFFT plans (mi_fft_plan_*): linked with -lhipfft below
     "nlist.hip": ["-ffp-contract=off"] + os.environ.get("MI_NLIST_EXTRA_FLAGS", "").split(),
     # D3 pair math is fp32 with 1/x and sqrt on every pair: hardware v_rcp/v_sqrt (1 ulp) instead of the IEEE-exact expansions
     # (~10 instructions each); energies/forces stay inside the stated 2e-6 / 1e-5 tolerances
@@ -74,7 +75,9 @@ def build(force: bool = False, verbose: bool = True) -> str:
     with ThreadPoolExecutor(max_workers=4) as ex:
         list(ex.map(run, jobs))
     if force or jobs or _stale(LIB, objs):
-        run([HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs)
+        # libhipfft.so.0: inside a Python process torch has loaded its own copy of that SONAME already (same rocFFT the torch.fft path
+        # used); a plain C caller resolves it from the ROCm installation
+        run([HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs + ["-L/opt/rocm/lib", "-lhipfft"])
     if force or _stale(LIB_D3_IEEE, [ieee_obj, os.path.join(build_dir, "capi.o")]):
         run([HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB_D3_IEEE, ieee_obj, os.path.join(build_dir, "capi.o")])
     return LIB

@@ -5,7 +5,7 @@
 //   scan     exclusive prefix over the bins: BS_CHUNK bins per block in registers + LDS, then one tiny block over the block sums
 //   scatter  slot = start[key] + bs_wave_add(fill[key]): items land inside their bin's segment in arrival order
 // Bin starts are produced as absolute offsets (`start_abs`, with the end sentinel start_abs[nbins] = N) by the scatter launch
-// itself, so the pipeline is 1 memset + 3 kernels behind the key kernel.  Order INSIDE a bin is arrival order; callers that
+// itself, so the pipeline is 1 memset + 2 kernels behind the key kernel (3 above 4 M bins).  Order INSIDE a bin is arrival order; callers that
 // need a deterministic order (neighbour rows: ascending atom index) rank the few items of a bin afterwards (nlist.hip).
 #pragma once
 #include "common.h"
@@ -99,23 +99,48 @@ __global__ __launch_bounds__(256) void bs_scan_blocks_kernel(const int* __restri
   }
 }
 
-__device__ __forceinline__ int bs_start_of(const int* __restrict__ local, const int* __restrict__ block_off, int key) {
-  return local[key] + block_off[key / BS_CHUNK];
-}
+#define BS_INLINE_BLOCKS 1024  // up to this many scan blocks (4 M bins) the scatter launch prefixes the block sums itself
 
 // thread t < N: item t goes to slot start[key] + (arrival rank in its bin); thread t <= nbins: absolute bin start t
-// (start_abs[nbins] = N is the end sentinel).  `local` / `block_off` are read-only here.
+// (start_abs[nbins] = N is the end sentinel).  `local` is read-only here.  INLINE (round 4): every block first turns the <= 1024 block
+// sums of the partial scan into their exclusive prefix in LDS (4 loads + one shuffle scan per thread) -- the one-block
+// bs_scan_blocks_kernel between the two launches, ~5 us of pure launch latency three times per step, is gone; with more scan blocks
+// than that the prefix comes from that kernel through `block_off` as before.
+template <bool INLINE>
 __global__ __launch_bounds__(256) void bs_scatter_kernel(const int* __restrict__ keys, int N, const int* __restrict__ local,
-                                                        const int* __restrict__ block_off, const int* __restrict__ nbins_dev, long long cap,
-                                                        int* __restrict__ fill, int* __restrict__ items_out, int* __restrict__ start_abs) {
+                                                        const int* __restrict__ block_sum, int nblocks, const int* __restrict__ block_off,
+                                                        const int* __restrict__ nbins_dev, long long cap, int* __restrict__ fill,
+                                                        int* __restrict__ items_out, int* __restrict__ start_abs) {
+  __shared__ int s_off[INLINE ? BS_INLINE_BLOCKS : 1];
+  __shared__ int wave_tot[4];
+  if (INLINE) {
+    const int lane = threadIdx.x & (MI_WAVE - 1), wave = threadIdx.x / MI_WAVE;
+    int v[4], tsum = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { const int b = threadIdx.x * 4 + k; v[k] = b < nblocks ? block_sum[b] : 0; }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { const int c = v[k]; v[k] = tsum; tsum += c; }
+    int inc = tsum;
+#pragma unroll
+    for (int o = 1; o < MI_WAVE; o <<= 1) { const int up = __shfl_up(inc, o, MI_WAVE); if (lane >= o) inc += up; }
+    if (lane == MI_WAVE - 1) wave_tot[wave] = inc;
+    __syncthreads();
+    int woff = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) woff += (w < wave) ? wave_tot[w] : 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) s_off[threadIdx.x * 4 + k] = woff + inc - tsum + v[k];
+    __syncthreads();
+  }
+  auto start_of = [&](int key) { return local[key] + (INLINE ? s_off[key / BS_CHUNK] : block_off[key / BS_CHUNK]); };
   const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   long long n = cap;
   if (nbins_dev) { const long long want = (long long)(*nbins_dev) + 1; n = want < cap ? want : cap; }
-  if (start_abs && t < n) start_abs[t] = bs_start_of(local, block_off, (int)t);
+  if (start_abs && t < n) start_abs[t] = start_of((int)t);
   const bool in = t < N;
   const int key = in ? keys[t] : 0;
   const int rank = bs_wave_add<true>(fill, key, in);
-  if (in) items_out[bs_start_of(local, block_off, key) + rank] = (int)t;
+  if (in) items_out[start_of(key) + rank] = (int)t;
 }
 
 // host side: scratch = {count[cap], fill[cap], block_sum[nb], block_off[nb]} (ints); count and fill are contiguous so that one
@@ -136,9 +161,15 @@ inline hipError_t bs_clear(const BsScratch& s, hipStream_t st) { return hipMemse
 // after the key kernel: scan + scatter.  items_out[N] receives the item indices grouped by bin, start_abs[<= cap] the bin starts.
 inline hipError_t bs_sort(const BsScratch& s, const int* keys, int N, const int* nbins_dev, int* items_out, int* start_abs, hipStream_t st) {
   bs_scan_partial_kernel<<<s.nblocks, 256, 0, st>>>(s.count, nbins_dev, s.cap, s.block_sum);
-  bs_scan_blocks_kernel<<<1, 256, 0, st>>>(s.block_sum, s.nblocks, s.block_off);
   const long long threads = (long long)N > s.cap ? (long long)N : s.cap;
-  bs_scatter_kernel<<<mi_blocks(threads, 256), 256, 0, st>>>(keys, N, s.count, s.block_off, nbins_dev, s.cap, s.fill, items_out, start_abs);
+  if (s.nblocks <= BS_INLINE_BLOCKS) {
+    bs_scatter_kernel<true><<<mi_blocks(threads, 256), 256, 0, st>>>(keys, N, s.count, s.block_sum, s.nblocks, nullptr, nbins_dev, s.cap, s.fill,
+                                                                     items_out, start_abs);
+  } else {
+    bs_scan_blocks_kernel<<<1, 256, 0, st>>>(s.block_sum, s.nblocks, s.block_off);
+    bs_scatter_kernel<false><<<mi_blocks(threads, 256), 256, 0, st>>>(keys, N, s.count, s.block_sum, s.nblocks, s.block_off, nbins_dev, s.cap, s.fill,
+                                                                      items_out, start_abs);
+  }
   return hipGetLastError();
 }
 

@@ -1125,12 +1125,20 @@ D3Layout d3_layout(int N, int nz, int dtype, int B) {
 // the decision is taken from a measurement of an EARLIER call, without any synchronisation: every D3_ORDER_PROBE_EVERY-th call the key
 // kernel counts the consecutive atoms that sit in far-apart bins and the count is copied to pinned host memory asynchronously; a later
 // call reads whatever has arrived (first calls: "coherent").  Both paths give bit-identical results, so a switch is invisible.
+// This is the ONE piece of state the library keeps between calls (include/nvalchemiops_hip.h says so): per device, a pinned ring of
+// D3_ORDER_SLOTS records and the (n_atoms, n_systems) it describes.  A change of (n_atoms, n_systems) starts a new GENERATION with a
+// fresh ring slot, so an asynchronous copy still in flight for the previous system lands in ITS slot and can never be taken for a
+// measurement of the new one.  Two different systems of equal size alternating on one device share a record: they then share
+// one heuristic, never a result.  Under HIP-graph capture nothing is probed or published and the decision taken at capture time is frozen
+// into the graph.  The ring (64 bytes of pinned host memory per device) lives until the process exits.
 #define D3_ORDER_PROBE_EVERY 64
-struct D3OrderState { int* h_count = nullptr; /* pinned {far-apart pairs, largest pair distance bits} */ int n_atoms = -1, n_systems = -1; long long calls = 0; };
+#define D3_ORDER_SLOTS 8
+struct D3OrderState { int* h_count = nullptr; /* pinned [D3_ORDER_SLOTS][2] = {far-apart pairs, largest pair distance bits} */ int n_atoms = -1, n_systems = -1; long long calls = 0; unsigned gen = 0; };
 static D3OrderState g_d3_order[16];
 static std::mutex g_d3_order_mu;
-static bool d3_order_decide(int N, int B, hipStream_t st, bool* probe, float* rc_est) {
+static bool d3_order_decide(int N, int B, hipStream_t st, bool* probe, float* rc_est, int** publish_to) {
   *probe = false;
+  *publish_to = nullptr;
   *rc_est = 0.0f;
   const char* force = getenv("NVALCHEMIOPS_D3_SORT");  // tuning aid: 0 = never, 1 = always
   if (force && atoi(force) == 0) return false;
@@ -1141,11 +1149,15 @@ static bool d3_order_decide(int N, int B, hipStream_t st, bool* probe, float* rc
   std::lock_guard<std::mutex> lock(g_d3_order_mu);
   D3OrderState& S = g_d3_order[dev];
   if (!S.h_count) {
-    if (capturing || hipHostMalloc(reinterpret_cast<void**>(&S.h_count), 2 * sizeof(int), hipHostMallocDefault) != hipSuccess) { S.h_count = nullptr; return force != nullptr; }
-    S.h_count[0] = S.h_count[1] = 0;
+    if (capturing || hipHostMalloc(reinterpret_cast<void**>(&S.h_count), 2 * D3_ORDER_SLOTS * sizeof(int), hipHostMallocDefault) != hipSuccess) { S.h_count = nullptr; return force != nullptr; }
+    for (int k = 0; k < 2 * D3_ORDER_SLOTS; ++k) S.h_count[k] = 0;
   }
-  volatile int* h = S.h_count;
-  if (S.n_atoms != N || S.n_systems != B) { S.n_atoms = N; S.n_systems = B; S.calls = 0; h[0] = 0; h[1] = 0; }
+  if (S.n_atoms != N || S.n_systems != B) {  // another system: new generation, fresh slot (late copies of the old one keep their slot)
+    S.n_atoms = N; S.n_systems = B; S.calls = 0; ++S.gen;
+    S.h_count[2 * (S.gen % D3_ORDER_SLOTS)] = 0; S.h_count[2 * (S.gen % D3_ORDER_SLOTS) + 1] = 0;
+  }
+  volatile int* h = S.h_count + 2 * (S.gen % D3_ORDER_SLOTS);
+  *publish_to = S.h_count + 2 * (S.gen % D3_ORDER_SLOTS);
   *probe = !capturing && (S.calls < 4 || (S.calls % D3_ORDER_PROBE_EVERY) == 0);  // the first calls, then now and then
   ++S.calls;
   const int bits = h[1];
@@ -1153,11 +1165,8 @@ static bool d3_order_decide(int N, int B, hipStream_t st, bool* probe, float* rc
   if (force) return true;
   return 4ll * h[0] > (long long)N;  // more than a quarter of the consecutive pairs are far apart
 }
-static void d3_order_publish(const int* d_count, hipStream_t st) {
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return;
-  int* h = g_d3_order[dev].h_count;
-  if (h) (void)hipMemcpyAsync(h, d_count, 2 * sizeof(int), hipMemcpyDeviceToHost, st);
+static void d3_order_publish(const int* d_count, int* h_slot, hipStream_t st) {
+  if (h_slot) (void)hipMemcpyAsync(h_slot, d_count, 2 * sizeof(int), hipMemcpyDeviceToHost, st);
 }
 
 template <class T, bool CSR>
@@ -1186,7 +1195,8 @@ int d3_impl(const T* pos, const int* numbers, int N, const int* idx, const int* 
   int* order_probe = present + hp->nz;  // cleared with `present` below
   bool probe = false;
   float rc_est = 0.0f;
-  const bool sorted = sortable && d3_order_decide(N, B, st, &probe, &rc_est);
+  int* order_slot = nullptr;  // pinned ring slot of this system's generation (null: nothing to publish)
+  const bool sorted = sortable && d3_order_decide(N, B, st, &probe, &rc_est, &order_slot);
   int* inv = sorted ? reinterpret_cast<int*>(ws + L.inv) : nullptr;
   auto* apos_s = reinterpret_cast<typename Vec4<T>::type*>(ws + L.apos_s);
   auto* acn = reinterpret_cast<typename Vec4<T>::type*>(ws + L.acn);
@@ -1234,7 +1244,7 @@ int d3_impl(const T* pos, const int* numbers, int N, const int* idx, const int* 
   if (big_list) { if (sorted) { MI_TIMED("d3_cn", st, (MI_D3_CN(true, true))); } else { MI_TIMED("d3_cn", st, (MI_D3_CN(true, false))); } }
   else { if (sorted) { MI_TIMED("d3_cn", st, (MI_D3_CN(false, true))); } else { MI_TIMED("d3_cn", st, (MI_D3_CN(false, false))); } }
 #undef MI_D3_CN
-  if (publish) d3_order_publish(order_probe, st);
+  if (publish) d3_order_publish(order_probe, order_slot, st);
   MI_LAUNCH_CHECK();
   d3_weights_kernel<<<mi_blocks(N, 256), 256, 0, st>>>(cn, aaux, sinfo, fcr, hp->k3, N,
                                                        sizeof(T) == 4 ? reinterpret_cast<const float4*>(apos) : nullptr, aw, inv, aw_s);

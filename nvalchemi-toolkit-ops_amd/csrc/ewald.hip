@@ -76,7 +76,7 @@ __device__ __forceinline__ unsigned long long ew_entry_hash(unsigned a, unsigned
   g ^= g >> 15; g *= 0x846CA68Bu; g ^= g >> 16;
   return ((unsigned long long)g << 32) | h;
 }
-// Checksum scratch: sym[0..1] = final {forward, reverse} sums (written by ew_sym_reduce_kernel), then EW_SYM_SLOTS pairs of
+// Checksum scratch: sym[0..1] = final {forward, reverse} sums (written by block 0 of ewald_fixup_zero_kernel), then EW_SYM_SLOTS pairs of
 // partial sums.  A wave adds its partials to the slot pair of its atom index: 100k waves on ONE address would serialise at
 // ~12 ns per device-scope atomic (2.4 ms measured); spread over 1024 slot pairs they cost nothing measurable.
 #define EW_SYM_SLOTS 1024
@@ -89,24 +89,16 @@ __device__ __forceinline__ void ew_sym_flush(unsigned long long hf, unsigned lon
     atomicAdd(&slot[0], hf); atomicAdd(&slot[1], hr);
   }
 }
-__global__ __launch_bounds__(EW_SYM_SLOTS) void ew_sym_reduce_kernel(unsigned long long* __restrict__ sym) {
-  __shared__ unsigned long long part[2][EW_SYM_SLOTS / MI_WAVE];
-  const unsigned long long f = wave_sum(sym[2 + 2 * threadIdx.x]), r = wave_sum(sym[3 + 2 * threadIdx.x]);
-  if ((threadIdx.x & (MI_WAVE - 1)) == 0) { part[0][threadIdx.x / MI_WAVE] = f; part[1][threadIdx.x / MI_WAVE] = r; }
-  __syncthreads();
-  if (threadIdx.x < 2) {
-    unsigned long long t = 0;
-    for (int k = 0; k < EW_SYM_SLOTS / MI_WAVE; ++k) t += part[threadIdx.x][k];
-    sym[threadIdx.x] = t;
-  }
-}
 
 // {x, y, z, q} per atom in one 16 / 32-byte record: the pair loop gathers ONE record per neighbour (fp64: two 16-byte loads of one
 // line) instead of three coordinate loads plus the charge from a second array.  Same values, same arithmetic: results are bit-identical
 // with and without the records; measured 0.205 -> 0.195 ms on the headline list (pack kernel included).
+// `sym` (may be null): the checksum words of the same call, cleared here instead of by a memset node of their own (round 4).
 template <class T>
-__global__ void ewald_pack_kernel(const T* __restrict__ pos, const T* __restrict__ q, int N, typename Vec4<T>::type* __restrict__ rec) {
+__global__ void ewald_pack_kernel(const T* __restrict__ pos, const T* __restrict__ q, int N, typename Vec4<T>::type* __restrict__ rec,
+                                  unsigned long long* __restrict__ sym) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (sym) for (int k = i; k < EW_SYM_WORDS; k += gridDim.x * blockDim.x) sym[k] = 0ull;
   if (i >= N) return;
   typename Vec4<T>::type r;
   r.x = pos[3 * (size_t)i]; r.y = pos[3 * (size_t)i + 1]; r.z = pos[3 * (size_t)i + 2]; r.w = q[i];
@@ -181,9 +173,21 @@ __global__ __launch_bounds__(256) void ewald_real_kernel(const T* __restrict__ p
 }
 
 // ---- fix-up for lists that are not symmetric: the reference's scatter (ewald_kernels.py:518-544, :864-873) ---------------------
+// Round 4: this kernel also folds the EW_SYM_SLOTS partial checksums (every block for its own decision -- 16 KB from L2 -- and block 0
+// publishes {forward, reverse} in sym[0..1] for the scatter kernel behind it): the separate one-block reduce launch is gone.
 template <class T>
-__global__ void ewald_fixup_zero_kernel(const unsigned long long* __restrict__ sym, T* __restrict__ a3, T* __restrict__ a1, double* __restrict__ d1, int N) {
-  if (sym[0] == sym[1]) return;
+__global__ __launch_bounds__(256) void ewald_fixup_zero_kernel(unsigned long long* __restrict__ sym, T* __restrict__ a3, T* __restrict__ a1, double* __restrict__ d1, int N) {
+  __shared__ unsigned long long part[2][256 / MI_WAVE];
+  unsigned long long f = 0, r = 0;
+  for (int k = threadIdx.x; k < EW_SYM_SLOTS; k += 256) { f += sym[2 + 2 * k]; r += sym[3 + 2 * k]; }
+  f = wave_sum(f); r = wave_sum(r);
+  if ((threadIdx.x & (MI_WAVE - 1)) == 0) { part[0][threadIdx.x / MI_WAVE] = f; part[1][threadIdx.x / MI_WAVE] = r; }
+  __syncthreads();
+  f = 0; r = 0;
+#pragma unroll
+  for (int k = 0; k < 256 / MI_WAVE; ++k) { f += part[0][k]; r += part[1][k]; }
+  if (blockIdx.x == 0 && threadIdx.x == 0) { sym[0] = f; sym[1] = r; }
+  if (f == r) return;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= N) return;
   if (a3) { a3[3 * (size_t)i] = T(0); a3[3 * (size_t)i + 1] = T(0); a3[3 * (size_t)i + 2] = T(0); }
@@ -800,7 +804,6 @@ extern "C" int mi_ewald_real_forces_bwd(const void* positions, const void* charg
   do {                                                                                                                                         \
     if (sym) {  /* owner pass + checksums; the scatter variant behind it only works when the list turned out not to be symmetric */          \
       ewald_real_force_bwd_kernel<T_, CSR_, true><<<blocks, 256, 0, st>>>(MI_EFB_ARGS(T_), grad_cell, grad_alpha, part, sym);                  \
-      ew_sym_reduce_kernel<<<1, EW_SYM_SLOTS, 0, st>>>(sym);                                                                                   \
       ewald_fixup_zero_kernel<double><<<mi_blocks(n_atoms, 256), 256, 0, st>>>(sym, grad_positions, grad_charges, nullptr, n_atoms);            \
       ewald_real_force_bwd_kernel<T_, CSR_, false><<<blocks, 256, 0, st>>>(MI_EFB_ARGS(T_), nullptr, nullptr, nullptr, sym);                    \
     } else {                                                                                                                                   \
@@ -875,7 +878,6 @@ extern "C" int mi_ewald_real_bwd(const void* positions, const void* charges, con
   mi_timing_end(stream);
   MI_LAUNCH_CHECK();
   if (sym) {
-    ew_sym_reduce_kernel<<<1, EW_SYM_SLOTS, 0, st>>>(sym);
     if (dtype == MI_F32) { if (csr) MI_EWBS(float, true); else MI_EWBS(float, false); }
     else { if (csr) MI_EWBS(double, true); else MI_EWBS(double, false); }
     MI_LAUNCH_CHECK();
@@ -900,7 +902,7 @@ extern "C" int mi_ewald_real(const void* positions, const void* charges, const v
 #define MI_EW(T_, CSR_)                                                                                                                        \
   do {                                                                                                                                         \
     if (rec) {                                                                                                                                 \
-      ewald_pack_kernel<T_><<<mi_blocks(n_atoms, 256), 256, 0, st>>>((const T_*)positions, (const T_*)charges, n_atoms, (Vec4<T_>::type*)rec);  \
+      ewald_pack_kernel<T_><<<mi_blocks(n_atoms, 256), 256, 0, st>>>((const T_*)positions, (const T_*)charges, n_atoms, (Vec4<T_>::type*)rec, sym);  \
       ewald_real_kernel<T_, CSR_, true><<<blocks, 256, 0, st>>>((const T_*)positions, (const T_*)charges, (const T_*)cell, (const T_*)alpha,   \
                                                                 batch_idx, n_atoms, idx_j, unit_shifts, neighbor_ptr, max_neighbors, mask_value,  \
                                                                 flags, energies, (T_*)forces, charge_grads, sym, (const Vec4<T_>::type*)rec);  \
@@ -924,14 +926,13 @@ extern "C" int mi_ewald_real(const void* positions, const void* charges, const v
   // the symmetry check only matters for outputs that are scattered in the reference (forces, charge gradients); energies are per owner
   unsigned long long* sym = ((flags & (MI_EW_FORCES | MI_EW_CHARGE_GRAD)) && scratch_bytes >= sym_bytes) ? (unsigned long long*)scratch : nullptr;
   void* rec = scratch_bytes >= sym_bytes + rec_bytes ? (void*)((char*)scratch + sym_bytes) : nullptr;
-  if (sym) MI_HIP_CHECK(hipMemsetAsync(sym, 0, sizeof(unsigned long long) * EW_SYM_WORDS, st));
+  if (sym && !rec) MI_HIP_CHECK(hipMemsetAsync(sym, 0, sizeof(unsigned long long) * EW_SYM_WORDS, st));  // with records: cleared by the pack kernel
   mi_timing_begin("ewald_real", stream);
   if (dtype == MI_F32) { if (csr) MI_EW(float, true); else MI_EW(float, false); }
   else { if (csr) MI_EW(double, true); else MI_EW(double, false); }
   mi_timing_end(stream);
   MI_LAUNCH_CHECK();
   if (sym) {
-    ew_sym_reduce_kernel<<<1, EW_SYM_SLOTS, 0, st>>>(sym);
     if (dtype == MI_F32) { if (csr) MI_EWS(float, true); else MI_EWS(float, false); }
     else { if (csr) MI_EWS(double, true); else MI_EWS(double, false); }
     MI_LAUNCH_CHECK();

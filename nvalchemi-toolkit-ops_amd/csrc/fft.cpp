@@ -1,0 +1,109 @@
+// fft.cpp -- 3-D real <-> complex FFT plans over a batch of meshes (hipFFT on rocFFT), behind mi_fft_plan_{create,exec,destroy}.
+//
+// Replaces the torch.fft.rfftn / irfftn calls of the reciprocal-space PME pipeline (reference: interactions/electrostatics/pme.py:1398
+// forward, :1422 and :1455-1457 inverse; SURVEY.md 8(b) proposed these entry points).  Why the library owns the plans instead of going
+// through torch.fft: the multi-dimensional C2R transform of rocFFT may overwrite its input, so torch clones the spectrum before every
+// irfftn and copies the result once more (two 68 MB device copies per step on the headline box, ~48 us); here the convolved spectrum is
+// scratch of the same call, so the transform consumes it in place and writes the real meshes where the gather kernel reads them.
+//
+// Layout (both directions, contiguous, row-major): real [batch][nx][ny][nz], complex [batch][nx][ny][nz/2+1] interleaved (re, im).
+// Both transforms are UNSCALED: forward = torch.fft.rfftn(norm="backward"), inverse = torch.fft.irfftn(norm="forward").
+// A plan owns its rocFFT work area (allocated at creation, released at destruction); execution allocates nothing, never synchronises
+// and is capturable in a HIP graph.  A plan is bound to the device that was current at creation.
+#include <hip/hip_runtime_api.h>
+#include <hipfft/hipfft.h>
+#include <stddef.h>
+
+#include "../../include/nvalchemiops_hip.h"
+
+void mi_set_error(const char* fmt, ...);
+void mi_timing_begin(const char* name, void* stream);
+void mi_timing_end(void* stream);
+
+namespace {
+struct MiFftPlan {
+  hipfftHandle handle;
+  int nx, ny, nz, batch, dtype, inverse;
+  size_t work_bytes;
+};
+const char* fft_error(hipfftResult r) {
+  switch (r) {
+    case HIPFFT_SUCCESS: return "success";
+    case HIPFFT_INVALID_PLAN: return "invalid plan";
+    case HIPFFT_ALLOC_FAILED: return "allocation failed";
+    case HIPFFT_INVALID_VALUE: return "invalid value";
+    case HIPFFT_INTERNAL_ERROR: return "internal error";
+    case HIPFFT_EXEC_FAILED: return "execution failed";
+    case HIPFFT_SETUP_FAILED: return "setup failed";
+    case HIPFFT_INVALID_SIZE: return "invalid size";
+    default: return "hipFFT error";
+  }
+}
+}  // namespace
+
+#define MI_FFT_CHECK(expr)                                                               \
+  do {                                                                                   \
+    hipfftResult _r = (expr);                                                            \
+    if (_r != HIPFFT_SUCCESS) {                                                          \
+      mi_set_error("%s failed: %s (%s:%d)", #expr, fft_error(_r), __FILE__, __LINE__);  \
+      return MI_EHIP;                                                                    \
+    }                                                                                    \
+  } while (0)
+
+extern "C" {
+
+int mi_fft_plan_create(int nx, int ny, int nz, int batch, int dtype, int inverse, void** plan_out) {
+  if (!plan_out || nx <= 0 || ny <= 0 || nz <= 0 || batch <= 0 || (dtype != MI_F32 && dtype != MI_F64)) {
+    mi_set_error("invalid argument: mi_fft_plan_create(nx, ny, nz, batch > 0; dtype f32|f64; plan_out)");
+    return MI_EINVAL;
+  }
+  *plan_out = nullptr;
+  MiFftPlan* p = new MiFftPlan{0, nx, ny, nz, batch, dtype, inverse != 0, 0};
+  int n[3] = {nx, ny, nz};
+  const hipfftType type = dtype == MI_F32 ? (inverse ? HIPFFT_C2R : HIPFFT_R2C) : (inverse ? HIPFFT_Z2D : HIPFFT_D2Z);
+  hipfftResult r = hipfftCreate(&p->handle);
+  // (a channel-interleaved real side, [nx][ny][nz][batch] -- one 32-byte record per mesh point for the gather -- was probed in round 4:
+  // rocFFT runs the strided C2R 3x slower, 293 vs 94 us for 4 x 128^3 fp64: tools/probe/fft_layout.py, profiles/README.md)
+  if (r == HIPFFT_SUCCESS) r = hipfftMakePlanMany(p->handle, 3, n, nullptr, 1, 0, nullptr, 1, 0, type, batch, &p->work_bytes);
+  if (r != HIPFFT_SUCCESS) {
+    mi_set_error("hipFFT plan %dx%dx%d x %d (%s, %s) failed: %s", nx, ny, nz, batch, dtype == MI_F32 ? "f32" : "f64", inverse ? "C2R" : "R2C",
+                 fft_error(r));
+    if (p->handle) (void)hipfftDestroy(p->handle);
+    delete p;
+    return MI_EHIP;
+  }
+  *plan_out = p;
+  return MI_OK;
+}
+
+size_t mi_fft_plan_work_bytes(const void* plan) { return plan ? static_cast<const MiFftPlan*>(plan)->work_bytes : 0; }
+
+int mi_fft_plan_exec(void* plan, void* in, void* out, void* stream) {
+  MiFftPlan* p = static_cast<MiFftPlan*>(plan);
+  if (!p || !in || !out) {
+    mi_set_error("invalid argument: mi_fft_plan_exec(plan, in, out)");
+    return MI_EINVAL;
+  }
+  MI_FFT_CHECK(hipfftSetStream(p->handle, (hipStream_t)stream));
+  mi_timing_begin(p->inverse ? "fft_c2r" : "fft_r2c", stream);
+  hipfftResult r;
+  if (p->dtype == MI_F32)
+    r = p->inverse ? hipfftExecC2R(p->handle, (hipfftComplex*)in, (hipfftReal*)out) : hipfftExecR2C(p->handle, (hipfftReal*)in, (hipfftComplex*)out);
+  else
+    r = p->inverse ? hipfftExecZ2D(p->handle, (hipfftDoubleComplex*)in, (hipfftDoubleReal*)out)
+                   : hipfftExecD2Z(p->handle, (hipfftDoubleReal*)in, (hipfftDoubleComplex*)out);
+  mi_timing_end(stream);
+  MI_FFT_CHECK(r);
+  return MI_OK;
+}
+
+int mi_fft_plan_destroy(void* plan) {
+  MiFftPlan* p = static_cast<MiFftPlan*>(plan);
+  if (!p) return MI_OK;
+  hipfftResult r = hipfftDestroy(p->handle);
+  delete p;
+  MI_FFT_CHECK(r);
+  return MI_OK;
+}
+
+}  // extern "C"

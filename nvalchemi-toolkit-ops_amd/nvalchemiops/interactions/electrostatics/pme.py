@@ -17,6 +17,7 @@ from __future__ import annotations
 
 import functools
 import math
+import os
 
 import torch
 
@@ -161,6 +162,37 @@ def pme_energy_corrections_with_charge_grad(raw_energies, charges, cell, alpha, 
     return _corrections(raw_energies, charges, cell, alpha, batch_idx, True)
 
 
+class _FftPlan:
+    """One hipFFT plan of the library (`mi_fft_plan_create`, csrc/fft.cpp) kept for the life of the process."""
+
+    def __init__(self, dims, batch, code, inverse):
+        import ctypes
+
+        self.handle = ctypes.c_void_p()
+        C.check(C.lib().mi_fft_plan_create(int(dims[0]), int(dims[1]), int(dims[2]), int(batch), int(code), int(inverse), ctypes.byref(self.handle)),
+                "mi_fft_plan_create")
+
+    def __call__(self, src: torch.Tensor, dst: torch.Tensor) -> None:
+        C.check(C.lib().mi_fft_plan_exec(self.handle, C.ptr(src), C.ptr(dst), C.stream_of(src)), "mi_fft_plan_exec")
+
+
+_FFT_PLANS: dict = {}
+# NVALCHEMIOPS_PME_FFT=torch: the round-3 path (torch.fft.rfftn / irfftn: rocFFT behind torch's plan cache, two clones around the C2R) for A/B
+_OWN_FFT = os.environ.get("NVALCHEMIOPS_PME_FFT", "own") != "torch"
+
+
+def _fft_plan(device: torch.device, dims, batch: int, code: int, inverse: bool) -> _FftPlan:
+    """Plan cache keyed by (device, mesh, batch, dtype, direction).  Plans are created outside any HIP-graph capture (creation allocates
+    the work area); a step that is captured must have run once eagerly -- as every capture recipe does for its warm-up."""
+    key = (device.index, tuple(int(v) for v in dims), int(batch), int(code), bool(inverse))
+    plan = _FFT_PLANS.get(key)
+    if plan is None:
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("particle_mesh_ewald: run one eager step before capturing it in a HIP graph (FFT plans are created on first use)")
+        plan = _FFT_PLANS[key] = _FftPlan(dims, batch, code, inverse)
+    return plan
+
+
 def _reciprocal_fused(pos, q, cells, alpha, mesh_dimensions, spline_order, bi, compute_forces, compute_charge_gradients, add=(None, None, None),
                       k_vectors=None, k_squared=None):
     """The MI355X path: k-space algebra and the gather epilogue fused (k evaluated in registers).  `add` = (float64 energies, forces,
@@ -182,9 +214,16 @@ def _reciprocal_fused(pos, q, cells, alpha, mesh_dimensions, spline_order, bi, c
     al = alpha.to(dt).contiguous()
     # tile_order: the atoms grouped by mesh tile, a by-product of the tile-owned spread; the gather epilogue walks the atoms in that order
     mesh, tile_order = _launch_spread(pos, q, cit, bi, nsys, (nx, ny, nz), int(spline_order), batched, want_order=True)
-    spec = torch.fft.rfftn(mesh, norm="backward", dim=(1, 2, 3))  # unscaled forward (pme.py:1398)
     nch = 4 if compute_forces else 1
-    conv = torch.empty((nsys, nch, nx, ny, nz // 2 + 1), dtype=spec.dtype, device=dev)
+    cdt = torch.complex64 if dt == torch.float32 else torch.complex128
+    if _OWN_FFT:
+        # the library's own hipFFT plans (mi_fft_plan_*): the spectra and the real meshes are buffers of this call, so the C2R transform may
+        # consume its input in place -- torch.fft.irfftn has to clone it first and copies its result once more (2 x 68 MB per headline step)
+        spec = torch.empty((nsys, nx, ny, nz // 2 + 1), dtype=cdt, device=dev)
+        _fft_plan(dev, (nx, ny, nz), nsys, code, False)(mesh, spec)  # unscaled forward (pme.py:1398)
+    else:
+        spec = torch.fft.rfftn(mesh, norm="backward", dim=(1, 2, 3))
+    conv = torch.empty((nsys, nch, nx, ny, nz // 2 + 1), dtype=cdt, device=dev)
     # caller-supplied k arrays are READ by the same kernel instead of being evaluated in registers (the reference's benchmark protocol
     # passes them precomputed); [nx,ny,nzr(,3)] shared by all systems or with a leading batch dimension
     kv = k2 = None
@@ -205,7 +244,11 @@ def _reciprocal_fused(pos, q, cells, alpha, mesh_dimensions, spline_order, bi, c
     rc = C.lib().mi_pme_convolve(C.ptr(spec), C.ptr(recip), C.ptr(al), C.ptr(vol), nsys, nx, ny, nz, C.spline_order_arg(spline_order), int(compute_forces), code,
                                  C.ptr(kv), C.ptr(k2), k_batched, C.ptr(conv), st)
     C.check(rc, "mi_pme_convolve")
-    real = torch.fft.irfftn(conv, norm="forward", s=(nx, ny, nz), dim=(2, 3, 4)).contiguous()  # unscaled inverse (pme.py:1422)
+    if _OWN_FFT:
+        real = torch.empty((nsys, nch, nx, ny, nz), dtype=dt, device=dev)
+        _fft_plan(dev, (nx, ny, nz), nsys * nch, code, True)(conv, real)  # ONE batched unscaled inverse over all channels (pme.py:1422, 1455-1457)
+    else:
+        real = torch.fft.irfftn(conv, norm="forward", s=(nx, ny, nz), dim=(2, 3, 4)).contiguous()
     energies = torch.empty(n, dtype=dt, device=dev)
     forces = torch.empty((n, 3), dtype=dt, device=dev) if compute_forces else None
     cgrads = torch.empty(n, dtype=dt, device=dev) if compute_charge_gradients else None
