@@ -59,8 +59,8 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 VALU_PEAK_GINSTR = 256 * 4 * 2.4 / 2.0
 # VALU wave-instructions per launch of the VALU-bound kernels on the headline box, from the committed SQ_INSTS_VALU pass
 # (profiles/: counters cannot be read from inside the timed run)
-VALU_PROFILE = next((p for p in (os.path.join(ROOT, "profiles", n) for n in ("r03_pmc_valu.json", "r02_pmc_valu.json")) if os.path.exists(p)),
-                    os.path.join(ROOT, "profiles", "r03_pmc_valu.json"))
+VALU_PROFILE = next((p for p in (os.path.join(ROOT, "profiles", n) for n in ("r04_pmc_valu.json", "r03_pmc_valu.json", "r02_pmc_valu.json")) if os.path.exists(p)),
+                    os.path.join(ROOT, "profiles", "r04_pmc_valu.json"))
 PME = dict(cutoff=9.0, alpha=0.35, mesh=(128, 128, 128), order=5, max_neighbors=256)
 D3 = dict(cutoff=40.0, a1=0.4289, a2=4.4407, s8=0.7875, max_neighbors=2560)  # row width: explicit, as in the reference's own
 # D3 benchmark (benchmarks/interactions/dispersion/benchmark_dftd3.py:325-347 + its yaml `max_neighbors`); the fullest row of the headline box has 2497 entries
@@ -217,8 +217,18 @@ def make_step(sysd, tables, device, world):
         if need > md:
             md = D3["max_neighbors"] = (need + 63) // 64 * 64
         del trial
-        d3_bufs = (torch.empty((n, md), dtype=torch.int32, device=device), torch.empty((n, md, 3), dtype=torch.int32, device=device),
-                   torch.empty(n, dtype=torch.int32, device=device))
+        if os.environ.get("BENCH_ARENA"):
+            # tuning aid (list-fill drift): the two row buffers carved at 2 MiB-aligned offsets out of ONE large block
+            gib = float(os.environ["BENCH_ARENA"])
+            arena = torch.empty(int(gib * (1 << 30)), dtype=torch.uint8, device=device)
+            base = (-arena.data_ptr()) % (2 << 20)
+            nb_j, nb_s = n * md * 4, n * md * 12
+            off_s = base + (nb_j + (2 << 20) - 1) // (2 << 20) * (2 << 20)
+            d3_bufs = (arena[base:base + nb_j].view(torch.int32).view(n, md), arena[off_s:off_s + nb_s].view(torch.int32).view(n, md, 3),
+                       torch.empty(n, dtype=torch.int32, device=device))
+        else:
+            d3_bufs = (torch.empty((n, md), dtype=torch.int32, device=device), torch.empty((n, md, 3), dtype=torch.int32, device=device),
+                       torch.empty(n, dtype=torch.int32, device=device))
     gathered = [torch.zeros(2, dtype=torch.float64, device=device) for _ in range(world)] if world > 1 else None
     stage_ms = {}
     side = torch.cuda.Stream(device=device, priority=int(os.environ.get("BENCH_SIDE_PRIORITY", "0")))
@@ -330,7 +340,7 @@ def profile_lookup(path: str, kernel: str, field: str, atoms: int, workload: str
 
 
 def traffic_profile():
-    for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+    for name in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
         path = os.path.join(ROOT, "profiles", name)
         if os.path.exists(path):
             return path
@@ -968,6 +978,45 @@ def self_launch(n: int) -> int:
     return subprocess.run(cmd, env=env).returncode
 
 
+def fresh_processes(args) -> int:
+    """The headline line as the MEDIAN of `args.processes` fresh processes.  Every child is this script with
+    `--processes 1 --cpu-sample 0`: W warm-up + exactly K timed steps, barrier / synchronize on both sides, one JSON line.  This parent never
+    touches the GPU; it prints the child line with the median ms_per_step, adds `processes` (every child's step time, list-fill state and
+    calibration) and runs the CPU baseline once."""
+    argv = [a for a in sys.argv[1:]]
+    for flag in ("--processes", "--cpu-sample"):
+        while flag in argv:
+            k = argv.index(flag)
+            del argv[k:k + 2]
+        argv = [a for a in argv if not a.startswith(flag + "=")]
+    lines, t_children = [], time.perf_counter()
+    for k in range(args.processes):
+        r = subprocess.run([sys.executable, os.path.abspath(__file__)] + argv + ["--processes", "1", "--cpu-sample", "0"], capture_output=True, text=True)
+        out = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        if r.returncode != 0 or not out:
+            sys.stderr.write(r.stderr[-4000:])
+            return r.returncode or 1
+        lines.append(json.loads(out[-1]))
+    order = sorted(range(len(lines)), key=lambda k: lines[k]["ms_per_step"])
+    pick = order[len(order) // 2]
+    res = lines[pick]
+
+    def state(d):
+        k = d["kernels"].get("nl_query_matrix_f32", {})
+        return {"ms_per_step": d["ms_per_step"], "value": d["value"], "list_fill_40bohr_isolated_median_ms": k.get("isolated_median_ms"),
+                "list_fill_40bohr_in_step_ms": k.get("avg_ms_timed_region"), "d3_cn_in_step_ms": d["kernels"].get("d3_cn", {}).get("avg_ms_timed_region"),
+                "calibration_fill_GBps": (d.get("calibration") or {}).get("fill_GBps")}
+
+    res["processes"] = {"count": len(lines), "reported": f"process {pick + 1} of {len(lines)} (median ms_per_step)", "seconds_all": time.perf_counter() - t_children,
+                        "each": [state(d) for d in lines],
+                        "note": "fresh processes run one after the other; the list fill is in one of two states for the life of a process "
+                                "(placement of its row buffers by the driver: DESIGN.md 3.3), so the line is the median process, not a coin flip"}
+    if args.cpu_sample > 0:
+        res["cpu_baseline"] = cpu_baseline(args.cpu_sample, args.cpu_full_size)
+    print(json.dumps(res), flush=True)
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -985,6 +1034,10 @@ def main():
                     help="neighbour-list format of the D3 leg: padded matrix with explicit row width (default; what the reference's own D3 benchmark "
                          "uses) or exact-size COO/CSR (two-pass build)")
     ap.add_argument("--overlap", type=int, default=1, choices=[0, 1, 2, 3], help="1 (default): PME and D3 branches on two HIP streams; 0: one stream, per-stage times; 2: tuning aid")
+    ap.add_argument("--processes", type=int, default=0,
+                    help="headline, 1 GPU: run the timed region in this many FRESH processes one after the other and report the one with the median "
+                         "ms_per_step (default 3; 1 = time in this process).  The 40-Bohr list fill has two states that are fixed for the life of a "
+                         "process (0.82 / 1.13 ms: a property of where the driver places the row buffers, DESIGN.md 3.3): one process is a coin flip")
     args = ap.parse_args()
     global VIRIAL, OVERLAP, D3_FORMAT
     VIRIAL = not args.no_virial
@@ -993,6 +1046,11 @@ def main():
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args.gpus))
+    if args.processes == 0:
+        args.processes = 3 if (args.workload == "headline" and args.gpus == 1 and "WORLD_SIZE" not in os.environ
+                               and os.environ.get("BENCH_GRAPH") != "1") else 1
+    if args.processes > 1:
+        sys.exit(fresh_processes(args))
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))

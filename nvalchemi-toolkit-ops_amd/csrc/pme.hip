@@ -711,6 +711,61 @@ __global__ void pme_convolve_kernel(const Cplx<T>* __restrict__ spec, const T* _
   }
 }
 
+// ---- adjoint of the k-space pass w.r.t. its PARAMETERS (round 4: fused forward under autograd) -------------------------------------
+// L depends on the potential mesh phi = F^H D F rho only through <A, phi> (A = the spread of the upstream per-atom weights, a_hat its
+// unscaled spectrum), D_k = G(k^2; alpha, V) / sf2_k.  Hence dL/dtheta = sum_k h_k Re(conj(a_hat_k) rho_hat_k) / sf2_k * dG_k/dtheta over
+// the half spectrum with Hermitian weights h_k (1 on the planes kz = 0 and -- even nz -- kz = nz/2, else 2).  One pass produces, per
+// system, the 11 sums   [0] h Re(.) G / sf2                      -> dL/dV = -[0] / V
+//                        [1] h Re(.) G k^2 / (2 alpha^3) / sf2     =  dL/dalpha
+//                        [2 + 3 c + d] h Re(.) dG/dk^2 2 k_c m_d / sf2 = dL/d(2 pi cell^-1)[c][d]   (k_c = sum_d m_d recip[c][d])
+// as `partial[b][block][11]` in double (the caller folds the blocks: no same-address atomics).  Reference: the Warp tape differentiates
+// pme_kernels.py:121-331 + the torch glue of pme.py:1398-1422; this is the closed form of those adjoints.
+#define PME_BWD_BLOCKS 256
+template <class T>
+__global__ __launch_bounds__(256) void pme_convolve_bwd_kernel(const Cplx<T>* __restrict__ spec, const Cplx<T>* __restrict__ aspec,
+                                                              const T* __restrict__ recip, const T* __restrict__ alpha,
+                                                              const T* __restrict__ volume, int nx, int ny, int nz, int order,
+                                                              double* __restrict__ partial) {
+  const int b = blockIdx.y;
+  const int nzr = nz / 2 + 1;
+  const size_t per = (size_t)nx * ny * nzr;
+  const T* R = recip + 9 * (size_t)b;
+  const T al = alpha[b], vol = volume[b];
+  double acc[11];
+#pragma unroll
+  for (int q = 0; q < 11; ++q) acc[q] = 0.0;
+  for (size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x; r < per; r += (size_t)gridDim.x * blockDim.x) {
+    const int k = (int)(r % nzr), j = (int)((r / nzr) % ny), i = (int)(r / ((size_t)nzr * ny));
+    if (i == 0 && j == 0 && k == 0) continue;
+    const int mx = miller_of(i, nx), my = miller_of(j, ny), mz = k;
+    const T m[3] = {(T)mx, (T)my, (T)mz};
+    T kv[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) kv[c] = m[0] * R[3 * c] + m[1] * R[3 * c + 1] + m[2] * R[3 * c + 2];
+    const T k2 = kv[0] * kv[0] + kv[1] * kv[1] + kv[2] * kv[2];
+    if (!(k2 > T(1e-12)) || k2 < T(1e-10)) continue;  // clamped / masked in the forward pass: no dependence on the parameters
+    const T G = green_of(k2, al, vol, false);
+    const T sf2 = sf_sq_of<T>(mx, my, mz, nx, ny, nz, order);
+    const Cplx<T> v = spec[(size_t)b * per + r], a = aspec[(size_t)b * per + r];
+    const double h = (k == 0 || (2 * k == nz)) ? 1.0 : 2.0;
+    const double w = h * ((double)a.re * (double)v.re + (double)a.im * (double)v.im) / (double)sf2;
+    const double g = (double)G;
+    acc[0] += w * g;
+    acc[1] += w * g * (double)k2 / (2.0 * (double)al * (double)al * (double)al);
+    const double dg = w * g * (-1.0 / (4.0 * (double)al * (double)al) - 1.0 / (double)k2) * 2.0;
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+      for (int d = 0; d < 3; ++d) acc[2 + 3 * c + d] += dg * (double)kv[c] * (double)m[d];
+  }
+  __shared__ double part[4][11];
+  const int lane = threadIdx.x & (MI_WAVE - 1), wave = threadIdx.x / MI_WAVE;
+#pragma unroll
+  for (int q = 0; q < 11; ++q) { const double t = wave_sum(acc[q]); if (lane == 0) part[wave][q] = t; }
+  __syncthreads();
+  if (threadIdx.x < 11) partial[((size_t)b * gridDim.x + blockIdx.x) * 11 + threadIdx.x] = part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x];
+}
+
 template <class T>
 __global__ void pme_corrections_kernel(const T* __restrict__ raw, const T* __restrict__ q, const int* __restrict__ batch_idx,
                                        const T* __restrict__ vol, const T* __restrict__ alpha, const T* __restrict__ qtot, int N,
@@ -1015,6 +1070,22 @@ int mi_pme_convolve(const void* spec, const void* recip_cell, const void* alpha,
   MI_LAUNCH_CHECK();
   return MI_OK;
 }
+
+int mi_pme_convolve_bwd(const void* spec, const void* weight_spec, const void* recip_cell, const void* alpha, const void* volume, int n_systems,
+                        int nx, int ny, int nz, int order, int dtype, double* partial /*[n_systems][mi_pme_convolve_bwd_blocks()][11]*/, void* stream) {
+  MI_REQUIRE(dtype == MI_F32 || dtype == MI_F64, "dtype");
+  MI_REQUIRE(spec && weight_spec && recip_cell && alpha && volume && partial && n_systems >= 1, "null pointer");
+  order = decode_order(order).sf_exponent;
+  hipStream_t st = (hipStream_t)stream;
+  mi_timing_begin("pme_convolve_bwd", stream);
+  MI_DISPATCH_T(dtype, (pme_convolve_bwd_kernel<T_><<<dim3(PME_BWD_BLOCKS, n_systems), 256, 0, st>>>((const Cplx<T_>*)spec, (const Cplx<T_>*)weight_spec,
+                                                                                                    (const T_*)recip_cell, (const T_*)alpha,
+                                                                                                    (const T_*)volume, nx, ny, nz, order, partial)));
+  mi_timing_end(stream);
+  MI_LAUNCH_CHECK();
+  return MI_OK;
+}
+int mi_pme_convolve_bwd_blocks(void) { return PME_BWD_BLOCKS; }
 
 int mi_pme_gather_finish(const void* positions, const void* charges, const int32_t* batch_idx, const void* cell_inv_t, const void* meshes,
                          const void* alpha, const void* volume, const void* total_charge, int n_atoms, int n_systems, int nx, int ny, int nz,

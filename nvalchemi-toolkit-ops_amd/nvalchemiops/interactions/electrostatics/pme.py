@@ -179,6 +179,8 @@ class _FftPlan:
 _FFT_PLANS: dict = {}
 # NVALCHEMIOPS_PME_FFT=torch: the round-3 path (torch.fft.rfftn / irfftn: rocFFT behind torch's plan cache, two clones around the C2R) for A/B
 _OWN_FFT = os.environ.get("NVALCHEMIOPS_PME_FFT", "own") != "torch"
+# NVALCHEMIOPS_PME_FUSED_AUTOGRAD=0: energies under autograd through the op-by-op composition as in round 3 (A/B and cross-check of the adjoint)
+_FUSED_AUTOGRAD = os.environ.get("NVALCHEMIOPS_PME_FUSED_AUTOGRAD", "1") != "0"
 
 
 def _fft_plan(device: torch.device, dims, batch: int, code: int, inverse: bool) -> _FftPlan:
@@ -194,7 +196,7 @@ def _fft_plan(device: torch.device, dims, batch: int, code: int, inverse: bool) 
 
 
 def _reciprocal_fused(pos, q, cells, alpha, mesh_dimensions, spline_order, bi, compute_forces, compute_charge_gradients, add=(None, None, None),
-                      k_vectors=None, k_squared=None):
+                      k_vectors=None, k_squared=None, keep=None):
     """The MI355X path: k-space algebra and the gather epilogue fused (k evaluated in registers).  `add` = (float64 energies, forces,
     float64 charge gradients) of the real-space sum, added in the gather epilogue (particle_mesh_ewald's `real + reciprocal`)."""
     dt, dev = pos.dtype, pos.device
@@ -258,7 +260,167 @@ def _reciprocal_fused(pos, q, cells, alpha, mesh_dimensions, spline_order, bi, c
                                       C.ptr(add_e), C.ptr(add_f if compute_forces else None), C.ptr(add_cg if compute_charge_gradients else None),
                                       C.ptr(tile_order), st)
     C.check(rc, "mi_pme_gather_finish")
+    if keep is not None:  # what the hand-written adjoint of `_FusedReciprocal` needs: nothing here is recomputed in its backward
+        keep.update(spec=spec, phi=real[:, 0], cit=cit, recip=recip, vol=vol, qtot=qtot, alpha=al)
     return energies, forces, cgrads
+
+
+class _FusedReciprocal(torch.autograd.Function):
+    """Reciprocal-space PME ENERGIES under autograd with the fused forward kernels (round 4).
+
+    Until round 3 anything that required grad left the fused path for the op-by-op composition (`_reciprocal_composed`), 2.7x the inference
+    forward.  Here the forward IS the inference path (spread -> R2C -> fused k-space pass -> C2R -> fused gather + corrections) and keeps
+    what its adjoint needs -- the charge spectrum, the potential mesh, the per-atom charge gradients -- and the backward is the closed form
+    of what the reference's Warp tape + torch autograd compute for pme.py:1338-1479:
+
+        w = g q;  A = spread(w);  B = F^H D F A   (the k-space operator is self-adjoint);  psi = gather(B)
+        dL/dq   = g (phi - 2 q alpha/sqrt(pi) - pi Q/(2 alpha^2 V)) + psi - pi/(2 alpha^2 V) sum(w)
+        dL/dr   = [w grad_u gather(phi) + q grad_u gather(B)] . cell^-T          (u = fractional coordinates)
+        dL/dalpha, dL/dV, dL/d(2 pi cell^-1): one reduction over the two spectra (`mi_pme_convolve_bwd`) + the correction terms
+        dL/dcell: through cell^-T (fractional coordinates), 2 pi cell^-1 (k vectors) and V = |det cell|
+
+    First order only on this path: when the backward itself is being recorded (`create_graph=True`, e.g. forces by autograd inside a
+    force-matching loss) it re-runs the differentiable composition instead, so second derivatives keep working."""
+
+    @staticmethod
+    def forward(ctx, positions, charges, cells, alpha, mesh_dimensions, spline_order, batch_idx):
+        dt = positions.dtype
+        pos = positions.detach().contiguous()
+        q = charges.detach().to(dt).contiguous()
+        cc = cells.detach().to(dt).contiguous()
+        bi = None if batch_idx is None else C.i32(batch_idx)
+        keep = {}
+        energies, _, cg = _reciprocal_fused(pos, q, cc, alpha.detach(), mesh_dimensions, spline_order, bi, False, True, keep=keep)
+        ctx.save_for_backward(positions, charges, cells, alpha, keep["spec"], keep["phi"], cg, keep["cit"], keep["recip"], keep["vol"], keep["qtot"])
+        ctx.dims, ctx.order, ctx.bi, ctx.batch_idx = tuple(mesh_dimensions), int(spline_order), bi, batch_idx
+        return energies
+
+    @staticmethod
+    def backward(ctx, g_energies):
+        positions, charges, cells, alpha = ctx.saved_tensors[:4]
+        need = ctx.needs_input_grad
+        if torch.is_grad_enabled():
+            # the backward is being differentiated (create_graph=True): take it from the differentiable composition (which supports what
+            # it supports: second derivatives of the explicit outputs, NotImplementedError for those of autograd forces -- never a silent zero)
+            with torch.enable_grad():
+                e, _, _ = _reciprocal_composed(positions, charges, cells, alpha, ctx.dims, ctx.order, ctx.batch_idx, False, False)
+                inputs = [t for t, n in zip((positions, charges, cells, alpha), need[:4]) if n]
+                grads = iter(torch.autograd.grad(e, inputs, g_energies, create_graph=True, allow_unused=True))
+            return tuple(next(grads) if n else None for n in need[:4]) + (None, None, None)
+        return _reciprocal_energy_adjoint(ctx.saved_tensors, need, g_energies, ctx.dims, ctx.order, ctx.bi) + (None, None, None)
+
+
+def _reciprocal_energy_adjoint(saved, need, g_energies, dims, order, bi):
+    """(dL/dpositions, dL/dcharges, dL/dcells, dL/dalpha) of L = sum_i g_i E_i for the reciprocal-space energies, from what the fused forward
+    kept (formulas: `_FusedReciprocal`).  Raw launches on detached tensors: first order only."""
+    from nvalchemiops import _eops as E
+    from nvalchemiops.spline import _launch_gather
+
+    positions, charges, cells, alpha, spec, phi, cg, cit, recip, vol, qtot = saved
+    dt, dev = positions.dtype, positions.device
+    code = C.dtype_code(dt)
+    nx, ny, nz = dims
+    batched = bi is not None
+    nsys = cit.shape[0] if batched else 1
+    pos = positions.detach().contiguous()
+    q = charges.detach().to(dt).contiguous()
+    al = alpha.detach().to(dt).reshape(-1).contiguous()
+    g = g_energies.detach().to(dt).contiguous()
+    sel = bi.long() if batched else None
+    per = (lambda t: t[sel]) if batched else (lambda t: t[0])  # per-system value at every atom
+    st = C.stream_of(pos)
+    cdt = torch.complex64 if dt == torch.float32 else torch.complex128
+    # A = spread(g q), its spectrum, the parameter sums, B = K[A]
+    w = g * q
+    a_mesh = _launch_spread(pos, w, cit, bi, nsys, (nx, ny, nz), order, batched)
+    a_spec = torch.empty((nsys, nx, ny, nz // 2 + 1), dtype=cdt, device=dev)
+    _fft_plan(dev, (nx, ny, nz), nsys, code, False)(a_mesh, a_spec)
+    sums = None
+    if need[2] or (need[3] and alpha.dim() > 0):
+        nblk = int(C.lib().mi_pme_convolve_bwd_blocks())
+        partial = torch.empty((nsys, nblk, 11), dtype=torch.float64, device=dev)
+        C.check(C.lib().mi_pme_convolve_bwd(C.ptr(spec), C.ptr(a_spec), C.ptr(recip), C.ptr(al), C.ptr(vol), nsys, nx, ny, nz, C.spline_order_arg(order),
+                                            code, C.ptr(partial), st), "mi_pme_convolve_bwd")
+        sums = partial.sum(1).to(dt)  # [B, 11]
+    conv = torch.empty((nsys, 1, nx, ny, nz // 2 + 1), dtype=cdt, device=dev)
+    C.check(C.lib().mi_pme_convolve(C.ptr(a_spec), C.ptr(recip), C.ptr(al), C.ptr(vol), nsys, nx, ny, nz, C.spline_order_arg(order), 0, code,
+                                    None, None, 0, C.ptr(conv), st), "mi_pme_convolve")
+    b_mesh = torch.empty((nsys, nx, ny, nz), dtype=dt, device=dev)
+    _fft_plan(dev, (nx, ny, nz), nsys, code, True)(conv, b_mesh)
+    sqrt_pi = math.sqrt(math.pi)
+    a_i, v_i, qt_i = per(al), per(vol), per(qtot)
+    g_pos = g_q = g_cells = g_alpha = g_cit = None
+    if need[1]:
+        wsum = E.seg_sum(w, bi, nsys)  # sum_i g_i q_i per system
+        psi = _launch_gather(pos, b_mesh, cit, bi, order)
+        # phi_j from the forward's charge gradient 2 phi - 2 alpha q/sqrt(pi) - pi Q/(alpha^2 V)
+        phi_j = 0.5 * (cg + 2.0 * a_i * q / sqrt_pi + math.pi * qt_i / (a_i * a_i * v_i))
+        g_q = g * (phi_j - 2.0 * q * a_i / sqrt_pi - math.pi * qt_i / (2.0 * a_i * a_i * v_i)) + psi - math.pi / (2.0 * a_i * a_i * v_i) * per(wsum)
+        g_q = g_q.to(charges.dtype)
+    if need[0] or need[2]:
+        gfrac = w.unsqueeze(-1) * _launch_gather(pos, phi.contiguous(), cit, bi, order, grad=True) \
+            + q.unsqueeze(-1) * _launch_gather(pos, b_mesh, cit, bi, order, grad=True)
+        g_pos, g_cit = E._coordinate_grads(torch.ones_like(q), gfrac, pos, cit, bi)
+    if need[3] and alpha.dim() > 0:
+        corr = E.seg_sum(g * (-q * q / sqrt_pi + q * math.pi * qt_i / (a_i ** 3 * v_i)), bi, nsys)
+        g_alpha = (sums[:, 1] + corr).reshape(alpha.shape).to(alpha.dtype)
+    if need[2]:
+        g_vol = -sums[:, 0] / vol + E.seg_sum(g * q * math.pi * qt_i / (2.0 * a_i * a_i * v_i * v_i), bi, nsys)
+        inv_t = cit                      # cell^-T;  recip = 2 pi cell^-1
+        d_inv = 2.0 * math.pi * sums[:, 2:11].reshape(nsys, 3, 3) + g_cit.transpose(-1, -2)
+        g_cells = -(inv_t @ d_inv @ inv_t) + (g_vol * vol).reshape(-1, 1, 1) * inv_t
+        g_cells = g_cells.reshape(cells.shape).to(cells.dtype)
+    return (g_pos if need[0] else None), g_q, g_cells, g_alpha
+
+
+class _FusedPME(torch.autograd.Function):
+    """`particle_mesh_ewald` ENERGIES under autograd as ONE node: the inference step forward (real-space kernel, then the fused reciprocal
+    pipeline whose gather epilogue adds the real-space energies), `_reciprocal_energy_adjoint` + `mi_ewald_real_bwd` backward.  Saves the
+    custom-op dispatch of the real-space op and the torch add of the two parts that the round-3 path paid on every forward."""
+
+    @staticmethod
+    def forward(ctx, positions, charges, cells, alpha, mesh_dimensions, spline_order, batch_idx, mask_value, nl):
+        p = _real_space_inputs(positions, charges, cells, alpha, nl[0], nl[1], nl[2], nl[3], nl[4], batch_idx)
+        add = _real_space_launch(p, mask_value, False, False)
+        keep = {}
+        energies, _, cg = _reciprocal_fused(p["pos"], p["q"], p["cells"], p["alpha"], mesh_dimensions, spline_order, p["bi"], False, True,
+                                            add=(add[0], None, None), keep=keep)
+        ctx.save_for_backward(positions, charges, cells, alpha, keep["spec"], keep["phi"], cg, keep["cit"], keep["recip"], keep["vol"], keep["qtot"],
+                              *[t for t in nl if t is not None])
+        ctx.nl_present = [t is not None for t in nl]
+        ctx.dims, ctx.order, ctx.bi, ctx.batch_idx, ctx.mask_value = tuple(mesh_dimensions), int(spline_order), p["bi"], batch_idx, int(mask_value)
+        return energies
+
+    @staticmethod
+    def backward(ctx, g_energies):
+        saved = ctx.saved_tensors
+        positions, charges, cells, alpha = saved[:4]
+        rest = iter(saved[11:])
+        nl = [next(rest) if present else None for present in ctx.nl_present]
+        need = ctx.needs_input_grad
+        if torch.is_grad_enabled():  # create_graph=True: the differentiable composition (see _FusedReciprocal.backward)
+            with torch.enable_grad():
+                real = ewald_real_space(positions=positions, charges=charges, cell=cells, alpha=alpha, neighbor_list=nl[0], neighbor_ptr=nl[1],
+                                        neighbor_shifts=nl[2], neighbor_matrix=nl[3], neighbor_matrix_shifts=nl[4], mask_value=ctx.mask_value,
+                                        batch_idx=ctx.batch_idx)
+                rec, _, _ = _reciprocal_composed(positions, charges, cells, alpha, ctx.dims, ctx.order, ctx.batch_idx, False, False)
+                inputs = [t for t, n in zip((positions, charges, cells, alpha), need[:4]) if n]
+                grads = iter(torch.autograd.grad(real + rec, inputs, g_energies, create_graph=True, allow_unused=True))
+            return tuple(next(grads) if n else None for n in need[:4]) + (None,) * 5
+        from nvalchemiops import _eops as E
+
+        g_pos, g_q, g_cells, g_alpha = _reciprocal_energy_adjoint(saved[:11], need, g_energies, ctx.dims, ctx.order, ctx.bi)
+        r_pos, r_q, r_cell, r_alpha = E._real_bwd(positions, charges, cells, alpha, ctx.batch_idx, nl[0], nl[1], nl[2], nl[3], nl[4], ctx.mask_value,
+                                                  g_energies)
+        if need[0]:
+            g_pos = g_pos + r_pos.to(g_pos.dtype)
+        if need[1]:
+            g_q = g_q + r_q.to(g_q.dtype)
+        if need[2]:
+            g_cells = g_cells + r_cell.reshape(g_cells.shape).to(g_cells.dtype)
+        if need[3] and alpha.dim() > 0:
+            g_alpha = g_alpha + r_alpha.reshape(g_alpha.shape).to(g_alpha.dtype)
+        return (g_pos if need[0] else None), (g_q if need[1] else None), (g_cells if need[2] else None), g_alpha, None, None, None, None, None
 
 
 def _reciprocal_composed(positions, charges, cells, alpha, mesh_dimensions, spline_order, batch_idx, compute_forces, compute_charge_gradients,
@@ -348,8 +510,14 @@ def pme_reciprocal_space(positions: torch.Tensor, charges: torch.Tensor, cell: t
         C.dtype_code(dt)
         if composed:
             alpha_g = _traceable_alpha(alpha, num_systems, dt, dev)
-            energies, forces, cgrads = _reciprocal_composed(positions, charges, cells, alpha_g, mesh_dimensions, spline_order, batch_idx,
-                                                            compute_forces, compute_charge_gradients, k_vectors, k_squared)
+            fusable = (_FUSED_AUTOGRAD and not C.tracing() and not compute_forces and not compute_charge_gradients and k_vectors is None
+                       and k_squared is None and (batch_idx is None or cells.shape[0] == num_systems))
+            if fusable:
+                # energies only, eager autograd: the inference kernels forward, a hand-written adjoint backward (`_FusedReciprocal`)
+                energies, forces, cgrads = _FusedReciprocal.apply(positions, charges, cells, alpha_g, mesh_dimensions, spline_order, batch_idx), None, None
+            else:
+                energies, forces, cgrads = _reciprocal_composed(positions, charges, cells, alpha_g, mesh_dimensions, spline_order, batch_idx,
+                                                                compute_forces, compute_charge_gradients, k_vectors, k_squared)
         else:
             bi = None if batch_idx is None else C.i32(batch_idx)
             pos = positions.detach().contiguous()
@@ -405,6 +573,13 @@ def particle_mesh_ewald(positions: torch.Tensor, charges: torch.Tensor, cell: to
                                                          compute_forces, compute_charge_gradients, add=add)
             out = (energies,) + ((forces,) if compute_forces else ()) + ((cgrads,) if compute_charge_gradients else ())
             return out if len(out) > 1 else out[0]
+    if (wants_grad and _FUSED_AUTOGRAD and not C.tracing() and num_atoms > 0 and not compute_forces and not compute_charge_gradients
+            and k_vectors is None and k_squared is None
+            and ((neighbor_matrix is not None and neighbor_matrix.numel() > 0) or (neighbor_list is not None and neighbor_list.numel() > 0))):
+        # energies under eager autograd: ONE node, inference kernels forward, hand-written adjoints backward (`_FusedPME`)
+        C.require_device(positions, charges, cell, batch_idx)
+        return _FusedPME.apply(positions, charges, cells, alpha, tuple(int(v) for v in mesh_dimensions), spline_order, batch_idx, int(mask_value),
+                               (neighbor_list, neighbor_ptr, neighbor_shifts, neighbor_matrix, neighbor_matrix_shifts))
     real = ewald_real_space(positions=positions, charges=charges, cell=cells, alpha=alpha, neighbor_list=neighbor_list,
                             neighbor_ptr=neighbor_ptr, neighbor_shifts=neighbor_shifts, neighbor_matrix=neighbor_matrix,
                             neighbor_matrix_shifts=neighbor_matrix_shifts, mask_value=mask_value, batch_idx=batch_idx,

@@ -584,3 +584,115 @@ def test_direct_op_calls_without_cell_inv_t_give_the_cell_gradient():
                 cm[idx] -= eps
                 fd = (direct(cp) - direct(cm)).item() / (2 * eps)
                 assert abs(fd - g_direct[idx].item()) < 2e-5 * max(1.0, abs(fd)), (order, idx, fd, g_direct[idx].item())
+
+
+@pytest.mark.parametrize("batched", [False, True])
+@pytest.mark.parametrize("order", [4, 5])
+def test_fused_forward_under_autograd_equals_the_composition(batched, order, monkeypatch):
+    """Energies under autograd run the inference kernels forward and a hand-written adjoint backward (`pme._FusedReciprocal`, round 4).
+    Oracle for the adjoint: the op-by-op composition of round 3 (`_reciprocal_composed` = pme.py:1338-1479 step by step, itself checked
+    against explicit forces and finite differences above).  Random upstream weights; gradients w.r.t. positions, charges, the (triclinic)
+    cell and a per-system alpha tensor; fp64 to 1e-9, fp32 to 2e-4; one finite difference on the cell for good measure."""
+    from nvalchemiops.interactions.electrostatics import pme as P
+    from nvalchemiops.interactions.electrostatics import pme_reciprocal_space
+
+    pos, cell, q = _system(70, seed=5)
+    bi = None
+    if batched:
+        p2, c2, q2 = _system(50, box=9.0, seed=6)
+        pos, q, cell = torch.cat([pos, p2]), torch.cat([q, q2]), torch.stack([cell, c2])
+        bi = torch.tensor([0] * 70 + [1] * 50, dtype=torch.int32, device=DEV)
+    nsys = 2 if batched else 1
+    dims = (16, 18, 20)
+    gen = torch.Generator(device=DEV).manual_seed(1)
+    wts = torch.randn(pos.shape[0], dtype=torch.float64, device=DEV, generator=gen)
+    alpha0 = torch.tensor([0.42, 0.37][:nsys], dtype=torch.float64, device=DEV)
+
+    def grads(fused, dtype):
+        monkeypatch.setattr(P, "_FUSED_AUTOGRAD", fused)
+        p = pos.to(dtype).requires_grad_(True)
+        v = q.to(dtype).requires_grad_(True)
+        c = cell.to(dtype).requires_grad_(True)
+        a = alpha0.to(dtype).requires_grad_(True)
+        e = pme_reciprocal_space(p, v, c, a, mesh_dimensions=dims, spline_order=order, batch_idx=bi)
+        assert (type(e.grad_fn).__name__ == "_FusedReciprocalBackward") == fused
+        return (e.detach(),) + torch.autograd.grad((e * wts.to(dtype)).sum(), (p, v, c, a))
+
+    for dtype, tol in ((torch.float64, 1e-9), (torch.float32, 2e-4)):
+        got, want = grads(True, dtype), grads(False, dtype)
+        for a, b, what in zip(got, want, ("energies", "d/dpositions", "d/dcharges", "d/dcell", "d/dalpha")):
+            assert a.shape == b.shape and a.dtype == b.dtype, what
+            assert (a - b).abs().max().item() <= tol * max(1.0, b.abs().max().item()), (what, dtype, (a - b).abs().max().item())
+    # central difference on one cell entry (fused path, no grad needed for the evaluations)
+    monkeypatch.setattr(P, "_FUSED_AUTOGRAD", True)
+    g_cell = grads(True, torch.float64)[3]
+    eps = 1e-5
+    for idx in ((0, 1, 0), (nsys - 1, 2, 2)):
+        idx = idx if batched else idx[1:]
+        cp, cm = cell.clone(), cell.clone()
+        cp[idx] += eps
+        cm[idx] -= eps
+        f = lambda c_: (pme_reciprocal_space(pos, q, c_, alpha0, mesh_dimensions=dims, spline_order=order, batch_idx=bi) * wts).sum()  # noqa: E731
+        fd = (f(cp) - f(cm)) / (2 * eps)
+        assert abs(fd.item() - g_cell[idx].item()) < 2e-6 * max(1.0, abs(fd.item())), (idx, fd.item(), g_cell[idx].item())
+
+
+@pytest.mark.parametrize("fmt", ["matrix", "list"])
+def test_fused_particle_mesh_ewald_node_equals_the_composition(fmt, monkeypatch):
+    """`particle_mesh_ewald` energies under autograd as ONE node (`pme._FusedPME`: inference kernels forward, reciprocal adjoint +
+    `mi_ewald_real_bwd` backward) against the round-3 composition (real-space op + reciprocal ops + torch add): a batch of two triclinic
+    systems, random upstream weights, gradients w.r.t. positions, charges, cells and alpha to 1e-9."""
+    from nvalchemiops.interactions.electrostatics import particle_mesh_ewald
+    from nvalchemiops.interactions.electrostatics import pme as P
+    from nvalchemiops.neighborlist import batch_cell_list
+
+    p1, c1, q1 = _system(70, seed=5)
+    p2, c2, q2 = _system(50, box=9.5, seed=6)
+    pos, q, cell = torch.cat([p1, p2]), torch.cat([q1, q2]), torch.stack([c1, c2])
+    bi = torch.tensor([0] * 70 + [1] * 50, dtype=torch.int32, device=DEV)
+    pbc = torch.ones((2, 3), dtype=torch.bool, device=DEV)
+    if fmt == "matrix":
+        nm, num, sh = batch_cell_list(pos, 4.5, cell, pbc, bi, max_neighbors=96)
+        nl = dict(neighbor_matrix=nm, neighbor_matrix_shifts=sh)
+    else:
+        lst, ptr, lsh = batch_cell_list(pos, 4.5, cell, pbc, bi, return_neighbor_list=True)
+        nl = dict(neighbor_list=lst, neighbor_ptr=ptr, neighbor_shifts=lsh)
+    wts = torch.randn(120, dtype=torch.float64, device=DEV, generator=torch.Generator(device=DEV).manual_seed(2))
+    alpha0 = torch.tensor([0.45, 0.5], dtype=torch.float64, device=DEV)
+
+    def grads(fused):
+        monkeypatch.setattr(P, "_FUSED_AUTOGRAD", fused)
+        p, v, c, a = (t.clone().requires_grad_(True) for t in (pos, q, cell, alpha0))
+        e = particle_mesh_ewald(p, v, c, alpha=a, mesh_dimensions=(16, 16, 18), spline_order=4, batch_idx=bi, **nl)
+        assert (type(e.grad_fn).__name__ == "_FusedPMEBackward") == fused
+        return (e.detach(),) + torch.autograd.grad((e * wts).sum(), (p, v, c, a))
+
+    for a, b, what in zip(grads(True), grads(False), ("energies", "d/dpositions", "d/dcharges", "d/dcell", "d/dalpha")):
+        assert a.shape == b.shape and (a - b).abs().max().item() <= 1e-9 * max(1.0, b.abs().max().item()), (what, (a - b).abs().max().item())
+    # explicit forces of the inference path are minus the autograd gradient of the summed energies (test_pme.py:1458)
+    monkeypatch.setattr(P, "_FUSED_AUTOGRAD", True)
+    p = pos.clone().requires_grad_(True)
+    (gp,) = torch.autograd.grad(particle_mesh_ewald(p, q, cell, alpha=alpha0, mesh_dimensions=(16, 16, 18), spline_order=4, batch_idx=bi, **nl).sum(), p)
+    f = particle_mesh_ewald(pos, q, cell, alpha=alpha0, mesh_dimensions=(16, 16, 18), spline_order=4, batch_idx=bi, compute_forces=True, **nl)[1]
+    assert torch.allclose(-gp, f, rtol=1e-8, atol=1e-10)
+
+
+def test_fused_autograd_nodes_never_return_a_silent_second_derivative():
+    """create_graph=True through the fused nodes (forces by autograd inside a loss): their backward hands over to the differentiable
+    composition, which raises for second derivatives of the autograd position gradient exactly as it did in round 3 ("differentiate the
+    energies instead": the EXPLICIT force outputs are the differentiable ones) -- the fused path must not turn that into a silent zero."""
+    from nvalchemiops.interactions.electrostatics import pme as P
+    from nvalchemiops.interactions.electrostatics import pme_reciprocal_space
+
+    pos, cell, q = _system(40, seed=8)
+    dims = (12, 12, 14)
+    for fused in (True, False):
+        P._FUSED_AUTOGRAD = fused
+        try:
+            p = pos.clone().requires_grad_(True)
+            e = pme_reciprocal_space(p, q, cell, 0.4, mesh_dimensions=dims, spline_order=4)
+            (f,) = torch.autograd.grad(e.sum(), p, create_graph=True)
+            with pytest.raises(NotImplementedError, match="second derivatives"):
+                torch.autograd.grad((f ** 2).sum(), p)
+        finally:
+            P._FUSED_AUTOGRAD = True

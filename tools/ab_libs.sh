@@ -5,7 +5,7 @@ rounds=$1; shift
 L=nvalchemi-toolkit-ops_amd/nvalchemiops/lib
 for r in $(seq $rounds); do for v in "$@"; do
   cp $L/alt_$v.so $L/libnvalchemiops_hip.so
-  timeout 300 python bench.py --steps 40 --warmup 5 --cpu-sample 0 2>/dev/null | tail -1 | python -c "
+  timeout 300 python bench.py --processes 1 --steps 40 --warmup 5 --cpu-sample 0 2>/dev/null | tail -1 | python -c "
 import sys,json; d=json.loads(sys.stdin.read()); k=d['kernels']
 g=lambda n: round(k[n]['isolated_median_ms'],4) if n in k and k[n]['isolated_median_ms'] else None
 print('%-10s step %.3f (median %.3f) | nl_f32 %s cn %s energy %s chain %s | nl_f64 %s ewald %s spread %s gather %s build %s' % ('$v', d['ms_per_step'], d['stats']['step_ms_median'],

@@ -14,9 +14,9 @@ if [[ $WHAT == all || $WHAT == tests ]]; then
   cp gpurun_out/d3_error_budget.json $OUT/ 2>/dev/null
 fi
 if [[ $WHAT == all || $WHAT == bench ]]; then
-  timeout 600 python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err; echo "bench rc=$?"
-  timeout 300 python bench.py --steps 20 --warmup 5 --cpu-sample 0 > $OUT/bench_k20.json 2>> $OUT/bench_default.err
-  timeout 300 python bench.py --overlap 0 --steps 50 --cpu-sample 0 > $OUT/bench_serial.json 2>> $OUT/bench_default.err
+  timeout 600 python bench.py --processes 1 > $OUT/bench_default.json 2> $OUT/bench_default.err; echo "bench rc=$?"
+  timeout 300 python bench.py --processes 1 --steps 20 --warmup 5 --cpu-sample 0 > $OUT/bench_k20.json 2>> $OUT/bench_default.err
+  timeout 300 python bench.py --processes 1 --overlap 0 --steps 50 --cpu-sample 0 > $OUT/bench_serial.json 2>> $OUT/bench_default.err
   timeout 300 python bench.py --workload c5 --steps 20 --warmup 3 > $OUT/bench_c5.json 2>> $OUT/bench_default.err
   timeout 600 python bench.py --gpus 2 --steps 20 --warmup 3 --cpu-sample 0 > $OUT/bench_gpus2.json 2> $OUT/bench_gpus2.err; echo "gpus2 rc=$?"
   head -c 1500 $OUT/bench_default.json; echo

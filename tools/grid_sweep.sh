@@ -1,6 +1,6 @@
 export TMPDIR=/tmp BENCH_CALIB=0
 for g in 1536 1280 1024 768 2048; do
-NVALCHEMIOPS_NL_TILED_GRID=$g timeout 300 python bench.py --steps 40 --warmup 5 --cpu-sample 0 2>/dev/null | tail -1 | python -c "
+NVALCHEMIOPS_NL_TILED_GRID=$g timeout 300 python bench.py --processes 1 --steps 40 --warmup 5 --cpu-sample 0 2>/dev/null | tail -1 | python -c "
 import sys,json; d=json.loads(sys.stdin.read()); k=d['kernels']
 g=lambda n: round(k[n]['isolated_median_ms'],4)
 t=lambda n: round(k[n]['median_ms_timed_region'],4)
