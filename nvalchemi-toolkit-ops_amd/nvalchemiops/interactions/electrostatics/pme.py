@@ -553,7 +553,10 @@ def particle_mesh_ewald(positions: torch.Tensor, charges: torch.Tensor, cell: to
         if mesh_dimensions is None and mesh_spacing is None:
             mesh_dimensions = tuple(est.mesh_dimensions)
     wants_grad = C.tracing() or (torch.is_grad_enabled() and any(isinstance(t, torch.Tensor) and t.requires_grad for t in (positions, charges, cell, alpha)))
-    alpha = (_traceable_alpha if wants_grad else _prepare_alpha)(alpha, num_systems, positions.dtype, positions.device)
+    # a Python-float alpha under eager autograd needs no gradient: the cached constant tensor serves (no fill kernel per call); the
+    # uncached form is for traces (an lru_cache'd helper is opaque to TorchDynamo) and for tensors that carry a graph
+    plain_alpha = isinstance(alpha, (int, float)) and not C.tracing()
+    alpha = (_traceable_alpha if (wants_grad and not plain_alpha) else _prepare_alpha)(alpha, num_systems, positions.dtype, positions.device)
     if mask_value is None:
         mask_value = num_atoms
     if mesh_dimensions is None:
