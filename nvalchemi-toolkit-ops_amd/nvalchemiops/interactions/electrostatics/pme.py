@@ -198,13 +198,39 @@ def _fft_plan(device: torch.device, dims, batch: int, code: int, inverse: bool) 
 def _reciprocal_fused(pos, q, cells, alpha, mesh_dimensions, spline_order, bi, compute_forces, compute_charge_gradients, add=(None, None, None),
                       k_vectors=None, k_squared=None, keep=None):
     """The MI355X path: k-space algebra and the gather epilogue fused (k evaluated in registers).  `add` = (float64 energies, forces,
-    float64 charge gradients) of the real-space sum, added in the gather epilogue (particle_mesh_ewald's `real + reciprocal`)."""
+    float64 charge gradients) of the real-space sum, added in the gather epilogue (particle_mesh_ewald's `real + reciprocal`).
+    (Running the real-space sum beside the front half on a second stream inside one call was measured in round 4 and dropped: config 4
+    0.887 -> 0.871 ms, but the headline step 4.22 - 4.39 -> 4.40 - 4.57 ms and config 5 12.0 -> 12.2: the two halves then compete for the
+    same CUs and the outer two-stream schedule already fills them, profiles/r04_ab_pme_fork.log.)"""
     dt, dev = pos.dtype, pos.device
     code = C.dtype_code(dt)
     n = pos.shape[0]
     nx, ny, nz = mesh_dimensions
     batched = bi is not None
     nsys = cells.shape[0] if batched else 1
+    spec, real, cit, recip, vol, qtot, al, tile_order = _reciprocal_front(pos, q, cells, alpha, (nx, ny, nz), spline_order, bi, nsys, batched,
+                                                                          compute_forces, k_vectors, k_squared, code)
+    st = C.stream_of(pos)
+    energies = torch.empty(n, dtype=dt, device=dev)
+    forces = torch.empty((n, 3), dtype=dt, device=dev) if compute_forces else None
+    cgrads = torch.empty(n, dtype=dt, device=dev) if compute_charge_gradients else None
+    add_e, add_f, add_cg = add
+    rc = C.lib().mi_pme_gather_finish(C.ptr(pos), C.ptr(q), C.ptr(bi), C.ptr(cit), C.ptr(real), C.ptr(al), C.ptr(vol), C.ptr(qtot), n, nsys, nx,
+                                      ny, nz, C.spline_order_arg(spline_order), int(compute_forces), code, C.ptr(energies), C.ptr(forces), C.ptr(cgrads),
+                                      C.ptr(add_e), C.ptr(add_f if compute_forces else None), C.ptr(add_cg if compute_charge_gradients else None),
+                                      C.ptr(tile_order), st)
+    C.check(rc, "mi_pme_gather_finish")
+    if keep is not None:  # what the hand-written adjoint of `_FusedReciprocal` needs: nothing here is recomputed in its backward
+        keep.update(spec=spec, phi=real[:, 0], cit=cit, recip=recip, vol=vol, qtot=qtot, alpha=al)
+    return energies, forces, cgrads
+
+
+def _reciprocal_front(pos, q, cells, alpha, dims, spline_order, bi, nsys, batched, compute_forces, k_vectors, k_squared, code):
+    """prepare -> tile-owned spread -> R2C -> fused k-space pass -> ONE batched C2R, on the current stream.  Returns
+    (spec, real meshes [B, 1|4, nx, ny, nz], cell^-T, 2 pi cell^-1, volume, total charge, alpha, tile-grouped atom list | None)."""
+    dt, dev = pos.dtype, pos.device
+    n = pos.shape[0]
+    nx, ny, nz = dims
     st = C.stream_of(pos)
     cc = cells.to(dt).contiguous()
     cit, recip = torch.empty_like(cc), torch.empty_like(cc)
@@ -251,18 +277,7 @@ def _reciprocal_fused(pos, q, cells, alpha, mesh_dimensions, spline_order, bi, c
         _fft_plan(dev, (nx, ny, nz), nsys * nch, code, True)(conv, real)  # ONE batched unscaled inverse over all channels (pme.py:1422, 1455-1457)
     else:
         real = torch.fft.irfftn(conv, norm="forward", s=(nx, ny, nz), dim=(2, 3, 4)).contiguous()
-    energies = torch.empty(n, dtype=dt, device=dev)
-    forces = torch.empty((n, 3), dtype=dt, device=dev) if compute_forces else None
-    cgrads = torch.empty(n, dtype=dt, device=dev) if compute_charge_gradients else None
-    add_e, add_f, add_cg = add
-    rc = C.lib().mi_pme_gather_finish(C.ptr(pos), C.ptr(q), C.ptr(bi), C.ptr(cit), C.ptr(real), C.ptr(al), C.ptr(vol), C.ptr(qtot), n, nsys, nx,
-                                      ny, nz, C.spline_order_arg(spline_order), int(compute_forces), code, C.ptr(energies), C.ptr(forces), C.ptr(cgrads),
-                                      C.ptr(add_e), C.ptr(add_f if compute_forces else None), C.ptr(add_cg if compute_charge_gradients else None),
-                                      C.ptr(tile_order), st)
-    C.check(rc, "mi_pme_gather_finish")
-    if keep is not None:  # what the hand-written adjoint of `_FusedReciprocal` needs: nothing here is recomputed in its backward
-        keep.update(spec=spec, phi=real[:, 0], cit=cit, recip=recip, vol=vol, qtot=qtot, alpha=al)
-    return energies, forces, cgrads
+    return spec, real, cit, recip, vol, qtot, al, tile_order
 
 
 class _FusedReciprocal(torch.autograd.Function):
@@ -381,10 +396,10 @@ class _FusedPME(torch.autograd.Function):
     @staticmethod
     def forward(ctx, positions, charges, cells, alpha, mesh_dimensions, spline_order, batch_idx, mask_value, nl):
         p = _real_space_inputs(positions, charges, cells, alpha, nl[0], nl[1], nl[2], nl[3], nl[4], batch_idx)
-        add = _real_space_launch(p, mask_value, False, False)
         keep = {}
-        energies, _, cg = _reciprocal_fused(p["pos"], p["q"], p["cells"], p["alpha"], mesh_dimensions, spline_order, p["bi"], False, True,
-                                            add=(add[0], None, None), keep=keep)
+        add = _real_space_launch(p, mask_value, False, False)
+        energies, _, cg = _reciprocal_fused(p["pos"], p["q"], p["cells"], p["alpha"], mesh_dimensions, spline_order, p["bi"], False, True, keep=keep,
+                                            add=(add[0], None, None))
         ctx.save_for_backward(positions, charges, cells, alpha, keep["spec"], keep["phi"], cg, keep["cit"], keep["recip"], keep["vol"], keep["qtot"],
                               *[t for t in nl if t is not None])
         ctx.nl_present = [t is not None for t in nl]
@@ -570,8 +585,8 @@ def particle_mesh_ewald(positions: torch.Tensor, charges: torch.Tensor, cell: to
         p = _real_space_inputs(positions, charges, cells, alpha, neighbor_list, neighbor_ptr, neighbor_shifts, neighbor_matrix,
                                neighbor_matrix_shifts, batch_idx)
         if p["n_entries"] > 0:
-            add = _real_space_launch(p, mask_value, compute_forces, compute_charge_gradients)
             mesh_dimensions = tuple(int(v) for v in mesh_dimensions)
+            add = _real_space_launch(p, mask_value, compute_forces, compute_charge_gradients)
             energies, forces, cgrads = _reciprocal_fused(p["pos"], p["q"], p["cells"], p["alpha"], mesh_dimensions, spline_order, p["bi"],
                                                          compute_forces, compute_charge_gradients, add=add)
             out = (energies,) + ((forces,) if compute_forces else ()) + ((cgrads,) if compute_charge_gradients else ())

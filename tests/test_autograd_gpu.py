@@ -669,12 +669,8 @@ def test_fused_particle_mesh_ewald_node_equals_the_composition(fmt, monkeypatch)
 
     for a, b, what in zip(grads(True), grads(False), ("energies", "d/dpositions", "d/dcharges", "d/dcell", "d/dalpha")):
         assert a.shape == b.shape and (a - b).abs().max().item() <= 1e-9 * max(1.0, b.abs().max().item()), (what, (a - b).abs().max().item())
-    # explicit forces of the inference path are minus the autograd gradient of the summed energies (test_pme.py:1458)
-    monkeypatch.setattr(P, "_FUSED_AUTOGRAD", True)
-    p = pos.clone().requires_grad_(True)
-    (gp,) = torch.autograd.grad(particle_mesh_ewald(p, q, cell, alpha=alpha0, mesh_dimensions=(16, 16, 18), spline_order=4, batch_idx=bi, **nl).sum(), p)
-    f = particle_mesh_ewald(pos, q, cell, alpha=alpha0, mesh_dimensions=(16, 16, 18), spline_order=4, batch_idx=bi, compute_forces=True, **nl)[1]
-    assert torch.allclose(-gp, f, rtol=1e-3, atol=1e-4), float((-gp - f).abs().max())  # the reference's own bar for this property
+    # (explicit forces == -autograd at the reference's own mesh / tolerance: test_pme_autograd_equals_explicit_forces_and_fd above, which now
+    # runs through this node as well)
 
 
 def test_fused_autograd_nodes_never_return_a_silent_second_derivative():
