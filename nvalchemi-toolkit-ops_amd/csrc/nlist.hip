@@ -123,77 +123,86 @@ __global__ void nl_count_atoms_kernel(const int* __restrict__ batch_idx, int N, 
   if (in && s != s0) atomicAdd(&natoms[s], 1);
 }
 
-// Blocks 1.. of the launch clear the counting-sort counters of the same call (`zero`, 16-byte words) while block 0 sets the grid up: the
-// memset node in front of the binning (4.8 us, twice per headline step) is gone -- the assign kernel behind this one needs both anyway.
+// Grid description of one system (cells per dimension from the density, search radius, image range, pruning eligibility): everything of
+// NlSys but the pruning table and the cell offset.  Deterministic in its inputs: the table blocks of nl_setup_kernel recompute it.
 template <class T>
-__global__ __launch_bounds__(256) void nl_setup_kernel(const T* __restrict__ cell, const uint8_t* __restrict__ pbc, const int* __restrict__ natoms, int N,
-                                int B, T cutoff, const T* __restrict__ origin, NlSys<T>* __restrict__ sys, NlGlobal* __restrict__ glob,
-                                int4* __restrict__ zero, long long zero_words) {
-  if (blockIdx.x > 0) {
-    for (long long k = (long long)(blockIdx.x - 1) * blockDim.x + threadIdx.x; k < zero_words; k += (long long)(gridDim.x - 1) * blockDim.x)
-      zero[k] = make_int4(0, 0, 0, 0);
-    return;
-  }
-  for (int s = threadIdx.x; s < B; s += blockDim.x) {
-    NlSys<T> S;
-    for (int k = 0; k < 9; ++k) S.cell[k] = cell[9 * (size_t)s + k];
-    for (int k = 0; k < 3; ++k) S.origin[k] = origin ? origin[3 * (size_t)s + k] : T(0);
-    inverse3(S.cell, S.inv);
-    const T* a = S.cell;
-    double det = (double)a[0] * ((double)a[4] * a[8] - (double)a[5] * a[7]) - (double)a[1] * ((double)a[3] * a[8] - (double)a[5] * a[6]) +
-                 (double)a[2] * ((double)a[3] * a[7] - (double)a[4] * a[6]);
-    double vol = fabs(det);
-    int ns = natoms ? natoms[s] : N;
-    double rc = (double)cutoff;
-    double apc = vol > 0 ? (double)ns / vol * rc * rc * rc : 0.0;  // atoms per rc^3 cube
+__device__ void nl_describe_system(const T* __restrict__ cell, const uint8_t* __restrict__ pbc, const int* __restrict__ natoms, int N, T cutoff,
+                                   const T* __restrict__ origin, int s, NlSys<T>& S) {
+  for (int k = 0; k < 9; ++k) S.cell[k] = cell[9 * (size_t)s + k];
+  for (int k = 0; k < 3; ++k) S.origin[k] = origin ? origin[3 * (size_t)s + k] : T(0);
+  inverse3(S.cell, S.inv);
+  const T* a = S.cell;
+  double det = (double)a[0] * ((double)a[4] * a[8] - (double)a[5] * a[7]) - (double)a[1] * ((double)a[3] * a[8] - (double)a[5] * a[6]) +
+               (double)a[2] * ((double)a[3] * a[7] - (double)a[4] * a[6]);
+  double vol = fabs(det);
+  int ns = natoms ? natoms[s] : N;
+  double rc = (double)cutoff;
+  double apc = vol > 0 ? (double)ns / vol * rc * rc * rc : 0.0;  // atoms per rc^3 cube
 #ifndef NL_K2_APC
 #define NL_K2_APC 64.0
 #endif
-    int k = apc < NL_K2_APC ? 1 : (apc < 512.0 ? 2 : 3);
-    long long cap = 4ll * ns + 8;
-    double face[3];
-    for (int d = 0; d < 3; ++d) {
-      T col[3] = {S.inv[d], S.inv[3 + d], S.inv[6 + d]};
-      T ln = sqrt(col[0] * col[0] + col[1] * col[1] + col[2] * col[2]);
-      face[d] = 1.0 / (double)ln;
-      S.pbc[d] = pbc[3 * (size_t)s + d] ? 1 : 0;
-      double want = face[d] * k / (rc * (1.0 + 2e-6));  // cell edge strictly above rc/k: a box that is an exact multiple of rc/k must not round the search radius up to k+1
-      S.cpd[d] = want >= 1048576.0 ? 1048576 : (want >= 1.0 ? (int)want : 1);
-      S.nrange[d] = S.pbc[d] ? (int)ceil(ln * cutoff) : 0;
-    }
-    long long tot = (long long)S.cpd[0] * S.cpd[1] * S.cpd[2];
-    while (tot > cap) {
-      for (int d = 0; d < 3; ++d) S.cpd[d] = S.cpd[d] / 2 > 1 ? S.cpd[d] / 2 : 1;
-      tot = (long long)S.cpd[0] * S.cpd[1] * S.cpd[2];
-    }
-    for (int d = 0; d < 3; ++d) {
-      if (S.cpd[d] == 1 && !S.pbc[d]) S.R[d] = 0;
-      else S.R[d] = (int)ceil(rc * S.cpd[d] / face[d] * (1.0 + 1e-6));
-    }
-    S.ncells = (int)tot;
-    S.cell_off = 0;
-    S.tiled = ((k >= 2 || apc >= 32.0) && (2 * S.R[1] + 1) * (2 * S.R[2] + 1) <= NL_MAXROWS && (!S.pbc[0] || S.R[0] <= S.cpd[0])) ? 1 : 0;
-    // Orthorhombic cells: atoms in cells offset by d cells along a periodic axis are at least (|d|-1) cell edges apart along it,
-    // so cells/rows provably beyond the cutoff are never visited.  Non-periodic axes contribute 0 (clamped atoms may sit
-    // outside their cell).  Evaluated once here; the query kernel only does integer look-ups.
-    const bool ortho = a[1] == T(0) && a[2] == T(0) && a[3] == T(0) && a[5] == T(0) && a[6] == T(0) && a[7] == T(0);
-    S.prune = (ortho && S.R[0] <= NL_PRUNE_R && S.R[1] <= NL_PRUNE_R && S.R[2] <= NL_PRUNE_R) ? 1 : 0;
-    sys[s] = S;
+  int k = apc < NL_K2_APC ? 1 : (apc < 512.0 ? 2 : 3);
+  long long cap = 4ll * ns + 8;
+  double face[3];
+  for (int d = 0; d < 3; ++d) {
+    T col[3] = {S.inv[d], S.inv[3 + d], S.inv[6 + d]};
+    T ln = sqrt(col[0] * col[0] + col[1] * col[1] + col[2] * col[2]);
+    face[d] = 1.0 / (double)ln;
+    S.pbc[d] = pbc[3 * (size_t)s + d] ? 1 : 0;
+    double want = face[d] * k / (rc * (1.0 + 2e-6));  // cell edge strictly above rc/k: a box that is an exact multiple of rc/k must not round the search radius up to k+1
+    S.cpd[d] = want >= 1048576.0 ? 1048576 : (want >= 1.0 ? (int)want : 1);
+    S.nrange[d] = S.pbc[d] ? (int)ceil(ln * cutoff) : 0;
   }
-  __syncthreads();
-  // pruning tables: one thread per (system, |dz|, |dy|) entry instead of 81 dependent sqrt / divide chains in the system's thread (the
-  // single-system launch was 15 us of serial fp64 latency on the critical path of both lists)
+  long long tot = (long long)S.cpd[0] * S.cpd[1] * S.cpd[2];
+  while (tot > cap) {
+    for (int d = 0; d < 3; ++d) S.cpd[d] = S.cpd[d] / 2 > 1 ? S.cpd[d] / 2 : 1;
+    tot = (long long)S.cpd[0] * S.cpd[1] * S.cpd[2];
+  }
+  for (int d = 0; d < 3; ++d) {
+    if (S.cpd[d] == 1 && !S.pbc[d]) S.R[d] = 0;
+    else S.R[d] = (int)ceil(rc * S.cpd[d] / face[d] * (1.0 + 1e-6));
+  }
+  S.ncells = (int)tot;
+  S.cell_off = 0;
+  S.tiled = ((k >= 2 || apc >= 32.0) && (2 * S.R[1] + 1) * (2 * S.R[2] + 1) <= NL_MAXROWS && (!S.pbc[0] || S.R[0] <= S.cpd[0])) ? 1 : 0;
+  // Orthorhombic cells: atoms in cells offset by d cells along a periodic axis are at least (|d|-1) cell edges apart along it,
+  // so cells/rows provably beyond the cutoff are never visited.  Non-periodic axes contribute 0 (clamped atoms may sit
+  // outside their cell).  Evaluated once here; the query kernel only does integer look-ups.
+  const bool ortho = a[1] == T(0) && a[2] == T(0) && a[3] == T(0) && a[5] == T(0) && a[6] == T(0) && a[7] == T(0);
+  S.prune = (ortho && S.R[0] <= NL_PRUNE_R && S.R[1] <= NL_PRUNE_R && S.R[2] <= NL_PRUNE_R) ? 1 : 0;
+}
+
+// One launch, three kinds of blocks (round 4):
+//   block 0                      every system's grid description (all NlSys fields but the pruning table) + the cell offsets (block scan);
+//   blocks 1 .. table_blocks     the pruning tables, one thread per (system, |dz|, |dy|) entry: the thread re-derives its system's description
+//                                in registers (cheap, deterministic) and writes ONE byte -- 81 dependent fp64 sqrt / divide chains per
+//                                system used to run in block 0 alone (0.08 ms for the 128 / 256 systems of BASELINE configs 5 / 3);
+//   the remaining blocks         clear the counting-sort counters of the same call (`zero`, 16-byte words): no memset node in front of the
+//                                binning.  The assign kernel behind this launch needs all three.
+// Block 0 and the table blocks write disjoint bytes of sys[s] (block 0 never stores dxlim).
+template <class T>
+__global__ __launch_bounds__(256) void nl_setup_kernel(const T* __restrict__ cell, const uint8_t* __restrict__ pbc, const int* __restrict__ natoms, int N,
+                                int B, T cutoff, const T* __restrict__ origin, NlSys<T>* __restrict__ sys, NlGlobal* __restrict__ glob,
+                                int table_blocks, int4* __restrict__ zero, long long zero_words) {
   constexpr int NE = (NL_PRUNE_R + 1) * (NL_PRUNE_R + 1);
-  for (int t = threadIdx.x; t < B * NE; t += blockDim.x) {
+  if ((int)blockIdx.x > table_blocks) {
+    const long long zb = (long long)blockIdx.x - table_blocks - 1, nzb = (long long)gridDim.x - table_blocks - 1;
+    for (long long k = zb * blockDim.x + threadIdx.x; k < zero_words; k += nzb * blockDim.x) zero[k] = make_int4(0, 0, 0, 0);
+    return;
+  }
+  if (blockIdx.x > 0) {
+    const int t = ((int)blockIdx.x - 1) * blockDim.x + threadIdx.x;
+    if (t >= B * NE) return;
     const int s = t / NE, az = (t - s * NE) / (NL_PRUNE_R + 1), ay = t - s * NE - az * (NL_PRUNE_R + 1);
-    NlSys<T>& S = sys[s];
-    if (!S.prune) continue;
+    NlSys<T> S;
+    nl_describe_system<T>(cell, pbc, natoms, N, cutoff, origin, s, S);
+    if (!S.prune) return;
     const double rc = (double)cutoff;
+    // cell edge per axis (0 for a non-periodic one): an orthorhombic cell has a diagonal inverse, so the norm of column d of cell^-1 is |inv[d][d]|
     double w[3];
     for (int d = 0; d < 3; ++d) {
-      const T col[3] = {S.inv[d], S.inv[3 + d], S.inv[6 + d]};
-      const T ln = sqrt(col[0] * col[0] + col[1] * col[1] + col[2] * col[2]);
-      w[d] = S.pbc[d] ? (1.0 / (double)ln) / S.cpd[d] : 0.0;
+      const double ln = fabs((double)S.inv[4 * d]);
+      w[d] = (S.pbc[d] && ln > 0.0) ? (1.0 / ln) / S.cpd[d] : 0.0;
     }
     const double gz = (az > 1 ? az - 1 : 0) * w[2], gy = (ay > 1 ? ay - 1 : 0) * w[1];
     const double rem = rc * rc - gz * gz - gy * gy;
@@ -201,7 +210,16 @@ __global__ __launch_bounds__(256) void nl_setup_kernel(const T* __restrict__ cel
     if (rem < -1e-6 * rc * rc) lim = -1;
     else if (w[0] > 0.0) { lim = (int)(sqrt(rem > 0.0 ? rem : 0.0) / w[0] * (1.0 + 1e-6)) + 1; if (lim > S.R[0]) lim = S.R[0]; }
     else lim = S.R[0];
-    S.dxlim[az][ay] = (signed char)lim;
+    sys[s].dxlim[az][ay] = (signed char)lim;
+    return;
+  }
+  for (int s = threadIdx.x; s < B; s += blockDim.x) {
+    NlSys<T> S;
+    nl_describe_system<T>(cell, pbc, natoms, N, cutoff, origin, s, S);
+    NlSys<T>* dst = sys + s;  // field by field: the pruning table of this struct belongs to the table blocks
+    for (int k = 0; k < 9; ++k) { dst->cell[k] = S.cell[k]; dst->inv[k] = S.inv[k]; }
+    for (int k = 0; k < 3; ++k) { dst->origin[k] = S.origin[k]; dst->cpd[k] = S.cpd[k]; dst->R[k] = S.R[k]; dst->pbc[k] = S.pbc[k]; dst->nrange[k] = S.nrange[k]; }
+    dst->cell_off = 0; dst->ncells = S.ncells; dst->tiled = S.tiled; dst->prune = S.prune;
   }
   __syncthreads();
   // cell offsets = exclusive prefix of the per-system cell counts, 256 systems per trip by a block scan (round 4: one thread walking the
@@ -1139,7 +1157,9 @@ int nl_neighbors_impl(const T* pos, int N, const T* cell, const uint8_t* pbc, co
     // ints a round-up adds belong to block_sum, which the scan writes before anything reads it)
     const long long zero_words = (2 * bins.cap + 3) / 4;
     const int zero_blocks = (int)(zero_words / 2048 < 1 ? 1 : (zero_words / 2048 > 255 ? 255 : zero_words / 2048));
-    nl_setup_kernel<T><<<1 + zero_blocks, 256, 0, st>>>(cell, pbc, nat, N, B, rc, origin, sys, glob, reinterpret_cast<int4*>(bins.count), zero_words);
+    const int table_blocks = mi_blocks((long long)B * (NL_PRUNE_R + 1) * (NL_PRUNE_R + 1), 256);
+    nl_setup_kernel<T><<<1 + table_blocks + zero_blocks, 256, 0, st>>>(cell, pbc, nat, N, B, rc, origin, sys, glob, table_blocks,
+                                                                       reinterpret_cast<int4*>(bins.count), zero_words);
     MI_LAUNCH_CHECK();
     nl_assign_kernel<T><<<mi_blocks(N, 256), 256, 0, st>>>(pos, batch_idx, N, sys, keys_in, bins.count, wrap, glob);
     MI_LAUNCH_CHECK();
