@@ -383,13 +383,15 @@ int mi_pme_convolve(const void* spec /*complex [B,nx,ny,nzr]*/, const void* reci
                     int sf_exponent, int with_field, int dtype,
                     const void* k_vectors /*[(B,)nx,ny,nzr,3] or NULL*/, const void* k_squared /*[(B,)nx,ny,nzr] or NULL*/,
                     int k_batched /*the k arrays carry a leading system dimension*/, void* out /*complex [B,(1|4),nx,ny,nzr]*/, void* stream);
-/* Parameter adjoint of the k-space pass (the backward of a fused forward under autograd, pme.py `_FusedReciprocal`): with `spec` the
- * unscaled spectrum of the charge mesh and `weight_spec` that of the spread upstream weights, per system and per block the eleven sums
- * {-V dL/dV, dL/dalpha, dL/d(2 pi cell^-1)[3][3]} of the Green-function dependence (closed form of what the reference's Warp tape +
- * torch autograd produce for pme_kernels.py:121-331 / pme.py:1398-1422).  partial: [n_systems][mi_pme_convolve_bwd_blocks()][11] doubles,
- * every entry written; the caller folds the block dimension.                                                                      */
-int mi_pme_convolve_bwd(const void* spec, const void* weight_spec, const void* recip_cell, const void* alpha, const void* volume, int n_systems,
-                        int nx, int ny, int nz, int order, int dtype, double* partial, void* stream);
+/* Adjoint of the k-space pass (the backward of the fused forward under autograd, pme.py `_FusedPME` / `_FusedReciprocal`).  `spec`: unscaled
+ * spectrum of the charge mesh [n_systems][nx][ny][nz/2+1]; `weight_spec`: spectra of the spread upstream weights, channel-major
+ * [n_channels][n_systems][...] -- channel 0 for a loss on the energies (weights g_E q), channels 1..3 (n_channels = 4) for a loss on the explicit
+ * forces (weights 2 g_F,d q).  Writes conv_out = D (A_E_hat + sum_d i k_d A_d_hat), whose unscaled inverse transform is dL/d(charge mesh), and per
+ * system and block 20 sums: {-V dL/dV, dL/dalpha, dL/d(2 pi cell^-1)[3][3] through k^2, the same through the explicit k_d of the field}: closed
+ * form of what the reference's Warp tape + torch autograd produce for pme_kernels.py:121-331 / pme.py:1398-1457.  partial:
+ * [n_systems][mi_pme_convolve_bwd_blocks()][20] doubles, every entry written; the caller folds the block dimension.                     */
+int mi_pme_convolve_bwd(const void* spec, const void* weight_spec, int n_channels, const void* recip_cell, const void* alpha, const void* volume,
+                        int n_systems, int nx, int ny, int nz, int order, int dtype, void* conv_out, double* partial, void* stream);
 int mi_pme_convolve_bwd_blocks(void);
 
 int mi_pme_gather_finish(const void* positions, const void* charges, const int32_t* batch_idx, const void* cell_inv_t,

@@ -711,59 +711,82 @@ __global__ void pme_convolve_kernel(const Cplx<T>* __restrict__ spec, const T* _
   }
 }
 
-// ---- adjoint of the k-space pass w.r.t. its PARAMETERS (round 4: fused forward under autograd) -------------------------------------
-// L depends on the potential mesh phi = F^H D F rho only through <A, phi> (A = the spread of the upstream per-atom weights, a_hat its
-// unscaled spectrum), D_k = G(k^2; alpha, V) / sf2_k.  Hence dL/dtheta = sum_k h_k Re(conj(a_hat_k) rho_hat_k) / sf2_k * dG_k/dtheta over
-// the half spectrum with Hermitian weights h_k (1 on the planes kz = 0 and -- even nz -- kz = nz/2, else 2).  One pass produces, per
-// system, the 11 sums   [0] h Re(.) G / sf2                      -> dL/dV = -[0] / V
-//                        [1] h Re(.) G k^2 / (2 alpha^3) / sf2     =  dL/dalpha
-//                        [2 + 3 c + d] h Re(.) dG/dk^2 2 k_c m_d / sf2 = dL/d(2 pi cell^-1)[c][d]   (k_c = sum_d m_d recip[c][d])
-// as `partial[b][block][11]` in double (the caller folds the blocks: no same-address atomics).  Reference: the Warp tape differentiates
-// pme_kernels.py:121-331 + the torch glue of pme.py:1398-1422; this is the closed form of those adjoints.
+// ---- adjoint of the k-space pass (round 4: fused forward under autograd) ------------------------------------------------------------
+// Upstream weights arrive as meshes: A_E = spread(g_E q) for a loss on the energies and, with `nchan` = 4, A_d = spread(2 g_F,d q) for a loss
+// on the explicit forces F = 2 q gather(E_d), E_d = F^H (-i k_d D) F rho.  With W_hat = A_E_hat + sum_d (i k_d) A_d_hat the whole loss is
+// L = sum_k h_k Re(conj(W_hat_k) D_k rho_hat_k), D_k = G(k^2; alpha, V) / sf2_k, h_k the Hermitian weights of the half spectrum (1 on the planes
+// kz = 0 and -- even nz -- kz = nz/2, else 2).  One pass over the spectra produces
+//   conv_out = D W_hat                     its unscaled inverse transform is dL/d(charge mesh): the operator is self-adjoint
+//   per system and block, 20 sums (double; the caller folds the blocks: no same-address atomics):
+//     [0]  h Re(.) G / sf2                               -> dL/dV = -[0] / V
+//     [1]  h Re(.) G k^2 / (2 alpha^3) / sf2               =  dL/dalpha
+//     [2 + 3c + d]  h Re(.) dG/dk^2 2 k_c m_d / sf2       =  dL/d(2 pi cell^-1)[c][d] through k^2   (k_c = sum_d m_d recip[c][d])
+//     [11 + 3c + d] h D Im(conj(A_c_hat) rho_hat) m_d      =  dL/d(2 pi cell^-1)[c][d] through the explicit k_c of the field (nchan = 4 only)
+// Spectra: `spec` [B][...], `aspec` channel-major [nchan][B][...].  Reference: the Warp tape + torch autograd over pme_kernels.py:121-331 and
+// pme.py:1398-1457; this is the closed form of those adjoints.
 #define PME_BWD_BLOCKS 256
+#define PME_BWD_SUMS 20
 template <class T>
-__global__ __launch_bounds__(256) void pme_convolve_bwd_kernel(const Cplx<T>* __restrict__ spec, const Cplx<T>* __restrict__ aspec,
+__global__ __launch_bounds__(256) void pme_convolve_bwd_kernel(const Cplx<T>* __restrict__ spec, const Cplx<T>* __restrict__ aspec, int nchan,
                                                               const T* __restrict__ recip, const T* __restrict__ alpha,
-                                                              const T* __restrict__ volume, int nx, int ny, int nz, int order,
-                                                              double* __restrict__ partial) {
+                                                              const T* __restrict__ volume, int B, int nx, int ny, int nz, int order,
+                                                              Cplx<T>* __restrict__ conv_out, double* __restrict__ partial) {
   const int b = blockIdx.y;
   const int nzr = nz / 2 + 1;
   const size_t per = (size_t)nx * ny * nzr;
   const T* R = recip + 9 * (size_t)b;
   const T al = alpha[b], vol = volume[b];
-  double acc[11];
+  double acc[PME_BWD_SUMS];
 #pragma unroll
-  for (int q = 0; q < 11; ++q) acc[q] = 0.0;
+  for (int q = 0; q < PME_BWD_SUMS; ++q) acc[q] = 0.0;
   for (size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x; r < per; r += (size_t)gridDim.x * blockDim.x) {
     const int k = (int)(r % nzr), j = (int)((r / nzr) % ny), i = (int)(r / ((size_t)nzr * ny));
-    if (i == 0 && j == 0 && k == 0) continue;
     const int mx = miller_of(i, nx), my = miller_of(j, ny), mz = k;
     const T m[3] = {(T)mx, (T)my, (T)mz};
     T kv[3];
 #pragma unroll
     for (int c = 0; c < 3; ++c) kv[c] = m[0] * R[3 * c] + m[1] * R[3 * c + 1] + m[2] * R[3 * c + 2];
     const T k2 = kv[0] * kv[0] + kv[1] * kv[1] + kv[2] * kv[2];
-    if (!(k2 > T(1e-12)) || k2 < T(1e-10)) continue;  // clamped / masked in the forward pass: no dependence on the parameters
-    const T G = green_of(k2, al, vol, false);
+    // clamped / masked in the forward pass (origin, k^2 <= 1e-12, G = 0 below 1e-10): no contribution and no dependence on the parameters
+    const bool live = !(i == 0 && j == 0 && k == 0) && (k2 > T(1e-12)) && !(k2 < T(1e-10));
+    const T G = live ? green_of(k2, al, vol, false) : T(0);
     const T sf2 = sf_sq_of<T>(mx, my, mz, nx, ny, nz, order);
-    const Cplx<T> v = spec[(size_t)b * per + r], a = aspec[(size_t)b * per + r];
+    const Cplx<T> v = spec[(size_t)b * per + r];
+    const Cplx<T> ae = aspec[(size_t)b * per + r];
+    double wre = (double)ae.re, wim = (double)ae.im;  // W_hat
+    double imd[3] = {0.0, 0.0, 0.0};                  // Im(conj(A_d_hat) rho_hat)
+    if (nchan == 4) {
+#pragma unroll
+      for (int d = 0; d < 3; ++d) {
+        const Cplx<T> ad = aspec[((size_t)(d + 1) * B + b) * per + r];
+        wre -= (double)kv[d] * (double)ad.im;  // (i k_d)(re + i im) = -k_d im + i k_d re
+        wim += (double)kv[d] * (double)ad.re;
+        imd[d] = (double)ad.re * (double)v.im - (double)ad.im * (double)v.re;
+      }
+    }
+    const double dk = (double)G / (double)sf2;
+    if (conv_out) conv_out[(size_t)b * per + r] = Cplx<T>{(T)(dk * wre), (T)(dk * wim)};
+    if (!live) continue;
     const double h = (k == 0 || (2 * k == nz)) ? 1.0 : 2.0;
-    const double w = h * ((double)a.re * (double)v.re + (double)a.im * (double)v.im) / (double)sf2;
-    const double g = (double)G;
-    acc[0] += w * g;
-    acc[1] += w * g * (double)k2 / (2.0 * (double)al * (double)al * (double)al);
-    const double dg = w * g * (-1.0 / (4.0 * (double)al * (double)al) - 1.0 / (double)k2) * 2.0;
+    const double w = h * (wre * (double)v.re + wim * (double)v.im) * dk;  // h Re(conj(W) rho) G / sf2
+    acc[0] += w;
+    acc[1] += w * (double)k2 / (2.0 * (double)al * (double)al * (double)al);
+    const double dg = w * (-1.0 / (4.0 * (double)al * (double)al) - 1.0 / (double)k2) * 2.0;
 #pragma unroll
     for (int c = 0; c < 3; ++c)
 #pragma unroll
-      for (int d = 0; d < 3; ++d) acc[2 + 3 * c + d] += dg * (double)kv[c] * (double)m[d];
+      for (int d = 0; d < 3; ++d) {
+        acc[2 + 3 * c + d] += dg * (double)kv[c] * (double)m[d];
+        acc[11 + 3 * c + d] += h * dk * imd[c] * (double)m[d];
+      }
   }
-  __shared__ double part[4][11];
+  __shared__ double part[4][PME_BWD_SUMS];
   const int lane = threadIdx.x & (MI_WAVE - 1), wave = threadIdx.x / MI_WAVE;
 #pragma unroll
-  for (int q = 0; q < 11; ++q) { const double t = wave_sum(acc[q]); if (lane == 0) part[wave][q] = t; }
+  for (int q = 0; q < PME_BWD_SUMS; ++q) { const double t = wave_sum(acc[q]); if (lane == 0) part[wave][q] = t; }
   __syncthreads();
-  if (threadIdx.x < 11) partial[((size_t)b * gridDim.x + blockIdx.x) * 11 + threadIdx.x] = part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x];
+  if (threadIdx.x < PME_BWD_SUMS)
+    partial[((size_t)b * gridDim.x + blockIdx.x) * PME_BWD_SUMS + threadIdx.x] = part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x];
 }
 
 template <class T>
@@ -1071,16 +1094,18 @@ int mi_pme_convolve(const void* spec, const void* recip_cell, const void* alpha,
   return MI_OK;
 }
 
-int mi_pme_convolve_bwd(const void* spec, const void* weight_spec, const void* recip_cell, const void* alpha, const void* volume, int n_systems,
-                        int nx, int ny, int nz, int order, int dtype, double* partial /*[n_systems][mi_pme_convolve_bwd_blocks()][11]*/, void* stream) {
+int mi_pme_convolve_bwd(const void* spec, const void* weight_spec, int n_channels, const void* recip_cell, const void* alpha, const void* volume,
+                        int n_systems, int nx, int ny, int nz, int order, int dtype, void* conv_out,
+                        double* partial /*[n_systems][mi_pme_convolve_bwd_blocks()][20]*/, void* stream) {
   MI_REQUIRE(dtype == MI_F32 || dtype == MI_F64, "dtype");
+  MI_REQUIRE(n_channels == 1 || n_channels == 4, "n_channels must be 1 (energy weights) or 4 (energy + three force-component weights)");
   MI_REQUIRE(spec && weight_spec && recip_cell && alpha && volume && partial && n_systems >= 1, "null pointer");
   order = decode_order(order).sf_exponent;
   hipStream_t st = (hipStream_t)stream;
   mi_timing_begin("pme_convolve_bwd", stream);
-  MI_DISPATCH_T(dtype, (pme_convolve_bwd_kernel<T_><<<dim3(PME_BWD_BLOCKS, n_systems), 256, 0, st>>>((const Cplx<T_>*)spec, (const Cplx<T_>*)weight_spec,
-                                                                                                    (const T_*)recip_cell, (const T_*)alpha,
-                                                                                                    (const T_*)volume, nx, ny, nz, order, partial)));
+  MI_DISPATCH_T(dtype, (pme_convolve_bwd_kernel<T_><<<dim3(PME_BWD_BLOCKS, n_systems), 256, 0, st>>>(
+                           (const Cplx<T_>*)spec, (const Cplx<T_>*)weight_spec, n_channels, (const T_*)recip_cell, (const T_*)alpha, (const T_*)volume,
+                           n_systems, nx, ny, nz, order, (Cplx<T_>*)conv_out, partial)));
   mi_timing_end(stream);
   MI_LAUNCH_CHECK();
   return MI_OK;

@@ -221,7 +221,7 @@ def _reciprocal_fused(pos, q, cells, alpha, mesh_dimensions, spline_order, bi, c
                                       C.ptr(tile_order), st)
     C.check(rc, "mi_pme_gather_finish")
     if keep is not None:  # what the hand-written adjoint of `_FusedReciprocal` needs: nothing here is recomputed in its backward
-        keep.update(spec=spec, phi=real[:, 0], cit=cit, recip=recip, vol=vol, qtot=qtot, alpha=al)
+        keep.update(spec=spec, real=real, cit=cit, recip=recip, vol=vol, qtot=qtot, alpha=al)
     return energies, forces, cgrads
 
 
@@ -280,58 +280,72 @@ def _reciprocal_front(pos, q, cells, alpha, dims, spline_order, bi, nsys, batche
     return spec, real, cit, recip, vol, qtot, al, tile_order
 
 
+def _fusable(compute_forces, compute_charge_gradients, k_vectors, k_squared) -> bool:
+    """Can this call run as one fused autograd node?  Energies (+ explicit forces); not charge-gradient outputs, not caller-supplied k arrays,
+    never inside a torch.compile trace (those take the op-by-op composition)."""
+    return _FUSED_AUTOGRAD and not C.tracing() and not compute_charge_gradients and k_vectors is None and k_squared is None
+
+
 class _FusedReciprocal(torch.autograd.Function):
-    """Reciprocal-space PME ENERGIES under autograd with the fused forward kernels (round 4).
+    """Reciprocal-space PME energies (+ explicit forces) under autograd with the fused forward kernels (round 4).
 
     Until round 3 anything that required grad left the fused path for the op-by-op composition (`_reciprocal_composed`), 2.7x the inference
     forward.  Here the forward IS the inference path (spread -> R2C -> fused k-space pass -> C2R -> fused gather + corrections) and keeps
-    what its adjoint needs -- the charge spectrum, the potential mesh, the per-atom charge gradients -- and the backward is the closed form
-    of what the reference's Warp tape + torch autograd compute for pme.py:1338-1479:
+    what its adjoint needs -- the charge spectrum, the potential (and field) meshes, the per-atom charge gradients -- and the backward is the
+    closed form of what the reference's Warp tape + torch autograd compute for pme.py:1338-1479 (`_reciprocal_adjoint`).
 
-        w = g q;  A = spread(w);  B = F^H D F A   (the k-space operator is self-adjoint);  psi = gather(B)
-        dL/dq   = g (phi - 2 q alpha/sqrt(pi) - pi Q/(2 alpha^2 V)) + psi - pi/(2 alpha^2 V) sum(w)
-        dL/dr   = [w grad_u gather(phi) + q grad_u gather(B)] . cell^-T          (u = fractional coordinates)
-        dL/dalpha, dL/dV, dL/d(2 pi cell^-1): one reduction over the two spectra (`mi_pme_convolve_bwd`) + the correction terms
-        dL/dcell: through cell^-T (fractional coordinates), 2 pi cell^-1 (k vectors) and V = |det cell|
-
-    First order only on this path: when the backward itself is being recorded (`create_graph=True`, e.g. forces by autograd inside a
-    force-matching loss) it re-runs the differentiable composition instead, so second derivatives keep working."""
+    First order only on this path: when the backward itself is being recorded (`create_graph=True`) it re-runs the differentiable composition
+    instead, which supports what it supported before and raises for the rest -- never a silent zero."""
 
     @staticmethod
-    def forward(ctx, positions, charges, cells, alpha, mesh_dimensions, spline_order, batch_idx):
+    def forward(ctx, positions, charges, cells, alpha, mesh_dimensions, spline_order, batch_idx, compute_forces):
         dt = positions.dtype
         pos = positions.detach().contiguous()
         q = charges.detach().to(dt).contiguous()
         cc = cells.detach().to(dt).contiguous()
         bi = None if batch_idx is None else C.i32(batch_idx)
         keep = {}
-        energies, _, cg = _reciprocal_fused(pos, q, cc, alpha.detach(), mesh_dimensions, spline_order, bi, False, True, keep=keep)
-        ctx.save_for_backward(positions, charges, cells, alpha, keep["spec"], keep["phi"], cg, keep["cit"], keep["recip"], keep["vol"], keep["qtot"])
-        ctx.dims, ctx.order, ctx.bi, ctx.batch_idx = tuple(mesh_dimensions), int(spline_order), bi, batch_idx
-        return energies
+        energies, forces, cg = _reciprocal_fused(pos, q, cc, alpha.detach(), mesh_dimensions, spline_order, bi, compute_forces, True, keep=keep)
+        ctx.save_for_backward(positions, charges, cells, alpha, keep["spec"], keep["real"], cg, keep["cit"], keep["recip"], keep["vol"], keep["qtot"])
+        ctx.dims, ctx.order, ctx.bi, ctx.batch_idx, ctx.with_forces = tuple(mesh_dimensions), int(spline_order), bi, batch_idx, bool(compute_forces)
+        ctx.set_materialize_grads(False)
+        return (energies, forces) if compute_forces else energies
 
     @staticmethod
-    def backward(ctx, g_energies):
+    def backward(ctx, g_energies, g_forces=None):
         positions, charges, cells, alpha = ctx.saved_tensors[:4]
         need = ctx.needs_input_grad
         if torch.is_grad_enabled():
-            # the backward is being differentiated (create_graph=True): take it from the differentiable composition (which supports what
-            # it supports: second derivatives of the explicit outputs, NotImplementedError for those of autograd forces -- never a silent zero)
+            # the backward is being differentiated (create_graph=True): take it from the differentiable composition
             with torch.enable_grad():
-                e, _, _ = _reciprocal_composed(positions, charges, cells, alpha, ctx.dims, ctx.order, ctx.batch_idx, False, False)
-                inputs = [t for t, n in zip((positions, charges, cells, alpha), need[:4]) if n]
-                grads = iter(torch.autograd.grad(e, inputs, g_energies, create_graph=True, allow_unused=True))
-            return tuple(next(grads) if n else None for n in need[:4]) + (None, None, None)
-        return _reciprocal_energy_adjoint(ctx.saved_tensors, need, g_energies, ctx.dims, ctx.order, ctx.bi) + (None, None, None)
+                e, f, _ = _reciprocal_composed(positions, charges, cells, alpha, ctx.dims, ctx.order, ctx.batch_idx, ctx.with_forces, False)
+                grads = _composed_grads(((e, g_energies), (f, g_forces)), (positions, charges, cells, alpha), need)
+            return grads + (None, None, None, None)
+        return _reciprocal_adjoint(ctx.saved_tensors, need, g_energies, g_forces, ctx.dims, ctx.order, ctx.bi) + (None, None, None, None)
 
 
-def _reciprocal_energy_adjoint(saved, need, g_energies, dims, order, bi):
-    """(dL/dpositions, dL/dcharges, dL/dcells, dL/dalpha) of L = sum_i g_i E_i for the reciprocal-space energies, from what the fused forward
-    kept (formulas: `_FusedReciprocal`).  Raw launches on detached tensors: first order only."""
+def _composed_grads(outputs_and_grads, inputs, need):
+    """autograd.grad of the differentiable composition for the inputs that need a gradient (create_graph=True hand-over of the fused nodes)."""
+    outs = [o for o, g in outputs_and_grads if o is not None and g is not None]
+    gs = [g for o, g in outputs_and_grads if o is not None and g is not None]
+    wanted = [t for t, n in zip(inputs, need[:len(inputs)]) if n]
+    got = iter(torch.autograd.grad(outs, wanted, gs, create_graph=True, allow_unused=True)) if outs and wanted else iter(())
+    return tuple(next(got) if n else None for n in need[:len(inputs)])
+
+
+def _reciprocal_adjoint(saved, need, g_energies, g_forces, dims, order, bi):
+    """(dL/dpositions, dL/dcharges, dL/dcells, dL/dalpha) of L = sum_i g_i E_i + sum_i G_i . F_i for the reciprocal-space outputs, from what the
+    fused forward kept.  Raw launches on detached tensors: first order only.  With w = g q and u_d = 2 G_d q the upstream weights:
+
+        A_E = spread(w), A_d = spread(u_d);   B = F^H D (A_E_hat + sum_d i k_d A_d_hat)      (one pass: `mi_pme_convolve_bwd`; self-adjoint operator)
+        dL/dq   = g (phi - 2 q alpha/sqrt(pi) - pi Q/(2 alpha^2 V)) - pi/(2 alpha^2 V) sum(w) + gather(B) + sum_d 2 G_d gather(E_d)
+        dL/dr   = [w grad_u gather(phi) + q grad_u gather(B) + sum_d u_d grad_u gather(E_d)] . cell^-T          (u = fractional coordinates)
+        dL/dalpha, dL/dV, dL/d(2 pi cell^-1): the 20 sums of the same pass + the correction terms
+        dL/dcell: through cell^-T (fractional coordinates), 2 pi cell^-1 (k vectors) and V = |det cell| in closed form"""
     from nvalchemiops import _eops as E
     from nvalchemiops.spline import _launch_gather
 
-    positions, charges, cells, alpha, spec, phi, cg, cit, recip, vol, qtot = saved
+    positions, charges, cells, alpha, spec, real, cg, cit, recip, vol, qtot = saved
     dt, dev = positions.dtype, positions.device
     code = C.dtype_code(dt)
     nx, ny, nz = dims
@@ -340,74 +354,94 @@ def _reciprocal_energy_adjoint(saved, need, g_energies, dims, order, bi):
     pos = positions.detach().contiguous()
     q = charges.detach().to(dt).contiguous()
     al = alpha.detach().to(dt).reshape(-1).contiguous()
-    g = g_energies.detach().to(dt).contiguous()
+    n = pos.shape[0]
+    g = None if g_energies is None else g_energies.detach().to(dt).contiguous()
+    gf = None if g_forces is None else g_forces.detach().to(dt).contiguous()
+    if g is None and gf is None:
+        return None, None, None, None
     sel = bi.long() if batched else None
     per = (lambda t: t[sel]) if batched else (lambda t: t[0])  # per-system value at every atom
     st = C.stream_of(pos)
     cdt = torch.complex64 if dt == torch.float32 else torch.complex128
-    # A = spread(g q), its spectrum, the parameter sums, B = K[A]
-    w = g * q
-    a_mesh = _launch_spread(pos, w, cit, bi, nsys, (nx, ny, nz), order, batched)
-    a_spec = torch.empty((nsys, nx, ny, nz // 2 + 1), dtype=cdt, device=dev)
-    _fft_plan(dev, (nx, ny, nz), nsys, code, False)(a_mesh, a_spec)
-    sums = None
-    if need[2] or (need[3] and alpha.dim() > 0):
-        nblk = int(C.lib().mi_pme_convolve_bwd_blocks())
-        partial = torch.empty((nsys, nblk, 11), dtype=torch.float64, device=dev)
-        C.check(C.lib().mi_pme_convolve_bwd(C.ptr(spec), C.ptr(a_spec), C.ptr(recip), C.ptr(al), C.ptr(vol), nsys, nx, ny, nz, C.spline_order_arg(order),
-                                            code, C.ptr(partial), st), "mi_pme_convolve_bwd")
-        sums = partial.sum(1).to(dt)  # [B, 11]
+    nchan = 1 if gf is None else 4
+    w = g * q if g is not None else torch.zeros(n, dtype=dt, device=dev)
+    weights = [w] + ([] if gf is None else [(2.0 * gf[:, d] * q).contiguous() for d in range(3)])
+    # spectra of the spread upstream weights, channel-major
+    a_spec = torch.empty((nchan, nsys, nx, ny, nz // 2 + 1), dtype=cdt, device=dev)
+    fwd = _fft_plan(dev, (nx, ny, nz), nsys, code, False)
+    for c, wt in enumerate(weights):
+        fwd(_launch_spread(pos, wt, cit, bi, nsys, (nx, ny, nz), order, batched), a_spec[c])
+    nblk = int(C.lib().mi_pme_convolve_bwd_blocks())
+    partial = torch.empty((nsys, nblk, 20), dtype=torch.float64, device=dev)
     conv = torch.empty((nsys, 1, nx, ny, nz // 2 + 1), dtype=cdt, device=dev)
-    C.check(C.lib().mi_pme_convolve(C.ptr(a_spec), C.ptr(recip), C.ptr(al), C.ptr(vol), nsys, nx, ny, nz, C.spline_order_arg(order), 0, code,
-                                    None, None, 0, C.ptr(conv), st), "mi_pme_convolve")
+    C.check(C.lib().mi_pme_convolve_bwd(C.ptr(spec), C.ptr(a_spec), nchan, C.ptr(recip), C.ptr(al), C.ptr(vol), nsys, nx, ny, nz, C.spline_order_arg(order),
+                                        code, C.ptr(conv), C.ptr(partial), st), "mi_pme_convolve_bwd")
     b_mesh = torch.empty((nsys, nx, ny, nz), dtype=dt, device=dev)
     _fft_plan(dev, (nx, ny, nz), nsys, code, True)(conv, b_mesh)
     sqrt_pi = math.sqrt(math.pi)
     a_i, v_i, qt_i = per(al), per(vol), per(qtot)
+    phi = real[:, 0]
+    field = [real[:, d + 1].contiguous() for d in range(3)] if gf is not None else None
     g_pos = g_q = g_cells = g_alpha = g_cit = None
     if need[1]:
-        wsum = E.seg_sum(w, bi, nsys)  # sum_i g_i q_i per system
-        psi = _launch_gather(pos, b_mesh, cit, bi, order)
-        # phi_j from the forward's charge gradient 2 phi - 2 alpha q/sqrt(pi) - pi Q/(alpha^2 V)
-        phi_j = 0.5 * (cg + 2.0 * a_i * q / sqrt_pi + math.pi * qt_i / (a_i * a_i * v_i))
-        g_q = g * (phi_j - 2.0 * q * a_i / sqrt_pi - math.pi * qt_i / (2.0 * a_i * a_i * v_i)) + psi - math.pi / (2.0 * a_i * a_i * v_i) * per(wsum)
+        g_q = _launch_gather(pos, b_mesh, cit, bi, order)
+        if g is not None:
+            wsum = E.seg_sum(w, bi, nsys)  # sum_i g_i q_i per system
+            # phi_j from the forward's charge gradient 2 phi - 2 alpha q/sqrt(pi) - pi Q/(alpha^2 V)
+            phi_j = 0.5 * (cg + 2.0 * a_i * q / sqrt_pi + math.pi * qt_i / (a_i * a_i * v_i))
+            g_q = g_q + g * (phi_j - 2.0 * q * a_i / sqrt_pi - math.pi * qt_i / (2.0 * a_i * a_i * v_i)) - math.pi / (2.0 * a_i * a_i * v_i) * per(wsum)
+        if gf is not None:
+            for d in range(3):
+                g_q = g_q + 2.0 * gf[:, d] * _launch_gather(pos, field[d], cit, bi, order)
         g_q = g_q.to(charges.dtype)
     if need[0] or need[2]:
-        gfrac = w.unsqueeze(-1) * _launch_gather(pos, phi.contiguous(), cit, bi, order, grad=True) \
-            + q.unsqueeze(-1) * _launch_gather(pos, b_mesh, cit, bi, order, grad=True)
+        gfrac = q.unsqueeze(-1) * _launch_gather(pos, b_mesh, cit, bi, order, grad=True)
+        if g is not None:
+            gfrac = gfrac + w.unsqueeze(-1) * _launch_gather(pos, phi.contiguous(), cit, bi, order, grad=True)
+        if gf is not None:
+            for d in range(3):
+                gfrac = gfrac + weights[d + 1].unsqueeze(-1) * _launch_gather(pos, field[d], cit, bi, order, grad=True)
         g_pos, g_cit = E._coordinate_grads(torch.ones_like(q), gfrac, pos, cit, bi)
+    sums = partial.sum(1).to(dt) if (need[2] or (need[3] and alpha.dim() > 0)) else None  # [B, 20]
     if need[3] and alpha.dim() > 0:
-        corr = E.seg_sum(g * (-q * q / sqrt_pi + q * math.pi * qt_i / (a_i ** 3 * v_i)), bi, nsys)
-        g_alpha = (sums[:, 1] + corr).reshape(alpha.shape).to(alpha.dtype)
+        g_alpha = sums[:, 1]
+        if g is not None:
+            g_alpha = g_alpha + E.seg_sum(g * (-q * q / sqrt_pi + q * math.pi * qt_i / (a_i ** 3 * v_i)), bi, nsys)
+        g_alpha = g_alpha.reshape(alpha.shape).to(alpha.dtype)
     if need[2]:
-        g_vol = -sums[:, 0] / vol + E.seg_sum(g * q * math.pi * qt_i / (2.0 * a_i * a_i * v_i * v_i), bi, nsys)
+        g_vol = -sums[:, 0] / vol
+        if g is not None:
+            g_vol = g_vol + E.seg_sum(g * q * math.pi * qt_i / (2.0 * a_i * a_i * v_i * v_i), bi, nsys)
         inv_t = cit                      # cell^-T;  recip = 2 pi cell^-1
-        d_inv = 2.0 * math.pi * sums[:, 2:11].reshape(nsys, 3, 3) + g_cit.transpose(-1, -2)
+        d_inv = 2.0 * math.pi * (sums[:, 2:11] + sums[:, 11:20]).reshape(nsys, 3, 3) + g_cit.transpose(-1, -2)
         g_cells = -(inv_t @ d_inv @ inv_t) + (g_vol * vol).reshape(-1, 1, 1) * inv_t
         g_cells = g_cells.reshape(cells.shape).to(cells.dtype)
     return (g_pos if need[0] else None), g_q, g_cells, g_alpha
 
 
 class _FusedPME(torch.autograd.Function):
-    """`particle_mesh_ewald` ENERGIES under autograd as ONE node: the inference step forward (real-space kernel, then the fused reciprocal
-    pipeline whose gather epilogue adds the real-space energies), `_reciprocal_energy_adjoint` + `mi_ewald_real_bwd` backward.  Saves the
-    custom-op dispatch of the real-space op and the torch add of the two parts that the round-3 path paid on every forward."""
+    """`particle_mesh_ewald` energies (+ explicit forces) under autograd as ONE node: the inference step forward (real-space kernel, then the
+    fused reciprocal pipeline whose gather epilogue adds the real-space outputs), `_reciprocal_adjoint` + `mi_ewald_real_bwd` /
+    `mi_ewald_real_forces_bwd` backward.  Saves the custom-op dispatches, the four separate inverse FFTs and the torch adds of the two parts
+    that the round-3 path paid on every forward."""
 
     @staticmethod
-    def forward(ctx, positions, charges, cells, alpha, mesh_dimensions, spline_order, batch_idx, mask_value, nl):
+    def forward(ctx, positions, charges, cells, alpha, mesh_dimensions, spline_order, batch_idx, mask_value, nl, compute_forces):
         p = _real_space_inputs(positions, charges, cells, alpha, nl[0], nl[1], nl[2], nl[3], nl[4], batch_idx)
         keep = {}
-        add = _real_space_launch(p, mask_value, False, False)
-        energies, _, cg = _reciprocal_fused(p["pos"], p["q"], p["cells"], p["alpha"], mesh_dimensions, spline_order, p["bi"], False, True, keep=keep,
-                                            add=(add[0], None, None))
-        ctx.save_for_backward(positions, charges, cells, alpha, keep["spec"], keep["phi"], cg, keep["cit"], keep["recip"], keep["vol"], keep["qtot"],
+        add = _real_space_launch(p, mask_value, compute_forces, False)
+        energies, forces, cg = _reciprocal_fused(p["pos"], p["q"], p["cells"], p["alpha"], mesh_dimensions, spline_order, p["bi"], compute_forces, True,
+                                                 keep=keep, add=(add[0], add[1], None))
+        ctx.save_for_backward(positions, charges, cells, alpha, keep["spec"], keep["real"], cg, keep["cit"], keep["recip"], keep["vol"], keep["qtot"],
                               *[t for t in nl if t is not None])
         ctx.nl_present = [t is not None for t in nl]
         ctx.dims, ctx.order, ctx.bi, ctx.batch_idx, ctx.mask_value = tuple(mesh_dimensions), int(spline_order), p["bi"], batch_idx, int(mask_value)
-        return energies
+        ctx.with_forces = bool(compute_forces)
+        ctx.set_materialize_grads(False)
+        return (energies, forces) if compute_forces else energies
 
     @staticmethod
-    def backward(ctx, g_energies):
+    def backward(ctx, g_energies, g_forces=None):
         saved = ctx.saved_tensors
         positions, charges, cells, alpha = saved[:4]
         rest = iter(saved[11:])
@@ -417,25 +451,25 @@ class _FusedPME(torch.autograd.Function):
             with torch.enable_grad():
                 real = ewald_real_space(positions=positions, charges=charges, cell=cells, alpha=alpha, neighbor_list=nl[0], neighbor_ptr=nl[1],
                                         neighbor_shifts=nl[2], neighbor_matrix=nl[3], neighbor_matrix_shifts=nl[4], mask_value=ctx.mask_value,
-                                        batch_idx=ctx.batch_idx)
-                rec, _, _ = _reciprocal_composed(positions, charges, cells, alpha, ctx.dims, ctx.order, ctx.batch_idx, False, False)
-                inputs = [t for t, n in zip((positions, charges, cells, alpha), need[:4]) if n]
-                grads = iter(torch.autograd.grad(real + rec, inputs, g_energies, create_graph=True, allow_unused=True))
-            return tuple(next(grads) if n else None for n in need[:4]) + (None,) * 5
+                                        batch_idx=ctx.batch_idx, compute_forces=ctx.with_forces)
+                e, f, _ = _reciprocal_composed(positions, charges, cells, alpha, ctx.dims, ctx.order, ctx.batch_idx, ctx.with_forces, False)
+                e_tot = (real[0] if ctx.with_forces else real) + e
+                f_tot = real[1] + f if ctx.with_forces else None
+                grads = _composed_grads(((e_tot, g_energies), (f_tot, g_forces)), (positions, charges, cells, alpha), need)
+            return grads + (None,) * 6
         from nvalchemiops import _eops as E
 
-        g_pos, g_q, g_cells, g_alpha = _reciprocal_energy_adjoint(saved[:11], need, g_energies, ctx.dims, ctx.order, ctx.bi)
-        r_pos, r_q, r_cell, r_alpha = E._real_bwd(positions, charges, cells, alpha, ctx.batch_idx, nl[0], nl[1], nl[2], nl[3], nl[4], ctx.mask_value,
-                                                  g_energies)
-        if need[0]:
-            g_pos = g_pos + r_pos.to(g_pos.dtype)
-        if need[1]:
-            g_q = g_q + r_q.to(g_q.dtype)
-        if need[2]:
-            g_cells = g_cells + r_cell.reshape(g_cells.shape).to(g_cells.dtype)
-        if need[3] and alpha.dim() > 0:
-            g_alpha = g_alpha + r_alpha.reshape(g_alpha.shape).to(g_alpha.dtype)
-        return (g_pos if need[0] else None), (g_q if need[1] else None), (g_cells if need[2] else None), g_alpha, None, None, None, None, None
+        out = list(_reciprocal_adjoint(saved[:11], need, g_energies, g_forces, ctx.dims, ctx.order, ctx.bi))
+        parts = []
+        if g_energies is not None:
+            parts.append(E._real_bwd(positions, charges, cells, alpha, ctx.batch_idx, nl[0], nl[1], nl[2], nl[3], nl[4], ctx.mask_value, g_energies))
+        if g_forces is not None:
+            parts.append(E._real_forces_bwd(positions, charges, cells, alpha, ctx.batch_idx, nl[0], nl[1], nl[2], nl[3], nl[4], ctx.mask_value, g_forces, None))
+        for r_pos, r_q, r_cell, r_alpha in parts:
+            for k, r in enumerate((r_pos, r_q, r_cell, r_alpha)):
+                if need[k] and out[k] is not None:
+                    out[k] = out[k] + r.reshape(out[k].shape).to(out[k].dtype)
+        return tuple(out[k] if need[k] else None for k in range(4)) + (None,) * 6
 
 
 def _reciprocal_composed(positions, charges, cells, alpha, mesh_dimensions, spline_order, batch_idx, compute_forces, compute_charge_gradients,
@@ -525,11 +559,10 @@ def pme_reciprocal_space(positions: torch.Tensor, charges: torch.Tensor, cell: t
         C.dtype_code(dt)
         if composed:
             alpha_g = _traceable_alpha(alpha, num_systems, dt, dev)
-            fusable = (_FUSED_AUTOGRAD and not C.tracing() and not compute_forces and not compute_charge_gradients and k_vectors is None
-                       and k_squared is None and (batch_idx is None or cells.shape[0] == num_systems))
-            if fusable:
-                # energies only, eager autograd: the inference kernels forward, a hand-written adjoint backward (`_FusedReciprocal`)
-                energies, forces, cgrads = _FusedReciprocal.apply(positions, charges, cells, alpha_g, mesh_dimensions, spline_order, batch_idx), None, None
+            if _fusable(compute_forces, compute_charge_gradients, k_vectors, k_squared):
+                # eager autograd: the inference kernels forward, a hand-written adjoint backward (`_FusedReciprocal`)
+                out = _FusedReciprocal.apply(positions, charges, cells, alpha_g, mesh_dimensions, spline_order, batch_idx, bool(compute_forces))
+                energies, forces, cgrads = (out[0], out[1], None) if compute_forces else (out, None, None)
             else:
                 energies, forces, cgrads = _reciprocal_composed(positions, charges, cells, alpha_g, mesh_dimensions, spline_order, batch_idx,
                                                                 compute_forces, compute_charge_gradients, k_vectors, k_squared)
@@ -591,13 +624,12 @@ def particle_mesh_ewald(positions: torch.Tensor, charges: torch.Tensor, cell: to
                                                          compute_forces, compute_charge_gradients, add=add)
             out = (energies,) + ((forces,) if compute_forces else ()) + ((cgrads,) if compute_charge_gradients else ())
             return out if len(out) > 1 else out[0]
-    if (wants_grad and _FUSED_AUTOGRAD and not C.tracing() and num_atoms > 0 and not compute_forces and not compute_charge_gradients
-            and k_vectors is None and k_squared is None
+    if (wants_grad and num_atoms > 0 and _fusable(compute_forces, compute_charge_gradients, k_vectors, k_squared)
             and ((neighbor_matrix is not None and neighbor_matrix.numel() > 0) or (neighbor_list is not None and neighbor_list.numel() > 0))):
-        # energies under eager autograd: ONE node, inference kernels forward, hand-written adjoints backward (`_FusedPME`)
+        # eager autograd: ONE node, inference kernels forward, hand-written adjoints backward (`_FusedPME`)
         C.require_device(positions, charges, cell, batch_idx)
         return _FusedPME.apply(positions, charges, cells, alpha, tuple(int(v) for v in mesh_dimensions), spline_order, batch_idx, int(mask_value),
-                               (neighbor_list, neighbor_ptr, neighbor_shifts, neighbor_matrix, neighbor_matrix_shifts))
+                               (neighbor_list, neighbor_ptr, neighbor_shifts, neighbor_matrix, neighbor_matrix_shifts), bool(compute_forces))
     real = ewald_real_space(positions=positions, charges=charges, cell=cells, alpha=alpha, neighbor_list=neighbor_list,
                             neighbor_ptr=neighbor_ptr, neighbor_shifts=neighbor_shifts, neighbor_matrix=neighbor_matrix,
                             neighbor_matrix_shifts=neighbor_matrix_shifts, mask_value=mask_value, batch_idx=batch_idx,

@@ -692,3 +692,48 @@ def test_fused_autograd_nodes_never_return_a_silent_second_derivative():
                 torch.autograd.grad((f ** 2).sum(), p)
         finally:
             P._FUSED_AUTOGRAD = True
+
+
+@pytest.mark.parametrize("batched", [False, True])
+@pytest.mark.parametrize("which", ["pme_reciprocal_space", "particle_mesh_ewald"])
+def test_fused_nodes_with_explicit_forces_equal_the_composition(which, batched, monkeypatch):
+    """Force matching on the EXPLICIT forces: L = sum_i g_i E_i + sum_i G_i . F_i through the fused nodes (second-derivative adjoint in closed
+    form: three more spread / FFT channels, `mi_pme_convolve_bwd` with four weight channels, gather-gradients of the field meshes,
+    `mi_ewald_real_forces_bwd`) against the round-3 composition: positions, charges, triclinic cells, per-system alpha; also with the force
+    term alone (no gradient flowing into the energies)."""
+    from nvalchemiops.interactions.electrostatics import particle_mesh_ewald, pme_reciprocal_space
+    from nvalchemiops.interactions.electrostatics import pme as P
+    from nvalchemiops.neighborlist import batch_cell_list, cell_list
+
+    pos, cell, q = _system(70, seed=5)
+    bi, nsys = None, 1
+    if batched:
+        p2, c2, q2 = _system(50, box=9.5, seed=6)
+        pos, q, cell = torch.cat([pos, p2]), torch.cat([q, q2]), torch.stack([cell, c2])
+        bi, nsys = torch.tensor([0] * 70 + [1] * 50, dtype=torch.int32, device=DEV), 2
+    n = pos.shape[0]
+    gen = torch.Generator(device=DEV).manual_seed(3)
+    wts = torch.randn(n, dtype=torch.float64, device=DEV, generator=gen)
+    wf = torch.randn((n, 3), dtype=torch.float64, device=DEV, generator=gen)
+    alpha0 = torch.tensor([0.45, 0.5][:nsys], dtype=torch.float64, device=DEV)
+    kw = dict(mesh_dimensions=(16, 18, 16), spline_order=4, batch_idx=bi, compute_forces=True)
+    if which == "particle_mesh_ewald":
+        if batched:
+            nm, num, sh = batch_cell_list(pos, 4.5, cell, torch.ones((2, 3), dtype=torch.bool, device=DEV), bi, max_neighbors=96)
+        else:
+            nm, num, sh = cell_list(pos, 4.5, cell, torch.tensor([True] * 3, device=DEV), max_neighbors=96)
+        kw.update(neighbor_matrix=nm, neighbor_matrix_shifts=sh)
+    fn = particle_mesh_ewald if which == "particle_mesh_ewald" else pme_reciprocal_space
+
+    def grads(fused, energy_term):
+        monkeypatch.setattr(P, "_FUSED_AUTOGRAD", fused)
+        p, v, c, a = (t.clone().requires_grad_(True) for t in (pos, q, cell, alpha0))
+        e, f = fn(p, v, c, alpha=a, **kw)
+        assert type(e.grad_fn).__name__.startswith("_Fused") == fused
+        loss = (f * wf).sum() + ((e * wts).sum() if energy_term else 0.0)
+        return (e.detach(), f.detach()) + torch.autograd.grad(loss, (p, v, c, a))
+
+    for energy_term in (True, False):
+        got, want = grads(True, energy_term), grads(False, energy_term)
+        for a, b, what in zip(got, want, ("energies", "forces", "d/dpositions", "d/dcharges", "d/dcell", "d/dalpha")):
+            assert a.shape == b.shape and (a - b).abs().max().item() <= 1e-9 * max(1.0, b.abs().max().item()), (which, batched, energy_term, what, (a - b).abs().max().item())
