@@ -180,7 +180,7 @@ struct SpTile { int ex, ey, ez; };
 static int sp_edge(int n) { for (int e = SP_T; e > 1; --e) if (n % e == 0) return e; return 1; }
 static SpTile sp_tile(int nx, int ny, int nz) { return SpTile{sp_edge(nx), sp_edge(ny), sp_edge(nz)}; }
 
-struct SpLayout { size_t keys_in, vals_out, bin_start, lo3, wts, bins, total; long long nbins; };
+struct SpLayout { size_t keys_in, vals_out, bin_start, lo3, theta, bins, boxes, total; long long nbins; };
 static SpLayout sp_layout(int N, int B, int nx, int ny, int nz) {
   SpLayout L;
   size_t o = 0;
@@ -190,9 +190,11 @@ static SpLayout sp_layout(int N, int B, int nx, int ny, int nz) {
   L.keys_in = take(sizeof(int) * (size_t)N);
   L.vals_out = take(sizeof(int) * ((size_t)N + 4));                // [0]: order header (see spread_key_kernel), [4..]: atom ids grouped by tile
   L.bin_start = take(sizeof(int) * (size_t)(L.nbins + 2));
-  L.lo3 = take(sizeof(int) * 4 * (size_t)N);                       // first stencil index per axis (wrapped), per atom
-  L.wts = take(sizeof(double) * 3 * MI_MAX_ORDER * (size_t)N);     // 1-D weights [3][MI_MAX_ORDER] per atom (sized for fp64)
+  L.lo3 = take(sizeof(int) * 4 * (size_t)N);                       // first stencil index per axis (wrapped) + system, per atom
+  L.theta = take(sizeof(double) * 3 * (size_t)N);                  // fractional offset inside the mesh cell per axis, [3][N] (sized for fp64)
   L.bins = take(sizeof(int) * bs_scratch_ints(L.nbins + 1));  // counting-sort counters (binsort.h)
+  // per-tile accumulation boxes of the two-phase spread: (e + MI_MAX_ORDER - 1)^3 points per tile (sized for fp64 and the largest order)
+  L.boxes = take(sizeof(double) * (size_t)L.nbins * (e.ex + MI_MAX_ORDER - 1) * (e.ey + MI_MAX_ORDER - 1) * (e.ez + MI_MAX_ORDER - 1));
   L.total = o;
   return L;
 }
@@ -207,8 +209,8 @@ static bool sp_tiled_ok(int nx, int ny, int nz, int B, int order) {
 
 template <class T>
 __global__ void spread_key_kernel(const T* __restrict__ pos, const int* __restrict__ batch_idx, const T* __restrict__ cit, int N, int nx, int ny,
-                                  int nz, int order, SpTile e, int* __restrict__ keys, int* __restrict__ count, int4* __restrict__ lo3, T* __restrict__ wts,
-                                  int* __restrict__ incoherent) {
+                                  int nz, int order, SpTile e, int* __restrict__ keys, int* __restrict__ count, int4* __restrict__ lo3,
+                                  T* __restrict__ theta, int* __restrict__ incoherent) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const bool in = i < N;
   int key = 0;
@@ -218,19 +220,10 @@ __global__ void spread_key_kernel(const T* __restrict__ pos, const int* __restri
     const int lx = wrap_idx(st.base[0] + st.off0[0], nx), ly = wrap_idx(st.base[1] + st.off0[1], ny), lz = wrap_idx(st.base[2] + st.off0[2], nz);
     key = ((s * (nx / e.ex) + lx / e.ex) * (ny / e.ey) + ly / e.ey) * (nz / e.ez) + lz / e.ez;
     keys[i] = key;
+    // the box kernel evaluates the 1-D weights of its own atoms from exactly these numbers (round 4; this kernel used to store 144 B of weights
+    // per atom): stencil start and fractional offsets come from ONE evaluation, so tile and weights cannot disagree at a mesh-cell boundary
     lo3[i] = make_int4(lx, ly, lz, s);
-    // the 1-D weights are evaluated once per atom here; the tile kernel (up to 8 tiles x order^2 threads per atom) only reads them.
-    // Written as 16-byte (fp64) / 8-byte (fp32) pieces: the record of an atom is 144 / 72 bytes, so every lane of a store instruction
-    // touches its own cache line anyway -- half (a quarter) as many instructions as one store per weight
-    T wrec[3 * MI_MAX_ORDER];
-#pragma unroll
-    for (int d = 0; d < 3; ++d)
-#pragma unroll
-      for (int t = 0; t < MI_MAX_ORDER; ++t) wrec[d * MI_MAX_ORDER + t] = t < order ? weight_1d(st, d, t, order) : T(0);
-    typedef T wt2 __attribute__((ext_vector_type(2)));
-    wt2* dst = reinterpret_cast<wt2*>(wts + (size_t)i * 3 * MI_MAX_ORDER);
-#pragma unroll
-    for (int k = 0; k < 3 * MI_MAX_ORDER / 2; ++k) dst[k] = wt2{wrec[2 * k], wrec[2 * k + 1]};
+    theta[i] = st.theta[0]; theta[(size_t)N + i] = st.theta[1]; theta[2 * (size_t)N + i] = st.theta[2];
   }
   bs_wave_add<false>(count, key, in);  // the tile's atom counter (binsort.h): one atomic per distinct tile per wave
   // Is the caller's atom order spatially coherent?  Count the consecutive atoms (i, i + 1) that share neither a tile nor a neighbouring
@@ -248,64 +241,104 @@ __global__ void spread_key_kernel(const T* __restrict__ pos, const int* __restri
   const unsigned long long m = __ballot(bad);
   if (m && (threadIdx.x & (MI_WAVE - 1)) == 0) atomicAdd(incoherent, (int)__popcll(m));
 }
-// ORDER is a template parameter (round 3): the item -> (atom, tx, ty) split and the z loop become constant divisions / a full unroll, and
-// the "does this point fall into my tile" tests are range compares instead of divisions by the tile edge
+// ---- two-phase tile spread (round 4) -------------------------------------------------------------------------------------------------
+// Rounds 1 - 3 ran a tile-owned kernel: a block per mesh tile collected from the atoms of up to 8 source tiles (a stencil starting in tile t
+// reaches t and t+1 per axis) and threw seven eighths of the visited points away -- 20 M thread-visits for 2.5 M useful columns on the
+// headline mesh, each behind three dependent loads (0.092 ms, latency-bound).  Here a tile's block handles ITS atoms once, accumulating whole stencils into an LDS box of
+// (e + order - 1)^3 points (tile + forward halo, no wrap inside the box), and writes the box to scratch; a second kernel owns the mesh
+// points and adds the <= 8 boxes that cover each: plain coalesced loads, a fixed summation order across tiles, no global atomics.
+#define SPB_CHUNK 64  // atoms of the tile staged per pass: their 1-D weights (3 x order each) are evaluated once, by 3 threads per atom, into LDS
 template <class T, int ORDER>
-__global__ __launch_bounds__(256) void spread_tiled_kernel(const T* __restrict__ values, const int* __restrict__ atom_of, const int* __restrict__ bin_start,
-                                                           const int4* __restrict__ lo3, const T* __restrict__ wts, int nx, int ny, int nz,
-                                                           int batched, SpTile e, T* __restrict__ mesh, int* __restrict__ order_hdr,
-                                                           const int* __restrict__ incoherent) {
-  constexpr int order = ORDER;
-  __shared__ T tile[SP_T * SP_T * SP_T];
+__global__ __launch_bounds__(256) void spread_box_kernel(const T* __restrict__ values, const int* __restrict__ atom_of, const int* __restrict__ bin_start,
+                                                         const int4* __restrict__ lo3, const T* __restrict__ theta_all, int N, int nx, int ny, int nz,
+                                                         int batched, SpTile e, T* __restrict__ boxes, int* __restrict__ order_hdr,
+                                                         const int* __restrict__ incoherent) {
+  constexpr int order = ORDER, H = ORDER - 1;
+  __shared__ T box[(SP_T + H) * (SP_T + H) * (SP_T + H)];
+  __shared__ T wl[SPB_CHUNK][3][ORDER];
+  __shared__ int lo_s[SPB_CHUNK][3];
+  __shared__ T val_s[SPB_CHUNK];
   if (blockIdx.x == 0 && threadIdx.x == 0) order_hdr[0] = *incoherent;  // header of the tile-grouped atom list (read by the gather epilogue)
-  const int nbx = nx / e.ex, nby = ny / e.ey, nbz = nz / e.ez, tile_n = e.ex * e.ey * e.ez;
+  const int nbx = nx / e.ex, nby = ny / e.ey, nbz = nz / e.ez;
+  const int bxn = e.ex + H, byn = e.ey + H, bzn = e.ez + H, box_n = bxn * byn * bzn;
   int b = blockIdx.x;
   const int bz = b % nbz; b /= nbz;
   const int by = b % nby; b /= nby;
   const int bx = b % nbx;
-  const int s = b / nbx;
-  for (int k = threadIdx.x; k < tile_n; k += blockDim.x) tile[k] = T(0);
-  __syncthreads();
+  const int org[3] = {bx * e.ex, by * e.ey, bz * e.ez};
+  for (int k = threadIdx.x; k < box_n; k += blockDim.x) box[k] = T(0);
   const int tpa = order * order;
   const T thr = batched ? T(1e-8) : T(0);  // spline.py:548 (w > 0) vs :820 (w > 1e-8)
-  // a stencil starting in tile t reaches t and t+1 (periodic): this tile collects from source bins {b, b-1} per axis
-  const int sxn = nbx > 1 ? 2 : 1, syn = nby > 1 ? 2 : 1, szn = nbz > 1 ? 2 : 1;
-  for (int sx = 0; sx < sxn; ++sx)
-    for (int sy = 0; sy < syn; ++sy)
-      for (int sz = 0; sz < szn; ++sz) {
-        const int cx = (bx - sx + nbx) % nbx, cy = (by - sy + nby) % nby, cz = (bz - sz + nbz) % nbz;
-        const int key = ((s * nbx + cx) * nby + cy) * nbz + cz;
-        const int beg = bin_start[key], end = bin_start[key + 1];
-        for (int t = threadIdx.x; t < (end - beg) * tpa; t += blockDim.x) {
-          const int a = beg + t / tpa, col = t - (t / tpa) * tpa;
-          const int i = atom_of[a];
-          const int4 lo = lo3[i];
-          const int tx = col / order, ty = col - tx * order;
-          int gx = lo.x + tx, gy = lo.y + ty;  // lo is already wrapped and order <= n: one conditional subtraction wraps
-          gx -= gx >= nx ? nx : 0;
-          gy -= gy >= ny ? ny : 0;
-          const int rx = gx - bx * e.ex, ry = gy - by * e.ey;  // offsets inside this tile, if the point belongs to it
-          if ((unsigned)rx >= (unsigned)e.ex || (unsigned)ry >= (unsigned)e.ey) continue;
-          const T* w3 = wts + (size_t)i * 3 * MI_MAX_ORDER;
-          const T wxy = w3[tx] * w3[MI_MAX_ORDER + ty];
-          const T val = values[i];
-          T* row = tile + (rx * e.ey + ry) * e.ez;
+  const int beg = bin_start[blockIdx.x], end = bin_start[blockIdx.x + 1];
+  for (int c0 = beg; c0 < end; c0 += SPB_CHUNK) {
+    const int nc = end - c0 < SPB_CHUNK ? end - c0 : SPB_CHUNK;
+    __syncthreads();  // box zeroed / previous chunk consumed
+    if (threadIdx.x < 3 * nc) {
+      // one thread per (atom, axis): the `order` 1-D weights of that axis from the key kernel's fractional offset (weight_1d's expression:
+      // bspline_grid_offset + bspline_weight_3d, spline.py:300-408) and the stencil start in box coordinates
+      const int a = threadIdx.x / 3, d = threadIdx.x - 3 * a;
+      const int i = atom_of[c0 + a];
+      const int4 lo = lo3[i];
+      const T theta = theta_all[(size_t)d * N + i];
+      const int off0 = (int)floor(theta - (T)(order - 2) * T(0.5));
+      lo_s[a][d] = (d == 0 ? lo.x : (d == 1 ? lo.y : lo.z)) - org[d];  // inside [0, e): the bin key IS the tile of the stencil's first point
 #pragma unroll
-          for (int tz = 0; tz < order; ++tz) {
-            int gz = lo.z + tz;
-            gz -= gz >= nz ? nz : 0;
-            const int rz = gz - bz * e.ez;
-            if ((unsigned)rz >= (unsigned)e.ez) continue;
-            const T w = wxy * w3[2 * MI_MAX_ORDER + tz];
-            if (w > thr) atomicAdd(row + rz, val * w);
-          }
-        }
+      for (int t = 0; t < order; ++t) {
+        const T u = (T)order * T(0.5) + theta - (T)(t + off0);
+        wl[a][d][t] = (u < T(0) || u >= (T)order) ? T(0) : bspline_weight(u, order);
       }
-  __syncthreads();
-  for (int k = threadIdx.x; k < tile_n; k += blockDim.x) {
-    const int lx = k / (e.ey * e.ez), ly = (k / e.ez) % e.ey, lz = k % e.ez;
-    mesh[(((size_t)s * nx + bx * e.ex + lx) * ny + by * e.ey + ly) * nz + bz * e.ez + lz] = tile[k];
+      if (d == 0) val_s[a] = values[i];
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < nc * tpa; t += blockDim.x) {
+      const int a = t / tpa, col = t - a * tpa;
+      const int tx = col / order, ty = col - tx * order;
+      const T wxy = wl[a][0][tx] * wl[a][1][ty];
+      const T val = val_s[a];
+      T* row = box + ((lo_s[a][0] + tx) * byn + lo_s[a][1] + ty) * bzn + lo_s[a][2];  // box coordinates need no wrap
+#pragma unroll
+      for (int tz = 0; tz < order; ++tz) {
+        const T w = wxy * wl[a][2][tz];
+        if (w > thr) atomicAdd(row + tz, val * w);
+      }
+    }
   }
+  __syncthreads();
+  T* out = boxes + (size_t)blockIdx.x * box_n;
+  for (int k = threadIdx.x; k < box_n; k += blockDim.x) out[k] = box[k];
+}
+// thread per mesh point: its own tile's box plus, per axis, the previous tile's box where the point lies inside that tile's forward halo
+template <class T>
+__global__ __launch_bounds__(256) void spread_box_reduce_kernel(const T* __restrict__ boxes, int nx, int ny, int nz, int B, int order, SpTile e,
+                                                               T* __restrict__ mesh) {
+  const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t per = (size_t)nx * ny * nz;
+  if (g >= per * B) return;
+  const int s = (int)(g / per);
+  const size_t r = g - (size_t)s * per;
+  const int z = (int)(r % nz), y = (int)((r / nz) % ny), x = (int)(r / ((size_t)nz * ny));
+  const int H = order - 1;
+  const int nbx = nx / e.ex, nby = ny / e.ey, nbz = nz / e.ez;
+  const int bxn = e.ex + H, byn = e.ey + H, bzn = e.ez + H;
+  const size_t box_n = (size_t)bxn * byn * bzn;
+  const int tx = x / e.ex, ty = y / e.ey, tz = z / e.ez;
+  const int lx = x - tx * e.ex, ly = y - ty * e.ey, lz = z - tz * e.ez;
+  T acc = T(0);
+  for (int dx = 0; dx < 2; ++dx) {
+    if (dx && lx >= H) break;
+    const int sx = dx ? (tx == 0 ? nbx - 1 : tx - 1) : tx, px = lx + dx * e.ex;
+    for (int dy = 0; dy < 2; ++dy) {
+      if (dy && ly >= H) break;
+      const int sy = dy ? (ty == 0 ? nby - 1 : ty - 1) : ty, py = ly + dy * e.ey;
+      for (int dz = 0; dz < 2; ++dz) {
+        if (dz && lz >= H) break;
+        const int sz = dz ? (tz == 0 ? nbz - 1 : tz - 1) : tz, pz = lz + dz * e.ez;
+        const size_t tile = (((size_t)s * nbx + sx) * nby + sy) * nbz + sz;
+        acc += boxes[tile * box_n + ((size_t)px * byn + py) * bzn + pz];
+      }
+    }
+  }
+  mesh[g] = acc;
 }
 
 // ---- per-system cell geometry in one launch: cell^-T (fractional-coordinate transform), 2 pi cell^-1 (reciprocal rows), |det|
@@ -828,21 +861,25 @@ int spread_tiled(const T* pos, const T* values, const int* batch_idx, const T* c
   int* vals_out = order_hdr + 4;
   int* bin_start = reinterpret_cast<int*>(ws + L.bin_start);
   int4* lo3 = reinterpret_cast<int4*>(ws + L.lo3);
-  T* wts = reinterpret_cast<T*>(ws + L.wts);
+  T* theta = reinterpret_cast<T*>(ws + L.theta);
   const BsScratch bins = bs_carve(reinterpret_cast<int*>(ws + L.bins), L.nbins + 1);  // + 1: the end sentinel bin_start[nbins] = N
   MI_HIP_CHECK(bs_clear(bins, st));
   int* incoherent = bins.fill + L.nbins;  // the sentinel's fill slot: cleared with the counters, touched by no key
-  spread_key_kernel<T><<<mi_blocks(N, 256), 256, 0, st>>>(pos, batch_idx, cit, N, nx, ny, nz, order, e, keys_in, bins.count, lo3, wts, incoherent);
+  spread_key_kernel<T><<<mi_blocks(N, 256), 256, 0, st>>>(pos, batch_idx, cit, N, nx, ny, nz, order, e, keys_in, bins.count, lo3, theta, incoherent);
   MI_LAUNCH_CHECK();
   // order inside a tile's atom list is arrival order: the tile kernel adds the contributions with LDS atomics, whose order is
   // not fixed either (fp64/fp32 sums of <= a few hundred terms per mesh point; parity tests hold at 1e-10)
   MI_HIP_CHECK(bs_sort(bins, keys_in, N, nullptr, vals_out, bin_start, st));
+  // two-phase spread: per-tile LDS boxes, then every mesh point adds the boxes that cover it
+  T* boxes = reinterpret_cast<T*>(ws + L.boxes);
   switch (order) {
-#define MI_SPT(O_) case O_: spread_tiled_kernel<T, O_><<<(int)L.nbins, 256, 0, st>>>(values, vals_out, bin_start, lo3, wts, nx, ny, nz, batched, e, mesh, order_hdr, incoherent); break
-    MI_SPT(1); MI_SPT(2); MI_SPT(3); MI_SPT(4); MI_SPT(5);
-    default: spread_tiled_kernel<T, 6><<<(int)L.nbins, 256, 0, st>>>(values, vals_out, bin_start, lo3, wts, nx, ny, nz, batched, e, mesh, order_hdr, incoherent); break;
-#undef MI_SPT
+#define MI_SPB(O_) case O_: spread_box_kernel<T, O_><<<(int)L.nbins, 256, 0, st>>>(values, vals_out, bin_start, lo3, theta, N, nx, ny, nz, batched, e, boxes, order_hdr, incoherent); break
+    MI_SPB(1); MI_SPB(2); MI_SPB(3); MI_SPB(4); MI_SPB(5);
+    default: spread_box_kernel<T, 6><<<(int)L.nbins, 256, 0, st>>>(values, vals_out, bin_start, lo3, theta, N, nx, ny, nz, batched, e, boxes, order_hdr, incoherent); break;
+#undef MI_SPB
   }
+  MI_LAUNCH_CHECK();
+  spread_box_reduce_kernel<T><<<mi_blocks((long long)B * nx * ny * nz, 256), 256, 0, st>>>(boxes, nx, ny, nz, B, order, e, mesh);
   MI_LAUNCH_CHECK();
   return MI_OK;
 }
