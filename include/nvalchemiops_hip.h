@@ -373,7 +373,7 @@ int mi_fft_plan_destroy(void* plan);
  *   (pme.py:1429-1477; pme_kernels.py:340-657) fused over the 4 planar real-space meshes.  add_energies / add_forces /
  *   add_charge_grads (NULL ok): the real-space part (mi_ewald_real outputs: float64 energies and charge gradients, forces in
  *   `dtype`) added in the epilogue -- the `real + reciprocal` sums of particle_mesh_ewald (pme.py:1975-1990).
- *   atom_order only changes which lanes work on which atom (mesh locality for callers whose atoms are not spatially ordered), never a result.
+ *   spread_workspace selects the tile-staged kernel (round 4); results equal the per-atom kernel's up to the order of the order^3 additions.
  */
 int mi_pme_green_sf(const void* k_squared /*[B,nx,ny,nzr]*/, const void* alpha /*[B]*/, const void* volume /*[B]*/,
                     int n_systems, int nx, int ny, int nz, int sf_exponent, int dtype, void* green /*[B,nx,ny,nzr]*/,
@@ -400,8 +400,9 @@ int mi_pme_gather_finish(const void* positions, const void* charges, const int32
                          int order, int with_field, int dtype, void* energies /*[n_atoms]*/,
                          void* forces /*[n_atoms,3] or NULL*/, void* charge_grads /*[n_atoms] or NULL*/,
                          const double* add_energies, const void* add_forces, const double* add_charge_grads,
-                         const int32_t* atom_order /*NULL, or the int32[4 + n_atoms] array the spread of the same call left in its workspace
-                           (mi_spline_spread_order_offset): the atoms are walked tile by tile when [0] > n_atoms / 4*/,
+                         const void* spread_workspace /*NULL, or the workspace of the tile-owned mi_spline_spread of the SAME step (same positions,
+                           mesh, order; see mi_spline_spread_is_tiled): atoms grouped by mesh tile + stencil starts + fractional offsets -> the
+                           tile-staged gather (mesh boxes through LDS); NULL -> the per-atom gather*/,
                          void* stream);
 int mi_pme_corrections(const void* raw, const void* charges, const int32_t* batch_idx, const void* volume,
                        const void* alpha, const void* total_charge, int n_atoms, int dtype, void* energies,

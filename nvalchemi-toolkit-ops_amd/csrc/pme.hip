@@ -247,7 +247,7 @@ __global__ void spread_key_kernel(const T* __restrict__ pos, const int* __restri
 // headline mesh, each behind three dependent loads (0.092 ms, latency-bound).  Here a tile's block handles ITS atoms once, accumulating whole stencils into an LDS box of
 // (e + order - 1)^3 points (tile + forward halo, no wrap inside the box), and writes the box to scratch; a second kernel owns the mesh
 // points and adds the <= 8 boxes that cover each: plain coalesced loads, a fixed summation order across tiles, no global atomics.
-#define SPB_CHUNK 64  // atoms of the tile staged per pass: their 1-D weights (3 x order each) are evaluated once, by 3 threads per atom, into LDS
+#define SPB_CHUNK 32  // atoms of the tile staged per pass: their 1-D weights (3 x order each) are evaluated once, by 3 threads per atom, into LDS
 template <class T, int ORDER>
 __global__ __launch_bounds__(256) void spread_box_kernel(const T* __restrict__ values, const int* __restrict__ atom_of, const int* __restrict__ bin_start,
                                                          const int4* __restrict__ lo3, const T* __restrict__ theta_all, int N, int nx, int ny, int nz,
@@ -662,6 +662,119 @@ __global__ __launch_bounds__(256) void pme_gather_finish_kernel(const T* __restr
       forces[3 * (size_t)i] = add_f[3 * (size_t)i] + fx; forces[3 * (size_t)i + 1] = add_f[3 * (size_t)i + 1] + fy;
       forces[3 * (size_t)i + 2] = add_f[3 * (size_t)i + 2] + fz;
     } else { forces[3 * (size_t)i] = fx; forces[3 * (size_t)i + 1] = fy; forces[3 * (size_t)i + 2] = fz; }
+  }
+}
+
+// ---- tile-staged gather epilogue (round 4) ----------------------------------------------------------------------------------------------------
+// The kernel above reads order^3 x (1 | 4) mesh values per atom straight from L2 / MALL: 50 M scattered 8-byte loads on the headline mesh,
+// latency-bound (0.11 ms) with 5 of 8 lanes busy at order 5.  The spread of the same step has already grouped the atoms by mesh tile and left
+// each atom's stencil start and fractional offsets in its workspace; a stencil that starts in tile t lies inside t's box (tile + forward halo).
+// So: a block per tile stages the box of one mesh channel at a time in LDS with coalesced loads (periodic wrap applied while staging), its
+// atoms take their order^3 values from LDS -- one (x, y) column per lane, 25 of 32 lanes per atom at order 5, fixed shuffle tree: the sums
+// do not depend on any arrival order -- and one thread per atom finishes exactly as above (corrections, x2 force, real-space parts added).
+#define PGB_CHUNK 32  // atoms of the tile per pass (tiles hold ~24 atoms at liquid density; denser tiles take more passes and re-stage the boxes)
+template <class T, int ORDER>
+__global__ __launch_bounds__(256) void pme_gather_box_kernel(const T* __restrict__ charges, const T* __restrict__ meshes, const T* __restrict__ alpha,
+                                                            const T* __restrict__ volume, const T* __restrict__ qtot, const int* __restrict__ atom_of,
+                                                            const int* __restrict__ bin_start, const int4* __restrict__ lo3,
+                                                            const T* __restrict__ theta_all, int N, int nx, int ny, int nz, int with_field, SpTile e,
+                                                            T* __restrict__ energies, T* __restrict__ forces, T* __restrict__ cgrads,
+                                                            const double* __restrict__ add_e, const T* __restrict__ add_f,
+                                                            const double* __restrict__ add_cg, T wscale) {
+  constexpr int order = ORDER, H = ORDER - 1;
+  constexpr int GL = ORDER * ORDER <= 16 ? 16 : (ORDER * ORDER <= 32 ? 32 : 64);  // lanes per atom: the (x, y) columns, rounded up to a power of two
+  __shared__ T box[(SP_T + H) * (SP_T + H) * (SP_T + H)];
+  __shared__ T wl[PGB_CHUNK][3][ORDER];
+  __shared__ int lo_s[PGB_CHUNK][3];
+  __shared__ T res[PGB_CHUNK][4];
+  const int nbx = nx / e.ex, nby = ny / e.ey, nbz = nz / e.ez;
+  const int bxn = e.ex + H, byn = e.ey + H, bzn = e.ez + H, box_n = bxn * byn * bzn;
+  int b = blockIdx.x;
+  const int bz = b % nbz; b /= nbz;
+  const int by = b % nby; b /= nby;
+  const int bx = b % nbx;
+  const int s = b / nbx;
+  const int org[3] = {bx * e.ex, by * e.ey, bz * e.ez};
+  const size_t plane = (size_t)nx * ny * nz;
+  const int C = with_field ? 4 : 1;
+  const T* m0 = meshes + (size_t)s * C * plane;
+  const int beg = bin_start[blockIdx.x], end = bin_start[blockIdx.x + 1];
+  const int grp = threadIdx.x / GL, gl = threadIdx.x - grp * GL, ngrp = 256 / GL;
+  const int gtx = gl / order, gty = gl - gtx * order;
+  for (int c0 = beg; c0 < end; c0 += PGB_CHUNK) {
+    const int nc = end - c0 < PGB_CHUNK ? end - c0 : PGB_CHUNK;
+    __syncthreads();  // previous pass consumed
+    if (threadIdx.x < 3 * nc) {  // 1-D weights of this pass's atoms, exactly as the spread's box kernel forms them (weight_1d's expression)
+      const int a = threadIdx.x / 3, d = threadIdx.x - 3 * a;
+      const int i = atom_of[c0 + a];
+      const int4 lo = lo3[i];
+      const T theta = theta_all[(size_t)d * N + i];
+      const int off0 = (int)floor(theta - (T)(order - 2) * T(0.5));
+      lo_s[a][d] = (d == 0 ? lo.x : (d == 1 ? lo.y : lo.z)) - org[d];
+#pragma unroll
+      for (int t = 0; t < order; ++t) {
+        const T u = (T)order * T(0.5) + theta - (T)(t + off0);
+        wl[a][d][t] = ((u < T(0) || u >= (T)order) ? T(0) : bspline_weight(u, order)) * (d == 0 ? wscale : T(1));
+      }
+    }
+    // the box of channel ch + 1 is fetched into registers while channel ch is being gathered from LDS (staging latency off the critical path)
+    constexpr int NPT = ((SP_T + H) * (SP_T + H) * (SP_T + H) + 255) / 256;
+    T pre[NPT];
+    auto fetch = [&](int ch) {
+      const T* mc = m0 + (size_t)ch * plane;
+#pragma unroll
+      for (int u = 0; u < NPT; ++u) {
+        const int k = threadIdx.x + u * 256;
+        if (k < box_n) {
+          const int pz = k % bzn, pxy = k / bzn, py = pxy % byn, px = pxy / byn;
+          int gx = org[0] + px, gy = org[1] + py, gz = org[2] + pz;  // forward halo: at most one wrap
+          gx -= gx >= nx ? nx : 0; gy -= gy >= ny ? ny : 0; gz -= gz >= nz ? nz : 0;
+          pre[u] = mc[((size_t)gx * ny + gy) * nz + gz];
+        }
+      }
+    };
+    fetch(0);
+    for (int ch = 0; ch < C; ++ch) {
+      __syncthreads();  // weights ready / previous channel's box consumed
+#pragma unroll
+      for (int u = 0; u < NPT; ++u) { const int k = threadIdx.x + u * 256; if (k < box_n) box[k] = pre[u]; }
+      if (ch + 1 < C) fetch(ch + 1);
+      __syncthreads();
+      for (int a = grp; a < nc; a += ngrp) {
+        T part = T(0);
+        if (gl < order * order) {
+          const T wxy = wl[a][0][gtx] * wl[a][1][gty];
+          const T* row = box + ((lo_s[a][0] + gtx) * byn + lo_s[a][1] + gty) * bzn + lo_s[a][2];
+          const T q = ch ? charges[atom_of[c0 + a]] : T(1);  // field channels: (q * mesh) * w as in gather_vec3
+#pragma unroll
+          for (int tz = 0; tz < order; ++tz) {
+            const T w = wxy * wl[a][2][tz];
+            if (w > T(1e-8)) part += (ch ? q * row[tz] : row[tz]) * w;
+          }
+        }
+#pragma unroll
+        for (int o = GL / 2; o > 0; o >>= 1) part += __shfl_xor(part, o, GL);
+        if (gl == 0) res[a][ch] = part;
+      }
+    }
+    __syncthreads();
+    if (threadIdx.x < nc) {
+      // `_pme_energy_corrections[_with_charge_grad]_kernel` (pme_kernels.py:340-657) and the real-space parts, as in pme_gather_finish_kernel
+      const int i = atom_of[c0 + threadIdx.x];
+      const T q = charges[i], phi = res[threadIdx.x][0];
+      const T pi = T(3.14159265358979323846), two = 2;
+      const T al = alpha[s], vol = volume[s], qt = qtot[s];
+      const T er = q * phi - q * q * al / sqrt(pi) - q * pi * qt / (two * al * al * vol);
+      energies[i] = add_e ? (T)add_e[i] + er : er;
+      if (cgrads) { const T cr = two * phi - two * al * q / sqrt(pi) - pi * qt / (al * al * vol); cgrads[i] = add_cg ? (T)add_cg[i] + cr : cr; }
+      if (with_field && forces) {  // forces = 2 * gather_vec3 (pme.py:1477)
+        const T fx = two * res[threadIdx.x][1], fy = two * res[threadIdx.x][2], fz = two * res[threadIdx.x][3];
+        if (add_f) {
+          forces[3 * (size_t)i] = add_f[3 * (size_t)i] + fx; forces[3 * (size_t)i + 1] = add_f[3 * (size_t)i + 1] + fy;
+          forces[3 * (size_t)i + 2] = add_f[3 * (size_t)i + 2] + fz;
+        } else { forces[3 * (size_t)i] = fx; forces[3 * (size_t)i + 1] = fy; forces[3 * (size_t)i + 2] = fz; }
+      }
+    }
   }
 }
 
@@ -1152,20 +1265,38 @@ int mi_pme_convolve_bwd_blocks(void) { return PME_BWD_BLOCKS; }
 int mi_pme_gather_finish(const void* positions, const void* charges, const int32_t* batch_idx, const void* cell_inv_t, const void* meshes,
                          const void* alpha, const void* volume, const void* total_charge, int n_atoms, int n_systems, int nx, int ny, int nz,
                          int order, int with_field, int dtype, void* energies, void* forces, void* charge_grads, const double* add_energies,
-                         const void* add_forces, const double* add_charge_grads, const int32_t* atom_order, void* stream) {
+                         const void* add_forces, const double* add_charge_grads, const void* spread_workspace, void* stream) {
   MI_REQUIRE(dtype == MI_F32 || dtype == MI_F64, "dtype");
   const OrderArg oa = decode_order(order);
   order = oa.order;
   MI_REQUIRE(order >= 1 && order <= MI_MAX_ORDER, "spline order must be 1..6");
-  (void)n_systems;
   if (n_atoms <= 0) return MI_OK;
-  MI_REQUIRE(positions && charges && cell_inv_t && meshes && alpha && volume && total_charge && energies, "null pointer");
+  MI_REQUIRE(positions && charges && cell_inv_t && meshes && alpha && volume && total_charge && energies && n_systems >= 1, "null pointer");
   hipStream_t st = (hipStream_t)stream;
   mi_timing_begin("pme_gather_finish", stream);
-  MI_DISPATCH_ORDER(order, MI_DISPATCH_T(dtype, (pme_gather_finish_kernel<T_, O_><<<mi_blocks((long long)n_atoms * PG_LANES, 256), 256, 0, st>>>(
-                           (const T_*)positions, (const T_*)charges, batch_idx, (const T_*)cell_inv_t, (const T_*)meshes, (const T_*)alpha,
-                           (const T_*)volume, (const T_*)total_charge, n_atoms, nx, ny, nz, with_field, (T_*)energies, (T_*)forces,
-                           (T_*)charge_grads, add_energies, (const T_*)add_forces, add_charge_grads, atom_order, oa.ref_zero ? T_(0) : T_(1)))));
+  // the workspace of the tile-owned mi_spline_spread of the SAME step (same positions, mesh, order): atoms grouped by mesh tile, stencil
+  // starts and fractional offsets -- the tile-staged kernel; without it the per-atom kernel
+  static const bool allow_box = []() { const char* v = getenv("NVALCHEMIOPS_GATHER"); return !(v && v[0] == 'a'); }();  // "atom": A/B
+  if (spread_workspace && allow_box && !oa.ref_zero && sp_tiled_ok(nx, ny, nz, n_systems, order)) {
+    const SpLayout L = sp_layout(n_atoms, n_systems, nx, ny, nz);
+    const SpTile e = sp_tile(nx, ny, nz);
+    const char* ws = static_cast<const char*>(spread_workspace);
+    const int* atom_of = reinterpret_cast<const int*>(ws + L.vals_out) + 4;
+    const int* bin_start = reinterpret_cast<const int*>(ws + L.bin_start);
+    const int4* lo3 = reinterpret_cast<const int4*>(ws + L.lo3);
+    MI_DISPATCH_ORDER(order, MI_DISPATCH_T(dtype, (pme_gather_box_kernel<T_, O_><<<(int)L.nbins, 256, 0, st>>>(
+                             (const T_*)charges, (const T_*)meshes, (const T_*)alpha, (const T_*)volume, (const T_*)total_charge, atom_of, bin_start, lo3,
+                             reinterpret_cast<const T_*>(ws + L.theta), n_atoms, nx, ny, nz, with_field, e, (T_*)energies, (T_*)forces,
+                             (T_*)charge_grads, add_energies, (const T_*)add_forces, add_charge_grads, T_(1)))));
+  } else {
+    const int32_t* atom_order = nullptr;
+    if (spread_workspace && sp_tiled_ok(nx, ny, nz, n_systems, order))
+      atom_order = reinterpret_cast<const int32_t*>(static_cast<const char*>(spread_workspace) + sp_layout(n_atoms, n_systems, nx, ny, nz).vals_out);
+    MI_DISPATCH_ORDER(order, MI_DISPATCH_T(dtype, (pme_gather_finish_kernel<T_, O_><<<mi_blocks((long long)n_atoms * PG_LANES, 256), 256, 0, st>>>(
+                             (const T_*)positions, (const T_*)charges, batch_idx, (const T_*)cell_inv_t, (const T_*)meshes, (const T_*)alpha,
+                             (const T_*)volume, (const T_*)total_charge, n_atoms, nx, ny, nz, with_field, (T_*)energies, (T_*)forces,
+                             (T_*)charge_grads, add_energies, (const T_*)add_forces, add_charge_grads, atom_order, oa.ref_zero ? T_(0) : T_(1)))));
+  }
   mi_timing_end(stream);
   MI_LAUNCH_CHECK();
   return MI_OK;

@@ -60,8 +60,8 @@ def _prep(positions: torch.Tensor, cell: torch.Tensor, batch_idx, cell_inv_t):
 def _launch_spread(pos, vals, cit, bi, nsys, dims, order, batched, want_order=False):
     """mesh[nsys,nx,ny,nz] = spread of `vals` at `pos`.  The library runs tile-owned (no global atomics) when every mesh dimension
     has a divisor in [max(order - 1, 2), 8] and falls back to atomic adds into the zeroed mesh otherwise; the scratch buffer covers the former.
-    want_order: also return the header + atom ids grouped by mesh tile (int32[4 + n] view into the scratch buffer, see
-    mi_spline_spread_order_offset; None after the atomic kernel)."""
+    want_order: also return the scratch buffer of a tile-owned run (None after the atomic kernel): atoms grouped by mesh tile, stencil starts
+    and fractional offsets, which `mi_pme_gather_finish` of the same step takes as `spread_workspace` for its tile-staged gather."""
     import ctypes
 
     nx, ny, nz = (int(v) for v in dims)
@@ -76,8 +76,7 @@ def _launch_spread(pos, vals, cit, bi, nsys, dims, order, batched, want_order=Fa
     C.check(rc, "mi_spline_spread")
     if not want_order:
         return mesh
-    off = int(C.lib().mi_spline_spread_order_offset(n, nsys, nx, ny, nz, C.spline_order_arg(order))) if tiled else -1
-    return mesh, (ws[off:off + 4 * (n + 4)].view(torch.int32) if off >= 0 else None)
+    return mesh, (ws if tiled else None)
 
 
 def _launch_gather(pos, mesh, cit, bi, order, grad=False):
