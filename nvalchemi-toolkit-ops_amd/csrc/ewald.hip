@@ -119,6 +119,8 @@ __global__ __launch_bounds__(256) void ewald_real_kernel(const T* __restrict__ p
   const double qi = (double)q[i], al = (double)alpha[s];
   T cm[9];
   for (int k = 0; k < 9; ++k) cm[k] = cell[9 * (size_t)s + k];
+  // orthorhombic cell (wave-uniform): S . cell has one non-zero product per component; adding the exact zeros of the other six changes nothing
+  const bool ortho = cm[1] == T(0) && cm[2] == T(0) && cm[3] == T(0) && cm[5] == T(0) && cm[6] == T(0) && cm[7] == T(0);
   const T pix = pos[3 * (size_t)i], piy = pos[3 * (size_t)i + 1], piz = pos[3 * (size_t)i + 2];
   const bool wf = (flags & MI_EW_FORCES) != 0, wc = (flags & MI_EW_CHARGE_GRAD) != 0;
   const double two_over_sqrt_pi = 2.0 / 1.7724538509055159;
@@ -138,7 +140,8 @@ __global__ __launch_bounds__(256) void ewald_real_kernel(const T* __restrict__ p
     if (sym) { hf += ew_entry_hash((unsigned)i, (unsigned)j, S0, S1, S2); hr += ew_entry_hash((unsigned)j, (unsigned)i, -S0, -S1, -S2); }
     const T fs[3] = {(T)S0, (T)S1, (T)S2};
     T sh[3];
-    rowvec_mat3(fs, cm, sh);  // == transpose(cell) * S with the same summation order
+    if (ortho) { sh[0] = cm[0] * fs[0]; sh[1] = cm[4] * fs[1]; sh[2] = cm[8] * fs[2]; }  // the other six products are exact zeros
+    else rowvec_mat3(fs, cm, sh);  // == transpose(cell) * S with the same summation order
     const T sx = (pjx - pix) + sh[0], sy = (pjy - piy) + sh[1], sz = (pjz - piz) + sh[2];
     // distance and its reciprocal: fp64 positions -> one reciprocal square root (dist = r2 * rinv, <= 1 ulp from sqrt); fp32 positions keep
     // the reference's fp32 sqrt (the distance is an fp32 quantity there) and take the reciprocal of its fp64 cast
