@@ -7,6 +7,8 @@ piecewise polynomials; orders 5 and 6 are true cardinal B-splines (the reference
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
 from nvalchemiops import _capi as C
@@ -57,6 +59,9 @@ def _prep(positions: torch.Tensor, cell: torch.Tensor, batch_idx, cell_inv_t):
 
 
 # ---- raw launchers (detached, contiguous tensors) ------------------------------------------------------------------
+_TILE_MIN_ATOMS = max(1, int(os.environ.get("NVALCHEMIOPS_SPREAD_TILE_MIN_ATOMS", "1")))
+
+
 def _launch_spread(pos, vals, cit, bi, nsys, dims, order, batched, want_order=False):
     """mesh[nsys,nx,ny,nz] = spread of `vals` at `pos`.  The library runs tile-owned (no global atomics) when every mesh dimension
     has a divisor in [max(order - 1, 2), 8] and falls back to atomic adds into the zeroed mesh otherwise; the scratch buffer covers the former.
@@ -66,10 +71,11 @@ def _launch_spread(pos, vals, cit, bi, nsys, dims, order, batched, want_order=Fa
 
     nx, ny, nz = (int(v) for v in dims)
     n = pos.shape[0]
-    # the tile-owned kernel writes every mesh point exactly once: no zero-fill pass then
-    tiled = n > 0 and bool(C.lib().mi_spline_spread_is_tiled(nsys, nx, ny, nz, C.spline_order_arg(order)))
+    # the tile-owned kernel writes every mesh point exactly once: no zero-fill pass then.  Small systems take the atomic kernel: one
+    # zero-fill + one launch instead of the six launches of the tile pipeline (launch latency is all there is to pay below a few thousand atoms)
+    tiled = n >= _TILE_MIN_ATOMS and bool(C.lib().mi_spline_spread_is_tiled(nsys, nx, ny, nz, C.spline_order_arg(order)))
     mesh = (torch.empty if tiled else torch.zeros)((nsys, nx, ny, nz), dtype=pos.dtype, device=pos.device)
-    ws_bytes = int(C.lib().mi_spline_spread_workspace_bytes(n, nsys, nx, ny, nz))
+    ws_bytes = int(C.lib().mi_spline_spread_workspace_bytes(n, nsys, nx, ny, nz)) if tiled else 0
     ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=pos.device)
     rc = C.lib().mi_spline_spread(C.ptr(pos), C.ptr(vals), C.ptr(bi), C.ptr(cit), n, nsys, nx, ny, nz, C.spline_order_arg(order), int(batched),
                                   C.dtype_code(pos.dtype), C.ptr(mesh), C.ptr(ws), ctypes.c_size_t(ws_bytes), C.stream_of(pos))

@@ -716,3 +716,29 @@ def test_tile_owned_spread(dims, order):
         else:
             # the batch kernels drop weights <= 1e-8 (reference semantics, spline.py:820): conservation only to that level
             assert abs(float(bm[1].sum()) - 2 * q.sum()) < max(tol, 1e-4)
+
+
+@pytest.mark.parametrize("dims", [(8, 8, 8), (16, 8, 24), (30, 36, 45), (12, 10, 14), (31, 9, 6)])
+@pytest.mark.parametrize("order", [3, 4])
+def test_tile_staged_gather_epilogue(dims, order):
+    """The fused reciprocal pipeline on small / odd meshes: the tile-staged gather epilogue (mesh boxes through LDS, fed by the spread's
+    workspace; one tile per axis wraps onto itself for n = e) and its per-atom fallback (31 is prime, 9 -> e = 3 carries order <= 4 only)
+    against the oracle -- energies, forces and charge gradients, atoms outside the cell, fp64 and fp32, single system and a batch of two."""
+    from nvalchemiops.interactions.electrostatics import pme_reciprocal_space
+
+    for dtype in (np.float64, np.float32):
+        pos, cell, q = _system(220, dtype, triclinic=True, seed=order + dims[1])
+        pos = (pos + np.random.default_rng(6).integers(-1, 2, (220, 1)) * cell[1]).astype(dtype)  # some atoms outside the cell
+        e, f, cg = pme_reciprocal_space(_t(pos), _t(q), _t(cell), 0.4, mesh_dimensions=dims, spline_order=order, compute_forces=True,
+                                        compute_charge_gradients=True)
+        ref = O.pme_reciprocal_space(pos, q, cell, 0.4, dims, order, compute_forces=True, compute_charge_gradients=True)
+        for got, want, what in zip((e, f, cg), ref, ("energies", "forces", "charge gradients")):
+            _close(got, want, dtype, f"{what} {dims} order {order}")
+        pos2, q2 = np.concatenate([pos, pos * 0.8]).astype(dtype), np.concatenate([q, 2 * q]).astype(dtype)
+        cells = np.stack([cell, cell * 0.8]).astype(dtype)
+        bi = np.repeat(np.arange(2, dtype=np.int32), len(pos))
+        be, bf = pme_reciprocal_space(_t(pos2), _t(q2), _t(cells), torch.tensor([0.4, 0.5], dtype=_t(pos).dtype, device=DEV), mesh_dimensions=dims,
+                                      spline_order=order, batch_idx=_t(bi), compute_forces=True)
+        bref = O.pme_reciprocal_space(pos2, q2, cells, np.array([0.4, 0.5]), dims, order, batch_idx=bi, compute_forces=True)
+        _close(be, bref[0], dtype, f"batch energies {dims}")
+        _close(bf, bref[1], dtype, f"batch forces {dims}")
