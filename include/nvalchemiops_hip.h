@@ -310,6 +310,10 @@ int mi_pme_prepare(const void* cell, const void* charges, const int32_t* batch_i
 /* 1 when mi_spline_spread (given its workspace) runs tile-owned for this mesh / order: every mesh point is then written, so the
  * caller may skip the zero-fill of `mesh`.                                                                                          */
 int mi_spline_spread_is_tiled(int n_systems, int nx, int ny, int nz, int order);
+/* 1 when the tile-owned run is also the FASTER one for this atom count (host policy: >= 12 000 atoms and >= 128 mesh tiles over all systems;
+ * below that the zero-fill + atomic kernel + per-atom gather cost fewer launches).  A caller that follows it passes workspace = NULL (and a
+ * zeroed mesh, and spread_workspace = NULL to mi_pme_gather_finish) when this returns 0.                                                   */
+int mi_spline_spread_prefers_tiles(int n_atoms, int n_systems, int nx, int ny, int nz, int order);
 int mi_spline_spread(const void* positions, const void* values, const int32_t* batch_idx,
                      const void* cell_inv_t /*[n_systems,3,3]*/, int n_atoms, int n_systems, int nx, int ny,
                      int nz, int order, int batched, int dtype, void* mesh /* zeroed by caller unless mi_spline_spread_is_tiled */,

@@ -174,6 +174,8 @@ __global__ __launch_bounds__(256) void spline_spread_kernel(const T* __restrict_
 }
 
 // ---- tiled spread ----------------------------------------------------------------------------------------------------------
+#define MI_SPREAD_TILE_MIN_ATOMS 12000
+#define MI_SPREAD_TILE_MIN_TILES 128
 #define SP_T 8  // largest mesh tile edge (points).  Per axis the edge is the largest divisor of the mesh dimension that is <= SP_T; a
                 // stencil of `order` points starting in tile t reaches at most t and t+1 when order <= edge + 1
 struct SpTile { int ex, ey, ez; };
@@ -1066,6 +1068,15 @@ int mi_spline_spread_is_tiled(int n_systems, int nx, int ny, int nz, int order) 
   if (decode_order(order).ref_zero) return 0;  // reference-mode orders 5 / 6: the mesh is just zero-filled, no tile list
   order &= 0xff;
   return (nx > 0 && ny > 0 && nz > 0 && n_systems >= 1 && order >= 1 && order <= MI_MAX_ORDER && sp_tiled_ok(nx, ny, nz, n_systems, order)) ? 1 : 0;
+}
+
+/* Host policy, measured on MI355X (profiles/r04_ab_spread_path.log): the tile pipeline (5 launches, every mesh point written once) beats the
+ * atomic kernel + per-atom gather (zero-fill + 1 launch) from about 12k atoms on, provided the mesh has enough tiles to occupy the CUs. */
+int mi_spline_spread_prefers_tiles(int n_atoms, int n_systems, int nx, int ny, int nz, int order) {
+  if (!mi_spline_spread_is_tiled(n_systems, nx, ny, nz, order)) return 0;
+  const SpTile e = sp_tile(nx, ny, nz);
+  const long long tiles = (long long)n_systems * (nx / e.ex) * (ny / e.ey) * (nz / e.ez);
+  return (n_atoms >= MI_SPREAD_TILE_MIN_ATOMS && tiles >= MI_SPREAD_TILE_MIN_TILES) ? 1 : 0;
 }
 
 long long mi_spline_spread_order_offset(int n_atoms, int n_systems, int nx, int ny, int nz, int order) {

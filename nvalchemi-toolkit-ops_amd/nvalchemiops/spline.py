@@ -59,7 +59,9 @@ def _prep(positions: torch.Tensor, cell: torch.Tensor, batch_idx, cell_inv_t):
 
 
 # ---- raw launchers (detached, contiguous tensors) ------------------------------------------------------------------
-_TILE_MIN_ATOMS = max(1, int(os.environ.get("NVALCHEMIOPS_SPREAD_TILE_MIN_ATOMS", "1")))
+# "auto": the library's measured policy (mi_spline_spread_prefers_tiles); "tile": the tile pipeline wherever the mesh allows it; "atomic":
+# never.  The override exists for A/B runs and for the parity tests, which drive the tile kernels with small inputs.
+_SPREAD_PATH = os.environ.get("NVALCHEMIOPS_SPREAD_PATH", "auto")
 
 
 def _launch_spread(pos, vals, cit, bi, nsys, dims, order, batched, want_order=False):
@@ -72,8 +74,11 @@ def _launch_spread(pos, vals, cit, bi, nsys, dims, order, batched, want_order=Fa
     nx, ny, nz = (int(v) for v in dims)
     n = pos.shape[0]
     # the tile-owned kernel writes every mesh point exactly once: no zero-fill pass then.  Small systems take the atomic kernel: one
-    # zero-fill + one launch instead of the six launches of the tile pipeline (launch latency is all there is to pay below a few thousand atoms)
-    tiled = n >= _TILE_MIN_ATOMS and bool(C.lib().mi_spline_spread_is_tiled(nsys, nx, ny, nz, C.spline_order_arg(order)))
+    # zero-fill + one launch instead of the five launches of the tile pipeline (launch latency is all there is to pay below ~12k atoms)
+    if _SPREAD_PATH == "auto":
+        tiled = n > 0 and bool(C.lib().mi_spline_spread_prefers_tiles(n, nsys, nx, ny, nz, C.spline_order_arg(order)))
+    else:
+        tiled = _SPREAD_PATH == "tile" and n > 0 and bool(C.lib().mi_spline_spread_is_tiled(nsys, nx, ny, nz, C.spline_order_arg(order)))
     mesh = (torch.empty if tiled else torch.zeros)((nsys, nx, ny, nz), dtype=pos.dtype, device=pos.device)
     ws_bytes = int(C.lib().mi_spline_spread_workspace_bytes(n, nsys, nx, ny, nz)) if tiled else 0
     ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=pos.device)

@@ -333,3 +333,18 @@ def test_every_reference_custom_op_name_is_registered():
     s = torch.ops.nvalchemiops._batch_coulomb_energy_matrix.default._schema
     assert [a.name for a in s.arguments] == ["positions", "charges", "cell", "neighbor_matrix", "neighbor_matrix_shifts", "batch_idx", "cutoff",
                                              "alpha", "fill_value"]
+
+
+def test_spread_path_policy():
+    """Host policy of the PME mesh path (no compute): the tile pipeline only where it is possible (`mi_spline_spread_is_tiled`) AND measured faster
+    (>= 12 000 atoms, >= 128 mesh tiles over all systems: profiles/r04_ab_spread_path.log); reference-mode orders 5 / 6 never build a tile list."""
+    from nvalchemiops import _capi as C
+
+    L = C.lib()
+    prefers, possible = L.mi_spline_spread_prefers_tiles, L.mi_spline_spread_is_tiled
+    assert possible(1, 128, 128, 128, 5) == 1 and prefers(100_000, 1, 128, 128, 128, 5) == 1
+    assert prefers(11_999, 1, 128, 128, 128, 5) == 0 and prefers(12_000, 1, 128, 128, 128, 5) == 1
+    assert possible(1, 32, 32, 32, 4) == 1 and prefers(100_000, 1, 32, 32, 32, 4) == 0      # 64 tiles: too few blocks for 256 CUs
+    assert prefers(256_000, 128, 32, 32, 32, 4) == 1                                         # ... but 128 systems of them are 8192 tiles
+    assert possible(1, 31, 31, 31, 4) == 0 and prefers(100_000, 1, 31, 31, 31, 4) == 0       # prime mesh: atomic kernel
+    assert prefers(100_000, 1, 128, 128, 128, 5 | C.SPLINE_REFERENCE_ORDERS) == 0

@@ -12,6 +12,16 @@ from oracle import oracle as O
 from tests import systems as S
 
 pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True, params=["tile", "auto"])
+def spread_path(request, monkeypatch):
+    """Every test of this module runs twice: with the tile pipeline forced wherever the mesh allows it (the kernels of the large-system path, driven
+    here by small inputs) and with the library's own policy (small systems: zero-fill + atomic spread + per-atom gather)."""
+    from nvalchemiops import spline
+
+    monkeypatch.setattr(spline, "_SPREAD_PATH", request.param)
+
 DEV = "cuda:0"
 
 

@@ -17,7 +17,7 @@ def wall(f, it=50):
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(it): f()
     torch.cuda.synchronize(); return (time.perf_counter() - t0) / it * 1e3
-for n in (64, 1024, 8192, 16384):
+for n in (64, 1024, 4096, 8192, 16384, 32768):
     pos, cell, q, z = S.fcc_box(n, dtype=np.float32)
     tp, tc = torch.as_tensor(pos, device=dev), torch.as_tensor(cell, device=dev)
     tq, tz = torch.as_tensor(q, device=dev), torch.as_tensor(z, device=dev)
