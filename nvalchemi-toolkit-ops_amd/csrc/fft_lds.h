@@ -1,0 +1,589 @@
+// In-LDS 3-D FFT pieces of the fused PME mesh solve (csrc/pme.hip: pme_solve_*_kernel).
+//
+// The reference runs torch.fft.rfftn -> three elementwise spectrum kernels -> four torch.fft.irfftn (pme.py:1398-1440).  A library 3-D
+// FFT is three passes over HBM per transform; here the whole k-space step of a power-of-two mesh is three kernels:
+//   A  one block per (system, x) plane:   real rows -> R2C along z -> FFT along y, the plane never leaves LDS           (1 read, 1 write)
+//   B  one block per 8 (y,z) columns:     FFT along x -> Green function / B-spline moduli / -i k_d -> inverse FFT along x (1 read, C writes)
+//   C  one block per (system, channel, x) plane:  inverse FFT along y -> C2R along z -> real rows                         (1 read, 1 write)
+// The 1-D transforms are in-place decimation-in-frequency forward (natural order in, digit-reversed "slots" out) and the mirrored
+// decimation-in-time inverse (slots in, natural order out): no reordering pass, every butterfly reads and writes the same R addresses, so
+// a stage needs no second buffer and one barrier.  Between the kernels the spectra stay in slot order along y and z (kernel B looks the
+// frequencies up); x is transformed forth and back inside kernel B.  The first / last stage of a transform that touches HBM reads /
+// writes it directly (no staging copy) wherever consecutive lanes then touch consecutive addresses.
+//
+// Everything in here is written as per-item bodies over (tid, nthreads) with MI_FFT_SYNC() between phases, so that the same code runs as
+// one "thread" on the host (tests/native/fft_host_harness.cpp: index arithmetic checked against numpy without a GPU).  TEST-ONLY host
+// use: the product never runs these bodies on the CPU.
+#pragma once
+#include <math.h>
+#include <stddef.h>
+
+#ifdef __HIPCC__
+#define MI_HD __host__ __device__ __forceinline__
+#else
+#define MI_HD inline
+#endif
+
+namespace mifft {
+
+template <class T> struct alignas(2 * sizeof(T)) Cx { T re, im; };
+
+template <class T> MI_HD Cx<T> cadd(Cx<T> a, Cx<T> b) { return Cx<T>{a.re + b.re, a.im + b.im}; }
+template <class T> MI_HD Cx<T> csub(Cx<T> a, Cx<T> b) { return Cx<T>{a.re - b.re, a.im - b.im}; }
+template <class T> MI_HD Cx<T> cmul(Cx<T> a, Cx<T> b) { return Cx<T>{a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re}; }
+template <class T> MI_HD Cx<T> cconj(Cx<T> a) { return Cx<T>{a.re, -a.im}; }
+// a * (-i) for SIGN = -1 (forward), a * (+i) for SIGN = +1
+template <int SIGN, class T> MI_HD Cx<T> crot(Cx<T> a) { return SIGN < 0 ? Cx<T>{a.im, -a.re} : Cx<T>{-a.im, a.re}; }
+
+// ---- 1-D plan: n = product of radices out of {16, 8, 4, 2}, at most three stages (n <= 512) -----------------------------------------------
+struct Plan {
+  int n, lg, nst, radix[4], lr[4];  // lr = log2(radix)
+};
+MI_HD bool plan_ok(int n) { return n >= 2 && n <= 512 && (n & (n - 1)) == 0; }
+// max_lr: log2 of the largest radix (4: radix 16 -- 64 VGPRs of fp64 points per butterfly, for kernels that can afford them; 3: radix 8)
+MI_HD Plan make_plan(int n, int max_lr = 3) {
+  Plan p;
+  p.n = n;
+  p.nst = 0;
+  for (int s = 0; s < 4; ++s) { p.radix[s] = 1; p.lr[s] = 0; }
+  int lg = 0;
+  while ((1 << lg) < n) ++lg;
+  p.lg = lg;
+  // as few stages as the radix allows, the large radices first (the last stage walks adjacent elements: keep it the small one)
+  const int nst = (lg + max_lr - 1) / max_lr;
+  int rem = lg;
+  for (int s = 0; s < nst; ++s) {
+    const int left = nst - s;
+    const int l = (rem + left - 1) / left;  // ceil: 7 -> 4 + 3, 9 -> 3 + 3 + 3, 5 -> 3 + 2
+    p.radix[p.nst] = 1 << l;
+    p.lr[p.nst++] = l;
+    rem -= l;
+  }
+  return p;
+}
+// log2 of the sub-transform length of stage s
+MI_HD int stage_lgL(const Plan& p, int s) {
+  int l = p.lg;
+  for (int t = 0; t < s; ++t) l -= p.lr[t];
+  return l;
+}
+// slot p of the forward output holds frequency k:  p = q0 n/R0 + q1 n/(R0 R1) + ...,  k = q0 + R0 q1 + R0 R1 q2 + ...
+MI_HD int slot_freq(const Plan& p, int slot) {
+  int k = 0, sh = 0, rem = p.lg;
+  for (int s = 0; s < p.nst; ++s) {
+    rem -= p.lr[s];
+    const int q = slot >> rem;
+    slot -= q << rem;
+    k += q << sh;
+    sh += p.lr[s];
+  }
+  return k;
+}
+MI_HD int freq_slot(const Plan& p, int k) {
+  int slot = 0, rem = p.lg;
+  for (int s = 0; s < p.nst; ++s) {
+    rem -= p.lr[s];
+    slot += (k & (p.radix[s] - 1)) << rem;
+    k >>= p.lr[s];
+  }
+  return slot;
+}
+
+// division of an item index by a line count that need not be a power of two (the row pitch nz/2 + 1): multiply-high by a magic number,
+// exact for x * d < 2^32 (items stay below 2^21, d below 2^9)
+struct FastDiv {
+  unsigned d, magic;
+  int shift;  // >= 0: d is 2^shift
+};
+MI_HD FastDiv make_div(unsigned d) {
+  FastDiv f;
+  f.d = d;
+  f.shift = -1;
+  for (int s = 0; s < 31; ++s)
+    if (d == (1u << s)) f.shift = s;
+  f.magic = (unsigned)(0x100000000ull / d) + 1u;
+  return f;
+}
+MI_HD unsigned fdiv(const FastDiv& f, unsigned x) { return f.shift >= 0 ? x >> f.shift : (unsigned)(((unsigned long long)x * f.magic) >> 32); }
+
+// ---- register butterflies: y_q = sum_r x_r exp(SIGN 2 pi i r q / R) --------------------------------------------------------------------
+template <int SIGN, class T> MI_HD void dft2(Cx<T>* v) {
+  const Cx<T> a = v[0], b = v[1];
+  v[0] = cadd(a, b);
+  v[1] = csub(a, b);
+}
+template <int SIGN, class T> MI_HD void dft4(Cx<T>* v) {
+  const Cx<T> a0 = cadd(v[0], v[2]), a1 = csub(v[0], v[2]), a2 = cadd(v[1], v[3]), a3 = crot<SIGN>(csub(v[1], v[3]));
+  v[0] = cadd(a0, a2);
+  v[2] = csub(a0, a2);
+  v[1] = cadd(a1, a3);
+  v[3] = csub(a1, a3);
+}
+template <int SIGN, class T> MI_HD void dft8(Cx<T>* v) {
+  const T h = T(0.70710678118654752440);
+  Cx<T> u[4], w[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    u[r] = cadd(v[r], v[r + 4]);
+    w[r] = csub(v[r], v[r + 4]);
+  }
+  // w_r *= exp(SIGN i pi r / 4)
+  w[1] = SIGN < 0 ? Cx<T>{h * (w[1].re + w[1].im), h * (w[1].im - w[1].re)} : Cx<T>{h * (w[1].re - w[1].im), h * (w[1].im + w[1].re)};
+  w[2] = crot<SIGN>(w[2]);
+  w[3] = SIGN < 0 ? Cx<T>{h * (w[3].im - w[3].re), -h * (w[3].re + w[3].im)} : Cx<T>{-h * (w[3].re + w[3].im), h * (w[3].re - w[3].im)};
+  dft4<SIGN>(u);
+  dft4<SIGN>(w);
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    v[2 * m] = u[m];
+    v[2 * m + 1] = w[m];
+  }
+}
+template <int SIGN, class T> MI_HD void dft16(Cx<T>* v) {
+  const T c1 = T(0.92387953251128675613), s1 = T(0.38268343236508977173), h = T(0.70710678118654752440);
+  Cx<T> u[8], w[8];
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+    u[r] = cadd(v[r], v[r + 8]);
+    w[r] = csub(v[r], v[r + 8]);
+  }
+  // w_r *= exp(SIGN i pi r / 8)
+  const T sg = SIGN < 0 ? T(-1) : T(1);
+  w[1] = cmul(w[1], Cx<T>{c1, sg * s1});
+  w[2] = cmul(w[2], Cx<T>{h, sg * h});
+  w[3] = cmul(w[3], Cx<T>{s1, sg * c1});
+  w[4] = crot<SIGN>(w[4]);
+  w[5] = cmul(w[5], Cx<T>{-s1, sg * c1});
+  w[6] = cmul(w[6], Cx<T>{-h, sg * h});
+  w[7] = cmul(w[7], Cx<T>{-c1, sg * s1});
+  dft8<SIGN>(u);
+  dft8<SIGN>(w);
+#pragma unroll
+  for (int m = 0; m < 8; ++m) {
+    v[2 * m] = u[m];
+    v[2 * m + 1] = w[m];
+  }
+}
+template <int SIGN, int R, class T> MI_HD void dftR(Cx<T>* v) {
+  if (R == 2) dft2<SIGN>(v);
+  if (R == 4) dft4<SIGN>(v);
+  if (R == 8) dft8<SIGN>(v);
+  if (R == 16) dft16<SIGN>(v);
+}
+
+// One butterfly of one stage.  Stage with sub-transform length L = 2^lgL, radix R: butterfly j in [0, n / R) works on the points
+// blk * L + o + r * sub (r < R; sub = L / R, blk = j / sub, o = j % sub) -- `ld(point)` fetches them, `st(point, value)` stores the results
+// to the same point numbers.  W: table of exp(-2 pi i t / NW) with NW = 2^lgNW >= L.
+// Forward (decimation in frequency): butterfly, then twiddle exp(-2 pi i o q / L).  Inverse (decimation in time): conjugate twiddle, then
+// butterfly -- R times the exact inverse of the forward stage, so forward stages 0..S-1 followed by inverse stages S-1..0 give n * identity.
+template <int SIGN, int R, class T, class Ld, class St>
+MI_HD void butterfly(const Cx<T>* W, int lgNW, int lgL, int lgR, int j, Ld ld, St st) {
+  const int lsub = lgL - lgR;
+  const int blk = j >> lsub, o = j & ((1 << lsub) - 1);
+  const int base = (blk << lgL) + o;
+  const int wl = o << (lgNW - lgL);  // o * (NW / L)
+  Cx<T> v[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) v[r] = ld(base + (r << lsub));
+  if (SIGN > 0) {
+#pragma unroll
+    for (int q = 1; q < R; ++q) v[q] = cmul(v[q], cconj(W[q * wl]));
+  }
+  dftR<SIGN, R>(v);
+  if (SIGN < 0) {
+#pragma unroll
+    for (int q = 1; q < R; ++q) v[q] = cmul(v[q], W[q * wl]);
+  }
+#pragma unroll
+  for (int r = 0; r < R; ++r) st(base + (r << lsub), v[r]);
+}
+// MAXLR: the largest radix the caller's plans contain (make_plan's max_lr) -- radix 16 is only instantiated where it can occur
+template <int SIGN, int MAXLR = 3, class T, class Ld, class St>
+MI_HD void butterfly_r(int lgR, const Cx<T>* W, int lgNW, int lgL, int j, Ld ld, St st) {
+  if (MAXLR >= 4 && lgR == 4) butterfly<SIGN, MAXLR >= 4 ? 16 : 8>(W, lgNW, lgL, MAXLR >= 4 ? 4 : 3, j, ld, st);
+  else if (lgR == 3) butterfly<SIGN, 8>(W, lgNW, lgL, 3, j, ld, st);
+  else if (lgR == 2) butterfly<SIGN, 4>(W, lgNW, lgL, 2, j, ld, st);
+  else butterfly<SIGN, 2>(W, lgNW, lgL, 1, j, ld, st);
+}
+
+// exp(-2 pi i t / n), evaluated in double whatever T is
+template <class T> MI_HD Cx<T> unit_root(int t, int n) {
+  double s, c;
+#ifdef __HIP_DEVICE_COMPILE__
+  sincospi(-2.0 * (double)t / (double)n, &s, &c);
+#else
+  const double a = -2.0 * 3.14159265358979323846 * (double)t / (double)n;
+  s = sin(a);
+  c = cos(a);
+#endif
+  return Cx<T>{(T)c, (T)s};
+}
+
+#ifdef __HIP_DEVICE_COMPILE__
+#define MI_FFT_SYNC() __syncthreads()
+#else
+#define MI_FFT_SYNC() ((void)0)
+#endif
+
+// item -> (line, butterfly) of a stage over n_lines lines of per = n / R butterflies.  Consecutive items (lanes) take consecutive addresses
+// wherever that is conflict-free: along the line while the butterfly's own points are far apart (rows, sub >= 16), across the lines
+// otherwise (rows: the pitch is odd in 16-byte units, conflict-free for b128; columns: the lines are adjacent elements).
+struct ItemMap {
+  bool along;
+  int lper;
+  FastDiv lines;
+};
+MI_HD void item_of(const ItemMap& m, int it, int& line, int& j) {
+  if (m.along) { line = it >> m.lper; j = it & ((1 << m.lper) - 1); }
+  else { j = (int)fdiv(m.lines, (unsigned)it); line = it - j * (int)m.lines.d; }
+}
+
+// one stage, in place, over lines of an LDS array: element (line, point) at a[line * line_stride + point * point_stride]
+template <int SIGN, class T>
+MI_HD void lds_stage(Cx<T>* a, const Plan& pl, int s, int n_lines, const FastDiv& lines_div, int line_stride, int point_stride, const Cx<T>* W,
+                     int lgNW, int tid, int nth) {
+  const int lgL = stage_lgL(pl, s), lgR = pl.lr[s];
+  ItemMap m;
+  m.lper = pl.lg - lgR;
+  m.along = point_stride == 1 && (lgL - lgR) >= 4;
+  m.lines = lines_div;
+  const int items = n_lines << m.lper;
+  for (int it = tid; it < items; it += nth) {
+    int line, j;
+    item_of(m, it, line, j);
+    Cx<T>* d = a + line * line_stride;
+    butterfly_r<SIGN>(lgR, W, lgNW, lgL, j, [=](int p) { return d[p * point_stride]; }, [=](int p, Cx<T> v) { d[p * point_stride] = v; });
+  }
+}
+// all stages of a batch of 1-D transforms held in LDS, forward or inverse, a barrier after each
+template <int SIGN, class T>
+MI_HD void lines_fft(Cx<T>* a, const Plan& pl, int n_lines, const FastDiv& lines_div, int line_stride, int point_stride, const Cx<T>* W, int lgNW,
+                     int tid, int nth) {
+  for (int si = 0; si < pl.nst; ++si) {
+    lds_stage<SIGN>(a, pl, SIGN < 0 ? si : pl.nst - 1 - si, n_lines, lines_div, line_stride, point_stride, W, lgNW, tid, nth);
+    MI_FFT_SYNC();
+  }
+}
+
+// ---- R2C / C2R of a row held as M = n/2 complex points z_j = (x_2j, x_2j+1) ---------------------------------------------------------------
+// forward: after the M-point forward FFT (slots), X_k = 1/2 [(Z_k + conj Z_{M-k}) - i w_k (Z_k - conj Z_{M-k})], w_k = exp(-2 pi i k / n);
+// X_k lands in the slot Z_k had, X_M (the Nyquist bin) in element M.  item k in [0, M/2].
+template <class T> MI_HD void r2c_post_item(Cx<T>* row, const Plan& pz, const Cx<T>* Wn /*exp(-2 pi i t / n)*/, int M, int k) {
+  if (k == 0) {
+    const Cx<T> z = row[0];
+    row[0] = Cx<T>{z.re + z.im, T(0)};
+    row[M] = Cx<T>{z.re - z.im, T(0)};
+    return;
+  }
+  const int sa = freq_slot(pz, k), sb = freq_slot(pz, M - k);
+  const Cx<T> a = row[sa], b = row[sb];
+  const T h = T(0.5);
+  {
+    const Cx<T> e = cadd(a, cconj(b)), o = cmul(Wn[k], csub(a, cconj(b)));  // -i * o: (o.im, -o.re)
+    row[sa] = Cx<T>{h * (e.re + o.im), h * (e.im - o.re)};
+  }
+  if (sa != sb) {
+    const Cx<T> e = cadd(b, cconj(a)), o = cmul(Wn[M - k], csub(b, cconj(a)));
+    row[sb] = Cx<T>{h * (e.re + o.im), h * (e.im - o.re)};
+  }
+}
+// inverse (unnormalised, numpy.fft.irfft convention: the imaginary parts of the DC and Nyquist bins are not read):
+// Z_k = (X_k + conj X_{M-k}) + i conj(w_k) (X_k - conj X_{M-k}), then the M-point inverse FFT gives z_j = (x_2j, x_2j+1) (sum over all n bins)
+template <class T> MI_HD void c2r_pre_item(Cx<T>* row, const Plan& pz, const Cx<T>* Wn, int M, int k) {
+  if (k == 0) {
+    const T a = row[0].re, c = row[M].re;
+    row[0] = Cx<T>{a + c, a - c};
+    return;
+  }
+  const int sa = freq_slot(pz, k), sb = freq_slot(pz, M - k);
+  const Cx<T> a = row[sa], b = row[sb];
+  {
+    const Cx<T> e = cadd(a, cconj(b)), o = cmul(cconj(Wn[k]), csub(a, cconj(b)));  // +i * o: (-o.im, o.re)
+    row[sa] = Cx<T>{e.re - o.im, e.im + o.re};
+  }
+  if (sa != sb) {
+    const Cx<T> e = cadd(b, cconj(a)), o = cmul(cconj(Wn[M - k]), csub(b, cconj(a)));
+    row[sb] = Cx<T>{e.re - o.im, e.im + o.re};
+  }
+}
+
+// ---- geometry shared by the kernels ---------------------------------------------------------------------------------------------------
+struct Geom {
+  int B, nx, ny, nz, M, P;  // M = nz / 2 complex points per packed real row, P = M + 1 bins per row (and the LDS row pitch)
+  Plan px, py, pz;          // pz: the M-point transform of the packed rows
+  FastDiv divP, divNy;
+};
+MI_HD bool geom_ok(int nx, int ny, int nz) { return plan_ok(nx) && plan_ok(ny) && plan_ok(nz) && nx >= 8 && ny >= 8 && nz >= 8 && nx <= 256 && ny <= 256 && nz <= 512; }
+MI_HD Geom make_geom(int B, int nx, int ny, int nz) {
+  Geom g;
+  g.B = B; g.nx = nx; g.ny = ny; g.nz = nz; g.M = nz / 2; g.P = nz / 2 + 1;
+  g.px = make_plan(nx, 4); g.py = make_plan(ny); g.pz = make_plan(nz / 2);  // x columns: one wave per block, radix 16 affordable
+  g.divP = make_div((unsigned)g.P);
+  g.divNy = make_div((unsigned)ny);
+  return g;
+}
+
+// ---- tables of one mesh shape (computed once per shape by the library, kept on the device) ---------------------------------------------
+// unit roots exp(-2 pi i t / n) of the three axes; sinc(m / n) and the Miller index m of every SLOT of the three axes (z: P bins)
+MI_HD int miller_index(int i, int n) { return i < (n + 1) / 2 ? i : i - n; }  // fftfreq(n, 1/n), as the k-grid of the reference (k_vectors.py:270-282)
+template <class T> MI_HD T sinc_of(T x) {  // sin(pi x) / (pi x), pme_kernels.py:208-225
+  if (fabs(x) < T(1e-6)) return T(1);
+  const T px = T(3.14159265358979323846) * x;
+  return sin(px) / px;
+}
+template <class T> struct Tables {
+  const Cx<T>*Wx, *Wy, *Wz;
+  const T *sx, *sy, *sz, *mx, *my, *mz;
+};
+template <class T> MI_HD size_t tables_bytes(const Geom& g) {
+  return (size_t)(g.nx + g.ny + g.nz) * sizeof(Cx<T>) + (size_t)2 * (g.nx + g.ny + g.P) * sizeof(T);
+}
+template <class T> MI_HD Tables<T> tables_at(void* base, const Geom& g) {
+  Tables<T> t;
+  Cx<T>* w = (Cx<T>*)base;
+  t.Wx = w; t.Wy = w + g.nx; t.Wz = w + g.nx + g.ny;
+  T* r = (T*)(w + g.nx + g.ny + g.nz);
+  t.sx = r; t.sy = r + g.nx; t.sz = r + g.nx + g.ny;
+  r += g.nx + g.ny + g.P;
+  t.mx = r; t.my = r + g.nx; t.mz = r + g.nx + g.ny;
+  return t;
+}
+template <class T> MI_HD void tables_body(void* base, const Geom& g, int tid, int nth) {
+  const Tables<T> t = tables_at<T>(base, g);
+  for (int i = tid; i < g.nx; i += nth) {
+    const int m = miller_index(slot_freq(g.px, i), g.nx);
+    ((Cx<T>*)t.Wx)[i] = unit_root<T>(i, g.nx);
+    ((T*)t.mx)[i] = (T)m;
+    ((T*)t.sx)[i] = sinc_of((T)m / (T)g.nx);
+  }
+  for (int i = tid; i < g.ny; i += nth) {
+    const int m = miller_index(slot_freq(g.py, i), g.ny);
+    ((Cx<T>*)t.Wy)[i] = unit_root<T>(i, g.ny);
+    ((T*)t.my)[i] = (T)m;
+    ((T*)t.sy)[i] = sinc_of((T)m / (T)g.ny);
+  }
+  for (int i = tid; i < g.nz; i += nth) ((Cx<T>*)t.Wz)[i] = unit_root<T>(i, g.nz);
+  for (int i = tid; i < g.P; i += nth) {
+    const int m = i < g.M ? slot_freq(g.pz, i) : g.M;
+    ((T*)t.mz)[i] = (T)m;
+    ((T*)t.sz)[i] = sinc_of((T)m / (T)g.nz);
+  }
+}
+
+// LDS bytes of the plane kernels: the plane + exp(-2 pi i t / nz) + exp(-2 pi i t / ny)
+template <class T> MI_HD size_t plane_lds_bytes(const Geom& g) { return ((size_t)g.ny * g.P + g.nz + g.ny) * sizeof(Cx<T>); }
+
+template <class T> MI_HD void plane_tables(Cx<T>* Wz, Cx<T>* Wy, const Tables<T>& tb, const Geom& g, int tid, int nth) {
+  for (int t = tid; t < g.nz; t += nth) Wz[t] = tb.Wz[t];
+  for (int t = tid; t < g.ny; t += nth) Wy[t] = tb.Wy[t];
+}
+
+// ---- kernel A body: one (system, x) plane -------------------------------------------------------------------------------------------
+// in: real plane [ny][nz]; out: [ny][P] complex in (y slot, z slot) order; lds: plane_lds_bytes
+template <class T> MI_HD void fwd_plane_body(const T* in, Cx<T>* out, Cx<T>* lds, const Geom& g, const Tables<T>& tb, int tid, int nth) {
+  Cx<T>* plane = lds;
+  Cx<T>* Wz = lds + g.ny * g.P;
+  Cx<T>* Wy = Wz + g.nz;
+  plane_tables(Wz, Wy, tb, g, tid, nth);
+  const Cx<T>* src = (const Cx<T>*)in;
+  const int lgM = g.pz.lg;
+  for (int e = tid; e < g.ny * g.M; e += nth) {
+    const int y = e >> lgM, j = e & (g.M - 1);
+    plane[y * g.P + j] = src[e];
+  }
+  MI_FFT_SYNC();
+  // rows: M-point forward FFT; exp(-2 pi i t / M) = Wz[2 t]: the table of nz entries serves both (lgNW = lg nz)
+  lines_fft<-1>(plane, g.pz, g.ny, g.divNy, g.P, 1, Wz, lgM + 1, tid, nth);
+  const int half = g.M / 2 + 1;
+  for (int it = tid; it < g.ny * half; it += nth) {
+    const int k = (int)fdiv(g.divNy, (unsigned)it), y = it - k * g.ny;
+    r2c_post_item(plane + y * g.P, g.pz, Wz, g.M, k);
+  }
+  MI_FFT_SYNC();
+  // columns: ny-point forward FFT for each of the P bins; the last stage stores straight to HBM (lanes along the row: coalesced)
+  for (int s = 0; s + 1 < g.py.nst; ++s) {
+    lds_stage<-1>(plane, g.py, s, g.P, g.divP, 1, g.P, Wy, g.py.lg, tid, nth);
+    MI_FFT_SYNC();
+  }
+  {
+    const int s = g.py.nst - 1, lgL = stage_lgL(g.py, s), lgR = g.py.lr[s];
+    const int items = g.P << (g.py.lg - lgR);
+    const int P = g.P;
+    for (int it = tid; it < items; it += nth) {
+      const int j = (int)fdiv(g.divP, (unsigned)it), c = it - j * P;
+      butterfly_r<-1>(lgR, Wy, g.py.lg, lgL, j, [=](int p) { return plane[p * P + c]; }, [=](int p, Cx<T> v) { out[p * P + c] = v; });
+    }
+  }
+}
+
+// ---- kernel C body: one (system, channel, x) plane ----------------------------------------------------------------------------------
+// in: [ny][P] complex in (y slot, z slot) order; out: real plane [ny][nz]
+template <class T> MI_HD void inv_plane_body(const Cx<T>* in, T* out, Cx<T>* lds, const Geom& g, const Tables<T>& tb, int tid, int nth) {
+  Cx<T>* plane = lds;
+  Cx<T>* Wz = lds + g.ny * g.P;
+  Cx<T>* Wy = Wz + g.nz;
+  plane_tables(Wz, Wy, tb, g, tid, nth);
+  MI_FFT_SYNC();
+  const int P = g.P;
+  {  // first inverse stage of the columns reads HBM directly
+    const int s = g.py.nst - 1, lgL = stage_lgL(g.py, s), lgR = g.py.lr[s];
+    const int items = P << (g.py.lg - lgR);
+    for (int it = tid; it < items; it += nth) {
+      const int j = (int)fdiv(g.divP, (unsigned)it), c = it - j * P;
+      butterfly_r<+1>(lgR, Wy, g.py.lg, lgL, j, [=](int p) { return in[p * P + c]; }, [=](int p, Cx<T> v) { plane[p * P + c] = v; });
+    }
+    MI_FFT_SYNC();
+  }
+  for (int s = g.py.nst - 2; s >= 0; --s) {
+    lds_stage<+1>(plane, g.py, s, P, g.divP, 1, P, Wy, g.py.lg, tid, nth);
+    MI_FFT_SYNC();
+  }
+  const int half = g.M / 2 + 1;
+  for (int it = tid; it < g.ny * half; it += nth) {
+    const int k = (int)fdiv(g.divNy, (unsigned)it), y = it - k * g.ny;
+    c2r_pre_item(plane + y * P, g.pz, Wz, g.M, k);
+  }
+  MI_FFT_SYNC();
+  const int lgM = g.pz.lg;
+  lines_fft<+1>(plane, g.pz, g.ny, g.divNy, P, 1, Wz, lgM + 1, tid, nth);
+  Cx<T>* dst = (Cx<T>*)out;
+  for (int e = tid; e < g.ny * g.M; e += nth) {
+    const int y = e >> lgM, j = e & (g.M - 1);
+    dst[e] = plane[y * P + j];
+  }
+}
+
+// ---- kernels B1 / B2: MI_SOLVE_COLS columns (y slot, z slot) of one system, all x ---------------------------------------------------
+// Sixteen 16-byte columns = 256 contiguous bytes per x; two waves per block (radix 16 x 8 for 128 points: 16 points per lane, one exchange
+// through LDS), several blocks per CU for the loads in flight.  B1 transforms the columns forward along x
+// and multiplies by the k-space factor G / sf^2 on its way out, in place (the spectrum is then in slot order along all three axes);
+// B2 -- one block per (columns, channel) -- reads them back with the channel factor (1 | -i k_d) and transforms back.
+#define MI_SOLVE_COLS 16
+#define MI_SOLVE_LGCOLS 4
+// LDS of B1: tile + unit roots + KX[3][nx] + sinc_x[nx] + per column KC[3][8], sinc_y sinc_z [8], origin flag [8]
+template <class T> MI_HD size_t fwd_cols_lds_bytes(const Geom& g) {
+  return ((size_t)g.nx * MI_SOLVE_COLS + g.nx) * sizeof(Cx<T>) + ((size_t)4 * g.nx + 5 * MI_SOLVE_COLS) * sizeof(T);
+}
+// LDS of B2: tile + unit roots + KX[nx] + KC[8] of the block's channel
+template <class T> MI_HD size_t inv_cols_lds_bytes(const Geom& g) {
+  return ((size_t)g.nx * MI_SOLVE_COLS + g.nx) * sizeof(Cx<T>) + ((size_t)g.nx + MI_SOLVE_COLS) * sizeof(T);
+}
+// spec: [nx][ny*P] complex of system b (slot order in y, z), transformed in place into conv = (FFT_x spec / sf2) * G in slot order along x
+// (pme.py:1418-1419, pme_kernels.py:194-225); recip: 2 pi cell^-1 of the system (row-major 3x3, k_d = sum_e m_e recip[d][e],
+// k_vectors.py:270-282); sf_expo: exponent of the B-spline modulus (decode_order().sf_exponent)
+template <class T>
+MI_HD void fwd_cols_body(Cx<T>* spec, Cx<T>* lds, const Geom& g, const Tables<T>& tb, const T* recip, T alpha, T volume, int sf_expo, int col0, int tid,
+                         int nth) {
+  const int COLS = MI_SOLVE_COLS, LGC = MI_SOLVE_LGCOLS;
+  const int ncol = g.ny * g.P, nx = g.nx;
+  Cx<T>* S = lds;
+  Cx<T>* Wx = S + nx * COLS;
+  T* KX = (T*)(Wx + nx);  // [3][nx]
+  T* SX = KX + 3 * nx;    // [nx]
+  T* KC = SX + nx;        // [3][COLS]
+  T* SC = KC + 3 * COLS;  // [COLS] sinc_y * sinc_z
+  T* OC = SC + COLS;      // [COLS] 1 where m_y = m_z = 0
+  for (int t = tid; t < nx; t += nth) {
+    Wx[t] = tb.Wx[t];
+    SX[t] = tb.sx[t];
+    const T m = tb.mx[t];
+    KX[t] = m * recip[0]; KX[nx + t] = m * recip[3]; KX[2 * nx + t] = m * recip[6];
+  }
+  for (int c = tid; c < COLS; c += nth) {
+    const int col = col0 + c < ncol ? col0 + c : ncol - 1;
+    const int ys = (int)fdiv(g.divP, (unsigned)col), zs = col - ys * g.P;
+    const T my = tb.my[ys], mz = tb.mz[zs];
+    for (int d = 0; d < 3; ++d) KC[d * COLS + c] = my * recip[3 * d + 1] + mz * recip[3 * d + 2];
+    SC[c] = tb.sy[ys] * tb.sz[zs];
+    OC[c] = (my == T(0) && mz == T(0)) ? T(1) : T(0);
+  }
+  MI_FFT_SYNC();
+  const T inv4a2 = T(1) / (T(4) * alpha * alpha);
+  auto factor_of = [=](int xs, int c) {
+    const T k0 = KX[xs] + KC[c], k1 = KX[nx + xs] + KC[COLS + c], k2v = KX[2 * nx + xs] + KC[2 * COLS + c];
+    T k2 = k0 * k0 + k1 * k1 + k2v * k2v;
+    if (!(k2 > T(1e-12))) k2 = T(1e-12);
+    const bool origin = OC[c] != T(0) && KX[xs] == T(0) && KX[nx + xs] == T(0) && KX[2 * nx + xs] == T(0) && SX[xs] == T(1);
+    const T sp = SX[xs] * SC[c];
+    T sf = sp;
+    for (int t = 1; t < sf_expo; ++t) sf = sf * sp;
+    if (sf < T(1e-10)) sf = T(1e-10);
+    return (origin || k2 < T(1e-10)) ? T(0) : T(6.283185307179586) * exp(-inv4a2 * k2) / (k2 * volume * (sf * sf));
+  };
+  const Plan& px = g.px;
+  for (int s = 0; s < px.nst; ++s) {
+    const int lgL = stage_lgL(px, s), lgR = px.lr[s];
+    const int items = COLS << (px.lg - lgR);
+    const bool first = s == 0;
+    for (int it = tid; it < items; it += nth) {
+      const int j = it >> LGC, c = it & (COLS - 1);
+      const bool live = col0 + c < ncol;
+      const Cx<T>* col = spec + col0 + c;
+      butterfly_r<-1, 4>(lgR, Wx, px.lg, lgL, j,
+                      [=](int p) { return first ? (live ? col[(size_t)p * ncol] : Cx<T>{T(0), T(0)}) : S[(p << LGC) + c]; },
+                      [=](int p, Cx<T> v) { S[(p << LGC) + c] = v; });
+    }
+    MI_FFT_SYNC();
+  }
+  // k-space factor on the way out (its own pass over the tile: the butterflies above keep their registers to themselves)
+  for (int e = tid; e < nx * COLS; e += nth) {
+    const int xs = e >> LGC, c = e & (COLS - 1);
+    if (col0 + c < ncol) {
+      const T f = factor_of(xs, c);
+      const Cx<T> v = S[e];
+      spec[(size_t)xs * ncol + col0 + c] = Cx<T>{v.re * f, v.im * f};
+    }
+  }
+}
+// conv: [nx][ny*P] complex of system b in slot order along x, y, z; out: [nx][ny*P] of (system b, channel ch), natural order along x again:
+// the inverse x transform of conv (ch = 0, the potential) or of (-i k_d) conv (ch = 1 + d, the field components; pme.py:1455-1457)
+template <class T>
+MI_HD void inv_cols_body(const Cx<T>* conv, Cx<T>* out, Cx<T>* lds, const Geom& g, const Tables<T>& tb, const T* recip, int ch, int col0, int tid, int nth) {
+  const int COLS = MI_SOLVE_COLS, LGC = MI_SOLVE_LGCOLS;
+  const int ncol = g.ny * g.P, nx = g.nx;
+  Cx<T>* S = lds;
+  Cx<T>* Wx = S + nx * COLS;
+  T* KX = (T*)(Wx + nx);  // [nx] of this channel's d
+  T* KC = KX + nx;        // [COLS]
+  const int d = ch > 0 ? ch - 1 : 0;
+  for (int t = tid; t < nx; t += nth) {
+    Wx[t] = tb.Wx[t];
+    KX[t] = tb.mx[t] * recip[3 * d];
+  }
+  for (int c = tid; c < COLS; c += nth) {
+    const int col = col0 + c < ncol ? col0 + c : ncol - 1;
+    const int ys = (int)fdiv(g.divP, (unsigned)col), zs = col - ys * g.P;
+    KC[c] = tb.my[ys] * recip[3 * d + 1] + tb.mz[zs] * recip[3 * d + 2];
+  }
+  MI_FFT_SYNC();
+  const Plan& px = g.px;
+  const bool field = ch > 0;
+  for (int s = px.nst - 1; s >= 0; --s) {
+    const int lgL = stage_lgL(px, s), lgR = px.lr[s];
+    const int items = COLS << (px.lg - lgR);
+    const bool first = s == px.nst - 1, last = s == 0;
+    for (int it = tid; it < items; it += nth) {
+      const int j = it >> LGC, c = it & (COLS - 1);
+      const bool live = col0 + c < ncol;
+      const Cx<T>* src = conv + col0 + c;
+      Cx<T>* dst = out + col0 + c;
+      // (staging the tile through LDS together with the tables, all loads in flight in one phase, measured slower: 33.5 -> 39 us)
+      butterfly_r<+1, 4>(lgR, Wx, px.lg, lgL, j,
+                      [=](int p) {
+                        if (!first) return S[(p << LGC) + c];
+                        if (!live) return Cx<T>{T(0), T(0)};
+                        const Cx<T> v = src[(size_t)p * ncol];
+                        if (!field) return v;
+                        const T kd = KX[p] + KC[c];
+                        return Cx<T>{kd * v.im, -(kd * v.re)};
+                      },
+                      [=](int p, Cx<T> v) {
+                        if (last) { if (live) dst[(size_t)p * ncol] = v; }
+                        else S[(p << LGC) + c] = v;
+                      });
+    }
+    MI_FFT_SYNC();
+  }
+}
+
+}  // namespace mifft

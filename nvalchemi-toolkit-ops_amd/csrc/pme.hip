@@ -22,6 +22,7 @@
 //     SURVEY F2) use the cardinal B-spline recursion.
 #include "binsort.h"
 #include "common.h"
+#include "fft_lds.h"
 
 namespace {
 
@@ -999,6 +1000,103 @@ int spread_tiled(const T* pos, const T* values, const int* batch_idx, const T* c
   return MI_OK;
 }
 
+
+// ---- fused mesh solve: the whole k-space step of a power-of-two mesh in four kernels (bodies: fft_lds.h) ----------------------------------
+#define MI_LDS_MAX 163840
+template <class T> __global__ void pme_solve_tables_kernel(void* base, mifft::Geom g) { mifft::tables_body<T>(base, g, threadIdx.x, blockDim.x); }
+template <class T>
+__global__ __launch_bounds__(1024) void pme_solve_fwd_kernel(const T* __restrict__ mesh, mifft::Cx<T>* __restrict__ spec, mifft::Geom g, mifft::Tables<T> tb) {
+  extern __shared__ __align__(16) unsigned char solve_smem[];
+  const size_t plane = blockIdx.x;  // (system, x)
+  mifft::fwd_plane_body<T>(mesh + plane * g.ny * g.nz, spec + plane * g.ny * g.P, (mifft::Cx<T>*)solve_smem, g, tb, threadIdx.x, blockDim.x);
+}
+template <class T>
+__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2))) void pme_solve_fwd_cols_kernel(mifft::Cx<T>* __restrict__ spec, mifft::Geom g, mifft::Tables<T> tb, const T* __restrict__ recip,
+                                                                const T* __restrict__ alpha, const T* __restrict__ volume, int sf_expo) {
+  extern __shared__ __align__(16) unsigned char solve_smem[];
+  const int b = blockIdx.y;
+  const size_t per = (size_t)g.nx * g.ny * g.P;
+  mifft::fwd_cols_body<T>(spec + b * per, (mifft::Cx<T>*)solve_smem, g, tb, recip + 9 * b, alpha[b], volume[b], sf_expo, blockIdx.x * MI_SOLVE_COLS,
+                          threadIdx.x, blockDim.x);
+}
+// grid.x = 8-padded column tiles x channels.  The channels of one tile read the same conv lines: consecutive block ids go round the 8 XCDs,
+// so the id is unpacked as (xcd, channel, tile group) -- the n_channels blocks of a tile follow each other on ONE XCD and share its L2.
+template <class T>
+__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2))) void pme_solve_inv_cols_kernel(const mifft::Cx<T>* __restrict__ conv_spec, mifft::Cx<T>* __restrict__ conv, mifft::Geom g,
+                                                                mifft::Tables<T> tb, const T* __restrict__ recip, int n_channels, int col_blocks) {
+  extern __shared__ __align__(16) unsigned char solve_smem[];
+  const int b = blockIdx.y;
+  const int xcd = blockIdx.x & 7, i = blockIdx.x >> 3;
+  const int ch = i % n_channels, tile = (i / n_channels) * 8 + xcd;
+  if (tile >= col_blocks) return;
+  const size_t per = (size_t)g.nx * g.ny * g.P;
+  mifft::inv_cols_body<T>(conv_spec + b * per, conv + ((size_t)b * n_channels + ch) * per, (mifft::Cx<T>*)solve_smem, g, tb, recip + 9 * b, ch,
+                          tile * MI_SOLVE_COLS, threadIdx.x, blockDim.x);
+}
+template <class T>
+__global__ __launch_bounds__(1024) void pme_solve_inv_kernel(const mifft::Cx<T>* __restrict__ conv, T* __restrict__ real, mifft::Geom g, mifft::Tables<T> tb) {
+  extern __shared__ __align__(16) unsigned char solve_smem[];
+  const size_t plane = blockIdx.x;  // (system, channel, x)
+  mifft::inv_plane_body<T>(conv + plane * g.ny * g.P, real + plane * g.ny * g.nz, (mifft::Cx<T>*)solve_smem, g, tb, threadIdx.x, blockDim.x);
+}
+template <class T> static bool solve_fits(const mifft::Geom& g) {
+  return mifft::plane_lds_bytes<T>(g) <= MI_LDS_MAX && mifft::fwd_cols_lds_bytes<T>(g) <= MI_LDS_MAX;
+}
+static int solve_plane_threads(const mifft::Geom& g) {
+  const long long items = (long long)g.ny * g.M / 8;  // radix-8 butterflies of one row stage
+  return items >= 1024 ? 1024 : items >= 512 ? 512 : 256;
+}
+// Unit roots / sinc / Miller-index tables of a mesh shape: computed on first use, kept on the device for the life of the process (like the
+// FFT plans of fft.cpp: the first call for a shape must not be inside a HIP-graph capture).
+struct SolveTables { int dev, nx, ny, nz, dtype; void* ptr; };
+static SolveTables g_solve_tables[16];
+static int g_solve_tables_n = 0;
+template <class T> static int solve_tables_get(const mifft::Geom& g, int dtype, hipStream_t st, void** out) {
+  int dev = 0;
+  MI_HIP_CHECK(hipGetDevice(&dev));
+  for (int i = 0; i < g_solve_tables_n; ++i) {
+    const SolveTables& e = g_solve_tables[i];
+    if (e.dev == dev && e.nx == g.nx && e.ny == g.ny && e.nz == g.nz && e.dtype == dtype) { *out = e.ptr; return MI_OK; }
+  }
+  MI_REQUIRE(g_solve_tables_n < 16, "more than 16 distinct mesh shapes in one process for the fused mesh solve");
+  void* p = nullptr;
+  MI_HIP_CHECK(hipMalloc(&p, mifft::tables_bytes<T>(g)));
+  pme_solve_tables_kernel<T><<<1, 256, 0, st>>>(p, g);
+  MI_LAUNCH_CHECK();
+  g_solve_tables[g_solve_tables_n++] = SolveTables{dev, g.nx, g.ny, g.nz, dtype, p};
+  *out = p;
+  return MI_OK;
+}
+template <class T>
+static int solve_launch(const void* mesh, const void* recip_cell, const void* alpha, const void* volume, const mifft::Geom& g, int expo, int nch,
+                        void* spec, void* conv, void* real_out, int pt, int col_blocks, int dtype, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  const size_t pl = mifft::plane_lds_bytes<T>(g), fl = mifft::fwd_cols_lds_bytes<T>(g), il = mifft::inv_cols_lds_bytes<T>(g);
+  static bool raised = false;  // more than 64 KB of dynamic LDS has to be asked for once per kernel
+  if (!raised) {
+    MI_HIP_CHECK(hipFuncSetAttribute((const void*)pme_solve_fwd_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, MI_LDS_MAX));
+    MI_HIP_CHECK(hipFuncSetAttribute((const void*)pme_solve_fwd_cols_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, MI_LDS_MAX));
+    MI_HIP_CHECK(hipFuncSetAttribute((const void*)pme_solve_inv_cols_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, MI_LDS_MAX));
+    MI_HIP_CHECK(hipFuncSetAttribute((const void*)pme_solve_inv_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, MI_LDS_MAX));
+    raised = true;
+  }
+  void* tab = nullptr;
+  const int rc = solve_tables_get<T>(g, dtype, st, &tab);
+  if (rc != MI_OK) return rc;
+  const mifft::Tables<T> tb = mifft::tables_at<T>(tab, g);
+  mi_timing_begin("pme_solve_fwd", stream);
+  pme_solve_fwd_kernel<T><<<g.B * g.nx, pt, pl, st>>>((const T*)mesh, (mifft::Cx<T>*)spec, g, tb);
+  mi_timing_end(stream);
+  mi_timing_begin("pme_solve_cols", stream);
+  pme_solve_fwd_cols_kernel<T><<<dim3(col_blocks, g.B), 128, fl, st>>>((mifft::Cx<T>*)spec, g, tb, (const T*)recip_cell, (const T*)alpha, (const T*)volume, expo);
+  pme_solve_inv_cols_kernel<T><<<dim3((col_blocks + 7) / 8 * 8 * nch, g.B), 128, il, st>>>((const mifft::Cx<T>*)spec, (mifft::Cx<T>*)conv, g, tb,
+                                                                                          (const T*)recip_cell, nch, col_blocks);
+  mi_timing_end(stream);
+  mi_timing_begin("pme_solve_inv", stream);
+  pme_solve_inv_kernel<T><<<g.B * nch * g.nx, pt, pl, st>>>((const mifft::Cx<T>*)conv, (T*)real_out, g, tb);
+  mi_timing_end(stream);
+  return MI_OK;
+}
 }  // namespace
 
 #define MI_DISPATCH_T(dtype, CALL)                     \
@@ -1272,6 +1370,38 @@ int mi_pme_convolve_bwd(const void* spec, const void* weight_spec, int n_channel
   return MI_OK;
 }
 int mi_pme_convolve_bwd_blocks(void) { return PME_BWD_BLOCKS; }
+
+/* ---- fused mesh solve ------------------------------------------------------------------------------------------------------------------ */
+int mi_pme_solve_supported(int n_systems, int nx, int ny, int nz, int dtype) {
+  if (n_systems < 1 || !(dtype == MI_F32 || dtype == MI_F64) || !mifft::geom_ok(nx, ny, nz)) return 0;
+  const mifft::Geom g = mifft::make_geom(n_systems, nx, ny, nz);
+  if ((long long)n_systems * 4 * nx > 0x7fffffffll || n_systems > 65535) return 0;
+  return (dtype == MI_F32 ? solve_fits<float>(g) : solve_fits<double>(g)) ? 1 : 0;
+}
+size_t mi_pme_solve_scratch_bytes(int n_systems, int nx, int ny, int nz, int n_channels, int dtype) {
+  const size_t per = (size_t)n_systems * nx * ny * (nz / 2 + 1) * (dtype == MI_F32 ? 8 : 16);
+  return mi_align(per) + mi_align(per * (size_t)n_channels);
+}
+int mi_pme_solve(const void* mesh, const void* recip_cell, const void* alpha, const void* volume, int n_systems, int nx, int ny, int nz, int order,
+                 int with_field, int dtype, void* scratch, size_t scratch_bytes, void* real_out, void* stream) {
+  MI_REQUIRE(dtype == MI_F32 || dtype == MI_F64, "dtype");
+  MI_REQUIRE(mesh && recip_cell && alpha && volume && scratch && real_out, "null pointer");
+  MI_REQUIRE(mi_pme_solve_supported(n_systems, nx, ny, nz, dtype), "mesh not supported by the fused solve (see mi_pme_solve_supported)");
+  const int nch = with_field ? 4 : 1;
+  MI_REQUIRE(scratch_bytes >= mi_pme_solve_scratch_bytes(n_systems, nx, ny, nz, nch, dtype), "scratch too small (mi_pme_solve_scratch_bytes)");
+  const int expo = decode_order(order).sf_exponent;
+  const mifft::Geom g = mifft::make_geom(n_systems, nx, ny, nz);
+  const size_t per = (size_t)n_systems * nx * ny * g.P * (dtype == MI_F32 ? 8 : 16);
+  void* spec = scratch;
+  void* conv = (char*)scratch + mi_align(per);
+  const int pt = solve_plane_threads(g);
+  const int col_blocks = (g.ny * g.P + MI_SOLVE_COLS - 1) / MI_SOLVE_COLS;
+  int rc = MI_OK;
+  MI_DISPATCH_T(dtype, (rc = solve_launch<T_>(mesh, recip_cell, alpha, volume, g, expo, nch, spec, conv, real_out, pt, col_blocks, dtype, stream)));
+  if (rc != MI_OK) return rc;
+  MI_LAUNCH_CHECK();
+  return MI_OK;
+}
 
 int mi_pme_gather_finish(const void* positions, const void* charges, const int32_t* batch_idx, const void* cell_inv_t, const void* meshes,
                          const void* alpha, const void* volume, const void* total_charge, int n_atoms, int n_systems, int nx, int ny, int nz,

@@ -181,6 +181,8 @@ _FFT_PLANS: dict = {}
 _OWN_FFT = os.environ.get("NVALCHEMIOPS_PME_FFT", "own") != "torch"
 # NVALCHEMIOPS_PME_FUSED_AUTOGRAD=0: energies under autograd through the op-by-op composition as in round 3 (A/B and cross-check of the adjoint)
 _FUSED_AUTOGRAD = os.environ.get("NVALCHEMIOPS_PME_FUSED_AUTOGRAD", "1") != "0"
+# NVALCHEMIOPS_PME_MESH_SOLVE=0: always hipFFT plans + mi_pme_convolve (A/B of the fused mesh solve)
+_MESH_SOLVE = os.environ.get("NVALCHEMIOPS_PME_MESH_SOLVE", "1") != "0"
 
 
 def _fft_plan(device: torch.device, dims, batch: int, code: int, inverse: bool) -> _FftPlan:
@@ -209,7 +211,8 @@ def _reciprocal_fused(pos, q, cells, alpha, mesh_dimensions, spline_order, bi, c
     batched = bi is not None
     nsys = cells.shape[0] if batched else 1
     spec, real, cit, recip, vol, qtot, al, tile_order = _reciprocal_front(pos, q, cells, alpha, (nx, ny, nz), spline_order, bi, nsys, batched,
-                                                                          compute_forces, k_vectors, k_squared, code)
+                                                                          compute_forces, k_vectors, k_squared, code,
+                                                                          need_spec=keep is not None)
     st = C.stream_of(pos)
     energies = torch.empty(n, dtype=dt, device=dev)
     forces = torch.empty((n, 3), dtype=dt, device=dev) if compute_forces else None
@@ -225,9 +228,11 @@ def _reciprocal_fused(pos, q, cells, alpha, mesh_dimensions, spline_order, bi, c
     return energies, forces, cgrads
 
 
-def _reciprocal_front(pos, q, cells, alpha, dims, spline_order, bi, nsys, batched, compute_forces, k_vectors, k_squared, code):
-    """prepare -> tile-owned spread -> R2C -> fused k-space pass -> ONE batched C2R, on the current stream.  Returns
-    (spec, real meshes [B, 1|4, nx, ny, nz], cell^-T, 2 pi cell^-1, volume, total charge, alpha, tile-grouped atom list | None)."""
+def _reciprocal_front(pos, q, cells, alpha, dims, spline_order, bi, nsys, batched, compute_forces, k_vectors, k_squared, code, need_spec=True):
+    """prepare -> spread -> k-space step -> real meshes, on the current stream.  The k-space step is the library's fused mesh solve
+    (`mi_pme_solve`: three kernels with the FFT planes / columns in LDS) for power-of-two meshes when nobody needs the charge spectrum,
+    and R2C (hipFFT plan) -> fused k-space pass -> ONE batched C2R otherwise.  Returns
+    (spec | None, real meshes [B, 1|4, nx, ny, nz], cell^-T, 2 pi cell^-1, volume, total charge, alpha, tile-grouped atom list | None)."""
     dt, dev = pos.dtype, pos.device
     n = pos.shape[0]
     nx, ny, nz = dims
@@ -244,6 +249,17 @@ def _reciprocal_front(pos, q, cells, alpha, dims, spline_order, bi, nsys, batche
     mesh, tile_order = _launch_spread(pos, q, cit, bi, nsys, (nx, ny, nz), int(spline_order), batched, want_order=True)
     nch = 4 if compute_forces else 1
     cdt = torch.complex64 if dt == torch.float32 else torch.complex128
+    if (_MESH_SOLVE and not need_spec and k_squared is None and k_vectors is None
+            and C.lib().mi_pme_solve_supported(nsys, nx, ny, nz, code)):
+        import ctypes
+
+        nbytes = int(C.lib().mi_pme_solve_scratch_bytes(nsys, nx, ny, nz, nch, code))
+        scratch = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        real = torch.empty((nsys, nch, nx, ny, nz), dtype=dt, device=dev)
+        rc = C.lib().mi_pme_solve(C.ptr(mesh), C.ptr(recip), C.ptr(al), C.ptr(vol), nsys, nx, ny, nz, C.spline_order_arg(spline_order),
+                                  int(compute_forces), code, C.ptr(scratch), ctypes.c_size_t(nbytes), C.ptr(real), st)
+        C.check(rc, "mi_pme_solve")
+        return None, real, cit, recip, vol, qtot, al, tile_order
     if _OWN_FFT:
         # the library's own hipFFT plans (mi_fft_plan_*): the spectra and the real meshes are buffers of this call, so the C2R transform may
         # consume its input in place -- torch.fft.irfftn has to clone it first and copies its result once more (2 x 68 MB per headline step)

@@ -1,0 +1,103 @@
+"""Index arithmetic of the fused PME mesh solve (csrc/fft_lds.h) against numpy, without a GPU.
+
+The kernels of `mi_pme_solve` are thin launch wrappers around per-item bodies; tests/native/fft_host_harness.cpp runs those bodies as one
+host thread per block.  Checked here: the slot maps, every 1-D plan, the packed R2C / C2R rows, the forward planes against numpy.fft and
+the whole k-space step (forward, Green function / B-spline moduli / -i k_d, inverse) against the oracle's numpy restatement of
+pme.py:1398-1440.  TEST INFRASTRUCTURE: the product has no CPU path (tests/test_host_cpu.py::test_no_cpu_fallback)."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def H(tmp_path_factory):
+    so = str(tmp_path_factory.mktemp("fft_harness") / "fft_host_harness.so")
+    subprocess.check_call(["g++", "-O1", "-shared", "-fPIC", "-I" + os.path.join(ROOT, "nvalchemi-toolkit-ops_amd", "csrc"),
+                           os.path.join(ROOT, "tests", "native", "fft_host_harness.cpp"), "-o", so])
+    return ctypes.CDLL(so)
+
+
+def _p(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def _slots(H, n, max_lr=3):
+    radix = np.zeros(4, np.int32)
+    s_of_f, f_of_s = np.zeros(n, np.int32), np.zeros(n, np.int32)
+    nst = H.h_plan(n, max_lr, _p(radix), _p(s_of_f), _p(f_of_s))
+    assert nst == -(-int(np.log2(n)) // max_lr) and radix[:nst].max() <= 2 ** max_lr
+    assert nst >= 1 and int(np.prod(radix[:nst])) == n
+    return s_of_f, f_of_s
+
+
+@pytest.mark.parametrize("max_lr", [3, 4])
+@pytest.mark.parametrize("n", [2, 4, 8, 16, 32, 64, 128, 256, 512])
+def test_line_forward_slots_and_inverse(H, n, max_lr):
+    rng = np.random.default_rng(n)
+    x = rng.standard_normal(n) + 1j * rng.standard_normal(n)
+    s_of_f, f_of_s = _slots(H, n, max_lr)
+    assert np.array_equal(f_of_s[s_of_f], np.arange(n)) and np.array_equal(np.sort(s_of_f), np.arange(n))
+    d = np.ascontiguousarray(np.stack([x.real, x.imag], -1))
+    assert H.h_line(_p(d), n, max_lr, 0) == 0
+    got = d[:, 0] + 1j * d[:, 1]
+    assert np.allclose(got[s_of_f], np.fft.fft(x), rtol=0, atol=1e-12 * n)
+    # the inverse takes the slots and returns n * x in natural order
+    assert H.h_line(_p(d), n, max_lr, 1) == 0
+    assert np.allclose(d[:, 0] + 1j * d[:, 1], n * x, rtol=0, atol=1e-12 * n * n)
+
+
+def _unscramble(H, spec, ny, nz):
+    """[..., ny, P] in (y slot, z slot) order -> natural order along y and z"""
+    M = nz // 2
+    sy, _ = _slots(H, ny)
+    sz, _ = _slots(H, M)
+    zs = np.concatenate([sz, [M]])
+    return spec[..., sy, :][..., zs]
+
+
+@pytest.mark.parametrize("dims", [(8, 8, 8), (8, 16, 32), (16, 8, 64), (32, 32, 32), (8, 64, 16), (16, 16, 128)])
+def test_forward_planes_equal_numpy_over_y_and_z(H, dims):
+    nx, ny, nz = dims
+    B = 2
+    rng = np.random.default_rng(sum(dims))
+    mesh = np.ascontiguousarray(rng.standard_normal((B, nx, ny, nz)))
+    spec = np.zeros((B, nx, ny, nz // 2 + 1, 2))
+    assert H.h_forward(_p(mesh), _p(spec), B, nx, ny, nz) == 0
+    got = _unscramble(H, spec[..., 0] + 1j * spec[..., 1], ny, nz)
+    want = np.fft.fft(np.fft.rfft(mesh, axis=-1), axis=-2)
+    assert np.allclose(got, want, rtol=0, atol=1e-11 * ny * nz)
+
+
+@pytest.mark.parametrize("dims,order,nch", [((8, 8, 8), 4, 4), ((16, 8, 32), 5, 4), ((8, 32, 16), 3, 1), ((32, 16, 8), 6, 4), ((16, 16, 16), 2, 4)])
+def test_whole_kspace_step_equals_the_numpy_restatement(H, dims, order, nch):
+    """mesh -> rfftn -> (spec / sf2) G, (-i k_d) conv -> irfftn * N for the potential + three field components (the middle of
+    oracle.pme_reciprocal_space: pme.py:1398-1440); triclinic cells, two systems with their own alpha."""
+    nx, ny, nz = dims
+    B = 2
+    rng = np.random.default_rng(7 + sum(dims))
+    mesh = np.ascontiguousarray(rng.standard_normal((B, nx, ny, nz)))
+    cells = np.stack([np.diag([9.0, 10.0, 11.0]) + 0.6 * rng.standard_normal((3, 3)) for _ in range(B)])
+    alpha = np.array([0.35, 0.42])
+    recip = np.ascontiguousarray(2.0 * np.pi * np.linalg.inv(cells))
+    vol = np.ascontiguousarray(np.abs(np.linalg.det(cells)))
+    out = np.zeros((B, nch, nx, ny, nz))
+    expo = min(order, 4)   # the reference's structure-factor exponent
+    assert H.h_solve(_p(mesh), _p(out), B, nx, ny, nz, _p(recip), _p(alpha), _p(vol), expo, nch) == 0
+    axes = (-3, -2, -1)
+    kvec, k2 = O.generate_k_vectors_pme(cells, dims)
+    g, sf2 = O.pme_green_structure_factor(k2, dims, alpha, cells, order)   # default oracle mode: exponent min(order, 4)
+    conv = (np.fft.rfftn(mesh, axes=axes) / sf2) * g
+    ntot = float(nx * ny * nz)
+    want = [np.fft.irfftn(conv, dims, axes=axes) * ntot]
+    for d in range(3):
+        want.append(np.fft.irfftn(-1j * kvec[..., d] * conv, dims, axes=axes) * ntot)
+    want = np.stack(want[:nch], 1)
+    scale = np.abs(want).max()
+    assert np.allclose(out, want, rtol=0, atol=1e-11 * scale), np.abs(out - want).max() / scale

@@ -752,3 +752,60 @@ def test_tile_staged_gather_epilogue(dims, order):
         bref = O.pme_reciprocal_space(pos2, q2, cells, np.array([0.4, 0.5]), dims, order, batch_idx=bi, compute_forces=True)
         _close(be, bref[0], dtype, f"batch energies {dims}")
         _close(bf, bref[1], dtype, f"batch forces {dims}")
+
+
+@pytest.mark.parametrize("dims", [(8, 8, 8), (16, 8, 32), (8, 64, 16), (32, 32, 32), (64, 16, 128), (16, 256, 8), (128, 128, 128)])
+@pytest.mark.parametrize("order", [4, 5])
+def test_fused_mesh_solve(dims, order, monkeypatch):
+    """Power-of-two meshes take the library's fused mesh solve (`mi_pme_solve`: plane / column FFTs in LDS with the Green function, the
+    B-spline moduli and -i k_d between the forward and inverse x transforms, csrc/fft_lds.h) instead of hipFFT R2C -> `mi_pme_convolve` ->
+    hipFFT C2R: same energies / forces / charge gradients from both, and both against the oracle (numpy FFTs); triclinic cell, fp64 and fp32,
+    energies only (one channel) and with forces (four), single system and a batch of three with their own alpha."""
+    from nvalchemiops import _capi as C
+    from nvalchemiops.interactions.electrostatics import pme as P
+    from nvalchemiops.interactions.electrostatics import pme_reciprocal_space
+
+    for dtype in (np.float64, np.float32):
+        assert C.lib().mi_pme_solve_supported(1, *dims, C.dtype_code(torch.float64 if dtype == np.float64 else torch.float32)) == 1
+        n = 300 if max(dims) < 128 else 3000
+        pos, cell, q = _system(n, dtype, triclinic=True, seed=order + dims[2])
+        tol = dict(rtol=1e-10, atol=1e-12) if dtype == np.float64 else dict(rtol=2e-4, atol=2e-5)
+        out = {}
+        for solve in (True, False):
+            monkeypatch.setattr(P, "_MESH_SOLVE", solve)
+            e0 = pme_reciprocal_space(_t(pos), _t(q), _t(cell), 0.4, mesh_dimensions=dims, spline_order=order)
+            e, f, cg = pme_reciprocal_space(_t(pos), _t(q), _t(cell), 0.4, mesh_dimensions=dims, spline_order=order, compute_forces=True,
+                                            compute_charge_gradients=True)
+            out[solve] = (e0, e, f, cg)
+        for a, b in zip(out[True], out[False]):
+            scale = float(b.abs().max())
+            assert torch.allclose(a, b, rtol=tol["rtol"], atol=tol["atol"] * max(scale, 1.0)), (dims, order, dtype, float((a - b).abs().max()), scale)
+        monkeypatch.setattr(P, "_MESH_SOLVE", True)
+        if max(dims) < 128:
+            with O.extended_splines():
+                ref = O.pme_reciprocal_space(pos, q, cell, 0.4, dims, order, compute_forces=True, compute_charge_gradients=True)
+            for got, want, what in zip(out[True][1:], ref, ("energies", "forces", "charge gradients")):
+                _close(got, want, dtype, f"{what} {dims} order {order}")
+            pos3 = np.concatenate([pos, pos * 0.8, pos * 1.1]).astype(dtype)
+            q3 = np.concatenate([q, 2 * q, -q]).astype(dtype)
+            cells = np.stack([cell, cell * 0.8, cell * 1.1]).astype(dtype)
+            bi = np.repeat(np.arange(3, dtype=np.int32), len(pos))
+            al = np.array([0.4, 0.5, 0.35])
+            be, bf = pme_reciprocal_space(_t(pos3), _t(q3), _t(cells), torch.tensor(al, dtype=_t(pos).dtype, device=DEV), mesh_dimensions=dims,
+                                          spline_order=order, batch_idx=_t(bi), compute_forces=True)
+            with O.extended_splines():
+                bref = O.pme_reciprocal_space(pos3, q3, cells, al, dims, order, batch_idx=bi, compute_forces=True)
+            _close(be, bref[0], dtype, f"batch energies {dims}")
+            _close(bf, bref[1], dtype, f"batch forces {dims}")
+
+
+def test_fused_mesh_solve_support_table():
+    """What the fused solve takes: powers of two whose (ny, nz/2+1) plane fits LDS; everything else keeps hipFFT."""
+    from nvalchemiops import _capi as C
+
+    ok = C.lib().mi_pme_solve_supported
+    f64, f32 = C.dtype_code(torch.float64), C.dtype_code(torch.float32)
+    assert ok(1, 128, 128, 128, f64) == 1 and ok(128, 32, 32, 32, f64) == 1 and ok(1, 256, 64, 256, f64) == 1
+    assert ok(1, 256, 256, 256, f64) == 0 and ok(1, 128, 256, 128, f64) == 0      # plane larger than 160 KB
+    assert ok(1, 128, 256, 128, f32) == 1 and ok(1, 256, 256, 256, f32) == 0
+    assert ok(1, 48, 48, 48, f64) == 0 and ok(1, 30, 36, 45, f64) == 0 and ok(1, 4, 8, 8, f64) == 0

@@ -1,0 +1,13 @@
+#!/bin/bash
+# PMC passes over config 4 for the fused mesh solve kernels (pme_solve_*): where do the cycles go?
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$R/gpurun_out/solve_pmc
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+for set in "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_BUSY_CYCLES" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_WAVES"; do
+  tag=$(echo $set | cut -d' ' -f1)
+  rm -rf /tmp/prof_$tag
+  BENCH_CALIB=0 rocprofv3 --kernel-trace --pmc $set -d /tmp/prof_$tag -- python $R/bench.py --workload c4 --processes 1 --steps 3 --warmup 1 --cpu-sample 0 > /tmp/prof_$tag.log 2>&1
+  python $R/tools/rocpd_pmc.py $(find /tmp/prof_$tag -name "*.db" | head -1) $OUT/pmc_$tag.csv 2>&1 | tail -2
+done
+grep -h "pme_solve\|^kernel" $OUT/pmc_SQ_WAVE_CYCLES.csv $OUT/pmc_SQ_INSTS_VALU.csv | cut -c1-60,150-400
