@@ -380,6 +380,13 @@ def kernel_accounting(kernel: str, n: int, pairs_d3: int):
         return "hbm", 4 * mesh * 8 + n * 4 * 8 + n * 4 * 8, None, "L2/MALL-resident mesh gather"
     if kernel == "pme_convolve":
         return "hbm", (mesh / 2) * 16 * 5, None, ""
+    # fused mesh solve (mi_pme_solve): complex half-spectra of 16 B per point; every kernel reads and writes its planes / columns once
+    if kernel == "pme_solve_fwd":
+        return "hbm", mesh * 8 + (mesh / 2) * 16, None, "real planes in, (y,z)-transformed half spectrum out"
+    if kernel == "pme_solve_cols":
+        return "hbm", (mesh / 2) * 16 * (2 + 1 + 4), None, "x transform + Green function in place, then 4 channels back along x"
+    if kernel == "pme_solve_inv":
+        return "hbm", 4 * ((mesh / 2) * 16 + mesh * 8), None, "4 channels: half spectrum in, real planes out"
     return "latency", None, None, ""
 
 
@@ -708,6 +715,31 @@ def _timed_steps(step, steps, warmup):
     return out, elapsed, [a.elapsed_time(b) for a, b in zip(ev[:-1], ev[1:])], kernel_report()
 
 
+def _graph_replay(step, steps):
+    """BENCH_GRAPH=1: the same step captured once in a HIP graph (torch.cuda.CUDAGraph: the library launches on torch's current stream, which
+    is the capturing one) and replayed `steps` times -- what the eager number pays in launch gaps.  Reported beside `ms_per_step`, never as it."""
+    try:
+        g = torch.cuda.CUDAGraph()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            step()  # shapes / tables / plans exist before the capture
+            torch.cuda.synchronize()
+            with torch.cuda.graph(g, stream=side):
+                step()
+        torch.cuda.synchronize()
+        for _ in range(3):
+            g.replay()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            g.replay()
+        torch.cuda.synchronize()
+        return {"captured": True, "ms_per_step": (time.perf_counter() - t0) / steps * 1e3, "steps": steps}
+    except Exception as exc:  # a host read inside the step (an allocation size, an overflow check) cannot be captured
+        return {"captured": False, "error": f"{type(exc).__name__}: {exc}"[:300]}
+
+
 def _config_rows(kernels, acct):
     """Kernel table of a config workload: every timed kernel with its in-step average and, where `acct` prices it, SURVEY 8(d) bytes."""
     rows = {}
@@ -850,7 +882,10 @@ def config_c4(device, args):
             "ewald_real": ("hbm", 16.0 * n * m + n * (3 * 8 + 8) + n * (8 + 3 * 8), "fp64 erfc pair sum over the padded rows"),
             "spline_spread": ("latency", n * 4 * 8 + mesh * 8, "binning + LDS-tile accumulation"),
             "pme_gather_finish": ("hbm", 4 * mesh * 8 + n * 4 * 8 + n * 4 * 8, "L2/MALL-resident mesh gather"),
-            "pme_convolve": ("hbm", (mesh / 2) * 16 * 5, "")}
+            "pme_convolve": ("hbm", (mesh / 2) * 16 * 5, ""),
+            "pme_solve_fwd": ("hbm", mesh * 8 + (mesh / 2) * 16, "real planes in, (y,z)-transformed half spectrum out"),
+            "pme_solve_cols": ("hbm", (mesh / 2) * 16 * (2 + 1 + 4), "x transform + Green function in place, then 4 channels back along x"),
+            "pme_solve_inv": ("hbm", 4 * ((mesh / 2) * 16 + mesh * 8), "4 channels: half spectrum in, real planes out")}
     host = sysd["host"]
 
     def cpu():
@@ -890,6 +925,8 @@ def run_config(name, device, args):
            "config": {"workload": cfg["workload"], "atoms_per_gpu": n, **cfg["extra"](out)},
            "stats": {"step_ms_median": statistics.median(step_ms), "step_ms_min": min(step_ms), "step_ms_max": max(step_ms), "timed_region_s": elapsed},
            "roofline": roof, "calibration": calibration, "kernels": rows}
+    if os.environ.get("BENCH_GRAPH", "0") == "1":
+        res["hip_graph"] = _graph_replay(cfg["step"], args.steps)
     if args.cpu_sample > 0:
         res["cpu_baseline"] = cfg["cpu"]()
     print(json.dumps(res), flush=True)

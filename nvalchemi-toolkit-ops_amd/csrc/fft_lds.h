@@ -176,15 +176,18 @@ template <int SIGN, int R, class T> MI_HD void dftR(Cx<T>* v) {
 // to the same point numbers.  W: table of exp(-2 pi i t / NW) with NW = 2^lgNW >= L.
 // Forward (decimation in frequency): butterfly, then twiddle exp(-2 pi i o q / L).  Inverse (decimation in time): conjugate twiddle, then
 // butterfly -- R times the exact inverse of the forward stage, so forward stages 0..S-1 followed by inverse stages S-1..0 give n * identity.
-template <int SIGN, int R, class T, class Ld, class St>
-MI_HD void butterfly(const Cx<T>* W, int lgNW, int lgL, int lgR, int j, Ld ld, St st) {
+template <int R, class T, class Ld> MI_HD void butterfly_load(Cx<T>* v, int lgL, int lgR, int j, Ld ld) {
+  const int lsub = lgL - lgR;
+  const int blk = j >> lsub, o = j & ((1 << lsub) - 1);
+  const int base = (blk << lgL) + o;
+#pragma unroll
+  for (int r = 0; r < R; ++r) v[r] = ld(base + (r << lsub));
+}
+template <int SIGN, int R, class T, class St> MI_HD void butterfly_finish(Cx<T>* v, const Cx<T>* W, int lgNW, int lgL, int lgR, int j, St st) {
   const int lsub = lgL - lgR;
   const int blk = j >> lsub, o = j & ((1 << lsub) - 1);
   const int base = (blk << lgL) + o;
   const int wl = o << (lgNW - lgL);  // o * (NW / L)
-  Cx<T> v[R];
-#pragma unroll
-  for (int r = 0; r < R; ++r) v[r] = ld(base + (r << lsub));
   if (SIGN > 0) {
 #pragma unroll
     for (int q = 1; q < R; ++q) v[q] = cmul(v[q], cconj(W[q * wl]));
@@ -196,6 +199,12 @@ MI_HD void butterfly(const Cx<T>* W, int lgNW, int lgL, int lgR, int j, Ld ld, S
   }
 #pragma unroll
   for (int r = 0; r < R; ++r) st(base + (r << lsub), v[r]);
+}
+template <int SIGN, int R, class T, class Ld, class St>
+MI_HD void butterfly(const Cx<T>* W, int lgNW, int lgL, int lgR, int j, Ld ld, St st) {
+  Cx<T> v[R];
+  butterfly_load<R>(v, lgL, lgR, j, ld);
+  butterfly_finish<SIGN, R>(v, W, lgNW, lgL, lgR, j, st);
 }
 // MAXLR: the largest radix the caller's plans contain (make_plan's max_lr) -- radix 16 is only instantiated where it can occur
 template <int SIGN, int MAXLR = 3, class T, class Ld, class St>
@@ -562,25 +571,40 @@ MI_HD void inv_cols_body(const Cx<T>* conv, Cx<T>* out, Cx<T>* lds, const Geom& 
     const int lgL = stage_lgL(px, s), lgR = px.lr[s];
     const int items = COLS << (px.lg - lgR);
     const bool first = s == px.nst - 1, last = s == 0;
-    for (int it = tid; it < items; it += nth) {
-      const int j = it >> LGC, c = it & (COLS - 1);
-      const bool live = col0 + c < ncol;
+    auto ld_of = [=](int c, bool live) {
       const Cx<T>* src = conv + col0 + c;
+      return [=](int p) {
+        if (!first) return S[(p << LGC) + c];
+        if (!live) return Cx<T>{T(0), T(0)};
+        const Cx<T> v = src[(size_t)p * ncol];
+        if (!field) return v;
+        const T kd = KX[p] + KC[c];
+        return Cx<T>{kd * v.im, -(kd * v.re)};
+      };
+    };
+    auto st_of = [=](int c, bool live) {
       Cx<T>* dst = out + col0 + c;
-      // (staging the tile through LDS together with the tables, all loads in flight in one phase, measured slower: 33.5 -> 39 us)
-      butterfly_r<+1, 4>(lgR, Wx, px.lg, lgL, j,
-                      [=](int p) {
-                        if (!first) return S[(p << LGC) + c];
-                        if (!live) return Cx<T>{T(0), T(0)};
-                        const Cx<T> v = src[(size_t)p * ncol];
-                        if (!field) return v;
-                        const T kd = KX[p] + KC[c];
-                        return Cx<T>{kd * v.im, -(kd * v.re)};
-                      },
-                      [=](int p, Cx<T> v) {
-                        if (last) { if (live) dst[(size_t)p * ncol] = v; }
-                        else S[(p << LGC) + c] = v;
-                      });
+      return [=](int p, Cx<T> v) {
+        if (last) { if (live) dst[(size_t)p * ncol] = v; }
+        else S[(p << LGC) + c] = v;
+      };
+    };
+    if (first && lgR == 3 && items == 2 * nth) {
+      // the stage that reads HBM: both butterflies of the lane load first (16 lines in flight per lane instead of 8 + 8 one after the other)
+      const int ia = tid, ib = tid + nth;
+      const int ja = ia >> LGC, ca = ia & (COLS - 1), jb = ib >> LGC, cb = ib & (COLS - 1);
+      const bool la = col0 + ca < ncol, lb = col0 + cb < ncol;
+      Cx<T> va[8], vb[8];
+      butterfly_load<8>(va, lgL, 3, ja, ld_of(ca, la));
+      butterfly_load<8>(vb, lgL, 3, jb, ld_of(cb, lb));
+      butterfly_finish<+1, 8>(va, Wx, px.lg, lgL, 3, ja, st_of(ca, la));
+      butterfly_finish<+1, 8>(vb, Wx, px.lg, lgL, 3, jb, st_of(cb, lb));
+    } else {
+      for (int it = tid; it < items; it += nth) {
+        const int j = it >> LGC, c = it & (COLS - 1);
+        const bool live = col0 + c < ncol;
+        butterfly_r<+1, 4>(lgR, Wx, px.lg, lgL, j, ld_of(c, live), st_of(c, live));
+      }
     }
     MI_FFT_SYNC();
   }

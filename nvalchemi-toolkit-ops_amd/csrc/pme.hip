@@ -1033,11 +1033,25 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2))) void p
   mifft::inv_cols_body<T>(conv_spec + b * per, conv + ((size_t)b * n_channels + ch) * per, (mifft::Cx<T>*)solve_smem, g, tb, recip + 9 * b, ch,
                           tile * MI_SOLVE_COLS, threadIdx.x, blockDim.x);
 }
+// persistent: one block per CU walks its planes, so that the stores of one plane are still draining while the loads of the next are issued
+// (with one 133 KB plane per CU in LDS nothing else overlaps the two)
 template <class T>
-__global__ __launch_bounds__(1024) void pme_solve_inv_kernel(const mifft::Cx<T>* __restrict__ conv, T* __restrict__ real, mifft::Geom g, mifft::Tables<T> tb) {
+__global__ __launch_bounds__(1024) void pme_solve_inv_kernel(const mifft::Cx<T>* __restrict__ conv, T* __restrict__ real, mifft::Geom g, mifft::Tables<T> tb,
+                                                             int n_planes) {
   extern __shared__ __align__(16) unsigned char solve_smem[];
-  const size_t plane = blockIdx.x;  // (system, channel, x)
-  mifft::inv_plane_body<T>(conv + plane * g.ny * g.P, real + plane * g.ny * g.nz, (mifft::Cx<T>*)solve_smem, g, tb, threadIdx.x, blockDim.x);
+  for (size_t plane = blockIdx.x; plane < (size_t)n_planes; plane += gridDim.x) {  // (system, channel, x)
+    mifft::inv_plane_body<T>(conv + plane * g.ny * g.P, real + plane * g.ny * g.nz, (mifft::Cx<T>*)solve_smem, g, tb, threadIdx.x, blockDim.x);
+    __syncthreads();
+  }
+}
+static int solve_cus() {
+  static int n = 0;
+  if (!n) {
+    int dev = 0;
+    hipDeviceProp_t p;
+    n = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0) ? p.multiProcessorCount : 256;
+  }
+  return n;
 }
 template <class T> static bool solve_fits(const mifft::Geom& g) {
   return mifft::plane_lds_bytes<T>(g) <= MI_LDS_MAX && mifft::fwd_cols_lds_bytes<T>(g) <= MI_LDS_MAX;
@@ -1093,7 +1107,8 @@ static int solve_launch(const void* mesh, const void* recip_cell, const void* al
                                                                                           (const T*)recip_cell, nch, col_blocks);
   mi_timing_end(stream);
   mi_timing_begin("pme_solve_inv", stream);
-  pme_solve_inv_kernel<T><<<g.B * nch * g.nx, pt, pl, st>>>((const mifft::Cx<T>*)conv, (T*)real_out, g, tb);
+  const int n_planes = g.B * nch * g.nx;
+  pme_solve_inv_kernel<T><<<n_planes < solve_cus() ? n_planes : solve_cus(), pt, pl, st>>>((const mifft::Cx<T>*)conv, (T*)real_out, g, tb, n_planes);
   mi_timing_end(stream);
   return MI_OK;
 }

@@ -10,7 +10,9 @@ import re
 import sys
 
 SHORT = {"d3_energy_kernel": "d3_energy", "d3_energy_kernel_w5": "d3_energy", "d3_cn_kernel": "d3_cn", "d3_chain_kernel": "d3_chain", "ewald_real_kernel": "ewald_real",
-         "spline_spread_kernel": "spline_spread", "spread_tiled_kernel": "spline_spread", "pme_convolve_kernel": "pme_convolve", "pme_gather_finish_kernel": "pme_gather_finish",
+         "spline_spread_kernel": "spline_spread", "spread_tiled_kernel": "spline_spread", "pme_convolve_kernel": "pme_convolve", "pme_gather_finish_kernel": "pme_gather_finish", "pme_gather_box_kernel": "pme_gather_finish",
+         "spread_box_kernel": "spline_spread", "pme_solve_fwd_kernel": "pme_solve_fwd", "pme_solve_inv_kernel": "pme_solve_inv",
+         "pme_solve_inv_cols_kernel": "pme_solve_cols",  # (+ pme_solve_fwd_cols_kernel under the same timing name: 17 MB in place)
          "nl_query_tiled_kernel": None, "nl_query_kernel": None}
 MODE = {"0": "nl_query_matrix", "1": "nl_query_count", "2": "nl_query_csr"}
 

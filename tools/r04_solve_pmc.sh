@@ -10,4 +10,17 @@ for set in "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_AC
   BENCH_CALIB=0 rocprofv3 --kernel-trace --pmc $set -d /tmp/prof_$tag -- python $R/bench.py --workload c4 --processes 1 --steps 3 --warmup 1 --cpu-sample 0 > /tmp/prof_$tag.log 2>&1
   python $R/tools/rocpd_pmc.py $(find /tmp/prof_$tag -name "*.db" | head -1) $OUT/pmc_$tag.csv 2>&1 | tail -2
 done
-grep -h "pme_solve\|^kernel" $OUT/pmc_SQ_WAVE_CYCLES.csv $OUT/pmc_SQ_INSTS_VALU.csv | cut -c1-60,150-400
+python - "$OUT" <<PYEOF
+import csv,sys,collections
+out=sys.argv[1]
+rows=[]
+for f in ("pmc_SQ_WAVE_CYCLES.csv","pmc_SQ_INSTS_VALU.csv"):
+    rows+=list(csv.DictReader(open(out+"/"+f)))
+t=collections.defaultdict(dict)
+for r in rows:
+    if "pme_solve" in r["kernel"]:
+        k=r["kernel"].split("::")[1].split("(")[0]
+        t[k][r["counter"]]=float(r["per_launch"]); t[k]["us"]=float(r["avg_ns"])/1e3
+for k,v in t.items():
+    print(k, {a:(round(b/1e6,3) if a!="us" else round(b,1)) for a,b in sorted(v.items())})
+PYEOF
