@@ -1060,30 +1060,9 @@ static int solve_plane_threads(const mifft::Geom& g) {
   const long long items = (long long)g.ny * g.M / 8;  // radix-8 butterflies of one row stage
   return items >= 1024 ? 1024 : items >= 512 ? 512 : 256;
 }
-// Unit roots / sinc / Miller-index tables of a mesh shape: computed on first use, kept on the device for the life of the process (like the
-// FFT plans of fft.cpp: the first call for a shape must not be inside a HIP-graph capture).
-struct SolveTables { int dev, nx, ny, nz, dtype; void* ptr; };
-static SolveTables g_solve_tables[16];
-static int g_solve_tables_n = 0;
-template <class T> static int solve_tables_get(const mifft::Geom& g, int dtype, hipStream_t st, void** out) {
-  int dev = 0;
-  MI_HIP_CHECK(hipGetDevice(&dev));
-  for (int i = 0; i < g_solve_tables_n; ++i) {
-    const SolveTables& e = g_solve_tables[i];
-    if (e.dev == dev && e.nx == g.nx && e.ny == g.ny && e.nz == g.nz && e.dtype == dtype) { *out = e.ptr; return MI_OK; }
-  }
-  MI_REQUIRE(g_solve_tables_n < 16, "more than 16 distinct mesh shapes in one process for the fused mesh solve");
-  void* p = nullptr;
-  MI_HIP_CHECK(hipMalloc(&p, mifft::tables_bytes<T>(g)));
-  pme_solve_tables_kernel<T><<<1, 256, 0, st>>>(p, g);
-  MI_LAUNCH_CHECK();
-  g_solve_tables[g_solve_tables_n++] = SolveTables{dev, g.nx, g.ny, g.nz, dtype, p};
-  *out = p;
-  return MI_OK;
-}
 template <class T>
 static int solve_launch(const void* mesh, const void* recip_cell, const void* alpha, const void* volume, const mifft::Geom& g, int expo, int nch,
-                        void* spec, void* conv, void* real_out, int pt, int col_blocks, int dtype, void* stream) {
+                        void* spec, void* conv, void* tab, void* real_out, int pt, int col_blocks, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   const size_t pl = mifft::plane_lds_bytes<T>(g), fl = mifft::fwd_cols_lds_bytes<T>(g), il = mifft::inv_cols_lds_bytes<T>(g);
   static bool raised = false;  // more than 64 KB of dynamic LDS has to be asked for once per kernel
@@ -1094,9 +1073,9 @@ static int solve_launch(const void* mesh, const void* recip_cell, const void* al
     MI_HIP_CHECK(hipFuncSetAttribute((const void*)pme_solve_inv_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, MI_LDS_MAX));
     raised = true;
   }
-  void* tab = nullptr;
-  const int rc = solve_tables_get<T>(g, dtype, st, &tab);
-  if (rc != MI_OK) return rc;
+  // unit roots / sinc / Miller index per FFT slot: a few KB, recomputed by one small launch per call into the caller's scratch -- the
+  // library keeps NO device memory of its own here (a per-shape cache allocated with hipMalloc was tried first)
+  pme_solve_tables_kernel<T><<<1, 256, 0, st>>>(tab, g);
   const mifft::Tables<T> tb = mifft::tables_at<T>(tab, g);
   mi_timing_begin("pme_solve_fwd", stream);
   pme_solve_fwd_kernel<T><<<g.B * g.nx, pt, pl, st>>>((const T*)mesh, (mifft::Cx<T>*)spec, g, tb);
@@ -1108,7 +1087,9 @@ static int solve_launch(const void* mesh, const void* recip_cell, const void* al
   mi_timing_end(stream);
   mi_timing_begin("pme_solve_inv", stream);
   const int n_planes = g.B * nch * g.nx;
-  pme_solve_inv_kernel<T><<<n_planes < solve_cus() ? n_planes : solve_cus(), pt, pl, st>>>((const mifft::Cx<T>*)conv, (T*)real_out, g, tb, n_planes);
+  // persistent only where one plane fills the CU's LDS; small planes run several blocks per CU and overlap by themselves
+  const int inv_grid = (2 * pl <= MI_LDS_MAX || n_planes < solve_cus()) ? n_planes : solve_cus();
+  pme_solve_inv_kernel<T><<<inv_grid, pt, pl, st>>>((const mifft::Cx<T>*)conv, (T*)real_out, g, tb, n_planes);
   mi_timing_end(stream);
   return MI_OK;
 }
@@ -1393,9 +1374,16 @@ int mi_pme_solve_supported(int n_systems, int nx, int ny, int nz, int dtype) {
   if ((long long)n_systems * 4 * nx > 0x7fffffffll || n_systems > 65535) return 0;
   return (dtype == MI_F32 ? solve_fits<float>(g) : solve_fits<double>(g)) ? 1 : 0;
 }
+/* Host policy, measured (profiles/r04_ab_solve_size.log): batches of small meshes stay with hipFFT's batched plans (128 x 32^3: 0.66 vs 0.85 ms,
+ * 8 x 64^3: 0.33 vs 0.36); one system, or meshes from 128^3 on, take the fused solve (32^3: 0.077 vs 0.087 ms, 128^3: 0.34 vs 0.37, 2 x 128^3: 0.58 vs 0.64). */
+int mi_pme_solve_preferred(int n_systems, int nx, int ny, int nz, int dtype) {
+  if (!mi_pme_solve_supported(n_systems, nx, ny, nz, dtype)) return 0;
+  return (n_systems == 1 || (long long)nx * ny * nz >= (1ll << 21)) ? 1 : 0;
+}
 size_t mi_pme_solve_scratch_bytes(int n_systems, int nx, int ny, int nz, int n_channels, int dtype) {
   const size_t per = (size_t)n_systems * nx * ny * (nz / 2 + 1) * (dtype == MI_F32 ? 8 : 16);
-  return mi_align(per) + mi_align(per * (size_t)n_channels);
+  const mifft::Geom g = mifft::make_geom(n_systems, nx, ny, nz);
+  return mi_align(per) + mi_align(per * (size_t)n_channels) + mi_align(dtype == MI_F32 ? mifft::tables_bytes<float>(g) : mifft::tables_bytes<double>(g));
 }
 int mi_pme_solve(const void* mesh, const void* recip_cell, const void* alpha, const void* volume, int n_systems, int nx, int ny, int nz, int order,
                  int with_field, int dtype, void* scratch, size_t scratch_bytes, void* real_out, void* stream) {
@@ -1409,10 +1397,11 @@ int mi_pme_solve(const void* mesh, const void* recip_cell, const void* alpha, co
   const size_t per = (size_t)n_systems * nx * ny * g.P * (dtype == MI_F32 ? 8 : 16);
   void* spec = scratch;
   void* conv = (char*)scratch + mi_align(per);
+  void* tab = (char*)conv + mi_align(per * (size_t)nch);
   const int pt = solve_plane_threads(g);
   const int col_blocks = (g.ny * g.P + MI_SOLVE_COLS - 1) / MI_SOLVE_COLS;
   int rc = MI_OK;
-  MI_DISPATCH_T(dtype, (rc = solve_launch<T_>(mesh, recip_cell, alpha, volume, g, expo, nch, spec, conv, real_out, pt, col_blocks, dtype, stream)));
+  MI_DISPATCH_T(dtype, (rc = solve_launch<T_>(mesh, recip_cell, alpha, volume, g, expo, nch, spec, conv, tab, real_out, pt, col_blocks, stream)));
   if (rc != MI_OK) return rc;
   MI_LAUNCH_CHECK();
   return MI_OK;

@@ -181,8 +181,9 @@ _FFT_PLANS: dict = {}
 _OWN_FFT = os.environ.get("NVALCHEMIOPS_PME_FFT", "own") != "torch"
 # NVALCHEMIOPS_PME_FUSED_AUTOGRAD=0: energies under autograd through the op-by-op composition as in round 3 (A/B and cross-check of the adjoint)
 _FUSED_AUTOGRAD = os.environ.get("NVALCHEMIOPS_PME_FUSED_AUTOGRAD", "1") != "0"
-# NVALCHEMIOPS_PME_MESH_SOLVE=0: always hipFFT plans + mi_pme_convolve (A/B of the fused mesh solve)
-_MESH_SOLVE = os.environ.get("NVALCHEMIOPS_PME_MESH_SOLVE", "1") != "0"
+# "auto": the library's measured policy (mi_pme_solve_preferred); True / NVALCHEMIOPS_PME_MESH_SOLVE=1: the fused mesh solve wherever it is
+# supported; False / =0: always hipFFT plans + mi_pme_convolve (A/B runs, and the parity tests that drive the solve's batch kernels)
+_MESH_SOLVE = {"0": False, "1": True}.get(os.environ.get("NVALCHEMIOPS_PME_MESH_SOLVE", "auto"), "auto")
 
 
 def _fft_plan(device: torch.device, dims, batch: int, code: int, inverse: bool) -> _FftPlan:
@@ -250,7 +251,7 @@ def _reciprocal_front(pos, q, cells, alpha, dims, spline_order, bi, nsys, batche
     nch = 4 if compute_forces else 1
     cdt = torch.complex64 if dt == torch.float32 else torch.complex128
     if (_MESH_SOLVE and not need_spec and k_squared is None and k_vectors is None
-            and C.lib().mi_pme_solve_supported(nsys, nx, ny, nz, code)):
+            and (C.lib().mi_pme_solve_supported if _MESH_SOLVE is True else C.lib().mi_pme_solve_preferred)(nsys, nx, ny, nz, code)):
         import ctypes
 
         nbytes = int(C.lib().mi_pme_solve_scratch_bytes(nsys, nx, ny, nz, nch, code))
