@@ -348,3 +348,25 @@ def test_spread_path_policy():
     assert prefers(256_000, 128, 32, 32, 32, 4) == 1                                         # ... but 128 systems of them are 8192 tiles
     assert possible(1, 31, 31, 31, 4) == 0 and prefers(100_000, 1, 31, 31, 31, 4) == 0       # prime mesh: atomic kernel
     assert prefers(100_000, 1, 128, 128, 128, 5 | C.SPLINE_REFERENCE_ORDERS) == 0
+
+
+def test_mesh_solve_policy():
+    """Host logic of the fused PME mesh solve (no compute): which meshes it supports (powers of two whose (ny, nz/2+1) complex plane and tables
+    fit 160 KB of LDS), where it is preferred (one system, or >= 2^21 mesh points: profiles/r04_ab_solve_size.log), and that its scratch covers
+    the half spectrum, the channel spectra and the per-call tables."""
+    import ctypes
+
+    from nvalchemiops import _capi as C
+
+    L = C.lib()
+    ok, pref = L.mi_pme_solve_supported, L.mi_pme_solve_preferred
+    f32, f64 = 0, 1
+    assert ok(1, 128, 128, 128, f64) == 1 and ok(1, 256, 64, 256, f64) == 1 and ok(1, 128, 256, 128, f32) == 1
+    assert ok(1, 128, 256, 128, f64) == 0 and ok(1, 256, 256, 256, f32) == 0        # plane larger than the LDS
+    assert ok(1, 48, 48, 48, f64) == 0 and ok(1, 31, 9, 6, f64) == 0 and ok(1, 4, 8, 8, f64) == 0 and ok(0, 32, 32, 32, f64) == 0
+    assert pref(1, 32, 32, 32, f64) == 1 and pref(128, 32, 32, 32, f64) == 0 and pref(8, 64, 64, 64, f64) == 0 and pref(2, 128, 128, 128, f64) == 1
+    L.mi_pme_solve_scratch_bytes.restype = ctypes.c_size_t
+    for nch in (1, 4):
+        half = 128 * 128 * 65 * 16
+        need = int(L.mi_pme_solve_scratch_bytes(1, 128, 128, 128, nch, f64))
+        assert half * (1 + nch) <= need <= half * (1 + nch) + 3 * 256 + 3 * 128 * 16 + 6 * 128 * 8 + 1024
