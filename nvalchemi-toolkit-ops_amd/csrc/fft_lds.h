@@ -228,8 +228,10 @@ template <class T> MI_HD Cx<T> unit_root(int t, int n) {
   return Cx<T>{(T)c, (T)s};
 }
 
-#ifdef __HIP_DEVICE_COMPILE__
+#if defined(__HIP_DEVICE_COMPILE__)
 #define MI_FFT_SYNC() __syncthreads()
+#elif defined(MI_FFT_HOST_BARRIER)
+#define MI_FFT_SYNC() MI_FFT_HOST_BARRIER()  // tests/native/fft_race_check.cpp: one host thread per "lane group", a pthread barrier, ThreadSanitizer
 #else
 #define MI_FFT_SYNC() ((void)0)
 #endif

@@ -1,0 +1,88 @@
+// TEST PROGRAM (never part of the product): runs the kernel bodies of csrc/fft_lds.h with SEVERAL host threads per block -- thread t plays
+// (tid = t, nthreads = T), MI_FFT_SYNC() is a pthread barrier -- under ThreadSanitizer.  Two things are checked that the single-thread harness
+// cannot see: (1) the tid-strided partition of every phase gives bit-identical results for any thread count, (2) no two threads touch the same
+// LDS / global element between two barriers (a data race here is a missing __syncthreads on the GPU).  Built and run by
+// tests/test_fft_lds_cpu.py::test_barrier_placement_under_thread_sanitizer:  g++ -fsanitize=thread -O1 -pthread.
+#include <pthread.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <thread>
+#include <vector>
+
+static thread_local pthread_barrier_t* tl_barrier = nullptr;
+static bool g_drop_barriers = false;  // negative control (argv[1] = "drop"): the detector must then report races
+static void host_barrier() {
+  if (tl_barrier && !g_drop_barriers) pthread_barrier_wait(tl_barrier);
+}
+#define MI_FFT_HOST_BARRIER host_barrier
+#include "fft_lds.h"
+
+using namespace mifft;
+
+template <class F> static void run_block(int nth, F body) {
+  if (nth == 1) { tl_barrier = nullptr; body(0, 1); return; }
+  pthread_barrier_t bar;
+  pthread_barrier_init(&bar, nullptr, nth);
+  std::vector<std::thread> th;
+  for (int t = 0; t < nth; ++t) th.emplace_back([&, t] { tl_barrier = &bar; body(t, nth); });
+  for (auto& x : th) x.join();
+  pthread_barrier_destroy(&bar);
+}
+
+static std::vector<double> solve(int B, int nx, int ny, int nz, int nch, int nth, const std::vector<double>& mesh) {
+  const Geom g = make_geom(B, nx, ny, nz);
+  std::vector<char> tab(tables_bytes<double>(g));
+  run_block(nth, [&](int tid, int n) { tables_body<double>(tab.data(), g, tid, n); });
+  const Tables<double> tb = tables_at<double>(tab.data(), g);
+  const size_t ncol = (size_t)ny * g.P;
+  std::vector<Cx<double>> spec((size_t)B * nx * ncol), conv((size_t)B * nch * nx * ncol);
+  size_t need = plane_lds_bytes<double>(g);
+  if (inv_cols_lds_bytes<double>(g) > need) need = inv_cols_lds_bytes<double>(g);
+  if (fwd_cols_lds_bytes<double>(g) > need) need = fwd_cols_lds_bytes<double>(g);
+  std::vector<char> lds(need);
+  std::vector<double> out((size_t)B * nch * nx * ny * nz);
+  double recip[18] = {0.61, 0.02, -0.03, 0.05, 0.57, 0.01, -0.02, 0.04, 0.52, 0.66, 0.0, 0.0, 0.0, 0.6, 0.0, 0.0, 0.0, 0.55};
+  const double alpha[2] = {0.35, 0.42}, volume[2] = {1100.0, 900.0};
+  for (int bx = 0; bx < B * nx; ++bx)
+    run_block(nth, [&](int tid, int n) {
+      fwd_plane_body<double>(mesh.data() + (size_t)bx * ny * nz, spec.data() + (size_t)bx * ncol, (Cx<double>*)lds.data(), g, tb, tid, n);
+    });
+  const int blocks = (int)((ncol + MI_SOLVE_COLS - 1) / MI_SOLVE_COLS);
+  for (int b = 0; b < B; ++b)
+    for (int blk = 0; blk < blocks; ++blk)
+      run_block(nth, [&](int tid, int n) {
+        fwd_cols_body<double>(spec.data() + (size_t)b * nx * ncol, (Cx<double>*)lds.data(), g, tb, recip + 9 * b, alpha[b], volume[b], 4, blk * MI_SOLVE_COLS, tid, n);
+      });
+  for (int b = 0; b < B; ++b)
+    for (int ch = 0; ch < nch; ++ch)
+      for (int blk = 0; blk < blocks; ++blk)
+        run_block(nth, [&](int tid, int n) {
+          inv_cols_body<double>(spec.data() + (size_t)b * nx * ncol, conv.data() + ((size_t)b * nch + ch) * nx * ncol, (Cx<double>*)lds.data(), g, tb, recip + 9 * b, ch,
+                                blk * MI_SOLVE_COLS, tid, n);
+        });
+  for (int p = 0; p < B * nch * nx; ++p)
+    run_block(nth, [&](int tid, int n) { inv_plane_body<double>(conv.data() + (size_t)p * ncol, out.data() + (size_t)p * ny * nz, (Cx<double>*)lds.data(), g, tb, tid, n); });
+  return out;
+}
+
+int main(int argc, char** argv) {
+  g_drop_barriers = argc > 1 && strcmp(argv[1], "drop") == 0;
+  const int shapes[][3] = {{16, 8, 32}, {128, 8, 8}, {8, 32, 16}};
+  int bad = 0;
+  for (const auto& s : shapes) {
+    const int B = 2, nch = 4, nx = s[0], ny = s[1], nz = s[2];
+    std::vector<double> mesh((size_t)B * nx * ny * nz);
+    unsigned long long z = 88172645463325252ull + nx * 131 + ny * 17 + nz;
+    for (auto& v : mesh) { z ^= z << 13; z ^= z >> 7; z ^= z << 17; v = (double)(z % 20001) / 10000.0 - 1.0; }
+    const std::vector<double> ref = solve(B, nx, ny, nz, nch, 1, mesh);
+    for (int nth : {3, 16}) {
+      if (g_drop_barriers && nth != 3) continue;
+      const std::vector<double> got = solve(B, nx, ny, nz, nch, nth, mesh);
+      const bool same = memcmp(ref.data(), got.data(), ref.size() * sizeof(double)) == 0;
+      printf("mesh %dx%dx%d threads %d: %s\n", nx, ny, nz, nth, same ? "bit-identical" : "DIFFERENT");
+      bad += !same;
+    }
+  }
+  return bad ? 1 : 0;
+}

@@ -101,3 +101,20 @@ def test_whole_kspace_step_equals_the_numpy_restatement(H, dims, order, nch):
     want = np.stack(want[:nch], 1)
     scale = np.abs(want).max()
     assert np.allclose(out, want, rtol=0, atol=1e-11 * scale), np.abs(out - want).max() / scale
+
+
+def test_barrier_placement_under_thread_sanitizer(tmp_path):
+    """tests/native/fft_race_check.cpp: the same bodies with 3 and 16 host threads per block, MI_FFT_SYNC() = a pthread barrier, under
+    ThreadSanitizer.  Any two threads touching one LDS / global element between two barriers would be a missing __syncthreads on the GPU:
+    none reported, and every thread count gives the single-thread result bit for bit.  Negative control: with the barriers dropped the
+    detector does report races (so a clean run means something)."""
+    exe = str(tmp_path / "fft_race_check")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=thread", "-pthread", "-I" + os.path.join(ROOT, "nvalchemi-toolkit-ops_amd", "csrc"),
+                           os.path.join(ROOT, "tests", "native", "fft_race_check.cpp"), "-o", exe])
+    run = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    assert run.returncode == 0, run.stdout[-2000:] + run.stderr[-2000:]
+    assert "ThreadSanitizer" not in run.stderr, run.stderr[-3000:]
+    lines = [l for l in run.stdout.splitlines() if l.startswith("mesh")]
+    assert len(lines) == 6 and all(l.endswith("bit-identical") for l in lines), run.stdout
+    control = subprocess.run([exe, "drop"], capture_output=True, text=True, timeout=600)
+    assert "ThreadSanitizer: data race" in control.stderr
