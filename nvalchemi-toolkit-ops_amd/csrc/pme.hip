@@ -3,8 +3,9 @@
 // B-spline charge spreading / gathering (reference: spline.py:127-488 functions, :497-676 and :763-959 kernels),
 // Green function + sinc structure factor (interactions/electrostatics/pme_kernels.py:93-331), self/background
 // corrections (:340-657) and the elementwise spectrum algebra of _pme_reciprocal_space_impl (pme.py:1418-1419,
-// 1455-1477).  The FFTs themselves stay with rocFFT/hipFFT through torch.fft, exactly as the reference leans on
-// torch.fft (pme.py:1398,1422,1459-1461).
+// 1455-1477), and -- since round 4 -- the FFTs themselves for power-of-two meshes: the fused mesh solve at the end of this file
+// (mi_pme_solve: plane / column transforms in LDS, bodies in fft_lds.h) replaces rfftn -> spectrum algebra -> irfftn (pme.py:1398-1461);
+// other meshes go through the hipFFT plans of fft.cpp (the reference leans on torch.fft for all of it).
 //
 // MI355X-first choices:
 //   * spread: MESH-TILE OWNERSHIP, no global atomics on the mesh.  Atoms are binned by the 8^3 mesh tile their stencil starts in
