@@ -775,7 +775,7 @@ def test_fused_mesh_solve(dims, order, monkeypatch):
         out = {}
         # the A/B against the hipFFT-plan path runs for the headline mesh (whose plans the other tests use anyway) and, for the small meshes,
         # only on request: every forced-hipFFT call creates library-owned plans for one more shape, and with some dozens of live plans in
-        # one process rocFFT results for EARLIER shapes drift -- the small meshes are pinned by the oracle below instead
+        # one process a hipFFT plan can come back computing the wrong transform (tools/probe/rocfft_drift_repro.py) -- the small meshes are pinned by the oracle below instead
         both = max(dims) >= 128 or os.environ.get("NVALCHEMIOPS_TEST_FFT_AB", "0") == "1"
         for solve in ((True, False) if both else (True,)):
             monkeypatch.setattr(P, "_MESH_SOLVE", solve)
