@@ -403,6 +403,14 @@ size_t mi_pme_solve_scratch_bytes(int n_systems, int nx, int ny, int nz, int n_c
 int mi_pme_solve(const void* mesh, const void* recip_cell /*[n_systems,3,3]*/, const void* alpha /*[n_systems]*/,
                  const void* volume /*[n_systems]*/, int n_systems, int nx, int ny, int nz, int order /* as mi_pme_convolve */,
                  int with_field, int dtype, void* scratch, size_t scratch_bytes, void* real_out, void* stream);
+/* The same, and additionally the charge spectrum itself: spectrum_out (NULL ok) [n_systems][nx][ny][nz/2+1] complex, UNSCALED forward
+ * transform of `mesh` in natural frequency order -- what mi_fft_plan_exec (R2C) / torch.fft.rfftn leave -- written by the forward column
+ * kernel as a by-product (one 16-byte store per bin).  For callers that need it later (the backward of the autograd node).  Prepared at the
+ * end of round 4: index arithmetic checked on the host (tests/test_fft_lds_cpu.py), not yet run or timed on a GPU; the Python host code
+ * uses it only under NVALCHEMIOPS_PME_SOLVE_AUTOGRAD=1.                                                                                  */
+int mi_pme_solve_keep(const void* mesh, const void* recip_cell, const void* alpha, const void* volume, int n_systems, int nx, int ny, int nz,
+                      int order, int with_field, int dtype, void* scratch, size_t scratch_bytes, void* real_out, void* spectrum_out,
+                      void* stream);
 /* Adjoint of the k-space pass (the backward of the fused forward under autograd, pme.py `_FusedPME` / `_FusedReciprocal`).  `spec`: unscaled
  * spectrum of the charge mesh [n_systems][nx][ny][nz/2+1]; `weight_spec`: spectra of the spread upstream weights, channel-major
  * [n_channels][n_systems][...] -- channel 0 for a loss on the energies (weights g_E q), channels 1..3 (n_channels = 4) for a loss on the explicit

@@ -473,7 +473,7 @@ template <class T> MI_HD void inv_plane_body(const Cx<T>* in, T* out, Cx<T>* lds
 #define MI_SOLVE_LGCOLS 4
 // LDS of B1: tile + unit roots + KX[3][nx] + sinc_x[nx] + per column KC[3][8], sinc_y sinc_z [8], origin flag [8]
 template <class T> MI_HD size_t fwd_cols_lds_bytes(const Geom& g) {
-  return ((size_t)g.nx * MI_SOLVE_COLS + g.nx) * sizeof(Cx<T>) + ((size_t)4 * g.nx + 5 * MI_SOLVE_COLS) * sizeof(T);
+  return ((size_t)g.nx * MI_SOLVE_COLS + g.nx) * sizeof(Cx<T>) + ((size_t)4 * g.nx + 5 * MI_SOLVE_COLS) * sizeof(T) + ((size_t)g.nx + MI_SOLVE_COLS) * sizeof(int);
 }
 // LDS of B2: tile + unit roots + KX[nx] + KC[8] of the block's channel
 template <class T> MI_HD size_t inv_cols_lds_bytes(const Geom& g) {
@@ -482,9 +482,11 @@ template <class T> MI_HD size_t inv_cols_lds_bytes(const Geom& g) {
 // spec: [nx][ny*P] complex of system b (slot order in y, z), transformed in place into conv = (FFT_x spec / sf2) * G in slot order along x
 // (pme.py:1418-1419, pme_kernels.py:194-225); recip: 2 pi cell^-1 of the system (row-major 3x3, k_d = sum_e m_e recip[d][e],
 // k_vectors.py:270-282); sf_expo: exponent of the B-spline modulus (decode_order().sf_exponent)
+// spec_nat (NULL or [nx][ny][P] of system b): the UNFACTORED spectrum in natural frequency order -- numpy.fft.rfftn(mesh) -- for a caller that
+// needs the charge spectrum itself (the backward of the autograd node); 16-byte scattered stores, one per element
 template <class T>
 MI_HD void fwd_cols_body(Cx<T>* spec, Cx<T>* lds, const Geom& g, const Tables<T>& tb, const T* recip, T alpha, T volume, int sf_expo, int col0, int tid,
-                         int nth) {
+                         int nth, Cx<T>* spec_nat = nullptr) {
   const int COLS = MI_SOLVE_COLS, LGC = MI_SOLVE_LGCOLS;
   const int ncol = g.ny * g.P, nx = g.nx;
   Cx<T>* S = lds;
@@ -494,7 +496,10 @@ MI_HD void fwd_cols_body(Cx<T>* spec, Cx<T>* lds, const Geom& g, const Tables<T>
   T* KC = SX + nx;        // [3][COLS]
   T* SC = KC + 3 * COLS;  // [COLS] sinc_y * sinc_z
   T* OC = SC + COLS;      // [COLS] 1 where m_y = m_z = 0
+  int* NATC = (int*)(OC + COLS);  // [COLS] natural-order offset f_y * P + f_z of the column
+  int* NATX = NATC + COLS;        // [nx]   natural-order index f_x of the slot
   for (int t = tid; t < nx; t += nth) {
+    NATX[t] = slot_freq(g.px, t);
     Wx[t] = tb.Wx[t];
     SX[t] = tb.sx[t];
     const T m = tb.mx[t];
@@ -507,6 +512,7 @@ MI_HD void fwd_cols_body(Cx<T>* spec, Cx<T>* lds, const Geom& g, const Tables<T>
     for (int d = 0; d < 3; ++d) KC[d * COLS + c] = my * recip[3 * d + 1] + mz * recip[3 * d + 2];
     SC[c] = tb.sy[ys] * tb.sz[zs];
     OC[c] = (my == T(0) && mz == T(0)) ? T(1) : T(0);
+    NATC[c] = slot_freq(g.py, ys) * g.P + (zs < g.M ? slot_freq(g.pz, zs) : g.M);
   }
   MI_FFT_SYNC();
   const T inv4a2 = T(1) / (T(4) * alpha * alpha);
@@ -543,6 +549,7 @@ MI_HD void fwd_cols_body(Cx<T>* spec, Cx<T>* lds, const Geom& g, const Tables<T>
       const T f = factor_of(xs, c);
       const Cx<T> v = S[e];
       spec[(size_t)xs * ncol + col0 + c] = Cx<T>{v.re * f, v.im * f};
+      if (spec_nat) spec_nat[(size_t)NATX[xs] * ncol + NATC[c]] = v;
     }
   }
 }

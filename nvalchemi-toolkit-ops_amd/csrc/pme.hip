@@ -1013,12 +1013,13 @@ __global__ __launch_bounds__(1024) void pme_solve_fwd_kernel(const T* __restrict
 }
 template <class T>
 __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2))) void pme_solve_fwd_cols_kernel(mifft::Cx<T>* __restrict__ spec, mifft::Geom g, mifft::Tables<T> tb, const T* __restrict__ recip,
-                                                                const T* __restrict__ alpha, const T* __restrict__ volume, int sf_expo) {
+                                                                const T* __restrict__ alpha, const T* __restrict__ volume, int sf_expo,
+                                                                mifft::Cx<T>* __restrict__ spec_nat /*NULL or [B][nx][ny][P]*/) {
   extern __shared__ __align__(16) unsigned char solve_smem[];
   const int b = blockIdx.y;
   const size_t per = (size_t)g.nx * g.ny * g.P;
   mifft::fwd_cols_body<T>(spec + b * per, (mifft::Cx<T>*)solve_smem, g, tb, recip + 9 * b, alpha[b], volume[b], sf_expo, blockIdx.x * MI_SOLVE_COLS,
-                          threadIdx.x, blockDim.x);
+                          threadIdx.x, blockDim.x, spec_nat ? spec_nat + b * per : nullptr);
 }
 // grid.x = 8-padded column tiles x channels.  The channels of one tile read the same conv lines: consecutive block ids go round the 8 XCDs,
 // so the id is unpacked as (xcd, channel, tile group) -- the n_channels blocks of a tile follow each other on ONE XCD and share its L2.
@@ -1063,7 +1064,7 @@ static int solve_plane_threads(const mifft::Geom& g) {
 }
 template <class T>
 static int solve_launch(const void* mesh, const void* recip_cell, const void* alpha, const void* volume, const mifft::Geom& g, int expo, int nch,
-                        void* spec, void* conv, void* tab, void* real_out, int pt, int col_blocks, void* stream) {
+                        void* spec, void* conv, void* tab, void* real_out, void* spec_nat, int pt, int col_blocks, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   const size_t pl = mifft::plane_lds_bytes<T>(g), fl = mifft::fwd_cols_lds_bytes<T>(g), il = mifft::inv_cols_lds_bytes<T>(g);
   static bool raised = false;  // more than 64 KB of dynamic LDS has to be asked for once per kernel
@@ -1082,7 +1083,8 @@ static int solve_launch(const void* mesh, const void* recip_cell, const void* al
   pme_solve_fwd_kernel<T><<<g.B * g.nx, pt, pl, st>>>((const T*)mesh, (mifft::Cx<T>*)spec, g, tb);
   mi_timing_end(stream);
   mi_timing_begin("pme_solve_cols", stream);
-  pme_solve_fwd_cols_kernel<T><<<dim3(col_blocks, g.B), 128, fl, st>>>((mifft::Cx<T>*)spec, g, tb, (const T*)recip_cell, (const T*)alpha, (const T*)volume, expo);
+  pme_solve_fwd_cols_kernel<T><<<dim3(col_blocks, g.B), 128, fl, st>>>((mifft::Cx<T>*)spec, g, tb, (const T*)recip_cell, (const T*)alpha, (const T*)volume, expo,
+                                                                      (mifft::Cx<T>*)spec_nat);
   pme_solve_inv_cols_kernel<T><<<dim3((col_blocks + 7) / 8 * 8 * nch, g.B), 128, il, st>>>((const mifft::Cx<T>*)spec, (mifft::Cx<T>*)conv, g, tb,
                                                                                           (const T*)recip_cell, nch, col_blocks);
   mi_timing_end(stream);
@@ -1388,6 +1390,10 @@ size_t mi_pme_solve_scratch_bytes(int n_systems, int nx, int ny, int nz, int n_c
 }
 int mi_pme_solve(const void* mesh, const void* recip_cell, const void* alpha, const void* volume, int n_systems, int nx, int ny, int nz, int order,
                  int with_field, int dtype, void* scratch, size_t scratch_bytes, void* real_out, void* stream) {
+  return mi_pme_solve_keep(mesh, recip_cell, alpha, volume, n_systems, nx, ny, nz, order, with_field, dtype, scratch, scratch_bytes, real_out, nullptr, stream);
+}
+int mi_pme_solve_keep(const void* mesh, const void* recip_cell, const void* alpha, const void* volume, int n_systems, int nx, int ny, int nz, int order,
+                      int with_field, int dtype, void* scratch, size_t scratch_bytes, void* real_out, void* spectrum_out, void* stream) {
   MI_REQUIRE(dtype == MI_F32 || dtype == MI_F64, "dtype");
   MI_REQUIRE(mesh && recip_cell && alpha && volume && scratch && real_out, "null pointer");
   MI_REQUIRE(mi_pme_solve_supported(n_systems, nx, ny, nz, dtype), "mesh not supported by the fused solve (see mi_pme_solve_supported)");
@@ -1402,7 +1408,7 @@ int mi_pme_solve(const void* mesh, const void* recip_cell, const void* alpha, co
   const int pt = solve_plane_threads(g);
   const int col_blocks = (g.ny * g.P + MI_SOLVE_COLS - 1) / MI_SOLVE_COLS;
   int rc = MI_OK;
-  MI_DISPATCH_T(dtype, (rc = solve_launch<T_>(mesh, recip_cell, alpha, volume, g, expo, nch, spec, conv, tab, real_out, pt, col_blocks, stream)));
+  MI_DISPATCH_T(dtype, (rc = solve_launch<T_>(mesh, recip_cell, alpha, volume, g, expo, nch, spec, conv, tab, real_out, spectrum_out, pt, col_blocks, stream)));
   if (rc != MI_OK) return rc;
   MI_LAUNCH_CHECK();
   return MI_OK;

@@ -184,6 +184,10 @@ _FUSED_AUTOGRAD = os.environ.get("NVALCHEMIOPS_PME_FUSED_AUTOGRAD", "1") != "0"
 # "auto": the library's measured policy (mi_pme_solve_preferred); True / NVALCHEMIOPS_PME_MESH_SOLVE=1: the fused mesh solve wherever it is
 # supported; False / =0: always hipFFT plans + mi_pme_convolve (A/B runs, and the parity tests that drive the solve's batch kernels)
 _MESH_SOLVE = {"0": False, "1": True}.get(os.environ.get("NVALCHEMIOPS_PME_MESH_SOLVE", "auto"), "auto")
+# NVALCHEMIOPS_PME_SOLVE_AUTOGRAD=1: the autograd node's forward takes the fused mesh solve too, with the charge spectrum its backward needs
+# written as a by-product (`mi_pme_solve_keep`).  Off by default: prepared at the end of round 4 (host-checked index arithmetic), not yet run
+# on a GPU -- tests/test_autograd_gpu.py has the parity test that switches it on (NVALCHEMIOPS_TEST_EXPERIMENTAL=1).
+_SOLVE_AUTOGRAD = os.environ.get("NVALCHEMIOPS_PME_SOLVE_AUTOGRAD", "0") == "1"
 
 
 def _fft_plan(device: torch.device, dims, batch: int, code: int, inverse: bool) -> _FftPlan:
@@ -250,17 +254,19 @@ def _reciprocal_front(pos, q, cells, alpha, dims, spline_order, bi, nsys, batche
     mesh, tile_order = _launch_spread(pos, q, cit, bi, nsys, (nx, ny, nz), int(spline_order), batched, want_order=True)
     nch = 4 if compute_forces else 1
     cdt = torch.complex64 if dt == torch.float32 else torch.complex128
-    if (_MESH_SOLVE and not need_spec and k_squared is None and k_vectors is None
+    if (_MESH_SOLVE and (not need_spec or _SOLVE_AUTOGRAD) and k_squared is None and k_vectors is None
             and (C.lib().mi_pme_solve_supported if _MESH_SOLVE is True else C.lib().mi_pme_solve_preferred)(nsys, nx, ny, nz, code)):
         import ctypes
 
         nbytes = int(C.lib().mi_pme_solve_scratch_bytes(nsys, nx, ny, nz, nch, code))
         scratch = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         real = torch.empty((nsys, nch, nx, ny, nz), dtype=dt, device=dev)
-        rc = C.lib().mi_pme_solve(C.ptr(mesh), C.ptr(recip), C.ptr(al), C.ptr(vol), nsys, nx, ny, nz, C.spline_order_arg(spline_order),
-                                  int(compute_forces), code, C.ptr(scratch), ctypes.c_size_t(nbytes), C.ptr(real), st)
-        C.check(rc, "mi_pme_solve")
-        return None, real, cit, recip, vol, qtot, al, tile_order
+        # need_spec (the autograd node): the forward column kernel leaves the natural-order charge spectrum as a by-product
+        spec = torch.empty((nsys, nx, ny, nz // 2 + 1), dtype=cdt, device=dev) if need_spec else None
+        rc = C.lib().mi_pme_solve_keep(C.ptr(mesh), C.ptr(recip), C.ptr(al), C.ptr(vol), nsys, nx, ny, nz, C.spline_order_arg(spline_order),
+                                       int(compute_forces), code, C.ptr(scratch), ctypes.c_size_t(nbytes), C.ptr(real), C.ptr(spec), st)
+        C.check(rc, "mi_pme_solve_keep")
+        return spec, real, cit, recip, vol, qtot, al, tile_order
     if _OWN_FFT:
         # the library's own hipFFT plans (mi_fft_plan_*): the spectra and the real meshes are buffers of this call, so the C2R transform may
         # consume its input in place -- torch.fft.irfftn has to clone it first and copies its result once more (2 x 68 MB per headline step)

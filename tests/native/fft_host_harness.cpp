@@ -51,7 +51,7 @@ int h_forward(const double* mesh, double* spec, int B, int nx, int ny, int nz) {
 
 // kernels A, B1, B2, C: mesh [B][nx][ny][nz] -> real meshes [B][C][nx][ny][nz]  (unnormalised both ways, like hipFFT / the reference's norm='forward' inverse)
 int h_solve(const double* mesh, double* out, int B, int nx, int ny, int nz, const double* recip /*[B][9]*/, const double* alpha, const double* volume,
-            int sf_expo, int n_channels) {
+            int sf_expo, int n_channels, double* spec_nat /*NULL or [B][nx][ny][P][2]: numpy.fft.rfftn(mesh)*/) {
   if (!geom_ok(nx, ny, nz)) return -1;
   const Geom g = make_geom(B, nx, ny, nz);
   std::vector<char> tab(tables_bytes<double>(g));
@@ -69,7 +69,7 @@ int h_solve(const double* mesh, double* out, int B, int nx, int ny, int nz, cons
   for (int b = 0; b < B; ++b)
     for (int blk = 0; blk < blocks; ++blk)
       fwd_cols_body<double>(spec.data() + (size_t)b * nx * ncol, (Cx<double>*)lds.data(), g, tb, recip + 9 * b, alpha[b], volume[b], sf_expo,
-                            blk * MI_SOLVE_COLS, 0, 1);
+                            blk * MI_SOLVE_COLS, 0, 1, spec_nat ? (Cx<double>*)spec_nat + (size_t)b * nx * ncol : nullptr);
   for (int b = 0; b < B; ++b)
     for (int ch = 0; ch < n_channels; ++ch)
       for (int blk = 0; blk < blocks; ++blk)

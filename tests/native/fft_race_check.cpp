@@ -42,6 +42,7 @@ static std::vector<double> solve(int B, int nx, int ny, int nz, int nch, int nth
   if (fwd_cols_lds_bytes<double>(g) > need) need = fwd_cols_lds_bytes<double>(g);
   std::vector<char> lds(need);
   std::vector<double> out((size_t)B * nch * nx * ny * nz);
+  std::vector<Cx<double>> nat((size_t)B * nx * ncol);  // the natural-order by-product is written too (scattered stores: one owner per element)
   double recip[18] = {0.61, 0.02, -0.03, 0.05, 0.57, 0.01, -0.02, 0.04, 0.52, 0.66, 0.0, 0.0, 0.0, 0.6, 0.0, 0.0, 0.0, 0.55};
   const double alpha[2] = {0.35, 0.42}, volume[2] = {1100.0, 900.0};
   for (int bx = 0; bx < B * nx; ++bx)
@@ -52,7 +53,8 @@ static std::vector<double> solve(int B, int nx, int ny, int nz, int nch, int nth
   for (int b = 0; b < B; ++b)
     for (int blk = 0; blk < blocks; ++blk)
       run_block(nth, [&](int tid, int n) {
-        fwd_cols_body<double>(spec.data() + (size_t)b * nx * ncol, (Cx<double>*)lds.data(), g, tb, recip + 9 * b, alpha[b], volume[b], 4, blk * MI_SOLVE_COLS, tid, n);
+        fwd_cols_body<double>(spec.data() + (size_t)b * nx * ncol, (Cx<double>*)lds.data(), g, tb, recip + 9 * b, alpha[b], volume[b], 4, blk * MI_SOLVE_COLS, tid, n,
+                              nat.data() + (size_t)b * nx * ncol);
       });
   for (int b = 0; b < B; ++b)
     for (int ch = 0; ch < nch; ++ch)

@@ -2,6 +2,8 @@
 real-space sum, torch autograd for the FFT/elementwise middle.  Checks the reference's own properties
 (test/interactions/electrostatics/test_pme.py:1458 explicit forces == -autograd, :1510-1578 finite differences) plus adjoint
 identities of the spline ops (test/test_spline.py:637)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -747,3 +749,37 @@ def test_fused_nodes_with_explicit_forces_equal_the_composition(which, batched, 
         got, want = grads(True, energy_term), grads(False, energy_term)
         for a, b, what in zip(got, want, ("energies", "forces", "d/dpositions", "d/dcharges", "d/dcell", "d/dalpha")):
             assert a.shape == b.shape and (a - b).abs().max().item() <= 1e-9 * max(1.0, b.abs().max().item()), (which, batched, energy_term, what, (a - b).abs().max().item())
+
+
+@pytest.mark.skipif(os.environ.get("NVALCHEMIOPS_TEST_EXPERIMENTAL", "0") != "1",
+                    reason="prepared at the end of round 4, not yet run on a GPU: NVALCHEMIOPS_TEST_EXPERIMENTAL=1 switches it on")
+@pytest.mark.parametrize("with_forces", [False, True])
+def test_fused_node_through_the_mesh_solve(with_forces, monkeypatch):
+    """`_SOLVE_AUTOGRAD`: the autograd node's forward through the fused mesh solve, its backward fed by the natural-order charge spectrum the
+    forward column kernel leaves behind (`mi_pme_solve_keep`) instead of a hipFFT R2C -- same energies, forces and gradients as the node on
+    hipFFT plans, power-of-two mesh, fp64 1e-9 / fp32 2e-4."""
+    from nvalchemiops.interactions.electrostatics import pme as P
+    from nvalchemiops.interactions.electrostatics import pme_reciprocal_space
+
+    pos, cell, q = _system(70, seed=5)
+    dims = (16, 32, 16)
+    gen = torch.Generator(device=DEV).manual_seed(2)
+    wts = torch.randn(pos.shape[0], dtype=torch.float64, device=DEV, generator=gen)
+    wf = torch.randn(pos.shape[0], 3, dtype=torch.float64, device=DEV, generator=gen)
+
+    def grads(through_solve, dtype):
+        monkeypatch.setattr(P, "_SOLVE_AUTOGRAD", through_solve)
+        monkeypatch.setattr(P, "_MESH_SOLVE", True)
+        p = pos.to(dtype).requires_grad_(True)
+        v = q.to(dtype).requires_grad_(True)
+        c = cell.to(dtype).requires_grad_(True)
+        a = torch.tensor([0.4], dtype=dtype, device=DEV, requires_grad=True)
+        out = pme_reciprocal_space(p, v, c, a, mesh_dimensions=dims, spline_order=4, compute_forces=with_forces)
+        e, f = out if with_forces else (out, None)
+        loss = (e * wts.to(dtype)).sum() + ((f * wf.to(dtype)).sum() if with_forces else 0.0)
+        return (e.detach(),) + ((f.detach(),) if with_forces else ()) + torch.autograd.grad(loss, (p, v, c, a))
+
+    for dtype, tol in ((torch.float64, 1e-9), (torch.float32, 2e-4)):
+        got, want = grads(True, dtype), grads(False, dtype)
+        for a, b in zip(got, want):
+            assert a.shape == b.shape and (a - b).abs().max().item() <= tol * max(1.0, b.abs().max().item())

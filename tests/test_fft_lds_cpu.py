@@ -89,8 +89,11 @@ def test_whole_kspace_step_equals_the_numpy_restatement(H, dims, order, nch):
     vol = np.ascontiguousarray(np.abs(np.linalg.det(cells)))
     out = np.zeros((B, nch, nx, ny, nz))
     expo = min(order, 4)   # the reference's structure-factor exponent
-    assert H.h_solve(_p(mesh), _p(out), B, nx, ny, nz, _p(recip), _p(alpha), _p(vol), expo, nch) == 0
+    nat = np.zeros((B, nx, ny, nz // 2 + 1, 2))
+    assert H.h_solve(_p(mesh), _p(out), B, nx, ny, nz, _p(recip), _p(alpha), _p(vol), expo, nch, _p(nat)) == 0
     axes = (-3, -2, -1)
+    # the by-product for callers that need the charge spectrum: unfactored, natural frequency order = numpy.fft.rfftn
+    assert np.allclose(nat[..., 0] + 1j * nat[..., 1], np.fft.rfftn(mesh, axes=axes), rtol=0, atol=1e-11 * nx * ny * nz)
     kvec, k2 = O.generate_k_vectors_pme(cells, dims)
     g, sf2 = O.pme_green_structure_factor(k2, dims, alpha, cells, order)   # default oracle mode: exponent min(order, 4)
     conv = (np.fft.rfftn(mesh, axes=axes) / sf2) * g
