@@ -37,39 +37,39 @@ static std::vector<double> solve(int B, int nx, int ny, int nz, int nch, int nth
   const Tables<double> tb = tables_at<double>(tab.data(), g);
   const size_t ncol = (size_t)ny * g.P;
   std::vector<Cx<double>> spec((size_t)B * nx * ncol), conv((size_t)B * nch * nx * ncol);
-  size_t need = plane_lds_bytes<double>(g);
-  if (inv_cols_lds_bytes<double>(g) > need) need = inv_cols_lds_bytes<double>(g);
-  if (fwd_cols_lds_bytes<double>(g) > need) need = fwd_cols_lds_bytes<double>(g);
-  std::vector<char> lds(need);
+  // one buffer per kernel, EXACTLY the size its launch requests: the AddressSanitizer build of this file (argv[1] = "asan" skips the threads)
+  // then sees any body that walks past its LDS
+  std::vector<char> lds_plane(plane_lds_bytes<double>(g)), lds_fwd_cols(fwd_cols_lds_bytes<double>(g)), lds_inv_cols(inv_cols_lds_bytes<double>(g));
   std::vector<double> out((size_t)B * nch * nx * ny * nz);
   std::vector<Cx<double>> nat((size_t)B * nx * ncol);  // the natural-order by-product is written too (scattered stores: one owner per element)
   double recip[18] = {0.61, 0.02, -0.03, 0.05, 0.57, 0.01, -0.02, 0.04, 0.52, 0.66, 0.0, 0.0, 0.0, 0.6, 0.0, 0.0, 0.0, 0.55};
   const double alpha[2] = {0.35, 0.42}, volume[2] = {1100.0, 900.0};
   for (int bx = 0; bx < B * nx; ++bx)
     run_block(nth, [&](int tid, int n) {
-      fwd_plane_body<double>(mesh.data() + (size_t)bx * ny * nz, spec.data() + (size_t)bx * ncol, (Cx<double>*)lds.data(), g, tb, tid, n);
+      fwd_plane_body<double>(mesh.data() + (size_t)bx * ny * nz, spec.data() + (size_t)bx * ncol, (Cx<double>*)lds_plane.data(), g, tb, tid, n);
     });
   const int blocks = (int)((ncol + MI_SOLVE_COLS - 1) / MI_SOLVE_COLS);
   for (int b = 0; b < B; ++b)
     for (int blk = 0; blk < blocks; ++blk)
       run_block(nth, [&](int tid, int n) {
-        fwd_cols_body<double>(spec.data() + (size_t)b * nx * ncol, (Cx<double>*)lds.data(), g, tb, recip + 9 * b, alpha[b], volume[b], 4, blk * MI_SOLVE_COLS, tid, n,
+        fwd_cols_body<double>(spec.data() + (size_t)b * nx * ncol, (Cx<double>*)lds_fwd_cols.data(), g, tb, recip + 9 * b, alpha[b], volume[b], 4, blk * MI_SOLVE_COLS, tid, n,
                               nat.data() + (size_t)b * nx * ncol);
       });
   for (int b = 0; b < B; ++b)
     for (int ch = 0; ch < nch; ++ch)
       for (int blk = 0; blk < blocks; ++blk)
         run_block(nth, [&](int tid, int n) {
-          inv_cols_body<double>(spec.data() + (size_t)b * nx * ncol, conv.data() + ((size_t)b * nch + ch) * nx * ncol, (Cx<double>*)lds.data(), g, tb, recip + 9 * b, ch,
+          inv_cols_body<double>(spec.data() + (size_t)b * nx * ncol, conv.data() + ((size_t)b * nch + ch) * nx * ncol, (Cx<double>*)lds_inv_cols.data(), g, tb, recip + 9 * b, ch,
                                 blk * MI_SOLVE_COLS, tid, n);
         });
   for (int p = 0; p < B * nch * nx; ++p)
-    run_block(nth, [&](int tid, int n) { inv_plane_body<double>(conv.data() + (size_t)p * ncol, out.data() + (size_t)p * ny * nz, (Cx<double>*)lds.data(), g, tb, tid, n); });
+    run_block(nth, [&](int tid, int n) { inv_plane_body<double>(conv.data() + (size_t)p * ncol, out.data() + (size_t)p * ny * nz, (Cx<double>*)lds_plane.data(), g, tb, tid, n); });
   return out;
 }
 
 int main(int argc, char** argv) {
   g_drop_barriers = argc > 1 && strcmp(argv[1], "drop") == 0;
+  const bool asan = argc > 1 && strcmp(argv[1], "asan") == 0;  // bounds run: single-threaded, every buffer exactly sized
   const int shapes[][3] = {{16, 8, 32}, {128, 8, 8}, {8, 32, 16}};
   int bad = 0;
   for (const auto& s : shapes) {
@@ -78,6 +78,7 @@ int main(int argc, char** argv) {
     unsigned long long z = 88172645463325252ull + nx * 131 + ny * 17 + nz;
     for (auto& v : mesh) { z ^= z << 13; z ^= z >> 7; z ^= z << 17; v = (double)(z % 20001) / 10000.0 - 1.0; }
     const std::vector<double> ref = solve(B, nx, ny, nz, nch, 1, mesh);
+    if (asan) { printf("mesh %dx%dx%d single thread: in bounds\n", nx, ny, nz); continue; }
     for (int nth : {3, 16}) {
       if (g_drop_barriers && nth != 3) continue;
       const std::vector<double> got = solve(B, nx, ny, nz, nch, nth, mesh);

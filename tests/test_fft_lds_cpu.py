@@ -121,3 +121,14 @@ def test_barrier_placement_under_thread_sanitizer(tmp_path):
     assert len(lines) == 6 and all(l.endswith("bit-identical") for l in lines), run.stdout
     control = subprocess.run([exe, "drop"], capture_output=True, text=True, timeout=600)
     assert "ThreadSanitizer: data race" in control.stderr
+
+
+def test_kernel_bodies_stay_inside_their_buffers(tmp_path):
+    """The same program under AddressSanitizer, single-threaded, with every buffer -- the LDS of each kernel as `*_lds_bytes` sizes it for the
+    launch, the spectra, the tables, the outputs -- allocated at exactly its size: no body reads or writes past an end."""
+    exe = str(tmp_path / "fft_asan_check")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address", "-pthread", "-I" + os.path.join(ROOT, "nvalchemi-toolkit-ops_amd", "csrc"),
+                           os.path.join(ROOT, "tests", "native", "fft_race_check.cpp"), "-o", exe])
+    run = subprocess.run([exe, "asan"], capture_output=True, text=True, timeout=600)
+    assert run.returncode == 0 and "AddressSanitizer" not in run.stderr, run.stderr[-3000:]
+    assert sum(l.endswith("in bounds") for l in run.stdout.splitlines()) == 3, run.stdout
