@@ -30,41 +30,60 @@ template <class F> static void run_block(int nth, F body) {
   pthread_barrier_destroy(&bar);
 }
 
-static std::vector<double> solve(int B, int nx, int ny, int nz, int nch, int nth, const std::vector<double>& mesh) {
+template <class R> static std::vector<R> solve(int B, int nx, int ny, int nz, int nch, int nth, const std::vector<R>& mesh) {
   const Geom g = make_geom(B, nx, ny, nz);
-  std::vector<char> tab(tables_bytes<double>(g));
-  run_block(nth, [&](int tid, int n) { tables_body<double>(tab.data(), g, tid, n); });
-  const Tables<double> tb = tables_at<double>(tab.data(), g);
+  std::vector<char> tab(tables_bytes<R>(g));
+  run_block(nth, [&](int tid, int n) { tables_body<R>(tab.data(), g, tid, n); });
+  const Tables<R> tb = tables_at<R>(tab.data(), g);
   const size_t ncol = (size_t)ny * g.P;
-  std::vector<Cx<double>> spec((size_t)B * nx * ncol), conv((size_t)B * nch * nx * ncol);
+  std::vector<Cx<R>> spec((size_t)B * nx * ncol), conv((size_t)B * nch * nx * ncol);
   // one buffer per kernel, EXACTLY the size its launch requests: the AddressSanitizer build of this file (argv[1] = "asan" skips the threads)
   // then sees any body that walks past its LDS
-  std::vector<char> lds_plane(plane_lds_bytes<double>(g)), lds_fwd_cols(fwd_cols_lds_bytes<double>(g)), lds_inv_cols(inv_cols_lds_bytes<double>(g));
-  std::vector<double> out((size_t)B * nch * nx * ny * nz);
-  std::vector<Cx<double>> nat((size_t)B * nx * ncol);  // the natural-order by-product is written too (scattered stores: one owner per element)
-  double recip[18] = {0.61, 0.02, -0.03, 0.05, 0.57, 0.01, -0.02, 0.04, 0.52, 0.66, 0.0, 0.0, 0.0, 0.6, 0.0, 0.0, 0.0, 0.55};
-  const double alpha[2] = {0.35, 0.42}, volume[2] = {1100.0, 900.0};
+  std::vector<char> lds_plane(plane_lds_bytes<R>(g)), lds_fwd_cols(fwd_cols_lds_bytes<R>(g)), lds_inv_cols(inv_cols_lds_bytes<R>(g));
+  std::vector<R> out((size_t)B * nch * nx * ny * nz);
+  std::vector<Cx<R>> nat((size_t)B * nx * ncol);  // the natural-order by-product is written too (scattered stores: one owner per element)
+  R recip[18] = {0.61, 0.02, -0.03, 0.05, 0.57, 0.01, -0.02, 0.04, 0.52, 0.66, 0.0, 0.0, 0.0, 0.6, 0.0, 0.0, 0.0, 0.55};
+  const R alpha[2] = {R(0.35), R(0.42)}, volume[2] = {R(1100.0), R(900.0)};
   for (int bx = 0; bx < B * nx; ++bx)
     run_block(nth, [&](int tid, int n) {
-      fwd_plane_body<double>(mesh.data() + (size_t)bx * ny * nz, spec.data() + (size_t)bx * ncol, (Cx<double>*)lds_plane.data(), g, tb, tid, n);
+      fwd_plane_body<R>(mesh.data() + (size_t)bx * ny * nz, spec.data() + (size_t)bx * ncol, (Cx<R>*)lds_plane.data(), g, tb, tid, n);
     });
   const int blocks = (int)((ncol + MI_SOLVE_COLS - 1) / MI_SOLVE_COLS);
   for (int b = 0; b < B; ++b)
     for (int blk = 0; blk < blocks; ++blk)
       run_block(nth, [&](int tid, int n) {
-        fwd_cols_body<double>(spec.data() + (size_t)b * nx * ncol, (Cx<double>*)lds_fwd_cols.data(), g, tb, recip + 9 * b, alpha[b], volume[b], 4, blk * MI_SOLVE_COLS, tid, n,
+        fwd_cols_body<R>(spec.data() + (size_t)b * nx * ncol, (Cx<R>*)lds_fwd_cols.data(), g, tb, recip + 9 * b, alpha[b], volume[b], 4, blk * MI_SOLVE_COLS, tid, n,
                               nat.data() + (size_t)b * nx * ncol);
       });
   for (int b = 0; b < B; ++b)
     for (int ch = 0; ch < nch; ++ch)
       for (int blk = 0; blk < blocks; ++blk)
         run_block(nth, [&](int tid, int n) {
-          inv_cols_body<double>(spec.data() + (size_t)b * nx * ncol, conv.data() + ((size_t)b * nch + ch) * nx * ncol, (Cx<double>*)lds_inv_cols.data(), g, tb, recip + 9 * b, ch,
+          inv_cols_body<R>(spec.data() + (size_t)b * nx * ncol, conv.data() + ((size_t)b * nch + ch) * nx * ncol, (Cx<R>*)lds_inv_cols.data(), g, tb, recip + 9 * b, ch,
                                 blk * MI_SOLVE_COLS, tid, n);
         });
   for (int p = 0; p < B * nch * nx; ++p)
-    run_block(nth, [&](int tid, int n) { inv_plane_body<double>(conv.data() + (size_t)p * ncol, out.data() + (size_t)p * ny * nz, (Cx<double>*)lds_plane.data(), g, tb, tid, n); });
+    run_block(nth, [&](int tid, int n) { inv_plane_body<R>(conv.data() + (size_t)p * ncol, out.data() + (size_t)p * ny * nz, (Cx<R>*)lds_plane.data(), g, tb, tid, n); });
   return out;
+}
+
+template <class R> static int check(int nx, int ny, int nz, bool asan, const char* what) {
+  const int B = 2, nch = 4;
+  int bad = 0;
+  std::vector<R> mesh((size_t)B * nx * ny * nz);
+  unsigned long long z = 88172645463325252ull + nx * 131 + ny * 17 + nz;
+  for (auto& v : mesh) { z ^= z << 13; z ^= z >> 7; z ^= z << 17; v = (R)((double)(z % 20001) / 10000.0 - 1.0); }
+  const std::vector<R> ref = solve<R>(B, nx, ny, nz, nch, 1, mesh);
+  if (asan) { printf("%s mesh %dx%dx%d single thread: in bounds\n", what, nx, ny, nz); return 0; }
+  for (int nth : {3, 16}) {
+    if (g_drop_barriers && nth != 3) continue;
+    if (sizeof(R) == 4 && nth != 16) continue;  // fp32: one thread count is enough for the partition, the layout is what differs
+    const std::vector<R> got = solve<R>(B, nx, ny, nz, nch, nth, mesh);
+    const bool same = memcmp(ref.data(), got.data(), ref.size() * sizeof(R)) == 0;
+    printf("%s mesh %dx%dx%d threads %d: %s\n", what, nx, ny, nz, nth, same ? "bit-identical" : "DIFFERENT");
+    bad += !same;
+  }
+  return bad;
 }
 
 int main(int argc, char** argv) {
@@ -72,20 +91,7 @@ int main(int argc, char** argv) {
   const bool asan = argc > 1 && strcmp(argv[1], "asan") == 0;  // bounds run: single-threaded, every buffer exactly sized
   const int shapes[][3] = {{16, 8, 32}, {128, 8, 8}, {8, 32, 16}};
   int bad = 0;
-  for (const auto& s : shapes) {
-    const int B = 2, nch = 4, nx = s[0], ny = s[1], nz = s[2];
-    std::vector<double> mesh((size_t)B * nx * ny * nz);
-    unsigned long long z = 88172645463325252ull + nx * 131 + ny * 17 + nz;
-    for (auto& v : mesh) { z ^= z << 13; z ^= z >> 7; z ^= z << 17; v = (double)(z % 20001) / 10000.0 - 1.0; }
-    const std::vector<double> ref = solve(B, nx, ny, nz, nch, 1, mesh);
-    if (asan) { printf("mesh %dx%dx%d single thread: in bounds\n", nx, ny, nz); continue; }
-    for (int nth : {3, 16}) {
-      if (g_drop_barriers && nth != 3) continue;
-      const std::vector<double> got = solve(B, nx, ny, nz, nch, nth, mesh);
-      const bool same = memcmp(ref.data(), got.data(), ref.size() * sizeof(double)) == 0;
-      printf("mesh %dx%dx%d threads %d: %s\n", nx, ny, nz, nth, same ? "bit-identical" : "DIFFERENT");
-      bad += !same;
-    }
-  }
+  for (const auto& s : shapes) bad += check<double>(s[0], s[1], s[2], asan, "fp64");
+  for (const auto& s : shapes) bad += check<float>(s[0], s[1], s[2], asan, "fp32");
   return bad ? 1 : 0;
 }

@@ -107,7 +107,7 @@ def test_whole_kspace_step_equals_the_numpy_restatement(H, dims, order, nch):
 
 
 def test_barrier_placement_under_thread_sanitizer(tmp_path):
-    """tests/native/fft_race_check.cpp: the same bodies with 3 and 16 host threads per block, MI_FFT_SYNC() = a pthread barrier, under
+    """tests/native/fft_race_check.cpp: the same bodies (fp64 and fp32) with 3 and 16 host threads per block, MI_FFT_SYNC() = a pthread barrier, under
     ThreadSanitizer.  Any two threads touching one LDS / global element between two barriers would be a missing __syncthreads on the GPU:
     none reported, and every thread count gives the single-thread result bit for bit.  Negative control: with the barriers dropped the
     detector does report races (so a clean run means something)."""
@@ -117,8 +117,8 @@ def test_barrier_placement_under_thread_sanitizer(tmp_path):
     run = subprocess.run([exe], capture_output=True, text=True, timeout=600)
     assert run.returncode == 0, run.stdout[-2000:] + run.stderr[-2000:]
     assert "ThreadSanitizer" not in run.stderr, run.stderr[-3000:]
-    lines = [l for l in run.stdout.splitlines() if l.startswith("mesh")]
-    assert len(lines) == 6 and all(l.endswith("bit-identical") for l in lines), run.stdout
+    lines = [l for l in run.stdout.splitlines() if " mesh " in l]
+    assert len(lines) == 9 and all(l.endswith("bit-identical") for l in lines), run.stdout   # fp64: 3 meshes x 2 thread counts, fp32: 3 x 1
     control = subprocess.run([exe, "drop"], capture_output=True, text=True, timeout=600)
     assert "ThreadSanitizer: data race" in control.stderr
 
@@ -131,4 +131,4 @@ def test_kernel_bodies_stay_inside_their_buffers(tmp_path):
                            os.path.join(ROOT, "tests", "native", "fft_race_check.cpp"), "-o", exe])
     run = subprocess.run([exe, "asan"], capture_output=True, text=True, timeout=600)
     assert run.returncode == 0 and "AddressSanitizer" not in run.stderr, run.stderr[-3000:]
-    assert sum(l.endswith("in bounds") for l in run.stdout.splitlines()) == 3, run.stdout
+    assert sum(l.endswith("in bounds") for l in run.stdout.splitlines()) == 6, run.stdout   # 3 meshes x (fp64, fp32)
