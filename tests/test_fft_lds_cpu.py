@@ -75,7 +75,10 @@ def test_forward_planes_equal_numpy_over_y_and_z(H, dims):
     assert np.allclose(got, want, rtol=0, atol=1e-11 * ny * nz)
 
 
-@pytest.mark.parametrize("dims,order,nch", [((8, 8, 8), 4, 4), ((16, 8, 32), 5, 4), ((8, 32, 16), 3, 1), ((32, 16, 8), 6, 4), ((16, 16, 16), 2, 4)])
+@pytest.mark.parametrize("dims,order,nch", [((8, 8, 8), 4, 4), ((16, 8, 32), 5, 4), ((8, 32, 16), 3, 1), ((32, 16, 8), 6, 4), ((16, 16, 16), 2, 4),
+                                            # every plan shape the kernels can meet: x 128 = 16 x 8 and 256 = 16 x 16 (radix 16), y 256 = 8 x 8 x 4,
+                                            # packed z rows of 128 = 8 x 8 x 2 and 64 = 8 x 8 points
+                                            ((128, 8, 16), 4, 4), ((256, 8, 8), 4, 1), ((8, 256, 8), 4, 1), ((8, 8, 256), 5, 4), ((64, 16, 128), 4, 4)])
 def test_whole_kspace_step_equals_the_numpy_restatement(H, dims, order, nch):
     """mesh -> rfftn -> (spec / sf2) G, (-i k_d) conv -> irfftn * N for the potential + three field components (the middle of
     oracle.pme_reciprocal_space: pme.py:1398-1440); triclinic cells, two systems with their own alpha."""
