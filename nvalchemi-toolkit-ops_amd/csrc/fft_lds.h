@@ -1,15 +1,16 @@
 // In-LDS 3-D FFT pieces of the fused PME mesh solve (csrc/pme.hip: pme_solve_*_kernel).
 //
 // The reference runs torch.fft.rfftn -> three elementwise spectrum kernels -> four torch.fft.irfftn (pme.py:1398-1440).  A library 3-D
-// FFT is three passes over HBM per transform; here the whole k-space step of a power-of-two mesh is three kernels:
-//   A  one block per (system, x) plane:   real rows -> R2C along z -> FFT along y, the plane never leaves LDS           (1 read, 1 write)
-//   B  one block per 8 (y,z) columns:     FFT along x -> Green function / B-spline moduli / -i k_d -> inverse FFT along x (1 read, C writes)
-//   C  one block per (system, channel, x) plane:  inverse FFT along y -> C2R along z -> real rows                         (1 read, 1 write)
+// FFT is three passes over HBM per transform; here the whole k-space step of a power-of-two mesh is four kernels that touch their data once:
+//   A   one block per (system, x) plane:        real rows -> packed R2C along z -> FFT along y, the plane never leaves LDS
+//   B1  one block per 16 (y,z) columns:         FFT along x (radix 16 x 8), times the Green function / B-spline moduli on the way out, in place
+//   B2  one block per (16 columns, channel):    (1 | -i k_d) on the way in, inverse FFT along x; the channels of a tile share one XCD's L2
+//   C   persistent block per CU over the (system, channel, x) planes:  inverse FFT along y -> packed C2R along z -> real rows
 // The 1-D transforms are in-place decimation-in-frequency forward (natural order in, digit-reversed "slots" out) and the mirrored
 // decimation-in-time inverse (slots in, natural order out): no reordering pass, every butterfly reads and writes the same R addresses, so
-// a stage needs no second buffer and one barrier.  Between the kernels the spectra stay in slot order along y and z (kernel B looks the
-// frequencies up); x is transformed forth and back inside kernel B.  The first / last stage of a transform that touches HBM reads /
-// writes it directly (no staging copy) wherever consecutive lanes then touch consecutive addresses.
+// a stage needs no second buffer and one barrier.  Between the kernels the spectra stay in slot order along x, y and z (the k-space factor
+// looks its Miller indices up in a small per-call table).  The first / last stage of a transform that touches HBM reads / writes it directly
+// (no staging copy) wherever consecutive lanes then touch consecutive addresses.
 //
 // Everything in here is written as per-item bodies over (tid, nthreads) with MI_FFT_SYNC() between phases, so that the same code runs as
 // one "thread" on the host (tests/native/fft_host_harness.cpp: index arithmetic checked against numpy without a GPU).  TEST-ONLY host
