@@ -175,10 +175,48 @@ class _FftPlan:
     def __call__(self, src: torch.Tensor, dst: torch.Tensor) -> None:
         C.check(C.lib().mi_fft_plan_exec(self.handle, C.ptr(src), C.ptr(dst), C.stream_of(src)), "mi_fft_plan_exec")
 
+    def self_test(self, device, dims, batch, code, inverse) -> None:
+        """Known-answer test of a NEW plan, once, at creation: the transform of a unit impulse per batch entry against its closed form.  Round 4
+        met a hipFFT plan that computed a different transform (60 % off) depending on which other plans were alive; this turns
+        that kind of failure from silent wrong energies into a warning at plan creation.  Warn-only, never raises (NVALCHEMIOPS_FFT_SELFTEST=0
+        switches it off); costs two small launches and one host read when a mesh shape is first seen."""
+        import math
+        import warnings
+
+        try:
+            nx, ny, nz = (int(v) for v in dims)
+            rdt = torch.float32 if code == C.dtype_code(torch.float32) else torch.float64
+            cdt = torch.complex64 if rdt == torch.float32 else torch.complex128
+            nzr = nz // 2 + 1
+            x0 = torch.arange(batch, device=device) % nx
+            y0 = (2 * torch.arange(batch, device=device) + 1) % ny
+            z0 = (3 * torch.arange(batch, device=device) + 2) % nz
+            kx = torch.arange(nx, device=device, dtype=torch.float64).view(1, nx, 1, 1)
+            ky = torch.arange(ny, device=device, dtype=torch.float64).view(1, 1, ny, 1)
+            kz = torch.arange(nzr, device=device, dtype=torch.float64).view(1, 1, 1, nzr)
+            phase = -2.0 * math.pi * (kx * x0.view(-1, 1, 1, 1) / nx + ky * y0.view(-1, 1, 1, 1) / ny + kz * z0.view(-1, 1, 1, 1) / nz)
+            spectrum = torch.polar(torch.ones_like(phase), phase).to(cdt).contiguous()   # rfftn of the impulses, unscaled
+            impulse = torch.zeros((batch, nx, ny, nz), dtype=rdt, device=device)
+            impulse[torch.arange(batch, device=device), x0, y0, z0] = 1.0
+            if inverse:
+                out = torch.empty((batch, nx, ny, nz), dtype=rdt, device=device)
+                self(spectrum.clone(), out)
+                err = float((out / float(nx * ny * nz) - impulse).abs().max())
+            else:
+                out = torch.empty((batch, nx, ny, nzr), dtype=cdt, device=device)
+                self(impulse.clone(), out)
+                err = float((out - spectrum).abs().max())
+            if not err < (1e-3 if rdt == torch.float32 else 1e-9):
+                warnings.warn(f"hipFFT plan {nx}x{ny}x{nz} x {batch} ({'C2R' if inverse else 'R2C'}, {rdt}) failed its impulse test at creation: max error {err:.3e} "
+                              "-- results of this mesh shape are not to be trusted in this process (DESIGN.md 3.7); NVALCHEMIOPS_PME_FFT=torch avoids library-owned plans")
+        except Exception as exc:  # the check must never be the thing that breaks a run
+            warnings.warn(f"hipFFT plan self-test could not run: {type(exc).__name__}: {exc}")
+
 
 _FFT_PLANS: dict = {}
 # NVALCHEMIOPS_PME_FFT=torch: the round-3 path (torch.fft.rfftn / irfftn: rocFFT behind torch's plan cache, two clones around the C2R) for A/B
 _OWN_FFT = os.environ.get("NVALCHEMIOPS_PME_FFT", "own") != "torch"
+_FFT_SELFTEST = os.environ.get("NVALCHEMIOPS_FFT_SELFTEST", "1") != "0"
 # NVALCHEMIOPS_PME_FUSED_AUTOGRAD=0: energies under autograd through the op-by-op composition as in round 3 (A/B and cross-check of the adjoint)
 _FUSED_AUTOGRAD = os.environ.get("NVALCHEMIOPS_PME_FUSED_AUTOGRAD", "1") != "0"
 # "auto": the library's measured policy (mi_pme_solve_preferred); True / NVALCHEMIOPS_PME_MESH_SOLVE=1: the fused mesh solve wherever it is
@@ -199,6 +237,8 @@ def _fft_plan(device: torch.device, dims, batch: int, code: int, inverse: bool) 
         if torch.cuda.is_current_stream_capturing():
             raise RuntimeError("particle_mesh_ewald: run one eager step before capturing it in a HIP graph (FFT plans are created on first use)")
         plan = _FFT_PLANS[key] = _FftPlan(dims, batch, code, inverse)
+        if _FFT_SELFTEST:
+            plan.self_test(device, dims, batch, code, inverse)
     return plan
 
 

@@ -370,3 +370,29 @@ def test_mesh_solve_policy():
         half = 128 * 128 * 65 * 16
         need = int(L.mi_pme_solve_scratch_bytes(1, 128, 128, 128, nch, f64))
         assert half * (1 + nch) <= need <= half * (1 + nch) + 3 * 256 + 3 * 128 * 16 + 6 * 128 * 8 + 1024
+
+
+def test_fft_plan_self_test_logic():
+    """`_FftPlan.self_test` (the known-answer check a new hipFFT plan gets at creation) on CPU tensors with stand-in plans that
+    run torch.fft: a correct transform is quiet, a transform that is off warns -- both directions, both precisions, a batch of three."""
+    import warnings
+
+    from nvalchemiops import _capi as C
+    from nvalchemiops.interactions.electrostatics import pme as P
+
+    class StandIn(P._FftPlan):
+        def __init__(self, inverse, dims, scale):
+            self.inverse, self.dims, self.scale = inverse, dims, scale
+
+        def __call__(self, src, dst):
+            r = torch.fft.irfftn(src, s=self.dims, dim=(1, 2, 3), norm="forward") if self.inverse else torch.fft.rfftn(src, dim=(1, 2, 3))
+            dst.copy_(r * self.scale)
+
+    dims = (6, 5, 8)
+    for dt in (torch.float32, torch.float64):
+        for inverse in (False, True):
+            for scale, expect in ((1.0, 0), (1.6, 1)):
+                with warnings.catch_warnings(record=True) as caught:
+                    warnings.simplefilter("always")
+                    StandIn(inverse, dims, scale).self_test(torch.device("cpu"), dims, 3, C.dtype_code(dt), inverse)
+                assert len(caught) == expect, (dt, inverse, scale, [str(w.message) for w in caught])
