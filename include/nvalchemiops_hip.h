@@ -91,6 +91,21 @@ int mi_nl_neighbors(const void* positions,          /* [n_atoms,3] dtype        
                                                        caller's coordinates unchanged                        */
                     void* workspace, size_t workspace_bytes, void* stream);
 
+/* Matrix-mode search that also leaves a PACKED COMPANION of the padded matrix (round 5): one 32-bit word per slot -- neighbour index in
+ * bits 0-25, unit shift + 1 in three 2-bit fields (bits 26-31), 0xffffffff = padding -- behind a 256-byte header whose first int32 is
+ * raised (non-zero) when a stored shift lies outside {-1, 0, 1} (the companion is then unusable).  It is the format the D3 passes stream
+ * (mi_d3_packed below): the search has index and shift of every hit in registers when it stores the 16 bytes of the API format, so the
+ * 4-byte word costs one more store there and saves the consumer a 16 B/slot read + 4 B/slot write.  No reference counterpart: the
+ * reference's dftd3 kernels re-read neighbor_matrix + neighbor_matrix_shifts in every pass (dftd3.py:833-1260).  The companion describes
+ * exactly what was written to neighbor_matrix / neighbor_matrix_shifts by THIS call; keeping the two in step afterwards is the caller's
+ * business (the Python layer keys it on the tensors' version counters).  Requires shifts, padding, a full (not half-filled) list and
+ * n_atoms < 2^26.  packed_out: mi_nl_packed_bytes(n_atoms, max_neighbors) bytes (0 = not available for these sizes).                    */
+size_t mi_nl_packed_bytes(int n_atoms, int max_neighbors);
+int mi_nl_neighbors_packed(const void* positions, int n_atoms, const void* cell, const uint8_t* pbc, const int32_t* batch_idx, int n_systems,
+                           double cutoff, int dtype, int flags, int32_t* neighbor_matrix, int32_t* neighbor_matrix_shifts,
+                           int32_t* num_neighbors, int max_neighbors, int fill_value, const void* bin_origin, void* workspace,
+                           size_t workspace_bytes, void* packed_out, size_t packed_bytes, void* stream);
+
 /* Single-sweep dual-cutoff search: ONE walk over the candidate pairs fills two padded matrices, the short list nested in the long one and
  * both with the image range of the long cutoff.  Replaces: _fill_naive_neighbor_matrix[_pbc]_dual_cutoff and the batch variants
  * (neighborlist/naive_dual_cutoff.py:36,115 / batch_naive_dual_cutoff.py:37,126).  flags as for mi_nl_neighbors (matrix mode). */
@@ -182,6 +197,17 @@ int mi_d3(const void* positions, const int32_t* numbers, int n_atoms, int dtype,
           int n_systems, const mi_d3_params* params /* [host] */, int compute_virial,
           float* energy /*[n_systems]*/, float* forces /*[n_atoms,3]*/, float* coord_num /*[n_atoms]*/,
           float* virial /*[n_systems,3,3] or NULL*/, void* workspace, size_t workspace_bytes, void* stream);
+
+/* mi_d3 on a periodic padded matrix whose packed companion the search already wrote (mi_nl_neighbors_packed): the CN pass streams the
+ * 4 B/slot companion instead of the 16 B/slot arrays and writes no copy of its own; the energy and chain passes read the companion too.
+ * neighbor_matrix / neighbor_matrix_shifts must still be the arrays the companion was built with: they are what the passes read when the
+ * companion's flag is raised (device-side choice, no host round trip), and the results are bit-identical to mi_d3's either way.
+ * `workspace` as for mi_d3 (with mi_d3_workspace_bytes_packed's size the spatial order stays available for incoherently numbered atoms).
+ * Requires cell, shifts, fill_value >= n_atoms, n_atoms < 2^26.                                                                          */
+int mi_d3_packed(const void* positions, const int32_t* numbers, int n_atoms, int dtype, const int32_t* neighbor_matrix,
+                 const int32_t* neighbor_matrix_shifts, int max_neighbors, int fill_value, const void* cell, const int32_t* batch_idx,
+                 int n_systems, const mi_d3_params* params, int compute_virial, float* energy, float* forces, float* coord_num, float* virial,
+                 void* workspace, size_t workspace_bytes, const void* packed_list, void* stream);
 
 /* ---- Ewald real space -----------------------------------------------------------------------
  * Replaces the 12 alchemiops::_[batch_]ewald_real_space_* ops (ewald.py:263-1365; kernels

@@ -374,14 +374,21 @@ __device__ __forceinline__ int d3_lockstep_trips(long long beg, long long end) {
 #ifndef D3_CN_DG
 #define D3_CN_DG 1  // trips of gathered atom records in flight (<= D3_CN_DS)
 #endif
-template <class T, bool CSR, bool BIG, bool SORT>  // BIG: the caller's list is far larger than the Infinity Cache -> streamed with non-temporal loads
+// PKIN (round 5): the rows are read from a packed companion the neighbour search wrote next to the matrix (`mi_nl_neighbors_packed`, 4 B/slot,
+// same word format as the copy this pass otherwise writes) instead of the 16 B/slot API arrays.  `gate_flag` / `gate_want`: the launch does
+// its work only when (*gate_flag != 0) == gate_want -- the PKIN launch runs when the companion's flag is clear, the plain launch beside
+// it when the search raised it (a shift outside {-1, 0, 1}); one of the two exits at once, no host round trip.
+template <class T, bool CSR, bool BIG, bool SORT, bool PKIN = false>  // BIG: the caller's list is far larger than the Infinity Cache -> streamed with non-temporal loads
 __global__ __launch_bounds__(D3_LS_WAVES * MI_WAVE) void d3_cn_kernel(const T* __restrict__ pos, const int* __restrict__ numbers, int N, const int* __restrict__ idx,
                                                     const int* __restrict__ ush, const int* __restrict__ nptr, int M, int fill_value,
                                                     const T* __restrict__ cell, const int* __restrict__ batch_idx, D3Dev P,
                                                     const typename Vec4<T>::type* __restrict__ apos, float4* __restrict__ aaux,
                                                     float* __restrict__ cn, unsigned* __restrict__ pk_out, int* __restrict__ pk_flag,
                                                     const int* __restrict__ inv, const typename Vec4<T>::type* __restrict__ acn,
-                                                    float4* __restrict__ aaux_s, int* __restrict__ rmax_bits) {
+                                                    float4* __restrict__ aaux_s, int* __restrict__ rmax_bits,
+                                                    const unsigned* __restrict__ pk_in, const int* __restrict__ gate_flag, int gate_want) {
+  static_assert(!PKIN || !CSR, "a packed companion belongs to a padded matrix");
+  if (gate_flag && ((*gate_flag != 0) != (gate_want != 0))) return;  // block-uniform (see PKIN above)
   const int lane = threadIdx.x & (MI_WAVE - 1);
   const int i0 = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x / MI_WAVE) + threadIdx.x / MI_WAVE);
   const int k0 = i0 < N ? i0 : N - 1;
@@ -416,13 +423,14 @@ __global__ __launch_bounds__(D3_LS_WAVES * MI_WAVE) void d3_cn_kernel(const T* _
   D3Step s[D3_CN_DS + 1];
   bool v[D3_CN_DG + 1];
   typename Vec4<T>::type p[D3_CN_DG + 1];
+  auto fetch = [&](long long at) { if constexpr (PKIN) return d3_fetch_pk(pk_in, at, end); else return d3_fetch<BIG>(idx, ush3, at, end, periodic); };
 #pragma unroll
-  for (int k = 0; k < D3_CN_DS; ++k) s[k] = d3_fetch<BIG>(idx, ush3, e + (long long)k * MI_WAVE, end, periodic);
+  for (int k = 0; k < D3_CN_DS; ++k) s[k] = fetch(e + (long long)k * MI_WAVE);
 #pragma unroll
   for (int k = 0; k < D3_CN_DG; ++k) { v[k] = s[k].in && ((unsigned)s[k].j < jlim); p[k] = arec[v[k] ? s[k].j : i]; }
   for (int trip = 0; trip < trips; ++trip) {
     __syncthreads();  // lock-step: the block's waves walk rows of consecutive atoms, i.e. nearly the same neighbours in nearly the same order
-    s[D3_CN_DS] = d3_fetch<BIG>(idx, ush3, e + (long long)D3_CN_DS * MI_WAVE, end, periodic);
+    s[D3_CN_DS] = fetch(e + (long long)D3_CN_DS * MI_WAVE);
     v[D3_CN_DG] = s[D3_CN_DG].in && ((unsigned)s[D3_CN_DG].j < jlim);
     p[D3_CN_DG] = arec[v[D3_CN_DG] ? s[D3_CN_DG].j : i];
     const D3Step s0 = s[0];
@@ -1172,10 +1180,15 @@ static void d3_order_publish(const int* d_count, int* h_slot, hipStream_t st) {
 template <class T, bool CSR>
 int d3_impl(const T* pos, const int* numbers, int N, const int* idx, const int* ush, const int* nptr, int M, int fill_value, const T* cell,
             const int* batch_idx, int B, const mi_d3_params* hp, int want_virial, float* energy, float* forces, float* cn, float* virial,
-            char* ws, const D3Layout& L, unsigned* pk, long long n_entries, hipStream_t st) {
+            char* ws, const D3Layout& L, unsigned* pk, long long n_entries, const unsigned* pre, hipStream_t st) {
   // `pk` (optional, [N*M] words + one flag word in front): packed copy of a periodic padded list, see d3_fetch_pk
   int* pk_flag = nullptr;
   if (pk) { pk_flag = reinterpret_cast<int*>(pk); pk += 64; MI_HIP_CHECK(hipMemsetAsync(pk_flag, 0, sizeof(int), st)); }
+  // `pre` (optional, same layout, read-only): the companion the neighbour search wrote with the matrix (mi_nl_neighbors_packed).  The CN
+  // pass then streams 4 B/slot instead of 16 and -- unless the spatial order is on, whose packed list holds places, not indices -- writes
+  // nothing; the energy and chain passes read `pre` directly.
+  const int* pre_flag = pre ? reinterpret_cast<const int*>(pre) : nullptr;
+  const unsigned* pre_words = pre ? pre + 64 : nullptr;
   float* dEdCN = reinterpret_cast<float*>(ws + L.dEdCN);
   float* e_atom = reinterpret_cast<float*>(ws + L.e_atom);
   double* v_atom = reinterpret_cast<double*>(ws + L.v_atom);
@@ -1197,6 +1210,10 @@ int d3_impl(const T* pos, const int* numbers, int N, const int* idx, const int* 
   float rc_est = 0.0f;
   int* order_slot = nullptr;  // pinned ring slot of this system's generation (null: nothing to publish)
   const bool sorted = sortable && d3_order_decide(N, B, st, &probe, &rc_est, &order_slot);
+  if (pre && !sorted) {  // the later passes take the search's companion as their packed list (its flag says whether it is usable)
+    pk = const_cast<unsigned*>(pre_words);
+    pk_flag = const_cast<int*>(pre_flag);  // read-only from here on: the CN launches below get no output list
+  }
   int* inv = sorted ? reinterpret_cast<int*>(ws + L.inv) : nullptr;
   auto* apos_s = reinterpret_cast<typename Vec4<T>::type*>(ws + L.apos_s);
   auto* acn = reinterpret_cast<typename Vec4<T>::type*>(ws + L.acn);
@@ -1239,10 +1256,25 @@ int d3_impl(const T* pos, const int* numbers, int N, const int* idx, const int* 
                                                              want_virial ? v_atom : nullptr, inv, apos_s, aaux_s, acn);
   MI_LAUNCH_CHECK();
   const int blocks = mi_blocks(N, 4);
-#define MI_D3_CN(BIG_, SORT_) d3_cn_kernel<T, CSR, BIG_, SORT_><<<mi_blocks(N, D3_LS_WAVES), D3_LS_WAVES * MI_WAVE, 0, st>>>(pos, numbers, N, idx, ush, nptr, M, fill_value, cell, batch_idx, P, apos, aaux, cn, pk, pk_flag, inv, acn, aaux_s, sortable ? order_probe + 1 : nullptr)
+#define MI_D3_CN(BIG_, SORT_, PKIN_, OUT_, OUTFLAG_, GATE_, WANT_)                                                                                 \
+  d3_cn_kernel<T, CSR, BIG_, SORT_, PKIN_><<<mi_blocks(N, D3_LS_WAVES), D3_LS_WAVES * MI_WAVE, 0, st>>>(                                             \
+      pos, numbers, N, idx, ush, nptr, M, fill_value, cell, batch_idx, P, apos, aaux, cn, OUT_, OUTFLAG_, inv, acn, aaux_s,                           \
+      sortable ? order_probe + 1 : nullptr, pre_words, GATE_, WANT_)
   const bool big_list = (double)n_entries * ((cell && ush) ? 16.0 : 4.0) > 2.0e9;  // list bytes (see d3_fetch)
-  if (big_list) { if (sorted) { MI_TIMED("d3_cn", st, (MI_D3_CN(true, true))); } else { MI_TIMED("d3_cn", st, (MI_D3_CN(true, false))); } }
-  else { if (sorted) { MI_TIMED("d3_cn", st, (MI_D3_CN(false, true))); } else { MI_TIMED("d3_cn", st, (MI_D3_CN(false, false))); } }
+  if constexpr (!CSR) {
+    if (pre) {
+      // companion given: the PKIN launch works when its flag is clear, the plain launch when the search raised it.  Sorted: both write the
+      // place-coded list of the spatial order into the workspace copy; otherwise nothing is written (the later passes read `pre`).
+      unsigned* out = sorted ? pk : nullptr;
+      int* outflag = sorted ? pk_flag : nullptr;
+      if (sorted) { MI_TIMED("d3_cn", st, (MI_D3_CN(true, true, true, out, outflag, pre_flag, 0))); MI_D3_CN(true, true, false, out, outflag, pre_flag, 1); }
+      else { MI_TIMED("d3_cn", st, (MI_D3_CN(true, false, true, out, outflag, pre_flag, 0))); MI_D3_CN(true, false, false, out, outflag, pre_flag, 1); }
+    }
+  }
+  if (!pre) {
+    if (big_list) { if (sorted) { MI_TIMED("d3_cn", st, (MI_D3_CN(true, true, false, pk, pk_flag, nullptr, 0))); } else { MI_TIMED("d3_cn", st, (MI_D3_CN(true, false, false, pk, pk_flag, nullptr, 0))); } }
+    else { if (sorted) { MI_TIMED("d3_cn", st, (MI_D3_CN(false, true, false, pk, pk_flag, nullptr, 0))); } else { MI_TIMED("d3_cn", st, (MI_D3_CN(false, false, false, pk, pk_flag, nullptr, 0))); } }
+  }
 #undef MI_D3_CN
   if (publish) d3_order_publish(order_probe, order_slot, st);
   MI_LAUNCH_CHECK();
@@ -1314,11 +1346,12 @@ size_t mi_d3_workspace_bytes_packed(int n_atoms, int n_systems, int nz, int max_
   return mi_d3_workspace_bytes_entries(n_atoms, n_systems, nz, max_neighbors > 0 ? (long long)n_atoms * max_neighbors : 0);
 }
 
-int mi_d3(const void* positions, const int32_t* numbers, int n_atoms, int dtype, const int32_t* idx_j, const int32_t* unit_shifts,
+}  // extern "C" (the helper below has internal linkage)
+static int d3_entry(const void* positions, const int32_t* numbers, int n_atoms, int dtype, const int32_t* idx_j, const int32_t* unit_shifts,
           const int32_t* neighbor_ptr, int max_neighbors, long long n_list_entries, int fill_value, const void* cell,
           const int32_t* batch_idx, int n_systems,
           const mi_d3_params* params, int compute_virial, float* energy, float* forces, float* coord_num, float* virial, void* workspace,
-          size_t workspace_bytes, void* stream) {
+          size_t workspace_bytes, void* stream, const void* packed_list) {
   MI_REQUIRE(dtype == MI_F32 || dtype == MI_F64, "dtype");
   MI_REQUIRE(n_atoms >= 0 && n_systems >= 1, "sizes");
   if (n_atoms == 0) return MI_OK;
@@ -1329,6 +1362,10 @@ int mi_d3(const void* positions, const int32_t* numbers, int n_atoms, int dtype,
   if (workspace_bytes < L.total) { mi_set_error("workspace too small: %zu < %zu", workspace_bytes, L.total); return MI_EWORKSPACE; }
   hipStream_t st = (hipStream_t)stream;
   const bool csr = neighbor_ptr != nullptr;
+  // fill_value >= n_atoms: every stored index is then a neighbour (the companion marks padding itself; an index limit below n_atoms would
+  // turn real entries into padding, which only the CN pass re-checks)
+  MI_REQUIRE(!packed_list || (!csr && cell && unit_shifts && max_neighbors > 0 && n_atoms < D3_PK_MAX_ATOMS && fill_value >= n_atoms),
+             "packed_list: periodic padded matrix (cell + shifts), fill_value >= n_atoms, n_atoms < 2^26");
   // a periodic padded list is re-read by all three passes: with the larger workspace the CN pass leaves a 4 B/slot copy for the others
   unsigned* pk = nullptr;
   // CSR: `n_list_entries` = length of idx_j (0 = not given: no packed copy); matrix: n_atoms x max_neighbors
@@ -1338,10 +1375,30 @@ int mi_d3(const void* positions, const int32_t* numbers, int n_atoms, int dtype,
     pk = reinterpret_cast<unsigned*>((char*)workspace + ((mi_d3_workspace_bytes(n_atoms, n_systems, params->nz) + 255) & ~(size_t)255));
 #define MI_D3_CALL(T_, CSR_)                                                                                                              \
   return d3_impl<T_, CSR_>((const T_*)positions, numbers, n_atoms, idx_j, unit_shifts, neighbor_ptr, max_neighbors, fill_value, (const T_*)cell, \
-                           batch_idx, n_systems, params, compute_virial, energy, forces, coord_num, virial, (char*)workspace, L, pk, n_entries, st)
+                           batch_idx, n_systems, params, compute_virial, energy, forces, coord_num, virial, (char*)workspace, L, pk, n_entries,      \
+                           (const unsigned*)packed_list, st)
   if (dtype == MI_F32) { if (csr) MI_D3_CALL(float, true); else MI_D3_CALL(float, false); }
   else { if (csr) MI_D3_CALL(double, true); else MI_D3_CALL(double, false); }
 #undef MI_D3_CALL
+}
+
+extern "C" {
+int mi_d3(const void* positions, const int32_t* numbers, int n_atoms, int dtype, const int32_t* idx_j, const int32_t* unit_shifts,
+          const int32_t* neighbor_ptr, int max_neighbors, long long n_list_entries, int fill_value, const void* cell,
+          const int32_t* batch_idx, int n_systems,
+          const mi_d3_params* params, int compute_virial, float* energy, float* forces, float* coord_num, float* virial, void* workspace,
+          size_t workspace_bytes, void* stream) {
+  return d3_entry(positions, numbers, n_atoms, dtype, idx_j, unit_shifts, neighbor_ptr, max_neighbors, n_list_entries, fill_value, cell, batch_idx,
+                  n_systems, params, compute_virial, energy, forces, coord_num, virial, workspace, workspace_bytes, stream, nullptr);
+}
+
+int mi_d3_packed(const void* positions, const int32_t* numbers, int n_atoms, int dtype, const int32_t* neighbor_matrix,
+                 const int32_t* neighbor_matrix_shifts, int max_neighbors, int fill_value, const void* cell, const int32_t* batch_idx,
+                 int n_systems, const mi_d3_params* params, int compute_virial, float* energy, float* forces, float* coord_num, float* virial,
+                 void* workspace, size_t workspace_bytes, const void* packed_list, void* stream) {
+  MI_REQUIRE(packed_list != nullptr, "packed_list");
+  return d3_entry(positions, numbers, n_atoms, dtype, neighbor_matrix, neighbor_matrix_shifts, nullptr, max_neighbors, 0, fill_value, cell, batch_idx,
+                  n_systems, params, compute_virial, energy, forces, coord_num, virial, workspace, workspace_bytes, stream, packed_list);
 }
 
 }  // extern "C"

@@ -347,6 +347,20 @@ __device__ __forceinline__ long long nl_uniform64(long long v) {
 // fills list 2 and, nested in it, `dist_sq < cutoff1_sq` fills list 1 -- same image range for both).  The primary outputs of the query
 // kernels take the LONG cutoff, this struct the short one.
 template <class T> struct NlSecond { T rc2; int* nm; int* nsh; int* num; int M; };
+// Optional by-product of a matrix-mode search (round 5): a 4-byte-per-slot companion of the padded matrix in the format mi_d3's passes
+// stream (`d3_fetch_pk`, csrc/d3.hip): neighbour index in bits 0-25, unit shift + 1 in three 2-bit fields, all ones = padding.  The search has
+// index and shift of every hit in registers when it stores the 16 bytes of the API format; emitting the packed word there costs one more
+// 4-byte store per hit and saves the consumer the 16 B/slot read + 4 B/slot write of the pass that used to derive it (mi_d3's CN pass:
+// 5.1 GB -> 1.0 GB on the headline list).  `flag` is raised when a stored shift lies outside {-1, 0, 1} (the companion is then unusable
+// and the consumer reads the API arrays, bit-identical results).  words == nullptr: nothing is written.
+struct NlPacked { unsigned* words; int* flag; };
+#define NL_PK_PAD 0xffffffffu
+#define NL_PK_ZERO_SHIFT 0x54000000u  // (0 + 1) in each of the three fields
+__device__ __forceinline__ unsigned nl_pk_code(int Sx, int Sy, int Sz, bool& bad) {
+  const unsigned cx = (unsigned)(Sx + 1), cy = (unsigned)(Sy + 1), cz = (unsigned)(Sz + 1);
+  bad = (cx > 2u) | (cy > 2u) | (cz > 2u);
+  return ((cx & 3u) << 26) | ((cy & 3u) << 28) | (cz << 30);
+}
 
 template <class T>
 __device__ __forceinline__ bool nl_pair_hit(T pix, T piy, T piz, int i, T cjx, T cjy, T cjz, int j, int Sx, int Sy, int Sz, const T* cart,
@@ -390,7 +404,7 @@ __global__ __launch_bounds__(256) void nl_query_tiled_kernel(
     const typename Vec4<T>::type* __restrict__ spos, const short4* __restrict__ swrap, const int* __restrict__ cell_start,
     const NlSys<T>* __restrict__ sys, const NlGlobal* __restrict__ glob, int B, T rc2, int flags, int* __restrict__ nm,
     int* __restrict__ nsh, int* __restrict__ num, int M, int fill_value, const int* __restrict__ ptr, int* __restrict__ list_ij,
-    int* __restrict__ list_sh, long long P, NlSecond<T> D) {
+    int* __restrict__ list_sh, long long P, NlSecond<T> D, NlPacked K) {
   static_assert(!DUAL || (MODE == MI_NL_MODE_MATRIX && !FAST), "the dual-cutoff sweep is instantiated for the general matrix kernel only");
   // candidates staged in LDS per tile: fp64 records are twice as large and the fp64 kernel needs 112 VGPRs (4 waves / SIMD), so the smaller
   // tile is what lets a fourth block fit the LDS of a CU (9 A headline list: 0.254 -> 0.226 ms, profiles/r03_ab_nl_segfill.log)
@@ -569,14 +583,16 @@ __global__ __launch_bounds__(256) void nl_query_tiled_kernel(
           // loop went from ~14 to ~7 vector instructions (profiles/r03_ab_nl_valu.log).
           int* row_j[NC];
           NlInt3* row_s[NC];
+          unsigned* row_p[NC];  // packed companion row (matrix mode, optional)
 #pragma unroll
           for (int u = 0; u < NC; ++u) {
             const long long ob = nl_uniform64(out_base[u]);
+            row_p[u] = (MODE == MI_NL_MODE_MATRIX && !DUAL && K.words) ? K.words + ob : nullptr;
             if (MODE == MI_NL_MODE_MATRIX) { row_j[u] = nm + ob; row_s[u] = nsh ? reinterpret_cast<NlInt3*>(nsh) + ob : nullptr; }
             else if (MODE == MI_NL_MODE_CSR) { row_j[u] = list_ij + P + ob; row_s[u] = list_sh ? reinterpret_cast<NlInt3*>(list_sh) + ob : nullptr; }
             else { row_j[u] = nullptr; row_s[u] = nullptr; }
           }
-          auto emit_m = [&](int u, unsigned long long mask, bool hit, int j, int Sx, int Sy, int Sz) {
+          auto emit_m = [&](int u, unsigned long long mask, bool hit, int j, int Sx, int Sy, int Sz, unsigned code) {
             if (MODE == MI_NL_MODE_COUNT) { cnt[u] += __popcll(mask); return; }
             if (mask) {
               // slot = entries already in the row + hits in lower lanes
@@ -587,11 +603,12 @@ __global__ __launch_bounds__(256) void nl_query_tiled_kernel(
                 // when the centre is finished)
                 *reinterpret_cast<int*>(reinterpret_cast<char*>(row_j[u]) + slot * 4u) = j;
                 if (row_s[u]) *reinterpret_cast<NlInt3*>(reinterpret_cast<char*>(row_s[u]) + __umul24(slot, 12u)) = NlInt3{Sx, Sy, Sz};
+                if (MODE == MI_NL_MODE_MATRIX && !DUAL && row_p[u]) *reinterpret_cast<unsigned*>(reinterpret_cast<char*>(row_p[u]) + slot * 4u) = (unsigned)j | code;
               }
               cnt[u] += __popcll(mask);
             }
           };
-          auto emit = [&](int u, bool hit, int j, int Sx, int Sy, int Sz) { emit_m(u, __builtin_amdgcn_ballot_w64(hit), hit, j, Sx, Sy, Sz); };
+          auto emit = [&](int u, bool hit, int j, int Sx, int Sy, int Sz, unsigned code) { emit_m(u, __builtin_amdgcn_ballot_w64(hit), hit, j, Sx, Sy, Sz, code); };
           // software-pipelined by one group: the LDS reads of group g+1 are issued before group g is tested, so the wave
           // does not sit out an LDS round trip at the top of every trip
           struct Cand { int j, tt, zg; T x, y, z; };
@@ -619,18 +636,22 @@ __global__ __launch_bounds__(256) void nl_query_tiled_kernel(
                 const T dr0 = cjx - ccx[u], dr1 = cjy - ccy[u], dr2 = cjz - ccz[u];
                 const T d2 = dr0 * dr0 + dr1 * dr1 + dr2 * dr2;
                 const bool in = d2 < rc2, other = j != ii[u];
-                emit_m(u, __builtin_amdgcn_ballot_w64(in) & __builtin_amdgcn_ballot_w64(other), in & other, j, 0, 0, 0);
+                emit_m(u, __builtin_amdgcn_ballot_w64(in) & __builtin_amdgcn_ballot_w64(other), in & other, j, 0, 0, 0, NL_PK_ZERO_SHIFT);
               }
             } else if (FAST && gs != NL_MIXED) {  // one common non-zero shift: S.cell once per group, no self-pair possible
               const int Sx = (gs << 22) >> 22, Sy = (gs << 12) >> 22, Sz = (gs << 2) >> 22;
               T cart[3];
               if (ortho) { cart[0] = cm[0] * (T)Sx; cart[1] = cm[4] * (T)Sy; cart[2] = cm[8] * (T)Sz; }
               else { const T fs[3] = {(T)Sx, (T)Sy, (T)Sz}; rowvec_mat3(fs, cm, cart); }
+              bool bad;  // group-uniform: a shift that does not fit the packed word makes the companion unusable
+              const unsigned code = nl_pk_code(Sx, Sy, Sz, bad);
 #pragma unroll
               for (int u = 0; u < NC; ++u) {
                 const T dr0 = (cjx - ccx[u]) + cart[0], dr1 = (cjy - ccy[u]) + cart[1], dr2 = (cjz - ccz[u]) + cart[2];
                 const T d2 = dr0 * dr0 + dr1 * dr1 + dr2 * dr2;
-                emit(u, d2 < rc2, j, Sx, Sy, Sz);
+                const bool h = d2 < rc2;
+                if (MODE == MI_NL_MODE_MATRIX && bad && row_p[u] && h) *K.flag = 1;  // benign race: every writer stores 1
+                emit(u, h, j, Sx, Sy, Sz, code);
               }
             } else {
               const int Sx0 = tsx[tt], Sy0 = tsy[tt], Sz0 = tsz[tt];
@@ -663,7 +684,10 @@ __global__ __launch_bounds__(256) void nl_query_tiled_kernel(
                     }
                   }
                 }
-                emit(u, h, j, Sx, Sy, Sz);
+                bool bad;
+                const unsigned code = nl_pk_code(Sx, Sy, Sz, bad);
+                if (MODE == MI_NL_MODE_MATRIX && !DUAL && bad && row_p[u] && h) *K.flag = 1;
+                emit(u, h, j, Sx, Sy, Sz, code);
               }
             }
           }
@@ -689,6 +713,7 @@ __global__ __launch_bounds__(256) void nl_query_tiled_kernel(
           const int used = cnt < M ? cnt : M;
           wave_fill(nm, out_base + used, out_base + M, fill_value, lane);
           if (nsh) wave_fill(nsh, (out_base + used) * 3, (out_base + M) * 3, 0, lane);
+          if (!DUAL && K.words) wave_fill(reinterpret_cast<int*>(K.words), out_base + used, out_base + M, (int)NL_PK_PAD, lane);
         }
         if (DUAL) {
           const int c2 = ccnt2[ci - cbase];
@@ -715,7 +740,8 @@ __global__ __launch_bounds__(256) void nl_query_kernel(
     const typename Vec4<T>::type* __restrict__ spos, const short4* __restrict__ swrap, const int* __restrict__ keys_sorted,
     const int* __restrict__ cell_start, const int* __restrict__ batch_idx, const NlSys<T>* __restrict__ sys,
     const NlGlobal* __restrict__ glob, int N, T rc2, int flags, int* __restrict__ nm, int* __restrict__ nsh, int* __restrict__ num,
-    int M, int fill_value, const int* __restrict__ ptr, int* __restrict__ list_ij, int* __restrict__ list_sh, long long P, NlSecond<T> D) {
+    int M, int fill_value, const int* __restrict__ ptr, int* __restrict__ list_ij, int* __restrict__ list_sh, long long P, NlSecond<T> D,
+    NlPacked K) {
   static_assert(!DUAL || MODE == MI_NL_MODE_MATRIX, "the dual-cutoff sweep fills two padded matrices");
   if (glob->use_tiled) return;  // dense cells: the block-per-cell LDS-tiled kernel (launched next to this one) does the work
   const int lane = threadIdx.x & (MI_WAVE - 1);
@@ -799,6 +825,12 @@ __global__ __launch_bounds__(256) void nl_query_kernel(
           if (hit && slot < cap_row) {
             nm[out_base + slot] = j;
             if (nsh) reinterpret_cast<NlInt3*>(nsh)[out_base + slot] = NlInt3{Sx, Sy, Sz};
+            if (K.words) {  // packed companion (see NlPacked)
+              bool bad;
+              const unsigned code = nl_pk_code(Sx, Sy, Sz, bad);
+              if (bad) *K.flag = 1;
+              K.words[out_base + slot] = (unsigned)j | code;
+            }
           }
         } else if (MODE == MI_NL_MODE_CSR) {
           if (hit && slot < cap_row) {  // the source row (constant i) is written in bulk at the end
@@ -898,6 +930,7 @@ __global__ __launch_bounds__(256) void nl_query_kernel(
     const int used = cnt < M ? cnt : M;
     wave_fill(nm, out_base + used, out_base + M, fill_value, lane);
     if (nsh) wave_fill(nsh, (out_base + used) * 3, (out_base + M) * 3, 0, lane);
+    if (K.words) wave_fill(reinterpret_cast<int*>(K.words), out_base + used, out_base + M, (int)NL_PK_PAD, lane);
   }
   if (DUAL) {
     if (lane == 0) D.num[i] = cnt2;
@@ -1126,7 +1159,8 @@ __global__ void nl_moved_kernel(const T* __restrict__ ref, const T* __restrict__
 template <class T>
 int nl_neighbors_impl(const T* pos, int N, const T* cell, const uint8_t* pbc, const int* batch_idx, int B, double cutoff, int mode, int flags,
                       int* nm, int* nsh, int* num, int M, int fill_value, const int* ptr, int* list_ij, int* list_sh, long long P,
-                      const T* origin, char* ws, const NlLayout& L, hipStream_t st, const NlSecond<T>* second = nullptr) {
+                      const T* origin, char* ws, const NlLayout& L, hipStream_t st, const NlSecond<T>* second = nullptr,
+                      NlPacked K = NlPacked{nullptr, nullptr}) {
   auto* sys = reinterpret_cast<NlSys<T>*>(ws + L.sys);
   auto* glob = reinterpret_cast<NlGlobal*>(ws + L.glob);
   int* natoms = reinterpret_cast<int*>(ws + L.natoms);
@@ -1170,28 +1204,30 @@ int nl_neighbors_impl(const T* pos, int N, const T* cell, const uint8_t* pbc, co
   }
   const int blocks = mi_blocks(N, 4);
   const NlSecond<T> none{T(0), nullptr, nullptr, nullptr, 0};
+  const NlPacked nopk{nullptr, nullptr};
+  if (K.words) MI_HIP_CHECK(hipMemsetAsync(K.flag, 0, sizeof(int), st));
   if (second) {  // single-sweep dual cutoff: the primary outputs take the long cutoff, `second` the short one
     MI_TIMED("nl_query_dual", st,
              (nl_query_kernel<T, MI_NL_MODE_MATRIX, true><<<blocks, 256, 0, st>>>(spos, swrap, keys_out, cell_start, batch_idx, sys, glob, N, rc2, flags, nm, nsh,
-                                                                                 num, M, fill_value, ptr, list_ij, list_sh, P, *second),
+                                                                                 num, M, fill_value, ptr, list_ij, list_sh, P, *second, nopk),
               nl_query_tiled_kernel<T, MI_NL_MODE_MATRIX, false, true><<<nl_tiled_grid(), 256, 0, st>>>(spos, swrap, cell_start, sys, glob, B, rc2, flags, nm, nsh,
-                                                                                                       num, M, fill_value, ptr, list_ij, list_sh, P, *second)));
+                                                                                                       num, M, fill_value, ptr, list_ij, list_sh, P, *second, nopk)));
     MI_LAUNCH_CHECK();
     return MI_OK;
   }
 #define MI_NLQ(MODE_)                                                                                                              \
   nl_query_kernel<T, MODE_><<<blocks, 256, 0, st>>>(spos, swrap, keys_out, cell_start, batch_idx, sys, glob, N, rc2, flags, nm, nsh, num, M, \
-                                                    fill_value, ptr, list_ij, list_sh, P, none)
+                                                    fill_value, ptr, list_ij, list_sh, P, none, K)
   // both query kernels are launched; the device-side grid description (glob->use_tiled) decides which one does the work
   // and the other returns at once -- no host synchronisation to pick a variant
 #define MI_NLT(MODE_)                                                                                                                    \
   do {                                                                                                                                   \
     if ((flags & (MI_NL_HALF_FILL | MI_NL_NAIVE_EXPR)) == 0)                                                                             \
       nl_query_tiled_kernel<T, MODE_, true><<<nl_tiled_grid(), 256, 0, st>>>(spos, swrap, cell_start, sys, glob, B, rc2, flags, nm, nsh, num, \
-                                                                          M, fill_value, ptr, list_ij, list_sh, P, none);                \
+                                                                          M, fill_value, ptr, list_ij, list_sh, P, none, K);             \
     else                                                                                                                                 \
       nl_query_tiled_kernel<T, MODE_, false><<<nl_tiled_grid(), 256, 0, st>>>(spos, swrap, cell_start, sys, glob, B, rc2, flags, nm, nsh, num, \
-                                                                           M, fill_value, ptr, list_ij, list_sh, P, none);               \
+                                                                           M, fill_value, ptr, list_ij, list_sh, P, none, K);            \
   } while (0)
   if (mode == MI_NL_MODE_MATRIX) MI_TIMED(sizeof(T) == 4 ? "nl_query_matrix_f32" : "nl_query_matrix_f64", st, MI_NLQ(MI_NL_MODE_MATRIX); MI_NLT(MI_NL_MODE_MATRIX));
   else if (mode == MI_NL_MODE_COUNT) MI_TIMED("nl_query_count", st, MI_NLQ(MI_NL_MODE_COUNT); MI_NLT(MI_NL_MODE_COUNT));
@@ -1237,10 +1273,11 @@ size_t mi_nl_workspace_bytes(int n_atoms, int n_systems, int dtype) {
   return nl_layout(n_atoms, n_systems, dtype).total;
 }
 
-int mi_nl_neighbors(const void* positions, int n_atoms, const void* cell, const uint8_t* pbc, const int32_t* batch_idx, int n_systems,
+}  // extern "C" (helper below has internal linkage)
+static int nl_neighbors_entry(const void* positions, int n_atoms, const void* cell, const uint8_t* pbc, const int32_t* batch_idx, int n_systems,
                     double cutoff, int dtype, int mode, int flags, int32_t* neighbor_matrix, int32_t* neighbor_matrix_shifts,
                     int32_t* num_neighbors, int max_neighbors, int fill_value, const int32_t* neighbor_ptr, int32_t* list_ij,
-                    int32_t* list_shifts, long long n_pairs, const void* bin_origin, void* workspace, size_t workspace_bytes, void* stream) {
+                    int32_t* list_shifts, long long n_pairs, const void* bin_origin, void* workspace, size_t workspace_bytes, void* stream, void* packed_out) {
   MI_REQUIRE(dtype == MI_F32 || dtype == MI_F64, "dtype must be MI_F32 or MI_F64");
   MI_REQUIRE(n_atoms >= 0 && n_systems >= 1, "n_atoms >= 0 and n_systems >= 1");
   MI_REQUIRE(cutoff > 0, "cutoff must be positive");
@@ -1254,13 +1291,46 @@ int mi_nl_neighbors(const void* positions, int n_atoms, const void* cell, const 
   NlLayout L = nl_layout(n_atoms, n_systems, dtype);
   if (workspace_bytes < L.total) { mi_set_error("workspace too small: %zu < %zu", workspace_bytes, L.total); return MI_EWORKSPACE; }
   hipStream_t st = (hipStream_t)stream;
+  NlPacked K{nullptr, nullptr};
+  if (packed_out) {  // [64 words: flag line][n_atoms * max_neighbors words], the layout mi_d3_packed reads
+    MI_REQUIRE(mode == MI_NL_MODE_MATRIX && neighbor_matrix_shifts && !(flags & (MI_NL_NO_PAD | MI_NL_HALF_FILL)) && n_atoms < (1 << 26),
+               "packed companion: full (not half-filled) padded matrix with shifts, n_atoms < 2^26");
+    K.flag = reinterpret_cast<int*>(packed_out);
+    K.words = reinterpret_cast<unsigned*>(packed_out) + 64;
+  }
   if (dtype == MI_F32)
     return nl_neighbors_impl<float>((const float*)positions, n_atoms, (const float*)cell, pbc, batch_idx, n_systems, cutoff, mode, flags,
                                     neighbor_matrix, neighbor_matrix_shifts, num_neighbors, max_neighbors, fill_value, neighbor_ptr, list_ij,
-                                    list_shifts, n_pairs, (const float*)bin_origin, (char*)workspace, L, st);
+                                    list_shifts, n_pairs, (const float*)bin_origin, (char*)workspace, L, st, nullptr, K);
   return nl_neighbors_impl<double>((const double*)positions, n_atoms, (const double*)cell, pbc, batch_idx, n_systems, cutoff, mode, flags,
                                    neighbor_matrix, neighbor_matrix_shifts, num_neighbors, max_neighbors, fill_value, neighbor_ptr, list_ij,
-                                   list_shifts, n_pairs, (const double*)bin_origin, (char*)workspace, L, st);
+                                   list_shifts, n_pairs, (const double*)bin_origin, (char*)workspace, L, st, nullptr, K);
+}
+
+extern "C" {
+int mi_nl_neighbors(const void* positions, int n_atoms, const void* cell, const uint8_t* pbc, const int32_t* batch_idx, int n_systems,
+                    double cutoff, int dtype, int mode, int flags, int32_t* neighbor_matrix, int32_t* neighbor_matrix_shifts,
+                    int32_t* num_neighbors, int max_neighbors, int fill_value, const int32_t* neighbor_ptr, int32_t* list_ij,
+                    int32_t* list_shifts, long long n_pairs, const void* bin_origin, void* workspace, size_t workspace_bytes, void* stream) {
+  return nl_neighbors_entry(positions, n_atoms, cell, pbc, batch_idx, n_systems, cutoff, dtype, mode, flags, neighbor_matrix, neighbor_matrix_shifts,
+                            num_neighbors, max_neighbors, fill_value, neighbor_ptr, list_ij, list_shifts, n_pairs, bin_origin, workspace,
+                            workspace_bytes, stream, nullptr);
+}
+
+size_t mi_nl_packed_bytes(int n_atoms, int max_neighbors) {
+  if (n_atoms <= 0 || max_neighbors <= 0 || n_atoms >= (1 << 26)) return 0;
+  return 256 + sizeof(unsigned) * (size_t)n_atoms * (size_t)max_neighbors;
+}
+
+int mi_nl_neighbors_packed(const void* positions, int n_atoms, const void* cell, const uint8_t* pbc, const int32_t* batch_idx, int n_systems,
+                           double cutoff, int dtype, int flags, int32_t* neighbor_matrix, int32_t* neighbor_matrix_shifts,
+                           int32_t* num_neighbors, int max_neighbors, int fill_value, const void* bin_origin, void* workspace,
+                           size_t workspace_bytes, void* packed_out, size_t packed_bytes, void* stream) {
+  MI_REQUIRE(packed_out != nullptr && packed_bytes >= mi_nl_packed_bytes(n_atoms, max_neighbors) && mi_nl_packed_bytes(n_atoms, max_neighbors) > 0,
+             "packed_out: mi_nl_packed_bytes(n_atoms, max_neighbors) bytes");
+  return nl_neighbors_entry(positions, n_atoms, cell, pbc, batch_idx, n_systems, cutoff, dtype, MI_NL_MODE_MATRIX, flags, neighbor_matrix,
+                            neighbor_matrix_shifts, num_neighbors, max_neighbors, fill_value, nullptr, nullptr, nullptr, 0, bin_origin, workspace,
+                            workspace_bytes, stream, packed_out);
 }
 
 int mi_nl_neighbors_dual(const void* positions, int n_atoms, const void* cell, const uint8_t* pbc, const int32_t* batch_idx, int n_systems,

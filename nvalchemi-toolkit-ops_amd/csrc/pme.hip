@@ -21,6 +21,8 @@
 //     force factor applied in the epilogue (reference: 2 gathers of N*order^3 atomics + 2 elementwise kernels + torch ops).
 //   * orders 1-4 use the reference's piecewise polynomials verbatim; orders 5-6 (which the reference evaluates as 0,
 //     SURVEY F2) use the cardinal B-spline recursion.
+#include <atomic>
+
 #include "binsort.h"
 #include "common.h"
 #include "fft_lds.h"
@@ -1046,12 +1048,22 @@ __global__ __launch_bounds__(1024) void pme_solve_inv_kernel(const mifft::Cx<T>*
     __syncthreads();
   }
 }
+// per-device facts (a process may drive several GPUs: HIP function attributes and CU counts are per device -- ADVICE r4): indexed by the
+// current device, published with release / acquire so two host threads cannot see a half-written entry
+#define MI_SOLVE_MAX_DEVICES 64
+static int solve_device() {
+  int dev = 0;
+  return (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < MI_SOLVE_MAX_DEVICES) ? dev : -1;
+}
 static int solve_cus() {
-  static int n = 0;
+  static std::atomic<int> cus[MI_SOLVE_MAX_DEVICES];
+  const int dev = solve_device();
+  if (dev < 0) return 256;
+  int n = cus[dev].load(std::memory_order_acquire);
   if (!n) {
-    int dev = 0;
-    hipDeviceProp_t p;
-    n = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0) ? p.multiProcessorCount : 256;
+    int v = 0;
+    n = (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 256;
+    cus[dev].store(n, std::memory_order_release);
   }
   return n;
 }
@@ -1067,13 +1079,16 @@ static int solve_launch(const void* mesh, const void* recip_cell, const void* al
                         void* spec, void* conv, void* tab, void* real_out, void* spec_nat, int pt, int col_blocks, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   const size_t pl = mifft::plane_lds_bytes<T>(g), fl = mifft::fwd_cols_lds_bytes<T>(g), il = mifft::inv_cols_lds_bytes<T>(g);
-  static bool raised = false;  // more than 64 KB of dynamic LDS has to be asked for once per kernel
-  if (!raised) {
+  // more than 64 KB of dynamic LDS has to be asked for once per kernel AND device (setting it again is harmless: a race between two
+  // threads costs a repeated call, never a launch without the opt-in)
+  static std::atomic<bool> raised_on[MI_SOLVE_MAX_DEVICES];
+  const int dev_ix = solve_device();
+  if (dev_ix < 0 || !raised_on[dev_ix].load(std::memory_order_acquire)) {
     MI_HIP_CHECK(hipFuncSetAttribute((const void*)pme_solve_fwd_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, MI_LDS_MAX));
     MI_HIP_CHECK(hipFuncSetAttribute((const void*)pme_solve_fwd_cols_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, MI_LDS_MAX));
     MI_HIP_CHECK(hipFuncSetAttribute((const void*)pme_solve_inv_cols_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, MI_LDS_MAX));
     MI_HIP_CHECK(hipFuncSetAttribute((const void*)pme_solve_inv_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, MI_LDS_MAX));
-    raised = true;
+    if (dev_ix >= 0) raised_on[dev_ix].store(true, std::memory_order_release);
   }
   // unit roots / sinc / Miller index per FFT slot: a few KB, recomputed by one small launch per call into the caller's scratch -- the
   // library keeps NO device memory of its own here (a per-shape cache allocated with hipMalloc was tried first)

@@ -48,6 +48,8 @@ def lib() -> ctypes.CDLL:
         L.mi_spline_spread_workspace_bytes.argtypes = [ctypes.c_int] * 5
         L.mi_spline_spread_order_offset.restype = ctypes.c_longlong
         L.mi_spline_spread_order_offset.argtypes = [ctypes.c_int] * 6
+        L.mi_nl_packed_bytes.restype = ctypes.c_size_t
+        L.mi_nl_packed_bytes.argtypes = [ctypes.c_int, ctypes.c_int]
         if hasattr(L, "mi_d3_workspace_bytes"):
             L.mi_d3_workspace_bytes.restype = ctypes.c_size_t
             L.mi_d3_workspace_bytes.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int]

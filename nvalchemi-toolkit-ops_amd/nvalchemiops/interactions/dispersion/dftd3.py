@@ -72,7 +72,9 @@ _LIB_OVERRIDE = None  # tests only: a ctypes handle of the IEEE-arithmetic build
 
 
 def _launch(positions, numbers, idx, shifts, nptr, max_neighbors, fill_value, cell, batch_idx, num_systems, tables, scalars,
-            compute_virial, energy, forces, coord_num, virial) -> None:
+            compute_virial, energy, forces, coord_num, virial, packed=None) -> None:
+    """`packed`: the companion word list the neighbour search left next to (idx, shifts) (`neighborlist/_engine.py`), already validated by the
+    caller; the passes then stream 4 B/slot from the first pass on (`mi_d3_packed`)."""
     dev = positions.device
     n = positions.shape[0]
     pos = positions.detach().contiguous()
@@ -98,6 +100,14 @@ def _launch(positions, numbers, idx, shifts, nptr, max_neighbors, fill_value, ce
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
     vir = virial if compute_virial else None
     z = C.i32(numbers)  # converted tensors stay referenced until the launch is enqueued (the allocator may otherwise reuse their blocks)
+    if packed is not None and periodic and nptr is None and mode != "0":
+        rc = L.mi_d3_packed(C.ptr(pos), C.ptr(z), n, code, C.ptr(idx), C.ptr(sh), int(max_neighbors), int(fill_value), C.ptr(cell_t), C.ptr(bi),
+                            int(num_systems), ctypes.byref(par), int(bool(compute_virial)), C.ptr(energy), C.ptr(forces), C.ptr(coord_num),
+                            C.ptr(vir), C.ptr(ws), ctypes.c_size_t(ws_bytes), C.ptr(packed), C.stream_of(pos))
+        if rc != 0 and _LIB_OVERRIDE is not None:
+            raise C.NativeLibraryError(f"mi_d3_packed (override library) failed with code {rc}")
+        C.check(rc, "mi_d3_packed")
+        return
     rc = L.mi_d3(C.ptr(pos), C.ptr(z), n, code, C.ptr(idx), C.ptr(sh), C.ptr(nptr), int(max_neighbors),
                  ctypes.c_longlong(idx.shape[0] if nptr is not None else 0), int(fill_value),  # CSR: the entry count (packing is decided by the workspace size)
                  C.ptr(cell_t), C.ptr(bi), int(num_systems), ctypes.byref(par), int(bool(compute_virial)), C.ptr(energy), C.ptr(forces),
@@ -195,8 +205,15 @@ def dftd3(positions: torch.Tensor, numbers: torch.Tensor, a1: float, a2: float, 
     tables = (covalent_radii, r4r2, c6_reference, coord_num_ref)
     if use_matrix:
         nm = C.i32(neighbor_matrix)
-        _launch(positions, numbers, nm, neighbor_matrix_shifts, None, nm.size(1), n if fill_value is None else fill_value, cell,
-                batch_idx, num_systems, tables, scalars, compute_virial, energy, forces, coord_num, virial)
+        fill = n if fill_value is None else fill_value
+        packed = None
+        if nm is neighbor_matrix and cell is not None and neighbor_matrix_shifts is not None and int(fill) >= n:
+            from nvalchemiops.neighborlist import _engine as E
+
+            # valid only while matrix and shifts are provably what the search wrote (tensor identity + version counters); else None
+            packed = E.packed_companion(nm, neighbor_matrix_shifts, fill)
+        _launch(positions, numbers, nm, neighbor_matrix_shifts, None, nm.size(1), fill, cell,
+                batch_idx, num_systems, tables, scalars, compute_virial, energy, forces, coord_num, virial, packed=packed)
     else:
         idx_j = C.i32(neighbor_list[1])
         _launch(positions, numbers, idx_j, unit_shifts, C.i32(neighbor_ptr), 0, 0, cell, batch_idx, num_systems, tables, scalars,

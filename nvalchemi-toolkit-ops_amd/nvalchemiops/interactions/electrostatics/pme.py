@@ -163,7 +163,7 @@ def pme_energy_corrections_with_charge_grad(raw_energies, charges, cell, alpha, 
 
 
 class _FftPlan:
-    """One hipFFT plan of the library (`mi_fft_plan_create`, csrc/fft.cpp) kept for the life of the process."""
+    """One hipFFT plan of the library (`mi_fft_plan_create`, csrc/fft.cpp), owned by the plan cache below and destroyed when it leaves it."""
 
     def __init__(self, dims, batch, code, inverse):
         import ctypes
@@ -175,13 +175,17 @@ class _FftPlan:
     def __call__(self, src: torch.Tensor, dst: torch.Tensor) -> None:
         C.check(C.lib().mi_fft_plan_exec(self.handle, C.ptr(src), C.ptr(dst), C.stream_of(src)), "mi_fft_plan_exec")
 
-    def self_test(self, device, dims, batch, code, inverse) -> None:
-        """Known-answer test of a NEW plan, once, at creation: the transform of a unit impulse per batch entry against its closed form.  Round 4
-        met a hipFFT plan that computed a different transform (60 % off) depending on which other plans were alive; this turns
-        that kind of failure from silent wrong energies into a warning at plan creation.  Warn-only, never raises (NVALCHEMIOPS_FFT_SELFTEST=0
-        switches it off); costs two small launches and one host read when a mesh shape is first seen."""
+    def destroy(self) -> None:
+        h, self.handle = getattr(self, "handle", None), None
+        if h:
+            C.lib().mi_fft_plan_destroy(h)  # hipfftDestroy frees the work area (a device-wide wait): only ever on eviction / a failed self-test
+
+    def self_test(self, device, dims, batch, code, inverse):
+        """Known-answer test of a NEW plan, once, at creation: the transform of one unit impulse per batch entry against its closed form.
+        Round 4 met a hipFFT plan that computed a different transform (60 % off) depending on which other plans were alive.
+        Returns (ok, detail): ok = True / False, or None when the check itself could not run -- the cache treats None like False (a plan that
+        cannot be vouched for is not used).  Costs two small launches and one host read when a (mesh, batch, dtype, direction, stream) is first seen."""
         import math
-        import warnings
 
         try:
             nx, ny, nz = (int(v) for v in dims)
@@ -206,14 +210,41 @@ class _FftPlan:
                 out = torch.empty((batch, nx, ny, nzr), dtype=cdt, device=device)
                 self(impulse.clone(), out)
                 err = float((out - spectrum).abs().max())
-            if not err < (1e-3 if rdt == torch.float32 else 1e-9):
-                warnings.warn(f"hipFFT plan {nx}x{ny}x{nz} x {batch} ({'C2R' if inverse else 'R2C'}, {rdt}) failed its impulse test at creation: max error {err:.3e} "
-                              "-- results of this mesh shape are not to be trusted in this process (DESIGN.md 3.7); NVALCHEMIOPS_PME_FFT=torch avoids library-owned plans")
-        except Exception as exc:  # the check must never be the thing that breaks a run
-            warnings.warn(f"hipFFT plan self-test could not run: {type(exc).__name__}: {exc}")
+            ok = err < (1e-3 if rdt == torch.float32 else 1e-9)  # NaN compares False
+            return ok, f"max error {err:.3e}"
+        except Exception as exc:
+            return None, f"{type(exc).__name__}: {exc}"
 
 
-_FFT_PLANS: dict = {}
+class _TorchFft:
+    """Stand-in for a plan that failed (or could not run) its self-test: the same (src, dst) call through torch.fft, which was exact in the
+    process where the library plan was 60 % off (profiles/r04_rocfft_drift_repro.log).  Costs the clone / copy torch makes around a
+    multi-dimensional C2R; correctness first."""
+
+    def __init__(self, dims, batch, inverse):
+        self.dims, self.batch, self.inverse = tuple(int(v) for v in dims), int(batch), bool(inverse)
+
+    def __call__(self, src: torch.Tensor, dst: torch.Tensor) -> None:
+        nx, ny, nz = self.dims
+        if self.inverse:
+            out = torch.fft.irfftn(src.reshape(self.batch, nx, ny, nz // 2 + 1), s=self.dims, dim=(1, 2, 3), norm="forward")
+        else:
+            out = torch.fft.rfftn(src.reshape(self.batch, nx, ny, nz), dim=(1, 2, 3), norm="backward")
+        dst.view(out.shape).copy_(out)
+
+    def destroy(self) -> None:
+        pass
+
+
+import collections  # noqa: E402
+
+# LRU of live plans, keyed by (device, mesh, batch, dtype, direction, stream): bounded, so an MD run over varying batch sizes or meshes does
+# not pile up dozens of live rocFFT plans (the condition round 4's wrong-transform plan appeared under); a plan that leaves the cache is
+# destroyed, and one that comes back is created -- and self-tested -- again.  The stream is part of the key because a plan owns ONE work
+# area: two streams running the same shape concurrently must not share it (ADVICE r4).
+_FFT_PLANS: "collections.OrderedDict" = collections.OrderedDict()
+_FFT_PLAN_CAP = max(2, int(os.environ.get("NVALCHEMIOPS_FFT_PLAN_CACHE", "16")))
+_FFT_FALLBACKS: list = []  # (key, detail) of every plan replaced by torch.fft in this process (tests and bench read it)
 # NVALCHEMIOPS_PME_FFT=torch: the round-3 path (torch.fft.rfftn / irfftn: rocFFT behind torch's plan cache, two clones around the C2R) for A/B
 _OWN_FFT = os.environ.get("NVALCHEMIOPS_PME_FFT", "own") != "torch"
 _FFT_SELFTEST = os.environ.get("NVALCHEMIOPS_FFT_SELFTEST", "1") != "0"
@@ -223,22 +254,40 @@ _FUSED_AUTOGRAD = os.environ.get("NVALCHEMIOPS_PME_FUSED_AUTOGRAD", "1") != "0"
 # supported; False / =0: always hipFFT plans + mi_pme_convolve (A/B runs, and the parity tests that drive the solve's batch kernels)
 _MESH_SOLVE = {"0": False, "1": True}.get(os.environ.get("NVALCHEMIOPS_PME_MESH_SOLVE", "auto"), "auto")
 # NVALCHEMIOPS_PME_SOLVE_AUTOGRAD=1: the autograd node's forward takes the fused mesh solve too, with the charge spectrum its backward needs
-# written as a by-product (`mi_pme_solve_keep`).  Off by default: prepared at the end of round 4 (host-checked index arithmetic), not yet run
-# on a GPU -- tests/test_autograd_gpu.py has the parity test that switches it on (NVALCHEMIOPS_TEST_EXPERIMENTAL=1).
+# written as a by-product (`mi_pme_solve_keep`).
 _SOLVE_AUTOGRAD = os.environ.get("NVALCHEMIOPS_PME_SOLVE_AUTOGRAD", "0") == "1"
 
 
-def _fft_plan(device: torch.device, dims, batch: int, code: int, inverse: bool) -> _FftPlan:
-    """Plan cache keyed by (device, mesh, batch, dtype, direction).  Plans are created outside any HIP-graph capture (creation allocates
-    the work area); a step that is captured must have run once eagerly -- as every capture recipe does for its warm-up."""
-    key = (device.index, tuple(int(v) for v in dims), int(batch), int(code), bool(inverse))
+def _fft_plan(device: torch.device, dims, batch: int, code: int, inverse: bool):
+    """Plan cache (see `_FFT_PLANS`).  Plans are created outside any HIP-graph capture (creation allocates the work area); a step that is
+    captured must have run once eagerly -- as every capture recipe does for its warm-up.  FAIL-SAFE: a new plan that does not reproduce the
+    closed-form transform of an impulse -- or whose check cannot run -- is destroyed on the spot and this key is served by torch.fft from
+    then on (one warning); a wrong plan is never executed on user data."""
+    import warnings
+
+    stream = torch.cuda.current_stream(device).cuda_stream if device.type == "cuda" else 0
+    key = (device.index, tuple(int(v) for v in dims), int(batch), int(code), bool(inverse), int(stream))
     plan = _FFT_PLANS.get(key)
-    if plan is None:
-        if torch.cuda.is_current_stream_capturing():
-            raise RuntimeError("particle_mesh_ewald: run one eager step before capturing it in a HIP graph (FFT plans are created on first use)")
-        plan = _FFT_PLANS[key] = _FftPlan(dims, batch, code, inverse)
-        if _FFT_SELFTEST:
-            plan.self_test(device, dims, batch, code, inverse)
+    if plan is not None:
+        _FFT_PLANS.move_to_end(key)
+        return plan
+    capturing = device.type == "cuda" and torch.cuda.is_current_stream_capturing()
+    if capturing:
+        raise RuntimeError("particle_mesh_ewald: run one eager step before capturing it in a HIP graph (FFT plans are created on first use)")
+    plan = _FftPlan(dims, batch, code, inverse)
+    if _FFT_SELFTEST:
+        ok, detail = plan.self_test(device, dims, batch, code, inverse)
+        if not ok:
+            plan.destroy()
+            plan = _TorchFft(dims, batch, inverse)
+            _FFT_FALLBACKS.append((key, detail))
+            warnings.warn(f"hipFFT plan {tuple(dims)} x {batch} ({'C2R' if inverse else 'R2C'}) " +
+                          ("failed its impulse test at creation" if ok is False else "could not be self-tested") +
+                          f" ({detail}): destroyed; this shape runs through torch.fft in this process (DESIGN.md 3.7)")
+    _FFT_PLANS[key] = plan
+    while len(_FFT_PLANS) > _FFT_PLAN_CAP:
+        _, old = _FFT_PLANS.popitem(last=False)
+        old.destroy()
     return plan
 
 

@@ -6,12 +6,79 @@ batch_cell_list.py:739-1067, naive.py:221-397).
 from __future__ import annotations
 
 import ctypes
+import os
+import weakref
 
 import torch
 
 from nvalchemiops import _capi as C
 
 _WS_BYTES: dict[tuple[int, int, int], int] = {}
+
+# ---- packed companion of a padded matrix (round 5) ---------------------------------------------------------------------------------------
+# `mi_nl_neighbors_packed` can leave, next to the API-format matrix, the 4 B/slot word list the D3 passes stream (include/nvalchemiops_hip.h).
+# The companion rides on the returned matrix tensor as a Python attribute and is only ever USED by `dftd3` when the matrix and the shifts
+# are provably the ones it was built with: same tensor objects, same torch version counters (every in-place torch op bumps them, and every
+# launch of this package that writes a matrix bumps them by hand, see `_written`).  Anything else -- a clone, a view, an edited entry --
+# silently takes the ordinary path; results are bit-identical either way, the companion only removes HBM traffic.
+# Policy (NVALCHEMIOPS_NL_PACKED): "0" never, "1" whenever the list qualifies, "auto" (default): only for (device, n_atoms, row width) shapes
+# that `dftd3` has been handed before WITHOUT a companion -- so a caller who only wants neighbour lists never pays the extra 4 B/slot
+# of writes, and an MD loop gets the fused path from its second step on.
+_PACKED_POLICY = os.environ.get("NVALCHEMIOPS_NL_PACKED", "auto")
+_PACKED_WANTED: set[tuple[int, int, int]] = set()
+_PACKED_ATTR = "_nvalchemiops_packed"
+_BUILT_ATTR = "_nvalchemiops_built"
+
+
+class PackedCompanion:
+    """What `dftd3` needs to trust a companion: the words, and the identity + version of the two tensors they describe."""
+    __slots__ = ("words", "nm_version", "nsh_ref", "nsh_version", "n_atoms", "row_width", "fill_value")
+
+    def __init__(self, words, nm, nsh, fill_value):
+        self.words = words
+        self.nm_version = nm._version
+        self.nsh_ref = weakref.ref(nsh)
+        self.nsh_version = nsh._version
+        self.n_atoms, self.row_width = int(nm.shape[0]), int(nm.shape[1])
+        self.fill_value = int(fill_value)
+
+    def matches(self, nm: torch.Tensor, nsh: torch.Tensor | None, fill_value: int) -> bool:
+        return (nsh is not None and self.nsh_ref() is nsh and nm._version == self.nm_version and nsh._version == self.nsh_version
+                and tuple(nm.shape) == (self.n_atoms, self.row_width) and int(fill_value) == self.fill_value
+                and nm.dtype == torch.int32 and nsh.dtype == torch.int32 and nm.is_contiguous() and nsh.is_contiguous())
+
+
+def _written(*tensors) -> None:
+    """A launch of this package wrote these tensors through raw pointers: bump their version counters as an in-place torch op would, and
+    drop whatever companion described the old contents."""
+    for t in tensors:
+        if t is None:
+            continue
+        for attr in (_PACKED_ATTR, _BUILT_ATTR):
+            if hasattr(t, attr):
+                delattr(t, attr)
+        try:
+            torch.autograd.graph.increment_version(t)
+        except Exception:  # inference tensors carry no version counter; they can carry no companion either (PackedCompanion reads it)
+            pass
+
+
+def packed_companion(nm: torch.Tensor, nsh: torch.Tensor | None, fill_value: int):
+    """The companion of (nm, nsh) if it is still valid, else None.  Also where the "auto" policy learns: a matrix this package built without
+    a companion, handed to a consumer that would have used one, registers its shape."""
+    rec = getattr(nm, _PACKED_ATTR, None)
+    if rec is not None:
+        try:
+            if rec.matches(nm, nsh, fill_value):
+                return rec.words
+        except Exception:
+            pass
+        return None
+    if _PACKED_POLICY == "auto" and nsh is not None and getattr(nm, _BUILT_ATTR, None) == nm._version and nm.is_cuda:
+        if len(_PACKED_WANTED) > 64:
+            _PACKED_WANTED.clear()
+        _PACKED_WANTED.add((nm.device.index, int(nm.shape[0]), int(nm.shape[1])))
+    return None
 
 
 def workspace(n_atoms: int, n_systems: int, dtype: torch.dtype, device: torch.device) -> torch.Tensor:
@@ -50,6 +117,8 @@ def run(pos, cell, pbc, batch_idx, cutoff, mode, flags, *, nm=None, nsh=None, nu
     nsys = cell.shape[0]
     if ws is None:
         ws = workspace(n, nsys, pos.dtype, pos.device)
+    if mode == C.NL_MATRIX:
+        _written(nm, nsh, num)
     rc = C.lib().mi_nl_neighbors(
         C.ptr(pos), n, C.ptr(cell), C.ptr(pbc), C.ptr(batch_idx), nsys, C.cdouble(cutoff), C.dtype_code(pos.dtype), mode, flags,
         C.ptr(nm), C.ptr(nsh), C.ptr(num), int(max_neighbors), int(fill_value), C.ptr(nptr), C.ptr(list_ij), C.ptr(list_sh),
@@ -69,8 +138,33 @@ def neighbor_matrix(pos, cell, pbc, batch_idx, cutoff, max_neighbors, fill_value
         torch.ops.nvalchemiops.neighbor_search(pos, cell, pbc, batch_idx, cutoff, flags, fill_value, nm, nsh if want_shifts else None, num,
                                                origin)
         return
-    run(pos, cell, pbc, batch_idx, cutoff, C.NL_MATRIX, flags, nm=nm, nsh=nsh if want_shifts else None, num=num,
-        max_neighbors=max_neighbors, fill_value=fill_value, origin=origin)
+    n = pos.shape[0]
+    qualifies = (want_shifts and pad and not half_fill and nsh is not None and nm.is_contiguous() and nsh.is_contiguous() and int(fill_value) >= n
+                 and int(max_neighbors) > 0)
+    emit = qualifies and (_PACKED_POLICY == "1" or (_PACKED_POLICY == "auto" and (pos.device.index, n, int(max_neighbors)) in _PACKED_WANTED))
+    nbytes = int(C.lib().mi_nl_packed_bytes(n, int(max_neighbors))) if emit else 0
+    if nbytes == 0:
+        run(pos, cell, pbc, batch_idx, cutoff, C.NL_MATRIX, flags, nm=nm, nsh=nsh if want_shifts else None, num=num,
+            max_neighbors=max_neighbors, fill_value=fill_value, origin=origin)
+        if qualifies and _PACKED_POLICY == "auto":
+            try:
+                setattr(nm, _BUILT_ATTR, nm._version)  # "built here, full periodic-capable matrix, no companion": what `packed_companion` learns from
+            except Exception:
+                pass
+        return
+    old = getattr(nm, _PACKED_ATTR, None)  # an MD loop searches into the same buffers every step: reuse the companion's storage
+    words = old.words if (old is not None and old.words.numel() == nbytes and old.words.device == pos.device) else torch.empty(nbytes, dtype=torch.uint8, device=pos.device)
+    ws = workspace(n, cell.shape[0], pos.dtype, pos.device)
+    _written(nm, nsh, num)
+    rc = C.lib().mi_nl_neighbors_packed(
+        C.ptr(pos), n, C.ptr(cell), C.ptr(pbc), C.ptr(batch_idx), cell.shape[0], C.cdouble(cutoff), C.dtype_code(pos.dtype), flags,
+        C.ptr(nm), C.ptr(nsh), C.ptr(num), int(max_neighbors), int(fill_value), C.ptr(origin), C.ptr(ws), ctypes.c_size_t(ws.numel()),
+        C.ptr(words), ctypes.c_size_t(nbytes), C.stream_of(pos))
+    C.check(rc, "mi_nl_neighbors_packed")
+    try:
+        setattr(nm, _PACKED_ATTR, PackedCompanion(words, nm, nsh, fill_value))
+    except Exception:  # no version counter (inference tensor): no companion
+        pass
 
 
 def neighbor_matrix_dual(pos, cell, pbc, batch_idx, cutoff_short, cutoff_long, fill_value, half_fill, short, long_, *, naive=True, want_shifts=True,
@@ -86,6 +180,7 @@ def neighbor_matrix_dual(pos, cell, pbc, batch_idx, cutoff_short, cutoff_long, f
                                                     nsh1 if want_shifts else None, num1, nm2, nsh2 if want_shifts else None, num2, origin)
         return
     ws = workspace(n, nsys, pos.dtype, pos.device)
+    _written(nm1, nsh1, num1, nm2, nsh2, num2)
     rc = C.lib().mi_nl_neighbors_dual(
         C.ptr(pos), n, C.ptr(cell), C.ptr(pbc), C.ptr(batch_idx), nsys, C.cdouble(cutoff_short), C.cdouble(cutoff_long), C.dtype_code(pos.dtype), flags,
         C.ptr(nm1), C.ptr(nsh1 if want_shifts else None), C.ptr(num1), int(nm1.shape[1]),

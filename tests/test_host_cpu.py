@@ -374,9 +374,8 @@ def test_mesh_solve_policy():
 
 def test_fft_plan_self_test_logic():
     """`_FftPlan.self_test` (the known-answer check a new hipFFT plan gets at creation) on CPU tensors with stand-in plans that
-    run torch.fft: a correct transform is quiet, a transform that is off warns -- both directions, both precisions, a batch of three."""
-    import warnings
-
+    run torch.fft: a correct transform passes, a transform that is off fails, a check that cannot run reports None -- both directions, both
+    precisions, a batch of three."""
     from nvalchemiops import _capi as C
     from nvalchemiops.interactions.electrostatics import pme as P
 
@@ -385,14 +384,114 @@ def test_fft_plan_self_test_logic():
             self.inverse, self.dims, self.scale = inverse, dims, scale
 
         def __call__(self, src, dst):
+            if self.scale is None:
+                raise RuntimeError("exec failed")
             r = torch.fft.irfftn(src, s=self.dims, dim=(1, 2, 3), norm="forward") if self.inverse else torch.fft.rfftn(src, dim=(1, 2, 3))
             dst.copy_(r * self.scale)
 
     dims = (6, 5, 8)
     for dt in (torch.float32, torch.float64):
         for inverse in (False, True):
-            for scale, expect in ((1.0, 0), (1.6, 1)):
-                with warnings.catch_warnings(record=True) as caught:
-                    warnings.simplefilter("always")
-                    StandIn(inverse, dims, scale).self_test(torch.device("cpu"), dims, 3, C.dtype_code(dt), inverse)
-                assert len(caught) == expect, (dt, inverse, scale, [str(w.message) for w in caught])
+            for scale, expect in ((1.0, True), (1.6, False), (float("nan"), False), (None, None)):
+                ok, detail = StandIn(inverse, dims, scale).self_test(torch.device("cpu"), dims, 3, C.dtype_code(dt), inverse)
+                assert ok is expect, (dt, inverse, scale, ok, detail)
+
+
+def test_fft_plan_cache_is_fail_safe_and_bounded(monkeypatch):
+    """`_fft_plan` (pme.py) with stand-in plans on CPU tensors: a plan that fails -- or cannot run -- its self-test is DESTROYED and the key is
+    served by torch.fft (exact), with one warning; the cache is an LRU that destroys what it evicts and re-tests what comes back."""
+    import warnings
+
+    import numpy as np
+
+    from nvalchemiops import _capi as C
+    from nvalchemiops.interactions.electrostatics import pme as P
+
+    log = []
+
+    class Fake(P._FftPlan):
+        bad_shapes = {(6, 5, 8): 1.6, (4, 4, 6): None}
+
+        def __init__(self, dims, batch, code, inverse):
+            self.dims, self.batch, self.inverse = tuple(dims), batch, inverse
+            self.scale = self.bad_shapes.get(self.dims, 1.0)
+            log.append(("create", self.dims, inverse))
+
+        def __call__(self, src, dst):
+            if self.scale is None:
+                raise RuntimeError("exec failed")
+            r = torch.fft.irfftn(src, s=self.dims, dim=(1, 2, 3), norm="forward") if self.inverse else torch.fft.rfftn(src, dim=(1, 2, 3))
+            dst.copy_(r * self.scale)
+
+        def destroy(self):
+            log.append(("destroy", self.dims, self.inverse))
+
+    monkeypatch.setattr(P, "_FftPlan", Fake)
+    monkeypatch.setattr(P, "_FFT_PLANS", type(P._FFT_PLANS)())
+    monkeypatch.setattr(P, "_FFT_FALLBACKS", [])
+    monkeypatch.setattr(P, "_FFT_PLAN_CAP", 3)
+    dev, code = torch.device("cpu"), C.dtype_code(torch.float64)
+    g = torch.Generator().manual_seed(0)
+    for dims in ((6, 5, 8), (4, 4, 6)):  # wrong transform; exec raises
+        with warnings.catch_warnings(record=True) as caught:
+            warnings.simplefilter("always")
+            plan = P._fft_plan(dev, dims, 2, code, False)
+            again = P._fft_plan(dev, dims, 2, code, False)
+        assert isinstance(plan, P._TorchFft) and again is plan and len(caught) == 1, [str(w.message) for w in caught]
+        assert ("destroy", dims, False) in log
+        mesh = torch.randn((2,) + dims, generator=g, dtype=torch.float64)
+        out = torch.empty((2, dims[0], dims[1], dims[2] // 2 + 1), dtype=torch.complex128)
+        plan(mesh, out)
+        assert np.abs(out.numpy() - np.fft.rfftn(mesh.numpy(), axes=(1, 2, 3))).max() < 1e-12
+        back = torch.empty_like(mesh)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            P._fft_plan(dev, dims, 2, code, True)(out.clone(), back)
+        assert (back / float(np.prod(dims)) - mesh).abs().max() < 1e-12
+    assert len(P._FFT_FALLBACKS) == 4
+    # LRU: capacity 3 -> creating more good plans evicts (and destroys) the oldest; a shape that returns is created and tested again
+    P._FFT_PLANS.clear()
+    log.clear()
+    shapes = [(8, 8, 8), (8, 8, 10), (8, 10, 8), (10, 8, 8)]
+    for d in shapes:
+        assert isinstance(P._fft_plan(dev, d, 1, code, False), Fake)
+    assert len(P._FFT_PLANS) == 3 and ("destroy", (8, 8, 8), False) in log
+    P._fft_plan(dev, (8, 8, 10), 1, code, False)  # touch: now the most recent
+    P._fft_plan(dev, (8, 8, 8), 1, code, False)   # back again: re-created, (8, 10, 8) is the one that goes
+    assert log.count(("create", (8, 8, 8), False)) == 2 and ("destroy", (8, 10, 8), False) in log and ("destroy", (8, 8, 10), False) not in log
+
+
+def test_packed_companion_validity_rules():
+    """Host logic of the packed companion (neighborlist/_engine.py), no GPU: it is served only for the very tensors it was built with, at
+    the versions it was built at; every write -- by torch or by this package (`_written`) -- retires it; the "auto" policy learns a shape
+    only from a matrix this package built and a consumer asked about."""
+    import torch
+
+    from nvalchemiops.neighborlist import _engine as E
+
+    nm = torch.zeros((6, 4), dtype=torch.int32)
+    sh = torch.zeros((6, 4, 3), dtype=torch.int32)
+    E._written(nm, sh)
+    words = torch.zeros(8, dtype=torch.uint8)
+    setattr(nm, E._PACKED_ATTR, E.PackedCompanion(words, nm, sh, 6))
+    assert E.packed_companion(nm, sh, 6) is words
+    assert E.packed_companion(nm, sh.clone(), 6) is None      # another tensor, equal contents
+    assert E.packed_companion(nm, sh, 5) is None              # another index limit
+    assert E.packed_companion(nm, None, 6) is None
+    assert E.packed_companion(nm.clone(), sh, 6) is None      # attributes do not travel with clones
+    sh.add_(0)                                                # any in-place op moves the version counter
+    assert E.packed_companion(nm, sh, 6) is None
+    setattr(nm, E._PACKED_ATTR, E.PackedCompanion(words, nm, sh, 6))
+    assert E.packed_companion(nm, sh, 6) is words
+    nm[0, 0] = 3
+    assert E.packed_companion(nm, sh, 6) is None
+    setattr(nm, E._PACKED_ATTR, E.PackedCompanion(words, nm, sh, 6))
+    E._written(nm)                                            # a raw-pointer write of this package: attribute gone, version bumped
+    assert not hasattr(nm, E._PACKED_ATTR)
+    v = nm._version
+    E._written(nm)
+    assert nm._version == v + 1
+    # a shifts tensor that died: the weak reference is dead, never a match (even if a new tensor reuses the address)
+    setattr(nm, E._PACKED_ATTR, E.PackedCompanion(words, nm, sh, 6))
+    del sh
+    assert E.packed_companion(nm, torch.zeros((6, 4, 3), dtype=torch.int32), 6) is None
