@@ -6,6 +6,7 @@ to the library, which never allocates, frees or retains them.
 """
 from __future__ import annotations
 
+import contextvars
 import ctypes
 import functools
 import os
@@ -114,13 +115,23 @@ def require_device(*tensors: torch.Tensor | None) -> torch.device:
 
 
 SPLINE_REFERENCE_ORDERS = 0x100  # MI_SPLINE_REFERENCE_ORDERS of include/nvalchemiops_hip.h
-_REFERENCE_SPLINE_ORDERS = os.environ.get("NVALCHEMIOPS_REFERENCE_SPLINE_ORDERS", "0") not in ("", "0")
+_REFERENCE_SPLINE_ORDERS = os.environ.get("NVALCHEMIOPS_REFERENCE_SPLINE_ORDERS", "0") not in ("", "0")  # process default
+# context-local override (`with nvalchemiops.spline.reference_spline_orders():`): a contextvars.ContextVar, so the setting belongs to the
+# thread / asyncio task that entered the block -- another thread launching PME at the same time keeps its own setting, and an exception
+# anywhere cannot leave the switch flipped for someone else
+_REFERENCE_SPLINE_ORDERS_CTX: contextvars.ContextVar = contextvars.ContextVar("nvalchemiops_reference_spline_orders", default=None)
+
+
+def reference_spline_orders_active() -> bool:
+    v = _REFERENCE_SPLINE_ORDERS_CTX.get()
+    return _REFERENCE_SPLINE_ORDERS if v is None else bool(v)
 
 
 def spline_order_arg(order: int) -> int:
     """The `order` argument of the C ABI: the spline order, plus the reference-compatibility bit while
-    `nvalchemiops.spline.reference_spline_orders` is active (orders 5 / 6 evaluated as the reference does: zero weights, exponent 4)."""
-    return int(order) | (SPLINE_REFERENCE_ORDERS if _REFERENCE_SPLINE_ORDERS else 0)
+    `nvalchemiops.spline.reference_spline_orders` is active (orders 5 / 6 evaluated as the reference does: zero weights, exponent 4).
+    The bit travels with every launch: the library itself holds no such state."""
+    return int(order) | (SPLINE_REFERENCE_ORDERS if reference_spline_orders_active() else 0)
 
 
 def cdouble(x: float):

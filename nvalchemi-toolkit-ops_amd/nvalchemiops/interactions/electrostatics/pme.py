@@ -192,16 +192,20 @@ class _FftPlan:
             rdt = torch.float32 if code == C.dtype_code(torch.float32) else torch.float64
             cdt = torch.complex64 if rdt == torch.float32 else torch.complex128
             nzr = nz // 2 + 1
-            x0 = torch.arange(batch, device=device) % nx
-            y0 = (2 * torch.arange(batch, device=device) + 1) % ny
-            z0 = (3 * torch.arange(batch, device=device) + 2) % nz
+            # three weighted impulses per batch entry at positions that differ from entry to entry and never sit on an axis plane of the
+            # mesh together: a transposed, partially applied or mis-strided transform cannot reproduce their spectrum by accident
+            b = torch.arange(batch, device=device)
             kx = torch.arange(nx, device=device, dtype=torch.float64).view(1, nx, 1, 1)
             ky = torch.arange(ny, device=device, dtype=torch.float64).view(1, 1, ny, 1)
             kz = torch.arange(nzr, device=device, dtype=torch.float64).view(1, 1, 1, nzr)
-            phase = -2.0 * math.pi * (kx * x0.view(-1, 1, 1, 1) / nx + ky * y0.view(-1, 1, 1, 1) / ny + kz * z0.view(-1, 1, 1, 1) / nz)
-            spectrum = torch.polar(torch.ones_like(phase), phase).to(cdt).contiguous()   # rfftn of the impulses, unscaled
-            impulse = torch.zeros((batch, nx, ny, nz), dtype=rdt, device=device)
-            impulse[torch.arange(batch, device=device), x0, y0, z0] = 1.0
+            spectrum = torch.zeros((batch, nx, ny, nzr), dtype=torch.complex128, device=device)
+            impulse = torch.zeros((batch, nx, ny, nz), dtype=torch.float64, device=device)
+            for w, (ax, bx), (ay, by), (az, bz) in ((1.0, (1, 0), (2, 1), (3, 2)), (-0.5, (3, 1), (1, 0), (5, 1)), (0.25, (5, 2), (7, 3), (1, 0))):
+                x0, y0, z0 = (ax * b + bx) % nx, (ay * b + by) % ny, (az * b + bz) % nz
+                phase = -2.0 * math.pi * (kx * x0.view(-1, 1, 1, 1) / nx + ky * y0.view(-1, 1, 1, 1) / ny + kz * z0.view(-1, 1, 1, 1) / nz)
+                spectrum += w * torch.polar(torch.ones_like(phase), phase)   # rfftn of an impulse, unscaled
+                impulse.index_put_((b, x0, y0, z0), torch.full((batch,), w, dtype=torch.float64, device=device), accumulate=True)
+            spectrum, impulse = spectrum.to(cdt).contiguous(), impulse.to(rdt)
             if inverse:
                 out = torch.empty((batch, nx, ny, nz), dtype=rdt, device=device)
                 self(spectrum.clone(), out)
@@ -254,8 +258,9 @@ _FUSED_AUTOGRAD = os.environ.get("NVALCHEMIOPS_PME_FUSED_AUTOGRAD", "1") != "0"
 # supported; False / =0: always hipFFT plans + mi_pme_convolve (A/B runs, and the parity tests that drive the solve's batch kernels)
 _MESH_SOLVE = {"0": False, "1": True}.get(os.environ.get("NVALCHEMIOPS_PME_MESH_SOLVE", "auto"), "auto")
 # NVALCHEMIOPS_PME_SOLVE_AUTOGRAD=1: the autograd node's forward takes the fused mesh solve too, with the charge spectrum its backward needs
-# written as a by-product (`mi_pme_solve_keep`).
-_SOLVE_AUTOGRAD = os.environ.get("NVALCHEMIOPS_PME_SOLVE_AUTOGRAD", "0") == "1"
+# written as a by-product (`mi_pme_solve_keep`).  Default since round 5 (first run on a GPU then: 4 parity tests green, forward under grad
+# 0.427 -> 0.418 / 0.582 -> 0.565 ms on the 100k box, profiles/r05_bench_pme_train_*.json); =0 keeps the hipFFT plans in the node's forward.
+_SOLVE_AUTOGRAD = os.environ.get("NVALCHEMIOPS_PME_SOLVE_AUTOGRAD", "1") != "0"
 
 
 def _fft_plan(device: torch.device, dims, batch: int, code: int, inverse: bool):

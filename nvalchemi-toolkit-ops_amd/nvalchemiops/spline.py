@@ -15,31 +15,37 @@ from nvalchemiops import _capi as C
 
 
 def set_reference_spline_orders(enabled: bool) -> bool:
-    """Switch for the one deliberate numerical deviation of this build.
+    """PROCESS-WIDE default of the one deliberate numerical deviation of this build; for a scoped
+    change use the context manager `reference_spline_orders` below, which is local to the calling thread / task.
 
     False (default): spline orders 5 and 6 are true cardinal B-splines and the PME structure factor uses exponent = order.
     True: they are evaluated exactly as the reference evaluates them -- its weight function has cases for orders 1-4 only and returns 0
     otherwise (spline.py:150-193), and its structure-factor exponent is min(order, 4) (pme_kernels.py:213-225) -- so an order-5 PME
     call returns the reference's numbers (reciprocal potential identically zero, self / background corrections only).  Orders 1-4 are
-    unaffected.  Also settable at import time with NVALCHEMIOPS_REFERENCE_SPLINE_ORDERS=1.  Returns the previous setting.  The setting is
-    read at launch time (inside the custom ops as well), so it also applies to graphs compiled earlier."""
+    unaffected.  Also settable at import time with NVALCHEMIOPS_REFERENCE_SPLINE_ORDERS=1.  Returns the previous default.  Read at launch
+    time (inside the custom ops as well), so it also applies to graphs compiled earlier.  Meant to be set once at start-up: flipping it
+    while other threads launch is a data race on their results, which is what the context manager avoids."""
     prev = C._REFERENCE_SPLINE_ORDERS
     C._REFERENCE_SPLINE_ORDERS = bool(enabled)
     return prev
 
 
 class reference_spline_orders:
-    """Context manager around `set_reference_spline_orders(True)`: ``with reference_spline_orders(): particle_mesh_ewald(..., spline_order=5)``."""
+    """``with reference_spline_orders(): particle_mesh_ewald(..., spline_order=5)`` -- the reference's evaluation of orders 5 / 6 for the
+    calls made inside the block BY THIS THREAD / TASK (a `contextvars.ContextVar`: nothing process-wide changes, another thread's launches
+    keep their own setting, and leaving the block -- normally or by an exception -- restores exactly what this context had before).
+    ``reference_spline_orders(False)`` scopes the true B-splines inside a process whose default is the reference's evaluation."""
 
     def __init__(self, enabled: bool = True):
-        self.enabled = enabled
+        self.enabled = bool(enabled)
+        self._token = None
 
     def __enter__(self):
-        self.prev = set_reference_spline_orders(self.enabled)
+        self._token = C._REFERENCE_SPLINE_ORDERS_CTX.set(self.enabled)
         return self
 
     def __exit__(self, *exc):
-        set_reference_spline_orders(self.prev)
+        C._REFERENCE_SPLINE_ORDERS_CTX.reset(self._token)
         return False
 
 

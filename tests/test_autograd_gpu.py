@@ -751,8 +751,6 @@ def test_fused_nodes_with_explicit_forces_equal_the_composition(which, batched, 
             assert a.shape == b.shape and (a - b).abs().max().item() <= 1e-9 * max(1.0, b.abs().max().item()), (which, batched, energy_term, what, (a - b).abs().max().item())
 
 
-@pytest.mark.skipif(os.environ.get("NVALCHEMIOPS_TEST_EXPERIMENTAL", "0") != "1",
-                    reason="prepared at the end of round 4, not yet run on a GPU: NVALCHEMIOPS_TEST_EXPERIMENTAL=1 switches it on")
 @pytest.mark.parametrize("with_forces", [False, True])
 def test_fused_node_through_the_mesh_solve(with_forces, monkeypatch):
     """`_SOLVE_AUTOGRAD`: the autograd node's forward through the fused mesh solve, its backward fed by the natural-order charge spectrum the

@@ -57,7 +57,7 @@ def _words_of(E, nm):
 
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
-@pytest.mark.parametrize("n,cutoff,m", [(4000, 14.0, 512), (300, 6.0, 96)])  # dense cells (tiled kernel) and sparse cells (wave-per-atom kernel)
+@pytest.mark.parametrize("n,cutoff,m", [(4000, 11.0, 384), (300, 6.0, 96)])  # dense cells (tiled kernel) and sparse cells (wave-per-atom kernel)
 def test_companion_words_describe_the_matrix(engine, dtype, n, cutoff, m):
     from nvalchemiops.neighborlist import cell_list
 
@@ -93,7 +93,8 @@ def test_d3_with_and_without_the_companion_is_bit_identical(engine, sort, monkey
     perm = np.random.default_rng(5).permutation(n)  # incoherent numbering: the spatial order has something to do
     pos, numbers = pos[perm], numbers[perm]
     tp, tz, tc = _t(pos), _t(numbers), _t(cell)
-    nm, num, sh = cell_list(tp, 14.0, tc, torch.tensor([True] * 3, device=DEV), max_neighbors=512)
+    nm, num, sh = cell_list(tp, 11.0, tc, torch.tensor([True] * 3, device=DEV), max_neighbors=384)
+    assert int(num.max()) <= 384
     assert hasattr(nm, engine._PACKED_ATTR) and engine.packed_companion(nm, sh, n) is not None
     monkeypatch.setenv("NVALCHEMIOPS_D3_SORT", sort)
     with_pk = _d3(tp, tz, p, nm, sh, tc[None])
