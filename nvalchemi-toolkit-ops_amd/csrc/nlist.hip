@@ -355,9 +355,6 @@ template <class T> struct NlSecond { T rc2; int* nm; int* nsh; int* num; int M; 
 // and the consumer reads the API arrays, bit-identical results).  words == nullptr: nothing is written.
 struct NlPacked { unsigned* words; int* flag; };
 #define NL_PK_PAD 0xffffffffu
-#ifndef NL_PK_NT
-#define NL_PK_NT 0
-#endif
 #define NL_PK_ZERO_SHIFT 0x54000000u  // (0 + 1) in each of the three fields
 __device__ __forceinline__ unsigned nl_pk_code(int Sx, int Sy, int Sz, bool& bad) {
   const unsigned cx = (unsigned)(Sx + 1), cy = (unsigned)(Sy + 1), cz = (unsigned)(Sz + 1);
@@ -606,13 +603,9 @@ __global__ __launch_bounds__(256) void nl_query_tiled_kernel(
                 // when the centre is finished)
                 *reinterpret_cast<int*>(reinterpret_cast<char*>(row_j[u]) + slot * 4u) = j;
                 if (row_s[u]) *reinterpret_cast<NlInt3*>(reinterpret_cast<char*>(row_s[u]) + __umul24(slot, 12u)) = NlInt3{Sx, Sy, Sz};
-                if (MODE == MI_NL_MODE_MATRIX && !DUAL && row_p[u]) {
-#if NL_PK_NT  // tuning aid (probe): non-temporal companion stores
-                  __builtin_nontemporal_store((unsigned)j | code, reinterpret_cast<unsigned*>(reinterpret_cast<char*>(row_p[u]) + slot * 4u));
-#else
-                  *reinterpret_cast<unsigned*>(reinterpret_cast<char*>(row_p[u]) + slot * 4u) = (unsigned)j | code;
-#endif
-                }
+                // (plain store like the two above: a non-temporal companion store was measured at +0.25 - 0.3 ms on the headline fill,
+                // profiles/r05_ab_companion_nt_store.log)
+                if (MODE == MI_NL_MODE_MATRIX && !DUAL && row_p[u]) *reinterpret_cast<unsigned*>(reinterpret_cast<char*>(row_p[u]) + slot * 4u) = (unsigned)j | code;
               }
               cnt[u] += __popcll(mask);
             }

@@ -1,6 +1,7 @@
 """Neighbour-list API (reference: nvalchemiops/neighborlist/__init__.py:15-74) for the MI355X hot path."""
 from nvalchemiops.neighborlist.batch_cell_list import (batch_build_cell_list, batch_cell_list, batch_query_cell_list,
                                                        estimate_batch_cell_list_sizes)
+from nvalchemiops.neighborlist.buffers import tuned_neighbor_buffers
 from nvalchemiops.neighborlist.batch_naive import batch_naive_neighbor_list
 from nvalchemiops.neighborlist.batch_naive_dual_cutoff import batch_naive_neighbor_list_dual_cutoff
 from nvalchemiops.neighborlist.cell_list import build_cell_list, cell_list, estimate_cell_list_sizes, query_cell_list
@@ -19,4 +20,5 @@ __all__ = [
     "NeighborOverflowError", "cell_list_needs_rebuild", "neighbor_list_needs_rebuild", "check_cell_list_rebuild_needed",
     "check_neighbor_list_rebuild_needed", "batch_naive_neighbor_list", "naive_neighbor_list_dual_cutoff",
     "batch_naive_neighbor_list_dual_cutoff",
+    "tuned_neighbor_buffers",  # MI355X addition: output buffers chosen by a measured trial search (neighborlist/buffers.py)
 ]

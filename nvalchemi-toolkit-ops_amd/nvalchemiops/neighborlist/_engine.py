@@ -48,6 +48,13 @@ class PackedCompanion:
                 and nm.dtype == torch.int32 and nsh.dtype == torch.int32 and nm.is_contiguous() and nsh.is_contiguous())
 
 
+def want_packed_companion(device: torch.device, n_atoms: int, row_width: int) -> None:
+    """Tell the "auto" policy up front that matrices of this shape feed `dftd3` (what it otherwise learns from the first dftd3 call)."""
+    if len(_PACKED_WANTED) > 64:
+        _PACKED_WANTED.clear()
+    _PACKED_WANTED.add((device.index, int(n_atoms), int(row_width)))
+
+
 def _written(*tensors) -> None:
     """A launch of this package wrote these tensors through raw pointers: bump their version counters as an in-place torch op would, and
     drop whatever companion described the old contents."""

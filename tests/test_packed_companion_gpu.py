@@ -171,8 +171,8 @@ def test_batch_companion(engine):
     bi = np.repeat(np.arange(3, dtype=np.int32), 864)
     tp, tz, tc, tb = _t(pos), _t(z), _t(cell), _t(bi)
     pbc = torch.ones((3, 3), dtype=torch.bool, device=DEV)
-    nm, num, sh = batch_cell_list(tp, 12.0, tc, pbc, tb, max_neighbors=384)
-    assert int(num.max()) <= 384 and engine.packed_companion(nm, sh, len(pos)) is not None
+    nm, num, sh = batch_cell_list(tp, 12.0, tc, pbc, tb, max_neighbors=512)
+    assert int(num.max()) <= 512 and engine.packed_companion(nm, sh, len(pos)) is not None
     flag, words = _words_of(engine, nm)
     assert flag == 0 and torch.equal(words, _expected_words(nm, num, sh))
     a = _d3(tp, tz, p, nm, sh, tc, tb, 3)
@@ -193,8 +193,8 @@ def test_auto_policy_learns_from_dftd3_and_reuses_the_storage(monkeypatch):
     pos, cell, _, numbers = S.fcc_box(2048, dtype=np.float32)
     tp, tz, tc = _t(pos), _t(numbers), _t(cell)
     pbc = torch.tensor([True] * 3, device=DEV)
-    nm = torch.empty((2048, 320), dtype=torch.int32, device=DEV)
-    sh = torch.empty((2048, 320, 3), dtype=torch.int32, device=DEV)
+    nm = torch.empty((2048, 384), dtype=torch.int32, device=DEV)
+    sh = torch.empty((2048, 384, 3), dtype=torch.int32, device=DEV)
     num = torch.empty(2048, dtype=torch.int32, device=DEV)
     for _ in range(2):
         cell_list(tp, 11.0, tc, pbc, neighbor_matrix=nm, neighbor_matrix_shifts=sh, num_neighbors=num)
@@ -213,3 +213,29 @@ def test_auto_policy_learns_from_dftd3_and_reuses_the_storage(monkeypatch):
     # a half-filled or shift-less search into the same buffers drops it
     cell_list(tp, 11.0, tc, pbc, half_fill=True, neighbor_matrix=nm, neighbor_matrix_shifts=sh, num_neighbors=num)
     assert not hasattr(nm, E._PACKED_ATTR)
+
+
+def test_tuned_neighbor_buffers(monkeypatch):
+    """`tuned_neighbor_buffers`: candidate buffer sets timed by a trial search, the fastest kept.  Whatever set wins, a search into it gives
+    the list a search into plain `torch.empty` buffers gives; with `for_dftd3` the searches emit the companion from the first one on."""
+    from nvalchemiops.neighborlist import _engine as E
+    from nvalchemiops.neighborlist import cell_list, tuned_neighbor_buffers
+
+    monkeypatch.setattr(E, "_PACKED_POLICY", "auto")
+    monkeypatch.setattr(E, "_PACKED_WANTED", set())
+    n, m, rc = 24000, 768, 13.0  # 16 n m = 295 MB: above the size where the choice is made by measurement
+    pos, cell, _, _ = S.fcc_box(n, dtype=np.float32)
+    tp, tc = _t(pos), _t(cell)
+    pbc = torch.tensor([True] * 3, device=DEV)
+    rep = {}
+    nm, sh, num = tuned_neighbor_buffers(tp, rc, tc, pbc, m, candidates=3, for_dftd3=True, report=rep)
+    assert nm.shape == (n, m) and sh.shape == (n, m, 3) and num.shape == (n,)
+    assert rep["candidates"] == 3 and len(rep["trial_ms"]) == 3 and 0 <= rep["chosen"] < 3 and rep["trial_ms"][rep["chosen"]] == min(rep["trial_ms"])
+    cell_list(tp, rc, tc, pbc, neighbor_matrix=nm, neighbor_matrix_shifts=sh, num_neighbors=num)
+    assert int(num.max()) <= m and E.packed_companion(nm, sh, n) is not None
+    nm0, num0, sh0 = cell_list(tp, rc, tc, pbc, max_neighbors=m)
+    assert torch.equal(nm, nm0) and torch.equal(sh, sh0) and torch.equal(num, num0)
+    # a small list: nothing to choose
+    rep = {}
+    a, b, c = tuned_neighbor_buffers(tp[:500], 6.0, tc, pbc, 64, report=rep)
+    assert a.shape == (500, 64) and rep["candidates"] == 1

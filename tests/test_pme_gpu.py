@@ -858,7 +858,8 @@ def test_a_failing_fft_plan_is_replaced_not_used(dtype, monkeypatch):
         warnings.simplefilter("always")
         e2, f2 = pme_reciprocal_space(_t(pos), _t(q), _t(cell), 0.4, mesh_dimensions=dims, spline_order=order, compute_forces=True)
     assert not [w for w in caught if "impulse test" in str(w.message)]
-    assert torch.equal(e, e2) and torch.equal(f, f2)
+    _close(e2, ref[0], dtype, "energies through the cached fallback")  # (not bitwise: a 300-atom system takes the atomic spread)
+    _close(f2, ref[1], dtype, "forces through the cached fallback")
 
 
 def test_fft_plan_cache_is_bounded_on_the_device(monkeypatch):
