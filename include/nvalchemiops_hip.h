@@ -392,6 +392,17 @@ size_t mi_fft_plan_work_bytes(const void* plan);
 int mi_fft_plan_exec(void* plan, void* in, void* out, void* stream);
 int mi_fft_plan_destroy(void* plan);
 
+/* ---- dense DFT (csrc/dft.hip) -------------------------------------------------------------------------------------------
+ * The same transforms as mi_fft_plan_exec -- real [batch][nx][ny][nz] <-> complex [batch][nx][ny][nz/2+1], both directions unscaled --
+ * for ANY mesh size, evaluated from the definition (three passes of dense 1-D DFTs, sincospi twiddles in double): no plan, no library
+ * behind it, no state.  O(n) per output: this is the transform of last resort, used when a hipFFT plan fails its known-answer test at
+ * creation (rocFFT on this stack can return a wrong transform for some shapes depending on what the process planned before),
+ * and the cross-check of every other FFT path in the tests.  inverse != 0: `in` (complex) is transformed in place along x and y before
+ * the z pass writes `out` -- it is scratch, as for hipFFT's multi-dimensional C2R.  Replaces torch.fft.rfftn / irfftn of
+ * interactions/electrostatics/pme.py:1398, :1422, :1455-1457 on that path.                                                          */
+#define MI_DFT_MAX_N 1024
+int mi_dft3d(void* in, void* out, int nx, int ny, int nz, int batch, int dtype, int inverse, void* stream);
+
 /* ---- PME reciprocal-space mesh kernels ------------------------------------------------------
  * mi_pme_green_sf: alchemiops::_[batch_]pme_green_structure_factor (pme.py:273-553, pme_kernels.py:121-331)
  * mi_pme_convolve: the torch elementwise block of _pme_reciprocal_space_impl (pme.py:1418-1419,1455-1457):

@@ -30,6 +30,7 @@ SOURCES = {
     "d3.hip": ["-fno-hip-fp32-correctly-rounded-divide-sqrt", "-fno-slp-vectorize"] + os.environ.get("MI_D3_EXTRA_FLAGS", "").split(),
     "ewald.hip": os.environ.get("MI_EWALD_EXTRA_FLAGS", "").split(),
     "pme.hip": os.environ.get("MI_PME_EXTRA_FLAGS", "").split(),
+    "dft.hip": [],  # dense DFT of any mesh size: the transform of last resort behind the self-tested hipFFT plans
     "calib.hip": [],
 }
 COMMON = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]

@@ -220,21 +220,18 @@ class _FftPlan:
             return None, f"{type(exc).__name__}: {exc}"
 
 
-class _TorchFft:
-    """Stand-in for a plan that failed (or could not run) its self-test: the same (src, dst) call through torch.fft, which was exact in the
-    process where the library plan was 60 % off (profiles/r04_rocfft_drift_repro.log).  Costs the clone / copy torch makes around a
-    multi-dimensional C2R; correctness first."""
+class _DenseDft:
+    """Stand-in for a plan that failed (or could not run) its self-test, with the same (src, dst) call: the library's dense DFT (`mi_dft3d`,
+    csrc/dft.hip) -- the transform evaluated from its definition, any mesh size, no plan and no library state.  Slower than an FFT (O(n) per
+    output), exact by construction.  Not torch.fft: in the process where the hipFFT plans for (16, 8, 32) failed their self-test, torch.fft
+    -- the same rocFFT underneath -- returned a transform 5 % off for the same shape (gpurun r05_s5)."""
 
-    def __init__(self, dims, batch, inverse):
-        self.dims, self.batch, self.inverse = tuple(int(v) for v in dims), int(batch), bool(inverse)
+    def __init__(self, dims, batch, code, inverse):
+        self.dims, self.batch, self.code, self.inverse = tuple(int(v) for v in dims), int(batch), int(code), bool(inverse)
 
     def __call__(self, src: torch.Tensor, dst: torch.Tensor) -> None:
         nx, ny, nz = self.dims
-        if self.inverse:
-            out = torch.fft.irfftn(src.reshape(self.batch, nx, ny, nz // 2 + 1), s=self.dims, dim=(1, 2, 3), norm="forward")
-        else:
-            out = torch.fft.rfftn(src.reshape(self.batch, nx, ny, nz), dim=(1, 2, 3), norm="backward")
-        dst.view(out.shape).copy_(out)
+        C.check(C.lib().mi_dft3d(C.ptr(src), C.ptr(dst), nx, ny, nz, self.batch, self.code, int(self.inverse), C.stream_of(src)), "mi_dft3d")
 
     def destroy(self) -> None:
         pass
@@ -248,9 +245,11 @@ import collections  # noqa: E402
 # area: two streams running the same shape concurrently must not share it.
 _FFT_PLANS: "collections.OrderedDict" = collections.OrderedDict()
 _FFT_PLAN_CAP = max(2, int(os.environ.get("NVALCHEMIOPS_FFT_PLAN_CACHE", "16")))
-_FFT_FALLBACKS: list = []  # (key, detail) of every plan replaced by torch.fft in this process (tests and bench read it)
-# NVALCHEMIOPS_PME_FFT=torch: the round-3 path (torch.fft.rfftn / irfftn: rocFFT behind torch's plan cache, two clones around the C2R) for A/B
+_FFT_FALLBACKS: list = []  # (key, detail) of every plan replaced by the dense DFT in this process (tests and bench read it)
+# NVALCHEMIOPS_PME_FFT=torch: the round-3 path (torch.fft.rfftn / irfftn: rocFFT behind torch's plan cache, two clones around the C2R) for A/B;
+# =dft: every transform of the plan path through the library's dense DFT (no rocFFT at all; the parity tests' cross-check)
 _OWN_FFT = os.environ.get("NVALCHEMIOPS_PME_FFT", "own") != "torch"
+_FORCE_DFT = os.environ.get("NVALCHEMIOPS_PME_FFT", "own") == "dft"
 _FFT_SELFTEST = os.environ.get("NVALCHEMIOPS_FFT_SELFTEST", "1") != "0"
 # NVALCHEMIOPS_PME_FUSED_AUTOGRAD=0: energies under autograd through the op-by-op composition as in round 3 (A/B and cross-check of the adjoint)
 _FUSED_AUTOGRAD = os.environ.get("NVALCHEMIOPS_PME_FUSED_AUTOGRAD", "1") != "0"
@@ -266,8 +265,8 @@ _SOLVE_AUTOGRAD = os.environ.get("NVALCHEMIOPS_PME_SOLVE_AUTOGRAD", "1") != "0"
 def _fft_plan(device: torch.device, dims, batch: int, code: int, inverse: bool):
     """Plan cache (see `_FFT_PLANS`).  Plans are created outside any HIP-graph capture (creation allocates the work area); a step that is
     captured must have run once eagerly -- as every capture recipe does for its warm-up.  FAIL-SAFE: a new plan that does not reproduce the
-    closed-form transform of an impulse -- or whose check cannot run -- is destroyed on the spot and this key is served by torch.fft from
-    then on (one warning); a wrong plan is never executed on user data."""
+    closed-form transform of three impulses -- or whose check cannot run -- is destroyed on the spot and this key is served by the library's
+    dense DFT (`mi_dft3d`) from then on (one warning); a wrong plan is never executed on user data."""
     import warnings
 
     stream = torch.cuda.current_stream(device).cuda_stream if device.type == "cuda" else 0
@@ -279,16 +278,19 @@ def _fft_plan(device: torch.device, dims, batch: int, code: int, inverse: bool):
     capturing = device.type == "cuda" and torch.cuda.is_current_stream_capturing()
     if capturing:
         raise RuntimeError("particle_mesh_ewald: run one eager step before capturing it in a HIP graph (FFT plans are created on first use)")
+    if _FORCE_DFT:
+        plan = _FFT_PLANS[key] = _DenseDft(dims, batch, code, inverse)
+        return plan
     plan = _FftPlan(dims, batch, code, inverse)
     if _FFT_SELFTEST:
         ok, detail = plan.self_test(device, dims, batch, code, inverse)
         if not ok:
             plan.destroy()
-            plan = _TorchFft(dims, batch, inverse)
+            plan = _DenseDft(dims, batch, code, inverse)
             _FFT_FALLBACKS.append((key, detail))
             warnings.warn(f"hipFFT plan {tuple(dims)} x {batch} ({'C2R' if inverse else 'R2C'}) " +
                           ("failed its impulse test at creation" if ok is False else "could not be self-tested") +
-                          f" ({detail}): destroyed; this shape runs through torch.fft in this process (DESIGN.md 3.7)")
+                          f" ({detail}): destroyed; this shape runs through the library's dense DFT in this process (DESIGN.md 3.7)")
     _FFT_PLANS[key] = plan
     while len(_FFT_PLANS) > _FFT_PLAN_CAP:
         _, old = _FFT_PLANS.popitem(last=False)

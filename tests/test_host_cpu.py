@@ -399,7 +399,7 @@ def test_fft_plan_self_test_logic():
 
 def test_fft_plan_cache_is_fail_safe_and_bounded(monkeypatch):
     """`_fft_plan` (pme.py) with stand-in plans on CPU tensors: a plan that fails -- or cannot run -- its self-test is DESTROYED and the key is
-    served by torch.fft (exact), with one warning; the cache is an LRU that destroys what it evicts and re-tests what comes back."""
+    served by the dense-DFT stand-in (exact), with one warning; the cache is an LRU that destroys what it evicts and re-tests what comes back."""
     import warnings
 
     import numpy as np
@@ -426,7 +426,23 @@ def test_fft_plan_cache_is_fail_safe_and_bounded(monkeypatch):
         def destroy(self):
             log.append(("destroy", self.dims, self.inverse))
 
+    class CpuDft:  # stand-in for `_DenseDft` (whose kernels need the GPU): the same contract on CPU tensors
+        def __init__(self, dims, batch, code, inverse):
+            self.dims, self.batch, self.inverse = tuple(dims), batch, inverse
+
+        def __call__(self, src, dst):
+            nx, ny, nz = self.dims
+            if self.inverse:
+                out = torch.fft.irfftn(src.reshape(self.batch, nx, ny, nz // 2 + 1), s=self.dims, dim=(1, 2, 3), norm="forward")
+            else:
+                out = torch.fft.rfftn(src.reshape(self.batch, nx, ny, nz), dim=(1, 2, 3), norm="backward")
+            dst.view(out.shape).copy_(out)
+
+        def destroy(self):
+            pass
+
     monkeypatch.setattr(P, "_FftPlan", Fake)
+    monkeypatch.setattr(P, "_DenseDft", CpuDft)
     monkeypatch.setattr(P, "_FFT_PLANS", type(P._FFT_PLANS)())
     monkeypatch.setattr(P, "_FFT_FALLBACKS", [])
     monkeypatch.setattr(P, "_FFT_PLAN_CAP", 3)
@@ -437,7 +453,7 @@ def test_fft_plan_cache_is_fail_safe_and_bounded(monkeypatch):
             warnings.simplefilter("always")
             plan = P._fft_plan(dev, dims, 2, code, False)
             again = P._fft_plan(dev, dims, 2, code, False)
-        assert isinstance(plan, P._TorchFft) and again is plan and len(caught) == 1, [str(w.message) for w in caught]
+        assert isinstance(plan, CpuDft) and again is plan and len(caught) == 1, [str(w.message) for w in caught]
         assert ("destroy", dims, False) in log
         mesh = torch.randn((2,) + dims, generator=g, dtype=torch.float64)
         out = torch.empty((2, dims[0], dims[1], dims[2] // 2 + 1), dtype=torch.complex128)

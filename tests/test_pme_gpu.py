@@ -827,7 +827,7 @@ def test_fused_mesh_solve_support_table():
 def test_a_failing_fft_plan_is_replaced_not_used(dtype, monkeypatch):
     """Fail-safe of the library-owned hipFFT plans (round 5): every plan created here computes a WRONG transform (its
     result scaled by 1.6, injected below the self-test).  The impulse test at creation catches it, the plan is destroyed, the shape runs
-    through torch.fft -- energies and forces still equal the oracle's -- and the failure is on record.  A wrong plan is never run on user data."""
+    through the library's dense DFT (`mi_dft3d`) -- energies and forces still equal the oracle's -- and the failure is on record.  A wrong plan is never run on user data."""
     import collections
     import warnings
 
@@ -850,7 +850,7 @@ def test_a_failing_fft_plan_is_replaced_not_used(dtype, monkeypatch):
         e, f = pme_reciprocal_space(_t(pos), _t(q), _t(cell), 0.4, mesh_dimensions=dims, spline_order=order, compute_forces=True)
     msgs = [str(w.message) for w in caught if "impulse test" in str(w.message)]
     assert len(msgs) == 2 and len(P._FFT_FALLBACKS) == 2, msgs  # the R2C and the C2R plan
-    assert all(isinstance(p, P._TorchFft) for p in P._FFT_PLANS.values())
+    assert all(isinstance(p, P._DenseDft) for p in P._FFT_PLANS.values())
     ref = O.pme_reciprocal_space(pos, q, cell, 0.4, dims, order, compute_forces=True)
     _close(e, ref[0], dtype, "energies through the fallback")
     _close(f, ref[1], dtype, "forces through the fallback")
@@ -885,4 +885,64 @@ def test_fft_plan_cache_is_bounded_on_the_device(monkeypatch):
     if P._FFT_FALLBACKS:  # still correct (checked above): on record whether the rocFFT defect shows up under this churn at all
         import warnings
 
-        warnings.warn(f"hipFFT plans replaced by torch.fft under plan churn: {P._FFT_FALLBACKS}")
+        warnings.warn(f"hipFFT plans replaced by the dense DFT under plan churn: {P._FFT_FALLBACKS}")
+
+
+@pytest.mark.parametrize("dims,batch", [((8, 8, 8), 1), ((7, 11, 13), 2), ((30, 36, 45), 1), ((16, 8, 32), 3), ((32, 8, 16), 1), ((1, 5, 4), 2),
+                                        ((31, 9, 6), 4), ((64, 16, 128), 1), ((20, 18, 24), 5), ((3, 2, 1), 2), ((128, 128, 128), 1), ((257, 4, 6), 1)])
+def test_dense_dft_matches_numpy(dims, batch):
+    """`mi_dft3d` (csrc/dft.hip): the 3-D real <-> complex transform from its definition, any mesh size -- primes, odd and even last
+    dimensions, a length of one, batches -- against numpy.fft in both directions and both precisions (unscaled, like the plan path)."""
+    import ctypes  # noqa: F401
+
+    from nvalchemiops import _capi as C
+
+    nx, ny, nz = dims
+    g = np.random.default_rng(nx * 131 + ny * 17 + nz)
+    for dt, cdt, tol in ((torch.float64, torch.complex128, 2e-13), (torch.float32, torch.complex64, 2e-5)):
+        x = g.standard_normal((batch, nx, ny, nz))
+        want = np.fft.rfftn(x, axes=(1, 2, 3))
+        tx = torch.as_tensor(x, dtype=dt, device=DEV).contiguous()
+        spec = torch.empty((batch, nx, ny, nz // 2 + 1), dtype=cdt, device=DEV)
+        C.check(C.lib().mi_dft3d(C.ptr(tx), C.ptr(spec), nx, ny, nz, batch, C.dtype_code(dt), 0, C.stream_of(tx)), "mi_dft3d")
+        scale = np.abs(want).max()
+        assert np.abs(spec.cpu().numpy() - want).max() <= tol * scale * max(1.0, np.sqrt(max(dims)) / 4), (dims, dt)
+        # inverse of a Hermitian half spectrum with junk in the imaginary parts of the DC / Nyquist terms (which a C2R transform ignores)
+        s = (g.standard_normal(want.shape) + 1j * g.standard_normal(want.shape))
+        back_want = np.fft.irfftn(s, s=dims, axes=(1, 2, 3)) * (nx * ny * nz)
+        ts = torch.as_tensor(s, dtype=cdt, device=DEV).contiguous()
+        back = torch.empty((batch, nx, ny, nz), dtype=dt, device=DEV)
+        C.check(C.lib().mi_dft3d(C.ptr(ts), C.ptr(back), nx, ny, nz, batch, C.dtype_code(dt), 1, C.stream_of(ts)), "mi_dft3d")
+        assert np.abs(back.cpu().numpy() - back_want).max() <= tol * np.abs(back_want).max() * max(1.0, np.sqrt(max(dims)) / 4), (dims, dt, "inverse")
+
+
+@pytest.mark.parametrize("dims", [(20, 18, 24), (16, 8, 32), (32, 8, 16), (30, 36, 45)])
+def test_pme_through_the_dense_dft(dims, monkeypatch):
+    """NVALCHEMIOPS_PME_FFT=dft: the reciprocal-space sum with no rocFFT anywhere (spread -> mi_dft3d -> fused k-space pass -> mi_dft3d ->
+    gather), single system and a batch of three, against the oracle -- the shapes include the two for which rocFFT has returned wrong
+    transforms on this stack."""
+    import collections
+
+    from nvalchemiops.interactions.electrostatics import pme as P
+    from nvalchemiops.interactions.electrostatics import pme_reciprocal_space
+
+    monkeypatch.setattr(P, "_FFT_PLANS", collections.OrderedDict())
+    monkeypatch.setattr(P, "_FORCE_DFT", True)
+    monkeypatch.setattr(P, "_MESH_SOLVE", False)
+    for dtype in (np.float64, np.float32):
+        pos, cell, q = _system(250, dtype, triclinic=True, seed=dims[0])
+        e, f = pme_reciprocal_space(_t(pos), _t(q), _t(cell), 0.4, mesh_dimensions=dims, spline_order=4, compute_forces=True)
+        assert all(isinstance(p, P._DenseDft) for p in P._FFT_PLANS.values()) and len(P._FFT_PLANS) >= 2
+        ref = O.pme_reciprocal_space(pos, q, cell, 0.4, dims, 4, compute_forces=True)
+        _close(e, ref[0], dtype, f"energies {dims}")
+        _close(f, ref[1], dtype, f"forces {dims}")
+        pos3 = np.concatenate([pos, pos * 0.8, pos * 1.1]).astype(dtype)
+        q3 = np.concatenate([q, 2 * q, -q]).astype(dtype)
+        cells = np.stack([cell, cell * 0.8, cell * 1.1]).astype(dtype)
+        bi = np.repeat(np.arange(3, dtype=np.int32), len(pos))
+        al = np.array([0.4, 0.5, 0.35])
+        be, bf = pme_reciprocal_space(_t(pos3), _t(q3), _t(cells), torch.tensor(al, dtype=_t(pos).dtype, device=DEV), mesh_dimensions=dims,
+                                      spline_order=4, batch_idx=_t(bi), compute_forces=True)
+        bref = O.pme_reciprocal_space(pos3, q3, cells, al, dims, 4, batch_idx=bi, compute_forces=True)
+        _close(be, bref[0], dtype, f"batch energies {dims}")
+        _close(bf, bref[1], dtype, f"batch forces {dims}")
