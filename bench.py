@@ -127,8 +127,8 @@ def make_batch_step(sysd, tables, device, world, sizes):
         if need > md:
             md = D3["max_neighbors"] = (need + 63) // 64 * 64
         del trial
-        d3_bufs = (torch.empty((n, md), dtype=torch.int32, device=device), torch.empty((n, md, 3), dtype=torch.int32, device=device),
-                   torch.empty(n, dtype=torch.int32, device=device))
+        d3_bufs = list_buffers(sysd["pos32b"], D3["cutoff"], sysd["cell32b"], sysd["pbc"], md, device, batch_idx=sysd["bi"], for_dftd3=True,
+                               report=BUFFER_REPORT)
 
     def step(record=None):
         ev = []
@@ -223,6 +223,19 @@ def cu_masked_streams(device):
     return main, side
 
 
+def list_buffers(pos, cutoff, cell, pbc, m, device, batch_idx=None, for_dftd3=False, report=None):
+    """(matrix, shifts, counts) for a list the workload searches into every step: chosen among a few candidate allocations by a trial search
+    (`nvalchemiops.neighborlist.tuned_neighbor_buffers`) -- set-up, outside every timed region; BENCH_TUNED_BUFFERS=0: plain torch.empty."""
+    n = pos.shape[0]
+    if os.environ.get("BENCH_TUNED_BUFFERS", "1") == "0":
+        return (torch.empty((n, m), dtype=torch.int32, device=device), torch.empty((n, m, 3), dtype=torch.int32, device=device),
+                torch.empty(n, dtype=torch.int32, device=device))
+    from nvalchemiops.neighborlist import tuned_neighbor_buffers
+
+    return tuned_neighbor_buffers(pos, cutoff, cell, pbc, m, batch_idx=batch_idx, for_dftd3=for_dftd3,
+                                  candidates=int(os.environ.get("BENCH_BUFFER_CANDIDATES", "6")), report=report)
+
+
 def d3_branch(sysd, params, cell_list, dftd3, n, d3_bufs, between=None):
     """40-Bohr neighbour list + DFT-D3(BJ) with forces and virial, in the selected list format; `between()` is called after the
     list is enqueued (stage timing).  Returns (energy, forces, per-atom counts [matrix] or neighbor_ptr [csr])."""
@@ -273,16 +286,10 @@ def make_step(sysd, tables, device, world):
             off_s = base + (nb_j + (2 << 20) - 1) // (2 << 20) * (2 << 20)
             d3_bufs = (arena[base:base + nb_j].view(torch.int32).view(n, md), arena[off_s:off_s + nb_s].view(torch.int32).view(n, md, 3),
                        torch.empty(n, dtype=torch.int32, device=device))
-        elif os.environ.get("BENCH_TUNED_BUFFERS", "1") != "0":
+        else:
             # set-up, outside the timed region: the row buffers are chosen among a few candidate allocations by a trial search (the fill's
             # time is a property of where the driver placed them) -- what an MD code does once when it allocates its lists
-            from nvalchemiops.neighborlist import tuned_neighbor_buffers
-
-            d3_bufs = tuned_neighbor_buffers(sysd["pos32b"], D3["cutoff"], sysd["cell32b"], sysd["pbc"], md, for_dftd3=True,
-                                             candidates=int(os.environ.get("BENCH_BUFFER_CANDIDATES", "6")), report=BUFFER_REPORT)
-        else:
-            d3_bufs = (torch.empty((n, md), dtype=torch.int32, device=device), torch.empty((n, md, 3), dtype=torch.int32, device=device),
-                       torch.empty(n, dtype=torch.int32, device=device))
+            d3_bufs = list_buffers(sysd["pos32b"], D3["cutoff"], sysd["cell32b"], sysd["pbc"], md, device, for_dftd3=True, report=BUFFER_REPORT)
     gathered = [torch.zeros(2, dtype=torch.float64, device=device) for _ in range(world)] if world > 1 else None
     stage_ms = {}
     side = torch.cuda.Stream(device=device, priority=int(os.environ.get("BENCH_SIDE_PRIORITY", "0")))
@@ -908,9 +915,7 @@ def config_c2(device, args):
     tp, tc = torch.as_tensor(pos, device=device), torch.as_tensor(cell, device=device)
     pbc = torch.tensor([True] * 3, device=device)
     m = estimate_max_neighbors(rc)
-    nm = torch.empty((n, m), dtype=torch.int32, device=device)
-    sh = torch.empty((n, m, 3), dtype=torch.int32, device=device)
-    num = torch.empty(n, dtype=torch.int32, device=device)
+    nm, sh, num = list_buffers(tp, rc, tc, pbc, m, device, report=BUFFER_REPORT)
 
     def step():
         cell_list(tp, rc, tc, pbc, neighbor_matrix=nm, neighbor_matrix_shifts=sh, num_neighbors=num)
@@ -950,9 +955,7 @@ def config_c3(device, args):
     params = D3Parameters(rcov=t(tables["rcov"]), r4r2=t(tables["r4r2"]), c6ab=t(tables["c6ab"]), cn_ref=t(tables["cn_ref"]))
     tp, tz, tb, tc = t(pos), t(z), t(bi), t(cell)
     pbc = torch.zeros((nmol, 3), dtype=torch.bool, device=device)
-    nm = torch.empty((n, m), dtype=torch.int32, device=device)
-    sh = torch.empty((n, m, 3), dtype=torch.int32, device=device)
-    num = torch.empty(n, dtype=torch.int32, device=device)
+    nm, sh, num = list_buffers(tp, rc, tc, pbc, m, device, batch_idx=tb, for_dftd3=True, report=BUFFER_REPORT)
     bj = dict(a1=D3["a1"], a2=D3["a2"], s8=D3["s8"])
 
     def step():
@@ -998,9 +1001,7 @@ def config_c4(device, args):
     n = 100000
     sysd, _ = build_system(n, 1234, device)
     m, mesh = PME["max_neighbors"], float(np.prod(PME["mesh"]))
-    nm = torch.empty((n, m), dtype=torch.int32, device=device)
-    sh = torch.empty((n, m, 3), dtype=torch.int32, device=device)
-    num = torch.empty(n, dtype=torch.int32, device=device)
+    nm, sh, num = list_buffers(sysd["pos64"], PME["cutoff"], sysd["cell64"], sysd["pbc"], m, device, report=BUFFER_REPORT)
 
     def step():
         cell_list(sysd["pos64"], PME["cutoff"], sysd["cell64"], sysd["pbc"], neighbor_matrix=nm, neighbor_matrix_shifts=sh, num_neighbors=num)
@@ -1052,7 +1053,9 @@ def run_config(name, device, args):
     res = {"metric": f"atom-steps/sec of BASELINE config {name[1]} (one pass of its hot path per step)", "value": n * args.steps / elapsed,
            "unit": "atom-steps/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": cfg["dtype"], "data": "synthetic",
-           "config": {"workload": cfg["workload"], "atoms_per_gpu": n, **cfg["extra"](out)},
+           "config": {"workload": cfg["workload"], "atoms_per_gpu": n, **cfg["extra"](out),
+                      "list_buffers": ({"selection": "tuned_neighbor_buffers (fastest candidate by a trial search at set-up, untimed)", **BUFFER_REPORT}
+                                       if BUFFER_REPORT else "torch.empty")},
            "stats": {"step_ms_median": statistics.median(step_ms), "step_ms_min": min(step_ms), "step_ms_max": max(step_ms), "timed_region_s": elapsed},
            "roofline": roof, "calibration": calibration, "kernels": rows}
     if os.environ.get("BENCH_GRAPH", "0") == "1":

@@ -53,6 +53,12 @@ def tuned_neighbor_buffers(positions: torch.Tensor, cutoff: float, cell: torch.T
         if report is not None:
             report.update(candidates=1, chosen=0, trial_ms=[])
         return bufs
+    # never more candidates than half of the free device memory holds (a set is 16 B/slot + 4 B/slot of companion)
+    try:
+        free_bytes, _ = torch.cuda.mem_get_info(dev)
+        candidates = max(1, min(int(candidates), int(0.5 * free_bytes // (20 * n * m + 1))))
+    except Exception:
+        pass
     sets, times = [], []
     for _ in range(int(candidates)):  # all candidates stay alive until the choice is made: each one is distinct memory
         bufs = fresh()
