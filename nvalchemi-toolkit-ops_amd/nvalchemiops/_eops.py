@@ -82,6 +82,78 @@ def seg_sum(x: Tensor, batch_idx: Optional[Tensor], num_systems: int) -> Tensor:
 
 
 # =====================================================================================================================================
+# guarded mesh FFTs (round 5): rfftn / irfftn of the op-by-op composition through the library's self-tested plan cache
+# =====================================================================================================================================
+# The composition (pme._reciprocal_composed: what runs under torch.compile and for the outputs the fused autograd node does not cover)
+# used to call torch.fft directly, as the reference does (pme.py:1398, :1422, :1455-1457).  rocFFT on this stack can return a wrong
+# transform for some mesh shapes depending on what the process planned before -- through torch.fft too (DESIGN.md 3.7) -- so these two ops
+# route the same unscaled transforms through `pme._fft_plan`: a hipFFT plan that reproduced a known answer at creation, or the library's
+# dense DFT when it did not.  Each is the other's adjoint up to the half-spectrum weights, so first and higher derivatives stay ops.
+def _half_weights(nz: int, like: Tensor, interior: float) -> Tensor:
+    """[nz/2+1] real weights: `interior` for the bins that stand for two conjugate frequencies, 1 for the self-conjugate ones (DC, Nyquist)."""
+    w = torch.full((nz // 2 + 1,), interior, dtype=like.real.dtype if like.is_complex() else like.dtype, device=like.device)
+    w[0] = 1.0
+    if nz % 2 == 0:
+        w[-1] = 1.0
+    return w
+
+
+def _mesh_rfftn(mesh: Tensor) -> Tensor:
+    from nvalchemiops.interactions.electrostatics import pme as P
+
+    m = mesh.detach().contiguous()
+    b, nx, ny, nz = m.shape
+    out = torch.empty((b, nx, ny, nz // 2 + 1), dtype=torch.complex64 if m.dtype == torch.float32 else torch.complex128, device=m.device)
+    P._fft_plan(m.device, (nx, ny, nz), b, C.dtype_code(m.dtype), False)(m.clone(), out)  # (an R2C transform may use its input as scratch)
+    return out
+
+
+def _mesh_irfftn(spec: Tensor, nz: int) -> Tensor:
+    from nvalchemiops.interactions.electrostatics import pme as P
+
+    sp = spec.detach().contiguous().clone()  # the multi-dimensional C2R consumes its input
+    b, nx, ny, _ = sp.shape
+    rdt = torch.float32 if sp.dtype == torch.complex64 else torch.float64
+    out = torch.empty((b, nx, ny, int(nz)), dtype=rdt, device=sp.device)
+    P._fft_plan(sp.device, (nx, ny, int(nz)), b, C.dtype_code(rdt), True)(sp, out)
+    return out
+
+
+mesh_rfftn_op = torch.library.custom_op("nvalchemiops::mesh_rfftn", _mesh_rfftn, mutates_args=())
+mesh_rfftn_op.register_fake(lambda mesh: mesh.new_empty(tuple(mesh.shape[:3]) + (mesh.shape[3] // 2 + 1,),
+                                                         dtype=torch.complex64 if mesh.dtype == torch.float32 else torch.complex128))
+mesh_irfftn_op = torch.library.custom_op("nvalchemiops::mesh_irfftn", _mesh_irfftn, mutates_args=())
+mesh_irfftn_op.register_fake(lambda spec, nz: spec.new_empty(tuple(spec.shape[:3]) + (int(nz),),
+                                                             dtype=torch.float32 if spec.dtype == torch.complex64 else torch.float64))
+
+
+def _mesh_rfftn_bwd(ctx, g):
+    # y_k = sum_n x_n e^{-ikn} over the half spectrum: dL/dx_n = Re sum_k g_k e^{+ikn} with every stored bin counted ONCE -- the C2R
+    # transform counts the interior bins twice, hence the 1/2
+    return mesh_irfftn_op(g * _half_weights(ctx.nz, g, 0.5), ctx.nz)
+
+
+def _mesh_irfftn_bwd(ctx, g):
+    # x_n = sum_k c_k Re(y_k e^{+ikn}), c = 2 for the interior bins: dL/dy_k = c_k (R2C g)_k
+    spec = mesh_rfftn_op(g)
+    return spec * _half_weights(ctx.nz, spec, 2.0), None
+
+
+mesh_rfftn_op.register_autograd(_mesh_rfftn_bwd, setup_context=lambda ctx, inputs, output: setattr(ctx, "nz", int(inputs[0].shape[3])))
+mesh_irfftn_op.register_autograd(_mesh_irfftn_bwd, setup_context=lambda ctx, inputs, output: setattr(ctx, "nz", int(inputs[1])))
+
+
+def mesh_rfftn(mesh: Tensor) -> Tensor:
+    """Unscaled rfftn over the last three dimensions of a [nx, ny, nz] or [B, nx, ny, nz] mesh (torch.fft.rfftn(norm="backward"))."""
+    return mesh_rfftn_op(mesh.unsqueeze(0)).squeeze(0) if mesh.dim() == 3 else mesh_rfftn_op(mesh)
+
+
+def mesh_irfftn(spec: Tensor, nz: int) -> Tensor:
+    """Unscaled irfftn over the last three dimensions (torch.fft.irfftn(norm="forward", s=(nx, ny, nz)))."""
+    return mesh_irfftn_op(spec.unsqueeze(0), nz).squeeze(0) if spec.dim() == 3 else mesh_irfftn_op(spec, nz)
+
+
+# =====================================================================================================================================
 # B-spline spread / gather
 # =====================================================================================================================================
 def _spread_impl(positions, values, batch_idx, cit, nsys, dims, order):

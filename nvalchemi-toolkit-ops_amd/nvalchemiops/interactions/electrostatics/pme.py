@@ -616,7 +616,12 @@ def _reciprocal_composed(positions, charges, cells, alpha, mesh_dimensions, spli
         mesh = O._batch_spline_spread(positions, q, batch_idx, cc, nsys, nx, ny, nz, order, cit)
     else:
         mesh = O._spline_spread(positions, q, cc[0], nx, ny, nz, order, cit[:1])
-    spec = torch.fft.rfftn(mesh, norm="backward", dim=fdims)  # unscaled forward (pme.py:1398)
+    # the FFTs go through the library's self-tested plans / dense DFT (`nvalchemiops::mesh_rfftn` / `::mesh_irfftn`, _eops.py), not through
+    # torch.fft as in the reference: rocFFT's wrong-transform defect reaches torch.fft as well
+    guarded = _OWN_FFT and positions.is_cuda
+    rfftn = _eops.mesh_rfftn if guarded else (lambda m: torch.fft.rfftn(m, norm="backward", dim=fdims))
+    irfftn = (lambda sp: _eops.mesh_irfftn(sp, nz)) if guarded else (lambda sp: torch.fft.irfftn(sp, norm="forward", s=(nx, ny, nz), dim=fdims))
+    spec = rfftn(mesh)  # unscaled forward (pme.py:1398)
     if k_vectors is None or k_squared is None:
         k_vectors, k_squared = generate_k_vectors_pme(cc if batched else cc[0], (nx, ny, nz), reciprocal_cell=TWOPI * (cell_inv if batched else cell_inv[:1]))
     k_squared = k_squared.to(dt)
@@ -629,7 +634,7 @@ def _reciprocal_composed(positions, charges, cells, alpha, mesh_dimensions, spli
         k2, kv = k_squared.reshape(nx, ny, nz // 2 + 1), k_vectors.reshape(nx, ny, nz // 2 + 1, 3)
         green, sf2 = O._pme_green_structure_factor(k2.contiguous(), mx, my, mz, al[:1], vol[:1], nx, ny, nz, order)
     conv = spec / sf2 * green                                                                   # pme.py:1418-1419
-    phi = torch.fft.irfftn(conv, norm="forward", s=(nx, ny, nz), dim=fdims).to(dt)             # unscaled inverse (pme.py:1422)
+    phi = irfftn(conv).to(dt)                                                                   # unscaled inverse (pme.py:1422)
     if batched:
         raw = O._batch_spline_gather(positions, phi, batch_idx, cc, order, cit)
         qtot = torch.zeros(nsys, dtype=dt, device=dev).index_add(0, batch_idx.long(), q)
@@ -642,7 +647,7 @@ def _reciprocal_composed(positions, charges, cells, alpha, mesh_dimensions, spli
     energies, cgrads = corr if compute_charge_gradients else (corr, None)
     forces = None
     if compute_forces:
-        comps = [torch.fft.irfftn(-1j * kv[..., d] * conv, norm="forward", s=(nx, ny, nz), dim=fdims) for d in range(3)]
+        comps = [irfftn(-1j * kv[..., d] * conv) for d in range(3)]
         field = torch.stack(comps, dim=-1).to(dt)
         if batched:
             forces = 2.0 * O._batch_spline_gather_vec3(positions, q, field, batch_idx, cc, order, cit)

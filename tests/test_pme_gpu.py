@@ -946,3 +946,47 @@ def test_pme_through_the_dense_dft(dims, monkeypatch):
         bref = O.pme_reciprocal_space(pos3, q3, cells, al, dims, 4, batch_idx=bi, compute_forces=True)
         _close(be, bref[0], dtype, f"batch energies {dims}")
         _close(bf, bref[1], dtype, f"batch forces {dims}")
+
+
+@pytest.mark.parametrize("dims,batch", [((8, 6, 10), 1), ((7, 11, 13), 2), ((16, 8, 32), 1), ((20, 18, 24), 3), ((5, 4, 9), 1)])
+def test_guarded_fft_ops_and_their_adjoints_equal_torch_fft(dims, batch):
+    """`nvalchemiops::mesh_rfftn` / `::mesh_irfftn` (the composition's FFTs since round 5: self-tested plans or the dense DFT instead of a
+    direct torch.fft call): values, first derivatives and a second derivative against torch.fft's own, even and odd last dimensions."""
+    from nvalchemiops import _eops as E
+
+    nx, ny, nz = dims
+    g = torch.Generator(device=DEV).manual_seed(nx * 7 + nz)
+    for dt, cdt, tol in ((torch.float64, torch.complex128, 1e-11), (torch.float32, torch.complex64, 2e-4)):
+        x = torch.randn((batch, nx, ny, nz), dtype=dt, device=DEV, generator=g)
+        wr = torch.randn((batch, nx, ny, nz // 2 + 1), dtype=dt, device=DEV, generator=g)
+        wi = torch.randn((batch, nx, ny, nz // 2 + 1), dtype=dt, device=DEV, generator=g)
+        w = torch.complex(wr, wi)
+        xs = torch.randn((batch, nx, ny, nz), dtype=dt, device=DEV, generator=g)
+
+        def loss_r2c(fft, inp):
+            y = fft(inp)
+            return (y * w).real.sum() + (y.abs() ** 2).sum() * 0.01  # linear + quadratic: the second derivative is not identically zero
+
+        def loss_c2r(ifft, sp):
+            return (ifft(sp) * xs).sum() + (ifft(sp) ** 2).sum() * 0.01
+
+        a = x.clone().requires_grad_(True)
+        b = x.clone().requires_grad_(True)
+        la = loss_r2c(E.mesh_rfftn, a)
+        lb = loss_r2c(lambda m: torch.fft.rfftn(m, norm="backward", dim=(1, 2, 3)), b)
+        (ga,), (gb,) = torch.autograd.grad(la, a, create_graph=True), torch.autograd.grad(lb, b, create_graph=True)
+        scale = float(gb.detach().abs().max())
+        assert abs(float(la.detach()) - float(lb.detach())) <= tol * abs(float(lb.detach())) + tol and float((ga - gb).detach().abs().max()) <= tol * scale, (dims, dt, "r2c")
+        (ha,), (hb,) = torch.autograd.grad((ga * xs).sum(), a), torch.autograd.grad((gb * xs).sum(), b)
+        assert float((ha - hb).abs().max()) <= tol * max(float(hb.abs().max()), 1.0), (dims, dt, "r2c second derivative")
+
+        s0 = torch.fft.rfftn(x, norm="backward", dim=(1, 2, 3)) + w  # a generic half spectrum (not Hermitian-consistent: C2R semantics matter)
+        a = s0.clone().requires_grad_(True)
+        b = s0.clone().requires_grad_(True)
+        la = loss_c2r(lambda sp: E.mesh_irfftn(sp, nz), a)
+        lb = loss_c2r(lambda sp: torch.fft.irfftn(sp, norm="forward", s=dims, dim=(1, 2, 3)), b)
+        (ga,), (gb,) = torch.autograd.grad(la, a, create_graph=True), torch.autograd.grad(lb, b, create_graph=True)
+        assert abs(float(la.detach()) - float(lb.detach())) <= tol * abs(float(lb.detach())) + tol, (dims, dt, "c2r value")
+        assert float((ga - gb).detach().abs().max()) <= tol * float(gb.detach().abs().max()), (dims, dt, "c2r")
+        (ha,), (hb,) = torch.autograd.grad((ga * w.conj()).real.sum(), a), torch.autograd.grad((gb * w.conj()).real.sum(), b)
+        assert float((ha - hb).abs().max()) <= tol * max(float(hb.abs().max()), 1.0), (dims, dt, "c2r second derivative")
