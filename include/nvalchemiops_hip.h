@@ -348,6 +348,9 @@ int mi_spline_spread(const void* positions, const void* values, const int32_t* b
  * binned by ex*ey*ez mesh tile, LDS accumulation, every mesh point written once, no global atomics); otherwise order^2 threads per
  * atom add into the zeroed mesh.                                                                                               */
 size_t mi_spline_spread_workspace_bytes(int n_atoms, int n_systems, int nx, int ny, int nz);
+/* The exact size for one (order, dtype): the tile-box scratch, by far the largest part, is (e + order - 1)^3 values of the mesh dtype per
+ * tile instead of the any-order fp64 bound above (256^3, fp32, order 4: 178 MB instead of 576).  mi_spline_spread accepts either size.   */
+size_t mi_spline_spread_workspace_bytes_for(int n_atoms, int n_systems, int nx, int ny, int nz, int order, int dtype);
 /* byte offset, inside the workspace mi_spline_spread was given, of int32[4 + n_atoms] that the tile-owned spread leaves behind (valid until
  * the workspace is reused): [0] = number of consecutive atom pairs (i, i+1) that sit in neither the same nor neighbouring mesh tiles (a
  * measure of how spatially incoherent the caller's atom order is), [1..3] unused, [4..] = the atom ids grouped by mesh tile.
@@ -391,6 +394,10 @@ int mi_fft_plan_create(int nx, int ny, int nz, int batch, int dtype, int inverse
 size_t mi_fft_plan_work_bytes(const void* plan);
 int mi_fft_plan_exec(void* plan, void* in, void* out, void* stream);
 int mi_fft_plan_destroy(void* plan);
+
+/* hipFFT versions as major * 10000 + minor * 100 + patch: compiled-against and loaded at run time (they can differ inside a Python process,
+ * where torch has already loaded its own copy of the same SONAME).                                                                  */
+int mi_fft_library_versions(int* compiled, int* loaded);
 
 /* ---- dense DFT (csrc/dft.hip) -------------------------------------------------------------------------------------------
  * The same transforms as mi_fft_plan_exec -- real [batch][nx][ny][nz] <-> complex [batch][nx][ny][nz/2+1], both directions unscaled --

@@ -15,7 +15,8 @@ CSRC = os.path.join(HERE, "csrc")
 OUT_DIR = os.path.join(HERE, "nvalchemiops", "lib")
 LIB = os.path.join(OUT_DIR, "libnvalchemiops_hip.so")
 LIB_D3_IEEE = os.path.join(OUT_DIR, "libnvalchemiops_d3_ieee.so")
-HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+ROCM = os.environ.get("ROCM_PATH", "/opt/rocm")  # the one ROCm installation headers, compiler and link-time libraries come from
+HIPCC = os.environ.get("HIPCC", os.path.join(ROCM, "bin", "hipcc"))
 ARCH = "gfx950"
 
 # per-file extra flags.  nlist.hip must evaluate the cutoff test exactly like the oracle: no FMA contraction.
@@ -78,7 +79,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
     if force or jobs or _stale(LIB, objs):
         # libhipfft.so.0: inside a Python process torch has loaded its own copy of that SONAME already (same rocFFT the torch.fft path
         # used); a plain C caller resolves it from the ROCm installation
-        run([HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs + ["-L/opt/rocm/lib", "-lhipfft"])
+        run([HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs + ["-L" + os.path.join(ROCM, "lib"), "-lhipfft"])
     if force or _stale(LIB_D3_IEEE, [ieee_obj, os.path.join(build_dir, "capi.o")]):
         run([HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB_D3_IEEE, ieee_obj, os.path.join(build_dir, "capi.o")])
     return LIB

@@ -12,6 +12,7 @@
 // and is capturable in a HIP graph.  A plan is bound to the device that was current at creation.
 #include <hip/hip_runtime_api.h>
 #include <hipfft/hipfft.h>
+#include <hipfft/hipfft-version.h>
 #include <stddef.h>
 #include <stdlib.h>
 #include <string.h>
@@ -89,6 +90,17 @@ int mi_fft_plan_create(int nx, int ny, int nz, int batch, int dtype, int inverse
     return MI_EHIP;
   }
   *plan_out = p;
+  return MI_OK;
+}
+
+/* hipFFT versions: [0] the headers this library was compiled against, [1] the library loaded at run time (inside a Python process that is
+ * torch's bundled libhipfft, the same rocFFT torch.fft uses).  A mismatch of the major version is worth a warning at import. */
+int mi_fft_library_versions(int* compiled, int* loaded) {
+  if (compiled) *compiled = hipfftVersionMajor * 10000 + hipfftVersionMinor * 100 + hipfftVersionPatch;
+  if (loaded) {
+    *loaded = 0;
+    MI_FFT_CHECK(hipfftGetVersion(loaded));
+  }
   return MI_OK;
 }
 

@@ -187,7 +187,11 @@ static int sp_edge(int n) { for (int e = SP_T; e > 1; --e) if (n % e == 0) retur
 static SpTile sp_tile(int nx, int ny, int nz) { return SpTile{sp_edge(nx), sp_edge(ny), sp_edge(nz)}; }
 
 struct SpLayout { size_t keys_in, vals_out, bin_start, lo3, theta, bins, boxes, total; long long nbins; };
-static SpLayout sp_layout(int N, int B, int nx, int ny, int nz) {
+// `order` / `elem_bytes`: what the box scratch -- the last and by far the largest field -- is sized for.  The defaults (largest order, fp64)
+// give the size every run fits in (mi_spline_spread_workspace_bytes); an actual (order, dtype) gives the exact size
+// (mi_spline_spread_workspace_bytes_for): (e + order - 1)^3 values of the mesh dtype per tile instead of (e + 5)^3 doubles -- a 256^3 fp32
+// order-4 mesh needs 178 MB of boxes instead of 576.  All other offsets do not depend on either.
+static SpLayout sp_layout(int N, int B, int nx, int ny, int nz, int order = MI_MAX_ORDER, size_t elem_bytes = sizeof(double)) {
   SpLayout L;
   size_t o = 0;
   auto take = [&](size_t b) { size_t at = o; o += mi_align(b); return at; };
@@ -199,8 +203,9 @@ static SpLayout sp_layout(int N, int B, int nx, int ny, int nz) {
   L.lo3 = take(sizeof(int) * 4 * (size_t)N);                       // first stencil index per axis (wrapped) + system, per atom
   L.theta = take(sizeof(double) * 3 * (size_t)N);                  // fractional offset inside the mesh cell per axis, [3][N] (sized for fp64)
   L.bins = take(sizeof(int) * bs_scratch_ints(L.nbins + 1));  // counting-sort counters (binsort.h)
-  // per-tile accumulation boxes of the two-phase spread: (e + MI_MAX_ORDER - 1)^3 points per tile (sized for fp64 and the largest order)
-  L.boxes = take(sizeof(double) * (size_t)L.nbins * (e.ex + MI_MAX_ORDER - 1) * (e.ey + MI_MAX_ORDER - 1) * (e.ez + MI_MAX_ORDER - 1));
+  // per-tile accumulation boxes of the two-phase spread: (e + order - 1)^3 points per tile
+  if (order < 1 || order > MI_MAX_ORDER) order = MI_MAX_ORDER;
+  L.boxes = take(elem_bytes * (size_t)L.nbins * (e.ex + order - 1) * (e.ey + order - 1) * (e.ez + order - 1));
   L.total = o;
   return L;
 }
@@ -1205,6 +1210,14 @@ size_t mi_spline_spread_workspace_bytes(int n_atoms, int n_systems, int nx, int 
   return sp_layout(n_atoms, n_systems, nx, ny, nz).total;
 }
 
+size_t mi_spline_spread_workspace_bytes_for(int n_atoms, int n_systems, int nx, int ny, int nz, int order, int dtype) {
+  if (n_atoms < 0 || n_systems < 1 || nx <= 0 || ny <= 0 || nz <= 0 || (dtype != MI_F32 && dtype != MI_F64)) return 0;
+  const OrderArg oa = decode_order(order);
+  if (oa.order < 1 || oa.order > MI_MAX_ORDER) return 0;
+  if (oa.ref_zero || !sp_tiled_ok(nx, ny, nz, n_systems, oa.order)) return 256;
+  return sp_layout(n_atoms, n_systems, nx, ny, nz, oa.order, dtype_bytes(dtype)).total;
+}
+
 int mi_spline_spread(const void* positions, const void* values, const int32_t* batch_idx, const void* cell_inv_t, int n_atoms, int n_systems,
                      int nx, int ny, int nz, int order, int batched, int dtype, void* mesh, void* workspace, size_t workspace_bytes,
                      void* stream) {
@@ -1222,7 +1235,7 @@ int mi_spline_spread(const void* positions, const void* values, const int32_t* b
   }
   mi_timing_begin("spline_spread", stream);
   int rc = MI_OK;
-  if (workspace && sp_tiled_ok(nx, ny, nz, n_systems, order) && workspace_bytes >= sp_layout(n_atoms, n_systems, nx, ny, nz).total) {
+  if (workspace && sp_tiled_ok(nx, ny, nz, n_systems, order) && workspace_bytes >= sp_layout(n_atoms, n_systems, nx, ny, nz, order, dtype_bytes(dtype)).total) {
     if (dtype == MI_F32)
       rc = spread_tiled<float>((const float*)positions, (const float*)values, batch_idx, (const float*)cell_inv_t, n_atoms, n_systems, nx, ny, nz,
                                order, batched, (float*)mesh, (char*)workspace, st);

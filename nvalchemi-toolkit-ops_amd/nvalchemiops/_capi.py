@@ -47,6 +47,8 @@ def lib() -> ctypes.CDLL:
         L.mi_pme_solve_scratch_bytes.restype = ctypes.c_size_t
         L.mi_pme_solve_scratch_bytes.argtypes = [ctypes.c_int] * 6
         L.mi_spline_spread_workspace_bytes.argtypes = [ctypes.c_int] * 5
+        L.mi_spline_spread_workspace_bytes_for.restype = ctypes.c_size_t
+        L.mi_spline_spread_workspace_bytes_for.argtypes = [ctypes.c_int] * 7
         L.mi_spline_spread_order_offset.restype = ctypes.c_longlong
         L.mi_spline_spread_order_offset.argtypes = [ctypes.c_int] * 6
         L.mi_nl_packed_bytes.restype = ctypes.c_size_t

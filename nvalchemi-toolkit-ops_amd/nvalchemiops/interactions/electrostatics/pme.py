@@ -262,6 +262,28 @@ _MESH_SOLVE = {"0": False, "1": True}.get(os.environ.get("NVALCHEMIOPS_PME_MESH_
 _SOLVE_AUTOGRAD = os.environ.get("NVALCHEMIOPS_PME_SOLVE_AUTOGRAD", "1") != "0"
 
 
+_FFT_VERSION_CHECKED = False
+
+
+def _check_fft_library_once() -> None:
+    """First use of a hipFFT plan: warn when the hipFFT loaded into this process (torch's bundled copy wins the SONAME) is another major
+    version than the headers the library was compiled against.  Results are still guarded by the per-plan self-test."""
+    global _FFT_VERSION_CHECKED
+    if _FFT_VERSION_CHECKED:
+        return
+    _FFT_VERSION_CHECKED = True
+    import ctypes
+    import warnings
+
+    try:
+        comp, load = ctypes.c_int(0), ctypes.c_int(0)
+        if C.lib().mi_fft_library_versions(ctypes.byref(comp), ctypes.byref(load)) == 0 and comp.value // 10000 != load.value // 10000:
+            warnings.warn(f"hipFFT {load.value} is loaded but libnvalchemiops_hip.so was compiled against {comp.value}; plans are self-tested, "
+                          "a failing one is replaced by the dense DFT")
+    except Exception:
+        pass
+
+
 def _fft_plan(device: torch.device, dims, batch: int, code: int, inverse: bool):
     """Plan cache (see `_FFT_PLANS`).  Plans are created outside any HIP-graph capture (creation allocates the work area); a step that is
     captured must have run once eagerly -- as every capture recipe does for its warm-up.  FAIL-SAFE: a new plan that does not reproduce the
@@ -281,6 +303,7 @@ def _fft_plan(device: torch.device, dims, batch: int, code: int, inverse: bool):
     if _FORCE_DFT:
         plan = _FFT_PLANS[key] = _DenseDft(dims, batch, code, inverse)
         return plan
+    _check_fft_library_once()
     plan = _FftPlan(dims, batch, code, inverse)
     if _FFT_SELFTEST:
         ok, detail = plan.self_test(device, dims, batch, code, inverse)

@@ -86,7 +86,7 @@ def _launch_spread(pos, vals, cit, bi, nsys, dims, order, batched, want_order=Fa
     else:
         tiled = _SPREAD_PATH == "tile" and n > 0 and bool(C.lib().mi_spline_spread_is_tiled(nsys, nx, ny, nz, C.spline_order_arg(order)))
     mesh = (torch.empty if tiled else torch.zeros)((nsys, nx, ny, nz), dtype=pos.dtype, device=pos.device)
-    ws_bytes = int(C.lib().mi_spline_spread_workspace_bytes(n, nsys, nx, ny, nz)) if tiled else 0
+    ws_bytes = int(C.lib().mi_spline_spread_workspace_bytes_for(n, nsys, nx, ny, nz, C.spline_order_arg(order), C.dtype_code(pos.dtype))) if tiled else 0
     ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=pos.device)
     rc = C.lib().mi_spline_spread(C.ptr(pos), C.ptr(vals), C.ptr(bi), C.ptr(cit), n, nsys, nx, ny, nz, C.spline_order_arg(order), int(batched),
                                   C.dtype_code(pos.dtype), C.ptr(mesh), C.ptr(ws), ctypes.c_size_t(ws_bytes), C.stream_of(pos))

@@ -511,3 +511,20 @@ def test_packed_companion_validity_rules():
     setattr(nm, E._PACKED_ATTR, E.PackedCompanion(words, nm, sh, 6))
     del sh
     assert E.packed_companion(nm, torch.zeros((6, 4, 3), dtype=torch.int32), 6) is None
+
+
+def test_spread_workspace_is_sized_for_the_order_and_dtype_it_serves():
+    """`mi_spline_spread_workspace_bytes_for`: the tile-box scratch scales with (e + order - 1)^3 and the mesh dtype; the
+    any-order fp64 bound of `mi_spline_spread_workspace_bytes` is its maximum (host arithmetic, no GPU)."""
+    from nvalchemiops import _capi as C
+
+    L = C.lib()
+    n, b, dims = 100000, 1, (256, 256, 256)
+    full = int(L.mi_spline_spread_workspace_bytes(n, b, *dims))
+    sizes = {(o, dt): int(L.mi_spline_spread_workspace_bytes_for(n, b, *dims, o, dt)) for o in (3, 4, 5, 6) for dt in (C.MI_F32, C.MI_F64)}
+    assert sizes[(6, C.MI_F64)] == full
+    assert all(v <= full for v in sizes.values())
+    assert sizes[(4, C.MI_F32)] < 0.4 * full and sizes[(5, C.MI_F64)] < 0.85 * full
+    assert sizes[(4, C.MI_F32)] < sizes[(4, C.MI_F64)] < sizes[(5, C.MI_F64)] < sizes[(6, C.MI_F64)]
+    assert int(L.mi_spline_spread_workspace_bytes_for(n, b, *dims, 4 | C.SPLINE_REFERENCE_ORDERS, C.MI_F32)) == sizes[(4, C.MI_F32)]
+    assert int(L.mi_spline_spread_workspace_bytes_for(n, b, 31, 29, 37, 4, C.MI_F64)) == 256  # prime dimensions: the atomic kernel, no scratch
