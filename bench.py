@@ -59,7 +59,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 VALU_PEAK_GINSTR = 256 * 4 * 2.4 / 2.0
 # VALU wave-instructions per launch of the VALU-bound kernels on the headline box, from the committed SQ_INSTS_VALU pass
 # (profiles/: counters cannot be read from inside the timed run)
-VALU_PROFILE = next((p for p in (os.path.join(ROOT, "profiles", n) for n in ("r04_pmc_valu.json", "r03_pmc_valu.json", "r02_pmc_valu.json")) if os.path.exists(p)),
+VALU_PROFILE = next((p for p in (os.path.join(ROOT, "profiles", n) for n in ("r05_pmc_valu.json", "r04_pmc_valu.json", "r03_pmc_valu.json", "r02_pmc_valu.json")) if os.path.exists(p)),
                     os.path.join(ROOT, "profiles", "r04_pmc_valu.json"))
 PME = dict(cutoff=9.0, alpha=0.35, mesh=(128, 128, 128), order=5, max_neighbors=256)
 D3 = dict(cutoff=40.0, a1=0.4289, a2=4.4407, s8=0.7875, max_neighbors=2560)  # row width: explicit, as in the reference's own
@@ -407,7 +407,7 @@ def profile_lookup(path: str, kernel: str, field: str, atoms: int, workload: str
 
 
 def traffic_profile():
-    for name in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+    for name in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
         path = os.path.join(ROOT, "profiles", name)
         if os.path.exists(path):
             return path
@@ -874,9 +874,17 @@ def _graph_replay(step, steps):
         return {"captured": False, "error": f"{type(exc).__name__}: {exc}"[:300]}
 
 
-def _config_rows(kernels, acct):
-    """Kernel table of a config workload: every timed kernel with its in-step average and, where `acct` prices it, SURVEY 8(d) bytes."""
+def _config_rows(kernels, acct, workload=None):
+    """Kernel table of a config workload: every timed kernel with its in-step average and, where `acct` prices it, SURVEY 8(d) bytes;
+    `traffic_bytes` from the committed PMC summary of the same workload (profiles/r05_pmc_traffic_<workload>.json) when there is one."""
     rows = {}
+    tfile = os.path.join(ROOT, "profiles", f"r05_pmc_traffic_{workload}.json") if workload else ""
+    traffic = {}
+    if tfile and os.path.exists(tfile):
+        try:
+            traffic = json.load(open(tfile)).get("kernels", {})
+        except Exception:
+            traffic = {}
     for name, (cnt, tot, med, lo, hi) in sorted(kernels.items()):
         bound, algo, note = acct.get(name, ("latency", None, ""))
         row = {"launches": cnt, "avg_ms_timed_region": tot / cnt, "median_ms_timed_region": med, "isolated_median_ms": None, "bound": bound,
@@ -886,6 +894,8 @@ def _config_rows(kernels, acct):
             row["frac_of_hbm_peak"] = row["algorithmic_GBps"] / HBM_PEAK_GBS
         if note:
             row["note"] = note
+        if name in traffic and traffic[name].get("hbm_bytes_per_launch") is not None:
+            row["traffic_bytes"], row["traffic_from_profile"] = traffic[name]["hbm_bytes_per_launch"], os.path.relpath(tfile, ROOT)
         rows[name] = row
     return rows
 
@@ -1044,7 +1054,7 @@ def run_config(name, device, args):
     cfg = {"c2": config_c2, "c3": config_c3, "c4": config_c4}[name](device, args)
     calibration = hbm_calibration(device, gib=1.0) if os.environ.get("BENCH_CALIB", "1") != "0" else None
     out, elapsed, step_ms, kernels = _timed_steps(cfg["step"], args.steps, args.warmup)
-    rows = _config_rows(kernels, cfg["acct"])
+    rows = _config_rows(kernels, cfg["acct"], name)
     roof = roofline_of({k: v for k, v in rows.items() if v.get("algorithmic_bytes")} or rows)
     if roof and calibration and roof.get("achieved") and roof["bound"] == "hbm":
         roof["frac_of_box_fill"] = roof["achieved"] / calibration["fill_GBps"]
@@ -1448,6 +1458,7 @@ def main():
                 moved = result["roofline"]["design_bytes_per_launch"] / (result["roofline"]["launch_ms"] * 1e-3) / 1e9
                 result["roofline"]["moved_GBps"] = moved
                 result["roofline"]["moved_frac_of_box_copy"] = moved / calibration["copy_GBps"]
+                result["roofline"]["moved_frac_of_box_fill"] = moved / calibration["fill_GBps"]  # the list kernels only write
         if world == 1 and args.cpu_sample > 0:
             result["cpu_baseline"] = cpu_baseline(args.cpu_sample, args.cpu_full_size)
             add_parity(result)

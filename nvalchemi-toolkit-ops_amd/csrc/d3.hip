@@ -368,11 +368,13 @@ __device__ __forceinline__ int d3_lockstep_trips(long long beg, long long end) {
 }
 
 // ---- pass 1: coordination numbers ------------------------------------------------------------------
+// (round 5, with the 4 B/slot companion as input the pass is all gather: 3 / 2 instead of 2 / 1 is worth 0.487 -> 0.472 ms on the headline
+// list, 4 / 2 the same, 8 lock-step waves still beat 4 and 16: profiles/r05_ab_cn_pipeline.log)
 #ifndef D3_CN_DS
-#define D3_CN_DS 2  // trips of index / shift words in flight ahead of the one being evaluated
+#define D3_CN_DS 3  // trips of index / shift words in flight ahead of the one being evaluated
 #endif
 #ifndef D3_CN_DG
-#define D3_CN_DG 1  // trips of gathered atom records in flight (<= D3_CN_DS)
+#define D3_CN_DG 2  // trips of gathered atom records in flight (<= D3_CN_DS)
 #endif
 // PKIN (round 5): the rows are read from a packed companion the neighbour search wrote next to the matrix (`mi_nl_neighbors_packed`, 4 B/slot,
 // same word format as the copy this pass otherwise writes) instead of the 16 B/slot API arrays.  `gate_flag` / `gate_want`: the launch does

@@ -21,5 +21,15 @@ for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_AN
   python $R/tools/rocpd_pmc.py $(find /tmp/prof_$tag -name "*.db" | head -1) $OUT/pmc_$tag.csv 2>&1 | tail -2
 done
 python $R/tools/pmc_traffic.py $OUT/pmc_FETCH_SIZE.csv $OUT/pmc_WRITE_SIZE.csv $OUT/pmc_traffic.json
+# config 4 (the electrostatics branch alone): kernel stats + traffic of the solve / spread / gather kernels
+rm -rf /tmp/prof_c4
+rocprofv3 --kernel-trace --stats -d /tmp/prof_c4 -- python $R/bench.py --workload c4 --steps 50 --cpu-sample 0 > $OUT/bench_c4_under_rocprof.json 2> /tmp/prof_c4.log
+python $R/tools/rocpd_stats.py $(find /tmp/prof_c4 -name "*.db" | head -1) $OUT/kernel_stats_c4.csv 2>&1 | tail -2
+for set in "FETCH_SIZE" "WRITE_SIZE"; do
+  rm -rf /tmp/prof_c4_$set
+  rocprofv3 --kernel-trace --pmc $set -d /tmp/prof_c4_$set -- python $R/bench.py --workload c4 --steps 2 --warmup 1 --cpu-sample 0 > /tmp/prof_c4_$set.log 2>&1
+  python $R/tools/rocpd_pmc.py $(find /tmp/prof_c4_$set -name "*.db" | head -1) $OUT/pmc_c4_$set.csv 2>&1 | tail -2
+done
+python $R/tools/pmc_traffic.py $OUT/pmc_c4_FETCH_SIZE.csv $OUT/pmc_c4_WRITE_SIZE.csv $OUT/pmc_traffic_c4.json
 python $R/tools/pmc_valu.py $OUT/pmc_SQ_INSTS_VALU.csv $OUT/pmc_valu.json
 ls -la $OUT
