@@ -950,6 +950,13 @@ __global__ __launch_bounds__(256) void d3_energy_fallback_kernel(D3_ENERGY_PARAM
 #undef D3_ENERGY_PARAMS
 
 // ---- pass 3: chain-rule force through the coordination numbers ---------------------------------------
+#ifndef D3_CH_DS
+#define D3_CH_DS 2  // chain pass: trips of list words in flight ahead of the evaluated one (round 5: parametrised like the CN pass; 3/1, 3/2, 4/2 measured
+                    // equal or 2 % slower -- two gathers per neighbour leave less to hide: profiles/r05_ab_chain_pipeline.log)
+#endif
+#ifndef D3_CH_DG
+#define D3_CH_DG 1  // ... and of gathered records (<= D3_CH_DS)
+#endif
 template <class T, bool CSR, bool PK>
 __global__ __launch_bounds__(D3_LS_WAVES * MI_WAVE) void d3_chain_kernel(const T* __restrict__ pos, const int* __restrict__ numbers, int N, const int* __restrict__ idx,
                                                        const int* __restrict__ ush, const int* __restrict__ nptr, int M, int fill_value,
@@ -987,17 +994,25 @@ __global__ __launch_bounds__(D3_LS_WAVES * MI_WAVE) void d3_chain_kernel(const T
   const Int3* __restrict__ ush3 = reinterpret_cast<const Int3*>(ush);
   long long e = beg + lane;
   const unsigned jlim = d3_index_limit<CSR>(N, fill_value);
-  D3Step s0 = d3_fetch_any<PK>(idx, ush3, pk, use_pk, e, end, periodic), s1 = d3_fetch_any<PK>(idx, ush3, pk, use_pk, e + MI_WAVE, end, periodic);
-  bool v0 = s0.in && ((unsigned)s0.j < jlim);
-  auto p0 = arec[v0 ? s0.j : self];
-  float d0 = drec[v0 ? s0.j : self];
+  // software pipeline as in the CN pass: list words D3_CH_DS trips ahead, gathered records D3_CH_DG trips ahead of the one being evaluated
+  D3Step s[D3_CH_DS + 1];
+  bool v[D3_CH_DG + 1];
+  typename Vec4<T>::type p[D3_CH_DG + 1];
+  float d[D3_CH_DG + 1];
+#pragma unroll
+  for (int k = 0; k < D3_CH_DS; ++k) s[k] = d3_fetch_any<PK>(idx, ush3, pk, use_pk, e + (long long)k * MI_WAVE, end, periodic);
+#pragma unroll
+  for (int k = 0; k < D3_CH_DG; ++k) { v[k] = s[k].in && ((unsigned)s[k].j < jlim); p[k] = arec[v[k] ? s[k].j : self]; d[k] = drec[v[k] ? s[k].j : self]; }
   for (int trip = 0; trip < trips; ++trip) {
     __syncthreads();  // lock-step (see d3_cn_kernel)
-    e += MI_WAVE;
-    const D3Step s2 = d3_fetch_any<PK>(idx, ush3, pk, use_pk, e + MI_WAVE, end, periodic);
-    const bool v1 = s1.in && ((unsigned)s1.j < jlim);
-    const auto p1 = arec[v1 ? s1.j : self];
-    const float d1 = drec[v1 ? s1.j : self];
+    s[D3_CH_DS] = d3_fetch_any<PK>(idx, ush3, pk, use_pk, e + (long long)D3_CH_DS * MI_WAVE, end, periodic);
+    v[D3_CH_DG] = s[D3_CH_DG].in && ((unsigned)s[D3_CH_DG].j < jlim);
+    p[D3_CH_DG] = arec[v[D3_CH_DG] ? s[D3_CH_DG].j : self];
+    d[D3_CH_DG] = drec[v[D3_CH_DG] ? s[D3_CH_DG].j : self];
+    const D3Step s0 = s[0];
+    const bool v0 = v[0];
+    const auto p0 = p[0];
+    const float d0 = d[0];
     if (__any(v0)) {
       bool valid = v0 && !(p0.w < (T)0);  // padding atom (Z == 0)
       const PairGeom<T> g = d3_geom<T>(p0, pix, piy, piz, s0.sh, cm, periodic);
@@ -1012,7 +1027,11 @@ __global__ __launch_bounds__(D3_LS_WAVES * MI_WAVE) void d3_chain_kernel(const T
         V[3] = fmaf(fy, g.ry, V[3]); V[4] = fmaf(fy, g.rz, V[4]); V[5] = fmaf(fz, g.rz, V[5]);
       }
     }
-    s0 = s1; v0 = v1; p0 = p1; d0 = d1; s1 = s2;
+#pragma unroll
+    for (int k = 0; k < D3_CH_DS; ++k) s[k] = s[k + 1];
+#pragma unroll
+    for (int k = 0; k < D3_CH_DG; ++k) { v[k] = v[k + 1]; p[k] = p[k + 1]; d[k] = d[k + 1]; }
+    e += MI_WAVE;
   }
   Fx = wave_sum(Fx); Fy = wave_sum(Fy); Fz = wave_sum(Fz);
   double V6[6];
