@@ -401,8 +401,9 @@ int mi_fft_library_versions(int* compiled, int* loaded);
 
 /* ---- dense DFT (csrc/dft.hip) -------------------------------------------------------------------------------------------
  * The same transforms as mi_fft_plan_exec -- real [batch][nx][ny][nz] <-> complex [batch][nx][ny][nz/2+1], both directions unscaled --
- * for ANY mesh size, evaluated from the definition (three passes of dense 1-D DFTs, sincospi twiddles in double): no plan, no library
- * behind it, no state.  O(n) per output: this is the transform of last resort, used when a hipFFT plan fails its known-answer test at
+ * for ANY mesh size, evaluated from the definition (three passes of 1-D DFTs, each split once into two dense levels, n1 + n2 multiply-adds
+ * per output; sincospi twiddles in double): no plan, no library
+ * behind it, no state.  O(sqrt n) per output: this is the transform of last resort, used when a hipFFT plan fails its known-answer test at
  * creation (rocFFT on this stack can return a wrong transform for some shapes depending on what the process planned before),
  * and the cross-check of every other FFT path in the tests.  inverse != 0: `in` (complex) is transformed in place along x and y before
  * the z pass writes `out` -- it is scratch, as for hipFFT's multi-dimensional C2R.  Replaces torch.fft.rfftn / irfftn of
