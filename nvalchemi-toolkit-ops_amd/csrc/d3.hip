@@ -1122,9 +1122,11 @@ D3Layout d3_layout(int N, int nz, int dtype, int B) {
   L.dEdCN = take(sizeof(float) * (size_t)N);
   L.e_atom = take(sizeof(float) * (size_t)N);
   L.v_atom = take(sizeof(double) * 9 * (size_t)N);  // fp64: the direct and the chain-rule part of an atom's virial can cancel (dense systems)
+  // `sums` and `present` sit next to each other: both start a call as zeros and are cleared by ONE memset (round 5: one launch less on the
+  // dependent chain of small D3 kernels)
   L.sums = take(sizeof(double) * 10 * D3_REDUCE_SLOTS * (size_t)(B > 0 ? B : 1));
-  L.tab = take(sizeof(float4) * (size_t)nz * nz * 25);
   L.present = take(sizeof(int) * ((size_t)nz + 2));  // + 2: the atom-order probe {far-apart consecutive pairs, largest pair distance (bits)}, cleared with the table
+  L.tab = take(sizeof(float4) * (size_t)nz * nz * 25);
   L.smap = take(sizeof(int) * (size_t)nz);
   L.sinfo = take(sizeof(D3Species));
   L.ctab = take(sizeof(float4) * D3_SMAX * D3_SMAX * 25);
@@ -1204,7 +1206,8 @@ int d3_impl(const T* pos, const int* numbers, int N, const int* idx, const int* 
             char* ws, const D3Layout& L, unsigned* pk, long long n_entries, const unsigned* pre, hipStream_t st) {
   // `pk` (optional, [N*M] words + one flag word in front): packed copy of a periodic padded list, see d3_fetch_pk
   int* pk_flag = nullptr;
-  if (pk) { pk_flag = reinterpret_cast<int*>(pk); pk += 64; MI_HIP_CHECK(hipMemsetAsync(pk_flag, 0, sizeof(int), st)); }
+  if (pk) { pk_flag = reinterpret_cast<int*>(pk); pk += 64; }
+  int* ws_pk_flag = pk_flag;  // cleared below, unless the search's companion makes the workspace copy unnecessary
   // `pre` (optional, same layout, read-only): the companion the neighbour search wrote with the matrix (mi_nl_neighbors_packed).  The CN
   // pass then streams 4 B/slot instead of 16 and -- unless the spatial order is on, whose packed list holds places, not indices -- writes
   // nothing; the energy and chain passes read `pre` directly.
@@ -1234,6 +1237,8 @@ int d3_impl(const T* pos, const int* numbers, int N, const int* idx, const int* 
   if (pre && !sorted) {  // the later passes take the search's companion as their packed list (its flag says whether it is usable)
     pk = const_cast<unsigned*>(pre_words);
     pk_flag = const_cast<int*>(pre_flag);  // read-only from here on: the CN launches below get no output list
+  } else if (ws_pk_flag) {
+    MI_HIP_CHECK(hipMemsetAsync(ws_pk_flag, 0, sizeof(int), st));
   }
   int* inv = sorted ? reinterpret_cast<int*>(ws + L.inv) : nullptr;
   auto* apos_s = reinterpret_cast<typename Vec4<T>::type*>(ws + L.apos_s);
@@ -1248,7 +1253,8 @@ int d3_impl(const T* pos, const int* numbers, int N, const int* idx, const int* 
   P.inv_w = (hp->s5_off > hp->s5_on) ? (float)(1.0 / ((double)hp->s5_off - (double)hp->s5_on)) : 0.0f;
   // outputs are zeroed like the reference wrapper does (dftd3.py:1933-1936; atoms with Z == 0 keep zeros): the per-atom arrays by
   // the pack kernel below, energy / virial are written for every system by the finish kernel
-  MI_HIP_CHECK(hipMemsetAsync(present, 0, sizeof(int) * ((size_t)hp->nz + 2), st));
+  // (one memset: the per-system reduction slots `sums`, only touched by the reduce kernel at the very end, lie directly in front of `present`)
+  MI_HIP_CHECK(hipMemsetAsync(ws + L.sums, 0, (L.present - L.sums) + sizeof(int) * ((size_t)hp->nz + 2), st));
   D3Grid* sgrid = reinterpret_cast<D3Grid*>(ws + L.sgrid);
   if (sorted || (sortable && probe)) {
     d3_sort_setup_kernel<T><<<1, 256, 0, st>>>(cell, B, N, rc_est, sgrid, d3_sort_cap(N, B));
@@ -1339,8 +1345,7 @@ int d3_impl(const T* pos, const int* numbers, int N, const int* idx, const int* 
   if (pk) { MI_TIMED("d3_chain", st, (launch_chain(Packed{}))); }
   else { MI_TIMED("d3_chain", st, (launch_chain(Plain{}))); }
   MI_LAUNCH_CHECK();
-  double* sums = reinterpret_cast<double*>(ws + L.sums);
-  MI_HIP_CHECK(hipMemsetAsync(sums, 0, sizeof(double) * 10 * D3_REDUCE_SLOTS * (size_t)B, st));
+  double* sums = reinterpret_cast<double*>(ws + L.sums);  // zeroed with `present` at the top of the call
   d3_reduce_kernel<<<D3_REDUCE_WAVES / 4, 256, 0, st>>>(e_atom, v_atom, batch_idx, N, want_virial, sums);
   MI_LAUNCH_CHECK();
   d3_finish_kernel<<<mi_blocks(10ll * B, 256), 256, 0, st>>>(sums, B, want_virial, energy, virial);

@@ -183,8 +183,9 @@ __device__ void nl_describe_system(const T* __restrict__ cell, const uint8_t* __
 template <class T>
 __global__ __launch_bounds__(256) void nl_setup_kernel(const T* __restrict__ cell, const uint8_t* __restrict__ pbc, const int* __restrict__ natoms, int N,
                                 int B, T cutoff, const T* __restrict__ origin, NlSys<T>* __restrict__ sys, NlGlobal* __restrict__ glob,
-                                int table_blocks, int4* __restrict__ zero, long long zero_words) {
+                                int table_blocks, int4* __restrict__ zero, long long zero_words, int* __restrict__ pk_flag) {
   constexpr int NE = (NL_PRUNE_R + 1) * (NL_PRUNE_R + 1);
+  if (pk_flag && blockIdx.x == 0 && threadIdx.x == 0) *pk_flag = 0;  // the packed companion's "unusable" flag starts clear (see NlPacked)
   if ((int)blockIdx.x > table_blocks) {
     const long long zb = (long long)blockIdx.x - table_blocks - 1, nzb = (long long)gridDim.x - table_blocks - 1;
     for (long long k = zb * blockDim.x + threadIdx.x; k < zero_words; k += nzb * blockDim.x) zero[k] = make_int4(0, 0, 0, 0);
@@ -1195,7 +1196,7 @@ int nl_neighbors_impl(const T* pos, int N, const T* cell, const uint8_t* pbc, co
     const int zero_blocks = (int)(zero_words / 2048 < 1 ? 1 : (zero_words / 2048 > 255 ? 255 : zero_words / 2048));
     const int table_blocks = mi_blocks((long long)B * (NL_PRUNE_R + 1) * (NL_PRUNE_R + 1), 256);
     nl_setup_kernel<T><<<1 + table_blocks + zero_blocks, 256, 0, st>>>(cell, pbc, nat, N, B, rc, origin, sys, glob, table_blocks,
-                                                                       reinterpret_cast<int4*>(bins.count), zero_words);
+                                                                       reinterpret_cast<int4*>(bins.count), zero_words, K.words ? K.flag : nullptr);
     MI_LAUNCH_CHECK();
     nl_assign_kernel<T><<<mi_blocks(N, 256), 256, 0, st>>>(pos, batch_idx, N, sys, keys_in, bins.count, wrap, glob);
     MI_LAUNCH_CHECK();
@@ -1207,7 +1208,8 @@ int nl_neighbors_impl(const T* pos, int N, const T* cell, const uint8_t* pbc, co
   const int blocks = mi_blocks(N, 4);
   const NlSecond<T> none{T(0), nullptr, nullptr, nullptr, 0};
   const NlPacked nopk{nullptr, nullptr};
-  if (K.words) MI_HIP_CHECK(hipMemsetAsync(K.flag, 0, sizeof(int), st));
+  // the companion's flag is cleared by nl_setup_kernel (one launch less); a search that reuses the grid has no set-up stage
+  if (K.words && (flags & MI_NL_REUSE_GRID)) MI_HIP_CHECK(hipMemsetAsync(K.flag, 0, sizeof(int), st));
   if (second) {  // single-sweep dual cutoff: the primary outputs take the long cutoff, `second` the short one
     MI_TIMED("nl_query_dual", st,
              (nl_query_kernel<T, MI_NL_MODE_MATRIX, true><<<blocks, 256, 0, st>>>(spos, swrap, keys_out, cell_start, batch_idx, sys, glob, N, rc2, flags, nm, nsh,
