@@ -239,3 +239,52 @@ def test_tuned_neighbor_buffers(monkeypatch):
     rep = {}
     a, b, c = tuned_neighbor_buffers(tp[:500], 6.0, tc, pbc, 64, report=rep)
     assert a.shape == (500, 64) and rep["candidates"] == 1
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4])
+def test_companion_on_awkward_systems(engine, seed):
+    """Triclinic cells, atoms far outside the cell (per-atom wraps: the searches' mixed-shift path), rows that overflow the matrix, a batch
+    with a non-periodic axis: wherever the stored shifts fit the packed word the companion equals the matrix word for word and its flag is
+    clear, otherwise the flag is raised; either way D3 with the companion equals D3 without it bit for bit."""
+    from nvalchemiops.neighborlist import batch_cell_list, cell_list
+
+    _, p = _params()
+    g = np.random.default_rng(100 + seed)
+    n = int(g.integers(200, 900))
+    box = float(g.uniform(9.0, 16.0))
+    pos, cell = S.random_box(n, box, seed=seed, dtype=np.float32, triclinic=bool(seed % 2), outside=seed >= 3)
+    z = g.choice(np.array([1, 6, 8, 17], np.int32), n)
+    rc = float(g.uniform(4.0, 7.0))
+    m = 48 if seed == 4 else 160  # seed 4: rows overflow (the search keeps counting past the row width)
+    tp, tz, tc = _t(pos), _t(z), _t(cell)
+    pbc = torch.tensor([True, True, seed != 2], device=DEV)
+    nm, num, sh = cell_list(tp, rc, tc, pbc, max_neighbors=m)
+    flag, words = _words_of(engine, nm)
+    fits = int(sh.abs().max()) <= 1
+    overflow = int(num.max()) > m  # (a hit past the row width is not stored, but a shift it carries may still raise the flag: conservative)
+    assert (flag != 0) if not fits else (flag == 0 or overflow), (flag, int(sh.abs().max()), overflow)
+    if fits and flag == 0:
+        assert torch.equal(words, _expected_words(nm, num, sh))
+    if int(num.max()) <= m:  # D3 needs a full list
+        a = _d3(tp, tz, p, nm, sh, tc[None])
+        b = _d3(tp, tz, p, nm.clone(), sh.clone(), tc[None])
+        for x, y in zip(a, b):
+            assert torch.equal(x, y)
+    # the same atoms as two systems of a batch
+    half = n // 2
+    bi = _t(np.repeat(np.arange(2, dtype=np.int32), [half, n - half]))
+    cells = torch.stack([tc, tc * 1.1])
+    pbc2 = torch.tensor([[True, True, True], [True, seed != 2, True]], device=DEV)
+    nm2, num2, sh2 = batch_cell_list(tp, rc, cells, pbc2, bi, max_neighbors=m)
+    flag2, words2 = _words_of(engine, nm2)
+    if int(sh2.abs().max()) > 1:
+        assert flag2 != 0
+    elif flag2 == 0:
+        assert torch.equal(words2, _expected_words(nm2, num2, sh2))
+    else:
+        assert int(num2.max()) > m
+    if int(num2.max()) <= m:
+        a = _d3(tp, tz, p, nm2, sh2, cells, bi, 2)
+        b = _d3(tp, tz, p, nm2.clone(), sh2.clone(), cells, bi, 2)
+        for x, y in zip(a, b):
+            assert torch.equal(x, y)
