@@ -442,8 +442,8 @@ int mi_pme_convolve(const void* spec /*complex [B,nx,ny,nzr]*/, const void* reci
  * supported: nx, ny in {8..256}, nz in {8..512}, powers of two, one (ny, nz/2+1) complex plane + its tables within 160 KB of LDS
  * (fp64: 128 x 128, 64 x 256; fp32: 256 x 128, 128 x 256).  k is evaluated from recip_cell (2 pi cell^-1, mi_pme_prepare).            */
 int mi_pme_solve_supported(int n_systems, int nx, int ny, int nz, int dtype);
-/* 1 when the fused solve is also the faster choice (host policy: one system, or meshes of >= 2^21 points; batches of small meshes keep
- * the batched hipFFT plans) */
+/* 1 when the fused solve is the path to take (host policy, measured: since round 5 wherever it is supported -- at parity with hipFFT's
+ * batched plans for batches of small meshes, ahead for single and large meshes, and independent of rocFFT) */
 int mi_pme_solve_preferred(int n_systems, int nx, int ny, int nz, int dtype);
 size_t mi_pme_solve_scratch_bytes(int n_systems, int nx, int ny, int nz, int n_channels /*1 | 4*/, int dtype);
 int mi_pme_solve(const void* mesh, const void* recip_cell /*[n_systems,3,3]*/, const void* alpha /*[n_systems]*/,

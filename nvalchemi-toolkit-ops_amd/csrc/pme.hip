@@ -1405,11 +1405,13 @@ int mi_pme_solve_supported(int n_systems, int nx, int ny, int nz, int dtype) {
   if ((long long)n_systems * 4 * nx > 0x7fffffffll || n_systems > 65535) return 0;
   return (dtype == MI_F32 ? solve_fits<float>(g) : solve_fits<double>(g)) ? 1 : 0;
 }
-/* Host policy, measured (profiles/r04_ab_solve_size.log): batches of small meshes stay with hipFFT's batched plans (128 x 32^3: 0.66 vs 0.85 ms,
- * 8 x 64^3: 0.33 vs 0.36); one system, or meshes from 128^3 on, take the fused solve (32^3: 0.077 vs 0.087 ms, 128^3: 0.34 vs 0.37, 2 x 128^3: 0.58 vs 0.64). */
+/* Host policy, measured.  Round 4 kept hipFFT's batched plans for batches of small meshes (128 x 32^3: 0.66 vs 0.85 ms with a build whose
+ * persistent inverse plane kernel walked the small planes one after the other, profiles/r04_ab_solve_size.log).  With the round-5 build the
+ * fused solve is at parity there and ahead elsewhere (profiles/r05_ab_solve_size.log: 128 x 32^3 0.674 vs 0.659 ms with forces, 0.402 vs
+ * 0.407 energies only; 16 x 32^3 0.152 vs 0.149; 8 x 64^3 0.326 vs 0.335; 128^3 0.343 vs 0.371; 2 x 128^3 0.582 vs 0.650), and it is the
+ * path that does not depend on rocFFT: every mesh the solve supports takes it. */
 int mi_pme_solve_preferred(int n_systems, int nx, int ny, int nz, int dtype) {
-  if (!mi_pme_solve_supported(n_systems, nx, ny, nz, dtype)) return 0;
-  return (n_systems == 1 || (long long)nx * ny * nz >= (1ll << 21)) ? 1 : 0;
+  return mi_pme_solve_supported(n_systems, nx, ny, nz, dtype);
 }
 size_t mi_pme_solve_scratch_bytes(int n_systems, int nx, int ny, int nz, int n_channels, int dtype) {
   const size_t per = (size_t)n_systems * nx * ny * (nz / 2 + 1) * (dtype == MI_F32 ? 8 : 16);

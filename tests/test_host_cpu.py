@@ -352,7 +352,7 @@ def test_spread_path_policy():
 
 def test_mesh_solve_policy():
     """Host logic of the fused PME mesh solve (no compute): which meshes it supports (powers of two whose (ny, nz/2+1) complex plane and tables
-    fit 160 KB of LDS), where it is preferred (one system, or >= 2^21 mesh points: profiles/r04_ab_solve_size.log), and that its scratch covers
+    fit 160 KB of LDS), where it is preferred (since round 5: wherever it is supported, profiles/r05_ab_solve_size.log), and that its scratch covers
     the half spectrum, the channel spectra and the per-call tables."""
     import ctypes
 
@@ -364,7 +364,8 @@ def test_mesh_solve_policy():
     assert ok(1, 128, 128, 128, f64) == 1 and ok(1, 256, 64, 256, f64) == 1 and ok(1, 128, 256, 128, f32) == 1
     assert ok(1, 128, 256, 128, f64) == 0 and ok(1, 256, 256, 256, f32) == 0        # plane larger than the LDS
     assert ok(1, 48, 48, 48, f64) == 0 and ok(1, 31, 9, 6, f64) == 0 and ok(1, 4, 8, 8, f64) == 0 and ok(0, 32, 32, 32, f64) == 0
-    assert pref(1, 32, 32, 32, f64) == 1 and pref(128, 32, 32, 32, f64) == 0 and pref(8, 64, 64, 64, f64) == 0 and pref(2, 128, 128, 128, f64) == 1
+    assert pref(1, 32, 32, 32, f64) == 1 and pref(128, 32, 32, 32, f64) == 1 and pref(8, 64, 64, 64, f64) == 1 and pref(2, 128, 128, 128, f64) == 1
+    assert pref(1, 48, 48, 48, f64) == 0 and pref(4, 128, 256, 128, f64) == 0  # unsupported meshes keep the (self-tested) plans
     L.mi_pme_solve_scratch_bytes.restype = ctypes.c_size_t
     for nch in (1, 4):
         half = 128 * 128 * 65 * 16

@@ -818,8 +818,8 @@ def test_fused_mesh_solve_support_table():
     assert ok(1, 256, 256, 256, f64) == 0 and ok(1, 128, 256, 128, f64) == 0      # plane larger than 160 KB
     assert ok(1, 128, 256, 128, f32) == 1 and ok(1, 256, 256, 256, f32) == 0
     assert ok(1, 48, 48, 48, f64) == 0 and ok(1, 30, 36, 45, f64) == 0 and ok(1, 4, 8, 8, f64) == 0
-    pref = C.lib().mi_pme_solve_preferred   # measured policy: batches of small meshes keep hipFFT's batched plans
-    assert pref(1, 32, 32, 32, f64) == 1 and pref(128, 32, 32, 32, f64) == 0 and pref(8, 64, 64, 64, f64) == 0 and pref(2, 128, 128, 128, f64) == 1
+    pref = C.lib().mi_pme_solve_preferred   # measured policy (round 5): wherever it is supported, batches of small meshes included
+    assert pref(1, 32, 32, 32, f64) == 1 and pref(128, 32, 32, 32, f64) == 1 and pref(8, 64, 64, 64, f64) == 1 and pref(2, 128, 128, 128, f64) == 1
     assert pref(1, 48, 48, 48, f64) == 0
 
 
