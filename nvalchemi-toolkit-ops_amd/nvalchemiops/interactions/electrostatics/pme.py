@@ -243,6 +243,9 @@ import collections  # noqa: E402
 # not pile up dozens of live rocFFT plans (the condition round 4's wrong-transform plan appeared under); a plan that leaves the cache is
 # destroyed, and one that comes back is created -- and self-tested -- again.  The stream is part of the key because a plan owns ONE work
 # area: two streams running the same shape concurrently must not share it.
+import threading  # noqa: E402
+
+_FFT_LOCK = threading.RLock()  # the cache is shared by every thread of the process: look-up, creation (+ self-test) and eviction are one critical section
 _FFT_PLANS: "collections.OrderedDict" = collections.OrderedDict()
 _FFT_PLAN_CAP = max(2, int(os.environ.get("NVALCHEMIOPS_FFT_PLAN_CACHE", "16")))
 _FFT_FALLBACKS: list = []  # (key, detail) of every plan replaced by the dense DFT in this process (tests and bench read it)
@@ -291,34 +294,35 @@ def _fft_plan(device: torch.device, dims, batch: int, code: int, inverse: bool):
     dense DFT (`mi_dft3d`) from then on (one warning); a wrong plan is never executed on user data."""
     import warnings
 
-    stream = torch.cuda.current_stream(device).cuda_stream if device.type == "cuda" else 0
-    key = (device.index, tuple(int(v) for v in dims), int(batch), int(code), bool(inverse), int(stream))
-    plan = _FFT_PLANS.get(key)
-    if plan is not None:
-        _FFT_PLANS.move_to_end(key)
+    with _FFT_LOCK:
+        stream = torch.cuda.current_stream(device).cuda_stream if device.type == "cuda" else 0
+        key = (device.index, tuple(int(v) for v in dims), int(batch), int(code), bool(inverse), int(stream))
+        plan = _FFT_PLANS.get(key)
+        if plan is not None:
+            _FFT_PLANS.move_to_end(key)
+            return plan
+        capturing = device.type == "cuda" and torch.cuda.is_current_stream_capturing()
+        if capturing:
+            raise RuntimeError("particle_mesh_ewald: run one eager step before capturing it in a HIP graph (FFT plans are created on first use)")
+        if _FORCE_DFT:
+            plan = _FFT_PLANS[key] = _DenseDft(dims, batch, code, inverse)
+            return plan
+        _check_fft_library_once()
+        plan = _FftPlan(dims, batch, code, inverse)
+        if _FFT_SELFTEST:
+            ok, detail = plan.self_test(device, dims, batch, code, inverse)
+            if not ok:
+                plan.destroy()
+                plan = _DenseDft(dims, batch, code, inverse)
+                _FFT_FALLBACKS.append((key, detail))
+                warnings.warn(f"hipFFT plan {tuple(dims)} x {batch} ({'C2R' if inverse else 'R2C'}) " +
+                              ("failed its impulse test at creation" if ok is False else "could not be self-tested") +
+                              f" ({detail}): destroyed; this shape runs through the library's dense DFT in this process (DESIGN.md 3.7)")
+        _FFT_PLANS[key] = plan
+        while len(_FFT_PLANS) > _FFT_PLAN_CAP:
+            _, old = _FFT_PLANS.popitem(last=False)
+            old.destroy()
         return plan
-    capturing = device.type == "cuda" and torch.cuda.is_current_stream_capturing()
-    if capturing:
-        raise RuntimeError("particle_mesh_ewald: run one eager step before capturing it in a HIP graph (FFT plans are created on first use)")
-    if _FORCE_DFT:
-        plan = _FFT_PLANS[key] = _DenseDft(dims, batch, code, inverse)
-        return plan
-    _check_fft_library_once()
-    plan = _FftPlan(dims, batch, code, inverse)
-    if _FFT_SELFTEST:
-        ok, detail = plan.self_test(device, dims, batch, code, inverse)
-        if not ok:
-            plan.destroy()
-            plan = _DenseDft(dims, batch, code, inverse)
-            _FFT_FALLBACKS.append((key, detail))
-            warnings.warn(f"hipFFT plan {tuple(dims)} x {batch} ({'C2R' if inverse else 'R2C'}) " +
-                          ("failed its impulse test at creation" if ok is False else "could not be self-tested") +
-                          f" ({detail}): destroyed; this shape runs through the library's dense DFT in this process (DESIGN.md 3.7)")
-    _FFT_PLANS[key] = plan
-    while len(_FFT_PLANS) > _FFT_PLAN_CAP:
-        _, old = _FFT_PLANS.popitem(last=False)
-        old.destroy()
-    return plan
 
 
 def _reciprocal_fused(pos, q, cells, alpha, mesh_dimensions, spline_order, bi, compute_forces, compute_charge_gradients, add=(None, None, None),
