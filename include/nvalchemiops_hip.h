@@ -207,7 +207,8 @@ int mi_d3(const void* positions, const int32_t* numbers, int n_atoms, int dtype,
 int mi_d3_packed(const void* positions, const int32_t* numbers, int n_atoms, int dtype, const int32_t* neighbor_matrix,
                  const int32_t* neighbor_matrix_shifts, int max_neighbors, int fill_value, const void* cell, const int32_t* batch_idx,
                  int n_systems, const mi_d3_params* params, int compute_virial, float* energy, float* forces, float* coord_num, float* virial,
-                 void* workspace, size_t workspace_bytes, const void* packed_list, void* stream);
+                 void* workspace, size_t workspace_bytes, const void* packed_list, size_t packed_bytes /* >= mi_nl_packed_bytes(...) */,
+                 void* stream);
 
 /* ---- Ewald real space -----------------------------------------------------------------------
  * Replaces the 12 alchemiops::_[batch_]ewald_real_space_* ops (ewald.py:263-1365; kernels

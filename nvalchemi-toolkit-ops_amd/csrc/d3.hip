@@ -1421,8 +1421,10 @@ int mi_d3(const void* positions, const int32_t* numbers, int n_atoms, int dtype,
 int mi_d3_packed(const void* positions, const int32_t* numbers, int n_atoms, int dtype, const int32_t* neighbor_matrix,
                  const int32_t* neighbor_matrix_shifts, int max_neighbors, int fill_value, const void* cell, const int32_t* batch_idx,
                  int n_systems, const mi_d3_params* params, int compute_virial, float* energy, float* forces, float* coord_num, float* virial,
-                 void* workspace, size_t workspace_bytes, const void* packed_list, void* stream) {
+                 void* workspace, size_t workspace_bytes, const void* packed_list, size_t packed_bytes, void* stream) {
   MI_REQUIRE(packed_list != nullptr, "packed_list");
+  MI_REQUIRE(max_neighbors > 0 && packed_bytes >= 256 + sizeof(unsigned) * (size_t)n_atoms * (size_t)max_neighbors,
+             "packed_bytes: mi_nl_packed_bytes(n_atoms, max_neighbors)");
   return d3_entry(positions, numbers, n_atoms, dtype, neighbor_matrix, neighbor_matrix_shifts, nullptr, max_neighbors, 0, fill_value, cell, batch_idx,
                   n_systems, params, compute_virial, energy, forces, coord_num, virial, workspace, workspace_bytes, stream, packed_list);
 }

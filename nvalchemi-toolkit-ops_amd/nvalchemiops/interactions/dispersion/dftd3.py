@@ -103,7 +103,8 @@ def _launch(positions, numbers, idx, shifts, nptr, max_neighbors, fill_value, ce
     if packed is not None and periodic and nptr is None and mode != "0":
         rc = L.mi_d3_packed(C.ptr(pos), C.ptr(z), n, code, C.ptr(idx), C.ptr(sh), int(max_neighbors), int(fill_value), C.ptr(cell_t), C.ptr(bi),
                             int(num_systems), ctypes.byref(par), int(bool(compute_virial)), C.ptr(energy), C.ptr(forces), C.ptr(coord_num),
-                            C.ptr(vir), C.ptr(ws), ctypes.c_size_t(ws_bytes), C.ptr(packed), C.stream_of(pos))
+                            C.ptr(vir), C.ptr(ws), ctypes.c_size_t(ws_bytes), C.ptr(packed), ctypes.c_size_t(packed.numel() * packed.element_size()),
+                            C.stream_of(pos))
         if rc != 0 and _LIB_OVERRIDE is not None:
             raise C.NativeLibraryError(f"mi_d3_packed (override library) failed with code {rc}")
         C.check(rc, "mi_d3_packed")
