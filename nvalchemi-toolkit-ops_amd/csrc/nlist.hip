@@ -304,6 +304,7 @@ __global__ void nl_rank_gather_kernel(const T* __restrict__ pos, const int* __re
 struct NlInt3 { int a, b, c; };  // one 12-byte store per hit for the unit shift
 
 // coalesced wave-wide fill of dst[begin,end) with `value`; 16-byte stores in the aligned body
+template <bool NT = true>
 __device__ __forceinline__ void wave_fill(int* __restrict__ dst, long long begin, long long end, int value, int lane) {
   long long n = end - begin;
   if (n <= 0) return;
@@ -316,7 +317,10 @@ __device__ __forceinline__ void wave_fill(int* __restrict__ dst, long long begin
   // padding is never read back by this library: non-temporal stores (ref-nlist 524 288 atoms, 78 % padding: 1.09 -> 1.01 ms)
   typedef int nl_i4 __attribute__((ext_vector_type(4)));
   const nl_i4 w4 = {value, value, value, value};
-  for (long long t = lane; t < body; t += MI_WAVE) __builtin_nontemporal_store(w4, reinterpret_cast<nl_i4*>(p4 + t));
+  for (long long t = lane; t < body; t += MI_WAVE) {
+    if constexpr (NT) __builtin_nontemporal_store(w4, reinterpret_cast<nl_i4*>(p4 + t));
+    else *reinterpret_cast<nl_i4*>(p4 + t) = w4;
+  }
   long long done = head + (body << 2);
   if (done + lane < n) p[done + lane] = value;
 }
@@ -356,6 +360,18 @@ template <class T> struct NlSecond { T rc2; int* nm; int* nsh; int* num; int M; 
 // and the consumer reads the API arrays, bit-identical results).  words == nullptr: nothing is written.
 struct NlPacked { unsigned* words; int* flag; };
 #define NL_PK_PAD 0xffffffffu
+// NL_PREZERO_SHIFTS (round 5): in matrix mode with padding, the tiled kernel's owner wave zero-fills the whole shifts row with wide
+// non-temporal streaming stores when it first meets a centre (30 KB in one go for the headline rows: DRAM-page-friendly), and the hits of
+// un-shifted image groups -- 3 of 4 hits in a large box -- then store no shift at all; the row's padding needs no second pass.  Same bytes
+// in the end, fewer of them in short runs: the fill into badly placed buffers drops from 1.30 - 1.55 to 1.17 - 1.39 ms,
+// into well placed ones it is 1.07 - 1.17 either way (profiles/r05_ab_prezero_shifts.log; plain instead of non-temporal zero stores: no
+// gain).  The wave waits for its zero stores (vmcnt) before the first hit store of the row, so program order is memory order.
+#ifndef NL_PREZERO_SHIFTS
+#define NL_PREZERO_SHIFTS 1
+#endif
+#ifndef NL_PREZERO_NT
+#define NL_PREZERO_NT 1
+#endif
 #define NL_PK_ZERO_SHIFT 0x54000000u  // (0 + 1) in each of the three fields
 __device__ __forceinline__ unsigned nl_pk_code(int Sx, int Sy, int Sz, bool& bad) {
   const unsigned cx = (unsigned)(Sx + 1), cy = (unsigned)(Sy + 1), cz = (unsigned)(Sz + 1);
@@ -593,7 +609,15 @@ __global__ __launch_bounds__(256) void nl_query_tiled_kernel(
             else if (MODE == MI_NL_MODE_CSR) { row_j[u] = list_ij + P + ob; row_s[u] = list_sh ? reinterpret_cast<NlInt3*>(list_sh) + ob : nullptr; }
             else { row_j[u] = nullptr; row_s[u] = nullptr; }
           }
-          auto emit_m = [&](int u, unsigned long long mask, bool hit, int j, int Sx, int Sy, int Sz, unsigned code) {
+          constexpr bool PREZERO = NL_PREZERO_SHIFTS && MODE == MI_NL_MODE_MATRIX && !DUAL;
+          const bool prezero = PREZERO && nsh && !(flags & MI_NL_NO_PAD);  // kernel-uniform
+          if (PREZERO && prezero && tile0 == 0) {
+#pragma unroll
+            for (int u = 0; u < NC; ++u)
+              if (u < nc) wave_fill<NL_PREZERO_NT != 0>(nsh, out_base[u] * 3, (out_base[u] + M) * 3, 0, lane);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the zeros are at the L2 before any shift of these rows is stored
+          }
+          auto emit_m = [&](int u, unsigned long long mask, bool hit, int j, int Sx, int Sy, int Sz, unsigned code, bool zero_shift = false) {
             if (MODE == MI_NL_MODE_COUNT) { cnt[u] += __popcll(mask); return; }
             if (mask) {
               // slot = entries already in the row + hits in lower lanes
@@ -603,7 +627,8 @@ __global__ __launch_bounds__(256) void nl_query_tiled_kernel(
                 // cost +20-60 % on the headline list, profiles/r02_ab_nt.log.  CSR: the source row (constant i) is written in bulk
                 // when the centre is finished)
                 *reinterpret_cast<int*>(reinterpret_cast<char*>(row_j[u]) + slot * 4u) = j;
-                if (row_s[u]) *reinterpret_cast<NlInt3*>(reinterpret_cast<char*>(row_s[u]) + __umul24(slot, 12u)) = NlInt3{Sx, Sy, Sz};
+                if (row_s[u] && !(PREZERO && prezero && zero_shift))
+                  *reinterpret_cast<NlInt3*>(reinterpret_cast<char*>(row_s[u]) + __umul24(slot, 12u)) = NlInt3{Sx, Sy, Sz};
                 // (plain store like the two above: a non-temporal companion store was measured at +0.25 - 0.3 ms on the headline fill,
                 // profiles/r05_ab_companion_nt_store.log)
                 if (MODE == MI_NL_MODE_MATRIX && !DUAL && row_p[u]) *reinterpret_cast<unsigned*>(reinterpret_cast<char*>(row_p[u]) + slot * 4u) = (unsigned)j | code;
@@ -639,7 +664,7 @@ __global__ __launch_bounds__(256) void nl_query_tiled_kernel(
                 const T dr0 = cjx - ccx[u], dr1 = cjy - ccy[u], dr2 = cjz - ccz[u];
                 const T d2 = dr0 * dr0 + dr1 * dr1 + dr2 * dr2;
                 const bool in = d2 < rc2, other = j != ii[u];
-                emit_m(u, __builtin_amdgcn_ballot_w64(in) & __builtin_amdgcn_ballot_w64(other), in & other, j, 0, 0, 0, NL_PK_ZERO_SHIFT);
+                emit_m(u, __builtin_amdgcn_ballot_w64(in) & __builtin_amdgcn_ballot_w64(other), in & other, j, 0, 0, 0, NL_PK_ZERO_SHIFT, true);
               }
             } else if (FAST && gs != NL_MIXED) {  // one common non-zero shift: S.cell once per group, no self-pair possible
               const int Sx = (gs << 22) >> 22, Sy = (gs << 12) >> 22, Sz = (gs << 2) >> 22;
@@ -715,7 +740,7 @@ __global__ __launch_bounds__(256) void nl_query_tiled_kernel(
           const long long out_base = (long long)i * M;
           const int used = cnt < M ? cnt : M;
           wave_fill(nm, out_base + used, out_base + M, fill_value, lane);
-          if (nsh) wave_fill(nsh, (out_base + used) * 3, (out_base + M) * 3, 0, lane);
+          if (nsh && !(NL_PREZERO_SHIFTS && !DUAL)) wave_fill(nsh, (out_base + used) * 3, (out_base + M) * 3, 0, lane);
           if (!DUAL && K.words) wave_fill(reinterpret_cast<int*>(K.words), out_base + used, out_base + M, (int)NL_PK_PAD, lane);
         }
         if (DUAL) {
