@@ -42,7 +42,11 @@ namespace {
 #ifndef NL_TILED_WAVES
 #define NL_TILED_WAVES 0   // > 0: register cap of the tiled query for this many waves per SIMD (tuning aid)
 #endif
-#define NL_CCHUNK 64     // centre atoms of a cell handled per sweep over its candidate tiles (cells above this are swept again)
+#ifndef NL_CCHUNK
+#define NL_CCHUNK 64     // centre atoms of a cell handled per sweep over its candidate tiles (cells above this are swept again); 8 / 16 / 32 (rows
+                         // written in fewer, longer stretches at the price of re-staging the tiles): -3 % into badly placed buffers, +3 % into well
+                         // placed ones (profiles/r05_ab_nl_cchunk.log)
+#endif
 #define NL_MAXROWS 96     // (2Ry+1)(2Rz+1) rows of cells a block can describe (R <= 4)
 #define NL_MIXED 0x7fffffff
 #define NL_TILED_GRID 1536   // persistent blocks (6 per CU); cells are handed out dynamically
