@@ -427,9 +427,9 @@ def _reciprocal_front(pos, q, cells, alpha, dims, spline_order, bi, nsys, batche
 
 
 def _fusable(compute_forces, compute_charge_gradients, k_vectors, k_squared) -> bool:
-    """Can this call run as one fused autograd node?  Energies (+ explicit forces); not charge-gradient outputs, not caller-supplied k arrays,
+    """Can this call run as one fused autograd node?  Energies, explicit forces and (round 5) charge gradients; not caller-supplied k arrays,
     never inside a torch.compile trace (those take the op-by-op composition)."""
-    return _FUSED_AUTOGRAD and not C.tracing() and not compute_charge_gradients and k_vectors is None and k_squared is None
+    return _FUSED_AUTOGRAD and not C.tracing() and k_vectors is None and k_squared is None
 
 
 class _FusedReciprocal(torch.autograd.Function):
@@ -444,7 +444,7 @@ class _FusedReciprocal(torch.autograd.Function):
     instead, which supports what it supported before and raises for the rest -- never a silent zero."""
 
     @staticmethod
-    def forward(ctx, positions, charges, cells, alpha, mesh_dimensions, spline_order, batch_idx, compute_forces):
+    def forward(ctx, positions, charges, cells, alpha, mesh_dimensions, spline_order, batch_idx, compute_forces, compute_charge_gradients=False):
         dt = positions.dtype
         pos = positions.detach().contiguous()
         q = charges.detach().to(dt).contiguous()
@@ -452,22 +452,29 @@ class _FusedReciprocal(torch.autograd.Function):
         bi = None if batch_idx is None else C.i32(batch_idx)
         keep = {}
         energies, forces, cg = _reciprocal_fused(pos, q, cc, alpha.detach(), mesh_dimensions, spline_order, bi, compute_forces, True, keep=keep)
-        ctx.save_for_backward(positions, charges, cells, alpha, keep["spec"], keep["real"], cg, keep["cit"], keep["recip"], keep["vol"], keep["qtot"])
+        # (the saved copy of the charge gradients is the adjoint's own: an output handed to the caller may be modified in place)
+        ctx.save_for_backward(positions, charges, cells, alpha, keep["spec"], keep["real"], cg.clone() if compute_charge_gradients else cg, keep["cit"],
+                              keep["recip"], keep["vol"], keep["qtot"])
         ctx.dims, ctx.order, ctx.bi, ctx.batch_idx, ctx.with_forces = tuple(mesh_dimensions), int(spline_order), bi, batch_idx, bool(compute_forces)
+        ctx.with_cg = bool(compute_charge_gradients)
         ctx.set_materialize_grads(False)
-        return (energies, forces) if compute_forces else energies
+        out = (energies,) + ((forces,) if compute_forces else ()) + ((cg,) if compute_charge_gradients else ())
+        return out if len(out) > 1 else out[0]
 
     @staticmethod
-    def backward(ctx, g_energies, g_forces=None):
+    def backward(ctx, g_energies, *g_rest):
+        g_rest = list(g_rest)
+        g_forces = g_rest.pop(0) if ctx.with_forces else None
+        g_cg = g_rest.pop(0) if ctx.with_cg else None
         positions, charges, cells, alpha = ctx.saved_tensors[:4]
         need = ctx.needs_input_grad
         if torch.is_grad_enabled():
             # the backward is being differentiated (create_graph=True): take it from the differentiable composition
             with torch.enable_grad():
-                e, f, _ = _reciprocal_composed(positions, charges, cells, alpha, ctx.dims, ctx.order, ctx.batch_idx, ctx.with_forces, False)
-                grads = _composed_grads(((e, g_energies), (f, g_forces)), (positions, charges, cells, alpha), need)
-            return grads + (None, None, None, None)
-        return _reciprocal_adjoint(ctx.saved_tensors, need, g_energies, g_forces, ctx.dims, ctx.order, ctx.bi) + (None, None, None, None)
+                e, f, c = _reciprocal_composed(positions, charges, cells, alpha, ctx.dims, ctx.order, ctx.batch_idx, ctx.with_forces, ctx.with_cg)
+                grads = _composed_grads(((e, g_energies), (f, g_forces), (c, g_cg)), (positions, charges, cells, alpha), need)
+            return grads + (None,) * 5
+        return _reciprocal_adjoint(ctx.saved_tensors, need, g_energies, g_forces, ctx.dims, ctx.order, ctx.bi, g_cg) + (None,) * 5
 
 
 def _composed_grads(outputs_and_grads, inputs, need):
@@ -479,9 +486,12 @@ def _composed_grads(outputs_and_grads, inputs, need):
     return tuple(next(got) if n else None for n in need[:len(inputs)])
 
 
-def _reciprocal_adjoint(saved, need, g_energies, g_forces, dims, order, bi):
-    """(dL/dpositions, dL/dcharges, dL/dcells, dL/dalpha) of L = sum_i g_i E_i + sum_i G_i . F_i for the reciprocal-space outputs, from what the
-    fused forward kept.  Raw launches on detached tensors: first order only.  With w = g q and u_d = 2 G_d q the upstream weights:
+def _reciprocal_adjoint(saved, need, g_energies, g_forces, dims, order, bi, g_cgrads=None):
+    """(dL/dpositions, dL/dcharges, dL/dcells, dL/dalpha) of L = sum_i g_i E_i + sum_i G_i . F_i + sum_i v_i cg_i for the reciprocal-space outputs,
+    from what the fused forward kept.  Raw launches on detached tensors: first order only.  The charge gradient cg_i = 2 phi_i - 2 alpha q_i /
+    sqrt(pi) - pi Q / (alpha^2 V) sees the mesh through phi_i only, like E_i = q_i phi_i - ...: its upstream weight joins the energy's,
+    w = g q + 2 v, and everything that depends on the mesh (A_E, B, the k-space sums, the position gradient) follows from w unchanged (round 5).
+    With that w and u_d = 2 G_d q the upstream weights:
 
         A_E = spread(w), A_d = spread(u_d);   B = F^H D (A_E_hat + sum_d i k_d A_d_hat)      (one pass: `mi_pme_convolve_bwd`; self-adjoint operator)
         dL/dq   = g (phi - 2 q alpha/sqrt(pi) - pi Q/(2 alpha^2 V)) - pi/(2 alpha^2 V) sum(w) + gather(B) + sum_d 2 G_d gather(E_d)
@@ -503,14 +513,18 @@ def _reciprocal_adjoint(saved, need, g_energies, g_forces, dims, order, bi):
     n = pos.shape[0]
     g = None if g_energies is None else g_energies.detach().to(dt).contiguous()
     gf = None if g_forces is None else g_forces.detach().to(dt).contiguous()
-    if g is None and gf is None:
+    gv = None if g_cgrads is None else g_cgrads.detach().to(dt).contiguous()
+    if g is None and gf is None and gv is None:
         return None, None, None, None
+    has_w = g is not None or gv is not None
     sel = bi.long() if batched else None
     per = (lambda t: t[sel]) if batched else (lambda t: t[0])  # per-system value at every atom
     st = C.stream_of(pos)
     cdt = torch.complex64 if dt == torch.float32 else torch.complex128
     nchan = 1 if gf is None else 4
     w = g * q if g is not None else torch.zeros(n, dtype=dt, device=dev)
+    if gv is not None:
+        w = w + 2.0 * gv
     weights = [w] + ([] if gf is None else [(2.0 * gf[:, d] * q).contiguous() for d in range(3)])
     # spectra of the spread upstream weights, channel-major
     a_spec = torch.empty((nchan, nsys, nx, ny, nz // 2 + 1), dtype=cdt, device=dev)
@@ -531,18 +545,22 @@ def _reciprocal_adjoint(saved, need, g_energies, g_forces, dims, order, bi):
     g_pos = g_q = g_cells = g_alpha = g_cit = None
     if need[1]:
         g_q = _launch_gather(pos, b_mesh, cit, bi, order)
+        if has_w:
+            wsum = E.seg_sum(w, bi, nsys)  # sum_i (g_i q_i + 2 v_i) per system: the total-charge term of both outputs (dQ/dq_j = 1)
+            g_q = g_q - math.pi / (2.0 * a_i * a_i * v_i) * per(wsum)
         if g is not None:
-            wsum = E.seg_sum(w, bi, nsys)  # sum_i g_i q_i per system
             # phi_j from the forward's charge gradient 2 phi - 2 alpha q/sqrt(pi) - pi Q/(alpha^2 V)
             phi_j = 0.5 * (cg + 2.0 * a_i * q / sqrt_pi + math.pi * qt_i / (a_i * a_i * v_i))
-            g_q = g_q + g * (phi_j - 2.0 * q * a_i / sqrt_pi - math.pi * qt_i / (2.0 * a_i * a_i * v_i)) - math.pi / (2.0 * a_i * a_i * v_i) * per(wsum)
+            g_q = g_q + g * (phi_j - 2.0 * q * a_i / sqrt_pi - math.pi * qt_i / (2.0 * a_i * a_i * v_i))
+        if gv is not None:
+            g_q = g_q - 2.0 * a_i / sqrt_pi * gv
         if gf is not None:
             for d in range(3):
                 g_q = g_q + 2.0 * gf[:, d] * _launch_gather(pos, field[d], cit, bi, order)
         g_q = g_q.to(charges.dtype)
     if need[0] or need[2]:
         gfrac = q.unsqueeze(-1) * _launch_gather(pos, b_mesh, cit, bi, order, grad=True)
-        if g is not None:
+        if has_w:
             gfrac = gfrac + w.unsqueeze(-1) * _launch_gather(pos, phi.contiguous(), cit, bi, order, grad=True)
         if gf is not None:
             for d in range(3):
@@ -553,11 +571,15 @@ def _reciprocal_adjoint(saved, need, g_energies, g_forces, dims, order, bi):
         g_alpha = sums[:, 1]
         if g is not None:
             g_alpha = g_alpha + E.seg_sum(g * (-q * q / sqrt_pi + q * math.pi * qt_i / (a_i ** 3 * v_i)), bi, nsys)
+        if gv is not None:
+            g_alpha = g_alpha + E.seg_sum(gv * (-2.0 * q / sqrt_pi + 2.0 * math.pi * qt_i / (a_i ** 3 * v_i)), bi, nsys)
         g_alpha = g_alpha.reshape(alpha.shape).to(alpha.dtype)
     if need[2]:
         g_vol = -sums[:, 0] / vol
         if g is not None:
             g_vol = g_vol + E.seg_sum(g * q * math.pi * qt_i / (2.0 * a_i * a_i * v_i * v_i), bi, nsys)
+        if gv is not None:
+            g_vol = g_vol + E.seg_sum(gv * math.pi * qt_i / (a_i * a_i * v_i * v_i), bi, nsys)
         inv_t = cit                      # cell^-T;  recip = 2 pi cell^-1
         d_inv = 2.0 * math.pi * (sums[:, 2:11] + sums[:, 11:20]).reshape(nsys, 3, 3) + g_cit.transpose(-1, -2)
         g_cells = -(inv_t @ d_inv @ inv_t) + (g_vol * vol).reshape(-1, 1, 1) * inv_t
@@ -572,22 +594,28 @@ class _FusedPME(torch.autograd.Function):
     that the round-3 path paid on every forward."""
 
     @staticmethod
-    def forward(ctx, positions, charges, cells, alpha, mesh_dimensions, spline_order, batch_idx, mask_value, nl, compute_forces):
+    def forward(ctx, positions, charges, cells, alpha, mesh_dimensions, spline_order, batch_idx, mask_value, nl, compute_forces,
+                compute_charge_gradients=False):
         p = _real_space_inputs(positions, charges, cells, alpha, nl[0], nl[1], nl[2], nl[3], nl[4], batch_idx)
         keep = {}
-        add = _real_space_launch(p, mask_value, compute_forces, False)
+        add = _real_space_launch(p, mask_value, compute_forces, compute_charge_gradients)
+        # the reciprocal charge gradients stay free of the real-space part: the adjoint reads phi back out of them
         energies, forces, cg = _reciprocal_fused(p["pos"], p["q"], p["cells"], p["alpha"], mesh_dimensions, spline_order, p["bi"], compute_forces, True,
                                                  keep=keep, add=(add[0], add[1], None))
         ctx.save_for_backward(positions, charges, cells, alpha, keep["spec"], keep["real"], cg, keep["cit"], keep["recip"], keep["vol"], keep["qtot"],
                               *[t for t in nl if t is not None])
         ctx.nl_present = [t is not None for t in nl]
         ctx.dims, ctx.order, ctx.bi, ctx.batch_idx, ctx.mask_value = tuple(mesh_dimensions), int(spline_order), p["bi"], batch_idx, int(mask_value)
-        ctx.with_forces = bool(compute_forces)
+        ctx.with_forces, ctx.with_cg = bool(compute_forces), bool(compute_charge_gradients)
         ctx.set_materialize_grads(False)
-        return (energies, forces) if compute_forces else energies
+        out = (energies,) + ((forces,) if compute_forces else ()) + ((cg + add[2].to(cg.dtype),) if compute_charge_gradients else ())
+        return out if len(out) > 1 else out[0]
 
     @staticmethod
-    def backward(ctx, g_energies, g_forces=None):
+    def backward(ctx, g_energies, *g_rest):
+        g_rest = list(g_rest)
+        g_forces = g_rest.pop(0) if ctx.with_forces else None
+        g_cg = g_rest.pop(0) if ctx.with_cg else None
         saved = ctx.saved_tensors
         positions, charges, cells, alpha = saved[:4]
         rest = iter(saved[11:])
@@ -597,25 +625,27 @@ class _FusedPME(torch.autograd.Function):
             with torch.enable_grad():
                 real = ewald_real_space(positions=positions, charges=charges, cell=cells, alpha=alpha, neighbor_list=nl[0], neighbor_ptr=nl[1],
                                         neighbor_shifts=nl[2], neighbor_matrix=nl[3], neighbor_matrix_shifts=nl[4], mask_value=ctx.mask_value,
-                                        batch_idx=ctx.batch_idx, compute_forces=ctx.with_forces)
-                e, f, _ = _reciprocal_composed(positions, charges, cells, alpha, ctx.dims, ctx.order, ctx.batch_idx, ctx.with_forces, False)
-                e_tot = (real[0] if ctx.with_forces else real) + e
+                                        batch_idx=ctx.batch_idx, compute_forces=ctx.with_forces, compute_charge_gradients=ctx.with_cg)
+                real = real if isinstance(real, tuple) else (real,)
+                e, f, c = _reciprocal_composed(positions, charges, cells, alpha, ctx.dims, ctx.order, ctx.batch_idx, ctx.with_forces, ctx.with_cg)
+                e_tot = real[0] + e
                 f_tot = real[1] + f if ctx.with_forces else None
-                grads = _composed_grads(((e_tot, g_energies), (f_tot, g_forces)), (positions, charges, cells, alpha), need)
-            return grads + (None,) * 6
+                c_tot = real[-1] + c if ctx.with_cg else None
+                grads = _composed_grads(((e_tot, g_energies), (f_tot, g_forces), (c_tot, g_cg)), (positions, charges, cells, alpha), need)
+            return grads + (None,) * 7
         from nvalchemiops import _eops as E
 
-        out = list(_reciprocal_adjoint(saved[:11], need, g_energies, g_forces, ctx.dims, ctx.order, ctx.bi))
+        out = list(_reciprocal_adjoint(saved[:11], need, g_energies, g_forces, ctx.dims, ctx.order, ctx.bi, g_cg))
         parts = []
         if g_energies is not None:
             parts.append(E._real_bwd(positions, charges, cells, alpha, ctx.batch_idx, nl[0], nl[1], nl[2], nl[3], nl[4], ctx.mask_value, g_energies))
-        if g_forces is not None:
-            parts.append(E._real_forces_bwd(positions, charges, cells, alpha, ctx.batch_idx, nl[0], nl[1], nl[2], nl[3], nl[4], ctx.mask_value, g_forces, None))
+        if g_forces is not None or g_cg is not None:
+            parts.append(E._real_forces_bwd(positions, charges, cells, alpha, ctx.batch_idx, nl[0], nl[1], nl[2], nl[3], nl[4], ctx.mask_value, g_forces, g_cg))
         for r_pos, r_q, r_cell, r_alpha in parts:
             for k, r in enumerate((r_pos, r_q, r_cell, r_alpha)):
                 if need[k] and out[k] is not None:
                     out[k] = out[k] + r.reshape(out[k].shape).to(out[k].dtype)
-        return tuple(out[k] if need[k] else None for k in range(4)) + (None,) * 6
+        return tuple(out[k] if need[k] else None for k in range(4)) + (None,) * 7
 
 
 def _reciprocal_composed(positions, charges, cells, alpha, mesh_dimensions, spline_order, batch_idx, compute_forces, compute_charge_gradients,
@@ -712,8 +742,12 @@ def pme_reciprocal_space(positions: torch.Tensor, charges: torch.Tensor, cell: t
             alpha_g = _traceable_alpha(alpha, num_systems, dt, dev)
             if _fusable(compute_forces, compute_charge_gradients, k_vectors, k_squared):
                 # eager autograd: the inference kernels forward, a hand-written adjoint backward (`_FusedReciprocal`)
-                out = _FusedReciprocal.apply(positions, charges, cells, alpha_g, mesh_dimensions, spline_order, batch_idx, bool(compute_forces))
-                energies, forces, cgrads = (out[0], out[1], None) if compute_forces else (out, None, None)
+                out = _FusedReciprocal.apply(positions, charges, cells, alpha_g, mesh_dimensions, spline_order, batch_idx, bool(compute_forces),
+                                             bool(compute_charge_gradients))
+                out = list(out) if isinstance(out, tuple) else [out]
+                energies = out.pop(0)
+                forces = out.pop(0) if compute_forces else None
+                cgrads = out.pop(0) if compute_charge_gradients else None
             else:
                 energies, forces, cgrads = _reciprocal_composed(positions, charges, cells, alpha_g, mesh_dimensions, spline_order, batch_idx,
                                                                 compute_forces, compute_charge_gradients, k_vectors, k_squared)
@@ -780,7 +814,8 @@ def particle_mesh_ewald(positions: torch.Tensor, charges: torch.Tensor, cell: to
         # eager autograd: ONE node, inference kernels forward, hand-written adjoints backward (`_FusedPME`)
         C.require_device(positions, charges, cell, batch_idx)
         return _FusedPME.apply(positions, charges, cells, alpha, tuple(int(v) for v in mesh_dimensions), spline_order, batch_idx, int(mask_value),
-                               (neighbor_list, neighbor_ptr, neighbor_shifts, neighbor_matrix, neighbor_matrix_shifts), bool(compute_forces))
+                               (neighbor_list, neighbor_ptr, neighbor_shifts, neighbor_matrix, neighbor_matrix_shifts), bool(compute_forces),
+                               bool(compute_charge_gradients))
     real = ewald_real_space(positions=positions, charges=charges, cell=cells, alpha=alpha, neighbor_list=neighbor_list,
                             neighbor_ptr=neighbor_ptr, neighbor_shifts=neighbor_shifts, neighbor_matrix=neighbor_matrix,
                             neighbor_matrix_shifts=neighbor_matrix_shifts, mask_value=mask_value, batch_idx=batch_idx,

@@ -685,6 +685,54 @@ def test_fused_particle_mesh_ewald_node_equals_the_composition(fmt, monkeypatch)
     # runs through this node as well)
 
 
+@pytest.mark.parametrize("with_forces", [False, True])
+@pytest.mark.parametrize("which", ["reciprocal", "pme"])
+def test_fused_nodes_with_charge_gradient_outputs_equal_the_composition(which, with_forces, monkeypatch):
+    """Round 5: calls that return charge gradients under autograd run as the fused node too (`_FusedReciprocal` / `_FusedPME` with a third
+    output).  cg_i = 2 phi_i - 2 alpha q_i / sqrt(pi) - pi Q / (alpha^2 V) sees the mesh through phi_i only, so its upstream weight joins
+    the energy's in the adjoint (w = g q + 2 v).  Oracle: the op-by-op composition; a batch of two triclinic systems with their own alpha;
+    losses on the charge gradients alone, and on energies + forces + charge gradients together; fp64 to 1e-9, fp32 to 2e-4."""
+    from nvalchemiops.interactions.electrostatics import particle_mesh_ewald, pme_reciprocal_space
+    from nvalchemiops.interactions.electrostatics import pme as P
+    from nvalchemiops.neighborlist import batch_cell_list
+
+    p1, c1, q1 = _system(70, seed=5)
+    p2, c2, q2 = _system(50, box=9.5, seed=6)
+    pos, q, cell = torch.cat([p1, p2]), torch.cat([q1, q2]), torch.stack([c1, c2])
+    bi = torch.tensor([0] * 70 + [1] * 50, dtype=torch.int32, device=DEV)
+    pbc = torch.ones((2, 3), dtype=torch.bool, device=DEV)
+    nm, num, sh = batch_cell_list(pos, 4.5, cell, pbc, bi, max_neighbors=96)
+    gen = torch.Generator(device=DEV).manual_seed(4)
+    we = torch.randn(120, dtype=torch.float64, device=DEV, generator=gen)
+    wf = torch.randn(120, 3, dtype=torch.float64, device=DEV, generator=gen)
+    wc = torch.randn(120, dtype=torch.float64, device=DEV, generator=gen)
+    alpha0 = torch.tensor([0.45, 0.5], dtype=torch.float64, device=DEV)
+    node = "_FusedReciprocalBackward" if which == "reciprocal" else "_FusedPMEBackward"
+
+    def grads(fused, dtype, cg_only):
+        monkeypatch.setattr(P, "_FUSED_AUTOGRAD", fused)
+        p, v, c, a = (t.to(dtype).clone().requires_grad_(True) for t in (pos, q, cell, alpha0))
+        kw = dict(mesh_dimensions=(16, 16, 18), spline_order=4, batch_idx=bi, compute_forces=with_forces, compute_charge_gradients=True)
+        if which == "reciprocal":
+            out = pme_reciprocal_space(p, v, c, a, **kw)
+        else:
+            out = particle_mesh_ewald(p, v, c, alpha=a, neighbor_matrix=nm, neighbor_matrix_shifts=sh, **kw)
+        e, cg = out[0], out[-1]
+        f = out[1] if with_forces else None
+        assert (type(cg.grad_fn).__name__ == node) == fused, type(cg.grad_fn).__name__
+        loss = (cg * wc.to(dtype)).sum()
+        if not cg_only:
+            loss = loss + (e * we.to(dtype)).sum() + ((f * wf.to(dtype)).sum() if with_forces else 0.0)
+        return (e.detach(), cg.detach()) + ((f.detach(),) if with_forces else ()) + torch.autograd.grad(loss, (p, v, c, a))
+
+    for dtype, tol in ((torch.float64, 1e-9), (torch.float32, 2e-4)):
+        for cg_only in (True, False):
+            got, want = grads(True, dtype, cg_only), grads(False, dtype, cg_only)
+            for k, (a, b) in enumerate(zip(got, want)):
+                assert a.shape == b.shape and a.dtype == b.dtype, (k, a.shape, b.shape)
+                assert (a - b).abs().max().item() <= tol * max(1.0, b.abs().max().item()), (which, with_forces, dtype, cg_only, k, (a - b).abs().max().item())
+
+
 def test_fused_autograd_nodes_never_return_a_silent_second_derivative():
     """create_graph=True through the fused nodes (forces by autograd inside a loss): their backward hands over to the differentiable
     composition, which raises for second derivatives of the autograd position gradient exactly as it did in round 3 ("differentiate the
