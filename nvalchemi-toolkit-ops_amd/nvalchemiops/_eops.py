@@ -1191,6 +1191,86 @@ def coulomb_op(batched: bool, fmt: str, forces: bool):
     return COULOMB_OPS[(batched, fmt, forces)]
 
 
+# =====================================================================================================================================
+# the fused reciprocal-space step as ONE op, for torch.compile (round 5)
+# =====================================================================================================================================
+# Outside a trace the reciprocal sum under autograd is the `pme._FusedReciprocal` node (inference kernels forward, hand-written adjoint).  A
+# trace cannot look inside an autograd.Function that launches through ctypes, so until round 5 every `torch.compile` of PME took the op-by-op
+# composition (2.7 x the forward).  These two ops are the same node in traceable form: the forward returns what its adjoint needs as extra
+# outputs (the charge spectrum, the potential / field meshes, the per-system geometry), the backward is `pme._reciprocal_adjoint` behind a
+# second op.  First order: the backward op raises for a second derivative (the eager node hands create_graph=True over to the composition;
+# a compiled graph that needs it can set NVALCHEMIOPS_PME_FUSED_AUTOGRAD=0).
+PME_FUSED_OP_CALLS = [0, 0]  # forward / backward launches of the traceable fused op (tests read it)
+
+
+def _pme_fused_fwd(positions: Tensor, charges: Tensor, cells: Tensor, alpha: Tensor, batch_idx: Optional[Tensor], nx: int, ny: int, nz: int,
+                   spline_order: int, compute_forces: bool) -> tuple[Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor]:
+    from nvalchemiops.interactions.electrostatics.pme import _reciprocal_fused
+
+    PME_FUSED_OP_CALLS[0] += 1
+
+    dt = positions.dtype
+    pos = positions.detach().contiguous()
+    bi = None if batch_idx is None else C.i32(batch_idx)
+    keep = {}
+    e, f, cg = _reciprocal_fused(pos, charges.detach().to(dt).contiguous(), cells.detach().to(dt).contiguous(), alpha.detach().to(dt).reshape(-1).contiguous(),
+                                 (int(nx), int(ny), int(nz)), int(spline_order), bi, bool(compute_forces), True, keep=keep)
+    if f is None:
+        f = pos.new_empty((0, 3))
+    return e, f, cg, keep["spec"], keep["real"], keep["cit"].clone(), keep["recip"].clone(), keep["vol"].clone(), keep["qtot"].clone()
+
+
+def _pme_fused_fwd_fake(positions, charges, cells, alpha, batch_idx, nx, ny, nz, spline_order, compute_forces):
+    n, nsys, dt = positions.shape[0], cells.shape[0], positions.dtype
+    cdt = torch.complex64 if dt == torch.float32 else torch.complex128
+    new = positions.new_empty
+    return (new((n,)), new((n, 3) if compute_forces else (0, 3)), new((n,)), new((nsys, nx, ny, nz // 2 + 1), dtype=cdt),
+            new((nsys, 4 if compute_forces else 1, nx, ny, nz)), new((nsys, 3, 3)), new((nsys, 3, 3)), new((nsys,)), new((nsys,)))
+
+
+def _pme_fused_bwd(positions: Tensor, charges: Tensor, cells: Tensor, alpha: Tensor, batch_idx: Optional[Tensor], spec: Tensor, real: Tensor, cg: Tensor,
+                   cit: Tensor, recip: Tensor, vol: Tensor, qtot: Tensor, grad_energies: Optional[Tensor], grad_forces: Optional[Tensor],
+                   grad_charge_grads: Optional[Tensor], nx: int, ny: int, nz: int, spline_order: int) -> tuple[Tensor, Tensor, Tensor, Tensor]:
+    from nvalchemiops.interactions.electrostatics.pme import _reciprocal_adjoint
+
+    PME_FUSED_OP_CALLS[1] += 1
+    bi = None if batch_idx is None else C.i32(batch_idx)
+    a = alpha.detach().reshape(-1)
+    gp, gq, gc, ga = _reciprocal_adjoint((positions, charges, cells, a, spec, real, cg, cit, recip, vol, qtot), (True, True, True, True), grad_energies,
+                                         grad_forces, (int(nx), int(ny), int(nz)), int(spline_order), bi, grad_charge_grads)
+    z = torch.zeros_like
+    return (z(positions) if gp is None else gp.to(positions.dtype), z(charges) if gq is None else gq.to(charges.dtype),
+            z(cells) if gc is None else gc.to(cells.dtype), z(a) if ga is None else ga.reshape(a.shape).to(a.dtype))
+
+
+pme_fused_op = torch.library.custom_op("nvalchemiops::pme_reciprocal_fused", _pme_fused_fwd, mutates_args=())
+pme_fused_op.register_fake(_pme_fused_fwd_fake)
+pme_fused_bwd_op = torch.library.custom_op("nvalchemiops::pme_reciprocal_fused_backward", _pme_fused_bwd, mutates_args=())
+pme_fused_bwd_op.register_fake(lambda positions, charges, cells, alpha, *rest: (torch.empty_like(positions), torch.empty_like(charges), torch.empty_like(cells),
+                                                                                 alpha.new_empty((alpha.numel(),))))
+pme_fused_bwd_op.register_autograd(lambda ctx, *g: (_ for _ in ()).throw(NotImplementedError(
+    "nvalchemiops::pme_reciprocal_fused_backward: second derivatives through the fused reciprocal op are not provided "
+    "(NVALCHEMIOPS_PME_FUSED_AUTOGRAD=0 selects the differentiable op-by-op composition)")), setup_context=lambda ctx, inputs, output: None)
+
+
+def _pme_fused_setup(ctx, inputs, output):
+    positions, charges, cells, alpha, batch_idx, nx, ny, nz, order, compute_forces = inputs
+    e, f, cg, spec, real, cit, recip, vol, qtot = output
+    ctx.save_for_backward(positions, charges, cells, alpha, batch_idx, spec, real, cg, cit, recip, vol, qtot)
+    ctx.meta = (int(nx), int(ny), int(nz), int(order), bool(compute_forces))
+
+
+def _pme_fused_autograd(ctx, g_e, g_f, g_cg, *g_kept):
+    positions, charges, cells, alpha, batch_idx, spec, real, cg, cit, recip, vol, qtot = ctx.saved_tensors
+    nx, ny, nz, order, with_forces = ctx.meta
+    gp, gq, gc, ga = pme_fused_bwd_op(positions, charges, cells, alpha, batch_idx, spec, real, cg, cit, recip, vol, qtot, g_e,
+                                      g_f if with_forces else None, g_cg, nx, ny, nz, order)
+    return gp, gq, gc, ga.reshape(alpha.shape), None, None, None, None, None, None
+
+
+pme_fused_op.register_autograd(_pme_fused_autograd, setup_context=_pme_fused_setup)
+
+
 __all__ = ["spline_spread_op", "batch_spline_spread_op", "spline_gather_op", "batch_spline_gather_op", "spline_gather_vec3_op",
            "batch_spline_gather_vec3_op", "spline_gather_gradient_op", "batch_spline_gather_gradient_op", "pme_green_structure_factor_op",
            "batch_pme_green_structure_factor_op", "pme_energy_corrections_op", "batch_pme_energy_corrections_op",

@@ -748,6 +748,15 @@ def pme_reciprocal_space(positions: torch.Tensor, charges: torch.Tensor, cell: t
                 energies = out.pop(0)
                 forces = out.pop(0) if compute_forces else None
                 cgrads = out.pop(0) if compute_charge_gradients else None
+            elif C.tracing() and _FUSED_AUTOGRAD and k_vectors is None and k_squared is None and positions.is_cuda:
+                # torch.compile: the same node as ONE traceable op (`nvalchemiops::pme_reciprocal_fused`, _eops.py; round 5)
+                from nvalchemiops import _eops
+
+                nx, ny, nz = (int(v) for v in mesh_dimensions)
+                energies, forces, cgrads = _eops.pme_fused_op(positions, charges, cells, alpha_g, batch_idx, nx, ny, nz, int(spline_order),
+                                                              bool(compute_forces))[:3]
+                forces = forces if compute_forces else None
+                cgrads = cgrads if compute_charge_gradients else None
             else:
                 energies, forces, cgrads = _reciprocal_composed(positions, charges, cells, alpha_g, mesh_dimensions, spline_order, batch_idx,
                                                                 compute_forces, compute_charge_gradients, k_vectors, k_squared)
