@@ -288,3 +288,23 @@ def test_companion_on_awkward_systems(engine, seed):
         b = _d3(tp, tz, p, nm2.clone(), sh2.clone(), cells, bi, 2)
         for x, y in zip(a, b):
             assert torch.equal(x, y)
+
+
+def test_inference_mode_tensors_simply_take_the_ordinary_path(engine):
+    """Tensors created under `torch.inference_mode()` carry no version counter, so nothing could vouch for a companion: the search attaches
+    none, and dftd3 gives the result it gives for ordinary tensors."""
+    from nvalchemiops.neighborlist import cell_list
+
+    _, p = _params()
+    pos, cell, _, numbers = S.fcc_box(500, dtype=np.float32)
+    pbc = torch.tensor([True] * 3, device=DEV)
+    tp, tz, tc = _t(pos), _t(numbers), _t(cell)
+    with torch.inference_mode():
+        nm, num, sh = cell_list(tp, 10.0, tc, pbc, max_neighbors=256)
+        assert not hasattr(nm, engine._PACKED_ATTR)
+        a = _d3(tp, tz, p, nm, sh, tc[None])
+    nm2, num2, sh2 = cell_list(tp, 10.0, tc, pbc, max_neighbors=256)
+    b = _d3(tp, tz, p, nm2, sh2, tc[None])
+    assert torch.equal(nm, nm2) and torch.equal(sh, sh2)
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
