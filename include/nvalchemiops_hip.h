@@ -30,6 +30,7 @@ extern "C" {
 #define MI_EINVAL (-1)   /* bad argument                                   */
 #define MI_EHIP (-2)     /* a HIP runtime call failed                      */
 #define MI_EWORKSPACE (-3) /* workspace too small                          */
+#define MI_ECOMM (-4)    /* RCCL missing, or an RCCL call failed           */
 
 #define MI_F32 0
 #define MI_F64 1
@@ -484,6 +485,28 @@ int mi_pme_corrections(const void* raw, const void* charges, const int32_t* batc
                        void* charge_grads /*NULL ok*/, void* stream);
 /* per-system sum of charges (charges.sum() / scatter_add_, pme.py:1225,1241-1244); out zeroed by caller */
 int mi_segment_sum(const void* values, const int32_t* batch_idx, int n_atoms, int dtype, void* out /*[B]*/, void* stream);
+
+/* ---- multi-GPU: the one collective of the path (csrc/comm.cpp) ------------------------------------------------------------
+ * The reference has no multi-GPU code; the path shards at SYSTEM granularity -- no pair crosses systems
+ * (batch_cell_list.py:448-457, dftd3.py:823,1126, spline.py:809) -- so every rank runs the kernels above on its own contiguous range of
+ * systems and the only exchange is an all-gather of per-system values (D3 energies fp32, PME energies fp32 / fp64): RCCL over xGMI, one
+ * rank per GPU.  Python programs use nvalchemiops.distributed (torch.distributed, backend "nccl" = RCCL); these entry points give a plain
+ * C / C++ caller of this ABI the same step.  RCCL is bound at run time (the copy already loaded in the process, else librccl.so.1 from the
+ * ROCm installation); MI_ECOMM if there is none.
+ *   rank 0: mi_comm_unique_id(id) -> ship the MI_COMM_ID_BYTES to every rank by any host channel (MPI, a socket, a file);
+ *   every rank, with its GPU current (hipSetDevice): mi_comm_init(id, ..., n_ranks, rank, &comm)   -- collective, blocks until all joined;
+ *   per step: mi_comm_allgather_f32(comm, mine, all, count_per_rank, stream)  -- all[r * count .. (r + 1) * count) = rank r's `mine`;
+ *             equal counts on every rank (pad ragged shards to the largest, as nvalchemiops.distributed.all_gather_system_values does);
+ *             enqueued on `stream`, in order with the kernels that produced `mine`; in place when mine == all + rank * count;
+ *   mi_comm_destroy(comm) after the stream has drained.                                                                            */
+#define MI_COMM_ID_BYTES 128
+int mi_comm_library_version(int* version /*[host] RCCL's NCCL_VERSION_CODE*/);
+int mi_comm_unique_id(void* id_out /*[host] MI_COMM_ID_BYTES*/, size_t bytes);
+int mi_comm_init(const void* id /*[host]*/, size_t bytes, int n_ranks, int rank, void** comm_out);
+int mi_comm_size(const void* comm, int* n_ranks /*NULL ok*/, int* rank /*NULL ok*/);
+int mi_comm_allgather_f32(void* comm, const float* send, float* recv /*[n_ranks * count_per_rank]*/, size_t count_per_rank, void* stream);
+int mi_comm_allgather_f64(void* comm, const double* send, double* recv, size_t count_per_rank, void* stream);
+int mi_comm_destroy(void* comm);
 
 #ifdef __cplusplus
 }

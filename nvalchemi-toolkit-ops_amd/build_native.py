@@ -23,6 +23,7 @@ ARCH = "gfx950"
 SOURCES = {
     "capi.cpp": [],
     "fft.cpp": [],  # hipFFT plans (mi_fft_plan_*): linked with -lhipfft below
+    "comm.cpp": [],  # mi_comm_*: RCCL bound at run time (dlopen), nothing to link but libdl
     "nlist.hip": ["-ffp-contract=off"] + os.environ.get("MI_NLIST_EXTRA_FLAGS", "").split(),
     # D3 pair math is fp32 with 1/x and sqrt on every pair: hardware v_rcp/v_sqrt (1 ulp) instead of the IEEE-exact expansions
     # (~10 instructions each); energies/forces stay inside the stated 2e-6 / 1e-5 tolerances
@@ -79,7 +80,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
     if force or jobs or _stale(LIB, objs):
         # libhipfft.so.0: inside a Python process torch has loaded its own copy of that SONAME already (same rocFFT the torch.fft path
         # used); a plain C caller resolves it from the ROCm installation
-        run([HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs + ["-L" + os.path.join(ROCM, "lib"), "-lhipfft"])
+        run([HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs + ["-L" + os.path.join(ROCM, "lib"), "-lhipfft", "-ldl"])
     if force or _stale(LIB_D3_IEEE, [ieee_obj, os.path.join(build_dir, "capi.o")]):
         run([HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB_D3_IEEE, ieee_obj, os.path.join(build_dir, "capi.o")])
     return LIB

@@ -75,6 +75,13 @@ def _worker(rank, world, port, out, backend="gloo", own_device=False):
                   tables, dev)
     sizes = [b - a for a, b in partition_systems(counts, world)]
     full = all_gather_system_values(local, sizes)
+    if backend == "nccl":  # the same gather through the C ABI's own communicator (mi_comm_*): the id travels over the process group once
+        from nvalchemiops.distributed import NativeCommunicator
+
+        with NativeCommunicator(rank, world) as comm:
+            again = all_gather_system_values(local, sizes, comm=comm)
+            torch.cuda.synchronize()
+        assert torch.equal(again, full)
     if rank == 0:
         bi_all = torch.repeat_interleave(torch.arange(len(counts), dtype=torch.int32, device=dev), torch.tensor(counts, device=dev))
         single = _step(d["pos"], d["cell"], d["q"], d["numbers"], d["pos_b"], d["cell_b"], bi_all, len(counts), tables, dev)
@@ -112,6 +119,44 @@ def test_two_ranks_over_rccl_one_gpu_each():
     g, s = out["gathered"], out["single"]
     np.testing.assert_allclose(g[:, 0], s[:, 0], rtol=1e-6, atol=1e-6)
     np.testing.assert_allclose(g[:, 1], s[:, 1], rtol=1e-10, atol=1e-10)
+
+
+def test_native_communicator_single_rank():
+    """`mi_comm_*` (csrc/comm.cpp) on the one GPU of the test box: an RCCL communicator of one rank -- id, init, fp32 / fp64 all-gather on the
+    current stream, ragged per-system gather, in-place form, destroy.  The two-rank form runs in the RCCL test above on boxes with 2 GPUs."""
+    import ctypes
+
+    sys.path[:0] = [ROOT, os.path.join(ROOT, "nvalchemi-toolkit-ops_amd")]
+    from nvalchemiops import _capi as C
+    from nvalchemiops.distributed import NativeCommunicator, all_gather_system_values
+
+    dev = torch.device("cuda:0")
+    ver = ctypes.c_int(0)
+    C.check(C.lib().mi_comm_library_version(ctypes.byref(ver)), "mi_comm_library_version")
+    assert ver.value > 20000  # NCCL_VERSION_CODE of an RCCL 2.x
+    with NativeCommunicator(0, 1, device=dev) as comm:
+        n_ranks, rank = ctypes.c_int(-1), ctypes.c_int(-1)
+        C.check(C.lib().mi_comm_size(comm._comm, ctypes.byref(n_ranks), ctypes.byref(rank)), "mi_comm_size")
+        assert (n_ranks.value, rank.value) == (1, 0)
+        for dt in (torch.float32, torch.float64):
+            local = torch.randn(7, 2, dtype=dt, device=dev)
+            (got,) = comm.all_gather(local)
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):  # the collective is enqueued on the caller's current stream
+                (got2,) = comm.all_gather(local * 2)
+            torch.cuda.current_stream().wait_stream(side)
+            assert torch.equal(got, local) and torch.equal(got2, local * 2)
+            assert torch.equal(all_gather_system_values(local, [7], comm=comm), local)
+            buf = local.clone().reshape(-1)  # in place: send == recv + rank * count
+            C.check((C.lib().mi_comm_allgather_f32 if dt == torch.float32 else C.lib().mi_comm_allgather_f64)(
+                comm._comm, C.ptr(buf), C.ptr(buf), ctypes.c_size_t(buf.numel()), C.stream_of(buf)), "mi_comm_allgather (in place)")
+            assert torch.equal(buf, local.reshape(-1))
+        with pytest.raises(ValueError):
+            comm.all_gather(torch.zeros(3, dtype=torch.int32, device=dev))
+        assert comm.all_gather(torch.zeros(0, dtype=torch.float32, device=dev))[0].numel() == 0
+    with pytest.raises(RuntimeError):
+        comm.all_gather(torch.zeros(3, device=dev))
 
 
 @pytest.mark.parametrize("workload", ["headline", "c5"])

@@ -25,6 +25,29 @@ def test_library_exports_every_declared_symbol():
     assert lib.mi_nl_workspace_bytes(100000, 1, 0) > 0
 
 
+def test_comm_entry_points_validate_before_touching_rccl():
+    """`mi_comm_*` (csrc/comm.cpp): argument errors are MI_EINVAL with a message, a NULL communicator destroys to MI_OK -- none of this needs
+    RCCL or a GPU (RCCL is bound on the first call that really needs it)."""
+    import ctypes
+
+    from nvalchemiops import _capi
+
+    lib = _capi.lib()
+    comm = ctypes.c_void_p()
+    ident = ctypes.create_string_buffer(128)
+    assert lib.mi_comm_unique_id(None, ctypes.c_size_t(128)) == -1
+    assert lib.mi_comm_unique_id(ident, ctypes.c_size_t(64)) == -1 and b"128" in lib.mi_last_error()
+    assert lib.mi_comm_init(None, ctypes.c_size_t(128), 2, 0, ctypes.byref(comm)) == -1
+    assert lib.mi_comm_init(ident, ctypes.c_size_t(128), 2, 2, ctypes.byref(comm)) == -1 and b"rank 2 of 2" in lib.mi_last_error()
+    assert lib.mi_comm_init(ident, ctypes.c_size_t(128), 0, 0, ctypes.byref(comm)) == -1 and comm.value is None
+    assert lib.mi_comm_init(ident, ctypes.c_size_t(128), 1, 0, None) == -1
+    assert lib.mi_comm_size(None, None, None) == -1
+    assert lib.mi_comm_allgather_f32(None, None, None, ctypes.c_size_t(4), None) == -1
+    assert lib.mi_comm_allgather_f64(None, None, None, ctypes.c_size_t(4), None) == -1
+    assert lib.mi_comm_library_version(None) == -1
+    assert lib.mi_comm_destroy(None) == 0
+
+
 def test_no_cpu_fallback():
     from nvalchemiops._capi import NativeLibraryError
     from nvalchemiops.interactions.dispersion import D3Parameters, dftd3
