@@ -752,7 +752,8 @@ __device__ __forceinline__ void d3_energy_body(const T* __restrict__ pos, const 
                                                         const unsigned* __restrict__ pk, const int* __restrict__ pk_flag,
                                                         const int* __restrict__ inv, const typename Vec4<T>::type* __restrict__ apos_s,
                                                         const float4* __restrict__ aaux_s, const float4* __restrict__ aw_s, float* __restrict__ dEdCN_s,
-                                                        float4* __restrict__ lds_buf /* 4 * d3_wave_f4(MODE) float4 of the kernel's LDS */) {
+                                                        float4* __restrict__ lds_buf /* 4 * d3_wave_f4(MODE) float4 of the kernel's LDS */,
+                                                        int vblock = -1 /* block index to work as (the fallback kernel's grid-stride loop); -1: blockIdx.x */) {
   constexpr bool LDS = MODE == 1;
   constexpr bool PACKED = MODE == 2 && sizeof(T) == 4;  // one 32-byte record per neighbour (see d3_weights_kernel)
   constexpr int WAVE_F4 = d3_wave_f4(MODE);  // float4 per wave
@@ -763,7 +764,7 @@ __device__ __forceinline__ void d3_energy_body(const T* __restrict__ pos, const 
   if (PK ? *pk_flag != 0 : (pk_flag != nullptr && *pk_flag == 0)) return;
   constexpr bool use_pk = PK;
   const int lane = threadIdx.x & (MI_WAVE - 1);
-  const int k0 = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x / MI_WAVE) + threadIdx.x / MI_WAVE);
+  const int k0 = __builtin_amdgcn_readfirstlane((vblock < 0 ? (int)blockIdx.x : vblock) * (blockDim.x / MI_WAVE) + threadIdx.x / MI_WAVE);
   if (k0 >= N) return;
   // spatial order (inv != NULL): rows are taken in that order; the packed list then holds PLACES in the order and the packed variants
   // gather from the ordered copies of the records, the plain variants keep the caller's indices and the records in atom order
@@ -935,16 +936,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PK ? D3_ENE
 // Everything but the common case in ONE launch behind the packed factorised variant: the packed general / global-table variants and the
 // three plain-list variants (the bodies select themselves on the device-side species info and the packed-list flag; all but at most one
 // return at once).  Round 3: this replaces three dead launches per call (~7 us each on the dependent D3 chain) by one.
+// Round 5: a grid of at most D3_FALLBACK_GRID blocks that take the `n_blocks` block indices of the main variant's grid in a stride loop, and
+// leave at once when the main variant (packed list, factorised interpolation) has done the work -- the common case, where this launch used
+// to cost the dependent chain 14 - 16 us for tens of thousands of blocks that each ran five body prologues.
+#define D3_FALLBACK_GRID 2048
 template <class T, bool CSR>
-__global__ __launch_bounds__(256) void d3_energy_fallback_kernel(D3_ENERGY_PARAMS, const unsigned* __restrict__ pk_packed) {
+__global__ __launch_bounds__(256) void d3_energy_fallback_kernel(D3_ENERGY_PARAMS, const unsigned* __restrict__ pk_packed, int n_blocks) {
   __shared__ float4 lds_buf[4 * d3_wave_f4(1)];  // one buffer for all bodies (the general form's is the largest): at most one of them works
-  d3_energy_body<T, CSR, 1, true>(pos, numbers, N, idx, ush, nptr, M, fill_value, cell, batch_idx, P, cn, want_virial, smap, sinfo, ctab, ftab, fcr, apos, aaux,
-                                  aw, dEdCN, forces, e_atom, v_atom, pk_packed, pk_flag, inv, apos_s, aaux_s, aw_s, dEdCN_s, lds_buf);
-  d3_energy_body<T, CSR, 0, true>(pos, numbers, N, idx, ush, nptr, M, fill_value, cell, batch_idx, P, cn, want_virial, smap, sinfo, ctab, ftab, fcr, apos, aaux,
-                                  aw, dEdCN, forces, e_atom, v_atom, pk_packed, pk_flag, inv, apos_s, aaux_s, aw_s, dEdCN_s, lds_buf);
-  d3_energy_body<T, CSR, 2, false>(D3_ENERGY_ARGS);
-  d3_energy_body<T, CSR, 1, false>(D3_ENERGY_ARGS);
-  d3_energy_body<T, CSR, 0, false>(D3_ENERGY_ARGS);
+  if (sinfo->S <= D3_SMAX && sinfo->factorized && *pk_flag == 0) return;  // d3_energy_body<T, CSR, 2, true> took this call
+  for (int vb = blockIdx.x; vb < n_blocks; vb += gridDim.x) {
+    d3_energy_body<T, CSR, 1, true>(pos, numbers, N, idx, ush, nptr, M, fill_value, cell, batch_idx, P, cn, want_virial, smap, sinfo, ctab, ftab, fcr, apos, aaux,
+                                    aw, dEdCN, forces, e_atom, v_atom, pk_packed, pk_flag, inv, apos_s, aaux_s, aw_s, dEdCN_s, lds_buf, vb);
+    d3_energy_body<T, CSR, 0, true>(pos, numbers, N, idx, ush, nptr, M, fill_value, cell, batch_idx, P, cn, want_virial, smap, sinfo, ctab, ftab, fcr, apos, aaux,
+                                    aw, dEdCN, forces, e_atom, v_atom, pk_packed, pk_flag, inv, apos_s, aaux_s, aw_s, dEdCN_s, lds_buf, vb);
+    d3_energy_body<T, CSR, 2, false>(D3_ENERGY_ARGS, vb);
+    d3_energy_body<T, CSR, 1, false>(D3_ENERGY_ARGS, vb);
+    d3_energy_body<T, CSR, 0, false>(D3_ENERGY_ARGS, vb);
+  }
 }
 #undef D3_ENERGY_ARGS
 #undef D3_ENERGY_PARAMS
@@ -1333,8 +1341,9 @@ int d3_impl(const T* pos, const int* numbers, int N, const int* idx, const int* 
   if (pk) {
     MI_TIMED("d3_energy", st, (launch_energy(std::integral_constant<int, 2>{}, Packed{})));
     MI_LAUNCH_CHECK();
-    d3_energy_fallback_kernel<T, CSR><<<blocks, 256, 0, st>>>(pos, numbers, N, idx, ush, nptr, M, fill_value, cell, batch_idx, P, cn, want_virial, smap, sinfo,
-                                                              ctab, ftab, fcr, apos, aaux, aw, dEdCN, forces, e_atom, v_atom, nullptr, pk_flag, inv, apos_s, aaux_s, aw_s, dEdCN_s, pk);
+    d3_energy_fallback_kernel<T, CSR><<<blocks < D3_FALLBACK_GRID ? blocks : D3_FALLBACK_GRID, 256, 0, st>>>(
+        pos, numbers, N, idx, ush, nptr, M, fill_value, cell, batch_idx, P, cn, want_virial, smap, sinfo, ctab, ftab, fcr, apos, aaux, aw, dEdCN, forces, e_atom,
+        v_atom, nullptr, pk_flag, inv, apos_s, aaux_s, aw_s, dEdCN_s, pk, blocks);
   } else { MI_TIMED("d3_energy", st, (launch_modes(Plain{}))); }
   MI_LAUNCH_CHECK();
   auto launch_chain = [&](auto packed) {
