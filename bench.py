@@ -127,8 +127,8 @@ def make_batch_step(sysd, tables, device, world, sizes):
         if need > md:
             md = D3["max_neighbors"] = (need + 63) // 64 * 64
         del trial
-        d3_bufs = list_buffers(sysd["pos32b"], D3["cutoff"], sysd["cell32b"], sysd["pbc"], md, device, batch_idx=sysd["bi"], for_dftd3=True,
-                               report=BUFFER_REPORT)
+        d3_bufs = list_buffers(sysd["pos32b"], D3["cutoff"], sysd["cell32b"], sysd["pbc"], md, device, batch_idx=sysd["bi"],
+                               for_dftd3=d3_search_context(sysd["numbers"], params), report=BUFFER_REPORT)
 
     def step(record=None):
         ev = []
@@ -174,6 +174,7 @@ def make_batch_step(sysd, tables, device, world, sizes):
 
 VIRIAL = True
 BUFFER_REPORT: dict = {}  # how the 40-Bohr list's buffers were chosen (tuned_neighbor_buffers)
+SEARCH_CN = False  # set after the warm-up: did the 40-Bohr search also sum the DFT-D3 coordination numbers (round 6)?
 COMPANION = False  # set after the warm-up: does the 40-Bohr matrix carry the packed companion the D3 passes stream (round 5)?
 D3_FORMAT = "matrix"  # D3 leg: padded neighbour matrix (default, the format the reference's D3 benchmark uses) or "csr" (exact-size COO/CSR)
 OVERLAP = False
@@ -223,13 +224,28 @@ def cu_masked_streams(device):
     return main, side
 
 
+def d3_search_context(numbers, params):
+    """What lets the searches into a D3 list's buffers also sum the DFT-D3 coordination numbers (round 6): set-up, like the
+    buffers themselves.  BENCH_SEARCH_CN=0 (A/B switch): the companion only, dftd3 runs its own CN pass."""
+    if os.environ.get("BENCH_SEARCH_CN", "1") == "0":
+        return True
+    from nvalchemiops.neighborlist import D3SearchContext
+
+    return D3SearchContext(numbers, params.rcov, 16.0)
+
+
 def list_buffers(pos, cutoff, cell, pbc, m, device, batch_idx=None, for_dftd3=False, report=None):
     """(matrix, shifts, counts) for a list the workload searches into every step: chosen among a few candidate allocations by a trial search
     (`nvalchemiops.neighborlist.tuned_neighbor_buffers`) -- set-up, outside every timed region; BENCH_TUNED_BUFFERS=0: plain torch.empty."""
     n = pos.shape[0]
     if os.environ.get("BENCH_TUNED_BUFFERS", "1") == "0":
-        return (torch.empty((n, m), dtype=torch.int32, device=device), torch.empty((n, m, 3), dtype=torch.int32, device=device),
+        bufs = (torch.empty((n, m), dtype=torch.int32, device=device), torch.empty((n, m, 3), dtype=torch.int32, device=device),
                 torch.empty(n, dtype=torch.int32, device=device))
+        if for_dftd3 is not False and for_dftd3 is not True:  # what a caller with plain buffers does once: announce the species to the search
+            from nvalchemiops.neighborlist import attach_dftd3_context
+
+            attach_dftd3_context(bufs[0], for_dftd3.numbers, for_dftd3.rcov, for_dftd3.k1)
+        return bufs
     from nvalchemiops.neighborlist import tuned_neighbor_buffers
 
     return tuned_neighbor_buffers(pos, cutoff, cell, pbc, m, batch_idx=batch_idx, for_dftd3=for_dftd3,
@@ -289,7 +305,8 @@ def make_step(sysd, tables, device, world):
         else:
             # set-up, outside the timed region: the row buffers are chosen among a few candidate allocations by a trial search (the fill's
             # time is a property of where the driver placed them) -- what an MD code does once when it allocates its lists
-            d3_bufs = list_buffers(sysd["pos32b"], D3["cutoff"], sysd["cell32b"], sysd["pbc"], md, device, for_dftd3=True, report=BUFFER_REPORT)
+            d3_bufs = list_buffers(sysd["pos32b"], D3["cutoff"], sysd["cell32b"], sysd["pbc"], md, device,
+                                   for_dftd3=d3_search_context(sysd["numbers"], params), report=BUFFER_REPORT)
     gathered = [torch.zeros(2, dtype=torch.float64, device=device) for _ in range(world)] if world > 1 else None
     stage_ms = {}
     side = torch.cuda.Stream(device=device, priority=int(os.environ.get("BENCH_SIDE_PRIORITY", "0")))
@@ -427,6 +444,10 @@ def kernel_accounting(kernel: str, n: int, pairs_d3: int):
         entries = float(n) * D3["max_neighbors"] if D3_FORMAT == "matrix" else float(pairs_d3)
         algo = 16.0 * entries + 40.0 * n
         cn_bytes = 4.0 if COMPANION else 20.0  # with the search's companion the CN pass streams 4 B/slot and writes nothing
+        if kernel == "d3_cn" and SEARCH_CN:
+            # the neighbour search summed the coordination numbers while it wrote the list: what is left of this pass is one small launch
+            # that verifies the fingerprint of the inputs and copies N floats (no list walk; its bytes are priced with the search kernel)
+            return "latency", None, 12.0 * n, "adopts the coordination numbers the neighbour search summed (fingerprint check + N-float copy); no list walk"
         design = ((cn_bytes if kernel == "d3_cn" else 4.0) * entries + 40.0 * n) if packed else algo
         if kernel == "d3_energy":
             return "valu", algo, design, "C6 contraction + BJ damping per directed pair: VALU-issue-bound, not HBM-bound (DESIGN.md 3.1)"
@@ -443,7 +464,8 @@ def kernel_accounting(kernel: str, n: int, pairs_d3: int):
     if kernel == "nl_query_matrix_f32":
         algo = n * (3 * 4 + 4) + 16.0 * n * D3["max_neighbors"]
         return ("hbm", algo, (algo + 4.0 * n * D3["max_neighbors"]) if COMPANION else None,
-                "HBM writes + 6.3e8 distance tests" + ("; also writes the 4 B/slot packed companion for the D3 passes" if COMPANION else ""))
+                "HBM writes + 6.3e8 distance tests" + ("; also writes the 4 B/slot packed companion for the D3 passes" if COMPANION else "") +
+                ("; also sums the DFT-D3 coordination numbers over its hits (the D3 CN pass's work, none of its bytes)" if SEARCH_CN else ""))
     if kernel == "ewald_real":
         return "hbm", 16.0 * n * m + n * (3 * 8 + 8) + n * (8 + 3 * 8), None, ""
     if kernel == "spline_spread":
@@ -973,7 +995,7 @@ def config_c3(device, args):
     params = D3Parameters(rcov=t(tables["rcov"]), r4r2=t(tables["r4r2"]), c6ab=t(tables["c6ab"]), cn_ref=t(tables["cn_ref"]))
     tp, tz, tb, tc = t(pos), t(z), t(bi), t(cell)
     pbc = torch.zeros((nmol, 3), dtype=torch.bool, device=device)
-    nm, sh, num = list_buffers(tp, rc, tc, pbc, m, device, batch_idx=tb, for_dftd3=True, report=BUFFER_REPORT)
+    nm, sh, num = list_buffers(tp, rc, tc, pbc, m, device, batch_idx=tb, for_dftd3=d3_search_context(tz, params), report=BUFFER_REPORT)
     bj = dict(a1=D3["a1"], a2=D3["a2"], s8=D3["s8"])
 
     def step():
@@ -1315,11 +1337,12 @@ def main():
     for _ in range(args.warmup):
         out = step()
     barrier()
-    global COMPANION
+    global COMPANION, SEARCH_CN
     from nvalchemiops.neighborlist import _engine as NE
 
     bufs = getattr(step, "d3_bufs", None)
     COMPANION = bool(bufs) and hasattr(bufs[0], NE._PACKED_ATTR)
+    SEARCH_CN = COMPANION and getattr(bufs[0], NE._PACKED_ATTR).cn is not None
     records = []
     step_events = []
     graph_mode = os.environ.get("BENCH_GRAPH") == "1"
@@ -1446,6 +1469,9 @@ def main():
         result["config"]["d3_list_companion"] = (
             "on: the 40-Bohr search also writes a 4 B/slot packed companion (policy 'auto', learned from the warm-up's first dftd3 call), "
             "all three D3 passes stream it; outputs bit-identical to the plain path" if COMPANION else "off")
+        result["config"]["d3_search_cn"] = (
+            "on: the 40-Bohr search also sums the DFT-D3 coordination numbers over its hits (D3SearchContext attached to the list buffers at set-up); "
+            "dftd3 adopts them after a device-side fingerprint check of positions / species / cell / k1 and skips its CN pass" if SEARCH_CN else "off")
         # bytes the step's timed kernels really move per step (design bytes where they differ from the 8(d) formula, else the formula's)
         # against the ~6.3 TB/s the guide gives as achievable: the whole step's distance from an HBM floor, not one kernel's
         moved = sum((r.get("design_bytes") or r.get("algorithmic_bytes") or 0.0) * r["launches"] / args.steps for r in rows.values())

@@ -107,6 +107,32 @@ int mi_nl_neighbors_packed(const void* positions, int n_atoms, const void* cell,
                            int32_t* num_neighbors, int max_neighbors, int fill_value, const void* bin_origin, void* workspace,
                            size_t workspace_bytes, void* packed_out, size_t packed_bytes, void* stream);
 
+/* mi_nl_neighbors_packed that ALSO sums the DFT-D3 coordination numbers of the list it writes (round 6):
+ *   CN_i = sum over the stored entries (j, S) of row i of 1 / (1 + exp(-k1 ((rcov[Z_i] + rcov[Z_j]) / |r_j - r_i + S.cell| - 1)))
+ * -- what the reference's first D3 pass computes by walking the whole list again (`_cn_kernel_nm`, interactions/dispersion/dftd3.py:833-941,
+ * `_cn_counting` :608-645).  The search has the squared distance of every hit in registers and both atoms' records in LDS, so the sum is a
+ * handful of instructions inside a kernel that waits for its stores; mi_d3_packed_cn below then skips its CN pass.  Atoms with Z <= 0 or
+ * Z >= nz take part in the search but neither have nor contribute a coordination number (dftd3.py:871-885).
+ * cn_out: mi_nl_cn_bytes(n_atoms) bytes = a 1 KiB header + float cn[n_atoms] (caller's atom order).  Header: int32[0] is raised when the
+ * numbers must not be used (a row overflowed max_neighbors: the stored list's own sum is smaller); float[2] = cutoff, float[3] = k1 log2(e);
+ * 64 uint64 checksum slots at byte 256 whose wrapping sum fingerprints the inputs the numbers were computed from (every atom's index,
+ * system, position bits and covalent radius, the cell, k1).  mi_d3_packed_cn recomputes the fingerprint from ITS inputs on the device and
+ * only adopts the numbers on a match, so a consumer called with other positions (an MD step that reuses the list), other species or
+ * another cell silently runs its own pass -- there is no host-side bookkeeping to get wrong.
+ * `request` is read on the host; its pointers are device pointers.  Not combinable with MI_NL_REUSE_GRID / half-fill.                    */
+typedef struct mi_nl_cn_request {
+  const int32_t* numbers;       /* [n_atoms] atomic numbers                                   */
+  const float* covalent_radii;  /* [nz] fp32, index 0 = padding (D3Parameters.rcov as fp32)    */
+  int nz;
+  float k1;                     /* steepness of the counting function (dftd3 default 16)       */
+} mi_nl_cn_request;
+size_t mi_nl_cn_bytes(int n_atoms);
+int mi_nl_neighbors_packed_cn(const void* positions, int n_atoms, const void* cell, const uint8_t* pbc, const int32_t* batch_idx, int n_systems,
+                              double cutoff, int dtype, int flags, int32_t* neighbor_matrix, int32_t* neighbor_matrix_shifts,
+                              int32_t* num_neighbors, int max_neighbors, int fill_value, const void* bin_origin, void* workspace,
+                              size_t workspace_bytes, void* packed_out, size_t packed_bytes, const mi_nl_cn_request* request /* [host] */,
+                              void* cn_out, size_t cn_bytes, void* stream);
+
 /* Single-sweep dual-cutoff search: ONE walk over the candidate pairs fills two padded matrices, the short list nested in the long one and
  * both with the image range of the long cutoff.  Replaces: _fill_naive_neighbor_matrix[_pbc]_dual_cutoff and the batch variants
  * (neighborlist/naive_dual_cutoff.py:36,115 / batch_naive_dual_cutoff.py:37,126).  flags as for mi_nl_neighbors (matrix mode). */
@@ -210,6 +236,24 @@ int mi_d3_packed(const void* positions, const int32_t* numbers, int n_atoms, int
                  int n_systems, const mi_d3_params* params, int compute_virial, float* energy, float* forces, float* coord_num, float* virial,
                  void* workspace, size_t workspace_bytes, const void* packed_list, size_t packed_bytes /* >= mi_nl_packed_bytes(...) */,
                  void* stream);
+
+/* mi_d3_packed with two additions (round 6):
+ *  - `cn_block` (optional, NULL = none): the coordination numbers the search summed while it wrote the list (mi_nl_neighbors_packed_cn).
+ *    They are adopted -- and the CN pass skipped -- iff the block's flag is clear AND the fingerprint in its header equals the one this call
+ *    computes on the device from its own positions, numbers, params->rcov, params->k1, cell and batch_idx; otherwise the CN pass runs as in
+ *    mi_d3_packed.  Either way coord_num is the reference's sum over the stored list to fp32 rounding (the two evaluations differ in
+ *    summation order and in one rounding of the exponent: <= 1e-6 relative, tests/test_search_cn_gpu.py).
+ *  - a sampled consistency check of the companion against the arrays it claims to describe: every `verify_stride`-th row (rows
+ *    i = verify_phase mod verify_stride) is re-derived from neighbor_matrix / neighbor_matrix_shifts and compared word by word; on a
+ *    mismatch the call falls back to the 16 B/slot arrays (device-side flag, no host round trip, results = mi_d3's on the arrays as they
+ *    are NOW).  verify_stride = 1 checks every row, 0 disables the check (mi_d3_packed itself uses stride 64, phase 0).  This catches
+ *    arrays edited behind the companion's back in bulk (a filtering kernel, a copy from elsewhere); a single edited entry in an unsampled
+ *    row is not seen -- callers who edit lists through raw pointers must drop the companion.                                           */
+int mi_d3_packed_cn(const void* positions, const int32_t* numbers, int n_atoms, int dtype, const int32_t* neighbor_matrix,
+                    const int32_t* neighbor_matrix_shifts, int max_neighbors, int fill_value, const void* cell, const int32_t* batch_idx,
+                    int n_systems, const mi_d3_params* params, int compute_virial, float* energy, float* forces, float* coord_num, float* virial,
+                    void* workspace, size_t workspace_bytes, const void* packed_list, size_t packed_bytes, const void* cn_block, size_t cn_bytes,
+                    int verify_stride, int verify_phase, void* stream);
 
 /* ---- Ewald real space -----------------------------------------------------------------------
  * Replaces the 12 alchemiops::_[batch_]ewald_real_space_* ops (ewald.py:263-1365; kernels

@@ -83,6 +83,46 @@ template <class T> __host__ __device__ __forceinline__ void mat3_colvec(const T*
     out[r] = s;
   }
 }
+// ---- coordination-number block of a neighbour search (round 6; csrc/nlist.hip writes it, csrc/d3.hip adopts it) ------------------------
+// Layout of the buffer (mi_nl_cn_bytes): a 1 KiB header, then float cn[n_atoms] in the caller's atom order.
+//   int32  [0]        raised (non-zero) when cn[] must not be used (a row overflowed its slots)
+//   float  [2], [3]   the search's cutoff; k1 * log2(e) the terms were evaluated with
+//   uint64 [32 .. 95] checksum slots (byte offset 256): the wrapping sum over all slots fingerprints what the numbers were computed FROM --
+//                     every atom's index, system, position bits and scaled covalent radius, the cell entries and k1 -- so the consumer can
+//                     verify, on the device, that it is being asked about the very same atoms (no reliance on host-side bookkeeping).
+#define MI_CN_HEADER_BYTES 1024
+#define MI_CN_SLOTS 64
+#define MI_CN_SLOT_OFFSET_U64 32
+__host__ __device__ __forceinline__ float mi_cn_scale(float k1) { return k1 * 1.44269504f; }  // exp(-k1 (rr - 1)) = 2^(K - K rr), K = k1 log2(e)
+__host__ __device__ __forceinline__ unsigned long long mi_mix64(unsigned long long x) {  // splitmix64 finaliser
+  x ^= x >> 30; x *= 0xbf58476d1ce4e5b9ull;
+  x ^= x >> 27; x *= 0x94d049bb133111ebull;
+  x ^= x >> 31;
+  return x;
+}
+__device__ __forceinline__ unsigned long long mi_bits64(float v) { return (unsigned long long)(unsigned)__float_as_int(v); }
+__device__ __forceinline__ unsigned long long mi_bits64(double v) { return (unsigned long long)__double_as_longlong(v); }
+// scaled covalent radius of an atom as the CN terms use it: rcov[Z] * K, -inf for an atom outside the tables (every term with it is 0)
+__device__ __forceinline__ float mi_cn_rk(int z, int nz, const float* __restrict__ rcov, float K) {
+  return (z > 0 && z < nz) ? rcov[z] * K : -INFINITY;
+}
+template <class T> __device__ __forceinline__ unsigned long long mi_cn_atom_hash(int i, int sys, T x, T y, T z, float rk) {
+  unsigned long long h = mi_mix64(((unsigned long long)(unsigned)i << 32 | (unsigned)sys) + 0x9e3779b97f4a7c15ull);
+  h = mi_mix64(h ^ mi_bits64(x));
+  h = mi_mix64(h ^ mi_bits64(y));
+  h = mi_mix64(h ^ mi_bits64(z));
+  return mi_mix64(h ^ mi_bits64(rk));
+}
+// terms that do not belong to an atom: cell entry k of the [n_systems,3,3] array, and the scale K (thread 0)
+template <class T> __device__ __forceinline__ unsigned long long mi_cn_cell_hash(int k, T v) { return mi_mix64(mi_mix64(0xce11ull + (unsigned long long)k) ^ mi_bits64(v)); }
+__device__ __forceinline__ unsigned long long mi_cn_scale_hash(float K) { return mi_mix64(0x4b31ull ^ mi_bits64(K)); }
+// adds every lane's value into slots[slot] with one atomic per wave (inactive lanes pass 0; all 64 lanes must call)
+__device__ __forceinline__ void mi_cn_slot_add(unsigned long long* slots, int slot, unsigned long long v) {
+#pragma unroll
+  for (int o = MI_WAVE / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, MI_WAVE);
+  if ((threadIdx.x & (MI_WAVE - 1)) == 0 && v != 0) atomicAdd(&slots[slot & (MI_CN_SLOTS - 1)], v);
+}
+
 template <class T> __host__ __device__ inline void inverse3(const T* a, T* b) {
   b[0] = a[4] * a[8] - a[5] * a[7];
   b[1] = a[2] * a[7] - a[1] * a[8];

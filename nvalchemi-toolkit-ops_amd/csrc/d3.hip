@@ -168,14 +168,57 @@ __global__ void d3_sort_key_kernel(const T* __restrict__ pos, const T* __restric
 // Per-atom records gathered by neighbour index j: ONE 16/32-byte load instead of x, y, z, Z, rcov as five gathers.
 //   apos[j] = {x, y, z, rcov[Z_j]}   (w < 0 flags a padding atom, Z_j == 0)      in the positions dtype
 //   aaux[j] = {CN_j, r4r2[Z_j], bits(Z_j << 8 | compact species id), 0}
+// What mi_d3 checks ON THE DEVICE before it trusts a by-product of the neighbour search (round 6).  Both checks ride in the pack kernel:
+//  * `slots`: the fingerprint of this call's inputs (common.h: every atom's index, system, position bits and scaled covalent radius, the
+//    cell, k1), summed into MI_CN_SLOTS words of the workspace; the CN stage compares it with the one in the search's coordination-number
+//    block and adopts those numbers only on a match (d3_cn_pre_kernel).
+//  * `words`: a sampled re-derivation of the packed companion from the arrays it claims to describe (extra blocks behind the atom
+//    blocks: one wave per sampled row); a mismatch, or the search's own "unusable" header flag, raises `flag`, and every pass then walks
+//    the caller's arrays.  Arrays edited in bulk behind the companion's back are caught here; a single edited entry in an unsampled row
+//    is not (include/nvalchemiops_hip.h says so).
+struct D3Guard {
+  unsigned long long* slots; float K; const void* cell; int n_cell; const int* batch_idx;
+  const int* nm; const int* nsh; const unsigned* words; const int* hdr_flag; int* flag; int M; int stride, phase; int atom_blocks;
+};
 template <class T>
 __global__ void d3_pack_atoms_kernel(const T* __restrict__ pos, const int* __restrict__ numbers, int N, const float* __restrict__ rcov,
                                      const float* __restrict__ r4r2, const int* __restrict__ smap, int nz,
                                      typename Vec4<T>::type* __restrict__ apos, float4* __restrict__ aaux, float* __restrict__ forces,
                                      float* __restrict__ cn, float* __restrict__ dEdCN, float* __restrict__ e_atom, double* __restrict__ v_atom,
                                      const int* __restrict__ inv, typename Vec4<T>::type* __restrict__ apos_s, float4* __restrict__ aaux_s,
-                                     typename Vec4<T>::type* __restrict__ acn) {
+                                     typename Vec4<T>::type* __restrict__ acn, D3Guard G) {
+  if ((int)blockIdx.x >= G.atom_blocks) {  // ---- sampled check of the packed companion (block-uniform branch)
+    const int lane = threadIdx.x & (MI_WAVE - 1);
+    const int w = ((int)blockIdx.x - G.atom_blocks) * (blockDim.x / MI_WAVE) + threadIdx.x / MI_WAVE;
+    if (w == 0 && lane == 0 && *G.hdr_flag != 0) *G.flag = 1;  // the search itself found the companion unusable (a shift outside {-1, 0, 1})
+    if (G.stride <= 0) return;
+    const long long row = (long long)G.phase % G.stride + (long long)w * G.stride;
+    if (row >= N) return;
+    bool bad = false;
+    for (int t = lane; t < G.M; t += MI_WAVE) {
+      const long long e = row * G.M + t;
+      const int j = G.nm[e];
+      const Int3 sh = reinterpret_cast<const Int3*>(G.nsh)[e];
+      const unsigned cx = (unsigned)(sh.a + 1), cy = (unsigned)(sh.b + 1), cz = (unsigned)(sh.c + 1);
+      const bool entry = (unsigned)j < (unsigned)N;  // (a companion is only built for fill_value >= N: everything else is padding)
+      const unsigned want = entry ? ((unsigned)j | ((cx & 3u) << 26) | ((cy & 3u) << 28) | (cz << 30)) : 0xffffffffu;
+      bad |= G.words[e] != want || (entry && (cx > 2u || cy > 2u || cz > 2u));
+    }
+    if (bad) *G.flag = 1;  // benign race: every writer stores 1
+    return;
+  }
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (G.slots) {  // (kernel-uniform) fingerprint of the inputs; every lane of the wave takes part in the sum
+    unsigned long long h = 0;
+    if (k < N) {
+      const int a = inv ? inv[k] : k;
+      h = mi_cn_atom_hash<T>(a, G.batch_idx ? G.batch_idx[a] : 0, pos[3 * (size_t)a], pos[3 * (size_t)a + 1], pos[3 * (size_t)a + 2],
+                             mi_cn_rk(numbers[a], nz, rcov, G.K));
+    }
+    if (k < G.n_cell) h += mi_cn_cell_hash<T>(k, reinterpret_cast<const T*>(G.cell)[k]);
+    if (k == 0) h += mi_cn_scale_hash(G.K);
+    mi_cn_slot_add(G.slots, k / MI_WAVE, h);
+  }
   if (k >= N) return;
   const int i = inv ? inv[k] : k;  // inv: atom at position k of the spatial order (d3_sort_key_kernel), or NULL
   forces[3 * (size_t)i] = forces[3 * (size_t)i + 1] = forces[3 * (size_t)i + 2] = 0.0f;  // outputs of atoms the passes skip (Z == 0)
@@ -380,19 +423,13 @@ __device__ __forceinline__ int d3_lockstep_trips(long long beg, long long end) {
 // same word format as the copy this pass otherwise writes) instead of the 16 B/slot API arrays.  `gate_flag` / `gate_want`: the launch does
 // its work only when (*gate_flag != 0) == gate_want -- the PKIN launch runs when the companion's flag is clear, the plain launch beside
 // it when the search raised it (a shift outside {-1, 0, 1}); one of the two exits at once, no host round trip.
-template <class T, bool CSR, bool BIG, bool SORT, bool PKIN = false>  // BIG: the caller's list is far larger than the Infinity Cache -> streamed with non-temporal loads
-__global__ __launch_bounds__(D3_LS_WAVES * MI_WAVE) void d3_cn_kernel(const T* __restrict__ pos, const int* __restrict__ numbers, int N, const int* __restrict__ idx,
-                                                    const int* __restrict__ ush, const int* __restrict__ nptr, int M, int fill_value,
-                                                    const T* __restrict__ cell, const int* __restrict__ batch_idx, D3Dev P,
-                                                    const typename Vec4<T>::type* __restrict__ apos, float4* __restrict__ aaux,
-                                                    float* __restrict__ cn, unsigned* __restrict__ pk_out, int* __restrict__ pk_flag,
-                                                    const int* __restrict__ inv, const typename Vec4<T>::type* __restrict__ acn,
-                                                    float4* __restrict__ aaux_s, int* __restrict__ rmax_bits,
-                                                    const unsigned* __restrict__ pk_in, const int* __restrict__ gate_flag, int gate_want) {
+#define D3_CN_PARAMS const T* __restrict__ pos, const int* __restrict__ numbers, int N, const int* __restrict__ idx, const int* __restrict__ ush, const int* __restrict__ nptr, int M, int fill_value, const T* __restrict__ cell, const int* __restrict__ batch_idx, D3Dev P, const typename Vec4<T>::type* __restrict__ apos, float4* __restrict__ aaux, float* __restrict__ cn, unsigned* __restrict__ pk_out, int* __restrict__ pk_flag, const int* __restrict__ inv, const typename Vec4<T>::type* __restrict__ acn, float4* __restrict__ aaux_s, int* __restrict__ rmax_bits, const unsigned* __restrict__ pk_in
+#define D3_CN_ARGS pos, numbers, N, idx, ush, nptr, M, fill_value, cell, batch_idx, P, apos, aaux, cn, pk_out, pk_flag, inv, acn, aaux_s, rmax_bits, pk_in
+template <class T, bool CSR, bool BIG, bool SORT, bool PKIN>  // BIG: the caller's list is far larger than the Infinity Cache -> streamed with non-temporal loads
+__device__ __forceinline__ void d3_cn_body(D3_CN_PARAMS, int vblock /* the block of D3_LS_WAVES consecutive rows to work as */) {
   static_assert(!PKIN || !CSR, "a packed companion belongs to a padded matrix");
-  if (gate_flag && ((*gate_flag != 0) != (gate_want != 0))) return;  // block-uniform (see PKIN above)
   const int lane = threadIdx.x & (MI_WAVE - 1);
-  const int i0 = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x / MI_WAVE) + threadIdx.x / MI_WAVE);
+  const int i0 = __builtin_amdgcn_readfirstlane(vblock * (blockDim.x / MI_WAVE) + threadIdx.x / MI_WAVE);
   const int k0 = i0 < N ? i0 : N - 1;
   // SORT: rows are walked in the spatial order, the gathered record is acn[j] = {position, place of j in the order << 7 | Z_j}
   const int i = SORT ? __builtin_amdgcn_readfirstlane(inv[k0]) : k0;
@@ -467,6 +504,51 @@ __global__ __launch_bounds__(D3_LS_WAVES * MI_WAVE) void d3_cn_kernel(const T* _
     if (lane == 0 && rmx > 0.0f) atomicMax(rmax_bits, __float_as_int(rmx));
   }
 }
+template <class T, bool CSR, bool BIG, bool SORT, bool PKIN = false>
+__global__ __launch_bounds__(D3_LS_WAVES * MI_WAVE) void d3_cn_kernel(D3_CN_PARAMS, const int* __restrict__ gate_flag, int gate_want) {
+  if (gate_flag && ((*gate_flag != 0) != (gate_want != 0))) return;  // block-uniform (see PKIN above)
+  d3_cn_body<T, CSR, BIG, SORT, PKIN>(D3_CN_ARGS, (int)blockIdx.x);
+}
+// The CN stage when the neighbour search summed the coordination numbers itself (mi_nl_neighbors_packed_cn, csrc/nlist.hip).  One launch of
+// a small grid decides on the device: if the block's flag is clear and its fingerprint equals the one the pack kernel just computed from
+// THIS call's inputs (D3Guard), the numbers are copied into cn / the per-atom records and the walk over the list does not happen; else the
+// blocks take the rows in a stride loop and run the ordinary pass -- from the companion, or from the caller's arrays when `comp_flag` says
+// the companion is unusable.  Padded matrix, caller's atom order (no spatial order: that pass has to write its place-coded list anyway).
+#define D3_CN_PRE_GRID 2048
+template <class T>
+__global__ __launch_bounds__(D3_LS_WAVES * MI_WAVE) void d3_cn_pre_kernel(D3_CN_PARAMS, const int* __restrict__ comp_flag, const int* __restrict__ cn_hdr,
+                                                                          const unsigned long long* __restrict__ got_slots, const float* __restrict__ cn_pre,
+                                                                          int n_blocks) {
+  __shared__ int adopt_sh;
+  if (threadIdx.x < MI_WAVE) {
+    const unsigned long long* want_slots = reinterpret_cast<const unsigned long long*>(cn_hdr) + MI_CN_SLOT_OFFSET_U64;
+    unsigned long long a = want_slots[threadIdx.x], b = got_slots[threadIdx.x];
+#pragma unroll
+    for (int o = MI_WAVE / 2; o > 0; o >>= 1) { a += __shfl_xor(a, o, MI_WAVE); b += __shfl_xor(b, o, MI_WAVE); }
+    if (threadIdx.x == 0) adopt_sh = (a == b && cn_hdr[0] == 0 && __int_as_float(cn_hdr[3]) == mi_cn_scale(P.k1)) ? 1 : 0;
+  }
+  __syncthreads();
+  if (adopt_sh) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += gridDim.x * blockDim.x) {
+      const int z = numbers[i];
+      if (z == 0) continue;  // outputs of such atoms stay zero, as in the pass itself
+      const float c = cn_pre[i];
+      cn[i] = c;
+      aaux[i].x = c;
+    }
+    // the list's cutoff, for the grid of the spatial order (what the pass reports as the largest pair distance it met)
+    if (rmax_bits && blockIdx.x == 0 && threadIdx.x == 0 && __int_as_float(cn_hdr[2]) > 0.0f) atomicMax(rmax_bits, cn_hdr[2]);
+    return;
+  }
+  const bool from_companion = *comp_flag == 0;
+  for (int vb = blockIdx.x; vb < n_blocks; vb += gridDim.x) {
+    if (from_companion) d3_cn_body<T, false, true, false, true>(D3_CN_ARGS, vb);
+    else d3_cn_body<T, false, true, false, false>(D3_CN_ARGS, vb);
+    __syncthreads();  // the lock-step bookkeeping in LDS is reused by the next row block
+  }
+}
+#undef D3_CN_ARGS
+#undef D3_CN_PARAMS
 
 // `_s5_switch` (dftd3.py:341-423)
 __device__ __forceinline__ void d3_s5(float r, float on, float off, float inv_w, float& sw, float& dsw) {
@@ -1122,7 +1204,7 @@ __global__ void d3_finish_kernel(const double* __restrict__ sums, int B, int wan
 }
 
 inline long long d3_sort_cap(int N, int B) { return 4ll * N + 8ll * (B > 0 ? B : 1); }
-struct D3Layout { size_t dEdCN, e_atom, v_atom, sums, tab, present, smap, sinfo, ctab, ftab, fcr, apos, aaux, aw, inv, skeys, sgrid, sbins, apos_s, acn, aaux_s, aw_s, dEdCN_s, total; };
+struct D3Layout { size_t dEdCN, e_atom, v_atom, guard, sums, tab, present, smap, sinfo, ctab, ftab, fcr, apos, aaux, aw, inv, skeys, sgrid, sbins, apos_s, acn, aaux_s, aw_s, dEdCN_s, total; };
 D3Layout d3_layout(int N, int nz, int dtype, int B) {
   D3Layout L;
   size_t o = 0;
@@ -1130,8 +1212,9 @@ D3Layout d3_layout(int N, int nz, int dtype, int B) {
   L.dEdCN = take(sizeof(float) * (size_t)N);
   L.e_atom = take(sizeof(float) * (size_t)N);
   L.v_atom = take(sizeof(double) * 9 * (size_t)N);  // fp64: the direct and the chain-rule part of an atom's virial can cancel (dense systems)
-  // `sums` and `present` sit next to each other: both start a call as zeros and are cleared by ONE memset (round 5: one launch less on the
-  // dependent chain of small D3 kernels)
+  // `guard`, `sums` and `present` sit next to each other: all start a call as zeros and are cleared by ONE memset (round 5: one launch less
+  // on the dependent chain of small D3 kernels).  guard = MI_CN_SLOTS fingerprint words + the "companion unusable" flag (D3Guard)
+  L.guard = take(sizeof(unsigned long long) * MI_CN_SLOTS + 256);
   L.sums = take(sizeof(double) * 10 * D3_REDUCE_SLOTS * (size_t)(B > 0 ? B : 1));
   L.present = take(sizeof(int) * ((size_t)nz + 2));  // + 2: the atom-order probe {far-apart consecutive pairs, largest pair distance (bits)}, cleared with the table
   L.tab = take(sizeof(float4) * (size_t)nz * nz * 25);
@@ -1211,7 +1294,8 @@ static void d3_order_publish(const int* d_count, int* h_slot, hipStream_t st) {
 template <class T, bool CSR>
 int d3_impl(const T* pos, const int* numbers, int N, const int* idx, const int* ush, const int* nptr, int M, int fill_value, const T* cell,
             const int* batch_idx, int B, const mi_d3_params* hp, int want_virial, float* energy, float* forces, float* cn, float* virial,
-            char* ws, const D3Layout& L, unsigned* pk, long long n_entries, const unsigned* pre, hipStream_t st) {
+            char* ws, const D3Layout& L, unsigned* pk, long long n_entries, const unsigned* pre, const void* cn_block, int verify_stride, int verify_phase,
+            hipStream_t st) {
   // `pk` (optional, [N*M] words + one flag word in front): packed copy of a periodic padded list, see d3_fetch_pk
   int* pk_flag = nullptr;
   if (pk) { pk_flag = reinterpret_cast<int*>(pk); pk += 64; }
@@ -1221,6 +1305,10 @@ int d3_impl(const T* pos, const int* numbers, int N, const int* idx, const int* 
   // nothing; the energy and chain passes read `pre` directly.
   const int* pre_flag = pre ? reinterpret_cast<const int*>(pre) : nullptr;
   const unsigned* pre_words = pre ? pre + 64 : nullptr;
+  // device-side guards of the search's by-products (D3Guard): fingerprint slots + the flag every pass consults instead of the companion's
+  // own header flag (raised by the pack kernel when the header says "unusable" or the sampled rows do not match the caller's arrays)
+  unsigned long long* gslots = reinterpret_cast<unsigned long long*>(ws + L.guard);
+  int* gflag = reinterpret_cast<int*>(ws + L.guard + sizeof(unsigned long long) * MI_CN_SLOTS);
   float* dEdCN = reinterpret_cast<float*>(ws + L.dEdCN);
   float* e_atom = reinterpret_cast<float*>(ws + L.e_atom);
   double* v_atom = reinterpret_cast<double*>(ws + L.v_atom);
@@ -1244,7 +1332,7 @@ int d3_impl(const T* pos, const int* numbers, int N, const int* idx, const int* 
   const bool sorted = sortable && d3_order_decide(N, B, st, &probe, &rc_est, &order_slot);
   if (pre && !sorted) {  // the later passes take the search's companion as their packed list (its flag says whether it is usable)
     pk = const_cast<unsigned*>(pre_words);
-    pk_flag = const_cast<int*>(pre_flag);  // read-only from here on: the CN launches below get no output list
+    pk_flag = gflag;  // read-only from here on: the CN launches below get no output list
   } else if (ws_pk_flag) {
     MI_HIP_CHECK(hipMemsetAsync(ws_pk_flag, 0, sizeof(int), st));
   }
@@ -1262,7 +1350,7 @@ int d3_impl(const T* pos, const int* numbers, int N, const int* idx, const int* 
   // outputs are zeroed like the reference wrapper does (dftd3.py:1933-1936; atoms with Z == 0 keep zeros): the per-atom arrays by
   // the pack kernel below, energy / virial are written for every system by the finish kernel
   // (one memset: the per-system reduction slots `sums`, only touched by the reduce kernel at the very end, lie directly in front of `present`)
-  MI_HIP_CHECK(hipMemsetAsync(ws + L.sums, 0, (L.present - L.sums) + sizeof(int) * ((size_t)hp->nz + 2), st));
+  MI_HIP_CHECK(hipMemsetAsync(ws + L.guard, 0, (L.present - L.guard) + sizeof(int) * ((size_t)hp->nz + 2), st));
   D3Grid* sgrid = reinterpret_cast<D3Grid*>(ws + L.sgrid);
   if (sorted || (sortable && probe)) {
     d3_sort_setup_kernel<T><<<1, 256, 0, st>>>(cell, B, N, rc_est, sgrid, d3_sort_cap(N, B));
@@ -1287,8 +1375,18 @@ int d3_impl(const T* pos, const int* numbers, int N, const int* idx, const int* 
   const long long nt = (long long)hp->nz * hp->nz * 25;
   d3_pack_tables_kernel<<<mi_blocks(nt, 256), 256, 0, st>>>(hp->c6ab, hp->cn_ref, hp->nz, sinfo, tab);  // only works for > 16 species
   MI_LAUNCH_CHECK();
-  d3_pack_atoms_kernel<T><<<mi_blocks(N, 256), 256, 0, st>>>(pos, numbers, N, hp->rcov, hp->r4r2, smap, hp->nz, apos, aaux, forces, cn, dEdCN, e_atom,
-                                                             want_virial ? v_atom : nullptr, inv, apos_s, aaux_s, acn);
+  // the search's coordination numbers are taken only in the caller's atom order (the spatial order's CN pass writes its place-coded list anyway)
+  const bool use_cn = !CSR && cn_block != nullptr && pre != nullptr && !sorted;
+  D3Guard G{};
+  G.atom_blocks = mi_blocks(use_cn && 9 * B > N ? 9 * B : N, 256);
+  int verify_blocks = 0;
+  if (use_cn) { G.slots = gslots; G.K = mi_cn_scale(hp->k1); G.cell = cell; G.n_cell = 9 * B; G.batch_idx = batch_idx; }
+  if (pre) {
+    G.nm = idx; G.nsh = ush; G.words = pre_words; G.hdr_flag = pre_flag; G.flag = gflag; G.M = M; G.stride = verify_stride; G.phase = verify_phase;
+    verify_blocks = verify_stride > 0 ? mi_blocks(((long long)N + verify_stride - 1) / verify_stride, 4) : 1;  // (one block at least: the header flag)
+  }
+  d3_pack_atoms_kernel<T><<<G.atom_blocks + verify_blocks, 256, 0, st>>>(pos, numbers, N, hp->rcov, hp->r4r2, smap, hp->nz, apos, aaux, forces, cn, dEdCN, e_atom,
+                                                                         want_virial ? v_atom : nullptr, inv, apos_s, aaux_s, acn, G);
   MI_LAUNCH_CHECK();
   const int blocks = mi_blocks(N, 4);
 #define MI_D3_CN(BIG_, SORT_, PKIN_, OUT_, OUTFLAG_, GATE_, WANT_)                                                                                 \
@@ -1297,13 +1395,21 @@ int d3_impl(const T* pos, const int* numbers, int N, const int* idx, const int* 
       sortable ? order_probe + 1 : nullptr, pre_words, GATE_, WANT_)
   const bool big_list = (double)n_entries * ((cell && ush) ? 16.0 : 4.0) > 2.0e9;  // list bytes (see d3_fetch)
   if constexpr (!CSR) {
-    if (pre) {
-      // companion given: the PKIN launch works when its flag is clear, the plain launch when the search raised it.  Sorted: both write the
+    if (use_cn) {
+      // the search summed the coordination numbers: ONE small launch adopts them, or -- fingerprint mismatch, overflowed rows -- runs the pass
+      const int n_blocks = mi_blocks(N, D3_LS_WAVES);
+      const int* hdr = reinterpret_cast<const int*>(cn_block);
+      MI_TIMED("d3_cn", st, (d3_cn_pre_kernel<T><<<n_blocks < D3_CN_PRE_GRID ? n_blocks : D3_CN_PRE_GRID, D3_LS_WAVES * MI_WAVE, 0, st>>>(
+                                pos, numbers, N, idx, ush, nptr, M, fill_value, cell, batch_idx, P, apos, aaux, cn, nullptr, nullptr, inv, acn, aaux_s,
+                                sortable ? order_probe + 1 : nullptr, pre_words, gflag, hdr, gslots,
+                                reinterpret_cast<const float*>((const char*)cn_block + MI_CN_HEADER_BYTES), n_blocks)));
+    } else if (pre) {
+      // companion given: the PKIN launch works when it is usable (D3Guard), the plain launch beside it otherwise.  Sorted: both write the
       // place-coded list of the spatial order into the workspace copy; otherwise nothing is written (the later passes read `pre`).
       unsigned* out = sorted ? pk : nullptr;
       int* outflag = sorted ? pk_flag : nullptr;
-      if (sorted) { MI_TIMED("d3_cn", st, (MI_D3_CN(true, true, true, out, outflag, pre_flag, 0))); MI_D3_CN(true, true, false, out, outflag, pre_flag, 1); }
-      else { MI_TIMED("d3_cn", st, (MI_D3_CN(true, false, true, out, outflag, pre_flag, 0))); MI_D3_CN(true, false, false, out, outflag, pre_flag, 1); }
+      if (sorted) { MI_TIMED("d3_cn", st, (MI_D3_CN(true, true, true, out, outflag, gflag, 0))); MI_D3_CN(true, true, false, out, outflag, gflag, 1); }
+      else { MI_TIMED("d3_cn", st, (MI_D3_CN(true, false, true, out, outflag, gflag, 0))); MI_D3_CN(true, false, false, out, outflag, gflag, 1); }
     }
   }
   if (!pre) {
@@ -1386,7 +1492,7 @@ static int d3_entry(const void* positions, const int32_t* numbers, int n_atoms, 
           const int32_t* neighbor_ptr, int max_neighbors, long long n_list_entries, int fill_value, const void* cell,
           const int32_t* batch_idx, int n_systems,
           const mi_d3_params* params, int compute_virial, float* energy, float* forces, float* coord_num, float* virial, void* workspace,
-          size_t workspace_bytes, void* stream, const void* packed_list) {
+          size_t workspace_bytes, void* stream, const void* packed_list, const void* cn_block = nullptr, int verify_stride = 64, int verify_phase = 0) {
   MI_REQUIRE(dtype == MI_F32 || dtype == MI_F64, "dtype");
   MI_REQUIRE(n_atoms >= 0 && n_systems >= 1, "sizes");
   if (n_atoms == 0) return MI_OK;
@@ -1411,7 +1517,7 @@ static int d3_entry(const void* positions, const int32_t* numbers, int n_atoms, 
 #define MI_D3_CALL(T_, CSR_)                                                                                                              \
   return d3_impl<T_, CSR_>((const T_*)positions, numbers, n_atoms, idx_j, unit_shifts, neighbor_ptr, max_neighbors, fill_value, (const T_*)cell, \
                            batch_idx, n_systems, params, compute_virial, energy, forces, coord_num, virial, (char*)workspace, L, pk, n_entries,      \
-                           (const unsigned*)packed_list, st)
+                           (const unsigned*)packed_list, cn_block, verify_stride, verify_phase, st)
   if (dtype == MI_F32) { if (csr) MI_D3_CALL(float, true); else MI_D3_CALL(float, false); }
   else { if (csr) MI_D3_CALL(double, true); else MI_D3_CALL(double, false); }
 #undef MI_D3_CALL
@@ -1436,6 +1542,21 @@ int mi_d3_packed(const void* positions, const int32_t* numbers, int n_atoms, int
              "packed_bytes: mi_nl_packed_bytes(n_atoms, max_neighbors)");
   return d3_entry(positions, numbers, n_atoms, dtype, neighbor_matrix, neighbor_matrix_shifts, nullptr, max_neighbors, 0, fill_value, cell, batch_idx,
                   n_systems, params, compute_virial, energy, forces, coord_num, virial, workspace, workspace_bytes, stream, packed_list);
+}
+
+int mi_d3_packed_cn(const void* positions, const int32_t* numbers, int n_atoms, int dtype, const int32_t* neighbor_matrix,
+                    const int32_t* neighbor_matrix_shifts, int max_neighbors, int fill_value, const void* cell, const int32_t* batch_idx,
+                    int n_systems, const mi_d3_params* params, int compute_virial, float* energy, float* forces, float* coord_num, float* virial,
+                    void* workspace, size_t workspace_bytes, const void* packed_list, size_t packed_bytes, const void* cn_block, size_t cn_bytes,
+                    int verify_stride, int verify_phase, void* stream) {
+  MI_REQUIRE(packed_list != nullptr, "packed_list");
+  MI_REQUIRE(max_neighbors > 0 && packed_bytes >= 256 + sizeof(unsigned) * (size_t)n_atoms * (size_t)max_neighbors,
+             "packed_bytes: mi_nl_packed_bytes(n_atoms, max_neighbors)");
+  MI_REQUIRE(!cn_block || cn_bytes >= MI_CN_HEADER_BYTES + sizeof(float) * (size_t)n_atoms, "cn_bytes: mi_nl_cn_bytes(n_atoms)");
+  MI_REQUIRE(verify_stride >= 0 && verify_phase >= 0, "verify_stride / verify_phase");
+  return d3_entry(positions, numbers, n_atoms, dtype, neighbor_matrix, neighbor_matrix_shifts, nullptr, max_neighbors, 0, fill_value, cell, batch_idx,
+                  n_systems, params, compute_virial, energy, forces, coord_num, virial, workspace, workspace_bytes, stream, packed_list, cn_block,
+                  verify_stride, verify_phase);
 }
 
 }  // extern "C"

@@ -76,7 +76,7 @@ struct NlGlobal {
 };
 
 struct NlLayout {
-  size_t sys, glob, natoms, keys_in, keys_out, vals_in, vals_out, wrap, swrap, spos, cell_start, bins, total;
+  size_t sys, glob, natoms, keys_in, keys_out, vals_in, vals_out, wrap, swrap, spos, srk, cell_start, bins, total;
   long long cell_cap;
 };
 
@@ -105,6 +105,7 @@ NlLayout nl_layout(int N, int B, int dtype) {
   L.wrap = take(8 * (size_t)N);
   L.swrap = take(8 * (size_t)N);
   L.spos = take(4 * esz * (size_t)N);
+  L.srk = take(sizeof(float) * (size_t)N);  // cell-ordered scaled covalent radii (searches that also sum coordination numbers, NlCn)
   L.cell_start = take(sizeof(int) * (size_t)(L.cell_cap + 2));
   L.bins = take(sizeof(int) * bs_scratch_ints(L.cell_cap + 2));  // counting-sort counters (binsort.h)
   L.total = o;
@@ -187,9 +188,14 @@ __device__ void nl_describe_system(const T* __restrict__ cell, const uint8_t* __
 template <class T>
 __global__ __launch_bounds__(256) void nl_setup_kernel(const T* __restrict__ cell, const uint8_t* __restrict__ pbc, const int* __restrict__ natoms, int N,
                                 int B, T cutoff, const T* __restrict__ origin, NlSys<T>* __restrict__ sys, NlGlobal* __restrict__ glob,
-                                int table_blocks, int4* __restrict__ zero, long long zero_words, int* __restrict__ pk_flag) {
+                                int table_blocks, int4* __restrict__ zero, long long zero_words, int* __restrict__ pk_flag,
+                                int* __restrict__ cn_hdr, float cn_scale) {
   constexpr int NE = (NL_PRUNE_R + 1) * (NL_PRUNE_R + 1);
   if (pk_flag && blockIdx.x == 0 && threadIdx.x == 0) *pk_flag = 0;  // the packed companion's "unusable" flag starts clear (see NlPacked)
+  if (cn_hdr && blockIdx.x == 0) {  // header of the coordination-number block (common.h): flag clear, cutoff, scale, checksum slots zero
+    if (threadIdx.x == 0) { cn_hdr[0] = 0; cn_hdr[1] = 0; cn_hdr[2] = __float_as_int((float)cutoff); cn_hdr[3] = __float_as_int(cn_scale); }
+    if (threadIdx.x < MI_CN_SLOTS) reinterpret_cast<unsigned long long*>(cn_hdr)[MI_CN_SLOT_OFFSET_U64 + threadIdx.x] = 0ull;
+  }
   if ((int)blockIdx.x > table_blocks) {
     const long long zb = (long long)blockIdx.x - table_blocks - 1, nzb = (long long)gridDim.x - table_blocks - 1;
     for (long long k = zb * blockDim.x + threadIdx.x; k < zero_words; k += nzb * blockDim.x) zero[k] = make_int4(0, 0, 0, 0);
@@ -288,21 +294,38 @@ __global__ void nl_assign_kernel(const T* __restrict__ pos, const int* __restric
 // with a smaller index): rows come out in ascending atom index inside a cell whatever order the atomics ran in.  The ids of a
 // cell are adjacent, the lanes of a wave sit in one or two cells and read the same addresses (L1 broadcasts).  Same kernel:
 // the cell-ordered record the query streams.
+// What a search that also sums DFT-D3 coordination numbers (NlCn below) needs from the binning stage: the atoms' scaled covalent radii in
+// cell order, and the fingerprint of everything the sums are computed from (common.h: positions, radii, cell, k1) in the block's header.
+struct NlCnBuild { const int* numbers; const float* rcov; int nz; float K; float* srk; unsigned long long* slots; const void* cell; int n_cell; const int* batch_idx; };
 template <class T>
 __global__ void nl_rank_gather_kernel(const T* __restrict__ pos, const int* __restrict__ ids, const int* __restrict__ keys,
                                       const int* __restrict__ cell_start, const short4* __restrict__ wrap, int N,
-                                      typename Vec4<T>::type* __restrict__ spos, short4* __restrict__ swrap, int* __restrict__ keys_sorted) {
+                                      typename Vec4<T>::type* __restrict__ spos, short4* __restrict__ swrap, int* __restrict__ keys_sorted,
+                                      NlCnBuild C) {
   int p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= N) return;
-  const int i = ids[p];
-  const int key = keys[i];
-  const int b = cell_start[key], e = cell_start[key + 1];
-  int rank = 0;
-  for (int q = b; q < e; ++q) rank += ids[q] < i ? 1 : 0;
-  const int dst = b + rank;
-  spos[dst] = pack4(pos[3 * (size_t)i], pos[3 * (size_t)i + 1], pos[3 * (size_t)i + 2], i);
-  swrap[dst] = wrap[i];
-  keys_sorted[dst] = key;
+  unsigned long long h = 0;
+  if (p < N) {
+    const int i = ids[p];
+    const int key = keys[i];
+    const int b = cell_start[key], e = cell_start[key + 1];
+    int rank = 0;
+    for (int q = b; q < e; ++q) rank += ids[q] < i ? 1 : 0;
+    const int dst = b + rank;
+    const T x = pos[3 * (size_t)i], y = pos[3 * (size_t)i + 1], z = pos[3 * (size_t)i + 2];
+    spos[dst] = pack4(x, y, z, i);
+    swrap[dst] = wrap[i];
+    keys_sorted[dst] = key;
+    if (C.srk) {
+      const float rk = mi_cn_rk(C.numbers[i], C.nz, C.rcov, C.K);
+      C.srk[dst] = rk;
+      h = mi_cn_atom_hash<T>(i, C.batch_idx ? C.batch_idx[i] : 0, x, y, z, rk);
+    }
+  }
+  if (C.srk) {  // (kernel-uniform) every lane takes part in the wave-level sum
+    if (p < C.n_cell) h += mi_cn_cell_hash<T>(p, reinterpret_cast<const T*>(C.cell)[p]);
+    if (p == 0) h += mi_cn_scale_hash(C.K);
+    mi_cn_slot_add(C.slots, p / MI_WAVE, h);
+  }
 }
 
 struct NlInt3 { int a, b, c; };  // one 12-byte store per hit for the unit shift
@@ -350,6 +373,10 @@ __device__ __forceinline__ long long nl_uniform64(long long v) {
   return (long long)(((unsigned long long)hi << 32) | lo);
 }
 
+// a wave-uniform float / double pinned into scalar registers (the compiler cannot prove uniformity of a value loaded from LDS)
+__device__ __forceinline__ float nl_uni(float x) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(x))); }
+__device__ __forceinline__ double nl_uni(double x) { return __longlong_as_double(nl_uniform64(__double_as_longlong(x))); }
+
 // The pair test shared by both query kernels: reference expression order (cell_list.py:531-544), or the naive method's
 // orientation / image range (naive.py:163-172), self-pair exclusion, canonical half-fill rule.
 // Second output set of the single-sweep dual-cutoff search (naive_dual_cutoff.py:115-290: one walk over the pair set, `dist_sq < cutoff2_sq`
@@ -363,6 +390,19 @@ template <class T> struct NlSecond { T rc2; int* nm; int* nsh; int* num; int M; 
 // 5.1 GB -> 1.0 GB on the headline list).  `flag` is raised when a stored shift lies outside {-1, 0, 1} (the companion is then unusable
 // and the consumer reads the API arrays, bit-identical results).  words == nullptr: nothing is written.
 struct NlPacked { unsigned* words; int* flag; };
+// Optional by-product #2 of a matrix-mode search (round 6): the DFT-D3 coordination numbers CN_i = sum_j 1 / (1 + exp(-k1 ((rcov_i + rcov_j) / r_ij - 1)))
+// over exactly the pairs the search stores (`_cn_kernel_nm`, dftd3.py:833-941, sums over the row; `_cn_counting` :608-645).  The search has
+// d^2 of every hit in registers and both atoms' records in LDS, so the sum costs one rsq, one exp2, one rcp and three FMAs per tested pair
+// inside a kernel that waits for its stores to drain -- and mi_d3's CN pass (a walk over the whole list with one 16-byte gather per
+// neighbour) disappears.  fp32 terms, lane partials of <= 16 terms summed in fp64 across lanes and passes; the exponential is a plain
+// v_exp_f32 of K - K rr (K = k1 log2 e): df <= f (1 - f) ln2 |t| 2^-23 <= 3e-7 where f is not tiny, the size of the rsq's own error.
+// `flag` is raised when a row overflowed its M slots (the reference's sum stops at the stored entries): the consumer then runs its own pass.
+struct NlCn { const float* rk; float* cn; int* flag; float K; };
+__device__ __forceinline__ float nl_cn_term(float d2, float rki, float rkj, float K) {
+  const float rinv = __builtin_amdgcn_rsqf(d2);
+  const float t = fmaf(-(rki + rkj), rinv, K);  // -k1 (rr - 1) log2(e); an atom outside the tables carries rk = -inf: t = +inf, the term is 0
+  return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(t));
+}
 #define NL_PK_PAD 0xffffffffu
 // NL_PREZERO_SHIFTS (round 5): in matrix mode with padding, the tiled kernel's owner wave zero-fills the whole shifts row with wide
 // non-temporal streaming stores when it first meets a centre (30 KB in one go for the headline rows: DRAM-page-friendly), and the hits of
@@ -416,26 +456,34 @@ __device__ __forceinline__ bool nl_pair_hit(T pix, T piy, T piz, int i, T cjx, T
 // latency inside the 64-candidates-per-step loop, and every candidate record is fetched from L2 once per cell, not once
 // per atom.  Output path (ballot/popcount compaction, owner-written padding) is the same as the wave-per-atom kernel's.
 // FAST = neither naive-expression nor half-fill requested: the per-candidate test is straight-line code.
-template <class T, int MODE, bool FAST, bool DUAL = false>
+// CNF: also sum the DFT-D3 coordination numbers of the centres over their hits (NlCn; matrix mode, FAST path only).
+template <class T, int MODE, bool FAST, bool DUAL = false, bool CNF = false>
 #if NL_TILED_WAVES > 0
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NL_TILED_WAVES, NL_TILED_WAVES))) void nl_query_tiled_kernel(
 #else
-__global__ __launch_bounds__(256) void nl_query_tiled_kernel(
+// (the CN-summing float variant is held to the plain variant's 5 waves / SIMD: left alone the compiler takes 113 VGPRs = 4 waves)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((CNF && sizeof(T) == 4) ? 5 : 1, (CNF && sizeof(T) == 4) ? 5 : 8))) void nl_query_tiled_kernel(
 #endif
     const typename Vec4<T>::type* __restrict__ spos, const short4* __restrict__ swrap, const int* __restrict__ cell_start,
     const NlSys<T>* __restrict__ sys, const NlGlobal* __restrict__ glob, int B, T rc2, int flags, int* __restrict__ nm,
     int* __restrict__ nsh, int* __restrict__ num, int M, int fill_value, const int* __restrict__ ptr, int* __restrict__ list_ij,
-    int* __restrict__ list_sh, long long P, NlSecond<T> D, NlPacked K) {
+    int* __restrict__ list_sh, long long P, NlSecond<T> D, NlPacked K, NlCn CN = NlCn{nullptr, nullptr, nullptr, 0.0f}) {
   static_assert(!DUAL || (MODE == MI_NL_MODE_MATRIX && !FAST), "the dual-cutoff sweep is instantiated for the general matrix kernel only");
+  static_assert(!CNF || (MODE == MI_NL_MODE_MATRIX && FAST && !DUAL), "coordination numbers ride with the plain full-list matrix search");
   // candidates staged in LDS per tile: fp64 records are twice as large and the fp64 kernel needs 112 VGPRs (4 waves / SIMD), so the smaller
   // tile is what lets a fourth block fit the LDS of a CU (9 A headline list: 0.254 -> 0.226 ms, profiles/r03_ab_nl_segfill.log)
   constexpr int TILE = sizeof(T) == 8 ? NL_TILE_F64 : NL_TILE;
   if (!glob->use_tiled) return;
   if (!DUAL && FAST != ((flags & (MI_NL_HALF_FILL | MI_NL_NAIVE_EXPR)) == 0)) return;  // the other instantiation handles this call
+  __shared__ float trk[CNF ? TILE : 1], cen_rk[CNF ? NL_CCHUNK : 1];  // scaled covalent radii of the staged candidates / of the chunk's centres
+  __shared__ double ccn[CNF ? NL_CCHUNK : 1];                           // running coordination number of each centre of the chunk
   __shared__ int ccnt2[DUAL ? NL_CCHUNK : 1];
   __shared__ T tx[TILE], ty[TILE], tz[TILE];
   __shared__ int tj[TILE];
-  __shared__ short tsx[TILE], tsy[TILE], tsz[TILE];
+  // per-candidate image shift: three shorts -- or, in the CN-summing variant, one word of 10-bit fields (its extra LDS arrays must not cost
+  // the fifth block per CU: 160 KB / 5 = 32 KB per block)
+  __shared__ short tsx[CNF ? 1 : TILE], tsy[CNF ? 1 : TILE], tsz[CNF ? 1 : TILE];
+  __shared__ int tsp[CNF ? TILE : 1];
   __shared__ int run_beg[3 * NL_MAXROWS], run_pre[3 * NL_MAXROWS + 1], run_cs[3 * NL_MAXROWS];
   __shared__ int ccnt[NL_CCHUNK];
   // the centre atoms of the current chunk, staged once per chunk: a wave must not LOAD from global memory inside the tile loop, because
@@ -446,7 +494,12 @@ __global__ __launch_bounds__(256) void nl_query_tiled_kernel(
   __shared__ short4 cen_w[NL_CCHUNK];
   __shared__ int grp_run[TILE / MI_WAVE];  // run containing the first candidate of each 64-candidate group of the current tile
   __shared__ int grp_shift[TILE / MI_WAVE];  // packed image shift common to all 64 candidates of the group, or NL_MIXED
-  __shared__ int u_beg[3 * NL_MAXROWS], u_len[3 * NL_MAXROWS], u_cs[3 * NL_MAXROWS];  // run table before ordering by image
+  // run table before ordering by image (CN-summing variant: it lives in the candidate tile, which is staged only after the table is final)
+  __shared__ int u_store[CNF ? 1 : 9 * NL_MAXROWS];
+  static_assert(sizeof(T) * TILE >= sizeof(int) * 9 * NL_MAXROWS, "the run table must fit the x array of a tile");
+  int* const u_beg = CNF ? reinterpret_cast<int*>(tx) : u_store;
+  int* const u_len = u_beg + 3 * NL_MAXROWS;
+  int* const u_cs = u_beg + 6 * NL_MAXROWS;
   const int tid = threadIdx.x, lane = tid & (MI_WAVE - 1), wave = tid / MI_WAVE;
   const int total_cells = glob->total_cells;
   const bool anyw = glob->any_wrap != 0;
@@ -538,6 +591,7 @@ __global__ __launch_bounds__(256) void nl_query_tiled_kernel(
           cen_x[tid] = cr.x; cen_y[tid] = cr.y; cen_z[tid] = cr.z;
           cen_i[tid] = idx_of(cr);
           cen_w[tid] = anyw ? swrap[c_beg + cbase + tid] : make_short4(0, 0, 0, 0);
+          if (CNF) { cen_rk[tid] = CN.rk[c_beg + cbase + tid]; ccn[tid] = 0.0; }
         }
       }
       for (int tile0 = 0; tile0 < total; tile0 += TILE) {
@@ -558,6 +612,7 @@ __global__ __launch_bounds__(256) void nl_query_tiled_kernel(
           const auto rec = spos[q];
           tx[t] = rec.x; ty[t] = rec.y; tz[t] = rec.z;
           tj[t] = idx_of(rec);
+          if (CNF) trk[t] = CN.rk[q];
           const int cs = run_cs[lo];
           int sx = (cs << 22) >> 22, sy = (cs << 12) >> 22, sz = (cs << 2) >> 22;  // sign-extend the 10-bit fields
           if (anyw) {
@@ -566,7 +621,8 @@ __global__ __launch_bounds__(256) void nl_query_tiled_kernel(
             if (pby) sy -= wj.y;
             if (pbz) sz -= wj.z;
           }
-          tsx[t] = (short)sx; tsy[t] = (short)sy; tsz[t] = (short)sz;
+          if (CNF) tsp[t] = (sx & 0x3ff) | ((sy & 0x3ff) << 10) | ((sz & 0x3ff) << 20);
+          else { tsx[t] = (short)sx; tsy[t] = (short)sy; tsz[t] = (short)sz; }
           // t = tid + 256 k: one wave stages exactly one 64-candidate group per trip (lanes past tile_n have left the loop)
           const int cs0 = __builtin_amdgcn_readfirstlane(cs);
           const bool same = __all(cs == cs0) && !anyw;  // per-atom wraps make the shift lane-dependent
@@ -580,6 +636,7 @@ __global__ __launch_bounds__(256) void nl_query_tiled_kernel(
         for (int ci0 = cbase + wave; ci0 < cend; ci0 += 4 * NC) {
           T ccx[NC], ccy[NC], ccz[NC];
           int ii[NC], cap_row[NC], cnt[NC], cnt2[NC];
+          float rki[NC], cnp[NC];  // CNF: the centre's scaled radius (wave-uniform) and this pass's lane partial of its coordination number
           long long out_base[NC];
           short4 wi[NC];
           const int nc = (cend - ci0 + 3) / 4 < NC ? (cend - ci0 + 3) / 4 : NC;  // centres of this wave in this pass (uniform)
@@ -590,12 +647,14 @@ __global__ __launch_bounds__(256) void nl_query_tiled_kernel(
             // a missing centre (last pass of a chunk) gets NaN coordinates: every `d2 < rc2` is false, so the candidate loop
             // needs no per-centre predicate
             ccx[u] = live ? cen_x[ci - cbase] : (T)NAN; ccy[u] = cen_y[ci - cbase]; ccz[u] = cen_z[ci - cbase];
+            if (CNF) { ccx[u] = nl_uni(ccx[u]); ccy[u] = nl_uni(ccy[u]); ccz[u] = nl_uni(ccz[u]); }  // centre coordinates in SGPRs: room for the CN partials at 5 waves / SIMD
             ii[u] = __builtin_amdgcn_readfirstlane(cen_i[ci - cbase]);
             wi[u] = cen_w[ci - cbase];
             if (MODE == MI_NL_MODE_CSR) { out_base[u] = ptr[ii[u]]; cap_row[u] = ptr[ii[u] + 1] - ptr[ii[u]]; }
             else { out_base[u] = (long long)ii[u] * M; cap_row[u] = M; }
             cnt[u] = ccnt[ci - cbase];
             cnt2[u] = DUAL ? ccnt2[ci - cbase] : 0;
+            if (CNF) { rki[u] = nl_uni(cen_rk[ci - cbase]); cnp[u] = 0.0f; }
           }
           const bool ortho = S->prune != 0;  // orthorhombic: S.cell has one non-zero term per component (adding exact zeros changes nothing)
           // Row bases as wave-uniform pointers and slots as 32-bit byte offsets: the hit stores become `global_store v_off, v_data, s[base]`
@@ -660,6 +719,9 @@ __global__ __launch_bounds__(256) void nl_query_tiled_kernel(
             const Cand cur = nxt;
             nxt = fetch(t0 + MI_WAVE);
             const int j = cur.j, tt = cur.tt;
+            // (read where it is used, not a trip ahead like the coordinates: one loop-carried register less, and the term is only formed
+            // after d^2 -- the LDS round trip hides behind the distance arithmetic)
+            const float rkj = CNF ? trk[tt] : 0.0f;
             const T cjx = cur.x, cjy = cur.y, cjz = cur.z;
             const int gs = __builtin_amdgcn_readfirstlane(cur.zg);
             if (FAST && gs == 0) {  // un-shifted image: adding S.cell = 0 cannot change the reference expression
@@ -668,6 +730,7 @@ __global__ __launch_bounds__(256) void nl_query_tiled_kernel(
                 const T dr0 = cjx - ccx[u], dr1 = cjy - ccy[u], dr2 = cjz - ccz[u];
                 const T d2 = dr0 * dr0 + dr1 * dr1 + dr2 * dr2;
                 const bool in = d2 < rc2, other = j != ii[u];
+                if (CNF) cnp[u] += (in & other & ((float)d2 >= 1e-24f)) ? nl_cn_term((float)d2, rki[u], rkj, CN.K) : 0.0f;  // (r < 1e-12: no term, dftd3.py:597)
                 emit_m(u, __builtin_amdgcn_ballot_w64(in) & __builtin_amdgcn_ballot_w64(other), in & other, j, 0, 0, 0, NL_PK_ZERO_SHIFT, true);
               }
             } else if (FAST && gs != NL_MIXED) {  // one common non-zero shift: S.cell once per group, no self-pair possible
@@ -682,11 +745,14 @@ __global__ __launch_bounds__(256) void nl_query_tiled_kernel(
                 const T dr0 = (cjx - ccx[u]) + cart[0], dr1 = (cjy - ccy[u]) + cart[1], dr2 = (cjz - ccz[u]) + cart[2];
                 const T d2 = dr0 * dr0 + dr1 * dr1 + dr2 * dr2;
                 const bool h = d2 < rc2;
+                if (CNF) cnp[u] += (h & ((float)d2 >= 1e-24f)) ? nl_cn_term((float)d2, rki[u], rkj, CN.K) : 0.0f;
                 if (MODE == MI_NL_MODE_MATRIX && bad && row_p[u] && h) *K.flag = 1;  // benign race: every writer stores 1
                 emit(u, h, j, Sx, Sy, Sz, code);
               }
             } else {
-              const int Sx0 = tsx[tt], Sy0 = tsy[tt], Sz0 = tsz[tt];
+              int Sx0, Sy0, Sz0;
+              if (CNF) { const int w = tsp[tt]; Sx0 = (w << 22) >> 22; Sy0 = (w << 12) >> 22; Sz0 = (w << 2) >> 22; }
+              else { Sx0 = tsx[tt]; Sy0 = tsy[tt]; Sz0 = tsz[tt]; }
 #pragma unroll
               for (int u = 0; u < NC; ++u) {
                 int Sx = Sx0, Sy = Sy0, Sz = Sz0;
@@ -699,6 +765,7 @@ __global__ __launch_bounds__(256) void nl_query_tiled_kernel(
                   const T dr0 = (cjx - ccx[u]) + cart[0], dr1 = (cjy - ccy[u]) + cart[1], dr2 = (cjz - ccz[u]) + cart[2];
                   const T d2 = dr0 * dr0 + dr1 * dr1 + dr2 * dr2;
                   h = (d2 < rc2) & !((j == ii[u]) & ((Sx | Sy | Sz) == 0));
+                  if (CNF) cnp[u] += (h & ((float)d2 >= 1e-24f)) ? nl_cn_term((float)d2, rki[u], rkj, CN.K) : 0.0f;
                 } else {
                   T d2;
                   h = nl_pair_hit<T>(ccx[u], ccy[u], ccz[u], ii[u], cjx, cjy, cjz, j, Sx, Sy, Sz, cart, rc2, naive, half, nr0, nr1, nr2, &d2);
@@ -723,6 +790,13 @@ __global__ __launch_bounds__(256) void nl_query_tiled_kernel(
               }
             }
           }
+          if (CNF) {  // <= TILE / 64 fp32 terms per lane and pass; across lanes and passes the sum is fp64 (one wave owns a centre: no race on ccn)
+#pragma unroll
+            for (int u = 0; u < NC; ++u) {
+              const double part = wave_sum((double)cnp[u]);
+              if (lane == 0 && u < nc) ccn[ci0 + 4 * u - cbase] += part;
+            }
+          }
           if (lane == 0) {
 #pragma unroll
             for (int u = 0; u < NC; ++u) if (u < nc) { ccnt[ci0 + 4 * u - cbase] = cnt[u]; if (DUAL) ccnt2[ci0 + 4 * u - cbase] = cnt2[u]; }
@@ -735,6 +809,10 @@ __global__ __launch_bounds__(256) void nl_query_tiled_kernel(
         const int i = __builtin_amdgcn_readfirstlane(cen_i[ci - cbase]);
         const int cnt = ccnt[ci - cbase];
         if (MODE != MI_NL_MODE_CSR) { if (lane == 0) num[i] = cnt; }
+        if (CNF && lane == 0) {
+          CN.cn[i] = (float)ccn[ci - cbase];
+          if (cnt > M) *CN.flag = 1;  // entries past the row width are counted but not stored: the list's own sum is smaller
+        }
         if (MODE == MI_NL_MODE_CSR) {
           const long long rb = ptr[i];
           const int room = ptr[i + 1] - ptr[i];
@@ -767,14 +845,15 @@ __global__ __launch_bounds__(256) void nl_query_tiled_kernel(
   }
 }
 
-template <class T, int MODE, bool DUAL = false>
+template <class T, int MODE, bool DUAL = false, bool CNF = false>
 __global__ __launch_bounds__(256) void nl_query_kernel(
     const typename Vec4<T>::type* __restrict__ spos, const short4* __restrict__ swrap, const int* __restrict__ keys_sorted,
     const int* __restrict__ cell_start, const int* __restrict__ batch_idx, const NlSys<T>* __restrict__ sys,
     const NlGlobal* __restrict__ glob, int N, T rc2, int flags, int* __restrict__ nm, int* __restrict__ nsh, int* __restrict__ num,
     int M, int fill_value, const int* __restrict__ ptr, int* __restrict__ list_ij, int* __restrict__ list_sh, long long P, NlSecond<T> D,
-    NlPacked K) {
+    NlPacked K, NlCn CN = NlCn{nullptr, nullptr, nullptr, 0.0f}) {
   static_assert(!DUAL || MODE == MI_NL_MODE_MATRIX, "the dual-cutoff sweep fills two padded matrices");
+  static_assert(!CNF || (MODE == MI_NL_MODE_MATRIX && !DUAL), "coordination numbers ride with the plain matrix search");
   if (glob->use_tiled) return;  // dense cells: the block-per-cell LDS-tiled kernel (launched next to this one) does the work
   const int lane = threadIdx.x & (MI_WAVE - 1);
   const int p = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x / MI_WAVE) + (threadIdx.x / MI_WAVE));
@@ -805,6 +884,10 @@ __global__ __launch_bounds__(256) void nl_query_kernel(
   if (MODE == MI_NL_MODE_CSR) { out_base = ptr[i]; cap_row = ptr[i + 1] - ptr[i]; }
   else { out_base = (long long)i * M; cap_row = M; }
   int cnt = 0, cnt2 = 0;
+  // CNF: DFT-D3 coordination number of this centre over its hits (NlCn): the wave owns the row, so the lane partials live in registers
+  // for the whole walk (fp64, as mi_d3's own pass keeps them)
+  const float rki = CNF ? __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(CN.rk[p]))) : 0.0f;
+  double cnacc = 0.0;
 
   const bool prune = S->prune != 0;
 
@@ -837,6 +920,7 @@ __global__ __launch_bounds__(256) void nl_query_kernel(
         T d2;
         hit = nl_pair_hit<T>(pix, piy, piz, i, cj.x, cj.y, cj.z, j, Sx, Sy, Sz, cart, rc2, naive, half, nr0, nr1, nr2, &d2);
         hit2 = DUAL && hit && (d2 < D.rc2);
+        if (CNF) cnacc += (hit && (float)d2 >= 1e-24f) ? (double)nl_cn_term((float)d2, rki, CN.rk[q], CN.K) : 0.0;
       }
       if (DUAL) {  // the short list, nested in the long one
         const unsigned long long m2 = __ballot(hit2);
@@ -956,6 +1040,13 @@ __global__ __launch_bounds__(256) void nl_query_kernel(
     if (lane == 0) num[i] = cnt;
   } else {
     wave_fill(list_ij, out_base, out_base + (cnt < cap_row ? cnt : cap_row), i, lane);
+  }
+  if (CNF) {
+    cnacc = wave_sum(cnacc);
+    if (lane == 0) {
+      CN.cn[i] = (float)cnacc;
+      if (cnt > M || half) *CN.flag = 1;  // truncated rows / half lists: the stored list's own sum differs
+    }
   }
   if (MODE == MI_NL_MODE_MATRIX && !(flags & MI_NL_NO_PAD)) {
     // the row owner also writes the padding (replaces torch.full + zeros of cell_list.py:1358-1373)
@@ -1192,7 +1283,7 @@ template <class T>
 int nl_neighbors_impl(const T* pos, int N, const T* cell, const uint8_t* pbc, const int* batch_idx, int B, double cutoff, int mode, int flags,
                       int* nm, int* nsh, int* num, int M, int fill_value, const int* ptr, int* list_ij, int* list_sh, long long P,
                       const T* origin, char* ws, const NlLayout& L, hipStream_t st, const NlSecond<T>* second = nullptr,
-                      NlPacked K = NlPacked{nullptr, nullptr}) {
+                      NlPacked K = NlPacked{nullptr, nullptr}, const mi_nl_cn_request* cnreq = nullptr, void* cn_block = nullptr) {
   auto* sys = reinterpret_cast<NlSys<T>*>(ws + L.sys);
   auto* glob = reinterpret_cast<NlGlobal*>(ws + L.glob);
   int* natoms = reinterpret_cast<int*>(ws + L.natoms);
@@ -1205,6 +1296,18 @@ int nl_neighbors_impl(const T* pos, int N, const T* cell, const uint8_t* pbc, co
   auto* spos = reinterpret_cast<typename Vec4<T>::type*>(ws + L.spos);
   int* cell_start = reinterpret_cast<int*>(ws + L.cell_start);
   const T rc = (T)cutoff;
+  // coordination numbers as a by-product (NlCn): header words + checksum slots + cn[] of the caller's block, scaled radii in the workspace
+  NlCn CN{nullptr, nullptr, nullptr, 0.0f};
+  NlCnBuild CB{nullptr, nullptr, 0, 0.0f, nullptr, nullptr, nullptr, 0, nullptr};
+  if (cnreq && cn_block) {
+    const float K1 = mi_cn_scale(cnreq->k1);
+    int* hdr = reinterpret_cast<int*>(cn_block);
+    CN = NlCn{reinterpret_cast<const float*>(ws + L.srk), reinterpret_cast<float*>((char*)cn_block + MI_CN_HEADER_BYTES), hdr, K1};
+    CB = NlCnBuild{cnreq->numbers, cnreq->covalent_radii, cnreq->nz, K1, reinterpret_cast<float*>(ws + L.srk),
+                   reinterpret_cast<unsigned long long*>(cn_block) + MI_CN_SLOT_OFFSET_U64, cell, 9 * B, batch_idx};
+    // (the header -- {unusable flag = 0, 0, cutoff, K} -- and the cleared checksum slots are written by nl_setup_kernel: no extra launch)
+    MI_REQUIRE(!(flags & MI_NL_REUSE_GRID), "a search that sums coordination numbers bins its atoms itself (no MI_NL_REUSE_GRID)");
+  }
   // cell list: cutoff cast to the positions dtype, then squared (cell_list.py:444,1020);
   // naive: squared in double, then cast (naive.py:290,388)
   const T rc2 = (flags & MI_NL_NAIVE_EXPR) ? (T)(cutoff * cutoff) : rc * rc;
@@ -1225,12 +1328,13 @@ int nl_neighbors_impl(const T* pos, int N, const T* cell, const uint8_t* pbc, co
     const int zero_blocks = (int)(zero_words / 2048 < 1 ? 1 : (zero_words / 2048 > 255 ? 255 : zero_words / 2048));
     const int table_blocks = mi_blocks((long long)B * (NL_PRUNE_R + 1) * (NL_PRUNE_R + 1), 256);
     nl_setup_kernel<T><<<1 + table_blocks + zero_blocks, 256, 0, st>>>(cell, pbc, nat, N, B, rc, origin, sys, glob, table_blocks,
-                                                                       reinterpret_cast<int4*>(bins.count), zero_words, K.words ? K.flag : nullptr);
+                                                                       reinterpret_cast<int4*>(bins.count), zero_words, K.words ? K.flag : nullptr,
+                                                                       CN.flag, CN.K);
     MI_LAUNCH_CHECK();
     nl_assign_kernel<T><<<mi_blocks(N, 256), 256, 0, st>>>(pos, batch_idx, N, sys, keys_in, bins.count, wrap, glob);
     MI_LAUNCH_CHECK();
     MI_HIP_CHECK(bs_sort(bins, keys_in, N, &glob->total_cells, vals_out, cell_start, st));
-    nl_rank_gather_kernel<T><<<mi_blocks(N, 256), 256, 0, st>>>(pos, vals_out, keys_in, cell_start, wrap, N, spos, swrap, keys_out);
+    nl_rank_gather_kernel<T><<<mi_blocks(CB.srk && 9 * B > N ? 9 * B : N, 256), 256, 0, st>>>(pos, vals_out, keys_in, cell_start, wrap, N, spos, swrap, keys_out, CB);
     MI_LAUNCH_CHECK();
     mi_timing_end((void*)st);
   }
@@ -1262,7 +1366,14 @@ int nl_neighbors_impl(const T* pos, int N, const T* cell, const uint8_t* pbc, co
       nl_query_tiled_kernel<T, MODE_, false><<<nl_tiled_grid(), 256, 0, st>>>(spos, swrap, cell_start, sys, glob, B, rc2, flags, nm, nsh, num, \
                                                                            M, fill_value, ptr, list_ij, list_sh, P, none, K);            \
   } while (0)
-  if (mode == MI_NL_MODE_MATRIX) MI_TIMED(sizeof(T) == 4 ? "nl_query_matrix_f32" : "nl_query_matrix_f64", st, MI_NLQ(MI_NL_MODE_MATRIX); MI_NLT(MI_NL_MODE_MATRIX));
+  if (mode == MI_NL_MODE_MATRIX && CN.cn) {
+    // the search that also sums the coordination numbers: FAST tiled kernel + wave-per-atom kernel, as above (the device picks one)
+    MI_TIMED(sizeof(T) == 4 ? "nl_query_matrix_f32" : "nl_query_matrix_f64", st,
+             (nl_query_kernel<T, MI_NL_MODE_MATRIX, false, true><<<blocks, 256, 0, st>>>(spos, swrap, keys_out, cell_start, batch_idx, sys, glob, N, rc2, flags, nm,
+                                                                                        nsh, num, M, fill_value, ptr, list_ij, list_sh, P, none, K, CN),
+              nl_query_tiled_kernel<T, MI_NL_MODE_MATRIX, true, false, true><<<nl_tiled_grid(), 256, 0, st>>>(
+                  spos, swrap, cell_start, sys, glob, B, rc2, flags, nm, nsh, num, M, fill_value, ptr, list_ij, list_sh, P, none, K, CN)));
+  } else if (mode == MI_NL_MODE_MATRIX) MI_TIMED(sizeof(T) == 4 ? "nl_query_matrix_f32" : "nl_query_matrix_f64", st, MI_NLQ(MI_NL_MODE_MATRIX); MI_NLT(MI_NL_MODE_MATRIX));
   else if (mode == MI_NL_MODE_COUNT) MI_TIMED("nl_query_count", st, MI_NLQ(MI_NL_MODE_COUNT); MI_NLT(MI_NL_MODE_COUNT));
   else MI_TIMED("nl_query_csr", st, MI_NLQ(MI_NL_MODE_CSR); MI_NLT(MI_NL_MODE_CSR));
 #undef MI_NLT
@@ -1310,7 +1421,8 @@ size_t mi_nl_workspace_bytes(int n_atoms, int n_systems, int dtype) {
 static int nl_neighbors_entry(const void* positions, int n_atoms, const void* cell, const uint8_t* pbc, const int32_t* batch_idx, int n_systems,
                     double cutoff, int dtype, int mode, int flags, int32_t* neighbor_matrix, int32_t* neighbor_matrix_shifts,
                     int32_t* num_neighbors, int max_neighbors, int fill_value, const int32_t* neighbor_ptr, int32_t* list_ij,
-                    int32_t* list_shifts, long long n_pairs, const void* bin_origin, void* workspace, size_t workspace_bytes, void* stream, void* packed_out) {
+                    int32_t* list_shifts, long long n_pairs, const void* bin_origin, void* workspace, size_t workspace_bytes, void* stream, void* packed_out,
+                    const mi_nl_cn_request* cnreq = nullptr, void* cn_block = nullptr) {
   MI_REQUIRE(dtype == MI_F32 || dtype == MI_F64, "dtype must be MI_F32 or MI_F64");
   MI_REQUIRE(n_atoms >= 0 && n_systems >= 1, "n_atoms >= 0 and n_systems >= 1");
   MI_REQUIRE(cutoff > 0, "cutoff must be positive");
@@ -1331,13 +1443,14 @@ static int nl_neighbors_entry(const void* positions, int n_atoms, const void* ce
     K.flag = reinterpret_cast<int*>(packed_out);
     K.words = reinterpret_cast<unsigned*>(packed_out) + 64;
   }
+  if (cnreq) MI_REQUIRE(packed_out && cn_block && cnreq->numbers && cnreq->covalent_radii && cnreq->nz >= 2, "coordination numbers: companion, output block, numbers and radii");
   if (dtype == MI_F32)
     return nl_neighbors_impl<float>((const float*)positions, n_atoms, (const float*)cell, pbc, batch_idx, n_systems, cutoff, mode, flags,
                                     neighbor_matrix, neighbor_matrix_shifts, num_neighbors, max_neighbors, fill_value, neighbor_ptr, list_ij,
-                                    list_shifts, n_pairs, (const float*)bin_origin, (char*)workspace, L, st, nullptr, K);
+                                    list_shifts, n_pairs, (const float*)bin_origin, (char*)workspace, L, st, nullptr, K, cnreq, cn_block);
   return nl_neighbors_impl<double>((const double*)positions, n_atoms, (const double*)cell, pbc, batch_idx, n_systems, cutoff, mode, flags,
                                    neighbor_matrix, neighbor_matrix_shifts, num_neighbors, max_neighbors, fill_value, neighbor_ptr, list_ij,
-                                   list_shifts, n_pairs, (const double*)bin_origin, (char*)workspace, L, st, nullptr, K);
+                                   list_shifts, n_pairs, (const double*)bin_origin, (char*)workspace, L, st, nullptr, K, cnreq, cn_block);
 }
 
 extern "C" {
@@ -1364,6 +1477,21 @@ int mi_nl_neighbors_packed(const void* positions, int n_atoms, const void* cell,
   return nl_neighbors_entry(positions, n_atoms, cell, pbc, batch_idx, n_systems, cutoff, dtype, MI_NL_MODE_MATRIX, flags, neighbor_matrix,
                             neighbor_matrix_shifts, num_neighbors, max_neighbors, fill_value, nullptr, nullptr, nullptr, 0, bin_origin, workspace,
                             workspace_bytes, stream, packed_out);
+}
+
+size_t mi_nl_cn_bytes(int n_atoms) { return n_atoms > 0 ? MI_CN_HEADER_BYTES + sizeof(float) * (size_t)n_atoms : 0; }
+
+int mi_nl_neighbors_packed_cn(const void* positions, int n_atoms, const void* cell, const uint8_t* pbc, const int32_t* batch_idx, int n_systems,
+                              double cutoff, int dtype, int flags, int32_t* neighbor_matrix, int32_t* neighbor_matrix_shifts,
+                              int32_t* num_neighbors, int max_neighbors, int fill_value, const void* bin_origin, void* workspace,
+                              size_t workspace_bytes, void* packed_out, size_t packed_bytes, const mi_nl_cn_request* request, void* cn_out,
+                              size_t cn_bytes, void* stream) {
+  MI_REQUIRE(packed_out != nullptr && packed_bytes >= mi_nl_packed_bytes(n_atoms, max_neighbors) && mi_nl_packed_bytes(n_atoms, max_neighbors) > 0,
+             "packed_out: mi_nl_packed_bytes(n_atoms, max_neighbors) bytes");
+  MI_REQUIRE(request != nullptr && cn_out != nullptr && cn_bytes >= mi_nl_cn_bytes(n_atoms), "cn_out: mi_nl_cn_bytes(n_atoms) bytes and a request");
+  return nl_neighbors_entry(positions, n_atoms, cell, pbc, batch_idx, n_systems, cutoff, dtype, MI_NL_MODE_MATRIX, flags, neighbor_matrix,
+                            neighbor_matrix_shifts, num_neighbors, max_neighbors, fill_value, nullptr, nullptr, nullptr, 0, bin_origin, workspace,
+                            workspace_bytes, stream, packed_out, request, cn_out);
 }
 
 int mi_nl_neighbors_dual(const void* positions, int n_atoms, const void* cell, const uint8_t* pbc, const int32_t* batch_idx, int n_systems,

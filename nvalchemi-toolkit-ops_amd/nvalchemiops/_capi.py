@@ -32,6 +32,11 @@ class MiD3Params(ctypes.Structure):
                 ("k1", ctypes.c_float), ("k3", ctypes.c_float), ("s5_on", ctypes.c_float), ("s5_off", ctypes.c_float)]
 
 
+class MiNlCnRequest(ctypes.Structure):
+    """`mi_nl_cn_request` of include/nvalchemiops_hip.h: what a search needs to sum DFT-D3 coordination numbers over the list it writes."""
+    _fields_ = [("numbers", ctypes.c_void_p), ("covalent_radii", ctypes.c_void_p), ("nz", ctypes.c_int), ("k1", ctypes.c_float)]
+
+
 def lib() -> ctypes.CDLL:
     global _LIB
     if _LIB is None:
@@ -53,6 +58,8 @@ def lib() -> ctypes.CDLL:
         L.mi_spline_spread_order_offset.argtypes = [ctypes.c_int] * 6
         L.mi_nl_packed_bytes.restype = ctypes.c_size_t
         L.mi_nl_packed_bytes.argtypes = [ctypes.c_int, ctypes.c_int]
+        L.mi_nl_cn_bytes.restype = ctypes.c_size_t
+        L.mi_nl_cn_bytes.argtypes = [ctypes.c_int]
         if hasattr(L, "mi_d3_workspace_bytes"):
             L.mi_d3_workspace_bytes.restype = ctypes.c_size_t
             L.mi_d3_workspace_bytes.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int]

@@ -73,8 +73,10 @@ _LIB_OVERRIDE = None  # tests only: a ctypes handle of the IEEE-arithmetic build
 
 def _launch(positions, numbers, idx, shifts, nptr, max_neighbors, fill_value, cell, batch_idx, num_systems, tables, scalars,
             compute_virial, energy, forces, coord_num, virial, packed=None) -> None:
-    """`packed`: the companion word list the neighbour search left next to (idx, shifts) (`neighborlist/_engine.py`), already validated by the
-    caller; the passes then stream 4 B/slot from the first pass on (`mi_d3_packed`)."""
+    """`packed`: the companion record the neighbour search left next to (idx, shifts) (`neighborlist/_engine.py`: `.words`, and `.cn` when the
+    search also summed the coordination numbers), already validated by the caller against tensor identity / versions; the passes then stream
+    4 B/slot (`mi_d3_packed_cn`), the CN pass is skipped when the device-side fingerprint check lets the search's numbers in, and every call
+    re-derives a rotating sample of the companion's rows from (idx, shifts) on the device before trusting it."""
     dev = positions.device
     n = positions.shape[0]
     pos = positions.detach().contiguous()
@@ -101,13 +103,18 @@ def _launch(positions, numbers, idx, shifts, nptr, max_neighbors, fill_value, ce
     vir = virial if compute_virial else None
     z = C.i32(numbers)  # converted tensors stay referenced until the launch is enqueued (the allocator may otherwise reuse their blocks)
     if packed is not None and periodic and nptr is None and mode != "0":
-        rc = L.mi_d3_packed(C.ptr(pos), C.ptr(z), n, code, C.ptr(idx), C.ptr(sh), int(max_neighbors), int(fill_value), C.ptr(cell_t), C.ptr(bi),
-                            int(num_systems), ctypes.byref(par), int(bool(compute_virial)), C.ptr(energy), C.ptr(forces), C.ptr(coord_num),
-                            C.ptr(vir), C.ptr(ws), ctypes.c_size_t(ws_bytes), C.ptr(packed), ctypes.c_size_t(packed.numel() * packed.element_size()),
-                            C.stream_of(pos))
+        from nvalchemiops.neighborlist import _engine as E
+
+        words = packed.words
+        cn = packed.cn if os.environ.get("NVALCHEMIOPS_D3_SEARCH_CN", "1") != "0" else None  # (A/B switch: "0" ignores the search's coordination numbers)
+        stride, phase = E.verify_args()
+        rc = L.mi_d3_packed_cn(C.ptr(pos), C.ptr(z), n, code, C.ptr(idx), C.ptr(sh), int(max_neighbors), int(fill_value), C.ptr(cell_t), C.ptr(bi),
+                               int(num_systems), ctypes.byref(par), int(bool(compute_virial)), C.ptr(energy), C.ptr(forces), C.ptr(coord_num),
+                               C.ptr(vir), C.ptr(ws), ctypes.c_size_t(ws_bytes), C.ptr(words), ctypes.c_size_t(words.numel() * words.element_size()),
+                               C.ptr(cn), ctypes.c_size_t(cn.numel() if cn is not None else 0), int(stride), int(phase), C.stream_of(pos))
         if rc != 0 and _LIB_OVERRIDE is not None:
-            raise C.NativeLibraryError(f"mi_d3_packed (override library) failed with code {rc}")
-        C.check(rc, "mi_d3_packed")
+            raise C.NativeLibraryError(f"mi_d3_packed_cn (override library) failed with code {rc}")
+        C.check(rc, "mi_d3_packed_cn")
         return
     rc = L.mi_d3(C.ptr(pos), C.ptr(z), n, code, C.ptr(idx), C.ptr(sh), C.ptr(nptr), int(max_neighbors),
                  ctypes.c_longlong(idx.shape[0] if nptr is not None else 0), int(fill_value),  # CSR: the entry count (packing is decided by the workspace size)

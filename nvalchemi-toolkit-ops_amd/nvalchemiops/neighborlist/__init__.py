@@ -2,6 +2,7 @@
 from nvalchemiops.neighborlist.batch_cell_list import (batch_build_cell_list, batch_cell_list, batch_query_cell_list,
                                                        estimate_batch_cell_list_sizes)
 from nvalchemiops.neighborlist.buffers import tuned_neighbor_buffers
+from nvalchemiops.neighborlist._engine import D3SearchContext, attach_dftd3_context, invalidate
 from nvalchemiops.neighborlist.batch_naive import batch_naive_neighbor_list
 from nvalchemiops.neighborlist.batch_naive_dual_cutoff import batch_naive_neighbor_list_dual_cutoff
 from nvalchemiops.neighborlist.cell_list import build_cell_list, cell_list, estimate_cell_list_sizes, query_cell_list
@@ -21,4 +22,7 @@ __all__ = [
     "check_neighbor_list_rebuild_needed", "batch_naive_neighbor_list", "naive_neighbor_list_dual_cutoff",
     "batch_naive_neighbor_list_dual_cutoff",
     "tuned_neighbor_buffers",  # MI355X addition: output buffers chosen by a measured trial search (neighborlist/buffers.py)
+    # MI355X additions around the packed companion of a padded matrix (neighborlist/_engine.py): a search that also sums the DFT-D3
+    # coordination numbers, and the call that drops a companion after a raw-pointer edit of the matrix
+    "D3SearchContext", "attach_dftd3_context", "invalidate",
 ]

@@ -28,14 +28,69 @@ _PACKED_POLICY = os.environ.get("NVALCHEMIOPS_NL_PACKED", "auto")
 _PACKED_WANTED: set[tuple[int, int, int]] = set()
 _PACKED_ATTR = "_nvalchemiops_packed"
 _BUILT_ATTR = "_nvalchemiops_built"
+_D3CTX_ATTR = "_nvalchemiops_d3ctx"
+# Device-side check of a companion against the arrays it describes, run by `dftd3` on every call (csrc/d3.hip, D3Guard): every
+# NVALCHEMIOPS_NL_PACKED_VERIFY-th row is re-derived from matrix + shifts and compared word by word (default 64: +1.6 % of the list's
+# traffic; "1" compares every row; "0" switches the check off).  The sampled rows rotate from call to call, so an edit that persists is
+# seen within `stride` calls wherever it sits.
+_VERIFY_STRIDE = max(0, int(os.environ.get("NVALCHEMIOPS_NL_PACKED_VERIFY", "64") or 0))
+_verify_calls = 0
+
+
+def verify_args() -> tuple[int, int]:
+    """(stride, phase) of the sampled companion check for the next `dftd3` call."""
+    global _verify_calls
+    _verify_calls += 1
+    return _VERIFY_STRIDE, (_verify_calls - 1) % max(_VERIFY_STRIDE, 1)
+
+
+class D3SearchContext:
+    """What a neighbour search needs in order to sum the DFT-D3 coordination numbers of the list while it writes it (round 6,
+    `mi_nl_neighbors_packed_cn`): atomic numbers, covalent radii (fp32 table indexed by Z, `D3Parameters.rcov`) and the counting function's
+    steepness k1.  Attached to the OUTPUT buffer (`attach_dftd3_context`, or `tuned_neighbor_buffers(for_dftd3=ctx)`), so the reference
+    signatures of `cell_list` / `batch_cell_list` stay what they are.  The tensors are converted once, here; a caller who later hands
+    `dftd3` other species, radii, positions or cell simply gets the ordinary CN pass: the numbers are only adopted when the fingerprint
+    `dftd3` computes on the device from ITS arguments equals the one the search stored (csrc/common.h)."""
+    __slots__ = ("numbers", "rcov", "k1")
+
+    def __init__(self, numbers: torch.Tensor, covalent_radii: torch.Tensor, k1: float = 16.0):
+        self.numbers = numbers.detach().to(torch.int32).contiguous()
+        self.rcov = covalent_radii.detach().to(device=numbers.device, dtype=torch.float32).contiguous()
+        self.k1 = float(k1)
+
+
+def attach_dftd3_context(neighbor_matrix: torch.Tensor, numbers: torch.Tensor, covalent_radii: torch.Tensor, k1: float = 16.0) -> None:
+    """Every later search into `neighbor_matrix` that qualifies for a packed companion also sums the DFT-D3 coordination numbers."""
+    setattr(neighbor_matrix, _D3CTX_ATTR, D3SearchContext(numbers, covalent_radii, k1))
+    want_packed_companion(neighbor_matrix.device, int(neighbor_matrix.shape[0]), int(neighbor_matrix.shape[1]))
+
+
+def invalidate(*tensors: torch.Tensor) -> None:
+    """Drop the packed companion (and the coordination numbers riding with it) of a neighbour matrix.  Call this after writing
+    `neighbor_matrix` / `neighbor_matrix_shifts` through anything torch's version counters do not see -- a raw-pointer kernel, DLPack,
+    `tensor.data[...] = ...`, `untyped_storage().copy_` -- and pass either tensor (or both): `dftd3` then reads the arrays themselves."""
+    for t in tensors:
+        if t is None:
+            continue
+        for attr in (_PACKED_ATTR, _BUILT_ATTR):
+            if hasattr(t, attr):
+                delattr(t, attr)
+        owner = getattr(t, "_nvalchemiops_owner", None)  # the shifts tensor knows its matrix
+        nm = owner() if owner is not None else None
+        if nm is not None and nm is not t:
+            for attr in (_PACKED_ATTR, _BUILT_ATTR):
+                if hasattr(nm, attr):
+                    delattr(nm, attr)
 
 
 class PackedCompanion:
-    """What `dftd3` needs to trust a companion: the words, and the identity + version of the two tensors they describe."""
-    __slots__ = ("words", "nm_version", "nsh_ref", "nsh_version", "n_atoms", "row_width", "fill_value")
+    """What `dftd3` needs to trust a companion: the words, and the identity + version of the two tensors they describe.  `cn`: the block of
+    coordination numbers the same search summed (or None); its validity is checked on the device, not here."""
+    __slots__ = ("words", "cn", "nm_version", "nsh_ref", "nsh_version", "n_atoms", "row_width", "fill_value")
 
-    def __init__(self, words, nm, nsh, fill_value):
+    def __init__(self, words, nm, nsh, fill_value, cn=None):
         self.words = words
+        self.cn = cn
         self.nm_version = nm._version
         self.nsh_ref = weakref.ref(nsh)
         self.nsh_version = nsh._version
@@ -71,13 +126,13 @@ def _written(*tensors) -> None:
 
 
 def packed_companion(nm: torch.Tensor, nsh: torch.Tensor | None, fill_value: int):
-    """The companion of (nm, nsh) if it is still valid, else None.  Also where the "auto" policy learns: a matrix this package built without
-    a companion, handed to a consumer that would have used one, registers its shape."""
+    """The companion record of (nm, nsh) if it is still valid (`.words`, `.cn`), else None.  Also where the "auto" policy learns: a matrix
+    this package built without a companion, handed to a consumer that would have used one, registers its shape."""
     rec = getattr(nm, _PACKED_ATTR, None)
     if rec is not None:
         try:
             if rec.matches(nm, nsh, fill_value):
-                return rec.words
+                return rec
         except Exception:
             pass
         return None
@@ -162,14 +217,29 @@ def neighbor_matrix(pos, cell, pbc, batch_idx, cutoff, max_neighbors, fill_value
     old = getattr(nm, _PACKED_ATTR, None)  # an MD loop searches into the same buffers every step: reuse the companion's storage
     words = old.words if (old is not None and old.words.numel() == nbytes and old.words.device == pos.device) else torch.empty(nbytes, dtype=torch.uint8, device=pos.device)
     ws = workspace(n, cell.shape[0], pos.dtype, pos.device)
+    ctx = getattr(nm, _D3CTX_ATTR, None)  # the caller announced that this list feeds dftd3 with these species: also sum the coordination numbers
+    if ctx is not None and (ctx.numbers.shape[0] != n or ctx.numbers.device != pos.device):
+        ctx = None
     _written(nm, nsh, num)
-    rc = C.lib().mi_nl_neighbors_packed(
-        C.ptr(pos), n, C.ptr(cell), C.ptr(pbc), C.ptr(batch_idx), cell.shape[0], C.cdouble(cutoff), C.dtype_code(pos.dtype), flags,
-        C.ptr(nm), C.ptr(nsh), C.ptr(num), int(max_neighbors), int(fill_value), C.ptr(origin), C.ptr(ws), ctypes.c_size_t(ws.numel()),
-        C.ptr(words), ctypes.c_size_t(nbytes), C.stream_of(pos))
-    C.check(rc, "mi_nl_neighbors_packed")
+    cn = None
+    if ctx is not None:
+        cn_bytes = int(C.lib().mi_nl_cn_bytes(n))
+        cn = old.cn if (old is not None and old.cn is not None and old.cn.numel() == cn_bytes and old.cn.device == pos.device) else torch.empty(cn_bytes, dtype=torch.uint8, device=pos.device)
+        req = C.MiNlCnRequest(numbers=ctx.numbers.data_ptr(), covalent_radii=ctx.rcov.data_ptr(), nz=int(ctx.rcov.shape[0]), k1=ctx.k1)
+        rc = C.lib().mi_nl_neighbors_packed_cn(
+            C.ptr(pos), n, C.ptr(cell), C.ptr(pbc), C.ptr(batch_idx), cell.shape[0], C.cdouble(cutoff), C.dtype_code(pos.dtype), flags,
+            C.ptr(nm), C.ptr(nsh), C.ptr(num), int(max_neighbors), int(fill_value), C.ptr(origin), C.ptr(ws), ctypes.c_size_t(ws.numel()),
+            C.ptr(words), ctypes.c_size_t(nbytes), ctypes.byref(req), C.ptr(cn), ctypes.c_size_t(cn_bytes), C.stream_of(pos))
+        C.check(rc, "mi_nl_neighbors_packed_cn")
+    else:
+        rc = C.lib().mi_nl_neighbors_packed(
+            C.ptr(pos), n, C.ptr(cell), C.ptr(pbc), C.ptr(batch_idx), cell.shape[0], C.cdouble(cutoff), C.dtype_code(pos.dtype), flags,
+            C.ptr(nm), C.ptr(nsh), C.ptr(num), int(max_neighbors), int(fill_value), C.ptr(origin), C.ptr(ws), ctypes.c_size_t(ws.numel()),
+            C.ptr(words), ctypes.c_size_t(nbytes), C.stream_of(pos))
+        C.check(rc, "mi_nl_neighbors_packed")
     try:
-        setattr(nm, _PACKED_ATTR, PackedCompanion(words, nm, nsh, fill_value))
+        setattr(nm, _PACKED_ATTR, PackedCompanion(words, nm, nsh, fill_value, cn=cn))
+        setattr(nsh, "_nvalchemiops_owner", weakref.ref(nm))  # so that `invalidate(shifts)` finds the matrix the companion rides on
     except Exception:  # no version counter (inference tensor): no companion
         pass
 

@@ -20,14 +20,16 @@ from nvalchemiops.neighborlist import _engine as E
 
 @torch.compiler.disable
 def tuned_neighbor_buffers(positions: torch.Tensor, cutoff: float, cell: torch.Tensor, pbc: torch.Tensor, max_neighbors: int, *,
-                           batch_idx: torch.Tensor | None = None, candidates: int = 6, trials: int = 3, for_dftd3: bool = False,
-                           release_unused: bool = True, report: dict | None = None):
+                           batch_idx: torch.Tensor | None = None, candidates: int = 6, trials: int = 3,
+                           for_dftd3: "bool | E.D3SearchContext" = False, release_unused: bool = True, report: dict | None = None):
     """Allocate ``(neighbor_matrix[N, M], neighbor_matrix_shifts[N, M, 3], num_neighbors[N])`` for repeated
     ``cell_list(..., neighbor_matrix=..., neighbor_matrix_shifts=..., num_neighbors=...)`` / ``batch_cell_list`` calls, picking among
     `candidates` freshly allocated buffer sets the one a trial search of THIS system fills fastest.
 
     for_dftd3: the buffers will feed `dftd3` -- the trial searches (and every later search into these buffers) also emit the packed
-    companion the D3 passes stream (`neighborlist/_engine.py`), so its placement is part of what is measured.
+    companion the D3 passes stream (`neighborlist/_engine.py`), so its placement is part of what is measured.  Pass a
+    `D3SearchContext(numbers, covalent_radii, k1)` instead of True and the searches also sum the DFT-D3 coordination numbers of the list
+    (the context is attached to the returned matrix: `dftd3` then skips its CN pass whenever it is called with the same atoms).
     release_unused: hand the losing candidates back to the driver (`torch.cuda.empty_cache()`), not just to torch's caching allocator.
     report: optional dict that receives the per-candidate trial times (ms) and the index chosen.
     Small lists (< 256 MiB of output) gain nothing: one set is allocated and returned."""
@@ -36,9 +38,14 @@ def tuned_neighbor_buffers(positions: torch.Tensor, cutoff: float, cell: torch.T
 
     n, m, dev = positions.shape[0], int(max_neighbors), positions.device
 
+    ctx = for_dftd3 if isinstance(for_dftd3, E.D3SearchContext) else None
+
     def fresh():
-        return (torch.empty((n, m), dtype=torch.int32, device=dev), torch.empty((n, m, 3), dtype=torch.int32, device=dev),
+        bufs = (torch.empty((n, m), dtype=torch.int32, device=dev), torch.empty((n, m, 3), dtype=torch.int32, device=dev),
                 torch.empty((n,), dtype=torch.int32, device=dev))
+        if ctx is not None:
+            setattr(bufs[0], E._D3CTX_ATTR, ctx)
+        return bufs
 
     def search(bufs):
         if batch_idx is None:

@@ -514,7 +514,7 @@ def test_packed_companion_validity_rules():
     E._written(nm, sh)
     words = torch.zeros(8, dtype=torch.uint8)
     setattr(nm, E._PACKED_ATTR, E.PackedCompanion(words, nm, sh, 6))
-    assert E.packed_companion(nm, sh, 6) is words
+    assert E.packed_companion(nm, sh, 6).words is words
     assert E.packed_companion(nm, sh.clone(), 6) is None      # another tensor, equal contents
     assert E.packed_companion(nm, sh, 5) is None              # another index limit
     assert E.packed_companion(nm, None, 6) is None
@@ -522,7 +522,7 @@ def test_packed_companion_validity_rules():
     sh.add_(0)                                                # any in-place op moves the version counter
     assert E.packed_companion(nm, sh, 6) is None
     setattr(nm, E._PACKED_ATTR, E.PackedCompanion(words, nm, sh, 6))
-    assert E.packed_companion(nm, sh, 6) is words
+    assert E.packed_companion(nm, sh, 6).words is words
     nm[0, 0] = 3
     assert E.packed_companion(nm, sh, 6) is None
     setattr(nm, E._PACKED_ATTR, E.PackedCompanion(words, nm, sh, 6))
@@ -535,6 +535,22 @@ def test_packed_companion_validity_rules():
     setattr(nm, E._PACKED_ATTR, E.PackedCompanion(words, nm, sh, 6))
     del sh
     assert E.packed_companion(nm, torch.zeros((6, 4, 3), dtype=torch.int32), 6) is None
+    # the public way out for writers torch's version counters do not see (`tensor.data[...] = ...`, raw-pointer kernels, DLPack):
+    # `invalidate` on either tensor drops the companion
+    sh2 = torch.zeros((6, 4, 3), dtype=torch.int32)
+    import weakref
+    setattr(nm, E._PACKED_ATTR, E.PackedCompanion(words, nm, sh2, 6))
+    setattr(sh2, "_nvalchemiops_owner", weakref.ref(nm))
+    nm.data[0, 0] = 5                                         # does NOT move nm._version: the host-side record cannot see it
+    assert E.packed_companion(nm, sh2, 6) is not None
+    E.invalidate(sh2)
+    assert E.packed_companion(nm, sh2, 6) is None and not hasattr(nm, E._PACKED_ATTR)
+    setattr(nm, E._PACKED_ATTR, E.PackedCompanion(words, nm, sh2, 6))
+    E.invalidate(nm)
+    assert E.packed_companion(nm, sh2, 6) is None
+    # sampled device-side check: (stride, phase) rotate from call to call
+    a, b = E.verify_args(), E.verify_args()
+    assert a[0] == b[0] and (a[0] == 0 or b[1] == (a[1] + 1) % a[0])
 
 
 def test_spread_workspace_is_sized_for_the_order_and_dtype_it_serves():
