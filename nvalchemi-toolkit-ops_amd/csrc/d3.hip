@@ -176,6 +176,7 @@ __global__ void d3_sort_key_kernel(const T* __restrict__ pos, const T* __restric
 //    blocks: one wave per sampled row); a mismatch, or the search's own "unusable" header flag, raises `flag`, and every pass then walks
 //    the caller's arrays.  Arrays edited in bulk behind the companion's back are caught here; a single edited entry in an unsampled row
 //    is not (include/nvalchemiops_hip.h says so).
+#define D3_VERIFY_CHUNK 512
 struct D3Guard {
   unsigned long long* slots; float K; const void* cell; int n_cell; const int* batch_idx;
   const int* nm; const int* nsh; const unsigned* words; const int* hdr_flag; int* flag; int M; int stride, phase; int atom_blocks;
@@ -192,10 +193,15 @@ __global__ void d3_pack_atoms_kernel(const T* __restrict__ pos, const int* __res
     const int w = ((int)blockIdx.x - G.atom_blocks) * (blockDim.x / MI_WAVE) + threadIdx.x / MI_WAVE;
     if (w == 0 && lane == 0 && *G.hdr_flag != 0) *G.flag = 1;  // the search itself found the companion unusable (a shift outside {-1, 0, 1})
     if (G.stride <= 0) return;
-    const long long row = (long long)G.phase % G.stride + (long long)w * G.stride;
+    // one wave per (sampled row, D3_VERIFY_CHUNK slots of it): a wave per whole row was 1.5 waves per CU walking 50 KB each (29 us on the
+    // headline list, all latency)
+    const int chunks = (G.M + D3_VERIFY_CHUNK - 1) / D3_VERIFY_CHUNK;
+    const long long row = (long long)G.phase % G.stride + (long long)(w / chunks) * G.stride;
     if (row >= N) return;
+    const int t_beg = (w % chunks) * D3_VERIFY_CHUNK, t_end = t_beg + D3_VERIFY_CHUNK < G.M ? t_beg + D3_VERIFY_CHUNK : G.M;
     bool bad = false;
-    for (int t = lane; t < G.M; t += MI_WAVE) {
+#pragma unroll 4
+    for (int t = t_beg + lane; t < t_end; t += MI_WAVE) {
       const long long e = row * G.M + t;
       const int j = G.nm[e];
       const Int3 sh = reinterpret_cast<const Int3*>(G.nsh)[e];
@@ -525,7 +531,9 @@ __global__ __launch_bounds__(D3_LS_WAVES * MI_WAVE) void d3_cn_pre_kernel(D3_CN_
     unsigned long long a = want_slots[threadIdx.x], b = got_slots[threadIdx.x];
 #pragma unroll
     for (int o = MI_WAVE / 2; o > 0; o >>= 1) { a += __shfl_xor(a, o, MI_WAVE); b += __shfl_xor(b, o, MI_WAVE); }
-    if (threadIdx.x == 0) adopt_sh = (a == b && cn_hdr[0] == 0 && __int_as_float(cn_hdr[3]) == mi_cn_scale(P.k1)) ? 1 : 0;
+    // (the sums were taken over the list the companion describes: a companion that failed its check against the caller's arrays -- *comp_flag --
+    // vouches for nothing)
+    if (threadIdx.x == 0) adopt_sh = (a == b && cn_hdr[0] == 0 && *comp_flag == 0 && __int_as_float(cn_hdr[3]) == mi_cn_scale(P.k1)) ? 1 : 0;
   }
   __syncthreads();
   if (adopt_sh) {
@@ -1383,7 +1391,8 @@ int d3_impl(const T* pos, const int* numbers, int N, const int* idx, const int* 
   if (use_cn) { G.slots = gslots; G.K = mi_cn_scale(hp->k1); G.cell = cell; G.n_cell = 9 * B; G.batch_idx = batch_idx; }
   if (pre) {
     G.nm = idx; G.nsh = ush; G.words = pre_words; G.hdr_flag = pre_flag; G.flag = gflag; G.M = M; G.stride = verify_stride; G.phase = verify_phase;
-    verify_blocks = verify_stride > 0 ? mi_blocks(((long long)N + verify_stride - 1) / verify_stride, 4) : 1;  // (one block at least: the header flag)
+    // one wave per (sampled row, D3_VERIFY_CHUNK slots); one block at least: it also forwards the header flag
+    verify_blocks = verify_stride > 0 ? mi_blocks((((long long)N + verify_stride - 1) / verify_stride) * ((M + D3_VERIFY_CHUNK - 1) / D3_VERIFY_CHUNK), 4) : 1;
   }
   d3_pack_atoms_kernel<T><<<G.atom_blocks + verify_blocks, 256, 0, st>>>(pos, numbers, N, hp->rcov, hp->r4r2, smap, hp->nz, apos, aaux, forces, cn, dEdCN, e_atom,
                                                                          want_virial ? v_atom : nullptr, inv, apos_s, aaux_s, acn, G);

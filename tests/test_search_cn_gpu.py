@@ -260,11 +260,14 @@ def test_bulk_edits_behind_torchs_back_are_caught_on_the_device(engine, how, mon
     if how == "data":  # drop the second half of every row
         nm.data[:, m // 2:] = n
         sh.data[:, m // 2:, :] = 0
-    elif how == "raw_pointer":  # the library's streaming fill over the first quarter of the matrix: zeros = "neighbour 0, no shift" entries
+    elif how == "raw_pointer":  # the library's streaming fill over the first quarter of the matrix: every entry becomes `n` (= padding: rows emptied)
+        import struct
         C.lib().mi_calibrate_fill.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_float, ctypes.c_void_p]
         nbytes = (n // 4) * m * 4 // 16384 * 16384
-        assert C.lib().mi_calibrate_fill(ctypes.c_void_p(nm.data_ptr()), ctypes.c_size_t(nbytes), ctypes.c_float(0.0), C.stream_of(nm)) == 0
+        as_float = struct.unpack("f", struct.pack("i", n))[0]  # the float whose bit pattern is the integer n (a denormal: stored, never computed with)
+        assert C.lib().mi_calibrate_fill(ctypes.c_void_p(nm.data_ptr()), ctypes.c_size_t(nbytes), ctypes.c_float(as_float), C.stream_of(nm)) == 0
         torch.cuda.synchronize()
+        assert int(nm[0, 0]) == n and int(nm[n // 4 - 8, 5]) == n
     else:
         other = nm.clone()
         other[::2] = n  # every other row emptied
