@@ -41,6 +41,9 @@ const char* mi_last_error(void);      /* [host] message of the last failure on t
 /* Optional per-kernel timing with HIP events recorded on the launch stream (used by bench.py for the live
  * roofline figure).  mi_timing_report waits for the events and writes "<kernel> <launches> <total_ms>\n" lines. */
 int mi_timing_enable(int on);
+/* record only the kernel brackets called `name` (NULL / "": all of them): an event record is a packet of its own in the stream, ~5 us of
+ * bubble on either side of a kernel, so a timed region that needs ONE kernel's duration selects it and leaves the rest back to back      */
+int mi_timing_select(const char* name /*[host]*/);
 int mi_timing_report(char* buf /*[host]*/, int cap);
 /* same records with per-launch statistics: "<kernel> <launches> <total_ms> <median_ms> <min_ms> <max_ms>\n" */
 int mi_timing_report_stats(char* buf /*[host]*/, int cap);

@@ -26,6 +26,8 @@ namespace {
 struct Rec { const char* name; hipEvent_t a, b; };
 std::mutex g_mu;
 bool g_timing = false;
+std::string g_only;  // when not empty: only brackets of this name are recorded (mi_timing_select)
+bool g_skipped = false;  // the bracket opened last was filtered out: its mi_timing_end must not close an older record
 std::vector<Rec> g_recs;
 std::vector<hipEvent_t> g_pool;
 hipEvent_t take_event() {
@@ -40,6 +42,8 @@ hipEvent_t take_event() {
 void mi_timing_begin(const char* name, void* stream) {
   if (!g_timing) return;
   std::lock_guard<std::mutex> lk(g_mu);
+  g_skipped = !g_only.empty() && g_only != name;
+  if (g_skipped) return;
   Rec r{name, take_event(), take_event()};
   (void)hipEventRecord(r.a, (hipStream_t)stream);
   g_recs.push_back(r);
@@ -47,6 +51,7 @@ void mi_timing_begin(const char* name, void* stream) {
 void mi_timing_end(void* stream) {
   if (!g_timing) return;
   std::lock_guard<std::mutex> lk(g_mu);
+  if (g_skipped) { g_skipped = false; return; }
   if (!g_recs.empty()) (void)hipEventRecord(g_recs.back().b, (hipStream_t)stream);
 }
 
@@ -57,6 +62,15 @@ const char* mi_last_error(void) { return g_err; }
 int mi_timing_enable(int on) {
   std::lock_guard<std::mutex> lk(g_mu);
   g_timing = on != 0;
+  return MI_OK;
+}
+
+// Restricts the recording to the brackets called `name` (NULL or "": every bracket again).  An event record is a packet of its own in the
+// stream: ~5 us of bubble on either side of a kernel.  A benchmark that needs ONE kernel's duration inside its timed region selects it and
+// leaves the other ~25 launches of a step back to back.
+int mi_timing_select(const char* name) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  g_only = name ? name : "";
   return MI_OK;
 }
 
