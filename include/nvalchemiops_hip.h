@@ -246,8 +246,10 @@ int mi_d3_packed(const void* positions, const int32_t* numbers, int n_atoms, int
  *    computes on the device from its own positions, numbers, params->rcov, params->k1, cell and batch_idx; otherwise the CN pass runs as in
  *    mi_d3_packed.  Either way coord_num is the reference's sum over the stored list to fp32 rounding (the two evaluations differ in
  *    summation order and in one rounding of the exponent: <= 1e-6 relative, tests/test_search_cn_gpu.py).
- *  - a sampled consistency check of the companion against the arrays it claims to describe: every `verify_stride`-th row (rows
- *    i = verify_phase mod verify_stride) is re-derived from neighbor_matrix / neighbor_matrix_shifts and compared word by word; on a
+ *  - a sampled consistency check of the companion against the arrays it claims to describe: one row in every block of `verify_stride`
+ *    consecutive rows (at offset (verify_phase + hash(block)) mod verify_stride: consecutive phases visit every row once in verify_stride
+ *    calls, and no regular edit pattern can hide between the samples) is re-derived from neighbor_matrix / neighbor_matrix_shifts and
+ *    compared word by word; on a
  *    mismatch the call falls back to the 16 B/slot arrays (device-side flag, no host round trip, results = mi_d3's on the arrays as they
  *    are NOW).  verify_stride = 1 checks every row, 0 disables the check (mi_d3_packed itself uses stride 64, phase 0).  This catches
  *    arrays edited behind the companion's back in bulk (a filtering kernel, a copy from elsewhere); a single edited entry in an unsampled

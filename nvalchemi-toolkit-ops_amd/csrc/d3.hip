@@ -196,7 +196,11 @@ __global__ void d3_pack_atoms_kernel(const T* __restrict__ pos, const int* __res
     // one wave per (sampled row, D3_VERIFY_CHUNK slots of it): a wave per whole row was 1.5 waves per CU walking 50 KB each (29 us on the
     // headline list, all latency)
     const int chunks = (G.M + D3_VERIFY_CHUNK - 1) / D3_VERIFY_CHUNK;
-    const long long row = (long long)G.phase % G.stride + (long long)(w / chunks) * G.stride;
+    // the sample: ONE row in every block of `stride` consecutive rows, at offset (phase + hash(block)) mod stride -- over `stride` calls with
+    // consecutive phases every row is visited once, and within a call the offsets differ from block to block, so an edit with a regular
+    // row pattern (every other row, every 64th) cannot sit between the samples
+    const long long blk = w / chunks;
+    const long long row = blk * G.stride + (long long)(((unsigned long long)G.phase + mi_mix64(0x51ull + (unsigned long long)blk)) % (unsigned long long)G.stride);
     if (row >= N) return;
     const int t_beg = (w % chunks) * D3_VERIFY_CHUNK, t_end = t_beg + D3_VERIFY_CHUNK < G.M ? t_beg + D3_VERIFY_CHUNK : G.M;
     bool bad = false;

@@ -283,24 +283,32 @@ def test_bulk_edits_behind_torchs_back_are_caught_on_the_device(engine, how, mon
 
 
 def test_single_entry_edit_needs_invalidate(engine, monkeypatch):
-    """The documented limit of the sampled check: one entry edited through `tensor.data` in a row the current call does not sample is not
-    seen (the result is the one for the unedited list) -- within `stride` calls the rotating sample reaches the row; `invalidate` is the
-    contract for such writers; with NVALCHEMIOPS_NL_PACKED_VERIFY=1 every row is compared on every call."""
+    """The documented limit of the sampled check: one entry edited through `tensor.data` is only seen by the call whose sample contains
+    that row -- one call in `stride` (the sampled rows rotate: consecutive calls visit every row once) -- and the other calls answer for
+    the unedited list.  `invalidate` is the contract for such writers; NVALCHEMIOPS_NL_PACKED_VERIFY=1 compares every row on every call."""
     tables, p, pos, cell, numbers, tp, tz, tc, nm, num, sh = _setup(engine, seed=7)
     n, m = nm.shape
     before = _d3(tp, tz, p, nm, sh, tc[None])
-    row = 1000
-    nm.data[row, 0] = n  # one neighbour of one atom removed behind torch's back
+    nm.data[1000, 0] = n  # one neighbour of one atom removed behind torch's back
     ref = _oracle(pos, numbers, tables, nm, sh, cell)
+    assert not _close(before[2], ref[2])
     monkeypatch.setattr(engine, "_VERIFY_STRIDE", 64)
-    monkeypatch.setattr(engine, "_verify_calls", 0)  # phase 0: rows 0, 64, 128, ... -- row 1000 is not among them
-    stale = _d3(tp, tz, p, nm, sh, tc[None])
-    assert torch.equal(stale[2], before[2])  # unseen: the documented limit
-    seen = False
-    for _ in range(64):  # the sampled rows rotate: phase 1000 % 64 = 40 comes up
+    monkeypatch.setattr(engine, "_verify_calls", 0)
+    seen = stale = 0
+    for _ in range(64):  # phases 0 .. 63: exactly one of them samples row 1000
         out = _d3(tp, tz, p, nm, sh, tc[None])
-        seen = seen or _close(out[2], ref[2]) and not torch.equal(out[2], before[2])
-    assert seen
+        if torch.equal(out[2], before[2]):
+            stale += 1
+        else:
+            assert _close(out[2], ref[2]) and _close(out[0], ref[0])
+            seen += 1
+    assert (seen, stale) == (1, 63)
+    monkeypatch.setattr(engine, "_VERIFY_STRIDE", 1)  # every row, every call
+    out = _d3(tp, tz, p, nm, sh, tc[None])
+    assert _close(out[2], ref[2]) and _close(out[0], ref[0])
+    monkeypatch.setattr(engine, "_VERIFY_STRIDE", 0)  # check off: the companion is believed
+    out = _d3(tp, tz, p, nm, sh, tc[None])
+    assert torch.equal(out[2], before[2])
     from nvalchemiops.neighborlist import invalidate
     invalidate(nm)
     out = _d3(tp, tz, p, nm, sh, tc[None])
