@@ -136,11 +136,33 @@ def reference_spline_orders_active() -> bool:
     return _REFERENCE_SPLINE_ORDERS if v is None else bool(v)
 
 
+SPLINE_RESOLVED = 0x200  # Python-side only (never reaches the C ABI): the reference-compatibility decision has been taken for this order value
+
+
+def resolve_spline_order(order: int) -> int:
+    """The spline order with the reference-compatibility decision FROZEN into it: low byte = the order, SPLINE_REFERENCE_ORDERS if
+    `nvalchemiops.spline.reference_spline_orders` is active where this is called, SPLINE_RESOLVED so that later calls leave it alone.
+    Every public electrostatics / spline entry point calls this once, on the caller's thread, and hands the result down; autograd nodes and
+    custom-op contexts store it, so a backward pass -- which the autograd engine runs on ITS OWN worker thread for device tensors, where
+    the caller's `contextvars` context does not exist -- launches with the same evaluation as its forward."""
+    order = int(order)
+    if order & SPLINE_RESOLVED or torch.compiler.is_compiling():
+        # (while TorchDynamo traces the caller the value stays plain: a context variable cannot be guarded on, and freezing today's setting
+        # into a compiled graph would outlive the `with` block; the ops then read the switch at launch time, as before round 6)
+        return order
+    return (order & 0xff) | SPLINE_RESOLVED | (SPLINE_REFERENCE_ORDERS if reference_spline_orders_active() else 0)
+
+
+def plain_spline_order(order: int) -> int:
+    """The order itself (1 - 6 ...), whatever flags ride on the value."""
+    return int(order) & 0xff
+
+
 def spline_order_arg(order: int) -> int:
-    """The `order` argument of the C ABI: the spline order, plus the reference-compatibility bit while
-    `nvalchemiops.spline.reference_spline_orders` is active (orders 5 / 6 evaluated as the reference does: zero weights, exponent 4).
-    The bit travels with every launch: the library itself holds no such state."""
-    return int(order) | (SPLINE_REFERENCE_ORDERS if reference_spline_orders_active() else 0)
+    """The `order` argument of the C ABI: the spline order, plus the reference-compatibility bit (orders 5 / 6 evaluated as the reference
+    does: zero weights, exponent 4).  A value that went through `resolve_spline_order` keeps the decision taken there; a plain order takes
+    the one of the calling context.  The bit travels with every launch: the library itself holds no such state."""
+    return resolve_spline_order(order) & (0xff | SPLINE_REFERENCE_ORDERS)
 
 
 def cdouble(x: float):

@@ -85,6 +85,7 @@ def pme_green_structure_factor(k_squared: torch.Tensor, mesh_dimensions: tuple[i
     is 2 min(order, 4): identical for orders 1-4, selected for 5-6 by `nvalchemiops.spline.reference_spline_orders()`).
     Differentiable w.r.t. k_squared, alpha and the cell (through the volume): op `alchemiops::_[batch_]pme_green_structure_factor`."""
     C.require_device(k_squared, cell)
+    spline_order = C.resolve_spline_order(spline_order)
     nx, ny, nz = (int(v) for v in mesh_dimensions)
     dt, dev = k_squared.dtype, k_squared.device
     cells = cell if cell.dim() == 3 else cell.unsqueeze(0)
@@ -169,11 +170,21 @@ class _FftPlan:
         import ctypes
 
         self.handle = ctypes.c_void_p()
+        self.pinned = False  # executed while a HIP graph was being captured: the graph replays into this plan's work area, so the cache keeps it
+        self.shape = (tuple(int(v) for v in dims), int(batch), int(code), bool(inverse))
         C.check(C.lib().mi_fft_plan_create(int(dims[0]), int(dims[1]), int(dims[2]), int(batch), int(code), int(inverse), ctypes.byref(self.handle)),
                 "mi_fft_plan_create")
 
     def __call__(self, src: torch.Tensor, dst: torch.Tensor) -> None:
-        C.check(C.lib().mi_fft_plan_exec(self.handle, C.ptr(src), C.ptr(dst), C.stream_of(src)), "mi_fft_plan_exec")
+        # enqueued under the cache's lock: another thread's eviction cannot destroy the plan between look-up and launch; a plan
+        # that was evicted after the caller fetched it serves this one call through the dense DFT
+        with _FFT_LOCK:
+            if not self.handle:
+                _DenseDft(*self.shape)(src, dst)
+                return
+            if src.is_cuda and torch.cuda.is_current_stream_capturing():
+                self.pinned = True
+            C.check(C.lib().mi_fft_plan_exec(self.handle, C.ptr(src), C.ptr(dst), C.stream_of(src)), "mi_fft_plan_exec")
 
     def destroy(self) -> None:
         h, self.handle = getattr(self, "handle", None), None
@@ -320,8 +331,11 @@ def _fft_plan(device: torch.device, dims, batch: int, code: int, inverse: bool):
                               f" ({detail}): destroyed; this shape runs through the library's dense DFT in this process (DESIGN.md 3.7)")
         _FFT_PLANS[key] = plan
         while len(_FFT_PLANS) > _FFT_PLAN_CAP:
-            _, old = _FFT_PLANS.popitem(last=False)
-            old.destroy()
+            # oldest plan that no captured HIP graph replays into (a graph holds the plan's work area by address: ADVICE r5)
+            victim = next((k for k, v in _FFT_PLANS.items() if not getattr(v, "pinned", False) and k != key), None)
+            if victim is None:
+                break
+            _FFT_PLANS.pop(victim).destroy()
         return plan
 
 
@@ -721,6 +735,7 @@ def pme_reciprocal_space(positions: torch.Tensor, charges: torch.Tensor, cell: t
     """Reciprocal-space PME energies per atom (+ forces, + charge gradients), self and background corrections included.
 
     Return arity as pme.py:1655-1665."""
+    spline_order = C.resolve_spline_order(spline_order)  # the reference-orders switch is read HERE, once: backward passes reuse this value
     cells, num_systems = _prepare_cell(cell)
     n, dev, dt = positions.shape[0], positions.device, positions.dtype
     composed = C.tracing() or (torch.is_grad_enabled() and any(isinstance(t, torch.Tensor) and t.requires_grad for t in (positions, charges, cell, alpha)))
@@ -787,6 +802,7 @@ def particle_mesh_ewald(positions: torch.Tensor, charges: torch.Tensor, cell: to
                         compute_charge_gradients: bool = False, accuracy: float = 1e-6):
     """Total Coulomb energy per atom = erfc-damped real-space sum over the neighbour list + mesh reciprocal sum
     (+ forces / charge gradients).  Coulomb constant 1.  Same argument handling as pme.py:1917-1994."""
+    spline_order = C.resolve_spline_order(spline_order)  # the reference-orders switch is read HERE, once: backward passes reuse this value
     num_atoms = positions.shape[0]
     cells, num_systems = _prepare_cell(cell)
     if alpha is None:

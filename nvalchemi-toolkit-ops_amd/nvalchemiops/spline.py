@@ -130,6 +130,7 @@ def spline_spread(positions: torch.Tensor, values: torch.Tensor, cell: torch.Ten
                   batch_idx: torch.Tensor | None = None, cell_inv_t: torch.Tensor | None = None) -> torch.Tensor:
     """mesh[(B,) nx, ny, nz] += values_i * M_n(x) M_n(y) M_n(z) over each atom's order^3 stencil (periodic wrap).
     Differentiable w.r.t. positions, values and cell (hand-written adjoint kernels)."""
+    spline_order = C.resolve_spline_order(spline_order)  # read the reference-orders switch once, here (backward passes reuse the value)
     C.require_device(positions, values, cell)
     if C.tracing() or _wants_grad(positions, values, cell, cell_inv_t):
         c, cit, nsys = _op_inputs(positions, cell, batch_idx, cell_inv_t)
@@ -150,6 +151,7 @@ def spline_gather(positions: torch.Tensor, mesh: torch.Tensor, cell: torch.Tenso
                   batch_idx: torch.Tensor | None = None, cell_inv_t: torch.Tensor | None = None) -> torch.Tensor:
     """out_i = sum over the stencil of mesh[g] * w  (weights <= 1e-8 are skipped, spline.py:608).
     Differentiable w.r.t. positions, mesh and cell."""
+    spline_order = C.resolve_spline_order(spline_order)  # read the reference-orders switch once, here (backward passes reuse the value)
     C.require_device(positions, mesh, cell)
     if C.tracing() or _wants_grad(positions, mesh, cell, cell_inv_t):
         c, cit, _ = _op_inputs(positions, cell, batch_idx, cell_inv_t)
@@ -171,6 +173,7 @@ def spline_gather_vec3(positions: torch.Tensor, charges: torch.Tensor, mesh: tor
                        batch_idx: torch.Tensor | None = None, cell_inv_t: torch.Tensor | None = None) -> torch.Tensor:
     """out_i[3] = sum over the stencil of q_i * mesh[g, :] * w for a mesh of shape [(B,) nx, ny, nz, 3].
     Differentiable w.r.t. positions, charges, mesh and cell (adjoint in nvalchemiops/_eops.py)."""
+    spline_order = C.resolve_spline_order(spline_order)  # read the reference-orders switch once, here (backward passes reuse the value)
     C.require_device(positions, charges, mesh, cell)
     if C.tracing() or _wants_grad(positions, charges, mesh, cell, cell_inv_t):
         c, cit, _ = _op_inputs(positions, cell, batch_idx, cell_inv_t)
@@ -195,6 +198,7 @@ def spline_gather_gradient(positions: torch.Tensor, charges: torch.Tensor, mesh:
     """F_i = -q_i sum_g mesh[g] grad_r w(r_i, g): the fractional-coordinate gradient (scaled by the mesh dimensions) mapped to Cartesian
     with cell_inv_t^T (spline.py:2733-2785; kernels :678-755).  Differentiable w.r.t. positions, charges, mesh and cell: the adjoint uses
     the second derivatives of the spline weights (nvalchemiops/_eops.py `_gather_gradient_backward`)."""
+    spline_order = C.resolve_spline_order(spline_order)  # read the reference-orders switch once, here (backward passes reuse the value)
     C.require_device(positions, charges, mesh, cell)
     if C.tracing() or _wants_grad(positions, charges, mesh, cell, cell_inv_t):
         c, cit, _ = _op_inputs(positions, cell, batch_idx, cell_inv_t)

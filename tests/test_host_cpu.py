@@ -499,6 +499,15 @@ def test_fft_plan_cache_is_fail_safe_and_bounded(monkeypatch):
     P._fft_plan(dev, (8, 8, 10), 1, code, False)  # touch: now the most recent
     P._fft_plan(dev, (8, 8, 8), 1, code, False)   # back again: re-created, (8, 10, 8) is the one that goes
     assert log.count(("create", (8, 8, 8), False)) == 2 and ("destroy", (8, 10, 8), False) in log and ("destroy", (8, 8, 10), False) not in log
+    # a plan that a captured HIP graph replays into (`pinned`: executed during stream capture) is never evicted: the graph holds its work area
+    # by address; the eviction takes the oldest plan that is not pinned instead
+    oldest = next(iter(P._FFT_PLANS))
+    P._FFT_PLANS[oldest].pinned = True
+    log.clear()
+    for d in ((12, 8, 8), (8, 12, 8)):
+        P._fft_plan(dev, d, 1, code, False)
+    assert oldest in P._FFT_PLANS and ("destroy", oldest[1], False) not in log and len([e for e in log if e[0] == "destroy"]) == 2
+    assert len(P._FFT_PLANS) == 3
 
 
 def test_packed_companion_validity_rules():

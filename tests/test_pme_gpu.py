@@ -456,6 +456,51 @@ def test_reference_spline_orders_switch_vs_default_oracle(dtype, order):
     _close(bf, bref[1], dtype, "batch forces")
 
 
+@pytest.mark.parametrize("order", [5, 6])
+@pytest.mark.parametrize("where", ["inside", "outside"])
+def test_backward_keeps_the_spline_evaluation_of_its_forward(order, where):
+    """`reference_spline_orders()` is a context variable of the CALLING thread, and the autograd engine runs the backward of
+    device tensors on its own worker thread, where that context does not exist.  The switch is therefore read once, in the forward, and
+    travels with the order value into every saved context: a forward evaluated the reference way (zero mesh for orders 5 / 6: the
+    reciprocal energies are the self / background corrections, which do not depend on the positions) has a ZERO position gradient --
+    whether `backward()` runs inside the `with` block or after it -- and equals -forces of the same call; a forward evaluated with the
+    true B-splines keeps them in its backward even when that runs inside a `with reference_spline_orders()` block entered later."""
+    from nvalchemiops.interactions.electrostatics import pme_reciprocal_space
+    from nvalchemiops.spline import reference_spline_orders, spline_gather, spline_spread
+
+    dtype = np.float64
+    pos, cell, q = _system(300, dtype, triclinic=True, seed=5, box=14.0)
+    dims = (16, 20, 24)
+    tq, tc = _t(q), _t(cell)
+    field = _t(np.random.default_rng(1).normal(size=dims).astype(dtype))
+
+    def grads(enter_for_forward, enter_for_backward):
+        tp = _t(pos).requires_grad_(True)
+        tv = _t(q).requires_grad_(True)
+        ctx_f = reference_spline_orders() if enter_for_forward else reference_spline_orders(False)
+        ctx_b = reference_spline_orders() if enter_for_backward else reference_spline_orders(False)
+        with ctx_f:
+            e = pme_reciprocal_space(tp, tv, tc, alpha=0.4, mesh_dimensions=dims, spline_order=order)
+            g = spline_gather(tp, field, tc, order)
+            m = spline_spread(tp, tv, tc, dims, order)
+            loss = e.sum() + (g * g).sum() + (m * field).sum()
+            if where == "inside":
+                loss.backward()
+        if where == "outside":
+            with ctx_b:
+                loss.backward()
+        return tp.grad.clone(), tv.grad.clone(), e.detach()
+
+    # forward the reference way: nothing depends on the positions through the mesh, whatever the backward's surroundings say
+    gp, gq, e_ref = grads(True, False)
+    assert float(gp.abs().max()) == 0.0
+    # forward with the true splines: the gradient is that of the true splines, even if the backward runs inside a reference block
+    gp_t, gq_t, e_true = grads(False, True)
+    gp_t2, gq_t2, _ = grads(False, False)
+    assert float(gp_t.abs().max()) > 1e-3 and torch.allclose(gp_t, gp_t2, rtol=1e-12, atol=1e-12) and torch.allclose(gq_t, gq_t2, rtol=1e-12, atol=1e-12)
+    assert float((e_true - e_ref).abs().max()) > 1e-3
+
+
 # ---- explicit-k Ewald (SURVEY 8f N3) ---------------------------------------------------------------------------------------
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
 @pytest.mark.parametrize("triclinic", [False, True])
