@@ -48,10 +48,12 @@ struct D3Dev {
 
 struct D3Species;
 __device__ __forceinline__ int d3_species_count(const D3Species* info);
-__global__ void d3_pack_tables_kernel(const float* __restrict__ c6ab, const float* __restrict__ cnref, int nz, const D3Species* __restrict__ info,
-                                      float4* __restrict__ tab) {
+// (round 6: the blocks behind the atom and companion-check blocks of d3_pack_atoms_kernel; a launch of its own before)
+struct D3Tables { const float* c6ab; const float* cnref; int nz; const D3Species* info; float4* tab; int first_block; };
+__device__ __forceinline__ void d3_pack_tables_body(const float* __restrict__ c6ab, const float* __restrict__ cnref, int nz, const D3Species* __restrict__ info,
+                                      float4* __restrict__ tab, long long vblock) {
   if (d3_species_count(info) <= 16) return;  // the global table is only read by the > 16 species variant of the energy pass
-  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long t = vblock * blockDim.x + threadIdx.x;
   const long long total = (long long)nz * nz * 25;
   if (t >= total) return;
   const int pq = (int)(t % 25), p = pq / 5, q = pq % 5;
@@ -187,7 +189,11 @@ __global__ void d3_pack_atoms_kernel(const T* __restrict__ pos, const int* __res
                                      typename Vec4<T>::type* __restrict__ apos, float4* __restrict__ aaux, float* __restrict__ forces,
                                      float* __restrict__ cn, float* __restrict__ dEdCN, float* __restrict__ e_atom, double* __restrict__ v_atom,
                                      const int* __restrict__ inv, typename Vec4<T>::type* __restrict__ apos_s, float4* __restrict__ aaux_s,
-                                     typename Vec4<T>::type* __restrict__ acn, D3Guard G) {
+                                     typename Vec4<T>::type* __restrict__ acn, D3Guard G, D3Tables TB) {
+  if ((int)blockIdx.x >= TB.first_block) {  // ---- the global species-pair table (only built for > 16 species)
+    d3_pack_tables_body(TB.c6ab, TB.cnref, TB.nz, TB.info, TB.tab, (long long)blockIdx.x - TB.first_block);
+    return;
+  }
   if ((int)blockIdx.x >= G.atom_blocks) {  // ---- sampled check of the packed companion (block-uniform branch)
     const int lane = threadIdx.x & (MI_WAVE - 1);
     const int w = ((int)blockIdx.x - G.atom_blocks) * (blockDim.x / MI_WAVE) + threadIdx.x / MI_WAVE;
@@ -433,8 +439,14 @@ __device__ __forceinline__ int d3_lockstep_trips(long long beg, long long end) {
 // same word format as the copy this pass otherwise writes) instead of the 16 B/slot API arrays.  `gate_flag` / `gate_want`: the launch does
 // its work only when (*gate_flag != 0) == gate_want -- the PKIN launch runs when the companion's flag is clear, the plain launch beside
 // it when the search raised it (a shift outside {-1, 0, 1}); one of the two exits at once, no host round trip.
-#define D3_CN_PARAMS const T* __restrict__ pos, const int* __restrict__ numbers, int N, const int* __restrict__ idx, const int* __restrict__ ush, const int* __restrict__ nptr, int M, int fill_value, const T* __restrict__ cell, const int* __restrict__ batch_idx, D3Dev P, const typename Vec4<T>::type* __restrict__ apos, float4* __restrict__ aaux, float* __restrict__ cn, unsigned* __restrict__ pk_out, int* __restrict__ pk_flag, const int* __restrict__ inv, const typename Vec4<T>::type* __restrict__ acn, float4* __restrict__ aaux_s, int* __restrict__ rmax_bits, const unsigned* __restrict__ pk_in
-#define D3_CN_ARGS pos, numbers, N, idx, ush, nptr, M, fill_value, cell, batch_idx, P, apos, aaux, cn, pk_out, pk_flag, inv, acn, aaux_s, rmax_bits, pk_in
+// The j-side Gaussian weights of the factorised C6 interpolation (d3_weights_atom, defined with the interpolation below) are a function of
+// an atom's own coordination number, so the CN stage writes them the moment it knows that number: one launch less on the chain of small
+// kernels in front of the energy pass (round 6; `d3_weights_kernel` before).
+struct D3Species;
+struct D3Weights { const D3Species* sinfo; const float* fcr; float k3; const float4* apos_f32; float4* aw; float4* aw_s; };
+__device__ __forceinline__ void d3_weights_atom(int j, int place, float cnj, const float4* __restrict__ aaux, const D3Weights& W);
+#define D3_CN_PARAMS const T* __restrict__ pos, const int* __restrict__ numbers, int N, const int* __restrict__ idx, const int* __restrict__ ush, const int* __restrict__ nptr, int M, int fill_value, const T* __restrict__ cell, const int* __restrict__ batch_idx, D3Dev P, const typename Vec4<T>::type* __restrict__ apos, float4* __restrict__ aaux, float* __restrict__ cn, unsigned* __restrict__ pk_out, int* __restrict__ pk_flag, const int* __restrict__ inv, const typename Vec4<T>::type* __restrict__ acn, float4* __restrict__ aaux_s, int* __restrict__ rmax_bits, const unsigned* __restrict__ pk_in, D3Weights W
+#define D3_CN_ARGS pos, numbers, N, idx, ush, nptr, M, fill_value, cell, batch_idx, P, apos, aaux, cn, pk_out, pk_flag, inv, acn, aaux_s, rmax_bits, pk_in, W
 template <class T, bool CSR, bool BIG, bool SORT, bool PKIN>  // BIG: the caller's list is far larger than the Infinity Cache -> streamed with non-temporal loads
 __device__ __forceinline__ void d3_cn_body(D3_CN_PARAMS, int vblock /* the block of D3_LS_WAVES consecutive rows to work as */) {
   static_assert(!PKIN || !CSR, "a packed companion belongs to a padded matrix");
@@ -508,6 +520,7 @@ __device__ __forceinline__ void d3_cn_body(D3_CN_PARAMS, int vblock /* the block
   }
   acc = wave_sum(acc);
   if (lane == 0 && live) { cn[i] = (float)acc; aaux[i].x = (float)acc; if (SORT) aaux_s[k0].x = (float)acc; }
+  if (lane == 0 && i0 < N) d3_weights_atom(i, SORT ? k0 : -1, live ? (float)acc : 0.0f, aaux, W);  // (atoms outside the tables get all-zero weights)
   if (rmax_bits && (i0 & 63) == 0) {  // (wave-uniform) positive floats order like their bit patterns
 #pragma unroll
     for (int o = MI_WAVE / 2; o > 0; o >>= 1) rmx = fmaxf(rmx, __shfl_xor(rmx, o, MI_WAVE));
@@ -548,6 +561,7 @@ __global__ __launch_bounds__(D3_LS_WAVES * MI_WAVE) void d3_cn_pre_kernel(D3_CN_
       cn[i] = c;
       aaux[i].x = c;
     }
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += gridDim.x * blockDim.x) d3_weights_atom(i, -1, numbers[i] == 0 ? 0.0f : cn_pre[i], aaux, W);
     // the list's cutoff, for the grid of the spatial order (what the pass reports as the largest pair distance it met)
     if (rmax_bits && blockIdx.x == 0 && threadIdx.x == 0 && __int_as_float(cn_hdr[2]) > 0.0f) atomicMax(rmax_bits, cn_hdr[2]);
     return;
@@ -578,13 +592,7 @@ struct D3Species { int S; int factorized; int pad[2]; };
 __device__ __forceinline__ int d3_species_count(const D3Species* info) { return info->S; }
 #define D3_FROW 44  // factorised block per partner species: 5 c6 rows x 8 floats (b = 0..4 used) + {q, r0^6, r0^8, 0} of the BJ damping
 
-__global__ void d3_mark_species_kernel(const int* __restrict__ numbers, int N, int nz, int* __restrict__ present) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= N) return;
-  const int z = numbers[i];
-  if (z > 0 && z < nz) present[z] = 1;  // benign race: every writer stores 1
-}
-// one block: compact ids of the species present, then the dense [S][S][25] table of {c6, cn_ref_i, cn_ref_j^T}
+// one block (the last one of d3_species_kernel to finish): compact ids of the species present, then the dense [S][S][25] table of {c6, cn_ref_i, cn_ref_j^T}
 //
 // Factorised form.  In Grimme's tables the reference CN of atom i at reference point (a, b) is a property of (Z_i, a) alone, and
 // the set of populated points is a rectangle (a < n_ref(Z_i), b < n_ref(Z_j)).  When the tables of the species present have
@@ -592,7 +600,7 @@ __global__ void d3_mark_species_kernel(const int* __restrict__ numbers, int N, i
 //   exp(k3 [(CN_i - c_i(a))^2 + (CN_j - c_j(b))^2] - max) = u_a(i) v_b(j),
 // so a pair needs 5 exponentials instead of 25 and u_a is wave-uniform.  `ftab` [S][S][5][8] holds c6, `fcr` [S][8] holds
 // {c(0..4), validity bits}.  Tables without that structure keep the general 25-term path.
-__global__ void d3_compact_species_kernel(const int* __restrict__ present, const float* __restrict__ c6ab, const float* __restrict__ cnref, int nz,
+__device__ __forceinline__ void d3_compact_species_body(const int* __restrict__ present, const float* __restrict__ c6ab, const float* __restrict__ cnref, int nz,
                                           int* __restrict__ smap, D3Species* __restrict__ info, float4* __restrict__ ctab,
                                           float* __restrict__ ftab, float* __restrict__ fcr, float k3, const float* __restrict__ r4r2,
                                           float a1, float a2) {
@@ -603,7 +611,8 @@ __global__ void d3_compact_species_kernel(const int* __restrict__ present, const
     fact_ok = 1;
     int S = 0;
     for (int z = 0; z < nz; ++z) {
-      if (z > 0 && present[z]) { smap[z] = S < D3_SMAX ? S : -1; if (S < D3_SMAX) zlist[S] = z; ++S; }
+      // (device-scope atomic load: the marks were stored by other blocks, and this block's caches must not answer for them)
+      if (z > 0 && __hip_atomic_load(&present[z], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { smap[z] = S < D3_SMAX ? S : -1; if (S < D3_SMAX) zlist[S] = z; ++S; }
       else smap[z] = -1;
     }
     count = S;
@@ -647,6 +656,27 @@ __global__ void d3_compact_species_kernel(const int* __restrict__ present, const
   }
   __syncthreads();
   if (threadIdx.x == 0) info->factorized = fact_ok && k3 < 0.0f;  // the -inf masking of missing points needs k3 < 0
+}
+// Species marks and tables in ONE launch (round 6; two before): every block marks the species of its 256 atoms, takes a ticket, and the block
+// that draws the last one -- all marks are then in memory (fence before the ticket) -- builds the compact tables.  `present[nz + 2]` is the
+// ticket counter, cleared with the marks by the call's one memset.
+__global__ __launch_bounds__(256) void d3_species_kernel(const int* __restrict__ numbers, int N, int* __restrict__ present, const float* __restrict__ c6ab,
+                                                         const float* __restrict__ cnref, int nz, int* __restrict__ smap, D3Species* __restrict__ info,
+                                                         float4* __restrict__ ctab, float* __restrict__ ftab, float* __restrict__ fcr, float k3,
+                                                         const float* __restrict__ r4r2, float a1, float a2) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < N) {
+    const int z = numbers[i];
+    if (z > 0 && z < nz) present[z] = 1;  // benign race: every writer stores 1
+  }
+  __shared__ int last_sh;
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x == 0) last_sh = atomicAdd(&present[nz + 2], 1) == (int)gridDim.x - 1;
+  __syncthreads();
+  if (!last_sh) return;
+  __threadfence();
+  d3_compact_species_body(present, c6ab, cnref, nz, smap, info, ctab, ftab, fcr, k3, r4r2, a1, a2);
 }
 
 // `_c6ab_interpolate` (dftd3.py:427-547) on 25 packed terms {c6, cn_ref_i, cn_ref_j}.  Branch-free: the reference's
@@ -749,23 +779,17 @@ typedef float d3_f2 __attribute__((ext_vector_type(2)));
 // fp32 positions: the record is {x, y, z, v_4 | v_0, v_1, v_2, v_3} with the 4-bit species id in the two spare top bits of v_0 and v_1
 // (weights are in [0, 1]: sign and top exponent bit are always clear), so the energy pass gathers 32 bytes per neighbour instead
 // of 16 (position) + 32 (weights): that pass is bound by its per-neighbour gathers once the exponentials are gone.
-__global__ void d3_weights_kernel(const float* __restrict__ cn, const float4* __restrict__ aaux, const D3Species* __restrict__ sinfo,
-                                  const float* __restrict__ fcr, float k3, int N, const float4* __restrict__ apos_f32, float4* __restrict__ aw,
-                                  const int* __restrict__ inv, float4* __restrict__ aw_s) {
-  if (!sinfo->factorized || sinfo->S > D3_SMAX) return;
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= N) return;
-  const int j = inv ? inv[t] : t;  // (the weight record is also written at the atom's place t in the spatial order)
+__device__ __forceinline__ void d3_weights_atom(int j, int place /* in the spatial order, or -1 */, float cnj, const float4* __restrict__ aaux, const D3Weights& W) {
+  if (!W.sinfo->factorized || W.sinfo->S > D3_SMAX) return;
   const float4 a = aaux[j];
   const int code = __float_as_int(a.z), sj = code & 0xff;
   float v[5] = {0, 0, 0, 0, 0};
   if (sj < D3_SMAX) {  // real atom of a present species (padding atoms carry 0xff)
-    const float cnj = cn[j];
     float B[5], mx = -INFINITY;
 #pragma unroll
     for (int b = 0; b < 5; ++b) {
-      const float dj = cnj - fcr[sj * 8 + b];
-      B[b] = k3 * (dj * dj);
+      const float dj = cnj - W.fcr[sj * 8 + b];
+      B[b] = W.k3 * (dj * dj);
       mx = fmaxf(mx, B[b]);
     }
 #pragma unroll
@@ -775,18 +799,18 @@ __global__ void d3_weights_kernel(const float* __restrict__ cn, const float4* __
       v[b] = keep ? d3_exp_neg(keep ? Bp : 0.0f) : 0.0f;
     }
   }
-  if (apos_f32) {
-    const float4 p = apos_f32[j];
+  float4 r0, r1;
+  if (W.apos_f32) {
+    const float4 p = W.apos_f32[j];
     const int s4 = sj < D3_SMAX ? sj : 0;  // padding atoms: all weights are zero, any table row will do
-    const float4 r0 = make_float4(p.x, p.y, p.z, v[4]);
-    const float4 r1 = make_float4(__int_as_float(__float_as_int(v[0]) | ((s4 & 3) << 30)), __int_as_float(__float_as_int(v[1]) | ((s4 >> 2) << 30)), v[2], v[3]);
-    aw[2 * (size_t)j] = r0; aw[2 * (size_t)j + 1] = r1;
-    if (inv) { aw_s[2 * (size_t)t] = r0; aw_s[2 * (size_t)t + 1] = r1; }
-    return;
+    r0 = make_float4(p.x, p.y, p.z, v[4]);
+    r1 = make_float4(__int_as_float(__float_as_int(v[0]) | ((s4 & 3) << 30)), __int_as_float(__float_as_int(v[1]) | ((s4 >> 2) << 30)), v[2], v[3]);
+  } else {
+    r0 = make_float4(v[0], v[1], v[2], v[3]);
+    r1 = make_float4(v[4], a.y, a.z, 0.0f);
   }
-  const float4 r0 = make_float4(v[0], v[1], v[2], v[3]), r1 = make_float4(v[4], a.y, a.z, 0.0f);
-  aw[2 * (size_t)j] = r0; aw[2 * (size_t)j + 1] = r1;
-  if (inv) { aw_s[2 * (size_t)t] = r0; aw_s[2 * (size_t)t + 1] = r1; }
+  W.aw[2 * (size_t)j] = r0; W.aw[2 * (size_t)j + 1] = r1;
+  if (place >= 0) { W.aw_s[2 * (size_t)place] = r0; W.aw_s[2 * (size_t)place + 1] = r1; }
 }
 
 // Per pair: the (a, b) contraction only.  Same sums and thresholds as `_c6ab_interpolate`: a term survives iff
@@ -849,7 +873,7 @@ __device__ __forceinline__ void d3_energy_body(const T* __restrict__ pos, const 
                                                         float4* __restrict__ lds_buf /* 4 * d3_wave_f4(MODE) float4 of the kernel's LDS */,
                                                         int vblock = -1 /* block index to work as (the fallback kernel's grid-stride loop); -1: blockIdx.x */) {
   constexpr bool LDS = MODE == 1;
-  constexpr bool PACKED = MODE == 2 && sizeof(T) == 4;  // one 32-byte record per neighbour (see d3_weights_kernel)
+  constexpr bool PACKED = MODE == 2 && sizeof(T) == 4;  // one 32-byte record per neighbour (see d3_weights_atom)
   constexpr int WAVE_F4 = d3_wave_f4(MODE);  // float4 per wave
   const int S = sinfo->S;
   const int want_mode = S > D3_SMAX ? 0 : (sinfo->factorized ? 2 : 1);
@@ -1165,7 +1189,8 @@ __global__ __launch_bounds__(D3_LS_WAVES * MI_WAVE) void d3_chain_kernel(const T
 #define D3_REDUCE_SLOTS 16
 __global__ __launch_bounds__(256) void d3_reduce_kernel(const float* __restrict__ e_atom, const double* __restrict__ v_atom,
                                                         const int* __restrict__ batch_idx, int N, int want_virial,
-                                                        double* __restrict__ sums /*[B][D3_REDUCE_SLOTS][10], zeroed*/) {
+                                                        double* __restrict__ sums /*[B][D3_REDUCE_SLOTS][10] + ticket word, zeroed*/, int B,
+                                                        float* __restrict__ energy, float* __restrict__ virial) {
   const int lane = threadIdx.x & (MI_WAVE - 1);
   const int wave = blockIdx.x * (blockDim.x / MI_WAVE) + threadIdx.x / MI_WAVE;
   const int slot = wave & (D3_REDUCE_SLOTS - 1);
@@ -1203,16 +1228,25 @@ __global__ __launch_bounds__(256) void d3_reduce_kernel(const float* __restrict_
     }
   }
   flush();
-}
-__global__ void d3_finish_kernel(const double* __restrict__ sums, int B, int want_virial, float* __restrict__ energy, float* __restrict__ virial) {
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= 10 * B) return;
-  const int s = t / 10, k = t - 10 * s;
-  double v = 0.0;
+  // the block that finishes last folds the slots into the outputs (round 6: `d3_finish_kernel`, a launch of its own before).  Every block's
+  // atomics are at device scope and fenced before its ticket, so the last block's device-scope loads see all of them.
+  __shared__ int last_sh;
+  unsigned long long* ticket = reinterpret_cast<unsigned long long*>(sums + 10 * (size_t)D3_REDUCE_SLOTS * B);
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x == 0) last_sh = atomicAdd(ticket, 1ull) == (unsigned long long)gridDim.x - 1ull;
+  __syncthreads();
+  if (!last_sh) return;
+  __threadfence();
+  for (int t = threadIdx.x; t < 10 * B; t += blockDim.x) {
+    const int s = t / 10, k = t - 10 * s;
+    double v = 0.0;
 #pragma unroll
-  for (int q = 0; q < D3_REDUCE_SLOTS; ++q) v += sums[10 * ((size_t)s * D3_REDUCE_SLOTS + q) + k];  // fixed order: deterministic given the slot sums
-  if (k == 0) energy[s] = (float)v;
-  else if (want_virial) virial[9 * (size_t)s + (k - 1)] = (float)v;
+    for (int q = 0; q < D3_REDUCE_SLOTS; ++q)  // fixed order: deterministic given the slot sums
+      v += __hip_atomic_load(&sums[10 * ((size_t)s * D3_REDUCE_SLOTS + q) + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (k == 0) energy[s] = (float)v;
+    else if (want_virial) virial[9 * (size_t)s + (k - 1)] = (float)v;
+  }
 }
 
 inline long long d3_sort_cap(int N, int B) { return 4ll * N + 8ll * (B > 0 ? B : 1); }
@@ -1227,8 +1261,8 @@ D3Layout d3_layout(int N, int nz, int dtype, int B) {
   // `guard`, `sums` and `present` sit next to each other: all start a call as zeros and are cleared by ONE memset (round 5: one launch less
   // on the dependent chain of small D3 kernels).  guard = MI_CN_SLOTS fingerprint words + the "companion unusable" flag (D3Guard)
   L.guard = take(sizeof(unsigned long long) * MI_CN_SLOTS + 256);
-  L.sums = take(sizeof(double) * 10 * D3_REDUCE_SLOTS * (size_t)(B > 0 ? B : 1));
-  L.present = take(sizeof(int) * ((size_t)nz + 2));  // + 2: the atom-order probe {far-apart consecutive pairs, largest pair distance (bits)}, cleared with the table
+  L.sums = take(sizeof(double) * (10 * D3_REDUCE_SLOTS * (size_t)(B > 0 ? B : 1) + 1));  // + 1: the ticket counter of d3_reduce_kernel (cleared with the sums)
+  L.present = take(sizeof(int) * ((size_t)nz + 3));  // + 3: the atom-order probe {far-apart consecutive pairs, largest pair distance (bits)} and the ticket counter of d3_species_kernel, cleared with the table
   L.tab = take(sizeof(float4) * (size_t)nz * nz * 25);
   L.smap = take(sizeof(int) * (size_t)nz);
   L.sinfo = take(sizeof(D3Species));
@@ -1362,7 +1396,7 @@ int d3_impl(const T* pos, const int* numbers, int N, const int* idx, const int* 
   // outputs are zeroed like the reference wrapper does (dftd3.py:1933-1936; atoms with Z == 0 keep zeros): the per-atom arrays by
   // the pack kernel below, energy / virial are written for every system by the finish kernel
   // (one memset: the per-system reduction slots `sums`, only touched by the reduce kernel at the very end, lie directly in front of `present`)
-  MI_HIP_CHECK(hipMemsetAsync(ws + L.guard, 0, (L.present - L.guard) + sizeof(int) * ((size_t)hp->nz + 2), st));
+  MI_HIP_CHECK(hipMemsetAsync(ws + L.guard, 0, (L.present - L.guard) + sizeof(int) * ((size_t)hp->nz + 3), st));
   D3Grid* sgrid = reinterpret_cast<D3Grid*>(ws + L.sgrid);
   if (sorted || (sortable && probe)) {
     d3_sort_setup_kernel<T><<<1, 256, 0, st>>>(cell, B, N, rc_est, sgrid, d3_sort_cap(N, B));
@@ -1380,13 +1414,10 @@ int d3_impl(const T* pos, const int* numbers, int N, const int* idx, const int* 
     MI_LAUNCH_CHECK();
   }
   const bool publish = sortable && probe;  // (after the CN pass, which adds the largest pair distance)
-  d3_mark_species_kernel<<<mi_blocks(N, 256), 256, 0, st>>>(numbers, N, hp->nz, present);
-  MI_LAUNCH_CHECK();
-  d3_compact_species_kernel<<<1, 256, 0, st>>>(present, hp->c6ab, hp->cn_ref, hp->nz, smap, sinfo, ctab, ftab, fcr, hp->k3, hp->r4r2, hp->a1, hp->a2);
+  d3_species_kernel<<<mi_blocks(N, 256), 256, 0, st>>>(numbers, N, present, hp->c6ab, hp->cn_ref, hp->nz, smap, sinfo, ctab, ftab, fcr, hp->k3, hp->r4r2,
+                                                       hp->a1, hp->a2);
   MI_LAUNCH_CHECK();
   const long long nt = (long long)hp->nz * hp->nz * 25;
-  d3_pack_tables_kernel<<<mi_blocks(nt, 256), 256, 0, st>>>(hp->c6ab, hp->cn_ref, hp->nz, sinfo, tab);  // only works for > 16 species
-  MI_LAUNCH_CHECK();
   // the search's coordination numbers are taken only in the caller's atom order (the spatial order's CN pass writes its place-coded list anyway)
   const bool use_cn = !CSR && cn_block != nullptr && pre != nullptr && !sorted;
   D3Guard G{};
@@ -1398,14 +1429,16 @@ int d3_impl(const T* pos, const int* numbers, int N, const int* idx, const int* 
     // one wave per (sampled row, D3_VERIFY_CHUNK slots); one block at least: it also forwards the header flag
     verify_blocks = verify_stride > 0 ? mi_blocks((((long long)N + verify_stride - 1) / verify_stride) * ((M + D3_VERIFY_CHUNK - 1) / D3_VERIFY_CHUNK), 4) : 1;
   }
-  d3_pack_atoms_kernel<T><<<G.atom_blocks + verify_blocks, 256, 0, st>>>(pos, numbers, N, hp->rcov, hp->r4r2, smap, hp->nz, apos, aaux, forces, cn, dEdCN, e_atom,
-                                                                         want_virial ? v_atom : nullptr, inv, apos_s, aaux_s, acn, G);
+  const D3Tables TB{hp->c6ab, hp->cn_ref, hp->nz, sinfo, tab, G.atom_blocks + verify_blocks};  // (its blocks leave at once unless > 16 species are present)
+  d3_pack_atoms_kernel<T><<<G.atom_blocks + verify_blocks + mi_blocks(nt, 256), 256, 0, st>>>(pos, numbers, N, hp->rcov, hp->r4r2, smap, hp->nz, apos, aaux, forces, cn,
+                                                                                              dEdCN, e_atom, want_virial ? v_atom : nullptr, inv, apos_s, aaux_s, acn, G, TB);
   MI_LAUNCH_CHECK();
   const int blocks = mi_blocks(N, 4);
+  const D3Weights W{sinfo, fcr, hp->k3, sizeof(T) == 4 ? reinterpret_cast<const float4*>(apos) : nullptr, aw, aw_s};
 #define MI_D3_CN(BIG_, SORT_, PKIN_, OUT_, OUTFLAG_, GATE_, WANT_)                                                                                 \
   d3_cn_kernel<T, CSR, BIG_, SORT_, PKIN_><<<mi_blocks(N, D3_LS_WAVES), D3_LS_WAVES * MI_WAVE, 0, st>>>(                                             \
       pos, numbers, N, idx, ush, nptr, M, fill_value, cell, batch_idx, P, apos, aaux, cn, OUT_, OUTFLAG_, inv, acn, aaux_s,                           \
-      sortable ? order_probe + 1 : nullptr, pre_words, GATE_, WANT_)
+      sortable ? order_probe + 1 : nullptr, pre_words, W, GATE_, WANT_)
   const bool big_list = (double)n_entries * ((cell && ush) ? 16.0 : 4.0) > 2.0e9;  // list bytes (see d3_fetch)
   if constexpr (!CSR) {
     if (use_cn) {
@@ -1414,7 +1447,7 @@ int d3_impl(const T* pos, const int* numbers, int N, const int* idx, const int* 
       const int* hdr = reinterpret_cast<const int*>(cn_block);
       MI_TIMED("d3_cn", st, (d3_cn_pre_kernel<T><<<n_blocks < D3_CN_PRE_GRID ? n_blocks : D3_CN_PRE_GRID, D3_LS_WAVES * MI_WAVE, 0, st>>>(
                                 pos, numbers, N, idx, ush, nptr, M, fill_value, cell, batch_idx, P, apos, aaux, cn, nullptr, nullptr, inv, acn, aaux_s,
-                                sortable ? order_probe + 1 : nullptr, pre_words, gflag, hdr, gslots,
+                                sortable ? order_probe + 1 : nullptr, pre_words, W, gflag, hdr, gslots,
                                 reinterpret_cast<const float*>((const char*)cn_block + MI_CN_HEADER_BYTES), n_blocks)));
     } else if (pre) {
       // companion given: the PKIN launch works when it is usable (D3Guard), the plain launch beside it otherwise.  Sorted: both write the
@@ -1431,9 +1464,6 @@ int d3_impl(const T* pos, const int* numbers, int N, const int* idx, const int* 
   }
 #undef MI_D3_CN
   if (publish) d3_order_publish(order_probe, order_slot, st);
-  MI_LAUNCH_CHECK();
-  d3_weights_kernel<<<mi_blocks(N, 256), 256, 0, st>>>(cn, aaux, sinfo, fcr, hp->k3, N,
-                                                       sizeof(T) == 4 ? reinterpret_cast<const float4*>(apos) : nullptr, aw, inv, aw_s);
   MI_LAUNCH_CHECK();
   // all three variants are launched; two of them exit at once on the device-side species info.  Only the fp32 factorised variant
   // is instantiated with the 5-waves-per-SIMD register cap (the others would spill under it).
@@ -1474,9 +1504,7 @@ int d3_impl(const T* pos, const int* numbers, int N, const int* idx, const int* 
   else { MI_TIMED("d3_chain", st, (launch_chain(Plain{}))); }
   MI_LAUNCH_CHECK();
   double* sums = reinterpret_cast<double*>(ws + L.sums);  // zeroed with `present` at the top of the call
-  d3_reduce_kernel<<<D3_REDUCE_WAVES / 4, 256, 0, st>>>(e_atom, v_atom, batch_idx, N, want_virial, sums);
-  MI_LAUNCH_CHECK();
-  d3_finish_kernel<<<mi_blocks(10ll * B, 256), 256, 0, st>>>(sums, B, want_virial, energy, virial);
+  d3_reduce_kernel<<<D3_REDUCE_WAVES / 4, 256, 0, st>>>(e_atom, v_atom, batch_idx, N, want_virial, sums, B, energy, virial);
   MI_LAUNCH_CHECK();
   return MI_OK;
 }
