@@ -199,16 +199,18 @@ __global__ void d3_pack_atoms_kernel(const T* __restrict__ pos, const int* __res
     const int w = ((int)blockIdx.x - G.atom_blocks) * (blockDim.x / MI_WAVE) + threadIdx.x / MI_WAVE;
     if (w == 0 && lane == 0 && *G.hdr_flag != 0) *G.flag = 1;  // the search itself found the companion unusable (a shift outside {-1, 0, 1})
     if (G.stride <= 0) return;
-    // one wave per (sampled row, D3_VERIFY_CHUNK slots of it): a wave per whole row was 1.5 waves per CU walking 50 KB each (29 us on the
-    // headline list, all latency)
-    const int chunks = (G.M + D3_VERIFY_CHUNK - 1) / D3_VERIFY_CHUNK;
+    // one wave per sampled row, which compares ONE D3_VERIFY_CHUNK-slot stretch of it (chosen by hash, like the row): whole rows were 80 MB
+    // per call on the headline list -- 30 us; a stretch per row is 16 MB and still 1 563 x 512 slots spread over the whole matrix
+    const int chunks = 1, all_chunks = (G.M + D3_VERIFY_CHUNK - 1) / D3_VERIFY_CHUNK;
     // the sample: ONE row in every block of `stride` consecutive rows, at offset (phase + hash(block)) mod stride -- over `stride` calls with
     // consecutive phases every row is visited once, and within a call the offsets differ from block to block, so an edit with a regular
     // row pattern (every other row, every 64th) cannot sit between the samples
     const long long blk = w / chunks;
     const long long row = blk * G.stride + (long long)(((unsigned long long)G.phase + mi_mix64(0x51ull + (unsigned long long)blk)) % (unsigned long long)G.stride);
     if (row >= N) return;
-    const int t_beg = (w % chunks) * D3_VERIFY_CHUNK, t_end = t_beg + D3_VERIFY_CHUNK < G.M ? t_beg + D3_VERIFY_CHUNK : G.M;
+    const int pick = G.stride == 1 ? -1 : (int)(mi_mix64(0x77ull + (unsigned long long)row * 1315423911ull + (unsigned long long)G.phase / (unsigned long long)G.stride) % (unsigned long long)all_chunks);
+    // (stride 1 = "compare everything": the whole row)
+    const int t_beg = pick < 0 ? 0 : pick * D3_VERIFY_CHUNK, t_end = pick < 0 ? G.M : (t_beg + D3_VERIFY_CHUNK < G.M ? t_beg + D3_VERIFY_CHUNK : G.M);
     bool bad = false;
 #pragma unroll 4
     for (int t = t_beg + lane; t < t_end; t += MI_WAVE) {
@@ -592,7 +594,13 @@ struct D3Species { int S; int factorized; int pad[2]; };
 __device__ __forceinline__ int d3_species_count(const D3Species* info) { return info->S; }
 #define D3_FROW 44  // factorised block per partner species: 5 c6 rows x 8 floats (b = 0..4 used) + {q, r0^6, r0^8, 0} of the BJ damping
 
-// one block (the last one of d3_species_kernel to finish): compact ids of the species present, then the dense [S][S][25] table of {c6, cn_ref_i, cn_ref_j^T}
+__global__ void d3_mark_species_kernel(const int* __restrict__ numbers, int N, int nz, int* __restrict__ present) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  const int z = numbers[i];
+  if (z > 0 && z < nz) present[z] = 1;  // benign race: every writer stores 1
+}
+// one block: compact ids of the species present, then the dense [S][S][25] table of {c6, cn_ref_i, cn_ref_j^T}
 //
 // Factorised form.  In Grimme's tables the reference CN of atom i at reference point (a, b) is a property of (Z_i, a) alone, and
 // the set of populated points is a rectangle (a < n_ref(Z_i), b < n_ref(Z_j)).  When the tables of the species present have
@@ -600,7 +608,7 @@ __device__ __forceinline__ int d3_species_count(const D3Species* info) { return 
 //   exp(k3 [(CN_i - c_i(a))^2 + (CN_j - c_j(b))^2] - max) = u_a(i) v_b(j),
 // so a pair needs 5 exponentials instead of 25 and u_a is wave-uniform.  `ftab` [S][S][5][8] holds c6, `fcr` [S][8] holds
 // {c(0..4), validity bits}.  Tables without that structure keep the general 25-term path.
-__device__ __forceinline__ void d3_compact_species_body(const int* __restrict__ present, const float* __restrict__ c6ab, const float* __restrict__ cnref, int nz,
+__global__ void d3_compact_species_kernel(const int* __restrict__ present, const float* __restrict__ c6ab, const float* __restrict__ cnref, int nz,
                                           int* __restrict__ smap, D3Species* __restrict__ info, float4* __restrict__ ctab,
                                           float* __restrict__ ftab, float* __restrict__ fcr, float k3, const float* __restrict__ r4r2,
                                           float a1, float a2) {
@@ -611,8 +619,7 @@ __device__ __forceinline__ void d3_compact_species_body(const int* __restrict__ 
     fact_ok = 1;
     int S = 0;
     for (int z = 0; z < nz; ++z) {
-      // (device-scope atomic load: the marks were stored by other blocks, and this block's caches must not answer for them)
-      if (z > 0 && __hip_atomic_load(&present[z], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { smap[z] = S < D3_SMAX ? S : -1; if (S < D3_SMAX) zlist[S] = z; ++S; }
+      if (z > 0 && present[z]) { smap[z] = S < D3_SMAX ? S : -1; if (S < D3_SMAX) zlist[S] = z; ++S; }
       else smap[z] = -1;
     }
     count = S;
@@ -657,27 +664,9 @@ __device__ __forceinline__ void d3_compact_species_body(const int* __restrict__ 
   __syncthreads();
   if (threadIdx.x == 0) info->factorized = fact_ok && k3 < 0.0f;  // the -inf masking of missing points needs k3 < 0
 }
-// Species marks and tables in ONE launch (round 6; two before): every block marks the species of its 256 atoms, takes a ticket, and the block
-// that draws the last one -- all marks are then in memory (fence before the ticket) -- builds the compact tables.  `present[nz + 2]` is the
-// ticket counter, cleared with the marks by the call's one memset.
-__global__ __launch_bounds__(256) void d3_species_kernel(const int* __restrict__ numbers, int N, int* __restrict__ present, const float* __restrict__ c6ab,
-                                                         const float* __restrict__ cnref, int nz, int* __restrict__ smap, D3Species* __restrict__ info,
-                                                         float4* __restrict__ ctab, float* __restrict__ ftab, float* __restrict__ fcr, float k3,
-                                                         const float* __restrict__ r4r2, float a1, float a2) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < N) {
-    const int z = numbers[i];
-    if (z > 0 && z < nz) present[z] = 1;  // benign race: every writer stores 1
-  }
-  __shared__ int last_sh;
-  __threadfence();
-  __syncthreads();
-  if (threadIdx.x == 0) last_sh = atomicAdd(&present[nz + 2], 1) == (int)gridDim.x - 1;
-  __syncthreads();
-  if (!last_sh) return;
-  __threadfence();
-  d3_compact_species_body(present, c6ab, cnref, nz, smap, info, ctab, ftab, fcr, k3, r4r2, a1, a2);
-}
+// (Round 6 tried both as ONE launch -- every block marks, takes a ticket, the last one builds the tables -- and measured 58 us instead of
+// 4.6 + 9.6: the device-scope fence in front of each ticket makes a block write back its XCD's L2, which at that point holds the tail of the
+// 5 GB neighbour list the search has just written.  Cross-block hand-offs inside a kernel are not cheap on an 8-L2 part; a kernel boundary is.)
 
 // `_c6ab_interpolate` (dftd3.py:427-547) on 25 packed terms {c6, cn_ref_i, cn_ref_j}.  Branch-free: the reference's
 // `continue`s (c6 == 0, exp_arg - max < -12) become selects, so every lane runs the same 25 + 25 steps with no
@@ -1189,8 +1178,7 @@ __global__ __launch_bounds__(D3_LS_WAVES * MI_WAVE) void d3_chain_kernel(const T
 #define D3_REDUCE_SLOTS 16
 __global__ __launch_bounds__(256) void d3_reduce_kernel(const float* __restrict__ e_atom, const double* __restrict__ v_atom,
                                                         const int* __restrict__ batch_idx, int N, int want_virial,
-                                                        double* __restrict__ sums /*[B][D3_REDUCE_SLOTS][10] + ticket word, zeroed*/, int B,
-                                                        float* __restrict__ energy, float* __restrict__ virial) {
+                                                        double* __restrict__ sums /*[B][D3_REDUCE_SLOTS][10], zeroed*/) {
   const int lane = threadIdx.x & (MI_WAVE - 1);
   const int wave = blockIdx.x * (blockDim.x / MI_WAVE) + threadIdx.x / MI_WAVE;
   const int slot = wave & (D3_REDUCE_SLOTS - 1);
@@ -1228,25 +1216,18 @@ __global__ __launch_bounds__(256) void d3_reduce_kernel(const float* __restrict_
     }
   }
   flush();
-  // the block that finishes last folds the slots into the outputs (round 6: `d3_finish_kernel`, a launch of its own before).  Every block's
-  // atomics are at device scope and fenced before its ticket, so the last block's device-scope loads see all of them.
-  __shared__ int last_sh;
-  unsigned long long* ticket = reinterpret_cast<unsigned long long*>(sums + 10 * (size_t)D3_REDUCE_SLOTS * B);
-  __threadfence();
-  __syncthreads();
-  if (threadIdx.x == 0) last_sh = atomicAdd(ticket, 1ull) == (unsigned long long)gridDim.x - 1ull;
-  __syncthreads();
-  if (!last_sh) return;
-  __threadfence();
-  for (int t = threadIdx.x; t < 10 * B; t += blockDim.x) {
-    const int s = t / 10, k = t - 10 * s;
-    double v = 0.0;
+}
+// (a separate launch: folding the slots in the reduce kernel's last block needs a device-scope fence per block, which costs more than this
+// launch does -- see d3_mark_species_kernel)
+__global__ void d3_finish_kernel(const double* __restrict__ sums, int B, int want_virial, float* __restrict__ energy, float* __restrict__ virial) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= 10 * B) return;
+  const int s = t / 10, k = t - 10 * s;
+  double v = 0.0;
 #pragma unroll
-    for (int q = 0; q < D3_REDUCE_SLOTS; ++q)  // fixed order: deterministic given the slot sums
-      v += __hip_atomic_load(&sums[10 * ((size_t)s * D3_REDUCE_SLOTS + q) + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (k == 0) energy[s] = (float)v;
-    else if (want_virial) virial[9 * (size_t)s + (k - 1)] = (float)v;
-  }
+  for (int q = 0; q < D3_REDUCE_SLOTS; ++q) v += sums[10 * ((size_t)s * D3_REDUCE_SLOTS + q) + k];  // fixed order: deterministic given the slot sums
+  if (k == 0) energy[s] = (float)v;
+  else if (want_virial) virial[9 * (size_t)s + (k - 1)] = (float)v;
 }
 
 inline long long d3_sort_cap(int N, int B) { return 4ll * N + 8ll * (B > 0 ? B : 1); }
@@ -1261,8 +1242,8 @@ D3Layout d3_layout(int N, int nz, int dtype, int B) {
   // `guard`, `sums` and `present` sit next to each other: all start a call as zeros and are cleared by ONE memset (round 5: one launch less
   // on the dependent chain of small D3 kernels).  guard = MI_CN_SLOTS fingerprint words + the "companion unusable" flag (D3Guard)
   L.guard = take(sizeof(unsigned long long) * MI_CN_SLOTS + 256);
-  L.sums = take(sizeof(double) * (10 * D3_REDUCE_SLOTS * (size_t)(B > 0 ? B : 1) + 1));  // + 1: the ticket counter of d3_reduce_kernel (cleared with the sums)
-  L.present = take(sizeof(int) * ((size_t)nz + 3));  // + 3: the atom-order probe {far-apart consecutive pairs, largest pair distance (bits)} and the ticket counter of d3_species_kernel, cleared with the table
+  L.sums = take(sizeof(double) * 10 * D3_REDUCE_SLOTS * (size_t)(B > 0 ? B : 1));
+  L.present = take(sizeof(int) * ((size_t)nz + 2));  // + 2: the atom-order probe {far-apart consecutive pairs, largest pair distance (bits)}, cleared with the table
   L.tab = take(sizeof(float4) * (size_t)nz * nz * 25);
   L.smap = take(sizeof(int) * (size_t)nz);
   L.sinfo = take(sizeof(D3Species));
@@ -1396,7 +1377,7 @@ int d3_impl(const T* pos, const int* numbers, int N, const int* idx, const int* 
   // outputs are zeroed like the reference wrapper does (dftd3.py:1933-1936; atoms with Z == 0 keep zeros): the per-atom arrays by
   // the pack kernel below, energy / virial are written for every system by the finish kernel
   // (one memset: the per-system reduction slots `sums`, only touched by the reduce kernel at the very end, lie directly in front of `present`)
-  MI_HIP_CHECK(hipMemsetAsync(ws + L.guard, 0, (L.present - L.guard) + sizeof(int) * ((size_t)hp->nz + 3), st));
+  MI_HIP_CHECK(hipMemsetAsync(ws + L.guard, 0, (L.present - L.guard) + sizeof(int) * ((size_t)hp->nz + 2), st));
   D3Grid* sgrid = reinterpret_cast<D3Grid*>(ws + L.sgrid);
   if (sorted || (sortable && probe)) {
     d3_sort_setup_kernel<T><<<1, 256, 0, st>>>(cell, B, N, rc_est, sgrid, d3_sort_cap(N, B));
@@ -1414,8 +1395,9 @@ int d3_impl(const T* pos, const int* numbers, int N, const int* idx, const int* 
     MI_LAUNCH_CHECK();
   }
   const bool publish = sortable && probe;  // (after the CN pass, which adds the largest pair distance)
-  d3_species_kernel<<<mi_blocks(N, 256), 256, 0, st>>>(numbers, N, present, hp->c6ab, hp->cn_ref, hp->nz, smap, sinfo, ctab, ftab, fcr, hp->k3, hp->r4r2,
-                                                       hp->a1, hp->a2);
+  d3_mark_species_kernel<<<mi_blocks(N, 256), 256, 0, st>>>(numbers, N, hp->nz, present);
+  MI_LAUNCH_CHECK();
+  d3_compact_species_kernel<<<1, 256, 0, st>>>(present, hp->c6ab, hp->cn_ref, hp->nz, smap, sinfo, ctab, ftab, fcr, hp->k3, hp->r4r2, hp->a1, hp->a2);
   MI_LAUNCH_CHECK();
   const long long nt = (long long)hp->nz * hp->nz * 25;
   // the search's coordination numbers are taken only in the caller's atom order (the spatial order's CN pass writes its place-coded list anyway)
@@ -1426,8 +1408,8 @@ int d3_impl(const T* pos, const int* numbers, int N, const int* idx, const int* 
   if (use_cn) { G.slots = gslots; G.K = mi_cn_scale(hp->k1); G.cell = cell; G.n_cell = 9 * B; G.batch_idx = batch_idx; }
   if (pre) {
     G.nm = idx; G.nsh = ush; G.words = pre_words; G.hdr_flag = pre_flag; G.flag = gflag; G.M = M; G.stride = verify_stride; G.phase = verify_phase;
-    // one wave per (sampled row, D3_VERIFY_CHUNK slots); one block at least: it also forwards the header flag
-    verify_blocks = verify_stride > 0 ? mi_blocks((((long long)N + verify_stride - 1) / verify_stride) * ((M + D3_VERIFY_CHUNK - 1) / D3_VERIFY_CHUNK), 4) : 1;
+    // one wave per sampled row; one block at least: it also forwards the header flag
+    verify_blocks = verify_stride > 0 ? mi_blocks(((long long)N + verify_stride - 1) / verify_stride, 4) : 1;
   }
   const D3Tables TB{hp->c6ab, hp->cn_ref, hp->nz, sinfo, tab, G.atom_blocks + verify_blocks};  // (its blocks leave at once unless > 16 species are present)
   d3_pack_atoms_kernel<T><<<G.atom_blocks + verify_blocks + mi_blocks(nt, 256), 256, 0, st>>>(pos, numbers, N, hp->rcov, hp->r4r2, smap, hp->nz, apos, aaux, forces, cn,
@@ -1504,7 +1486,9 @@ int d3_impl(const T* pos, const int* numbers, int N, const int* idx, const int* 
   else { MI_TIMED("d3_chain", st, (launch_chain(Plain{}))); }
   MI_LAUNCH_CHECK();
   double* sums = reinterpret_cast<double*>(ws + L.sums);  // zeroed with `present` at the top of the call
-  d3_reduce_kernel<<<D3_REDUCE_WAVES / 4, 256, 0, st>>>(e_atom, v_atom, batch_idx, N, want_virial, sums, B, energy, virial);
+  d3_reduce_kernel<<<D3_REDUCE_WAVES / 4, 256, 0, st>>>(e_atom, v_atom, batch_idx, N, want_virial, sums);
+  MI_LAUNCH_CHECK();
+  d3_finish_kernel<<<mi_blocks(10ll * B, 256), 256, 0, st>>>(sums, B, want_virial, energy, virial);
   MI_LAUNCH_CHECK();
   return MI_OK;
 }

@@ -41,7 +41,7 @@ def verify_args() -> tuple[int, int]:
     """(stride, phase) of the sampled companion check for the next `dftd3` call."""
     global _verify_calls
     _verify_calls += 1
-    return _VERIFY_STRIDE, (_verify_calls - 1) % max(_VERIFY_STRIDE, 1)
+    return _VERIFY_STRIDE, (_verify_calls - 1) & 0x3fffffff  # the raw call counter: row offset = phase mod stride, stretch of the row = f(phase div stride)
 
 
 class D3SearchContext:

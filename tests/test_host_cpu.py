@@ -559,7 +559,7 @@ def test_packed_companion_validity_rules():
     assert E.packed_companion(nm, sh2, 6) is None
     # sampled device-side check: (stride, phase) rotate from call to call
     a, b = E.verify_args(), E.verify_args()
-    assert a[0] == b[0] and (a[0] == 0 or b[1] == (a[1] + 1) % a[0])
+    assert a[0] == b[0] and b[1] == a[1] + 1
 
 
 def test_spread_workspace_is_sized_for_the_order_and_dtype_it_serves():
