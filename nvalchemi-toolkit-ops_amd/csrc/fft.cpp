@@ -67,13 +67,19 @@ int mi_fft_plan_create(int nx, int ny, int nz, int batch, int dtype, int inverse
   hipfftResult r = hipfftCreate(&p->handle);
   // (a channel-interleaved real side, [nx][ny][nz][batch] -- one 32-byte record per mesh point for the gather -- was probed in round 4:
   // rocFFT runs the strided C2R 3x slower, 293 vs 94 us for 4 x 128^3 fp64: tools/probe/fft_layout.py, profiles/README.md)
-  // The layout is spelled out (inembed / onembed = the dense extents) instead of passing NULL embeds.  Found at the end of round 4
-  // (tools/probe/rocfft_drift_repro.py, profiles/r04_rocfft_drift_repro.log): with NULL embeds, a plan for (32, 8, 16) created while plans
-  // for other shapes built from the same 1-D lengths -- (32, 16, 8) among them -- were alive computed a transform 60 % off numpy, in fp32 and
-  // fp64, every time, while torch.fft was exact in the same process.  torch always passes explicit embeds, so this build does too: the same
-  // dense layout, described the way the known-good caller describes it.  Verified with this form: the odd-mesh / headline / config-4 PME
-  // tests against the oracle (24 tests).  NOT yet verified (the round's GPU budget ended): that it removes the defect -- rerun the probe.
-  // NVALCHEMIOPS_FFT_LAYOUT=default restores the NULL form for that comparison.
+  // The layout is spelled out (inembed / onembed = the dense extents), as torch spells it out; NULL embeds describe the same dense layout
+  // (NVALCHEMIOPS_FFT_LAYOUT=default passes them, for comparisons).
+  //
+  // Neither form protects against the rocFFT defect this library guards its plans for (self-test at creation + dense-DFT fallback,
+  // nvalchemiops/interactions/electrostatics/pme.py::_fft_plan).  It is reproduced with no line of this repository loaded by
+  // tests/native/hipfft_repro.cpp (hipFFT + HIP runtime only; profiles/r06_hipfft_repro.log, r06_hipfft_narrow.log): in ONE process,
+  //     plan (16, 16, 16) D2Z / Z2D   ->  correct
+  //     plan (16,  8, 32) D2Z / Z2D   ->  59 % off the transform's definition, R2C and C2R, fp64 and fp32, NULL and explicit embeds,
+  // and in the other order ((16, 8, 32), (16, 16, 8), then (16, 16, 16)) it is the 16^3 plan that is wrong (34 % off) -- the failure the
+  // GPU suite's impulse tests report for 16^3.  Each shape alone, in a fresh process, is exact; the system ROCm's libraries and the copies
+  // inside the PyTorch wheel behave the same (hipFFT 1.0.36).  Two live plans with the same leading length and the same number of points
+  // share something they must not (a run-time-compiled kernel keyed without one of the lengths is the likely mechanism; there is no rocFFT
+  // source here to confirm).  A caller of hipFFT cannot avoid it by how it plans: only by checking what a new plan computes.
   static const bool null_embeds = [] { const char* e = getenv("NVALCHEMIOPS_FFT_LAYOUT"); return e && strcmp(e, "default") == 0; }();
   int real_dims[3] = {nx, ny, nz}, half_dims[3] = {nx, ny, nz / 2 + 1};
   const int real_dist = nx * ny * nz, half_dist = nx * ny * (nz / 2 + 1);

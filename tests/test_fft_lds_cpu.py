@@ -135,3 +135,18 @@ def test_kernel_bodies_stay_inside_their_buffers(tmp_path):
     run = subprocess.run([exe, "asan"], capture_output=True, text=True, timeout=600)
     assert run.returncode == 0 and "AddressSanitizer" not in run.stderr, run.stderr[-3000:]
     assert sum(l.endswith("in bounds") for l in run.stdout.splitlines()) == 6, run.stdout   # 3 meshes x (fp64, fp32)
+
+
+def test_standalone_hipfft_reproducer_compiles(tmp_path):
+    """tests/native/hipfft_repro.cpp is the stand-alone reproducer of the wrong-transform hipFFT plans: hipFFT and the HIP
+    runtime only, no line of this repository.  Here: it still compiles against the installed hipFFT headers (it runs in
+    tests/test_pme_gpu.py::test_hipfft_defect_reproduces_without_this_library)."""
+    import shutil
+
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    exe = str(tmp_path / "hipfft_repro")
+    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O1", os.path.join(ROOT, "tests", "native", "hipfft_repro.cpp"), "-o", exe, "-lhipfft"],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]

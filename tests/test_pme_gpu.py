@@ -1035,3 +1035,32 @@ def test_guarded_fft_ops_and_their_adjoints_equal_torch_fft(dims, batch):
         assert float((ga - gb).detach().abs().max()) <= tol * float(gb.detach().abs().max()), (dims, dt, "c2r")
         (ha,), (hb,) = torch.autograd.grad((ga * w.conj()).real.sum(), a), torch.autograd.grad((gb * w.conj()).real.sum(), b)
         assert float((ha - hb).abs().max()) <= tol * max(float(hb.abs().max()), 1.0), (dims, dt, "c2r second derivative")
+
+
+def test_hipfft_defect_reproduces_without_this_library(tmp_path):
+    """Why the plan cache self-tests every hipFFT plan: tests/native/hipfft_repro.cpp -- hipFFT and the HIP runtime, not one
+    line of this repository -- plans (16, 16, 16) and then (16, 8, 32) in one process, and the second plan computes a transform ~59 % off
+    its definition (each shape alone is exact).  The test documents the state of the INSTALLED rocFFT: it passes when the defect shows (the
+    guard is needed) and when it does not (a fixed rocFFT: the guard costs one known-answer test per new plan), and fails only if the
+    reproducer itself cannot run.  The outcome is written to gpurun_out/hipfft_repro_status.txt."""
+    import os
+    import shutil
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc on this box")
+    exe = str(tmp_path / "hipfft_repro")
+    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O2", os.path.join(root, "tests", "native", "hipfft_repro.cpp"), "-o", exe, "-lhipfft"],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    alone = subprocess.run([exe, "seq", "explicit", "16", "8", "32"], capture_output=True, text=True, timeout=300)
+    assert alone.returncode == 0 and " ok" in alone.stdout, alone.stdout + alone.stderr  # a fresh process: exact
+    pair = subprocess.run([exe, "seq", "explicit", "16", "16", "16", "16", "8", "32"], capture_output=True, text=True, timeout=300)
+    assert pair.returncode in (0, 1), pair.stdout + pair.stderr
+    status = "DEFECT PRESENT: " if pair.returncode == 1 else "defect not reproduced: "
+    out = os.path.join(root, "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    with open(os.path.join(out, "hipfft_repro_status.txt"), "w") as f:
+        f.write(status + pair.stdout.strip().splitlines()[-1] + "\n")
