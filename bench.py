@@ -59,7 +59,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 VALU_PEAK_GINSTR = 256 * 4 * 2.4 / 2.0
 # VALU wave-instructions per launch of the VALU-bound kernels on the headline box, from the committed SQ_INSTS_VALU pass
 # (profiles/: counters cannot be read from inside the timed run)
-VALU_PROFILE = next((p for p in (os.path.join(ROOT, "profiles", n) for n in ("r05_pmc_valu.json", "r04_pmc_valu.json", "r03_pmc_valu.json", "r02_pmc_valu.json")) if os.path.exists(p)),
+VALU_PROFILE = next((p for p in (os.path.join(ROOT, "profiles", n) for n in ("r06_pmc_valu.json", "r05_pmc_valu.json", "r04_pmc_valu.json", "r03_pmc_valu.json", "r02_pmc_valu.json")) if os.path.exists(p)),
                     os.path.join(ROOT, "profiles", "r04_pmc_valu.json"))
 PME = dict(cutoff=9.0, alpha=0.35, mesh=(128, 128, 128), order=5, max_neighbors=256)
 D3 = dict(cutoff=40.0, a1=0.4289, a2=4.4407, s8=0.7875, max_neighbors=2560)  # row width: explicit, as in the reference's own
@@ -369,6 +369,23 @@ def make_step(sysd, tables, device, world):
                 box = []
                 e_d3, f_d3, nptr = d3_branch(sysd, params, cell_list, dftd3, n, d3_bufs, after_list)
                 e_pme, f_pme = box[0]
+            elif OVERLAP == 4:
+                # schedule 4 (tuning aid, round 6): the side stream runs the reciprocal half BEFORE the real-space sum -- the mesh solve's blocks
+                # need a whole CU's LDS and sit out every long kernel of the main stream, so they should meet the gap between the 40-Bohr fill
+                # and the energy pass; the real-space sum and the gather (small blocks) can share CUs with the D3 passes
+                from nvalchemiops.interactions.electrostatics import ewald_real_space, pme_reciprocal_space
+
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    cell_list(sysd["pos64"], PME["cutoff"], sysd["cell64"], sysd["pbc"], neighbor_matrix=nm, neighbor_matrix_shifts=nsh,
+                              num_neighbors=num)
+                    e_k, f_k = pme_reciprocal_space(sysd["pos64"], sysd["q64"], sysd["cell64"], PME["alpha"], mesh_dimensions=PME["mesh"],
+                                                    spline_order=PME["order"], compute_forces=True)
+                    al = torch.full((1,), PME["alpha"], dtype=torch.float64, device=device)
+                    e_r, f_r = ewald_real_space(sysd["pos64"], sysd["q64"], sysd["cell64"], al, neighbor_matrix=nm, neighbor_matrix_shifts=nsh,
+                                                mask_value=n, compute_forces=True)
+                    e_pme, f_pme = e_r + e_k, f_r + f_k
+                e_d3, f_d3, nptr = d3_branch(sysd, params, cell_list, dftd3, n, d3_bufs)
             else:  # schedule 2 (tuning aid): the PME branch is enqueued after the D3 list, next to the D3 passes only
                 box = []
                 e_d3, f_d3, nptr = d3_branch(sysd, params, cell_list, dftd3, n, d3_bufs, lambda: box.append(pme_branch()))
@@ -424,7 +441,7 @@ def profile_lookup(path: str, kernel: str, field: str, atoms: int, workload: str
 
 
 def traffic_profile():
-    for name in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+    for name in ("r06_pmc_traffic.json", "r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
         path = os.path.join(ROOT, "profiles", name)
         if os.path.exists(path):
             return path
@@ -1002,7 +1019,7 @@ def _config_rows(kernels, acct, workload=None):
     """Kernel table of a config workload: every timed kernel with its in-step average and, where `acct` prices it, SURVEY 8(d) bytes;
     `traffic_bytes` from the committed PMC summary of the same workload (profiles/r05_pmc_traffic_<workload>.json) when there is one."""
     rows = {}
-    tfile = os.path.join(ROOT, "profiles", f"r05_pmc_traffic_{workload}.json") if workload else ""
+    tfile = next((p for p in (os.path.join(ROOT, "profiles", f"{r}_pmc_traffic_{workload}.json") for r in ("r06", "r05")) if os.path.exists(p)), "") if workload else ""
     traffic = {}
     if tfile and os.path.exists(tfile):
         try:
@@ -1348,7 +1365,7 @@ def main():
     ap.add_argument("--d3-format", default="matrix", choices=["matrix", "csr"],
                     help="neighbour-list format of the D3 leg: padded matrix with explicit row width (default; what the reference's own D3 benchmark "
                          "uses) or exact-size COO/CSR (two-pass build)")
-    ap.add_argument("--overlap", type=int, default=1, choices=[0, 1, 2, 3], help="1 (default): PME and D3 branches on two HIP streams; 0: one stream, per-stage times; 2: tuning aid")
+    ap.add_argument("--overlap", type=int, default=1, choices=[0, 1, 2, 3, 4], help="1 (default): PME and D3 branches on two HIP streams; 0: one stream, per-stage times; 2: tuning aid")
     ap.add_argument("--processes", type=int, default=0,
                     help="headline, 1 GPU: run the timed region in this many FRESH processes one after the other and report the one with the median "
                          "ms_per_step (default 3; 1 = time in this process).  The 40-Bohr list fill has two states that are fixed for the life of a "
