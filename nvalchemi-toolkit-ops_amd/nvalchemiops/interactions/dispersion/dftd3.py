@@ -220,6 +220,7 @@ def dftd3(positions: torch.Tensor, numbers: torch.Tensor, a1: float, a2: float, 
 
             # valid only while matrix and shifts are provably what the search wrote (tensor identity + version counters); else None
             packed = E.packed_companion(nm, neighbor_matrix_shifts, fill)
+            E.learn_dftd3_context(nm, numbers, covalent_radii, k1)  # "auto" policy: the next search into this buffer also sums the CNs
         _launch(positions, numbers, nm, neighbor_matrix_shifts, None, nm.size(1), fill, cell,
                 batch_idx, num_systems, tables, scalars, compute_virial, energy, forces, coord_num, virial, packed=packed)
     else:

@@ -29,6 +29,7 @@ _PACKED_WANTED: set[tuple[int, int, int]] = set()
 _PACKED_ATTR = "_nvalchemiops_packed"
 _BUILT_ATTR = "_nvalchemiops_built"
 _D3CTX_ATTR = "_nvalchemiops_d3ctx"
+_D3CTX_BY_SHAPE: dict = {}  # "auto" policy: (device, n_atoms, row width) -> the species `dftd3` was last run with on a matrix of that shape (<= 64 entries)
 # Device-side check of a companion against the arrays it describes, run by `dftd3` on every call (csrc/d3.hip, D3Guard): every
 # NVALCHEMIOPS_NL_PACKED_VERIFY-th row is re-derived from matrix + shifts and compared word by word (default 64: +1.6 % of the list's
 # traffic; "1" compares every row; "0" switches the check off).  The sampled rows rotate from call to call, so an edit that persists is
@@ -51,18 +52,54 @@ class D3SearchContext:
     signatures of `cell_list` / `batch_cell_list` stay what they are.  The tensors are converted once, here; a caller who later hands
     `dftd3` other species, radii, positions or cell simply gets the ordinary CN pass: the numbers are only adopted when the fingerprint
     `dftd3` computes on the device from ITS arguments equals the one the search stored (csrc/common.h)."""
-    __slots__ = ("numbers", "rcov", "k1")
+    __slots__ = ("numbers", "rcov", "k1", "_src")
 
     def __init__(self, numbers: torch.Tensor, covalent_radii: torch.Tensor, k1: float = 16.0):
         self.numbers = numbers.detach().to(torch.int32).contiguous()
         self.rcov = covalent_radii.detach().to(device=numbers.device, dtype=torch.float32).contiguous()
         self.k1 = float(k1)
+        # what the converted copies were made from (identity + torch version): lets `dftd3` tell cheaply whether the context it finds on a
+        # buffer still describes the species it is being called with (a host-side hint only -- adoption is decided on the device)
+        self._src = (weakref.ref(numbers), numbers._version, weakref.ref(covalent_radii), covalent_radii._version)
+
+    def describes(self, numbers: torch.Tensor, covalent_radii: torch.Tensor, k1: float) -> bool:
+        n_ref, n_ver, r_ref, r_ver = self._src
+        return (n_ref() is numbers and numbers._version == n_ver and r_ref() is covalent_radii and covalent_radii._version == r_ver
+                and float(k1) == self.k1)
 
 
 def attach_dftd3_context(neighbor_matrix: torch.Tensor, numbers: torch.Tensor, covalent_radii: torch.Tensor, k1: float = 16.0) -> None:
     """Every later search into `neighbor_matrix` that qualifies for a packed companion also sums the DFT-D3 coordination numbers."""
     setattr(neighbor_matrix, _D3CTX_ATTR, D3SearchContext(numbers, covalent_radii, k1))
     want_packed_companion(neighbor_matrix.device, int(neighbor_matrix.shape[0]), int(neighbor_matrix.shape[1]))
+
+
+def learn_dftd3_context(neighbor_matrix: torch.Tensor, numbers: torch.Tensor, covalent_radii: torch.Tensor, k1: float) -> None:
+    """Policy "auto", the coordination numbers' half: `dftd3` was handed a padded matrix this package built into the caller's buffer (it carries a
+    companion, or the "built here" mark).  An MD loop searches into the same buffers every step, so the species it runs D3 with are attached
+    to the buffer and the NEXT search into it also sums the coordination numbers -- the unmodified reference call sequence gets the fused
+    path from its second or third step on.  A caller whose species differ from call to call just has the context replaced each time (and
+    `dftd3` falls back to its own pass whenever the device-side fingerprints disagree)."""
+    if _PACKED_POLICY != "auto" or not neighbor_matrix.is_cuda:
+        return
+    if getattr(neighbor_matrix, _PACKED_ATTR, None) is None and getattr(neighbor_matrix, _BUILT_ATTR, None) is None:
+        return
+    ctx = getattr(neighbor_matrix, _D3CTX_ATTR, None)
+    try:
+        if ctx is not None and ctx.describes(numbers, covalent_radii, k1):
+            return
+        if numbers.shape[0] != neighbor_matrix.shape[0]:
+            return
+        key = (neighbor_matrix.device.index, int(neighbor_matrix.shape[0]), int(neighbor_matrix.shape[1]))
+        known = _D3CTX_BY_SHAPE.get(key)
+        ctx = known if (known is not None and known.describes(numbers, covalent_radii, k1)) else D3SearchContext(numbers, covalent_radii, k1)
+        setattr(neighbor_matrix, _D3CTX_ATTR, ctx)
+        # a caller who lets every search allocate its outputs never searches into the same tensor twice: the shape remembers the context
+        if len(_D3CTX_BY_SHAPE) > 64:
+            _D3CTX_BY_SHAPE.clear()
+        _D3CTX_BY_SHAPE[key] = ctx
+    except Exception:
+        pass
 
 
 def invalidate(*tensors: torch.Tensor) -> None:
@@ -217,7 +254,11 @@ def neighbor_matrix(pos, cell, pbc, batch_idx, cutoff, max_neighbors, fill_value
     old = getattr(nm, _PACKED_ATTR, None)  # an MD loop searches into the same buffers every step: reuse the companion's storage
     words = old.words if (old is not None and old.words.numel() == nbytes and old.words.device == pos.device) else torch.empty(nbytes, dtype=torch.uint8, device=pos.device)
     ws = workspace(n, cell.shape[0], pos.dtype, pos.device)
-    ctx = getattr(nm, _D3CTX_ATTR, None)  # the caller announced that this list feeds dftd3 with these species: also sum the coordination numbers
+    # the caller announced that this list feeds dftd3 with these species (or, policy "auto", dftd3 was last run with them on a matrix of this
+    # shape): also sum the coordination numbers
+    ctx = getattr(nm, _D3CTX_ATTR, None)
+    if ctx is None and _PACKED_POLICY == "auto":
+        ctx = _D3CTX_BY_SHAPE.get((pos.device.index, n, int(max_neighbors)))
     if ctx is not None and (ctx.numbers.shape[0] != n or ctx.numbers.device != pos.device):
         ctx = None
     _written(nm, nsh, num)

@@ -325,3 +325,46 @@ def test_search_without_context_is_unchanged(engine):
     assert torch.equal(nm, nm0) and torch.equal(num, num0) and torch.equal(sh, sh0)
     a, b = _d3(tp, tz, p, nm, sh, tc[None]), _d3(tp, tz, p, nm0, sh0, tc[None])
     assert _close(a[2], b[2]) and _close(a[0], b[0])
+
+
+def test_auto_policy_learns_the_species_from_dftd3(monkeypatch):
+    """Policy "auto", untouched reference call sequence (no `attach_dftd3_context`, no `tuned_neighbor_buffers`): the first `dftd3` call on a
+    matrix this package built registers shape and species; the next search into the same buffers -- or into freshly allocated outputs of
+    the same shape -- carries companion AND coordination numbers, and `dftd3` adopts them (CN output = the search's block, bit for bit).
+    Results stay the oracle's throughout."""
+    from nvalchemiops.neighborlist import _engine as E
+    from nvalchemiops.neighborlist import cell_list
+
+    monkeypatch.setattr(E, "_PACKED_POLICY", "auto")
+    monkeypatch.setattr(E, "_PACKED_WANTED", set())
+    monkeypatch.setattr(E, "_D3CTX_BY_SHAPE", {})
+    tables, p = _params()
+    pos, cell, _, numbers = S.fcc_box(2048, seed=9, dtype=np.float32)
+    tp, tz, tc = _t(pos), _t(numbers), _t(cell)
+    pbc = torch.tensor([True] * 3, device=DEV)
+    n, m = 2048, 256
+    nm = torch.empty((n, m), dtype=torch.int32, device=DEV)
+    sh = torch.empty((n, m, 3), dtype=torch.int32, device=DEV)
+    num = torch.empty(n, dtype=torch.int32, device=DEV)
+    cell_list(tp, 9.0, tc, pbc, neighbor_matrix=nm, neighbor_matrix_shifts=sh, num_neighbors=num)
+    assert not hasattr(nm, E._PACKED_ATTR)  # nobody asked yet
+    ref = _oracle(pos, numbers, tables, nm, sh, cell)
+    out0 = _d3(tp, tz, p, nm, sh, tc[None])  # learns shape + species
+    assert _close(out0[2], ref[2]) and _close(out0[0], ref[0])
+    cell_list(tp, 9.0, tc, pbc, neighbor_matrix=nm, neighbor_matrix_shifts=sh, num_neighbors=num)
+    rec = getattr(nm, E._PACKED_ATTR)
+    assert rec.cn is not None
+    out1 = _d3(tp, tz, p, nm, sh, tc[None])
+    assert torch.equal(out1[2], rec.cn[1024:].view(torch.float32)) and _close(out1[2], ref[2]) and _close(out1[0], ref[0])
+    # outputs allocated by the search itself: the shape remembers
+    nm2, num2, sh2 = cell_list(tp, 9.0, tc, pbc, max_neighbors=m)
+    rec2 = getattr(nm2, E._PACKED_ATTR)
+    assert rec2.cn is not None
+    out2 = _d3(tp, tz, p, nm2, sh2, tc[None])
+    assert torch.equal(out2[2], rec2.cn[1024:].view(torch.float32)) and _close(out2[0], ref[0])
+    # other species on the next call: the stale context's numbers are not adopted, the context is replaced
+    z2 = numbers.copy()
+    z2[::2] = 1
+    out3 = _d3(tp, _t(z2), p, nm2, sh2, tc[None])
+    ref3 = _oracle(pos, z2, tables, nm2, sh2, cell)
+    assert _close(out3[2], ref3[2]) and _close(out3[0], ref3[0])
