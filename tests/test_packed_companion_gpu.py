@@ -189,6 +189,7 @@ def test_auto_policy_learns_from_dftd3_and_reuses_the_storage(monkeypatch):
 
     monkeypatch.setattr(E, "_PACKED_POLICY", "auto")
     monkeypatch.setattr(E, "_PACKED_WANTED", set())
+    monkeypatch.setattr(E, "_D3CTX_BY_SHAPE", {})
     _, p = _params()
     pos, cell, _, numbers = S.fcc_box(2048, dtype=np.float32)
     tp, tz, tc = _t(pos), _t(numbers), _t(cell)
@@ -203,12 +204,15 @@ def test_auto_policy_learns_from_dftd3_and_reuses_the_storage(monkeypatch):
     cell_list(tp, 11.0, tc, pbc, neighbor_matrix=nm, neighbor_matrix_shifts=sh, num_neighbors=num)
     rec = getattr(nm, E._PACKED_ATTR)
     second = _d3(tp, tz, p, nm, sh, tc[None])
-    for a, b in zip(first, second):
-        assert torch.equal(a, b)
+    # round 6: the first dftd3 call also taught the policy the SPECIES, so this search summed the coordination numbers and dftd3 adopted
+    # them -- another summation order for CN (<= 1e-6 relative, tests/test_search_cn_gpu.py), everything else follows within its own bar
+    assert rec.cn is not None and torch.equal(second[2], rec.cn[1024:].view(torch.float32))
+    for a, b, scale in zip(first, second, (1.0, 5.0 * float(first[1].abs().max()), 1.0, 0.2 * float(first[3].abs().max()))):
+        assert bool(((a - b).abs() <= 1e-6 + 1e-6 * b.abs() + 1e-6 * scale).all())
     cell_list(tp, 11.0, tc, pbc, neighbor_matrix=nm, neighbor_matrix_shifts=sh, num_neighbors=num)
-    assert getattr(nm, E._PACKED_ATTR).words.data_ptr() == rec.words.data_ptr()
+    assert getattr(nm, E._PACKED_ATTR).words.data_ptr() == rec.words.data_ptr() and getattr(nm, E._PACKED_ATTR).cn.data_ptr() == rec.cn.data_ptr()
     third = _d3(tp, tz, p, nm, sh, tc[None])
-    for a, b in zip(first, third):
+    for a, b in zip(second, third):  # the fused path is deterministic: same buffers, same inputs, same bits
         assert torch.equal(a, b)
     # a half-filled or shift-less search into the same buffers drops it
     cell_list(tp, 11.0, tc, pbc, half_fill=True, neighbor_matrix=nm, neighbor_matrix_shifts=sh, num_neighbors=num)
