@@ -484,13 +484,13 @@ int mi_pme_convolve(const void* spec /*complex [B,nx,ny,nzr]*/, const void* reci
                     const void* k_vectors /*[(B,)nx,ny,nzr,3] or NULL*/, const void* k_squared /*[(B,)nx,ny,nzr] or NULL*/,
                     int k_batched /*the k arrays carry a leading system dimension*/, void* out /*complex [B,(1|4),nx,ny,nzr]*/, void* stream);
 /* Fused mesh solve: everything between the spread and the gather of pme.py:1398-1461 -- rfftn, (spec / sf^2) G, the three field spectra
- * -i k_d conv, and the four inverse transforms (norm="forward": unscaled) -- for a power-of-two mesh, in four kernels (+ one tiny table
+ * -i k_d conv, and the four inverse transforms (norm="forward": unscaled) -- for a mesh whose sizes are products of 2, 3 and 5 (round 6: mixed-radix lines; powers of two only before), in four kernels (+ one tiny table
  * launch into the scratch) that keep a whole (y,z) plane resp. 16 x-columns in LDS (csrc/fft_lds.h): mesh [n_systems][nx][ny][nz] real -> real_out [n_systems][1|4][nx][ny][nz]
  * (potential, then E_x, E_y, E_z when with_field), exactly what mi_fft_plan_exec (R2C) -> mi_pme_convolve -> mi_fft_plan_exec (C2R) leave,
  * without the charge spectrum as a by-product (callers that need it -- the adjoint of the autograd node -- keep the three-call form, or
  * mi_pme_solve_keep below).  No state outlives the call.
  * The inverse follows numpy / torch irfftn in not reading the imaginary parts of the DC and Nyquist bins along z.
- * supported: nx, ny in {8..256}, nz in {8..512}, powers of two, one (ny, nz/2+1) complex plane + its tables within 160 KB of LDS
+ * supported: nx, ny in {8..256}, nz in {8..512} and even, every size a product of 2, 3 and 5 (96, 100, 120 ... as well as the powers of two), one (ny, nz/2+1) complex plane + its tables within 160 KB of LDS
  * (fp64: 128 x 128, 64 x 256; fp32: 256 x 128, 128 x 256).  k is evaluated from recip_cell (2 pi cell^-1, mi_pme_prepare).            */
 int mi_pme_solve_supported(int n_systems, int nx, int ny, int nz, int dtype);
 /* 1 when the fused solve is the path to take (host policy, measured: since round 5 wherever it is supported -- at parity with hipFFT's

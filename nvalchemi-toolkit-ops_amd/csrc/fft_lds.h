@@ -1,7 +1,8 @@
 // In-LDS 3-D FFT pieces of the fused PME mesh solve (csrc/pme.hip: pme_solve_*_kernel).
 //
 // The reference runs torch.fft.rfftn -> three elementwise spectrum kernels -> four torch.fft.irfftn (pme.py:1398-1440).  A library 3-D
-// FFT is three passes over HBM per transform; here the whole k-space step of a power-of-two mesh is four kernels that touch their data once:
+// FFT is three passes over HBM per transform; here the whole k-space step of a mesh whose sizes are products of 2, 3 and 5 (round 6: mixed
+// radix; rounds 4 - 5: powers of two only) is four kernels that touch their data once:
 //   A   one block per (system, x) plane:        real rows -> packed R2C along z -> FFT along y, the plane never leaves LDS
 //   B1  one block per 16 (y,z) columns:         FFT along x (radix 16 x 8), times the Green function / B-spline moduli on the way out, in place
 //   B2  one block per (16 columns, channel):    (1 | -i k_d) on the way in, inverse FFT along x; the channels of a tile share one XCD's L2
@@ -36,62 +37,8 @@ template <class T> MI_HD Cx<T> cconj(Cx<T> a) { return Cx<T>{a.re, -a.im}; }
 // a * (-i) for SIGN = -1 (forward), a * (+i) for SIGN = +1
 template <int SIGN, class T> MI_HD Cx<T> crot(Cx<T> a) { return SIGN < 0 ? Cx<T>{a.im, -a.re} : Cx<T>{-a.im, a.re}; }
 
-// ---- 1-D plan: n = product of radices out of {16, 8, 4, 2}, at most three stages (n <= 512) -----------------------------------------------
-struct Plan {
-  int n, lg, nst, radix[4], lr[4];  // lr = log2(radix)
-};
-MI_HD bool plan_ok(int n) { return n >= 2 && n <= 512 && (n & (n - 1)) == 0; }
-// max_lr: log2 of the largest radix (4: radix 16 -- 64 VGPRs of fp64 points per butterfly, for kernels that can afford them; 3: radix 8)
-MI_HD Plan make_plan(int n, int max_lr = 3) {
-  Plan p;
-  p.n = n;
-  p.nst = 0;
-  for (int s = 0; s < 4; ++s) { p.radix[s] = 1; p.lr[s] = 0; }
-  int lg = 0;
-  while ((1 << lg) < n) ++lg;
-  p.lg = lg;
-  // as few stages as the radix allows, the large radices first (the last stage walks adjacent elements: keep it the small one)
-  const int nst = (lg + max_lr - 1) / max_lr;
-  int rem = lg;
-  for (int s = 0; s < nst; ++s) {
-    const int left = nst - s;
-    const int l = (rem + left - 1) / left;  // ceil: 7 -> 4 + 3, 9 -> 3 + 3 + 3, 5 -> 3 + 2
-    p.radix[p.nst] = 1 << l;
-    p.lr[p.nst++] = l;
-    rem -= l;
-  }
-  return p;
-}
-// log2 of the sub-transform length of stage s
-MI_HD int stage_lgL(const Plan& p, int s) {
-  int l = p.lg;
-  for (int t = 0; t < s; ++t) l -= p.lr[t];
-  return l;
-}
-// slot p of the forward output holds frequency k:  p = q0 n/R0 + q1 n/(R0 R1) + ...,  k = q0 + R0 q1 + R0 R1 q2 + ...
-MI_HD int slot_freq(const Plan& p, int slot) {
-  int k = 0, sh = 0, rem = p.lg;
-  for (int s = 0; s < p.nst; ++s) {
-    rem -= p.lr[s];
-    const int q = slot >> rem;
-    slot -= q << rem;
-    k += q << sh;
-    sh += p.lr[s];
-  }
-  return k;
-}
-MI_HD int freq_slot(const Plan& p, int k) {
-  int slot = 0, rem = p.lg;
-  for (int s = 0; s < p.nst; ++s) {
-    rem -= p.lr[s];
-    slot += (k & (p.radix[s] - 1)) << rem;
-    k >>= p.lr[s];
-  }
-  return slot;
-}
-
-// division of an item index by a line count that need not be a power of two (the row pitch nz/2 + 1): multiply-high by a magic number,
-// exact for x * d < 2^32 (items stay below 2^21, d below 2^9)
+// division of an index by a small runtime constant: a shift for powers of two, else multiply-high by a magic number,
+// exact for x * d < 2^32 (items stay below 2^21, d below 2^10)
 struct FastDiv {
   unsigned d, magic;
   int shift;  // >= 0: d is 2^shift
@@ -106,6 +53,74 @@ MI_HD FastDiv make_div(unsigned d) {
   return f;
 }
 MI_HD unsigned fdiv(const FastDiv& f, unsigned x) { return f.shift >= 0 ? x >> f.shift : (unsigned)(((unsigned long long)x * f.magic) >> 32); }
+
+// ---- 1-D plan: n = product of radices out of {16, 8, 4, 2, 5, 3}, n <= 512 -------------------------------------------------------------------
+// Stage s transforms sub-sequences of length L_s = n / (R_0 ... R_{s-1}) with radix R_s; sub_s = L_s / R_s.  Powers of two keep their shifts
+// (FastDiv degenerates to one); other lengths pay a multiply-high per index.
+#define MI_FFT_MAX_STAGES 8
+struct Plan {
+  int n, nst, radix[MI_FFT_MAX_STAGES], len[MI_FFT_MAX_STAGES] /* L_s */, sub[MI_FFT_MAX_STAGES] /* L_s / R_s */;
+  FastDiv dsub[MI_FFT_MAX_STAGES];  // division by sub_s
+  FastDiv dper[MI_FFT_MAX_STAGES];  // division by n / R_s, the butterflies of one line in stage s
+};
+MI_HD bool plan_ok(int n) {
+  if (n < 2 || n > 512) return false;
+  int m = n;
+  while (m % 2 == 0) m /= 2;
+  while (m % 3 == 0) m /= 3;
+  while (m % 5 == 0) m /= 5;
+  return m == 1;
+}
+// max_lr: log2 of the largest power-of-two radix (4: radix 16 -- 64 VGPRs of fp64 points per butterfly, for kernels that can afford them; 3: radix 8)
+MI_HD Plan make_plan(int n, int max_lr = 3) {
+  Plan p;
+  p.n = n;
+  p.nst = 0;
+  for (int s = 0; s < MI_FFT_MAX_STAGES; ++s) { p.radix[s] = 1; p.len[s] = 1; p.sub[s] = 1; p.dsub[s] = make_div(1); p.dper[s] = make_div(1); }
+  int lg = 0, m = n;
+  while (m % 2 == 0) { m /= 2; ++lg; }
+  // the power-of-two part: as few stages as the radix allows, the large radices first
+  const int nst2 = (lg + max_lr - 1) / max_lr;
+  int rem = lg;
+  for (int s = 0; s < nst2; ++s) {
+    const int left = nst2 - s;
+    const int l = (rem + left - 1) / left;  // ceil: 7 -> 4 + 3, 9 -> 3 + 3 + 3, 5 -> 3 + 2
+    p.radix[p.nst++] = 1 << l;
+    rem -= l;
+  }
+  // then the fives and the threes, one radix each (the last stage walks adjacent elements: keep it a small one)
+  while (m % 5 == 0) { m /= 5; p.radix[p.nst++] = 5; }
+  while (m % 3 == 0) { m /= 3; p.radix[p.nst++] = 3; }
+  int L = n;
+  for (int s = 0; s < p.nst; ++s) {
+    p.len[s] = L;
+    p.sub[s] = L / p.radix[s];
+    p.dsub[s] = make_div((unsigned)p.sub[s]);
+    p.dper[s] = make_div((unsigned)(n / p.radix[s]));
+    L = p.sub[s];
+  }
+  return p;
+}
+// slot p of the forward output holds frequency k:  p = q0 n/R0 + q1 n/(R0 R1) + ...,  k = q0 + R0 q1 + R0 R1 q2 + ...
+MI_HD int slot_freq(const Plan& p, int slot) {
+  int k = 0, w = 1;
+  for (int s = 0; s < p.nst; ++s) {
+    const int q = (int)fdiv(p.dsub[s], (unsigned)slot);
+    slot -= q * p.sub[s];
+    k += q * w;
+    w *= p.radix[s];
+  }
+  return k;
+}
+MI_HD int freq_slot(const Plan& p, int k) {
+  int slot = 0;
+  for (int s = 0; s < p.nst; ++s) {
+    const int q = k % p.radix[s];
+    slot += q * p.sub[s];
+    k /= p.radix[s];
+  }
+  return slot;
+}
 
 // ---- register butterflies: y_q = sum_r x_r exp(SIGN 2 pi i r q / R) --------------------------------------------------------------------
 template <int SIGN, class T> MI_HD void dft2(Cx<T>* v) {
@@ -165,30 +180,56 @@ template <int SIGN, class T> MI_HD void dft16(Cx<T>* v) {
     v[2 * m + 1] = w[m];
   }
 }
+template <int SIGN, class T> MI_HD void dft3(Cx<T>* v) {
+  const T c = T(-0.5), sn = (SIGN < 0 ? T(-1) : T(1)) * T(0.86602540378443864676);  // exp(SIGN 2 pi i / 3) = c + i sn
+  const Cx<T> a = v[0], t = cadd(v[1], v[2]), d = csub(v[1], v[2]);
+  const Cx<T> m{a.re + c * t.re, a.im + c * t.im};
+  const Cx<T> r{-sn * d.im, sn * d.re};  // i sn d
+  v[0] = cadd(a, t);
+  v[1] = cadd(m, r);
+  v[2] = csub(m, r);
+}
+template <int SIGN, class T> MI_HD void dft5(Cx<T>* v) {
+  const T sg = SIGN < 0 ? T(-1) : T(1);
+  const T c1 = T(0.30901699437494742410), c2 = T(-0.80901699437494742410);           // cos(2 pi / 5), cos(4 pi / 5)
+  const T s1 = sg * T(0.95105651629515357212), s2 = sg * T(0.58778525229247312917);  // SIGN sin(2 pi / 5), SIGN sin(4 pi / 5)
+  const Cx<T> a = v[0], t1 = cadd(v[1], v[4]), t2 = cadd(v[2], v[3]), d1 = csub(v[1], v[4]), d2 = csub(v[2], v[3]);
+  const Cx<T> m1{a.re + c1 * t1.re + c2 * t2.re, a.im + c1 * t1.im + c2 * t2.im};
+  const Cx<T> m2{a.re + c2 * t1.re + c1 * t2.re, a.im + c2 * t1.im + c1 * t2.im};
+  const Cx<T> r1{-(s1 * d1.im + s2 * d2.im), s1 * d1.re + s2 * d2.re};  // i (s1 d1 + s2 d2)
+  const Cx<T> r2{-(s2 * d1.im - s1 * d2.im), s2 * d1.re - s1 * d2.re};  // i (s2 d1 - s1 d2)
+  v[0] = cadd(a, cadd(t1, t2));
+  v[1] = cadd(m1, r1);
+  v[4] = csub(m1, r1);
+  v[2] = cadd(m2, r2);
+  v[3] = csub(m2, r2);
+}
 template <int SIGN, int R, class T> MI_HD void dftR(Cx<T>* v) {
   if (R == 2) dft2<SIGN>(v);
+  if (R == 3) dft3<SIGN>(v);
   if (R == 4) dft4<SIGN>(v);
+  if (R == 5) dft5<SIGN>(v);
   if (R == 8) dft8<SIGN>(v);
   if (R == 16) dft16<SIGN>(v);
 }
 
-// One butterfly of one stage.  Stage with sub-transform length L = 2^lgL, radix R: butterfly j in [0, n / R) works on the points
-// blk * L + o + r * sub (r < R; sub = L / R, blk = j / sub, o = j % sub) -- `ld(point)` fetches them, `st(point, value)` stores the results
-// to the same point numbers.  W: table of exp(-2 pi i t / NW) with NW = 2^lgNW >= L.
+// One butterfly of one stage.  Stage s of plan `pl` (sub-transform length L = pl.len[s], radix R = pl.radix[s], sub = L / R): butterfly j in
+// [0, n / R) works on the points blk * L + o + r * sub (r < R; blk = j / sub, o = j % sub) -- `ld(point)` fetches them, `st(point, value)`
+// stores the results to the same point numbers.  W: table of exp(-2 pi i t / NW), NW a multiple of L.
 // Forward (decimation in frequency): butterfly, then twiddle exp(-2 pi i o q / L).  Inverse (decimation in time): conjugate twiddle, then
 // butterfly -- R times the exact inverse of the forward stage, so forward stages 0..S-1 followed by inverse stages S-1..0 give n * identity.
-template <int R, class T, class Ld> MI_HD void butterfly_load(Cx<T>* v, int lgL, int lgR, int j, Ld ld) {
-  const int lsub = lgL - lgR;
-  const int blk = j >> lsub, o = j & ((1 << lsub) - 1);
-  const int base = (blk << lgL) + o;
+template <int R, class T, class Ld> MI_HD void butterfly_load(Cx<T>* v, const Plan& pl, int s, int j, Ld ld) {
+  const int sub = pl.sub[s];
+  const int blk = (int)fdiv(pl.dsub[s], (unsigned)j), o = j - blk * sub;
+  const int base = blk * pl.len[s] + o;
 #pragma unroll
-  for (int r = 0; r < R; ++r) v[r] = ld(base + (r << lsub));
+  for (int r = 0; r < R; ++r) v[r] = ld(base + r * sub);
 }
-template <int SIGN, int R, class T, class St> MI_HD void butterfly_finish(Cx<T>* v, const Cx<T>* W, int lgNW, int lgL, int lgR, int j, St st) {
-  const int lsub = lgL - lgR;
-  const int blk = j >> lsub, o = j & ((1 << lsub) - 1);
-  const int base = (blk << lgL) + o;
-  const int wl = o << (lgNW - lgL);  // o * (NW / L)
+template <int SIGN, int R, class T, class St> MI_HD void butterfly_finish(Cx<T>* v, const Cx<T>* W, int NW, const Plan& pl, int s, int j, St st) {
+  const int sub = pl.sub[s];
+  const int blk = (int)fdiv(pl.dsub[s], (unsigned)j), o = j - blk * sub;
+  const int base = blk * pl.len[s] + o;
+  const int wl = o * (NW / pl.len[s]);  // q * wl < NW for q < R: o < sub = L / R
   if (SIGN > 0) {
 #pragma unroll
     for (int q = 1; q < R; ++q) v[q] = cmul(v[q], cconj(W[q * wl]));
@@ -199,21 +240,24 @@ template <int SIGN, int R, class T, class St> MI_HD void butterfly_finish(Cx<T>*
     for (int q = 1; q < R; ++q) v[q] = cmul(v[q], W[q * wl]);
   }
 #pragma unroll
-  for (int r = 0; r < R; ++r) st(base + (r << lsub), v[r]);
+  for (int r = 0; r < R; ++r) st(base + r * sub, v[r]);
 }
 template <int SIGN, int R, class T, class Ld, class St>
-MI_HD void butterfly(const Cx<T>* W, int lgNW, int lgL, int lgR, int j, Ld ld, St st) {
+MI_HD void butterfly(const Cx<T>* W, int NW, const Plan& pl, int s, int j, Ld ld, St st) {
   Cx<T> v[R];
-  butterfly_load<R>(v, lgL, lgR, j, ld);
-  butterfly_finish<SIGN, R>(v, W, lgNW, lgL, lgR, j, st);
+  butterfly_load<R>(v, pl, s, j, ld);
+  butterfly_finish<SIGN, R>(v, W, NW, pl, s, j, st);
 }
-// MAXLR: the largest radix the caller's plans contain (make_plan's max_lr) -- radix 16 is only instantiated where it can occur
+// MAXLR: the largest power-of-two radix the caller's plans contain (make_plan's max_lr) -- radix 16 is only instantiated where it can occur
 template <int SIGN, int MAXLR = 3, class T, class Ld, class St>
-MI_HD void butterfly_r(int lgR, const Cx<T>* W, int lgNW, int lgL, int j, Ld ld, St st) {
-  if (MAXLR >= 4 && lgR == 4) butterfly<SIGN, MAXLR >= 4 ? 16 : 8>(W, lgNW, lgL, MAXLR >= 4 ? 4 : 3, j, ld, st);
-  else if (lgR == 3) butterfly<SIGN, 8>(W, lgNW, lgL, 3, j, ld, st);
-  else if (lgR == 2) butterfly<SIGN, 4>(W, lgNW, lgL, 2, j, ld, st);
-  else butterfly<SIGN, 2>(W, lgNW, lgL, 1, j, ld, st);
+MI_HD void butterfly_r(const Plan& pl, int s, const Cx<T>* W, int NW, int j, Ld ld, St st) {
+  const int R = pl.radix[s];
+  if (MAXLR >= 4 && R == 16) butterfly<SIGN, MAXLR >= 4 ? 16 : 8>(W, NW, pl, s, j, ld, st);
+  else if (R == 8) butterfly<SIGN, 8>(W, NW, pl, s, j, ld, st);
+  else if (R == 4) butterfly<SIGN, 4>(W, NW, pl, s, j, ld, st);
+  else if (R == 2) butterfly<SIGN, 2>(W, NW, pl, s, j, ld, st);
+  else if (R == 5) butterfly<SIGN, 5>(W, NW, pl, s, j, ld, st);
+  else butterfly<SIGN, 3>(W, NW, pl, s, j, ld, st);
 }
 
 // exp(-2 pi i t / n), evaluated in double whatever T is
@@ -242,37 +286,37 @@ template <class T> MI_HD Cx<T> unit_root(int t, int n) {
 // otherwise (rows: the pitch is odd in 16-byte units, conflict-free for b128; columns: the lines are adjacent elements).
 struct ItemMap {
   bool along;
-  int lper;
-  FastDiv lines;
+  int per;
+  FastDiv dper, lines;
 };
 MI_HD void item_of(const ItemMap& m, int it, int& line, int& j) {
-  if (m.along) { line = it >> m.lper; j = it & ((1 << m.lper) - 1); }
+  if (m.along) { line = (int)fdiv(m.dper, (unsigned)it); j = it - line * m.per; }
   else { j = (int)fdiv(m.lines, (unsigned)it); line = it - j * (int)m.lines.d; }
 }
 
 // one stage, in place, over lines of an LDS array: element (line, point) at a[line * line_stride + point * point_stride]
 template <int SIGN, class T>
 MI_HD void lds_stage(Cx<T>* a, const Plan& pl, int s, int n_lines, const FastDiv& lines_div, int line_stride, int point_stride, const Cx<T>* W,
-                     int lgNW, int tid, int nth) {
-  const int lgL = stage_lgL(pl, s), lgR = pl.lr[s];
+                     int NW, int tid, int nth) {
   ItemMap m;
-  m.lper = pl.lg - lgR;
-  m.along = point_stride == 1 && (lgL - lgR) >= 4;
+  m.per = pl.n / pl.radix[s];
+  m.dper = pl.dper[s];
+  m.along = point_stride == 1 && pl.sub[s] >= 16;
   m.lines = lines_div;
-  const int items = n_lines << m.lper;
+  const int items = n_lines * m.per;
   for (int it = tid; it < items; it += nth) {
     int line, j;
     item_of(m, it, line, j);
     Cx<T>* d = a + line * line_stride;
-    butterfly_r<SIGN>(lgR, W, lgNW, lgL, j, [=](int p) { return d[p * point_stride]; }, [=](int p, Cx<T> v) { d[p * point_stride] = v; });
+    butterfly_r<SIGN>(pl, s, W, NW, j, [=](int p) { return d[p * point_stride]; }, [=](int p, Cx<T> v) { d[p * point_stride] = v; });
   }
 }
 // all stages of a batch of 1-D transforms held in LDS, forward or inverse, a barrier after each
 template <int SIGN, class T>
-MI_HD void lines_fft(Cx<T>* a, const Plan& pl, int n_lines, const FastDiv& lines_div, int line_stride, int point_stride, const Cx<T>* W, int lgNW,
+MI_HD void lines_fft(Cx<T>* a, const Plan& pl, int n_lines, const FastDiv& lines_div, int line_stride, int point_stride, const Cx<T>* W, int NW,
                      int tid, int nth) {
   for (int si = 0; si < pl.nst; ++si) {
-    lds_stage<SIGN>(a, pl, SIGN < 0 ? si : pl.nst - 1 - si, n_lines, lines_div, line_stride, point_stride, W, lgNW, tid, nth);
+    lds_stage<SIGN>(a, pl, SIGN < 0 ? si : pl.nst - 1 - si, n_lines, lines_div, line_stride, point_stride, W, NW, tid, nth);
     MI_FFT_SYNC();
   }
 }
@@ -323,15 +367,19 @@ template <class T> MI_HD void c2r_pre_item(Cx<T>* row, const Plan& pz, const Cx<
 struct Geom {
   int B, nx, ny, nz, M, P;  // M = nz / 2 complex points per packed real row, P = M + 1 bins per row (and the LDS row pitch)
   Plan px, py, pz;          // pz: the M-point transform of the packed rows
-  FastDiv divP, divNy;
+  FastDiv divP, divNy, divM;
 };
-MI_HD bool geom_ok(int nx, int ny, int nz) { return plan_ok(nx) && plan_ok(ny) && plan_ok(nz) && nx >= 8 && ny >= 8 && nz >= 8 && nx <= 256 && ny <= 256 && nz <= 512; }
+// sizes: products of 2, 3 and 5; nz even (the real rows are packed as nz / 2 complex points)
+MI_HD bool geom_ok(int nx, int ny, int nz) {
+  return plan_ok(nx) && plan_ok(ny) && nz % 2 == 0 && plan_ok(nz / 2) && nx >= 8 && ny >= 8 && nz >= 8 && nx <= 256 && ny <= 256 && nz <= 512;
+}
 MI_HD Geom make_geom(int B, int nx, int ny, int nz) {
   Geom g;
   g.B = B; g.nx = nx; g.ny = ny; g.nz = nz; g.M = nz / 2; g.P = nz / 2 + 1;
   g.px = make_plan(nx, 4); g.py = make_plan(ny); g.pz = make_plan(nz / 2);  // x columns: one wave per block, radix 16 affordable
   g.divP = make_div((unsigned)g.P);
   g.divNy = make_div((unsigned)ny);
+  g.divM = make_div((unsigned)g.M);
   return g;
 }
 
@@ -398,14 +446,13 @@ template <class T> MI_HD void fwd_plane_body(const T* in, Cx<T>* out, Cx<T>* lds
   Cx<T>* Wy = Wz + g.nz;
   plane_tables(Wz, Wy, tb, g, tid, nth);
   const Cx<T>* src = (const Cx<T>*)in;
-  const int lgM = g.pz.lg;
   for (int e = tid; e < g.ny * g.M; e += nth) {
-    const int y = e >> lgM, j = e & (g.M - 1);
+    const int y = (int)fdiv(g.divM, (unsigned)e), j = e - y * g.M;
     plane[y * g.P + j] = src[e];
   }
   MI_FFT_SYNC();
-  // rows: M-point forward FFT; exp(-2 pi i t / M) = Wz[2 t]: the table of nz entries serves both (lgNW = lg nz)
-  lines_fft<-1>(plane, g.pz, g.ny, g.divNy, g.P, 1, Wz, lgM + 1, tid, nth);
+  // rows: M-point forward FFT; exp(-2 pi i t / M) = Wz[2 t]: the table of nz entries serves both (NW = nz)
+  lines_fft<-1>(plane, g.pz, g.ny, g.divNy, g.P, 1, Wz, g.nz, tid, nth);
   const int half = g.M / 2 + 1;
   for (int it = tid; it < g.ny * half; it += nth) {
     const int k = (int)fdiv(g.divNy, (unsigned)it), y = it - k * g.ny;
@@ -414,16 +461,16 @@ template <class T> MI_HD void fwd_plane_body(const T* in, Cx<T>* out, Cx<T>* lds
   MI_FFT_SYNC();
   // columns: ny-point forward FFT for each of the P bins; the last stage stores straight to HBM (lanes along the row: coalesced)
   for (int s = 0; s + 1 < g.py.nst; ++s) {
-    lds_stage<-1>(plane, g.py, s, g.P, g.divP, 1, g.P, Wy, g.py.lg, tid, nth);
+    lds_stage<-1>(plane, g.py, s, g.P, g.divP, 1, g.P, Wy, g.ny, tid, nth);
     MI_FFT_SYNC();
   }
   {
-    const int s = g.py.nst - 1, lgL = stage_lgL(g.py, s), lgR = g.py.lr[s];
-    const int items = g.P << (g.py.lg - lgR);
+    const int s = g.py.nst - 1;
+    const int items = g.P * (g.ny / g.py.radix[s]);
     const int P = g.P;
     for (int it = tid; it < items; it += nth) {
       const int j = (int)fdiv(g.divP, (unsigned)it), c = it - j * P;
-      butterfly_r<-1>(lgR, Wy, g.py.lg, lgL, j, [=](int p) { return plane[p * P + c]; }, [=](int p, Cx<T> v) { out[p * P + c] = v; });
+      butterfly_r<-1>(g.py, s, Wy, g.ny, j, [=](int p) { return plane[p * P + c]; }, [=](int p, Cx<T> v) { out[p * P + c] = v; });
     }
   }
 }
@@ -438,16 +485,16 @@ template <class T> MI_HD void inv_plane_body(const Cx<T>* in, T* out, Cx<T>* lds
   MI_FFT_SYNC();
   const int P = g.P;
   {  // first inverse stage of the columns reads HBM directly
-    const int s = g.py.nst - 1, lgL = stage_lgL(g.py, s), lgR = g.py.lr[s];
-    const int items = P << (g.py.lg - lgR);
+    const int s = g.py.nst - 1;
+    const int items = P * (g.ny / g.py.radix[s]);
     for (int it = tid; it < items; it += nth) {
       const int j = (int)fdiv(g.divP, (unsigned)it), c = it - j * P;
-      butterfly_r<+1>(lgR, Wy, g.py.lg, lgL, j, [=](int p) { return in[p * P + c]; }, [=](int p, Cx<T> v) { plane[p * P + c] = v; });
+      butterfly_r<+1>(g.py, s, Wy, g.ny, j, [=](int p) { return in[p * P + c]; }, [=](int p, Cx<T> v) { plane[p * P + c] = v; });
     }
     MI_FFT_SYNC();
   }
   for (int s = g.py.nst - 2; s >= 0; --s) {
-    lds_stage<+1>(plane, g.py, s, P, g.divP, 1, P, Wy, g.py.lg, tid, nth);
+    lds_stage<+1>(plane, g.py, s, P, g.divP, 1, P, Wy, g.ny, tid, nth);
     MI_FFT_SYNC();
   }
   const int half = g.M / 2 + 1;
@@ -456,11 +503,10 @@ template <class T> MI_HD void inv_plane_body(const Cx<T>* in, T* out, Cx<T>* lds
     c2r_pre_item(plane + y * P, g.pz, Wz, g.M, k);
   }
   MI_FFT_SYNC();
-  const int lgM = g.pz.lg;
-  lines_fft<+1>(plane, g.pz, g.ny, g.divNy, P, 1, Wz, lgM + 1, tid, nth);
+  lines_fft<+1>(plane, g.pz, g.ny, g.divNy, P, 1, Wz, g.nz, tid, nth);
   Cx<T>* dst = (Cx<T>*)out;
   for (int e = tid; e < g.ny * g.M; e += nth) {
-    const int y = e >> lgM, j = e & (g.M - 1);
+    const int y = (int)fdiv(g.divM, (unsigned)e), j = e - y * g.M;
     dst[e] = plane[y * P + j];
   }
 }
@@ -530,14 +576,13 @@ MI_HD void fwd_cols_body(Cx<T>* spec, Cx<T>* lds, const Geom& g, const Tables<T>
   };
   const Plan& px = g.px;
   for (int s = 0; s < px.nst; ++s) {
-    const int lgL = stage_lgL(px, s), lgR = px.lr[s];
-    const int items = COLS << (px.lg - lgR);
+    const int items = COLS * (nx / px.radix[s]);
     const bool first = s == 0;
     for (int it = tid; it < items; it += nth) {
       const int j = it >> LGC, c = it & (COLS - 1);
       const bool live = col0 + c < ncol;
       const Cx<T>* col = spec + col0 + c;
-      butterfly_r<-1, 4>(lgR, Wx, px.lg, lgL, j,
+      butterfly_r<-1, 4>(px, s, Wx, nx, j,
                       [=](int p) { return first ? (live ? col[(size_t)p * ncol] : Cx<T>{T(0), T(0)}) : S[(p << LGC) + c]; },
                       [=](int p, Cx<T> v) { S[(p << LGC) + c] = v; });
     }
@@ -578,8 +623,7 @@ MI_HD void inv_cols_body(const Cx<T>* conv, Cx<T>* out, Cx<T>* lds, const Geom& 
   const Plan& px = g.px;
   const bool field = ch > 0;
   for (int s = px.nst - 1; s >= 0; --s) {
-    const int lgL = stage_lgL(px, s), lgR = px.lr[s];
-    const int items = COLS << (px.lg - lgR);
+    const int items = COLS * (nx / px.radix[s]);
     const bool first = s == px.nst - 1, last = s == 0;
     auto ld_of = [=](int c, bool live) {
       const Cx<T>* src = conv + col0 + c;
@@ -599,21 +643,21 @@ MI_HD void inv_cols_body(const Cx<T>* conv, Cx<T>* out, Cx<T>* lds, const Geom& 
         else S[(p << LGC) + c] = v;
       };
     };
-    if (first && lgR == 3 && items == 2 * nth) {
+    if (first && px.radix[s] == 8 && items == 2 * nth) {
       // the stage that reads HBM: both butterflies of the lane load first (16 lines in flight per lane instead of 8 + 8 one after the other)
       const int ia = tid, ib = tid + nth;
       const int ja = ia >> LGC, ca = ia & (COLS - 1), jb = ib >> LGC, cb = ib & (COLS - 1);
       const bool la = col0 + ca < ncol, lb = col0 + cb < ncol;
       Cx<T> va[8], vb[8];
-      butterfly_load<8>(va, lgL, 3, ja, ld_of(ca, la));
-      butterfly_load<8>(vb, lgL, 3, jb, ld_of(cb, lb));
-      butterfly_finish<+1, 8>(va, Wx, px.lg, lgL, 3, ja, st_of(ca, la));
-      butterfly_finish<+1, 8>(vb, Wx, px.lg, lgL, 3, jb, st_of(cb, lb));
+      butterfly_load<8>(va, px, s, ja, ld_of(ca, la));
+      butterfly_load<8>(vb, px, s, jb, ld_of(cb, lb));
+      butterfly_finish<+1, 8>(va, Wx, nx, px, s, ja, st_of(ca, la));
+      butterfly_finish<+1, 8>(vb, Wx, nx, px, s, jb, st_of(cb, lb));
     } else {
       for (int it = tid; it < items; it += nth) {
         const int j = it >> LGC, c = it & (COLS - 1);
         const bool live = col0 + c < ncol;
-        butterfly_r<+1, 4>(lgR, Wx, px.lg, lgL, j, ld_of(c, live), st_of(c, live));
+        butterfly_r<+1, 4>(px, s, Wx, nx, j, ld_of(c, live), st_of(c, live));
       }
     }
     MI_FFT_SYNC();

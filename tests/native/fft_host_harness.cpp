@@ -10,10 +10,10 @@ using namespace mifft;
 
 extern "C" {
 
-int h_plan(int n, int max_lr, int* radix /*[4]*/, int* slot_of_freq /*[n]*/, int* freq_of_slot /*[n]*/) {
+int h_plan(int n, int max_lr, int* radix /*[8]*/, int* slot_of_freq /*[n]*/, int* freq_of_slot /*[n]*/) {
   if (!plan_ok(n)) return -1;
   const Plan p = make_plan(n, max_lr);
-  for (int s = 0; s < 4; ++s) radix[s] = p.radix[s];
+  for (int s = 0; s < MI_FFT_MAX_STAGES; ++s) radix[s] = p.radix[s];
   for (int k = 0; k < n; ++k) { slot_of_freq[k] = freq_slot(p, k); freq_of_slot[k] = slot_freq(p, k); }
   return p.nst;
 }
@@ -28,9 +28,9 @@ int h_line(double* data /*[n][2]*/, int n, int max_lr, int inverse) {
   Cx<double>* d = (Cx<double>*)data;
   for (int si = 0; si < p.nst; ++si) {
     const int s = inverse ? p.nst - 1 - si : si;
-    for (int j = 0; j < (n >> p.lr[s]); ++j) {
-      if (inverse) butterfly_r<+1, 4>(p.lr[s], W.data(), p.lg, stage_lgL(p, s), j, [=](int q) { return d[q]; }, [=](int q, Cx<double> v) { d[q] = v; });
-      else butterfly_r<-1, 4>(p.lr[s], W.data(), p.lg, stage_lgL(p, s), j, [=](int q) { return d[q]; }, [=](int q, Cx<double> v) { d[q] = v; });
+    for (int j = 0; j < n / p.radix[s]; ++j) {
+      if (inverse) butterfly_r<+1, 4>(p, s, W.data(), n, j, [=](int q) { return d[q]; }, [=](int q, Cx<double> v) { d[q] = v; });
+      else butterfly_r<-1, 4>(p, s, W.data(), n, j, [=](int q) { return d[q]; }, [=](int q, Cx<double> v) { d[q] = v; });
     }
   }
   return 0;

@@ -29,16 +29,20 @@ def _p(a):
 
 
 def _slots(H, n, max_lr=3):
-    radix = np.zeros(4, np.int32)
+    radix = np.zeros(8, np.int32)
     s_of_f, f_of_s = np.zeros(n, np.int32), np.zeros(n, np.int32)
     nst = H.h_plan(n, max_lr, _p(radix), _p(s_of_f), _p(f_of_s))
-    assert nst == -(-int(np.log2(n)) // max_lr) and radix[:nst].max() <= 2 ** max_lr
-    assert nst >= 1 and int(np.prod(radix[:nst])) == n
+    assert nst >= 1 and int(np.prod(radix[:nst])) == n and set(radix[:nst].tolist()) <= {2, 3, 4, 5, 8, 16} and radix[:nst].max() <= max(2 ** max_lr, 5)
+    if n & (n - 1) == 0:
+        assert nst == -(-int(np.log2(n)) // max_lr)  # powers of two: as few stages as the radix allows
     return s_of_f, f_of_s
 
 
+# every power of two up to 512, and products of 2, 3 and 5 (round 6: mixed radix): 96 / 100 / 120 are what `mesh_spacing=` callers get
 @pytest.mark.parametrize("max_lr", [3, 4])
-@pytest.mark.parametrize("n", [2, 4, 8, 16, 32, 64, 128, 256, 512])
+@pytest.mark.parametrize("n", [2, 4, 8, 16, 32, 64, 128, 256, 512, 3, 5, 6, 9, 10, 12, 15, 18, 20, 24, 25, 27, 30, 36, 40, 45, 48, 50, 60, 72, 75, 80, 90, 96,
+                               100, 108, 120, 125, 135, 144, 150, 160, 180, 192, 200, 225, 240, 243, 250, 256, 270, 288, 300, 320, 360, 375, 384, 400, 405,
+                               432, 450, 480, 486, 500])
 def test_line_forward_slots_and_inverse(H, n, max_lr):
     rng = np.random.default_rng(n)
     x = rng.standard_normal(n) + 1j * rng.standard_normal(n)
@@ -62,7 +66,8 @@ def _unscramble(H, spec, ny, nz):
     return spec[..., sy, :][..., zs]
 
 
-@pytest.mark.parametrize("dims", [(8, 8, 8), (8, 16, 32), (16, 8, 64), (32, 32, 32), (8, 64, 16), (16, 16, 128)])
+@pytest.mark.parametrize("dims", [(8, 8, 8), (8, 16, 32), (16, 8, 64), (32, 32, 32), (8, 64, 16), (16, 16, 128),
+                                  (8, 12, 20), (10, 15, 18), (9, 25, 30), (8, 96, 100), (12, 50, 90), (8, 24, 250)])  # mixed radix; M = nz / 2 odd as well
 def test_forward_planes_equal_numpy_over_y_and_z(H, dims):
     nx, ny, nz = dims
     B = 2
@@ -78,7 +83,10 @@ def test_forward_planes_equal_numpy_over_y_and_z(H, dims):
 @pytest.mark.parametrize("dims,order,nch", [((8, 8, 8), 4, 4), ((16, 8, 32), 5, 4), ((8, 32, 16), 3, 1), ((32, 16, 8), 6, 4), ((16, 16, 16), 2, 4),
                                             # every plan shape the kernels can meet: x 128 = 16 x 8 and 256 = 16 x 16 (radix 16), y 256 = 8 x 8 x 4,
                                             # packed z rows of 128 = 8 x 8 x 2 and 64 = 8 x 8 points
-                                            ((128, 8, 16), 4, 4), ((256, 8, 8), 4, 1), ((8, 256, 8), 4, 1), ((8, 8, 256), 5, 4), ((64, 16, 128), 4, 4)])
+                                            ((128, 8, 16), 4, 4), ((256, 8, 8), 4, 1), ((8, 256, 8), 4, 1), ((8, 8, 256), 5, 4), ((64, 16, 128), 4, 4),
+                                            # mixed radix (round 6): the sizes a `mesh_spacing=` caller gets, odd packed rows (nz / 2 = 45, 25), three / four stages per axis
+                                            ((12, 10, 18), 4, 4), ((20, 18, 24), 5, 4), ((96, 8, 10), 4, 4), ((10, 100, 12), 4, 1), ((8, 9, 120), 5, 4), ((15, 25, 90), 3, 4),
+                                            ((48, 20, 50), 4, 4), ((100, 12, 8), 6, 4), ((120, 8, 10), 4, 4), ((240, 8, 8), 4, 1), ((8, 8, 500), 4, 1)])
 def test_whole_kspace_step_equals_the_numpy_restatement(H, dims, order, nch):
     """mesh -> rfftn -> (spec / sf2) G, (-i k_d) conv -> irfftn * N for the potential + three field components (the middle of
     oracle.pme_reciprocal_space: pme.py:1398-1440); triclinic cells, two systems with their own alpha."""

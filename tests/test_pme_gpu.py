@@ -801,10 +801,12 @@ def test_tile_staged_gather_epilogue(dims, order):
         _close(bf, bref[1], dtype, f"batch forces {dims}")
 
 
-@pytest.mark.parametrize("dims", [(8, 8, 8), (16, 8, 32), (8, 64, 16), (32, 32, 32), (64, 16, 128), (16, 256, 8), (128, 128, 128)])
+@pytest.mark.parametrize("dims", [(8, 8, 8), (16, 8, 32), (8, 64, 16), (32, 32, 32), (64, 16, 128), (16, 256, 8), (128, 128, 128),
+                                  # round 6, mixed radix (sizes that are products of 2, 3, 5; nz even): what a `mesh_spacing=` caller typically gets
+                                  (12, 10, 18), (20, 18, 24), (10, 12, 30), (48, 48, 48), (96, 100, 120), (120, 96, 100)])
 @pytest.mark.parametrize("order", [4, 5])
 def test_fused_mesh_solve(dims, order, monkeypatch):
-    """Power-of-two meshes take the library's fused mesh solve (`mi_pme_solve`: plane / column FFTs in LDS with the Green function, the
+    """Meshes whose sizes are products of 2, 3 and 5 (round 6; powers of two before) take the library's fused mesh solve (`mi_pme_solve`: plane / column FFTs in LDS with the Green function, the
     B-spline moduli and -i k_d between the forward and inverse x transforms, csrc/fft_lds.h) instead of hipFFT R2C -> `mi_pme_convolve` ->
     hipFFT C2R: same energies / forces / charge gradients from both, and both against the oracle (numpy FFTs); triclinic cell, fp64 and fp32,
     energies only (one channel) and with forces (four), single system and a batch of three with their own alpha."""
@@ -862,10 +864,13 @@ def test_fused_mesh_solve_support_table():
     assert ok(1, 128, 128, 128, f64) == 1 and ok(128, 32, 32, 32, f64) == 1 and ok(1, 256, 64, 256, f64) == 1
     assert ok(1, 256, 256, 256, f64) == 0 and ok(1, 128, 256, 128, f64) == 0      # plane larger than 160 KB
     assert ok(1, 128, 256, 128, f32) == 1 and ok(1, 256, 256, 256, f32) == 0
-    assert ok(1, 48, 48, 48, f64) == 0 and ok(1, 30, 36, 45, f64) == 0 and ok(1, 4, 8, 8, f64) == 0
+    assert ok(1, 30, 36, 45, f64) == 0 and ok(1, 4, 8, 8, f64) == 0        # odd nz (real rows are packed in pairs); an axis below 8
+    # round 6: products of 2, 3 and 5 -- 96 / 100 / 120 are what `mesh_spacing=` callers get -- but no other prime factor
+    assert ok(1, 48, 48, 48, f64) == 1 and ok(1, 96, 100, 120, f64) == 1 and ok(1, 20, 18, 24, f64) == 1 and ok(1, 10, 12, 30, f32) == 1
+    assert ok(1, 14, 22, 26, f64) == 0 and ok(1, 12, 10, 14, f64) == 0 and ok(1, 21, 16, 16, f64) == 0
     pref = C.lib().mi_pme_solve_preferred   # measured policy (round 5): wherever it is supported, batches of small meshes included
     assert pref(1, 32, 32, 32, f64) == 1 and pref(128, 32, 32, 32, f64) == 1 and pref(8, 64, 64, 64, f64) == 1 and pref(2, 128, 128, 128, f64) == 1
-    assert pref(1, 48, 48, 48, f64) == 0
+    assert pref(1, 48, 48, 48, f64) == 1 and pref(1, 14, 22, 26, f64) == 0
 
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
@@ -888,7 +893,7 @@ def test_a_failing_fft_plan_is_replaced_not_used(dtype, monkeypatch):
     monkeypatch.setattr(P._FftPlan, "__call__", off_by_60_percent)
     monkeypatch.setattr(P, "_FFT_PLANS", collections.OrderedDict())
     monkeypatch.setattr(P, "_FFT_FALLBACKS", [])
-    dims, order = (20, 18, 24), 4  # not powers of two: the fused mesh solve cannot take it, the plan path must
+    dims, order = (14, 22, 26), 4  # sizes with the prime factors 7, 11, 13: the fused mesh solve cannot take it, the plan path must
     pos, cell, q = _system(300, dtype, triclinic=True, seed=11)
     with warnings.catch_warnings(record=True) as caught:
         warnings.simplefilter("always")
