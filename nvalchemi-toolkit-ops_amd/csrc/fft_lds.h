@@ -40,15 +40,16 @@ template <int SIGN, class T> MI_HD Cx<T> crot(Cx<T> a) { return SIGN < 0 ? Cx<T>
 // division of an index by a small runtime constant: a shift for powers of two, else multiply-high by a magic number,
 // exact for x * d < 2^32 (items stay below 2^21, d below 2^10)
 struct FastDiv {
-  unsigned d, magic;
-  int shift;  // >= 0: d is 2^shift
-};
+  unsigned magic;
+  unsigned short d;
+  signed char shift;  // >= 0: d is 2^shift
+};  // (8 bytes: the plans travel as kernel arguments)
 MI_HD FastDiv make_div(unsigned d) {
   FastDiv f;
-  f.d = d;
+  f.d = (unsigned short)d;
   f.shift = -1;
-  for (int s = 0; s < 31; ++s)
-    if (d == (1u << s)) f.shift = s;
+  for (int s = 0; s < 16; ++s)
+    if (d == (1u << s)) f.shift = (signed char)s;
   f.magic = (unsigned)(0x100000000ull / d) + 1u;
   return f;
 }
@@ -57,12 +58,24 @@ MI_HD unsigned fdiv(const FastDiv& f, unsigned x) { return f.shift >= 0 ? x >> f
 // ---- 1-D plan: n = product of radices out of {16, 8, 4, 2, 5, 3}, n <= 512 -------------------------------------------------------------------
 // Stage s transforms sub-sequences of length L_s = n / (R_0 ... R_{s-1}) with radix R_s; sub_s = L_s / R_s.  Powers of two keep their shifts
 // (FastDiv degenerates to one); other lengths pay a multiply-high per index.
-#define MI_FFT_MAX_STAGES 8
+#define MI_FFT_MAX_STAGES 6  // n <= 512: 486 = 2 x 3^5 is the longest chain
 struct Plan {
-  int n, nst, radix[MI_FFT_MAX_STAGES], len[MI_FFT_MAX_STAGES] /* L_s */, sub[MI_FFT_MAX_STAGES] /* L_s / R_s */;
+  int n, nst;
+  short radix[MI_FFT_MAX_STAGES], len[MI_FFT_MAX_STAGES] /* L_s */, sub[MI_FFT_MAX_STAGES] /* L_s / R_s */;
+  short per[MI_FFT_MAX_STAGES];       // n / R_s: butterflies of one line in stage s
+  short wstep[MI_FFT_MAX_STAGES];     // n / L_s: stride of stage s in a table of n unit roots
   FastDiv dsub[MI_FFT_MAX_STAGES];  // division by sub_s
-  FastDiv dper[MI_FFT_MAX_STAGES];  // division by n / R_s, the butterflies of one line in stage s
-};
+  FastDiv dper[MI_FFT_MAX_STAGES];  // division by per_s
+  FastDiv drad[MI_FFT_MAX_STAGES];  // division by R_s
+  // powers of two keep the index arithmetic of rounds 4 - 5 (shifts and masks: the generic multiply-high / multiply form cost the headline
+  // mesh's kernels 8 - 19 %): p2 != 0 <=> every radix is a power of two; then lgr = log2 R_s, lgsub = log2 sub_s, lglen = log2 L_s
+  int p2;
+  signed char lgr[MI_FFT_MAX_STAGES], lgsub[MI_FFT_MAX_STAGES], lglen[MI_FFT_MAX_STAGES], lgw[MI_FFT_MAX_STAGES] /* log2 (n / L_s) */;
+  signed char lgper[MI_FFT_MAX_STAGES];  // log2 (n / R_s)
+  // GEN (template parameter of the bodies below): false = the caller guarantees p2 for every plan it passes and only the shift / mask forms
+  // and the power-of-two butterflies are compiled (the kernels of power-of-two meshes: same code as rounds 4 - 5, no radix-3 / radix-5 paths
+  // in their instruction stream); true = both forms, chosen per plan at run time (mixed-radix meshes, and the host test harness)
+};  // (every quotient the kernels need per item is a FastDiv or a stored integer: no runtime integer division in the bodies)
 MI_HD bool plan_ok(int n) {
   if (n < 2 || n > 512) return false;
   int m = n;
@@ -76,7 +89,12 @@ MI_HD Plan make_plan(int n, int max_lr = 3) {
   Plan p;
   p.n = n;
   p.nst = 0;
-  for (int s = 0; s < MI_FFT_MAX_STAGES; ++s) { p.radix[s] = 1; p.len[s] = 1; p.sub[s] = 1; p.dsub[s] = make_div(1); p.dper[s] = make_div(1); }
+  for (int s = 0; s < MI_FFT_MAX_STAGES; ++s) {
+    p.radix[s] = 1; p.len[s] = 1; p.sub[s] = 1; p.per[s] = (short)n; p.wstep[s] = 1;
+    p.dsub[s] = make_div(1); p.dper[s] = make_div(1); p.drad[s] = make_div(1);
+    p.lgr[s] = p.lgsub[s] = p.lglen[s] = p.lgw[s] = p.lgper[s] = 0;
+  }
+  p.p2 = (n & (n - 1)) == 0 ? 1 : 0;
   int lg = 0, m = n;
   while (m % 2 == 0) { m /= 2; ++lg; }
   // the power-of-two part: as few stages as the radix allows, the large radices first
@@ -85,7 +103,7 @@ MI_HD Plan make_plan(int n, int max_lr = 3) {
   for (int s = 0; s < nst2; ++s) {
     const int left = nst2 - s;
     const int l = (rem + left - 1) / left;  // ceil: 7 -> 4 + 3, 9 -> 3 + 3 + 3, 5 -> 3 + 2
-    p.radix[p.nst++] = 1 << l;
+    p.radix[p.nst++] = (short)(1 << l);
     rem -= l;
   }
   // then the fives and the threes, one radix each (the last stage walks adjacent elements: keep it a small one)
@@ -93,10 +111,18 @@ MI_HD Plan make_plan(int n, int max_lr = 3) {
   while (m % 3 == 0) { m /= 3; p.radix[p.nst++] = 3; }
   int L = n;
   for (int s = 0; s < p.nst; ++s) {
-    p.len[s] = L;
-    p.sub[s] = L / p.radix[s];
+    p.len[s] = (short)L;
+    p.sub[s] = (short)(L / p.radix[s]);
+    p.per[s] = (short)(n / p.radix[s]);
+    p.wstep[s] = (short)(n / L);
     p.dsub[s] = make_div((unsigned)p.sub[s]);
-    p.dper[s] = make_div((unsigned)(n / p.radix[s]));
+    p.dper[s] = make_div((unsigned)p.per[s]);
+    p.drad[s] = make_div((unsigned)p.radix[s]);
+    if (p.p2) {
+      auto lg2 = [](int v) { int l = 0; while ((1 << l) < v) ++l; return l; };
+      p.lgr[s] = (signed char)lg2(p.radix[s]); p.lgsub[s] = (signed char)lg2(p.sub[s]); p.lglen[s] = (signed char)lg2(L); p.lgw[s] = (signed char)lg2(n / L);
+      p.lgper[s] = (signed char)lg2(n / p.radix[s]);
+    }
     L = p.sub[s];
   }
   return p;
@@ -112,12 +138,19 @@ MI_HD int slot_freq(const Plan& p, int slot) {
   }
   return k;
 }
-MI_HD int freq_slot(const Plan& p, int k) {
+template <bool GEN = true> MI_HD int freq_slot(const Plan& p, int k) {
   int slot = 0;
+  if (!GEN || p.p2) {
+    for (int s = 0; s < p.nst; ++s) {
+      slot += (k & (p.radix[s] - 1)) << p.lgsub[s];
+      k >>= p.lgr[s];
+    }
+    return slot;
+  }
   for (int s = 0; s < p.nst; ++s) {
-    const int q = k % p.radix[s];
-    slot += q * p.sub[s];
-    k /= p.radix[s];
+    const int kq = (int)fdiv(p.drad[s], (unsigned)k);
+    slot += (k - kq * p.radix[s]) * p.sub[s];
+    k = kq;
   }
   return slot;
 }
@@ -215,21 +248,39 @@ template <int SIGN, int R, class T> MI_HD void dftR(Cx<T>* v) {
 
 // One butterfly of one stage.  Stage s of plan `pl` (sub-transform length L = pl.len[s], radix R = pl.radix[s], sub = L / R): butterfly j in
 // [0, n / R) works on the points blk * L + o + r * sub (r < R; blk = j / sub, o = j % sub) -- `ld(point)` fetches them, `st(point, value)`
-// stores the results to the same point numbers.  W: table of exp(-2 pi i t / NW), NW a multiple of L.
+// stores the results to the same point numbers.  W: table of exp(-2 pi i t / NW), NW = wmul * n (wmul = 1, or 2 for the packed real rows,
+// whose M-point transforms read the table of nz = 2 M roots).
 // Forward (decimation in frequency): butterfly, then twiddle exp(-2 pi i o q / L).  Inverse (decimation in time): conjugate twiddle, then
 // butterfly -- R times the exact inverse of the forward stage, so forward stages 0..S-1 followed by inverse stages S-1..0 give n * identity.
-template <int R, class T, class Ld> MI_HD void butterfly_load(Cx<T>* v, const Plan& pl, int s, int j, Ld ld) {
+template <int R, bool GEN = true, class T, class Ld> MI_HD void butterfly_load(Cx<T>* v, const Plan& pl, int s, int j, Ld ld) {
+  if (!GEN || pl.p2) {
+    const int lsub = pl.lgsub[s];
+    const int blk = j >> lsub, o = j & ((1 << lsub) - 1);
+    const int base = (blk << pl.lglen[s]) + o;
+#pragma unroll
+    for (int r = 0; r < R; ++r) v[r] = ld(base + (r << lsub));
+    return;
+  }
   const int sub = pl.sub[s];
   const int blk = (int)fdiv(pl.dsub[s], (unsigned)j), o = j - blk * sub;
   const int base = blk * pl.len[s] + o;
 #pragma unroll
   for (int r = 0; r < R; ++r) v[r] = ld(base + r * sub);
 }
-template <int SIGN, int R, class T, class St> MI_HD void butterfly_finish(Cx<T>* v, const Cx<T>* W, int NW, const Plan& pl, int s, int j, St st) {
-  const int sub = pl.sub[s];
-  const int blk = (int)fdiv(pl.dsub[s], (unsigned)j), o = j - blk * sub;
-  const int base = blk * pl.len[s] + o;
-  const int wl = o * (NW / pl.len[s]);  // q * wl < NW for q < R: o < sub = L / R
+template <int SIGN, int R, bool GEN = true, class T, class St> MI_HD void butterfly_finish(Cx<T>* v, const Cx<T>* W, int wmul, const Plan& pl, int s, int j, St st) {
+  int sub, base, wl;  // wl = o * (NW / L), NW = wmul * n the size of the table; q * wl < NW for q < R: o < sub = L / R
+  if (!GEN || pl.p2) {
+    const int lsub = pl.lgsub[s];
+    const int blk = j >> lsub, o = j & ((1 << lsub) - 1);
+    sub = 1 << lsub;
+    base = (blk << pl.lglen[s]) + o;
+    wl = (o << pl.lgw[s]) * wmul;
+  } else {
+    sub = pl.sub[s];
+    const int blk = (int)fdiv(pl.dsub[s], (unsigned)j), o = j - blk * sub;
+    base = blk * pl.len[s] + o;
+    wl = o * pl.wstep[s] * wmul;
+  }
   if (SIGN > 0) {
 #pragma unroll
     for (int q = 1; q < R; ++q) v[q] = cmul(v[q], cconj(W[q * wl]));
@@ -242,22 +293,22 @@ template <int SIGN, int R, class T, class St> MI_HD void butterfly_finish(Cx<T>*
 #pragma unroll
   for (int r = 0; r < R; ++r) st(base + r * sub, v[r]);
 }
-template <int SIGN, int R, class T, class Ld, class St>
-MI_HD void butterfly(const Cx<T>* W, int NW, const Plan& pl, int s, int j, Ld ld, St st) {
+template <int SIGN, int R, bool GEN = true, class T, class Ld, class St>
+MI_HD void butterfly(const Cx<T>* W, int wmul, const Plan& pl, int s, int j, Ld ld, St st) {
   Cx<T> v[R];
-  butterfly_load<R>(v, pl, s, j, ld);
-  butterfly_finish<SIGN, R>(v, W, NW, pl, s, j, st);
+  butterfly_load<R, GEN>(v, pl, s, j, ld);
+  butterfly_finish<SIGN, R, GEN>(v, W, wmul, pl, s, j, st);
 }
 // MAXLR: the largest power-of-two radix the caller's plans contain (make_plan's max_lr) -- radix 16 is only instantiated where it can occur
-template <int SIGN, int MAXLR = 3, class T, class Ld, class St>
-MI_HD void butterfly_r(const Plan& pl, int s, const Cx<T>* W, int NW, int j, Ld ld, St st) {
+template <int SIGN, int MAXLR = 3, bool GEN = true, class T, class Ld, class St>
+MI_HD void butterfly_r(const Plan& pl, int s, const Cx<T>* W, int wmul, int j, Ld ld, St st) {
   const int R = pl.radix[s];
-  if (MAXLR >= 4 && R == 16) butterfly<SIGN, MAXLR >= 4 ? 16 : 8>(W, NW, pl, s, j, ld, st);
-  else if (R == 8) butterfly<SIGN, 8>(W, NW, pl, s, j, ld, st);
-  else if (R == 4) butterfly<SIGN, 4>(W, NW, pl, s, j, ld, st);
-  else if (R == 2) butterfly<SIGN, 2>(W, NW, pl, s, j, ld, st);
-  else if (R == 5) butterfly<SIGN, 5>(W, NW, pl, s, j, ld, st);
-  else butterfly<SIGN, 3>(W, NW, pl, s, j, ld, st);
+  if (MAXLR >= 4 && R == 16) butterfly<SIGN, MAXLR >= 4 ? 16 : 8, GEN>(W, wmul, pl, s, j, ld, st);
+  else if (R == 8) butterfly<SIGN, 8, GEN>(W, wmul, pl, s, j, ld, st);
+  else if (R == 4) butterfly<SIGN, 4, GEN>(W, wmul, pl, s, j, ld, st);
+  else if (!GEN || R == 2) butterfly<SIGN, 2, GEN>(W, wmul, pl, s, j, ld, st);
+  else if (R == 5) butterfly<SIGN, GEN ? 5 : 2, GEN>(W, wmul, pl, s, j, ld, st);
+  else butterfly<SIGN, GEN ? 3 : 2, GEN>(W, wmul, pl, s, j, ld, st);
 }
 
 // exp(-2 pi i t / n), evaluated in double whatever T is
@@ -286,37 +337,41 @@ template <class T> MI_HD Cx<T> unit_root(int t, int n) {
 // otherwise (rows: the pitch is odd in 16-byte units, conflict-free for b128; columns: the lines are adjacent elements).
 struct ItemMap {
   bool along;
-  int per;
+  int per, lper;
   FastDiv dper, lines;
 };
-MI_HD void item_of(const ItemMap& m, int it, int& line, int& j) {
-  if (m.along) { line = (int)fdiv(m.dper, (unsigned)it); j = it - line * m.per; }
+template <bool GEN = true> MI_HD void item_of(const ItemMap& m, int it, int& line, int& j) {
+  if (m.along) {
+    if (!GEN) { line = it >> m.lper; j = it & ((1 << m.lper) - 1); }
+    else { line = (int)fdiv(m.dper, (unsigned)it); j = it - line * m.per; }
+  }
   else { j = (int)fdiv(m.lines, (unsigned)it); line = it - j * (int)m.lines.d; }
 }
 
 // one stage, in place, over lines of an LDS array: element (line, point) at a[line * line_stride + point * point_stride]
-template <int SIGN, class T>
+template <int SIGN, bool GEN = true, class T>
 MI_HD void lds_stage(Cx<T>* a, const Plan& pl, int s, int n_lines, const FastDiv& lines_div, int line_stride, int point_stride, const Cx<T>* W,
-                     int NW, int tid, int nth) {
+                     int wmul, int tid, int nth) {
   ItemMap m;
-  m.per = pl.n / pl.radix[s];
+  m.per = pl.per[s];
+  m.lper = pl.lgper[s];
   m.dper = pl.dper[s];
   m.along = point_stride == 1 && pl.sub[s] >= 16;
   m.lines = lines_div;
   const int items = n_lines * m.per;
   for (int it = tid; it < items; it += nth) {
     int line, j;
-    item_of(m, it, line, j);
+    item_of<GEN>(m, it, line, j);
     Cx<T>* d = a + line * line_stride;
-    butterfly_r<SIGN>(pl, s, W, NW, j, [=](int p) { return d[p * point_stride]; }, [=](int p, Cx<T> v) { d[p * point_stride] = v; });
+    butterfly_r<SIGN, 3, GEN>(pl, s, W, wmul, j, [=](int p) { return d[p * point_stride]; }, [=](int p, Cx<T> v) { d[p * point_stride] = v; });
   }
 }
 // all stages of a batch of 1-D transforms held in LDS, forward or inverse, a barrier after each
-template <int SIGN, class T>
-MI_HD void lines_fft(Cx<T>* a, const Plan& pl, int n_lines, const FastDiv& lines_div, int line_stride, int point_stride, const Cx<T>* W, int NW,
+template <int SIGN, bool GEN = true, class T>
+MI_HD void lines_fft(Cx<T>* a, const Plan& pl, int n_lines, const FastDiv& lines_div, int line_stride, int point_stride, const Cx<T>* W, int wmul,
                      int tid, int nth) {
   for (int si = 0; si < pl.nst; ++si) {
-    lds_stage<SIGN>(a, pl, SIGN < 0 ? si : pl.nst - 1 - si, n_lines, lines_div, line_stride, point_stride, W, NW, tid, nth);
+    lds_stage<SIGN, GEN>(a, pl, SIGN < 0 ? si : pl.nst - 1 - si, n_lines, lines_div, line_stride, point_stride, W, wmul, tid, nth);
     MI_FFT_SYNC();
   }
 }
@@ -324,14 +379,14 @@ MI_HD void lines_fft(Cx<T>* a, const Plan& pl, int n_lines, const FastDiv& lines
 // ---- R2C / C2R of a row held as M = n/2 complex points z_j = (x_2j, x_2j+1) ---------------------------------------------------------------
 // forward: after the M-point forward FFT (slots), X_k = 1/2 [(Z_k + conj Z_{M-k}) - i w_k (Z_k - conj Z_{M-k})], w_k = exp(-2 pi i k / n);
 // X_k lands in the slot Z_k had, X_M (the Nyquist bin) in element M.  item k in [0, M/2].
-template <class T> MI_HD void r2c_post_item(Cx<T>* row, const Plan& pz, const Cx<T>* Wn /*exp(-2 pi i t / n)*/, int M, int k) {
+template <bool GEN = true, class T> MI_HD void r2c_post_item(Cx<T>* row, const Plan& pz, const Cx<T>* Wn /*exp(-2 pi i t / n)*/, int M, int k) {
   if (k == 0) {
     const Cx<T> z = row[0];
     row[0] = Cx<T>{z.re + z.im, T(0)};
     row[M] = Cx<T>{z.re - z.im, T(0)};
     return;
   }
-  const int sa = freq_slot(pz, k), sb = freq_slot(pz, M - k);
+  const int sa = freq_slot<GEN>(pz, k), sb = freq_slot<GEN>(pz, M - k);
   const Cx<T> a = row[sa], b = row[sb];
   const T h = T(0.5);
   {
@@ -345,13 +400,13 @@ template <class T> MI_HD void r2c_post_item(Cx<T>* row, const Plan& pz, const Cx
 }
 // inverse (unnormalised, numpy.fft.irfft convention: the imaginary parts of the DC and Nyquist bins are not read):
 // Z_k = (X_k + conj X_{M-k}) + i conj(w_k) (X_k - conj X_{M-k}), then the M-point inverse FFT gives z_j = (x_2j, x_2j+1) (sum over all n bins)
-template <class T> MI_HD void c2r_pre_item(Cx<T>* row, const Plan& pz, const Cx<T>* Wn, int M, int k) {
+template <bool GEN = true, class T> MI_HD void c2r_pre_item(Cx<T>* row, const Plan& pz, const Cx<T>* Wn, int M, int k) {
   if (k == 0) {
     const T a = row[0].re, c = row[M].re;
     row[0] = Cx<T>{a + c, a - c};
     return;
   }
-  const int sa = freq_slot(pz, k), sb = freq_slot(pz, M - k);
+  const int sa = freq_slot<GEN>(pz, k), sb = freq_slot<GEN>(pz, M - k);
   const Cx<T> a = row[sa], b = row[sb];
   {
     const Cx<T> e = cadd(a, cconj(b)), o = cmul(cconj(Wn[k]), csub(a, cconj(b)));  // +i * o: (-o.im, o.re)
@@ -366,6 +421,7 @@ template <class T> MI_HD void c2r_pre_item(Cx<T>* row, const Plan& pz, const Cx<
 // ---- geometry shared by the kernels ---------------------------------------------------------------------------------------------------
 struct Geom {
   int B, nx, ny, nz, M, P;  // M = nz / 2 complex points per packed real row, P = M + 1 bins per row (and the LDS row pitch)
+  int p2, lgM;              // every axis a power of two (the GEN = false kernels); log2 M then
   Plan px, py, pz;          // pz: the M-point transform of the packed rows
   FastDiv divP, divNy, divM;
 };
@@ -380,6 +436,9 @@ MI_HD Geom make_geom(int B, int nx, int ny, int nz) {
   g.divP = make_div((unsigned)g.P);
   g.divNy = make_div((unsigned)ny);
   g.divM = make_div((unsigned)g.M);
+  g.p2 = (g.px.p2 && g.py.p2 && g.pz.p2) ? 1 : 0;
+  g.lgM = 0;
+  while ((1 << g.lgM) < g.M) ++g.lgM;
   return g;
 }
 
@@ -440,44 +499,44 @@ template <class T> MI_HD void plane_tables(Cx<T>* Wz, Cx<T>* Wy, const Tables<T>
 
 // ---- kernel A body: one (system, x) plane -------------------------------------------------------------------------------------------
 // in: real plane [ny][nz]; out: [ny][P] complex in (y slot, z slot) order; lds: plane_lds_bytes
-template <class T> MI_HD void fwd_plane_body(const T* in, Cx<T>* out, Cx<T>* lds, const Geom& g, const Tables<T>& tb, int tid, int nth) {
+template <class T, bool GEN = true> MI_HD void fwd_plane_body(const T* in, Cx<T>* out, Cx<T>* lds, const Geom& g, const Tables<T>& tb, int tid, int nth) {
   Cx<T>* plane = lds;
   Cx<T>* Wz = lds + g.ny * g.P;
   Cx<T>* Wy = Wz + g.nz;
   plane_tables(Wz, Wy, tb, g, tid, nth);
   const Cx<T>* src = (const Cx<T>*)in;
   for (int e = tid; e < g.ny * g.M; e += nth) {
-    const int y = (int)fdiv(g.divM, (unsigned)e), j = e - y * g.M;
+    const int y = GEN ? (int)fdiv(g.divM, (unsigned)e) : e >> g.lgM, j = GEN ? e - y * g.M : e & (g.M - 1);
     plane[y * g.P + j] = src[e];
   }
   MI_FFT_SYNC();
   // rows: M-point forward FFT; exp(-2 pi i t / M) = Wz[2 t]: the table of nz entries serves both (NW = nz)
-  lines_fft<-1>(plane, g.pz, g.ny, g.divNy, g.P, 1, Wz, g.nz, tid, nth);
+  lines_fft<-1, GEN>(plane, g.pz, g.ny, g.divNy, g.P, 1, Wz, 2, tid, nth);
   const int half = g.M / 2 + 1;
   for (int it = tid; it < g.ny * half; it += nth) {
     const int k = (int)fdiv(g.divNy, (unsigned)it), y = it - k * g.ny;
-    r2c_post_item(plane + y * g.P, g.pz, Wz, g.M, k);
+    r2c_post_item<GEN>(plane + y * g.P, g.pz, Wz, g.M, k);
   }
   MI_FFT_SYNC();
   // columns: ny-point forward FFT for each of the P bins; the last stage stores straight to HBM (lanes along the row: coalesced)
   for (int s = 0; s + 1 < g.py.nst; ++s) {
-    lds_stage<-1>(plane, g.py, s, g.P, g.divP, 1, g.P, Wy, g.ny, tid, nth);
+    lds_stage<-1, GEN>(plane, g.py, s, g.P, g.divP, 1, g.P, Wy, 1, tid, nth);
     MI_FFT_SYNC();
   }
   {
     const int s = g.py.nst - 1;
-    const int items = g.P * (g.ny / g.py.radix[s]);
+    const int items = g.P * g.py.per[s];
     const int P = g.P;
     for (int it = tid; it < items; it += nth) {
       const int j = (int)fdiv(g.divP, (unsigned)it), c = it - j * P;
-      butterfly_r<-1>(g.py, s, Wy, g.ny, j, [=](int p) { return plane[p * P + c]; }, [=](int p, Cx<T> v) { out[p * P + c] = v; });
+      butterfly_r<-1, 3, GEN>(g.py, s, Wy, 1, j, [=](int p) { return plane[p * P + c]; }, [=](int p, Cx<T> v) { out[p * P + c] = v; });
     }
   }
 }
 
 // ---- kernel C body: one (system, channel, x) plane ----------------------------------------------------------------------------------
 // in: [ny][P] complex in (y slot, z slot) order; out: real plane [ny][nz]
-template <class T> MI_HD void inv_plane_body(const Cx<T>* in, T* out, Cx<T>* lds, const Geom& g, const Tables<T>& tb, int tid, int nth) {
+template <class T, bool GEN = true> MI_HD void inv_plane_body(const Cx<T>* in, T* out, Cx<T>* lds, const Geom& g, const Tables<T>& tb, int tid, int nth) {
   Cx<T>* plane = lds;
   Cx<T>* Wz = lds + g.ny * g.P;
   Cx<T>* Wy = Wz + g.nz;
@@ -486,27 +545,27 @@ template <class T> MI_HD void inv_plane_body(const Cx<T>* in, T* out, Cx<T>* lds
   const int P = g.P;
   {  // first inverse stage of the columns reads HBM directly
     const int s = g.py.nst - 1;
-    const int items = P * (g.ny / g.py.radix[s]);
+    const int items = P * g.py.per[s];
     for (int it = tid; it < items; it += nth) {
       const int j = (int)fdiv(g.divP, (unsigned)it), c = it - j * P;
-      butterfly_r<+1>(g.py, s, Wy, g.ny, j, [=](int p) { return in[p * P + c]; }, [=](int p, Cx<T> v) { plane[p * P + c] = v; });
+      butterfly_r<+1, 3, GEN>(g.py, s, Wy, 1, j, [=](int p) { return in[p * P + c]; }, [=](int p, Cx<T> v) { plane[p * P + c] = v; });
     }
     MI_FFT_SYNC();
   }
   for (int s = g.py.nst - 2; s >= 0; --s) {
-    lds_stage<+1>(plane, g.py, s, P, g.divP, 1, P, Wy, g.ny, tid, nth);
+    lds_stage<+1, GEN>(plane, g.py, s, P, g.divP, 1, P, Wy, 1, tid, nth);
     MI_FFT_SYNC();
   }
   const int half = g.M / 2 + 1;
   for (int it = tid; it < g.ny * half; it += nth) {
     const int k = (int)fdiv(g.divNy, (unsigned)it), y = it - k * g.ny;
-    c2r_pre_item(plane + y * P, g.pz, Wz, g.M, k);
+    c2r_pre_item<GEN>(plane + y * P, g.pz, Wz, g.M, k);
   }
   MI_FFT_SYNC();
-  lines_fft<+1>(plane, g.pz, g.ny, g.divNy, P, 1, Wz, g.nz, tid, nth);
+  lines_fft<+1, GEN>(plane, g.pz, g.ny, g.divNy, P, 1, Wz, 2, tid, nth);
   Cx<T>* dst = (Cx<T>*)out;
   for (int e = tid; e < g.ny * g.M; e += nth) {
-    const int y = (int)fdiv(g.divM, (unsigned)e), j = e - y * g.M;
+    const int y = GEN ? (int)fdiv(g.divM, (unsigned)e) : e >> g.lgM, j = GEN ? e - y * g.M : e & (g.M - 1);
     dst[e] = plane[y * P + j];
   }
 }
@@ -531,7 +590,7 @@ template <class T> MI_HD size_t inv_cols_lds_bytes(const Geom& g) {
 // k_vectors.py:270-282); sf_expo: exponent of the B-spline modulus (decode_order().sf_exponent)
 // spec_nat (NULL or [nx][ny][P] of system b): the UNFACTORED spectrum in natural frequency order -- numpy.fft.rfftn(mesh) -- for a caller that
 // needs the charge spectrum itself (the backward of the autograd node); 16-byte scattered stores, one per element
-template <class T>
+template <class T, bool GEN = true>
 MI_HD void fwd_cols_body(Cx<T>* spec, Cx<T>* lds, const Geom& g, const Tables<T>& tb, const T* recip, T alpha, T volume, int sf_expo, int col0, int tid,
                          int nth, Cx<T>* spec_nat = nullptr) {
   const int COLS = MI_SOLVE_COLS, LGC = MI_SOLVE_LGCOLS;
@@ -576,13 +635,13 @@ MI_HD void fwd_cols_body(Cx<T>* spec, Cx<T>* lds, const Geom& g, const Tables<T>
   };
   const Plan& px = g.px;
   for (int s = 0; s < px.nst; ++s) {
-    const int items = COLS * (nx / px.radix[s]);
+    const int items = COLS * px.per[s];
     const bool first = s == 0;
     for (int it = tid; it < items; it += nth) {
       const int j = it >> LGC, c = it & (COLS - 1);
       const bool live = col0 + c < ncol;
       const Cx<T>* col = spec + col0 + c;
-      butterfly_r<-1, 4>(px, s, Wx, nx, j,
+      butterfly_r<-1, 4, GEN>(px, s, Wx, 1, j,
                       [=](int p) { return first ? (live ? col[(size_t)p * ncol] : Cx<T>{T(0), T(0)}) : S[(p << LGC) + c]; },
                       [=](int p, Cx<T> v) { S[(p << LGC) + c] = v; });
     }
@@ -601,7 +660,7 @@ MI_HD void fwd_cols_body(Cx<T>* spec, Cx<T>* lds, const Geom& g, const Tables<T>
 }
 // conv: [nx][ny*P] complex of system b in slot order along x, y, z; out: [nx][ny*P] of (system b, channel ch), natural order along x again:
 // the inverse x transform of conv (ch = 0, the potential) or of (-i k_d) conv (ch = 1 + d, the field components; pme.py:1455-1457)
-template <class T>
+template <class T, bool GEN = true>
 MI_HD void inv_cols_body(const Cx<T>* conv, Cx<T>* out, Cx<T>* lds, const Geom& g, const Tables<T>& tb, const T* recip, int ch, int col0, int tid, int nth) {
   const int COLS = MI_SOLVE_COLS, LGC = MI_SOLVE_LGCOLS;
   const int ncol = g.ny * g.P, nx = g.nx;
@@ -623,7 +682,7 @@ MI_HD void inv_cols_body(const Cx<T>* conv, Cx<T>* out, Cx<T>* lds, const Geom& 
   const Plan& px = g.px;
   const bool field = ch > 0;
   for (int s = px.nst - 1; s >= 0; --s) {
-    const int items = COLS * (nx / px.radix[s]);
+    const int items = COLS * px.per[s];
     const bool first = s == px.nst - 1, last = s == 0;
     auto ld_of = [=](int c, bool live) {
       const Cx<T>* src = conv + col0 + c;
@@ -649,15 +708,15 @@ MI_HD void inv_cols_body(const Cx<T>* conv, Cx<T>* out, Cx<T>* lds, const Geom& 
       const int ja = ia >> LGC, ca = ia & (COLS - 1), jb = ib >> LGC, cb = ib & (COLS - 1);
       const bool la = col0 + ca < ncol, lb = col0 + cb < ncol;
       Cx<T> va[8], vb[8];
-      butterfly_load<8>(va, px, s, ja, ld_of(ca, la));
-      butterfly_load<8>(vb, px, s, jb, ld_of(cb, lb));
-      butterfly_finish<+1, 8>(va, Wx, nx, px, s, ja, st_of(ca, la));
-      butterfly_finish<+1, 8>(vb, Wx, nx, px, s, jb, st_of(cb, lb));
+      butterfly_load<8, GEN>(va, px, s, ja, ld_of(ca, la));
+      butterfly_load<8, GEN>(vb, px, s, jb, ld_of(cb, lb));
+      butterfly_finish<+1, 8, GEN>(va, Wx, 1, px, s, ja, st_of(ca, la));
+      butterfly_finish<+1, 8, GEN>(vb, Wx, 1, px, s, jb, st_of(cb, lb));
     } else {
       for (int it = tid; it < items; it += nth) {
         const int j = it >> LGC, c = it & (COLS - 1);
         const bool live = col0 + c < ncol;
-        butterfly_r<+1, 4>(px, s, Wx, nx, j, ld_of(c, live), st_of(c, live));
+        butterfly_r<+1, 4, GEN>(px, s, Wx, 1, j, ld_of(c, live), st_of(c, live));
       }
     }
     MI_FFT_SYNC();

@@ -1012,25 +1012,26 @@ int spread_tiled(const T* pos, const T* values, const int* batch_idx, const T* c
 // ---- fused mesh solve: the whole k-space step of a power-of-two mesh in four kernels (bodies: fft_lds.h) ----------------------------------
 #define MI_LDS_MAX 163840
 template <class T> __global__ void pme_solve_tables_kernel(void* base, mifft::Geom g) { mifft::tables_body<T>(base, g, threadIdx.x, blockDim.x); }
-template <class T>
+// GEN: the mixed-radix form of the bodies (meshes with factors 3 and 5); false = power-of-two meshes, shift / mask index arithmetic only
+template <class T, bool GEN>
 __global__ __launch_bounds__(1024) void pme_solve_fwd_kernel(const T* __restrict__ mesh, mifft::Cx<T>* __restrict__ spec, mifft::Geom g, mifft::Tables<T> tb) {
   extern __shared__ __align__(16) unsigned char solve_smem[];
   const size_t plane = blockIdx.x;  // (system, x)
-  mifft::fwd_plane_body<T>(mesh + plane * g.ny * g.nz, spec + plane * g.ny * g.P, (mifft::Cx<T>*)solve_smem, g, tb, threadIdx.x, blockDim.x);
+  mifft::fwd_plane_body<T, GEN>(mesh + plane * g.ny * g.nz, spec + plane * g.ny * g.P, (mifft::Cx<T>*)solve_smem, g, tb, threadIdx.x, blockDim.x);
 }
-template <class T>
+template <class T, bool GEN>
 __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2))) void pme_solve_fwd_cols_kernel(mifft::Cx<T>* __restrict__ spec, mifft::Geom g, mifft::Tables<T> tb, const T* __restrict__ recip,
                                                                 const T* __restrict__ alpha, const T* __restrict__ volume, int sf_expo,
                                                                 mifft::Cx<T>* __restrict__ spec_nat /*NULL or [B][nx][ny][P]*/) {
   extern __shared__ __align__(16) unsigned char solve_smem[];
   const int b = blockIdx.y;
   const size_t per = (size_t)g.nx * g.ny * g.P;
-  mifft::fwd_cols_body<T>(spec + b * per, (mifft::Cx<T>*)solve_smem, g, tb, recip + 9 * b, alpha[b], volume[b], sf_expo, blockIdx.x * MI_SOLVE_COLS,
+  mifft::fwd_cols_body<T, GEN>(spec + b * per, (mifft::Cx<T>*)solve_smem, g, tb, recip + 9 * b, alpha[b], volume[b], sf_expo, blockIdx.x * MI_SOLVE_COLS,
                           threadIdx.x, blockDim.x, spec_nat ? spec_nat + b * per : nullptr);
 }
 // grid.x = 8-padded column tiles x channels.  The channels of one tile read the same conv lines: consecutive block ids go round the 8 XCDs,
 // so the id is unpacked as (xcd, channel, tile group) -- the n_channels blocks of a tile follow each other on ONE XCD and share its L2.
-template <class T>
+template <class T, bool GEN>
 __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2))) void pme_solve_inv_cols_kernel(const mifft::Cx<T>* __restrict__ conv_spec, mifft::Cx<T>* __restrict__ conv, mifft::Geom g,
                                                                 mifft::Tables<T> tb, const T* __restrict__ recip, int n_channels, int col_blocks) {
   extern __shared__ __align__(16) unsigned char solve_smem[];
@@ -1039,17 +1040,17 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2))) void p
   const int ch = i % n_channels, tile = (i / n_channels) * 8 + xcd;
   if (tile >= col_blocks) return;
   const size_t per = (size_t)g.nx * g.ny * g.P;
-  mifft::inv_cols_body<T>(conv_spec + b * per, conv + ((size_t)b * n_channels + ch) * per, (mifft::Cx<T>*)solve_smem, g, tb, recip + 9 * b, ch,
+  mifft::inv_cols_body<T, GEN>(conv_spec + b * per, conv + ((size_t)b * n_channels + ch) * per, (mifft::Cx<T>*)solve_smem, g, tb, recip + 9 * b, ch,
                           tile * MI_SOLVE_COLS, threadIdx.x, blockDim.x);
 }
 // persistent: one block per CU walks its planes, so that the stores of one plane are still draining while the loads of the next are issued
 // (with one 133 KB plane per CU in LDS nothing else overlaps the two)
-template <class T>
+template <class T, bool GEN>
 __global__ __launch_bounds__(1024) void pme_solve_inv_kernel(const mifft::Cx<T>* __restrict__ conv, T* __restrict__ real, mifft::Geom g, mifft::Tables<T> tb,
                                                              int n_planes) {
   extern __shared__ __align__(16) unsigned char solve_smem[];
   for (size_t plane = blockIdx.x; plane < (size_t)n_planes; plane += gridDim.x) {  // (system, channel, x)
-    mifft::inv_plane_body<T>(conv + plane * g.ny * g.P, real + plane * g.ny * g.nz, (mifft::Cx<T>*)solve_smem, g, tb, threadIdx.x, blockDim.x);
+    mifft::inv_plane_body<T, GEN>(conv + plane * g.ny * g.P, real + plane * g.ny * g.nz, (mifft::Cx<T>*)solve_smem, g, tb, threadIdx.x, blockDim.x);
     __syncthreads();
   }
 }
@@ -1079,20 +1080,20 @@ static int solve_plane_threads(const mifft::Geom& g) {
   const long long items = (long long)g.ny * g.M / 8;  // radix-8 butterflies of one row stage
   return items >= 1024 ? 1024 : items >= 512 ? 512 : 256;
 }
-template <class T>
-static int solve_launch(const void* mesh, const void* recip_cell, const void* alpha, const void* volume, const mifft::Geom& g, int expo, int nch,
+template <class T, bool GEN>
+static int solve_launch_as(const void* mesh, const void* recip_cell, const void* alpha, const void* volume, const mifft::Geom& g, int expo, int nch,
                         void* spec, void* conv, void* tab, void* real_out, void* spec_nat, int pt, int col_blocks, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   const size_t pl = mifft::plane_lds_bytes<T>(g), fl = mifft::fwd_cols_lds_bytes<T>(g), il = mifft::inv_cols_lds_bytes<T>(g);
   // more than 64 KB of dynamic LDS has to be asked for once per kernel AND device (setting it again is harmless: a race between two
   // threads costs a repeated call, never a launch without the opt-in)
-  static std::atomic<bool> raised_on[MI_SOLVE_MAX_DEVICES];
+  static std::atomic<bool> raised_on[MI_SOLVE_MAX_DEVICES];  // (one per instantiation of this function)
   const int dev_ix = solve_device();
   if (dev_ix < 0 || !raised_on[dev_ix].load(std::memory_order_acquire)) {
-    MI_HIP_CHECK(hipFuncSetAttribute((const void*)pme_solve_fwd_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, MI_LDS_MAX));
-    MI_HIP_CHECK(hipFuncSetAttribute((const void*)pme_solve_fwd_cols_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, MI_LDS_MAX));
-    MI_HIP_CHECK(hipFuncSetAttribute((const void*)pme_solve_inv_cols_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, MI_LDS_MAX));
-    MI_HIP_CHECK(hipFuncSetAttribute((const void*)pme_solve_inv_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, MI_LDS_MAX));
+    MI_HIP_CHECK(hipFuncSetAttribute((const void*)pme_solve_fwd_kernel<T, GEN>, hipFuncAttributeMaxDynamicSharedMemorySize, MI_LDS_MAX));
+    MI_HIP_CHECK(hipFuncSetAttribute((const void*)pme_solve_fwd_cols_kernel<T, GEN>, hipFuncAttributeMaxDynamicSharedMemorySize, MI_LDS_MAX));
+    MI_HIP_CHECK(hipFuncSetAttribute((const void*)pme_solve_inv_cols_kernel<T, GEN>, hipFuncAttributeMaxDynamicSharedMemorySize, MI_LDS_MAX));
+    MI_HIP_CHECK(hipFuncSetAttribute((const void*)pme_solve_inv_kernel<T, GEN>, hipFuncAttributeMaxDynamicSharedMemorySize, MI_LDS_MAX));
     if (dev_ix >= 0) raised_on[dev_ix].store(true, std::memory_order_release);
   }
   // unit roots / sinc / Miller index per FFT slot: a few KB, recomputed by one small launch per call into the caller's scratch -- the
@@ -1100,21 +1101,28 @@ static int solve_launch(const void* mesh, const void* recip_cell, const void* al
   pme_solve_tables_kernel<T><<<1, 256, 0, st>>>(tab, g);
   const mifft::Tables<T> tb = mifft::tables_at<T>(tab, g);
   mi_timing_begin("pme_solve_fwd", stream);
-  pme_solve_fwd_kernel<T><<<g.B * g.nx, pt, pl, st>>>((const T*)mesh, (mifft::Cx<T>*)spec, g, tb);
+  pme_solve_fwd_kernel<T, GEN><<<g.B * g.nx, pt, pl, st>>>((const T*)mesh, (mifft::Cx<T>*)spec, g, tb);
   mi_timing_end(stream);
   mi_timing_begin("pme_solve_cols", stream);
-  pme_solve_fwd_cols_kernel<T><<<dim3(col_blocks, g.B), 128, fl, st>>>((mifft::Cx<T>*)spec, g, tb, (const T*)recip_cell, (const T*)alpha, (const T*)volume, expo,
+  pme_solve_fwd_cols_kernel<T, GEN><<<dim3(col_blocks, g.B), 128, fl, st>>>((mifft::Cx<T>*)spec, g, tb, (const T*)recip_cell, (const T*)alpha, (const T*)volume, expo,
                                                                       (mifft::Cx<T>*)spec_nat);
-  pme_solve_inv_cols_kernel<T><<<dim3((col_blocks + 7) / 8 * 8 * nch, g.B), 128, il, st>>>((const mifft::Cx<T>*)spec, (mifft::Cx<T>*)conv, g, tb,
+  pme_solve_inv_cols_kernel<T, GEN><<<dim3((col_blocks + 7) / 8 * 8 * nch, g.B), 128, il, st>>>((const mifft::Cx<T>*)spec, (mifft::Cx<T>*)conv, g, tb,
                                                                                           (const T*)recip_cell, nch, col_blocks);
   mi_timing_end(stream);
   mi_timing_begin("pme_solve_inv", stream);
   const int n_planes = g.B * nch * g.nx;
   // persistent only where one plane fills the CU's LDS; small planes run several blocks per CU and overlap by themselves
   const int inv_grid = (2 * pl <= MI_LDS_MAX || n_planes < solve_cus()) ? n_planes : solve_cus();
-  pme_solve_inv_kernel<T><<<inv_grid, pt, pl, st>>>((const mifft::Cx<T>*)conv, (T*)real_out, g, tb, n_planes);
+  pme_solve_inv_kernel<T, GEN><<<inv_grid, pt, pl, st>>>((const mifft::Cx<T>*)conv, (T*)real_out, g, tb, n_planes);
   mi_timing_end(stream);
   return MI_OK;
+}
+template <class T>
+static int solve_launch(const void* mesh, const void* recip_cell, const void* alpha, const void* volume, const mifft::Geom& g, int expo, int nch,
+                        void* spec, void* conv, void* tab, void* real_out, void* spec_nat, int pt, int col_blocks, void* stream) {
+  // power-of-two meshes run the kernels compiled without the mixed-radix paths (the code of rounds 4 - 5); everything else the general ones
+  if (g.p2) return solve_launch_as<T, false>(mesh, recip_cell, alpha, volume, g, expo, nch, spec, conv, tab, real_out, spec_nat, pt, col_blocks, stream);
+  return solve_launch_as<T, true>(mesh, recip_cell, alpha, volume, g, expo, nch, spec, conv, tab, real_out, spec_nat, pt, col_blocks, stream);
 }
 }  // namespace
 

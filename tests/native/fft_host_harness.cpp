@@ -29,8 +29,8 @@ int h_line(double* data /*[n][2]*/, int n, int max_lr, int inverse) {
   for (int si = 0; si < p.nst; ++si) {
     const int s = inverse ? p.nst - 1 - si : si;
     for (int j = 0; j < n / p.radix[s]; ++j) {
-      if (inverse) butterfly_r<+1, 4>(p, s, W.data(), n, j, [=](int q) { return d[q]; }, [=](int q, Cx<double> v) { d[q] = v; });
-      else butterfly_r<-1, 4>(p, s, W.data(), n, j, [=](int q) { return d[q]; }, [=](int q, Cx<double> v) { d[q] = v; });
+      if (inverse) butterfly_r<+1, 4>(p, s, W.data(), 1, j, [=](int q) { return d[q]; }, [=](int q, Cx<double> v) { d[q] = v; });
+      else butterfly_r<-1, 4>(p, s, W.data(), 1, j, [=](int q) { return d[q]; }, [=](int q, Cx<double> v) { d[q] = v; });
     }
   }
   return 0;
