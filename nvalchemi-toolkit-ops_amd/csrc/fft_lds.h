@@ -583,14 +583,16 @@ template <class T> MI_HD size_t fwd_cols_lds_bytes(const Geom& g) {
 }
 // LDS of B2: tile + unit roots + KX[nx] + KC[8] of the block's channel
 template <class T> MI_HD size_t inv_cols_lds_bytes(const Geom& g) {
-  return ((size_t)g.nx * MI_SOLVE_COLS + g.nx) * sizeof(Cx<T>) + ((size_t)g.nx + MI_SOLVE_COLS) * sizeof(T);
+  return ((size_t)g.nx * MI_SOLVE_COLS + g.nx) * sizeof(Cx<T>) + ((size_t)g.nx + MI_SOLVE_COLS) * sizeof(T) + ((size_t)g.nx + MI_SOLVE_COLS) * sizeof(int);
 }
 // spec: [nx][ny*P] complex of system b (slot order in y, z), transformed in place into conv = (FFT_x spec / sf2) * G in slot order along x
 // (pme.py:1418-1419, pme_kernels.py:194-225); recip: 2 pi cell^-1 of the system (row-major 3x3, k_d = sum_e m_e recip[d][e],
 // k_vectors.py:270-282); sf_expo: exponent of the B-spline modulus (decode_order().sf_exponent)
 // spec_nat (NULL or [nx][ny][P] of system b): the UNFACTORED spectrum in natural frequency order -- numpy.fft.rfftn(mesh) -- for a caller that
 // needs the charge spectrum itself (the backward of the autograd node); 16-byte scattered stores, one per element
-template <class T, bool GEN = true>
+// PLAIN (round 6): a transform on its own (mi_fft_lds_r2c): no k-space factor, nothing stored back in slot order -- spec_nat is the output,
+// recip / alpha / volume are not read
+template <class T, bool GEN = true, bool PLAIN = false>
 MI_HD void fwd_cols_body(Cx<T>* spec, Cx<T>* lds, const Geom& g, const Tables<T>& tb, const T* recip, T alpha, T volume, int sf_expo, int col0, int tid,
                          int nth, Cx<T>* spec_nat = nullptr) {
   const int COLS = MI_SOLVE_COLS, LGC = MI_SOLVE_LGCOLS;
@@ -607,21 +609,25 @@ MI_HD void fwd_cols_body(Cx<T>* spec, Cx<T>* lds, const Geom& g, const Tables<T>
   for (int t = tid; t < nx; t += nth) {
     NATX[t] = slot_freq(g.px, t);
     Wx[t] = tb.Wx[t];
-    SX[t] = tb.sx[t];
-    const T m = tb.mx[t];
-    KX[t] = m * recip[0]; KX[nx + t] = m * recip[3]; KX[2 * nx + t] = m * recip[6];
+    if (!PLAIN) {
+      SX[t] = tb.sx[t];
+      const T m = tb.mx[t];
+      KX[t] = m * recip[0]; KX[nx + t] = m * recip[3]; KX[2 * nx + t] = m * recip[6];
+    }
   }
   for (int c = tid; c < COLS; c += nth) {
     const int col = col0 + c < ncol ? col0 + c : ncol - 1;
     const int ys = (int)fdiv(g.divP, (unsigned)col), zs = col - ys * g.P;
-    const T my = tb.my[ys], mz = tb.mz[zs];
-    for (int d = 0; d < 3; ++d) KC[d * COLS + c] = my * recip[3 * d + 1] + mz * recip[3 * d + 2];
-    SC[c] = tb.sy[ys] * tb.sz[zs];
-    OC[c] = (my == T(0) && mz == T(0)) ? T(1) : T(0);
+    if (!PLAIN) {
+      const T my = tb.my[ys], mz = tb.mz[zs];
+      for (int d = 0; d < 3; ++d) KC[d * COLS + c] = my * recip[3 * d + 1] + mz * recip[3 * d + 2];
+      SC[c] = tb.sy[ys] * tb.sz[zs];
+      OC[c] = (my == T(0) && mz == T(0)) ? T(1) : T(0);
+    }
     NATC[c] = slot_freq(g.py, ys) * g.P + (zs < g.M ? slot_freq(g.pz, zs) : g.M);
   }
   MI_FFT_SYNC();
-  const T inv4a2 = T(1) / (T(4) * alpha * alpha);
+  const T inv4a2 = PLAIN ? T(0) : T(1) / (T(4) * alpha * alpha);
   auto factor_of = [=](int xs, int c) {
     const T k0 = KX[xs] + KC[c], k1 = KX[nx + xs] + KC[COLS + c], k2v = KX[2 * nx + xs] + KC[2 * COLS + c];
     T k2 = k0 * k0 + k1 * k1 + k2v * k2v;
@@ -651,16 +657,20 @@ MI_HD void fwd_cols_body(Cx<T>* spec, Cx<T>* lds, const Geom& g, const Tables<T>
   for (int e = tid; e < nx * COLS; e += nth) {
     const int xs = e >> LGC, c = e & (COLS - 1);
     if (col0 + c < ncol) {
-      const T f = factor_of(xs, c);
       const Cx<T> v = S[e];
-      spec[(size_t)xs * ncol + col0 + c] = Cx<T>{v.re * f, v.im * f};
-      if (spec_nat) spec_nat[(size_t)NATX[xs] * ncol + NATC[c]] = v;
+      if (!PLAIN) {
+        const T f = factor_of(xs, c);
+        spec[(size_t)xs * ncol + col0 + c] = Cx<T>{v.re * f, v.im * f};
+      }
+      if (PLAIN || spec_nat) spec_nat[(size_t)NATX[xs] * ncol + NATC[c]] = v;
     }
   }
 }
 // conv: [nx][ny*P] complex of system b in slot order along x, y, z; out: [nx][ny*P] of (system b, channel ch), natural order along x again:
 // the inverse x transform of conv (ch = 0, the potential) or of (-i k_d) conv (ch = 1 + d, the field components; pme.py:1455-1457)
-template <class T, bool GEN = true>
+// PLAIN (round 6): a transform on its own (mi_fft_lds_c2r): `conv` is a half spectrum in NATURAL frequency order (numpy.fft.rfftn layout,
+// [nx][ny][P]) -- the loads of the first stage look the slots' frequencies up -- ch = 0, recip is not read
+template <class T, bool GEN = true, bool PLAIN = false>
 MI_HD void inv_cols_body(const Cx<T>* conv, Cx<T>* out, Cx<T>* lds, const Geom& g, const Tables<T>& tb, const T* recip, int ch, int col0, int tid, int nth) {
   const int COLS = MI_SOLVE_COLS, LGC = MI_SOLVE_LGCOLS;
   const int ncol = g.ny * g.P, nx = g.nx;
@@ -668,19 +678,23 @@ MI_HD void inv_cols_body(const Cx<T>* conv, Cx<T>* out, Cx<T>* lds, const Geom& 
   Cx<T>* Wx = S + nx * COLS;
   T* KX = (T*)(Wx + nx);  // [nx] of this channel's d
   T* KC = KX + nx;        // [COLS]
+  int* NATC = (int*)(KC + COLS);  // PLAIN: [COLS] natural-order offset f_y * P + f_z of the column
+  int* NATX = NATC + COLS;        // PLAIN: [nx]   natural-order index f_x of the slot
   const int d = ch > 0 ? ch - 1 : 0;
   for (int t = tid; t < nx; t += nth) {
     Wx[t] = tb.Wx[t];
-    KX[t] = tb.mx[t] * recip[3 * d];
+    if (PLAIN) NATX[t] = slot_freq(g.px, t);
+    else KX[t] = tb.mx[t] * recip[3 * d];
   }
   for (int c = tid; c < COLS; c += nth) {
     const int col = col0 + c < ncol ? col0 + c : ncol - 1;
     const int ys = (int)fdiv(g.divP, (unsigned)col), zs = col - ys * g.P;
-    KC[c] = tb.my[ys] * recip[3 * d + 1] + tb.mz[zs] * recip[3 * d + 2];
+    if (PLAIN) NATC[c] = slot_freq(g.py, ys) * g.P + (zs < g.M ? slot_freq(g.pz, zs) : g.M);
+    else KC[c] = tb.my[ys] * recip[3 * d + 1] + tb.mz[zs] * recip[3 * d + 2];
   }
   MI_FFT_SYNC();
   const Plan& px = g.px;
-  const bool field = ch > 0;
+  const bool field = !PLAIN && ch > 0;
   for (int s = px.nst - 1; s >= 0; --s) {
     const int items = COLS * px.per[s];
     const bool first = s == px.nst - 1, last = s == 0;
@@ -689,6 +703,7 @@ MI_HD void inv_cols_body(const Cx<T>* conv, Cx<T>* out, Cx<T>* lds, const Geom& 
       return [=](int p) {
         if (!first) return S[(p << LGC) + c];
         if (!live) return Cx<T>{T(0), T(0)};
+        if (PLAIN) return conv[(size_t)NATX[p] * ncol + NATC[c]];
         const Cx<T> v = src[(size_t)p * ncol];
         if (!field) return v;
         const T kd = KX[p] + KC[c];

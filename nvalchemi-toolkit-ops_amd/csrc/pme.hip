@@ -1019,19 +1019,23 @@ __global__ __launch_bounds__(1024) void pme_solve_fwd_kernel(const T* __restrict
   const size_t plane = blockIdx.x;  // (system, x)
   mifft::fwd_plane_body<T, GEN>(mesh + plane * g.ny * g.nz, spec + plane * g.ny * g.P, (mifft::Cx<T>*)solve_smem, g, tb, threadIdx.x, blockDim.x);
 }
-template <class T, bool GEN>
+template <class T, bool GEN, bool PLAIN = false>
 __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2))) void pme_solve_fwd_cols_kernel(mifft::Cx<T>* __restrict__ spec, mifft::Geom g, mifft::Tables<T> tb, const T* __restrict__ recip,
                                                                 const T* __restrict__ alpha, const T* __restrict__ volume, int sf_expo,
                                                                 mifft::Cx<T>* __restrict__ spec_nat /*NULL or [B][nx][ny][P]*/) {
   extern __shared__ __align__(16) unsigned char solve_smem[];
   const int b = blockIdx.y;
   const size_t per = (size_t)g.nx * g.ny * g.P;
-  mifft::fwd_cols_body<T, GEN>(spec + b * per, (mifft::Cx<T>*)solve_smem, g, tb, recip + 9 * b, alpha[b], volume[b], sf_expo, blockIdx.x * MI_SOLVE_COLS,
-                          threadIdx.x, blockDim.x, spec_nat ? spec_nat + b * per : nullptr);
+  if (PLAIN)  // a transform on its own (mi_fft_lds_r2c): recip / alpha / volume are null and never read
+    mifft::fwd_cols_body<T, GEN, true>(spec + b * per, (mifft::Cx<T>*)solve_smem, g, tb, nullptr, T(1), T(1), 1, blockIdx.x * MI_SOLVE_COLS, threadIdx.x, blockDim.x,
+                                       spec_nat + b * per);
+  else
+    mifft::fwd_cols_body<T, GEN>(spec + b * per, (mifft::Cx<T>*)solve_smem, g, tb, recip + 9 * b, alpha[b], volume[b], sf_expo, blockIdx.x * MI_SOLVE_COLS,
+                                 threadIdx.x, blockDim.x, spec_nat ? spec_nat + b * per : nullptr);
 }
 // grid.x = 8-padded column tiles x channels.  The channels of one tile read the same conv lines: consecutive block ids go round the 8 XCDs,
 // so the id is unpacked as (xcd, channel, tile group) -- the n_channels blocks of a tile follow each other on ONE XCD and share its L2.
-template <class T, bool GEN>
+template <class T, bool GEN, bool PLAIN = false>
 __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2))) void pme_solve_inv_cols_kernel(const mifft::Cx<T>* __restrict__ conv_spec, mifft::Cx<T>* __restrict__ conv, mifft::Geom g,
                                                                 mifft::Tables<T> tb, const T* __restrict__ recip, int n_channels, int col_blocks) {
   extern __shared__ __align__(16) unsigned char solve_smem[];
@@ -1040,8 +1044,12 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2))) void p
   const int ch = i % n_channels, tile = (i / n_channels) * 8 + xcd;
   if (tile >= col_blocks) return;
   const size_t per = (size_t)g.nx * g.ny * g.P;
-  mifft::inv_cols_body<T, GEN>(conv_spec + b * per, conv + ((size_t)b * n_channels + ch) * per, (mifft::Cx<T>*)solve_smem, g, tb, recip + 9 * b, ch,
-                          tile * MI_SOLVE_COLS, threadIdx.x, blockDim.x);
+  if (PLAIN)  // a transform on its own (mi_fft_lds_c2r): conv_spec is a half spectrum in natural order, one channel, recip is null
+    mifft::inv_cols_body<T, GEN, true>(conv_spec + b * per, conv + (size_t)b * per, (mifft::Cx<T>*)solve_smem, g, tb, nullptr, 0, tile * MI_SOLVE_COLS, threadIdx.x,
+                                       blockDim.x);
+  else
+    mifft::inv_cols_body<T, GEN>(conv_spec + b * per, conv + ((size_t)b * n_channels + ch) * per, (mifft::Cx<T>*)solve_smem, g, tb, recip + 9 * b, ch,
+                                 tile * MI_SOLVE_COLS, threadIdx.x, blockDim.x);
 }
 // persistent: one block per CU walks its planes, so that the stores of one plane are still draining while the loads of the next are issued
 // (with one 133 KB plane per CU in LDS nothing else overlaps the two)
@@ -1115,6 +1123,39 @@ static int solve_launch_as(const void* mesh, const void* recip_cell, const void*
   const int inv_grid = (2 * pl <= MI_LDS_MAX || n_planes < solve_cus()) ? n_planes : solve_cus();
   pme_solve_inv_kernel<T, GEN><<<inv_grid, pt, pl, st>>>((const mifft::Cx<T>*)conv, (T*)real_out, g, tb, n_planes);
   mi_timing_end(stream);
+  return MI_OK;
+}
+// The same kernels as transforms on their own (round 6): real [B][nx][ny][nz] <-> half spectrum [B][nx][ny][nz/2+1] in natural order, unscaled
+// both ways -- the layout and scaling of mi_fft_plan_exec, so that the autograd node's backward (and every other caller of a plan) runs
+// without hipFFT wherever the mesh solve itself is supported.  `work` = one half spectrum in slot order, `tab` = the per-shape tables.
+template <class T, bool GEN>
+static int fft_lds_launch_as(bool inverse, const void* in, void* out, const mifft::Geom& g, void* work, void* tab, int pt, int col_blocks, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  const size_t pl = mifft::plane_lds_bytes<T>(g), fl = mifft::fwd_cols_lds_bytes<T>(g), il = mifft::inv_cols_lds_bytes<T>(g);
+  static std::atomic<bool> raised_on[MI_SOLVE_MAX_DEVICES];
+  const int dev_ix = solve_device();
+  if (dev_ix < 0 || !raised_on[dev_ix].load(std::memory_order_acquire)) {
+    MI_HIP_CHECK(hipFuncSetAttribute((const void*)pme_solve_fwd_kernel<T, GEN>, hipFuncAttributeMaxDynamicSharedMemorySize, MI_LDS_MAX));
+    MI_HIP_CHECK(hipFuncSetAttribute((const void*)pme_solve_fwd_cols_kernel<T, GEN, true>, hipFuncAttributeMaxDynamicSharedMemorySize, MI_LDS_MAX));
+    MI_HIP_CHECK(hipFuncSetAttribute((const void*)pme_solve_inv_cols_kernel<T, GEN, true>, hipFuncAttributeMaxDynamicSharedMemorySize, MI_LDS_MAX));
+    MI_HIP_CHECK(hipFuncSetAttribute((const void*)pme_solve_inv_kernel<T, GEN>, hipFuncAttributeMaxDynamicSharedMemorySize, MI_LDS_MAX));
+    if (dev_ix >= 0) raised_on[dev_ix].store(true, std::memory_order_release);
+  }
+  pme_solve_tables_kernel<T><<<1, 256, 0, st>>>(tab, g);
+  const mifft::Tables<T> tb = mifft::tables_at<T>(tab, g);
+  if (!inverse) {
+    mi_timing_begin("fft_lds_r2c", stream);
+    pme_solve_fwd_kernel<T, GEN><<<g.B * g.nx, pt, pl, st>>>((const T*)in, (mifft::Cx<T>*)work, g, tb);
+    pme_solve_fwd_cols_kernel<T, GEN, true><<<dim3(col_blocks, g.B), 128, fl, st>>>((mifft::Cx<T>*)work, g, tb, nullptr, nullptr, nullptr, 1, (mifft::Cx<T>*)out);
+    mi_timing_end(stream);
+  } else {
+    mi_timing_begin("fft_lds_c2r", stream);
+    pme_solve_inv_cols_kernel<T, GEN, true><<<dim3((col_blocks + 7) / 8 * 8, g.B), 128, il, st>>>((const mifft::Cx<T>*)in, (mifft::Cx<T>*)work, g, tb, nullptr, 1, col_blocks);
+    const int n_planes = g.B * g.nx;
+    const int inv_grid = (2 * pl <= MI_LDS_MAX || n_planes < solve_cus()) ? n_planes : solve_cus();
+    pme_solve_inv_kernel<T, GEN><<<inv_grid, pt, pl, st>>>((const mifft::Cx<T>*)work, (T*)out, g, tb, n_planes);
+    mi_timing_end(stream);
+  }
   return MI_OK;
 }
 template <class T>
@@ -1420,6 +1461,30 @@ int mi_pme_solve_supported(int n_systems, int nx, int ny, int nz, int dtype) {
  * path that does not depend on rocFFT: every mesh the solve supports takes it. */
 int mi_pme_solve_preferred(int n_systems, int nx, int ny, int nz, int dtype) {
   return mi_pme_solve_supported(n_systems, nx, ny, nz, dtype);
+}
+size_t mi_fft_lds_scratch_bytes(int batch, int nx, int ny, int nz, int dtype) {
+  if (batch < 1 || nx < 1 || ny < 1 || nz < 2 || (dtype != MI_F32 && dtype != MI_F64) || !mifft::geom_ok(nx, ny, nz)) return 0;
+  const size_t per = (size_t)batch * nx * ny * (nz / 2 + 1) * (dtype == MI_F32 ? 8 : 16);
+  const mifft::Geom g = mifft::make_geom(batch, nx, ny, nz);
+  return mi_align(per) + mi_align(dtype == MI_F32 ? mifft::tables_bytes<float>(g) : mifft::tables_bytes<double>(g));
+}
+int mi_fft_lds(const void* in, void* out, int batch, int nx, int ny, int nz, int dtype, int inverse, void* scratch, size_t scratch_bytes, void* stream) {
+  MI_REQUIRE(dtype == MI_F32 || dtype == MI_F64, "dtype");
+  MI_REQUIRE(in && out && scratch, "null pointer");
+  MI_REQUIRE(mi_pme_solve_supported(batch, nx, ny, nz, dtype), "mesh not supported by the in-LDS transforms (see mi_pme_solve_supported)");
+  MI_REQUIRE(scratch_bytes >= mi_fft_lds_scratch_bytes(batch, nx, ny, nz, dtype), "scratch too small (mi_fft_lds_scratch_bytes)");
+  const mifft::Geom g = mifft::make_geom(batch, nx, ny, nz);
+  const size_t per = (size_t)batch * nx * ny * g.P * (dtype == MI_F32 ? 8 : 16);
+  void* work = scratch;
+  void* tab = (char*)scratch + mi_align(per);
+  const int pt = solve_plane_threads(g);
+  const int col_blocks = (g.ny * g.P + MI_SOLVE_COLS - 1) / MI_SOLVE_COLS;
+  int rc = MI_OK;
+  MI_DISPATCH_T(dtype, (rc = g.p2 ? fft_lds_launch_as<T_, false>(inverse != 0, in, out, g, work, tab, pt, col_blocks, stream)
+                                  : fft_lds_launch_as<T_, true>(inverse != 0, in, out, g, work, tab, pt, col_blocks, stream)));
+  if (rc != MI_OK) return rc;
+  MI_LAUNCH_CHECK();
+  return MI_OK;
 }
 size_t mi_pme_solve_scratch_bytes(int n_systems, int nx, int ny, int nz, int n_channels, int dtype) {
   const size_t per = (size_t)n_systems * nx * ny * (nz / 2 + 1) * (dtype == MI_F32 ? 8 : 16);

@@ -51,6 +51,8 @@ def lib() -> ctypes.CDLL:
         L.mi_spline_spread_workspace_bytes.restype = ctypes.c_size_t
         L.mi_pme_solve_scratch_bytes.restype = ctypes.c_size_t
         L.mi_pme_solve_scratch_bytes.argtypes = [ctypes.c_int] * 6
+        L.mi_fft_lds_scratch_bytes.restype = ctypes.c_size_t
+        L.mi_fft_lds_scratch_bytes.argtypes = [ctypes.c_int] * 5
         L.mi_spline_spread_workspace_bytes.argtypes = [ctypes.c_int] * 5
         L.mi_spline_spread_workspace_bytes_for.restype = ctypes.c_size_t
         L.mi_spline_spread_workspace_bytes_for.argtypes = [ctypes.c_int] * 7

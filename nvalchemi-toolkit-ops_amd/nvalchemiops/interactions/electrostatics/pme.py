@@ -248,6 +248,32 @@ class _DenseDft:
         pass
 
 
+class _LdsFft:
+    """The mesh solve's in-LDS kernels as a transform on their own (`mi_fft_lds`, round 6), with the (src, dst) call of a plan: real
+    [batch, nx, ny, nz] <-> half spectrum in natural order, unscaled both ways.  No plan object, no library state, no rocFFT: the scratch (one
+    half spectrum + the per-shape tables) is a tensor of the call, so it is capturable and there is nothing to evict or self-test.  Serves every
+    `_fft_plan` request whose mesh the solve supports (axis lengths 2^a 3^b 5^c, one complex plane within LDS): the backward of the autograd
+    node, the composed differentiable path, caller-supplied k arrays."""
+
+    pinned = True  # (nothing to destroy: the cache may hold any number of these)
+
+    def __init__(self, dims, batch, code, inverse):
+        self.dims, self.batch, self.code, self.inverse = tuple(int(v) for v in dims), int(batch), int(code), bool(inverse)
+        nx, ny, nz = self.dims
+        self.nbytes = int(C.lib().mi_fft_lds_scratch_bytes(self.batch, nx, ny, nz, self.code))
+
+    def __call__(self, src: torch.Tensor, dst: torch.Tensor) -> None:
+        import ctypes
+
+        nx, ny, nz = self.dims
+        scratch = torch.empty(self.nbytes, dtype=torch.uint8, device=src.device)
+        C.check(C.lib().mi_fft_lds(C.ptr(src), C.ptr(dst), self.batch, nx, ny, nz, self.code, int(self.inverse), C.ptr(scratch),
+                                   ctypes.c_size_t(self.nbytes), C.stream_of(src)), "mi_fft_lds")
+
+    def destroy(self) -> None:
+        pass
+
+
 import collections  # noqa: E402
 
 # LRU of live plans, keyed by (device, mesh, batch, dtype, direction, stream): bounded, so an MD run over varying batch sizes or meshes does
@@ -265,6 +291,9 @@ _FFT_FALLBACKS: list = []  # (key, detail) of every plan replaced by the dense D
 _OWN_FFT = os.environ.get("NVALCHEMIOPS_PME_FFT", "own") != "torch"
 _FORCE_DFT = os.environ.get("NVALCHEMIOPS_PME_FFT", "own") == "dft"
 _FFT_SELFTEST = os.environ.get("NVALCHEMIOPS_FFT_SELFTEST", "1") != "0"
+# NVALCHEMIOPS_FFT_LDS=0: plan requests go to hipFFT even where the in-LDS transforms (`mi_fft_lds`) support the mesh (A/B runs, and the tests
+# that exercise the guarded hipFFT plans on small meshes)
+_FFT_LDS = os.environ.get("NVALCHEMIOPS_FFT_LDS", "1") != "0"
 # NVALCHEMIOPS_PME_FUSED_AUTOGRAD=0: energies under autograd through the op-by-op composition as in round 3 (A/B and cross-check of the adjoint)
 _FUSED_AUTOGRAD = os.environ.get("NVALCHEMIOPS_PME_FUSED_AUTOGRAD", "1") != "0"
 # "auto": the library's measured policy (mi_pme_solve_preferred); True / NVALCHEMIOPS_PME_MESH_SOLVE=1: the fused mesh solve wherever it is
@@ -305,6 +334,11 @@ def _fft_plan(device: torch.device, dims, batch: int, code: int, inverse: bool):
     dense DFT (`mi_dft3d`) from then on (one warning); a wrong plan is never executed on user data."""
     import warnings
 
+    # the in-LDS transforms first: stateless, so nothing is cached and a captured step needs no warm-up for them
+    # (`_MESH_SOLVE = False` -- "always hipFFT plans", the A/B setting -- keeps its meaning: no in-LDS kernels anywhere)
+    if (_FFT_LDS and _MESH_SOLVE is not False and _OWN_FFT and not _FORCE_DFT and device.type == "cuda"
+            and C.lib().mi_pme_solve_supported(int(batch), int(dims[0]), int(dims[1]), int(dims[2]), int(code))):
+        return _LdsFft(dims, batch, code, inverse)
     with _FFT_LOCK:
         stream = torch.cuda.current_stream(device).cuda_stream if device.type == "cuda" else 0
         key = (device.index, tuple(int(v) for v in dims), int(batch), int(code), bool(inverse), int(stream))

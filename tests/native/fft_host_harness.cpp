@@ -49,6 +49,49 @@ int h_forward(const double* mesh, double* spec, int B, int nx, int ny, int nz) {
   return 0;
 }
 
+// the transforms on their own (mi_fft_lds): R2C = kernel A + the PLAIN forward column kernel (natural-order half spectrum out);
+// C2R = the PLAIN inverse column kernel (natural-order half spectrum in) + kernel C.  Unscaled both ways.
+int h_r2c(const double* mesh, double* spec_nat /*[B][nx][ny][P][2]*/, int B, int nx, int ny, int nz) {
+  if (!geom_ok(nx, ny, nz)) return -1;
+  const Geom g = make_geom(B, nx, ny, nz);
+  std::vector<char> tab(tables_bytes<double>(g));
+  tables_body<double>(tab.data(), g, 0, 1);
+  const Tables<double> tb = tables_at<double>(tab.data(), g);
+  const size_t ncol = (size_t)ny * g.P;
+  std::vector<Cx<double>> work((size_t)B * nx * ncol);
+  size_t need = plane_lds_bytes<double>(g);
+  if (fwd_cols_lds_bytes<double>(g) > need) need = fwd_cols_lds_bytes<double>(g);
+  std::vector<char> lds(need);
+  for (int bx = 0; bx < B * nx; ++bx)
+    fwd_plane_body<double>(mesh + (size_t)bx * ny * nz, work.data() + (size_t)bx * ncol, (Cx<double>*)lds.data(), g, tb, 0, 1);
+  const int blocks = (int)((ncol + MI_SOLVE_COLS - 1) / MI_SOLVE_COLS);
+  for (int b = 0; b < B; ++b)
+    for (int blk = 0; blk < blocks; ++blk)
+      fwd_cols_body<double, true, true>(work.data() + (size_t)b * nx * ncol, (Cx<double>*)lds.data(), g, tb, nullptr, 1.0, 1.0, 1, blk * MI_SOLVE_COLS, 0, 1,
+                                        (Cx<double>*)spec_nat + (size_t)b * nx * ncol);
+  return 0;
+}
+int h_c2r(const double* spec_nat, double* mesh, int B, int nx, int ny, int nz) {
+  if (!geom_ok(nx, ny, nz)) return -1;
+  const Geom g = make_geom(B, nx, ny, nz);
+  std::vector<char> tab(tables_bytes<double>(g));
+  tables_body<double>(tab.data(), g, 0, 1);
+  const Tables<double> tb = tables_at<double>(tab.data(), g);
+  const size_t ncol = (size_t)ny * g.P;
+  std::vector<Cx<double>> work((size_t)B * nx * ncol);
+  size_t need = plane_lds_bytes<double>(g);
+  if (inv_cols_lds_bytes<double>(g) > need) need = inv_cols_lds_bytes<double>(g);
+  std::vector<char> lds(need);
+  const int blocks = (int)((ncol + MI_SOLVE_COLS - 1) / MI_SOLVE_COLS);
+  for (int b = 0; b < B; ++b)
+    for (int blk = 0; blk < blocks; ++blk)
+      inv_cols_body<double, true, true>((const Cx<double>*)spec_nat + (size_t)b * nx * ncol, work.data() + (size_t)b * nx * ncol, (Cx<double>*)lds.data(), g, tb,
+                                        nullptr, 0, blk * MI_SOLVE_COLS, 0, 1);
+  for (int p = 0; p < B * nx; ++p)
+    inv_plane_body<double>(work.data() + (size_t)p * ncol, mesh + (size_t)p * ny * nz, (Cx<double>*)lds.data(), g, tb, 0, 1);
+  return 0;
+}
+
 // kernels A, B1, B2, C: mesh [B][nx][ny][nz] -> real meshes [B][C][nx][ny][nz]  (unnormalised both ways, like hipFFT / the reference's norm='forward' inverse)
 int h_solve(const double* mesh, double* out, int B, int nx, int ny, int nz, const double* recip /*[B][9]*/, const double* alpha, const double* volume,
             int sf_expo, int n_channels, double* spec_nat /*NULL or [B][nx][ny][P][2]: numpy.fft.rfftn(mesh)*/) {

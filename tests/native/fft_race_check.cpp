@@ -64,6 +64,30 @@ template <class R> static std::vector<R> solve(int B, int nx, int ny, int nz, in
         });
   for (int p = 0; p < B * nch * nx; ++p)
     run_block(nth, [&](int tid, int n) { inv_plane_body<R>(conv.data() + (size_t)p * ncol, out.data() + (size_t)p * ny * nz, (Cx<R>*)lds_plane.data(), g, tb, tid, n); });
+  // the PLAIN column bodies (mi_fft_lds: transforms on their own): natural-order spectrum out of the forward one, and back in through the inverse
+  // one; their results join `out`, so the thread-count comparison and the bounds run cover them too
+  std::vector<Cx<R>> nat2((size_t)B * nx * ncol), work((size_t)B * nx * ncol);
+  for (int bx = 0; bx < B * nx; ++bx)
+    run_block(nth, [&](int tid, int n) {
+      fwd_plane_body<R>(mesh.data() + (size_t)bx * ny * nz, spec.data() + (size_t)bx * ncol, (Cx<R>*)lds_plane.data(), g, tb, tid, n);
+    });
+  for (int b = 0; b < B; ++b)
+    for (int blk = 0; blk < blocks; ++blk)
+      run_block(nth, [&](int tid, int n) {
+        fwd_cols_body<R, true, true>(spec.data() + (size_t)b * nx * ncol, (Cx<R>*)lds_fwd_cols.data(), g, tb, nullptr, R(1), R(1), 1, blk * MI_SOLVE_COLS, tid, n,
+                                     nat2.data() + (size_t)b * nx * ncol);
+      });
+  for (int b = 0; b < B; ++b)
+    for (int blk = 0; blk < blocks; ++blk)
+      run_block(nth, [&](int tid, int n) {
+        inv_cols_body<R, true, true>(nat2.data() + (size_t)b * nx * ncol, work.data() + (size_t)b * nx * ncol, (Cx<R>*)lds_inv_cols.data(), g, tb, nullptr, 0,
+                                     blk * MI_SOLVE_COLS, tid, n);
+      });
+  std::vector<R> back((size_t)B * nx * ny * nz);
+  for (int p = 0; p < B * nx; ++p)
+    run_block(nth, [&](int tid, int n) { inv_plane_body<R>(work.data() + (size_t)p * ncol, back.data() + (size_t)p * ny * nz, (Cx<R>*)lds_plane.data(), g, tb, tid, n); });
+  out.insert(out.end(), back.begin(), back.end());
+  for (const auto& v : nat2) { out.push_back(v.re); out.push_back(v.im); }
   return out;
 }
 

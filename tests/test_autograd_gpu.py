@@ -829,3 +829,43 @@ def test_fused_node_through_the_mesh_solve(with_forces, monkeypatch):
         got, want = grads(True, dtype), grads(False, dtype)
         for a, b in zip(got, want):
             assert a.shape == b.shape and (a - b).abs().max().item() <= tol * max(1.0, b.abs().max().item())
+
+
+@pytest.mark.parametrize("dims", [(16, 32, 16), (12, 20, 18), (48, 50, 60)])
+@pytest.mark.parametrize("with_forces", [False, True])
+def test_training_step_without_a_hipfft_plan(dims, with_forces, monkeypatch):
+    """Round 6: the node's backward (two R2C / C2R transforms of the upstream-weight meshes, pme.py:1398 / :1422) runs on the mesh solve's
+    in-LDS kernels (`mi_fft_lds`) wherever the solve itself is supported -- powers of two and the 2-3-5 sizes a `mesh_spacing=` caller gets.
+    Same energies, forces and gradients as the node on guarded hipFFT plans (fp64 1e-9, fp32 2e-4), and a whole forward + backward creates no
+    plan at all."""
+    import collections
+
+    from nvalchemiops.interactions.electrostatics import pme as P
+    from nvalchemiops.interactions.electrostatics import pme_reciprocal_space
+
+    pos, cell, q = _system(70, seed=9)
+    gen = torch.Generator(device=DEV).manual_seed(4)
+    wts = torch.randn(pos.shape[0], dtype=torch.float64, device=DEV, generator=gen)
+    wf = torch.randn(pos.shape[0], 3, dtype=torch.float64, device=DEV, generator=gen)
+
+    def grads(in_lds, dtype):
+        monkeypatch.setattr(P, "_FFT_LDS", in_lds)
+        monkeypatch.setattr(P, "_FFT_PLANS", collections.OrderedDict())
+        p = pos.to(dtype).requires_grad_(True)
+        v = q.to(dtype).requires_grad_(True)
+        c = cell.to(dtype).requires_grad_(True)
+        a = torch.tensor([0.4], dtype=dtype, device=DEV, requires_grad=True)
+        out = pme_reciprocal_space(p, v, c, a, mesh_dimensions=dims, spline_order=4, compute_forces=with_forces)
+        e, f = out if with_forces else (out, None)
+        loss = (e * wts.to(dtype)).sum() + ((f * wf.to(dtype)).sum() if with_forces else 0.0)
+        res = (e.detach(),) + ((f.detach(),) if with_forces else ()) + torch.autograd.grad(loss, (p, v, c, a))
+        n_plans = len(P._FFT_PLANS)
+        for plan in P._FFT_PLANS.values():
+            plan.destroy()
+        return res, n_plans
+
+    for dtype, tol in ((torch.float64, 1e-9), (torch.float32, 2e-4)):
+        (got, plans_lds), (want, plans_hipfft) = grads(True, dtype), grads(False, dtype)
+        assert plans_lds == 0 and plans_hipfft == 2, (plans_lds, plans_hipfft)
+        for a, b in zip(got, want):
+            assert a.shape == b.shape and (a - b).abs().max().item() <= tol * max(1.0, b.abs().max().item()), (dims, dtype, (a - b).abs().max().item())

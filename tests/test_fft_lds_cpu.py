@@ -117,6 +117,34 @@ def test_whole_kspace_step_equals_the_numpy_restatement(H, dims, order, nch):
     assert np.allclose(out, want, rtol=0, atol=1e-11 * scale), np.abs(out - want).max() / scale
 
 
+@pytest.mark.parametrize("dims", [(8, 8, 8), (16, 8, 32), (8, 32, 16), (128, 8, 16), (8, 8, 256), (12, 10, 18), (20, 18, 24), (96, 8, 10), (10, 100, 12), (8, 9, 120),
+                                  (15, 25, 90), (240, 8, 8)])
+def test_transforms_on_their_own_equal_numpy(H, dims):
+    """`mi_fft_lds` (round 6): the plane + column bodies as an unscaled rfftn / irfftn in natural frequency order -- what the backward of the
+    autograd node and every other former hipFFT-plan caller now runs (pme.py:1398, :1422, :1455-1457)."""
+    nx, ny, nz = dims
+    B = 3
+    rng = np.random.default_rng(11 + sum(dims))
+    mesh = np.ascontiguousarray(rng.standard_normal((B, nx, ny, nz)))
+    axes = (-3, -2, -1)
+    nat = np.zeros((B, nx, ny, nz // 2 + 1, 2))
+    assert H.h_r2c(_p(mesh), _p(nat), B, nx, ny, nz) == 0
+    want = np.fft.rfftn(mesh, axes=axes)
+    assert np.allclose(nat[..., 0] + 1j * nat[..., 1], want, rtol=0, atol=1e-11 * nx * ny * nz)
+    sp = np.ascontiguousarray(np.stack([want.real, want.imag], -1))
+    back = np.zeros((B, nx, ny, nz))
+    assert H.h_c2r(_p(sp), _p(back), B, nx, ny, nz) == 0
+    assert np.allclose(back, mesh * float(nx * ny * nz), rtol=0, atol=1e-10 * nx * ny * nz)
+    # ... and of an arbitrary half spectrum (not the transform of a real mesh): the same numbers as numpy's irfftn, which -- after the x and y
+    # transforms -- does not read the imaginary parts of the DC and Nyquist bins along z
+    spec = want + (rng.standard_normal(want.shape) + 1j * rng.standard_normal(want.shape))
+    sp = np.ascontiguousarray(np.stack([spec.real, spec.imag], -1))
+    assert H.h_c2r(_p(sp), _p(back), B, nx, ny, nz) == 0
+    ref = np.fft.irfftn(spec, dims, axes=axes) * float(nx * ny * nz)
+    assert np.allclose(back, ref, rtol=0, atol=1e-10 * nx * ny * nz)
+    assert np.array_equal(sp[..., 0] + 1j * sp[..., 1], spec)  # the input is left alone (hipFFT's multi-dimensional C2R overwrites it)
+
+
 def test_barrier_placement_under_thread_sanitizer(tmp_path):
     """tests/native/fft_race_check.cpp: the same bodies (fp64 and fp32) with 3 and 16 host threads per block, MI_FFT_SYNC() = a pthread barrier, under
     ThreadSanitizer.  Any two threads touching one LDS / global element between two barriers would be a missing __syncthreads on the GPU:

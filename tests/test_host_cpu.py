@@ -386,9 +386,16 @@ def test_mesh_solve_policy():
     f32, f64 = 0, 1
     assert ok(1, 128, 128, 128, f64) == 1 and ok(1, 256, 64, 256, f64) == 1 and ok(1, 128, 256, 128, f32) == 1
     assert ok(1, 128, 256, 128, f64) == 0 and ok(1, 256, 256, 256, f32) == 0        # plane larger than the LDS
-    assert ok(1, 48, 48, 48, f64) == 0 and ok(1, 31, 9, 6, f64) == 0 and ok(1, 4, 8, 8, f64) == 0 and ok(0, 32, 32, 32, f64) == 0
+    # round 6: mixed radix -- every axis length a product of 2, 3 and 5 (nz even): what `mesh_spacing=` callers get
+    assert ok(1, 48, 48, 48, f64) == 1 and ok(1, 96, 100, 120, f64) == 1 and ok(3, 120, 96, 100, f32) == 1
+    assert ok(1, 42, 48, 48, f64) == 0 and ok(1, 48, 48, 45, f64) == 0 and ok(1, 48, 48, 14, f64) == 0  # a factor 7; odd nz; nz / 2 = 7
+    assert ok(1, 31, 9, 6, f64) == 0 and ok(1, 4, 8, 8, f64) == 0 and ok(0, 32, 32, 32, f64) == 0
     assert pref(1, 32, 32, 32, f64) == 1 and pref(128, 32, 32, 32, f64) == 1 and pref(8, 64, 64, 64, f64) == 1 and pref(2, 128, 128, 128, f64) == 1
-    assert pref(1, 48, 48, 48, f64) == 0 and pref(4, 128, 256, 128, f64) == 0  # unsupported meshes keep the (self-tested) plans
+    assert pref(1, 96, 100, 120, f64) == 1
+    assert pref(1, 42, 48, 48, f64) == 0 and pref(4, 128, 256, 128, f64) == 0  # unsupported meshes keep the (self-tested) plans
+    # the transforms on their own (`mi_fft_lds`): one half spectrum of scratch + the tables; 0 for a mesh they do not take
+    assert 128 * 128 * 65 * 16 <= int(L.mi_fft_lds_scratch_bytes(1, 128, 128, 128, f64)) <= 128 * 128 * 65 * 16 + 65536
+    assert int(L.mi_fft_lds_scratch_bytes(1, 42, 48, 48, f64)) == 0
     L.mi_pme_solve_scratch_bytes.restype = ctypes.c_size_t
     for nch in (1, 4):
         half = 128 * 128 * 65 * 16

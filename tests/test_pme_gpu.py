@@ -855,6 +855,45 @@ def test_fused_mesh_solve(dims, order, monkeypatch):
             _close(bf, bref[1], dtype, f"batch forces {dims}")
 
 
+@pytest.mark.parametrize("dims", [(8, 8, 8), (16, 16, 16), (16, 8, 32), (32, 64, 16), (128, 128, 128), (64, 128, 256), (12, 10, 18), (20, 18, 24), (96, 100, 120),
+                                  (120, 96, 100), (240, 8, 10)])
+def test_in_lds_transforms_equal_numpy(dims):
+    """`mi_fft_lds` (round 6): the mesh solve's kernels as unscaled rfftn / irfftn in natural order, against numpy on the host (no rocFFT on
+    either side); batches of 1 and 3, fp64 and fp32; the C2R leaves its input untouched; and `_fft_plan` hands these out wherever the mesh
+    solve is supported (what the autograd node's backward runs, pme.py:1398 / :1422 / :1455-1457)."""
+    from nvalchemiops import _capi as C
+    from nvalchemiops.interactions.electrostatics import pme as P
+
+    nx, ny, nz = dims
+    rng = np.random.default_rng(sum(dims))
+    for rdt, cdt, tol in ((torch.float64, torch.complex128, 1e-12), (torch.float32, torch.complex64, 2e-5)):
+        code = C.dtype_code(rdt)
+        if not C.lib().mi_pme_solve_supported(1, nx, ny, nz, code):
+            assert rdt == torch.float64 and dims == (64, 128, 256)  # fp64: the 128 x 129 complex plane is beyond LDS
+            assert isinstance(P._fft_plan(torch.device(DEV), dims, 1, code, False), (P._FftPlan, P._DenseDft))
+            continue
+        for batch in (1, 3):
+            if batch == 3 and nx * ny * nz > 2 ** 21:
+                continue
+            fwd, inv = P._fft_plan(torch.device(DEV), dims, batch, code, False), P._fft_plan(torch.device(DEV), dims, batch, code, True)
+            assert isinstance(fwd, P._LdsFft) and isinstance(inv, P._LdsFft)
+            mesh = rng.standard_normal((batch, nx, ny, nz))
+            want = np.fft.rfftn(mesh, axes=(1, 2, 3))
+            spec = torch.empty((batch, nx, ny, nz // 2 + 1), dtype=cdt, device=DEV)
+            fwd(torch.as_tensor(mesh, dtype=rdt, device=DEV), spec)
+            scale = float(np.abs(want).max())
+            assert np.abs(spec.cpu().numpy() - want).max() <= tol * scale * 8, (dims, rdt, batch)
+            # an arbitrary half spectrum back: numpy's irfftn * N; the input survives
+            sp = want + rng.standard_normal(want.shape) + 1j * rng.standard_normal(want.shape)
+            tsp = torch.as_tensor(sp, dtype=cdt, device=DEV)
+            keep = tsp.clone()
+            back = torch.empty((batch, nx, ny, nz), dtype=rdt, device=DEV)
+            inv(tsp, back)
+            ref = np.fft.irfftn(sp, dims, axes=(1, 2, 3)) * float(nx * ny * nz)
+            assert np.abs(back.cpu().numpy() - ref).max() <= tol * float(np.abs(ref).max()) * 8, (dims, rdt, batch)
+            assert torch.equal(tsp, keep)
+
+
 def test_fused_mesh_solve_support_table():
     """What the fused solve takes: powers of two whose (ny, nz/2+1) plane fits LDS; everything else keeps hipFFT."""
     from nvalchemiops import _capi as C
