@@ -512,13 +512,24 @@ int mi_pme_solve_keep(const void* mesh, const void* recip_cell, const void* alph
  * (interleaved re, im; natural frequency order), UNSCALED in both directions -- layout and scaling of mi_fft_plan_exec / of
  * torch.fft.rfftn(norm="backward") and irfftn(norm="forward") (pme.py:1398, :1422, :1455-1457) -- without hipFFT: inverse = 0: plane kernel +
  * column kernel (R2C), inverse = 1: column kernel + plane kernel (C2R; like numpy / torch it does not read the imaginary parts of the DC
- * and Nyquist bins along z, and unlike hipFFT's multi-dimensional C2R it leaves its input untouched).  Supported exactly where
- * mi_pme_solve_supported(batch, nx, ny, nz, dtype) is.  scratch: mi_fft_lds_scratch_bytes (one half spectrum + the per-shape tables);
+ * and Nyquist bins along z, and unlike hipFFT's multi-dimensional C2R it leaves its input untouched).  Supported
+ * (mi_fft_lds_supported) where mi_pme_solve_supported(batch, nx, ny, nz, dtype) is and the plane kernel's two extra index tables still fit.  scratch: mi_fft_lds_scratch_bytes (one half spectrum + the per-shape tables);
  * nothing outlives the call, nothing is allocated or synchronised: capturable in a HIP graph.  The backward of the autograd node, the
  * composed differentiable path and the spectrum-keeping callers take these instead of a hipFFT plan wherever the mesh allows.          */
+int mi_fft_lds_supported(int batch, int nx, int ny, int nz, int dtype);
 size_t mi_fft_lds_scratch_bytes(int batch, int nx, int ny, int nz, int dtype);
 int mi_fft_lds(const void* in, void* out, int batch, int nx, int ny, int nz, int dtype, int inverse, void* scratch, size_t scratch_bytes,
-               void* stream);
+               const void* tables /*NULL, or a block filled by mi_fft_lds_tables for this (nx, ny, nz, dtype)*/, void* stream);
+/* The per-shape tables of the in-LDS kernels (unit roots, Miller index and sinc of every slot: a few KB; they depend on nx, ny, nz and the
+ * dtype only).  Every call of mi_fft_lds / mi_pme_solve* computes them into its scratch with one small launch unless the caller passes a
+ * block it filled ONCE with mi_fft_lds_tables -- caller-owned memory, read-only afterwards, shareable by any number of calls and streams
+ * once that launch has completed (saves ~6 us per call: the Python host keeps one block per mesh shape and device).                       */
+size_t mi_fft_lds_tables_bytes(int nx, int ny, int nz, int dtype);
+int mi_fft_lds_tables(int nx, int ny, int nz, int dtype, void* tables, void* stream);
+/* mi_pme_solve_keep with the tables handed in (NULL = computed by the call, as in mi_pme_solve / mi_pme_solve_keep) */
+int mi_pme_solve_tabled(const void* mesh, const void* recip_cell, const void* alpha, const void* volume, int n_systems, int nx, int ny, int nz,
+                        int order, int with_field, int dtype, void* scratch, size_t scratch_bytes, void* real_out, void* spectrum_out,
+                        const void* tables, void* stream);
 /* Adjoint of the k-space pass (the backward of the fused forward under autograd, pme.py `_FusedPME` / `_FusedReciprocal`).  `spec`: unscaled
  * spectrum of the charge mesh [n_systems][nx][ny][nz/2+1]; `weight_spec`: spectra of the spread upstream weights, channel-major
  * [n_channels][n_systems][...] -- channel 0 for a loss on the energies (weights g_E q), channels 1..3 (n_channels = 4) for a loss on the explicit

@@ -491,6 +491,12 @@ template <class T> MI_HD void tables_body(void* base, const Geom& g, int tid, in
 
 // LDS bytes of the plane kernels: the plane + exp(-2 pi i t / nz) + exp(-2 pi i t / ny)
 template <class T> MI_HD size_t plane_lds_bytes(const Geom& g) { return ((size_t)g.ny * g.P + g.nz + g.ny) * sizeof(Cx<T>); }
+// ... of their NAT forms (transforms on their own, mi_fft_lds): + the frequency of every y slot and z slot
+template <class T> MI_HD size_t plane_lds_bytes_nat(const Geom& g) { return plane_lds_bytes<T>(g) + ((size_t)g.ny + g.P) * sizeof(int); }
+template <bool GEN> MI_HD void plane_nat_tables(int* NATY, int* NATZ, const Geom& g, int tid, int nth) {
+  for (int t = tid; t < g.ny; t += nth) NATY[t] = slot_freq(g.py, t);
+  for (int t = tid; t < g.P; t += nth) NATZ[t] = t < g.M ? slot_freq(g.pz, t) : g.M;
+}
 
 template <class T> MI_HD void plane_tables(Cx<T>* Wz, Cx<T>* Wy, const Tables<T>& tb, const Geom& g, int tid, int nth) {
   for (int t = tid; t < g.nz; t += nth) Wz[t] = tb.Wz[t];
@@ -499,11 +505,16 @@ template <class T> MI_HD void plane_tables(Cx<T>* Wz, Cx<T>* Wy, const Tables<T>
 
 // ---- kernel A body: one (system, x) plane -------------------------------------------------------------------------------------------
 // in: real plane [ny][nz]; out: [ny][P] complex in (y slot, z slot) order; lds: plane_lds_bytes
-template <class T, bool GEN = true> MI_HD void fwd_plane_body(const T* in, Cx<T>* out, Cx<T>* lds, const Geom& g, const Tables<T>& tb, int tid, int nth) {
+// NAT (round 6, mi_fft_lds): out in NATURAL frequency order along y and z -- the last stage's stores go to the row / bin the slot stands for
+// (a wave still writes whole rows: the same lines, its lanes in another order); lds: plane_lds_bytes_nat
+template <class T, bool GEN = true, bool NAT = false> MI_HD void fwd_plane_body(const T* in, Cx<T>* out, Cx<T>* lds, const Geom& g, const Tables<T>& tb, int tid, int nth) {
   Cx<T>* plane = lds;
   Cx<T>* Wz = lds + g.ny * g.P;
   Cx<T>* Wy = Wz + g.nz;
+  int* NATY = (int*)(Wy + g.ny);
+  int* NATZ = NATY + g.ny;
   plane_tables(Wz, Wy, tb, g, tid, nth);
+  if (NAT) plane_nat_tables<GEN>(NATY, NATZ, g, tid, nth);
   const Cx<T>* src = (const Cx<T>*)in;
   for (int e = tid; e < g.ny * g.M; e += nth) {
     const int y = GEN ? (int)fdiv(g.divM, (unsigned)e) : e >> g.lgM, j = GEN ? e - y * g.M : e & (g.M - 1);
@@ -529,18 +540,23 @@ template <class T, bool GEN = true> MI_HD void fwd_plane_body(const T* in, Cx<T>
     const int P = g.P;
     for (int it = tid; it < items; it += nth) {
       const int j = (int)fdiv(g.divP, (unsigned)it), c = it - j * P;
-      butterfly_r<-1, 3, GEN>(g.py, s, Wy, 1, j, [=](int p) { return plane[p * P + c]; }, [=](int p, Cx<T> v) { out[p * P + c] = v; });
+      const int cz = NAT ? NATZ[c] : c;
+      butterfly_r<-1, 3, GEN>(g.py, s, Wy, 1, j, [=](int p) { return plane[p * P + c]; }, [=](int p, Cx<T> v) { out[(NAT ? NATY[p] : p) * P + cz] = v; });
     }
   }
 }
 
 // ---- kernel C body: one (system, channel, x) plane ----------------------------------------------------------------------------------
 // in: [ny][P] complex in (y slot, z slot) order; out: real plane [ny][nz]
-template <class T, bool GEN = true> MI_HD void inv_plane_body(const Cx<T>* in, T* out, Cx<T>* lds, const Geom& g, const Tables<T>& tb, int tid, int nth) {
+// NAT (round 6, mi_fft_lds): in is in NATURAL frequency order along y and z; lds: plane_lds_bytes_nat
+template <class T, bool GEN = true, bool NAT = false> MI_HD void inv_plane_body(const Cx<T>* in, T* out, Cx<T>* lds, const Geom& g, const Tables<T>& tb, int tid, int nth) {
   Cx<T>* plane = lds;
   Cx<T>* Wz = lds + g.ny * g.P;
   Cx<T>* Wy = Wz + g.nz;
+  int* NATY = (int*)(Wy + g.ny);
+  int* NATZ = NATY + g.ny;
   plane_tables(Wz, Wy, tb, g, tid, nth);
+  if (NAT) plane_nat_tables<GEN>(NATY, NATZ, g, tid, nth);
   MI_FFT_SYNC();
   const int P = g.P;
   {  // first inverse stage of the columns reads HBM directly
@@ -548,7 +564,8 @@ template <class T, bool GEN = true> MI_HD void inv_plane_body(const Cx<T>* in, T
     const int items = P * g.py.per[s];
     for (int it = tid; it < items; it += nth) {
       const int j = (int)fdiv(g.divP, (unsigned)it), c = it - j * P;
-      butterfly_r<+1, 3, GEN>(g.py, s, Wy, 1, j, [=](int p) { return in[p * P + c]; }, [=](int p, Cx<T> v) { plane[p * P + c] = v; });
+      const int cz = NAT ? NATZ[c] : c;
+      butterfly_r<+1, 3, GEN>(g.py, s, Wy, 1, j, [=](int p) { return in[(NAT ? NATY[p] : p) * P + cz]; }, [=](int p, Cx<T> v) { plane[p * P + c] = v; });
     }
     MI_FFT_SYNC();
   }
@@ -590,8 +607,9 @@ template <class T> MI_HD size_t inv_cols_lds_bytes(const Geom& g) {
 // k_vectors.py:270-282); sf_expo: exponent of the B-spline modulus (decode_order().sf_exponent)
 // spec_nat (NULL or [nx][ny][P] of system b): the UNFACTORED spectrum in natural frequency order -- numpy.fft.rfftn(mesh) -- for a caller that
 // needs the charge spectrum itself (the backward of the autograd node); 16-byte scattered stores, one per element
-// PLAIN (round 6): a transform on its own (mi_fft_lds_r2c): no k-space factor, nothing stored back in slot order -- spec_nat is the output,
-// recip / alpha / volume are not read
+// PLAIN (round 6): a transform on its own (mi_fft_lds, R2C): `spec` comes from the NAT plane kernel -- columns in natural (y, z) order -- no
+// k-space factor, nothing stored back; spec_nat is the output (row f_x of every column: 256 contiguous bytes per tile row); recip / alpha /
+// volume are not read
 template <class T, bool GEN = true, bool PLAIN = false>
 MI_HD void fwd_cols_body(Cx<T>* spec, Cx<T>* lds, const Geom& g, const Tables<T>& tb, const T* recip, T alpha, T volume, int sf_expo, int col0, int tid,
                          int nth, Cx<T>* spec_nat = nullptr) {
@@ -662,14 +680,16 @@ MI_HD void fwd_cols_body(Cx<T>* spec, Cx<T>* lds, const Geom& g, const Tables<T>
         const T f = factor_of(xs, c);
         spec[(size_t)xs * ncol + col0 + c] = Cx<T>{v.re * f, v.im * f};
       }
-      if (PLAIN || spec_nat) spec_nat[(size_t)NATX[xs] * ncol + NATC[c]] = v;
+      if (PLAIN) spec_nat[(size_t)NATX[xs] * ncol + col0 + c] = v;
+      else if (spec_nat) spec_nat[(size_t)NATX[xs] * ncol + NATC[c]] = v;
     }
   }
 }
 // conv: [nx][ny*P] complex of system b in slot order along x, y, z; out: [nx][ny*P] of (system b, channel ch), natural order along x again:
 // the inverse x transform of conv (ch = 0, the potential) or of (-i k_d) conv (ch = 1 + d, the field components; pme.py:1455-1457)
-// PLAIN (round 6): a transform on its own (mi_fft_lds_c2r): `conv` is a half spectrum in NATURAL frequency order (numpy.fft.rfftn layout,
-// [nx][ny][P]) -- the loads of the first stage look the slots' frequencies up -- ch = 0, recip is not read
+// PLAIN (round 6): a transform on its own (mi_fft_lds, C2R): `conv` is a half spectrum in NATURAL frequency order (numpy.fft.rfftn layout,
+// [nx][ny][P]) -- the first stage reads row f_x of the slot it needs, the columns stay in natural (y, z) order for the NAT plane kernel
+// behind it -- ch = 0, recip is not read
 template <class T, bool GEN = true, bool PLAIN = false>
 MI_HD void inv_cols_body(const Cx<T>* conv, Cx<T>* out, Cx<T>* lds, const Geom& g, const Tables<T>& tb, const T* recip, int ch, int col0, int tid, int nth) {
   const int COLS = MI_SOLVE_COLS, LGC = MI_SOLVE_LGCOLS;
@@ -689,8 +709,7 @@ MI_HD void inv_cols_body(const Cx<T>* conv, Cx<T>* out, Cx<T>* lds, const Geom& 
   for (int c = tid; c < COLS; c += nth) {
     const int col = col0 + c < ncol ? col0 + c : ncol - 1;
     const int ys = (int)fdiv(g.divP, (unsigned)col), zs = col - ys * g.P;
-    if (PLAIN) NATC[c] = slot_freq(g.py, ys) * g.P + (zs < g.M ? slot_freq(g.pz, zs) : g.M);
-    else KC[c] = tb.my[ys] * recip[3 * d + 1] + tb.mz[zs] * recip[3 * d + 2];
+    if (!PLAIN) KC[c] = tb.my[ys] * recip[3 * d + 1] + tb.mz[zs] * recip[3 * d + 2];
   }
   MI_FFT_SYNC();
   const Plan& px = g.px;
@@ -703,7 +722,7 @@ MI_HD void inv_cols_body(const Cx<T>* conv, Cx<T>* out, Cx<T>* lds, const Geom& 
       return [=](int p) {
         if (!first) return S[(p << LGC) + c];
         if (!live) return Cx<T>{T(0), T(0)};
-        if (PLAIN) return conv[(size_t)NATX[p] * ncol + NATC[c]];
+        if (PLAIN) return src[(size_t)NATX[p] * ncol];
         const Cx<T> v = src[(size_t)p * ncol];
         if (!field) return v;
         const T kd = KX[p] + KC[c];

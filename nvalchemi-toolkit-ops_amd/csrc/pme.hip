@@ -1013,11 +1013,11 @@ int spread_tiled(const T* pos, const T* values, const int* batch_idx, const T* c
 #define MI_LDS_MAX 163840
 template <class T> __global__ void pme_solve_tables_kernel(void* base, mifft::Geom g) { mifft::tables_body<T>(base, g, threadIdx.x, blockDim.x); }
 // GEN: the mixed-radix form of the bodies (meshes with factors 3 and 5); false = power-of-two meshes, shift / mask index arithmetic only
-template <class T, bool GEN>
+template <class T, bool GEN, bool NAT = false>
 __global__ __launch_bounds__(1024) void pme_solve_fwd_kernel(const T* __restrict__ mesh, mifft::Cx<T>* __restrict__ spec, mifft::Geom g, mifft::Tables<T> tb) {
   extern __shared__ __align__(16) unsigned char solve_smem[];
   const size_t plane = blockIdx.x;  // (system, x)
-  mifft::fwd_plane_body<T, GEN>(mesh + plane * g.ny * g.nz, spec + plane * g.ny * g.P, (mifft::Cx<T>*)solve_smem, g, tb, threadIdx.x, blockDim.x);
+  mifft::fwd_plane_body<T, GEN, NAT>(mesh + plane * g.ny * g.nz, spec + plane * g.ny * g.P, (mifft::Cx<T>*)solve_smem, g, tb, threadIdx.x, blockDim.x);
 }
 template <class T, bool GEN, bool PLAIN = false>
 __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2))) void pme_solve_fwd_cols_kernel(mifft::Cx<T>* __restrict__ spec, mifft::Geom g, mifft::Tables<T> tb, const T* __restrict__ recip,
@@ -1053,12 +1053,12 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2))) void p
 }
 // persistent: one block per CU walks its planes, so that the stores of one plane are still draining while the loads of the next are issued
 // (with one 133 KB plane per CU in LDS nothing else overlaps the two)
-template <class T, bool GEN>
+template <class T, bool GEN, bool NAT = false>
 __global__ __launch_bounds__(1024) void pme_solve_inv_kernel(const mifft::Cx<T>* __restrict__ conv, T* __restrict__ real, mifft::Geom g, mifft::Tables<T> tb,
                                                              int n_planes) {
   extern __shared__ __align__(16) unsigned char solve_smem[];
   for (size_t plane = blockIdx.x; plane < (size_t)n_planes; plane += gridDim.x) {  // (system, channel, x)
-    mifft::inv_plane_body<T, GEN>(conv + plane * g.ny * g.P, real + plane * g.ny * g.nz, (mifft::Cx<T>*)solve_smem, g, tb, threadIdx.x, blockDim.x);
+    mifft::inv_plane_body<T, GEN, NAT>(conv + plane * g.ny * g.P, real + plane * g.ny * g.nz, (mifft::Cx<T>*)solve_smem, g, tb, threadIdx.x, blockDim.x);
     __syncthreads();
   }
 }
@@ -1090,7 +1090,7 @@ static int solve_plane_threads(const mifft::Geom& g) {
 }
 template <class T, bool GEN>
 static int solve_launch_as(const void* mesh, const void* recip_cell, const void* alpha, const void* volume, const mifft::Geom& g, int expo, int nch,
-                        void* spec, void* conv, void* tab, void* real_out, void* spec_nat, int pt, int col_blocks, void* stream) {
+                        void* spec, void* conv, void* tab, bool tab_ready, void* real_out, void* spec_nat, int pt, int col_blocks, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   const size_t pl = mifft::plane_lds_bytes<T>(g), fl = mifft::fwd_cols_lds_bytes<T>(g), il = mifft::inv_cols_lds_bytes<T>(g);
   // more than 64 KB of dynamic LDS has to be asked for once per kernel AND device (setting it again is harmless: a race between two
@@ -1105,8 +1105,9 @@ static int solve_launch_as(const void* mesh, const void* recip_cell, const void*
     if (dev_ix >= 0) raised_on[dev_ix].store(true, std::memory_order_release);
   }
   // unit roots / sinc / Miller index per FFT slot: a few KB, recomputed by one small launch per call into the caller's scratch -- the
-  // library keeps NO device memory of its own here (a per-shape cache allocated with hipMalloc was tried first)
-  pme_solve_tables_kernel<T><<<1, 256, 0, st>>>(tab, g);
+  // library keeps NO device memory of its own here (a per-shape cache allocated with hipMalloc was tried first) --
+  // unless the caller hands in a block it filled once with mi_fft_lds_tables (round 6: the Python host keeps one per mesh shape)
+  if (!tab_ready) pme_solve_tables_kernel<T><<<1, 256, 0, st>>>(tab, g);
   const mifft::Tables<T> tb = mifft::tables_at<T>(tab, g);
   mi_timing_begin("pme_solve_fwd", stream);
   pme_solve_fwd_kernel<T, GEN><<<g.B * g.nx, pt, pl, st>>>((const T*)mesh, (mifft::Cx<T>*)spec, g, tb);
@@ -1129,23 +1130,23 @@ static int solve_launch_as(const void* mesh, const void* recip_cell, const void*
 // both ways -- the layout and scaling of mi_fft_plan_exec, so that the autograd node's backward (and every other caller of a plan) runs
 // without hipFFT wherever the mesh solve itself is supported.  `work` = one half spectrum in slot order, `tab` = the per-shape tables.
 template <class T, bool GEN>
-static int fft_lds_launch_as(bool inverse, const void* in, void* out, const mifft::Geom& g, void* work, void* tab, int pt, int col_blocks, void* stream) {
+static int fft_lds_launch_as(bool inverse, const void* in, void* out, const mifft::Geom& g, void* work, void* tab, bool tab_ready, int pt, int col_blocks, void* stream) {
   hipStream_t st = (hipStream_t)stream;
-  const size_t pl = mifft::plane_lds_bytes<T>(g), fl = mifft::fwd_cols_lds_bytes<T>(g), il = mifft::inv_cols_lds_bytes<T>(g);
+  const size_t pl = mifft::plane_lds_bytes_nat<T>(g), fl = mifft::fwd_cols_lds_bytes<T>(g), il = mifft::inv_cols_lds_bytes<T>(g);
   static std::atomic<bool> raised_on[MI_SOLVE_MAX_DEVICES];
   const int dev_ix = solve_device();
   if (dev_ix < 0 || !raised_on[dev_ix].load(std::memory_order_acquire)) {
-    MI_HIP_CHECK(hipFuncSetAttribute((const void*)pme_solve_fwd_kernel<T, GEN>, hipFuncAttributeMaxDynamicSharedMemorySize, MI_LDS_MAX));
+    MI_HIP_CHECK(hipFuncSetAttribute((const void*)pme_solve_fwd_kernel<T, GEN, true>, hipFuncAttributeMaxDynamicSharedMemorySize, MI_LDS_MAX));
     MI_HIP_CHECK(hipFuncSetAttribute((const void*)pme_solve_fwd_cols_kernel<T, GEN, true>, hipFuncAttributeMaxDynamicSharedMemorySize, MI_LDS_MAX));
     MI_HIP_CHECK(hipFuncSetAttribute((const void*)pme_solve_inv_cols_kernel<T, GEN, true>, hipFuncAttributeMaxDynamicSharedMemorySize, MI_LDS_MAX));
-    MI_HIP_CHECK(hipFuncSetAttribute((const void*)pme_solve_inv_kernel<T, GEN>, hipFuncAttributeMaxDynamicSharedMemorySize, MI_LDS_MAX));
+    MI_HIP_CHECK(hipFuncSetAttribute((const void*)pme_solve_inv_kernel<T, GEN, true>, hipFuncAttributeMaxDynamicSharedMemorySize, MI_LDS_MAX));
     if (dev_ix >= 0) raised_on[dev_ix].store(true, std::memory_order_release);
   }
-  pme_solve_tables_kernel<T><<<1, 256, 0, st>>>(tab, g);
+  if (!tab_ready) pme_solve_tables_kernel<T><<<1, 256, 0, st>>>(tab, g);
   const mifft::Tables<T> tb = mifft::tables_at<T>(tab, g);
   if (!inverse) {
     mi_timing_begin("fft_lds_r2c", stream);
-    pme_solve_fwd_kernel<T, GEN><<<g.B * g.nx, pt, pl, st>>>((const T*)in, (mifft::Cx<T>*)work, g, tb);
+    pme_solve_fwd_kernel<T, GEN, true><<<g.B * g.nx, pt, pl, st>>>((const T*)in, (mifft::Cx<T>*)work, g, tb);
     pme_solve_fwd_cols_kernel<T, GEN, true><<<dim3(col_blocks, g.B), 128, fl, st>>>((mifft::Cx<T>*)work, g, tb, nullptr, nullptr, nullptr, 1, (mifft::Cx<T>*)out);
     mi_timing_end(stream);
   } else {
@@ -1153,17 +1154,17 @@ static int fft_lds_launch_as(bool inverse, const void* in, void* out, const miff
     pme_solve_inv_cols_kernel<T, GEN, true><<<dim3((col_blocks + 7) / 8 * 8, g.B), 128, il, st>>>((const mifft::Cx<T>*)in, (mifft::Cx<T>*)work, g, tb, nullptr, 1, col_blocks);
     const int n_planes = g.B * g.nx;
     const int inv_grid = (2 * pl <= MI_LDS_MAX || n_planes < solve_cus()) ? n_planes : solve_cus();
-    pme_solve_inv_kernel<T, GEN><<<inv_grid, pt, pl, st>>>((const mifft::Cx<T>*)work, (T*)out, g, tb, n_planes);
+    pme_solve_inv_kernel<T, GEN, true><<<inv_grid, pt, pl, st>>>((const mifft::Cx<T>*)work, (T*)out, g, tb, n_planes);
     mi_timing_end(stream);
   }
   return MI_OK;
 }
 template <class T>
 static int solve_launch(const void* mesh, const void* recip_cell, const void* alpha, const void* volume, const mifft::Geom& g, int expo, int nch,
-                        void* spec, void* conv, void* tab, void* real_out, void* spec_nat, int pt, int col_blocks, void* stream) {
+                        void* spec, void* conv, void* tab, bool tab_ready, void* real_out, void* spec_nat, int pt, int col_blocks, void* stream) {
   // power-of-two meshes run the kernels compiled without the mixed-radix paths (the code of rounds 4 - 5); everything else the general ones
-  if (g.p2) return solve_launch_as<T, false>(mesh, recip_cell, alpha, volume, g, expo, nch, spec, conv, tab, real_out, spec_nat, pt, col_blocks, stream);
-  return solve_launch_as<T, true>(mesh, recip_cell, alpha, volume, g, expo, nch, spec, conv, tab, real_out, spec_nat, pt, col_blocks, stream);
+  if (g.p2) return solve_launch_as<T, false>(mesh, recip_cell, alpha, volume, g, expo, nch, spec, conv, tab, tab_ready, real_out, spec_nat, pt, col_blocks, stream);
+  return solve_launch_as<T, true>(mesh, recip_cell, alpha, volume, g, expo, nch, spec, conv, tab, tab_ready, real_out, spec_nat, pt, col_blocks, stream);
 }
 }  // namespace
 
@@ -1462,26 +1463,46 @@ int mi_pme_solve_supported(int n_systems, int nx, int ny, int nz, int dtype) {
 int mi_pme_solve_preferred(int n_systems, int nx, int ny, int nz, int dtype) {
   return mi_pme_solve_supported(n_systems, nx, ny, nz, dtype);
 }
+int mi_fft_lds_supported(int batch, int nx, int ny, int nz, int dtype) {
+  if (!mi_pme_solve_supported(batch, nx, ny, nz, dtype)) return 0;
+  const mifft::Geom g = mifft::make_geom(batch, nx, ny, nz);  // (the plane kernels of the transforms carry two small index tables more)
+  return (dtype == MI_F32 ? mifft::plane_lds_bytes_nat<float>(g) : mifft::plane_lds_bytes_nat<double>(g)) <= MI_LDS_MAX ? 1 : 0;
+}
 size_t mi_fft_lds_scratch_bytes(int batch, int nx, int ny, int nz, int dtype) {
-  if (batch < 1 || nx < 1 || ny < 1 || nz < 2 || (dtype != MI_F32 && dtype != MI_F64) || !mifft::geom_ok(nx, ny, nz)) return 0;
+  if (!mi_fft_lds_supported(batch, nx, ny, nz, dtype)) return 0;
   const size_t per = (size_t)batch * nx * ny * (nz / 2 + 1) * (dtype == MI_F32 ? 8 : 16);
   const mifft::Geom g = mifft::make_geom(batch, nx, ny, nz);
   return mi_align(per) + mi_align(dtype == MI_F32 ? mifft::tables_bytes<float>(g) : mifft::tables_bytes<double>(g));
 }
-int mi_fft_lds(const void* in, void* out, int batch, int nx, int ny, int nz, int dtype, int inverse, void* scratch, size_t scratch_bytes, void* stream) {
+size_t mi_fft_lds_tables_bytes(int nx, int ny, int nz, int dtype) {
+  if (nx < 1 || ny < 1 || nz < 2 || (dtype != MI_F32 && dtype != MI_F64) || !mifft::geom_ok(nx, ny, nz)) return 0;
+  const mifft::Geom g = mifft::make_geom(1, nx, ny, nz);
+  return mi_align(dtype == MI_F32 ? mifft::tables_bytes<float>(g) : mifft::tables_bytes<double>(g));
+}
+int mi_fft_lds_tables(int nx, int ny, int nz, int dtype, void* tables, void* stream) {
+  MI_REQUIRE(dtype == MI_F32 || dtype == MI_F64, "dtype");
+  MI_REQUIRE(tables && mifft::geom_ok(nx, ny, nz), "tables pointer / mesh not supported by the in-LDS transforms");
+  const mifft::Geom g = mifft::make_geom(1, nx, ny, nz);
+  MI_DISPATCH_T(dtype, (pme_solve_tables_kernel<T_><<<1, 256, 0, (hipStream_t)stream>>>(tables, g)));
+  MI_LAUNCH_CHECK();
+  return MI_OK;
+}
+int mi_fft_lds(const void* in, void* out, int batch, int nx, int ny, int nz, int dtype, int inverse, void* scratch, size_t scratch_bytes,
+               const void* tables, void* stream) {
   MI_REQUIRE(dtype == MI_F32 || dtype == MI_F64, "dtype");
   MI_REQUIRE(in && out && scratch, "null pointer");
-  MI_REQUIRE(mi_pme_solve_supported(batch, nx, ny, nz, dtype), "mesh not supported by the in-LDS transforms (see mi_pme_solve_supported)");
+  MI_REQUIRE(mi_fft_lds_supported(batch, nx, ny, nz, dtype), "mesh not supported by the in-LDS transforms (see mi_fft_lds_supported)");
   MI_REQUIRE(scratch_bytes >= mi_fft_lds_scratch_bytes(batch, nx, ny, nz, dtype), "scratch too small (mi_fft_lds_scratch_bytes)");
   const mifft::Geom g = mifft::make_geom(batch, nx, ny, nz);
   const size_t per = (size_t)batch * nx * ny * g.P * (dtype == MI_F32 ? 8 : 16);
   void* work = scratch;
-  void* tab = (char*)scratch + mi_align(per);
+  void* tab = tables ? const_cast<void*>(tables) : (void*)((char*)scratch + mi_align(per));
+  const bool ready = tables != nullptr;
   const int pt = solve_plane_threads(g);
   const int col_blocks = (g.ny * g.P + MI_SOLVE_COLS - 1) / MI_SOLVE_COLS;
   int rc = MI_OK;
-  MI_DISPATCH_T(dtype, (rc = g.p2 ? fft_lds_launch_as<T_, false>(inverse != 0, in, out, g, work, tab, pt, col_blocks, stream)
-                                  : fft_lds_launch_as<T_, true>(inverse != 0, in, out, g, work, tab, pt, col_blocks, stream)));
+  MI_DISPATCH_T(dtype, (rc = g.p2 ? fft_lds_launch_as<T_, false>(inverse != 0, in, out, g, work, tab, ready, pt, col_blocks, stream)
+                                  : fft_lds_launch_as<T_, true>(inverse != 0, in, out, g, work, tab, ready, pt, col_blocks, stream)));
   if (rc != MI_OK) return rc;
   MI_LAUNCH_CHECK();
   return MI_OK;
@@ -1497,6 +1518,11 @@ int mi_pme_solve(const void* mesh, const void* recip_cell, const void* alpha, co
 }
 int mi_pme_solve_keep(const void* mesh, const void* recip_cell, const void* alpha, const void* volume, int n_systems, int nx, int ny, int nz, int order,
                       int with_field, int dtype, void* scratch, size_t scratch_bytes, void* real_out, void* spectrum_out, void* stream) {
+  return mi_pme_solve_tabled(mesh, recip_cell, alpha, volume, n_systems, nx, ny, nz, order, with_field, dtype, scratch, scratch_bytes, real_out, spectrum_out,
+                             nullptr, stream);
+}
+int mi_pme_solve_tabled(const void* mesh, const void* recip_cell, const void* alpha, const void* volume, int n_systems, int nx, int ny, int nz, int order,
+                        int with_field, int dtype, void* scratch, size_t scratch_bytes, void* real_out, void* spectrum_out, const void* tables, void* stream) {
   MI_REQUIRE(dtype == MI_F32 || dtype == MI_F64, "dtype");
   MI_REQUIRE(mesh && recip_cell && alpha && volume && scratch && real_out, "null pointer");
   MI_REQUIRE(mi_pme_solve_supported(n_systems, nx, ny, nz, dtype), "mesh not supported by the fused solve (see mi_pme_solve_supported)");
@@ -1507,11 +1533,12 @@ int mi_pme_solve_keep(const void* mesh, const void* recip_cell, const void* alph
   const size_t per = (size_t)n_systems * nx * ny * g.P * (dtype == MI_F32 ? 8 : 16);
   void* spec = scratch;
   void* conv = (char*)scratch + mi_align(per);
-  void* tab = (char*)conv + mi_align(per * (size_t)nch);
+  void* tab = tables ? const_cast<void*>(tables) : (void*)((char*)conv + mi_align(per * (size_t)nch));
   const int pt = solve_plane_threads(g);
   const int col_blocks = (g.ny * g.P + MI_SOLVE_COLS - 1) / MI_SOLVE_COLS;
   int rc = MI_OK;
-  MI_DISPATCH_T(dtype, (rc = solve_launch<T_>(mesh, recip_cell, alpha, volume, g, expo, nch, spec, conv, tab, real_out, spectrum_out, pt, col_blocks, stream)));
+  MI_DISPATCH_T(dtype, (rc = solve_launch<T_>(mesh, recip_cell, alpha, volume, g, expo, nch, spec, conv, tab, tables != nullptr, real_out, spectrum_out, pt, col_blocks,
+                                              stream)));
   if (rc != MI_OK) return rc;
   MI_LAUNCH_CHECK();
   return MI_OK;

@@ -268,7 +268,7 @@ class _LdsFft:
         nx, ny, nz = self.dims
         scratch = torch.empty(self.nbytes, dtype=torch.uint8, device=src.device)
         C.check(C.lib().mi_fft_lds(C.ptr(src), C.ptr(dst), self.batch, nx, ny, nz, self.code, int(self.inverse), C.ptr(scratch),
-                                   ctypes.c_size_t(self.nbytes), C.stream_of(src)), "mi_fft_lds")
+                                   ctypes.c_size_t(self.nbytes), C.ptr(_solve_tables(src.device, self.dims, self.code)), C.stream_of(src)), "mi_fft_lds")
 
     def destroy(self) -> None:
         pass
@@ -305,6 +305,39 @@ _MESH_SOLVE = {"0": False, "1": True}.get(os.environ.get("NVALCHEMIOPS_PME_MESH_
 _SOLVE_AUTOGRAD = os.environ.get("NVALCHEMIOPS_PME_SOLVE_AUTOGRAD", "1") != "0"
 
 
+_SOLVE_TABLES: "collections.OrderedDict" = collections.OrderedDict()  # (device, mesh, dtype) -> the in-LDS kernels' per-shape tables (a few KB each)
+
+
+def _solve_tables(device: torch.device, dims, code: int):
+    """The per-shape tables of the in-LDS kernels (unit roots, Miller indices, sinc per slot), filled ONCE per (device, mesh, dtype) by
+    `mi_fft_lds_tables` into a tensor this module keeps, so that `mi_pme_solve*` / `mi_fft_lds` skip their table launch (~6 us per call).  The
+    filling stream is waited for once, at creation: afterwards the block is read-only and any stream may use it.  Returns None -- the call then
+    computes its own tables, as before -- while a HIP graph is being captured and the shape has not been seen yet (no host wait inside a capture)."""
+    import ctypes
+
+    key = (device.index, tuple(int(v) for v in dims), int(code))
+    with _FFT_LOCK:
+        t = _SOLVE_TABLES.get(key)
+        if t is not None:
+            _SOLVE_TABLES.move_to_end(key)
+            return t
+        if torch.cuda.is_current_stream_capturing():
+            return None
+        L = C.lib()
+        L.mi_fft_lds_tables_bytes.restype = ctypes.c_size_t
+        nbytes = int(L.mi_fft_lds_tables_bytes(key[1][0], key[1][1], key[1][2], key[2]))
+        if nbytes == 0:
+            return None
+        t = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        stream = torch.cuda.current_stream(device)
+        C.check(L.mi_fft_lds_tables(key[1][0], key[1][1], key[1][2], key[2], C.ptr(t), ctypes.c_void_p(stream.cuda_stream)), "mi_fft_lds_tables")
+        stream.synchronize()
+        _SOLVE_TABLES[key] = t
+        while len(_SOLVE_TABLES) > 64:
+            _SOLVE_TABLES.popitem(last=False)
+        return t
+
+
 _FFT_VERSION_CHECKED = False
 
 
@@ -337,7 +370,7 @@ def _fft_plan(device: torch.device, dims, batch: int, code: int, inverse: bool):
     # the in-LDS transforms first: stateless, so nothing is cached and a captured step needs no warm-up for them
     # (`_MESH_SOLVE = False` -- "always hipFFT plans", the A/B setting -- keeps its meaning: no in-LDS kernels anywhere)
     if (_FFT_LDS and _MESH_SOLVE is not False and _OWN_FFT and not _FORCE_DFT and device.type == "cuda"
-            and C.lib().mi_pme_solve_supported(int(batch), int(dims[0]), int(dims[1]), int(dims[2]), int(code))):
+            and C.lib().mi_fft_lds_supported(int(batch), int(dims[0]), int(dims[1]), int(dims[2]), int(code))):
         return _LdsFft(dims, batch, code, inverse)
     with _FFT_LOCK:
         stream = torch.cuda.current_stream(device).cuda_stream if device.type == "cuda" else 0
@@ -434,9 +467,10 @@ def _reciprocal_front(pos, q, cells, alpha, dims, spline_order, bi, nsys, batche
         real = torch.empty((nsys, nch, nx, ny, nz), dtype=dt, device=dev)
         # need_spec (the autograd node): the forward column kernel leaves the natural-order charge spectrum as a by-product
         spec = torch.empty((nsys, nx, ny, nz // 2 + 1), dtype=cdt, device=dev) if need_spec else None
-        rc = C.lib().mi_pme_solve_keep(C.ptr(mesh), C.ptr(recip), C.ptr(al), C.ptr(vol), nsys, nx, ny, nz, C.spline_order_arg(spline_order),
-                                       int(compute_forces), code, C.ptr(scratch), ctypes.c_size_t(nbytes), C.ptr(real), C.ptr(spec), st)
-        C.check(rc, "mi_pme_solve_keep")
+        rc = C.lib().mi_pme_solve_tabled(C.ptr(mesh), C.ptr(recip), C.ptr(al), C.ptr(vol), nsys, nx, ny, nz, C.spline_order_arg(spline_order),
+                                         int(compute_forces), code, C.ptr(scratch), ctypes.c_size_t(nbytes), C.ptr(real), C.ptr(spec),
+                                         C.ptr(_solve_tables(dev, (nx, ny, nz), code)), st)
+        C.check(rc, "mi_pme_solve_tabled")
         return spec, real, cit, recip, vol, qtot, al, tile_order
     if _OWN_FFT:
         # the library's own hipFFT plans (mi_fft_plan_*): the spectra and the real meshes are buffers of this call, so the C2R transform may
@@ -576,9 +610,11 @@ def _reciprocal_adjoint(saved, need, g_energies, g_forces, dims, order, bi, g_cg
     weights = [w] + ([] if gf is None else [(2.0 * gf[:, d] * q).contiguous() for d in range(3)])
     # spectra of the spread upstream weights, channel-major
     a_spec = torch.empty((nchan, nsys, nx, ny, nz // 2 + 1), dtype=cdt, device=dev)
-    fwd = _fft_plan(dev, (nx, ny, nz), nsys, code, False)
+    # ONE batched transform over all channels (round 6): a single 128^3 mesh is 128 planes for 256 CUs -- four of them in one launch fill the chip
+    a_mesh = torch.empty((nchan, nsys, nx, ny, nz), dtype=dt, device=dev)
     for c, wt in enumerate(weights):
-        fwd(_launch_spread(pos, wt, cit, bi, nsys, (nx, ny, nz), order, batched), a_spec[c])
+        _launch_spread(pos, wt, cit, bi, nsys, (nx, ny, nz), order, batched, out=a_mesh[c])
+    _fft_plan(dev, (nx, ny, nz), nchan * nsys, code, False)(a_mesh, a_spec)
     nblk = int(C.lib().mi_pme_convolve_bwd_blocks())
     partial = torch.empty((nsys, nblk, 20), dtype=torch.float64, device=dev)
     conv = torch.empty((nsys, 1, nx, ny, nz // 2 + 1), dtype=cdt, device=dev)

@@ -70,7 +70,7 @@ def _prep(positions: torch.Tensor, cell: torch.Tensor, batch_idx, cell_inv_t):
 _SPREAD_PATH = os.environ.get("NVALCHEMIOPS_SPREAD_PATH", "auto")
 
 
-def _launch_spread(pos, vals, cit, bi, nsys, dims, order, batched, want_order=False):
+def _launch_spread(pos, vals, cit, bi, nsys, dims, order, batched, want_order=False, out=None):
     """mesh[nsys,nx,ny,nz] = spread of `vals` at `pos`.  The library runs tile-owned (no global atomics) when every mesh dimension
     has a divisor in [max(order - 1, 2), 8] and falls back to atomic adds into the zeroed mesh otherwise; the scratch buffer covers the former.
     want_order: also return the scratch buffer of a tile-owned run (None after the atomic kernel): atoms grouped by mesh tile, stencil starts
@@ -85,7 +85,12 @@ def _launch_spread(pos, vals, cit, bi, nsys, dims, order, batched, want_order=Fa
         tiled = n > 0 and bool(C.lib().mi_spline_spread_prefers_tiles(n, nsys, nx, ny, nz, C.spline_order_arg(order)))
     else:
         tiled = _SPREAD_PATH == "tile" and n > 0 and bool(C.lib().mi_spline_spread_is_tiled(nsys, nx, ny, nz, C.spline_order_arg(order)))
-    mesh = (torch.empty if tiled else torch.zeros)((nsys, nx, ny, nz), dtype=pos.dtype, device=pos.device)
+    if out is not None:  # a caller's contiguous [nsys, nx, ny, nz] block (one of several meshes that share a batched transform)
+        mesh = out
+        if not tiled:
+            mesh.zero_()
+    else:
+        mesh = (torch.empty if tiled else torch.zeros)((nsys, nx, ny, nz), dtype=pos.dtype, device=pos.device)
     ws_bytes = int(C.lib().mi_spline_spread_workspace_bytes_for(n, nsys, nx, ny, nz, C.spline_order_arg(order), C.dtype_code(pos.dtype))) if tiled else 0
     ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=pos.device)
     rc = C.lib().mi_spline_spread(C.ptr(pos), C.ptr(vals), C.ptr(bi), C.ptr(cit), n, nsys, nx, ny, nz, C.spline_order_arg(order), int(batched),

@@ -59,11 +59,11 @@ int h_r2c(const double* mesh, double* spec_nat /*[B][nx][ny][P][2]*/, int B, int
   const Tables<double> tb = tables_at<double>(tab.data(), g);
   const size_t ncol = (size_t)ny * g.P;
   std::vector<Cx<double>> work((size_t)B * nx * ncol);
-  size_t need = plane_lds_bytes<double>(g);
+  size_t need = plane_lds_bytes_nat<double>(g);
   if (fwd_cols_lds_bytes<double>(g) > need) need = fwd_cols_lds_bytes<double>(g);
   std::vector<char> lds(need);
   for (int bx = 0; bx < B * nx; ++bx)
-    fwd_plane_body<double>(mesh + (size_t)bx * ny * nz, work.data() + (size_t)bx * ncol, (Cx<double>*)lds.data(), g, tb, 0, 1);
+    fwd_plane_body<double, true, true>(mesh + (size_t)bx * ny * nz, work.data() + (size_t)bx * ncol, (Cx<double>*)lds.data(), g, tb, 0, 1);
   const int blocks = (int)((ncol + MI_SOLVE_COLS - 1) / MI_SOLVE_COLS);
   for (int b = 0; b < B; ++b)
     for (int blk = 0; blk < blocks; ++blk)
@@ -79,7 +79,7 @@ int h_c2r(const double* spec_nat, double* mesh, int B, int nx, int ny, int nz) {
   const Tables<double> tb = tables_at<double>(tab.data(), g);
   const size_t ncol = (size_t)ny * g.P;
   std::vector<Cx<double>> work((size_t)B * nx * ncol);
-  size_t need = plane_lds_bytes<double>(g);
+  size_t need = plane_lds_bytes_nat<double>(g);
   if (inv_cols_lds_bytes<double>(g) > need) need = inv_cols_lds_bytes<double>(g);
   std::vector<char> lds(need);
   const int blocks = (int)((ncol + MI_SOLVE_COLS - 1) / MI_SOLVE_COLS);
@@ -88,7 +88,7 @@ int h_c2r(const double* spec_nat, double* mesh, int B, int nx, int ny, int nz) {
       inv_cols_body<double, true, true>((const Cx<double>*)spec_nat + (size_t)b * nx * ncol, work.data() + (size_t)b * nx * ncol, (Cx<double>*)lds.data(), g, tb,
                                         nullptr, 0, blk * MI_SOLVE_COLS, 0, 1);
   for (int p = 0; p < B * nx; ++p)
-    inv_plane_body<double>(work.data() + (size_t)p * ncol, mesh + (size_t)p * ny * nz, (Cx<double>*)lds.data(), g, tb, 0, 1);
+    inv_plane_body<double, true, true>(work.data() + (size_t)p * ncol, mesh + (size_t)p * ny * nz, (Cx<double>*)lds.data(), g, tb, 0, 1);
   return 0;
 }
 
@@ -102,7 +102,7 @@ int h_solve(const double* mesh, double* out, int B, int nx, int ny, int nz, cons
   const Tables<double> tb = tables_at<double>(tab.data(), g);
   const size_t ncol = (size_t)ny * g.P;
   std::vector<Cx<double>> spec((size_t)B * nx * ncol), conv((size_t)B * n_channels * nx * ncol);
-  size_t need = plane_lds_bytes<double>(g);
+  size_t need = plane_lds_bytes_nat<double>(g);
   if (inv_cols_lds_bytes<double>(g) > need) need = inv_cols_lds_bytes<double>(g);
   if (fwd_cols_lds_bytes<double>(g) > need) need = fwd_cols_lds_bytes<double>(g);
   std::vector<char> lds(need);

@@ -67,9 +67,10 @@ template <class R> static std::vector<R> solve(int B, int nx, int ny, int nz, in
   // the PLAIN column bodies (mi_fft_lds: transforms on their own): natural-order spectrum out of the forward one, and back in through the inverse
   // one; their results join `out`, so the thread-count comparison and the bounds run cover them too
   std::vector<Cx<R>> nat2((size_t)B * nx * ncol), work((size_t)B * nx * ncol);
+  std::vector<char> lds_plane_nat(plane_lds_bytes_nat<R>(g));
   for (int bx = 0; bx < B * nx; ++bx)
     run_block(nth, [&](int tid, int n) {
-      fwd_plane_body<R>(mesh.data() + (size_t)bx * ny * nz, spec.data() + (size_t)bx * ncol, (Cx<R>*)lds_plane.data(), g, tb, tid, n);
+      fwd_plane_body<R, true, true>(mesh.data() + (size_t)bx * ny * nz, spec.data() + (size_t)bx * ncol, (Cx<R>*)lds_plane_nat.data(), g, tb, tid, n);
     });
   for (int b = 0; b < B; ++b)
     for (int blk = 0; blk < blocks; ++blk)
@@ -85,7 +86,7 @@ template <class R> static std::vector<R> solve(int B, int nx, int ny, int nz, in
       });
   std::vector<R> back((size_t)B * nx * ny * nz);
   for (int p = 0; p < B * nx; ++p)
-    run_block(nth, [&](int tid, int n) { inv_plane_body<R>(work.data() + (size_t)p * ncol, back.data() + (size_t)p * ny * nz, (Cx<R>*)lds_plane.data(), g, tb, tid, n); });
+    run_block(nth, [&](int tid, int n) { inv_plane_body<R, true, true>(work.data() + (size_t)p * ncol, back.data() + (size_t)p * ny * nz, (Cx<R>*)lds_plane_nat.data(), g, tb, tid, n); });
   out.insert(out.end(), back.begin(), back.end());
   for (const auto& v : nat2) { out.push_back(v.re); out.push_back(v.im); }
   return out;
