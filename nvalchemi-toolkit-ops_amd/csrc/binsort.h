@@ -157,7 +157,9 @@ inline BsScratch bs_carve(int* base, long long cap) {
   s.block_off = s.block_sum + s.nblocks + 4;
   return s;
 }
-inline hipError_t bs_clear(const BsScratch& s, hipStream_t st) { return hipMemsetAsync(s.count, 0, sizeof(int) * 2 * (size_t)s.cap, st); }
+// (cleared in whole 16-byte words: a byte count that is not a multiple of 16 makes the runtime split the memset into two fill kernels; the up
+// to three ints a round-up adds belong to block_sum, which the scan writes before anything reads it)
+inline hipError_t bs_clear(const BsScratch& s, hipStream_t st) { return hipMemsetAsync(s.count, 0, (sizeof(int) * 2 * (size_t)s.cap + 15) / 16 * 16, st); }
 // after the key kernel: scan + scatter.  items_out[N] receives the item indices grouped by bin, start_abs[<= cap] the bin starts.
 inline hipError_t bs_sort(const BsScratch& s, const int* keys, int N, const int* nbins_dev, int* items_out, int* start_abs, hipStream_t st) {
   bs_scan_partial_kernel<<<s.nblocks, 256, 0, st>>>(s.count, nbins_dev, s.cap, s.block_sum);
