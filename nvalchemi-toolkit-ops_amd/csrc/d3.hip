@@ -1377,7 +1377,9 @@ int d3_impl(const T* pos, const int* numbers, int N, const int* idx, const int* 
   // outputs are zeroed like the reference wrapper does (dftd3.py:1933-1936; atoms with Z == 0 keep zeros): the per-atom arrays by
   // the pack kernel below, energy / virial are written for every system by the finish kernel
   // (one memset: the per-system reduction slots `sums`, only touched by the reduce kernel at the very end, lie directly in front of `present`)
-  MI_HIP_CHECK(hipMemsetAsync(ws + L.guard, 0, (L.present - L.guard) + sizeof(int) * ((size_t)hp->nz + 2), st));
+  // (in whole 16-byte words: a length that is not a multiple of 16 is split into two fill kernels by the runtime, ~5 us more on the dependent
+  // chain; the round-up stays inside the 256-byte padding of `present`)
+  MI_HIP_CHECK(hipMemsetAsync(ws + L.guard, 0, ((L.present - L.guard) + sizeof(int) * ((size_t)hp->nz + 2) + 15) / 16 * 16, st));
   D3Grid* sgrid = reinterpret_cast<D3Grid*>(ws + L.sgrid);
   if (sorted || (sortable && probe)) {
     d3_sort_setup_kernel<T><<<1, 256, 0, st>>>(cell, B, N, rc_est, sgrid, d3_sort_cap(N, B));
