@@ -249,7 +249,7 @@ def list_buffers(pos, cutoff, cell, pbc, m, device, batch_idx=None, for_dftd3=Fa
     from nvalchemiops.neighborlist import tuned_neighbor_buffers
 
     return tuned_neighbor_buffers(pos, cutoff, cell, pbc, m, batch_idx=batch_idx, for_dftd3=for_dftd3,
-                                  candidates=int(os.environ.get("BENCH_BUFFER_CANDIDATES", "12")), report=report)
+                                  candidates=int(os.environ.get("BENCH_BUFFER_CANDIDATES", "20")), report=report)
 
 
 def d3_branch(sysd, params, cell_list, dftd3, n, d3_bufs, between=None):
