@@ -845,15 +845,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((CNF && siz
   }
 }
 
-// One wave per centre atom `p` (position in the cell-sorted order): the body of nl_query_kernel below.
-#define NL_QUERY_PARAMS                                                                                                                        \
-  const typename Vec4<T>::type* __restrict__ spos, const short4* __restrict__ swrap, const int* __restrict__ keys_sorted,                        \
-      const int* __restrict__ cell_start, const int* __restrict__ batch_idx, const NlSys<T>* __restrict__ sys, const NlGlobal* __restrict__ glob, \
-      int N, T rc2, int flags, int* __restrict__ nm, int* __restrict__ nsh, int* __restrict__ num, int M, int fill_value,                         \
-      const int* __restrict__ ptr, int* __restrict__ list_ij, int* __restrict__ list_sh, long long P, NlSecond<T> D, NlPacked K
-#define NL_QUERY_ARGS spos, swrap, keys_sorted, cell_start, batch_idx, sys, glob, N, rc2, flags, nm, nsh, num, M, fill_value, ptr, list_ij, list_sh, P, D, K
-template <class T, int MODE, bool DUAL, bool CNF>
-__device__ __forceinline__ void nl_query_atom(NL_QUERY_PARAMS, NlCn CN, const int p, const int lane) {
+// Blocks of 4 waves, one centre per wave.  Both query kernels are launched for every search and the device-side grid description decides which
+// one works; the idle one costs 6 - 12 us of empty blocks in front of a tiled search (25 000 blocks for the headline box).  Three cheaper shapes
+// of this kernel were measured in round 6 and rejected because of what they do when it IS the working kernel (sparse cells: BASELINE config 2,
+// the reference's cell_list benchmark rows): a fixed grid of 2048 blocks with a stride loop over the centres (idle launch 3 us; config 2
+// 0.136 -> 0.154 ms); 16-wave blocks (idle launch 3 us; the reference's 524 288-atom row 1.02 -> 1.27 ms: a block's wave slots are only handed
+// back when its slowest wave is done); and even the loop form launched with the old grid (one trip per wave) costs the reference's rows 5 - 6 %
+// (0.961 -> 1.024 ms, same box).  profiles/r06_ab_atom_kernel_grid.log, r06_ab_atom_kernel_block_size.log, r06_ab_atom_kernel_loop_form.log.
+template <class T, int MODE, bool DUAL = false, bool CNF = false>
+__global__ __launch_bounds__(256) void nl_query_kernel(
+    const typename Vec4<T>::type* __restrict__ spos, const short4* __restrict__ swrap, const int* __restrict__ keys_sorted,
+    const int* __restrict__ cell_start, const int* __restrict__ batch_idx, const NlSys<T>* __restrict__ sys,
+    const NlGlobal* __restrict__ glob, int N, T rc2, int flags, int* __restrict__ nm, int* __restrict__ nsh, int* __restrict__ num,
+    int M, int fill_value, const int* __restrict__ ptr, int* __restrict__ list_ij, int* __restrict__ list_sh, long long P, NlSecond<T> D,
+    NlPacked K, NlCn CN = NlCn{nullptr, nullptr, nullptr, 0.0f}) {
+  static_assert(!DUAL || MODE == MI_NL_MODE_MATRIX, "the dual-cutoff sweep fills two padded matrices");
+  static_assert(!CNF || (MODE == MI_NL_MODE_MATRIX && !DUAL), "coordination numbers ride with the plain matrix search");
+  if (glob->use_tiled) return;  // dense cells: the block-per-cell LDS-tiled kernel (launched next to this one) does the work
+  const int lane = threadIdx.x & (MI_WAVE - 1);
+  const int p = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x / MI_WAVE) + (threadIdx.x / MI_WAVE));
+  if (p >= N) return;
   const auto ci = spos[p];
   const int i = __builtin_amdgcn_readfirstlane(idx_of(ci));
   const T pix = ci.x, piy = ci.y, piz = ci.z;
@@ -1061,24 +1072,6 @@ __device__ __forceinline__ void nl_query_atom(NL_QUERY_PARAMS, NlCn CN, const in
     }
   }
 }
-// Blocks of NL_ATOM_WAVES waves, one centre per wave (round 6: 16 waves instead of 4).  Both query kernels are launched for every search and the
-// device-side grid description decides which one works: with one block per four atoms the idle one cost 6 - 12 us of empty blocks in front of
-// every tiled search (25 000 blocks for the headline box); a quarter of the blocks leave in a quarter of the time.  The waves are independent
-// (no LDS, no barrier), so the block size is free.  (A fixed grid of 2048 blocks with a stride loop over the centres was tried first: the idle
-// launch drops to 3 us, but the kernel where it IS the working one -- sparse cells, BASELINE config 2 -- loses 13 %: 0.136 -> 0.154 ms,
-// profiles/r06_ab_atom_kernel_grid.log.  The loop stays in the code: any grid is valid.)
-#define NL_ATOM_WAVES 16
-template <class T, int MODE, bool DUAL = false, bool CNF = false>
-__global__ __launch_bounds__(NL_ATOM_WAVES * MI_WAVE) void nl_query_kernel(NL_QUERY_PARAMS, NlCn CN = NlCn{nullptr, nullptr, nullptr, 0.0f}) {
-  static_assert(!DUAL || MODE == MI_NL_MODE_MATRIX, "the dual-cutoff sweep fills two padded matrices");
-  static_assert(!CNF || (MODE == MI_NL_MODE_MATRIX && !DUAL), "coordination numbers ride with the plain matrix search");
-  if (glob->use_tiled) return;  // dense cells: the block-per-cell LDS-tiled kernel (launched next to this one) does the work
-  const int lane = threadIdx.x & (MI_WAVE - 1), wpb = blockDim.x / MI_WAVE;
-  for (int p = __builtin_amdgcn_readfirstlane(blockIdx.x * wpb + (threadIdx.x / MI_WAVE)); p < N; p += gridDim.x * wpb)
-    nl_query_atom<T, MODE, DUAL, CNF>(NL_QUERY_ARGS, CN, p, lane);
-}
-#undef NL_QUERY_ARGS
-#undef NL_QUERY_PARAMS
 
 // padded matrix -> COO (neighbor_utils.py:428-438: mask = matrix != fill_value, row-major order)
 __global__ __launch_bounds__(256) void nl_matrix_to_coo_kernel(const int* __restrict__ nm, const int* __restrict__ nsh,
@@ -1352,14 +1345,14 @@ int nl_neighbors_impl(const T* pos, int N, const T* cell, const uint8_t* pbc, co
     MI_LAUNCH_CHECK();
     mi_timing_end((void*)st);
   }
-  const int blocks = mi_blocks(N, NL_ATOM_WAVES);  // wave-per-atom kernel: one centre per wave
+  const int blocks = mi_blocks(N, 4);
   const NlSecond<T> none{T(0), nullptr, nullptr, nullptr, 0};
   const NlPacked nopk{nullptr, nullptr};
   // the companion's flag is cleared by nl_setup_kernel (one launch less); a search that reuses the grid has no set-up stage
   if (K.words && (flags & MI_NL_REUSE_GRID)) MI_HIP_CHECK(hipMemsetAsync(K.flag, 0, sizeof(int), st));
   if (second) {  // single-sweep dual cutoff: the primary outputs take the long cutoff, `second` the short one
     MI_TIMED("nl_query_dual", st,
-             (nl_query_kernel<T, MI_NL_MODE_MATRIX, true><<<blocks, NL_ATOM_WAVES * MI_WAVE, 0, st>>>(spos, swrap, keys_out, cell_start, batch_idx, sys, glob, N, rc2, flags, nm, nsh,
+             (nl_query_kernel<T, MI_NL_MODE_MATRIX, true><<<blocks, 256, 0, st>>>(spos, swrap, keys_out, cell_start, batch_idx, sys, glob, N, rc2, flags, nm, nsh,
                                                                                  num, M, fill_value, ptr, list_ij, list_sh, P, *second, nopk),
               nl_query_tiled_kernel<T, MI_NL_MODE_MATRIX, false, true><<<nl_tiled_grid(), 256, 0, st>>>(spos, swrap, cell_start, sys, glob, B, rc2, flags, nm, nsh,
                                                                                                        num, M, fill_value, ptr, list_ij, list_sh, P, *second, nopk)));
@@ -1367,7 +1360,7 @@ int nl_neighbors_impl(const T* pos, int N, const T* cell, const uint8_t* pbc, co
     return MI_OK;
   }
 #define MI_NLQ(MODE_)                                                                                                              \
-  nl_query_kernel<T, MODE_><<<blocks, NL_ATOM_WAVES * MI_WAVE, 0, st>>>(spos, swrap, keys_out, cell_start, batch_idx, sys, glob, N, rc2, flags, nm, nsh, num, M, \
+  nl_query_kernel<T, MODE_><<<blocks, 256, 0, st>>>(spos, swrap, keys_out, cell_start, batch_idx, sys, glob, N, rc2, flags, nm, nsh, num, M, \
                                                     fill_value, ptr, list_ij, list_sh, P, none, K)
   // both query kernels are launched; the device-side grid description (glob->use_tiled) decides which one does the work
   // and the other returns at once -- no host synchronisation to pick a variant
@@ -1383,7 +1376,7 @@ int nl_neighbors_impl(const T* pos, int N, const T* cell, const uint8_t* pbc, co
   if (mode == MI_NL_MODE_MATRIX && CN.cn) {
     // the search that also sums the coordination numbers: FAST tiled kernel + wave-per-atom kernel, as above (the device picks one)
     MI_TIMED(sizeof(T) == 4 ? "nl_query_matrix_f32" : "nl_query_matrix_f64", st,
-             (nl_query_kernel<T, MI_NL_MODE_MATRIX, false, true><<<blocks, NL_ATOM_WAVES * MI_WAVE, 0, st>>>(spos, swrap, keys_out, cell_start, batch_idx, sys, glob, N, rc2, flags, nm,
+             (nl_query_kernel<T, MI_NL_MODE_MATRIX, false, true><<<blocks, 256, 0, st>>>(spos, swrap, keys_out, cell_start, batch_idx, sys, glob, N, rc2, flags, nm,
                                                                                         nsh, num, M, fill_value, ptr, list_ij, list_sh, P, none, K, CN),
               nl_query_tiled_kernel<T, MI_NL_MODE_MATRIX, true, false, true><<<nl_tiled_grid(), 256, 0, st>>>(
                   spos, swrap, cell_start, sys, glob, B, rc2, flags, nm, nsh, num, M, fill_value, ptr, list_ij, list_sh, P, none, K, CN)));
