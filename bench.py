@@ -310,6 +310,7 @@ def make_step(sysd, tables, device, world):
     gathered = [torch.zeros(2, dtype=torch.float64, device=device) for _ in range(world)] if world > 1 else None
     stage_ms = {}
     side = torch.cuda.Stream(device=device, priority=int(os.environ.get("BENCH_SIDE_PRIORITY", "0")))
+    side2 = torch.cuda.Stream(device=device)  # schedule 5 only: the real-space half on a stream of its own
     cu_main, cu_side = cu_masked_streams(device)  # tuning aid, off by default
     if cu_side is not None:
         side = cu_side
@@ -386,6 +387,31 @@ def make_step(sysd, tables, device, world):
                                                 mask_value=n, compute_forces=True)
                     e_pme, f_pme = e_r + e_k, f_r + f_k
                 e_d3, f_d3, nptr = d3_branch(sysd, params, cell_list, dftd3, n, d3_bufs)
+            elif OVERLAP == 5:
+                # schedule 5 (round 6): three streams.  The mesh solve's plane kernels occupy a whole CU's LDS each and are only ever placed at a
+                # kernel BOUNDARY of the main stream.  With the reciprocal half on a stream of its own from t = 0, its spread is done
+                # long before the 40-Bohr fill ends, plane kernel A meets the fill -> energy boundary, the column kernels run beside the energy
+                # pass, plane kernel C meets the energy -> chain boundary and the gather runs beside the chain pass; the 9 A list and the
+                # real-space sum (fp64 VALU) keep their place beside the HBM-bound fill, on the third stream.
+                from nvalchemiops.interactions.electrostatics import ewald_real_space, pme_reciprocal_space
+
+                side.wait_stream(main)
+                side2.wait_stream(main)
+                with torch.cuda.stream(side):
+                    e_k, f_k = pme_reciprocal_space(sysd["pos64"], sysd["q64"], sysd["cell64"], PME["alpha"], mesh_dimensions=PME["mesh"],
+                                                    spline_order=PME["order"], compute_forces=True)
+                with torch.cuda.stream(side2):
+                    cell_list(sysd["pos64"], PME["cutoff"], sysd["cell64"], sysd["pbc"], neighbor_matrix=nm, neighbor_matrix_shifts=nsh,
+                              num_neighbors=num)
+                    al = torch.full((1,), PME["alpha"], dtype=torch.float64, device=device)
+                    e_r, f_r = ewald_real_space(sysd["pos64"], sysd["q64"], sysd["cell64"], al, neighbor_matrix=nm, neighbor_matrix_shifts=nsh,
+                                                mask_value=n, compute_forces=True)
+                e_d3, f_d3, nptr = d3_branch(sysd, params, cell_list, dftd3, n, d3_bufs)
+                with torch.cuda.stream(side):
+                    side.wait_stream(side2)
+                    e_pme, f_pme = e_r + e_k, f_r + f_k
+                    for t in (e_r, f_r):
+                        t.record_stream(side)
             else:  # schedule 2 (tuning aid): the PME branch is enqueued after the D3 list, next to the D3 passes only
                 box = []
                 e_d3, f_d3, nptr = d3_branch(sysd, params, cell_list, dftd3, n, d3_bufs, lambda: box.append(pme_branch()))
@@ -1394,7 +1420,7 @@ def main():
     ap.add_argument("--d3-format", default="matrix", choices=["matrix", "csr"],
                     help="neighbour-list format of the D3 leg: padded matrix with explicit row width (default; what the reference's own D3 benchmark "
                          "uses) or exact-size COO/CSR (two-pass build)")
-    ap.add_argument("--overlap", type=int, default=1, choices=[0, 1, 2, 3, 4], help="1 (default): PME and D3 branches on two HIP streams; 0: one stream, per-stage times; 2: tuning aid")
+    ap.add_argument("--overlap", type=int, default=1, choices=[0, 1, 2, 3, 4, 5], help="1 (default): PME and D3 branches on two HIP streams; 0: one stream, per-stage times; 2 - 4: tuning aids; 5: three streams (reciprocal half, real-space half, dispersion)")
     ap.add_argument("--processes", type=int, default=0,
                     help="headline, 1 GPU: run the timed region in this many FRESH processes one after the other and report the one with the median "
                          "ms_per_step (default 3; 1 = time in this process).  The 40-Bohr list fill has two states that are fixed for the life of a "
