@@ -105,15 +105,57 @@ __global__ void ewald_pack_kernel(const T* __restrict__ pos, const T* __restrict
   rec[i] = r;
 }
 
-template <class T, bool CSR, bool REC>
+// TRUST (round 6, padded matrices only): `snum` = the num_neighbors array of the full-list search that wrote idx / ush -- the host passes it
+// only while both are provably unchanged since (version counters: neighborlist/_engine.py::FullListRecord).  A full list is symmetric by
+// construction unless a row overflowed its M slots, so the two 64-bit hashes per stored entry (a fifth of this kernel's instructions:
+// 0.172 -> 0.138 ms on the 9 A headline list) are replaced by: (1) snum[i] > M raises the "not symmetric" mark, (2) every vstride-th row
+// (vstride a power of two, rotating with vphase) has one of its entries (j, S) looked up in row j as (i, -S); a miss raises the mark -- a
+// bulk edit behind torch's back is caught like a stale D3 companion is, a single edited entry is the caller's to announce
+// (neighborlist.invalidate).  The mark is a unit in a forward checksum slot: forward != reverse sends the call down the general scatter
+// path, as a failed hash would.  Rows are walked up to snum[i] instead of M (hits come first, padding behind them).
+// The look-ups run in `vblocks` blocks of their own at the FRONT of the grid, 16 lanes per sampled row: done by the sampled row's own wave
+// they cost 0.020 ms at stride 64 (four dependent loads in front of the pair loop keep the wave's whole block resident 2.5 x as long, and
+// this kernel lives off its occupancy); as 1 / 64 of the rows x 1 / 16 of a block each they are not measurable.
+template <class T, bool CSR, bool REC, bool TRUST = false>
 __global__ __launch_bounds__(256) void ewald_real_kernel(const T* __restrict__ pos, const T* __restrict__ q, const T* __restrict__ cell,
                                                          const T* __restrict__ alpha, const int* __restrict__ batch_idx, int N,
                                                          const int* __restrict__ idx, const int* __restrict__ ush, const int* __restrict__ nptr,
                                                          int M, int mask_value, int flags, double* __restrict__ energies,
                                                          T* __restrict__ forces, double* __restrict__ cgrad,
-                                                         unsigned long long* __restrict__ sym, const typename Vec4<T>::type* __restrict__ rec) {
+                                                         unsigned long long* __restrict__ sym, const typename Vec4<T>::type* __restrict__ rec,
+                                                         const int* __restrict__ snum = nullptr, int vblocks = 0, int vshift = 0, int vphase = 0) {
+  static_assert(!(TRUST && CSR), "the trusted form describes a padded matrix");
   const int lane = threadIdx.x & (MI_WAVE - 1);
-  const int i = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x / MI_WAVE) + threadIdx.x / MI_WAVE);
+  if (TRUST && (int)blockIdx.x < vblocks) {  // ---- sampled mirror look-ups: sample k is row (k << vshift) + ((-vphase) mod stride)
+    const int sub = lane >> 4, sl = lane & 15;
+    const long long k = ((long long)blockIdx.x * (blockDim.x / MI_WAVE) + threadIdx.x / MI_WAVE) * 4 + sub;
+    const long long il = (k << vshift) + ((-(long long)vphase) & ((1ll << vshift) - 1));
+    bool found = true;  // rows outside the list and empty rows have nothing to look up
+    int i = 0;
+    if (il < N) {
+      i = (int)il;
+      const int cnt_i = snum[i];
+      const int used = cnt_i < M ? cnt_i : M;
+      if (used > 0) {
+        unsigned h = ((unsigned)i * 0x9E3779B1u) ^ ((unsigned)vphase * 0x85EBCA77u);
+        h ^= h >> 15; h *= 0x2C1B3C6Du; h ^= h >> 13;
+        const long long ek = (long long)i * M + (long long)(h % (unsigned)used);
+        const int j = idx[ek];
+        const int S0 = ush[3 * ek], S1 = ush[3 * ek + 1], S2 = ush[3 * ek + 2];
+        found = false;
+        if ((unsigned)j < (unsigned)N) {
+          const int cnt_j = snum[j];
+          const long long jb = (long long)j * M, je = jb + (cnt_j < M ? cnt_j : M);
+          for (long long e = jb + sl; e < je; e += 16)
+            found = found || (idx[e] == i && ush[3 * e] == -S0 && ush[3 * e + 1] == -S1 && ush[3 * e + 2] == -S2);
+        }
+      }
+    }
+    const unsigned long long hits = __ballot(found);
+    if (sl == 0 && ((hits >> (16 * sub)) & 0xFFFFull) == 0ull && sym) atomicAdd(&sym[2 + 2 * (size_t)(i & (EW_SYM_SLOTS - 1))], 1ull);
+    return;
+  }
+  const int i = __builtin_amdgcn_readfirstlane((blockIdx.x - (TRUST ? vblocks : 0)) * (blockDim.x / MI_WAVE) + threadIdx.x / MI_WAVE);
   if (i >= N) return;
   const int s = batch_idx ? batch_idx[i] : 0;
   const double qi = (double)q[i], al = (double)alpha[s];
@@ -129,6 +171,12 @@ __global__ __launch_bounds__(256) void ewald_real_kernel(const T* __restrict__ p
   double eacc = 0.0, cgi = 0.0;
   T fx = 0, fy = 0, fz = 0;
   unsigned long long hf = 0, hr = 0;
+  if (TRUST) {
+    const int cnt_i = __builtin_amdgcn_readfirstlane(snum[i]);
+    end = beg + (cnt_i < M ? cnt_i : M);
+    // cnt_i > M: the search dropped entries of this row, their mirrors in other rows have no partner
+    if (cnt_i > M && lane == 0 && sym) atomicAdd(&sym[2 + 2 * (size_t)(i & (EW_SYM_SLOTS - 1))], 1ull);
+  }
   for (long long e = beg + lane; e < end; e += MI_WAVE) {
     const int j = idx[e];
     if ((!CSR && j == mask_value) || (unsigned)j >= (unsigned)N) continue;  // out-of-range indices (e.g. -1 padding with another mask_value) are padding
@@ -137,7 +185,7 @@ __global__ __launch_bounds__(256) void ewald_real_kernel(const T* __restrict__ p
     if (REC) { const typename Vec4<T>::type r = rec[j]; pjx = r.x; pjy = r.y; pjz = r.z; qj = (double)r.w; }
     else { pjx = pos[3 * (size_t)j]; pjy = pos[3 * (size_t)j + 1]; pjz = pos[3 * (size_t)j + 2]; qj = (double)q[j]; }
     const int S0 = ush[3 * e], S1 = ush[3 * e + 1], S2 = ush[3 * e + 2];
-    if (sym) { hf += ew_entry_hash((unsigned)i, (unsigned)j, S0, S1, S2); hr += ew_entry_hash((unsigned)j, (unsigned)i, -S0, -S1, -S2); }
+    if (!TRUST && sym) { hf += ew_entry_hash((unsigned)i, (unsigned)j, S0, S1, S2); hr += ew_entry_hash((unsigned)j, (unsigned)i, -S0, -S1, -S2); }
     const T fs[3] = {(T)S0, (T)S1, (T)S2};
     T sh[3];
     if (ortho) { sh[0] = cm[0] * fs[0]; sh[1] = cm[4] * fs[1]; sh[2] = cm[8] * fs[2]; }  // the other six products are exact zeros
@@ -172,7 +220,7 @@ __global__ __launch_bounds__(256) void ewald_real_kernel(const T* __restrict__ p
     cgi = wave_sum(cgi);
     if (lane == 0) cgrad[i] = 2.0 * cgi;
   }
-  if (sym) ew_sym_flush(hf, hr, sym, lane, i);
+  if (!TRUST && sym) ew_sym_flush(hf, hr, sym, lane, i);
 }
 
 // ---- fix-up for lists that are not symmetric: the reference's scatter (ewald_kernels.py:518-544, :864-873) ---------------------
@@ -894,6 +942,14 @@ extern "C" int mi_ewald_real(const void* positions, const void* charges, const v
                              int n_atoms, int dtype, const int32_t* idx_j, const int32_t* unit_shifts, const int32_t* neighbor_ptr,
                              int max_neighbors, int mask_value, int flags, double* energies, void* forces, double* charge_grads,
                              void* scratch, size_t scratch_bytes, void* stream) {
+  return mi_ewald_real_listed(positions, charges, cell, alpha, batch_idx, n_atoms, dtype, idx_j, unit_shifts, neighbor_ptr, max_neighbors, mask_value, flags,
+                              energies, forces, charge_grads, scratch, scratch_bytes, nullptr, 0, 0, stream);
+}
+extern "C" int mi_ewald_real_listed(const void* positions, const void* charges, const void* cell, const void* alpha, const int32_t* batch_idx,
+                                    int n_atoms, int dtype, const int32_t* idx_j, const int32_t* unit_shifts, const int32_t* neighbor_ptr,
+                                    int max_neighbors, int mask_value, int flags, double* energies, void* forces, double* charge_grads,
+                                    void* scratch, size_t scratch_bytes, const int32_t* search_num_neighbors, int verify_stride, int verify_phase,
+                                    void* stream) {
   MI_REQUIRE(dtype == MI_F32 || dtype == MI_F64, "dtype");
   if (n_atoms <= 0) return MI_OK;
   MI_REQUIRE(positions && charges && cell && alpha && idx_j && unit_shifts && energies, "null pointer");
@@ -906,6 +962,12 @@ extern "C" int mi_ewald_real(const void* positions, const void* charges, const v
   do {                                                                                                                                         \
     if (rec) {                                                                                                                                 \
       ewald_pack_kernel<T_><<<mi_blocks(n_atoms, 256), 256, 0, st>>>((const T_*)positions, (const T_*)charges, n_atoms, (Vec4<T_>::type*)rec, sym);  \
+      if (!CSR_ && trusted)                                                                                                                    \
+        ewald_real_kernel<T_, false, true, true><<<blocks + vblocks, 256, 0, st>>>((const T_*)positions, (const T_*)charges, (const T_*)cell, (const T_*)alpha, \
+                                                                batch_idx, n_atoms, idx_j, unit_shifts, neighbor_ptr, max_neighbors, mask_value,  \
+                                                                flags, energies, (T_*)forces, charge_grads, sym, (const Vec4<T_>::type*)rec,   \
+                                                                search_num_neighbors, vblocks, vshift, verify_phase);                           \
+      else                                                                                                                                     \
       ewald_real_kernel<T_, CSR_, true><<<blocks, 256, 0, st>>>((const T_*)positions, (const T_*)charges, (const T_*)cell, (const T_*)alpha,   \
                                                                 batch_idx, n_atoms, idx_j, unit_shifts, neighbor_ptr, max_neighbors, mask_value,  \
                                                                 flags, energies, (T_*)forces, charge_grads, sym, (const Vec4<T_>::type*)rec);  \
@@ -929,6 +991,15 @@ extern "C" int mi_ewald_real(const void* positions, const void* charges, const v
   // the symmetry check only matters for outputs that are scattered in the reference (forces, charge gradients); energies are per owner
   unsigned long long* sym = ((flags & (MI_EW_FORCES | MI_EW_CHARGE_GRAD)) && scratch_bytes >= sym_bytes) ? (unsigned long long*)scratch : nullptr;
   void* rec = scratch_bytes >= sym_bytes + rec_bytes ? (void*)((char*)scratch + sym_bytes) : nullptr;
+  // the trusted form needs the checksum words (its marks live there) and the record path (the pack kernel clears the words)
+  const bool trusted = search_num_neighbors != nullptr && !csr && sym != nullptr && rec != nullptr && max_neighbors > 0;
+  int vblocks = 0, vshift = 0;  // the stride rounded up to a power of two; 16 sampled rows per leading block
+  if (trusted && verify_stride > 0) {
+    while ((1ll << vshift) < (long long)verify_stride && vshift < 30) ++vshift;
+    const long long off = (-(long long)verify_phase) & ((1ll << vshift) - 1);
+    const long long samples = off < n_atoms ? (((long long)n_atoms - off + (1ll << vshift) - 1) >> vshift) : 0;
+    vblocks = (int)((samples + 15) / 16);
+  }
   if (sym && !rec) MI_HIP_CHECK(hipMemsetAsync(sym, 0, sizeof(unsigned long long) * EW_SYM_WORDS, st));  // with records: cleared by the pack kernel
   mi_timing_begin("ewald_real", stream);
   if (dtype == MI_F32) { if (csr) MI_EW(float, true); else MI_EW(float, false); }

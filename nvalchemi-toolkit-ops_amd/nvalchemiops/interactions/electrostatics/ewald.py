@@ -17,7 +17,12 @@ import torch
 import ctypes
 import math
 
+import os
+
 from nvalchemiops import _capi as C
+
+# NVALCHEMIOPS_EWALD_TRUST_FULL_LISTS=0: always checksum the list for symmetry, also when it is provably the output of a full search (A/B, tests)
+_TRUST_FULL_LISTS = os.environ.get("NVALCHEMIOPS_EWALD_TRUST_FULL_LISTS", "1") != "0"
 
 
 def _real_space_inputs(positions, charges, cell, alpha, neighbor_list, neighbor_ptr, neighbor_shifts, neighbor_matrix, neighbor_matrix_shifts,
@@ -40,8 +45,19 @@ def _real_space_inputs(positions, charges, cell, alpha, neighbor_list, neighbor_
     else:
         idx, nptr, m = C.i32(neighbor_matrix), None, neighbor_matrix.shape[1]
         sh, n_entries = neighbor_matrix_shifts, idx.numel()
+    # a padded matrix that is provably the unmodified output of a full search of this package: its counts let the real-space kernel skip the
+    # list-symmetry checksums (neighborlist/_engine.py::FullListRecord).  Not under torch.compile tracing (the record lives on the tensor object)
+    counts = None
+    if neighbor_list is None and neighbor_matrix_shifts is not None and _TRUST_FULL_LISTS and not C.tracing():
+        from nvalchemiops.neighborlist import _engine as E
+
+        counts = E.full_list_counts(neighbor_matrix, neighbor_matrix_shifts)
+        if counts is not None and (idx is not neighbor_matrix or counts.shape[0] != positions.shape[0]):
+            counts = None
     sh = torch.zeros((n_entries, 3), dtype=torch.int32, device=dev) if sh is None else C.i32(sh)
-    return dict(pos=positions.detach().contiguous(), q=charges.detach().to(dt).contiguous(), cells=cell.detach().to(dt).reshape(-1, 3, 3).contiguous(),
+    if counts is not None and sh is not neighbor_matrix_shifts:
+        counts = None
+    return dict(counts=counts, pos=positions.detach().contiguous(), q=charges.detach().to(dt).contiguous(), cells=cell.detach().to(dt).reshape(-1, 3, 3).contiguous(),
                 alpha=alpha_in.detach().contiguous(), alpha_in=alpha_in, bi=None if batch_idx is None else C.i32(batch_idx), idx=idx, sh=sh,
                 nptr=nptr, m=m, n_entries=n_entries)
 
@@ -57,6 +73,17 @@ def _real_space_launch(p, mask_value: int, compute_forces: bool, compute_charge_
     # scratch: list-symmetry checksums (zeroed by the library) + the {x,y,z,q} records the pair loop gathers
     nbytes = C.ewald_scratch_bytes(n, C.dtype_code(dt))
     scratch = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    counts = p.get("counts")
+    if counts is not None:
+        from nvalchemiops.neighborlist import _engine as E
+
+        stride, phase = E.verify_args()
+        rc = C.lib().mi_ewald_real_listed(C.ptr(pos), C.ptr(p["q"]), C.ptr(p["cells"]), C.ptr(p["alpha"]), C.ptr(p["bi"]), n, C.dtype_code(dt),
+                                          C.ptr(p["idx"]), C.ptr(p["sh"]), C.ptr(p["nptr"]), int(p["m"]), int(mask_value), flags, C.ptr(energies),
+                                          C.ptr(forces), C.ptr(cgrads), C.ptr(scratch), ctypes.c_size_t(nbytes), C.ptr(counts), int(stride),
+                                          int(phase), C.stream_of(pos))
+        C.check(rc, "mi_ewald_real_listed")
+        return energies, forces, cgrads
     rc = C.lib().mi_ewald_real(C.ptr(pos), C.ptr(p["q"]), C.ptr(p["cells"]), C.ptr(p["alpha"]), C.ptr(p["bi"]), n, C.dtype_code(dt), C.ptr(p["idx"]),
                                C.ptr(p["sh"]), C.ptr(p["nptr"]), int(p["m"]), int(mask_value), flags, C.ptr(energies), C.ptr(forces), C.ptr(cgrads),
                                C.ptr(scratch), ctypes.c_size_t(nbytes), C.stream_of(pos))

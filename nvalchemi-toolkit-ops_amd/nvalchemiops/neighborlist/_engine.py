@@ -28,6 +28,7 @@ _PACKED_POLICY = os.environ.get("NVALCHEMIOPS_NL_PACKED", "auto")
 _PACKED_WANTED: set[tuple[int, int, int]] = set()
 _PACKED_ATTR = "_nvalchemiops_packed"
 _BUILT_ATTR = "_nvalchemiops_built"
+_FULL_ATTR = "_nvalchemiops_full_list"  # FullListRecord: "this matrix is the unmodified output of a full (symmetric) search"
 _D3CTX_ATTR = "_nvalchemiops_d3ctx"
 _D3CTX_BY_SHAPE: dict = {}  # "auto" policy: (device, n_atoms, row width) -> the species `dftd3` was last run with on a matrix of that shape (<= 64 entries)
 # Device-side check of a companion against the arrays it describes, run by `dftd3` on every call (csrc/d3.hip, D3Guard): every
@@ -109,13 +110,13 @@ def invalidate(*tensors: torch.Tensor) -> None:
     for t in tensors:
         if t is None:
             continue
-        for attr in (_PACKED_ATTR, _BUILT_ATTR):
+        for attr in (_PACKED_ATTR, _BUILT_ATTR, _FULL_ATTR):
             if hasattr(t, attr):
                 delattr(t, attr)
         owner = getattr(t, "_nvalchemiops_owner", None)  # the shifts tensor knows its matrix
         nm = owner() if owner is not None else None
         if nm is not None and nm is not t:
-            for attr in (_PACKED_ATTR, _BUILT_ATTR):
+            for attr in (_PACKED_ATTR, _BUILT_ATTR, _FULL_ATTR):
                 if hasattr(nm, attr):
                     delattr(nm, attr)
 
@@ -140,6 +141,51 @@ class PackedCompanion:
                 and nm.dtype == torch.int32 and nsh.dtype == torch.int32 and nm.is_contiguous() and nsh.is_contiguous())
 
 
+class FullListRecord:
+    """What lets `ewald_real_space` skip its per-entry symmetry checksums (round 6): the matrix is the output of a FULL (not half-filled),
+    padded search of this package -- symmetric by construction unless a row overflowed, which the search's own `num_neighbors` shows -- and
+    matrix, shifts and counts still carry the version counters that search left.  An edit through torch bumps a counter and the record is
+    dead; edits behind torch's back are the caller's to announce (`invalidate`) -- the consumer also samples: `mi_ewald_real_listed`."""
+    __slots__ = ("nm_version", "nsh_ref", "nsh_version", "num_ref", "num_version", "n_atoms", "row_width", "fill_value")
+
+    def __init__(self, nm, nsh, num, fill_value):
+        self.nm_version = nm._version
+        self.nsh_ref, self.nsh_version = weakref.ref(nsh), nsh._version
+        self.num_ref, self.num_version = weakref.ref(num), num._version
+        self.n_atoms, self.row_width = int(nm.shape[0]), int(nm.shape[1])
+        self.fill_value = int(fill_value)
+
+    def counts(self, nm: torch.Tensor, nsh: torch.Tensor | None):
+        """The search's num_neighbors tensor if (nm, nsh) are still what it wrote, else None."""
+        num = self.num_ref()
+        ok = (nsh is not None and num is not None and self.nsh_ref() is nsh and nm._version == self.nm_version and nsh._version == self.nsh_version
+              and num._version == self.num_version and tuple(nm.shape) == (self.n_atoms, self.row_width) and nm.dtype == torch.int32
+              and nsh.dtype == torch.int32 and num.dtype == torch.int32 and nm.is_contiguous() and nsh.is_contiguous() and num.is_contiguous()
+              and num.device == nm.device)
+        return num if ok else None
+
+
+def full_list_counts(nm: torch.Tensor | None, nsh: torch.Tensor | None):
+    """`num_neighbors` of the full search that wrote (nm, nsh), while that is provably still their content; else None."""
+    rec = getattr(nm, _FULL_ATTR, None) if nm is not None else None
+    if rec is None:
+        return None
+    try:
+        return rec.counts(nm, nsh)
+    except Exception:
+        return None
+
+
+def _record_full_list(nm, nsh, num, fill_value, qualifies: bool) -> None:
+    if not qualifies or num is None:
+        return
+    try:
+        setattr(nm, _FULL_ATTR, FullListRecord(nm, nsh, num, fill_value))
+        setattr(nsh, "_nvalchemiops_owner", weakref.ref(nm))
+    except Exception:  # no version counter (inference tensor): no record
+        pass
+
+
 def want_packed_companion(device: torch.device, n_atoms: int, row_width: int) -> None:
     """Tell the "auto" policy up front that matrices of this shape feed `dftd3` (what it otherwise learns from the first dftd3 call)."""
     if len(_PACKED_WANTED) > 64:
@@ -153,7 +199,7 @@ def _written(*tensors) -> None:
     for t in tensors:
         if t is None:
             continue
-        for attr in (_PACKED_ATTR, _BUILT_ATTR):
+        for attr in (_PACKED_ATTR, _BUILT_ATTR, _FULL_ATTR):
             if hasattr(t, attr):
                 delattr(t, attr)
         try:
@@ -245,6 +291,7 @@ def neighbor_matrix(pos, cell, pbc, batch_idx, cutoff, max_neighbors, fill_value
     if nbytes == 0:
         run(pos, cell, pbc, batch_idx, cutoff, C.NL_MATRIX, flags, nm=nm, nsh=nsh if want_shifts else None, num=num,
             max_neighbors=max_neighbors, fill_value=fill_value, origin=origin)
+        _record_full_list(nm, nsh, num, fill_value, qualifies)
         if qualifies and _PACKED_POLICY == "auto":
             try:
                 setattr(nm, _BUILT_ATTR, nm._version)  # "built here, full periodic-capable matrix, no companion": what `packed_companion` learns from
@@ -278,6 +325,7 @@ def neighbor_matrix(pos, cell, pbc, batch_idx, cutoff, max_neighbors, fill_value
             C.ptr(nm), C.ptr(nsh), C.ptr(num), int(max_neighbors), int(fill_value), C.ptr(origin), C.ptr(ws), ctypes.c_size_t(ws.numel()),
             C.ptr(words), ctypes.c_size_t(nbytes), C.stream_of(pos))
         C.check(rc, "mi_nl_neighbors_packed")
+    _record_full_list(nm, nsh, num, fill_value, qualifies)
     try:
         setattr(nm, _PACKED_ATTR, PackedCompanion(words, nm, nsh, fill_value, cn=cn))
         setattr(nsh, "_nvalchemiops_owner", weakref.ref(nm))  # so that `invalidate(shifts)` finds the matrix the companion rides on

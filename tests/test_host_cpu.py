@@ -584,3 +584,35 @@ def test_spread_workspace_is_sized_for_the_order_and_dtype_it_serves():
     assert sizes[(4, C.MI_F32)] < sizes[(4, C.MI_F64)] < sizes[(5, C.MI_F64)] < sizes[(6, C.MI_F64)]
     assert int(L.mi_spline_spread_workspace_bytes_for(n, b, *dims, 4 | C.SPLINE_REFERENCE_ORDERS, C.MI_F32)) == sizes[(4, C.MI_F32)]
     assert int(L.mi_spline_spread_workspace_bytes_for(n, b, 31, 29, 37, 4, C.MI_F64)) == 256  # prime dimensions: the atomic kernel, no scratch
+
+
+def test_full_list_record_validity_rules():
+    """`FullListRecord` (what lets `ewald_real_space` skip its symmetry checksums, round 6): alive only while matrix, shifts and counts are
+    the tensors the search wrote, at the versions it left; `invalidate` (on either tensor) and the next search's `_written` drop it."""
+    from nvalchemiops.neighborlist import _engine as E
+
+    nm = torch.zeros((6, 4), dtype=torch.int32)
+    sh = torch.zeros((6, 4, 3), dtype=torch.int32)
+    num = torch.zeros(6, dtype=torch.int32)
+    assert E.full_list_counts(nm, sh) is None and E.full_list_counts(None, None) is None
+    E._record_full_list(nm, sh, num, 6, qualifies=False)
+    assert E.full_list_counts(nm, sh) is None
+    E._record_full_list(nm, sh, num, 6, qualifies=True)
+    assert E.full_list_counts(nm, sh) is num
+    assert E.full_list_counts(nm, sh.clone()) is None and E.full_list_counts(nm, None) is None   # other shifts tensor
+    nm[0, 0] = 1
+    assert E.full_list_counts(nm, sh) is None                                                      # version moved
+    E._record_full_list(nm, sh, num, 6, qualifies=True)
+    num += 0
+    assert E.full_list_counts(nm, sh) is None
+    E._record_full_list(nm, sh, num, 6, qualifies=True)
+    E.invalidate(sh)                                                                                # through the shifts' owner link
+    assert E.full_list_counts(nm, sh) is None
+    E._record_full_list(nm, sh, num, 6, qualifies=True)
+    E._written(nm, sh, num)                                                                         # what the next search does first
+    assert E.full_list_counts(nm, sh) is None
+    E._record_full_list(nm, sh, num, 6, qualifies=True)
+    del num
+    import gc
+    gc.collect()
+    assert E.full_list_counts(nm, sh) is None                                                      # the counts tensor is gone
