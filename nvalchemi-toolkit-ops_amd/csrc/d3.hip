@@ -44,7 +44,55 @@ struct D3Dev {
   const float4* tab;  // [nz,nz,25] {c6ab[zi,zj,p,q], cn_ref[zi,zj,p,q], cn_ref[zj,zi,q,p], 0}
   int nz;
   float a1, a2, s6, s8, k1, k3, s5_on, s5_off, inv_w;
+  // chain records (round 6, fp32 positions only; see D3CRec): one 16-byte record per atom, the species' radii by compact id, "do not use" flag
+  float4* crec;
+  const float* crc;
+  int* cflag;
 };
+
+// ---- chain records (round 6) -----------------------------------------------------------------------------------------------------------
+// The chain pass gathered TWO things per neighbour: the 16-byte record {x, y, z, rcov_j} and the 4-byte dE/dCN_j of another array.  A gather
+// costs by the cache lines its 64 lanes touch, whatever it loads: without the second one the pass runs in 0.61 instead of 0.74 ms and the
+// headline step in 3.26 instead of 3.38 (profiles/r06_ab_chain_gathers.log).  So the energy pass, which produces dE/dCN_i, leaves ONE record
+// {x, y, z, w} per atom with w = dE/dCN_i AND the atom's compact species id (<= 15 species + one code for padding atoms): the radius comes
+// from a 16-entry LDS table.  The id rides in the top `eb` EXPONENT bits of w: dE/dCN is scaled by a power of two so that everything below
+// 256 Ha has zeros there -- scaling by 2^k and back is exact, a zero stays a zero, values below the window's lower end (2^-54 for <= 3
+// species, 2^-22 otherwise) become denormals with an absolute resolution of 2^-45 or better -- so for <= 7 species the chain pass adds
+// bit for bit the numbers it added before.  8 - 15 species: one more id bit replaces the LOWEST mantissa bit (w rounded to 23 bits: half an
+// fp32 ulp).  More species, |dE/dCN| >= 256 Ha or a NaN (the energy pass raises P.cflag then), fp64 positions, or the packed list found
+// unusable: the two-gather walk as before.
+struct D3CRec {
+  bool on; int eb, eshift; unsigned emask, mbit, clear; float down, up; int pad_code;
+};
+__device__ __forceinline__ D3CRec d3_crec_format(int S) {
+  D3CRec f;
+  const int codes = S + 1;  // + the padding atoms' code (its table radius is negative, like apos.w of such an atom)
+  f.on = codes <= 16;
+  f.eb = codes <= 4 ? 2 : 3;
+  f.mbit = codes <= 8 ? 0u : 1u;
+  f.eshift = 31 - f.eb;
+  f.emask = ((1u << f.eb) - 1u) << f.eshift;
+  f.clear = ~(f.emask | f.mbit);
+  // |d| < 2^9 has exponent field <= 135; it must land on <= 2^(8 - eb) - 1 (63 or 31)
+  const int k = 135 - ((1 << (8 - f.eb)) - 1);
+  f.down = __int_as_float((127 - k) << 23);
+  f.up = __int_as_float((127 + k) << 23);
+  f.pad_code = S;
+  return f;
+}
+__device__ __forceinline__ float d3_crec_encode(float d, int id, const D3CRec& f, bool* bad) {
+  *bad = !(fabsf(d) < 256.0f);  // (one binade below the window's top: the rounding below may carry)
+  unsigned u = (unsigned)__float_as_int(d * f.down);
+  if (f.mbit) u = (u + 1u) & ~1u;  // nearest on the magnitude
+  u |= ((unsigned)id << f.eshift) & f.emask;
+  u |= ((unsigned)id >> f.eb) & f.mbit;
+  return __int_as_float((int)u);
+}
+__device__ __forceinline__ int d3_crec_id(float w, const D3CRec& f) {
+  const unsigned u = (unsigned)__float_as_int(w);
+  return (int)(((u & f.emask) >> f.eshift) | ((u & f.mbit) << f.eb));
+}
+__device__ __forceinline__ float d3_crec_value(float w, const D3CRec& f) { return __int_as_float((int)((unsigned)__float_as_int(w) & f.clear)); }  // x f.up = dE/dCN
 
 struct D3Species;
 __device__ __forceinline__ int d3_species_count(const D3Species* info);
@@ -189,7 +237,7 @@ __global__ void d3_pack_atoms_kernel(const T* __restrict__ pos, const int* __res
                                      typename Vec4<T>::type* __restrict__ apos, float4* __restrict__ aaux, float* __restrict__ forces,
                                      float* __restrict__ cn, float* __restrict__ dEdCN, float* __restrict__ e_atom, double* __restrict__ v_atom,
                                      const int* __restrict__ inv, typename Vec4<T>::type* __restrict__ apos_s, float4* __restrict__ aaux_s,
-                                     typename Vec4<T>::type* __restrict__ acn, D3Guard G, D3Tables TB) {
+                                     typename Vec4<T>::type* __restrict__ acn, D3Guard G, D3Tables TB, float4* __restrict__ crec) {
   if ((int)blockIdx.x >= TB.first_block) {  // ---- the global species-pair table (only built for > 16 species)
     d3_pack_tables_body(TB.c6ab, TB.cnref, TB.nz, TB.info, TB.tab, (long long)blockIdx.x - TB.first_block);
     return;
@@ -252,6 +300,11 @@ __global__ void d3_pack_atoms_kernel(const T* __restrict__ pos, const int* __res
   const int sj = real ? smap[z] : -1;
   const float4 ax = make_float4(0.0f, real ? r4r2[z] : 0.0f, __int_as_float((z << 8) | (sj & 0xff)), 0.0f);
   aaux[i] = ax;
+  if (crec) {  // the chain record of an atom the energy pass skips (Z == 0): dE/dCN = 0 under the padding code; real atoms: overwritten there
+    const D3CRec f = d3_crec_format(d3_species_count(TB.info));
+    bool bad;
+    if (f.on) crec[k] = make_float4((float)r.x, (float)r.y, (float)r.z, d3_crec_encode(0.0f, sj >= 0 ? sj : f.pad_code, f, &bad));
+  }
   if (inv) {  // the same records at the atom's place in the spatial order, and the CN pass's record: position + {place, Z}
     apos_s[k] = r;
     aaux_s[k] = ax;
@@ -611,7 +664,7 @@ __global__ void d3_mark_species_kernel(const int* __restrict__ numbers, int N, i
 __global__ void d3_compact_species_kernel(const int* __restrict__ present, const float* __restrict__ c6ab, const float* __restrict__ cnref, int nz,
                                           int* __restrict__ smap, D3Species* __restrict__ info, float4* __restrict__ ctab,
                                           float* __restrict__ ftab, float* __restrict__ fcr, float k3, const float* __restrict__ r4r2,
-                                          float a1, float a2) {
+                                          float a1, float a2, const float* __restrict__ rcov, float* __restrict__ crc) {
   __shared__ int zlist[D3_SMAX];
   __shared__ int count;
   __shared__ int fact_ok;
@@ -628,6 +681,7 @@ __global__ void d3_compact_species_kernel(const int* __restrict__ present, const
   __syncthreads();
   const int S = count;
   if (S > D3_SMAX) { if (threadIdx.x == 0) info->factorized = 0; return; }
+  if (threadIdx.x < 16) crc[threadIdx.x] = (int)threadIdx.x < S ? rcov[zlist[threadIdx.x]] : -1.0f;  // radii by compact id (D3CRec); the padding code's is negative
   for (int k = threadIdx.x; k < S * S * 25; k += blockDim.x) {
     const int pq = k % 25, p = pq / 5, q = pq % 5, sj = (k / 25) % S, si = k / (25 * S);
     const int zi = zlist[si], zj = zlist[sj];
@@ -1010,6 +1064,16 @@ __device__ __forceinline__ void d3_energy_body(const T* __restrict__ pos, const 
     dEdCN[i] = (float)dacc;
     if (inv) dEdCN_s[k0] = (float)dacc;
     e_atom[i] = 0.5f * (float)E;
+    if constexpr (sizeof(T) == 4) {
+      if (P.crec) {  // the chain pass's record of this atom (D3CRec): position + dE/dCN with the species id in its spare exponent bits
+        const D3CRec f = d3_crec_format(S);
+        if (f.on) {
+          bool bad;
+          P.crec[self] = make_float4(pix, piy, piz, d3_crec_encode((float)dacc, code_i & 0xff, f, &bad));
+          if (bad) *P.cflag = 1;  // benign race: every writer stores 1
+        }
+      }
+    }
   }
   if (want_virial && lane < 9) {
     const int r = lane / 3, c = lane - 3 * r, lo = r < c ? r : c, hi2 = r < c ? c : r;
@@ -1072,24 +1136,24 @@ __global__ __launch_bounds__(256) void d3_energy_fallback_kernel(D3_ENERGY_PARAM
 #ifndef D3_CH_DG
 #define D3_CH_DG 1  // ... and of gathered records (<= D3_CH_DS)
 #endif
-template <class T, bool CSR, bool PK>
-__global__ __launch_bounds__(D3_LS_WAVES * MI_WAVE) void d3_chain_kernel(const T* __restrict__ pos, const int* __restrict__ numbers, int N, const int* __restrict__ idx,
-                                                       const int* __restrict__ ush, const int* __restrict__ nptr, int M, int fill_value,
-                                                       const T* __restrict__ cell, const int* __restrict__ batch_idx, D3Dev P,
-                                                       const typename Vec4<T>::type* __restrict__ apos, const float* __restrict__ dEdCN,
-                                                       int want_virial, float* __restrict__ forces, double* __restrict__ v_atom,
-                                                       const unsigned* __restrict__ pk, const int* __restrict__ pk_flag,
-                                                       const int* __restrict__ inv, const typename Vec4<T>::type* __restrict__ apos_s,
-                                                       const float* __restrict__ dEdCN_s) {
-  const bool use_pk = PK && *pk_flag == 0;
+template <class T, bool CSR, bool PK, bool CREC>
+__device__ __forceinline__ void d3_chain_body(const T* __restrict__ pos, const int* __restrict__ numbers, int N, const int* __restrict__ idx,
+                                              const int* __restrict__ ush, const int* __restrict__ nptr, int M, int fill_value,
+                                              const T* __restrict__ cell, const int* __restrict__ batch_idx, const D3Dev& P,
+                                              const typename Vec4<T>::type* __restrict__ apos, const float* __restrict__ dEdCN,
+                                              int want_virial, float* __restrict__ forces, double* __restrict__ v_atom,
+                                              const unsigned* __restrict__ pk, const bool use_pk,
+                                              const int* __restrict__ inv, const typename Vec4<T>::type* __restrict__ apos_s,
+                                              const float* __restrict__ dEdCN_s, const D3CRec& cf, const float* rc_lds) {
   const int lane = threadIdx.x & (MI_WAVE - 1);
   const int i0 = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x / MI_WAVE) + threadIdx.x / MI_WAVE);
   const int k0 = i0 < N ? i0 : N - 1;
   const int i = inv ? __builtin_amdgcn_readfirstlane(inv[k0]) : k0;  // rows in the spatial order (see d3_sort_key_kernel)
   const bool ordered = use_pk && inv != nullptr;                      // the packed list holds places in that order: gather the ordered copies
-  const typename Vec4<T>::type* __restrict__ arec = ordered ? apos_s : apos;
+  // CREC: ONE gather per neighbour, the chain record {x, y, z, dE/dCN_j | species id} the energy pass left (indexed like the ordered copies)
+  const typename Vec4<T>::type* __restrict__ arec = CREC ? reinterpret_cast<const typename Vec4<T>::type*>(P.crec) : (ordered ? apos_s : apos);
   const float* __restrict__ drec = ordered ? dEdCN_s : dEdCN;
-  const int self = ordered ? k0 : i;
+  const int self = (CREC ? inv != nullptr : ordered) ? k0 : i;
   const int zi = numbers[i];
   const bool live = i0 < N && zi != 0;  // idle waves still take part in the block's lock-step barriers
   const bool periodic = (cell != nullptr) && (ush != nullptr);
@@ -1117,24 +1181,34 @@ __global__ __launch_bounds__(D3_LS_WAVES * MI_WAVE) void d3_chain_kernel(const T
 #pragma unroll
   for (int k = 0; k < D3_CH_DS; ++k) s[k] = d3_fetch_any<PK>(idx, ush3, pk, use_pk, e + (long long)k * MI_WAVE, end, periodic);
 #pragma unroll
-  for (int k = 0; k < D3_CH_DG; ++k) { v[k] = s[k].in && ((unsigned)s[k].j < jlim); p[k] = arec[v[k] ? s[k].j : self]; d[k] = drec[v[k] ? s[k].j : self]; }
+  for (int k = 0; k < D3_CH_DG; ++k) {
+    v[k] = s[k].in && ((unsigned)s[k].j < jlim); p[k] = arec[v[k] ? s[k].j : self];
+    if (!CREC) d[k] = drec[v[k] ? s[k].j : self];
+  }
   for (int trip = 0; trip < trips; ++trip) {
     __syncthreads();  // lock-step (see d3_cn_kernel)
     s[D3_CH_DS] = d3_fetch_any<PK>(idx, ush3, pk, use_pk, e + (long long)D3_CH_DS * MI_WAVE, end, periodic);
     v[D3_CH_DG] = s[D3_CH_DG].in && ((unsigned)s[D3_CH_DG].j < jlim);
     p[D3_CH_DG] = arec[v[D3_CH_DG] ? s[D3_CH_DG].j : self];
-    d[D3_CH_DG] = drec[v[D3_CH_DG] ? s[D3_CH_DG].j : self];
+    if (!CREC) d[D3_CH_DG] = drec[v[D3_CH_DG] ? s[D3_CH_DG].j : self];
     const D3Step s0 = s[0];
     const bool v0 = v[0];
     const auto p0 = p[0];
-    const float d0 = d[0];
     if (__any(v0)) {
-      bool valid = v0 && !(p0.w < (T)0);  // padding atom (Z == 0)
+      float rcj, dsum;
+      if constexpr (CREC) {
+        rcj = rc_lds[d3_crec_id((float)p0.w, cf)];
+        dsum = fmaf(d3_crec_value((float)p0.w, cf), cf.up, di);  // = di + dE/dCN_j, rounded once: the scaling by a power of two is exact
+      } else {
+        rcj = (float)p0.w;
+        dsum = di + d[0];
+      }
+      bool valid = v0 && !(rcj < 0.0f);  // padding atom (Z == 0)
       const PairGeom<T> g = d3_geom<T>(p0, pix, piy, piz, s0.sh, cm, periodic);
       valid = valid && g.ok;
       float dcn;
-      d3_cn_count(g.rinv, rci, (float)p0.w, P.k1, &dcn);
-      const float dEdr = valid ? (di + d0) * dcn : 0.0f;
+      d3_cn_count(g.rinv, rci, rcj, P.k1, &dcn);
+      const float dEdr = valid ? dsum * dcn : 0.0f;
       const float fx = dEdr * (g.rx * g.rinv), fy = dEdr * (g.ry * g.rinv), fz = dEdr * (g.rz * g.rinv);
       Fx += (double)fx; Fy += (double)fy; Fz += (double)fz;
       if (want_virial) {
@@ -1145,7 +1219,7 @@ __global__ __launch_bounds__(D3_LS_WAVES * MI_WAVE) void d3_chain_kernel(const T
 #pragma unroll
     for (int k = 0; k < D3_CH_DS; ++k) s[k] = s[k + 1];
 #pragma unroll
-    for (int k = 0; k < D3_CH_DG; ++k) { v[k] = v[k + 1]; p[k] = p[k + 1]; d[k] = d[k + 1]; }
+    for (int k = 0; k < D3_CH_DG; ++k) { v[k] = v[k + 1]; p[k] = p[k + 1]; if (!CREC) d[k] = d[k + 1]; }
     e += MI_WAVE;
   }
   Fx = wave_sum(Fx); Fy = wave_sum(Fy); Fz = wave_sum(Fz);
@@ -1167,6 +1241,33 @@ __global__ __launch_bounds__(D3_LS_WAVES * MI_WAVE) void d3_chain_kernel(const T
     for (int q = 1; q < 6; ++q) v = m == q ? V6[q] : v;
     v_atom[9 * (size_t)i + lane] += -0.5 * v;
   }
+}
+template <class T, bool CSR, bool PK>
+__global__ __launch_bounds__(D3_LS_WAVES * MI_WAVE) void d3_chain_kernel(const T* __restrict__ pos, const int* __restrict__ numbers, int N, const int* __restrict__ idx,
+                                                       const int* __restrict__ ush, const int* __restrict__ nptr, int M, int fill_value,
+                                                       const T* __restrict__ cell, const int* __restrict__ batch_idx, D3Dev P,
+                                                       const typename Vec4<T>::type* __restrict__ apos, const float* __restrict__ dEdCN,
+                                                       int want_virial, float* __restrict__ forces, double* __restrict__ v_atom,
+                                                       const unsigned* __restrict__ pk, const int* __restrict__ pk_flag,
+                                                       const int* __restrict__ inv, const typename Vec4<T>::type* __restrict__ apos_s,
+                                                       const float* __restrict__ dEdCN_s, const D3Species* __restrict__ sinfo) {
+  const bool use_pk = PK && *pk_flag == 0;
+  D3CRec cf{};
+  if constexpr (sizeof(T) == 4) {
+    // chain records (D3CRec): block-uniform decision.  They are indexed like the list the energy pass walked: with a packed list that the
+    // passes found unusable (the energy pass's fallback launch did the work) the two-gather walk below stays
+    __shared__ float rc_lds[16];
+    cf = d3_crec_format(sinfo->S);
+    if (P.crec != nullptr && cf.on && *P.cflag == 0 && (!PK || use_pk)) {
+      if (threadIdx.x < 16) rc_lds[threadIdx.x] = P.crc[threadIdx.x];
+      __syncthreads();
+      d3_chain_body<T, CSR, PK, true>(pos, numbers, N, idx, ush, nptr, M, fill_value, cell, batch_idx, P, apos, dEdCN, want_virial, forces, v_atom, pk, use_pk, inv,
+                                      apos_s, dEdCN_s, cf, rc_lds);
+      return;
+    }
+  }
+  d3_chain_body<T, CSR, PK, false>(pos, numbers, N, idx, ush, nptr, M, fill_value, cell, batch_idx, P, apos, dEdCN, want_virial, forces, v_atom, pk, use_pk, inv,
+                                   apos_s, dEdCN_s, cf, nullptr);
 }
 
 // per-system reduction of per-atom energies / virials.  A few hundred waves each own a contiguous slab of atoms, keep a
@@ -1231,7 +1332,7 @@ __global__ void d3_finish_kernel(const double* __restrict__ sums, int B, int wan
 }
 
 inline long long d3_sort_cap(int N, int B) { return 4ll * N + 8ll * (B > 0 ? B : 1); }
-struct D3Layout { size_t dEdCN, e_atom, v_atom, guard, sums, tab, present, smap, sinfo, ctab, ftab, fcr, apos, aaux, aw, inv, skeys, sgrid, sbins, apos_s, acn, aaux_s, aw_s, dEdCN_s, total; };
+struct D3Layout { size_t dEdCN, e_atom, v_atom, guard, sums, tab, present, smap, sinfo, ctab, ftab, fcr, apos, aaux, aw, inv, skeys, sgrid, sbins, apos_s, acn, aaux_s, aw_s, dEdCN_s, crec, crc, total; };
 D3Layout d3_layout(int N, int nz, int dtype, int B) {
   D3Layout L;
   size_t o = 0;
@@ -1263,6 +1364,8 @@ D3Layout d3_layout(int N, int nz, int dtype, int B) {
   L.aaux_s = take(sizeof(float4) * (size_t)N);
   L.aw_s = take(sizeof(float4) * 2 * (size_t)N);
   L.dEdCN_s = take(sizeof(float) * (size_t)N);
+  L.crec = take(sizeof(float4) * (size_t)N);  // chain records (D3CRec; fp32 positions)
+  L.crc = take(sizeof(float) * 16);
   L.total = o;
   return L;
 }
@@ -1374,6 +1477,11 @@ int d3_impl(const T* pos, const int* numbers, int N, const int* idx, const int* 
   P.a1 = hp->a1; P.a2 = hp->a2; P.s6 = hp->s6; P.s8 = hp->s8; P.k1 = hp->k1; P.k3 = hp->k3; P.s5_on = hp->s5_on; P.s5_off = hp->s5_off;
   // inv_w in double on the host, then cast (dftd3.py:1983-1986)
   P.inv_w = (hp->s5_off > hp->s5_on) ? (float)(1.0 / ((double)hp->s5_off - (double)hp->s5_on)) : 0.0f;
+  const char* crec_env = getenv("NVALCHEMIOPS_D3_CHAIN_RECORDS");  // "0": the two-gather chain walk (A/B, tests); read per call like NVALCHEMIOPS_D3_SORT
+  const bool crec_off = crec_env && crec_env[0] == '0';
+  P.crec = (sizeof(T) == 4 && !crec_off) ? reinterpret_cast<float4*>(ws + L.crec) : nullptr;
+  P.crc = reinterpret_cast<const float*>(ws + L.crc);
+  P.cflag = gflag + 4;  // inside the guard block: cleared with it by the memset below
   // outputs are zeroed like the reference wrapper does (dftd3.py:1933-1936; atoms with Z == 0 keep zeros): the per-atom arrays by
   // the pack kernel below, energy / virial are written for every system by the finish kernel
   // (one memset: the per-system reduction slots `sums`, only touched by the reduce kernel at the very end, lie directly in front of `present`)
@@ -1399,7 +1507,8 @@ int d3_impl(const T* pos, const int* numbers, int N, const int* idx, const int* 
   const bool publish = sortable && probe;  // (after the CN pass, which adds the largest pair distance)
   d3_mark_species_kernel<<<mi_blocks(N, 256), 256, 0, st>>>(numbers, N, hp->nz, present);
   MI_LAUNCH_CHECK();
-  d3_compact_species_kernel<<<1, 256, 0, st>>>(present, hp->c6ab, hp->cn_ref, hp->nz, smap, sinfo, ctab, ftab, fcr, hp->k3, hp->r4r2, hp->a1, hp->a2);
+  d3_compact_species_kernel<<<1, 256, 0, st>>>(present, hp->c6ab, hp->cn_ref, hp->nz, smap, sinfo, ctab, ftab, fcr, hp->k3, hp->r4r2, hp->a1, hp->a2, hp->rcov,
+                                               reinterpret_cast<float*>(ws + L.crc));
   MI_LAUNCH_CHECK();
   const long long nt = (long long)hp->nz * hp->nz * 25;
   // the search's coordination numbers are taken only in the caller's atom order (the spatial order's CN pass writes its place-coded list anyway)
@@ -1415,7 +1524,7 @@ int d3_impl(const T* pos, const int* numbers, int N, const int* idx, const int* 
   }
   const D3Tables TB{hp->c6ab, hp->cn_ref, hp->nz, sinfo, tab, G.atom_blocks + verify_blocks};  // (its blocks leave at once unless > 16 species are present)
   d3_pack_atoms_kernel<T><<<G.atom_blocks + verify_blocks + mi_blocks(nt, 256), 256, 0, st>>>(pos, numbers, N, hp->rcov, hp->r4r2, smap, hp->nz, apos, aaux, forces, cn,
-                                                                                              dEdCN, e_atom, want_virial ? v_atom : nullptr, inv, apos_s, aaux_s, acn, G, TB);
+                                                                                              dEdCN, e_atom, want_virial ? v_atom : nullptr, inv, apos_s, aaux_s, acn, G, TB, P.crec);
   MI_LAUNCH_CHECK();
   const int blocks = mi_blocks(N, 4);
   const D3Weights W{sinfo, fcr, hp->k3, sizeof(T) == 4 ? reinterpret_cast<const float4*>(apos) : nullptr, aw, aw_s};
@@ -1482,7 +1591,7 @@ int d3_impl(const T* pos, const int* numbers, int N, const int* idx, const int* 
   auto launch_chain = [&](auto packed) {
     constexpr bool PK_ = decltype(packed)::value;
     d3_chain_kernel<T, CSR, PK_><<<mi_blocks(N, D3_LS_WAVES), D3_LS_WAVES * MI_WAVE, 0, st>>>(pos, numbers, N, idx, ush, nptr, M, fill_value, cell, batch_idx, P, apos,
-                                                                                             dEdCN, want_virial, forces, v_atom, PK_ ? pk : nullptr, pk_flag, inv, apos_s, dEdCN_s);
+                                                                                             dEdCN, want_virial, forces, v_atom, PK_ ? pk : nullptr, pk_flag, inv, apos_s, dEdCN_s, sinfo);
   };
   if (pk) { MI_TIMED("d3_chain", st, (launch_chain(Packed{}))); }
   else { MI_TIMED("d3_chain", st, (launch_chain(Plain{}))); }
