@@ -50,7 +50,7 @@ struct D3Dev {
   int* cflag;
 };
 
-// ---- chain records (round 6) -----------------------------------------------------------------------------------------------------------
+// ---- chain records (round 6; the pass is `_cn_forces_contrib_kernel_nm` / `_nl`, dftd3.py:1133-1258 / :1534-1660) ----------------------------
 // The chain pass gathered TWO things per neighbour: the 16-byte record {x, y, z, rcov_j} and the 4-byte dE/dCN_j of another array.  A gather
 // costs by the cache lines its 64 lanes touch, whatever it loads: without the second one the pass runs in 0.61 instead of 0.74 ms and the
 // headline step in 3.26 instead of 3.38 (profiles/r06_ab_chain_gathers.log).  So the energy pass, which produces dE/dCN_i, leaves ONE record
