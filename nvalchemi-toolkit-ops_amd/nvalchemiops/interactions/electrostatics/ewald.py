@@ -74,7 +74,8 @@ def _real_space_launch(p, mask_value: int, compute_forces: bool, compute_charge_
     nbytes = C.ewald_scratch_bytes(n, C.dtype_code(dt))
     scratch = torch.empty(nbytes, dtype=torch.uint8, device=dev)
     counts = p.get("counts")
-    if counts is not None:
+    # (a mask_value that is an atom's index would turn stored entries into padding: the list as the reference reads it is then not the search's list)
+    if counts is not None and not (0 <= int(mask_value) < n):
         from nvalchemiops.neighborlist import _engine as E
 
         stride, phase = E.verify_args()

@@ -161,3 +161,32 @@ def test_particle_mesh_ewald_on_a_search_output_is_unchanged(monkeypatch):
                                          neighbor_matrix_shifts=sh, compute_forces=True)
     for a, b in zip(res[True], res[False]):
         assert float((a - b).abs().max()) <= 1e-11 * max(1.0, float(b.abs().max()))
+
+
+def test_a_mask_value_that_is_an_atom_index_keeps_the_checksum_path(monkeypatch):
+    """mask_value = 5 makes every stored entry j == 5 padding: the list the sum sees is no longer the search's symmetric list, so the trusted
+    form is not taken -- both settings run the checksum kernel and its scatter fix-up and agree to rounding.  (No oracle leg: with a mask_value other than the
+    fill value the reference -- and its restatement -- index out of bounds on the real padding.)"""
+    from nvalchemiops.interactions.electrostatics import ewald as EW
+    from nvalchemiops.interactions.electrostatics import ewald_real_space
+    from nvalchemiops.neighborlist import _engine as E
+    from nvalchemiops.neighborlist import cell_list
+
+    n, dtype = 250, np.float64
+    pos, cell, q = _system(n, dtype, seed=13)
+    pbc = torch.tensor([True] * 3, device=DEV)
+    nm, num, sh = cell_list(_t(pos), 7.0, _t(cell), pbc, max_neighbors=320)
+    assert E.full_list_counts(nm, sh) is num
+    alpha = torch.tensor([0.4], dtype=torch.float64, device=DEV)
+    out = {}
+    for trust in (True, False):
+        monkeypatch.setattr(EW, "_TRUST_FULL_LISTS", trust)
+        out[trust] = ewald_real_space(_t(pos), _t(q), _t(cell)[None], alpha, neighbor_matrix=nm, neighbor_matrix_shifts=sh, mask_value=5,
+                                      compute_forces=True, compute_charge_gradients=True)
+    for a, b in zip(out[True], out[False]):  # (the scatter path adds with atomics: equal to rounding, not bit for bit)
+        assert torch.isfinite(a).all() and float((a - b).abs().max()) <= 1e-11 * max(1.0, float(b.abs().max()))
+    # the entries to atom 5 really are dropped: other rows' energies differ from the ordinary call's
+    monkeypatch.setattr(EW, "_TRUST_FULL_LISTS", True)
+    plain = ewald_real_space(_t(pos), _t(q), _t(cell)[None], alpha, neighbor_matrix=nm, neighbor_matrix_shifts=sh, mask_value=n,
+                             compute_forces=True, compute_charge_gradients=True)
+    assert not torch.equal(plain[0], out[True][0])
