@@ -1130,11 +1130,13 @@ __global__ __launch_bounds__(256) void d3_energy_fallback_kernel(D3_ENERGY_PARAM
 
 // ---- pass 3: chain-rule force through the coordination numbers ---------------------------------------
 #ifndef D3_CH_DS
-#define D3_CH_DS 2  // chain pass: trips of list words in flight ahead of the evaluated one (round 5: parametrised like the CN pass; 3/1, 3/2, 4/2 measured
-                    // equal or 2 % slower -- two gathers per neighbour leave less to hide: profiles/r05_ab_chain_pipeline.log)
+#define D3_CH_DS 3  // chain pass: trips of list words in flight ahead of the evaluated one.  With two gathers per neighbour 3/1, 3/2, 4/2 were equal or 2 %
+                    // slower than 2/1 (profiles/r05_ab_chain_pipeline.log); with the ONE gather of the chain records (round 6) a second trip of records in
+                    // flight hides the gather behind the block's lock-step barrier: 2/1 0.674, 3/1 0.675, 3/2 0.596, 4/2 0.600, 4/3 0.619 (70 VGPRs, 7 waves),
+                    // 5/3 0.63, 5/4 0.64 ms; records as far ahead as the list words (2/2, 3/3) 0.74 (profiles/r06_ab_chain_pipeline_one_gather.log)
 #endif
 #ifndef D3_CH_DG
-#define D3_CH_DG 1  // ... and of gathered records (<= D3_CH_DS)
+#define D3_CH_DG 2  // ... and of gathered records (< D3_CH_DS)
 #endif
 template <class T, bool CSR, bool PK, bool CREC>
 __device__ __forceinline__ void d3_chain_body(const T* __restrict__ pos, const int* __restrict__ numbers, int N, const int* __restrict__ idx,
