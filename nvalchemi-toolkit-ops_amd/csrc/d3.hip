@@ -470,14 +470,19 @@ __device__ __forceinline__ void d3_row(int i, int M, const int* __restrict__ npt
 #define D3_LS_WAVES 8
 #endif
 #endif
+#ifndef D3_CH_LS_WAVES
+#define D3_CH_LS_WAVES 4  // the chain pass's own width (round 6): with ONE gather per neighbour and two trips of records in flight, 4 waves in lock-step
+                          // beat 8 (0.601 -> 0.545 ms; 16: 0.82) -- fewer waves wait for the slowest gather of a trip, and L1 still serves 4 rows' shared lines
+#endif
+template <int W = D3_LS_WAVES>
 __device__ __forceinline__ int d3_lockstep_trips(long long beg, long long end) {
-  __shared__ int trips_sh[D3_LS_WAVES];
+  __shared__ int trips_sh[W];
   const int w = threadIdx.x / MI_WAVE;
   if ((threadIdx.x & (MI_WAVE - 1)) == 0) trips_sh[w] = (int)((end - beg + MI_WAVE - 1) / MI_WAVE);
   __syncthreads();
   int t = 0;
 #pragma unroll
-  for (int k = 0; k < D3_LS_WAVES; ++k) t = max(t, trips_sh[k]);
+  for (int k = 0; k < W; ++k) t = max(t, trips_sh[k]);
   return t;
 }
 
@@ -1166,7 +1171,7 @@ __device__ __forceinline__ void d3_chain_body(const T* __restrict__ pos, const i
   long long beg, end;
   d3_row<T, CSR>(i, M, nptr, beg, end);
   if (!live) end = beg;
-  const int trips = d3_lockstep_trips(beg, end);
+  const int trips = d3_lockstep_trips<D3_CH_LS_WAVES>(beg, end);
   double Fx = 0, Fy = 0, Fz = 0;
   // virial: f (x) r is symmetric (f is parallel to r) -> six components, fp32 lane partials (~40 terms each) summed in fp64 across lanes,
   // exactly as in the energy pass.  Nine fp64 lane partials cost 27 instructions per pair (18 of them at the fp64 rate) against 6 FMAs
@@ -1245,7 +1250,7 @@ __device__ __forceinline__ void d3_chain_body(const T* __restrict__ pos, const i
   }
 }
 template <class T, bool CSR, bool PK>
-__global__ __launch_bounds__(D3_LS_WAVES * MI_WAVE) void d3_chain_kernel(const T* __restrict__ pos, const int* __restrict__ numbers, int N, const int* __restrict__ idx,
+__global__ __launch_bounds__(D3_CH_LS_WAVES * MI_WAVE) void d3_chain_kernel(const T* __restrict__ pos, const int* __restrict__ numbers, int N, const int* __restrict__ idx,
                                                        const int* __restrict__ ush, const int* __restrict__ nptr, int M, int fill_value,
                                                        const T* __restrict__ cell, const int* __restrict__ batch_idx, D3Dev P,
                                                        const typename Vec4<T>::type* __restrict__ apos, const float* __restrict__ dEdCN,
@@ -1592,7 +1597,7 @@ int d3_impl(const T* pos, const int* numbers, int N, const int* idx, const int* 
   MI_LAUNCH_CHECK();
   auto launch_chain = [&](auto packed) {
     constexpr bool PK_ = decltype(packed)::value;
-    d3_chain_kernel<T, CSR, PK_><<<mi_blocks(N, D3_LS_WAVES), D3_LS_WAVES * MI_WAVE, 0, st>>>(pos, numbers, N, idx, ush, nptr, M, fill_value, cell, batch_idx, P, apos,
+    d3_chain_kernel<T, CSR, PK_><<<mi_blocks(N, D3_CH_LS_WAVES), D3_CH_LS_WAVES * MI_WAVE, 0, st>>>(pos, numbers, N, idx, ush, nptr, M, fill_value, cell, batch_idx, P, apos,
                                                                                              dEdCN, want_virial, forces, v_atom, PK_ ? pk : nullptr, pk_flag, inv, apos_s, dEdCN_s, sinfo);
   };
   if (pk) { MI_TIMED("d3_chain", st, (launch_chain(Packed{}))); }
